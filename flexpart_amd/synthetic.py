@@ -1,0 +1,313 @@
+"""Deterministic synthetic scenarios for the particle-advection path.
+
+Everything here is built from integer arithmetic plus IEEE-exact float64
+operations (+ - * / sqrt, comparisons) only -- no libm transcendentals -- so a
+scenario regenerates bit-identically on any box (the GPU box has no access to
+the reference tree or to scenario files made elsewhere).
+
+A scenario is a plain dict whose keys follow the reference's own variable names
+(com_mod.f90 / par_mod.f90 of the reference); see `Scenario keys` below.  Field
+arrays are float64, C-ordered with shape (2, nz, ny, nx) (time slot, level, y,
+x), i.e. the reference's column-major (x, y, z, slot) order with only the used
+nx*ny*nz extent kept.
+
+The shapes follow SURVEY.md section 8(d): ECMWF-like 361x181x138 global grid,
+two wind-field time slots 10800 s apart, lsynctime 900 s.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# constants of the reference (par_mod.f90:59-60,76-79,112,123,213,254)
+PI_REF = 3.14159265
+R_EARTH = 6.371e6
+HMIXMIN, HMIXMAX = 100.0, 4500.0
+SWITCHNORTH, SWITCHSOUTH = 75.0, -75.0
+MAXRAND = 1000000
+MINSTEP = 1
+DEAD = -999999999
+
+
+def derive_switches(ctl_cmd: float, ifine_cmd: int, cblflag: int, lsynctime: int):
+    """COMMAND-file values -> the run-time switches the hot path reads.
+
+    Mirrors readcommand.f90:244-272,379-385 of the reference: returns a dict
+    with method, mintime, turbswitch, ifine, ctl (already inverted), lsynctime.
+    """
+    ifine = max(int(ifine_cmd), 1)
+    ctl = float(ctl_cmd)
+    if cblflag == 1:
+        turbswitch = True
+        lsynctime = min(lsynctime, 1200)           # maxtl, com_mod.f90:752
+        if ctl < 5:
+            ctl = 5.0
+        if ifine * ctl < 50:
+            ifine = int(50.0 / ctl) + 1
+    else:
+        if ctl >= 0.1:
+            turbswitch = True
+        else:
+            turbswitch = False
+            ifine = 1
+    ctl_inv = 1.0 / ctl
+    if ctl_inv > 0.0:
+        method, mintime = 1, MINSTEP
+    else:
+        method, mintime = 0, lsynctime
+    return dict(method=method, mintime=mintime, turbswitch=int(turbswitch),
+                ifine=ifine, ctl=ctl_inv, lsynctime=lsynctime, cblflag=int(cblflag))
+
+
+# --------------------------------------------------------------------------
+# exact building blocks
+# --------------------------------------------------------------------------
+def _wave(num, den):
+    """C1 'parabola sine' of phase num/den (integer arrays), range [-1, 1]."""
+    t = (np.asarray(num, dtype=np.int64) % int(den)).astype(np.float64) / float(den)
+    return np.where(t < 0.5, 16.0 * t * (0.5 - t), -16.0 * (t - 0.5) * (1.0 - t))
+
+
+def _splitmix64(n, seed):
+    """n uint64 values from SplitMix64 counters (vectorised, wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+             + np.uint64(seed))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def _uniform01(n, seed):
+    """float64 in [0, 1) with 53 random bits, exact on every platform."""
+    return (_splitmix64(n, seed) >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def make_height(nz, top=80000.0, lin=0.05):
+    """Stretched model-level heights [m], height[0] = 0 (verttransform output shape)."""
+    s = np.arange(nz, dtype=np.float64) / float(nz - 1)
+    return top * (lin * s + (1.0 - lin) * s * s * s)
+
+
+def nmixz_from_height(height):
+    """First level (1-based) above hmixmax, as verttransform_ecmwf.f90:186-192."""
+    for kz in range(len(height)):
+        if height[kz] > HMIXMAX:
+            return kz + 1
+    return len(height)
+
+
+# --------------------------------------------------------------------------
+# fields
+# --------------------------------------------------------------------------
+def make_fields(nx, ny, nz, height, *, uniform=None, polar=False, nspec=1, hmix_const=None):
+    """Smooth synthetic met fields on an (nx, ny, nz) grid with 2 time slots.
+
+    uniform: None for the ECMWF-shaped analytic fields, or a dict
+    {u, v, w, rho, hmix, ustar, wstar, oli} for spatially uniform fields (the
+    reference's own validation scenario, mpi_mod.f90:2903-2975).
+    """
+    f = {}
+    shp3 = (2, nz, ny, nx)
+    shp2 = (2, ny, nx)
+    if uniform is not None:
+        f["uu"] = np.full(shp3, float(uniform.get("u", 10.0)))
+        f["vv"] = np.full(shp3, float(uniform.get("v", 0.0)))
+        f["ww"] = np.full(shp3, float(uniform.get("w", 0.0)))
+        f["rho"] = np.full(shp3, float(uniform.get("rho", 1.3)))
+        f["drhodz"] = np.full(shp3, float(uniform.get("drhodz", 0.0)))
+        f["tt"] = np.full(shp3, float(uniform.get("tt", 273.0)))
+        f["hmix"] = np.full(shp2, float(uniform.get("hmix", 10000.0)))
+        f["ustar"] = np.full(shp2, float(uniform.get("ustar", 1.0)))
+        f["wstar"] = np.full(shp2, float(uniform.get("wstar", 1.0)))
+        f["oli"] = np.full(shp2, float(uniform.get("oli", 0.01)))
+        f["tropopause"] = np.full(shp2, float(uniform.get("tropopause", 10000.0)))
+        f["vdep"] = np.full((2, nspec, ny, nx), float(uniform.get("vdep", 0.002)))
+        if polar:
+            f["uupol"] = f["uu"].copy()
+            f["vvpol"] = f["vv"].copy()
+        return f
+
+    per = nx - 1                                   # cyclic period in x (column nx-1 == column 0)
+    i = np.arange(nx, dtype=np.int64)[None, None, :]
+    j = np.arange(ny, dtype=np.int64)[None, :, None]
+    k = np.arange(nz, dtype=np.int64)[:, None, None]
+    s = np.arange(ny, dtype=np.float64)[None, :, None] / float(ny - 1)
+    clat = 4.0 * s * (1.0 - s)                     # 0 at the poles, 1 at the equator
+    z = np.asarray(height, dtype=np.float64)[:, None, None]
+    zf = z / float(height[-1])
+    a = z / 8000.0
+    den = 1.0 + a + 0.5 * a * a
+    f["uu"] = np.empty(shp3); f["vv"] = np.empty(shp3); f["ww"] = np.empty(shp3)
+    f["rho"] = np.empty(shp3); f["drhodz"] = np.empty(shp3); f["tt"] = np.empty(shp3)
+    for m in range(2):
+        sh = 10 * m                                # second slot: pattern shifted by 10 columns
+        f["uu"][m] = (20.0 * clat * (1.0 + 0.3 * _wave(k, nz))
+                      + 5.0 * _wave(3 * (i + sh), per) + 0.0 * j)
+        f["vv"][m] = 5.0 * _wave(2 * (i + sh) + 0 * j, per) * clat + 1.5 * _wave(k + 3 * j, 40)
+        f["ww"][m] = (0.05 * _wave(i + sh, per) * _wave(2 * j + 0 * i, ny - 1)
+                      * 4.0 * zf * (1.0 - zf))
+        r = (1.2 + 0.02 * m) / den + 0.0 * (i + j)
+        f["rho"][m] = r * (1.0 + 0.01 * _wave(i + 2 * j, per))
+        f["drhodz"][m] = -(1.2 + 0.02 * m) * (1.0 + a) / 8000.0 / (den * den) + 0.0 * (i + j)
+        f["tt"][m] = np.maximum(288.0 - 0.0065 * z + 2.0 * _wave(i + sh + j, per), 216.0)
+    i2 = i[0]; j2 = j[0]; c2 = clat[0]
+    f["hmix"] = np.empty(shp2); f["ustar"] = np.empty(shp2); f["wstar"] = np.empty(shp2)
+    f["oli"] = np.empty(shp2); f["tropopause"] = np.empty(shp2)
+    f["vdep"] = np.empty((2, nspec, ny, nx))
+    for m in range(2):
+        sh = 10 * m
+        if hmix_const is not None:
+            f["hmix"][m] = float(hmix_const)
+        else:
+            hm = 300.0 + 1200.0 * (0.5 + 0.5 * _wave(i2 + sh, per) * c2) + 300.0 * _wave(3 * j2 + i2, 64)
+            f["hmix"][m] = np.minimum(np.maximum(hm, HMIXMIN), HMIXMAX)
+        f["ustar"][m] = 0.1 + 0.4 * c2 + 0.05 * _wave(5 * (i2 + sh), per)
+        olw = _wave(2 * (i2 + sh) + j2, per)
+        f["oli"][m] = 0.02 * olw * (0.25 + 0.75 * c2)
+        # convective velocity scale: sizeable where the surface layer is unstable (1/L < 0),
+        # small but non-zero elsewhere (the CBL scheme divides by powers of w*)
+        f["wstar"][m] = 0.1 + 1.9 * np.maximum(0.0, -olw) + 0.0 * c2
+        f["tropopause"][m] = 9000.0 + 7000.0 * c2 + 0.0 * i2
+        for ks in range(nspec):
+            f["vdep"][m, ks] = 0.002 * (ks + 1) + 0.001 * _wave(i2 + sh + j2, per)
+    if xcyclic_ok(nx):
+        for key in ("uu", "vv", "ww", "rho", "drhodz", "tt", "hmix", "ustar", "wstar", "oli",
+                    "tropopause", "vdep"):
+            f[key][..., nx - 1] = f[key][..., 0]   # cyclic duplicate column (gridcheck: nx = nxfield+1)
+    if polar:
+        # any smooth field serves parity: the real ones come from verttransform (out of scope)
+        f["uupol"] = 0.7 * f["uu"] + 0.2 * f["vv"]
+        f["vvpol"] = 0.7 * f["vv"] - 0.2 * f["uu"]
+    return f
+
+
+def xcyclic_ok(nx):
+    return nx >= 3
+
+
+# --------------------------------------------------------------------------
+# particles
+# --------------------------------------------------------------------------
+def make_particles(n, nx, ny, height, hmix, *, seed=0x5EED, lat_margin_cells=None,
+                   frac_pbl=0.5, zmax=12000.0, nspec=1, itime0=0):
+    """Fixed-seed particle cloud over the whole grid.
+
+    Half the particles (frac_pbl) are placed below the local mixing height so
+    that both branches of the trajectory step are exercised.
+    """
+    ux = _uniform01(n, seed + 1)
+    uy = _uniform01(n, seed + 2)
+    uz = _uniform01(n, seed + 3)
+    us = _uniform01(n, seed + 4)
+    eps = 361.0 / 3.0e5
+    if lat_margin_cells is None:
+        lat_margin_cells = 0.03 * (ny - 1)
+    x = eps + ux * (float(nx - 1) - 2.0 * eps)
+    y = lat_margin_cells + uy * (float(ny - 1) - 2.0 * lat_margin_cells)
+    ix = np.minimum(x.astype(np.int64), nx - 2)
+    jy = np.minimum(y.astype(np.int64), ny - 2)
+    hloc = np.maximum.reduce([hmix[0, jy, ix], hmix[0, jy, ix + 1], hmix[0, jy + 1, ix],
+                              hmix[0, jy + 1, ix + 1], hmix[1, jy, ix], hmix[1, jy, ix + 1],
+                              hmix[1, jy + 1, ix], hmix[1, jy + 1, ix + 1]])
+    in_pbl = us < frac_pbl
+    z = np.where(in_pbl, 10.0 + uz * np.maximum(hloc - 20.0, 1.0),
+                 hloc + 10.0 + uz * (zmax - hloc - 10.0))
+    p = dict(npart=n, xtra1=x, ytra1=y, ztra1=z,
+             itra1=np.full(n, itime0, np.int32), itramem=np.full(n, itime0, np.int32),
+             npoint=np.ones(n, np.int32), nclass=np.ones(n, np.int32),
+             xmass1=np.ones((nspec, n), np.float64))
+    return p
+
+
+def point_release(n, xlon, ylat, z, dx, dy, xlon0, ylat0, *, nspec=1, itime0=0):
+    """All particles at one point (options/RELEASES default case of the reference)."""
+    x = np.full(n, (xlon - xlon0) / dx)
+    y = np.full(n, (ylat - ylat0) / dy)
+    return dict(npart=n, xtra1=x, ytra1=y, ztra1=np.full(n, float(z)),
+                itra1=np.full(n, itime0, np.int32), itramem=np.full(n, itime0, np.int32),
+                npoint=np.ones(n, np.int32), nclass=np.ones(n, np.int32),
+                xmass1=np.full((nspec, n), 1.0 / n))
+
+
+# --------------------------------------------------------------------------
+# scenarios
+# --------------------------------------------------------------------------
+def base_scenario(nx=361, ny=181, nz=138, *, global_grid=True, polar=False, nspec=1,
+                  ctl=5.0, ifine=4, cblflag=0, lsynctime=900, uniform=None, hmix_const=None,
+                  turb_off=False, nsteps=2, ldirect=1):
+    """Grid + switches + fields; particles are added by the caller."""
+    height = make_height(nz, top=80000.0 if nz >= 60 else 30000.0,
+                         lin=0.05 if nz >= 60 else 0.15)
+    dx = 360.0 / (nx - 1) if global_grid else 1.0
+    dy = 180.0 / (ny - 1) if global_grid else 1.0
+    xlon0 = -180.0 if global_grid else -20.0
+    ylat0 = -90.0 if global_grid else 20.0
+    sw = derive_switches(ctl, ifine, cblflag, lsynctime)
+    sc = dict(
+        grid=np.array([nx, ny, nz], np.int32),
+        geom=np.array([dx, dy, xlon0, ylat0], np.float64),
+        globalflags=np.array([int(global_grid), int(global_grid and polar),
+                              int(global_grid and polar)], np.int32),
+        height=height, nmixz=nmixz_from_height(height),
+        memtime=np.array([0, 10800], np.int32), memind=np.array([1, 2], np.int32),
+        ldirect=ldirect, lsynctime=sw["lsynctime"], method=sw["method"], mintime=sw["mintime"],
+        ctl=sw["ctl"], ifine=sw["ifine"], turbswitch=sw["turbswitch"], cblflag=sw["cblflag"],
+        mdomainfill=0, lsettling=0, nspec=nspec,
+        drydep=0, drydepspec=np.zeros(nspec, np.int32),
+        density=np.zeros(nspec), dquer=np.zeros(nspec), vsetaver=np.zeros(nspec),
+        cunningham=np.ones(nspec), decay=np.zeros(nspec),
+        turbpar=np.array([0.0, 0.0, 0.0]) if turb_off else np.array([50.0, 0.1, 0.16]),
+        lage=np.array([999999999], np.int32),
+        nsteps=nsteps, itime0=0,
+    )
+    sc.update(make_fields(nx, ny, nz, height, uniform=uniform, polar=polar, nspec=nspec,
+                          hmix_const=hmix_const))
+    return sc
+
+
+def config1(n=10000, nsteps=2):
+    """BASELINE config 1: 10k particles, point release, uniform wind, no turbulence.
+
+    Uniform values of the reference's own validation set (mpi_mod.f90:2940-2973: u=10, v=0,
+    w=0, rho=1.3); 'no turbulence' is obtained the reference's run-time way (SURVEY appendix
+    A): particles above the mixing height and d_trop = d_strat = turbmesoscale = 0.
+    """
+    sc = base_scenario(uniform=dict(u=10.0, v=0.0, w=0.0, rho=1.3, hmix=HMIXMIN, ustar=1.0,
+                                    wstar=1.0, oli=0.01, tropopause=10000.0),
+                       ctl=-5.0, ifine=4, turb_off=True, nsteps=nsteps)
+    g = sc["geom"]
+    sc.update(point_release(n, 0.0, 20.0, 150.0, g[0], g[1], g[2], g[3]))
+    return sc
+
+
+def config2(n=10_000_000, nsteps=2, seed=0x5EED, nx=361, ny=181, nz=138):
+    """BASELINE config 2: advance + interpol_wind only (all particles above the PBL)."""
+    sc = base_scenario(nx, ny, nz, ctl=-5.0, ifine=4, turb_off=True, hmix_const=HMIXMIN,
+                       nsteps=nsteps)
+    sc.update(make_particles(n, nx, ny, sc["height"], sc["hmix"], seed=seed, frac_pbl=0.0))
+    return sc
+
+
+def config3(n=100_000_000, nsteps=2, seed=0x5EED, nx=361, ny=181, nz=138, cblflag=1,
+            ctl=5.0, ifine=4):
+    """BASELINE config 3: full Hanna turbulence + CBL, PBL sub-stepping."""
+    sc = base_scenario(nx, ny, nz, ctl=ctl, ifine=ifine, cblflag=cblflag, nsteps=nsteps)
+    sc.update(make_particles(n, nx, ny, sc["height"], sc["hmix"], seed=seed, frac_pbl=0.5))
+    return sc
+
+
+def small(n=2000, nx=40, ny=24, nz=30, **kw):
+    """A small grid + cloud for fast parity tests (same generators, reduced sizes)."""
+    cbl = kw.pop("cblflag", 0)
+    ctl = kw.pop("ctl", 5.0)
+    ifine = kw.pop("ifine", 4)
+    nsteps = kw.pop("nsteps", 3)
+    seed = kw.pop("seed", 1234)
+    frac_pbl = kw.pop("frac_pbl", 0.5)
+    zmax = kw.pop("zmax", 12000.0)
+    lat_margin = kw.pop("lat_margin_cells", None)
+    sc = base_scenario(nx, ny, nz, ctl=ctl, ifine=ifine, cblflag=cbl, nsteps=nsteps, **kw)
+    sc.update(make_particles(n, nx, ny, sc["height"], sc["hmix"], seed=seed, frac_pbl=frac_pbl,
+                             zmax=zmax, nspec=int(sc["nspec"]), lat_margin_cells=lat_margin))
+    return sc

@@ -1,0 +1,49 @@
+#!/bin/bash
+# TEST INFRASTRUCTURE ONLY.
+# Builds the real reference hot path (unmodified Fortran sources, compiled
+# where they lie under /root/reference/src) plus our own driver
+# oracle/ref_driver.f90 into oracle/_ref/flexref_r4 (reference precision:
+# default real = 4 bytes, as src/makefile compiles it) and
+# oracle/_ref/flexref_r8 (-fdefault-real-8: the "fp64" oracle of
+# BASELINE.json configs 2-3).  No reference source is copied into the repo;
+# only objects/binaries land in oracle/_ref/ (git-ignored).
+#
+# The reference's own build system (makefile + ecCodes + NetCDF) is NOT used:
+# the hot path needs none of those libraries.
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${FLEXPART_REFERENCE:-/root/reference}/src"
+OUT="$HERE/_ref"
+FC="${FC:-/opt/rocm/lib/llvm/bin/flang}"
+if [ ! -d "$REF" ]; then echo "build_ref: no reference tree at $REF (skipping)"; exit 0; fi
+if [ ! -x "$FC" ]; then echo "build_ref: no flang at $FC (skipping)"; exit 0; fi
+
+MODS="par_mod com_mod interpol_mod hanna_mod cmapf_mod point_mod random_mod unc_mod outg_mod"
+SUBS="advance initialize interpol_all interpol_wind interpol_wind_short interpol_misslev interpol_vdep \
+interpol_all_nests interpol_wind_nests interpol_wind_short_nests interpol_misslev_nests interpol_vdep_nests \
+hanna hanna1 hanna_short cbl re_initialize_particle initialize_cbl_vel windalign get_settling dynamic_viscosity \
+conccalc drydepokernel drydepokernel_nest"
+
+build_one() {
+  local kind="$1"; shift
+  local flags="$*"
+  local obj="$OUT/obj_$kind"
+  mkdir -p "$obj"
+  ( cd "$obj"
+    for m in $MODS; do
+      [ "$obj/$m.o" -nt "$REF/$m.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$m.f90" -o "$m.o"
+    done
+    for s in $SUBS; do
+      [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
+    done
+    "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_driver.f90" -o ref_driver.o
+    objs=""
+    for m in $MODS $SUBS; do objs="$objs $m.o"; done
+    "$FC" -O2 -mcmodel=medium $flags ref_driver.o $objs -o "$OUT/flexref_$kind"
+  )
+  echo "build_ref: built $OUT/flexref_$kind"
+}
+
+mkdir -p "$OUT"
+build_one r4
+build_one r8 -fdefault-real-8

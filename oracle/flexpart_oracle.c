@@ -1,0 +1,1413 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the reference's
+ * per-particle trajectory step.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this; the product path (flexpart_amd/)
+ * never does.
+ *
+ * Plain C restatement of the algorithm of MeteoSwiss/flexpart's
+ * timemanager -> initialize/advance path.  Every function cites the reference
+ * file:line it follows (paths relative to /root/reference/src).  It keeps the
+ * reference's control flow, operation order and quirks (module-global scratch,
+ * shared sequential ran3 stream, 1e6-entry Gaussian table) so that it can be
+ * pinned against outputs of the real reference compiled with flang
+ * (oracle/_ref/flexref_r4|r8, see oracle/build_ref.sh) -- the reference holds
+ * no test vectors of its own for this path.
+ *
+ * Built twice: -DORC_REAL=float  (reference precision, default real = 4 bytes)
+ *              -DORC_REAL=double (the -fdefault-real-8 "fp64" oracle).
+ * Compile with -ffp-contract=off: the flang x86-64 build has no FMA.
+ *
+ * Field layout: compact C arrays [slot][level][jy][ix] (= the reference's
+ * column-major (ix,jy,level,slot) without the nxmax/nymax padding).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef ORC_REAL
+#define ORC_REAL double
+#endif
+typedef ORC_REAL real;
+#define K(x) ((real)(x))
+
+#define ORC_MAXSPEC 5
+#define ORC_NZMAX 256
+#define ORC_MAXRAND 1000000
+#define ORC_MAXNESTS 4
+
+/* type-generic libm in the oracle's precision */
+static inline real r_exp(real x)  { return sizeof(real) == 4 ? (real)expf((float)x)  : (real)exp((double)x); }
+static inline real r_log(real x)  { return sizeof(real) == 4 ? (real)logf((float)x)  : (real)log((double)x); }
+static inline real r_sqrt(real x) { return sizeof(real) == 4 ? (real)sqrtf((float)x) : (real)sqrt((double)x); }
+static inline real r_sin(real x)  { return sizeof(real) == 4 ? (real)sinf((float)x)  : (real)sin((double)x); }
+static inline real r_cos(real x)  { return sizeof(real) == 4 ? (real)cosf((float)x)  : (real)cos((double)x); }
+static inline real r_erf(real x)  { return sizeof(real) == 4 ? (real)erff((float)x)  : (real)erf((double)x); }
+static inline real r_pow(real x, real y) { return sizeof(real) == 4 ? (real)powf((float)x, (float)y) : (real)pow((double)x, (double)y); }
+static inline real r_abs(real x)  { return x < 0 ? -x : x; }
+static inline real r_max(real a, real b) { return a > b ? a : b; }
+static inline real r_min(real a, real b) { return a < b ? a : b; }
+static inline real r_sign(real a, real b) { real m = r_abs(a); return (b < 0 || (b == 0 && signbit((double)b))) ? -m : m; }
+static inline real r_mod(real a, real p) { return sizeof(real) == 4 ? (real)fmodf((float)a, (float)p) : (real)fmod((double)a, (double)p); }
+static inline double d_modulo(double a, double p) { double r = fmod(a, p); if (r != 0.0 && ((r < 0) != (p < 0))) r += p; return r; }
+
+/* ------------------------------------------------------------------------- */
+/* context = the reference's com_mod/par_mod variables the path reads         */
+/* ------------------------------------------------------------------------- */
+typedef struct {
+  /* grid (com_mod.f90:298-299,551-560) */
+  int nx, ny, nz, nxmin1, nymin1, nmixz;
+  real dx, dy, xlon0, ylat0, dxconst, dyconst;
+  int xglobal, nglobal, sglobal;
+  real switchnorthg, switchsouthg;
+  real northpolemap[9], southpolemap[9];
+  real height[ORC_NZMAX];
+  int memtime[2], memind[2], lwindinterv;
+  /* run switches (com_mod.f90:56-77,112,144,188,589) */
+  int ldirect, lsynctime, method, mintime, ifine, turbswitch, cblflag, mdomainfill, lsettling;
+  int nspec, drydep, drydepspec[ORC_MAXSPEC];
+  real ctl, fine, d_trop, d_strat, turbmesoscale;
+  real density[ORC_MAXSPEC], dquer[ORC_MAXSPEC], vsetaver[ORC_MAXSPEC], cunningham[ORC_MAXSPEC];
+  real decay[ORC_MAXSPEC];
+  real xmass_rel[ORC_MAXSPEC];     /* point_mod xmass(1,:) */
+  int npart_rel;                   /* point_mod npart(1)   */
+  int lage_last;                   /* lage(nageclass)      */
+  /* nests (com_mod.f90:464-541) */
+  int numbnests;
+  int nxn[ORC_MAXNESTS], nyn[ORC_MAXNESTS];
+  real xln[ORC_MAXNESTS], yln[ORC_MAXNESTS], xrn[ORC_MAXNESTS], yrn[ORC_MAXNESTS];
+  real xresoln[ORC_MAXNESTS], yresoln[ORC_MAXNESTS];
+  /* fields */
+  const real *uu, *vv, *ww, *rho, *drhodz, *tt, *uupol, *vvpol;
+  const real *hmix, *ustar, *wstar, *oli, *tropopause, *vdep;
+  const real *uun[ORC_MAXNESTS], *vvn[ORC_MAXNESTS], *wwn[ORC_MAXNESTS], *rhon[ORC_MAXNESTS],
+             *drhodzn[ORC_MAXNESTS], *hmixn[ORC_MAXNESTS], *ustarn[ORC_MAXNESTS], *wstarn[ORC_MAXNESTS],
+             *olin[ORC_MAXNESTS], *tropopausen[ORC_MAXNESTS], *vdepn[ORC_MAXNESTS];
+  /* random table (com_mod.f90:744) */
+  real rannumb[ORC_MAXRAND + 64];  /* 1-based; the reference reads past the end on rare CBL re-draws */
+  long nan_count, nan_count2;
+
+  /* ---- interpol_mod.f90:7-16 (module-global scratch, persists between particles) */
+  real uprof[ORC_NZMAX + 1], vprof[ORC_NZMAX + 1], wprof[ORC_NZMAX + 1];
+  real usigprof[ORC_NZMAX + 1], vsigprof[ORC_NZMAX + 1], wsigprof[ORC_NZMAX + 1];
+  real rhoprof[ORC_NZMAX + 1], rhogradprof[ORC_NZMAX + 1];
+  real u, v, w, usig, vsig, wsig;
+  real p1, p2, p3, p4, ddx, ddy, rddx, rddy, dtt, dt1, dt2;
+  int ix, jy, ixp, jyp, ngrid, indz, indzp;
+  int depoindicator[ORC_MAXSPEC];
+  int indzindicator[ORC_NZMAX + 1];
+  /* ---- hanna_mod.f90:5-6 */
+  real ust, wst, ol, h, zeta, sigu, sigv, tlu, tlv, tlw, sigw, dsigwdz, dsigw2dz;
+  /* ---- random_mod.f90 saved state */
+  int ran3_iff, ran3_inext, ran3_inextp, ran3_ma[56];
+  int gasdev_iset; real gasdev_gset;
+  int idummy_init, idummy_adv;     /* initialize.f90:64, advance.f90:120 */
+  real settling;                   /* advance.f90:121 (saved) */
+} orc_ctx;
+
+#define F3(f, i, j, k, m) ((f)[(((size_t)((m) - 1) * c->nz + (size_t)((k) - 1)) * c->ny + (size_t)(j)) * c->nx + (size_t)(i)])
+#define F2(f, i, j, m)    ((f)[((size_t)((m) - 1) * c->ny + (size_t)(j)) * c->nx + (size_t)(i)])
+#define FV(f, i, j, ks, m) ((f)[((((size_t)((m) - 1) * c->nspec + (size_t)((ks) - 1)) * c->ny + (size_t)(j)) * c->nx) + (size_t)(i)])
+#define HGT(k) (c->height[(k) - 1])
+
+/* ------------------------------------------------------------------------- */
+/* RNG: random_mod.f90                                                         */
+/* ------------------------------------------------------------------------- */
+/* random_mod.f90:93-139 -- Knuth subtractive generator, integer state */
+static real orc_ran3(orc_ctx *c, int *idum) {
+  const int mbig = 1000000000, mseed = 161803398, mz = 0;
+  const real fac = K(1.) / (real)mbig;
+  int i, ii, k, mj, mk;
+  int *ma = c->ran3_ma;
+  if (*idum < 0 || c->ran3_iff == 0) {
+    c->ran3_iff = 1;
+    mj = mseed - abs(*idum);
+    mj = mj % mbig;
+    ma[55] = mj;
+    mk = 1;
+    for (i = 1; i <= 54; i++) {
+      ii = (21 * i) % 55;
+      ma[ii] = mk;
+      mk = mj - mk;
+      if (mk < mz) mk = mk + mbig;
+      mj = ma[ii];
+    }
+    for (k = 1; k <= 4; k++)
+      for (i = 1; i <= 55; i++) {
+        ma[i] = ma[i] - ma[1 + (i + 30) % 55];
+        if (ma[i] < mz) ma[i] = ma[i] + mbig;
+      }
+    c->ran3_inext = 0;
+    c->ran3_inextp = 31;
+    *idum = 1;
+  }
+  c->ran3_inext++;
+  if (c->ran3_inext == 56) c->ran3_inext = 1;
+  c->ran3_inextp++;
+  if (c->ran3_inextp == 56) c->ran3_inextp = 1;
+  mj = ma[c->ran3_inext] - ma[c->ran3_inextp];
+  if (mj < mz) mj = mj + mbig;
+  ma[c->ran3_inext] = mj;
+  return (real)mj * fac;
+}
+
+/* random_mod.f90:70-90 -- Box-Muller pair clipped to +-3 */
+static void orc_gasdev1(orc_ctx *c, int *idum, real *random1, real *random2) {
+  real v1, v2, r, fac;
+  do {
+    v1 = K(2.) * orc_ran3(c, idum) - K(1.);
+    v2 = K(2.) * orc_ran3(c, idum) - K(1.);
+    r = v1 * v1 + v2 * v2;
+  } while (r >= K(1.0) || r == K(0.0));
+  fac = r_sqrt(K(-2.) * r_log(r) / r);
+  *random1 = v1 * fac;
+  *random2 = v2 * fac;
+  if (*random1 < K(-3.)) *random1 = K(-3.);
+  if (*random2 < K(-3.)) *random2 = K(-3.);
+  if (*random1 > K(3.)) *random1 = K(3.);
+  if (*random2 > K(3.)) *random2 = K(3.);
+}
+
+/* random_mod.f90:45-67 */
+static real orc_gasdev(orc_ctx *c, int *idum) {
+  real v1, v2, r, fac;
+  if (c->gasdev_iset == 0) {
+    do {
+      v1 = K(2.) * orc_ran3(c, idum) - K(1.);
+      v2 = K(2.) * orc_ran3(c, idum) - K(1.);
+      r = v1 * v1 + v2 * v2;
+    } while (r >= K(1.0) || r == K(0.0));
+    fac = r_sqrt(K(-2.) * r_log(r) / r);
+    c->gasdev_gset = v1 * fac;
+    c->gasdev_iset = 1;
+    return v2 * fac;
+  }
+  c->gasdev_iset = 0;
+  return c->gasdev_gset;
+}
+
+/* FLEXPART.f90:47,56-59 -- fill the 1e6-entry table, seed -320 */
+static void orc_fill_rannumb(orc_ctx *c) {
+  int idummy = -320, i;
+  c->ran3_iff = 0;
+  for (i = 1; i <= ORC_MAXRAND - 1; i += 2) orc_gasdev1(c, &idummy, &c->rannumb[i], &c->rannumb[i + 1]);
+  orc_gasdev1(c, &idummy, &c->rannumb[ORC_MAXRAND], &c->rannumb[ORC_MAXRAND - 1]);
+}
+
+/* ------------------------------------------------------------------------- */
+/* interpolation: interpol_all / misslev / wind / wind_short / vdep            */
+/* ------------------------------------------------------------------------- */
+/* the horizontal weights block common to interpol_all.f90:57-71,
+   interpol_wind.f90:56-70, interpol_wind_short.f90:48-62 */
+static void orc_hweights(orc_ctx *c, int itime, real xt, real yt) {
+  c->ddx = xt - (real)c->ix;
+  c->ddy = yt - (real)c->jy;
+  c->rddx = K(1.) - c->ddx;
+  c->rddy = K(1.) - c->ddy;
+  c->p1 = c->rddx * c->rddy;
+  c->p2 = c->ddx * c->rddy;
+  c->p3 = c->rddx * c->ddy;
+  c->p4 = c->ddx * c->ddy;
+  c->dt1 = (real)(itime - c->memtime[0]);
+  c->dt2 = (real)(c->memtime[1] - itime);
+  c->dtt = K(1.) / (c->dt1 + c->dt2);
+}
+
+#define BIL(f, n, m) (c->p1 * F3(f, ix, jy, n, m) + c->p2 * F3(f, ixp, jy, n, m) + c->p3 * F3(f, ix, jyp, n, m) + c->p4 * F3(f, ixp, jyp, n, m))
+/* Fortran evaluates  usl=usl+a+b+c+d  left to right: keep that association */
+#define SUM4(acc, f, n, m) ((((acc) + F3(f, ix, jy, n, m)) + F3(f, ixp, jy, n, m)) + F3(f, ix, jyp, n, m)) + F3(f, ixp, jyp, n, m)
+#define SQ4(acc, f, n, m) ((((acc) + F3(f, ix, jy, n, m) * F3(f, ix, jy, n, m)) + F3(f, ixp, jy, n, m) * F3(f, ixp, jy, n, m)) + F3(f, ix, jyp, n, m) * F3(f, ix, jyp, n, m)) + F3(f, ixp, jyp, n, m) * F3(f, ixp, jyp, n, m)
+
+/* one level of profiles: interpol_all.f90:135-240 loop body == interpol_misslev.f90:56-159 */
+static void orc_profile_level(orc_ctx *c, int n) {
+  const real eps = K(1.0e-30);
+  real y1[2], y2[2], y3[2], rho1[2], rhograd1[2];
+  real usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0, xaux;
+  int m, ix = c->ix, jy = c->jy, ixp = c->ixp, jyp = c->jyp;
+  const real *fu = c->ngrid < 0 ? c->uupol : c->uu;
+  const real *fv = c->ngrid < 0 ? c->vvpol : c->vv;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    y1[m] = BIL(fu, n, indexh);
+    y2[m] = BIL(fv, n, indexh);
+    usl = SUM4(usl, fu, n, indexh);
+    vsl = SUM4(vsl, fv, n, indexh);
+    usq = SQ4(usq, fu, n, indexh);
+    vsq = SQ4(vsq, fv, n, indexh);
+    y3[m] = BIL(c->ww, n, indexh);
+    rhograd1[m] = BIL(c->drhodz, n, indexh);
+    rho1[m] = BIL(c->rho, n, indexh);
+    wsl = SUM4(wsl, c->ww, n, indexh);
+    wsq = SQ4(wsq, c->ww, n, indexh);
+  }
+  c->uprof[n] = (y1[0] * c->dt2 + y1[1] * c->dt1) * c->dtt;
+  c->vprof[n] = (y2[0] * c->dt2 + y2[1] * c->dt1) * c->dtt;
+  c->wprof[n] = (y3[0] * c->dt2 + y3[1] * c->dt1) * c->dtt;
+  c->rhoprof[n] = (rho1[0] * c->dt2 + rho1[1] * c->dt1) * c->dtt;
+  c->rhogradprof[n] = (rhograd1[0] * c->dt2 + rhograd1[1] * c->dt1) * c->dtt;
+  c->indzindicator[n] = 0;
+  /* 8-point standard deviations: interpol_all.f90:218-238 */
+  xaux = usq - usl * usl / K(8.);
+  c->usigprof[n] = xaux < eps ? K(0.) : r_sqrt(xaux / K(7.));
+  xaux = vsq - vsl * vsl / K(8.);
+  c->vsigprof[n] = xaux < eps ? K(0.) : r_sqrt(xaux / K(7.));
+  xaux = wsq - wsl * wsl / K(8.);
+  c->wsigprof[n] = xaux < eps ? K(0.) : r_sqrt(xaux / K(7.));
+}
+
+/* the linear level search, e.g. interpol_all.f90:118-125 (indz keeps its old
+   value if zt is above the top level -- the reference does the same) */
+static void orc_find_level(orc_ctx *c, real zt, int set_indzp) {
+  int i;
+  for (i = 2; i <= c->nz; i++)
+    if (HGT(i) > zt) {
+      c->indz = i - 1;
+      if (set_indzp) c->indzp = i;
+      break;
+    }
+}
+
+/* interpol_all.f90:57-240 */
+static void orc_interpol_all(orc_ctx *c, int itime, real xt, real yt, real zt) {
+  real ust1[2], wst1[2], oli1[2], oliaux;
+  int m, n, ix, jy, ixp, jyp;
+  orc_hweights(c, itime, xt, yt);
+  ix = c->ix; jy = c->jy; ixp = c->ixp; jyp = c->jyp;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    ust1[m] = c->p1 * F2(c->ustar, ix, jy, indexh) + c->p2 * F2(c->ustar, ixp, jy, indexh) + c->p3 * F2(c->ustar, ix, jyp, indexh) + c->p4 * F2(c->ustar, ixp, jyp, indexh);
+    wst1[m] = c->p1 * F2(c->wstar, ix, jy, indexh) + c->p2 * F2(c->wstar, ixp, jy, indexh) + c->p3 * F2(c->wstar, ix, jyp, indexh) + c->p4 * F2(c->wstar, ixp, jyp, indexh);
+    oli1[m] = c->p1 * F2(c->oli, ix, jy, indexh) + c->p2 * F2(c->oli, ixp, jy, indexh) + c->p3 * F2(c->oli, ix, jyp, indexh) + c->p4 * F2(c->oli, ixp, jyp, indexh);
+  }
+  c->ust = (ust1[0] * c->dt2 + ust1[1] * c->dt1) * c->dtt;
+  c->wst = (wst1[0] * c->dt2 + wst1[1] * c->dt1) * c->dtt;
+  oliaux = (oli1[0] * c->dt2 + oli1[1] * c->dt1) * c->dtt;
+  c->ol = oliaux != K(0.) ? K(1.) / oliaux : K(99999.);
+  orc_find_level(c, zt, 1);
+  for (n = c->indz; n <= c->indzp; n++) orc_profile_level(c, n);
+}
+
+/* interpol_wind.f90:56-214 (with_sigma=1) and interpol_wind_short.f90:48-140 (with_sigma=0) */
+static void orc_interpol_wind(orc_ctx *c, int itime, real xt, real yt, real zt, int with_sigma) {
+  const real eps = K(1.0e-30);
+  real dz1, dz2, dz, u1[2], v1[2], w1[2], uh[2], vh[2], wh[2];
+  real usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0, xaux;
+  int m, n, ix, jy, ixp, jyp;
+  const real *fu = c->ngrid < 0 ? c->uupol : c->uu;
+  const real *fv = c->ngrid < 0 ? c->vvpol : c->vv;
+  orc_hweights(c, itime, xt, yt);
+  ix = c->ix; jy = c->jy; ixp = c->ixp; jyp = c->jyp;
+  orc_find_level(c, zt, 0);
+  dz = K(1.) / (HGT(c->indz + 1) - HGT(c->indz));
+  dz1 = (zt - HGT(c->indz)) * dz;
+  dz2 = (HGT(c->indz + 1) - zt) * dz;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    for (n = 0; n < 2; n++) {
+      int indzh = c->indz + n;
+      u1[n] = BIL(fu, indzh, indexh);
+      v1[n] = BIL(fv, indzh, indexh);
+      if (with_sigma) {
+        usl = SUM4(usl, fu, indzh, indexh);
+        vsl = SUM4(vsl, fv, indzh, indexh);
+        usq = SQ4(usq, fu, indzh, indexh);
+        vsq = SQ4(vsq, fv, indzh, indexh);
+      }
+      w1[n] = BIL(c->ww, indzh, indexh);
+      if (with_sigma) {
+        wsl = SUM4(wsl, c->ww, indzh, indexh);
+        wsq = SQ4(wsq, c->ww, indzh, indexh);
+      }
+    }
+    uh[m] = dz2 * u1[0] + dz1 * u1[1];
+    vh[m] = dz2 * v1[0] + dz1 * v1[1];
+    wh[m] = dz2 * w1[0] + dz1 * w1[1];
+  }
+  c->u = (uh[0] * c->dt2 + uh[1] * c->dt1) * c->dtt;
+  c->v = (vh[0] * c->dt2 + vh[1] * c->dt1) * c->dtt;
+  c->w = (wh[0] * c->dt2 + wh[1] * c->dt1) * c->dtt;
+  if (with_sigma) {  /* interpol_wind.f90:194-214, 16 points */
+    xaux = usq - usl * usl / K(16.);
+    c->usig = xaux < eps ? K(0.) : r_sqrt(xaux / K(15.));
+    xaux = vsq - vsl * vsl / K(16.);
+    c->vsig = xaux < eps ? K(0.) : r_sqrt(xaux / K(15.));
+    xaux = wsq - wsl * wsl / K(16.);
+    c->wsig = xaux < eps ? K(0.) : r_sqrt(xaux / K(15.));
+  }
+}
+
+/* interpol_vdep.f90:39-54 */
+static void orc_interpol_vdep(orc_ctx *c, int level, real *vdepo) {
+  real y[2];
+  int m, ix = c->ix, jy = c->jy, ixp = c->ixp, jyp = c->jyp;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    y[m] = c->p1 * FV(c->vdep, ix, jy, level, indexh) + c->p2 * FV(c->vdep, ixp, jy, level, indexh) + c->p3 * FV(c->vdep, ix, jyp, level, indexh) + c->p4 * FV(c->vdep, ixp, jyp, level, indexh);
+  }
+  *vdepo = (y[0] * c->dt2 + y[1] * c->dt1) * c->dtt;
+  c->depoindicator[level - 1] = 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* turbulence parameterisation: hanna.f90 / hanna1.f90 / hanna_short.f90       */
+/* ------------------------------------------------------------------------- */
+/* the shared tlw branch hanna.f90:78-84 */
+static real orc_tlw_unstable(orc_ctx *c, real z) {
+  if (z < r_abs(c->ol)) return K(0.1) * z / (c->sigw * (K(0.55) - K(0.38) * r_abs(z / c->ol)));
+  if (c->zeta < K(0.1)) return K(0.59) * z / c->sigw;
+  return K(0.15) * c->h / c->sigw * (K(1.) - r_exp(K(-5) * c->zeta));
+}
+
+/* hanna.f90:41-106 */
+static void orc_hanna(orc_ctx *c, real z) {
+  real corr;
+  if (c->h / r_abs(c->ol) < K(1.)) {                       /* neutral */
+    c->ust = r_max(K(1.e-4), c->ust);
+    corr = z / c->ust;
+    c->sigu = K(1.e-2) + K(2.0) * c->ust * r_exp(K(-3.e-4) * corr);
+    c->sigw = K(1.3) * c->ust * r_exp(K(-2.e-4) * corr);
+    c->dsigwdz = K(-2.e-4) * c->sigw;
+    c->sigw = c->sigw + K(1.e-2);
+    c->sigv = c->sigw;
+    c->tlu = K(0.5) * z / c->sigw / (K(1.) + K(1.5e-3) * corr);
+    c->tlv = c->tlu;
+    c->tlw = c->tlu;
+  } else if (c->ol < K(0.)) {                              /* unstable */
+    c->sigu = K(1.e-2) + c->ust * r_pow(K(12) - K(0.5) * c->h / c->ol, K(0.33333));
+    c->sigv = c->sigu;
+    c->sigw = r_sqrt(K(1.2) * (c->wst * c->wst) * (K(1.) - K(.9) * c->zeta) * r_pow(c->zeta, K(0.66666)) + (K(1.8) - K(1.4) * c->zeta) * (c->ust * c->ust)) + K(1.e-2);
+    c->dsigwdz = K(0.5) / c->sigw / c->h * (K(-1.4) * (c->ust * c->ust) + (c->wst * c->wst) * (K(0.8) * r_pow(r_max(c->zeta, K(1.e-3)), K(-.33333)) - K(1.8) * r_pow(c->zeta, K(0.66666))));
+    c->tlu = K(0.15) * c->h / c->sigu;
+    c->tlv = c->tlu;
+    c->tlw = orc_tlw_unstable(c, z);
+  } else {                                                 /* stable */
+    c->sigu = K(1.e-2) + K(2.) * c->ust * (K(1.) - c->zeta);
+    c->sigv = K(1.e-2) + K(1.3) * c->ust * (K(1.) - c->zeta);
+    c->sigw = c->sigv;
+    c->dsigwdz = K(-1.3) * c->ust / c->h;
+    c->tlu = K(0.15) * c->h / c->sigu * r_sqrt(c->zeta);
+    c->tlv = K(0.467) * c->tlu;
+    c->tlw = K(0.1) * c->h / c->sigw * r_pow(c->zeta, K(0.8));
+  }
+  c->tlu = r_max(K(10.), c->tlu);
+  c->tlv = r_max(K(10.), c->tlv);
+  c->tlw = r_max(K(30.), c->tlw);
+  if (c->dsigwdz == K(0.)) c->dsigwdz = K(1.e-10);
+}
+
+/* hanna1.f90:41-129 */
+static void orc_hanna1(orc_ctx *c, real z) {
+  real s1, s2;
+  if (c->h / r_abs(c->ol) < K(1.)) {
+    c->ust = r_max(K(1.e-4), c->ust);
+    c->sigu = K(2.0) * c->ust * r_exp(K(-3.e-4) * z / c->ust);
+    c->sigu = r_max(c->sigu, K(1.e-5));
+    c->sigv = K(1.3) * c->ust * r_exp(K(-2.e-4) * z / c->ust);
+    c->sigv = r_max(c->sigv, K(1.e-5));
+    c->sigw = c->sigv;
+    c->dsigw2dz = K(-6.76e-4) * c->ust * r_exp(K(-4.e-4) * z / c->ust);
+    c->tlu = K(0.5) * z / c->sigw / (K(1.) + K(1.5e-3) * z / c->ust);
+    c->tlv = c->tlu;
+    c->tlw = c->tlu;
+  } else if (c->ol < K(0.)) {
+    c->sigu = c->ust * r_pow(K(12) - K(0.5) * c->h / c->ol, K(0.33333));
+    c->sigu = r_max(c->sigu, K(1.e-6));
+    c->sigv = c->sigu;
+    if (c->zeta < K(0.03)) {
+      c->sigw = K(0.96) * c->wst * r_pow(K(3) * c->zeta - c->ol / c->h, K(0.33333));
+      c->dsigw2dz = K(1.8432) * c->wst * c->wst / c->h * r_pow(K(3) * c->zeta - c->ol / c->h, K(-0.33333));
+    } else if (c->zeta < K(0.4)) {
+      s1 = K(0.96) * r_pow(K(3) * c->zeta - c->ol / c->h, K(0.33333));
+      s2 = K(0.763) * r_pow(c->zeta, K(0.175));
+      if (s1 < s2) {
+        c->sigw = c->wst * s1;
+        c->dsigw2dz = K(1.8432) * c->wst * c->wst / c->h * r_pow(K(3) * c->zeta - c->ol / c->h, K(-0.33333));
+      } else {
+        c->sigw = c->wst * s2;
+        c->dsigw2dz = K(0.203759) * c->wst * c->wst / c->h * r_pow(c->zeta, K(-0.65));
+      }
+    } else if (c->zeta < K(0.96)) {
+      c->sigw = K(0.722) * c->wst * r_pow(K(1) - c->zeta, K(0.207));
+      c->dsigw2dz = K(-.215812) * c->wst * c->wst / c->h * r_pow(K(1) - c->zeta, K(-0.586));
+    } else if (c->zeta < K(1.00)) {
+      c->sigw = K(0.37) * c->wst;
+      c->dsigw2dz = K(0.);
+    }   /* zeta >= 1: sigw, dsigw2dz keep their previous (module) values */
+    c->sigw = r_max(c->sigw, K(1.e-6));
+    c->tlu = K(0.15) * c->h / c->sigu;
+    c->tlv = c->tlu;
+    c->tlw = orc_tlw_unstable(c, z);
+  } else {
+    c->sigu = K(2.) * c->ust * (K(1.) - c->zeta);
+    c->sigv = K(1.3) * c->ust * (K(1.) - c->zeta);
+    c->sigu = r_max(c->sigu, K(1.e-6));
+    c->sigv = r_max(c->sigv, K(1.e-6));
+    c->sigw = c->sigv;
+    c->dsigw2dz = K(3.38) * c->ust * c->ust * (c->zeta - K(1.)) / c->h;
+    c->tlu = K(0.15) * c->h / c->sigu * r_sqrt(c->zeta);
+    c->tlv = K(0.467) * c->tlu;
+    c->tlw = K(0.1) * c->h / c->sigw * r_pow(c->zeta, K(0.8));
+  }
+  c->tlu = r_max(K(10.), c->tlu);
+  c->tlv = r_max(K(10.), c->tlv);
+  c->tlw = r_max(K(30.), c->tlw);
+}
+
+/* hanna_short.f90:41-92 */
+static void orc_hanna_short(orc_ctx *c, real z) {
+  if (c->h / r_abs(c->ol) < K(1.)) {
+    c->ust = r_max(K(1.e-4), c->ust);
+    c->sigw = K(1.3) * r_exp(K(-2.e-4) * z / c->ust);
+    c->dsigwdz = K(-2.e-4) * c->sigw;
+    c->sigw = c->sigw * c->ust + K(1.e-2);
+    c->tlw = K(0.5) * z / c->sigw / (K(1.) + K(1.5e-3) * z / c->ust);
+  } else if (c->ol < K(0.)) {
+    c->sigw = r_sqrt(K(1.2) * (c->wst * c->wst) * (K(1.) - K(.9) * c->zeta) * r_pow(c->zeta, K(0.66666)) + (K(1.8) - K(1.4) * c->zeta) * (c->ust * c->ust)) + K(1.e-2);
+    c->dsigwdz = K(0.5) / c->sigw / c->h * (K(-1.4) * (c->ust * c->ust) + (c->wst * c->wst) * (K(0.8) * r_pow(r_max(c->zeta, K(1.e-3)), K(-.33333)) - K(1.8) * r_pow(c->zeta, K(0.66666))));
+    c->tlw = orc_tlw_unstable(c, z);
+  } else {
+    c->sigw = K(1.e-2) + K(1.3) * c->ust * (K(1.) - c->zeta);
+    c->dsigwdz = K(-1.3) * c->ust / c->h;
+    c->tlw = K(0.1) * c->h / c->sigw * r_pow(c->zeta, K(0.8));
+  }
+  c->tlu = r_max(K(10.), c->tlu);
+  c->tlv = r_max(K(10.), c->tlv);
+  c->tlw = r_max(K(30.), c->tlw);
+  if (c->dsigwdz == K(0.)) c->dsigwdz = K(1.e-10);
+}
+
+/* ------------------------------------------------------------------------- */
+/* skewed CBL turbulence: cbl.f90, re_initialize_particle.f90,                 */
+/* initialize_cbl_vel.f90                                                      */
+/* ------------------------------------------------------------------------- */
+#define PI_PAR K(3.14159265)   /* par_mod.f90:59 */
+
+/* cbl.f90:220-234 */
+static real orc_cuberoot(real x) { return r_sign(r_pow(r_abs(x), K(0.333333333)), x); }
+
+/* cbl.f90:70-210 */
+static void orc_cbl(orc_ctx *c, real wp, real zp, real ust, real wst, real h, real rhoa, real rhograd,
+                    real sigmaw, real dsigmawdz, real tlw, real *ptot_o, real *Q_o, real *phi_o,
+                    real *ath, real *bth, real ol, int *flagrein) {
+  const real usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
+  real dens, ddens, fluarw, fluarw2, w3, w2, dw3, dw2, wb, wa, deltawa, deltawb, wold, wold2;
+  real pa, pb, alfa, Phi, Q, ptot, timedir, transition, aperfa, aperfb;
+  real z, skew, skew2, radw2, rluarw, xluarw, aluarw, bluarw, sigmawa, sigmawb, dskew, dradw2, dfluarw;
+  real drluarw, dxluarw, daluarw, dbluarw, dsigmawa, dsigmawb, dwa, dwb, sigmawa2, sigmawb2;
+  real a1, a3, t1;
+  (void)ust;
+  dens = rhoa;
+  ddens = rhograd;
+  timedir = (real)c->ldirect;
+  z = zp / h;
+  transition = K(1.);
+  if (-h / ol < K(15)) transition = r_sin(((-h / ol + K(10.)) / K(10.)) * PI_PAR) / K(2.) + K(0.5);
+  w2 = sigmaw * sigmaw;
+  dw2 = K(2.) * sigmaw * dsigmawdz;
+  alfa = K(2.) * w2 / (C0 * tlw);
+  wold = timedir * wp;
+  w3 = (K(1.2) * z * r_pow(K(1.) - z, K(1.5)) + eps) * (wst * wst * wst) * transition;
+  dw3 = (K(1.2) * (r_pow(K(1.) - z, K(1.5)) + z * K(1.5) * r_pow(K(1.) - z, K(0.5)) * K(-1.))) * (wst * wst * wst) * (K(1.) / h) * transition;
+  skew = w3 / r_pow(w2, K(1.5));
+  skew2 = skew * skew;
+  dskew = (dw3 * r_pow(w2, K(1.5)) - w3 * K(1.5) * r_pow(w2, K(0.5)) * dw2) / (w2 * w2 * w2);
+  radw2 = r_pow(w2, K(0.5));
+  dradw2 = K(0.5) * r_pow(w2, K(-0.5)) * dw2;
+  fluarw = costluar4 * orc_cuberoot(skew);
+  fluarw2 = fluarw * fluarw;
+  if (skew != K(0)) {
+    dfluarw = costluar4 * (K(1.) / K(3.)) * orc_cuberoot(r_pow(skew, K(-2.))) * dskew;
+    a1 = K(1.) + fluarw2;
+    a3 = K(3.) + fluarw2;
+    rluarw = r_pow(a1, K(3.)) * skew2 / (r_pow(a3, K(2.)) * fluarw2);
+    xluarw = r_pow(a1, K(1.5)) * skew / (a3 * fluarw);
+    drluarw = (((K(3.) * (a1 * a1) * (K(2.) * fluarw * dfluarw) * skew2) + (a1 * a1 * a1) * K(2.) * skew * dskew) * r_pow(a3, K(2.)) * fluarw2 -
+               (a1 * a1 * a1) * skew2 * ((K(2.) * a3 * (K(2.) * fluarw * dfluarw) * fluarw2) + (a3 * a3) * K(2.) * fluarw * dfluarw)) /
+              ((r_pow(a3, K(2.)) * fluarw2) * (r_pow(a3, K(2.)) * fluarw2));
+    dxluarw = (((K(1.5) * r_pow(a1, K(0.5)) * (K(2.) * fluarw * dfluarw) * skew) + r_pow(a1, K(1.5)) * dskew) * a3 * fluarw -
+               r_pow(a1, K(1.5)) * skew * (K(3.) * dfluarw + K(3) * fluarw2 * dfluarw)) /
+              ((a3 * fluarw) * (a3 * fluarw));
+  } else {
+    dfluarw = K(0.); rluarw = K(0.); drluarw = K(0.); xluarw = K(0.); dxluarw = K(0.);
+  }
+  aluarw = K(0.5) * (K(1.) - xluarw / r_pow(K(4.) + rluarw, K(0.5)));
+  bluarw = K(1.) - aluarw;
+  daluarw = K(-0.5) * ((dxluarw * r_pow(K(4.) + rluarw, K(0.5))) - (K(0.5) * xluarw * r_pow(K(4.) + rluarw, K(-0.5)) * drluarw)) / (K(4.) + rluarw);
+  dbluarw = -daluarw;
+  sigmawa = radw2 * r_pow(bluarw / (aluarw * (K(1.) + fluarw2)), K(0.5));
+  sigmawb = radw2 * r_pow(aluarw / (bluarw * (K(1.) + fluarw2)), K(0.5));
+  t1 = aluarw * (K(1.) + fluarw2);
+  dsigmawa = dradw2 * r_pow(bluarw / t1, K(0.5)) +
+             radw2 * ((K(0.5) * r_pow(bluarw / t1, K(-0.5))) *
+                      ((dbluarw * t1 - bluarw * (daluarw * (K(1.) + fluarw2) + aluarw * K(2.) * fluarw * dfluarw)) / (t1 * t1)));
+  t1 = bluarw * (K(1.) + fluarw2);
+  dsigmawb = dradw2 * r_pow(aluarw / t1, K(0.5)) +
+             radw2 * ((K(0.5) * r_pow(aluarw / t1, K(-0.5))) *
+                      ((daluarw * t1 - aluarw * (dbluarw * (K(1.) + fluarw2) + bluarw * K(2.) * fluarw * dfluarw)) / (t1 * t1)));
+  wa = fluarw * sigmawa;
+  wb = fluarw * sigmawb;
+  dwa = dfluarw * sigmawa + fluarw * dsigmawa;
+  dwb = dfluarw * sigmawb + fluarw * dsigmawb;
+  deltawa = wold - wa;
+  deltawb = wold + wb;
+  wold2 = wold * wold;
+  sigmawa2 = sigmawa * sigmawa;
+  sigmawb2 = sigmawb * sigmawb;
+  if (r_abs(deltawa) > K(6.) * sigmawa && r_abs(deltawb) > K(6.) * sigmawb) *flagrein = 1;
+  pa = (usurad2p * (K(1.) / sigmawa)) * r_exp(-(K(0.5) * ((deltawa / sigmawa) * (deltawa / sigmawa))));
+  pb = (usurad2p * (K(1.) / sigmawb)) * r_exp(-(K(0.5) * ((deltawb / sigmawb) * (deltawb / sigmawb))));
+  ptot = dens * aluarw * pa + dens * bluarw * pb;
+  aperfa = deltawa * usurad2 / sigmawa;
+  aperfb = deltawb * usurad2 / sigmawb;
+  Phi = K(-0.5) * (aluarw * dens * dwa + dens * wa * daluarw + aluarw * wa * ddens) * r_erf(aperfa) +
+        sigmawa * (aluarw * dens * dsigmawa * (wold2 / sigmawa2 + K(1.)) + sigmawa * dens * daluarw + sigmawa * ddens * aluarw +
+                   aluarw * wold * dens / sigmawa2 * (sigmawa * dwa - wa * dsigmawa)) * pa +
+        K(0.5) * (bluarw * dens * dwb + wb * dens * dbluarw + wb * bluarw * ddens) * r_erf(aperfb) +
+        sigmawb * (bluarw * dens * dsigmawb * (wold2 / sigmawb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
+                   bluarw * wold * dens / sigmawb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
+  Q = timedir * ((aluarw * dens * deltawa / sigmawa2) * pa + (bluarw * dens * deltawb / sigmawb2) * pb);
+  *ath = (K(1.) / ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
+  *bth = r_sqrt(C0 * alfa);
+  *ptot_o = ptot; *Q_o = Q; *phi_o = Phi;
+}
+
+/* the pdf set-up shared by re_initialize_particle.f90:47-70 and initialize_cbl_vel.f90:46-73 */
+static void orc_cbl_pdf(orc_ctx *c, real zp, real wst, real h, real sigmaw, real ol,
+                        real *aluarw, real *sigmawa, real *sigmawb, real *wa, real *wb) {
+  const real costluar4 = K(0.66667), eps = K(0.000001);
+  real z, transition, w2, w3, skew, skew2, radw2, fluarw, fluarw2, rluarw, xluarw, bluarw;
+  (void)c;
+  z = zp / h;
+  transition = K(1.);
+  if (-h / ol < K(15)) transition = r_sin(((-h / ol + K(10.)) / K(10.)) * PI_PAR) / K(2.) + K(0.5);
+  w2 = sigmaw * sigmaw;
+  w3 = ((K(1.2) * z * r_pow(K(1.) - z, K(1.5)) + eps) * (wst * wst * wst)) * transition;
+  skew = w3 / r_pow(w2, K(1.5));
+  skew2 = skew * skew;
+  radw2 = r_sqrt(w2);
+  fluarw = costluar4 * r_pow(skew, K(0.333333333333333));
+  fluarw2 = fluarw * fluarw;
+  rluarw = r_pow(K(1.) + fluarw2, K(3.)) * skew2 / (r_pow(K(3.) + fluarw2, K(2.)) * fluarw2);
+  xluarw = r_pow(rluarw, K(0.5));
+  *aluarw = K(0.5) * (K(1.) - xluarw / r_pow(K(4.) + rluarw, K(0.5)));
+  bluarw = K(1.) - *aluarw;
+  *sigmawa = radw2 * r_pow(bluarw / (*aluarw * (K(1.) + fluarw2)), K(0.5));
+  *sigmawb = radw2 * r_pow(*aluarw / (bluarw * (K(1.) + fluarw2)), K(0.5));
+  *wa = fluarw * *sigmawa;
+  *wb = fluarw * *sigmawb;
+}
+
+/* re_initialize_particle.f90:44-90 */
+static void orc_re_initialize_particle(orc_ctx *c, real zp, real ust, real wst, real h, real sigmaw, real *wp, int *nrand, real ol) {
+  real aluarw, sigmawa, sigmawb, wa, wb, dcas1, timedir;
+  (void)ust;
+  *nrand = *nrand + 1;
+  dcas1 = c->rannumb[*nrand];
+  timedir = (real)c->ldirect;
+  orc_cbl_pdf(c, zp, wst, h, sigmaw, ol, &aluarw, &sigmawa, &sigmawb, &wa, &wb);
+  if (r_sign(K(1.), *wp) * timedir > 0) {          /* updraft */
+    for (;;) {
+      *wp = dcas1 * sigmawa + wa;
+      if (*wp < 0) { *nrand = *nrand + 1; dcas1 = c->rannumb[*nrand]; continue; }
+      break;
+    }
+    *wp = *wp * timedir;
+  } else if (r_sign(K(1.), *wp) * timedir < 0) {   /* downdraft */
+    for (;;) {
+      *wp = dcas1 * sigmawb - wb;
+      if (*wp > 0) { *nrand = *nrand + 1; dcas1 = c->rannumb[*nrand]; continue; }
+      break;
+    }
+    *wp = *wp * timedir;
+  }
+}
+
+/* initialize_cbl_vel.f90:46-83 */
+static void orc_initialize_cbl_vel(orc_ctx *c, int *idum, real zp, real ust, real wst, real h, real sigmaw, real *wp, real ol) {
+  real aluarw, sigmawa, sigmawb, wa, wb, dcas, dcas1, timedir;
+  (void)ust;
+  timedir = (real)c->ldirect;
+  orc_cbl_pdf(c, zp, wst, h, sigmaw, ol, &aluarw, &sigmawa, &sigmawb, &wa, &wb);
+  dcas = orc_ran3(c, idum);
+  if (dcas <= aluarw) {
+    dcas1 = orc_gasdev(c, idum);
+    *wp = timedir * (dcas1 * sigmawa + wa);
+  } else {
+    dcas1 = orc_gasdev(c, idum);
+    *wp = timedir * (dcas1 * sigmawb - wb);
+  }
+}
+
+/* windalign.f90:36-54 */
+static void orc_windalign(real u, real v, real ffap, real ffcp, real *ux, real *vy) {
+  const real eps = K(1.e-30);
+  real ffinv, ux1, ux2, vy1, vy2, sinphi, cosphi;
+  ffinv = K(1.) / r_max(r_sqrt(u * u + v * v), eps);
+  sinphi = v * ffinv;
+  vy1 = sinphi * ffap;
+  cosphi = u * ffinv;
+  ux1 = cosphi * ffap;
+  ux2 = -sinphi * ffcp;
+  vy2 = cosphi * ffcp;
+  *ux = ux1 + ux2;
+  *vy = vy1 + vy2;
+}
+
+/* ------------------------------------------------------------------------- */
+/* map projection subset: cmapf_mod.f90                                        */
+/* ------------------------------------------------------------------------- */
+#define CM_REARTH K(6371.2)
+#define CM_ALMST1 K(.9999999)
+#define CM_PI K(3.14159265358979)
+#define CM_RADPDG (CM_PI / K(180.))
+#define CM_DGPRAD (K(180.) / CM_PI)
+
+/* cmapf_mod.f90:494-524 */
+static real orc_cspanf(real value, real begin, real end) {
+  real first = r_min(begin, end), last = r_max(begin, end), val;
+  val = r_mod(value - first, last - first);
+  return val <= K(0.) ? val + last : val + first;
+}
+
+/* cmapf_mod.f90:190-238 */
+static real orc_cgszll(const real *s, real xlat, real xlong) {
+  double slat, ymerc, efact;
+  (void)xlong;
+  if (xlat > K(89.985)) {
+    if (s[0] > K(0.9999)) return K(2.) * s[6];
+    efact = (double)r_cos(CM_RADPDG * xlat);
+    if (efact <= 0.) return K(0.);
+    ymerc = -log(efact / (double)(K(1.) + r_sin(CM_RADPDG * xlat)));
+  } else if (xlat < K(-89.985)) {
+    if (s[0] < K(-0.9999)) return K(2.) * s[6];
+    efact = (double)r_cos(CM_RADPDG * xlat);
+    if (efact <= 0.) return K(0.);
+    ymerc = log(efact / (double)(K(1.) - r_sin(CM_RADPDG * xlat)));
+  } else {
+    slat = (double)r_sin(CM_RADPDG * xlat);
+    ymerc = log((1. + slat) / (1. - slat)) / 2.;
+  }
+  return (real)((double)(s[6] * r_cos(CM_RADPDG * xlat)) * exp((double)s[0] * ymerc));
+}
+
+/* cmapf_mod.f90:310-365 */
+static void orc_cnllxy(const real *s, real xlat, real xlong, real *xi, real *eta) {
+  real gdlong, sndgam, csdgam, rhog1;
+  double gamma, dlong, dlat, slat, mercy, gmercy;
+  gamma = (double)s[0];
+  dlat = (double)xlat;
+  dlong = (double)orc_cspanf(xlong - s[1], K(-180.), K(180.));
+  dlong = dlong * (double)CM_RADPDG;
+  gdlong = (real)(gamma * dlong);
+  if (r_abs(gdlong) < K(.01)) {
+    gdlong = gdlong * gdlong;
+    sndgam = (real)(dlong * (double)(K(1.) - K(1.) / K(6.) * gdlong * (K(1.) - K(1.) / K(20.) * gdlong * (K(1.) - K(1.) / K(42.) * gdlong))));
+    csdgam = (real)(dlong * dlong * (double)K(.5) * (double)(K(1.) - K(1.) / K(12.) * gdlong * (K(1.) - K(1.) / K(30.) * gdlong * (K(1.) - K(1.) / K(56.) * gdlong))));
+  } else {
+    sndgam = (real)((double)r_sin(gdlong) / gamma);
+    csdgam = (real)((double)(K(1.) - r_cos(gdlong)) / gamma / gamma);
+  }
+  slat = sin((double)CM_RADPDG * dlat);
+  if (slat >= (double)CM_ALMST1 || slat <= -(double)CM_ALMST1) {
+    *eta = K(1.) / s[0];
+    *xi = K(0.);
+    return;
+  }
+  mercy = .5 * log((1. + slat) / (1. - slat));
+  gmercy = gamma * mercy;
+  if (fabs(gmercy) < (double)K(.001)) {
+    rhog1 = (real)(mercy * (1. - .5 * gmercy * (1. - (double)(K(1.) / K(3.)) * gmercy * (1. - (double)(K(1.) / K(4.)) * gmercy))));
+  } else {
+    rhog1 = (real)((1. - exp(-gmercy)) / gamma);
+  }
+  *eta = (real)((double)rhog1 + (1. - gamma * (double)rhog1) * gamma * (double)csdgam);
+  *xi = (real)((1. - gamma * (double)rhog1) * (double)sndgam);
+}
+
+/* cmapf_mod.f90:295-308 */
+static void orc_cll2xy(const real *s, real xlat, real xlong, real *x, real *y) {
+  real xi, eta;
+  orc_cnllxy(s, xlat, xlong, &xi, &eta);
+  *x = s[2] + CM_REARTH / s[6] * (xi * s[4] + eta * s[5]);
+  *y = s[3] + CM_REARTH / s[6] * (eta * s[4] - xi * s[5]);
+}
+
+/* cmapf_mod.f90:367-425 */
+static void orc_cnxyll(const real *s, double xi, double eta, real *xlat, real *xlong) {
+  double gamma, temp, arg1, arg2, ymerc, along, gxi, cgeta;
+  gamma = (double)s[0];
+  arg2 = 2. * eta - gamma * (xi * xi + eta * eta);
+  arg1 = gamma * arg2;
+  if (fabs(arg1) < (double)K(.01)) {
+    temp = (arg1 / (2. - arg1)) * (arg1 / (2. - arg1));
+    ymerc = arg2 / (2. - arg1) * (1. + temp * ((double)(K(1.) / K(3.)) + temp * ((double)(K(1.) / K(5.)) + temp * ((double)(K(1.) / K(7.))))));
+  } else {
+    ymerc = -log(1. - arg1) / 2. / gamma;
+  }
+  temp = exp(-fabs(ymerc));
+  {
+    double a = atan2((1. - temp) * (1. + temp), 2. * temp);
+    *xlat = (real)(ymerc < 0 ? -fabs(a) : fabs(a));
+  }
+  gxi = gamma * xi;
+  cgeta = 1. - gamma * eta;
+  if (fabs(gxi) < (double)K(.01) * cgeta) {
+    temp = (gxi / cgeta) * (gxi / cgeta);
+    along = xi / cgeta * (1. - temp * ((double)(K(1.) / K(3.)) - temp * ((double)(K(1.) / K(5.)) - temp * ((double)(K(1.) / K(7.))))));
+  } else {
+    along = atan2(gxi, cgeta) / gamma;
+  }
+  *xlong = (real)((double)s[1] + (double)CM_DGPRAD * along);
+  *xlat = *xlat * CM_DGPRAD;
+}
+
+/* cmapf_mod.f90:526-543 */
+static void orc_cxy2ll(const real *s, real x, real y, real *xlat, real *xlong) {
+  double xi0, eta0, xi, eta;
+  xi0 = (double)((x - s[2]) * s[6] / CM_REARTH);
+  eta0 = (double)((y - s[3]) * s[6] / CM_REARTH);
+  xi = xi0 * (double)s[4] - eta0 * (double)s[5];
+  eta = eta0 * (double)s[4] + xi0 * (double)s[5];
+  orc_cnxyll(s, xi, eta, xlat, xlong);
+  *xlong = orc_cspanf(*xlong, K(-180.), K(180.));
+}
+
+/* ------------------------------------------------------------------------- */
+/* gravitational settling: get_settling.f90:52-127, dynamic_viscosity.f90:7-17 */
+/* ------------------------------------------------------------------------- */
+static real orc_viscosity(real t) {
+  const real cc = K(120.), t_0 = K(291.15), eta_0 = K(1.827e-5);
+  return eta_0 * (t_0 + cc) / (t + cc) * r_pow(t / t_0, K(1.5));
+}
+
+static void orc_get_settling(orc_ctx *c, int itime, real xt, real yt, real zt, int nsp, real *settling) {
+  const real ga = K(9.81);
+  real dz1, dz2, dz, rho1[2], tt1[2], temperature, airdens, vis_dyn, vis_kin, settling_old, reynolds, c_d;
+  int i, n, nix, njy, indz = 1;
+  (void)itime;
+  nix = (int)xt;
+  njy = (int)yt;
+  for (i = 2; i <= c->nz; i++)
+    if (HGT(i) > zt) { indz = i - 1; break; }
+  dz = K(1.) / (HGT(indz + 1) - HGT(indz));
+  dz1 = (zt - HGT(indz)) * dz;
+  dz2 = (HGT(indz + 1) - zt) * dz;
+  for (n = 0; n < 2; n++) {            /* literal time slot 1 (get_settling.f90:83-84) */
+    rho1[n] = F3(c->rho, nix, njy, indz + n, 1);
+    tt1[n] = F3(c->tt, nix, njy, indz + n, 1);
+  }
+  temperature = dz2 * tt1[0] + dz1 * tt1[1];
+  airdens = dz2 * rho1[0] + dz1 * rho1[1];
+  vis_dyn = orc_viscosity(temperature);
+  vis_kin = vis_dyn / airdens;
+  reynolds = c->dquer[nsp - 1] / K(1.e6) * r_abs(c->vsetaver[nsp - 1]) / vis_kin;
+  settling_old = c->vsetaver[nsp - 1];
+  for (i = 1; i <= 20; i++) {
+    if (reynolds < K(1.917)) c_d = K(24.) / reynolds;
+    else if (reynolds < K(500.)) c_d = K(18.5) / r_pow(reynolds, K(0.6));
+    else c_d = K(0.44);
+    *settling = K(-1.) * r_sqrt(K(4) * ga * c->dquer[nsp - 1] / K(1.e6) * c->density[nsp - 1] * c->cunningham[nsp - 1] / (K(3.) * c_d * airdens));
+    if (r_abs((*settling - settling_old) / *settling) < K(0.01)) break;
+    reynolds = c->dquer[nsp - 1] / K(1.e6) * r_abs(*settling) / vis_kin;
+    settling_old = *settling;
+  }
+}
+
+/* the species pick + settling add repeated at advance.f90:518-531,686-699,893-906 */
+static void orc_add_settling(orc_ctx *c, int itime, double xt, double yt, real zt) {
+  const real eps3 = sizeof(real) == 4 ? (real)1.17549435e-38f : (real)2.2250738585072014e-308;
+  int nsp;
+  if (c->mdomainfill == 0 && c->lsettling) {
+    for (nsp = 1; nsp <= c->nspec; nsp++)
+      if (c->xmass_rel[nsp - 1] > eps3) break;
+    if (nsp > c->nspec) nsp = c->nspec;
+    if (c->density[nsp - 1] > K(0.)) {
+      orc_get_settling(c, itime, (real)xt, (real)yt, zt, nsp, &c->settling);
+      c->w = c->w + c->settling;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* initialize.f90:66-217                                                       */
+/* ------------------------------------------------------------------------- */
+static void orc_initialize(orc_ctx *c, int itime, int *ldt, real *up, real *vp, real *wp,
+                           real *usigold, real *vsigold, real *wsigold, double xt, double yt, real zt, int16_t *icbt) {
+  int nrand, m;
+  real dz, dz1, dz2, hh;
+  *icbt = 1;
+  nrand = (int)(orc_ran3(c, &c->idummy_init) * (real)(ORC_MAXRAND - 1)) + 1;
+  c->ix = (int)xt;
+  c->jy = (int)yt;
+  c->ixp = c->ix + 1;
+  c->jyp = c->jy + 1;
+  hh = F2(c->hmix, c->ix, c->jy, c->memind[0]);
+  for (m = 0; m < 2; m++) {
+    hh = r_max(hh, F2(c->hmix, c->ix, c->jy, c->memind[m]));
+    hh = r_max(hh, F2(c->hmix, c->ixp, c->jy, c->memind[m]));
+    hh = r_max(hh, F2(c->hmix, c->ix, c->jyp, c->memind[m]));
+    hh = r_max(hh, F2(c->hmix, c->ixp, c->jyp, c->memind[m]));
+  }
+  c->h = hh;
+  c->zeta = zt / c->h;
+  if (c->zeta <= K(1.)) {
+    orc_interpol_all(c, itime, (real)xt, (real)yt, zt);
+    dz1 = zt - HGT(c->indz);
+    dz2 = HGT(c->indzp) - zt;
+    dz = K(1.) / (dz1 + dz2);
+    c->u = (dz1 * c->uprof[c->indzp] + dz2 * c->uprof[c->indz]) * dz;
+    c->v = (dz1 * c->vprof[c->indzp] + dz2 * c->vprof[c->indz]) * dz;
+    c->w = (dz1 * c->wprof[c->indzp] + dz2 * c->wprof[c->indz]) * dz;
+    if (c->turbswitch) orc_hanna(c, zt); else orc_hanna1(c, zt);
+    if (nrand + 2 > ORC_MAXRAND) nrand = 1;
+    *up = c->rannumb[nrand] * c->sigu;
+    *vp = c->rannumb[nrand + 1] * c->sigv;
+    *wp = c->rannumb[nrand + 2];
+    if (!c->turbswitch) {
+      *wp = *wp * c->sigw;
+    } else if (c->cblflag == 1) {
+      if (-c->h / c->ol > K(5)) orc_initialize_cbl_vel(c, &c->idummy_init, zt, c->ust, c->wst, c->h, c->sigw, wp, c->ol);
+      else *wp = *wp * c->sigw;
+    }
+    if (c->turbswitch)
+      *ldt = (int)(r_min(r_min(r_min(c->tlw, c->h / r_max(K(2.) * r_abs(*wp * c->sigw), K(1.e-5))), K(0.5) / r_abs(c->dsigwdz)), K(600.)) * c->ctl);
+    else
+      *ldt = (int)(r_min(r_min(c->tlw, c->h / r_max(K(2.) * r_abs(*wp), K(1.e-5))), K(600.)) * c->ctl);
+    if (*ldt < c->mintime) *ldt = c->mintime;
+    c->usig = (c->usigprof[c->indzp] + c->usigprof[c->indz]) / K(2.);
+    c->vsig = (c->vsigprof[c->indzp] + c->vsigprof[c->indz]) / K(2.);
+    c->wsig = (c->wsigprof[c->indzp] + c->wsigprof[c->indz]) / K(2.);
+  } else {
+    orc_interpol_wind(c, itime, (real)xt, (real)yt, zt, 1);
+    *ldt = abs(c->lsynctime);
+    if (nrand + 1 > ORC_MAXRAND) nrand = 1;
+    *up = c->rannumb[nrand] * K(0.3);
+    *vp = c->rannumb[nrand + 1] * K(0.3);
+    nrand = nrand + 2;
+    *wp = K(0.);
+    c->sigw = K(0.);
+  }
+  if (nrand + 2 > ORC_MAXRAND) nrand = 1;
+  *usigold = c->rannumb[nrand] * c->usig;
+  *vsigold = c->rannumb[nrand + 1] * c->vsig;
+  *wsigold = c->rannumb[nrand + 2] * c->wsig;
+}
+
+/* ------------------------------------------------------------------------- */
+/* advance.f90:133-985                                                         */
+/* ------------------------------------------------------------------------- */
+/* grid choice: advance.f90:161-175 (and again :841-855) */
+static int orc_pick_grid(orc_ctx *c, double xt, double yt, real eps) {
+  int j;
+  if (c->nglobal && yt > (double)c->switchnorthg) return -1;
+  if (c->sglobal && yt < (double)c->switchsouthg) return -2;
+  for (j = c->numbnests; j >= 1; j--)
+    if (xt > (double)(c->xln[j - 1] + eps) && xt < (double)(c->xrn[j - 1] - eps) &&
+        yt > (double)(c->yln[j - 1] + eps) && yt < (double)(c->yrn[j - 1] - eps)) return j;
+  return 0;
+}
+
+/* boundary conditions: advance.f90:784-813 == :956-985; returns nstop */
+static int orc_boundary(orc_ctx *c, double *xt, double *yt, real *zt, real eps) {
+  if (c->xglobal) {
+    if (*xt >= (double)(real)c->nxmin1) *xt = *xt - (double)(real)c->nxmin1;
+    if (*xt < 0.) *xt = *xt + (double)(real)c->nxmin1;
+    if (*xt <= (double)eps) *xt = (double)eps;
+    if (fabs(*xt - (double)(real)c->nxmin1) <= (double)eps) *xt = (double)((real)c->nxmin1 - eps);
+    if (*yt < 0.) {
+      *xt = d_modulo(*xt * (double)c->dx + 180., 360.) / (double)c->dx;
+      *yt = -*yt;
+    } else if (*yt > (double)(real)c->nymin1) {
+      *xt = d_modulo(*xt * (double)c->dx + 180., 360.) / (double)c->dx;
+      *yt = (double)(K(2) * (real)c->nymin1) - *yt;
+    }
+  }
+  if (*xt < 0. || *xt >= (double)(real)c->nxmin1 || *yt < 0. || *yt > (double)(real)c->nymin1) return 3;
+  if (*zt >= HGT(c->nz)) *zt = HGT(c->nz) - K(100.) * eps;
+  return 0;
+}
+
+/* horizontal move by (du,dv) [m] on grid ngrid: advance.f90:750-778 == :923-951 */
+static void orc_move(orc_ctx *c, double *xt, double *yt, real du, real dv, real fac) {
+  const real pi180 = PI_PAR / K(180.);
+  if (c->ngrid >= 0) {
+    real cosfact = (real)((double)c->dxconst / cos((*yt * (double)c->dy + (double)c->ylat0) * (double)pi180));
+    *xt = *xt + (double)(du * cosfact * fac);
+    *yt = *yt + (double)(dv * c->dyconst * fac);
+  } else {
+    const real *map = c->ngrid == -1 ? c->northpolemap : c->southpolemap;
+    real xlon, ylat, xpol, ypol, gridsize;
+    xlon = (real)((double)c->xlon0 + *xt * (double)c->dx);
+    ylat = (real)((double)c->ylat0 + *yt * (double)c->dy);
+    orc_cll2xy(map, ylat, xlon, &xpol, &ypol);
+    gridsize = K(1000.) * orc_cgszll(map, ylat, xlon);
+    du = du / gridsize;
+    dv = dv / gridsize;
+    xpol = xpol + du * fac;
+    ypol = ypol + dv * fac;
+    orc_cxy2ll(map, xpol, ypol, &ylat, &xlon);
+    *xt = (double)((xlon - c->xlon0) / c->dx);
+    *yt = (double)((ylat - c->ylat0) / c->dy);
+  }
+}
+
+static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up, real *vp, real *wp,
+                       real *usigold, real *vsigold, real *wsigold, double *xt, double *yt, real *zt,
+                       real *prob, int16_t *icbt) {
+  const real eps = K(361) / K(3.e5);   /* nxmax/3.e5, par_mod.f90:144 (nxmax=361) */
+  const real eps2 = K(1.e-9);
+  const real href = K(15.);
+  int itimec, i, k, nrand, loop, ngr, nix, njy, ks, mind, flagrein;
+  real xts, yts, dz, dz1, dz2, ru, rv, rw, dt, ux, vy, tropop, dxsave, dysave, dawsave, dcwsave;
+  real r, rs, uold, vold, wold, vdepo[ORC_MAXSPEC], rhoa, rhograd, delz = 0, dtf, rhoaux, dtftlw, uxscale, wpscale, weight;
+  real ptot_lhh, Q_lhh, phi_lhh, ath, bth, old_wp_buf, del_test;
+  double xtn = 0, ytn = 0;
+  (void)nrelpoint;
+
+  /* advance.f90:133-153 */
+  for (i = 1; i <= c->nmixz; i++) c->indzindicator[i] = 1;
+  if (c->drydep)
+    for (ks = 0; ks < c->nspec; ks++) { c->depoindicator[ks] = 1; prob[ks] = K(0.); }
+  dxsave = K(0.); dysave = K(0.); dawsave = K(0.); dcwsave = K(0.);
+  itimec = itime;
+  nrand = (int)(orc_ran3(c, &c->idummy_adv) * (real)(ORC_MAXRAND - 1)) + 1;
+
+  /* :161-175 */
+  c->ngrid = orc_pick_grid(c, *xt, *yt, eps);
+
+  /* :191-231 */
+  if (c->ngrid > 0) {
+    xtn = (*xt - (double)c->xln[c->ngrid - 1]) * (double)c->xresoln[c->ngrid - 1];
+    ytn = (*yt - (double)c->yln[c->ngrid - 1]) * (double)c->yresoln[c->ngrid - 1];
+    c->ix = (int)xtn; c->jy = (int)ytn;
+    nix = (int)lround(xtn); njy = (int)lround(ytn);
+  } else {
+    c->ix = (int)*xt; c->jy = (int)*yt;
+    nix = (int)lround(*xt); njy = (int)lround(*yt);
+  }
+  c->ixp = c->ix + 1;
+  c->jyp = c->jy + 1;
+  c->ddx = (real)(*xt - (double)(real)c->ix);
+  c->ddy = (real)(*yt - (double)(real)c->jy);
+  c->rddx = K(1.) - c->ddx;
+  c->rddy = K(1.) - c->ddy;
+  c->p1 = c->rddx * c->rddy;
+  c->p2 = c->ddx * c->rddy;
+  c->p3 = c->rddx * c->ddy;
+  c->p4 = c->ddx * c->ddy;
+  c->dt1 = (real)(itime - c->memtime[0]);
+  c->dt2 = (real)(c->memtime[1] - itime);
+  c->dtt = K(1.) / (c->dt1 + c->dt2);
+  if (c->jyp >= c->ny) c->jyp = c->jyp - 1;   /* :228-231 (nymax == ny here: compact layout) */
+
+  /* :236-267, interpolhmix = .false. */
+  c->h = K(0.);
+  if (c->ngrid <= 0) {
+    for (k = 0; k < 2; k++) {
+      int jj, ii;
+      mind = c->memind[k];
+      for (jj = c->jy; jj <= c->jyp; jj++)
+        for (ii = c->ix; ii <= c->ixp; ii++)
+          if (F2(c->hmix, ii, jj, mind) > c->h) c->h = F2(c->hmix, ii, jj, mind);
+    }
+    tropop = F2(c->tropopause, nix, njy, 1);
+  } else {
+    tropop = K(0.);  /* nests: see orc_*_nests (not yet restated) */
+  }
+  c->zeta = *zt / c->h;
+
+  /* :276 PBL branch */
+  if (c->zeta <= K(1.)) {
+    loop = 0;
+  L100:
+    loop = loop + 1;
+    if (c->method == 1) {
+      int rem = abs(c->lsynctime - itimec + itime);
+      *ldt = *ldt < rem ? *ldt : rem;
+      itimec = itimec + *ldt * c->ldirect;
+    } else {
+      *ldt = abs(c->lsynctime);
+      itimec = itime + c->lsynctime;
+    }
+    dt = (real)*ldt;
+    c->zeta = *zt / c->h;
+
+    if (loop == 1) {
+      xts = (real)*xt;
+      yts = (real)*yt;
+      orc_interpol_all(c, itime, xts, yts, *zt);
+    } else {
+      for (i = 2; i <= c->nz; i++)
+        if (HGT(i) > *zt) { c->indz = i - 1; c->indzp = i; break; }
+      for (i = c->indz; i <= c->indzp; i++)
+        if (c->indzindicator[i]) orc_profile_level(c, i);
+    }
+
+    /* :342-350 */
+    dz = K(1.) / (HGT(c->indzp) - HGT(c->indz));
+    dz1 = (*zt - HGT(c->indz)) * dz;
+    dz2 = (HGT(c->indzp) - *zt) * dz;
+    c->u = dz1 * c->uprof[c->indzp] + dz2 * c->uprof[c->indz];
+    c->v = dz1 * c->vprof[c->indzp] + dz2 * c->vprof[c->indz];
+    c->w = dz1 * c->wprof[c->indzp] + dz2 * c->wprof[c->indz];
+    rhoa = dz1 * c->rhoprof[c->indzp] + dz2 * c->rhoprof[c->indz];
+    rhograd = dz1 * c->rhogradprof[c->indzp] + dz2 * c->rhogradprof[c->indz];
+
+    /* :357-361 */
+    if (c->turbswitch) orc_hanna(c, *zt); else orc_hanna1(c, *zt);
+
+    /* :371-384 horizontal Langevin */
+    if (nrand + 1 > ORC_MAXRAND) nrand = 1;
+    if (dt / c->tlu < K(.5)) {
+      *up = (K(1.) - dt / c->tlu) * *up + c->rannumb[nrand] * c->sigu * r_sqrt(K(2.) * dt / c->tlu);
+    } else {
+      ru = r_exp(-dt / c->tlu);
+      *up = ru * *up + c->rannumb[nrand] * c->sigu * r_sqrt(K(1.) - ru * ru);
+    }
+    if (dt / c->tlv < K(.5)) {
+      *vp = (K(1.) - dt / c->tlv) * *vp + c->rannumb[nrand + 1] * c->sigv * r_sqrt(K(2.) * dt / c->tlv);
+    } else {
+      rv = r_exp(-dt / c->tlv);
+      *vp = rv * *vp + c->rannumb[nrand + 1] * c->sigv * r_sqrt(K(1.) - rv * rv);
+    }
+    nrand = nrand + 2;
+
+    /* :387-391 */
+    if (nrand + c->ifine > ORC_MAXRAND) nrand = 1;
+    rhoaux = rhograd / rhoa;
+    dtf = dt * c->fine;
+    dtftlw = dtf / c->tlw;
+
+    /* :396-498 vertical Langevin, ifine sub-steps */
+    for (i = 1; i <= c->ifine; i++) {
+      if (c->turbswitch) {
+        if (dtftlw < K(.5)) {
+          if (c->cblflag == 1) {
+            if (-c->h / c->ol > K(5)) {
+              flagrein = 0;
+              nrand = nrand + 1;
+              old_wp_buf = *wp;
+              orc_cbl(c, *wp, *zt, c->ust, c->wst, c->h, rhoa, rhograd, c->sigw, c->dsigwdz, c->tlw, &ptot_lhh, &Q_lhh, &phi_lhh, &ath, &bth, c->ol, &flagrein);
+              *wp = (*wp + ath * dtf + bth * c->rannumb[nrand] * r_sqrt(dtf)) * (real)*icbt;
+              delz = *wp * dtf;
+              if (flagrein == 1) {
+                orc_re_initialize_particle(c, *zt, c->ust, c->wst, c->h, c->sigw, &old_wp_buf, &nrand, c->ol);
+                *wp = old_wp_buf;
+                delz = *wp * dtf;
+                c->nan_count++;
+              }
+            } else {
+              nrand = nrand + 1;
+              old_wp_buf = *wp;
+              ath = -*wp / c->tlw + c->sigw * c->dsigwdz + *wp * *wp / c->sigw * c->dsigwdz + c->sigw * c->sigw / rhoa * rhograd;
+              bth = c->sigw * c->rannumb[nrand] * r_sqrt(K(2.) * dtftlw);
+              *wp = (*wp + ath * dtf + bth) * (real)*icbt;
+              delz = *wp * dtf;
+              del_test = (K(1.) - *wp) / *wp;
+              if (isnan((double)*wp) || isnan((double)del_test)) {
+                nrand = nrand + 1;
+                *wp = c->sigw * c->rannumb[nrand];
+                delz = *wp * dtf;
+                c->nan_count2++;
+              }
+            }
+          } else {
+            *wp = ((K(1.) - dtftlw) * *wp + c->rannumb[nrand + i] * r_sqrt(K(2.) * dtftlw) + dtf * (c->dsigwdz + rhoaux * c->sigw)) * (real)*icbt;
+            delz = *wp * c->sigw * dtf;
+          }
+        } else {
+          rw = r_exp(-dtftlw);
+          *wp = (rw * *wp + c->rannumb[nrand + i] * r_sqrt(K(1.) - rw * rw) + c->tlw * (K(1.) - rw) * (c->dsigwdz + rhoaux * c->sigw)) * (real)*icbt;
+          delz = *wp * c->sigw * dtf;
+        }
+      } else {
+        rw = r_exp(-dtftlw);
+        *wp = (rw * *wp + c->rannumb[nrand + i] * r_sqrt(K(1.) - rw * rw) * c->sigw + c->tlw * (K(1.) - rw) * (c->dsigw2dz + rhoaux * (c->sigw * c->sigw))) * (real)*icbt;
+        delz = *wp * dtf;
+      }
+      /* turboff = .false. (com_mod.f90:778) */
+
+      /* :476-491 */
+      if (r_abs(delz) > c->h) delz = r_mod(delz, c->h);
+      if (delz < -*zt) {
+        *icbt = -1;
+        *zt = -*zt - delz;
+      } else if (delz > (c->h - *zt)) {
+        *icbt = -1;
+        *zt = -*zt - delz + K(2.) * c->h;
+      } else {
+        *icbt = 1;
+        *zt = *zt + delz;
+      }
+      if (i != c->ifine) {
+        c->zeta = *zt / c->h;
+        orc_hanna_short(c, *zt);
+      }
+    }
+    if (c->cblflag != 1) nrand = nrand + i;   /* i == ifine+1 here, as in the reference (:499) */
+
+    /* :504-510 */
+    if (c->turbswitch)
+      *ldt = (int)(r_min(r_min(c->tlw, c->h / r_max(K(2.) * r_abs(*wp * c->sigw), K(1.e-5))), K(0.5) / r_abs(c->dsigwdz)) * c->ctl);
+    else
+      *ldt = (int)(r_min(c->tlw, c->h / r_max(K(2.) * r_abs(*wp), K(1.e-5))) * c->ctl);
+    if (*ldt < c->mintime) *ldt = c->mintime;
+
+    /* :518-531 */
+    orc_add_settling(c, itime, *xt, *yt, *zt);
+
+    /* :539-547 */
+    dxsave = dxsave + c->u * dt;
+    dysave = dysave + c->v * dt;
+    dawsave = dawsave + *up * dt;
+    dcwsave = dcwsave + *vp * dt;
+    *zt = *zt + c->w * dt * (real)c->ldirect;
+    if (*zt >= HGT(c->nz)) *zt = HGT(c->nz) - K(100.) * eps;
+
+    /* :549-552 */
+    if (*zt > c->h) {
+      if (itimec == itime + c->lsynctime) goto L99;
+      goto L700;
+    }
+
+    /* :582-599 dry deposition probability */
+    if (c->drydep && *zt < K(2.) * href) {
+      for (ks = 1; ks <= c->nspec; ks++) {
+        if (c->drydepspec[ks - 1]) {
+          if (c->depoindicator[ks - 1]) orc_interpol_vdep(c, ks, &vdepo[ks - 1]);
+          prob[ks - 1] = K(1.) + (prob[ks - 1] - K(1.)) * r_exp(-vdepo[ks - 1] * r_abs(dt) / (K(2.) * href));
+        }
+      }
+    }
+
+    if (*zt < K(0.)) *zt = r_min(c->h - eps2, K(-1.) * *zt);   /* :601 */
+
+    if (itimec == itime + c->lsynctime) {   /* :603-608 */
+      c->usig = K(0.5) * (c->usigprof[c->indzp] + c->usigprof[c->indz]);
+      c->vsig = K(0.5) * (c->vsigprof[c->indzp] + c->vsigprof[c->indz]);
+      c->wsig = K(0.5) * (c->wsigprof[c->indzp] + c->wsigprof[c->indz]);
+      goto L99;
+    }
+    goto L100;
+  }
+
+L700:
+  /* :629-636 */
+  xts = (real)*xt;
+  yts = (real)*yt;
+  orc_interpol_wind(c, itime, xts, yts, *zt, 1);
+
+  /* :647-673 */
+  *ldt = abs(c->lsynctime - itimec + itime);
+  dt = (real)*ldt;
+  if (*zt < tropop) {
+    uxscale = r_sqrt(K(2.) * c->d_trop / dt);
+    if (nrand + 1 > ORC_MAXRAND) nrand = 1;
+    ux = c->rannumb[nrand] * uxscale;
+    vy = c->rannumb[nrand + 1] * uxscale;
+    nrand = nrand + 2;
+    *wp = K(0.);
+  } else if (*zt < tropop + K(1000.)) {
+    weight = (*zt - tropop) / K(1000.);
+    uxscale = r_sqrt(K(2.) * c->d_trop / dt * (K(1.) - weight));
+    if (nrand + 2 > ORC_MAXRAND) nrand = 1;
+    ux = c->rannumb[nrand] * uxscale;
+    vy = c->rannumb[nrand + 1] * uxscale;
+    wpscale = r_sqrt(K(2.) * c->d_strat / dt * weight);
+    *wp = c->rannumb[nrand + 2] * wpscale + c->d_strat / K(1000.);
+    nrand = nrand + 3;
+  } else {
+    if (nrand > ORC_MAXRAND) nrand = 1;
+    ux = K(0.);
+    vy = K(0.);
+    wpscale = r_sqrt(K(2.) * c->d_strat / dt);
+    *wp = c->rannumb[nrand] * wpscale;
+    nrand = nrand + 1;
+  }
+
+  /* :686-699 */
+  orc_add_settling(c, itime, *xt, *yt, *zt);
+
+  /* :705-708 */
+  dxsave = dxsave + (c->u + ux) * dt;
+  dysave = dysave + (c->v + vy) * dt;
+  *zt = *zt + (c->w + *wp) * dt * (real)c->ldirect;
+  if (*zt < K(0.)) *zt = r_min(c->h - eps2, K(-1.) * *zt);
+
+L99:
+  /* :728-739 mesoscale fluctuations */
+  r = r_exp(K(-2.) * (real)abs(c->lsynctime) / (real)c->lwindinterv);
+  rs = r_sqrt(K(1.) - r * r);
+  if (nrand + 2 > ORC_MAXRAND) nrand = 1;
+  *usigold = r * *usigold + rs * c->rannumb[nrand] * c->usig * c->turbmesoscale;
+  *vsigold = r * *vsigold + rs * c->rannumb[nrand + 1] * c->vsig * c->turbmesoscale;
+  *wsigold = r * *wsigold + rs * c->rannumb[nrand + 2] * c->wsig * c->turbmesoscale;
+  dxsave = dxsave + *usigold * (real)c->lsynctime;
+  dysave = dysave + *vsigold * (real)c->lsynctime;
+  *zt = *zt + *wsigold * (real)c->lsynctime;
+  if (*zt < K(0.)) *zt = K(-1.) * *zt;
+
+  /* :747-778 */
+  orc_windalign(dxsave, dysave, dawsave, dcwsave, &ux, &vy);
+  dxsave = dxsave + ux;
+  dysave = dysave + vy;
+  orc_move(c, xt, yt, dxsave, dysave, (real)c->ldirect);
+
+  /* :784-813 */
+  if (orc_boundary(c, xt, yt, zt, eps)) return 3;
+
+  /* :829-857 Petterssen gates */
+  if (*ldt != abs(c->lsynctime)) return 0;
+  if (abs(itime + *ldt * c->ldirect) > abs(c->memtime[1])) return 0;
+  ngr = orc_pick_grid(c, *xt, *yt, eps);
+  if (ngr != c->ngrid) return 0;
+
+  /* :862-872 */
+  if (c->ngrid > 0) {
+    xtn = (*xt - (double)c->xln[c->ngrid - 1]) * (double)c->xresoln[c->ngrid - 1];
+    ytn = (*yt - (double)c->yln[c->ngrid - 1]) * (double)c->yresoln[c->ngrid - 1];
+    c->ix = (int)xtn; c->jy = (int)ytn;
+  } else {
+    c->ix = (int)*xt; c->jy = (int)*yt;
+  }
+  c->ixp = c->ix + 1;
+  c->jyp = c->jy + 1;
+
+  /* :878-891 */
+  uold = c->u; vold = c->v; wold = c->w;
+  xts = (real)*xt;
+  yts = (real)*yt;
+  orc_interpol_wind(c, itime + *ldt * c->ldirect, xts, yts, *zt, 0);
+
+  /* :893-906 */
+  orc_add_settling(c, itime + *ldt, *xt, *yt, *zt);
+
+  /* :913-951 */
+  c->u = (c->u - uold) / K(2.);
+  c->v = (c->v - vold) / K(2.);
+  c->w = (c->w - wold) / K(2.);
+  *zt = *zt + c->w * (real)(*ldt * c->ldirect);
+  if (*zt < K(0.)) *zt = r_min(c->h - eps2, K(-1.) * *zt);
+  orc_move(c, xt, yt, c->u, c->v, (real)(*ldt * c->ldirect));
+
+  /* :956-985 */
+  if (orc_boundary(c, xt, yt, zt, eps)) return 3;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* public C entry points (ctypes)                                              */
+/* ------------------------------------------------------------------------- */
+orc_ctx *orc_create(void) {
+  orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
+  c->idummy_init = -7;
+  c->idummy_adv = -7;
+  c->ldirect = 1;
+  c->npart_rel = 1;
+  c->lage_last = 999999999;
+  orc_fill_rannumb(c);
+  return c;
+}
+void orc_destroy(orc_ctx *c) { free(c); }
+int orc_real_size(void) { return (int)sizeof(real); }
+const real *orc_rannumb(orc_ctx *c) { return &c->rannumb[1]; }
+
+void orc_set_grid(orc_ctx *c, int nx, int ny, int nz, double dx, double dy, double xlon0, double ylat0,
+                  int xglobal, int nglobal, int sglobal, const double *height, int nmixz) {
+  int k;
+  const real r_earth = K(6.371e6);
+  c->nx = nx; c->ny = ny; c->nz = nz; c->nxmin1 = nx - 1; c->nymin1 = ny - 1; c->nmixz = nmixz;
+  c->dx = (real)dx; c->dy = (real)dy; c->xlon0 = (real)xlon0; c->ylat0 = (real)ylat0;
+  c->dxconst = K(180.) / (c->dx * r_earth * PI_PAR);   /* gridcheck_ecmwf.f90:311-312 */
+  c->dyconst = K(180.) / (c->dy * r_earth * PI_PAR);
+  c->xglobal = xglobal; c->nglobal = nglobal; c->sglobal = sglobal;
+  c->switchnorthg = nglobal ? (K(75.) - c->ylat0) / c->dy : K(999999.);   /* gridcheck_ecmwf.f90:348,362 */
+  c->switchsouthg = sglobal ? (K(-75.) - c->ylat0) / c->dy : K(999999.);
+  for (k = 0; k < nz; k++) c->height[k] = (real)height[k];
+}
+void orc_set_polemaps(orc_ctx *c, const double *north, const double *south) {
+  int i;
+  for (i = 0; i < 9; i++) { c->northpolemap[i] = (real)north[i]; c->southpolemap[i] = (real)south[i]; }
+}
+void orc_set_time(orc_ctx *c, int memtime1, int memtime2, int memind1, int memind2) {
+  c->memtime[0] = memtime1; c->memtime[1] = memtime2; c->memind[0] = memind1; c->memind[1] = memind2;
+  c->lwindinterv = abs(memtime2 - memtime1);
+}
+void orc_set_switches(orc_ctx *c, int ldirect, int lsynctime, int method, int mintime, double ctl, int ifine,
+                      int turbswitch, int cblflag, int mdomainfill, int lsettling, int nspec, int drydep,
+                      const int *drydepspec, double d_trop, double d_strat, double turbmesoscale) {
+  int i;
+  c->ldirect = ldirect; c->lsynctime = lsynctime; c->method = method; c->mintime = mintime;
+  c->ctl = (real)ctl; c->ifine = ifine; c->fine = K(1.) / (real)ifine;
+  c->turbswitch = turbswitch; c->cblflag = cblflag; c->mdomainfill = mdomainfill; c->lsettling = lsettling;
+  c->nspec = nspec; c->drydep = drydep;
+  for (i = 0; i < nspec && i < ORC_MAXSPEC; i++) c->drydepspec[i] = drydepspec ? drydepspec[i] : 0;
+  c->d_trop = (real)d_trop; c->d_strat = (real)d_strat; c->turbmesoscale = (real)turbmesoscale;
+}
+void orc_set_species(orc_ctx *c, const double *density, const double *dquer, const double *vsetaver,
+                     const double *cunningham, const double *decay, const double *xmass_rel, int npart_rel, int lage_last) {
+  int i;
+  for (i = 0; i < c->nspec && i < ORC_MAXSPEC; i++) {
+    c->density[i] = (real)density[i]; c->dquer[i] = (real)dquer[i]; c->vsetaver[i] = (real)vsetaver[i];
+    c->cunningham[i] = (real)cunningham[i]; c->decay[i] = (real)decay[i]; c->xmass_rel[i] = (real)xmass_rel[i];
+  }
+  c->npart_rel = npart_rel; c->lage_last = lage_last;
+}
+/* field pointers (arrays stay owned by the caller, in the oracle's precision) */
+void orc_set_fields(orc_ctx *c, const real *uu, const real *vv, const real *ww, const real *rho, const real *drhodz,
+                    const real *tt, const real *uupol, const real *vvpol, const real *hmix, const real *ustar,
+                    const real *wstar, const real *oli, const real *tropopause, const real *vdep) {
+  c->uu = uu; c->vv = vv; c->ww = ww; c->rho = rho; c->drhodz = drhodz; c->tt = tt; c->uupol = uupol; c->vvpol = vvpol;
+  c->hmix = hmix; c->ustar = ustar; c->wstar = wstar; c->oli = oli; c->tropopause = tropopause; c->vdep = vdep;
+}
+
+/* One synchronisation step over all particles in index order: the particle
+   loop of timemanager.f90:531-712 (initialize if new :553-555, advance :609-611,
+   epilogue :630-708 without the deposition-grid kernels).  prob_out (npart*nspec,
+   species-major) receives advance's dry-deposition probabilities or may be NULL. */
+long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, real *ztra1,
+              real *uap, real *ucp, real *uzp, real *us, real *vs, real *ws,
+              int *idt, int *itra1, const int *itramem, const int *npoint, int16_t *cbt,
+              real *xmass1, real *prob_out) {
+  const real minmass = K(0.0001);
+  long nadv = 0;
+  int j, ks, nstop;
+  real prob[ORC_MAXSPEC];
+  for (j = 0; j < npart; j++) {
+    if (itra1[j] != itime) continue;
+    if (itramem[j] == itime || itime == 0)
+      orc_initialize(c, itime, &idt[j], &uap[j], &ucp[j], &uzp[j], &us[j], &vs[j], &ws[j], xtra1[j], ytra1[j], ztra1[j], &cbt[j]);
+    for (ks = 0; ks < ORC_MAXSPEC; ks++) prob[ks] = K(0.);
+    nstop = orc_advance(c, itime, npoint ? npoint[j] : 1, &idt[j], &uap[j], &ucp[j], &uzp[j], &us[j], &vs[j], &ws[j],
+                        &xtra1[j], &ytra1[j], &ztra1[j], prob, &cbt[j]);
+    nadv++;
+    if (prob_out)
+      for (ks = 0; ks < c->nspec; ks++) prob_out[(size_t)ks * npart + j] = prob[ks];
+    if (nstop > 1) {
+      itra1[j] = -999999999;
+    } else {
+      real xmassfract = K(0.), decfact;
+      itra1[j] = itime + c->lsynctime;
+      for (ks = 0; ks < c->nspec; ks++) {
+        if (c->decay[ks] > K(0.)) decfact = r_exp(-(real)abs(c->lsynctime) * c->decay[ks]);
+        else decfact = K(1.);
+        if (xmass1) {
+          if (c->drydepspec[ks]) xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * (K(1.) - prob[ks]) * decfact;
+          else xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * decfact;
+          if (c->mdomainfill == 0) {
+            if (c->xmass_rel[ks] > K(0.)) xmassfract = r_max(xmassfract, (real)c->npart_rel * xmass1[(size_t)ks * npart + j] / c->xmass_rel[ks]);
+          } else xmassfract = K(1.0);
+        } else xmassfract = K(1.0);
+      }
+      if (xmassfract < minmass) itra1[j] = -999999999;
+      if (abs(itra1[j] - itramem[j]) >= c->lage_last) itra1[j] = -999999999;
+    }
+  }
+  return nadv;
+}
+
+long orc_nan_count(orc_ctx *c, int which) { return which == 2 ? c->nan_count2 : c->nan_count; }
+
+/* expose the shared ran3 stream (tests of the host-side replica in the product) */
+double orc_ran3_next(orc_ctx *c, int *idum) { return (double)orc_ran3(c, idum); }
+void orc_reset_rng(orc_ctx *c) { c->ran3_iff = 0; c->idummy_init = -7; c->idummy_adv = -7; c->gasdev_iset = 0; c->gasdev_gset = 0; }

@@ -1,0 +1,153 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes front end of the CPU oracle (oracle/flexpart_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module; nothing under flexpart_amd/ does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def build(force=False):
+    """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
+    src = os.path.join(HERE, "flexpart_oracle.c")
+    for kind, real in (("r4", "float"), ("r8", "double")):
+        out = os.path.join(HERE, f"liboracle_{kind}.so")
+        if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
+                                   f"-DORC_REAL={real}", src, "-o", out, "-lm"])
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+class Oracle:
+    """The reference's serial particle loop, restated in C, driven from a scenario dict."""
+
+    def __init__(self, sc, kind="r8"):
+        build()
+        self.kind = kind
+        self.rt = np.float32 if kind == "r4" else np.float64
+        lib = C.CDLL(os.path.join(HERE, f"liboracle_{kind}.so"))
+        self.lib = lib
+        lib.orc_create.restype = C.c_void_p
+        lib.orc_rannumb.restype = C.c_void_p
+        lib.orc_step.restype = C.c_long
+        lib.orc_nan_count.restype = C.c_long
+        lib.orc_ran3_next.restype = C.c_double
+        self.h = C.c_void_p(lib.orc_create())
+        assert lib.orc_real_size() == np.dtype(self.rt).itemsize
+        self.sc = sc
+        nx, ny, nz = (int(v) for v in sc["grid"])
+        dx, dy, xlon0, ylat0 = (float(v) for v in sc["geom"])
+        xg, ng, sg = (int(v) for v in sc["globalflags"])
+        hgt = _f64(sc["height"])
+        dp = C.POINTER(C.c_double)
+        lib.orc_set_grid(self.h, nx, ny, nz, C.c_double(dx), C.c_double(dy), C.c_double(xlon0),
+                         C.c_double(ylat0), xg, ng, sg, hgt.ctypes.data_as(dp), int(sc["nmixz"]))
+        if "northpolemap" in sc:
+            n = _f64(sc["northpolemap"]); s = _f64(sc["southpolemap"])
+            lib.orc_set_polemaps(self.h, n.ctypes.data_as(dp), s.ctypes.data_as(dp))
+        mt = sc["memtime"]; mi = sc["memind"]
+        lib.orc_set_time(self.h, int(mt[0]), int(mt[1]), int(mi[0]), int(mi[1]))
+        nspec = int(sc["nspec"])
+        dds = np.ascontiguousarray(np.asarray(sc["drydepspec"], dtype=np.int32))
+        tp = sc["turbpar"]
+        lib.orc_set_switches(self.h, int(sc["ldirect"]), int(sc["lsynctime"]), int(sc["method"]),
+                             int(sc["mintime"]), C.c_double(float(sc["ctl"])), int(sc["ifine"]),
+                             int(sc["turbswitch"]), int(sc["cblflag"]), int(sc["mdomainfill"]),
+                             int(sc["lsettling"]), nspec, int(sc["drydep"]),
+                             dds.ctypes.data_as(C.POINTER(C.c_int)), C.c_double(float(tp[0])),
+                             C.c_double(float(tp[1])), C.c_double(float(tp[2])))
+        arrs = [_f64(sc[k]) for k in ("density", "dquer", "vsetaver", "cunningham", "decay")]
+        xm = _f64(sc.get("xmass", np.ones(nspec)))
+        lib.orc_set_species(self.h, *[a.ctypes.data_as(dp) for a in arrs], xm.ctypes.data_as(dp),
+                            int(sc["npart"]), int(np.asarray(sc["lage"]).ravel()[-1]))
+        # fields in the oracle's precision (kept alive on self)
+        self.f = {}
+        ptrs = []
+        for k in ("uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol", "hmix", "ustar",
+                  "wstar", "oli", "tropopause", "vdep"):
+            if k in sc:
+                self.f[k] = np.ascontiguousarray(np.asarray(sc[k]).astype(self.rt))
+                ptrs.append(self.f[k].ctypes.data_as(C.c_void_p))
+            else:
+                ptrs.append(C.c_void_p(0))
+        lib.orc_set_fields(self.h, *ptrs)
+        # particle state
+        n = int(sc["npart"])
+        self.n = n
+        self.nspec = nspec
+        self.x = _f64(sc["xtra1"]).copy()
+        self.y = _f64(sc["ytra1"]).copy()
+        self.z = np.asarray(sc["ztra1"]).astype(self.rt)
+
+        def opt(name, dtype, fill=0):
+            if name in sc:
+                return np.ascontiguousarray(np.asarray(sc[name]).astype(dtype))
+            return np.full(n, fill, dtype)
+        self.uap = opt("uap", self.rt); self.ucp = opt("ucp", self.rt); self.uzp = opt("uzp", self.rt)
+        self.us = opt("us", self.rt); self.vs = opt("vs", self.rt); self.ws = opt("ws", self.rt)
+        self.idt = opt("idt", np.int32); self.itra1 = opt("itra1", np.int32)
+        self.itramem = opt("itramem", np.int32); self.npoint = opt("npoint", np.int32, 1)
+        self.cbt = opt("cbt", np.int16, 1)
+        self.xmass1 = np.ascontiguousarray(np.asarray(sc["xmass1"]).astype(self.rt).reshape(nspec, n))
+        self.prob = np.zeros((nspec, n), self.rt)
+        self.itime = int(sc["itime0"])
+
+    def rannumb(self):
+        p = self.lib.orc_rannumb(self.h)
+        ct = C.c_float if self.kind == "r4" else C.c_double
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(1000000,)).copy()
+
+    def step(self):
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        nadv = self.lib.orc_step(self.h, self.itime, self.n, vp(self.x), vp(self.y), vp(self.z),
+                                 vp(self.uap), vp(self.ucp), vp(self.uzp), vp(self.us), vp(self.vs),
+                                 vp(self.ws), vp(self.idt), vp(self.itra1), vp(self.itramem),
+                                 vp(self.npoint), vp(self.cbt), vp(self.xmass1), vp(self.prob))
+        self.itime += int(self.sc["lsynctime"])
+        return nadv
+
+    def state(self):
+        return dict(xtra1=self.x.copy(), ytra1=self.y.copy(), ztra1=self.z.astype(np.float64),
+                    uap=self.uap.astype(np.float64), ucp=self.ucp.astype(np.float64),
+                    uzp=self.uzp.astype(np.float64), us=self.us.astype(np.float64),
+                    vs=self.vs.astype(np.float64), ws=self.ws.astype(np.float64),
+                    idt=self.idt.copy(), itra1=self.itra1.copy(), cbt=self.cbt.astype(np.int32),
+                    xmass1=self.xmass1.astype(np.float64), prob=self.prob.astype(np.float64))
+
+    def run(self, nsteps=None):
+        out = []
+        for _ in range(int(self.sc["nsteps"]) if nsteps is None else nsteps):
+            self.step()
+            out.append(self.state())
+        return out
+
+    def nan_counts(self):
+        return self.lib.orc_nan_count(self.h, 1), self.lib.orc_nan_count(self.h, 2)
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+
+def compare(a, b, keys=("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws")):
+    """-> dict key -> (max abs diff, max rel-to-range diff), plus integer mismatches."""
+    rep = {}
+    for k in keys:
+        d = np.abs(np.asarray(a[k], np.float64) - np.asarray(b[k], np.float64))
+        scale = max(float(np.max(np.abs(b[k]))), 1e-30)
+        rep[k] = (float(d.max()), float(d.max() / scale))
+    for k in ("idt", "itra1", "cbt"):
+        rep[k] = int(np.count_nonzero(np.asarray(a[k]) != np.asarray(b[k])))
+    return rep

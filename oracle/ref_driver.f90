@@ -1,0 +1,372 @@
+! TEST INFRASTRUCTURE ONLY -- never linked into or called by the product path.
+!
+! ref_driver: drives the *unmodified* reference FLEXPART hot path
+! (initialize.f90 / advance.f90 and their helpers, compiled where they lie
+! under /root/reference/src by oracle/build_ref.sh) from a scenario file, in
+! exactly the order of the reference's serial particle loop
+! (timemanager.f90:531-712), and dumps the particle SoA after every
+! synchronisation step.  This file is our own code: it contains no reference
+! source, only calls into it and assignments to its module variables.
+!
+! Usage:  flexref_rK scenario.bin out.bin [timing]
+!
+! Scenario file = sequence of records {name*16, dtype i4 (1=i32, 2=f64),
+! count i8, payload}, terminated by name 'END'.  All reals travel as f64 and
+! are converted to this build's default real kind (4 or 8) on assignment.
+
+module drv_io
+  implicit none
+  integer, parameter :: uin=31, uout=32
+contains
+  subroutine put_i(name, a, n)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: n
+    integer, intent(in) :: a(n)
+    character(len=16) :: nm
+    nm = name
+    write(uout) nm, 1_4, int(n,8), a(1:n)
+  end subroutine put_i
+  subroutine put_d(name, a, n)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: n
+    real(kind=8), intent(in) :: a(n)
+    character(len=16) :: nm
+    nm = name
+    write(uout) nm, 2_4, int(n,8), a(1:n)
+  end subroutine put_d
+end module drv_io
+
+program flexref
+  use par_mod
+  use com_mod
+  use point_mod
+  use interpol_mod
+  use hanna_mod
+  use cmapf_mod
+  use random_mod
+  use unc_mod
+  use outg_mod
+  use drv_io
+  implicit none
+
+  character(len=512) :: fscen, fout, arg3
+  character(len=16) :: name
+  integer(kind=4) :: dtype
+  integer(kind=8) :: cnt
+  integer, allocatable :: ibuf(:)
+  real(kind=8), allocatable :: dbuf(:)
+  integer :: ios, i, j, k, m, ks, n, idummy, istep, nsteps, itime0, itime
+  integer :: npart_in, gnx, gny, gnz, nstop, timing, do_conc, nage, kp
+  integer :: ldeltat, loutnext_d, itage
+  integer(kind=8) :: c0, c1, crate, nadv
+  real :: prob(maxspec), drydeposit(maxspec), decfact, xmassfract, weight
+  real :: sizenorth, sizesouth
+  real(kind=8), allocatable :: tmp(:)
+  logical :: have_pol, do_polar_setup
+  real(kind=8) :: tsec
+
+  call get_command_argument(1, fscen)
+  call get_command_argument(2, fout)
+  timing = 0
+  if (command_argument_count() .ge. 3) then
+    call get_command_argument(3, arg3)
+    if (trim(arg3) .eq. 'timing') timing = 1
+  end if
+
+  ! Random number table exactly as the reference main program fills it
+  ! (call sequence of /root/reference/src/FLEXPART.f90:47,56-59).
+  idummy = -320
+  do i=1,maxrand-1,2
+    call gasdev1(idummy,rannumb(i),rannumb(i+1))
+  end do
+  call gasdev1(idummy,rannumb(maxrand),rannumb(maxrand-1))
+
+  ! ---- defaults ----------------------------------------------------------
+  ipout=0; ldirect=1; lsynctime=900; method=1; mintime=1; ctl=0.2; ifine=4
+  fine=0.25; turbswitch=.true.; cblflag=0; mdomainfill=0; mquasilag=0
+  lsettling=.false.; nspec=1; maxpointspec_act=1
+  DRYDEP=.false.; WETDEP=.false.; DRYBKDEP=.false.; WETBKDEP=.false.
+  DRYDEPSPEC(:)=.false.; WETDEPSPEC(:)=.false.
+  density(:)=0.; decay(:)=0.; dquer(:)=0.; vsetaver(:)=0.; cunningham(:)=1.
+  numbnests=0; nageclass=1; lage(1)=999999999
+  ioutputforeachrelease=0; nested_output=0; linit_cond=0; ind_samp=0
+  xglobal=.false.; nglobal=.false.; sglobal=.false.
+  switchnorthg=999999.; switchsouthg=999999.
+  nsteps=1; itime0=0; nan_count=0; nan_count2=0
+  memind(1)=1; memind(2)=2; memind(3)=3
+  numpoint=1; have_pol=.false.; do_polar_setup=.false.; do_conc=0
+  numreceptor=0; loutnext_d=0
+  gnx=0; gny=0; gnz=0; npart_in=0
+
+  open(uin, file=trim(fscen), access='stream', form='unformatted', status='old')
+  do
+    read(uin, iostat=ios) name, dtype, cnt
+    if (ios .ne. 0) exit
+    if (trim(name) .eq. 'END') exit
+    n = int(cnt)
+    if (dtype .eq. 1) then
+      if (allocated(ibuf)) deallocate(ibuf)
+      allocate(ibuf(n)); read(uin) ibuf
+    else
+      if (allocated(dbuf)) deallocate(dbuf)
+      allocate(dbuf(n)); read(uin) dbuf
+    end if
+    select case (trim(name))
+    ! --- grid --------------------------------------------------------------
+    case ('grid')      ! nx ny nz
+      gnx=ibuf(1); gny=ibuf(2); gnz=ibuf(3)
+      if (gnx.gt.nxmax .or. gny.gt.nymax .or. gnz.gt.nzmax) stop 'grid too large'
+      nx=gnx; ny=gny; nz=gnz; nuvz=gnz; nwz=gnz; nxfield=gnx
+      nxmin1=nx-1; nymin1=ny-1
+    case ('geom')      ! dx dy xlon0 ylat0
+      dx=dbuf(1); dy=dbuf(2); xlon0=dbuf(3); ylat0=dbuf(4)
+      ! as /root/reference/src/gridcheck_ecmwf.f90:311-312
+      dxconst=180./(dx*r_earth*pi)
+      dyconst=180./(dy*r_earth*pi)
+    case ('globalflags') ! xglobal nglobal sglobal
+      xglobal=(ibuf(1).ne.0); nglobal=(ibuf(2).ne.0); sglobal=(ibuf(3).ne.0)
+      do_polar_setup = nglobal .or. sglobal
+    case ('height');   height(1:n)=dbuf(1:n)
+    case ('nmixz');    nmixz=ibuf(1)
+    case ('memtime');  memtime(1)=ibuf(1); memtime(2)=ibuf(2)
+      lwindinterv=abs(memtime(2)-memtime(1))
+    case ('memind');   memind(1)=ibuf(1); memind(2)=ibuf(2)
+    ! --- run switches --------------------------------------------------------
+    case ('ldirect');  ldirect=ibuf(1)
+    case ('lsynctime'); lsynctime=ibuf(1)
+    case ('method');   method=ibuf(1)
+    case ('mintime');  mintime=ibuf(1)
+    case ('ctl');      ctl=dbuf(1)
+    case ('ifine');    ifine=ibuf(1); fine=1./real(ifine)
+    case ('turbswitch'); turbswitch=(ibuf(1).ne.0)
+    case ('cblflag');  cblflag=ibuf(1)
+    case ('mdomainfill'); mdomainfill=ibuf(1)
+    case ('lsettling'); lsettling=(ibuf(1).ne.0)
+    case ('nspec');    nspec=ibuf(1)
+    case ('drydep');   DRYDEP=(ibuf(1).ne.0)
+    case ('drydepspec'); do i=1,n; DRYDEPSPEC(i)=(ibuf(i).ne.0); end do
+    case ('density');  density(1:n)=dbuf(1:n)
+    case ('dquer');    dquer(1:n)=dbuf(1:n)
+    case ('vsetaver'); vsetaver(1:n)=dbuf(1:n)
+    case ('cunningham'); cunningham(1:n)=dbuf(1:n)
+    case ('decay');    decay(1:n)=dbuf(1:n)
+    case ('turbpar')   ! d_trop d_strat turbmesoscale
+      d_trop=dbuf(1); d_strat=dbuf(2); turbmesoscale=dbuf(3)
+    case ('lage');     nageclass=n; lage(1:n)=ibuf(1:n)
+    case ('nsteps');   nsteps=ibuf(1)
+    case ('itime0');   itime0=ibuf(1)
+    ! --- 3-D fields: compact (nx,ny,nz,2), x fastest -------------------------
+    case ('uu');     call fill3(uu, dbuf)
+    case ('vv');     call fill3(vv, dbuf)
+    case ('ww');     call fill3(ww, dbuf)
+    case ('rho');    call fill3(rho, dbuf)
+    case ('drhodz'); call fill3(drhodz, dbuf)
+    case ('tt');     call fill3(tt, dbuf)
+    case ('uupol');  call fill3(uupol, dbuf); have_pol=.true.
+    case ('vvpol');  call fill3(vvpol, dbuf); have_pol=.true.
+    ! --- 2-D fields: compact (nx,ny,2) -----------------------------------------
+    case ('hmix');   call fill2(hmix, dbuf)
+    case ('ustar');  call fill2(ustar, dbuf)
+    case ('wstar');  call fill2(wstar, dbuf)
+    case ('oli');    call fill2(oli, dbuf)
+    case ('tropopause'); call fill2(tropopause, dbuf)
+    case ('vdep')    ! compact (nx,ny,nspec,2)
+      do m=1,2
+        do ks=1,nspec
+          do j=0,gny-1
+            do i=0,gnx-1
+              vdep(i,j,ks,m)=dbuf(1+i+gnx*(j+gny*((ks-1)+nspec*(m-1))))
+            end do
+          end do
+        end do
+      end do
+    ! --- particles -------------------------------------------------------------
+    case ('npart')
+      npart_in=ibuf(1); numpart=npart_in
+      call com_mod_allocate_part(npart_in)
+      allocate(xmass(numpoint,maxspec), npart(numpoint))
+      xmass(:,:)=1.; npart(:)=npart_in
+      itra1(:)=-999999999; npoint(:)=1; nclass(:)=1; idt(:)=0; itramem(:)=0
+      itrasplit(:)=999999999; xmass1(:,:)=0.
+      uap(:)=0.; ucp(:)=0.; uzp(:)=0.; us(:)=0.; vs(:)=0.; ws(:)=0.; cbt(:)=1
+    case ('xtra1');   xtra1(1:n)=dbuf(1:n)
+    case ('ytra1');   ytra1(1:n)=dbuf(1:n)
+    case ('ztra1');   ztra1(1:n)=dbuf(1:n)
+    case ('itra1');   itra1(1:n)=ibuf(1:n)
+    case ('itramem'); itramem(1:n)=ibuf(1:n)
+    case ('npoint');  npoint(1:n)=ibuf(1:n)
+    case ('nclass');  nclass(1:n)=ibuf(1:n)
+    case ('idt');     idt(1:n)=ibuf(1:n)
+    case ('uap');     uap(1:n)=dbuf(1:n)
+    case ('ucp');     ucp(1:n)=dbuf(1:n)
+    case ('uzp');     uzp(1:n)=dbuf(1:n)
+    case ('us');      us(1:n)=dbuf(1:n)
+    case ('vs');      vs(1:n)=dbuf(1:n)
+    case ('ws');      ws(1:n)=dbuf(1:n)
+    case ('cbt');     do i=1,n; cbt(i)=int(ibuf(i),2); end do
+    case ('xmass1')   ! (npart, nspec) species-major
+      do ks=1,nspec
+        xmass1(1:npart_in,ks)=dbuf(1+(ks-1)*npart_in:ks*npart_in)
+      end do
+    case ('xmass')    ! release mass per species (point 1)
+      xmass(1,1:n)=dbuf(1:n)
+    case default
+      write(*,*) 'ref_driver: unknown record ', trim(name)
+      stop 1
+    end select
+  end do
+  close(uin)
+
+  ! Polar stereographic maps as the reference sets them up
+  ! (call sequence of /root/reference/src/gridcheck_ecmwf.f90:341-366).
+  if (sglobal) then
+    sizesouth=6.*(switchsouth+90.)/dy
+    call stlmbr(southpolemap,-90.,0.)
+    call stcm2p(southpolemap,0.,0.,switchsouth,0.,sizesouth,sizesouth,switchsouth,180.)
+    switchsouthg=(switchsouth-ylat0)/dy
+  end if
+  if (nglobal) then
+    sizenorth=6.*(90.-switchnorth)/dy
+    call stlmbr(northpolemap,90.,0.)
+    call stcm2p(northpolemap,0.,0.,switchnorth,0.,sizenorth,sizenorth,switchnorth,180.)
+    switchnorthg=(switchnorth-ylat0)/dy
+  end if
+
+  open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')
+  allocate(tmp(max(npart_in,maxrand)))
+
+  if (timing .eq. 0) then
+    tmp(1:maxrand)=rannumb(1:maxrand)
+    call put_d('rannumb', tmp, maxrand)
+    tmp(1:9)=northpolemap(1:9); call put_d('northpolemap', tmp, 9)
+    tmp(1:9)=southpolemap(1:9); call put_d('southpolemap', tmp, 9)
+    tmp(1)=switchnorthg; tmp(2)=switchsouthg; tmp(3)=dxconst; tmp(4)=dyconst
+    call put_d('derived', tmp, 4)
+  end if
+
+  ! ---- the particle loop, in the order of timemanager.f90:531-712 ---------
+  nadv=0
+  call system_clock(c0, crate)
+  do istep=0,nsteps-1
+    itime=itime0+istep*lsynctime
+    ldeltat=0
+    do j=1,numpart
+      if (itra1(j).eq.itime) then
+        kp=1
+        itage=abs(itra1(j)-itramem(j))
+        do nage=1,nageclass
+          if (itage.lt.lage(nage)) exit
+        end do
+        if ((itramem(j).eq.itime).or.(itime.eq.0)) &
+             call initialize(itime,idt(j),uap(j),ucp(j),uzp(j), &
+             us(j),vs(j),ws(j),xtra1(j),ytra1(j),ztra1(j),cbt(j))
+        call advance(itime,npoint(j),idt(j),uap(j),ucp(j),uzp(j), &
+             us(j),vs(j),ws(j),nstop,xtra1(j),ytra1(j),ztra1(j),prob, &
+             cbt(j))
+        nadv=nadv+1
+        ! epilogue: our restatement of timemanager.f90:630-708 (mass update,
+        ! minmass and age termination); the deposition-grid kernels are driven
+        ! separately.
+        if (nstop.gt.1) then
+          itra1(j)=-999999999
+        else
+          itra1(j)=itime+lsynctime
+          xmassfract=0.
+          do ks=1,nspec
+            if (decay(ks).gt.0.) then
+              decfact=exp(-real(abs(lsynctime))*decay(ks))
+            else
+              decfact=1.
+            endif
+            if (DRYDEPSPEC(ks)) then
+              drydeposit(ks)=xmass1(j,ks)*prob(ks)*decfact
+              xmass1(j,ks)=xmass1(j,ks)*(1.-prob(ks))*decfact
+              if (decay(ks).gt.0.) then
+                drydeposit(ks)=drydeposit(ks)*exp(real(abs(ldeltat))*decay(ks))
+              endif
+            else
+              xmass1(j,ks)=xmass1(j,ks)*decfact
+            endif
+            if (mdomainfill.eq.0.and.mquasilag.eq.0) then
+              if (xmass(npoint(j),ks).gt.0.) &
+                   xmassfract=max(xmassfract,real(npart(npoint(j)))* &
+                   xmass1(j,ks)/xmass(npoint(j),ks))
+            else
+              xmassfract=1.0
+            end if
+          end do
+          if (xmassfract.lt.minmass) itra1(j)=-999999999
+          if (abs(itra1(j)-itramem(j)).ge.lage(nageclass)) itra1(j)=-999999999
+        endif
+      endif
+    end do
+    if (timing .eq. 0) call dump_state()
+  end do
+  call system_clock(c1)
+  tsec = real(c1-c0,8)/real(crate,8)
+
+  tmp(1)=tsec; tmp(2)=real(nadv,8); tmp(3)=real(nan_count,8); tmp(4)=real(nan_count2,8)
+  call put_d('timing', tmp, 4)
+  name='END'
+  write(uout) name, 1_4, 0_8
+  close(uout)
+  write(*,'(a,f10.4,a,i12,a,es12.4)') 'ref_driver: particle loop ', tsec, ' s, ', nadv, &
+       ' advance calls, particle-steps/s = ', real(nadv,8)/max(tsec,1d-9)
+
+contains
+
+  subroutine fill3(f, b)
+    real, intent(inout) :: f(0:nxmax-1,0:nymax-1,nzmax,numwfmem)
+    real(kind=8), intent(in) :: b(*)
+    integer :: ii,jj,kk,mm
+    do mm=1,2
+      do kk=1,gnz
+        do jj=0,gny-1
+          do ii=0,gnx-1
+            f(ii,jj,kk,mm)=b(1+ii+gnx*(jj+gny*((kk-1)+gnz*(mm-1))))
+          end do
+        end do
+      end do
+    end do
+  end subroutine fill3
+
+  subroutine fill2(f, b)
+    real, intent(inout) :: f(0:nxmax-1,0:nymax-1,1,numwfmem)
+    real(kind=8), intent(in) :: b(*)
+    integer :: ii,jj,mm
+    do mm=1,2
+      do jj=0,gny-1
+        do ii=0,gnx-1
+          f(ii,jj,1,mm)=b(1+ii+gnx*(jj+gny*(mm-1)))
+        end do
+      end do
+    end do
+  end subroutine fill2
+
+  subroutine dump_state()
+    integer :: np, kk
+    integer, allocatable :: it(:)
+    np=numpart
+    allocate(it(np))
+    tmp(1:np)=xtra1(1:np); call put_d('xtra1', tmp, np)
+    tmp(1:np)=ytra1(1:np); call put_d('ytra1', tmp, np)
+    tmp(1:np)=ztra1(1:np); call put_d('ztra1', tmp, np)
+    tmp(1:np)=uap(1:np);   call put_d('uap', tmp, np)
+    tmp(1:np)=ucp(1:np);   call put_d('ucp', tmp, np)
+    tmp(1:np)=uzp(1:np);   call put_d('uzp', tmp, np)
+    tmp(1:np)=us(1:np);    call put_d('us', tmp, np)
+    tmp(1:np)=vs(1:np);    call put_d('vs', tmp, np)
+    tmp(1:np)=ws(1:np);    call put_d('ws', tmp, np)
+    it(1:np)=idt(1:np);    call put_i('idt', it, np)
+    it(1:np)=itra1(1:np);  call put_i('itra1', it, np)
+    do kk=1,np
+      it(kk)=int(cbt(kk))
+    end do
+    call put_i('cbt', it, np)
+    do kk=1,nspec
+      tmp(1:np)=xmass1(1:np,kk); call put_d('xmass1', tmp, np)
+    end do
+    deallocate(it)
+  end subroutine dump_state
+
+end program flexref

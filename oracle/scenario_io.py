@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE ONLY -- scenario/record files for oracle/_ref/flexref_r{4,8}.
+
+Record stream: {name char[16], dtype int32 (1=int32, 2=float64), count int64,
+payload}, closed by an 'END' record.  Written for / read back from our own
+Fortran driver oracle/ref_driver.f90.
+"""
+from __future__ import annotations
+
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# order matters: 'grid' and 'nspec' before fields, 'npart' before particle arrays
+_ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind", "ldirect",
+          "lsynctime", "method", "mintime", "ctl", "ifine", "turbswitch", "cblflag",
+          "mdomainfill", "lsettling", "nspec", "drydep", "drydepspec", "density", "dquer",
+          "vsetaver", "cunningham", "decay", "turbpar", "lage", "nsteps", "itime0",
+          "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol",
+          "hmix", "ustar", "wstar", "oli", "tropopause", "vdep",
+          "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
+          "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass"]
+_INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
+        "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
+        "drydep", "drydepspec", "lage", "nsteps", "itime0", "npart", "itra1", "itramem",
+        "npoint", "nclass", "idt", "cbt"}
+
+
+def write_scenario(path, sc):
+    with open(path, "wb") as fh:
+        for name in _ORDER:
+            if name not in sc:
+                continue
+            v = sc[name]
+            if name in _INT:
+                a = np.ascontiguousarray(np.asarray(v, dtype=np.int32).ravel())
+                code = 1
+            else:
+                a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel())
+                code = 2
+            fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
+            fh.write(a.tobytes())
+        fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
+    unknown = set(sc) - set(_ORDER)
+    if unknown:
+        raise KeyError(f"scenario keys not understood by the reference driver: {sorted(unknown)}")
+
+
+def read_records(path):
+    """-> list of (name, ndarray) in file order."""
+    out = []
+    with open(path, "rb") as fh:
+        while True:
+            hdr = fh.read(28)
+            if len(hdr) < 28:
+                break
+            name, code, cnt = struct.unpack("<16siq", hdr)
+            name = name.decode().strip()
+            if name == "END":
+                break
+            dt = np.int32 if code == 1 else np.float64
+            a = np.frombuffer(fh.read(cnt * np.dtype(dt).itemsize), dtype=dt).copy()
+            out.append((name, a))
+    return out
+
+
+def ref_binary(kind):
+    return os.path.join(HERE, "_ref", f"flexref_{kind}")
+
+
+def have_ref(kind="r8"):
+    return os.access(ref_binary(kind), os.X_OK)
+
+
+def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen"):
+    """Run the compiled reference on a scenario -> dict(steps=[{...}], rannumb=..., ...)."""
+    os.makedirs(workdir, exist_ok=True)
+    fs = os.path.join(workdir, f"{tag}_{os.getpid()}.scen")
+    fo = os.path.join(workdir, f"{tag}_{os.getpid()}.out")
+    write_scenario(fs, sc)
+    cmd = f"ulimit -s unlimited; exec {ref_binary(kind)} {fs} {fo}" + (" timing" if timing else "")
+    res = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"reference driver failed: {res.stdout}\n{res.stderr}")
+    recs = read_records(fo)
+    os.remove(fs)
+    os.remove(fo)
+    nspec = int(np.asarray(sc.get("nspec", 1)).ravel()[0])
+    out = {"steps": [], "stdout": res.stdout}
+    cur = None
+    for name, a in recs:
+        if name in ("rannumb", "northpolemap", "southpolemap", "derived", "timing"):
+            out[name] = a
+            continue
+        if name == "xtra1":
+            cur = {}
+            out["steps"].append(cur)
+        if name == "xmass1":
+            cur.setdefault("xmass1", []).append(a)
+            if len(cur["xmass1"]) == nspec:
+                cur["xmass1"] = np.stack(cur["xmass1"])
+        else:
+            cur[name] = a
+    return out
