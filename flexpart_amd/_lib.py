@@ -1,0 +1,124 @@
+"""ctypes binding of the C ABI declared in include/flexpart_amd.h.
+
+The shared library is built in-tree by `__graft_entry__.build()` (hipcc,
+gfx950).  There is no CPU fallback: if the library is missing or fails to
+load, importing the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libflexpart_amd.so")
+
+FPX_MAXSPEC = 5
+DEAD = -999999999
+RNG_TABLE_SEQ, RNG_TABLE_COUNTER, RNG_PHILOX = 0, 1, 2
+
+
+class FpxConfig(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32), ("device", C.c_int32),
+        ("compute_real_bytes", C.c_int32), ("host_real_bytes", C.c_int32),
+        ("max_particles", C.c_int64),
+        ("nx", C.c_int32), ("ny", C.c_int32), ("nz", C.c_int32), ("nmixz", C.c_int32),
+        ("nxmax", C.c_int32), ("nymax", C.c_int32), ("nzmax", C.c_int32),
+        ("dx", C.c_double), ("dy", C.c_double), ("xlon0", C.c_double), ("ylat0", C.c_double),
+        ("xglobal", C.c_int32), ("nglobal", C.c_int32), ("sglobal", C.c_int32),
+        ("switchnorthg", C.c_double), ("switchsouthg", C.c_double),
+        ("northpolemap", C.c_double * 9), ("southpolemap", C.c_double * 9),
+        ("ldirect", C.c_int32), ("lsynctime", C.c_int32), ("method", C.c_int32),
+        ("mintime", C.c_int32), ("ifine", C.c_int32), ("turbswitch", C.c_int32),
+        ("cblflag", C.c_int32), ("mdomainfill", C.c_int32), ("lsettling", C.c_int32),
+        ("ctl", C.c_double),
+        ("d_trop", C.c_double), ("d_strat", C.c_double), ("turbmesoscale", C.c_double),
+        ("nspec", C.c_int32), ("maxspec", C.c_int32),
+        ("drydep", C.c_int32), ("drydepspec", C.c_int32 * FPX_MAXSPEC),
+        ("density", C.c_double * FPX_MAXSPEC), ("dquer", C.c_double * FPX_MAXSPEC),
+        ("vsetaver", C.c_double * FPX_MAXSPEC), ("cunningham", C.c_double * FPX_MAXSPEC),
+        ("decay", C.c_double * FPX_MAXSPEC), ("xmass_release", C.c_double * FPX_MAXSPEC),
+        ("npart_release", C.c_int32), ("lage_last", C.c_int32),
+        ("rng_mode", C.c_int32), ("seed", C.c_uint64),
+        ("sort_interval", C.c_int32), ("reserved", C.c_int32 * 7),
+    ]
+
+
+class FpxFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("uu", "vv", "ww", "uupol", "vvpol", "rho", "drhodz", "tt",
+                 "hmix", "ustar", "wstar", "oli", "tropopause", "vdep")]
+
+
+class FpxParticles(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws",
+                 "itra1", "itramem", "idt", "npoint", "nclass", "cbt", "xmass1")] + \
+               [("xmass1_ld", C.c_int64)]
+
+
+class FpxStepStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("n_due", "n_initialized", "n_left_domain", "n_min_mass", "n_max_age",
+                 "nan_count", "nan_count2", "n_bad_position")] + [("kernel_ms", C.c_double)]
+
+
+# every symbol include/flexpart_amd.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_set_height",
+    "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
+    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart",
+    "fpx_step", "fpx_step_async", "fpx_sync", "fpx_kernel_time", "fpx_sort_particles",
+    "fpx_seed_particles", "fpx_stream",
+]
+
+_lib = None
+
+
+def load():
+    """Load libflexpart_amd.so (once).  Raises if the HIP extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "flexpart_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.fpx_last_error.restype = C.c_char_p
+    lib.fpx_stream.restype = vp
+    lib.fpx_stream.argtypes = [vp]
+    lib.fpx_create.argtypes = [C.POINTER(vp), C.POINTER(FpxConfig)]
+    lib.fpx_destroy.argtypes = [vp]
+    lib.fpx_set_height.argtypes = [vp, vp, C.c_int32]
+    lib.fpx_upload_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxFields)]
+    lib.fpx_set_windtime.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.fpx_rng_fill_table.argtypes = [vp]
+    lib.fpx_rng_set_table.argtypes = [vp, vp, C.c_int32]
+    lib.fpx_rng_get_table.argtypes = [vp, vp, C.c_int32]
+    lib.fpx_upload_particles.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(FpxParticles)]
+    lib.fpx_download_particles.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(FpxParticles)]
+    lib.fpx_set_numpart.argtypes = [vp, C.c_int64]
+    lib.fpx_step.argtypes = [vp, C.c_int32, C.POINTER(FpxStepStats)]
+    lib.fpx_step_async.argtypes = [vp, C.c_int32]
+    lib.fpx_sync.argtypes = [vp]
+    lib.fpx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
+    lib.fpx_sort_particles.argtypes = [vp]
+    lib.fpx_seed_particles.argtypes = [vp, C.c_int64, C.c_uint64, C.c_double, C.c_double,
+                                       C.c_double, C.c_int32]
+    _lib = lib
+    return lib
+
+
+class FpxError(RuntimeError):
+    def __init__(self, code, where):
+        msg = load().fpx_last_error()
+        super().__init__(f"{where}: status {code}: {msg.decode() if msg else ''}")
+        self.code = code
+
+
+def check(code, where):
+    if code != 0:
+        raise FpxError(code, where)

@@ -1,0 +1,1277 @@
+// fpx_device.hpp -- per-particle physics of the trajectory step, written for
+// one GPU thread per particle (gfx950).  All state the reference keeps in
+// Fortran module globals (interpol_mod.f90:7-16, hanna_mod.f90:5-6) lives in
+// registers of the owning thread here, so the routine is re-entrant and
+// order-independent.  Reference citations are relative to /root/reference/src.
+//
+// Templated on the arithmetic type R (double: the all-fp64 build of
+// BASELINE.json configs 2-3; float: the reference's own typing, where only the
+// horizontal position is 8-byte).  Constants are written K(x) so that they
+// round like the Fortran literals of a default-real-R build.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fpx {
+
+#define K(x) ((R)(x))
+#define FPX_DEV __device__ __forceinline__
+
+constexpr int kMaxSpec = 5;
+constexpr int kDead = -999999999;
+
+// ---------------------------------------------------------------------------
+// math in R
+// ---------------------------------------------------------------------------
+FPX_DEV float m_exp(float x) { return expf(x); }
+FPX_DEV double m_exp(double x) { return exp(x); }
+FPX_DEV float m_log(float x) { return logf(x); }
+FPX_DEV double m_log(double x) { return log(x); }
+FPX_DEV float m_sqrt(float x) { return sqrtf(x); }
+FPX_DEV double m_sqrt(double x) { return sqrt(x); }
+FPX_DEV float m_sin(float x) { return sinf(x); }
+FPX_DEV double m_sin(double x) { return sin(x); }
+FPX_DEV float m_cos(float x) { return cosf(x); }
+FPX_DEV double m_cos(double x) { return cos(x); }
+FPX_DEV float m_erf(float x) { return erff(x); }
+FPX_DEV double m_erf(double x) { return erf(x); }
+FPX_DEV float m_pow(float x, float y) { return powf(x, y); }
+FPX_DEV double m_pow(double x, double y) { return pow(x, y); }
+FPX_DEV float m_fmod(float x, float y) { return fmodf(x, y); }
+FPX_DEV double m_fmod(double x, double y) { return fmod(x, y); }
+template <typename R> FPX_DEV R m_abs(R x) { return x < 0 ? -x : x; }
+template <typename R> FPX_DEV R m_max(R a, R b) { return a > b ? a : b; }
+template <typename R> FPX_DEV R m_min(R a, R b) { return a < b ? a : b; }
+template <typename R> FPX_DEV R m_sign(R a, R b) { R m = m_abs(a); return (b < 0 || (b == 0 && signbit(b))) ? -m : m; }
+FPX_DEV double d_modulo(double a, double p) { double r = fmod(a, p); if (r != 0.0 && ((r < 0) != (p < 0))) r += p; return r; }
+
+// ---------------------------------------------------------------------------
+// device view of everything the path reads (com_mod / par_mod variables)
+// ---------------------------------------------------------------------------
+template <typename R>
+struct View {
+  // grid, com_mod.f90:298-299,551-560
+  int nx, ny, nz, nxmin1, nymin1, nmixz;
+  R dx, dy, xlon0, ylat0, dxconst, dyconst;
+  int xglobal, nglobal, sglobal;
+  R switchnorthg, switchsouthg;
+  R northpolemap[9], southpolemap[9];
+  // wind-field window, com_mod.f90:276,286
+  int memtime0, memtime1, m1, m2, lwindinterv;   // m1/m2: physical slot (0|1) of memind(1)/(2)
+  // switches
+  int ldirect, lsynctime, method, mintime, ifine, turbswitch, cblflag, mdomainfill, lsettling;
+  int nspec, drydep, drydepspec[kMaxSpec];
+  R ctl, fine, d_trop, d_strat, turbmesoscale;
+  R density[kMaxSpec], dquer[kMaxSpec], vsetaver[kMaxSpec], cunningham[kMaxSpec], decay[kMaxSpec];
+  R xmass_rel[kMaxSpec];
+  int npart_rel, lage_last;
+  // fields, device layout (see DESIGN.md "data layout in HBM"):
+  const R *height;   // [nz]
+  const R *w3;       // [ny][nx][nz][2 slots][3]  (uu, vv, ww)
+  const R *w3pol;    // same with (uupol, vvpol, ww); only when a pole is in the grid
+  const R *r2;       // [ny][nx][nz][2 slots][2]  (rho, drhodz)
+  const R *sfc;      // [ny][nx][2 slots][4]      (ustar, wstar, oli, hmix)
+  const R *hcell;    // [ny][nx]  max of hmix over the cell's 4 corners x 2 slots
+  const R *tropo;    // [ny][nx]  tropopause, literal time slot 1 (advance.f90:253)
+  const R *vdep;     // [ny][nx][2 slots][nspec]
+  const R *rhott;    // [ny][nx][nz][2] (rho, tt) of literal slot 1 (get_settling.f90:83-84)
+  // RNG
+  const R *rannumb;  // [maxrand], 0-based copy of rannumb(1:maxrand)
+  int maxrand, rng_mode;
+  unsigned long long seed;
+};
+
+// particle SoA in HBM (com_mod.f90:678-695), R-typed except the position
+template <typename R>
+struct Parts {
+  double *xt, *yt;
+  R *zt, *up, *vp, *wp, *us, *vs, *ws;
+  int *idt, *itra1, *itramem, *npoint, *nclass;
+  short *cbt;
+  R *xmass1;             // [nspec][cap]
+  unsigned int *pid;     // reference particle number - 1 (stable across locality sorts)
+  long long cap;
+};
+
+// per-step RNG inputs of the TABLE_SEQ (parity) mode, indexed by pid
+struct SeqRng {
+  const int *nrand_adv;    // start index for advance (advance.f90:153)
+  const int *nrand_init;   // start index for initialize (initialize.f90:68); 0 = not initialised
+  const float *cbl_dcas;   // initialize_cbl_vel.f90:75 uniform
+  const float *cbl_dcas1;  // initialize_cbl_vel.f90:78/81 gaussian
+  const double *cbl_dcas_d, *cbl_dcas1_d;  // same in fp64 hosts
+};
+
+struct Stats {
+  unsigned long long n_due, n_init, n_left, n_minmass, n_maxage, nan_count, nan_count2, n_badpos;
+};
+
+// ---------------------------------------------------------------------------
+// counter-based generator: Philox4x32-10 (Salmon et al. 2011), keyed by seed,
+// counter = (particle id, step, draw index)
+// ---------------------------------------------------------------------------
+FPX_DEV void philox4x32(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                        unsigned int k0, unsigned int k1, unsigned int out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    unsigned int n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Gaussian table value source: either the reference's table or its counter twin
+template <typename R>
+struct Rng {
+  const R *tab;
+  int maxrand, mode;
+  unsigned int pid, step, k0, k1;
+  // rannumb(idx), 1-based like the reference
+  FPX_DEV R at(int idx) const {
+    if (mode != 2) return tab[min(idx, maxrand) - 1];   // the reference reads past the table on rare CBL re-draws; clamp instead
+    unsigned int o[4];
+    philox4x32(pid, step, (unsigned int)idx >> 1, 0x47415553u, k0, k1, o);
+    // clipped Box-Muller pair (the distribution of gasdev1, random_mod.f90:70-90)
+    float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float rr = sqrtf(-2.0f * __logf(u1));
+    float s, c;
+    __sincosf(6.2831853071795865f * u2, &s, &c);
+    float g = rr * ((idx & 1) ? s : c);
+    g = fminf(3.0f, fmaxf(-3.0f, g));
+    return (R)g;
+  }
+  // uniform [0,1) and start index for the counter modes
+  FPX_DEV unsigned int bits(unsigned int stream) const {
+    unsigned int o[4];
+    philox4x32(pid, step, stream, 0x554e4946u, k0, k1, o);
+    return o[0];
+  }
+  FPX_DEV int start_index(unsigned int stream) const {
+    // int(ran3*real(maxrand-1))+1 with a counter-based uniform (advance.f90:153)
+    return (int)(((unsigned long long)bits(stream) * (unsigned long long)(maxrand - 1)) >> 32) + 1;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// one model level of the horizontally + time interpolated profiles
+// (interpol_all.f90:135-240 loop body == interpol_misslev.f90:56-159)
+// ---------------------------------------------------------------------------
+template <typename R>
+struct Level {
+  R u, v, w, rho, rhograd, usig, vsig, wsig;
+};
+
+// horizontal/time weights and the four corner columns (interpol_mod.f90:13-14)
+template <typename R>
+struct Cell {
+  R p1, p2, p3, p4, dt1, dt2, dtt;
+  long long c00, c10, c01, c11;   // column indices jy*nx+ix of the corners (ix,jy) (ixp,jy) (ix,jyp) (ixp,jyp)
+};
+
+template <typename R>
+FPX_DEV void cell_setup(const View<R> &V, Cell<R> &C, int ix, int jy, int ixp, int jyp, R xt, R yt, int itime) {
+  // interpol_all.f90:57-71 (identical blocks open interpol_wind / interpol_wind_short)
+  R ddx = xt - (R)ix, ddy = yt - (R)jy;
+  R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
+  C.p1 = rddx * rddy; C.p2 = ddx * rddy; C.p3 = rddx * ddy; C.p4 = ddx * ddy;
+  C.dt1 = (R)(itime - V.memtime0);
+  C.dt2 = (R)(V.memtime1 - itime);
+  C.dtt = K(1.) / (C.dt1 + C.dt2);
+  C.c00 = (long long)jy * V.nx + ix;
+  C.c10 = (long long)jy * V.nx + ixp;
+  C.c01 = (long long)jyp * V.nx + ix;
+  C.c11 = (long long)jyp * V.nx + ixp;
+}
+
+// load (a,b,c) of one corner/level/slot from a [..][nz][2][3] array
+template <typename R>
+FPX_DEV void ld3(const R *base, long long col, int nz, int n, int slot, R &a, R &b, R &c) {
+  const R *p = base + ((col * nz + (n - 1)) * 2 + slot) * 3;
+  a = p[0]; b = p[1]; c = p[2];
+}
+
+template <typename R, bool WITH_RHO, bool WITH_SIG>
+FPX_DEV void level_profile(const View<R> &V, const Cell<R> &C, const R *w3, int n, Level<R> &L) {
+  const R eps = K(1.0e-30);
+  R y1[2], y2[2], y3[2], rho1[2], rhograd1[2];
+  R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    int slot = m == 0 ? V.m1 : V.m2;
+    R u00, v00, w00, u10, v10, w10, u01, v01, w01, u11, v11, w11;
+    ld3(w3, C.c00, V.nz, n, slot, u00, v00, w00);
+    ld3(w3, C.c10, V.nz, n, slot, u10, v10, w10);
+    ld3(w3, C.c01, V.nz, n, slot, u01, v01, w01);
+    ld3(w3, C.c11, V.nz, n, slot, u11, v11, w11);
+    y1[m] = C.p1 * u00 + C.p2 * u10 + C.p3 * u01 + C.p4 * u11;
+    y2[m] = C.p1 * v00 + C.p2 * v10 + C.p3 * v01 + C.p4 * v11;
+    y3[m] = C.p1 * w00 + C.p2 * w10 + C.p3 * w01 + C.p4 * w11;
+    if (WITH_SIG) {
+      usl = usl + u00 + u10 + u01 + u11;
+      vsl = vsl + v00 + v10 + v01 + v11;
+      wsl = wsl + w00 + w10 + w01 + w11;
+      usq = usq + u00 * u00 + u10 * u10 + u01 * u01 + u11 * u11;
+      vsq = vsq + v00 * v00 + v10 * v10 + v01 * v01 + v11 * v11;
+      wsq = wsq + w00 * w00 + w10 * w10 + w01 * w01 + w11 * w11;
+    }
+    if (WITH_RHO) {
+      const R *q00 = V.r2 + ((C.c00 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q10 = V.r2 + ((C.c10 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q01 = V.r2 + ((C.c01 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q11 = V.r2 + ((C.c11 * V.nz + (n - 1)) * 2 + slot) * 2;
+      rho1[m] = C.p1 * q00[0] + C.p2 * q10[0] + C.p3 * q01[0] + C.p4 * q11[0];
+      rhograd1[m] = C.p1 * q00[1] + C.p2 * q10[1] + C.p3 * q01[1] + C.p4 * q11[1];
+    }
+  }
+  L.u = (y1[0] * C.dt2 + y1[1] * C.dt1) * C.dtt;
+  L.v = (y2[0] * C.dt2 + y2[1] * C.dt1) * C.dtt;
+  L.w = (y3[0] * C.dt2 + y3[1] * C.dt1) * C.dtt;
+  if (WITH_RHO) {
+    L.rho = (rho1[0] * C.dt2 + rho1[1] * C.dt1) * C.dtt;
+    L.rhograd = (rhograd1[0] * C.dt2 + rhograd1[1] * C.dt1) * C.dtt;
+  }
+  if (WITH_SIG) {   // 8-point standard deviation, interpol_all.f90:218-238
+    R xaux = usq - usl * usl / K(8.);
+    L.usig = xaux < eps ? K(0.) : m_sqrt(xaux / K(7.));
+    xaux = vsq - vsl * vsl / K(8.);
+    L.vsig = xaux < eps ? K(0.) : m_sqrt(xaux / K(7.));
+    xaux = wsq - wsl * wsl / K(8.);
+    L.wsig = xaux < eps ? K(0.) : m_sqrt(xaux / K(7.));
+  }
+}
+
+// level below zt: first i in 2..nz with height(i) > zt gives indz = i-1
+// (the linear scans of interpol_all.f90:118-125 etc.; bisection finds the same
+// index because height is strictly increasing).  hgt points to LDS.
+template <typename R>
+FPX_DEV int find_level(const R *hgt, int nz, R zt) {
+  int lo = 2, hi = nz;             // answer i in [2, nz]; if none qualifies clamp to nz
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (hgt[mid - 1] > zt) hi = mid; else lo = mid + 1;
+  }
+  return lo - 1;
+}
+
+// ---------------------------------------------------------------------------
+// Hanna turbulence state (hanna_mod.f90:5-6)
+// ---------------------------------------------------------------------------
+template <typename R>
+struct Turb {
+  R ust, wst, ol, h, zeta, sigu, sigv, tlu, tlv, tlw, sigw, dsigwdz, dsigw2dz;
+};
+
+template <typename R>
+FPX_DEV R tlw_unstable(const Turb<R> &T, R z) {   // hanna.f90:78-84
+  if (z < m_abs(T.ol)) return K(0.1) * z / (T.sigw * (K(0.55) - K(0.38) * m_abs(z / T.ol)));
+  if (T.zeta < K(0.1)) return K(0.59) * z / T.sigw;
+  return K(0.15) * T.h / T.sigw * (K(1.) - m_exp(K(-5) * T.zeta));
+}
+
+template <typename R>
+FPX_DEV void sigw_unstable(Turb<R> &T) {   // hanna.f90:67-70 == hanna_short.f90:60-63
+  R z23 = m_pow(T.zeta, K(0.66666));
+  T.sigw = m_sqrt(K(1.2) * (T.wst * T.wst) * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * (T.ust * T.ust)) + K(1.e-2);
+  T.dsigwdz = K(0.5) / T.sigw / T.h * (K(-1.4) * (T.ust * T.ust) + (T.wst * T.wst) * (K(0.8) * m_pow(m_max(T.zeta, K(1.e-3)), K(-.33333)) - K(1.8) * z23));
+}
+
+template <typename R>
+FPX_DEV void hanna(Turb<R> &T, R z) {   // hanna.f90:41-106
+  if (T.h / m_abs(T.ol) < K(1.)) {
+    T.ust = m_max(K(1.e-4), T.ust);
+    R corr = z / T.ust;
+    T.sigu = K(1.e-2) + K(2.0) * T.ust * m_exp(K(-3.e-4) * corr);
+    T.sigw = K(1.3) * T.ust * m_exp(K(-2.e-4) * corr);
+    T.dsigwdz = K(-2.e-4) * T.sigw;
+    T.sigw = T.sigw + K(1.e-2);
+    T.sigv = T.sigw;
+    T.tlu = K(0.5) * z / T.sigw / (K(1.) + K(1.5e-3) * corr);
+    T.tlv = T.tlu;
+    T.tlw = T.tlu;
+  } else if (T.ol < K(0.)) {
+    T.sigu = K(1.e-2) + T.ust * m_pow(K(12) - K(0.5) * T.h / T.ol, K(0.33333));
+    T.sigv = T.sigu;
+    sigw_unstable(T);
+    T.tlu = K(0.15) * T.h / T.sigu;
+    T.tlv = T.tlu;
+    T.tlw = tlw_unstable(T, z);
+  } else {
+    T.sigu = K(1.e-2) + K(2.) * T.ust * (K(1.) - T.zeta);
+    T.sigv = K(1.e-2) + K(1.3) * T.ust * (K(1.) - T.zeta);
+    T.sigw = T.sigv;
+    T.dsigwdz = K(-1.3) * T.ust / T.h;
+    T.tlu = K(0.15) * T.h / T.sigu * m_sqrt(T.zeta);
+    T.tlv = K(0.467) * T.tlu;
+    T.tlw = K(0.1) * T.h / T.sigw * m_pow(T.zeta, K(0.8));
+  }
+  T.tlu = m_max(K(10.), T.tlu);
+  T.tlv = m_max(K(10.), T.tlv);
+  T.tlw = m_max(K(30.), T.tlw);
+  if (T.dsigwdz == K(0.)) T.dsigwdz = K(1.e-10);
+}
+
+template <typename R>
+FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
+  if (T.h / m_abs(T.ol) < K(1.)) {
+    T.ust = m_max(K(1.e-4), T.ust);
+    T.sigu = K(2.0) * T.ust * m_exp(K(-3.e-4) * z / T.ust);
+    T.sigu = m_max(T.sigu, K(1.e-5));
+    T.sigv = K(1.3) * T.ust * m_exp(K(-2.e-4) * z / T.ust);
+    T.sigv = m_max(T.sigv, K(1.e-5));
+    T.sigw = T.sigv;
+    T.dsigw2dz = K(-6.76e-4) * T.ust * m_exp(K(-4.e-4) * z / T.ust);
+    T.tlu = K(0.5) * z / T.sigw / (K(1.) + K(1.5e-3) * z / T.ust);
+    T.tlv = T.tlu;
+    T.tlw = T.tlu;
+  } else if (T.ol < K(0.)) {
+    T.sigu = T.ust * m_pow(K(12) - K(0.5) * T.h / T.ol, K(0.33333));
+    T.sigu = m_max(T.sigu, K(1.e-6));
+    T.sigv = T.sigu;
+    if (T.zeta < K(0.03)) {
+      T.sigw = K(0.96) * T.wst * m_pow(K(3) * T.zeta - T.ol / T.h, K(0.33333));
+      T.dsigw2dz = K(1.8432) * T.wst * T.wst / T.h * m_pow(K(3) * T.zeta - T.ol / T.h, K(-0.33333));
+    } else if (T.zeta < K(0.4)) {
+      R s1 = K(0.96) * m_pow(K(3) * T.zeta - T.ol / T.h, K(0.33333));
+      R s2 = K(0.763) * m_pow(T.zeta, K(0.175));
+      if (s1 < s2) {
+        T.sigw = T.wst * s1;
+        T.dsigw2dz = K(1.8432) * T.wst * T.wst / T.h * m_pow(K(3) * T.zeta - T.ol / T.h, K(-0.33333));
+      } else {
+        T.sigw = T.wst * s2;
+        T.dsigw2dz = K(0.203759) * T.wst * T.wst / T.h * m_pow(T.zeta, K(-0.65));
+      }
+    } else if (T.zeta < K(0.96)) {
+      T.sigw = K(0.722) * T.wst * m_pow(K(1) - T.zeta, K(0.207));
+      T.dsigw2dz = K(-.215812) * T.wst * T.wst / T.h * m_pow(K(1) - T.zeta, K(-0.586));
+    } else if (T.zeta < K(1.00)) {
+      T.sigw = K(0.37) * T.wst;
+      T.dsigw2dz = K(0.);
+    }  // zeta >= 1: the reference leaves sigw/dsigw2dz at whatever the module held; here: the thread's previous value
+    T.sigw = m_max(T.sigw, K(1.e-6));
+    T.tlu = K(0.15) * T.h / T.sigu;
+    T.tlv = T.tlu;
+    T.tlw = tlw_unstable(T, z);
+  } else {
+    T.sigu = K(2.) * T.ust * (K(1.) - T.zeta);
+    T.sigv = K(1.3) * T.ust * (K(1.) - T.zeta);
+    T.sigu = m_max(T.sigu, K(1.e-6));
+    T.sigv = m_max(T.sigv, K(1.e-6));
+    T.sigw = T.sigv;
+    T.dsigw2dz = K(3.38) * T.ust * T.ust * (T.zeta - K(1.)) / T.h;
+    T.tlu = K(0.15) * T.h / T.sigu * m_sqrt(T.zeta);
+    T.tlv = K(0.467) * T.tlu;
+    T.tlw = K(0.1) * T.h / T.sigw * m_pow(T.zeta, K(0.8));
+  }
+  T.tlu = m_max(K(10.), T.tlu);
+  T.tlv = m_max(K(10.), T.tlv);
+  T.tlw = m_max(K(30.), T.tlw);
+}
+
+template <typename R>
+FPX_DEV void hanna_short(Turb<R> &T, R z) {   // hanna_short.f90:41-92
+  if (T.h / m_abs(T.ol) < K(1.)) {
+    T.ust = m_max(K(1.e-4), T.ust);
+    T.sigw = K(1.3) * m_exp(K(-2.e-4) * z / T.ust);
+    T.dsigwdz = K(-2.e-4) * T.sigw;
+    T.sigw = T.sigw * T.ust + K(1.e-2);
+    T.tlw = K(0.5) * z / T.sigw / (K(1.) + K(1.5e-3) * z / T.ust);
+  } else if (T.ol < K(0.)) {
+    sigw_unstable(T);
+    T.tlw = tlw_unstable(T, z);
+  } else {
+    T.sigw = K(1.e-2) + K(1.3) * T.ust * (K(1.) - T.zeta);
+    T.dsigwdz = K(-1.3) * T.ust / T.h;
+    T.tlw = K(0.1) * T.h / T.sigw * m_pow(T.zeta, K(0.8));
+  }
+  T.tlu = m_max(K(10.), T.tlu);
+  T.tlv = m_max(K(10.), T.tlv);
+  T.tlw = m_max(K(30.), T.tlw);
+  if (T.dsigwdz == K(0.)) T.dsigwdz = K(1.e-10);
+}
+
+// ---------------------------------------------------------------------------
+// skewed convective-boundary-layer scheme: cbl.f90
+// ---------------------------------------------------------------------------
+#define FPX_PI_PAR K(3.14159265)   // par_mod.f90:59
+
+template <typename R>
+FPX_DEV R cuberoot(R x) { return m_sign(m_pow(m_abs(x), K(0.333333333)), x); }   // cbl.f90:220-234
+
+template <typename R>
+FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
+  R transition = K(1.);
+  if (-h / ol < K(15)) transition = m_sin(((-h / ol + K(10.)) / K(10.)) * FPX_PI_PAR) / K(2.) + K(0.5);
+  return transition;
+}
+
+// cbl.f90:70-210 -> drift ath, diffusion bth, blow-up flag
+template <typename R>
+FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigmaw, R dsigmawdz, R tlw, R ol,
+                 R &ath, R &bth, int &flagrein) {
+  const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
+  R dens = rhoa, ddens = rhograd, timedir = (R)ldirect;
+  R z = zp / h;
+  R transition = cbl_transition(h, ol);
+  R w2 = sigmaw * sigmaw;
+  R dw2 = K(2.) * sigmaw * dsigmawdz;
+  R alfa = K(2.) * w2 / (C0 * tlw);
+  R wold = timedir * wp;
+  R omz = K(1.) - z;
+  R omz15 = m_pow(omz, K(1.5)), omz05 = m_pow(omz, K(0.5));
+  R wst3 = wst * wst * wst;
+  R w3 = (K(1.2) * z * omz15 + eps) * wst3 * transition;
+  R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * (K(1.) / h) * transition;
+  R w215 = m_pow(w2, K(1.5)), w205 = m_pow(w2, K(0.5));
+  R skew = w3 / w215;
+  R skew2 = skew * skew;
+  R dskew = (dw3 * w215 - w3 * K(1.5) * w205 * dw2) / (w2 * w2 * w2);
+  R radw2 = w205;
+  R dradw2 = K(0.5) * m_pow(w2, K(-0.5)) * dw2;
+  R fluarw = costluar4 * cuberoot(skew);
+  R fluarw2 = fluarw * fluarw;
+  R dfluarw, rluarw, drluarw, xluarw, dxluarw;
+  if (skew != K(0)) {
+    dfluarw = costluar4 * (K(1.) / K(3.)) * cuberoot(m_pow(skew, K(-2.))) * dskew;
+    R a1 = K(1.) + fluarw2, a3 = K(3.) + fluarw2;
+    R a1c = m_pow(a1, K(3.)), a3s = m_pow(a3, K(2.)), a115 = m_pow(a1, K(1.5));
+    rluarw = a1c * skew2 / (a3s * fluarw2);
+    xluarw = a115 * skew / (a3 * fluarw);
+    drluarw = (((K(3.) * (a1 * a1) * (K(2.) * fluarw * dfluarw) * skew2) + (a1 * a1 * a1) * K(2.) * skew * dskew) * a3s * fluarw2 -
+               (a1 * a1 * a1) * skew2 * ((K(2.) * a3 * (K(2.) * fluarw * dfluarw) * fluarw2) + (a3 * a3) * K(2.) * fluarw * dfluarw)) /
+              ((a3s * fluarw2) * (a3s * fluarw2));
+    dxluarw = (((K(1.5) * m_pow(a1, K(0.5)) * (K(2.) * fluarw * dfluarw) * skew) + a115 * dskew) * a3 * fluarw -
+               a115 * skew * (K(3.) * dfluarw + K(3) * fluarw2 * dfluarw)) /
+              ((a3 * fluarw) * (a3 * fluarw));
+  } else {
+    dfluarw = K(0.); rluarw = K(0.); drluarw = K(0.); xluarw = K(0.); dxluarw = K(0.);
+  }
+  R r405 = m_pow(K(4.) + rluarw, K(0.5));
+  R aluarw = K(0.5) * (K(1.) - xluarw / r405);
+  R bluarw = K(1.) - aluarw;
+  R daluarw = K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * m_pow(K(4.) + rluarw, K(-0.5)) * drluarw)) / (K(4.) + rluarw);
+  R dbluarw = -daluarw;
+  R t1 = aluarw * (K(1.) + fluarw2);
+  R qa = bluarw / t1;
+  R qa05 = m_pow(qa, K(0.5));
+  R sigmawa = radw2 * qa05;
+  R dsigmawa = dradw2 * qa05 +
+               radw2 * ((K(0.5) * m_pow(qa, K(-0.5))) *
+                        ((dbluarw * t1 - bluarw * (daluarw * (K(1.) + fluarw2) + aluarw * K(2.) * fluarw * dfluarw)) / (t1 * t1)));
+  R t2 = bluarw * (K(1.) + fluarw2);
+  R qb = aluarw / t2;
+  R qb05 = m_pow(qb, K(0.5));
+  R sigmawb = radw2 * qb05;
+  R dsigmawb = dradw2 * qb05 +
+               radw2 * ((K(0.5) * m_pow(qb, K(-0.5))) *
+                        ((daluarw * t2 - aluarw * (dbluarw * (K(1.) + fluarw2) + bluarw * K(2.) * fluarw * dfluarw)) / (t2 * t2)));
+  R wa = fluarw * sigmawa, wb = fluarw * sigmawb;
+  R dwa = dfluarw * sigmawa + fluarw * dsigmawa;
+  R dwb = dfluarw * sigmawb + fluarw * dsigmawb;
+  R deltawa = wold - wa, deltawb = wold + wb;
+  R wold2 = wold * wold;
+  R sigmawa2 = sigmawa * sigmawa, sigmawb2 = sigmawb * sigmawb;
+  if (m_abs(deltawa) > K(6.) * sigmawa && m_abs(deltawb) > K(6.) * sigmawb) flagrein = 1;
+  R pa = (usurad2p * (K(1.) / sigmawa)) * m_exp(-(K(0.5) * ((deltawa / sigmawa) * (deltawa / sigmawa))));
+  R pb = (usurad2p * (K(1.) / sigmawb)) * m_exp(-(K(0.5) * ((deltawb / sigmawb) * (deltawb / sigmawb))));
+  R ptot = dens * aluarw * pa + dens * bluarw * pb;
+  R aperfa = deltawa * usurad2 / sigmawa;
+  R aperfb = deltawb * usurad2 / sigmawb;
+  R Phi = K(-0.5) * (aluarw * dens * dwa + dens * wa * daluarw + aluarw * wa * ddens) * m_erf(aperfa) +
+          sigmawa * (aluarw * dens * dsigmawa * (wold2 / sigmawa2 + K(1.)) + sigmawa * dens * daluarw + sigmawa * ddens * aluarw +
+                     aluarw * wold * dens / sigmawa2 * (sigmawa * dwa - wa * dsigmawa)) * pa +
+          K(0.5) * (bluarw * dens * dwb + wb * dens * dbluarw + wb * bluarw * ddens) * m_erf(aperfb) +
+          sigmawb * (bluarw * dens * dsigmawb * (wold2 / sigmawb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
+                     bluarw * wold * dens / sigmawb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
+  R Q = timedir * ((aluarw * dens * deltawa / sigmawa2) * pa + (bluarw * dens * deltawb / sigmawb2) * pb);
+  ath = (K(1.) / ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
+  bth = m_sqrt(C0 * alfa);
+}
+
+// bi-Gaussian pdf parameters shared by re_initialize_particle.f90:47-70 and initialize_cbl_vel.f90:46-73
+template <typename R>
+FPX_DEV void cbl_pdf(R zp, R wst, R h, R sigmaw, R ol, R &aluarw, R &sigmawa, R &sigmawb, R &wa, R &wb) {
+  const R costluar4 = K(0.66667), eps = K(0.000001);
+  R z = zp / h;
+  R transition = cbl_transition(h, ol);
+  R w2 = sigmaw * sigmaw;
+  R w3 = ((K(1.2) * z * m_pow(K(1.) - z, K(1.5)) + eps) * (wst * wst * wst)) * transition;
+  R skew = w3 / m_pow(w2, K(1.5));
+  R skew2 = skew * skew;
+  R radw2 = m_sqrt(w2);
+  R fluarw = costluar4 * m_pow(skew, K(0.333333333333333));
+  R fluarw2 = fluarw * fluarw;
+  R rluarw = m_pow(K(1.) + fluarw2, K(3.)) * skew2 / (m_pow(K(3.) + fluarw2, K(2.)) * fluarw2);
+  R xluarw = m_pow(rluarw, K(0.5));
+  aluarw = K(0.5) * (K(1.) - xluarw / m_pow(K(4.) + rluarw, K(0.5)));
+  R bluarw = K(1.) - aluarw;
+  sigmawa = radw2 * m_pow(bluarw / (aluarw * (K(1.) + fluarw2)), K(0.5));
+  sigmawb = radw2 * m_pow(aluarw / (bluarw * (K(1.) + fluarw2)), K(0.5));
+  wa = fluarw * sigmawa;
+  wb = fluarw * sigmawb;
+}
+
+// re_initialize_particle.f90:44-90; bounded re-draw loops (the reference's are unbounded)
+template <typename R>
+FPX_DEV void re_initialize_particle(int ldirect, const Rng<R> &G, R zp, R wst, R h, R sigmaw, R &wp, int &nrand, R ol) {
+  R aluarw, sigmawa, sigmawb, wa, wb;
+  nrand = nrand + 1;
+  R dcas1 = G.at(nrand);
+  R timedir = (R)ldirect;
+  cbl_pdf(zp, wst, h, sigmaw, ol, aluarw, sigmawa, sigmawb, wa, wb);
+  R sg = m_sign(K(1.), wp) * timedir;
+  if (sg > 0) {
+    for (int it = 0; it < 10000; it++) {
+      wp = dcas1 * sigmawa + wa;
+      if (wp < 0) { nrand = nrand + 1; dcas1 = G.at(nrand); continue; }
+      break;
+    }
+    wp = wp * timedir;
+  } else if (sg < 0) {
+    for (int it = 0; it < 10000; it++) {
+      wp = dcas1 * sigmawb - wb;
+      if (wp > 0) { nrand = nrand + 1; dcas1 = G.at(nrand); continue; }
+      break;
+    }
+    wp = wp * timedir;
+  }
+}
+
+// windalign.f90:36-54
+template <typename R>
+FPX_DEV void windalign(R u, R v, R ffap, R ffcp, R &ux, R &vy) {
+  const R eps = K(1.e-30);
+  R ffinv = K(1.) / m_max(m_sqrt(u * u + v * v), eps);
+  R sinphi = v * ffinv;
+  R vy1 = sinphi * ffap;
+  R cosphi = u * ffinv;
+  R ux1 = cosphi * ffap;
+  R ux2 = -sinphi * ffcp;
+  R vy2 = cosphi * ffcp;
+  ux = ux1 + ux2;
+  vy = vy1 + vy2;
+}
+
+// ---------------------------------------------------------------------------
+// polar stereographic map subset: cmapf_mod.f90
+// ---------------------------------------------------------------------------
+#define CM_REARTH K(6371.2)
+#define CM_ALMST1 K(.9999999)
+#define CM_PI K(3.14159265358979)
+#define CM_RADPDG (CM_PI / K(180.))
+#define CM_DGPRAD (K(180.) / CM_PI)
+
+template <typename R>
+FPX_DEV R cspanf(R value, R begin, R end) {   // cmapf_mod.f90:494-524
+  R first = m_min(begin, end), last = m_max(begin, end);
+  R val = m_fmod(value - first, last - first);
+  return val <= K(0.) ? val + last : val + first;
+}
+
+template <typename R>
+FPX_DEV R cgszll(const R *s, R xlat) {   // cmapf_mod.f90:190-238
+  double slat, ymerc, efact;
+  if (xlat > K(89.985)) {
+    if (s[0] > K(0.9999)) return K(2.) * s[6];
+    efact = (double)m_cos(CM_RADPDG * xlat);
+    if (efact <= 0.) return K(0.);
+    ymerc = -log(efact / (double)(K(1.) + m_sin(CM_RADPDG * xlat)));
+  } else if (xlat < K(-89.985)) {
+    if (s[0] < K(-0.9999)) return K(2.) * s[6];
+    efact = (double)m_cos(CM_RADPDG * xlat);
+    if (efact <= 0.) return K(0.);
+    ymerc = log(efact / (double)(K(1.) - m_sin(CM_RADPDG * xlat)));
+  } else {
+    slat = (double)m_sin(CM_RADPDG * xlat);
+    ymerc = log((1. + slat) / (1. - slat)) / 2.;
+  }
+  return (R)((double)(s[6] * m_cos(CM_RADPDG * xlat)) * exp((double)s[0] * ymerc));
+}
+
+template <typename R>
+FPX_DEV void cnllxy(const R *s, R xlat, R xlong, R &xi, R &eta) {   // cmapf_mod.f90:310-365
+  double gamma = (double)s[0];
+  double dlat = (double)xlat;
+  double dlong = (double)cspanf<R>(xlong - s[1], K(-180.), K(180.));
+  dlong = dlong * (double)CM_RADPDG;
+  R gdlong = (R)(gamma * dlong);
+  R sndgam, csdgam, rhog1;
+  if (m_abs(gdlong) < K(.01)) {
+    gdlong = gdlong * gdlong;
+    sndgam = (R)(dlong * (double)(K(1.) - K(1.) / K(6.) * gdlong * (K(1.) - K(1.) / K(20.) * gdlong * (K(1.) - K(1.) / K(42.) * gdlong))));
+    csdgam = (R)(dlong * dlong * (double)K(.5) * (double)(K(1.) - K(1.) / K(12.) * gdlong * (K(1.) - K(1.) / K(30.) * gdlong * (K(1.) - K(1.) / K(56.) * gdlong))));
+  } else {
+    sndgam = (R)((double)m_sin(gdlong) / gamma);
+    csdgam = (R)((double)(K(1.) - m_cos(gdlong)) / gamma / gamma);
+  }
+  double slat = sin((double)CM_RADPDG * dlat);
+  if (slat >= (double)CM_ALMST1 || slat <= -(double)CM_ALMST1) {
+    eta = K(1.) / s[0];
+    xi = K(0.);
+    return;
+  }
+  double mercy = .5 * log((1. + slat) / (1. - slat));
+  double gmercy = gamma * mercy;
+  if (fabs(gmercy) < (double)K(.001)) {
+    rhog1 = (R)(mercy * (1. - .5 * gmercy * (1. - (double)(K(1.) / K(3.)) * gmercy * (1. - (double)(K(1.) / K(4.)) * gmercy))));
+  } else {
+    rhog1 = (R)((1. - exp(-gmercy)) / gamma);
+  }
+  eta = (R)((double)rhog1 + (1. - gamma * (double)rhog1) * gamma * (double)csdgam);
+  xi = (R)((1. - gamma * (double)rhog1) * (double)sndgam);
+}
+
+template <typename R>
+FPX_DEV void cll2xy(const R *s, R xlat, R xlong, R &x, R &y) {   // cmapf_mod.f90:295-308
+  R xi, eta;
+  cnllxy(s, xlat, xlong, xi, eta);
+  x = s[2] + CM_REARTH / s[6] * (xi * s[4] + eta * s[5]);
+  y = s[3] + CM_REARTH / s[6] * (eta * s[4] - xi * s[5]);
+}
+
+template <typename R>
+FPX_DEV void cnxyll(const R *s, double xi, double eta, R &xlat, R &xlong) {   // cmapf_mod.f90:367-425
+  double gamma = (double)s[0], temp, ymerc, along;
+  double arg2 = 2. * eta - gamma * (xi * xi + eta * eta);
+  double arg1 = gamma * arg2;
+  if (fabs(arg1) < (double)K(.01)) {
+    temp = (arg1 / (2. - arg1)) * (arg1 / (2. - arg1));
+    ymerc = arg2 / (2. - arg1) * (1. + temp * ((double)(K(1.) / K(3.)) + temp * ((double)(K(1.) / K(5.)) + temp * ((double)(K(1.) / K(7.))))));
+  } else {
+    ymerc = -log(1. - arg1) / 2. / gamma;
+  }
+  temp = exp(-fabs(ymerc));
+  double a = atan2((1. - temp) * (1. + temp), 2. * temp);
+  xlat = (R)(ymerc < 0 ? -fabs(a) : fabs(a));
+  double gxi = gamma * xi, cgeta = 1. - gamma * eta;
+  if (fabs(gxi) < (double)K(.01) * cgeta) {
+    temp = (gxi / cgeta) * (gxi / cgeta);
+    along = xi / cgeta * (1. - temp * ((double)(K(1.) / K(3.)) - temp * ((double)(K(1.) / K(5.)) - temp * ((double)(K(1.) / K(7.))))));
+  } else {
+    along = atan2(gxi, cgeta) / gamma;
+  }
+  xlong = (R)((double)s[1] + (double)CM_DGPRAD * along);
+  xlat = xlat * CM_DGPRAD;
+}
+
+template <typename R>
+FPX_DEV void cxy2ll(const R *s, R x, R y, R &xlat, R &xlong) {   // cmapf_mod.f90:526-543
+  double xi0 = (double)((x - s[2]) * s[6] / CM_REARTH);
+  double eta0 = (double)((y - s[3]) * s[6] / CM_REARTH);
+  double xi = xi0 * (double)s[4] - eta0 * (double)s[5];
+  double eta = eta0 * (double)s[4] + xi0 * (double)s[5];
+  cnxyll(s, xi, eta, xlat, xlong);
+  xlong = cspanf<R>(xlong, K(-180.), K(180.));
+}
+
+// ---------------------------------------------------------------------------
+// gravitational settling: get_settling.f90:52-127, dynamic_viscosity.f90:7-17
+// ---------------------------------------------------------------------------
+template <typename R>
+FPX_DEV R get_settling(const View<R> &V, const R *hgt, R xt, R yt, R zt, int nsp) {
+  const R ga = K(9.81);
+  int nix = (int)xt, njy = (int)yt;
+  nix = min(max(nix, 0), V.nx - 1);
+  njy = min(max(njy, 0), V.ny - 1);
+  int indz = find_level(hgt, V.nz, zt);
+  R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
+  R dz1 = (zt - hgt[indz - 1]) * dz;
+  R dz2 = (hgt[indz] - zt) * dz;
+  const R *q = V.rhott + (((long long)njy * V.nx + nix) * V.nz + (indz - 1)) * 2;
+  R rho1 = q[0], tt1 = q[1], rho2 = q[2], tt2 = q[3];
+  R temperature = dz2 * tt1 + dz1 * tt2;
+  R airdens = dz2 * rho1 + dz1 * rho2;
+  const R cc = K(120.), t_0 = K(291.15), eta_0 = K(1.827e-5);
+  R vis_dyn = eta_0 * (t_0 + cc) / (temperature + cc) * m_pow(temperature / t_0, K(1.5));
+  R vis_kin = vis_dyn / airdens;
+  R reynolds = V.dquer[nsp] / K(1.e6) * m_abs(V.vsetaver[nsp]) / vis_kin;
+  R settling_old = V.vsetaver[nsp], settling = K(0.), c_d;
+  for (int i = 1; i <= 20; i++) {
+    if (reynolds < K(1.917)) c_d = K(24.) / reynolds;
+    else if (reynolds < K(500.)) c_d = K(18.5) / m_pow(reynolds, K(0.6));
+    else c_d = K(0.44);
+    settling = K(-1.) * m_sqrt(K(4) * ga * V.dquer[nsp] / K(1.e6) * V.density[nsp] * V.cunningham[nsp] / (K(3.) * c_d * airdens));
+    if (m_abs((settling - settling_old) / settling) < K(0.01)) break;
+    reynolds = V.dquer[nsp] / K(1.e6) * m_abs(settling) / vis_kin;
+    settling_old = settling;
+  }
+  return settling;
+}
+
+// species pick + settling velocity, the block repeated at advance.f90:518-531,686-699,893-906
+template <typename R>
+FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt, R zt) {
+  const R eps3 = sizeof(R) == 4 ? (R)1.17549435e-38f : (R)2.2250738585072014e-308;
+  if (V.mdomainfill != 0 || !V.lsettling) return K(0.);
+  int nsp;
+  for (nsp = 0; nsp < V.nspec; nsp++)
+    if (V.xmass_rel[nsp] > eps3) break;
+  if (nsp >= V.nspec) nsp = V.nspec - 1;
+  if (!(V.density[nsp] > K(0.))) return K(0.);
+  return get_settling(V, hgt, (R)xt, (R)yt, zt, nsp);
+}
+
+// ---------------------------------------------------------------------------
+// the per-thread trajectory step
+// ---------------------------------------------------------------------------
+template <typename R> FPX_DEV int pick_grid(const View<R> &V, double xt, double yt);
+
+template <typename R>
+struct PState {   // one particle in registers
+  double xt, yt;
+  R zt, up, vp, wp, usigold, vsigold, wsigold;
+  int ldt;
+  short icbt;
+};
+
+template <typename R>
+FPX_DEV int pick_grid(const View<R> &V, double xt, double yt) {   // advance.f90:161-175 (nests: TODO next)
+  if (V.nglobal && yt > (double)V.switchnorthg) return -1;
+  if (V.sglobal && yt < (double)V.switchsouthg) return -2;
+  return 0;
+}
+
+// boundary conditions advance.f90:784-813 == :956-985
+template <typename R>
+FPX_DEV int boundary(const View<R> &V, const R *hgt, double &xt, double &yt, R &zt, R eps) {
+  if (V.xglobal) {
+    double xm = (double)(R)V.nxmin1;
+    if (xt >= xm) xt = xt - xm;
+    if (xt < 0.) xt = xt + xm;
+    if (xt <= (double)eps) xt = (double)eps;
+    if (fabs(xt - xm) <= (double)eps) xt = (double)((R)V.nxmin1 - eps);
+    if (yt < 0.) {
+      xt = d_modulo(xt * (double)V.dx + 180., 360.) / (double)V.dx;
+      yt = -yt;
+    } else if (yt > (double)(R)V.nymin1) {
+      xt = d_modulo(xt * (double)V.dx + 180., 360.) / (double)V.dx;
+      yt = (double)(K(2) * (R)V.nymin1) - yt;
+    }
+  }
+  if (!(xt >= 0.) || !(xt < (double)(R)V.nxmin1) || !(yt >= 0.) || !(yt <= (double)(R)V.nymin1)) return 3;  // also catches NaN
+  if (zt >= hgt[V.nz - 1]) zt = hgt[V.nz - 1] - K(100.) * eps;
+  return 0;
+}
+
+// horizontal move by (du,dv) metres on grid `ngrid`: advance.f90:750-778 == :923-951
+template <typename R>
+FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, R dv, R fac) {
+  const R pi180 = FPX_PI_PAR / K(180.);
+  if (ngrid >= 0) {
+    R cosfact = (R)((double)V.dxconst / cos((yt * (double)V.dy + (double)V.ylat0) * (double)pi180));
+    xt = xt + (double)(du * cosfact * fac);
+    yt = yt + (double)(dv * V.dyconst * fac);
+  } else {
+    const R *map = ngrid == -1 ? V.northpolemap : V.southpolemap;
+    R xlon = (R)((double)V.xlon0 + xt * (double)V.dx);
+    R ylat = (R)((double)V.ylat0 + yt * (double)V.dy);
+    R xpol, ypol;
+    cll2xy(map, ylat, xlon, xpol, ypol);
+    R gridsize = K(1000.) * cgszll(map, ylat);
+    du = du / gridsize;
+    dv = dv / gridsize;
+    xpol = xpol + du * fac;
+    ypol = ypol + dv * fac;
+    cxy2ll(map, xpol, ypol, ylat, xlon);
+    xt = (double)((xlon - V.xlon0) / V.dx);
+    yt = (double)((ylat - V.ylat0) / V.dy);
+  }
+}
+
+// wind at (cell, zt): interpol_wind.f90:75-214 (SIG) / interpol_wind_short.f90:67-140
+template <typename R, bool SIG>
+FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const R *w3, R zt,
+                         R &u, R &v, R &w, R &usig, R &vsig, R &wsig) {
+  const R eps = K(1.0e-30);
+  int indz = find_level(hgt, V.nz, zt);
+  R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
+  R dz1 = (zt - hgt[indz - 1]) * dz;
+  R dz2 = (hgt[indz] - zt) * dz;
+  R uh[2], vh[2], wh[2];
+  R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    int slot = m == 0 ? V.m1 : V.m2;
+    R u1[2], v1[2], w1[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      int indzh = indz + n;
+      R u00, v00, w00, u10, v10, w10, u01, v01, w01, u11, v11, w11;
+      ld3(w3, C.c00, V.nz, indzh, slot, u00, v00, w00);
+      ld3(w3, C.c10, V.nz, indzh, slot, u10, v10, w10);
+      ld3(w3, C.c01, V.nz, indzh, slot, u01, v01, w01);
+      ld3(w3, C.c11, V.nz, indzh, slot, u11, v11, w11);
+      u1[n] = C.p1 * u00 + C.p2 * u10 + C.p3 * u01 + C.p4 * u11;
+      v1[n] = C.p1 * v00 + C.p2 * v10 + C.p3 * v01 + C.p4 * v11;
+      w1[n] = C.p1 * w00 + C.p2 * w10 + C.p3 * w01 + C.p4 * w11;
+      if (SIG) {
+        usl = usl + u00 + u10 + u01 + u11;
+        vsl = vsl + v00 + v10 + v01 + v11;
+        wsl = wsl + w00 + w10 + w01 + w11;
+        usq = usq + u00 * u00 + u10 * u10 + u01 * u01 + u11 * u11;
+        vsq = vsq + v00 * v00 + v10 * v10 + v01 * v01 + v11 * v11;
+        wsq = wsq + w00 * w00 + w10 * w10 + w01 * w01 + w11 * w11;
+      }
+    }
+    uh[m] = dz2 * u1[0] + dz1 * u1[1];
+    vh[m] = dz2 * v1[0] + dz1 * v1[1];
+    wh[m] = dz2 * w1[0] + dz1 * w1[1];
+  }
+  u = (uh[0] * C.dt2 + uh[1] * C.dt1) * C.dtt;
+  v = (vh[0] * C.dt2 + vh[1] * C.dt1) * C.dtt;
+  w = (wh[0] * C.dt2 + wh[1] * C.dt1) * C.dtt;
+  if (SIG) {   // 16-point sigma, interpol_wind.f90:194-214
+    R xaux = usq - usl * usl / K(16.);
+    usig = xaux < eps ? K(0.) : m_sqrt(xaux / K(15.));
+    xaux = vsq - vsl * vsl / K(16.);
+    vsig = xaux < eps ? K(0.) : m_sqrt(xaux / K(15.));
+    xaux = wsq - wsl * wsl / K(16.);
+    wsig = xaux < eps ? K(0.) : m_sqrt(xaux / K(15.));
+  }
+}
+
+// ust, wst, ol at the cell: interpol_all.f90:80-107
+template <typename R>
+FPX_DEV void interp_surface(const View<R> &V, const Cell<R> &C, Turb<R> &T) {
+  R ust1[2], wst1[2], oli1[2];
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    int slot = m == 0 ? V.m1 : V.m2;
+    const R *a = V.sfc + (C.c00 * 2 + slot) * 4, *b = V.sfc + (C.c10 * 2 + slot) * 4;
+    const R *c = V.sfc + (C.c01 * 2 + slot) * 4, *d = V.sfc + (C.c11 * 2 + slot) * 4;
+    ust1[m] = C.p1 * a[0] + C.p2 * b[0] + C.p3 * c[0] + C.p4 * d[0];
+    wst1[m] = C.p1 * a[1] + C.p2 * b[1] + C.p3 * c[1] + C.p4 * d[1];
+    oli1[m] = C.p1 * a[2] + C.p2 * b[2] + C.p3 * c[2] + C.p4 * d[2];
+  }
+  T.ust = (ust1[0] * C.dt2 + ust1[1] * C.dt1) * C.dtt;
+  T.wst = (wst1[0] * C.dt2 + wst1[1] * C.dt1) * C.dtt;
+  R oliaux = (oli1[0] * C.dt2 + oli1[1] * C.dt1) * C.dtt;
+  T.ol = oliaux != K(0.) ? K(1.) / oliaux : K(99999.);
+}
+
+// interpol_vdep.f90:39-54
+template <typename R>
+FPX_DEV R interp_vdep(const View<R> &V, const Cell<R> &C, int ks) {
+  R y[2];
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    int slot = m == 0 ? V.m1 : V.m2;
+    y[m] = C.p1 * V.vdep[(C.c00 * 2 + slot) * V.nspec + ks] + C.p2 * V.vdep[(C.c10 * 2 + slot) * V.nspec + ks] +
+           C.p3 * V.vdep[(C.c01 * 2 + slot) * V.nspec + ks] + C.p4 * V.vdep[(C.c11 * 2 + slot) * V.nspec + ks];
+  }
+  return (y[0] * C.dt2 + y[1] * C.dt1) * C.dtt;
+}
+
+// two-level profile cache: the reference caches every PBL level it has touched
+// (indzindicator, interpol_mod.f90:16); values are pure functions of the level,
+// so recomputing on a miss gives the same numbers with two levels in registers.
+template <typename R>
+struct LevelCache {
+  Level<R> lo, hi;
+  int ilo, ihi;
+};
+
+template <typename R>
+FPX_DEV void cache_fetch(const View<R> &V, const Cell<R> &C, const R *w3, LevelCache<R> &LC, int indz) {
+  int indzp = indz + 1;
+  if (LC.ilo == indz && LC.ihi == indzp) return;
+  if (LC.ilo == indzp) {            // moved one level down
+    LC.hi = LC.lo; LC.ihi = indzp;
+    level_profile<R, true, true>(V, C, w3, indz, LC.lo); LC.ilo = indz;
+  } else if (LC.ihi == indz) {      // moved one level up
+    LC.lo = LC.hi; LC.ilo = indz;
+    level_profile<R, true, true>(V, C, w3, indzp, LC.hi); LC.ihi = indzp;
+  } else {
+    level_profile<R, true, true>(V, C, w3, indz, LC.lo); LC.ilo = indz;
+    level_profile<R, true, true>(V, C, w3, indzp, LC.hi); LC.ihi = indzp;
+  }
+}
+
+// initialize.f90:66-217.  Returns nothing; fills the turbulent state of a new particle.
+template <typename R>
+FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const Rng<R> &G, int nrand, int itime,
+                                 PState<R> &P, R cbl_dcas, R cbl_dcas1) {
+  P.icbt = 1;
+  int ix = (int)P.xt, jy = (int)P.yt;
+  ix = min(max(ix, 0), V.nx - 2);           // guard only; in-domain particles are untouched
+  jy = min(max(jy, 0), V.ny - 2);
+  int ixp = ix + 1, jyp = jy + 1;
+  Turb<R> T;
+  T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);
+  T.h = V.hcell[(long long)jy * V.nx + ix];   // max of the 8 hmix values, initialize.f90:83-90
+  T.zeta = P.zt / T.h;
+  Cell<R> C;
+  cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime);
+  // The reference's initialize() reads the module variable ngrid left behind by the
+  // previous particle's advance() (interpol_all.f90:144); a parallel engine has no
+  // "previous particle", so the particle's own polar/lat-lon choice is used.
+  const R *w3 = pick_grid(V, P.xt, P.yt) < 0 ? V.w3pol : V.w3;
+  R usig, vsig, wsig;
+  if (T.zeta <= K(1.)) {
+    interp_surface(V, C, T);
+    int indz = find_level(hgt, V.nz, P.zt);
+    Level<R> lo, hi;
+    level_profile<R, false, true>(V, C, w3, indz, lo);
+    level_profile<R, false, true>(V, C, w3, indz + 1, hi);
+    // (u,v,w of initialize.f90:116-118 are not used further)
+    if (V.turbswitch) hanna(T, P.zt); else hanna1(T, P.zt);
+    if (nrand + 2 > V.maxrand) nrand = 1;
+    P.up = G.at(nrand) * T.sigu;
+    P.vp = G.at(nrand + 1) * T.sigv;
+    P.wp = G.at(nrand + 2);
+    if (!V.turbswitch) {
+      P.wp = P.wp * T.sigw;
+    } else if (V.cblflag == 1) {
+      if (-T.h / T.ol > K(5)) {   // initialize_cbl_vel.f90:46-83
+        R aluarw, sigmawa, sigmawb, wa, wb;
+        cbl_pdf(P.zt, T.wst, T.h, T.sigw, T.ol, aluarw, sigmawa, sigmawb, wa, wb);
+        R timedir = (R)V.ldirect;
+        if (cbl_dcas <= aluarw) P.wp = timedir * (cbl_dcas1 * sigmawa + wa);
+        else P.wp = timedir * (cbl_dcas1 * sigmawb - wb);
+      } else {
+        P.wp = P.wp * T.sigw;
+      }
+    }
+    if (V.turbswitch)
+      P.ldt = (int)(m_min(m_min(m_min(T.tlw, T.h / m_max(K(2.) * m_abs(P.wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)), K(600.)) * V.ctl);
+    else
+      P.ldt = (int)(m_min(m_min(T.tlw, T.h / m_max(K(2.) * m_abs(P.wp), K(1.e-5))), K(600.)) * V.ctl);
+    P.ldt = max(P.ldt, V.mintime);
+    usig = (hi.usig + lo.usig) / K(2.);
+    vsig = (hi.vsig + lo.vsig) / K(2.);
+    wsig = (hi.wsig + lo.wsig) / K(2.);
+  } else {
+    R u, v, w;
+    interp_wind<R, true>(V, hgt, C, w3, P.zt, u, v, w, usig, vsig, wsig);
+    P.ldt = abs(V.lsynctime);
+    if (nrand + 1 > V.maxrand) nrand = 1;
+    P.up = G.at(nrand) * K(0.3);
+    P.vp = G.at(nrand + 1) * K(0.3);
+    nrand = nrand + 2;
+    P.wp = K(0.);
+  }
+  if (nrand + 2 > V.maxrand) nrand = 1;
+  P.usigold = G.at(nrand) * usig;
+  P.vsigold = G.at(nrand + 1) * vsig;
+  P.wsigold = G.at(nrand + 2) * wsig;
+}
+
+// does initialize() take the CBL branch that consumes extra sequential draws?
+// (initialize.f90:142-146) -- used only to order the TABLE_SEQ host stream
+template <typename R>
+FPX_DEV int initialize_needs_cbl_draws(const View<R> &V, const R *hgt, int itime, double xt, double yt, R zt) {
+  if (!(V.cblflag == 1 && V.turbswitch)) return 0;
+  int ix = (int)xt, jy = (int)yt;
+  ix = min(max(ix, 0), V.nx - 2);
+  jy = min(max(jy, 0), V.ny - 2);
+  Turb<R> T;
+  T.h = V.hcell[(long long)jy * V.nx + ix];
+  if (!(zt / T.h <= K(1.))) return 0;
+  Cell<R> C;
+  cell_setup(V, C, ix, jy, ix + 1, jy + 1, (R)xt, (R)yt, itime);
+  interp_surface(V, C, T);
+  return (-T.h / T.ol > K(5)) ? 1 : 0;
+}
+
+// advance.f90:133-985.  Returns nstop (0 or 3).  prob[] receives the dry-deposition
+// probabilities (only touched when DRYDEP).
+template <typename R>
+FPX_DEV int advance_particle(const View<R> &V, const R *hgt, const Rng<R> &G, int nrand, int itime,
+                             PState<R> &P, R *prob, Stats *st) {
+  const R eps = K(361) / K(3.e5);   // nxmax/3.e5 with the reference's nxmax=361 (par_mod.f90:144, advance.f90:107)
+  const R eps2 = K(1.e-9);
+  const R href = K(15.);            // par_mod.f90:76
+
+  if (V.drydep)
+    for (int ks = 0; ks < V.nspec; ks++) prob[ks] = K(0.);
+  R dxsave = K(0.), dysave = K(0.), dawsave = K(0.), dcwsave = K(0.);
+  int itimec = itime;
+
+  // grid choice and cell, advance.f90:161-231
+  const int ngrid = pick_grid(V, P.xt, P.yt);
+  const R *w3 = ngrid < 0 ? V.w3pol : V.w3;
+  int ix = (int)P.xt, jy = (int)P.yt;
+  int nix = (int)lround(P.xt), njy = (int)lround(P.yt);
+  int ixp = ix + 1, jyp = jy + 1;
+  if (jyp >= V.ny) jyp = jyp - 1;   // advance.f90:228-231 (device rows are allocated ny, not nymax)
+  if (ixp >= V.nx) ixp = V.nx - 1;  // guard for a non-cyclic domain edge
+
+  R h = V.hcell[(long long)jy * V.nx + ix];                  // advance.f90:236-252 (interpolhmix=.false.)
+  R tropop = V.tropo[(long long)njy * V.nx + nix];           // advance.f90:253
+  Turb<R> T;
+  T.h = h; T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);
+  T.zeta = P.zt / h;
+
+  Cell<R> C;
+  R u = K(0.), v = K(0.), w = K(0.), usig = K(0.), vsig = K(0.), wsig = K(0.);
+  bool above = true;
+
+  if (T.zeta <= K(1.)) {
+    // ---------------- PBL: Langevin sub-stepping, advance.f90:276-609 ----------------
+    above = false;
+    cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime);   // interpol_all.f90:57-71
+    interp_surface(V, C, T);
+    LevelCache<R> LC;
+    LC.ilo = -1; LC.ihi = -1;
+    R vdepo[kMaxSpec];
+    bool have_vdep = false;
+    for (;;) {
+      if (V.method == 1) {
+        P.ldt = min(P.ldt, abs(V.lsynctime - itimec + itime));
+        itimec = itimec + P.ldt * V.ldirect;
+      } else {
+        P.ldt = abs(V.lsynctime);
+        itimec = itime + V.lsynctime;
+      }
+      R dt = (R)P.ldt;
+      T.zeta = P.zt / h;
+
+      int indz = find_level(hgt, V.nz, P.zt);
+      int indzp = indz + 1;
+      cache_fetch(V, C, w3, LC, indz);
+
+      // advance.f90:342-350
+      R dz = K(1.) / (hgt[indzp - 1] - hgt[indz - 1]);
+      R dz1 = (P.zt - hgt[indz - 1]) * dz;
+      R dz2 = (hgt[indzp - 1] - P.zt) * dz;
+      u = dz1 * LC.hi.u + dz2 * LC.lo.u;
+      v = dz1 * LC.hi.v + dz2 * LC.lo.v;
+      w = dz1 * LC.hi.w + dz2 * LC.lo.w;
+      R rhoa = dz1 * LC.hi.rho + dz2 * LC.lo.rho;
+      R rhograd = dz1 * LC.hi.rhograd + dz2 * LC.lo.rhograd;
+
+      if (V.turbswitch) hanna(T, P.zt); else hanna1(T, P.zt);
+
+      // horizontal Langevin, advance.f90:371-384
+      if (nrand + 1 > V.maxrand) nrand = 1;
+      if (dt / T.tlu < K(.5)) {
+        P.up = (K(1.) - dt / T.tlu) * P.up + G.at(nrand) * T.sigu * m_sqrt(K(2.) * dt / T.tlu);
+      } else {
+        R ru = m_exp(-dt / T.tlu);
+        P.up = ru * P.up + G.at(nrand) * T.sigu * m_sqrt(K(1.) - ru * ru);
+      }
+      if (dt / T.tlv < K(.5)) {
+        P.vp = (K(1.) - dt / T.tlv) * P.vp + G.at(nrand + 1) * T.sigv * m_sqrt(K(2.) * dt / T.tlv);
+      } else {
+        R rv = m_exp(-dt / T.tlv);
+        P.vp = rv * P.vp + G.at(nrand + 1) * T.sigv * m_sqrt(K(1.) - rv * rv);
+      }
+      nrand = nrand + 2;
+
+      if (nrand + V.ifine > V.maxrand) nrand = 1;
+      R rhoaux = rhograd / rhoa;
+      R dtf = dt * V.fine;
+      R dtftlw = dtf / T.tlw;
+
+      // vertical Langevin, ifine sub-steps, advance.f90:396-498
+      for (int i = 1; i <= V.ifine; i++) {
+        R delz;
+        if (V.turbswitch) {
+          if (dtftlw < K(.5)) {
+            if (V.cblflag == 1) {
+              if (-h / T.ol > K(5)) {
+                int flagrein = 0;
+                nrand = nrand + 1;
+                R old_wp_buf = P.wp, ath, bth;
+                cbl(V.ldirect, P.wp, P.zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, T.ol, ath, bth, flagrein);
+                P.wp = (P.wp + ath * dtf + bth * G.at(nrand) * m_sqrt(dtf)) * (R)P.icbt;
+                delz = P.wp * dtf;
+                if (flagrein == 1) {
+                  re_initialize_particle(V.ldirect, G, P.zt, T.wst, h, T.sigw, old_wp_buf, nrand, T.ol);
+                  P.wp = old_wp_buf;
+                  delz = P.wp * dtf;
+                  atomicAdd(&st->nan_count, 1ull);
+                }
+              } else {
+                nrand = nrand + 1;
+                R ath = -P.wp / T.tlw + T.sigw * T.dsigwdz + P.wp * P.wp / T.sigw * T.dsigwdz + T.sigw * T.sigw / rhoa * rhograd;
+                R bth = T.sigw * G.at(nrand) * m_sqrt(K(2.) * dtftlw);
+                P.wp = (P.wp + ath * dtf + bth) * (R)P.icbt;
+                delz = P.wp * dtf;
+                R del_test = (K(1.) - P.wp) / P.wp;
+                if (isnan(P.wp) || isnan(del_test)) {
+                  nrand = nrand + 1;
+                  P.wp = T.sigw * G.at(nrand);
+                  delz = P.wp * dtf;
+                  atomicAdd(&st->nan_count2, 1ull);
+                }
+              }
+            } else {
+              P.wp = ((K(1.) - dtftlw) * P.wp + G.at(nrand + i) * m_sqrt(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
+              delz = P.wp * T.sigw * dtf;
+            }
+          } else {
+            R rw = m_exp(-dtftlw);
+            P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
+            delz = P.wp * T.sigw * dtf;
+          }
+        } else {
+          R rw = m_exp(-dtftlw);
+          P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)P.icbt;
+          delz = P.wp * dtf;
+        }
+
+        // reflection at the ground / mixing height, advance.f90:476-491
+        if (m_abs(delz) > h) delz = m_fmod(delz, h);
+        if (delz < -P.zt) {
+          P.icbt = -1;
+          P.zt = -P.zt - delz;
+        } else if (delz > (h - P.zt)) {
+          P.icbt = -1;
+          P.zt = -P.zt - delz + K(2.) * h;
+        } else {
+          P.icbt = 1;
+          P.zt = P.zt + delz;
+        }
+        if (i != V.ifine) {
+          T.zeta = P.zt / h;
+          hanna_short(T, P.zt);
+        }
+      }
+      if (V.cblflag != 1) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i" with i = ifine+1 after the loop (advance.f90:499)
+
+      // next sub-step length, advance.f90:504-510
+      if (V.turbswitch)
+        P.ldt = (int)(m_min(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)) * V.ctl);
+      else
+        P.ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp), K(1.e-5))) * V.ctl);
+      P.ldt = max(P.ldt, V.mintime);
+
+      if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:518-531
+
+      // advance.f90:539-547
+      dxsave = dxsave + u * dt;
+      dysave = dysave + v * dt;
+      dawsave = dawsave + P.up * dt;
+      dcwsave = dcwsave + P.vp * dt;
+      P.zt = P.zt + w * dt * (R)V.ldirect;
+      if (P.zt >= hgt[V.nz - 1]) P.zt = hgt[V.nz - 1] - K(100.) * eps;
+
+      if (P.zt > h) {   // advance.f90:549-552
+        if (itimec == itime + V.lsynctime) {
+          // -> 99.  The reference reaches label 99 here with usig/vsig/wsig still holding
+          // whatever the previous particle left in interpol_mod; use this particle's own
+          // profile values, as the regular exit :603-606 does.
+          usig = K(0.5) * (LC.hi.usig + LC.lo.usig);
+          vsig = K(0.5) * (LC.hi.vsig + LC.lo.vsig);
+          wsig = K(0.5) * (LC.hi.wsig + LC.lo.wsig);
+          break;
+        }
+        above = true;                                 // -> 700
+        break;
+      }
+
+      // dry-deposition probability, advance.f90:582-599
+      if (V.drydep && P.zt < K(2.) * href) {
+        for (int ks = 0; ks < V.nspec; ks++) {
+          if (V.drydepspec[ks]) {
+            if (!have_vdep) vdepo[ks] = interp_vdep(V, C, ks);
+            prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_exp(-vdepo[ks] * m_abs(dt) / (K(2.) * href));
+          }
+        }
+        have_vdep = true;
+      }
+
+      if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);   // advance.f90:601
+
+      if (itimec == itime + V.lsynctime) {   // advance.f90:603-608
+        usig = K(0.5) * (LC.hi.usig + LC.lo.usig);
+        vsig = K(0.5) * (LC.hi.vsig + LC.lo.vsig);
+        wsig = K(0.5) * (LC.hi.wsig + LC.lo.wsig);
+        break;
+      }
+    }
+  }
+
+  if (above) {
+    // ---------------- above the PBL: one step, advance.f90:629-708 ----------------
+    cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime);
+    interp_wind<R, true>(V, hgt, C, w3, P.zt, u, v, w, usig, vsig, wsig);
+    P.ldt = abs(V.lsynctime - itimec + itime);
+    R dt = (R)P.ldt;
+    R ux, vy;
+    if (P.zt < tropop) {
+      R uxscale = m_sqrt(K(2.) * V.d_trop / dt);
+      if (nrand + 1 > V.maxrand) nrand = 1;
+      ux = G.at(nrand) * uxscale;
+      vy = G.at(nrand + 1) * uxscale;
+      nrand = nrand + 2;
+      P.wp = K(0.);
+    } else if (P.zt < tropop + K(1000.)) {
+      R weight = (P.zt - tropop) / K(1000.);
+      R uxscale = m_sqrt(K(2.) * V.d_trop / dt * (K(1.) - weight));
+      if (nrand + 2 > V.maxrand) nrand = 1;
+      ux = G.at(nrand) * uxscale;
+      vy = G.at(nrand + 1) * uxscale;
+      R wpscale = m_sqrt(K(2.) * V.d_strat / dt * weight);
+      P.wp = G.at(nrand + 2) * wpscale + V.d_strat / K(1000.);
+      nrand = nrand + 3;
+    } else {
+      if (nrand > V.maxrand) nrand = 1;
+      ux = K(0.);
+      vy = K(0.);
+      R wpscale = m_sqrt(K(2.) * V.d_strat / dt);
+      P.wp = G.at(nrand) * wpscale;
+      nrand = nrand + 1;
+    }
+    if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:686-699
+    dxsave = dxsave + (u + ux) * dt;
+    dysave = dysave + (v + vy) * dt;
+    P.zt = P.zt + (w + P.wp) * dt * (R)V.ldirect;
+    if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);
+  }
+
+  // ---------------- 99: mesoscale fluctuations, advance.f90:728-739 ----------------
+  {
+    R r = m_exp(K(-2.) * (R)abs(V.lsynctime) / (R)V.lwindinterv);
+    R rs = m_sqrt(K(1.) - r * r);
+    if (nrand + 2 > V.maxrand) nrand = 1;
+    P.usigold = r * P.usigold + rs * G.at(nrand) * usig * V.turbmesoscale;
+    P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * vsig * V.turbmesoscale;
+    P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * wsig * V.turbmesoscale;
+    dxsave = dxsave + P.usigold * (R)V.lsynctime;
+    dysave = dysave + P.vsigold * (R)V.lsynctime;
+    P.zt = P.zt + P.wsigold * (R)V.lsynctime;
+    if (P.zt < K(0.)) P.zt = K(-1.) * P.zt;
+  }
+
+  // wind alignment and position update, advance.f90:747-778
+  {
+    R ux, vy;
+    windalign(dxsave, dysave, dawsave, dcwsave, ux, vy);
+    dxsave = dxsave + ux;
+    dysave = dysave + vy;
+    move_xy(V, ngrid, P.xt, P.yt, dxsave, dysave, (R)V.ldirect);
+  }
+  if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) return 3;   // advance.f90:784-813
+
+  // ---------------- Petterssen correction, advance.f90:829-985 ----------------
+  if (P.ldt != abs(V.lsynctime)) return 0;
+  if (abs(itime + P.ldt * V.ldirect) > abs(V.memtime1)) return 0;
+  if (pick_grid(V, P.xt, P.yt) != ngrid) return 0;
+  ix = (int)P.xt; jy = (int)P.yt;
+  ixp = ix + 1; jyp = jy + 1;
+  if (jyp >= V.ny) jyp = V.ny - 1;   // guard: the reference would read the padding row nymax here
+  if (ixp >= V.nx) ixp = V.nx - 1;
+  R uold = u, vold = v, wold = w;
+  {
+    R d0, d1, d2;
+    cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime + P.ldt * V.ldirect);
+    interp_wind<R, false>(V, hgt, C, w3, P.zt, u, v, w, d0, d1, d2);
+  }
+  if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:893-906
+  u = (u - uold) / K(2.);
+  v = (v - vold) / K(2.);
+  w = (w - wold) / K(2.);
+  P.zt = P.zt + w * (R)(P.ldt * V.ldirect);
+  if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);
+  move_xy(V, ngrid, P.xt, P.yt, u, v, (R)(P.ldt * V.ldirect));
+  if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) return 3;   // advance.f90:956-985
+  return 0;
+}
+
+#undef K
+}  // namespace fpx

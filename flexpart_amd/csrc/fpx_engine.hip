@@ -1,0 +1,870 @@
+// fpx_engine.hip -- HIP kernels (gfx950) and the C ABI of include/flexpart_amd.h.
+//
+// One process drives one GPU through one handle.  All particle state and all
+// met fields stay resident in HBM between calls; a step is a single launch of
+// k_advance (one thread per particle slot) on the handle's stream.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/flexpart_amd.h"
+#include "fpx_device.hpp"
+#include "fpx_rng_host.hpp"
+
+namespace fpx {
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess)                                                                 \
+      return fail(FPX_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+constexpr int kBlock = 256;
+constexpr int kMaxNz = 512;
+
+// ---------------------------------------------------------------------------
+// field repacking kernels
+// ---------------------------------------------------------------------------
+// 3-D field (x fastest, strides nxmax,nymax) -> out[((jy*nx+ix)*nz + k)*stride + off]
+// (z fastest).  32x32 LDS tile transposes x<->z so both sides move whole rows.
+template <typename H, typename R>
+__global__ void k_pack3(const H *__restrict__ in, R *__restrict__ out, int nx, int ny, int nz, int nxmax, int nymax,
+                        int stride, int off) {
+  __shared__ R tile[32][33];
+  const int jy = blockIdx.z;
+  const int x0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int x = x0 + threadIdx.x, z = z0 + r;
+    if (x < nx && z < nz) tile[r][threadIdx.x] = (R)in[(size_t)x + (size_t)nxmax * ((size_t)jy + (size_t)nymax * z)];
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 32; r += blockDim.y) {
+    int x = x0 + r, z = z0 + threadIdx.x;
+    if (x < nx && z < nz) out[(((size_t)jy * nx + x) * nz + z) * stride + off] = tile[threadIdx.x][r];
+  }
+}
+
+template <typename H, typename R>
+__global__ void k_pack2(const H *__restrict__ in, R *__restrict__ out, int nx, int ny, int nxmax, int stride, int off) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nx * ny) return;
+  int ix = i % nx, jy = i / nx;
+  out[(size_t)i * stride + off] = (R)in[(size_t)ix + (size_t)nxmax * jy];
+}
+
+// hcell[jy][ix] = max of hmix over the cell's corners and both slots: the loop of
+// advance.f90:238-252 (start value 0, jyp clamp of :228-231) == initialize.f90:83-90
+template <typename R>
+__global__ void k_hcell(const R *__restrict__ sfc, R *__restrict__ hcell, int nx, int ny) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nx * ny) return;
+  int ix = i % nx, jy = i / nx;
+  int ixp = min(ix + 1, nx - 1), jyp = min(jy + 1, ny - 1);
+  R h = (R)0;
+  for (int s = 0; s < 2; s++) {
+    h = fmax(h, sfc[(((size_t)jy * nx + ix) * 2 + s) * 4 + 3]);
+    h = fmax(h, sfc[(((size_t)jy * nx + ixp) * 2 + s) * 4 + 3]);
+    h = fmax(h, sfc[(((size_t)jyp * nx + ix) * 2 + s) * 4 + 3]);
+    h = fmax(h, sfc[(((size_t)jyp * nx + ixp) * 2 + s) * 4 + 3]);
+  }
+  hcell[i] = h;
+}
+
+// ---------------------------------------------------------------------------
+// particle I/O kernels: host order (pid) <-> device slots
+// ---------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void k_scatter_in(const S *__restrict__ src, D *__restrict__ dst, const unsigned int *__restrict__ slot_of_pid,
+                             long long first, long long count) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  long long slot = slot_of_pid ? (long long)slot_of_pid[first + i] : first + i;
+  dst[slot] = (D)src[i];
+}
+template <typename S, typename D>
+__global__ void k_gather_out(const S *__restrict__ src, D *__restrict__ dst, const unsigned int *__restrict__ slot_of_pid,
+                             long long first, long long count) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  long long slot = slot_of_pid ? (long long)slot_of_pid[first + i] : first + i;
+  dst[i] = (D)src[slot];
+}
+template <typename D>
+__global__ void k_fill(D *__restrict__ dst, D val, long long first, long long count, const unsigned int *__restrict__ slot_of_pid) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  long long slot = slot_of_pid ? (long long)slot_of_pid[first + i] : first + i;
+  dst[slot] = val;
+}
+__global__ void k_iota_pid(unsigned int *__restrict__ pid, long long first, long long count) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  pid[first + i] = (unsigned int)(first + i);
+}
+
+// ---------------------------------------------------------------------------
+// synthetic cloud on the device (benchmarks): same SplitMix64 counters and the
+// same arithmetic as flexpart_amd/synthetic.py:make_particles
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double splitmix_u01(unsigned long long idx1, unsigned long long seed) {
+  unsigned long long z = idx1 * 0x9E3779B97F4A7C15ull + seed;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <typename R>
+__global__ void k_seed(View<R> V, Parts<R> P, long long n, unsigned long long seed, double frac_pbl, double zmax,
+                       double lat_margin, int itime0) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  {
+#pragma clang fp contract(off)
+  double ux = splitmix_u01(i + 1, seed + 1), uy = splitmix_u01(i + 1, seed + 2);
+  double uz = splitmix_u01(i + 1, seed + 3), us = splitmix_u01(i + 1, seed + 4);
+  const double eps = 361.0 / 3.0e5;
+  double x = eps + ux * ((double)(V.nx - 1) - 2.0 * eps);
+  double y = lat_margin + uy * ((double)(V.ny - 1) - 2.0 * lat_margin);
+  int ix = min((int)x, V.nx - 2), jy = min((int)y, V.ny - 2);
+  double hloc = (double)V.hcell[(size_t)jy * V.nx + ix];
+  double z = us < frac_pbl ? 10.0 + uz * fmax(hloc - 20.0, 1.0) : hloc + 10.0 + uz * (zmax - hloc - 10.0);
+  P.xt[i] = x; P.yt[i] = y; P.zt[i] = (R)z;
+  P.up[i] = 0; P.vp[i] = 0; P.wp[i] = 0; P.us[i] = 0; P.vs[i] = 0; P.ws[i] = 0;
+  P.idt[i] = 0; P.itra1[i] = itime0; P.itramem[i] = itime0; P.npoint[i] = 1; P.nclass[i] = 1;
+  P.cbt[i] = 1; P.pid[i] = (unsigned int)i;
+  for (int ks = 0; ks < V.nspec; ks++) P.xmass1[(size_t)ks * P.cap + i] = (R)1;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// TABLE_SEQ helper: which particles are due / new / take initialize()'s CBL draw
+// ---------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_classify(View<R> V, Parts<R> P, long long numpart, int itime, unsigned char *__restrict__ flags) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= numpart) return;
+  unsigned char f = 0;
+  if (P.itra1[s] == itime) {
+    f |= 1;
+    if (P.itramem[s] == itime || itime == 0) {
+      f |= 2;
+      double xt = P.xt[s], yt = P.yt[s];
+      if (xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1)
+        if (initialize_needs_cbl_draws(V, hgt, itime, xt, yt, P.zt[s])) f |= 4;
+    }
+  }
+  flags[P.pid[s]] = f;
+}
+
+// ---------------------------------------------------------------------------
+// the hot kernel: one pass of the particle loop timemanager.f90:531-712
+// ---------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_advance(View<R> V, Parts<R> P, SeqRng S, long long numpart, int itime, unsigned int step, Stats *st) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= numpart) return;
+  if (P.itra1[s] != itime) return;                       // timemanager.f90:537
+  atomicAdd(&st->n_due, 1ull);   // compiler folds this into one add per wave
+
+  PState<R> ps;
+  ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
+  const int itramem = P.itramem[s];
+  const unsigned int pid = P.pid[s];
+
+  // a non-finite or out-of-grid position would index outside the fields (the reference
+  // would read arbitrary memory): terminate the particle instead
+  if (!(ps.xt >= 0. && ps.xt <= (double)V.nxmin1 && ps.yt >= 0. && ps.yt <= (double)V.nymin1) || !(ps.zt == ps.zt)) {
+    P.itra1[s] = kDead;
+    atomicAdd(&st->n_badpos, 1ull);
+    return;
+  }
+
+  Rng<R> G;
+  G.tab = V.rannumb; G.maxrand = V.maxrand; G.mode = V.rng_mode;
+  G.pid = pid; G.step = step;
+  G.k0 = (unsigned int)V.seed; G.k1 = (unsigned int)(V.seed >> 32);
+
+  const bool is_new = (itramem == itime) || (itime == 0);   // timemanager.f90:553
+  if (is_new) {
+    int nrand_i;
+    R dcas = (R)0, dcas1 = (R)0;
+    Rng<R> Gi = G;
+    if (V.rng_mode == 0) {
+      nrand_i = S.nrand_init[pid];
+      if (sizeof(R) == 4) { dcas = (R)S.cbl_dcas[pid]; dcas1 = (R)S.cbl_dcas1[pid]; }
+      else { dcas = (R)S.cbl_dcas_d[pid]; dcas1 = (R)S.cbl_dcas1_d[pid]; }
+    } else {
+      Gi.step = step | 0x80000000u;           // a stream of its own for initialize()
+      nrand_i = V.rng_mode == 1 ? Gi.start_index(0) : 1;
+      dcas = (R)(((float)(Gi.bits(1) >> 8) + 0.5f) * (1.0f / 16777216.0f));
+      Rng<R> Gn = Gi;
+      Gn.mode = 2;
+      dcas1 = Gn.at(7);
+    }
+    initialize_particle(V, hgt, Gi, nrand_i, itime, ps, dcas, dcas1);
+    atomicAdd(&st->n_init, 1ull);
+  } else {
+    ps.up = P.up[s]; ps.vp = P.vp[s]; ps.wp = P.wp[s];
+    ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
+    ps.ldt = P.idt[s]; ps.icbt = P.cbt[s];
+  }
+
+  int nrand;
+  if (V.rng_mode == 0) nrand = S.nrand_adv[pid];
+  else if (V.rng_mode == 1) nrand = G.start_index(0);
+  else nrand = 1;
+
+  R prob[kMaxSpec];
+  const int nstop = advance_particle(V, hgt, G, nrand, itime, ps, prob, st);
+
+  // ---- epilogue, timemanager.f90:630-708 ----
+  int itra1;
+  if (nstop > 1) {
+    itra1 = kDead;
+    atomicAdd(&st->n_left, 1ull);
+  } else {
+    itra1 = itime + V.lsynctime;
+    R xmassfract = (R)0;
+    for (int ks = 0; ks < V.nspec; ks++) {
+      R decfact = V.decay[ks] > (R)0 ? m_exp(-(R)abs(V.lsynctime) * V.decay[ks]) : (R)1;
+      R xm = P.xmass1[(size_t)ks * P.cap + s];
+      if (V.drydep && V.drydepspec[ks]) xm = xm * ((R)1 - prob[ks]) * decfact;
+      else xm = xm * decfact;
+      P.xmass1[(size_t)ks * P.cap + s] = xm;
+      if (V.mdomainfill == 0) {
+        if (V.xmass_rel[ks] > (R)0) xmassfract = m_max(xmassfract, (R)V.npart_rel * xm / V.xmass_rel[ks]);
+      } else {
+        xmassfract = (R)1;
+      }
+    }
+    if (xmassfract < (R)0.0001) {   // minmass, par_mod.f90:213
+      itra1 = kDead;
+      atomicAdd(&st->n_minmass, 1ull);
+    } else if (abs(itra1 - itramem) >= V.lage_last) {
+      itra1 = kDead;
+      atomicAdd(&st->n_maxage, 1ull);
+    }
+  }
+
+  P.xt[s] = ps.xt; P.yt[s] = ps.yt; P.zt[s] = ps.zt;
+  P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
+  P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
+  P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt; P.itra1[s] = itra1;
+}
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+struct EngineBase {
+  virtual ~EngineBase() {}
+  virtual int set_height(const void *h, int n) = 0;
+  virtual int upload_fields(int slot, const fpx_fields *f) = 0;
+  virtual int set_windtime(const int32_t mt[2], const int32_t mi[2]) = 0;
+  virtual int rng_fill_table() = 0;
+  virtual int rng_set_table(const void *t, int n) = 0;
+  virtual int rng_get_table(void *t, int n) = 0;
+  virtual int upload_particles(long long first, long long count, const fpx_particles *p) = 0;
+  virtual int download_particles(long long first, long long count, const fpx_particles *p) = 0;
+  virtual int set_numpart(long long n) = 0;
+  virtual int step(int itime, fpx_step_stats *st, bool async) = 0;
+  virtual int sync() = 0;
+  virtual int kernel_time(double *ms, long long *launches, int reset) = 0;
+  virtual int sort_particles() = 0;
+  virtual int seed_particles(long long n, unsigned long long seed, double frac_pbl, double zmax, double lat_margin,
+                             int itime0) = 0;
+  virtual void *stream_ptr() = 0;
+};
+
+template <typename R>
+struct Engine : EngineBase {
+  fpx_config cfg;
+  hipStream_t stream = nullptr;
+  View<R> V;
+  Parts<R> P;
+  bool height_set = false, window_set = false, table_set = false, slot_loaded[2] = {false, false};
+  long long numpart = 0;
+  // owned device memory
+  std::vector<void *> owned;
+  void *staging = nullptr;
+  size_t staging_bytes = 0;
+  unsigned int *slot_of_pid = nullptr;   // only after a locality sort
+  Stats *d_stats = nullptr;
+  // TABLE_SEQ state
+  HostRng<float> rng4;
+  HostRng<double> rng8;
+  std::vector<float> tab4;
+  std::vector<double> tab8;
+  int *d_nrand_adv = nullptr, *d_nrand_init = nullptr;
+  float *d_dcas4 = nullptr, *d_dcas14 = nullptr;
+  double *d_dcas8 = nullptr, *d_dcas18 = nullptr;
+  unsigned char *d_flags = nullptr;
+  std::vector<unsigned char> h_flags;
+  std::vector<int> h_nrand_adv, h_nrand_init;
+  std::vector<float> h_dcas4, h_dcas14;
+  std::vector<double> h_dcas8, h_dcas18;
+  // timing
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double acc_ms = 0;
+  long long acc_launches = 0;
+  unsigned int step_counter = 0;
+
+  template <typename T>
+  int dalloc(T **p, size_t n) {
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(FPX_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    owned.push_back(q);
+    *p = (T *)q;
+    return 0;
+  }
+  int ensure_staging(size_t bytes) {
+    if (bytes <= staging_bytes) return 0;
+    if (staging) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(staging)); staging = nullptr; staging_bytes = 0; }
+    HIPCHK(hipMalloc(&staging, bytes));
+    staging_bytes = bytes;
+    return 0;
+  }
+
+  int init(const fpx_config *c) {
+    cfg = *c;
+    if (cfg.nz > kMaxNz) return fail(FPX_ERR_ARG, "nz exceeds the engine's level limit (512)");
+    if (cfg.nx < 2 || cfg.ny < 2 || cfg.nz < 2) return fail(FPX_ERR_ARG, "grid too small");
+    if (cfg.nxmax < cfg.nx || cfg.nymax < cfg.ny || cfg.nzmax < cfg.nz) return fail(FPX_ERR_ARG, "allocated extents smaller than used extents");
+    if (cfg.nspec < 1 || cfg.nspec > FPX_MAXSPEC || cfg.maxspec < cfg.nspec) return fail(FPX_ERR_ARG, "bad nspec/maxspec");
+    if (cfg.max_particles < 1 || cfg.max_particles > 0xFFFFFFF0ll) return fail(FPX_ERR_ARG, "bad max_particles");
+    if (cfg.ifine < 1) return fail(FPX_ERR_ARG, "ifine must be >= 1");
+    HIPCHK(hipSetDevice(cfg.device));
+    HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    memset(&V, 0, sizeof(V));
+    memset(&P, 0, sizeof(P));
+    // scalars: typed exactly as the reference's default-real variables
+    V.nx = cfg.nx; V.ny = cfg.ny; V.nz = cfg.nz; V.nxmin1 = cfg.nx - 1; V.nymin1 = cfg.ny - 1; V.nmixz = cfg.nmixz;
+    V.dx = (R)cfg.dx; V.dy = (R)cfg.dy; V.xlon0 = (R)cfg.xlon0; V.ylat0 = (R)cfg.ylat0;
+    {  // gridcheck_ecmwf.f90:311-312 with par_mod.f90:59 r_earth, pi
+      const R r_earth = (R)6.371e6, pi = (R)3.14159265;
+      V.dxconst = (R)180. / (V.dx * r_earth * pi);
+      V.dyconst = (R)180. / (V.dy * r_earth * pi);
+    }
+    V.xglobal = cfg.xglobal; V.nglobal = cfg.nglobal; V.sglobal = cfg.sglobal;
+    V.switchnorthg = (R)cfg.switchnorthg; V.switchsouthg = (R)cfg.switchsouthg;
+    for (int i = 0; i < 9; i++) { V.northpolemap[i] = (R)cfg.northpolemap[i]; V.southpolemap[i] = (R)cfg.southpolemap[i]; }
+    V.ldirect = cfg.ldirect; V.lsynctime = cfg.lsynctime; V.method = cfg.method; V.mintime = cfg.mintime;
+    V.ifine = cfg.ifine; V.turbswitch = cfg.turbswitch; V.cblflag = cfg.cblflag; V.mdomainfill = cfg.mdomainfill;
+    V.lsettling = cfg.lsettling; V.nspec = cfg.nspec; V.drydep = cfg.drydep;
+    V.ctl = (R)cfg.ctl; V.fine = (R)1. / (R)cfg.ifine;   // readcommand.f90:271
+    V.d_trop = (R)cfg.d_trop; V.d_strat = (R)cfg.d_strat; V.turbmesoscale = (R)cfg.turbmesoscale;
+    for (int i = 0; i < FPX_MAXSPEC; i++) {
+      V.drydepspec[i] = cfg.drydepspec[i];
+      V.density[i] = (R)cfg.density[i]; V.dquer[i] = (R)cfg.dquer[i]; V.vsetaver[i] = (R)cfg.vsetaver[i];
+      V.cunningham[i] = (R)cfg.cunningham[i]; V.decay[i] = (R)cfg.decay[i]; V.xmass_rel[i] = (R)cfg.xmass_release[i];
+    }
+    V.npart_rel = cfg.npart_release; V.lage_last = cfg.lage_last;
+    V.rng_mode = cfg.rng_mode; V.seed = cfg.seed; V.maxrand = 1000000;
+
+    const size_t ncol = (size_t)cfg.nx * cfg.ny, nlev = ncol * cfg.nz;
+    R *p;
+    int rc;
+    if ((rc = dalloc(&p, cfg.nz))) return rc; V.height = p;
+    if ((rc = dalloc(&p, nlev * 6))) return rc; V.w3 = p;
+    HIPCHK(hipMemsetAsync(p, 0, nlev * 6 * sizeof(R), stream));
+    if (cfg.nglobal || cfg.sglobal) {
+      if ((rc = dalloc(&p, nlev * 6))) return rc; V.w3pol = p;
+      HIPCHK(hipMemsetAsync(p, 0, nlev * 6 * sizeof(R), stream));
+    }
+    if ((rc = dalloc(&p, nlev * 4))) return rc; V.r2 = p;
+    HIPCHK(hipMemsetAsync(p, 0, nlev * 4 * sizeof(R), stream));
+    if ((rc = dalloc(&p, ncol * 8))) return rc; V.sfc = p;
+    HIPCHK(hipMemsetAsync(p, 0, ncol * 8 * sizeof(R), stream));
+    if ((rc = dalloc(&p, ncol))) return rc; V.hcell = p;
+    if ((rc = dalloc(&p, ncol))) return rc; V.tropo = p;
+    if (cfg.drydep) { if ((rc = dalloc(&p, ncol * 2 * cfg.nspec))) return rc; V.vdep = p; }
+    if (cfg.lsettling) { if ((rc = dalloc(&p, nlev * 2))) return rc; V.rhott = p; }
+    if ((rc = dalloc(&p, V.maxrand))) return rc; V.rannumb = p;
+    if ((rc = dalloc(&d_stats, 1))) return rc;
+
+    const size_t cap = (size_t)cfg.max_particles;
+    P.cap = (long long)cap;
+    if ((rc = dalloc(&P.xt, cap))) return rc;
+    if ((rc = dalloc(&P.yt, cap))) return rc;
+    R **rs[] = {&P.zt, &P.up, &P.vp, &P.wp, &P.us, &P.vs, &P.ws};
+    for (auto q : rs) if ((rc = dalloc(q, cap))) return rc;
+    int **is[] = {&P.idt, &P.itra1, &P.itramem, &P.npoint, &P.nclass};
+    for (auto q : is) if ((rc = dalloc(q, cap))) return rc;
+    if ((rc = dalloc(&P.cbt, cap))) return rc;
+    if ((rc = dalloc(&P.xmass1, cap * cfg.nspec))) return rc;
+    if ((rc = dalloc(&P.pid, cap))) return rc;
+    // every slot starts dead (FLEXPART.f90:315-317) with identity numbering
+    const int nb = (int)((cap + kBlock - 1) / kBlock);
+    k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, (long long)cap, nullptr);
+    k_iota_pid<<<nb, kBlock, 0, stream>>>(P.pid, 0, (long long)cap);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  ~Engine() override {
+    if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (void *q : owned) (void)hipFree(q);
+    if (staging) (void)hipFree(staging);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+
+  int set_height(const void *h, int n) override {
+    if (!h || n != cfg.nz) return fail(FPX_ERR_ARG, "set_height: need nz values");
+    std::vector<R> tmp(n);
+    for (int k = 0; k < n; k++) tmp[k] = cfg.host_real_bytes == 4 ? (R)((const float *)h)[k] : (R)((const double *)h)[k];
+    for (int k = 1; k < n; k++)
+      if (!(tmp[k] > tmp[k - 1])) return fail(FPX_ERR_ARG, "set_height: heights must increase strictly");
+    HIPCHK(hipMemcpyAsync((void *)V.height, tmp.data(), n * sizeof(R), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    height_set = true;
+    return 0;
+  }
+
+  // stage one host array and repack it
+  template <typename H>
+  int pack3(const void *host, R *out, int stride, int off) {
+    const size_t n = (size_t)cfg.nxmax * cfg.nymax * cfg.nz;   // levels beyond nz are never read
+    int rc = ensure_staging(n * sizeof(H));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(H), hipMemcpyHostToDevice, stream));
+    dim3 grid((cfg.nx + 31) / 32, (cfg.nz + 31) / 32, cfg.ny), block(32, 8);
+    k_pack3<H, R><<<grid, block, 0, stream>>>((const H *)staging, out, cfg.nx, cfg.ny, cfg.nz, cfg.nxmax, cfg.nymax, stride, off);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));   // staging is reused by the next field
+    return 0;
+  }
+  template <typename H>
+  int pack2(const void *host, R *out, int stride, int off) {
+    const size_t n = (size_t)cfg.nxmax * cfg.nymax;
+    int rc = ensure_staging(n * sizeof(H));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(H), hipMemcpyHostToDevice, stream));
+    int tot = cfg.nx * cfg.ny;
+    k_pack2<H, R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>((const H *)staging, out, cfg.nx, cfg.ny, cfg.nxmax, stride, off);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  int p3(const void *host, const R *out, int stride, int off) {
+    return cfg.host_real_bytes == 4 ? pack3<float>(host, (R *)out, stride, off) : pack3<double>(host, (R *)out, stride, off);
+  }
+  int p2(const void *host, const R *out, int stride, int off) {
+    return cfg.host_real_bytes == 4 ? pack2<float>(host, (R *)out, stride, off) : pack2<double>(host, (R *)out, stride, off);
+  }
+
+  int upload_fields(int slot, const fpx_fields *f) override {
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "upload_fields: slot must be 1 or 2");
+    if (!f || !f->uu || !f->vv || !f->ww || !f->rho || !f->drhodz || !f->hmix || !f->ustar || !f->wstar || !f->oli || !f->tropopause)
+      return fail(FPX_ERR_ARG, "upload_fields: uu, vv, ww, rho, drhodz, hmix, ustar, wstar, oli, tropopause are required");
+    if ((cfg.nglobal || cfg.sglobal) && (!f->uupol || !f->vvpol)) return fail(FPX_ERR_ARG, "upload_fields: uupol/vvpol required on a grid with poles");
+    if (cfg.drydep && !f->vdep) return fail(FPX_ERR_ARG, "upload_fields: vdep required with DRYDEP");
+    if (cfg.lsettling && !f->tt) return fail(FPX_ERR_ARG, "upload_fields: tt required with lsettling");
+    const int s = slot - 1;
+    int rc;
+    if ((rc = p3(f->uu, V.w3, 6, s * 3 + 0))) return rc;
+    if ((rc = p3(f->vv, V.w3, 6, s * 3 + 1))) return rc;
+    if ((rc = p3(f->ww, V.w3, 6, s * 3 + 2))) return rc;
+    if (V.w3pol) {
+      if ((rc = p3(f->uupol, V.w3pol, 6, s * 3 + 0))) return rc;
+      if ((rc = p3(f->vvpol, V.w3pol, 6, s * 3 + 1))) return rc;
+      if ((rc = p3(f->ww, V.w3pol, 6, s * 3 + 2))) return rc;
+    }
+    if ((rc = p3(f->rho, V.r2, 4, s * 2 + 0))) return rc;
+    if ((rc = p3(f->drhodz, V.r2, 4, s * 2 + 1))) return rc;
+    if ((rc = p2(f->ustar, V.sfc, 8, s * 4 + 0))) return rc;
+    if ((rc = p2(f->wstar, V.sfc, 8, s * 4 + 1))) return rc;
+    if ((rc = p2(f->oli, V.sfc, 8, s * 4 + 2))) return rc;
+    if ((rc = p2(f->hmix, V.sfc, 8, s * 4 + 3))) return rc;
+    if (slot == 1) {   // literal time index 1 uses: advance.f90:253, get_settling.f90:83-84
+      if ((rc = p2(f->tropopause, V.tropo, 1, 0))) return rc;
+      if (V.rhott) {
+        if ((rc = p3(f->rho, V.rhott, 2, 0))) return rc;
+        if ((rc = p3(f->tt, V.rhott, 2, 1))) return rc;
+      }
+    }
+    if (V.vdep) {
+      const size_t plane = (size_t)cfg.nxmax * cfg.nymax * cfg.host_real_bytes;
+      for (int ks = 0; ks < cfg.nspec; ks++)
+        if ((rc = p2((const char *)f->vdep + plane * ks, V.vdep, 2 * cfg.nspec, s * cfg.nspec + ks))) return rc;
+    }
+    int tot = cfg.nx * cfg.ny;
+    k_hcell<R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>(V.sfc, (R *)V.hcell, cfg.nx, cfg.ny);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    slot_loaded[s] = true;
+    return 0;
+  }
+
+  int set_windtime(const int32_t mt[2], const int32_t mi[2]) override {
+    if (!mt || !mi) return fail(FPX_ERR_ARG, "set_windtime: null");
+    if ((mi[0] != 1 && mi[0] != 2) || (mi[1] != 1 && mi[1] != 2) || mi[0] == mi[1]) return fail(FPX_ERR_ARG, "set_windtime: memind must be a permutation of (1,2)");
+    if (mt[0] == mt[1]) return fail(FPX_ERR_ARG, "set_windtime: memtime(1) == memtime(2)");
+    V.memtime0 = mt[0]; V.memtime1 = mt[1]; V.m1 = mi[0] - 1; V.m2 = mi[1] - 1;
+    V.lwindinterv = std::abs(mt[1] - mt[0]);
+    window_set = true;
+    return 0;
+  }
+
+  // ---- RNG -----------------------------------------------------------------
+  int rng_fill_table() override {
+    const int n = V.maxrand;
+    std::vector<R> t(n);
+    if (cfg.host_real_bytes == 4) { rng4 = HostRng<float>(); rng4.fill_table(tab4, n); for (int i = 0; i < n; i++) t[i] = (R)tab4[i]; }
+    else { rng8 = HostRng<double>(); rng8.fill_table(tab8, n); for (int i = 0; i < n; i++) t[i] = (R)tab8[i]; }
+    HIPCHK(hipMemcpyAsync((void *)V.rannumb, t.data(), n * sizeof(R), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    table_set = true;
+    return 0;
+  }
+  int rng_set_table(const void *tab, int n) override {
+    if (!tab || n != V.maxrand) return fail(FPX_ERR_ARG, "rng_set_table: need maxrand = 1000000 values");
+    std::vector<R> t(n);
+    tab4.clear(); tab8.clear();
+    if (cfg.host_real_bytes == 4) { tab4.assign((const float *)tab, (const float *)tab + n); for (int i = 0; i < n; i++) t[i] = (R)tab4[i]; }
+    else { tab8.assign((const double *)tab, (const double *)tab + n); for (int i = 0; i < n; i++) t[i] = (R)tab8[i]; }
+    HIPCHK(hipMemcpyAsync((void *)V.rannumb, t.data(), n * sizeof(R), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    table_set = true;
+    return 0;
+  }
+  int rng_get_table(void *out, int n) override {
+    if (!out || n != V.maxrand || !table_set) return fail(FPX_ERR_ARG, "rng_get_table: no table / bad size");
+    if (cfg.host_real_bytes == 4) memcpy(out, tab4.data(), n * sizeof(float));
+    else memcpy(out, tab8.data(), n * sizeof(double));
+    return 0;
+  }
+
+  // ---- particles -----------------------------------------------------------
+  template <typename H, typename D>
+  int put(const H *host, D *dev, long long first, long long count) {
+    int rc = ensure_staging((size_t)count * sizeof(H));
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(staging, host, (size_t)count * sizeof(H), hipMemcpyHostToDevice, stream));
+    k_scatter_in<H, D><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>((const H *)staging, dev, slot_of_pid, first, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  template <typename H, typename D>
+  int get(H *host, const D *dev, long long first, long long count) {
+    int rc = ensure_staging((size_t)count * sizeof(H));
+    if (rc) return rc;
+    k_gather_out<D, H><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dev, (H *)staging, slot_of_pid, first, count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host, staging, (size_t)count * sizeof(H), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  template <typename D>
+  int fill(D *dev, D val, long long first, long long count) {
+    k_fill<D><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dev, val, first, count, slot_of_pid);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int put_real(const void *host, R *dev, long long first, long long count) {
+    if (!host) return fill<R>(dev, (R)0, first, count);
+    return cfg.host_real_bytes == 4 ? put<float, R>((const float *)host, dev, first, count) : put<double, R>((const double *)host, dev, first, count);
+  }
+  int get_real(void *host, const R *dev, long long first, long long count) {
+    if (!host) return 0;
+    return cfg.host_real_bytes == 4 ? get<float, R>((float *)host, dev, first, count) : get<double, R>((double *)host, dev, first, count);
+  }
+
+  int upload_particles(long long first, long long count, const fpx_particles *p) override {
+    if (!p || first < 0 || count < 0 || first + count > P.cap) return fail(FPX_ERR_ARG, "upload_particles: range outside capacity");
+    if (count == 0) return 0;
+    if (!p->xtra1 || !p->ytra1 || !p->ztra1 || !p->itra1) return fail(FPX_ERR_ARG, "upload_particles: xtra1, ytra1, ztra1, itra1 are required");
+    int rc;
+    if ((rc = put<double, double>(p->xtra1, P.xt, first, count))) return rc;
+    if ((rc = put<double, double>(p->ytra1, P.yt, first, count))) return rc;
+    if ((rc = put_real(p->ztra1, P.zt, first, count))) return rc;
+    if ((rc = put_real(p->uap, P.up, first, count))) return rc;
+    if ((rc = put_real(p->ucp, P.vp, first, count))) return rc;
+    if ((rc = put_real(p->uzp, P.wp, first, count))) return rc;
+    if ((rc = put_real(p->us, P.us, first, count))) return rc;
+    if ((rc = put_real(p->vs, P.vs, first, count))) return rc;
+    if ((rc = put_real(p->ws, P.ws, first, count))) return rc;
+    if ((rc = put<int, int>(p->itra1, P.itra1, first, count))) return rc;
+    if (p->itramem) { if ((rc = put<int, int>(p->itramem, P.itramem, first, count))) return rc; } else if ((rc = fill<int>(P.itramem, 0, first, count))) return rc;
+    if (p->idt) { if ((rc = put<int, int>(p->idt, P.idt, first, count))) return rc; } else if ((rc = fill<int>(P.idt, 0, first, count))) return rc;
+    if (p->npoint) { if ((rc = put<int, int>(p->npoint, P.npoint, first, count))) return rc; } else if ((rc = fill<int>(P.npoint, 1, first, count))) return rc;
+    if (p->nclass) { if ((rc = put<int, int>(p->nclass, P.nclass, first, count))) return rc; } else if ((rc = fill<int>(P.nclass, 1, first, count))) return rc;
+    if (p->cbt) { if ((rc = put<short, short>(p->cbt, P.cbt, first, count))) return rc; } else if ((rc = fill<short>(P.cbt, (short)1, first, count))) return rc;
+    for (int ks = 0; ks < cfg.nspec; ks++) {
+      R *dst = P.xmass1 + (size_t)ks * P.cap;
+      if (p->xmass1) {
+        const char *src = (const char *)p->xmass1 + (size_t)ks * p->xmass1_ld * cfg.host_real_bytes;
+        if ((rc = put_real(src, dst, first, count))) return rc;
+      } else if ((rc = fill<R>(dst, (R)1, first, count))) return rc;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    numpart = std::max(numpart, first + count);
+    return 0;
+  }
+
+  int download_particles(long long first, long long count, const fpx_particles *p) override {
+    if (!p || first < 0 || count < 0 || first + count > P.cap) return fail(FPX_ERR_ARG, "download_particles: range outside capacity");
+    if (count == 0) return 0;
+    int rc;
+    if (p->xtra1 && (rc = get<double, double>(p->xtra1, P.xt, first, count))) return rc;
+    if (p->ytra1 && (rc = get<double, double>(p->ytra1, P.yt, first, count))) return rc;
+    if ((rc = get_real(p->ztra1, P.zt, first, count))) return rc;
+    if ((rc = get_real(p->uap, P.up, first, count))) return rc;
+    if ((rc = get_real(p->ucp, P.vp, first, count))) return rc;
+    if ((rc = get_real(p->uzp, P.wp, first, count))) return rc;
+    if ((rc = get_real(p->us, P.us, first, count))) return rc;
+    if ((rc = get_real(p->vs, P.vs, first, count))) return rc;
+    if ((rc = get_real(p->ws, P.ws, first, count))) return rc;
+    if (p->itra1 && (rc = get<int, int>(p->itra1, P.itra1, first, count))) return rc;
+    if (p->itramem && (rc = get<int, int>(p->itramem, P.itramem, first, count))) return rc;
+    if (p->idt && (rc = get<int, int>(p->idt, P.idt, first, count))) return rc;
+    if (p->npoint && (rc = get<int, int>(p->npoint, P.npoint, first, count))) return rc;
+    if (p->nclass && (rc = get<int, int>(p->nclass, P.nclass, first, count))) return rc;
+    if (p->cbt && (rc = get<short, short>(p->cbt, P.cbt, first, count))) return rc;
+    if (p->xmass1)
+      for (int ks = 0; ks < cfg.nspec; ks++) {
+        char *dst = (char *)p->xmass1 + (size_t)ks * p->xmass1_ld * cfg.host_real_bytes;
+        if ((rc = get_real(dst, P.xmass1 + (size_t)ks * P.cap, first, count))) return rc;
+      }
+    return 0;
+  }
+
+  int set_numpart(long long n) override {
+    if (n < 0 || n > P.cap) return fail(FPX_ERR_ARG, "set_numpart: outside capacity");
+    numpart = n;
+    return 0;
+  }
+
+  int seed_particles(long long n, unsigned long long seed, double frac_pbl, double zmax, double lat_margin, int itime0) override {
+    if (n < 1 || n > P.cap) return fail(FPX_ERR_ARG, "seed_particles: n outside capacity");
+    if (!slot_loaded[0] || !slot_loaded[1]) return fail(FPX_ERR_STATE, "seed_particles: upload both field slots first (mixing heights are needed)");
+    k_seed<R><<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, P, n, seed, frac_pbl, zmax, lat_margin, itime0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    slot_of_pid = nullptr;
+    numpart = n;
+    return 0;
+  }
+
+  // ---- TABLE_SEQ: per-step start indices in the reference's serial order -----
+  int prepare_seq(int itime) {
+    const long long n = numpart;
+    int rc;
+    if (!d_flags) {
+      const size_t cap = (size_t)P.cap;
+      if ((rc = dalloc(&d_flags, cap))) return rc;
+      if ((rc = dalloc(&d_nrand_adv, cap))) return rc;
+      if ((rc = dalloc(&d_nrand_init, cap))) return rc;
+      if ((rc = dalloc(&d_dcas4, cap))) return rc;
+      if ((rc = dalloc(&d_dcas14, cap))) return rc;
+      if ((rc = dalloc(&d_dcas8, cap))) return rc;
+      if ((rc = dalloc(&d_dcas18, cap))) return rc;
+    }
+    h_flags.resize(n); h_nrand_adv.assign(n, 1); h_nrand_init.assign(n, 1);
+    h_dcas4.assign(n, 0.f); h_dcas14.assign(n, 0.f); h_dcas8.assign(n, 0.); h_dcas18.assign(n, 0.);
+    k_classify<R><<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, P, n, itime, d_flags);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_flags.data(), d_flags, n, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    // walk the particles in index order exactly as the serial loop does
+    // (timemanager.f90:531-611): [initialize: ran3 -> nrand, (ran3, gasdev)] then advance: ran3 -> nrand
+    const bool h4 = cfg.host_real_bytes == 4;
+    for (long long j = 0; j < n; j++) {
+      unsigned char f = h_flags[j];
+      if (!(f & 1)) continue;
+      if (f & 2) {
+        if (h4) {
+          h_nrand_init[j] = rng4.start_index(rng4.idummy_init, V.maxrand);
+          if (f & 4) { h_dcas4[j] = rng4.ran3(rng4.idummy_init); h_dcas14[j] = rng4.gasdev(rng4.idummy_init); }
+        } else {
+          h_nrand_init[j] = rng8.start_index(rng8.idummy_init, V.maxrand);
+          if (f & 4) { h_dcas8[j] = rng8.ran3(rng8.idummy_init); h_dcas18[j] = rng8.gasdev(rng8.idummy_init); }
+        }
+      }
+      h_nrand_adv[j] = h4 ? rng4.start_index(rng4.idummy_adv, V.maxrand) : rng8.start_index(rng8.idummy_adv, V.maxrand);
+    }
+    if (h4) for (long long j = 0; j < n; j++) { h_dcas8[j] = h_dcas4[j]; h_dcas18[j] = h_dcas14[j]; }
+    else for (long long j = 0; j < n; j++) { h_dcas4[j] = (float)h_dcas8[j]; h_dcas14[j] = (float)h_dcas18[j]; }
+    HIPCHK(hipMemcpyAsync(d_nrand_adv, h_nrand_adv.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_nrand_init, h_nrand_init.data(), n * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_dcas4, h_dcas4.data(), n * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_dcas14, h_dcas14.data(), n * sizeof(float), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_dcas8, h_dcas8.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_dcas18, h_dcas18.data(), n * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // ---- the step --------------------------------------------------------------
+  int step(int itime, fpx_step_stats *out, bool async) override {
+    if (!height_set || !window_set || !slot_loaded[0] || !slot_loaded[1]) return fail(FPX_ERR_STATE, "step: height, both field slots and the wind-time window must be set first");
+    if (cfg.rng_mode != FPX_RNG_PHILOX && !table_set) return fail(FPX_ERR_STATE, "step: the table RNG modes need fpx_rng_fill_table/fpx_rng_set_table");
+    if (V.memtime0 == V.memtime1) return fail(FPX_ERR_STATE, "step: empty wind-time window");
+    if (out) memset(out, 0, sizeof(*out));
+    if (numpart == 0) return 0;
+    if (cfg.sort_interval > 0 && step_counter > 0 && step_counter % (unsigned)cfg.sort_interval == 0) {
+      int rc = sort_particles();
+      if (rc) return rc;
+    }
+    SeqRng S;
+    memset(&S, 0, sizeof(S));
+    if (cfg.rng_mode == FPX_RNG_TABLE_SEQ) {
+      int rc = prepare_seq(itime);
+      if (rc) return rc;
+      S.nrand_adv = d_nrand_adv; S.nrand_init = d_nrand_init;
+      S.cbl_dcas = d_dcas4; S.cbl_dcas1 = d_dcas14; S.cbl_dcas_d = d_dcas8; S.cbl_dcas1_d = d_dcas18;
+    }
+    HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(Stats), stream));
+    if (ev_used == ev_pool.size()) {
+      hipEvent_t a, b;
+      HIPCHK(hipEventCreate(&a));
+      HIPCHK(hipEventCreate(&b));
+      ev_pool.emplace_back(a, b);
+    }
+    auto &ev = ev_pool[ev_used++];
+    const int nb = (int)((numpart + kBlock - 1) / kBlock);
+    HIPCHK(hipEventRecord(ev.first, stream));
+    k_advance<R><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats);
+    HIPCHK(hipEventRecord(ev.second, stream));
+    HIPCHK(hipGetLastError());
+    step_counter++;
+    if (async) return 0;
+    Stats hs;
+    HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(Stats), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (out) {
+      out->n_due = (int64_t)hs.n_due; out->n_initialized = (int64_t)hs.n_init; out->n_left_domain = (int64_t)hs.n_left;
+      out->n_min_mass = (int64_t)hs.n_minmass; out->n_max_age = (int64_t)hs.n_maxage; out->nan_count = (int64_t)hs.nan_count;
+      out->nan_count2 = (int64_t)hs.nan_count2; out->n_bad_position = (int64_t)hs.n_badpos;
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+      out->kernel_ms = ms;
+    }
+    return 0;
+  }
+
+  int sync() override {
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  int kernel_time(double *ms, long long *launches, int reset) override {
+    HIPCHK(hipStreamSynchronize(stream));
+    for (size_t i = 0; i < ev_used; i++) {
+      float t = 0;
+      HIPCHK(hipEventElapsedTime(&t, ev_pool[i].first, ev_pool[i].second));
+      acc_ms += t;
+      acc_launches++;
+    }
+    ev_used = 0;
+    if (ms) *ms = acc_ms;
+    if (launches) *launches = acc_launches;
+    if (reset) { acc_ms = 0; acc_launches = 0; }
+    return 0;
+  }
+
+  int sort_particles() override { return 0; }   // locality sort: see fpx_sort (next milestone)
+
+  void *stream_ptr() override { return (void *)stream; }
+};
+
+}  // namespace fpx
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+struct fpx_engine {
+  fpx::EngineBase *impl;
+};
+
+#define FPX_GUARD(h)                                                   \
+  if (!(h) || !(h)->impl) return fpx::fail(FPX_ERR_ARG, "null handle")
+
+extern "C" {
+
+int fpx_abi_version(void) { return 1; }
+const char *fpx_last_error(void) { return fpx::g_err.c_str(); }
+
+int fpx_create(fpx_handle *out, const fpx_config *cfg) {
+  if (!out || !cfg) return fpx::fail(FPX_ERR_ARG, "fpx_create: null argument");
+  *out = nullptr;
+  if (cfg->struct_bytes != (int32_t)sizeof(fpx_config)) return fpx::fail(FPX_ERR_ARG, "fpx_create: fpx_config size mismatch (ABI)");
+  if (cfg->host_real_bytes != 4 && cfg->host_real_bytes != 8) return fpx::fail(FPX_ERR_ARG, "fpx_create: host_real_bytes must be 4 or 8");
+  if (cfg->rng_mode < 0 || cfg->rng_mode > 2) return fpx::fail(FPX_ERR_ARG, "fpx_create: bad rng_mode");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fpx::fail(FPX_ERR_DEVICE, "fpx_create: no HIP device visible");
+  if (cfg->device < 0 || cfg->device >= ndev) return fpx::fail(FPX_ERR_ARG, "fpx_create: device ordinal out of range");
+  fpx::EngineBase *e = nullptr;
+  int rc;
+  if (cfg->compute_real_bytes == 8) {
+    auto *p = new (std::nothrow) fpx::Engine<double>();
+    if (!p) return fpx::fail(FPX_ERR_NOMEM, "fpx_create: out of host memory");
+    rc = p->init(cfg);
+    e = p;
+  } else if (cfg->compute_real_bytes == 4) {
+    auto *p = new (std::nothrow) fpx::Engine<float>();
+    if (!p) return fpx::fail(FPX_ERR_NOMEM, "fpx_create: out of host memory");
+    rc = p->init(cfg);
+    e = p;
+  } else {
+    return fpx::fail(FPX_ERR_ARG, "fpx_create: compute_real_bytes must be 4 or 8");
+  }
+  if (rc) { delete e; return rc; }
+  fpx_engine *h = new (std::nothrow) fpx_engine{e};
+  if (!h) { delete e; return fpx::fail(FPX_ERR_NOMEM, "fpx_create: out of host memory"); }
+  *out = h;
+  return FPX_OK;
+}
+
+int fpx_destroy(fpx_handle h) {
+  if (!h) return FPX_OK;
+  delete h->impl;
+  delete h;
+  return FPX_OK;
+}
+
+int fpx_set_height(fpx_handle h, const void *height, int32_t n) { FPX_GUARD(h); return h->impl->set_height(height, n); }
+int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f) { FPX_GUARD(h); return h->impl->upload_fields(slot, f); }
+int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]) { FPX_GUARD(h); return h->impl->set_windtime(memtime, memind); }
+int fpx_rng_fill_table(fpx_handle h) { FPX_GUARD(h); return h->impl->rng_fill_table(); }
+int fpx_rng_set_table(fpx_handle h, const void *t, int32_t n) { FPX_GUARD(h); return h->impl->rng_set_table(t, n); }
+int fpx_rng_get_table(fpx_handle h, void *t, int32_t n) { FPX_GUARD(h); return h->impl->rng_get_table(t, n); }
+int fpx_upload_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p) { FPX_GUARD(h); return h->impl->upload_particles(first, count, p); }
+int fpx_download_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p) { FPX_GUARD(h); return h->impl->download_particles(first, count, p); }
+int fpx_set_numpart(fpx_handle h, int64_t n) { FPX_GUARD(h); return h->impl->set_numpart(n); }
+int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *st) { FPX_GUARD(h); return h->impl->step(itime, st, false); }
+int fpx_step_async(fpx_handle h, int32_t itime) { FPX_GUARD(h); return h->impl->step(itime, nullptr, true); }
+int fpx_sync(fpx_handle h) { FPX_GUARD(h); return h->impl->sync(); }
+int fpx_kernel_time(fpx_handle h, double *ms, int64_t *launches, int32_t reset) {
+  FPX_GUARD(h);
+  long long l = 0;
+  int rc = h->impl->kernel_time(ms, &l, reset);
+  if (launches) *launches = l;
+  return rc;
+}
+int fpx_sort_particles(fpx_handle h) { FPX_GUARD(h); return h->impl->sort_particles(); }
+int fpx_seed_particles(fpx_handle h, int64_t n, uint64_t seed, double frac_pbl, double zmax, double lat_margin_cells, int32_t itime0) {
+  FPX_GUARD(h);
+  return h->impl->seed_particles(n, seed, frac_pbl, zmax, lat_margin_cells, itime0);
+}
+void *fpx_stream(fpx_handle h) { return (h && h->impl) ? h->impl->stream_ptr() : nullptr; }
+
+}  // extern "C"

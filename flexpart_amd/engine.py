@@ -1,0 +1,236 @@
+"""Host-side mirror of the reference's particle loop, on top of the C ABI.
+
+`Engine` plays the role of the Fortran host around the replaced block
+(reference src/timemanager.f90:531-712): it owns com_mod-shaped host arrays,
+hands them to the GPU engine through include/flexpart_amd.h, and exposes the
+same vocabulary (xtra1, ytra1, ztra1, uap, ucp, uzp, us, vs, ws, idt, itra1,
+itramem, cbt, xmass1; memtime/memind; lsynctime ...).  All arithmetic happens
+in the HIP library; nothing here computes trajectories.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (FpxConfig, FpxFields, FpxParticles, FpxStepStats, RNG_PHILOX, RNG_TABLE_COUNTER,
+                   RNG_TABLE_SEQ, check)
+
+# polar stereographic set-up is host work in the reference (gridcheck_ecmwf.f90:341-366 via
+# cmapf_mod stlmbr/stcm2p); the engine only consumes the resulting 9-number map records.
+SWITCHNORTH, SWITCHSOUTH = 75.0, -75.0
+
+
+def _vp(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Engine:
+    def __init__(self, sc, *, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ,
+                 seed=0x5EED, max_particles=None, device=0, pad=(0, 0, 0), sort_interval=0,
+                 polemaps=None):
+        """sc: scenario dict (flexpart_amd.synthetic).  pad: extra allocated (nxmax-nx,
+        nymax-ny, nzmax-nz) to exercise the reference's padded-array convention."""
+        self.lib = _lib.load()
+        self.sc = sc
+        self.hreal = np.float32 if host_real_bytes == 4 else np.float64
+        nx, ny, nz = (int(v) for v in sc["grid"])
+        self.nx, self.ny, self.nz = nx, ny, nz
+        self.nxmax, self.nymax, self.nzmax = nx + pad[0], ny + pad[1], nz + pad[2]
+        dx, dy, xlon0, ylat0 = (float(v) for v in sc["geom"])
+        xg, ng, sg = (int(v) for v in sc["globalflags"])
+        nspec = int(sc["nspec"])
+        self.nspec = nspec
+        n = int(sc.get("npart", 0))
+        cfg = FpxConfig()
+        cfg.struct_bytes = C.sizeof(FpxConfig)
+        cfg.device = device
+        cfg.compute_real_bytes = compute_real_bytes
+        cfg.host_real_bytes = host_real_bytes
+        cfg.max_particles = int(max_particles or max(n, 1))
+        cfg.nx, cfg.ny, cfg.nz, cfg.nmixz = nx, ny, nz, int(sc["nmixz"])
+        cfg.nxmax, cfg.nymax, cfg.nzmax = self.nxmax, self.nymax, self.nzmax
+        cfg.dx, cfg.dy, cfg.xlon0, cfg.ylat0 = dx, dy, xlon0, ylat0
+        cfg.xglobal, cfg.nglobal, cfg.sglobal = xg, ng, sg
+        rt = self.hreal
+        # (switchnorth-ylat0)/dy in the host's default real kind, gridcheck_ecmwf.f90:348,362
+        cfg.switchnorthg = float((rt(SWITCHNORTH) - rt(ylat0)) / rt(dy)) if ng else 999999.0
+        cfg.switchsouthg = float((rt(SWITCHSOUTH) - rt(ylat0)) / rt(dy)) if sg else 999999.0
+        if ng or sg:
+            if polemaps is None:
+                raise ValueError("a grid with poles needs the host's northpolemap/southpolemap records")
+            for i in range(9):
+                cfg.northpolemap[i] = float(polemaps[0][i])
+                cfg.southpolemap[i] = float(polemaps[1][i])
+        for k in ("ldirect", "lsynctime", "method", "mintime", "ifine", "turbswitch", "cblflag",
+                  "mdomainfill", "lsettling"):
+            setattr(cfg, k, int(sc[k]))
+        cfg.ctl = float(sc["ctl"])
+        cfg.d_trop, cfg.d_strat, cfg.turbmesoscale = (float(v) for v in sc["turbpar"])
+        cfg.nspec = nspec
+        cfg.maxspec = nspec
+        cfg.drydep = int(sc["drydep"])
+        for i in range(nspec):
+            cfg.drydepspec[i] = int(np.asarray(sc["drydepspec"]).ravel()[i])
+            cfg.density[i] = float(sc["density"][i]); cfg.dquer[i] = float(sc["dquer"][i])
+            cfg.vsetaver[i] = float(sc["vsetaver"][i]); cfg.cunningham[i] = float(sc["cunningham"][i])
+            cfg.decay[i] = float(sc["decay"][i])
+            cfg.xmass_release[i] = float(np.asarray(sc.get("xmass", np.ones(nspec))).ravel()[i])
+        cfg.npart_release = max(n, 1)
+        cfg.lage_last = int(np.asarray(sc["lage"]).ravel()[-1])
+        cfg.rng_mode = rng_mode
+        cfg.seed = seed
+        cfg.sort_interval = sort_interval
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        check(self.lib.fpx_create(C.byref(self.h), C.byref(cfg)), "fpx_create")
+        hgt = np.ascontiguousarray(np.asarray(sc["height"]).astype(rt))
+        check(self.lib.fpx_set_height(self.h, _vp(hgt), nz), "fpx_set_height")
+        self.itime = int(sc.get("itime0", 0))
+        self.lsynctime = int(sc["lsynctime"])
+        self.n = 0
+        if rng_mode != RNG_PHILOX:
+            check(self.lib.fpx_rng_fill_table(self.h), "fpx_rng_fill_table")
+        if "uu" in sc:
+            self.upload_fields_from_scenario(sc)
+        if n:
+            self.upload_particles_from_scenario(sc)
+
+    # ---- met fields ---------------------------------------------------------
+    def _host3(self, a, m):
+        """slot m of a compact (2,nz,ny,nx) array -> com_mod-shaped padded host array."""
+        out = np.zeros((self.nzmax, self.nymax, self.nxmax), self.hreal)
+        out[: self.nz, : self.ny, : self.nx] = a[m]
+        return out
+
+    def _host2(self, a, m):
+        out = np.zeros((self.nymax, self.nxmax), self.hreal)
+        out[: self.ny, : self.nx] = a[m]
+        return out
+
+    def upload_fields_from_scenario(self, sc):
+        for m in (0, 1):
+            keep = {}
+            f = FpxFields()
+            for k in ("uu", "vv", "ww", "uupol", "vvpol", "rho", "drhodz", "tt"):
+                if k in sc:
+                    keep[k] = self._host3(sc[k], m)
+                    setattr(f, k, keep[k].ctypes.data)
+            for k in ("hmix", "ustar", "wstar", "oli", "tropopause"):
+                keep[k] = self._host2(sc[k], m)
+                setattr(f, k, keep[k].ctypes.data)
+            if "vdep" in sc:
+                v = np.zeros((self.nspec, self.nymax, self.nxmax), self.hreal)
+                v[:, : self.ny, : self.nx] = sc["vdep"][m]
+                keep["vdep"] = v
+                f.vdep = v.ctypes.data
+            check(self.lib.fpx_upload_fields(self.h, m + 1, C.byref(f)), "fpx_upload_fields")
+        self.set_windtime(sc["memtime"], sc["memind"])
+
+    def set_windtime(self, memtime, memind):
+        mt = (C.c_int32 * 2)(int(memtime[0]), int(memtime[1]))
+        mi = (C.c_int32 * 2)(int(memind[0]), int(memind[1]))
+        check(self.lib.fpx_set_windtime(self.h, mt, mi), "fpx_set_windtime")
+
+    # ---- particles ----------------------------------------------------------
+    def upload_particles_from_scenario(self, sc, first=0):
+        n = int(sc["npart"])
+        rt = self.hreal
+        keep = {}
+        p = FpxParticles()
+
+        def put(name, key, dtype):
+            if key in sc:
+                keep[name] = np.ascontiguousarray(np.asarray(sc[key]).astype(dtype))
+                setattr(p, name, keep[name].ctypes.data)
+        put("xtra1", "xtra1", np.float64); put("ytra1", "ytra1", np.float64); put("ztra1", "ztra1", rt)
+        for k in ("uap", "ucp", "uzp", "us", "vs", "ws"):
+            put(k, k, rt)
+        for k in ("itra1", "itramem", "idt", "npoint", "nclass"):
+            put(k, k, np.int32)
+        put("cbt", "cbt", np.int16)
+        if "xmass1" in sc:
+            keep["xmass1"] = np.ascontiguousarray(np.asarray(sc["xmass1"]).astype(rt).reshape(self.nspec, n))
+            p.xmass1 = keep["xmass1"].ctypes.data
+            p.xmass1_ld = n
+        check(self.lib.fpx_upload_particles(self.h, first, n, C.byref(p)), "fpx_upload_particles")
+        self.n = max(self.n, first + n)
+
+    def seed_particles(self, n, seed=0x5EED, frac_pbl=0.5, zmax=12000.0, lat_margin_cells=None, itime0=0):
+        if lat_margin_cells is None:
+            lat_margin_cells = 0.03 * (self.ny - 1)
+        check(self.lib.fpx_seed_particles(self.h, n, seed, frac_pbl, zmax, lat_margin_cells, itime0),
+              "fpx_seed_particles")
+        self.n = n
+
+    def download(self, first=0, count=None):
+        n = self.n - first if count is None else count
+        rt = self.hreal
+        out = dict(xtra1=np.empty(n, np.float64), ytra1=np.empty(n, np.float64), ztra1=np.empty(n, rt),
+                   uap=np.empty(n, rt), ucp=np.empty(n, rt), uzp=np.empty(n, rt), us=np.empty(n, rt),
+                   vs=np.empty(n, rt), ws=np.empty(n, rt), itra1=np.empty(n, np.int32),
+                   itramem=np.empty(n, np.int32), idt=np.empty(n, np.int32), npoint=np.empty(n, np.int32),
+                   nclass=np.empty(n, np.int32), cbt=np.empty(n, np.int16),
+                   xmass1=np.empty((self.nspec, n), rt))
+        p = FpxParticles()
+        for k, a in out.items():
+            setattr(p, k, a.ctypes.data)
+        p.xmass1_ld = n
+        check(self.lib.fpx_download_particles(self.h, first, n, C.byref(p)), "fpx_download_particles")
+        res = {k: (v.astype(np.float64) if v.dtype.kind == "f" else v.astype(np.int32)) for k, v in out.items()}
+        return res
+
+    # ---- the loop body --------------------------------------------------------
+    def step(self, itime=None):
+        """One pass of the particle loop at `itime` (default: the engine's clock)."""
+        if itime is None:
+            itime = self.itime
+        st = FpxStepStats()
+        check(self.lib.fpx_step(self.h, int(itime), C.byref(st)), "fpx_step")
+        self.itime = int(itime) + self.lsynctime
+        return {k: getattr(st, k) for k, _ in FpxStepStats._fields_}
+
+    def step_async(self, itime=None):
+        if itime is None:
+            itime = self.itime
+        check(self.lib.fpx_step_async(self.h, int(itime)), "fpx_step_async")
+        self.itime = int(itime) + self.lsynctime
+
+    def sync(self):
+        check(self.lib.fpx_sync(self.h), "fpx_sync")
+
+    def kernel_time(self, reset=False):
+        ms = C.c_double(0)
+        ln = C.c_int64(0)
+        check(self.lib.fpx_kernel_time(self.h, C.byref(ms), C.byref(ln), int(reset)), "fpx_kernel_time")
+        return ms.value, ln.value
+
+    def sort(self):
+        check(self.lib.fpx_sort_particles(self.h), "fpx_sort_particles")
+
+    def rannumb(self):
+        a = np.empty(1000000, self.hreal)
+        check(self.lib.fpx_rng_get_table(self.h, _vp(a), 1000000), "fpx_rng_get_table")
+        return a
+
+    def run(self, nsteps=None):
+        out = []
+        for _ in range(int(self.sc["nsteps"]) if nsteps is None else nsteps):
+            self.step()
+            out.append(self.download())
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.fpx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+__all__ = ["Engine", "RNG_TABLE_SEQ", "RNG_TABLE_COUNTER", "RNG_PHILOX"]

@@ -1,0 +1,193 @@
+/*
+ * flexpart_amd.h -- C ABI of the MI355X particle-advection engine.
+ *
+ * Drop-in boundary for ONE path of MeteoSwiss/flexpart: the per-particle loop
+ * of the time manager (reference src/timemanager.f90:531-712, MPI twin
+ * src/timemanager_mpi.f90:674-856), i.e. for every particle that is due:
+ *     initialize()  (src/initialize.f90:4)   when newly released
+ *     advance()     (src/advance.f90:4)      one lsynctime of motion
+ *     epilogue      (src/timemanager.f90:630-708: reschedule / terminate,
+ *                    decay and dry-deposition mass split)
+ * plus the concentration sampling loop conccalc() (src/conccalc.f90:4).
+ *
+ * The reference has no FFI for this path: state is passed implicitly through
+ * Fortran modules (com_mod, par_mod, interpol_mod, hanna_mod).  Every entry
+ * point below therefore names the module variables it replaces.  All entry
+ * points are extern "C", take plain pointers and sizes, return 0 on success or
+ * a negative fpx_status, never throw and never call exit/stop.  A handle owns
+ * all device memory; the caller owns every host array and may reuse it as soon
+ * as a call returns.  Calls on one handle must be serialised by the caller
+ * (the reference's time manager is single-threaded); use one handle per GPU.
+ *
+ * Host arrays keep the reference's conventions: column-major, x fastest,
+ * 0-based x/y extents allocated with stride nxmax/nymax (NOT nx/ny), 1-based
+ * levels with stride nzmax, species-major xmass1(maxpart, maxspec).
+ * `host_real_bytes` states the caller's default real kind: 4 for the reference
+ * as its makefile builds it, 8 for a -fdefault-real-8 build.  xtra1/ytra1 are
+ * always 8-byte reals (com_mod.f90:680), cbt is integer(kind=2) (com_mod.f90:695).
+ */
+#ifndef FLEXPART_AMD_H
+#define FLEXPART_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FPX_MAXSPEC 5          /* par_mod.f90:211 maxspec  */
+#define FPX_MAXNESTS 4
+#define FPX_DEAD (-999999999)  /* itra1 of a terminated particle, FLEXPART.f90:315-317 */
+
+typedef struct fpx_engine *fpx_handle;
+
+typedef enum {
+  FPX_OK = 0,
+  FPX_ERR_ARG = -1,        /* bad argument / inconsistent sizes            */
+  FPX_ERR_DEVICE = -2,     /* HIP runtime error (message via fpx_last_error) */
+  FPX_ERR_STATE = -3,      /* call order violated (e.g. step before fields) */
+  FPX_ERR_NOMEM = -4,
+  FPX_ERR_UNSUPPORTED = -5
+} fpx_status;
+
+/* RNG modes.  TABLE_SEQ reproduces the reference bit-for-bit: the 1e6-entry
+ * Gaussian table rannumb (com_mod.f90:744, filled as FLEXPART.f90:56-59) and a
+ * start index per particle-step drawn from the shared sequential ran3 stream
+ * in particle order (advance.f90:153, initialize.f90:68).  TABLE_COUNTER keeps
+ * the table but draws the start index from a counter-based generator keyed on
+ * (seed, particle id, step) -- order-independent, hence shardable.  PHILOX
+ * replaces the table by Philox4x32-10 + clipped Box-Muller per draw. */
+typedef enum { FPX_RNG_TABLE_SEQ = 0, FPX_RNG_TABLE_COUNTER = 1, FPX_RNG_PHILOX = 2 } fpx_rng_mode;
+
+typedef struct {
+  int32_t struct_bytes;      /* = sizeof(fpx_config), ABI check                        */
+  int32_t device;            /* HIP device ordinal                                     */
+  int32_t compute_real_bytes;/* 8: all-fp64 arithmetic; 4: reference typing (f32, xy f64) */
+  int32_t host_real_bytes;   /* default real kind of the host arrays (4 or 8)          */
+  int64_t max_particles;     /* capacity (com_mod_allocate_part(nmpart), com_mod.f90:782) */
+  /* grid: com_mod.f90:298-299 nx,ny,nz,nmixz,dx,dy,xlon0,ylat0; par_mod.f90:144 maxima */
+  int32_t nx, ny, nz, nmixz;
+  int32_t nxmax, nymax, nzmax;
+  double dx, dy, xlon0, ylat0;
+  /* com_mod.f90:551-560 */
+  int32_t xglobal, nglobal, sglobal;
+  double switchnorthg, switchsouthg;
+  double northpolemap[9], southpolemap[9];
+  /* run switches: com_mod.f90:56-77,112,144,188; derived in readcommand.f90:244-272,379-385 */
+  int32_t ldirect, lsynctime, method, mintime, ifine, turbswitch, cblflag, mdomainfill, lsettling;
+  double ctl;                /* com_mod ctl, i.e. already 1/CTL                         */
+  double d_trop, d_strat, turbmesoscale;   /* par_mod.f90:79                           */
+  /* species: com_mod.f90:170-189,589 ; point_mod xmass(1,:), npart(1) */
+  int32_t nspec, maxspec;    /* maxspec = species stride count of host xmass1           */
+  int32_t drydep, drydepspec[FPX_MAXSPEC];
+  double density[FPX_MAXSPEC], dquer[FPX_MAXSPEC], vsetaver[FPX_MAXSPEC], cunningham[FPX_MAXSPEC];
+  double decay[FPX_MAXSPEC];
+  double xmass_release[FPX_MAXSPEC];
+  int32_t npart_release;
+  int32_t lage_last;         /* lage(nageclass), com_mod.f90:129                        */
+  /* RNG */
+  int32_t rng_mode;          /* fpx_rng_mode                                            */
+  uint64_t seed;             /* counter modes                                           */
+  /* locality: re-sort particles by grid cell every `sort_interval` steps (0 = never) */
+  int32_t sort_interval;
+  int32_t reserved[7];
+} fpx_config;
+
+/* One time slot of the met fields the path gathers from (com_mod.f90:355-371,
+ * 423-451).  Each pointer addresses element (0,0,1,slot) of the host array,
+ * e.g. c_loc(uu(0,0,1,memind(k))) -- strides nxmax, nymax, nzmax as declared
+ * in fpx_config.  NULL is allowed for fields a configuration never reads
+ * (uupol/vvpol without poles, tt without settling, vdep without DRYDEP). */
+typedef struct {
+  const void *uu, *vv, *ww, *uupol, *vvpol, *rho, *drhodz, *tt;   /* (nxmax,nymax,nzmax)  */
+  const void *hmix, *ustar, *wstar, *oli, *tropopause;            /* (nxmax,nymax)        */
+  const void *vdep;                                               /* (nxmax,nymax,maxspec)*/
+} fpx_fields;
+
+/* Particle SoA: com_mod.f90:678-695.  reals other than xtra1/ytra1 have
+ * host_real_bytes each.  NULL members are skipped on upload (defaults: 0, cbt 1,
+ * npoint/nclass 1) and on download. */
+typedef struct {
+  double *xtra1, *ytra1;
+  void *ztra1, *uap, *ucp, *uzp, *us, *vs, *ws;
+  int32_t *itra1, *itramem, *idt, *npoint, *nclass;
+  int16_t *cbt;
+  void *xmass1;            /* (count or ld, nspec) species-major, leading dim xmass1_ld */
+  int64_t xmass1_ld;
+} fpx_particles;
+
+typedef struct {
+  int64_t n_due;           /* particles with itra1 == itime (advance calls made)     */
+  int64_t n_initialized;   /* of those, newly released (initialize calls)            */
+  int64_t n_left_domain;   /* nstop == 3, advance.f90:806                            */
+  int64_t n_min_mass;      /* timemanager.f90:681-686                                */
+  int64_t n_max_age;       /* timemanager.f90:701-707                                */
+  int64_t nan_count;       /* CBL re-initialisations, advance.f90:421                */
+  int64_t nan_count2;      /* advance.f90:439                                        */
+  int64_t n_bad_position;  /* non-finite position caught before a gather (terminated) */
+  double kernel_ms;        /* device time of the step's kernels (HIP events)         */
+} fpx_step_stats;
+
+/* ---- life cycle ----------------------------------------------------------- */
+int fpx_create(fpx_handle *out, const fpx_config *cfg);
+int fpx_destroy(fpx_handle h);
+const char *fpx_last_error(void);
+int fpx_abi_version(void);
+
+/* height(1:nz) of com_mod.f90:299 (host_real_bytes each) */
+int fpx_set_height(fpx_handle h, const void *height, int32_t n);
+
+/* ---- met fields ----------------------------------------------------------- */
+/* Upload one time slot (slot = 1 or 2, the value found in memind()) and repack
+ * it into the device layout.  Replaces the implicit use of com_mod's field
+ * arrays after getfields() (getfields.f90:81-225). */
+int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f);
+/* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
+int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]);
+
+/* ---- RNG ------------------------------------------------------------------ */
+/* Build rannumb exactly as FLEXPART.f90:47,56-59 does (seed -320, gasdev1 over
+ * the integer ran3 generator) in host_real_bytes precision, keep the ran3
+ * stream state for the per-step start indices, and upload the table. */
+int fpx_rng_fill_table(fpx_handle h);
+/* or install a table made by the caller (rannumb(1:maxrand)) */
+int fpx_rng_set_table(fpx_handle h, const void *rannumb, int32_t maxrand);
+/* copy of the table (tests) */
+int fpx_rng_get_table(fpx_handle h, void *rannumb, int32_t maxrand);
+
+/* ---- particles ------------------------------------------------------------ */
+/* Copy particles [first, first+count) from the host SoA (after releaseparticles,
+ * particle splitting or a warm start) / back to it. Indices are the reference's
+ * particle numbers j-1; an internal locality sort never changes them. */
+int fpx_upload_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p);
+int fpx_download_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p);
+int fpx_set_numpart(fpx_handle h, int64_t numpart);   /* com_mod numpart */
+
+/* ---- the hot path --------------------------------------------------------- */
+/* One pass of the particle loop timemanager.f90:531-712 at time itime. */
+int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *stats);
+/* Same, asynchronous on the handle's stream and without statistics read-back
+ * (benchmarks / graph capture).  fpx_sync() waits for it. */
+int fpx_step_async(fpx_handle h, int32_t itime);
+int fpx_sync(fpx_handle h);
+/* cumulative device time (ms) and launch count of the advance kernel since the
+ * last reset, measured with HIP events on the handle's stream */
+int fpx_kernel_time(fpx_handle h, double *advance_ms, int64_t *launches, int32_t reset);
+
+/* Force a locality re-sort now (normally driven by cfg.sort_interval). */
+int fpx_sort_particles(fpx_handle h);
+
+/* Device-side synthetic cloud for benchmarks: n particles uniformly over the
+ * grid from a SplitMix64 counter hash (same generator as
+ * flexpart_amd/synthetic.py:make_particles), frac_pbl of them below the local
+ * mixing height.  All due at itime0 and newly released. */
+int fpx_seed_particles(fpx_handle h, int64_t n, uint64_t seed, double frac_pbl, double zmax,
+                       double lat_margin_cells, int32_t itime0);
+
+/* raw stream handle (hipStream_t) for callers that enqueue their own work */
+void *fpx_stream(fpx_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLEXPART_AMD_H */

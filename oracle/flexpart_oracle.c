@@ -103,6 +103,11 @@ typedef struct {
   int gasdev_iset; real gasdev_gset;
   int idummy_init, idummy_adv;     /* initialize.f90:64, advance.f90:120 */
   real settling;                   /* advance.f90:121 (saved) */
+  /* 0 (default): the reference's exact serial semantics, including state that leaks from
+     one particle to the next through module variables.  1: the two order-dependent leaks
+     are replaced by the particle's own values -- what an order-independent (parallel)
+     engine computes; see DESIGN.md "deviations" D1/D2. */
+  int parallel_semantics;
 } orc_ctx;
 
 #define F3(f, i, j, k, m) ((f)[(((size_t)((m) - 1) * c->nz + (size_t)((k) - 1)) * c->ny + (size_t)(j)) * c->nx + (size_t)(i)])
@@ -850,6 +855,13 @@ static void orc_initialize(orc_ctx *c, int itime, int *ldt, real *up, real *vp, 
   }
   c->h = hh;
   c->zeta = zt / c->h;
+  /* D2: initialize.f90 never sets ngrid -- interpol_all/interpol_wind read the value the
+     previous particle's advance() left in interpol_mod. */
+  if (c->parallel_semantics) {
+    if (c->nglobal && yt > (double)c->switchnorthg) c->ngrid = -1;
+    else if (c->sglobal && yt < (double)c->switchsouthg) c->ngrid = -2;
+    else c->ngrid = 0;
+  }
   if (c->zeta <= K(1.)) {
     orc_interpol_all(c, itime, (real)xt, (real)yt, zt);
     dz1 = zt - HGT(c->indz);
@@ -1166,7 +1178,16 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
 
     /* :549-552 */
     if (*zt > c->h) {
-      if (itimec == itime + c->lsynctime) goto L99;
+      if (itimec == itime + c->lsynctime) {
+        /* D1: the reference jumps to 99 with usig/vsig/wsig left over from an earlier
+           particle (advance.f90:550 skips :604-606). */
+        if (c->parallel_semantics) {
+          c->usig = K(0.5) * (c->usigprof[c->indzp] + c->usigprof[c->indz]);
+          c->vsig = K(0.5) * (c->vsigprof[c->indzp] + c->vsigprof[c->indz]);
+          c->wsig = K(0.5) * (c->wsigprof[c->indzp] + c->wsigprof[c->indz]);
+        }
+        goto L99;
+      }
       goto L700;
     }
 
@@ -1405,6 +1426,8 @@ long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, re
   }
   return nadv;
 }
+
+void orc_set_parallel_semantics(orc_ctx *c, int on) { c->parallel_semantics = on; }
 
 long orc_nan_count(orc_ctx *c, int which) { return which == 2 ? c->nan_count2 : c->nan_count; }
 

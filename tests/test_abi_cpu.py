@@ -1,0 +1,63 @@
+"""CPU: the C-ABI library loads without a GPU and exports every symbol the header declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "flexpart_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fpx_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol(built):
+    from flexpart_amd import _lib
+    lib = _lib.load()
+    names = header_symbols()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"libflexpart_amd.so does not export {n}"
+    assert sorted(_lib.SYMBOLS) == names
+
+
+def test_struct_sizes_match_header(built):
+    """fpx_create checks struct_bytes; a mismatch between the ctypes mirror and the C header
+    would make every call fail, so pin it here without needing a device."""
+    from flexpart_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.FpxConfig()
+    cfg.struct_bytes = C.sizeof(_lib.FpxConfig) + 8
+    h = C.c_void_p()
+    rc = lib.fpx_create(C.byref(h), C.byref(cfg))
+    assert rc == -1 and b"size mismatch" in lib.fpx_last_error()
+    cfg.struct_bytes = C.sizeof(_lib.FpxConfig)
+    cfg.host_real_bytes = 3
+    rc = lib.fpx_create(C.byref(h), C.byref(cfg))
+    assert rc == -1 and b"host_real_bytes" in lib.fpx_last_error()
+    assert lib.fpx_abi_version() == 1
+
+
+def test_no_device_is_an_error_not_a_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from flexpart_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.FpxConfig()
+    cfg.struct_bytes = C.sizeof(_lib.FpxConfig)
+    cfg.host_real_bytes = 8
+    cfg.compute_real_bytes = 8
+    h = C.c_void_p()
+    rc = lib.fpx_create(C.byref(h), C.byref(cfg))
+    assert rc == -2 and not h.value
+
+
+def test_null_handle_is_rejected(built):
+    from flexpart_amd import _lib
+    lib = _lib.load()
+    assert lib.fpx_sync(None) == -1
+    assert lib.fpx_step(None, 0, None) == -1

@@ -1,0 +1,92 @@
+"""CPU tests: the oracle (C restatement) against the real reference compiled with flang
+(when oracle/_ref is present) and against the committed golden vectors; host logic."""
+import os
+
+import numpy as np
+import pytest
+
+from flexpart_amd import synthetic as syn
+from oracle import scenario_io as sio
+from oracle.oracle import Oracle, compare
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = {
+    "hanna": dict(ctl=5.0, ifine=4),
+    "hanna1_method0": dict(ctl=-5.0),
+    "cbl": dict(ctl=5.0, ifine=4, cblflag=1),
+    "above_pbl_only": dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True),
+}
+
+
+def golden_scenario(name):
+    return syn.small(n=1500, nx=48, ny=32, nz=36, nsteps=3, **CASES[name])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_oracle_matches_golden_reference_output(name, kind):
+    """tests/golden/*.npz hold outputs of the unmodified reference (flang build, made by
+    tests/golden/make_golden.py); the oracle must reproduce them."""
+    path = os.path.join(GOLD, f"{name}_{kind}.npz")
+    gold = np.load(path)
+    sc = golden_scenario(name)
+    st = Oracle(sc, kind).run()
+    tol_pos, tol_vel = (1e-13, 1e-11) if kind == "r8" else (1e-6, 1e-4)
+    for i, s in enumerate(st):
+        for k in ("xtra1", "ytra1", "ztra1"):
+            ref = gold[f"s{i}_{k}"]
+            err = np.abs(s[k] - ref).max() / max(np.abs(ref).max(), 1e-30)
+            assert err <= tol_pos, (name, kind, i, k, err)
+        for k in ("uap", "ucp", "uzp", "us", "vs", "ws"):
+            ref = gold[f"s{i}_{k}"]
+            err = np.abs(s[k] - ref).max() / max(np.abs(ref).max(), 1e-30)
+            assert err <= tol_vel, (name, kind, i, k, err)
+        for k in ("idt", "itra1", "cbt"):
+            assert np.array_equal(s[k], gold[f"s{i}_{k}"]), (name, kind, i, k)
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not sio.have_ref("r8"), reason="flang-built reference not present (GPU box)")
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_oracle_matches_live_reference(kind):
+    sc = syn.small(n=800, nx=40, ny=24, nz=30, nsteps=3, ctl=5.0, ifine=4, seed=77)
+    ref = sio.run_reference(sc, kind)
+    orc = Oracle(sc, kind)
+    assert np.array_equal(orc.rannumb(), ref["rannumb"].astype(orc.rt))
+    st = orc.run()
+    for a, b in zip(st, ref["steps"]):
+        rep = compare(a, b)
+        tol = 1e-12 if kind == "r8" else 1e-4
+        assert all(v[1] <= tol for v in rep.values() if isinstance(v, tuple)), rep
+        assert rep["idt"] == 0 and rep["itra1"] == 0 and rep["cbt"] == 0
+
+
+def test_derive_switches_follow_readcommand():
+    # readcommand.f90:244-272,379-385
+    s = syn.derive_switches(-5.0, 4, 0, 900)
+    assert (s["method"], s["mintime"], s["turbswitch"], s["ifine"]) == (0, 900, 0, 1)
+    assert s["ctl"] == pytest.approx(-0.2)
+    s = syn.derive_switches(5.0, 4, 0, 900)
+    assert (s["method"], s["mintime"], s["turbswitch"], s["ifine"]) == (1, 1, 1, 4)
+    s = syn.derive_switches(2.0, 4, 1, 1800)
+    assert (s["ifine"], s["lsynctime"], s["turbswitch"]) == (11, 1200, 1)
+    assert s["ctl"] == pytest.approx(0.2)
+
+
+def test_synthetic_is_deterministic():
+    a = syn.small(n=100, nx=20, ny=12, nz=10)
+    b = syn.small(n=100, nx=20, ny=12, nz=10)
+    for k in ("uu", "hmix", "xtra1", "ztra1", "height"):
+        assert np.array_equal(a[k], b[k])
+    assert np.array_equal(a["uu"][..., -1], a["uu"][..., 0])   # cyclic duplicate column
+    assert a["hmix"].min() >= syn.HMIXMIN and a["hmix"].max() <= syn.HMIXMAX
+
+
+def test_oracle_uniform_wind_closed_form():
+    sc = syn.config1(n=50, nsteps=2)
+    st = Oracle(sc, "r8").run()
+    g = sc["geom"]
+    dxconst = 180.0 / (g[0] * syn.R_EARTH * syn.PI_REF)
+    step = 10.0 * 900.0 * dxconst / np.cos(20.0 * syn.PI_REF / 180.0)
+    assert np.allclose(st[1]["xtra1"], sc["xtra1"] + 2 * step, rtol=0, atol=1e-10)
