@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the trajectory step (BASELINE.json metric).
+
+One "step" = one pass of the particle loop (reference timemanager.f90:531-712)
+over every particle resident on the GPU(s): one k_advance launch per GPU.
+Default workload (N=1): BASELINE config 3 -- 1e8 particles on the synthetic
+361x181x138 ECMWF-shaped grid, Hanna turbulence + CBL scheme, counter RNG, fp64.
+With --gpus N>1 (launched by torch.distributed.run, one rank per GPU) every rank
+holds its own shard of the same size: weak scaling, no data-path collective
+(particles are independent).
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3))
+    ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: 1e8 cfg 3, 1e7 cfg 2)")
+    ap.add_argument("--real", type=int, default=8, choices=(4, 8), help="compute real bytes")
+    ap.add_argument("--rng", default="philox", choices=("philox", "table_counter"))
+    ap.add_argument("--sort-interval", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="particles in the CPU baseline sample")
+    return ap.parse_args()
+
+
+def build_scenario(cfg, nsteps):
+    from flexpart_amd import synthetic as syn
+    if cfg == 2:
+        sc = syn.base_scenario(ctl=-5.0, ifine=4, turb_off=True, hmix_const=syn.HMIXMIN, nsteps=nsteps)
+        frac_pbl = 0.0
+    else:
+        sc = syn.base_scenario(ctl=5.0, ifine=4, cblflag=1, nsteps=nsteps)
+        frac_pbl = 0.5
+    return sc, frac_pbl
+
+
+def cpu_baseline(args, sc, frac_pbl):
+    """The reference itself (oracle/_ref, flang build of the unmodified Fortran) timed on this
+    box's host cores on a bounded sample of the same workload; 1 core (the reference hot path
+    is serial: no OpenMP, no MPI here).  Falls back to the C oracle when _ref is absent."""
+    from flexpart_amd import synthetic as syn
+    from oracle import scenario_io as sio
+    n = args.cpu_sample or (200_000 if args.config == 3 else 2_000_000)
+    s2 = dict(sc)
+    s2["nsteps"] = 2
+    nx, ny, nz = (int(v) for v in sc["grid"])
+    s2.update(syn.make_particles(n, nx, ny, sc["height"], sc["hmix"], seed=0x5EED, frac_pbl=frac_pbl))
+    kind = "r8" if args.real == 8 else "r4"
+    if sio.have_ref(kind):
+        out = sio.run_reference(s2, kind, workdir=os.environ.get("TMPDIR", "/tmp"), timing=True, tag="bench")
+        tsec, nadv = float(out["timing"][0]), float(out["timing"][1])
+        which = "reference"
+    else:
+        from oracle.oracle import Oracle
+        o = Oracle(s2, kind)
+        t0 = time.time()
+        nadv = 0
+        for _ in range(2):
+            nadv += o.step()
+        tsec = time.time() - t0
+        which = "port"
+    return {"value": nadv / tsec, "unit": "particle-steps/s", "cores": 1, "kind": which,
+            "sample": f"{n} particles x 2 steps of the same scenario ({tsec:.1f} s of CPU time, "
+                      f"first step includes initialize())"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+
+    from flexpart_amd.engine import Engine, RNG_PHILOX, RNG_TABLE_COUNTER
+    nper = int(args.particles or (1e8 if args.config == 3 else 1e7))
+    total_steps = args.warmup + args.steps
+    sc, frac_pbl = build_scenario(args.config, total_steps)
+    rng = RNG_PHILOX if args.rng == "philox" else RNG_TABLE_COUNTER
+    eng = Engine(sc, compute_real_bytes=args.real, host_real_bytes=args.real, rng_mode=rng,
+                 seed=0x5EED + rank, max_particles=nper, device=local, sort_interval=args.sort_interval)
+    eng.seed_particles(nper, seed=0x5EED + 7919 * rank, frac_pbl=frac_pbl)
+    lsync = int(sc["lsynctime"])
+    window = 10800
+
+    def do_step(i):
+        # stationary synthetic met: when the clock leaves the wind window, move the window
+        # (what getfields() does with new data; here the same two slots stay resident)
+        itime = i * lsync
+        w0 = (itime // window) * window
+        eng.set_windtime((w0, w0 + window), (1, 2))
+        eng.step_async(itime)
+
+    for i in range(args.warmup):
+        do_step(i)
+    eng.sync()
+    eng.kernel_time(reset=True)
+    eng.counters(reset=True)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total_steps):
+        do_step(i)
+    eng.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    kms, launches = eng.kernel_time(reset=True)
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # particle-steps actually executed (a step only processes particles that are due;
+    # the few that left the domain stay dead)
+    cnt = eng.counters()
+    nsteps_local = float(cnt["n_due"])
+    if dist:
+        t = torch.tensor([nsteps_local], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        psteps = float(t.item())
+    else:
+        psteps = nsteps_local
+    value = psteps / dt
+
+    # roofline of the dominant kernel (k_advance): compulsory traffic model of SURVEY.md 8(d)
+    nx, ny, nz = (int(v) for v in sc["grid"])
+    rb = args.real
+    nfield3 = 3 if args.config == 2 else 5            # uu,vv,ww (+rho,drhodz in the PBL)
+    field_bytes = nfield3 * 2 * nx * ny * nz * rb
+    b_state = (9 * rb + 14) + (9 * rb + 10) if rb == 8 else 112
+    b_alg = b_state + field_bytes / nper
+    avg_ms = kms / max(launches, 1)
+    achieved = b_alg * (nsteps_local / max(launches, 1)) / (avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "particle-steps/sec (whole node) + achieved HBM GB/s, 1e8 particles",
+        "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64" if rb == 8 else "f32",
+        "data": "synthetic",
+        "config": {"workload": (f"BASELINE config {args.config}: {nper:.0e} particles/GPU, synthetic "
+                                f"{nx}x{ny}x{nz} ECMWF-shaped fields, "
+                                + ("advance+interpol_wind only (all above PBL, turbulence off)" if args.config == 2
+                                   else "Hanna turbulence + CBL (ctl=1/5, ifine=11), PBL sub-stepping")
+                                + f", rng={args.rng}, lsynctime=900"),
+                   "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
+                   "sort_interval": args.sort_interval},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel": "k_advance", "avg_launch_ms": avg_ms, "launches": launches,
+                     "alg_bytes_per_particle_step": b_alg},
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        try:
+            out["cpu_baseline"] = cpu_baseline(args, sc, frac_pbl)
+        except Exception as e:  # the baseline must not sink the GPU number
+            out["cpu_baseline"] = {"value": None, "unit": "particle-steps/s", "cores": 1, "kind": "reference",
+                                   "sample": f"failed: {e}"}
+    eng.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

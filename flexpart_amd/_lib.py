@@ -68,7 +68,7 @@ SYMBOLS = [
     "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_set_height",
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
     "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart",
-    "fpx_step", "fpx_step_async", "fpx_sync", "fpx_kernel_time", "fpx_sort_particles",
+    "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream",
 ]
 
@@ -104,6 +104,7 @@ def load():
     lib.fpx_step.argtypes = [vp, C.c_int32, C.POINTER(FpxStepStats)]
     lib.fpx_step_async.argtypes = [vp, C.c_int32]
     lib.fpx_sync.argtypes = [vp]
+    lib.fpx_counters.argtypes = [vp, C.POINTER(FpxStepStats), C.c_int32]
     lib.fpx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
     lib.fpx_sort_particles.argtypes = [vp]
     lib.fpx_seed_particles.argtypes = [vp, C.c_int64, C.c_uint64, C.c_double, C.c_double,

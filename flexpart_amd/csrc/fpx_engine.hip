@@ -283,6 +283,7 @@ struct EngineBase {
   virtual int set_numpart(long long n) = 0;
   virtual int step(int itime, fpx_step_stats *st, bool async) = 0;
   virtual int sync() = 0;
+  virtual int counters(fpx_step_stats *out, int reset) = 0;
   virtual int kernel_time(double *ms, long long *launches, int reset) = 0;
   virtual int sort_particles() = 0;
   virtual int seed_particles(long long n, unsigned long long seed, double frac_pbl, double zmax, double lat_margin,
@@ -397,6 +398,7 @@ struct Engine : EngineBase {
     if (cfg.lsettling) { if ((rc = dalloc(&p, nlev * 2))) return rc; V.rhott = p; }
     if ((rc = dalloc(&p, V.maxrand))) return rc; V.rannumb = p;
     if ((rc = dalloc(&d_stats, 1))) return rc;
+    HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(Stats), stream));
 
     const size_t cap = (size_t)cfg.max_particles;
     P.cap = (long long)cap;
@@ -732,7 +734,6 @@ struct Engine : EngineBase {
       S.nrand_adv = d_nrand_adv; S.nrand_init = d_nrand_init;
       S.cbl_dcas = d_dcas4; S.cbl_dcas1 = d_dcas14; S.cbl_dcas_d = d_dcas8; S.cbl_dcas1_d = d_dcas18;
     }
-    HIPCHK(hipMemsetAsync(d_stats, 0, sizeof(Stats), stream));
     if (ev_used == ev_pool.size()) {
       hipEvent_t a, b;
       HIPCHK(hipEventCreate(&a));
@@ -751,13 +752,30 @@ struct Engine : EngineBase {
     HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(Stats), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     if (out) {
-      out->n_due = (int64_t)hs.n_due; out->n_initialized = (int64_t)hs.n_init; out->n_left_domain = (int64_t)hs.n_left;
-      out->n_min_mass = (int64_t)hs.n_minmass; out->n_max_age = (int64_t)hs.n_maxage; out->nan_count = (int64_t)hs.nan_count;
-      out->nan_count2 = (int64_t)hs.nan_count2; out->n_bad_position = (int64_t)hs.n_badpos;
+      fill_stats(out, hs, snap);
       float ms = 0;
       HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
       out->kernel_ms = ms;
     }
+    snap = hs;
+    return 0;
+  }
+
+  // device counters accumulate over steps; `snap`/`base` are host snapshots
+  Stats snap{}, base{};
+  static void fill_stats(fpx_step_stats *out, const Stats &a, const Stats &b) {
+    out->n_due = (int64_t)(a.n_due - b.n_due); out->n_initialized = (int64_t)(a.n_init - b.n_init);
+    out->n_left_domain = (int64_t)(a.n_left - b.n_left); out->n_min_mass = (int64_t)(a.n_minmass - b.n_minmass);
+    out->n_max_age = (int64_t)(a.n_maxage - b.n_maxage); out->nan_count = (int64_t)(a.nan_count - b.nan_count);
+    out->nan_count2 = (int64_t)(a.nan_count2 - b.nan_count2); out->n_bad_position = (int64_t)(a.n_badpos - b.n_badpos);
+  }
+  int counters(fpx_step_stats *out, int reset) override {
+    Stats hs;
+    HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(Stats), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (out) { memset(out, 0, sizeof(*out)); fill_stats(out, hs, base); }
+    snap = hs;
+    if (reset) base = hs;
     return 0;
   }
 
@@ -853,6 +871,7 @@ int fpx_set_numpart(fpx_handle h, int64_t n) { FPX_GUARD(h); return h->impl->set
 int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *st) { FPX_GUARD(h); return h->impl->step(itime, st, false); }
 int fpx_step_async(fpx_handle h, int32_t itime) { FPX_GUARD(h); return h->impl->step(itime, nullptr, true); }
 int fpx_sync(fpx_handle h) { FPX_GUARD(h); return h->impl->sync(); }
+int fpx_counters(fpx_handle h, fpx_step_stats *st, int32_t reset) { FPX_GUARD(h); return h->impl->counters(st, reset); }
 int fpx_kernel_time(fpx_handle h, double *ms, int64_t *launches, int32_t reset) {
   FPX_GUARD(h);
   long long l = 0;

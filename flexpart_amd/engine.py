@@ -200,6 +200,11 @@ class Engine:
     def sync(self):
         check(self.lib.fpx_sync(self.h), "fpx_sync")
 
+    def counters(self, reset=False):
+        st = FpxStepStats()
+        check(self.lib.fpx_counters(self.h, C.byref(st), int(reset)), "fpx_counters")
+        return {k: getattr(st, k) for k, _ in FpxStepStats._fields_}
+
     def kernel_time(self, reset=False):
         ms = C.c_double(0)
         ln = C.c_int64(0)

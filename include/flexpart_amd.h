@@ -170,6 +170,8 @@ int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *stats);
  * (benchmarks / graph capture).  fpx_sync() waits for it. */
 int fpx_step_async(fpx_handle h, int32_t itime);
 int fpx_sync(fpx_handle h);
+/* counters accumulated over all (sync or async) steps since the last reset; kernel_ms is 0 */
+int fpx_counters(fpx_handle h, fpx_step_stats *stats, int32_t reset);
 /* cumulative device time (ms) and launch count of the advance kernel since the
  * last reset, measured with HIP events on the handle's stream */
 int fpx_kernel_time(fpx_handle h, double *advance_ms, int64_t *launches, int32_t reset);
