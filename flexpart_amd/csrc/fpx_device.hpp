@@ -37,6 +37,11 @@ FPX_DEV float m_erf(float x) { return erff(x); }
 FPX_DEV double m_erf(double x) { return erf(x); }
 FPX_DEV float m_pow(float x, float y) { return powf(x, y); }
 FPX_DEV double m_pow(double x, double y) { return pow(x, y); }
+// x**y for the reference's non-integer exponents (0.33333, 0.66666, 0.8 ...).  fp64: exp(y*log(x)),
+// relative error <= ~|y ln x| ulp (a few 1e-16 here) at less than half the cost of the
+// correctly-rounded pow; fp32 keeps powf.  x == 0 and x < 0 behave like pow (0/inf, NaN).
+FPX_DEV float m_powr(float x, float y) { return powf(x, y); }
+FPX_DEV double m_powr(double x, double y) { return exp(y * log(x)); }
 FPX_DEV float m_fmod(float x, float y) { return fmodf(x, y); }
 FPX_DEV double m_fmod(double x, double y) { return fmod(x, y); }
 template <typename R> FPX_DEV R m_abs(R x) { return x < 0 ? -x : x; }
@@ -274,9 +279,12 @@ FPX_DEV R tlw_unstable(const Turb<R> &T, R z) {   // hanna.f90:78-84
 
 template <typename R>
 FPX_DEV void sigw_unstable(Turb<R> &T) {   // hanna.f90:67-70 == hanna_short.f90:60-63
-  R z23 = m_pow(T.zeta, K(0.66666));
+  // zeta**0.66666 and max(zeta,1.e-3)**(-.33333) from one logarithm
+  const R lz = m_log(T.zeta);
+  const R z23 = sizeof(R) == 8 ? m_exp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
+  const R zm13 = sizeof(R) == 8 ? m_exp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : m_log(K(1.e-3)))) : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
   T.sigw = m_sqrt(K(1.2) * (T.wst * T.wst) * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * (T.ust * T.ust)) + K(1.e-2);
-  T.dsigwdz = K(0.5) / T.sigw / T.h * (K(-1.4) * (T.ust * T.ust) + (T.wst * T.wst) * (K(0.8) * m_pow(m_max(T.zeta, K(1.e-3)), K(-.33333)) - K(1.8) * z23));
+  T.dsigwdz = K(0.5) / T.sigw / T.h * (K(-1.4) * (T.ust * T.ust) + (T.wst * T.wst) * (K(0.8) * zm13 - K(1.8) * z23));
 }
 
 template <typename R>
@@ -293,7 +301,7 @@ FPX_DEV void hanna(Turb<R> &T, R z) {   // hanna.f90:41-106
     T.tlv = T.tlu;
     T.tlw = T.tlu;
   } else if (T.ol < K(0.)) {
-    T.sigu = K(1.e-2) + T.ust * m_pow(K(12) - K(0.5) * T.h / T.ol, K(0.33333));
+    T.sigu = K(1.e-2) + T.ust * m_powr(K(12) - K(0.5) * T.h / T.ol, K(0.33333));
     T.sigv = T.sigu;
     sigw_unstable(T);
     T.tlu = K(0.15) * T.h / T.sigu;
@@ -306,7 +314,7 @@ FPX_DEV void hanna(Turb<R> &T, R z) {   // hanna.f90:41-106
     T.dsigwdz = K(-1.3) * T.ust / T.h;
     T.tlu = K(0.15) * T.h / T.sigu * m_sqrt(T.zeta);
     T.tlv = K(0.467) * T.tlu;
-    T.tlw = K(0.1) * T.h / T.sigw * m_pow(T.zeta, K(0.8));
+    T.tlw = K(0.1) * T.h / T.sigw * m_powr(T.zeta, K(0.8));
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -328,25 +336,25 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
     T.tlv = T.tlu;
     T.tlw = T.tlu;
   } else if (T.ol < K(0.)) {
-    T.sigu = T.ust * m_pow(K(12) - K(0.5) * T.h / T.ol, K(0.33333));
+    T.sigu = T.ust * m_powr(K(12) - K(0.5) * T.h / T.ol, K(0.33333));
     T.sigu = m_max(T.sigu, K(1.e-6));
     T.sigv = T.sigu;
     if (T.zeta < K(0.03)) {
-      T.sigw = K(0.96) * T.wst * m_pow(K(3) * T.zeta - T.ol / T.h, K(0.33333));
-      T.dsigw2dz = K(1.8432) * T.wst * T.wst / T.h * m_pow(K(3) * T.zeta - T.ol / T.h, K(-0.33333));
+      T.sigw = K(0.96) * T.wst * m_powr(K(3) * T.zeta - T.ol / T.h, K(0.33333));
+      T.dsigw2dz = K(1.8432) * T.wst * T.wst / T.h * m_powr(K(3) * T.zeta - T.ol / T.h, K(-0.33333));
     } else if (T.zeta < K(0.4)) {
-      R s1 = K(0.96) * m_pow(K(3) * T.zeta - T.ol / T.h, K(0.33333));
-      R s2 = K(0.763) * m_pow(T.zeta, K(0.175));
+      R s1 = K(0.96) * m_powr(K(3) * T.zeta - T.ol / T.h, K(0.33333));
+      R s2 = K(0.763) * m_powr(T.zeta, K(0.175));
       if (s1 < s2) {
         T.sigw = T.wst * s1;
-        T.dsigw2dz = K(1.8432) * T.wst * T.wst / T.h * m_pow(K(3) * T.zeta - T.ol / T.h, K(-0.33333));
+        T.dsigw2dz = K(1.8432) * T.wst * T.wst / T.h * m_powr(K(3) * T.zeta - T.ol / T.h, K(-0.33333));
       } else {
         T.sigw = T.wst * s2;
-        T.dsigw2dz = K(0.203759) * T.wst * T.wst / T.h * m_pow(T.zeta, K(-0.65));
+        T.dsigw2dz = K(0.203759) * T.wst * T.wst / T.h * m_powr(T.zeta, K(-0.65));
       }
     } else if (T.zeta < K(0.96)) {
-      T.sigw = K(0.722) * T.wst * m_pow(K(1) - T.zeta, K(0.207));
-      T.dsigw2dz = K(-.215812) * T.wst * T.wst / T.h * m_pow(K(1) - T.zeta, K(-0.586));
+      T.sigw = K(0.722) * T.wst * m_powr(K(1) - T.zeta, K(0.207));
+      T.dsigw2dz = K(-.215812) * T.wst * T.wst / T.h * m_powr(K(1) - T.zeta, K(-0.586));
     } else if (T.zeta < K(1.00)) {
       T.sigw = K(0.37) * T.wst;
       T.dsigw2dz = K(0.);
@@ -364,7 +372,7 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
     T.dsigw2dz = K(3.38) * T.ust * T.ust * (T.zeta - K(1.)) / T.h;
     T.tlu = K(0.15) * T.h / T.sigu * m_sqrt(T.zeta);
     T.tlv = K(0.467) * T.tlu;
-    T.tlw = K(0.1) * T.h / T.sigw * m_pow(T.zeta, K(0.8));
+    T.tlw = K(0.1) * T.h / T.sigw * m_powr(T.zeta, K(0.8));
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -385,7 +393,7 @@ FPX_DEV void hanna_short(Turb<R> &T, R z) {   // hanna_short.f90:41-92
   } else {
     T.sigw = K(1.e-2) + K(1.3) * T.ust * (K(1.) - T.zeta);
     T.dsigwdz = K(-1.3) * T.ust / T.h;
-    T.tlw = K(0.1) * T.h / T.sigw * m_pow(T.zeta, K(0.8));
+    T.tlw = K(0.1) * T.h / T.sigw * m_powr(T.zeta, K(0.8));
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -408,85 +416,95 @@ FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
   return transition;
 }
 
-// cbl.f90:70-210 -> drift ath, diffusion bth, blow-up flag
+// cbl.f90:70-210 -> drift ath, diffusion bth, blow-up flag.
+// Same algebra as the reference, evaluated the cheap way on the GPU: x**0.5 -> sqrt,
+// x**1.5 -> x*sqrt(x), x**(-0.5) -> 1/sqrt, x**2., x**3. -> products, the two cube roots
+// from one logarithm of |skew| (exponent 0.333333333 as in cbl.f90:227), each divisor
+// inverted once.  `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
 template <typename R>
-FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigmaw, R dsigmawdz, R tlw, R ol,
+FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigmaw, R dsigmawdz, R tlw, R transition,
                  R &ath, R &bth, int &flagrein) {
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
+  const R third = K(0.333333333);
   R dens = rhoa, ddens = rhograd, timedir = (R)ldirect;
   R z = zp / h;
-  R transition = cbl_transition(h, ol);
   R w2 = sigmaw * sigmaw;
   R dw2 = K(2.) * sigmaw * dsigmawdz;
   R alfa = K(2.) * w2 / (C0 * tlw);
   R wold = timedir * wp;
   R omz = K(1.) - z;
-  R omz15 = m_pow(omz, K(1.5)), omz05 = m_pow(omz, K(0.5));
+  R omz05 = m_sqrt(omz), omz15 = omz * omz05;
   R wst3 = wst * wst * wst;
   R w3 = (K(1.2) * z * omz15 + eps) * wst3 * transition;
   R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * (K(1.) / h) * transition;
-  R w215 = m_pow(w2, K(1.5)), w205 = m_pow(w2, K(0.5));
+  R w205 = m_sqrt(w2), w215 = w2 * w205;
   R skew = w3 / w215;
   R skew2 = skew * skew;
   R dskew = (dw3 * w215 - w3 * K(1.5) * w205 * dw2) / (w2 * w2 * w2);
   R radw2 = w205;
-  R dradw2 = K(0.5) * m_pow(w2, K(-0.5)) * dw2;
-  R fluarw = costluar4 * cuberoot(skew);
+  R dradw2 = K(0.5) * (K(1.) / w205) * dw2;
+  R lsk = m_log(m_abs(skew));
+  R fluarw = costluar4 * m_sign(m_exp(third * lsk), skew);            // costluar4*cuberoot(skew)
   R fluarw2 = fluarw * fluarw;
   R dfluarw, rluarw, drluarw, xluarw, dxluarw;
   if (skew != K(0)) {
-    dfluarw = costluar4 * (K(1.) / K(3.)) * cuberoot(m_pow(skew, K(-2.))) * dskew;
+    dfluarw = costluar4 * (K(1.) / K(3.)) * m_exp(K(-2.) * third * lsk) * dskew;   // cuberoot(skew**(-2.))
     R a1 = K(1.) + fluarw2, a3 = K(3.) + fluarw2;
-    R a1c = m_pow(a1, K(3.)), a3s = m_pow(a3, K(2.)), a115 = m_pow(a1, K(1.5));
-    rluarw = a1c * skew2 / (a3s * fluarw2);
-    xluarw = a115 * skew / (a3 * fluarw);
-    drluarw = (((K(3.) * (a1 * a1) * (K(2.) * fluarw * dfluarw) * skew2) + (a1 * a1 * a1) * K(2.) * skew * dskew) * a3s * fluarw2 -
-               (a1 * a1 * a1) * skew2 * ((K(2.) * a3 * (K(2.) * fluarw * dfluarw) * fluarw2) + (a3 * a3) * K(2.) * fluarw * dfluarw)) /
-              ((a3s * fluarw2) * (a3s * fluarw2));
-    dxluarw = (((K(1.5) * m_pow(a1, K(0.5)) * (K(2.) * fluarw * dfluarw) * skew) + a115 * dskew) * a3 * fluarw -
+    R a105 = m_sqrt(a1);
+    R a1c = a1 * a1 * a1, a3s = a3 * a3, a115 = a1 * a105;
+    R den_r = a3s * fluarw2, den_x = a3 * fluarw;
+    rluarw = a1c * skew2 / den_r;
+    xluarw = a115 * skew / den_x;
+    R ffd = K(2.) * fluarw * dfluarw;
+    drluarw = (((K(3.) * (a1 * a1) * ffd * skew2) + a1c * K(2.) * skew * dskew) * den_r -
+               a1c * skew2 * ((K(2.) * a3 * ffd * fluarw2) + a3s * ffd)) /
+              (den_r * den_r);
+    dxluarw = (((K(1.5) * a105 * ffd * skew) + a115 * dskew) * den_x -
                a115 * skew * (K(3.) * dfluarw + K(3) * fluarw2 * dfluarw)) /
-              ((a3 * fluarw) * (a3 * fluarw));
+              (den_x * den_x);
   } else {
     dfluarw = K(0.); rluarw = K(0.); drluarw = K(0.); xluarw = K(0.); dxluarw = K(0.);
   }
-  R r405 = m_pow(K(4.) + rluarw, K(0.5));
+  R r4 = K(4.) + rluarw;
+  R r405 = m_sqrt(r4);
   R aluarw = K(0.5) * (K(1.) - xluarw / r405);
   R bluarw = K(1.) - aluarw;
-  R daluarw = K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * m_pow(K(4.) + rluarw, K(-0.5)) * drluarw)) / (K(4.) + rluarw);
+  R daluarw = K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * (K(1.) / r405) * drluarw)) / r4;
   R dbluarw = -daluarw;
-  R t1 = aluarw * (K(1.) + fluarw2);
+  R f1 = K(1.) + fluarw2, ffd2 = K(2.) * fluarw * dfluarw;
+  R t1 = aluarw * f1;
   R qa = bluarw / t1;
-  R qa05 = m_pow(qa, K(0.5));
+  R qa05 = m_sqrt(qa);
   R sigmawa = radw2 * qa05;
   R dsigmawa = dradw2 * qa05 +
-               radw2 * ((K(0.5) * m_pow(qa, K(-0.5))) *
-                        ((dbluarw * t1 - bluarw * (daluarw * (K(1.) + fluarw2) + aluarw * K(2.) * fluarw * dfluarw)) / (t1 * t1)));
-  R t2 = bluarw * (K(1.) + fluarw2);
+               radw2 * ((K(0.5) * (K(1.) / qa05)) * ((dbluarw * t1 - bluarw * (daluarw * f1 + aluarw * ffd2)) / (t1 * t1)));
+  R t2 = bluarw * f1;
   R qb = aluarw / t2;
-  R qb05 = m_pow(qb, K(0.5));
+  R qb05 = m_sqrt(qb);
   R sigmawb = radw2 * qb05;
   R dsigmawb = dradw2 * qb05 +
-               radw2 * ((K(0.5) * m_pow(qb, K(-0.5))) *
-                        ((daluarw * t2 - aluarw * (dbluarw * (K(1.) + fluarw2) + bluarw * K(2.) * fluarw * dfluarw)) / (t2 * t2)));
+               radw2 * ((K(0.5) * (K(1.) / qb05)) * ((daluarw * t2 - aluarw * (dbluarw * f1 + bluarw * ffd2)) / (t2 * t2)));
   R wa = fluarw * sigmawa, wb = fluarw * sigmawb;
   R dwa = dfluarw * sigmawa + fluarw * dsigmawa;
   R dwb = dfluarw * sigmawb + fluarw * dsigmawb;
   R deltawa = wold - wa, deltawb = wold + wb;
   R wold2 = wold * wold;
-  R sigmawa2 = sigmawa * sigmawa, sigmawb2 = sigmawb * sigmawb;
+  R isa = K(1.) / sigmawa, isb = K(1.) / sigmawb;
+  R isa2 = isa * isa, isb2 = isb * isb;
   if (m_abs(deltawa) > K(6.) * sigmawa && m_abs(deltawb) > K(6.) * sigmawb) flagrein = 1;
-  R pa = (usurad2p * (K(1.) / sigmawa)) * m_exp(-(K(0.5) * ((deltawa / sigmawa) * (deltawa / sigmawa))));
-  R pb = (usurad2p * (K(1.) / sigmawb)) * m_exp(-(K(0.5) * ((deltawb / sigmawb) * (deltawb / sigmawb))));
+  R da = deltawa * isa, db = deltawb * isb;
+  R pa = (usurad2p * isa) * m_exp(-(K(0.5) * (da * da)));
+  R pb = (usurad2p * isb) * m_exp(-(K(0.5) * (db * db)));
   R ptot = dens * aluarw * pa + dens * bluarw * pb;
-  R aperfa = deltawa * usurad2 / sigmawa;
-  R aperfb = deltawb * usurad2 / sigmawb;
+  R aperfa = deltawa * usurad2 * isa;
+  R aperfb = deltawb * usurad2 * isb;
   R Phi = K(-0.5) * (aluarw * dens * dwa + dens * wa * daluarw + aluarw * wa * ddens) * m_erf(aperfa) +
-          sigmawa * (aluarw * dens * dsigmawa * (wold2 / sigmawa2 + K(1.)) + sigmawa * dens * daluarw + sigmawa * ddens * aluarw +
-                     aluarw * wold * dens / sigmawa2 * (sigmawa * dwa - wa * dsigmawa)) * pa +
+          sigmawa * (aluarw * dens * dsigmawa * (wold2 * isa2 + K(1.)) + sigmawa * dens * daluarw + sigmawa * ddens * aluarw +
+                     aluarw * wold * dens * isa2 * (sigmawa * dwa - wa * dsigmawa)) * pa +
           K(0.5) * (bluarw * dens * dwb + wb * dens * dbluarw + wb * bluarw * ddens) * m_erf(aperfb) +
-          sigmawb * (bluarw * dens * dsigmawb * (wold2 / sigmawb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
-                     bluarw * wold * dens / sigmawb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
-  R Q = timedir * ((aluarw * dens * deltawa / sigmawa2) * pa + (bluarw * dens * deltawb / sigmawb2) * pb);
+          sigmawb * (bluarw * dens * dsigmawb * (wold2 * isb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
+                     bluarw * wold * dens * isb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
+  R Q = timedir * ((aluarw * dens * deltawa * isa2) * pa + (bluarw * dens * deltawb * isb2) * pb);
   ath = (K(1.) / ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
   bth = m_sqrt(C0 * alfa);
 }
@@ -976,299 +994,351 @@ FPX_DEV int initialize_needs_cbl_draws(const View<R> &V, const R *hgt, int itime
   return (-T.h / T.ol > K(5)) ? 1 : 0;
 }
 
-// advance.f90:133-985.  Returns nstop (0 or 3).  prob[] receives the dry-deposition
-// probabilities (only touched when DRYDEP).
+// ---------------------------------------------------------------------------
+// advance.f90:133-985, decomposed for the GPU:
+//   adv_begin      :133-267  grid/cell choice, mixing height, PBL test
+//   pbl_begin      :295-302  (first pass) surface-layer parameters at the cell
+//   pbl_pass       :282-609  ONE pass of the Langevin loop (label 100 ... goto 100)
+//   above_step     :629-708  the single step above the PBL (label 700)
+//   adv_finish     :728-985  mesoscale term, wind alignment, move, boundary, Petterssen
+// A thread may run these back to back (above-PBL particles) or, in the PBL
+// kernel, interleave passes of different particles (lane refill).
+// ---------------------------------------------------------------------------
 template <typename R>
-FPX_DEV int advance_particle(const View<R> &V, const R *hgt, const Rng<R> &G, int nrand, int itime,
-                             PState<R> &P, R *prob, Stats *st) {
-  const R eps = K(361) / K(3.e5);   // nxmax/3.e5 with the reference's nxmax=361 (par_mod.f90:144, advance.f90:107)
+struct AdvCtx {                 // what advance() keeps between its labelled sections
+  int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
+  R h, tropop;
+  R dxsave, dysave, dawsave, dcwsave;
+  R u, v, w, usig, vsig, wsig;  // interpol_mod u..wsig
+  int itimec, nrand;
+  int ldt_last;                 // ldt of the step section that ran last (Petterssen gate :829)
+};
+
+enum { PBL_CONTINUE = 0, PBL_DONE = 1, PBL_ESCAPED = 2 };
+
+template <typename R>
+FPX_DEV R eps_domain() { return K(361) / K(3.e5); }   // nxmax/3.e5 with the reference's nxmax=361 (advance.f90:107)
+
+// returns true when the particle starts inside the PBL (zeta <= 1, advance.f90:276)
+template <typename R>
+FPX_DEV bool adv_begin(const View<R> &V, const PState<R> &P, int itime, int nrand, AdvCtx<R> &A) {
+  A.dxsave = K(0.); A.dysave = K(0.); A.dawsave = K(0.); A.dcwsave = K(0.);
+  A.u = K(0.); A.v = K(0.); A.w = K(0.); A.usig = K(0.); A.vsig = K(0.); A.wsig = K(0.);
+  A.itimec = itime;
+  A.nrand = nrand;
+  A.ngrid = pick_grid(V, P.xt, P.yt);
+  A.ix = (int)P.xt; A.jy = (int)P.yt;
+  int nix = (int)lround(P.xt), njy = (int)lround(P.yt);
+  A.ixp = A.ix + 1; A.jyp = A.jy + 1;
+  if (A.jyp >= V.ny) A.jyp = A.jyp - 1;   // advance.f90:228-231 (device rows are allocated ny, not nymax)
+  if (A.ixp >= V.nx) A.ixp = V.nx - 1;    // guard for a non-cyclic domain edge
+  A.h = V.hcell[(long long)A.jy * V.nx + A.ix];          // advance.f90:236-252 (interpolhmix=.false.)
+  A.tropop = V.tropo[(long long)njy * V.nx + nix];       // advance.f90:253
+  A.ldt_last = P.ldt;
+  return P.zt / A.h <= K(1.);
+}
+
+template <typename R>
+struct PblCtx {                 // live across passes of the PBL loop
+  Cell<R> C;
+  Turb<R> T;
+  LevelCache<R> LC;
+  R transition;                 // cbl.f90:79-81, constant during the step (depends on h/ol only)
+};
+
+template <typename R>
+FPX_DEV void pbl_begin(const View<R> &V, const PState<R> &P, int itime, const AdvCtx<R> &A, PblCtx<R> &B) {
+  cell_setup(V, B.C, A.ix, A.jy, A.ixp, A.jyp, (R)P.xt, (R)P.yt, itime);   // interpol_all.f90:57-71
+  B.T.h = A.h; B.T.sigw = K(0.); B.T.dsigw2dz = K(0.); B.T.dsigwdz = K(0.);
+  B.T.sigu = K(0.); B.T.sigv = K(0.); B.T.tlu = K(10.); B.T.tlv = K(10.); B.T.tlw = K(30.);
+  B.T.zeta = P.zt / A.h;
+  interp_surface(V, B.C, B.T);
+  B.transition = V.cblflag == 1 ? cbl_transition(A.h, B.T.ol) : K(1.);
+  B.LC.ilo = -1; B.LC.ihi = -1;
+}
+
+// One pass of the loop advance.f90:282-609.  prob: dry-deposition probabilities (DRYDEP only).
+template <typename R>
+FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A,
+                     PblCtx<R> &B, R *prob, Stats *st) {
+  const R eps = eps_domain<R>();
   const R eps2 = K(1.e-9);
   const R href = K(15.);            // par_mod.f90:76
+  Turb<R> &T = B.T;
+  const R h = A.h;
+  const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
+  int nrand = A.nrand;
 
-  if (V.drydep)
-    for (int ks = 0; ks < V.nspec; ks++) prob[ks] = K(0.);
-  R dxsave = K(0.), dysave = K(0.), dawsave = K(0.), dcwsave = K(0.);
-  int itimec = itime;
-
-  // grid choice and cell, advance.f90:161-231
-  const int ngrid = pick_grid(V, P.xt, P.yt);
-  const R *w3 = ngrid < 0 ? V.w3pol : V.w3;
-  int ix = (int)P.xt, jy = (int)P.yt;
-  int nix = (int)lround(P.xt), njy = (int)lround(P.yt);
-  int ixp = ix + 1, jyp = jy + 1;
-  if (jyp >= V.ny) jyp = jyp - 1;   // advance.f90:228-231 (device rows are allocated ny, not nymax)
-  if (ixp >= V.nx) ixp = V.nx - 1;  // guard for a non-cyclic domain edge
-
-  R h = V.hcell[(long long)jy * V.nx + ix];                  // advance.f90:236-252 (interpolhmix=.false.)
-  R tropop = V.tropo[(long long)njy * V.nx + nix];           // advance.f90:253
-  Turb<R> T;
-  T.h = h; T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);
+  if (V.method == 1) {
+    P.ldt = min(P.ldt, abs(V.lsynctime - A.itimec + itime));
+    A.itimec = A.itimec + P.ldt * V.ldirect;
+  } else {
+    P.ldt = abs(V.lsynctime);
+    A.itimec = itime + V.lsynctime;
+  }
+  const R dt = (R)P.ldt;
   T.zeta = P.zt / h;
 
-  Cell<R> C;
-  R u = K(0.), v = K(0.), w = K(0.), usig = K(0.), vsig = K(0.), wsig = K(0.);
-  bool above = true;
+  const int indz = find_level(hgt, V.nz, P.zt);
+  const int indzp = indz + 1;
+  cache_fetch(V, B.C, w3, B.LC, indz);
 
-  if (T.zeta <= K(1.)) {
-    // ---------------- PBL: Langevin sub-stepping, advance.f90:276-609 ----------------
-    above = false;
-    cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime);   // interpol_all.f90:57-71
-    interp_surface(V, C, T);
-    LevelCache<R> LC;
-    LC.ilo = -1; LC.ihi = -1;
-    R vdepo[kMaxSpec];
-    bool have_vdep = false;
-    for (;;) {
-      if (V.method == 1) {
-        P.ldt = min(P.ldt, abs(V.lsynctime - itimec + itime));
-        itimec = itimec + P.ldt * V.ldirect;
-      } else {
-        P.ldt = abs(V.lsynctime);
-        itimec = itime + V.lsynctime;
-      }
-      R dt = (R)P.ldt;
-      T.zeta = P.zt / h;
+  // advance.f90:342-350
+  const R dz = K(1.) / (hgt[indzp - 1] - hgt[indz - 1]);
+  const R dz1 = (P.zt - hgt[indz - 1]) * dz;
+  const R dz2 = (hgt[indzp - 1] - P.zt) * dz;
+  A.u = dz1 * B.LC.hi.u + dz2 * B.LC.lo.u;
+  A.v = dz1 * B.LC.hi.v + dz2 * B.LC.lo.v;
+  A.w = dz1 * B.LC.hi.w + dz2 * B.LC.lo.w;
+  const R rhoa = dz1 * B.LC.hi.rho + dz2 * B.LC.lo.rho;
+  const R rhograd = dz1 * B.LC.hi.rhograd + dz2 * B.LC.lo.rhograd;
 
-      int indz = find_level(hgt, V.nz, P.zt);
-      int indzp = indz + 1;
-      cache_fetch(V, C, w3, LC, indz);
+  if (V.turbswitch) hanna(T, P.zt); else hanna1(T, P.zt);
 
-      // advance.f90:342-350
-      R dz = K(1.) / (hgt[indzp - 1] - hgt[indz - 1]);
-      R dz1 = (P.zt - hgt[indz - 1]) * dz;
-      R dz2 = (hgt[indzp - 1] - P.zt) * dz;
-      u = dz1 * LC.hi.u + dz2 * LC.lo.u;
-      v = dz1 * LC.hi.v + dz2 * LC.lo.v;
-      w = dz1 * LC.hi.w + dz2 * LC.lo.w;
-      R rhoa = dz1 * LC.hi.rho + dz2 * LC.lo.rho;
-      R rhograd = dz1 * LC.hi.rhograd + dz2 * LC.lo.rhograd;
+  // horizontal Langevin, advance.f90:371-384
+  if (nrand + 1 > V.maxrand) nrand = 1;
+  {
+    const R g1 = G.at(nrand), g2 = G.at(nrand + 1);
+    if (dt / T.tlu < K(.5)) {
+      P.up = (K(1.) - dt / T.tlu) * P.up + g1 * T.sigu * m_sqrt(K(2.) * dt / T.tlu);
+    } else {
+      R ru = m_exp(-dt / T.tlu);
+      P.up = ru * P.up + g1 * T.sigu * m_sqrt(K(1.) - ru * ru);
+    }
+    if (dt / T.tlv < K(.5)) {
+      P.vp = (K(1.) - dt / T.tlv) * P.vp + g2 * T.sigv * m_sqrt(K(2.) * dt / T.tlv);
+    } else {
+      R rv = m_exp(-dt / T.tlv);
+      P.vp = rv * P.vp + g2 * T.sigv * m_sqrt(K(1.) - rv * rv);
+    }
+  }
+  nrand = nrand + 2;
 
-      if (V.turbswitch) hanna(T, P.zt); else hanna1(T, P.zt);
+  if (nrand + V.ifine > V.maxrand) nrand = 1;
+  const R rhoaux = rhograd / rhoa;
+  const R dtf = dt * V.fine;
+  const R dtftlw = dtf / T.tlw;
+  const bool cbl_on = V.cblflag == 1 && (-h / T.ol > K(5));
+  const R sqrt_dtf = m_sqrt(dtf);
 
-      // horizontal Langevin, advance.f90:371-384
-      if (nrand + 1 > V.maxrand) nrand = 1;
-      if (dt / T.tlu < K(.5)) {
-        P.up = (K(1.) - dt / T.tlu) * P.up + G.at(nrand) * T.sigu * m_sqrt(K(2.) * dt / T.tlu);
-      } else {
-        R ru = m_exp(-dt / T.tlu);
-        P.up = ru * P.up + G.at(nrand) * T.sigu * m_sqrt(K(1.) - ru * ru);
-      }
-      if (dt / T.tlv < K(.5)) {
-        P.vp = (K(1.) - dt / T.tlv) * P.vp + G.at(nrand + 1) * T.sigv * m_sqrt(K(2.) * dt / T.tlv);
-      } else {
-        R rv = m_exp(-dt / T.tlv);
-        P.vp = rv * P.vp + G.at(nrand + 1) * T.sigv * m_sqrt(K(1.) - rv * rv);
-      }
-      nrand = nrand + 2;
-
-      if (nrand + V.ifine > V.maxrand) nrand = 1;
-      R rhoaux = rhograd / rhoa;
-      R dtf = dt * V.fine;
-      R dtftlw = dtf / T.tlw;
-
-      // vertical Langevin, ifine sub-steps, advance.f90:396-498
-      for (int i = 1; i <= V.ifine; i++) {
-        R delz;
-        if (V.turbswitch) {
-          if (dtftlw < K(.5)) {
-            if (V.cblflag == 1) {
-              if (-h / T.ol > K(5)) {
-                int flagrein = 0;
-                nrand = nrand + 1;
-                R old_wp_buf = P.wp, ath, bth;
-                cbl(V.ldirect, P.wp, P.zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, T.ol, ath, bth, flagrein);
-                P.wp = (P.wp + ath * dtf + bth * G.at(nrand) * m_sqrt(dtf)) * (R)P.icbt;
-                delz = P.wp * dtf;
-                if (flagrein == 1) {
-                  re_initialize_particle(V.ldirect, G, P.zt, T.wst, h, T.sigw, old_wp_buf, nrand, T.ol);
-                  P.wp = old_wp_buf;
-                  delz = P.wp * dtf;
-                  atomicAdd(&st->nan_count, 1ull);
-                }
-              } else {
-                nrand = nrand + 1;
-                R ath = -P.wp / T.tlw + T.sigw * T.dsigwdz + P.wp * P.wp / T.sigw * T.dsigwdz + T.sigw * T.sigw / rhoa * rhograd;
-                R bth = T.sigw * G.at(nrand) * m_sqrt(K(2.) * dtftlw);
-                P.wp = (P.wp + ath * dtf + bth) * (R)P.icbt;
-                delz = P.wp * dtf;
-                R del_test = (K(1.) - P.wp) / P.wp;
-                if (isnan(P.wp) || isnan(del_test)) {
-                  nrand = nrand + 1;
-                  P.wp = T.sigw * G.at(nrand);
-                  delz = P.wp * dtf;
-                  atomicAdd(&st->nan_count2, 1ull);
-                }
-              }
-            } else {
-              P.wp = ((K(1.) - dtftlw) * P.wp + G.at(nrand + i) * m_sqrt(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
-              delz = P.wp * T.sigw * dtf;
+  // vertical Langevin, ifine sub-steps, advance.f90:396-498
+  for (int i = 1; i <= V.ifine; i++) {
+    R delz;
+    if (V.turbswitch) {
+      if (dtftlw < K(.5)) {
+        if (V.cblflag == 1) {
+          if (cbl_on) {
+            int flagrein = 0;
+            nrand = nrand + 1;
+            R old_wp_buf = P.wp, ath, bth;
+            cbl(V.ldirect, P.wp, P.zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, B.transition, ath, bth, flagrein);
+            P.wp = (P.wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)P.icbt;
+            delz = P.wp * dtf;
+            if (flagrein == 1) {
+              re_initialize_particle(V.ldirect, G, P.zt, T.wst, h, T.sigw, old_wp_buf, nrand, T.ol);
+              P.wp = old_wp_buf;
+              delz = P.wp * dtf;
+              atomicAdd(&st->nan_count, 1ull);
             }
           } else {
-            R rw = m_exp(-dtftlw);
-            P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
-            delz = P.wp * T.sigw * dtf;
+            nrand = nrand + 1;
+            R ath = -P.wp / T.tlw + T.sigw * T.dsigwdz + P.wp * P.wp / T.sigw * T.dsigwdz + T.sigw * T.sigw / rhoa * rhograd;
+            R bth = T.sigw * G.at(nrand) * m_sqrt(K(2.) * dtftlw);
+            P.wp = (P.wp + ath * dtf + bth) * (R)P.icbt;
+            delz = P.wp * dtf;
+            R del_test = (K(1.) - P.wp) / P.wp;
+            if (isnan(P.wp) || isnan(del_test)) {
+              nrand = nrand + 1;
+              P.wp = T.sigw * G.at(nrand);
+              delz = P.wp * dtf;
+              atomicAdd(&st->nan_count2, 1ull);
+            }
           }
         } else {
-          R rw = m_exp(-dtftlw);
-          P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)P.icbt;
-          delz = P.wp * dtf;
+          P.wp = ((K(1.) - dtftlw) * P.wp + G.at(nrand + i) * m_sqrt(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
+          delz = P.wp * T.sigw * dtf;
         }
-
-        // reflection at the ground / mixing height, advance.f90:476-491
-        if (m_abs(delz) > h) delz = m_fmod(delz, h);
-        if (delz < -P.zt) {
-          P.icbt = -1;
-          P.zt = -P.zt - delz;
-        } else if (delz > (h - P.zt)) {
-          P.icbt = -1;
-          P.zt = -P.zt - delz + K(2.) * h;
-        } else {
-          P.icbt = 1;
-          P.zt = P.zt + delz;
-        }
-        if (i != V.ifine) {
-          T.zeta = P.zt / h;
-          hanna_short(T, P.zt);
-        }
+      } else {
+        R rw = m_exp(-dtftlw);
+        P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
+        delz = P.wp * T.sigw * dtf;
       }
-      if (V.cblflag != 1) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i" with i = ifine+1 after the loop (advance.f90:499)
-
-      // next sub-step length, advance.f90:504-510
-      if (V.turbswitch)
-        P.ldt = (int)(m_min(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)) * V.ctl);
-      else
-        P.ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp), K(1.e-5))) * V.ctl);
-      P.ldt = max(P.ldt, V.mintime);
-
-      if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:518-531
-
-      // advance.f90:539-547
-      dxsave = dxsave + u * dt;
-      dysave = dysave + v * dt;
-      dawsave = dawsave + P.up * dt;
-      dcwsave = dcwsave + P.vp * dt;
-      P.zt = P.zt + w * dt * (R)V.ldirect;
-      if (P.zt >= hgt[V.nz - 1]) P.zt = hgt[V.nz - 1] - K(100.) * eps;
-
-      if (P.zt > h) {   // advance.f90:549-552
-        if (itimec == itime + V.lsynctime) {
-          // -> 99.  The reference reaches label 99 here with usig/vsig/wsig still holding
-          // whatever the previous particle left in interpol_mod; use this particle's own
-          // profile values, as the regular exit :603-606 does.
-          usig = K(0.5) * (LC.hi.usig + LC.lo.usig);
-          vsig = K(0.5) * (LC.hi.vsig + LC.lo.vsig);
-          wsig = K(0.5) * (LC.hi.wsig + LC.lo.wsig);
-          break;
-        }
-        above = true;                                 // -> 700
-        break;
-      }
-
-      // dry-deposition probability, advance.f90:582-599
-      if (V.drydep && P.zt < K(2.) * href) {
-        for (int ks = 0; ks < V.nspec; ks++) {
-          if (V.drydepspec[ks]) {
-            if (!have_vdep) vdepo[ks] = interp_vdep(V, C, ks);
-            prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_exp(-vdepo[ks] * m_abs(dt) / (K(2.) * href));
-          }
-        }
-        have_vdep = true;
-      }
-
-      if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);   // advance.f90:601
-
-      if (itimec == itime + V.lsynctime) {   // advance.f90:603-608
-        usig = K(0.5) * (LC.hi.usig + LC.lo.usig);
-        vsig = K(0.5) * (LC.hi.vsig + LC.lo.vsig);
-        wsig = K(0.5) * (LC.hi.wsig + LC.lo.wsig);
-        break;
-      }
-    }
-  }
-
-  if (above) {
-    // ---------------- above the PBL: one step, advance.f90:629-708 ----------------
-    cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime);
-    interp_wind<R, true>(V, hgt, C, w3, P.zt, u, v, w, usig, vsig, wsig);
-    P.ldt = abs(V.lsynctime - itimec + itime);
-    R dt = (R)P.ldt;
-    R ux, vy;
-    if (P.zt < tropop) {
-      R uxscale = m_sqrt(K(2.) * V.d_trop / dt);
-      if (nrand + 1 > V.maxrand) nrand = 1;
-      ux = G.at(nrand) * uxscale;
-      vy = G.at(nrand + 1) * uxscale;
-      nrand = nrand + 2;
-      P.wp = K(0.);
-    } else if (P.zt < tropop + K(1000.)) {
-      R weight = (P.zt - tropop) / K(1000.);
-      R uxscale = m_sqrt(K(2.) * V.d_trop / dt * (K(1.) - weight));
-      if (nrand + 2 > V.maxrand) nrand = 1;
-      ux = G.at(nrand) * uxscale;
-      vy = G.at(nrand + 1) * uxscale;
-      R wpscale = m_sqrt(K(2.) * V.d_strat / dt * weight);
-      P.wp = G.at(nrand + 2) * wpscale + V.d_strat / K(1000.);
-      nrand = nrand + 3;
     } else {
-      if (nrand > V.maxrand) nrand = 1;
-      ux = K(0.);
-      vy = K(0.);
-      R wpscale = m_sqrt(K(2.) * V.d_strat / dt);
-      P.wp = G.at(nrand) * wpscale;
-      nrand = nrand + 1;
+      R rw = m_exp(-dtftlw);
+      P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)P.icbt;
+      delz = P.wp * dtf;
     }
-    if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:686-699
-    dxsave = dxsave + (u + ux) * dt;
-    dysave = dysave + (v + vy) * dt;
-    P.zt = P.zt + (w + P.wp) * dt * (R)V.ldirect;
-    if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);
+
+    // reflection at the ground / mixing height, advance.f90:476-491
+    if (m_abs(delz) > h) delz = m_fmod(delz, h);
+    if (delz < -P.zt) {
+      P.icbt = -1;
+      P.zt = -P.zt - delz;
+    } else if (delz > (h - P.zt)) {
+      P.icbt = -1;
+      P.zt = -P.zt - delz + K(2.) * h;
+    } else {
+      P.icbt = 1;
+      P.zt = P.zt + delz;
+    }
+    if (i != V.ifine) {
+      T.zeta = P.zt / h;
+      hanna_short(T, P.zt);
+    }
+  }
+  if (V.cblflag != 1) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i", i = ifine+1 after the loop (advance.f90:499)
+  A.nrand = nrand;
+  A.ldt_last = P.ldt;
+
+  // next sub-step length, advance.f90:504-510
+  if (V.turbswitch)
+    P.ldt = (int)(m_min(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)) * V.ctl);
+  else
+    P.ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp), K(1.e-5))) * V.ctl);
+  P.ldt = max(P.ldt, V.mintime);
+
+  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:518-531
+
+  // advance.f90:539-547
+  A.dxsave = A.dxsave + A.u * dt;
+  A.dysave = A.dysave + A.v * dt;
+  A.dawsave = A.dawsave + P.up * dt;
+  A.dcwsave = A.dcwsave + P.vp * dt;
+  P.zt = P.zt + A.w * dt * (R)V.ldirect;
+  if (P.zt >= hgt[V.nz - 1]) P.zt = hgt[V.nz - 1] - K(100.) * eps;
+
+  const bool end_of_interval = A.itimec == itime + V.lsynctime;
+  if (P.zt > h) {   // advance.f90:549-552
+    if (end_of_interval) {
+      // -> 99.  The reference reaches label 99 here with usig/vsig/wsig still holding
+      // whatever the previous particle left in interpol_mod; use this particle's own
+      // profile values, as the regular exit :603-606 does.
+      A.usig = K(0.5) * (B.LC.hi.usig + B.LC.lo.usig);
+      A.vsig = K(0.5) * (B.LC.hi.vsig + B.LC.lo.vsig);
+      A.wsig = K(0.5) * (B.LC.hi.wsig + B.LC.lo.wsig);
+      return PBL_DONE;
+    }
+    return PBL_ESCAPED;   // -> 700
   }
 
-  // ---------------- 99: mesoscale fluctuations, advance.f90:728-739 ----------------
+  // dry-deposition probability, advance.f90:582-599
+  if (V.drydep && P.zt < K(2.) * href) {
+    for (int ks = 0; ks < V.nspec; ks++) {
+      if (V.drydepspec[ks]) {
+        R vdepo = interp_vdep(V, B.C, ks);   // same value every pass (depoindicator cache in the reference)
+        prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_exp(-vdepo * m_abs(dt) / (K(2.) * href));
+      }
+    }
+  }
+
+  if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);   // advance.f90:601
+
+  if (end_of_interval) {   // advance.f90:603-608
+    A.usig = K(0.5) * (B.LC.hi.usig + B.LC.lo.usig);
+    A.vsig = K(0.5) * (B.LC.hi.vsig + B.LC.lo.vsig);
+    A.wsig = K(0.5) * (B.LC.hi.wsig + B.LC.lo.wsig);
+    return PBL_DONE;
+  }
+  return PBL_CONTINUE;
+}
+
+// the single step above the PBL, advance.f90:629-708 (label 700)
+template <typename R>
+FPX_DEV void above_step(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A) {
+  const R eps2 = K(1.e-9);
+  const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
+  Cell<R> C;
+  cell_setup(V, C, A.ix, A.jy, A.ixp, A.jyp, (R)P.xt, (R)P.yt, itime);
+  interp_wind<R, true>(V, hgt, C, w3, P.zt, A.u, A.v, A.w, A.usig, A.vsig, A.wsig);
+  P.ldt = abs(V.lsynctime - A.itimec + itime);
+  A.ldt_last = P.ldt;
+  const R dt = (R)P.ldt;
+  int nrand = A.nrand;
+  R ux, vy;
+  if (P.zt < A.tropop) {
+    R uxscale = m_sqrt(K(2.) * V.d_trop / dt);
+    if (nrand + 1 > V.maxrand) nrand = 1;
+    ux = G.at(nrand) * uxscale;
+    vy = G.at(nrand + 1) * uxscale;
+    nrand = nrand + 2;
+    P.wp = K(0.);
+  } else if (P.zt < A.tropop + K(1000.)) {
+    R weight = (P.zt - A.tropop) / K(1000.);
+    R uxscale = m_sqrt(K(2.) * V.d_trop / dt * (K(1.) - weight));
+    if (nrand + 2 > V.maxrand) nrand = 1;
+    ux = G.at(nrand) * uxscale;
+    vy = G.at(nrand + 1) * uxscale;
+    R wpscale = m_sqrt(K(2.) * V.d_strat / dt * weight);
+    P.wp = G.at(nrand + 2) * wpscale + V.d_strat / K(1000.);
+    nrand = nrand + 3;
+  } else {
+    if (nrand > V.maxrand) nrand = 1;
+    ux = K(0.);
+    vy = K(0.);
+    R wpscale = m_sqrt(K(2.) * V.d_strat / dt);
+    P.wp = G.at(nrand) * wpscale;
+    nrand = nrand + 1;
+  }
+  A.nrand = nrand;
+  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:686-699
+  A.dxsave = A.dxsave + (A.u + ux) * dt;
+  A.dysave = A.dysave + (A.v + vy) * dt;
+  P.zt = P.zt + (A.w + P.wp) * dt * (R)V.ldirect;
+  if (P.zt < K(0.)) P.zt = m_min(A.h - eps2, K(-1.) * P.zt);
+}
+
+// label 99 to the end: advance.f90:728-985.  Returns nstop (0 or 3).
+template <typename R>
+FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A) {
+  const R eps = eps_domain<R>();
+  const R eps2 = K(1.e-9);
+  int nrand = A.nrand;
+  // mesoscale fluctuations, advance.f90:728-739
   {
     R r = m_exp(K(-2.) * (R)abs(V.lsynctime) / (R)V.lwindinterv);
     R rs = m_sqrt(K(1.) - r * r);
     if (nrand + 2 > V.maxrand) nrand = 1;
-    P.usigold = r * P.usigold + rs * G.at(nrand) * usig * V.turbmesoscale;
-    P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * vsig * V.turbmesoscale;
-    P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * wsig * V.turbmesoscale;
-    dxsave = dxsave + P.usigold * (R)V.lsynctime;
-    dysave = dysave + P.vsigold * (R)V.lsynctime;
+    P.usigold = r * P.usigold + rs * G.at(nrand) * A.usig * V.turbmesoscale;
+    P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * A.vsig * V.turbmesoscale;
+    P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * A.wsig * V.turbmesoscale;
+    A.dxsave = A.dxsave + P.usigold * (R)V.lsynctime;
+    A.dysave = A.dysave + P.vsigold * (R)V.lsynctime;
     P.zt = P.zt + P.wsigold * (R)V.lsynctime;
     if (P.zt < K(0.)) P.zt = K(-1.) * P.zt;
   }
-
   // wind alignment and position update, advance.f90:747-778
   {
     R ux, vy;
-    windalign(dxsave, dysave, dawsave, dcwsave, ux, vy);
-    dxsave = dxsave + ux;
-    dysave = dysave + vy;
-    move_xy(V, ngrid, P.xt, P.yt, dxsave, dysave, (R)V.ldirect);
+    windalign(A.dxsave, A.dysave, A.dawsave, A.dcwsave, ux, vy);
+    A.dxsave = A.dxsave + ux;
+    A.dysave = A.dysave + vy;
+    move_xy(V, A.ngrid, P.xt, P.yt, A.dxsave, A.dysave, (R)V.ldirect);
   }
   if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) return 3;   // advance.f90:784-813
 
-  // ---------------- Petterssen correction, advance.f90:829-985 ----------------
+  // Petterssen correction, advance.f90:829-985
   if (P.ldt != abs(V.lsynctime)) return 0;
   if (abs(itime + P.ldt * V.ldirect) > abs(V.memtime1)) return 0;
-  if (pick_grid(V, P.xt, P.yt) != ngrid) return 0;
-  ix = (int)P.xt; jy = (int)P.yt;
-  ixp = ix + 1; jyp = jy + 1;
+  if (pick_grid(V, P.xt, P.yt) != A.ngrid) return 0;
+  int ix = (int)P.xt, jy = (int)P.yt;
+  int ixp = ix + 1, jyp = jy + 1;
   if (jyp >= V.ny) jyp = V.ny - 1;   // guard: the reference would read the padding row nymax here
   if (ixp >= V.nx) ixp = V.nx - 1;
-  R uold = u, vold = v, wold = w;
+  const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
+  R u, v, w;
   {
     R d0, d1, d2;
+    Cell<R> C;
     cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime + P.ldt * V.ldirect);
     interp_wind<R, false>(V, hgt, C, w3, P.zt, u, v, w, d0, d1, d2);
   }
   if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:893-906
-  u = (u - uold) / K(2.);
-  v = (v - vold) / K(2.);
-  w = (w - wold) / K(2.);
+  u = (u - A.u) / K(2.);
+  v = (v - A.v) / K(2.);
+  w = (w - A.w) / K(2.);
   P.zt = P.zt + w * (R)(P.ldt * V.ldirect);
-  if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);
-  move_xy(V, ngrid, P.xt, P.yt, u, v, (R)(P.ldt * V.ldirect));
+  if (P.zt < K(0.)) P.zt = m_min(A.h - eps2, K(-1.) * P.zt);
+  move_xy(V, A.ngrid, P.xt, P.yt, u, v, (R)(P.ldt * V.ldirect));
   if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) return 3;   // advance.f90:956-985
   return 0;
 }

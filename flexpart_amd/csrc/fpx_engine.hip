@@ -169,17 +169,81 @@ __global__ void __launch_bounds__(kBlock) k_classify(View<R> V, Parts<R> P, long
 }
 
 // ---------------------------------------------------------------------------
-// the hot kernel: one pass of the particle loop timemanager.f90:531-712
+// the hot kernels: one pass of the particle loop timemanager.f90:531-712
+//
+//   k_prep : every due particle -- initialize() if newly released, grid/cell/PBL test;
+//            particles above the PBL finish here (one interpol_wind step + Petterssen:
+//            gather/stream bound); PBL particles are appended to a work list.
+//   k_pbl  : persistent waves over the work list.  Each lane owns one PBL particle and runs
+//            passes of the Langevin loop; a lane whose particle has finished its lsynctime
+//            immediately refills from the list, so lanes never idle on the data-dependent
+//            trip count (15-150 passes per particle).
 // ---------------------------------------------------------------------------
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_advance(View<R> V, Parts<R> P, SeqRng S, long long numpart, int itime, unsigned int step, Stats *st) {
+__device__ __forceinline__ void make_rng(const View<R> &V, unsigned int pid, unsigned int step, Rng<R> &G) {
+  G.tab = V.rannumb; G.maxrand = V.maxrand; G.mode = V.rng_mode;
+  G.pid = pid; G.step = step;
+  G.k0 = (unsigned int)V.seed; G.k1 = (unsigned int)(V.seed >> 32);
+}
+
+template <typename R>
+__device__ __forceinline__ int advance_start_index(const View<R> &V, const SeqRng &S, const Rng<R> &G, unsigned int pid) {
+  if (V.rng_mode == 0) return S.nrand_adv[pid];      // advance.f90:153, serial stream replayed by the host
+  if (V.rng_mode == 1) return G.start_index(0);
+  return 1;
+}
+
+// epilogue timemanager.f90:630-708 + write-back of the particle
+template <typename R, bool DRYDEP>
+__device__ __forceinline__ void epilogue_store(const View<R> &V, Parts<R> &P, long long s, int itime, int itramem,
+                                               int nstop, const PState<R> &ps, const R *prob, Stats *st) {
+  int itra1;
+  if (nstop > 1) {
+    itra1 = kDead;
+    atomicAdd(&st->n_left, 1ull);
+  } else {
+    itra1 = itime + V.lsynctime;
+    R xmassfract = (R)0;
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++) {
+      if (ks < V.nspec) {
+        R decfact = V.decay[ks] > (R)0 ? m_exp(-(R)abs(V.lsynctime) * V.decay[ks]) : (R)1;
+        R xm = P.xmass1[(size_t)ks * P.cap + s];
+        if (DRYDEP && V.drydepspec[ks]) xm = xm * ((R)1 - prob[ks]) * decfact;
+        else xm = xm * decfact;
+        if (DRYDEP || V.decay[ks] > (R)0) P.xmass1[(size_t)ks * P.cap + s] = xm;
+        if (V.mdomainfill == 0) {
+          if (V.xmass_rel[ks] > (R)0) xmassfract = m_max(xmassfract, (R)V.npart_rel * xm / V.xmass_rel[ks]);
+        } else {
+          xmassfract = (R)1;
+        }
+      }
+    }
+    if (xmassfract < (R)0.0001) {   // minmass, par_mod.f90:213
+      itra1 = kDead;
+      atomicAdd(&st->n_minmass, 1ull);
+    } else if (abs(itra1 - itramem) >= V.lage_last) {
+      itra1 = kDead;
+      atomicAdd(&st->n_maxage, 1ull);
+    }
+  }
+  P.xt[s] = ps.xt; P.yt[s] = ps.yt; P.zt[s] = ps.zt;
+  P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
+  P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
+  P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt; P.itra1[s] = itra1;
+}
+
+template <typename R, bool DRYDEP>
+__global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S, long long numpart, int itime,
+                                                 unsigned int step, Stats *st, unsigned int *__restrict__ pbl_list,
+                                                 unsigned int *__restrict__ pbl_count) {
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= numpart) return;
   if (P.itra1[s] != itime) return;                       // timemanager.f90:537
-  atomicAdd(&st->n_due, 1ull);   // compiler folds this into one add per wave
+  atomicAdd(&st->n_due, 1ull);   // one add per wave after the compiler's aggregation
 
   PState<R> ps;
   ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
@@ -195,10 +259,7 @@ __global__ void __launch_bounds__(kBlock) k_advance(View<R> V, Parts<R> P, SeqRn
   }
 
   Rng<R> G;
-  G.tab = V.rannumb; G.maxrand = V.maxrand; G.mode = V.rng_mode;
-  G.pid = pid; G.step = step;
-  G.k0 = (unsigned int)V.seed; G.k1 = (unsigned int)(V.seed >> 32);
-
+  make_rng(V, pid, step, G);
   const bool is_new = (itramem == itime) || (itime == 0);   // timemanager.f90:553
   if (is_new) {
     int nrand_i;
@@ -224,47 +285,83 @@ __global__ void __launch_bounds__(kBlock) k_advance(View<R> V, Parts<R> P, SeqRn
     ps.ldt = P.idt[s]; ps.icbt = P.cbt[s];
   }
 
-  int nrand;
-  if (V.rng_mode == 0) nrand = S.nrand_adv[pid];
-  else if (V.rng_mode == 1) nrand = G.start_index(0);
-  else nrand = 1;
-
+  AdvCtx<R> A;
+  const bool in_pbl = adv_begin(V, ps, itime, advance_start_index(V, S, G, pid), A);
+  if (in_pbl) {
+    if (is_new) {   // k_pbl re-reads the state from HBM
+      P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
+      P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
+      P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt;
+    }
+    pbl_list[atomicAdd(pbl_count, 1u)] = (unsigned int)s;
+    return;
+  }
+  above_step(V, hgt, G, itime, ps, A);
+  const int nstop = adv_finish(V, hgt, G, itime, ps, A);
   R prob[kMaxSpec];
-  const int nstop = advance_particle(V, hgt, G, nrand, itime, ps, prob, st);
+#pragma unroll
+  for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
+  epilogue_store<R, DRYDEP>(V, P, s, itime, itramem, nstop, ps, prob, st);
+}
 
-  // ---- epilogue, timemanager.f90:630-708 ----
-  int itra1;
-  if (nstop > 1) {
-    itra1 = kDead;
-    atomicAdd(&st->n_left, 1ull);
-  } else {
-    itra1 = itime + V.lsynctime;
-    R xmassfract = (R)0;
-    for (int ks = 0; ks < V.nspec; ks++) {
-      R decfact = V.decay[ks] > (R)0 ? m_exp(-(R)abs(V.lsynctime) * V.decay[ks]) : (R)1;
-      R xm = P.xmass1[(size_t)ks * P.cap + s];
-      if (V.drydep && V.drydepspec[ks]) xm = xm * ((R)1 - prob[ks]) * decfact;
-      else xm = xm * decfact;
-      P.xmass1[(size_t)ks * P.cap + s] = xm;
-      if (V.mdomainfill == 0) {
-        if (V.xmass_rel[ks] > (R)0) xmassfract = m_max(xmassfract, (R)V.npart_rel * xm / V.xmass_rel[ks]);
+template <typename R, bool DRYDEP>
+__global__ void __launch_bounds__(kBlock) k_pbl(View<R> V, Parts<R> P, SeqRng S, int itime, unsigned int step, Stats *st,
+                                                const unsigned int *__restrict__ pbl_list,
+                                                const unsigned int *__restrict__ pbl_count,
+                                                unsigned int *__restrict__ cursor) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  const unsigned int nlist = *pbl_count;
+  const int lane = threadIdx.x & 63;
+
+  bool have = false, exhausted = false;
+  long long s = 0;
+  int itramem = 0;
+  PState<R> ps;
+  AdvCtx<R> A;
+  PblCtx<R> B;
+  Rng<R> G;
+  R prob[kMaxSpec];
+
+  for (;;) {
+    if (!have && !exhausted) {
+      // wave-aggregated fetch of the next work items
+      const unsigned long long need = __ballot(1);
+      const unsigned int rank = __popcll(need & ((1ull << lane) - 1ull));
+      unsigned int base = 0;
+      if (rank == 0) base = atomicAdd(cursor, (unsigned int)__popcll(need));
+      base = __builtin_amdgcn_readfirstlane(base);
+      const unsigned int my = base + rank;
+      if (my < nlist) {
+        s = pbl_list[my];
+        ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
+        ps.up = P.up[s]; ps.vp = P.vp[s]; ps.wp = P.wp[s];
+        ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
+        ps.ldt = P.idt[s]; ps.icbt = P.cbt[s];
+        itramem = P.itramem[s];
+        const unsigned int pid = P.pid[s];
+        make_rng(V, pid, step, G);
+        adv_begin(V, ps, itime, advance_start_index(V, S, G, pid), A);
+        pbl_begin(V, ps, itime, A, B);
+#pragma unroll
+        for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
+        have = true;
       } else {
-        xmassfract = (R)1;
+        exhausted = true;
       }
     }
-    if (xmassfract < (R)0.0001) {   // minmass, par_mod.f90:213
-      itra1 = kDead;
-      atomicAdd(&st->n_minmass, 1ull);
-    } else if (abs(itra1 - itramem) >= V.lage_last) {
-      itra1 = kDead;
-      atomicAdd(&st->n_maxage, 1ull);
+    if (!__any(have)) break;   // every lane of the wave is out of work: the grid drains
+    if (have) {
+      const int rc = pbl_pass(V, hgt, G, itime, ps, A, B, prob, st);
+      if (rc != PBL_CONTINUE) {
+        if (rc == PBL_ESCAPED) above_step(V, hgt, G, itime, ps, A);
+        const int nstop = adv_finish(V, hgt, G, itime, ps, A);
+        epilogue_store<R, DRYDEP>(V, P, s, itime, itramem, nstop, ps, prob, st);
+        have = false;
+      }
     }
   }
-
-  P.xt[s] = ps.xt; P.yt[s] = ps.yt; P.zt[s] = ps.zt;
-  P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
-  P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
-  P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt; P.itra1[s] = itra1;
 }
 
 // ---------------------------------------------------------------------------
@@ -305,6 +402,8 @@ struct Engine : EngineBase {
   size_t staging_bytes = 0;
   unsigned int *slot_of_pid = nullptr;   // only after a locality sort
   Stats *d_stats = nullptr;
+  unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[0] = list length, ctr[1] = fetch cursor
+  int pbl_grid = 0;
   // TABLE_SEQ state
   HostRng<float> rng4;
   HostRng<double> rng8;
@@ -411,6 +510,8 @@ struct Engine : EngineBase {
     if ((rc = dalloc(&P.cbt, cap))) return rc;
     if ((rc = dalloc(&P.xmass1, cap * cfg.nspec))) return rc;
     if ((rc = dalloc(&P.pid, cap))) return rc;
+    if ((rc = dalloc(&d_pbl_list, cap))) return rc;
+    if ((rc = dalloc(&d_pbl_ctr, 2))) return rc;
     // every slot starts dead (FLEXPART.f90:315-317) with identity numbering
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, (long long)cap, nullptr);
@@ -742,8 +843,24 @@ struct Engine : EngineBase {
     }
     auto &ev = ev_pool[ev_used++];
     const int nb = (int)((numpart + kBlock - 1) / kBlock);
+    if (pbl_grid == 0) {
+      // persistent grid: as many blocks as the chip holds at this kernel's register budget
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
+      int per_cu = 0;
+      if (cfg.drydep) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl<R, true>, kBlock, 0));
+      else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl<R, false>, kBlock, 0));
+      pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
+    }
+    HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
     HIPCHK(hipEventRecord(ev.first, stream));
-    k_advance<R><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats);
+    if (cfg.drydep) {
+      k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+      k_pbl<R, true><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    } else {
+      k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+      k_pbl<R, false><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    }
     HIPCHK(hipEventRecord(ev.second, stream));
     HIPCHK(hipGetLastError());
     step_counter++;
