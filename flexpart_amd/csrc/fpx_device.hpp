@@ -170,26 +170,50 @@ struct Level {
   R u, v, w, rho, rhograd, usig, vsig, wsig;
 };
 
-// horizontal/time weights and the four corner columns (interpol_mod.f90:13-14)
+// horizontal weights and the corner indices of the cell (interpol_mod.f90:13-14)
 template <typename R>
 struct Cell {
-  R p1, p2, p3, p4, dt1, dt2, dtt;
-  long long c00, c10, c01, c11;   // column indices jy*nx+ix of the corners (ix,jy) (ixp,jy) (ix,jyp) (ixp,jyp)
+  R p1, p2, p3, p4;
+  int ix, jy, ixp, jyp;
+};
+// time weights dt1, dt2, dtt (interpol_mod.f90:13): the same for every particle of a step,
+// so they live in scalar registers
+template <typename R>
+struct TimeW {
+  R dt1, dt2, dtt;
 };
 
 template <typename R>
-FPX_DEV void cell_setup(const View<R> &V, Cell<R> &C, int ix, int jy, int ixp, int jyp, R xt, R yt, int itime) {
-  // interpol_all.f90:57-71 (identical blocks open interpol_wind / interpol_wind_short)
+FPX_DEV TimeW<R> time_weights(const View<R> &V, int itime) {   // interpol_all.f90:69-71
+  TimeW<R> W;
+  W.dt1 = (R)(itime - V.memtime0);
+  W.dt2 = (R)(V.memtime1 - itime);
+  W.dtt = K(1.) / (W.dt1 + W.dt2);
+  return W;
+}
+
+template <typename R>
+FPX_DEV void cell_setup(Cell<R> &C, int ix, int jy, int ixp, int jyp, R xt, R yt) {
+  // interpol_all.f90:57-64 (identical blocks open interpol_wind / interpol_wind_short)
   R ddx = xt - (R)ix, ddy = yt - (R)jy;
   R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
   C.p1 = rddx * rddy; C.p2 = ddx * rddy; C.p3 = rddx * ddy; C.p4 = ddx * ddy;
-  C.dt1 = (R)(itime - V.memtime0);
-  C.dt2 = (R)(V.memtime1 - itime);
-  C.dtt = K(1.) / (C.dt1 + C.dt2);
-  C.c00 = (long long)jy * V.nx + ix;
-  C.c10 = (long long)jy * V.nx + ixp;
-  C.c01 = (long long)jyp * V.nx + ix;
-  C.c11 = (long long)jyp * V.nx + ixp;
+  C.ix = ix; C.jy = jy; C.ixp = ixp; C.jyp = jyp;
+}
+
+// element offsets of the four corner columns (ix,jy) (ixp,jy) (ix,jyp) (ixp,jyp)
+template <typename R>
+struct Cols {
+  long long c00, c10, c01, c11;
+};
+template <typename R>
+FPX_DEV Cols<R> cols_of(const View<R> &V, const Cell<R> &C) {
+  Cols<R> Q;
+  Q.c00 = (long long)C.jy * V.nx + C.ix;
+  Q.c10 = (long long)C.jy * V.nx + C.ixp;
+  Q.c01 = (long long)C.jyp * V.nx + C.ix;
+  Q.c11 = (long long)C.jyp * V.nx + C.ixp;
+  return Q;
 }
 
 // load (a,b,c) of one corner/level/slot from a [..][nz][2][3] array
@@ -199,45 +223,52 @@ FPX_DEV void ld3(const R *base, long long col, int nz, int n, int slot, R &a, R 
   a = p[0]; b = p[1]; c = p[2];
 }
 
-template <typename R, bool WITH_RHO, bool WITH_SIG>
-FPX_DEV void level_profile(const View<R> &V, const Cell<R> &C, const R *w3, int n, Level<R> &L) {
+template <typename R, bool WITH_WIND, bool WITH_RHO, bool WITH_SIG>
+FPX_DEV void level_profile(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, const R *w3, int n, Level<R> &L) {
   const R eps = K(1.0e-30);
+  const Cols<R> Q = cols_of(V, C);
   R y1[2], y2[2], y3[2], rho1[2], rhograd1[2];
   R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     int slot = m == 0 ? V.m1 : V.m2;
-    R u00, v00, w00, u10, v10, w10, u01, v01, w01, u11, v11, w11;
-    ld3(w3, C.c00, V.nz, n, slot, u00, v00, w00);
-    ld3(w3, C.c10, V.nz, n, slot, u10, v10, w10);
-    ld3(w3, C.c01, V.nz, n, slot, u01, v01, w01);
-    ld3(w3, C.c11, V.nz, n, slot, u11, v11, w11);
-    y1[m] = C.p1 * u00 + C.p2 * u10 + C.p3 * u01 + C.p4 * u11;
-    y2[m] = C.p1 * v00 + C.p2 * v10 + C.p3 * v01 + C.p4 * v11;
-    y3[m] = C.p1 * w00 + C.p2 * w10 + C.p3 * w01 + C.p4 * w11;
-    if (WITH_SIG) {
-      usl = usl + u00 + u10 + u01 + u11;
-      vsl = vsl + v00 + v10 + v01 + v11;
-      wsl = wsl + w00 + w10 + w01 + w11;
-      usq = usq + u00 * u00 + u10 * u10 + u01 * u01 + u11 * u11;
-      vsq = vsq + v00 * v00 + v10 * v10 + v01 * v01 + v11 * v11;
-      wsq = wsq + w00 * w00 + w10 * w10 + w01 * w01 + w11 * w11;
+    if (WITH_WIND || WITH_SIG) {
+      R u00, v00, w00, u10, v10, w10, u01, v01, w01, u11, v11, w11;
+      ld3(w3, Q.c00, V.nz, n, slot, u00, v00, w00);
+      ld3(w3, Q.c10, V.nz, n, slot, u10, v10, w10);
+      ld3(w3, Q.c01, V.nz, n, slot, u01, v01, w01);
+      ld3(w3, Q.c11, V.nz, n, slot, u11, v11, w11);
+      if (WITH_WIND) {
+        y1[m] = C.p1 * u00 + C.p2 * u10 + C.p3 * u01 + C.p4 * u11;
+        y2[m] = C.p1 * v00 + C.p2 * v10 + C.p3 * v01 + C.p4 * v11;
+        y3[m] = C.p1 * w00 + C.p2 * w10 + C.p3 * w01 + C.p4 * w11;
+      }
+      if (WITH_SIG) {
+        usl = usl + u00 + u10 + u01 + u11;
+        vsl = vsl + v00 + v10 + v01 + v11;
+        wsl = wsl + w00 + w10 + w01 + w11;
+        usq = usq + u00 * u00 + u10 * u10 + u01 * u01 + u11 * u11;
+        vsq = vsq + v00 * v00 + v10 * v10 + v01 * v01 + v11 * v11;
+        wsq = wsq + w00 * w00 + w10 * w10 + w01 * w01 + w11 * w11;
+      }
     }
     if (WITH_RHO) {
-      const R *q00 = V.r2 + ((C.c00 * V.nz + (n - 1)) * 2 + slot) * 2;
-      const R *q10 = V.r2 + ((C.c10 * V.nz + (n - 1)) * 2 + slot) * 2;
-      const R *q01 = V.r2 + ((C.c01 * V.nz + (n - 1)) * 2 + slot) * 2;
-      const R *q11 = V.r2 + ((C.c11 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q00 = V.r2 + ((Q.c00 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q10 = V.r2 + ((Q.c10 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q01 = V.r2 + ((Q.c01 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q11 = V.r2 + ((Q.c11 * V.nz + (n - 1)) * 2 + slot) * 2;
       rho1[m] = C.p1 * q00[0] + C.p2 * q10[0] + C.p3 * q01[0] + C.p4 * q11[0];
       rhograd1[m] = C.p1 * q00[1] + C.p2 * q10[1] + C.p3 * q01[1] + C.p4 * q11[1];
     }
   }
-  L.u = (y1[0] * C.dt2 + y1[1] * C.dt1) * C.dtt;
-  L.v = (y2[0] * C.dt2 + y2[1] * C.dt1) * C.dtt;
-  L.w = (y3[0] * C.dt2 + y3[1] * C.dt1) * C.dtt;
+  if (WITH_WIND) {
+    L.u = (y1[0] * W.dt2 + y1[1] * W.dt1) * W.dtt;
+    L.v = (y2[0] * W.dt2 + y2[1] * W.dt1) * W.dtt;
+    L.w = (y3[0] * W.dt2 + y3[1] * W.dt1) * W.dtt;
+  }
   if (WITH_RHO) {
-    L.rho = (rho1[0] * C.dt2 + rho1[1] * C.dt1) * C.dtt;
-    L.rhograd = (rhograd1[0] * C.dt2 + rhograd1[1] * C.dt1) * C.dtt;
+    L.rho = (rho1[0] * W.dt2 + rho1[1] * W.dt1) * W.dtt;
+    L.rhograd = (rhograd1[0] * W.dt2 + rhograd1[1] * W.dt1) * W.dtt;
   }
   if (WITH_SIG) {   // 8-point standard deviation, interpol_all.f90:218-238
     R xaux = usq - usl * usl / K(8.);
@@ -801,9 +832,10 @@ FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, 
 
 // wind at (cell, zt): interpol_wind.f90:75-214 (SIG) / interpol_wind_short.f90:67-140
 template <typename R, bool SIG>
-FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const R *w3, R zt,
+FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const TimeW<R> &W, const R *w3, R zt,
                          R &u, R &v, R &w, R &usig, R &vsig, R &wsig) {
   const R eps = K(1.0e-30);
+  const Cols<R> Q = cols_of(V, C);
   int indz = find_level(hgt, V.nz, zt);
   R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
   R dz1 = (zt - hgt[indz - 1]) * dz;
@@ -818,10 +850,10 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const
     for (int n = 0; n < 2; n++) {
       int indzh = indz + n;
       R u00, v00, w00, u10, v10, w10, u01, v01, w01, u11, v11, w11;
-      ld3(w3, C.c00, V.nz, indzh, slot, u00, v00, w00);
-      ld3(w3, C.c10, V.nz, indzh, slot, u10, v10, w10);
-      ld3(w3, C.c01, V.nz, indzh, slot, u01, v01, w01);
-      ld3(w3, C.c11, V.nz, indzh, slot, u11, v11, w11);
+      ld3(w3, Q.c00, V.nz, indzh, slot, u00, v00, w00);
+      ld3(w3, Q.c10, V.nz, indzh, slot, u10, v10, w10);
+      ld3(w3, Q.c01, V.nz, indzh, slot, u01, v01, w01);
+      ld3(w3, Q.c11, V.nz, indzh, slot, u11, v11, w11);
       u1[n] = C.p1 * u00 + C.p2 * u10 + C.p3 * u01 + C.p4 * u11;
       v1[n] = C.p1 * v00 + C.p2 * v10 + C.p3 * v01 + C.p4 * v11;
       w1[n] = C.p1 * w00 + C.p2 * w10 + C.p3 * w01 + C.p4 * w11;
@@ -838,9 +870,9 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const
     vh[m] = dz2 * v1[0] + dz1 * v1[1];
     wh[m] = dz2 * w1[0] + dz1 * w1[1];
   }
-  u = (uh[0] * C.dt2 + uh[1] * C.dt1) * C.dtt;
-  v = (vh[0] * C.dt2 + vh[1] * C.dt1) * C.dtt;
-  w = (wh[0] * C.dt2 + wh[1] * C.dt1) * C.dtt;
+  u = (uh[0] * W.dt2 + uh[1] * W.dt1) * W.dtt;
+  v = (vh[0] * W.dt2 + vh[1] * W.dt1) * W.dtt;
+  w = (wh[0] * W.dt2 + wh[1] * W.dt1) * W.dtt;
   if (SIG) {   // 16-point sigma, interpol_wind.f90:194-214
     R xaux = usq - usl * usl / K(16.);
     usig = xaux < eps ? K(0.) : m_sqrt(xaux / K(15.));
@@ -853,59 +885,80 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const
 
 // ust, wst, ol at the cell: interpol_all.f90:80-107
 template <typename R>
-FPX_DEV void interp_surface(const View<R> &V, const Cell<R> &C, Turb<R> &T) {
+FPX_DEV void interp_surface(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, Turb<R> &T) {
+  const Cols<R> Q = cols_of(V, C);
   R ust1[2], wst1[2], oli1[2];
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     int slot = m == 0 ? V.m1 : V.m2;
-    const R *a = V.sfc + (C.c00 * 2 + slot) * 4, *b = V.sfc + (C.c10 * 2 + slot) * 4;
-    const R *c = V.sfc + (C.c01 * 2 + slot) * 4, *d = V.sfc + (C.c11 * 2 + slot) * 4;
+    const R *a = V.sfc + (Q.c00 * 2 + slot) * 4, *b = V.sfc + (Q.c10 * 2 + slot) * 4;
+    const R *c = V.sfc + (Q.c01 * 2 + slot) * 4, *d = V.sfc + (Q.c11 * 2 + slot) * 4;
     ust1[m] = C.p1 * a[0] + C.p2 * b[0] + C.p3 * c[0] + C.p4 * d[0];
     wst1[m] = C.p1 * a[1] + C.p2 * b[1] + C.p3 * c[1] + C.p4 * d[1];
     oli1[m] = C.p1 * a[2] + C.p2 * b[2] + C.p3 * c[2] + C.p4 * d[2];
   }
-  T.ust = (ust1[0] * C.dt2 + ust1[1] * C.dt1) * C.dtt;
-  T.wst = (wst1[0] * C.dt2 + wst1[1] * C.dt1) * C.dtt;
-  R oliaux = (oli1[0] * C.dt2 + oli1[1] * C.dt1) * C.dtt;
+  T.ust = (ust1[0] * W.dt2 + ust1[1] * W.dt1) * W.dtt;
+  T.wst = (wst1[0] * W.dt2 + wst1[1] * W.dt1) * W.dtt;
+  R oliaux = (oli1[0] * W.dt2 + oli1[1] * W.dt1) * W.dtt;
   T.ol = oliaux != K(0.) ? K(1.) / oliaux : K(99999.);
 }
 
 // interpol_vdep.f90:39-54
 template <typename R>
-FPX_DEV R interp_vdep(const View<R> &V, const Cell<R> &C, int ks) {
+FPX_DEV R interp_vdep(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, int ks) {
+  const Cols<R> Q = cols_of(V, C);
   R y[2];
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     int slot = m == 0 ? V.m1 : V.m2;
-    y[m] = C.p1 * V.vdep[(C.c00 * 2 + slot) * V.nspec + ks] + C.p2 * V.vdep[(C.c10 * 2 + slot) * V.nspec + ks] +
-           C.p3 * V.vdep[(C.c01 * 2 + slot) * V.nspec + ks] + C.p4 * V.vdep[(C.c11 * 2 + slot) * V.nspec + ks];
+    y[m] = C.p1 * V.vdep[(Q.c00 * 2 + slot) * V.nspec + ks] + C.p2 * V.vdep[(Q.c10 * 2 + slot) * V.nspec + ks] +
+           C.p3 * V.vdep[(Q.c01 * 2 + slot) * V.nspec + ks] + C.p4 * V.vdep[(Q.c11 * 2 + slot) * V.nspec + ks];
   }
-  return (y[0] * C.dt2 + y[1] * C.dt1) * C.dtt;
+  return (y[0] * W.dt2 + y[1] * W.dt1) * W.dtt;
 }
 
 // two-level profile cache: the reference caches every PBL level it has touched
 // (indzindicator, interpol_mod.f90:16); values are pure functions of the level,
 // so recomputing on a miss gives the same numbers with two levels in registers.
+// The 8-point sigmas (usigprof..) are only read when the interval ends
+// (advance.f90:604-606): they are evaluated then, for the final level pair.
 template <typename R>
 struct LevelCache {
-  Level<R> lo, hi;
-  int ilo, ihi;
+  R ulo, vlo, wlo, rholo, rhogradlo;
+  R uhi, vhi, whi, rhohi, rhogradhi;
+  int ilo;   // level index of *lo; *hi is ilo+1; -1 = empty
 };
 
 template <typename R>
-FPX_DEV void cache_fetch(const View<R> &V, const Cell<R> &C, const R *w3, LevelCache<R> &LC, int indz) {
-  int indzp = indz + 1;
-  if (LC.ilo == indz && LC.ihi == indzp) return;
-  if (LC.ilo == indzp) {            // moved one level down
-    LC.hi = LC.lo; LC.ihi = indzp;
-    level_profile<R, true, true>(V, C, w3, indz, LC.lo); LC.ilo = indz;
-  } else if (LC.ihi == indz) {      // moved one level up
-    LC.lo = LC.hi; LC.ilo = indz;
-    level_profile<R, true, true>(V, C, w3, indzp, LC.hi); LC.ihi = indzp;
+FPX_DEV void cache_fetch(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, const R *w3, LevelCache<R> &LC, int indz) {
+  if (LC.ilo == indz) return;
+  Level<R> L;
+  if (LC.ilo == indz + 1) {            // moved one level down
+    LC.uhi = LC.ulo; LC.vhi = LC.vlo; LC.whi = LC.wlo; LC.rhohi = LC.rholo; LC.rhogradhi = LC.rhogradlo;
+    level_profile<R, true, true, false>(V, C, W, w3, indz, L);
+    LC.ulo = L.u; LC.vlo = L.v; LC.wlo = L.w; LC.rholo = L.rho; LC.rhogradlo = L.rhograd;
+  } else if (LC.ilo == indz - 1) {     // moved one level up
+    LC.ulo = LC.uhi; LC.vlo = LC.vhi; LC.wlo = LC.whi; LC.rholo = LC.rhohi; LC.rhogradlo = LC.rhogradhi;
+    level_profile<R, true, true, false>(V, C, W, w3, indz + 1, L);
+    LC.uhi = L.u; LC.vhi = L.v; LC.whi = L.w; LC.rhohi = L.rho; LC.rhogradhi = L.rhograd;
   } else {
-    level_profile<R, true, true>(V, C, w3, indz, LC.lo); LC.ilo = indz;
-    level_profile<R, true, true>(V, C, w3, indzp, LC.hi); LC.ihi = indzp;
+    level_profile<R, true, true, false>(V, C, W, w3, indz, L);
+    LC.ulo = L.u; LC.vlo = L.v; LC.wlo = L.w; LC.rholo = L.rho; LC.rhogradlo = L.rhograd;
+    level_profile<R, true, true, false>(V, C, W, w3, indz + 1, L);
+    LC.uhi = L.u; LC.vhi = L.v; LC.whi = L.w; LC.rhohi = L.rho; LC.rhogradhi = L.rhograd;
   }
+  LC.ilo = indz;
+}
+
+// usig = 0.5*(usigprof(indzp)+usigprof(indz)) etc., advance.f90:604-606
+template <typename R>
+FPX_DEV void level_pair_sigma(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, const R *w3, int indz, R &usig, R &vsig, R &wsig) {
+  Level<R> lo, hi;
+  level_profile<R, false, false, true>(V, C, W, w3, indz, lo);
+  level_profile<R, false, false, true>(V, C, W, w3, indz + 1, hi);
+  usig = K(0.5) * (hi.usig + lo.usig);
+  vsig = K(0.5) * (hi.vsig + lo.vsig);
+  wsig = K(0.5) * (hi.wsig + lo.wsig);
 }
 
 // initialize.f90:66-217.  Returns nothing; fills the turbulent state of a new particle.
@@ -922,18 +975,19 @@ FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const Rng<R> &G
   T.h = V.hcell[(long long)jy * V.nx + ix];   // max of the 8 hmix values, initialize.f90:83-90
   T.zeta = P.zt / T.h;
   Cell<R> C;
-  cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime);
+  cell_setup(C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt);
+  const TimeW<R> W = time_weights(V, itime);
   // The reference's initialize() reads the module variable ngrid left behind by the
   // previous particle's advance() (interpol_all.f90:144); a parallel engine has no
   // "previous particle", so the particle's own polar/lat-lon choice is used.
   const R *w3 = pick_grid(V, P.xt, P.yt) < 0 ? V.w3pol : V.w3;
   R usig, vsig, wsig;
   if (T.zeta <= K(1.)) {
-    interp_surface(V, C, T);
+    interp_surface(V, C, W, T);
     int indz = find_level(hgt, V.nz, P.zt);
     Level<R> lo, hi;
-    level_profile<R, false, true>(V, C, w3, indz, lo);
-    level_profile<R, false, true>(V, C, w3, indz + 1, hi);
+    level_profile<R, false, false, true>(V, C, W, w3, indz, lo);
+    level_profile<R, false, false, true>(V, C, W, w3, indz + 1, hi);
     // (u,v,w of initialize.f90:116-118 are not used further)
     if (V.turbswitch) hanna(T, P.zt); else hanna1(T, P.zt);
     if (nrand + 2 > V.maxrand) nrand = 1;
@@ -963,7 +1017,7 @@ FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const Rng<R> &G
     wsig = (hi.wsig + lo.wsig) / K(2.);
   } else {
     R u, v, w;
-    interp_wind<R, true>(V, hgt, C, w3, P.zt, u, v, w, usig, vsig, wsig);
+    interp_wind<R, true>(V, hgt, C, W, w3, P.zt, u, v, w, usig, vsig, wsig);
     P.ldt = abs(V.lsynctime);
     if (nrand + 1 > V.maxrand) nrand = 1;
     P.up = G.at(nrand) * K(0.3);
@@ -989,8 +1043,8 @@ FPX_DEV int initialize_needs_cbl_draws(const View<R> &V, const R *hgt, int itime
   T.h = V.hcell[(long long)jy * V.nx + ix];
   if (!(zt / T.h <= K(1.))) return 0;
   Cell<R> C;
-  cell_setup(V, C, ix, jy, ix + 1, jy + 1, (R)xt, (R)yt, itime);
-  interp_surface(V, C, T);
+  cell_setup(C, ix, jy, ix + 1, jy + 1, (R)xt, (R)yt);
+  interp_surface(V, C, time_weights(V, itime), T);
   return (-T.h / T.ol > K(5)) ? 1 : 0;
 }
 
@@ -1007,11 +1061,10 @@ FPX_DEV int initialize_needs_cbl_draws(const View<R> &V, const R *hgt, int itime
 template <typename R>
 struct AdvCtx {                 // what advance() keeps between its labelled sections
   int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
-  R h, tropop;
+  R h;
   R dxsave, dysave, dawsave, dcwsave;
-  R u, v, w, usig, vsig, wsig;  // interpol_mod u..wsig
+  R u, v, w;                    // interpol_mod u, v, w
   int itimec, nrand;
-  int ldt_last;                 // ldt of the step section that ran last (Petterssen gate :829)
 };
 
 enum { PBL_CONTINUE = 0, PBL_DONE = 1, PBL_ESCAPED = 2 };
@@ -1021,95 +1074,96 @@ FPX_DEV R eps_domain() { return K(361) / K(3.e5); }   // nxmax/3.e5 with the ref
 
 // returns true when the particle starts inside the PBL (zeta <= 1, advance.f90:276)
 template <typename R>
-FPX_DEV bool adv_begin(const View<R> &V, const PState<R> &P, int itime, int nrand, AdvCtx<R> &A) {
+FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, int nrand, AdvCtx<R> &A) {
   A.dxsave = K(0.); A.dysave = K(0.); A.dawsave = K(0.); A.dcwsave = K(0.);
-  A.u = K(0.); A.v = K(0.); A.w = K(0.); A.usig = K(0.); A.vsig = K(0.); A.wsig = K(0.);
+  A.u = K(0.); A.v = K(0.); A.w = K(0.);
   A.itimec = itime;
   A.nrand = nrand;
-  A.ngrid = pick_grid(V, P.xt, P.yt);
-  A.ix = (int)P.xt; A.jy = (int)P.yt;
-  int nix = (int)lround(P.xt), njy = (int)lround(P.yt);
+  A.ngrid = pick_grid(V, xt, yt);
+  A.ix = (int)xt; A.jy = (int)yt;
   A.ixp = A.ix + 1; A.jyp = A.jy + 1;
   if (A.jyp >= V.ny) A.jyp = A.jyp - 1;   // advance.f90:228-231 (device rows are allocated ny, not nymax)
   if (A.ixp >= V.nx) A.ixp = V.nx - 1;    // guard for a non-cyclic domain edge
   A.h = V.hcell[(long long)A.jy * V.nx + A.ix];          // advance.f90:236-252 (interpolhmix=.false.)
-  A.tropop = V.tropo[(long long)njy * V.nx + nix];       // advance.f90:253
-  A.ldt_last = P.ldt;
-  return P.zt / A.h <= K(1.);
+  return zt / A.h <= K(1.);
 }
 
 template <typename R>
 struct PblCtx {                 // live across passes of the PBL loop
   Cell<R> C;
-  Turb<R> T;
+  R ust, wst, ol;               // hanna_mod ust, wst, ol
   LevelCache<R> LC;
   R transition;                 // cbl.f90:79-81, constant during the step (depends on h/ol only)
 };
 
 template <typename R>
-FPX_DEV void pbl_begin(const View<R> &V, const PState<R> &P, int itime, const AdvCtx<R> &A, PblCtx<R> &B) {
-  cell_setup(V, B.C, A.ix, A.jy, A.ixp, A.jyp, (R)P.xt, (R)P.yt, itime);   // interpol_all.f90:57-71
-  B.T.h = A.h; B.T.sigw = K(0.); B.T.dsigw2dz = K(0.); B.T.dsigwdz = K(0.);
-  B.T.sigu = K(0.); B.T.sigv = K(0.); B.T.tlu = K(10.); B.T.tlv = K(10.); B.T.tlw = K(30.);
-  B.T.zeta = P.zt / A.h;
-  interp_surface(V, B.C, B.T);
-  B.transition = V.cblflag == 1 ? cbl_transition(A.h, B.T.ol) : K(1.);
-  B.LC.ilo = -1; B.LC.ihi = -1;
+FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W, const AdvCtx<R> &A, PblCtx<R> &B) {
+  cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, (R)xt, (R)yt);   // interpol_all.f90:57-64
+  Turb<R> T;
+  interp_surface(V, B.C, W, T);
+  B.ust = T.ust; B.wst = T.wst; B.ol = T.ol;
+  B.transition = V.cblflag == 1 ? cbl_transition(A.h, T.ol) : K(1.);
+  B.LC.ilo = -1;
 }
 
 // One pass of the loop advance.f90:282-609.  prob: dry-deposition probabilities (DRYDEP only).
-template <typename R>
-FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A,
-                     PblCtx<R> &B, R *prob, Stats *st) {
+// usig/vsig/wsig are written when the pass ends the interval (return PBL_DONE).
+template <typename R, bool DRYDEP>
+FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const TimeW<R> &W, int itime, double xt, double yt,
+                     R &zt, R &up, R &vp, R &wp, int &ldt, short &icbt, AdvCtx<R> &A, PblCtx<R> &B,
+                     R &usig, R &vsig, R &wsig, R *prob, Stats *st) {
   const R eps = eps_domain<R>();
   const R eps2 = K(1.e-9);
   const R href = K(15.);            // par_mod.f90:76
-  Turb<R> &T = B.T;
   const R h = A.h;
   const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
   int nrand = A.nrand;
+  Turb<R> T;
+  T.ust = B.ust; T.wst = B.wst; T.ol = B.ol; T.h = h;
+  T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);   // only read if hanna1 meets zeta >= 1 (see hanna1)
 
   if (V.method == 1) {
-    P.ldt = min(P.ldt, abs(V.lsynctime - A.itimec + itime));
-    A.itimec = A.itimec + P.ldt * V.ldirect;
+    ldt = min(ldt, abs(V.lsynctime - A.itimec + itime));
+    A.itimec = A.itimec + ldt * V.ldirect;
   } else {
-    P.ldt = abs(V.lsynctime);
+    ldt = abs(V.lsynctime);
     A.itimec = itime + V.lsynctime;
   }
-  const R dt = (R)P.ldt;
-  T.zeta = P.zt / h;
+  const R dt = (R)ldt;
+  T.zeta = zt / h;
 
-  const int indz = find_level(hgt, V.nz, P.zt);
+  const int indz = find_level(hgt, V.nz, zt);
   const int indzp = indz + 1;
-  cache_fetch(V, B.C, w3, B.LC, indz);
+  cache_fetch(V, B.C, W, w3, B.LC, indz);
 
   // advance.f90:342-350
   const R dz = K(1.) / (hgt[indzp - 1] - hgt[indz - 1]);
-  const R dz1 = (P.zt - hgt[indz - 1]) * dz;
-  const R dz2 = (hgt[indzp - 1] - P.zt) * dz;
-  A.u = dz1 * B.LC.hi.u + dz2 * B.LC.lo.u;
-  A.v = dz1 * B.LC.hi.v + dz2 * B.LC.lo.v;
-  A.w = dz1 * B.LC.hi.w + dz2 * B.LC.lo.w;
-  const R rhoa = dz1 * B.LC.hi.rho + dz2 * B.LC.lo.rho;
-  const R rhograd = dz1 * B.LC.hi.rhograd + dz2 * B.LC.lo.rhograd;
+  const R dz1 = (zt - hgt[indz - 1]) * dz;
+  const R dz2 = (hgt[indzp - 1] - zt) * dz;
+  A.u = dz1 * B.LC.uhi + dz2 * B.LC.ulo;
+  A.v = dz1 * B.LC.vhi + dz2 * B.LC.vlo;
+  A.w = dz1 * B.LC.whi + dz2 * B.LC.wlo;
+  const R rhoa = dz1 * B.LC.rhohi + dz2 * B.LC.rholo;
+  const R rhograd = dz1 * B.LC.rhogradhi + dz2 * B.LC.rhogradlo;
 
-  if (V.turbswitch) hanna(T, P.zt); else hanna1(T, P.zt);
+  if (V.turbswitch) hanna(T, zt); else hanna1(T, zt);
+  B.ust = T.ust;   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
 
   // horizontal Langevin, advance.f90:371-384
   if (nrand + 1 > V.maxrand) nrand = 1;
   {
     const R g1 = G.at(nrand), g2 = G.at(nrand + 1);
     if (dt / T.tlu < K(.5)) {
-      P.up = (K(1.) - dt / T.tlu) * P.up + g1 * T.sigu * m_sqrt(K(2.) * dt / T.tlu);
+      up = (K(1.) - dt / T.tlu) * up + g1 * T.sigu * m_sqrt(K(2.) * dt / T.tlu);
     } else {
       R ru = m_exp(-dt / T.tlu);
-      P.up = ru * P.up + g1 * T.sigu * m_sqrt(K(1.) - ru * ru);
+      up = ru * up + g1 * T.sigu * m_sqrt(K(1.) - ru * ru);
     }
     if (dt / T.tlv < K(.5)) {
-      P.vp = (K(1.) - dt / T.tlv) * P.vp + g2 * T.sigv * m_sqrt(K(2.) * dt / T.tlv);
+      vp = (K(1.) - dt / T.tlv) * vp + g2 * T.sigv * m_sqrt(K(2.) * dt / T.tlv);
     } else {
       R rv = m_exp(-dt / T.tlv);
-      P.vp = rv * P.vp + g2 * T.sigv * m_sqrt(K(1.) - rv * rv);
+      vp = rv * vp + g2 * T.sigv * m_sqrt(K(1.) - rv * rv);
     }
   }
   nrand = nrand + 2;
@@ -1130,113 +1184,109 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, int itime,
           if (cbl_on) {
             int flagrein = 0;
             nrand = nrand + 1;
-            R old_wp_buf = P.wp, ath, bth;
-            cbl(V.ldirect, P.wp, P.zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, B.transition, ath, bth, flagrein);
-            P.wp = (P.wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)P.icbt;
-            delz = P.wp * dtf;
+            R old_wp_buf = wp, ath, bth;
+            cbl(V.ldirect, wp, zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, B.transition, ath, bth, flagrein);
+            wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
+            delz = wp * dtf;
             if (flagrein == 1) {
-              re_initialize_particle(V.ldirect, G, P.zt, T.wst, h, T.sigw, old_wp_buf, nrand, T.ol);
-              P.wp = old_wp_buf;
-              delz = P.wp * dtf;
+              re_initialize_particle(V.ldirect, G, zt, T.wst, h, T.sigw, old_wp_buf, nrand, T.ol);
+              wp = old_wp_buf;
+              delz = wp * dtf;
               atomicAdd(&st->nan_count, 1ull);
             }
           } else {
             nrand = nrand + 1;
-            R ath = -P.wp / T.tlw + T.sigw * T.dsigwdz + P.wp * P.wp / T.sigw * T.dsigwdz + T.sigw * T.sigw / rhoa * rhograd;
+            R ath = -wp / T.tlw + T.sigw * T.dsigwdz + wp * wp / T.sigw * T.dsigwdz + T.sigw * T.sigw / rhoa * rhograd;
             R bth = T.sigw * G.at(nrand) * m_sqrt(K(2.) * dtftlw);
-            P.wp = (P.wp + ath * dtf + bth) * (R)P.icbt;
-            delz = P.wp * dtf;
-            R del_test = (K(1.) - P.wp) / P.wp;
-            if (isnan(P.wp) || isnan(del_test)) {
+            wp = (wp + ath * dtf + bth) * (R)icbt;
+            delz = wp * dtf;
+            R del_test = (K(1.) - wp) / wp;
+            if (isnan(wp) || isnan(del_test)) {
               nrand = nrand + 1;
-              P.wp = T.sigw * G.at(nrand);
-              delz = P.wp * dtf;
+              wp = T.sigw * G.at(nrand);
+              delz = wp * dtf;
               atomicAdd(&st->nan_count2, 1ull);
             }
           }
         } else {
-          P.wp = ((K(1.) - dtftlw) * P.wp + G.at(nrand + i) * m_sqrt(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
-          delz = P.wp * T.sigw * dtf;
+          wp = ((K(1.) - dtftlw) * wp + G.at(nrand + i) * m_sqrt(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
+          delz = wp * T.sigw * dtf;
         }
       } else {
         R rw = m_exp(-dtftlw);
-        P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)P.icbt;
-        delz = P.wp * T.sigw * dtf;
+        wp = (rw * wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
+        delz = wp * T.sigw * dtf;
       }
     } else {
       R rw = m_exp(-dtftlw);
-      P.wp = (rw * P.wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)P.icbt;
-      delz = P.wp * dtf;
+      wp = (rw * wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)icbt;
+      delz = wp * dtf;
     }
 
     // reflection at the ground / mixing height, advance.f90:476-491
     if (m_abs(delz) > h) delz = m_fmod(delz, h);
-    if (delz < -P.zt) {
-      P.icbt = -1;
-      P.zt = -P.zt - delz;
-    } else if (delz > (h - P.zt)) {
-      P.icbt = -1;
-      P.zt = -P.zt - delz + K(2.) * h;
+    if (delz < -zt) {
+      icbt = -1;
+      zt = -zt - delz;
+    } else if (delz > (h - zt)) {
+      icbt = -1;
+      zt = -zt - delz + K(2.) * h;
     } else {
-      P.icbt = 1;
-      P.zt = P.zt + delz;
+      icbt = 1;
+      zt = zt + delz;
     }
     if (i != V.ifine) {
-      T.zeta = P.zt / h;
-      hanna_short(T, P.zt);
+      T.zeta = zt / h;
+      hanna_short(T, zt);
     }
   }
   if (V.cblflag != 1) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i", i = ifine+1 after the loop (advance.f90:499)
   A.nrand = nrand;
-  A.ldt_last = P.ldt;
 
   // next sub-step length, advance.f90:504-510
   if (V.turbswitch)
-    P.ldt = (int)(m_min(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)) * V.ctl);
+    ldt = (int)(m_min(m_min(T.tlw, h / m_max(K(2.) * m_abs(wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)) * V.ctl);
   else
-    P.ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(P.wp), K(1.e-5))) * V.ctl);
-  P.ldt = max(P.ldt, V.mintime);
+    ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(wp), K(1.e-5))) * V.ctl);
+  ldt = max(ldt, V.mintime);
 
-  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:518-531
+  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt);   // advance.f90:518-531
 
   // advance.f90:539-547
   A.dxsave = A.dxsave + A.u * dt;
   A.dysave = A.dysave + A.v * dt;
-  A.dawsave = A.dawsave + P.up * dt;
-  A.dcwsave = A.dcwsave + P.vp * dt;
-  P.zt = P.zt + A.w * dt * (R)V.ldirect;
-  if (P.zt >= hgt[V.nz - 1]) P.zt = hgt[V.nz - 1] - K(100.) * eps;
+  A.dawsave = A.dawsave + up * dt;
+  A.dcwsave = A.dcwsave + vp * dt;
+  zt = zt + A.w * dt * (R)V.ldirect;
+  if (zt >= hgt[V.nz - 1]) zt = hgt[V.nz - 1] - K(100.) * eps;
 
   const bool end_of_interval = A.itimec == itime + V.lsynctime;
-  if (P.zt > h) {   // advance.f90:549-552
+  if (zt > h) {   // advance.f90:549-552
     if (end_of_interval) {
       // -> 99.  The reference reaches label 99 here with usig/vsig/wsig still holding
       // whatever the previous particle left in interpol_mod; use this particle's own
       // profile values, as the regular exit :603-606 does.
-      A.usig = K(0.5) * (B.LC.hi.usig + B.LC.lo.usig);
-      A.vsig = K(0.5) * (B.LC.hi.vsig + B.LC.lo.vsig);
-      A.wsig = K(0.5) * (B.LC.hi.wsig + B.LC.lo.wsig);
+      level_pair_sigma(V, B.C, W, w3, indz, usig, vsig, wsig);
       return PBL_DONE;
     }
     return PBL_ESCAPED;   // -> 700
   }
 
   // dry-deposition probability, advance.f90:582-599
-  if (V.drydep && P.zt < K(2.) * href) {
-    for (int ks = 0; ks < V.nspec; ks++) {
-      if (V.drydepspec[ks]) {
-        R vdepo = interp_vdep(V, B.C, ks);   // same value every pass (depoindicator cache in the reference)
+  if (DRYDEP && zt < K(2.) * href) {
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++) {
+      if (ks < V.nspec && V.drydepspec[ks]) {
+        R vdepo = interp_vdep(V, B.C, W, ks);   // same value every pass (depoindicator cache in the reference)
         prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_exp(-vdepo * m_abs(dt) / (K(2.) * href));
       }
     }
   }
 
-  if (P.zt < K(0.)) P.zt = m_min(h - eps2, K(-1.) * P.zt);   // advance.f90:601
+  if (zt < K(0.)) zt = m_min(h - eps2, K(-1.) * zt);   // advance.f90:601
 
   if (end_of_interval) {   // advance.f90:603-608
-    A.usig = K(0.5) * (B.LC.hi.usig + B.LC.lo.usig);
-    A.vsig = K(0.5) * (B.LC.hi.vsig + B.LC.lo.vsig);
-    A.wsig = K(0.5) * (B.LC.hi.wsig + B.LC.lo.wsig);
+    level_pair_sigma(V, B.C, W, w3, indz, usig, vsig, wsig);
     return PBL_DONE;
   }
   return PBL_CONTINUE;
@@ -1244,52 +1294,54 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, int itime,
 
 // the single step above the PBL, advance.f90:629-708 (label 700)
 template <typename R>
-FPX_DEV void above_step(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A) {
+FPX_DEV void above_step(const View<R> &V, const R *hgt, const Rng<R> &G, const TimeW<R> &W, int itime, double xt, double yt,
+                        R &zt, R &wp, int &ldt, AdvCtx<R> &A, R &usig, R &vsig, R &wsig) {
   const R eps2 = K(1.e-9);
   const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
+  const R tropop = V.tropo[(long long)((int)lround(yt)) * V.nx + (int)lround(xt)];   // advance.f90:253
   Cell<R> C;
-  cell_setup(V, C, A.ix, A.jy, A.ixp, A.jyp, (R)P.xt, (R)P.yt, itime);
-  interp_wind<R, true>(V, hgt, C, w3, P.zt, A.u, A.v, A.w, A.usig, A.vsig, A.wsig);
-  P.ldt = abs(V.lsynctime - A.itimec + itime);
-  A.ldt_last = P.ldt;
-  const R dt = (R)P.ldt;
+  cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, (R)xt, (R)yt);
+  interp_wind<R, true>(V, hgt, C, W, w3, zt, A.u, A.v, A.w, usig, vsig, wsig);
+  ldt = abs(V.lsynctime - A.itimec + itime);
+  const R dt = (R)ldt;
   int nrand = A.nrand;
   R ux, vy;
-  if (P.zt < A.tropop) {
+  if (zt < tropop) {
     R uxscale = m_sqrt(K(2.) * V.d_trop / dt);
     if (nrand + 1 > V.maxrand) nrand = 1;
     ux = G.at(nrand) * uxscale;
     vy = G.at(nrand + 1) * uxscale;
     nrand = nrand + 2;
-    P.wp = K(0.);
-  } else if (P.zt < A.tropop + K(1000.)) {
-    R weight = (P.zt - A.tropop) / K(1000.);
+    wp = K(0.);
+  } else if (zt < tropop + K(1000.)) {
+    R weight = (zt - tropop) / K(1000.);
     R uxscale = m_sqrt(K(2.) * V.d_trop / dt * (K(1.) - weight));
     if (nrand + 2 > V.maxrand) nrand = 1;
     ux = G.at(nrand) * uxscale;
     vy = G.at(nrand + 1) * uxscale;
     R wpscale = m_sqrt(K(2.) * V.d_strat / dt * weight);
-    P.wp = G.at(nrand + 2) * wpscale + V.d_strat / K(1000.);
+    wp = G.at(nrand + 2) * wpscale + V.d_strat / K(1000.);
     nrand = nrand + 3;
   } else {
     if (nrand > V.maxrand) nrand = 1;
     ux = K(0.);
     vy = K(0.);
     R wpscale = m_sqrt(K(2.) * V.d_strat / dt);
-    P.wp = G.at(nrand) * wpscale;
+    wp = G.at(nrand) * wpscale;
     nrand = nrand + 1;
   }
   A.nrand = nrand;
-  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:686-699
+  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt);   // advance.f90:686-699
   A.dxsave = A.dxsave + (A.u + ux) * dt;
   A.dysave = A.dysave + (A.v + vy) * dt;
-  P.zt = P.zt + (A.w + P.wp) * dt * (R)V.ldirect;
-  if (P.zt < K(0.)) P.zt = m_min(A.h - eps2, K(-1.) * P.zt);
+  zt = zt + (A.w + wp) * dt * (R)V.ldirect;
+  if (zt < K(0.)) zt = m_min(A.h - eps2, K(-1.) * zt);
 }
 
 // label 99 to the end: advance.f90:728-985.  Returns nstop (0 or 3).
 template <typename R>
-FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A) {
+FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A,
+                       R usig, R vsig, R wsig) {
   const R eps = eps_domain<R>();
   const R eps2 = K(1.e-9);
   int nrand = A.nrand;
@@ -1298,9 +1350,9 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const Rng<R> &G, int itim
     R r = m_exp(K(-2.) * (R)abs(V.lsynctime) / (R)V.lwindinterv);
     R rs = m_sqrt(K(1.) - r * r);
     if (nrand + 2 > V.maxrand) nrand = 1;
-    P.usigold = r * P.usigold + rs * G.at(nrand) * A.usig * V.turbmesoscale;
-    P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * A.vsig * V.turbmesoscale;
-    P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * A.wsig * V.turbmesoscale;
+    P.usigold = r * P.usigold + rs * G.at(nrand) * usig * V.turbmesoscale;
+    P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * vsig * V.turbmesoscale;
+    P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * wsig * V.turbmesoscale;
     A.dxsave = A.dxsave + P.usigold * (R)V.lsynctime;
     A.dysave = A.dysave + P.vsigold * (R)V.lsynctime;
     P.zt = P.zt + P.wsigold * (R)V.lsynctime;
@@ -1329,8 +1381,8 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const Rng<R> &G, int itim
   {
     R d0, d1, d2;
     Cell<R> C;
-    cell_setup(V, C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt, itime + P.ldt * V.ldirect);
-    interp_wind<R, false>(V, hgt, C, w3, P.zt, u, v, w, d0, d1, d2);
+    cell_setup(C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt);
+    interp_wind<R, false>(V, hgt, C, time_weights(V, itime + P.ldt * V.ldirect), w3, P.zt, u, v, w, d0, d1, d2);
   }
   if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:893-906
   u = (u - A.u) / K(2.);

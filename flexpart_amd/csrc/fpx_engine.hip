@@ -4,6 +4,10 @@
 // met fields stay resident in HBM between calls; a step is a single launch of
 // k_advance (one thread per particle slot) on the handle's stream.
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -108,6 +112,51 @@ __global__ void k_iota_pid(unsigned int *__restrict__ pid, long long first, long
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   pid[first + i] = (unsigned int)(first + i);
+}
+
+// ---------------------------------------------------------------------------
+// locality sort: key = (jy, ix, level), the order in which the packed fields lie in
+// HBM; dead particles sort to the end.  Keeps waves homogeneous (same cell => same
+// mixing height, stability regime and similar sub-step counts) and turns the field
+// gathers of a wave into a few shared cache lines.
+// ---------------------------------------------------------------------------
+template <typename R>
+__global__ void k_sort_keys(View<R> V, Parts<R> P, long long n, unsigned int *__restrict__ keys, unsigned int *__restrict__ vals,
+                            unsigned int dead_key) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned int key = dead_key;
+  if (P.itra1[i] != kDead) {
+    double xt = P.xt[i], yt = P.yt[i];
+    if (xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) {
+      int ix = min((int)xt, V.nx - 1), jy = min((int)yt, V.ny - 1);
+      int lev = find_level(hgt, V.nz, P.zt[i]);   // 1 .. nz-1
+      key = ((unsigned int)jy * V.nx + ix) * (unsigned int)V.nz + (unsigned int)lev;
+    }
+  }
+  keys[i] = key;
+  vals[i] = (unsigned int)i;
+}
+
+// out[i] = in[perm[i]] for every particle array at once
+template <typename R>
+__global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict__ perm, long long n, int nspec,
+                          unsigned int *__restrict__ slot_of_pid) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int j = perm[i];
+  B.xt[i] = A.xt[j]; B.yt[i] = A.yt[j]; B.zt[i] = A.zt[j];
+  B.up[i] = A.up[j]; B.vp[i] = A.vp[j]; B.wp[i] = A.wp[j];
+  B.us[i] = A.us[j]; B.vs[i] = A.vs[j]; B.ws[i] = A.ws[j];
+  B.idt[i] = A.idt[j]; B.itra1[i] = A.itra1[j]; B.itramem[i] = A.itramem[j];
+  B.npoint[i] = A.npoint[j]; B.nclass[i] = A.nclass[j]; B.cbt[i] = A.cbt[j];
+  const unsigned int pid = A.pid[j];
+  B.pid[i] = pid;
+  slot_of_pid[pid] = (unsigned int)i;
+  for (int ks = 0; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
 }
 
 // ---------------------------------------------------------------------------
@@ -235,13 +284,13 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, Parts<R> &P, lo
 
 template <typename R, bool DRYDEP>
 __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S, long long numpart, int itime,
-                                                 unsigned int step, Stats *st, unsigned int *__restrict__ pbl_list,
-                                                 unsigned int *__restrict__ pbl_count) {
+                                                 unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag) {
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= numpart) return;
+  pbl_flag[s] = 0;
   if (P.itra1[s] != itime) return;                       // timemanager.f90:537
   atomicAdd(&st->n_due, 1ull);   // one add per wave after the compiler's aggregation
 
@@ -286,18 +335,19 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S
   }
 
   AdvCtx<R> A;
-  const bool in_pbl = adv_begin(V, ps, itime, advance_start_index(V, S, G, pid), A);
+  const bool in_pbl = adv_begin(V, ps.xt, ps.yt, ps.zt, itime, advance_start_index(V, S, G, pid), A);
   if (in_pbl) {
     if (is_new) {   // k_pbl re-reads the state from HBM
       P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
       P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
       P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt;
     }
-    pbl_list[atomicAdd(pbl_count, 1u)] = (unsigned int)s;
+    pbl_flag[s] = 1;   // compacted in slot order afterwards: the work list stays sorted by cell
     return;
   }
-  above_step(V, hgt, G, itime, ps, A);
-  const int nstop = adv_finish(V, hgt, G, itime, ps, A);
+  R usig, vsig, wsig;
+  above_step(V, hgt, G, time_weights(V, itime), itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
+  const int nstop = adv_finish(V, hgt, G, itime, ps, A, usig, vsig, wsig);
   R prob[kMaxSpec];
 #pragma unroll
   for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
@@ -314,50 +364,82 @@ __global__ void __launch_bounds__(kBlock) k_pbl(View<R> V, Parts<R> P, SeqRng S,
   __syncthreads();
   const unsigned int nlist = *pbl_count;
   const int lane = threadIdx.x & 63;
+  const TimeW<R> W = time_weights(V, itime);   // wave-uniform
 
-  bool have = false, exhausted = false;
-  long long s = 0;
-  int itramem = 0;
-  PState<R> ps;
+  // The list is in slot order, i.e. sorted by grid cell after a locality sort.  A wave takes
+  // CHUNKS of consecutive entries (one atomic per chunk) and refills its lanes from its own
+  // chunk, so the particles a wave works on at any moment come from neighbouring cells
+  // (same mixing height, same stability regime, shared cache lines).
+  const unsigned int nwaves = gridDim.x * (blockDim.x >> 6);
+  unsigned int chunk = nlist / (nwaves * 8u);
+  chunk = min(max(chunk, 64u), 4096u) & ~63u;
+  unsigned int cur = 0, end = 0;     // wave-uniform: the unread part of the wave's chunk
+  bool out_of_chunks = false;        // wave-uniform
+
+  bool have = false;
+  unsigned int s = 0, pid = 0;
+  // the part of the particle the Langevin loop touches; everything else is read at the end
+  double xt = 0, yt = 0;
+  R zt = 0, up = 0, vp = 0, wp = 0;
+  int ldt = 0;
+  short icbt = 1;
   AdvCtx<R> A;
   PblCtx<R> B;
-  Rng<R> G;
   R prob[kMaxSpec];
 
   for (;;) {
-    if (!have && !exhausted) {
-      // wave-aggregated fetch of the next work items
-      const unsigned long long need = __ballot(1);
-      const unsigned int rank = __popcll(need & ((1ull << lane) - 1ull));
-      unsigned int base = 0;
-      if (rank == 0) base = atomicAdd(cursor, (unsigned int)__popcll(need));
-      base = __builtin_amdgcn_readfirstlane(base);
-      const unsigned int my = base + rank;
-      if (my < nlist) {
-        s = pbl_list[my];
-        ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
-        ps.up = P.up[s]; ps.vp = P.vp[s]; ps.wp = P.wp[s];
-        ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
-        ps.ldt = P.idt[s]; ps.icbt = P.cbt[s];
-        itramem = P.itramem[s];
-        const unsigned int pid = P.pid[s];
-        make_rng(V, pid, step, G);
-        adv_begin(V, ps, itime, advance_start_index(V, S, G, pid), A);
-        pbl_begin(V, ps, itime, A, B);
-#pragma unroll
-        for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
-        have = true;
-      } else {
-        exhausted = true;
+    const unsigned long long need = __ballot(!have);
+    if (need != 0ull && !out_of_chunks) {
+      if (cur >= end) {   // wave-uniform: take the next chunk
+        unsigned int c = 0;
+        if (lane == 0) c = atomicAdd(cursor, 1u);
+        c = __builtin_amdgcn_readfirstlane(c);
+        const unsigned long long c0 = (unsigned long long)c * chunk;
+        if (c0 >= nlist) {
+          out_of_chunks = true;
+        } else {
+          cur = (unsigned int)c0;
+          end = min(cur + chunk, nlist);
+        }
       }
+      if (!out_of_chunks && !have) {
+        const unsigned int rank = __popcll(need & ((1ull << lane) - 1ull));
+        const unsigned int my = cur + rank;
+        if (my < end) {
+          s = pbl_list[my];
+          xt = P.xt[s]; yt = P.yt[s]; zt = P.zt[s];
+          up = P.up[s]; vp = P.vp[s]; wp = P.wp[s];
+          ldt = P.idt[s]; icbt = P.cbt[s];
+          pid = P.pid[s];
+          Rng<R> G;
+          make_rng(V, pid, step, G);
+          adv_begin(V, xt, yt, zt, itime, advance_start_index(V, S, G, pid), A);
+          pbl_begin(V, xt, yt, W, A, B);
+          if (DRYDEP) {
+#pragma unroll
+            for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
+          }
+          have = true;
+        }
+      }
+      if (!out_of_chunks) cur = min(cur + (unsigned int)__popcll(need), end);
     }
-    if (!__any(have)) break;   // every lane of the wave is out of work: the grid drains
+    if (!__any(have)) {
+      if (out_of_chunks) break;   // no lane has work and the list is used up: the grid drains
+      continue;                   // chunk ran dry mid-refill: take the next one
+    }
     if (have) {
-      const int rc = pbl_pass(V, hgt, G, itime, ps, A, B, prob, st);
+      Rng<R> G;
+      make_rng(V, pid, step, G);
+      R usig = (R)0, vsig = (R)0, wsig = (R)0;
+      const int rc = pbl_pass<R, DRYDEP>(V, hgt, G, W, itime, xt, yt, zt, up, vp, wp, ldt, icbt, A, B, usig, vsig, wsig, prob, st);
       if (rc != PBL_CONTINUE) {
-        if (rc == PBL_ESCAPED) above_step(V, hgt, G, itime, ps, A);
-        const int nstop = adv_finish(V, hgt, G, itime, ps, A);
-        epilogue_store<R, DRYDEP>(V, P, s, itime, itramem, nstop, ps, prob, st);
+        if (rc == PBL_ESCAPED) above_step(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, A, usig, vsig, wsig);
+        PState<R> ps;
+        ps.xt = xt; ps.yt = yt; ps.zt = zt; ps.up = up; ps.vp = vp; ps.wp = wp; ps.ldt = ldt; ps.icbt = icbt;
+        ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
+        const int nstop = adv_finish(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+        epilogue_store<R, DRYDEP>(V, P, s, itime, P.itramem[s], nstop, ps, prob, st);
         have = false;
       }
     }
@@ -401,8 +483,17 @@ struct Engine : EngineBase {
   void *staging = nullptr;
   size_t staging_bytes = 0;
   unsigned int *slot_of_pid = nullptr;   // only after a locality sort
+  unsigned int *d_slot_of_pid = nullptr;
+  Parts<R> P2;                           // second particle buffer set (sort ping-pong), allocated lazily
+  bool have_p2 = false;
+  unsigned int *d_keys = nullptr, *d_keys2 = nullptr, *d_vals = nullptr, *d_vals2 = nullptr;
+  void *d_sort_tmp = nullptr;
+  size_t sort_tmp_bytes = 0;
   Stats *d_stats = nullptr;
-  unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[0] = list length, ctr[1] = fetch cursor
+  unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[0] = list length, ctr[1] = chunk cursor
+  unsigned char *d_pbl_flag = nullptr;
+  void *d_sel_tmp = nullptr;
+  size_t sel_tmp_bytes = 0;
   int pbl_grid = 0;
   // TABLE_SEQ state
   HostRng<float> rng4;
@@ -512,6 +603,7 @@ struct Engine : EngineBase {
     if ((rc = dalloc(&P.pid, cap))) return rc;
     if ((rc = dalloc(&d_pbl_list, cap))) return rc;
     if ((rc = dalloc(&d_pbl_ctr, 2))) return rc;
+    if ((rc = dalloc(&d_pbl_flag, cap))) return rc;
     // every slot starts dead (FLEXPART.f90:315-317) with identity numbering
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, (long long)cap, nullptr);
@@ -526,6 +618,8 @@ struct Engine : EngineBase {
     for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     for (void *q : owned) (void)hipFree(q);
     if (staging) (void)hipFree(staging);
+    if (d_sort_tmp) (void)hipFree(d_sort_tmp);
+    if (d_sel_tmp) (void)hipFree(d_sel_tmp);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -852,15 +946,28 @@ struct Engine : EngineBase {
       else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl<R, false>, kBlock, 0));
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
     }
+    {
+      size_t need = 0;
+      HIPCHK(rocprim::select(nullptr, need, rocprim::counting_iterator<unsigned int>(0u), d_pbl_flag, d_pbl_list, d_pbl_ctr,
+                             (size_t)numpart, stream));
+      if (need > sel_tmp_bytes) {
+        if (d_sel_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_sel_tmp)); d_sel_tmp = nullptr; }
+        HIPCHK(hipMalloc(&d_sel_tmp, need));
+        sel_tmp_bytes = need;
+      }
+    }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
     HIPCHK(hipEventRecord(ev.first, stream));
-    if (cfg.drydep) {
-      k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-      k_pbl<R, true><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
-    } else {
-      k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-      k_pbl<R, false><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    if (cfg.drydep) k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_flag);
+    else k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_flag);
+    {
+      // ordered compaction of the flagged slots -> work list (length in d_pbl_ctr[0])
+      size_t need = sel_tmp_bytes;
+      HIPCHK(rocprim::select(d_sel_tmp, need, rocprim::counting_iterator<unsigned int>(0u), d_pbl_flag, d_pbl_list, d_pbl_ctr,
+                             (size_t)numpart, stream));
     }
+    if (cfg.drydep) k_pbl<R, true><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    else k_pbl<R, false><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
     HIPCHK(hipEventRecord(ev.second, stream));
     HIPCHK(hipGetLastError());
     step_counter++;
@@ -916,7 +1023,69 @@ struct Engine : EngineBase {
     return 0;
   }
 
-  int sort_particles() override { return 0; }   // locality sort: see fpx_sort (next milestone)
+  int alloc_parts(Parts<R> &Q) {
+    const size_t cap = (size_t)P.cap;
+    int rc;
+    memset(&Q, 0, sizeof(Q));
+    Q.cap = P.cap;
+    if ((rc = dalloc(&Q.xt, cap))) return rc;
+    if ((rc = dalloc(&Q.yt, cap))) return rc;
+    R **rs[] = {&Q.zt, &Q.up, &Q.vp, &Q.wp, &Q.us, &Q.vs, &Q.ws};
+    for (auto q : rs) if ((rc = dalloc(q, cap))) return rc;
+    int **is[] = {&Q.idt, &Q.itra1, &Q.itramem, &Q.npoint, &Q.nclass};
+    for (auto q : is) if ((rc = dalloc(q, cap))) return rc;
+    if ((rc = dalloc(&Q.cbt, cap))) return rc;
+    if ((rc = dalloc(&Q.xmass1, cap * cfg.nspec))) return rc;
+    if ((rc = dalloc(&Q.pid, cap))) return rc;
+    return 0;
+  }
+
+  int sort_particles() override {
+    if (!height_set) return fail(FPX_ERR_STATE, "sort_particles: set_height first");
+    const long long n = numpart;
+    if (n < 2) return 0;
+    int rc;
+    if (!have_p2) {
+      if ((rc = alloc_parts(P2))) return rc;
+      const size_t cap = (size_t)P.cap;
+      if ((rc = dalloc(&d_keys, cap))) return rc;
+      if ((rc = dalloc(&d_keys2, cap))) return rc;
+      if ((rc = dalloc(&d_vals, cap))) return rc;
+      if ((rc = dalloc(&d_vals2, cap))) return rc;
+      if ((rc = dalloc(&d_slot_of_pid, cap))) return rc;
+      have_p2 = true;
+    }
+    const unsigned long long nkeys = (unsigned long long)cfg.nx * cfg.ny * cfg.nz + 1ull;
+    if (nkeys > 0xFFFFFFFFull) return fail(FPX_ERR_UNSUPPORTED, "sort_particles: grid too large for 32-bit keys");
+    unsigned int bits = 1;
+    while ((1ull << bits) < nkeys + 1ull) bits++;
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    k_sort_keys<R><<<nb, kBlock, 0, stream>>>(V, P, n, d_keys, d_vals, (unsigned int)(nkeys - 1ull));
+    HIPCHK(hipGetLastError());
+    size_t need = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, need, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0u, bits, stream));
+    if (need > sort_tmp_bytes) {
+      if (d_sort_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_sort_tmp)); d_sort_tmp = nullptr; }
+      HIPCHK(hipMalloc(&d_sort_tmp, need));
+      sort_tmp_bytes = need;
+    }
+    HIPCHK(rocprim::radix_sort_pairs(d_sort_tmp, need, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0u, bits, stream));
+    k_permute<R><<<nb, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, d_slot_of_pid);
+    HIPCHK(hipGetLastError());
+    // slots >= n keep their (dead) contents in both sets; swap roles
+    std::swap(P, P2);
+    if (n < P.cap) {
+      // the untouched tail of the new front set must also be dead and identity-numbered
+      const long long rest = P.cap - n;
+      const int nbr = (int)((rest + kBlock - 1) / kBlock);
+      k_fill<int><<<nbr, kBlock, 0, stream>>>(P.itra1, kDead, n, rest, nullptr);
+      k_iota_pid<<<nbr, kBlock, 0, stream>>>(P.pid, n, rest);
+      k_iota_pid<<<nbr, kBlock, 0, stream>>>(d_slot_of_pid, n, rest);
+      HIPCHK(hipGetLastError());
+    }
+    slot_of_pid = d_slot_of_pid;
+    return 0;
+  }
 
   void *stream_ptr() override { return (void *)stream; }
 };
