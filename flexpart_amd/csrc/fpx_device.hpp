@@ -1107,11 +1107,12 @@ FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W
 }
 
 // One pass of the loop advance.f90:282-609.  prob: dry-deposition probabilities (DRYDEP only).
-// usig/vsig/wsig are written when the pass ends the interval (return PBL_DONE).
+// indz_last receives the level pair of this pass: when the pass ends the interval (PBL_DONE)
+// the caller evaluates usig/vsig/wsig for it (advance.f90:604-606, level_pair_sigma).
 template <typename R, bool DRYDEP>
 FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const TimeW<R> &W, int itime, double xt, double yt,
                      R &zt, R &up, R &vp, R &wp, int &ldt, short &icbt, AdvCtx<R> &A, PblCtx<R> &B,
-                     R &usig, R &vsig, R &wsig, R *prob, Stats *st) {
+                     int &indz_last, R *prob, Stats *st) {
   const R eps = eps_domain<R>();
   const R eps2 = K(1.e-9);
   const R href = K(15.);            // par_mod.f90:76
@@ -1134,6 +1135,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
 
   const int indz = find_level(hgt, V.nz, zt);
   const int indzp = indz + 1;
+  indz_last = indz;
   cache_fetch(V, B.C, W, w3, B.LC, indz);
 
   // advance.f90:342-350
@@ -1264,9 +1266,8 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
   if (zt > h) {   // advance.f90:549-552
     if (end_of_interval) {
       // -> 99.  The reference reaches label 99 here with usig/vsig/wsig still holding
-      // whatever the previous particle left in interpol_mod; use this particle's own
-      // profile values, as the regular exit :603-606 does.
-      level_pair_sigma(V, B.C, W, w3, indz, usig, vsig, wsig);
+      // whatever the previous particle left in interpol_mod; the caller uses this particle's
+      // own profile values, as the regular exit :603-606 does.
       return PBL_DONE;
     }
     return PBL_ESCAPED;   // -> 700
@@ -1285,10 +1286,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
 
   if (zt < K(0.)) zt = m_min(h - eps2, K(-1.) * zt);   // advance.f90:601
 
-  if (end_of_interval) {   // advance.f90:603-608
-    level_pair_sigma(V, B.C, W, w3, indz, usig, vsig, wsig);
-    return PBL_DONE;
-  }
+  if (end_of_interval) return PBL_DONE;   // advance.f90:603-608 (sigmas: see level_pair_sigma)
   return PBL_CONTINUE;
 }
 

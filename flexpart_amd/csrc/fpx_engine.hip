@@ -282,8 +282,20 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, Parts<R> &P, lo
   P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt; P.itra1[s] = itra1;
 }
 
+// per-slot hand-over records between the three PBL kernels (SoA in HBM)
+template <typename R>
+struct PblRec {
+  // k_prep -> k_pbl_loop
+  R *ust, *wst, *ol, *trans;
+  int *nrand0;
+  // k_pbl_loop -> k_pbl_finish
+  R *dxsave, *dysave, *dawsave, *dcwsave, *u, *v, *w;
+  R *prob;                 // [nspec][cap], DRYDEP only
+  int *nrand, *itimec, *status;   // status = rc | indz << 2
+};
+
 template <typename R, bool DRYDEP>
-__global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag) {
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
@@ -335,18 +347,25 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S
   }
 
   AdvCtx<R> A;
+  const TimeW<R> W = time_weights(V, itime);
   const bool in_pbl = adv_begin(V, ps.xt, ps.yt, ps.zt, itime, advance_start_index(V, S, G, pid), A);
   if (in_pbl) {
-    if (is_new) {   // k_pbl re-reads the state from HBM
+    if (is_new) {   // the PBL kernels re-read the state from HBM
       P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
       P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
       P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt;
     }
+    // first-pass set-up of interpol_all (ust, wst, ol: interpol_all.f90:80-107) done here, where
+    // the lanes are convergent; the Langevin kernel then starts from five numbers per particle
+    PblCtx<R> B;
+    pbl_begin(V, ps.xt, ps.yt, W, A, B);
+    Q.ust[s] = B.ust; Q.wst[s] = B.wst; Q.ol[s] = B.ol; Q.trans[s] = B.transition;
+    Q.nrand0[s] = A.nrand;
     pbl_flag[s] = 1;   // compacted in slot order afterwards: the work list stays sorted by cell
     return;
   }
   R usig, vsig, wsig;
-  above_step(V, hgt, G, time_weights(V, itime), itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
+  above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
   const int nstop = adv_finish(V, hgt, G, itime, ps, A, usig, vsig, wsig);
   R prob[kMaxSpec];
 #pragma unroll
@@ -354,11 +373,14 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S
   epilogue_store<R, DRYDEP>(V, P, s, itime, itramem, nstop, ps, prob, st);
 }
 
+// The Langevin kernel: persistent waves, lane refill (see the header comment above).
+// Only the pass loop lives here; set-up and completion run in k_prep / k_pbl_finish
+// where all lanes are active.
 template <typename R, bool DRYDEP>
-__global__ void __launch_bounds__(kBlock) k_pbl(View<R> V, Parts<R> P, SeqRng S, int itime, unsigned int step, Stats *st,
-                                                const unsigned int *__restrict__ pbl_list,
-                                                const unsigned int *__restrict__ pbl_count,
-                                                unsigned int *__restrict__ cursor) {
+__global__ void __launch_bounds__(kBlock) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+                                                     const unsigned int *__restrict__ pbl_list,
+                                                     const unsigned int *__restrict__ pbl_count,
+                                                     unsigned int *__restrict__ cursor) {
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
@@ -378,7 +400,6 @@ __global__ void __launch_bounds__(kBlock) k_pbl(View<R> V, Parts<R> P, SeqRng S,
 
   bool have = false;
   unsigned int s = 0, pid = 0;
-  // the part of the particle the Langevin loop touches; everything else is read at the end
   double xt = 0, yt = 0;
   R zt = 0, up = 0, vp = 0, wp = 0;
   int ldt = 0;
@@ -411,10 +432,10 @@ __global__ void __launch_bounds__(kBlock) k_pbl(View<R> V, Parts<R> P, SeqRng S,
           up = P.up[s]; vp = P.vp[s]; wp = P.wp[s];
           ldt = P.idt[s]; icbt = P.cbt[s];
           pid = P.pid[s];
-          Rng<R> G;
-          make_rng(V, pid, step, G);
-          adv_begin(V, xt, yt, zt, itime, advance_start_index(V, S, G, pid), A);
-          pbl_begin(V, xt, yt, W, A, B);
+          adv_begin(V, xt, yt, zt, itime, Q.nrand0[s], A);
+          cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, (R)xt, (R)yt);   // interpol_all.f90:57-64
+          B.ust = Q.ust[s]; B.wst = Q.wst[s]; B.ol = Q.ol[s]; B.transition = Q.trans[s];
+          B.LC.ilo = -1;
           if (DRYDEP) {
 #pragma unroll
             for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
@@ -431,18 +452,69 @@ __global__ void __launch_bounds__(kBlock) k_pbl(View<R> V, Parts<R> P, SeqRng S,
     if (have) {
       Rng<R> G;
       make_rng(V, pid, step, G);
-      R usig = (R)0, vsig = (R)0, wsig = (R)0;
-      const int rc = pbl_pass<R, DRYDEP>(V, hgt, G, W, itime, xt, yt, zt, up, vp, wp, ldt, icbt, A, B, usig, vsig, wsig, prob, st);
+      int indz = 1;
+      const int rc = pbl_pass<R, DRYDEP>(V, hgt, G, W, itime, xt, yt, zt, up, vp, wp, ldt, icbt, A, B, indz, prob, st);
       if (rc != PBL_CONTINUE) {
-        if (rc == PBL_ESCAPED) above_step(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, A, usig, vsig, wsig);
-        PState<R> ps;
-        ps.xt = xt; ps.yt = yt; ps.zt = zt; ps.up = up; ps.vp = vp; ps.wp = wp; ps.ldt = ldt; ps.icbt = icbt;
-        ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
-        const int nstop = adv_finish(V, hgt, G, itime, ps, A, usig, vsig, wsig);
-        epilogue_store<R, DRYDEP>(V, P, s, itime, P.itramem[s], nstop, ps, prob, st);
+        P.zt[s] = zt; P.up[s] = up; P.vp[s] = vp; P.wp[s] = wp; P.idt[s] = ldt; P.cbt[s] = icbt;
+        Q.dxsave[s] = A.dxsave; Q.dysave[s] = A.dysave; Q.dawsave[s] = A.dawsave; Q.dcwsave[s] = A.dcwsave;
+        Q.u[s] = A.u; Q.v[s] = A.v; Q.w[s] = A.w;
+        Q.nrand[s] = A.nrand; Q.itimec[s] = A.itimec; Q.status[s] = rc | (indz << 2);
+        if (DRYDEP) {
+#pragma unroll
+          for (int ks = 0; ks < kMaxSpec; ks++)
+            if (ks < V.nspec) Q.prob[(size_t)ks * P.cap + s] = prob[ks];
+        }
         have = false;
       }
     }
+  }
+}
+
+// completion of the PBL particles: label 700 if the particle left the PBL, sigmas for the
+// mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
+template <typename R, bool DRYDEP>
+__global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+                                                       const unsigned int *__restrict__ pbl_list,
+                                                       const unsigned int *__restrict__ pbl_count) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  const unsigned int nlist = *pbl_count;
+  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < nlist; i += gridDim.x * blockDim.x) {
+    const unsigned int s = pbl_list[i];
+    PState<R> ps;
+    ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
+    ps.up = P.up[s]; ps.vp = P.vp[s]; ps.wp = P.wp[s];
+    ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
+    ps.ldt = P.idt[s]; ps.icbt = P.cbt[s];
+    Rng<R> G;
+    make_rng(V, P.pid[s], step, G);
+    const TimeW<R> W = time_weights(V, itime);
+    AdvCtx<R> A;
+    {
+      // same cell as at entry: the horizontal position does not change inside the loop
+      AdvCtx<R> A0;
+      adv_begin(V, ps.xt, ps.yt, ps.zt, itime, 0, A0);
+      A = A0;
+    }
+    A.dxsave = Q.dxsave[s]; A.dysave = Q.dysave[s]; A.dawsave = Q.dawsave[s]; A.dcwsave = Q.dcwsave[s];
+    A.u = Q.u[s]; A.v = Q.v[s]; A.w = Q.w[s];
+    A.nrand = Q.nrand[s]; A.itimec = Q.itimec[s];
+    const int status = Q.status[s];
+    const int rc = status & 3, indz = status >> 2;
+    R usig = (R)0, vsig = (R)0, wsig = (R)0;
+    if (rc == PBL_ESCAPED) {
+      above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
+    } else {
+      Cell<R> C;
+      cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, (R)ps.xt, (R)ps.yt);
+      level_pair_sigma(V, C, W, A.ngrid < 0 ? V.w3pol : V.w3, indz, usig, vsig, wsig);   // advance.f90:604-606
+    }
+    const int nstop = adv_finish(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+    R prob[kMaxSpec];
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (DRYDEP && ks < V.nspec) ? Q.prob[(size_t)ks * P.cap + s] : (R)0;
+    epilogue_store<R, DRYDEP>(V, P, s, itime, P.itramem[s], nstop, ps, prob, st);
   }
 }
 
@@ -492,6 +564,7 @@ struct Engine : EngineBase {
   Stats *d_stats = nullptr;
   unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[0] = list length, ctr[1] = chunk cursor
   unsigned char *d_pbl_flag = nullptr;
+  PblRec<R> Q;
   void *d_sel_tmp = nullptr;
   size_t sel_tmp_bytes = 0;
   int pbl_grid = 0;
@@ -604,6 +677,14 @@ struct Engine : EngineBase {
     if ((rc = dalloc(&d_pbl_list, cap))) return rc;
     if ((rc = dalloc(&d_pbl_ctr, 2))) return rc;
     if ((rc = dalloc(&d_pbl_flag, cap))) return rc;
+    memset(&Q, 0, sizeof(Q));
+    {
+      R **qs[] = {&Q.ust, &Q.wst, &Q.ol, &Q.trans, &Q.dxsave, &Q.dysave, &Q.dawsave, &Q.dcwsave, &Q.u, &Q.v, &Q.w};
+      for (auto q : qs) if ((rc = dalloc(q, cap))) return rc;
+      int **qi[] = {&Q.nrand0, &Q.nrand, &Q.itimec, &Q.status};
+      for (auto q : qi) if ((rc = dalloc(q, cap))) return rc;
+      if (cfg.drydep && (rc = dalloc(&Q.prob, cap * cfg.nspec))) return rc;
+    }
     // every slot starts dead (FLEXPART.f90:315-317) with identity numbering
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, (long long)cap, nullptr);
@@ -942,8 +1023,8 @@ struct Engine : EngineBase {
       hipDeviceProp_t prop;
       HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
       int per_cu = 0;
-      if (cfg.drydep) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl<R, true>, kBlock, 0));
-      else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl<R, false>, kBlock, 0));
+      if (cfg.drydep) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl_loop<R, true>, kBlock, 0));
+      else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl_loop<R, false>, kBlock, 0));
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
     }
     {
@@ -958,16 +1039,22 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
     HIPCHK(hipEventRecord(ev.first, stream));
-    if (cfg.drydep) k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_flag);
-    else k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, P, S, numpart, itime, step_counter, d_stats, d_pbl_flag);
+    if (cfg.drydep) k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
+    else k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
     {
       // ordered compaction of the flagged slots -> work list (length in d_pbl_ctr[0])
       size_t need = sel_tmp_bytes;
       HIPCHK(rocprim::select(d_sel_tmp, need, rocprim::counting_iterator<unsigned int>(0u), d_pbl_flag, d_pbl_list, d_pbl_ctr,
                              (size_t)numpart, stream));
     }
-    if (cfg.drydep) k_pbl<R, true><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
-    else k_pbl<R, false><<<pbl_grid, kBlock, 0, stream>>>(V, P, S, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    const int fin_grid = std::min(nb, 8 * 256 * 4);
+    if (cfg.drydep) {
+      k_pbl_loop<R, true><<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+      k_pbl_finish<R, true><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+    } else {
+      k_pbl_loop<R, false><<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+      k_pbl_finish<R, false><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+    }
     HIPCHK(hipEventRecord(ev.second, stream));
     HIPCHK(hipGetLastError());
     step_counter++;
