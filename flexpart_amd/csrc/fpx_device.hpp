@@ -42,6 +42,19 @@ FPX_DEV double m_pow(double x, double y) { return pow(x, y); }
 // correctly-rounded pow; fp32 keeps powf.  x == 0 and x < 0 behave like pow (0/inf, NaN).
 FPX_DEV float m_powr(float x, float y) { return powf(x, y); }
 FPX_DEV double m_powr(double x, double y) { return exp(y * log(x)); }
+// Division for the inner Langevin arithmetic.  fp64: hardware reciprocal seed + two Newton
+// steps + one residual correction (error <= 1 ulp, 8 instructions instead of the 14 of the
+// IEEE sequence).  Only used where the divisor is finite and non-zero by construction.
+FPX_DEV float m_divf(float a, float b) { return a / b; }
+FPX_DEV double m_divf(double a, double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = fma(-b, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-b, r, 1.0);
+  r = fma(r, e, r);
+  double q = a * r;
+  return fma(fma(-b, q, a), r, q);
+}
 FPX_DEV float m_fmod(float x, float y) { return fmodf(x, y); }
 FPX_DEV double m_fmod(double x, double y) { return fmod(x, y); }
 template <typename R> FPX_DEV R m_abs(R x) { return x < 0 ? -x : x; }
@@ -128,15 +141,16 @@ FPX_DEV void philox4x32(unsigned int c0, unsigned int c1, unsigned int c2, unsig
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Gaussian table value source: either the reference's table or its counter twin
-template <typename R>
+// Gaussian table value source: either the reference's table or its counter twin.
+// MODE >= 0 fixes the rng mode at compile time (hot kernels), -1 reads it at run time.
+template <typename R, int MODE = -1>
 struct Rng {
   const R *tab;
   int maxrand, mode;
   unsigned int pid, step, k0, k1;
   // rannumb(idx), 1-based like the reference
   FPX_DEV R at(int idx) const {
-    if (mode != 2) return tab[min(idx, maxrand) - 1];   // the reference reads past the table on rare CBL re-draws; clamp instead
+    if ((MODE < 0 ? mode : MODE) != 2) return tab[min(idx, maxrand) - 1];   // the reference reads past the table on rare CBL re-draws; clamp instead
     unsigned int o[4];
     philox4x32(pid, step, (unsigned int)idx >> 1, 0x47415553u, k0, k1, o);
     // clipped Box-Muller pair (the distribution of gasdev1, random_mod.f90:70-90)
@@ -458,22 +472,22 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigma
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
   const R third = K(0.333333333);
   R dens = rhoa, ddens = rhograd, timedir = (R)ldirect;
-  R z = zp / h;
+  R z = m_divf(zp, h);
   R w2 = sigmaw * sigmaw;
   R dw2 = K(2.) * sigmaw * dsigmawdz;
-  R alfa = K(2.) * w2 / (C0 * tlw);
+  R alfa = m_divf(K(2.) * w2, C0 * tlw);
   R wold = timedir * wp;
   R omz = K(1.) - z;
   R omz05 = m_sqrt(omz), omz15 = omz * omz05;
   R wst3 = wst * wst * wst;
   R w3 = (K(1.2) * z * omz15 + eps) * wst3 * transition;
-  R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * (K(1.) / h) * transition;
+  R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * m_divf(K(1.), h) * transition;
   R w205 = m_sqrt(w2), w215 = w2 * w205;
-  R skew = w3 / w215;
+  R skew = m_divf(w3, w215);
   R skew2 = skew * skew;
-  R dskew = (dw3 * w215 - w3 * K(1.5) * w205 * dw2) / (w2 * w2 * w2);
+  R dskew = m_divf(dw3 * w215 - w3 * K(1.5) * w205 * dw2, w2 * w2 * w2);
   R radw2 = w205;
-  R dradw2 = K(0.5) * (K(1.) / w205) * dw2;
+  R dradw2 = K(0.5) * m_divf(K(1.), w205) * dw2;
   R lsk = m_log(m_abs(skew));
   R fluarw = costluar4 * m_sign(m_exp(third * lsk), skew);            // costluar4*cuberoot(skew)
   R fluarw2 = fluarw * fluarw;
@@ -484,43 +498,44 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigma
     R a105 = m_sqrt(a1);
     R a1c = a1 * a1 * a1, a3s = a3 * a3, a115 = a1 * a105;
     R den_r = a3s * fluarw2, den_x = a3 * fluarw;
-    rluarw = a1c * skew2 / den_r;
-    xluarw = a115 * skew / den_x;
+    rluarw = m_divf(a1c * skew2, den_r);
+    xluarw = m_divf(a115 * skew, den_x);
     R ffd = K(2.) * fluarw * dfluarw;
-    drluarw = (((K(3.) * (a1 * a1) * ffd * skew2) + a1c * K(2.) * skew * dskew) * den_r -
-               a1c * skew2 * ((K(2.) * a3 * ffd * fluarw2) + a3s * ffd)) /
-              (den_r * den_r);
-    dxluarw = (((K(1.5) * a105 * ffd * skew) + a115 * dskew) * den_x -
-               a115 * skew * (K(3.) * dfluarw + K(3) * fluarw2 * dfluarw)) /
-              (den_x * den_x);
+    drluarw = m_divf(((K(3.) * (a1 * a1) * ffd * skew2) + a1c * K(2.) * skew * dskew) * den_r -
+                         a1c * skew2 * ((K(2.) * a3 * ffd * fluarw2) + a3s * ffd),
+                     den_r * den_r);
+    dxluarw = m_divf(((K(1.5) * a105 * ffd * skew) + a115 * dskew) * den_x -
+                         a115 * skew * (K(3.) * dfluarw + K(3) * fluarw2 * dfluarw),
+                     den_x * den_x);
   } else {
     dfluarw = K(0.); rluarw = K(0.); drluarw = K(0.); xluarw = K(0.); dxluarw = K(0.);
   }
   R r4 = K(4.) + rluarw;
   R r405 = m_sqrt(r4);
-  R aluarw = K(0.5) * (K(1.) - xluarw / r405);
+  R ir405 = m_divf(K(1.), r405);
+  R aluarw = K(0.5) * (K(1.) - xluarw * ir405);
   R bluarw = K(1.) - aluarw;
-  R daluarw = K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * (K(1.) / r405) * drluarw)) / r4;
+  R daluarw = m_divf(K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * ir405 * drluarw)), r4);
   R dbluarw = -daluarw;
   R f1 = K(1.) + fluarw2, ffd2 = K(2.) * fluarw * dfluarw;
   R t1 = aluarw * f1;
-  R qa = bluarw / t1;
+  R qa = m_divf(bluarw, t1);
   R qa05 = m_sqrt(qa);
   R sigmawa = radw2 * qa05;
   R dsigmawa = dradw2 * qa05 +
-               radw2 * ((K(0.5) * (K(1.) / qa05)) * ((dbluarw * t1 - bluarw * (daluarw * f1 + aluarw * ffd2)) / (t1 * t1)));
+               radw2 * ((K(0.5) * m_divf(K(1.), qa05)) * m_divf(dbluarw * t1 - bluarw * (daluarw * f1 + aluarw * ffd2), t1 * t1));
   R t2 = bluarw * f1;
-  R qb = aluarw / t2;
+  R qb = m_divf(aluarw, t2);
   R qb05 = m_sqrt(qb);
   R sigmawb = radw2 * qb05;
   R dsigmawb = dradw2 * qb05 +
-               radw2 * ((K(0.5) * (K(1.) / qb05)) * ((daluarw * t2 - aluarw * (dbluarw * f1 + bluarw * ffd2)) / (t2 * t2)));
+               radw2 * ((K(0.5) * m_divf(K(1.), qb05)) * m_divf(daluarw * t2 - aluarw * (dbluarw * f1 + bluarw * ffd2), t2 * t2));
   R wa = fluarw * sigmawa, wb = fluarw * sigmawb;
   R dwa = dfluarw * sigmawa + fluarw * dsigmawa;
   R dwb = dfluarw * sigmawb + fluarw * dsigmawb;
   R deltawa = wold - wa, deltawb = wold + wb;
   R wold2 = wold * wold;
-  R isa = K(1.) / sigmawa, isb = K(1.) / sigmawb;
+  R isa = m_divf(K(1.), sigmawa), isb = m_divf(K(1.), sigmawb);
   R isa2 = isa * isa, isb2 = isb * isb;
   if (m_abs(deltawa) > K(6.) * sigmawa && m_abs(deltawb) > K(6.) * sigmawb) flagrein = 1;
   R da = deltawa * isa, db = deltawb * isb;
@@ -536,7 +551,7 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigma
           sigmawb * (bluarw * dens * dsigmawb * (wold2 * isb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
                      bluarw * wold * dens * isb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
   R Q = timedir * ((aluarw * dens * deltawa * isa2) * pa + (bluarw * dens * deltawb * isb2) * pb);
-  ath = (K(1.) / ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
+  ath = m_divf(K(1.), ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
   bth = m_sqrt(C0 * alfa);
 }
 
@@ -564,8 +579,8 @@ FPX_DEV void cbl_pdf(R zp, R wst, R h, R sigmaw, R ol, R &aluarw, R &sigmawa, R 
 }
 
 // re_initialize_particle.f90:44-90; bounded re-draw loops (the reference's are unbounded)
-template <typename R>
-FPX_DEV void re_initialize_particle(int ldirect, const Rng<R> &G, R zp, R wst, R h, R sigmaw, R &wp, int &nrand, R ol) {
+template <typename R, typename RNG>
+FPX_DEV void re_initialize_particle(int ldirect, const RNG &G, R zp, R wst, R h, R sigmaw, R &wp, int &nrand, R ol) {
   R aluarw, sigmawa, sigmawb, wa, wb;
   nrand = nrand + 1;
   R dcas1 = G.at(nrand);
@@ -962,8 +977,8 @@ FPX_DEV void level_pair_sigma(const View<R> &V, const Cell<R> &C, const TimeW<R>
 }
 
 // initialize.f90:66-217.  Returns nothing; fills the turbulent state of a new particle.
-template <typename R>
-FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const Rng<R> &G, int nrand, int itime,
+template <typename R, typename RNG>
+FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const RNG &G, int nrand, int itime,
                                  PState<R> &P, R cbl_dcas, R cbl_dcas1) {
   P.icbt = 1;
   int ix = (int)P.xt, jy = (int)P.yt;
@@ -1109,8 +1124,14 @@ FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W
 // One pass of the loop advance.f90:282-609.  prob: dry-deposition probabilities (DRYDEP only).
 // indz_last receives the level pair of this pass: when the pass ends the interval (PBL_DONE)
 // the caller evaluates usig/vsig/wsig for it (advance.f90:604-606, level_pair_sigma).
-template <typename R, bool DRYDEP>
-FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const TimeW<R> &W, int itime, double xt, double yt,
+// TSW / CBLF: -1 = read turbswitch / cblflag at run time, 0/1 = fixed at compile time
+// (specialised hot kernels: fewer scalar registers, no dead branches).  SETTLE/DRYDEP false
+// compile the aerosol paths out.
+template <int T>
+FPX_DEV bool sw(int runtime) { return T < 0 ? runtime != 0 : T != 0; }
+
+template <typename R, bool DRYDEP, bool SETTLE, int TSW, int CBLF, typename RNG>
+FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R> &W, int itime, double xt, double yt,
                      R &zt, R &up, R &vp, R &wp, int &ldt, short &icbt, AdvCtx<R> &A, PblCtx<R> &B,
                      int &indz_last, R *prob, Stats *st) {
   const R eps = eps_domain<R>();
@@ -1119,6 +1140,8 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
   const R h = A.h;
   const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
   int nrand = A.nrand;
+  const bool turbswitch = sw<TSW>(V.turbswitch);
+  const bool cblflag = sw<CBLF>(V.cblflag == 1);
   Turb<R> T;
   T.ust = B.ust; T.wst = B.wst; T.ol = B.ol; T.h = h;
   T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);   // only read if hanna1 meets zeta >= 1 (see hanna1)
@@ -1148,7 +1171,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
   const R rhoa = dz1 * B.LC.rhohi + dz2 * B.LC.rholo;
   const R rhograd = dz1 * B.LC.rhogradhi + dz2 * B.LC.rhogradlo;
 
-  if (V.turbswitch) hanna(T, zt); else hanna1(T, zt);
+  if (turbswitch) hanna(T, zt); else hanna1(T, zt);
   B.ust = T.ust;   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
 
   // horizontal Langevin, advance.f90:371-384
@@ -1174,15 +1197,15 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
   const R rhoaux = rhograd / rhoa;
   const R dtf = dt * V.fine;
   const R dtftlw = dtf / T.tlw;
-  const bool cbl_on = V.cblflag == 1 && (-h / T.ol > K(5));
+  const bool cbl_on = cblflag && (-h / T.ol > K(5));
   const R sqrt_dtf = m_sqrt(dtf);
 
   // vertical Langevin, ifine sub-steps, advance.f90:396-498
   for (int i = 1; i <= V.ifine; i++) {
     R delz;
-    if (V.turbswitch) {
+    if (turbswitch) {
       if (dtftlw < K(.5)) {
-        if (V.cblflag == 1) {
+        if (cblflag) {
           if (cbl_on) {
             int flagrein = 0;
             nrand = nrand + 1;
@@ -1242,17 +1265,17 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
       hanna_short(T, zt);
     }
   }
-  if (V.cblflag != 1) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i", i = ifine+1 after the loop (advance.f90:499)
+  if (!cblflag) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i", i = ifine+1 after the loop (advance.f90:499)
   A.nrand = nrand;
 
   // next sub-step length, advance.f90:504-510
-  if (V.turbswitch)
+  if (turbswitch)
     ldt = (int)(m_min(m_min(T.tlw, h / m_max(K(2.) * m_abs(wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)) * V.ctl);
   else
     ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(wp), K(1.e-5))) * V.ctl);
   ldt = max(ldt, V.mintime);
 
-  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt);   // advance.f90:518-531
+  if (SETTLE && V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt);   // advance.f90:518-531
 
   // advance.f90:539-547
   A.dxsave = A.dxsave + A.u * dt;
@@ -1291,8 +1314,8 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const Rng<R> &G, const Time
 }
 
 // the single step above the PBL, advance.f90:629-708 (label 700)
-template <typename R>
-FPX_DEV void above_step(const View<R> &V, const R *hgt, const Rng<R> &G, const TimeW<R> &W, int itime, double xt, double yt,
+template <typename R, typename RNG>
+FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R> &W, int itime, double xt, double yt,
                         R &zt, R &wp, int &ldt, AdvCtx<R> &A, R &usig, R &vsig, R &wsig) {
   const R eps2 = K(1.e-9);
   const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
@@ -1337,8 +1360,8 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const Rng<R> &G, const T
 }
 
 // label 99 to the end: advance.f90:728-985.  Returns nstop (0 or 3).
-template <typename R>
-FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const Rng<R> &G, int itime, PState<R> &P, AdvCtx<R> &A,
+template <typename R, typename RNG>
+FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, PState<R> &P, AdvCtx<R> &A,
                        R usig, R vsig, R wsig) {
   const R eps = eps_domain<R>();
   const R eps2 = K(1.e-9);

@@ -32,6 +32,9 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
   } while (0)
 
 constexpr int kBlock = 256;
+#ifndef FPX_LOOP_WAVES
+#define FPX_LOOP_WAVES 2   // minimum waves per SIMD the Langevin kernel is register-budgeted for
+#endif
 constexpr int kMaxNz = 512;
 
 // ---------------------------------------------------------------------------
@@ -228,8 +231,8 @@ __global__ void __launch_bounds__(kBlock) k_classify(View<R> V, Parts<R> P, long
 //            immediately refills from the list, so lanes never idle on the data-dependent
 //            trip count (15-150 passes per particle).
 // ---------------------------------------------------------------------------
-template <typename R>
-__device__ __forceinline__ void make_rng(const View<R> &V, unsigned int pid, unsigned int step, Rng<R> &G) {
+template <typename R, typename RNG>
+__device__ __forceinline__ void make_rng(const View<R> &V, unsigned int pid, unsigned int step, RNG &G) {
   G.tab = V.rannumb; G.maxrand = V.maxrand; G.mode = V.rng_mode;
   G.pid = pid; G.step = step;
   G.k0 = (unsigned int)V.seed; G.k1 = (unsigned int)(V.seed >> 32);
@@ -376,8 +379,9 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S
 // The Langevin kernel: persistent waves, lane refill (see the header comment above).
 // Only the pass loop lives here; set-up and completion run in k_prep / k_pbl_finish
 // where all lanes are active.
-template <typename R, bool DRYDEP>
-__global__ void __launch_bounds__(kBlock) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+// LEAN: no dry deposition, no settling (gases).  TSW / CBLF / RNGM: see pbl_pass.
+template <typename R, bool LEAN, int TSW, int CBLF, int RNGM>
+__global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                      const unsigned int *__restrict__ pbl_list,
                                                      const unsigned int *__restrict__ pbl_count,
                                                      unsigned int *__restrict__ cursor) {
@@ -436,7 +440,7 @@ __global__ void __launch_bounds__(kBlock) k_pbl_loop(View<R> V, Parts<R> P, PblR
           cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, (R)xt, (R)yt);   // interpol_all.f90:57-64
           B.ust = Q.ust[s]; B.wst = Q.wst[s]; B.ol = Q.ol[s]; B.transition = Q.trans[s];
           B.LC.ilo = -1;
-          if (DRYDEP) {
+          if (!LEAN && V.drydep) {
 #pragma unroll
             for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
           }
@@ -450,16 +454,16 @@ __global__ void __launch_bounds__(kBlock) k_pbl_loop(View<R> V, Parts<R> P, PblR
       continue;                   // chunk ran dry mid-refill: take the next one
     }
     if (have) {
-      Rng<R> G;
+      Rng<R, RNGM> G;
       make_rng(V, pid, step, G);
       int indz = 1;
-      const int rc = pbl_pass<R, DRYDEP>(V, hgt, G, W, itime, xt, yt, zt, up, vp, wp, ldt, icbt, A, B, indz, prob, st);
+      const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, up, vp, wp, ldt, icbt, A, B, indz, prob, st);
       if (rc != PBL_CONTINUE) {
         P.zt[s] = zt; P.up[s] = up; P.vp[s] = vp; P.wp[s] = wp; P.idt[s] = ldt; P.cbt[s] = icbt;
         Q.dxsave[s] = A.dxsave; Q.dysave[s] = A.dysave; Q.dawsave[s] = A.dawsave; Q.dcwsave[s] = A.dcwsave;
         Q.u[s] = A.u; Q.v[s] = A.v; Q.w[s] = A.w;
         Q.nrand[s] = A.nrand; Q.itimec[s] = A.itimec; Q.status[s] = rc | (indz << 2);
-        if (DRYDEP) {
+        if (!LEAN && V.drydep) {
 #pragma unroll
           for (int ks = 0; ks < kMaxSpec; ks++)
             if (ks < V.nspec) Q.prob[(size_t)ks * P.cap + s] = prob[ks];
@@ -1023,8 +1027,7 @@ struct Engine : EngineBase {
       hipDeviceProp_t prop;
       HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
       int per_cu = 0;
-      if (cfg.drydep) HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl_loop<R, true>, kBlock, 0));
-      else HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pbl_loop<R, false>, kBlock, 0));
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, 0));
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
     }
     {
@@ -1048,13 +1051,9 @@ struct Engine : EngineBase {
                              (size_t)numpart, stream));
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
-    if (cfg.drydep) {
-      k_pbl_loop<R, true><<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
-      k_pbl_finish<R, true><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-    } else {
-      k_pbl_loop<R, false><<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
-      k_pbl_finish<R, false><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-    }
+    loop_kernel()<<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    if (cfg.drydep) k_pbl_finish<R, true><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+    else k_pbl_finish<R, false><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
     HIPCHK(hipEventRecord(ev.second, stream));
     HIPCHK(hipGetLastError());
     step_counter++;
@@ -1088,6 +1087,19 @@ struct Engine : EngineBase {
     snap = hs;
     if (reset) base = hs;
     return 0;
+  }
+
+  // the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
+  typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *, unsigned int *);
+  loop_fn loop_kernel() const {
+    const bool lean = !cfg.drydep && !cfg.lsettling;
+    const bool philox = cfg.rng_mode == FPX_RNG_PHILOX;
+    if (lean) {
+      if (cfg.turbswitch && cfg.cblflag == 1) return philox ? k_pbl_loop<R, true, 1, 1, 2> : k_pbl_loop<R, true, 1, 1, 0>;
+      if (cfg.turbswitch && cfg.cblflag != 1) return philox ? k_pbl_loop<R, true, 1, 0, 2> : k_pbl_loop<R, true, 1, 0, 0>;
+      if (!cfg.turbswitch && cfg.cblflag != 1) return philox ? k_pbl_loop<R, true, 0, 0, 2> : k_pbl_loop<R, true, 0, 0, 0>;
+    }
+    return k_pbl_loop<R, false, -1, -1, -1>;
   }
 
   int sync() override {
