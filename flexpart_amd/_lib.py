@@ -65,7 +65,7 @@ class FpxStepStats(C.Structure):
 
 # every symbol include/flexpart_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_set_height",
+    "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_polar_maps", "fpx_set_height",
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
     "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_sort_particles",
@@ -92,6 +92,7 @@ def load():
     lib.fpx_stream.argtypes = [vp]
     lib.fpx_create.argtypes = [C.POINTER(vp), C.POINTER(FpxConfig)]
     lib.fpx_destroy.argtypes = [vp]
+    lib.fpx_polar_maps.argtypes = [C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fpx_set_height.argtypes = [vp, vp, C.c_int32]
     lib.fpx_upload_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxFields)]
     lib.fpx_set_windtime.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

@@ -16,6 +16,7 @@ namespace fpx {
 
 #define K(x) ((R)(x))
 #define FPX_DEV __device__ __forceinline__
+#define FPX_HD __host__ __device__ __forceinline__
 
 constexpr int kMaxSpec = 5;
 constexpr int kDead = -999999999;
@@ -23,25 +24,25 @@ constexpr int kDead = -999999999;
 // ---------------------------------------------------------------------------
 // math in R
 // ---------------------------------------------------------------------------
-FPX_DEV float m_exp(float x) { return expf(x); }
-FPX_DEV double m_exp(double x) { return exp(x); }
-FPX_DEV float m_log(float x) { return logf(x); }
-FPX_DEV double m_log(double x) { return log(x); }
-FPX_DEV float m_sqrt(float x) { return sqrtf(x); }
-FPX_DEV double m_sqrt(double x) { return sqrt(x); }
-FPX_DEV float m_sin(float x) { return sinf(x); }
-FPX_DEV double m_sin(double x) { return sin(x); }
-FPX_DEV float m_cos(float x) { return cosf(x); }
-FPX_DEV double m_cos(double x) { return cos(x); }
-FPX_DEV float m_erf(float x) { return erff(x); }
-FPX_DEV double m_erf(double x) { return erf(x); }
-FPX_DEV float m_pow(float x, float y) { return powf(x, y); }
-FPX_DEV double m_pow(double x, double y) { return pow(x, y); }
+FPX_HD float m_exp(float x) { return expf(x); }
+FPX_HD double m_exp(double x) { return exp(x); }
+FPX_HD float m_log(float x) { return logf(x); }
+FPX_HD double m_log(double x) { return log(x); }
+FPX_HD float m_sqrt(float x) { return sqrtf(x); }
+FPX_HD double m_sqrt(double x) { return sqrt(x); }
+FPX_HD float m_sin(float x) { return sinf(x); }
+FPX_HD double m_sin(double x) { return sin(x); }
+FPX_HD float m_cos(float x) { return cosf(x); }
+FPX_HD double m_cos(double x) { return cos(x); }
+FPX_HD float m_erf(float x) { return erff(x); }
+FPX_HD double m_erf(double x) { return erf(x); }
+FPX_HD float m_pow(float x, float y) { return powf(x, y); }
+FPX_HD double m_pow(double x, double y) { return pow(x, y); }
 // x**y for the reference's non-integer exponents (0.33333, 0.66666, 0.8 ...).  fp64: exp(y*log(x)),
 // relative error <= ~|y ln x| ulp (a few 1e-16 here) at less than half the cost of the
 // correctly-rounded pow; fp32 keeps powf.  x == 0 and x < 0 behave like pow (0/inf, NaN).
-FPX_DEV float m_powr(float x, float y) { return powf(x, y); }
-FPX_DEV double m_powr(double x, double y) { return exp(y * log(x)); }
+FPX_HD float m_powr(float x, float y) { return powf(x, y); }
+FPX_HD double m_powr(double x, double y) { return exp(y * log(x)); }
 // Division for the inner Langevin arithmetic.  fp64: hardware reciprocal seed + two Newton
 // steps + one residual correction (error <= 1 ulp, 8 instructions instead of the 14 of the
 // IEEE sequence).  Only used where the divisor is finite and non-zero by construction.
@@ -55,13 +56,13 @@ FPX_DEV double m_divf(double a, double b) {
   double q = a * r;
   return fma(fma(-b, q, a), r, q);
 }
-FPX_DEV float m_fmod(float x, float y) { return fmodf(x, y); }
-FPX_DEV double m_fmod(double x, double y) { return fmod(x, y); }
-template <typename R> FPX_DEV R m_abs(R x) { return x < 0 ? -x : x; }
-template <typename R> FPX_DEV R m_max(R a, R b) { return a > b ? a : b; }
-template <typename R> FPX_DEV R m_min(R a, R b) { return a < b ? a : b; }
-template <typename R> FPX_DEV R m_sign(R a, R b) { R m = m_abs(a); return (b < 0 || (b == 0 && signbit(b))) ? -m : m; }
-FPX_DEV double d_modulo(double a, double p) { double r = fmod(a, p); if (r != 0.0 && ((r < 0) != (p < 0))) r += p; return r; }
+FPX_HD float m_fmod(float x, float y) { return fmodf(x, y); }
+FPX_HD double m_fmod(double x, double y) { return fmod(x, y); }
+template <typename R> FPX_HD R m_abs(R x) { return x < 0 ? -x : x; }
+template <typename R> FPX_HD R m_max(R a, R b) { return a > b ? a : b; }
+template <typename R> FPX_HD R m_min(R a, R b) { return a < b ? a : b; }
+template <typename R> FPX_HD R m_sign(R a, R b) { R m = m_abs(a); return (b < 0 || (b == 0 && signbit(b))) ? -m : m; }
+FPX_HD double d_modulo(double a, double p) { double r = fmod(a, p); if (r != 0.0 && ((r < 0) != (p < 0))) r += p; return r; }
 
 // ---------------------------------------------------------------------------
 // device view of everything the path reads (com_mod / par_mod variables)
@@ -629,14 +630,14 @@ FPX_DEV void windalign(R u, R v, R ffap, R ffcp, R &ux, R &vy) {
 #define CM_DGPRAD (K(180.) / CM_PI)
 
 template <typename R>
-FPX_DEV R cspanf(R value, R begin, R end) {   // cmapf_mod.f90:494-524
+FPX_HD R cspanf(R value, R begin, R end) {   // cmapf_mod.f90:494-524
   R first = m_min(begin, end), last = m_max(begin, end);
   R val = m_fmod(value - first, last - first);
   return val <= K(0.) ? val + last : val + first;
 }
 
 template <typename R>
-FPX_DEV R cgszll(const R *s, R xlat) {   // cmapf_mod.f90:190-238
+FPX_HD R cgszll(const R *s, R xlat) {   // cmapf_mod.f90:190-238
   double slat, ymerc, efact;
   if (xlat > K(89.985)) {
     if (s[0] > K(0.9999)) return K(2.) * s[6];
@@ -656,7 +657,7 @@ FPX_DEV R cgszll(const R *s, R xlat) {   // cmapf_mod.f90:190-238
 }
 
 template <typename R>
-FPX_DEV void cnllxy(const R *s, R xlat, R xlong, R &xi, R &eta) {   // cmapf_mod.f90:310-365
+FPX_HD void cnllxy(const R *s, R xlat, R xlong, R &xi, R &eta) {   // cmapf_mod.f90:310-365
   double gamma = (double)s[0];
   double dlat = (double)xlat;
   double dlong = (double)cspanf<R>(xlong - s[1], K(-180.), K(180.));
@@ -689,7 +690,7 @@ FPX_DEV void cnllxy(const R *s, R xlat, R xlong, R &xi, R &eta) {   // cmapf_mod
 }
 
 template <typename R>
-FPX_DEV void cll2xy(const R *s, R xlat, R xlong, R &x, R &y) {   // cmapf_mod.f90:295-308
+FPX_HD void cll2xy(const R *s, R xlat, R xlong, R &x, R &y) {   // cmapf_mod.f90:295-308
   R xi, eta;
   cnllxy(s, xlat, xlong, xi, eta);
   x = s[2] + CM_REARTH / s[6] * (xi * s[4] + eta * s[5]);
@@ -729,6 +730,49 @@ FPX_DEV void cxy2ll(const R *s, R x, R y, R &xlat, R &xlong) {   // cmapf_mod.f9
   double eta = eta0 * (double)s[4] + xi0 * (double)s[5];
   cnxyll(s, xi, eta, xlat, xlong);
   xlong = cspanf<R>(xlong, K(-180.), K(180.));
+}
+
+// Host-side map set-up (what gridcheck_ecmwf.f90:341-366 does through cmapf_mod): only used
+// by hosts that do not have the reference's own northpolemap/southpolemap at hand.
+template <typename R>
+inline void stlmbr(R *s, R tnglat, R xlong) {   // cmapf_mod.f90:780-814
+  R xi, eta;
+  s[0] = m_sin(CM_RADPDG * tnglat);
+  s[1] = cspanf<R>(xlong, K(-180.), K(180.));
+  s[2] = K(0.); s[3] = K(0.); s[4] = K(1.); s[5] = K(0.);
+  s[6] = CM_REARTH;
+  cnllxy(s, K(89.), xlong, xi, eta);
+  s[7] = K(2.) * eta - s[0] * eta * eta;
+  cnllxy(s, K(-89.), xlong, xi, eta);
+  s[8] = K(2.) * eta - s[0] * eta * eta;
+}
+template <typename R>
+inline void stcm2p(R *s, R x1, R y1, R xlat1, R xlong1, R x2, R y2, R xlat2, R xlong2) {   // cmapf_mod.f90:603-633
+  R x1a, y1a, x2a, y2a;
+  for (int k = 2; k < 6; k++) s[k] = K(0.);
+  s[4] = K(1.);
+  s[6] = K(1.);
+  cll2xy(s, xlat1, xlong1, x1a, y1a);
+  cll2xy(s, xlat2, xlong2, x2a, y2a);
+  R den = m_sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+  R dena = m_sqrt((x1a - x2a) * (x1a - x2a) + (y1a - y2a) * (y1a - y2a));
+  s[4] = ((x1a - x2a) * (x1 - x2) + (y1a - y2a) * (y1 - y2)) / den / dena;
+  s[5] = ((y1a - y2a) * (x1 - x2) - (x1a - x2a) * (y1 - y2)) / den / dena;
+  s[6] = s[6] * dena / den;
+  cll2xy(s, xlat1, xlong1, x1a, y1a);
+  s[2] = s[2] + x1 - x1a;
+  s[3] = s[3] + y1 - y1a;
+}
+// gridcheck_ecmwf.f90:341-366: maps for the two polar caps of a global lat/lon grid
+template <typename R>
+inline void polar_maps(R dy, R *north, R *south) {
+  const R switchnorth = K(75.), switchsouth = K(-75.);   // par_mod.f90:123
+  R sizesouth = K(6.) * (switchsouth + K(90.)) / dy;
+  stlmbr(south, K(-90.), K(0.));
+  stcm2p(south, K(0.), K(0.), switchsouth, K(0.), sizesouth, sizesouth, switchsouth, K(180.));
+  R sizenorth = K(6.) * (K(90.) - switchnorth) / dy;
+  stlmbr(north, K(90.), K(0.));
+  stcm2p(north, K(0.), K(0.), switchnorth, K(0.), sizenorth, sizenorth, switchnorth, K(180.));
 }
 
 // ---------------------------------------------------------------------------

@@ -1204,6 +1204,20 @@ struct fpx_engine {
 extern "C" {
 
 int fpx_abi_version(void) { return 1; }
+
+int fpx_polar_maps(int32_t host_real_bytes, double dy, double north[9], double south[9]) {
+  if (!north || !south || !(dy > 0)) return fpx::fail(FPX_ERR_ARG, "fpx_polar_maps: bad argument");
+  if (host_real_bytes == 4) {
+    float n[9], s[9];
+    fpx::polar_maps<float>((float)dy, n, s);
+    for (int i = 0; i < 9; i++) { north[i] = n[i]; south[i] = s[i]; }
+  } else if (host_real_bytes == 8) {
+    fpx::polar_maps<double>(dy, north, south);
+  } else {
+    return fpx::fail(FPX_ERR_ARG, "fpx_polar_maps: host_real_bytes must be 4 or 8");
+  }
+  return FPX_OK;
+}
 const char *fpx_last_error(void) { return fpx::g_err.c_str(); }
 
 int fpx_create(fpx_handle *out, const fpx_config *cfg) {

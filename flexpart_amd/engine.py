@@ -58,8 +58,11 @@ class Engine:
         cfg.switchnorthg = float((rt(SWITCHNORTH) - rt(ylat0)) / rt(dy)) if ng else 999999.0
         cfg.switchsouthg = float((rt(SWITCHSOUTH) - rt(ylat0)) / rt(dy)) if sg else 999999.0
         if ng or sg:
-            if polemaps is None:
-                raise ValueError("a grid with poles needs the host's northpolemap/southpolemap records")
+            if polemaps is None:   # the host has no com_mod records: build them as gridcheck does
+                north = (C.c_double * 9)()
+                south = (C.c_double * 9)()
+                check(self.lib.fpx_polar_maps(host_real_bytes, dy, north, south), "fpx_polar_maps")
+                polemaps = (list(north), list(south))
             for i in range(9):
                 cfg.northpolemap[i] = float(polemaps[0][i])
                 cfg.southpolemap[i] = float(polemaps[1][i])

@@ -134,6 +134,12 @@ int fpx_destroy(fpx_handle h);
 const char *fpx_last_error(void);
 int fpx_abi_version(void);
 
+/* northpolemap/southpolemap (com_mod.f90:560) for a global grid with latitude spacing dy,
+ * computed as the reference's grid check does (gridcheck_ecmwf.f90:341-366 via cmapf_mod
+ * stlmbr/stcm2p) in the host's real kind.  Pure host helper for callers that do not have
+ * the reference's own records; a Fortran host passes its com_mod arrays instead. */
+int fpx_polar_maps(int32_t host_real_bytes, double dy, double north[9], double south[9]);
+
 /* height(1:nz) of com_mod.f90:299 (host_real_bytes each) */
 int fpx_set_height(fpx_handle h, const void *height, int32_t n);
 

@@ -1346,6 +1346,50 @@ void orc_set_grid(orc_ctx *c, int nx, int ny, int nz, double dx, double dy, doub
   c->switchsouthg = sglobal ? (K(-75.) - c->ylat0) / c->dy : K(999999.);
   for (k = 0; k < nz; k++) c->height[k] = (real)height[k];
 }
+/* cmapf_mod.f90:780-814 */
+static void orc_stlmbr(real *s, real tnglat, real xlong) {
+  real xi, eta;
+  s[0] = r_sin(CM_RADPDG * tnglat);
+  s[1] = orc_cspanf(xlong, K(-180.), K(180.));
+  s[2] = K(0.); s[3] = K(0.); s[4] = K(1.); s[5] = K(0.);
+  s[6] = CM_REARTH;
+  orc_cnllxy(s, K(89.), xlong, &xi, &eta);
+  s[7] = K(2.) * eta - s[0] * eta * eta;
+  orc_cnllxy(s, K(-89.), xlong, &xi, &eta);
+  s[8] = K(2.) * eta - s[0] * eta * eta;
+}
+/* cmapf_mod.f90:603-633 */
+static void orc_stcm2p(real *s, real x1, real y1, real xlat1, real xlong1, real x2, real y2, real xlat2, real xlong2) {
+  real x1a, y1a, x2a, y2a, den, dena;
+  int k;
+  for (k = 2; k < 6; k++) s[k] = K(0.);
+  s[4] = K(1.);
+  s[6] = K(1.);
+  orc_cll2xy(s, xlat1, xlong1, &x1a, &y1a);
+  orc_cll2xy(s, xlat2, xlong2, &x2a, &y2a);
+  den = r_sqrt((x1 - x2) * (x1 - x2) + (y1 - y2) * (y1 - y2));
+  dena = r_sqrt((x1a - x2a) * (x1a - x2a) + (y1a - y2a) * (y1a - y2a));
+  s[4] = ((x1a - x2a) * (x1 - x2) + (y1a - y2a) * (y1 - y2)) / den / dena;
+  s[5] = ((y1a - y2a) * (x1 - x2) - (x1a - x2a) * (y1 - y2)) / den / dena;
+  s[6] = s[6] * dena / den;
+  orc_cll2xy(s, xlat1, xlong1, &x1a, &y1a);
+  s[2] = s[2] + x1 - x1a;
+  s[3] = s[3] + y1 - y1a;
+}
+/* the polar-cap maps as gridcheck_ecmwf.f90:341-366 sets them up */
+void orc_make_polemaps(orc_ctx *c) {
+  const real switchnorth = K(75.), switchsouth = K(-75.);
+  real sizesouth = K(6.) * (switchsouth + K(90.)) / c->dy;
+  real sizenorth = K(6.) * (K(90.) - switchnorth) / c->dy;
+  orc_stlmbr(c->southpolemap, K(-90.), K(0.));
+  orc_stcm2p(c->southpolemap, K(0.), K(0.), switchsouth, K(0.), sizesouth, sizesouth, switchsouth, K(180.));
+  orc_stlmbr(c->northpolemap, K(90.), K(0.));
+  orc_stcm2p(c->northpolemap, K(0.), K(0.), switchnorth, K(0.), sizenorth, sizenorth, switchnorth, K(180.));
+}
+void orc_get_polemaps(orc_ctx *c, double *north, double *south) {
+  int i;
+  for (i = 0; i < 9; i++) { north[i] = (double)c->northpolemap[i]; south[i] = (double)c->southpolemap[i]; }
+}
 void orc_set_polemaps(orc_ctx *c, const double *north, const double *south) {
   int i;
   for (i = 0; i < 9; i++) { c->northpolemap[i] = (real)north[i]; c->southpolemap[i] = (real)south[i]; }

@@ -55,6 +55,8 @@ class Oracle:
         if "northpolemap" in sc:
             n = _f64(sc["northpolemap"]); s = _f64(sc["southpolemap"])
             lib.orc_set_polemaps(self.h, n.ctypes.data_as(dp), s.ctypes.data_as(dp))
+        elif ng or sg:
+            lib.orc_make_polemaps(self.h)
         mt = sc["memtime"]; mi = sc["memind"]
         lib.orc_set_time(self.h, int(mt[0]), int(mt[1]), int(mi[0]), int(mi[1]))
         nspec = int(sc["nspec"])
@@ -101,6 +103,12 @@ class Oracle:
         self.xmass1 = np.ascontiguousarray(np.asarray(sc["xmass1"]).astype(self.rt).reshape(nspec, n))
         self.prob = np.zeros((nspec, n), self.rt)
         self.itime = int(sc["itime0"])
+
+    def polemaps(self):
+        n = np.zeros(9); s = np.zeros(9)
+        dp = C.POINTER(C.c_double)
+        self.lib.orc_get_polemaps(self.h, n.ctypes.data_as(dp), s.ctypes.data_as(dp))
+        return n, s
 
     def rannumb(self):
         p = self.lib.orc_rannumb(self.h)

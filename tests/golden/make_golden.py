@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from oracle import scenario_io as sio  # noqa: E402
 from test_oracle_cpu import CASES, golden_scenario  # noqa: E402
 
-KEYS = ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt")
+KEYS = ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt", "xmass1")
 
 
 def main():
@@ -35,6 +35,9 @@ def main():
                     if kind == "r4" and a.dtype == np.float64 and k not in ("xtra1", "ytra1"):
                         a = a.astype(np.float32)      # exact: the values are f32 in the r4 build
                     out[f"s{i}_{k}"] = a
+            if name == "polar":
+                out["northpolemap"] = ref["northpolemap"]
+                out["southpolemap"] = ref["southpolemap"]
             if name == "hanna":
                 # pin the random table too: first/last entries and a checksum
                 t = ref["rannumb"]

@@ -63,6 +63,47 @@ def test_fp64_matches_oracle(built, name, kw):
         assert_close(g, w, 1e-9, 1e-7)
 
 
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna"])
+def test_fp64_matches_oracle_golden_scenarios(built, name):
+    """The scenarios the golden fixtures were made on: polar caps through the stereographic maps
+    (cmapf subset), an aerosol species with settling + dry deposition + decay, CBL, Hanna."""
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario(name)
+    got, want = run_pair(sc, "r8")
+    for g, w in zip(got, want):
+        assert_close(g, w, 1e-9, 1e-7)
+        scale = np.abs(w["xmass1"]).max()
+        assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * scale
+
+
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only"])
+def test_fp64_against_reference_fixtures(built, name):
+    """HIP path directly against the outputs of the unmodified reference (tests/golden, flang r8
+    build).  Only particles touched by the two order-dependent leaks of the serial code (DESIGN.md
+    D1/D2) may differ; they are counted and bounded, everything else must agree to 1e-9."""
+    import os
+    from flexpart_amd.engine import Engine
+    from test_oracle_cpu import GOLD, golden_scenario
+    sc = golden_scenario(name)
+    gold = np.load(os.path.join(GOLD, f"{name}_r8.npz"))
+    eng = Engine(sc)
+    got = eng.run()
+    eng.close()
+    n = int(sc["npart"])
+    bad = np.zeros(n, bool)
+    for i, g in enumerate(got):
+        for k in ("xtra1", "ytra1", "ztra1"):
+            ref = gold[f"s{i}_{k}"]
+            bad |= np.abs(g[k] - ref) > 1e-9 * np.abs(ref).max()
+    # D2 bites in the polar scenario only: every particle is initialised at itime 0 and the serial
+    # code gives it the lat-lon/polar wind choice of its *predecessor* for the first mesoscale
+    # sigma, so particles whose predecessor sat on the other kind of grid differ (about a quarter
+    # of this cloud).  The oracle reproduces that exactly (CPU test) and agrees with the GPU once
+    # its parallel semantics are on (test above); here the affected fraction is only bounded.
+    limit = 0.35 * n if name == "polar" else 0.02 * n
+    assert bad.sum() <= limit, f"{bad.sum()} of {n} particles differ from the reference"
+
+
 @pytest.mark.parametrize("name,kw", [
     ("hanna", dict(ctl=5.0, ifine=4)),
     ("hanna1_method0", dict(ctl=-5.0)),

@@ -11,8 +11,18 @@ from oracle.oracle import Oracle, compare
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
+def _aerosol(sc):
+    # one aerosol species with gravitational settling and dry deposition
+    sc.update(lsettling=1, drydep=1, drydepspec=np.array([1], np.int32), density=np.array([2000.0]),
+              dquer=np.array([8.0]), vsetaver=np.array([-0.004]), cunningham=np.array([1.02]),
+              decay=np.array([1.0e-6]), xmass=np.array([1.0]))
+    return sc
+
+
 CASES = {
     "hanna": dict(ctl=5.0, ifine=4),
+    "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
+    "aerosol": dict(ctl=5.0, ifine=4, post=_aerosol),
     "hanna1_method0": dict(ctl=-5.0),
     "cbl": dict(ctl=5.0, ifine=4, cblflag=1),
     "above_pbl_only": dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True),
@@ -20,7 +30,11 @@ CASES = {
 
 
 def golden_scenario(name):
-    return syn.small(n=1500, nx=48, ny=32, nz=36, nsteps=3, **CASES[name])
+    kw = dict(CASES[name])
+    post = kw.pop("post", None)
+    nx, ny, nz = kw.pop("grid", (48, 32, 36))
+    sc = syn.small(n=1500, nx=nx, ny=ny, nz=nz, nsteps=3, **kw)
+    return post(sc) if post else sc
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -44,6 +58,26 @@ def test_oracle_matches_golden_reference_output(name, kind):
             assert err <= tol_vel, (name, kind, i, k, err)
         for k in ("idt", "itra1", "cbt"):
             assert np.array_equal(s[k], gold[f"s{i}_{k}"]), (name, kind, i, k)
+        ref = gold[f"s{i}_xmass1"]
+        assert np.abs(s["xmass1"] - ref).max() <= (1e-13 if kind == "r8" else 1e-6) * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_polar_maps_match_reference(kind, built):
+    """northpolemap/southpolemap: reference output (golden) == oracle restatement == the product's
+    host helper fpx_polar_maps (used by hosts without the reference's com_mod records)."""
+    import ctypes as C
+    from flexpart_amd import _lib
+    gold = np.load(os.path.join(GOLD, f"polar_{kind}.npz"))
+    sc = golden_scenario("polar")
+    n, s = Oracle(sc, kind).polemaps()
+    tol = 1e-13 if kind == "r8" else 2e-6
+    for got, key in ((n, "northpolemap"), (s, "southpolemap")):
+        assert np.abs(got - gold[key]).max() <= tol * np.abs(gold[key]).max(), (key, got, gold[key])
+    north = (C.c_double * 9)(); south = (C.c_double * 9)()
+    assert _lib.load().fpx_polar_maps(8 if kind == "r8" else 4, float(sc["geom"][1]), north, south) == 0
+    for got, key in ((np.array(north), "northpolemap"), (np.array(south), "southpolemap")):
+        assert np.abs(got - gold[key]).max() <= tol * np.abs(gold[key]).max(), (key, got, gold[key])
 
 
 @pytest.mark.ref
