@@ -1,0 +1,290 @@
+! flexgpu_mod -- ISO_C_BINDING shim between the FLEXPART Fortran host and the
+! MI355X particle-advection engine (include/flexpart_amd.h).
+!
+! This is the file a maintainer adds to the reference's src/ (and to MODOBJS in
+! its makefile).  It marshals the module variables the replaced block reads --
+! the particle loop of timemanager.f90:531-712 -- into the explicit arguments of
+! the C ABI.  The host arrays are passed by address (c_loc): no copies are made
+! on the Fortran side, and the strides nxmax/nymax/nzmax of the static com_mod
+! arrays are honoured by the engine.
+!
+! Typical use inside timemanager (see INTEGRATION.md):
+!     call flexgpu_init(ierr)                       ! once, after gridcheck/readcommand
+!     call flexgpu_upload_fields(memind(1)); call flexgpu_upload_fields(memind(2))
+!     call flexgpu_set_windtime()                   ! after every getfields()
+!     call flexgpu_upload_particles(1, numpart)     ! after releaseparticles / splitting
+!     call flexgpu_step(itime, stats)               ! replaces "do j=1,numpart ... end do"
+!     call flexgpu_download_particles(1, numpart)   ! before conccalc/partoutput need them
+module flexgpu_mod
+  use iso_c_binding
+  use par_mod
+  use com_mod
+  use point_mod, only: xmass, npart
+  implicit none
+  private
+  public :: fpx_step_stats, flexgpu_init, flexgpu_finalize, flexgpu_upload_fields, &
+            flexgpu_set_windtime, flexgpu_upload_particles, flexgpu_download_particles, &
+            flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error
+
+  integer, parameter :: FPX_MAXSPEC = 5
+
+  type, bind(C) :: fpx_config
+    integer(c_int32_t) :: struct_bytes, device, compute_real_bytes, host_real_bytes
+    integer(c_int64_t) :: max_particles
+    integer(c_int32_t) :: nx, ny, nz, nmixz
+    integer(c_int32_t) :: nxmax, nymax, nzmax
+    real(c_double) :: dx, dy, xlon0, ylat0
+    integer(c_int32_t) :: xglobal, nglobal, sglobal
+    real(c_double) :: switchnorthg, switchsouthg
+    real(c_double) :: northpolemap(9), southpolemap(9)
+    integer(c_int32_t) :: ldirect, lsynctime, method, mintime, ifine, turbswitch, cblflag, mdomainfill, lsettling
+    real(c_double) :: ctl
+    real(c_double) :: d_trop, d_strat, turbmesoscale
+    integer(c_int32_t) :: nspec, maxspec
+    integer(c_int32_t) :: drydep, drydepspec(FPX_MAXSPEC)
+    real(c_double) :: density(FPX_MAXSPEC), dquer(FPX_MAXSPEC), vsetaver(FPX_MAXSPEC), cunningham(FPX_MAXSPEC)
+    real(c_double) :: decay(FPX_MAXSPEC)
+    real(c_double) :: xmass_release(FPX_MAXSPEC)
+    integer(c_int32_t) :: npart_release
+    integer(c_int32_t) :: lage_last
+    integer(c_int32_t) :: rng_mode
+    integer(c_int64_t) :: seed
+    integer(c_int32_t) :: sort_interval
+    integer(c_int32_t) :: reserved(7)
+  end type fpx_config
+
+  type, bind(C) :: fpx_fields
+    type(c_ptr) :: uu, vv, ww, uupol, vvpol, rho, drhodz, tt
+    type(c_ptr) :: hmix, ustar, wstar, oli, tropopause
+    type(c_ptr) :: vdep
+  end type fpx_fields
+
+  type, bind(C) :: fpx_particles
+    type(c_ptr) :: xtra1, ytra1
+    type(c_ptr) :: ztra1, uap, ucp, uzp, us, vs, ws
+    type(c_ptr) :: itra1, itramem, idt, npoint, nclass
+    type(c_ptr) :: cbt
+    type(c_ptr) :: xmass1
+    integer(c_int64_t) :: xmass1_ld
+  end type fpx_particles
+
+  type, bind(C) :: fpx_step_stats
+    integer(c_int64_t) :: n_due, n_initialized, n_left_domain, n_min_mass, n_max_age
+    integer(c_int64_t) :: nan_count, nan_count2, n_bad_position
+    real(c_double) :: kernel_ms
+  end type fpx_step_stats
+
+  interface
+    integer(c_int) function fpx_create(h, cfg) bind(C, name='fpx_create')
+      import :: c_ptr, c_int, fpx_config
+      type(c_ptr), intent(out) :: h
+      type(fpx_config), intent(in) :: cfg
+    end function
+    integer(c_int) function fpx_destroy(h) bind(C, name='fpx_destroy')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h
+    end function
+    type(c_ptr) function fpx_last_error() bind(C, name='fpx_last_error')
+      import :: c_ptr
+    end function
+    integer(c_int) function fpx_set_height(h, height, n) bind(C, name='fpx_set_height')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, height
+      integer(c_int32_t), value :: n
+    end function
+    integer(c_int) function fpx_upload_fields(h, slot, f) bind(C, name='fpx_upload_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: slot
+      type(fpx_fields), intent(in) :: f
+    end function
+    integer(c_int) function fpx_set_windtime(h, mt, mi) bind(C, name='fpx_set_windtime')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h
+      integer(c_int32_t), intent(in) :: mt(2), mi(2)
+    end function
+    integer(c_int) function fpx_rng_set_table(h, tab, n) bind(C, name='fpx_rng_set_table')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, tab
+      integer(c_int32_t), value :: n
+    end function
+    integer(c_int) function fpx_upload_particles(h, first, count, p) bind(C, name='fpx_upload_particles')
+      import :: c_ptr, c_int, c_int64_t, fpx_particles
+      type(c_ptr), value :: h
+      integer(c_int64_t), value :: first, count
+      type(fpx_particles), intent(in) :: p
+    end function
+    integer(c_int) function fpx_download_particles(h, first, count, p) bind(C, name='fpx_download_particles')
+      import :: c_ptr, c_int, c_int64_t, fpx_particles
+      type(c_ptr), value :: h
+      integer(c_int64_t), value :: first, count
+      type(fpx_particles), intent(in) :: p
+    end function
+    integer(c_int) function fpx_step(h, itime, st) bind(C, name='fpx_step')
+      import :: c_ptr, c_int, c_int32_t, fpx_step_stats
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: itime
+      type(fpx_step_stats), intent(out) :: st
+    end function
+  end interface
+
+  type(c_ptr), save :: flexgpu_handle = c_null_ptr
+
+contains
+
+  ! Address of a host array element.  com_mod's arrays carry no TARGET attribute, so c_loc is
+  ! applied to a TARGET dummy instead (sequence association: no copy is made for these
+  ! contiguous arrays, and the engine only uses the address during the call).
+  function loc_r(x) result(p)
+    real, target, intent(in) :: x(*)
+    type(c_ptr) :: p
+    p = c_loc(x)
+  end function loc_r
+  function loc_d(x) result(p)
+    real(kind=dp), target, intent(in) :: x(*)
+    type(c_ptr) :: p
+    p = c_loc(x)
+  end function loc_d
+  function loc_i(x) result(p)
+    integer, target, intent(in) :: x(*)
+    type(c_ptr) :: p
+    p = c_loc(x)
+  end function loc_i
+  function loc_i2(x) result(p)
+    integer(kind=2), target, intent(in) :: x(*)
+    type(c_ptr) :: p
+    p = c_loc(x)
+  end function loc_i2
+
+  subroutine flexgpu_last_error(msg)
+    character(len=*), intent(out) :: msg
+    type(c_ptr) :: p
+    character(kind=c_char), pointer :: s(:)
+    integer :: i
+    msg = ''
+    p = fpx_last_error()
+    if (.not. c_associated(p)) return
+    call c_f_pointer(p, s, [len(msg)])
+    do i = 1, len(msg)
+      if (s(i) == c_null_char) exit
+      msg(i:i) = s(i)
+    end do
+  end subroutine flexgpu_last_error
+
+  ! com_mod/par_mod -> fpx_config; creates the engine on `device` for `nmaxpart` particles.
+  subroutine flexgpu_init(ierr, device, nmaxpart, compute_real_bytes, rng_mode, seed)
+    integer, intent(out) :: ierr
+    integer, intent(in), optional :: device, nmaxpart, compute_real_bytes, rng_mode
+    integer(c_int64_t), intent(in), optional :: seed
+    type(fpx_config) :: cfg
+    integer :: ks
+    cfg%struct_bytes = int(c_sizeof(cfg), c_int32_t)
+    cfg%device = 0; if (present(device)) cfg%device = device
+    cfg%host_real_bytes = storage_size(1.0) / 8          ! 4 as shipped, 8 with -fdefault-real-8
+    cfg%compute_real_bytes = 8; if (present(compute_real_bytes)) cfg%compute_real_bytes = compute_real_bytes
+    cfg%max_particles = size(xtra1); if (present(nmaxpart)) cfg%max_particles = nmaxpart
+    cfg%nx = nx; cfg%ny = ny; cfg%nz = nz; cfg%nmixz = nmixz
+    cfg%nxmax = nxmax; cfg%nymax = nymax; cfg%nzmax = nzmax
+    cfg%dx = dx; cfg%dy = dy; cfg%xlon0 = xlon0; cfg%ylat0 = ylat0
+    cfg%xglobal = merge(1, 0, xglobal); cfg%nglobal = merge(1, 0, nglobal); cfg%sglobal = merge(1, 0, sglobal)
+    cfg%switchnorthg = switchnorthg; cfg%switchsouthg = switchsouthg
+    cfg%northpolemap = northpolemap; cfg%southpolemap = southpolemap
+    cfg%ldirect = ldirect; cfg%lsynctime = lsynctime; cfg%method = method; cfg%mintime = mintime
+    cfg%ifine = ifine; cfg%turbswitch = merge(1, 0, turbswitch); cfg%cblflag = cblflag
+    cfg%mdomainfill = mdomainfill; cfg%lsettling = merge(1, 0, lsettling)
+    cfg%ctl = ctl
+    cfg%d_trop = d_trop; cfg%d_strat = d_strat; cfg%turbmesoscale = turbmesoscale
+    cfg%nspec = nspec; cfg%maxspec = maxspec
+    cfg%drydep = merge(1, 0, DRYDEP)
+    cfg%drydepspec = 0; cfg%density = 0; cfg%dquer = 0; cfg%vsetaver = 0; cfg%cunningham = 1
+    cfg%decay = 0; cfg%xmass_release = 1
+    do ks = 1, nspec
+      cfg%drydepspec(ks) = merge(1, 0, DRYDEPSPEC(ks))
+      cfg%density(ks) = density(ks); cfg%dquer(ks) = dquer(ks); cfg%vsetaver(ks) = vsetaver(ks)
+      cfg%cunningham(ks) = cunningham(ks); cfg%decay(ks) = decay(ks)
+      cfg%xmass_release(ks) = xmass(1, ks)
+    end do
+    cfg%npart_release = npart(1)
+    cfg%lage_last = lage(nageclass)
+    cfg%rng_mode = 0; if (present(rng_mode)) cfg%rng_mode = rng_mode
+    cfg%seed = 24301_c_int64_t; if (present(seed)) cfg%seed = seed
+    cfg%sort_interval = 8
+    cfg%reserved = 0
+    ierr = fpx_create(flexgpu_handle, cfg)
+    if (ierr /= 0) return
+    ierr = fpx_set_height(flexgpu_handle, loc_r(height), int(nz, c_int32_t))
+  end subroutine flexgpu_init
+
+  subroutine flexgpu_finalize()
+    integer :: ierr
+    ierr = fpx_destroy(flexgpu_handle)
+    flexgpu_handle = c_null_ptr
+  end subroutine flexgpu_finalize
+
+  ! bit-parity mode: hand the host's own rannumb table (FLEXPART.f90:56-59) to the engine
+  subroutine flexgpu_use_table_rng(ierr)
+    integer, intent(out) :: ierr
+    ierr = fpx_rng_set_table(flexgpu_handle, loc_r(rannumb), int(maxrand, c_int32_t))
+  end subroutine flexgpu_use_table_rng
+
+  ! one time slot of the com_mod fields (slot = the value found in memind(k))
+  subroutine flexgpu_upload_fields(slot, ierr)
+    integer, intent(in) :: slot
+    integer, intent(out) :: ierr
+    type(fpx_fields) :: f
+    f%uu = loc_r(uu(0,0,1,slot)); f%vv = loc_r(vv(0,0,1,slot)); f%ww = loc_r(ww(0,0,1,slot))
+    f%uupol = loc_r(uupol(0,0,1,slot)); f%vvpol = loc_r(vvpol(0,0,1,slot))
+    f%rho = loc_r(rho(0,0,1,slot)); f%drhodz = loc_r(drhodz(0,0,1,slot)); f%tt = loc_r(tt(0,0,1,slot))
+    f%hmix = loc_r(hmix(0,0,1,slot)); f%ustar = loc_r(ustar(0,0,1,slot)); f%wstar = loc_r(wstar(0,0,1,slot))
+    f%oli = loc_r(oli(0,0,1,slot)); f%tropopause = loc_r(tropopause(0,0,1,slot))
+    f%vdep = loc_r(vdep(0,0,1,slot))
+    ierr = fpx_upload_fields(flexgpu_handle, int(slot, c_int32_t), f)
+  end subroutine flexgpu_upload_fields
+
+  subroutine flexgpu_set_windtime(ierr)
+    integer, intent(out) :: ierr
+    integer(c_int32_t) :: mt(2), mi(2)
+    mt = memtime(1:2); mi = memind(1:2)
+    ierr = fpx_set_windtime(flexgpu_handle, mt, mi)
+  end subroutine flexgpu_set_windtime
+
+  subroutine particle_ptrs(p, j1)
+    type(fpx_particles), intent(out) :: p
+    integer, intent(in) :: j1
+    p%xtra1 = loc_d(xtra1(j1:)); p%ytra1 = loc_d(ytra1(j1:)); p%ztra1 = loc_r(ztra1(j1:))
+    p%uap = loc_r(uap(j1:)); p%ucp = loc_r(ucp(j1:)); p%uzp = loc_r(uzp(j1:))
+    p%us = loc_r(us(j1:)); p%vs = loc_r(vs(j1:)); p%ws = loc_r(ws(j1:))
+    p%itra1 = loc_i(itra1(j1:)); p%itramem = loc_i(itramem(j1:)); p%idt = loc_i(idt(j1:))
+    p%npoint = loc_i(npoint(j1:)); p%nclass = loc_i(nclass(j1:)); p%cbt = loc_i2(cbt(j1:))
+    p%xmass1 = loc_r(xmass1(j1:,1))
+    p%xmass1_ld = size(xmass1, 1)
+  end subroutine particle_ptrs
+
+  ! particles j1..j2 (Fortran numbering) host -> device / device -> host
+  subroutine flexgpu_upload_particles(j1, j2, ierr)
+    integer, intent(in) :: j1, j2
+    integer, intent(out) :: ierr
+    type(fpx_particles) :: p
+    call particle_ptrs(p, j1)
+    ierr = fpx_upload_particles(flexgpu_handle, int(j1-1, c_int64_t), int(j2-j1+1, c_int64_t), p)
+  end subroutine flexgpu_upload_particles
+
+  subroutine flexgpu_download_particles(j1, j2, ierr)
+    integer, intent(in) :: j1, j2
+    integer, intent(out) :: ierr
+    type(fpx_particles) :: p
+    call particle_ptrs(p, j1)
+    ierr = fpx_download_particles(flexgpu_handle, int(j1-1, c_int64_t), int(j2-j1+1, c_int64_t), p)
+  end subroutine flexgpu_download_particles
+
+  ! the replacement of the particle loop timemanager.f90:531-712
+  subroutine flexgpu_step(itime, stats, ierr)
+    integer, intent(in) :: itime
+    type(fpx_step_stats), intent(out) :: stats
+    integer, intent(out) :: ierr
+    ierr = fpx_step(flexgpu_handle, int(itime, c_int32_t), stats)
+    nan_count = nan_count + int(stats%nan_count)      ! com_mod counters, advance.f90:421,439
+    nan_count2 = nan_count2 + int(stats%nan_count2)
+  end subroutine flexgpu_step
+
+end module flexgpu_mod

@@ -36,10 +36,17 @@ build_one() {
     for s in $SUBS; do
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
+    # the product's ISO_C_BINDING shim (compiled against the reference's modules) + our driver
+    "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/../flexpart_amd/fortran/flexgpu_mod.f90" -o flexgpu_mod.o
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_driver.f90" -o ref_driver.o
     objs=""
     for m in $MODS $SUBS; do objs="$objs $m.o"; done
-    "$FC" -O2 -mcmodel=medium $flags ref_driver.o $objs -o "$OUT/flexref_$kind"
+    # links libflexpart_amd.so (the HIP engine) for the drop-in mode; found at run time
+    # relative to the binary, which also lives inside the repo snapshot on the GPU box
+    "$FC" -O2 -mcmodel=medium $flags ref_driver.o flexgpu_mod.o $objs \
+        -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
+        -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
+        -o "$OUT/flexref_$kind"
   )
   echo "build_ref: built $OUT/flexref_$kind"
 }

@@ -8,7 +8,10 @@
 ! synchronisation step.  This file is our own code: it contains no reference
 ! source, only calls into it and assignments to its module variables.
 !
-! Usage:  flexref_rK scenario.bin out.bin [timing]
+! Usage:  flexref_rK scenario.bin out.bin [timing|gpu]
+!   gpu: the same host arrays (com_mod) are advanced by the MI355X engine through the
+!        ISO_C_BINDING shim flexpart_amd/fortran/flexgpu_mod.f90 instead of the Fortran loop --
+!        the drop-in integration test (needs a GPU; run on the GPU box).
 !
 ! Scenario file = sequence of records {name*16, dtype i4 (1=i32, 2=f64),
 ! count i8, payload}, terminated by name 'END'.  All reals travel as f64 and
@@ -47,8 +50,12 @@ program flexref
   use unc_mod
   use outg_mod
   use drv_io
+  use flexgpu_mod
   implicit none
 
+  type(fpx_step_stats) :: gstats
+  integer :: gerr, use_gpu
+  character(len=256) :: gmsg
   character(len=512) :: fscen, fout, arg3
   character(len=16) :: name
   integer(kind=4) :: dtype
@@ -68,9 +75,11 @@ program flexref
   call get_command_argument(1, fscen)
   call get_command_argument(2, fout)
   timing = 0
+  use_gpu = 0
   if (command_argument_count() .ge. 3) then
     call get_command_argument(3, arg3)
     if (trim(arg3) .eq. 'timing') timing = 1
+    if (trim(arg3) .eq. 'gpu') use_gpu = 1
   end if
 
   ! Random number table exactly as the reference main program fills it
@@ -244,6 +253,36 @@ program flexref
     call put_d('derived', tmp, 4)
   end if
 
+  if (use_gpu .eq. 1) then
+    ! ---- drop-in: the engine replaces the particle loop -------------------------------
+    call flexgpu_init(gerr, nmaxpart=numpart)
+    if (gerr .ne. 0) call gpu_fail('flexgpu_init')
+    call flexgpu_use_table_rng(gerr)
+    if (gerr .ne. 0) call gpu_fail('flexgpu_use_table_rng')
+    call flexgpu_upload_fields(memind(1), gerr)
+    if (gerr .ne. 0) call gpu_fail('flexgpu_upload_fields 1')
+    call flexgpu_upload_fields(memind(2), gerr)
+    if (gerr .ne. 0) call gpu_fail('flexgpu_upload_fields 2')
+    call flexgpu_set_windtime(gerr)
+    if (gerr .ne. 0) call gpu_fail('flexgpu_set_windtime')
+    call flexgpu_upload_particles(1, numpart, gerr)
+    if (gerr .ne. 0) call gpu_fail('flexgpu_upload_particles')
+    nadv=0
+    call system_clock(c0, crate)
+    do istep=0,nsteps-1
+      itime=itime0+istep*lsynctime
+      call flexgpu_step(itime, gstats, gerr)
+      if (gerr .ne. 0) call gpu_fail('flexgpu_step')
+      nadv=nadv+gstats%n_due
+      call flexgpu_download_particles(1, numpart, gerr)
+      if (gerr .ne. 0) call gpu_fail('flexgpu_download_particles')
+      call dump_state()
+    end do
+    call system_clock(c1)
+    call flexgpu_finalize()
+    goto 900
+  end if
+
   ! ---- the particle loop, in the order of timemanager.f90:531-712 ---------
   nadv=0
   call system_clock(c0, crate)
@@ -303,6 +342,7 @@ program flexref
     if (timing .eq. 0) call dump_state()
   end do
   call system_clock(c1)
+900 continue
   tsec = real(c1-c0,8)/real(crate,8)
 
   tmp(1)=tsec; tmp(2)=real(nadv,8); tmp(3)=real(nan_count,8); tmp(4)=real(nan_count2,8)
@@ -314,6 +354,13 @@ program flexref
        ' advance calls, particle-steps/s = ', real(nadv,8)/max(tsec,1d-9)
 
 contains
+
+  subroutine gpu_fail(where)
+    character(len=*), intent(in) :: where
+    call flexgpu_last_error(gmsg)
+    write(*,*) 'ref_driver: ', where, ' failed: ', gerr, ' ', trim(gmsg)
+    stop 2
+  end subroutine gpu_fail
 
   subroutine fill3(f, b)
     real, intent(inout) :: f(0:nxmax-1,0:nymax-1,nzmax,numwfmem)

@@ -75,13 +75,13 @@ def have_ref(kind="r8"):
     return os.access(ref_binary(kind), os.X_OK)
 
 
-def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen"):
+def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=False):
     """Run the compiled reference on a scenario -> dict(steps=[{...}], rannumb=..., ...)."""
     os.makedirs(workdir, exist_ok=True)
     fs = os.path.join(workdir, f"{tag}_{os.getpid()}.scen")
     fo = os.path.join(workdir, f"{tag}_{os.getpid()}.out")
     write_scenario(fs, sc)
-    cmd = f"ulimit -s unlimited; exec {ref_binary(kind)} {fs} {fo}" + (" timing" if timing else "")
+    cmd = f"ulimit -s unlimited; exec {ref_binary(kind)} {fs} {fo}" + (" timing" if timing else "") + (" gpu" if gpu else "")
     res = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"reference driver failed: {res.stdout}\n{res.stderr}")
