@@ -57,6 +57,21 @@ class FpxParticles(C.Structure):
                [("xmass1_ld", C.c_int64)]
 
 
+FPX_MAXAGECLASS = 8
+
+
+class FpxOutgrid(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32),
+        ("numxgrid", C.c_int32), ("numygrid", C.c_int32), ("numzgrid", C.c_int32),
+        ("dxout", C.c_double), ("dyout", C.c_double), ("xoutshift", C.c_double), ("youtshift", C.c_double),
+        ("maxpointspec_act", C.c_int32), ("nclassunc", C.c_int32), ("nageclass", C.c_int32),
+        ("lage", C.c_int32 * FPX_MAXAGECLASS),
+        ("ind_samp", C.c_int32), ("ioutputforeachrelease", C.c_int32), ("lusekerneloutput", C.c_int32),
+        ("reserved", C.c_int32 * 5),
+    ]
+
+
 class FpxStepStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("n_due", "n_initialized", "n_left_domain", "n_min_mass", "n_max_age",
@@ -69,7 +84,8 @@ SYMBOLS = [
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
     "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_sort_particles",
-    "fpx_seed_particles", "fpx_stream",
+    "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
+    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init",
 ]
 
 _lib = None
@@ -110,6 +126,12 @@ def load():
     lib.fpx_sort_particles.argtypes = [vp]
     lib.fpx_seed_particles.argtypes = [vp, C.c_int64, C.c_uint64, C.c_double, C.c_double,
                                        C.c_double, C.c_int32]
+    lib.fpx_outgrid_init.argtypes = [vp, C.POINTER(FpxOutgrid), vp]
+    lib.fpx_set_output_times.argtypes = [vp, C.c_int32, C.c_int32]
+    lib.fpx_conccalc.argtypes = [vp, C.c_int32, C.c_double]
+    lib.fpx_get_grids.argtypes = [vp, vp, vp, C.c_int32, C.c_int32]
+    lib.fpx_comm_unique_id.argtypes = [vp, C.c_int32]
+    lib.fpx_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
     _lib = lib
     return lib
 

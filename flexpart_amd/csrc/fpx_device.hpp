@@ -1460,5 +1460,146 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// output-grid sampling: conccalc.f90 (mother output grid) and drydepokernel.f90
+// ---------------------------------------------------------------------------
+constexpr int kMaxAge = 8;
+
+template <typename R>
+struct GridP {
+  int on;                                  // an output grid is configured
+  int numxgrid, numygrid, numzgrid, maxspec, maxpointspec_act, nclassunc, nageclass;
+  int lage[kMaxAge];
+  R dxout, dyout, xoutshift, youtshift;
+  int ind_samp, ioutputforeachrelease, lusekerneloutput;
+  int loutnext, loutstep;
+  const R *outheight;                      // [numzgrid]
+  R *gridunc;                              // (x, y, z, spec, pointspec, classunc, age), x fastest
+  float *drygridunc;                       // (x, y, spec, pointspec, classunc, age): real(dep_prec)
+};
+
+template <typename R>
+FPX_DEV int ageclass(const GridP<R> &Gp, int itage) {   // conccalc.f90:54-58, timemanager.f90:545-548
+  int nage = 1;
+  for (; nage <= Gp.nageclass; nage++)
+    if (itage < Gp.lage[nage - 1]) break;
+  return nage;
+}
+
+FPX_DEV double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+FPX_DEV float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Add val to base[idx] for the lanes with valid set.  Must be called by the whole wave.
+// After a locality sort the lanes of a wave mostly target the same cell (a point release puts
+// *all* particles into a handful of cells): then the wave is reduced in registers and issues
+// one atomic instead of 64 colliding ones.
+template <typename T>
+FPX_DEV void wave_scatter_add(T *base, long long idx, T val, bool valid) {
+  const unsigned long long m = __ballot(valid);
+  if (m == 0ull) return;
+  const int first = __ffsll((long long)m) - 1;
+  const long long idx0 = __shfl(idx, first);
+  if (__all(!valid || idx == idx0)) {
+    T v = wave_sum(valid ? val : (T)0);
+    if ((int)(threadIdx.x & 63) == first) atomicAdd(base + idx0, v);
+  } else if (valid) {
+    atomicAdd(base + idx, val);
+  }
+}
+
+// conccalc.f90:50-295 for one particle (active == this lane holds a particle that is due)
+template <typename R>
+FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hgt, bool active, double xt, double yt, R zt,
+                               int itage, int npoint, int nclass, const R *xmass, R weight) {
+  const int nage = ageclass(Gp, itage);
+  R rhoi = K(1.);
+  if (active && Gp.ind_samp == -1) {   // conccalc.f90:80-122, density at the particle
+    int ix = (int)xt, jy = (int)yt;
+    int ixp = min(ix + 1, V.nx - 1), jyp = jy + 1;
+    if (jyp >= V.ny) jyp = jyp - 1;
+    R ddx = (R)(xt - (double)(R)ix), ddy = (R)(yt - (double)(R)jy);
+    R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
+    R p1 = rddx * rddy, p2 = ddx * rddy, p3 = rddx * ddy, p4 = ddx * ddy;
+    int indz = find_level(hgt, V.nz, zt);
+    R dz1 = zt - hgt[indz - 1], dz2 = hgt[indz] - zt;
+    R dz = K(1.) / (dz1 + dz2);
+    R rhoprof[2];
+    const long long c00 = (long long)jy * V.nx + ix, c10 = (long long)jy * V.nx + ixp;
+    const long long c01 = (long long)jyp * V.nx + ix, c11 = (long long)jyp * V.nx + ixp;
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+      const int lev = indz + n;
+      // first corner: slot memind(2); the other three: literal slot 2 (conccalc.f90:117-120)
+      rhoprof[n] = p1 * V.r2[((c00 * V.nz + (lev - 1)) * 2 + V.m2) * 2] + p2 * V.r2[((c10 * V.nz + (lev - 1)) * 2 + 1) * 2] +
+                   p3 * V.r2[((c01 * V.nz + (lev - 1)) * 2 + 1) * 2] + p4 * V.r2[((c11 * V.nz + (lev - 1)) * 2 + 1) * 2];
+    }
+    rhoi = (dz1 * rhoprof[1] + dz2 * rhoprof[0]) * dz;
+  }
+  const int nrelpointer = (Gp.ioutputforeachrelease == 0 || V.mdomainfill == 1) ? 1 : npoint;
+  int kz = 1;
+  for (; kz <= Gp.numzgrid; kz++)
+    if (Gp.outheight[kz - 1] > zt) break;
+  const bool inside = active && kz <= Gp.numzgrid;
+  const R xl = (R)((xt * (double)V.dx + (double)Gp.xoutshift) / (double)Gp.dxout);
+  const R yl = (R)((yt * (double)V.dy + (double)Gp.youtshift) / (double)Gp.dyout);
+  int ix = (int)xl; if (xl < K(0.)) ix = ix - 1;
+  int jy = (int)yl; if (yl < K(0.)) jy = jy - 1;
+  const bool direct = !Gp.lusekerneloutput || itage < 10800 || xl < K(0.5) || yl < K(0.5) ||
+                      xl > (R)(Gp.numxgrid - 1) - K(0.5) || yl > (R)(Gp.numygrid - 1) - K(0.5);
+  const R ddx = xl - (R)ix, ddy = yl - (R)jy;
+  int ixp, jyp;
+  R wx, wy;
+  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+  const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
+  const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
+  const long long plane = (long long)Gp.numxgrid * Gp.numygrid;
+  const long long sstride = plane * Gp.numzgrid;
+  // offset of (.., kz, ks=1, nrelpointer, nclass, nage)
+  const long long off = plane * (kz - 1) + sstride * ((long long)Gp.maxspec * ((nrelpointer - 1) + (long long)Gp.maxpointspec_act * ((nclass - 1) + (long long)Gp.nclassunc * (nage - 1))));
+  for (int ks = 0; ks < V.nspec; ks++) {
+    const R m = active ? xmass[ks] / rhoi * weight : K(0.);
+    R *g = Gp.gridunc + off + sstride * ks;
+    wave_scatter_add<R>(g, (long long)jy * Gp.numxgrid + ix, direct ? m : m * (wx * wy), inside && okx && oky);
+    wave_scatter_add<R>(g, (long long)jyp * Gp.numxgrid + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
+    wave_scatter_add<R>(g, (long long)jyp * Gp.numxgrid + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
+    wave_scatter_add<R>(g, (long long)jy * Gp.numxgrid + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
+  }
+}
+
+// drydepokernel.f90:41-116 for one species (deposit already in dep_prec = float)
+template <typename R>
+FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp, int nunc, float deposit, int ks, R x, R y, int nage, int kp) {
+  if (!(fabsf(deposit) > 0.f)) return;
+  const R xl = (x * V.dx + Gp.xoutshift) / Gp.dxout;
+  const R yl = (y * V.dy + Gp.youtshift) / Gp.dyout;
+  const int ix = (int)xl, jy = (int)yl;   // no correction for negative xl here, as in the reference
+  const R ddx = xl - (R)ix, ddy = yl - (R)jy;
+  int ixp, jyp;
+  R wx, wy;
+  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+  const long long plane = (long long)Gp.numxgrid * Gp.numygrid;
+  float *g = Gp.drygridunc + plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1))));
+  const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
+  const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
+  if (!Gp.lusekerneloutput) {
+    if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, deposit);
+    return;
+  }
+  if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, (float)((R)deposit * (wx * wy)));
+  if (okxp && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * (K(1.) - wy))));
+  if (okxp && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * wy)));
+  if (okx && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ix, (float)((R)deposit * (wx * (K(1.) - wy))));
+}
+
 #undef K
 }  // namespace fpx

@@ -5,6 +5,7 @@
 // k_advance (one thread per particle slot) on the handle's stream.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <rccl/rccl.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
@@ -247,7 +248,7 @@ __device__ __forceinline__ int advance_start_index(const View<R> &V, const SeqRn
 
 // epilogue timemanager.f90:630-708 + write-back of the particle
 template <typename R, bool DRYDEP>
-__device__ __forceinline__ void epilogue_store(const View<R> &V, Parts<R> &P, long long s, int itime, int itramem,
+__device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> &Gp, Parts<R> &P, long long s, int itime, int itramem,
                                                int nstop, const PState<R> &ps, const R *prob, Stats *st) {
   int itra1;
   if (nstop > 1) {
@@ -261,8 +262,20 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, Parts<R> &P, lo
       if (ks < V.nspec) {
         R decfact = V.decay[ks] > (R)0 ? m_exp(-(R)abs(V.lsynctime) * V.decay[ks]) : (R)1;
         R xm = P.xmass1[(size_t)ks * P.cap + s];
-        if (DRYDEP && V.drydepspec[ks]) xm = xm * ((R)1 - prob[ks]) * decfact;
-        else xm = xm * decfact;
+        if (DRYDEP && V.drydepspec[ks]) {
+          // timemanager.f90:650-656; drydeposit is real(dep_prec): 4 bytes in every build
+          float drydeposit = (float)(xm * prob[ks] * decfact);
+          xm = xm * ((R)1 - prob[ks]) * decfact;
+          if (Gp.on && V.ldirect == 1) {   // timemanager.f90:690-696
+            if (V.decay[ks] > (R)0) {
+              const int ldeltat = itime < Gp.loutnext ? itime - (Gp.loutnext - Gp.loutstep) : itime - Gp.loutnext;   // :513-517
+              drydeposit = (float)((R)drydeposit * m_exp((R)abs(ldeltat) * V.decay[ks]));
+            }
+            const int nage = ageclass(Gp, abs(itime - itramem));
+            const int kp = Gp.ioutputforeachrelease == 1 ? P.npoint[s] : 1;
+            drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp);
+          }
+        } else xm = xm * decfact;
         if (DRYDEP || V.decay[ks] > (R)0) P.xmass1[(size_t)ks * P.cap + s] = xm;
         if (V.mdomainfill == 0) {
           if (V.xmass_rel[ks] > (R)0) xmassfract = m_max(xmassfract, (R)V.npart_rel * xm / V.xmass_rel[ks]);
@@ -298,7 +311,7 @@ struct PblRec {
 };
 
 template <typename R, bool DRYDEP>
-__global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag) {
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
@@ -373,7 +386,7 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, Parts<R> P, SeqRng S
   R prob[kMaxSpec];
 #pragma unroll
   for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
-  epilogue_store<R, DRYDEP>(V, P, s, itime, itramem, nstop, ps, prob, st);
+  epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
 }
 
 // The Langevin kernel: persistent waves, lane refill (see the header comment above).
@@ -477,7 +490,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
 // completion of the PBL particles: label 700 if the particle left the PBL, sigmas for the
 // mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
 template <typename R, bool DRYDEP>
-__global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+__global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                        const unsigned int *__restrict__ pbl_list,
                                                        const unsigned int *__restrict__ pbl_count) {
   __shared__ R hgt[kMaxNz];
@@ -518,12 +531,47 @@ __global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, Parts<R> P, Pb
     R prob[kMaxSpec];
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (DRYDEP && ks < V.nspec) ? Q.prob[(size_t)ks * P.cap + s] : (R)0;
-    epilogue_store<R, DRYDEP>(V, P, s, itime, P.itramem[s], nstop, ps, prob, st);
+    epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, P.itramem[s], nstop, ps, prob, st);
   }
+}
+
+// conccalc.f90:50-295: every slot, whole waves stay convergent for the wave-level pre-reduction
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V, GridP<R> Gp, Parts<R> P, long long numpart, int itime, R weight) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool active = s < numpart;
+  double xt = 0, yt = 0;
+  R zt = 0, xm[kMaxSpec];
+  int itage = 0, npoint = 1, nclass = 1;
+#pragma unroll
+  for (int ks = 0; ks < kMaxSpec; ks++) xm[ks] = (R)0;
+  if (active) active = P.itra1[s] == itime;
+  if (active) {
+    xt = P.xt[s]; yt = P.yt[s]; zt = P.zt[s];
+    itage = abs(itime - P.itramem[s]);
+    npoint = P.npoint[s]; nclass = P.nclass[s];
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++)
+      if (ks < V.nspec) xm[ks] = P.xmass1[(size_t)ks * P.cap + s];
+    if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) active = false;
+  }
+  conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight);
+}
+
+template <typename T>
+__global__ void k_convert(const T *__restrict__ src, double *__restrict__ dst64, float *__restrict__ dst32, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (dst64) dst64[i] = (double)src[i];
+  if (dst32) dst32[i] = (float)src[i];
 }
 
 // ---------------------------------------------------------------------------
 // engine
+// ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
 struct EngineBase {
   virtual ~EngineBase() {}
@@ -543,6 +591,11 @@ struct EngineBase {
   virtual int sort_particles() = 0;
   virtual int seed_particles(long long n, unsigned long long seed, double frac_pbl, double zmax, double lat_margin,
                              int itime0) = 0;
+  virtual int outgrid_init(const fpx_outgrid *g, const void *outheight) = 0;
+  virtual int set_output_times(int loutnext, int loutstep) = 0;
+  virtual int conccalc(int itime, double weight) = 0;
+  virtual int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) = 0;
+  virtual int comm_init(const void *id, int nbytes, int nranks, int rank) = 0;
   virtual void *stream_ptr() = 0;
 };
 
@@ -569,6 +622,10 @@ struct Engine : EngineBase {
   unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[0] = list length, ctr[1] = chunk cursor
   unsigned char *d_pbl_flag = nullptr;
   PblRec<R> Q;
+  GridP<R> Gp;
+  size_t n_grid3 = 0, n_grid2 = 0;
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 1;
   void *d_sel_tmp = nullptr;
   size_t sel_tmp_bytes = 0;
   int pbl_grid = 0;
@@ -621,6 +678,7 @@ struct Engine : EngineBase {
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     memset(&V, 0, sizeof(V));
     memset(&P, 0, sizeof(P));
+    memset(&Gp, 0, sizeof(Gp));
     // scalars: typed exactly as the reference's default-real variables
     V.nx = cfg.nx; V.ny = cfg.ny; V.nz = cfg.nz; V.nxmin1 = cfg.nx - 1; V.nymin1 = cfg.ny - 1; V.nmixz = cfg.nmixz;
     V.dx = (R)cfg.dx; V.dy = (R)cfg.dy; V.xlon0 = (R)cfg.xlon0; V.ylat0 = (R)cfg.ylat0;
@@ -705,6 +763,7 @@ struct Engine : EngineBase {
     if (staging) (void)hipFree(staging);
     if (d_sort_tmp) (void)hipFree(d_sort_tmp);
     if (d_sel_tmp) (void)hipFree(d_sel_tmp);
+    if (comm) (void)ncclCommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
   }
 
@@ -1042,8 +1101,8 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
     HIPCHK(hipEventRecord(ev.first, stream));
-    if (cfg.drydep) k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
-    else k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
+    if (cfg.drydep) k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
+    else k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
     {
       // ordered compaction of the flagged slots -> work list (length in d_pbl_ctr[0])
       size_t need = sel_tmp_bytes;
@@ -1052,8 +1111,8 @@ struct Engine : EngineBase {
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
     loop_kernel()<<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
-    if (cfg.drydep) k_pbl_finish<R, true><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-    else k_pbl_finish<R, false><<<fin_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+    if (cfg.drydep) k_pbl_finish<R, true><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+    else k_pbl_finish<R, false><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
     HIPCHK(hipEventRecord(ev.second, stream));
     HIPCHK(hipGetLastError());
     step_counter++;
@@ -1186,6 +1245,92 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // ---- output grids -----------------------------------------------------------
+  int outgrid_init(const fpx_outgrid *g, const void *outheight) override {
+    if (!g || !outheight) return fail(FPX_ERR_ARG, "outgrid_init: null argument");
+    if (g->struct_bytes != (int32_t)sizeof(fpx_outgrid)) return fail(FPX_ERR_ARG, "outgrid_init: fpx_outgrid size mismatch (ABI)");
+    if (g->numxgrid < 1 || g->numygrid < 1 || g->numzgrid < 1 || g->numzgrid > kMaxNz) return fail(FPX_ERR_ARG, "outgrid_init: bad grid extents");
+    if (g->maxpointspec_act < 1 || g->nclassunc < 1 || g->nageclass < 1 || g->nageclass > kMaxAge) return fail(FPX_ERR_ARG, "outgrid_init: bad maxpointspec_act/nclassunc/nageclass");
+    if (Gp.on) return fail(FPX_ERR_STATE, "outgrid_init: already initialised");
+    Gp.numxgrid = g->numxgrid; Gp.numygrid = g->numygrid; Gp.numzgrid = g->numzgrid;
+    Gp.maxspec = cfg.maxspec; Gp.maxpointspec_act = g->maxpointspec_act; Gp.nclassunc = g->nclassunc; Gp.nageclass = g->nageclass;
+    for (int i = 0; i < kMaxAge; i++) Gp.lage[i] = i < g->nageclass ? g->lage[i] : 0x7fffffff;
+    Gp.dxout = (R)g->dxout; Gp.dyout = (R)g->dyout; Gp.xoutshift = (R)g->xoutshift; Gp.youtshift = (R)g->youtshift;
+    Gp.ind_samp = g->ind_samp; Gp.ioutputforeachrelease = g->ioutputforeachrelease; Gp.lusekerneloutput = g->lusekerneloutput;
+    Gp.loutnext = 0; Gp.loutstep = 0;
+    n_grid2 = (size_t)g->numxgrid * g->numygrid * cfg.maxspec * g->maxpointspec_act * g->nclassunc * g->nageclass;
+    n_grid3 = n_grid2 * g->numzgrid;
+    int rc;
+    R *oh;
+    if ((rc = dalloc(&oh, g->numzgrid))) return rc;
+    std::vector<R> tmp(g->numzgrid);
+    for (int k = 0; k < g->numzgrid; k++) tmp[k] = cfg.host_real_bytes == 4 ? (R)((const float *)outheight)[k] : (R)((const double *)outheight)[k];
+    HIPCHK(hipMemcpyAsync(oh, tmp.data(), g->numzgrid * sizeof(R), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    Gp.outheight = oh;
+    if ((rc = dalloc(&Gp.gridunc, n_grid3))) return rc;
+    if ((rc = dalloc(&Gp.drygridunc, n_grid2))) return rc;
+    HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
+    HIPCHK(hipMemsetAsync(Gp.drygridunc, 0, n_grid2 * sizeof(float), stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    Gp.on = 1;
+    return 0;
+  }
+  int set_output_times(int loutnext, int loutstep) override {
+    Gp.loutnext = loutnext; Gp.loutstep = loutstep;
+    return 0;
+  }
+  int conccalc(int itime, double weight) override {
+    if (!Gp.on) return fail(FPX_ERR_STATE, "conccalc: fpx_outgrid_init first");
+    if (!height_set || (Gp.ind_samp == -1 && (!slot_loaded[0] || !slot_loaded[1]))) return fail(FPX_ERR_STATE, "conccalc: height / fields not set");
+    if (numpart == 0) return 0;
+    const int nb = (int)((numpart + kBlock - 1) / kBlock);
+    k_conccalc<R><<<nb, kBlock, 0, stream>>>(V, Gp, P, numpart, itime, (R)weight);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int comm_init(const void *id, int nbytes, int nranks, int rank) override {
+    if (!id || nbytes != (int)sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks) return fail(FPX_ERR_ARG, "comm_init: bad argument");
+    if (comm) return fail(FPX_ERR_STATE, "comm_init: communicator exists");
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    HIPCHK(hipSetDevice(cfg.device));
+    ncclResult_t r = ncclCommInitRank(&comm, nranks, uid, rank);
+    if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
+    comm_ranks = nranks;
+    return 0;
+  }
+  int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) override {
+    if (!Gp.on) return fail(FPX_ERR_STATE, "get_grids: fpx_outgrid_init first");
+    if (allreduce && comm_ranks > 1) {
+      if (!comm) return fail(FPX_ERR_STATE, "get_grids: allreduce requested without fpx_comm_init");
+      // the one collective of the path (mpi_mod.f90:2471-2492): sum of the sampling grids
+      ncclResult_t r = ncclAllReduce(Gp.gridunc, Gp.gridunc, n_grid3, sizeof(R) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream);
+      if (r == ncclSuccess) r = ncclAllReduce(Gp.drygridunc, Gp.drygridunc, n_grid2, ncclFloat, ncclSum, comm, stream);
+      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    }
+    if (gridunc) {
+      if ((size_t)cfg.host_real_bytes == sizeof(R)) {
+        HIPCHK(hipMemcpyAsync(gridunc, Gp.gridunc, n_grid3 * sizeof(R), hipMemcpyDeviceToHost, stream));
+      } else {
+        int rc = ensure_staging(n_grid3 * cfg.host_real_bytes);
+        if (rc) return rc;
+        const int nb = (int)((n_grid3 + kBlock - 1) / kBlock);
+        k_convert<R><<<nb, kBlock, 0, stream>>>(Gp.gridunc, cfg.host_real_bytes == 8 ? (double *)staging : nullptr,
+                                                cfg.host_real_bytes == 4 ? (float *)staging : nullptr, (long long)n_grid3);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(gridunc, staging, n_grid3 * cfg.host_real_bytes, hipMemcpyDeviceToHost, stream));
+      }
+    }
+    if (drygridunc) HIPCHK(hipMemcpyAsync(drygridunc, Gp.drygridunc, n_grid2 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (clear) {
+      HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
+      HIPCHK(hipMemsetAsync(Gp.drygridunc, 0, n_grid2 * sizeof(float), stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
   void *stream_ptr() override { return (void *)stream; }
 };
 
@@ -1283,6 +1428,19 @@ int fpx_seed_particles(fpx_handle h, int64_t n, uint64_t seed, double frac_pbl, 
   FPX_GUARD(h);
   return h->impl->seed_particles(n, seed, frac_pbl, zmax, lat_margin_cells, itime0);
 }
+int fpx_outgrid_init(fpx_handle h, const fpx_outgrid *g, const void *outheight) { FPX_GUARD(h); return h->impl->outgrid_init(g, outheight); }
+int fpx_set_output_times(fpx_handle h, int32_t loutnext, int32_t loutstep) { FPX_GUARD(h); return h->impl->set_output_times(loutnext, loutstep); }
+int fpx_conccalc(fpx_handle h, int32_t itime, double weight) { FPX_GUARD(h); return h->impl->conccalc(itime, weight); }
+int fpx_get_grids(fpx_handle h, void *gridunc, void *drygridunc, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_grids(gridunc, drygridunc, allreduce, clear); }
+int fpx_comm_unique_id(void *id, int32_t nbytes) {
+  if (!id || nbytes != (int32_t)sizeof(ncclUniqueId)) return fpx::fail(FPX_ERR_ARG, "fpx_comm_unique_id: the id is 128 bytes");
+  ncclUniqueId uid;
+  ncclResult_t r = ncclGetUniqueId(&uid);
+  if (r != ncclSuccess) return fpx::fail(FPX_ERR_DEVICE, std::string("ncclGetUniqueId: ") + ncclGetErrorString(r));
+  memcpy(id, &uid, sizeof(uid));
+  return FPX_OK;
+}
+int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
 void *fpx_stream(fpx_handle h) { return (h && h->impl) ? h->impl->stream_ptr() : nullptr; }
 
 }  // extern "C"

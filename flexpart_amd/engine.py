@@ -14,8 +14,8 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FpxConfig, FpxFields, FpxParticles, FpxStepStats, RNG_PHILOX, RNG_TABLE_COUNTER,
-                   RNG_TABLE_SEQ, check)
+from ._lib import (FpxConfig, FpxFields, FpxOutgrid, FpxParticles, FpxStepStats, RNG_PHILOX,
+                   RNG_TABLE_COUNTER, RNG_TABLE_SEQ, check)
 
 # polar stereographic set-up is host work in the reference (gridcheck_ecmwf.f90:341-366 via
 # cmapf_mod stlmbr/stcm2p); the engine only consumes the resulting 9-number map records.
@@ -99,6 +99,9 @@ class Engine:
             self.upload_fields_from_scenario(sc)
         if n:
             self.upload_particles_from_scenario(sc)
+        self.gshape = None
+        if "outgrid" in sc:
+            self.outgrid_from_scenario(sc)
 
     # ---- met fields ---------------------------------------------------------
     def _host3(self, a, m):
@@ -184,6 +187,55 @@ class Engine:
         res = {k: (v.astype(np.float64) if v.dtype.kind == "f" else v.astype(np.int32)) for k, v in out.items()}
         return res
 
+    # ---- output grids ---------------------------------------------------------
+    def outgrid_from_scenario(self, sc):
+        """OUTGRID state as readoutgrid.f90 / outgrid_init.f90 leave it."""
+        rt = self.hreal
+        nxg, nyg, nzg = (int(v) for v in sc["outgrid"])
+        dxo, dyo, lon0, lat0 = (float(v) for v in sc["outgeom"])
+        g = FpxOutgrid()
+        g.struct_bytes = C.sizeof(FpxOutgrid)
+        g.numxgrid, g.numygrid, g.numzgrid = nxg, nyg, nzg
+        g.dxout, g.dyout = float(rt(dxo)), float(rt(dyo))
+        # xoutshift=xlon0-outlon0 in the host's real kind (readoutgrid.f90:199-200)
+        g.xoutshift = float(rt(self.cfg.xlon0) - rt(lon0))
+        g.youtshift = float(rt(self.cfg.ylat0) - rt(lat0))
+        g.maxpointspec_act, g.nclassunc = 1, 1
+        lage = np.asarray(sc["lage"]).ravel()
+        g.nageclass = len(lage)
+        for i, v in enumerate(lage):
+            g.lage[i] = int(v)
+        g.ind_samp, g.ioutputforeachrelease = (int(v) for v in sc["concflags"])
+        g.lusekerneloutput = 1
+        oh = np.ascontiguousarray(np.asarray(sc["outheight"]).astype(rt))
+        check(self.lib.fpx_outgrid_init(self.h, C.byref(g), _vp(oh)), "fpx_outgrid_init")
+        if "outtimes" in sc:
+            check(self.lib.fpx_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1])),
+                  "fpx_set_output_times")
+        self.gshape = (len(lage), 1, 1, self.nspec, nzg, nyg, nxg)
+
+    def conccalc(self, itime=None, weight=1.0):
+        check(self.lib.fpx_conccalc(self.h, int(self.itime if itime is None else itime), float(weight)),
+              "fpx_conccalc")
+
+    def grids(self, allreduce=False, clear=False):
+        """-> (gridunc, drygridunc) as float64 arrays shaped (age, class, pointspec, spec, z, y, x) /
+        (age, class, pointspec, spec, y, x)."""
+        na, nc, mp, nsp, nzg, nyg, nxg = self.gshape
+        g = np.empty((na, nc, mp, nsp, nzg, nyg, nxg), self.hreal)
+        d = np.empty((na, nc, mp, nsp, nyg, nxg), np.float32)
+        check(self.lib.fpx_get_grids(self.h, _vp(g), _vp(d), int(allreduce), int(clear)), "fpx_get_grids")
+        return g.astype(np.float64), d.astype(np.float64)
+
+    def comm_unique_id(self):
+        buf = (C.c_char * 128)()
+        check(self.lib.fpx_comm_unique_id(buf, 128), "fpx_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, uid, nranks, rank):
+        buf = (C.c_char * 128).from_buffer_copy(uid)
+        check(self.lib.fpx_comm_init(self.h, buf, 128, int(nranks), int(rank)), "fpx_comm_init")
+
     # ---- the loop body --------------------------------------------------------
     def step(self, itime=None):
         """One pass of the particle loop at `itime` (default: the engine's clock)."""
@@ -226,6 +278,8 @@ class Engine:
         out = []
         for _ in range(int(self.sc["nsteps"]) if nsteps is None else nsteps):
             self.step()
+            if self.gshape is not None:
+                self.conccalc(self.itime, 1.0)     # sample at the new positions (conccalc.f90)
             out.append(self.download())
         return out
 

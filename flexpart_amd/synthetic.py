@@ -311,3 +311,32 @@ def small(n=2000, nx=40, ny=24, nz=30, **kw):
     sc.update(make_particles(n, nx, ny, sc["height"], sc["hmix"], seed=seed, frac_pbl=frac_pbl,
                              zmax=zmax, nspec=int(sc["nspec"]), lat_margin_cells=lat_margin))
     return sc
+
+
+def add_outgrid(sc, nxg=36, nyg=18, nzg=5, *, outlon0=None, outlat0=None, dxout=None, dyout=None,
+                ind_samp=-1, old_fraction=0.5, age=20000):
+    """Output grid of the concentration sampling (OUTGRID namelist shape, readoutgrid.f90) plus
+    a share of particles released `age` seconds ago, so that both the direct-cell and the
+    4-cell-kernel branch of conccalc (conccalc.f90:171) are exercised."""
+    nx, ny, _ = (int(v) for v in sc["grid"])
+    dx, dy, xlon0, ylat0 = (float(v) for v in sc["geom"])
+    if outlon0 is None:
+        outlon0 = xlon0 + 0.05 * (nx - 1) * dx
+    if outlat0 is None:
+        outlat0 = ylat0 + 0.10 * (ny - 1) * dy
+    if dxout is None:
+        dxout = 0.9 * (nx - 1) * dx / nxg
+    if dyout is None:
+        dyout = 0.8 * (ny - 1) * dy / nyg
+    sc["outgrid"] = np.array([nxg, nyg, nzg], np.int32)
+    sc["outgeom"] = np.array([dxout, dyout, outlon0, outlat0], np.float64)
+    sc["outheight"] = np.array([100.0, 500.0, 1500.0, 5000.0, 20000.0][:nzg] if nzg <= 5
+                               else 100.0 * (np.arange(nzg) + 1.0) ** 2)
+    sc["concflags"] = np.array([ind_samp, 0], np.int32)
+    sc["outtimes"] = np.array([3600, 3600], np.int32)
+    n = int(sc["npart"])
+    old = _uniform01(n, 0xA6E) < old_fraction
+    itramem = np.asarray(sc["itramem"]).copy()
+    itramem[old] = int(sc["itime0"]) - int(age)
+    sc["itramem"] = itramem.astype(np.int32)
+    return sc

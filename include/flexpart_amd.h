@@ -192,6 +192,41 @@ int fpx_sort_particles(fpx_handle h);
 int fpx_seed_particles(fpx_handle h, int64_t n, uint64_t seed, double frac_pbl, double zmax,
                        double lat_margin_cells, int32_t itime0);
 
+/* ---- concentration sampling and deposition grids ---------------- */
+#define FPX_MAXAGECLASS 8
+typedef struct {
+  int32_t struct_bytes;
+  int32_t numxgrid, numygrid, numzgrid;        /* com_mod.f90:583                          */
+  double dxout, dyout, xoutshift, youtshift;   /* com_mod.f90:584; readoutgrid.f90:199-200 */
+  int32_t maxpointspec_act, nclassunc, nageclass;   /* com_mod.f90:188, par_mod.f90:188    */
+  int32_t lage[FPX_MAXAGECLASS];               /* com_mod.f90:129                          */
+  int32_t ind_samp, ioutputforeachrelease;     /* com_mod.f90:74-75                        */
+  int32_t lusekerneloutput;                    /* par_mod.f90:39                           */
+  int32_t reserved[5];
+} fpx_outgrid;
+
+/* Allocate and zero the device copies of gridunc (unc_mod.f90:16, extents as allocated in
+ * outgrid_init.f90:192: (0:numxgrid-1,0:numygrid-1,numzgrid,maxspec,maxpointspec_act,nclassunc,
+ * nageclass)) and drygridunc (unc_mod.f90:25, no level dimension, real(dep_prec) = 4 bytes in
+ * every build).  outheight(1:numzgrid): outg_mod.f90, host_real_bytes each. */
+int fpx_outgrid_init(fpx_handle h, const fpx_outgrid *g, const void *outheight);
+/* loutnext, loutstep (com_mod.f90:62): used for the decay correction of deposited mass,
+ * timemanager.f90:513-517,654-655 */
+int fpx_set_output_times(fpx_handle h, int32_t loutnext, int32_t loutstep);
+/* conccalc(itime, weight), conccalc.f90:50-295: scatter-add of every particle with
+ * itra1 == itime into the device gridunc.  Dry-deposited mass is accumulated into drygridunc by
+ * fpx_step itself (drydepokernel.f90:41-116, called at timemanager.f90:690-696). */
+int fpx_conccalc(fpx_handle h, int32_t itime, double weight);
+/* Copy the grids to the host (gridunc: host_real_bytes per value, drygridunc: 4 bytes; either
+ * may be NULL).  allreduce != 0: sum over all ranks of the communicator first (the
+ * MPI_Reduce of mpi_mod.f90:2471-2492, as one RCCL all-reduce over xGMI).  clear != 0: zero the
+ * device grids afterwards (concoutput does this after writing, concoutput.f90). */
+int fpx_get_grids(fpx_handle h, void *gridunc, void *drygridunc, int32_t allreduce, int32_t clear);
+/* RCCL communicator for the grid reduction: rank 0 obtains an id (128 bytes), the host
+ * distributes it (MPI_Bcast / torch.distributed / a file), every rank calls fpx_comm_init. */
+int fpx_comm_unique_id(void *id, int32_t nbytes);
+int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank);
+
 /* raw stream handle (hipStream_t) for callers that enqueue their own work */
 void *fpx_stream(fpx_handle h);
 

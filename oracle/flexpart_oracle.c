@@ -29,6 +29,7 @@
 #define ORC_REAL double
 #endif
 typedef ORC_REAL real;
+typedef float dep_real;   /* par_mod.f90:33 dep_prec = sp: deposition grids stay 4-byte in every build */
 #define K(x) ((real)(x))
 
 #define ORC_MAXSPEC 5
@@ -108,6 +109,15 @@ typedef struct {
      are replaced by the particle's own values -- what an order-independent (parallel)
      engine computes; see DESIGN.md "deviations" D1/D2. */
   int parallel_semantics;
+  /* ---- output grid (com_mod.f90:583-586, outg_mod outheight, unc_mod gridunc/drygridunc) */
+  int numxgrid, numygrid, numzgrid, maxpointspec_act, nclassunc, nageclass, maxspec_out;
+  int lage[8];
+  real dxout, dyout, xoutshift, youtshift;
+  real outheight[ORC_NZMAX];
+  int ind_samp, ioutputforeachrelease, lusekerneloutput;
+  int loutnext, loutstep;
+  real *gridunc;
+  dep_real *drygridunc;
 } orc_ctx;
 
 #define F3(f, i, j, k, m) ((f)[(((size_t)((m) - 1) * c->nz + (size_t)((k) - 1)) * c->ny + (size_t)(j)) * c->nx + (size_t)(i)])
@@ -1317,6 +1327,141 @@ L99:
 }
 
 /* ------------------------------------------------------------------------- */
+/* grid sampling: conccalc.f90:50-295 (mother output grid), drydepokernel.f90   */
+/* ------------------------------------------------------------------------- */
+#define GIDX(ix, jy, kz, ks, kp, nc, na) ((size_t)(ix) + (size_t)c->numxgrid * ((size_t)(jy) + (size_t)c->numygrid * ((size_t)((kz) - 1) + (size_t)c->numzgrid * ((size_t)((ks) - 1) + (size_t)c->maxspec_out * ((size_t)((kp) - 1) + (size_t)c->maxpointspec_act * ((size_t)((nc) - 1) + (size_t)c->nclassunc * (size_t)((na) - 1)))))))
+#define DIDX(ix, jy, ks, kp, nc, na) ((size_t)(ix) + (size_t)c->numxgrid * ((size_t)(jy) + (size_t)c->numygrid * ((size_t)((ks) - 1) + (size_t)c->maxspec_out * ((size_t)((kp) - 1) + (size_t)c->maxpointspec_act * ((size_t)((nc) - 1) + (size_t)c->nclassunc * (size_t)((na) - 1))))))
+
+static int orc_ageclass(orc_ctx *c, int itage) {   /* conccalc.f90:54-58, timemanager.f90:545-548 */
+  int nage;
+  for (nage = 1; nage <= c->nageclass; nage++)
+    if (itage < c->lage[nage - 1]) break;
+  return nage;   /* nageclass+1 when older than every class, exactly as the Fortran loop leaves it */
+}
+
+/* conccalc.f90:50-295 */
+void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const double *xtra1, const double *ytra1,
+                  const real *ztra1, const int *itra1, const int *itramem, const int *npoint, const int *nclass,
+                  const real *xmass1) {
+  const real weight = (real)weight_d;
+  int i, ks;
+  for (i = 0; i < npart; i++) {
+    int itage, nage, ix, jy, ixp, jyp, kz, nrelpointer, il, ind, indz = 1, indzp = 2;
+    real rhoi = K(1.), xl, yl, ddx, ddy, wx, wy, w;
+    if (itra1[i] != itime) continue;
+    itage = abs(itra1[i] - itramem[i]);
+    nage = orc_ageclass(c, itage);
+    if (c->ind_samp == -1) {   /* :80-122 */
+      real rddx, rddy, p1, p2, p3, p4, dz1, dz2, dz, rhoprof[2];
+      ix = (int)xtra1[i]; jy = (int)ytra1[i];
+      ixp = ix + 1; jyp = jy + 1;
+      ddx = (real)(xtra1[i] - (double)(real)ix);
+      ddy = (real)(ytra1[i] - (double)(real)jy);
+      rddx = K(1.) - ddx; rddy = K(1.) - ddy;
+      p1 = rddx * rddy; p2 = ddx * rddy; p3 = rddx * ddy; p4 = ddx * ddy;
+      if (jyp >= c->ny) jyp = jyp - 1;
+      for (il = 2; il <= c->nz; il++)
+        if (HGT(il) > ztra1[i]) { indz = il - 1; indzp = il; break; }
+      dz1 = ztra1[i] - HGT(indz);
+      dz2 = HGT(indzp) - ztra1[i];
+      dz = K(1.) / (dz1 + dz2);
+      for (ind = indz; ind <= indzp; ind++)   /* the literal slot 2 of :118-120 is kept */
+        rhoprof[ind - indz] = p1 * F3(c->rho, ix, jy, ind, c->memind[1]) + p2 * F3(c->rho, ixp, jy, ind, 2) +
+                              p3 * F3(c->rho, ix, jyp, ind, 2) + p4 * F3(c->rho, ixp, jyp, ind, 2);
+      rhoi = (dz1 * rhoprof[1] + dz2 * rhoprof[0]) * dz;
+    }
+    nrelpointer = (c->ioutputforeachrelease == 0 || c->mdomainfill == 1) ? 1 : npoint[i];
+    for (kz = 1; kz <= c->numzgrid; kz++)
+      if (c->outheight[kz - 1] > ztra1[i]) break;
+    if (kz > c->numzgrid) continue;
+    xl = (real)((xtra1[i] * (double)c->dx + (double)c->xoutshift) / (double)c->dxout);
+    yl = (real)((ytra1[i] * (double)c->dy + (double)c->youtshift) / (double)c->dyout);
+    ix = (int)xl; if (xl < K(0.)) ix = ix - 1;
+    jy = (int)yl; if (yl < K(0.)) jy = jy - 1;
+    if (!c->lusekerneloutput || itage < 10800 || xl < K(0.5) || yl < K(0.5) ||
+        xl > (real)(c->numxgrid - 1) - K(0.5) || yl > (real)(c->numygrid - 1) - K(0.5)) {
+      if (ix >= 0 && jy >= 0 && ix <= c->numxgrid - 1 && jy <= c->numygrid - 1)
+        for (ks = 1; ks <= c->nspec; ks++)
+          c->gridunc[GIDX(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight;
+    } else {
+      ddx = xl - (real)ix;
+      ddy = yl - (real)jy;
+      if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+      if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+      if (ix >= 0 && ix <= c->numxgrid - 1) {
+        if (jy >= 0 && jy <= c->numygrid - 1) {
+          w = wx * wy;
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+        }
+        if (jyp >= 0 && jyp <= c->numygrid - 1) {
+          w = wx * (K(1.) - wy);
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ix, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+        }
+      }
+      if (ixp >= 0 && ixp <= c->numxgrid - 1) {
+        if (jyp >= 0 && jyp <= c->numygrid - 1) {
+          w = (K(1.) - wx) * (K(1.) - wy);
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ixp, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+        }
+        if (jy >= 0 && jy <= c->numygrid - 1) {
+          w = (K(1.) - wx) * wy;
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ixp, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+        }
+      }
+    }
+  }
+}
+
+/* drydepokernel.f90:41-116 */
+static void orc_drydepokernel(orc_ctx *c, int nunc, const dep_real *deposit, real x, real y, int nage, int kp) {
+  real xl, yl, ddx, ddy, wx, wy, w;
+  int ix, jy, ixp, jyp, ks;
+  xl = (x * c->dx + c->xoutshift) / c->dxout;
+  yl = (y * c->dy + c->youtshift) / c->dyout;
+  ix = (int)xl;
+  jy = (int)yl;
+  ddx = xl - (real)ix;
+  ddy = yl - (real)jy;
+  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+  for (ks = 1; ks <= c->nspec; ks++) {
+    if (!(fabsf(deposit[ks - 1]) > 0 && c->drydepspec[ks - 1])) continue;
+    if (!c->lusekerneloutput) {
+      if (ix >= 0 && jy >= 0 && ix <= c->numxgrid - 1 && jy <= c->numygrid - 1) c->drygridunc[DIDX(ix, jy, ks, kp, nunc, nage)] = (dep_real)(c->drygridunc[DIDX(ix, jy, ks, kp, nunc, nage)] + deposit[ks - 1]);
+      continue;
+    }
+    if (ix >= 0 && jy >= 0 && ix <= c->numxgrid - 1 && jy <= c->numygrid - 1) { w = wx * wy; c->drygridunc[DIDX(ix, jy, ks, kp, nunc, nage)] = (dep_real)((real)c->drygridunc[DIDX(ix, jy, ks, kp, nunc, nage)] + (real)deposit[ks - 1] * w); }
+    if (ixp >= 0 && jyp >= 0 && ixp <= c->numxgrid - 1 && jyp <= c->numygrid - 1) { w = (K(1.) - wx) * (K(1.) - wy); c->drygridunc[DIDX(ixp, jyp, ks, kp, nunc, nage)] = (dep_real)((real)c->drygridunc[DIDX(ixp, jyp, ks, kp, nunc, nage)] + (real)deposit[ks - 1] * w); }
+    if (ixp >= 0 && jy >= 0 && ixp <= c->numxgrid - 1 && jy <= c->numygrid - 1) { w = (K(1.) - wx) * wy; c->drygridunc[DIDX(ixp, jy, ks, kp, nunc, nage)] = (dep_real)((real)c->drygridunc[DIDX(ixp, jy, ks, kp, nunc, nage)] + (real)deposit[ks - 1] * w); }
+    if (ix >= 0 && jyp >= 0 && ix <= c->numxgrid - 1 && jyp <= c->numygrid - 1) { w = wx * (K(1.) - wy); c->drygridunc[DIDX(ix, jyp, ks, kp, nunc, nage)] = (dep_real)((real)c->drygridunc[DIDX(ix, jyp, ks, kp, nunc, nage)] + (real)deposit[ks - 1] * w); }
+  }
+}
+
+void orc_set_outgrid(orc_ctx *c, int numxgrid, int numygrid, int numzgrid, double dxout, double dyout, double outlon0,
+                     double outlat0, const double *outheight, int maxpointspec_act, int nclassunc, int nageclass,
+                     const int *lage, int ind_samp, int ioutputforeachrelease, int lusekerneloutput, int maxspec_out) {
+  int k;
+  size_t n2, n3;
+  c->numxgrid = numxgrid; c->numygrid = numygrid; c->numzgrid = numzgrid;
+  c->dxout = (real)dxout; c->dyout = (real)dyout;
+  c->xoutshift = c->xlon0 - (real)outlon0;   /* readoutgrid.f90:199-200 */
+  c->youtshift = c->ylat0 - (real)outlat0;
+  for (k = 0; k < numzgrid; k++) c->outheight[k] = (real)outheight[k];
+  c->maxpointspec_act = maxpointspec_act; c->nclassunc = nclassunc; c->nageclass = nageclass;
+  for (k = 0; k < nageclass && k < 8; k++) c->lage[k] = lage[k];
+  c->ind_samp = ind_samp; c->ioutputforeachrelease = ioutputforeachrelease; c->lusekerneloutput = lusekerneloutput;
+  c->maxspec_out = maxspec_out;
+  n2 = (size_t)numxgrid * numygrid * maxspec_out * maxpointspec_act * nclassunc * nageclass;
+  n3 = n2 * numzgrid;
+  free(c->gridunc); free(c->drygridunc);
+  c->gridunc = (real *)calloc(n3, sizeof(real));
+  c->drygridunc = (dep_real *)calloc(n2, sizeof(dep_real));
+}
+void orc_set_output_times(orc_ctx *c, int loutnext, int loutstep) { c->loutnext = loutnext; c->loutstep = loutstep; }
+const real *orc_gridunc(orc_ctx *c) { return c->gridunc; }
+const dep_real *orc_drygridunc(orc_ctx *c) { return c->drygridunc; }
+
+/* ------------------------------------------------------------------------- */
 /* public C entry points (ctypes)                                              */
 /* ------------------------------------------------------------------------- */
 orc_ctx *orc_create(void) {
@@ -1433,7 +1578,7 @@ void orc_set_fields(orc_ctx *c, const real *uu, const real *vv, const real *ww, 
 long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, real *ztra1,
               real *uap, real *ucp, real *uzp, real *us, real *vs, real *ws,
               int *idt, int *itra1, const int *itramem, const int *npoint, int16_t *cbt,
-              real *xmass1, real *prob_out) {
+              real *xmass1, real *prob_out, const int *nclass_arr) {
   const real minmass = K(0.0001);
   long nadv = 0;
   int j, ks, nstop;
@@ -1452,19 +1597,32 @@ long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, re
       itra1[j] = -999999999;
     } else {
       real xmassfract = K(0.), decfact;
+      dep_real drydeposit[ORC_MAXSPEC];
+      /* age class and release pointer taken at the start of the step, timemanager.f90:539-548 */
+      const int nage = orc_ageclass(c, abs(itime - itramem[j]));
+      const int kp = (c->ioutputforeachrelease == 1 && npoint) ? npoint[j] : 1;
+      /* timemanager.f90:513-517 */
+      const int ldeltat = itime < c->loutnext ? itime - (c->loutnext - c->loutstep) : itime - c->loutnext;
       itra1[j] = itime + c->lsynctime;
       for (ks = 0; ks < c->nspec; ks++) {
         if (c->decay[ks] > K(0.)) decfact = r_exp(-(real)abs(c->lsynctime) * c->decay[ks]);
         else decfact = K(1.);
+        drydeposit[ks] = 0.f;
         if (xmass1) {
-          if (c->drydepspec[ks]) xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * (K(1.) - prob[ks]) * decfact;
-          else xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * decfact;
+          if (c->drydepspec[ks]) {
+            drydeposit[ks] = (dep_real)(xmass1[(size_t)ks * npart + j] * prob[ks] * decfact);
+            xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * (K(1.) - prob[ks]) * decfact;
+            if (c->decay[ks] > K(0.)) drydeposit[ks] = (dep_real)((real)drydeposit[ks] * r_exp((real)abs(ldeltat) * c->decay[ks]));
+          } else xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * decfact;
           if (c->mdomainfill == 0) {
             if (c->xmass_rel[ks] > K(0.)) xmassfract = r_max(xmassfract, (real)c->npart_rel * xmass1[(size_t)ks * npart + j] / c->xmass_rel[ks]);
           } else xmassfract = K(1.0);
         } else xmassfract = K(1.0);
       }
       if (xmassfract < minmass) itra1[j] = -999999999;
+      /* timemanager.f90:690-696 (forward runs only) */
+      if (c->drydep && c->ldirect == 1 && c->drygridunc && xmass1)
+        orc_drydepokernel(c, nclass_arr ? nclass_arr[j] : 1, drydeposit, (real)xtra1[j], (real)ytra1[j], nage, kp);
       if (abs(itra1[j] - itramem[j]) >= c->lage_last) itra1[j] = -999999999;
     }
   }

@@ -103,6 +103,30 @@ class Oracle:
         self.xmass1 = np.ascontiguousarray(np.asarray(sc["xmass1"]).astype(self.rt).reshape(nspec, n))
         self.prob = np.zeros((nspec, n), self.rt)
         self.itime = int(sc["itime0"])
+        self.nclass = opt("nclass", np.int32, 1)
+        self.has_grid = "outgrid" in sc
+        if self.has_grid:
+            nxg, nyg, nzg = (int(v) for v in sc["outgrid"])
+            dxo, dyo, lon0, lat0 = (float(v) for v in sc["outgeom"])
+            oh = _f64(sc["outheight"])
+            lage = np.ascontiguousarray(np.asarray(sc["lage"], dtype=np.int32).ravel())
+            ind_samp, iofr = (int(v) for v in sc["concflags"])
+            self.gshape = (1, 1, 1, nspec, nzg, nyg, nxg)   # (nage, nclassunc, maxpointspec, spec, z, y, x)
+            lib.orc_set_outgrid(self.h, nxg, nyg, nzg, C.c_double(dxo), C.c_double(dyo), C.c_double(lon0),
+                                C.c_double(lat0), oh.ctypes.data_as(dp), 1, 1, len(lage),
+                                lage.ctypes.data_as(C.POINTER(C.c_int)), ind_samp, iofr, 1, nspec)
+            if "outtimes" in sc:
+                lib.orc_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1]))
+
+    def grids(self):
+        """(gridunc, drygridunc) as float64 arrays shaped (spec, z, y, x) / (spec, y, x)."""
+        nage, ncu, mps, nsp, nzg, nyg, nxg = self.gshape
+        self.lib.orc_gridunc.restype = C.c_void_p
+        self.lib.orc_drygridunc.restype = C.c_void_p
+        ct = C.c_float if self.kind == "r4" else C.c_double
+        g = np.ctypeslib.as_array(C.cast(self.lib.orc_gridunc(self.h), C.POINTER(ct)), shape=(nsp * nzg * nyg * nxg,))
+        d = np.ctypeslib.as_array(C.cast(self.lib.orc_drygridunc(self.h), C.POINTER(C.c_float)), shape=(nsp * nyg * nxg,))
+        return (g.astype(np.float64).reshape(nsp, nzg, nyg, nxg), d.astype(np.float64).reshape(nsp, nyg, nxg))
 
     def polemaps(self):
         n = np.zeros(9); s = np.zeros(9)
@@ -120,8 +144,11 @@ class Oracle:
         nadv = self.lib.orc_step(self.h, self.itime, self.n, vp(self.x), vp(self.y), vp(self.z),
                                  vp(self.uap), vp(self.ucp), vp(self.uzp), vp(self.us), vp(self.vs),
                                  vp(self.ws), vp(self.idt), vp(self.itra1), vp(self.itramem),
-                                 vp(self.npoint), vp(self.cbt), vp(self.xmass1), vp(self.prob))
+                                 vp(self.npoint), vp(self.cbt), vp(self.xmass1), vp(self.prob), vp(self.nclass))
         self.itime += int(self.sc["lsynctime"])
+        if self.has_grid:   # sample at the new positions (conccalc.f90), weight 1
+            self.lib.orc_conccalc(self.h, self.itime, C.c_double(1.0), self.n, vp(self.x), vp(self.y), vp(self.z),
+                                  vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1))
         return nadv
 
     def state(self):

@@ -66,7 +66,8 @@ program flexref
   integer :: npart_in, gnx, gny, gnz, nstop, timing, do_conc, nage, kp
   integer :: ldeltat, loutnext_d, itage
   integer(kind=8) :: c0, c1, crate, nadv
-  real :: prob(maxspec), drydeposit(maxspec), decfact, xmassfract, weight
+  real :: prob(maxspec), decfact, xmassfract, weight
+  real(dep_prec) :: drydeposit(maxspec)      ! as timemanager.f90:104
   real :: sizenorth, sizesouth
   real(kind=8), allocatable :: tmp(:)
   logical :: have_pol, do_polar_setup
@@ -163,6 +164,17 @@ program flexref
       d_trop=dbuf(1); d_strat=dbuf(2); turbmesoscale=dbuf(3)
     case ('lage');     nageclass=n; lage(1:n)=ibuf(1:n)
     case ('nsteps');   nsteps=ibuf(1)
+    ! --- output grid (readoutgrid.f90 / outgrid_init.f90 state) ---------------------------
+    case ('outgrid')   ! numxgrid numygrid numzgrid
+      numxgrid=ibuf(1); numygrid=ibuf(2); numzgrid=ibuf(3); do_conc=1
+    case ('outgeom')   ! dxout dyout outlon0 outlat0
+      dxout=dbuf(1); dyout=dbuf(2); outlon0=dbuf(3); outlat0=dbuf(4)
+    case ('outheight')
+      allocate(outheight(n), outheighthalf(n)); outheight(1:n)=dbuf(1:n)
+    case ('concflags') ! ind_samp ioutputforeachrelease
+      ind_samp=ibuf(1); ioutputforeachrelease=ibuf(2)
+    case ('outtimes')  ! loutnext loutstep
+      loutnext_d=ibuf(1); loutstep=ibuf(2)
     case ('itime0');   itime0=ibuf(1)
     ! --- 3-D fields: compact (nx,ny,nz,2), x fastest -------------------------
     case ('uu');     call fill3(uu, dbuf)
@@ -241,6 +253,17 @@ program flexref
     switchnorthg=(switchnorth-ylat0)/dy
   end if
 
+  if (do_conc .eq. 1) then
+    xoutshift=xlon0-outlon0          ! readoutgrid.f90:199-200
+    youtshift=ylat0-outlat0
+    maxpointspec_act=1
+    if (ioutputforeachrelease.eq.1) maxpointspec_act=numpoint
+    ! allocation as outgrid_init.f90:192-200
+    allocate(gridunc(0:numxgrid-1,0:numygrid-1,numzgrid,maxspec,maxpointspec_act,nclassunc,maxageclass))
+    allocate(drygridunc(0:numxgrid-1,0:numygrid-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
+    gridunc=0.; drygridunc=0.
+  end if
+
   open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')
   allocate(tmp(max(npart_in,maxrand)))
 
@@ -288,7 +311,11 @@ program flexref
   call system_clock(c0, crate)
   do istep=0,nsteps-1
     itime=itime0+istep*lsynctime
-    ldeltat=0
+    if (itime.lt.loutnext_d) then       ! timemanager.f90:513-517
+      ldeltat=itime-(loutnext_d-loutstep)
+    else
+      ldeltat=itime-loutnext_d
+    endif
     do j=1,numpart
       if (itra1(j).eq.itime) then
         kp=1
@@ -335,16 +362,22 @@ program flexref
             end if
           end do
           if (xmassfract.lt.minmass) itra1(j)=-999999999
+          if (DRYDEP.and.(ldirect.eq.1).and.(do_conc.eq.1)) &
+               call drydepokernel(nclass(j),drydeposit,real(xtra1(j)),real(ytra1(j)),nage,kp)
           if (abs(itra1(j)-itramem(j)).ge.lage(nageclass)) itra1(j)=-999999999
         endif
       endif
     end do
+    ! sample the particles at their new positions (conccalc.f90; the time manager does this at
+    ! the top of the next iteration, timemanager.f90:350-365)
+    if (do_conc .eq. 1) call conccalc(itime+lsynctime, 1.0)
     if (timing .eq. 0) call dump_state()
   end do
   call system_clock(c1)
 900 continue
   tsec = real(c1-c0,8)/real(crate,8)
 
+  if (do_conc .eq. 1 .and. use_gpu .eq. 0) call dump_grids()
   tmp(1)=tsec; tmp(2)=real(nadv,8); tmp(3)=real(nan_count,8); tmp(4)=real(nan_count2,8)
   call put_d('timing', tmp, 4)
   name='END'
@@ -389,6 +422,21 @@ contains
       end do
     end do
   end subroutine fill2
+
+  subroutine dump_grids()
+    real(kind=8), allocatable :: g(:)
+    integer :: ng
+    ng=size(gridunc)
+    allocate(g(ng))
+    g=reshape(real(gridunc,8), [ng])
+    call put_d('gridunc', g, ng)
+    deallocate(g)
+    ng=size(drygridunc)
+    allocate(g(ng))
+    g=reshape(real(drygridunc,8), [ng])
+    call put_d('drygridunc', g, ng)
+    deallocate(g)
+  end subroutine dump_grids
 
   subroutine dump_state()
     integer :: np, kk

@@ -19,6 +19,7 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
           "lsynctime", "method", "mintime", "ctl", "ifine", "turbswitch", "cblflag",
           "mdomainfill", "lsettling", "nspec", "drydep", "drydepspec", "density", "dquer",
           "vsetaver", "cunningham", "decay", "turbpar", "lage", "nsteps", "itime0",
+          "outgrid", "outgeom", "outheight", "concflags", "outtimes",
           "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol",
           "hmix", "ustar", "wstar", "oli", "tropopause", "vdep",
           "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
@@ -26,7 +27,7 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
 _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
         "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
         "drydep", "drydepspec", "lage", "nsteps", "itime0", "npart", "itra1", "itramem",
-        "npoint", "nclass", "idt", "cbt"}
+        "npoint", "nclass", "idt", "cbt", "outgrid", "concflags", "outtimes"}
 
 
 def write_scenario(path, sc):
@@ -92,7 +93,7 @@ def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=F
     out = {"steps": [], "stdout": res.stdout}
     cur = None
     for name, a in recs:
-        if name in ("rannumb", "northpolemap", "southpolemap", "derived", "timing"):
+        if name in ("rannumb", "northpolemap", "southpolemap", "derived", "timing", "gridunc", "drygridunc"):
             out[name] = a
             continue
         if name == "xtra1":
