@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=3, choices=(2, 3))
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4))
     ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: 1e8 cfg 3, 1e7 cfg 2)")
     ap.add_argument("--real", type=int, default=8, choices=(4, 8), help="compute real bytes")
     ap.add_argument("--rng", default="philox", choices=("philox", "table_counter"))
@@ -50,6 +50,15 @@ def build_scenario(cfg, nsteps):
     else:
         sc = syn.base_scenario(ctl=5.0, ifine=4, cblflag=1, nsteps=nsteps)
         frac_pbl = 0.5
+        if cfg == 4:
+            # config 4: + conccalc into a global 360x180x10 output grid every step, grids summed
+            # over the ranks with one RCCL all-reduce at the end of the timed region
+            sc["npart"] = 1
+            sc["itramem"] = np.zeros(1, np.int32)
+            sc["itime0"] = 0
+            syn.add_outgrid(sc, nxg=360, nyg=180, nzg=10, outlon0=-180.0, outlat0=-90.0, dxout=1.0, dyout=1.0,
+                            ind_samp=-1, old_fraction=0.0)
+            del sc["npart"], sc["itramem"]
     return sc, frac_pbl
 
 
@@ -107,6 +116,10 @@ def main():
     eng.seed_particles(nper, seed=0x5EED + 7919 * rank, frac_pbl=frac_pbl)
     if args.sort_interval > 0:
         eng.sort()          # a release normally arrives ordered; the synthetic cloud is random
+    if args.config == 4 and world > 1:
+        from flexpart_amd import sharding
+        uid = sharding.share_unique_id(dist, eng.comm_unique_id)
+        eng.comm_init(uid, world, rank)
     lsync = int(sc["lsynctime"])
     window = 10800
 
@@ -117,6 +130,8 @@ def main():
         w0 = (itime // window) * window
         eng.set_windtime((w0, w0 + window), (1, 2))
         eng.step_async(itime)
+        if args.config == 4:
+            eng.conccalc(itime + lsync, 1.0)
 
     for i in range(args.warmup):
         do_step(i)
@@ -129,6 +144,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         do_step(i)
+    if args.config == 4:
+        grid, _ = eng.grids(allreduce=world > 1)     # D2H of the (summed) grid: part of the job
     eng.sync()
     torch.cuda.synchronize()
     if dist:
@@ -171,6 +188,7 @@ def main():
                                 f"{nx}x{ny}x{nz} ECMWF-shaped fields, "
                                 + ("advance+interpol_wind only (all above PBL, turbulence off)" if args.config == 2
                                    else "Hanna turbulence + CBL (ctl=1/5, ifine=11), PBL sub-stepping")
+                                + (" + conccalc 360x180x10 every step + RCCL grid all-reduce" if args.config == 4 else "")
                                 + f", rng={args.rng}, lsynctime=900"),
                    "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
                    "sort_interval": args.sort_interval},

@@ -151,6 +151,12 @@ class Oracle:
                                   vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1))
         return nadv
 
+    def sample(self, weight=1.0):
+        """conccalc at the current time and positions."""
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        self.lib.orc_conccalc(self.h, self.itime, C.c_double(weight), self.n, vp(self.x), vp(self.y), vp(self.z),
+                              vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1))
+
     def state(self):
         return dict(xtra1=self.x.copy(), ytra1=self.y.copy(), ztra1=self.z.astype(np.float64),
                     uap=self.uap.astype(np.float64), ucp=self.ucp.astype(np.float64),

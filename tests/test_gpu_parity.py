@@ -260,3 +260,18 @@ def test_point_release_hits_few_cells(built):
     assert (og != 0).sum() <= 4
     assert np.abs(g[0, 0, 0] - og).max() <= 1e-12 * og.max()
     assert abs(g.sum() - 2.0) < 1e-9        # 2 samples x total mass 1
+
+
+def test_rccl_communicator_single_rank(built):
+    """fpx_comm_unique_id / fpx_comm_init / all-reduce path with a one-rank communicator (the
+    round driver exercises N = 2, 4, 8 on a full node)."""
+    from flexpart_amd.engine import Engine
+    sc = syn.add_outgrid(syn.small(n=500, nx=30, ny=20, nz=16, nsteps=1), nxg=12, nyg=8, nzg=3)
+    eng = Engine(sc)
+    eng.comm_init(eng.comm_unique_id(), 1, 0)
+    eng.run()
+    g1, _ = eng.grids(allreduce=True)
+    g2, _ = eng.grids(allreduce=False, clear=True)
+    g3, _ = eng.grids()
+    eng.close()
+    assert g1.sum() > 0 and np.array_equal(g1, g2) and g3.sum() == 0
