@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""gpurun_out/prof_<tag>/ -> profiles/<round>/<tag>_{kernel_stats.csv,pmc.json}.
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and WRITE_SIZE are
+in KiB and come from separate passes; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced
+reads, so it is doubled (our field gathers are 8-24 B per lane -- an uncalibrated width; the factor
+is applied as the guide prescribes and the raw counters are kept next to the corrected figure).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def per_kernel(path):
+    rows = list(csv.DictReader(open(path)))
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in rows:
+        agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return agg
+
+
+def main():
+    tag, rnd = sys.argv[1], sys.argv[2]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(root, "profiles", rnd)
+    os.makedirs(dst, exist_ok=True)
+    st = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+    shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "stats", "bench.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
+    out = {"note": __doc__.strip().splitlines()[2:], "kernels": {}}
+    sq = per_kernel(glob.glob(os.path.join(src, "sq", "*", "*counter_collection.csv"))[0])
+    fe = per_kernel(glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv"))[0])
+    wr = per_kernel(glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv"))[0])
+    for k in sq:
+        if "fpx::k_" not in k:
+            continue
+        short = k.split("(")[0].replace("void ", "")
+        d = {c: v[-1] for c, v in sq[k].items()}             # last launch = a timed step
+        e = {"launches_profiled": len(next(iter(sq[k].values()))), "sq_last_launch": d}
+        if d.get("SQ_ACTIVE_INST_VALU"):
+            e["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64)
+            e["valu_active_per_wave_cycle"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
+        f = fe.get(k, {}).get("FETCH_SIZE", [0])[-1]
+        w = wr.get(k, {}).get("WRITE_SIZE", [0])[-1]
+        e["FETCH_SIZE_KiB"] = f
+        e["WRITE_SIZE_KiB"] = w
+        e["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
+        out["kernels"][short] = e
+    json.dump(out, open(os.path.join(dst, f"{tag}_pmc.json"), "w"), indent=1)
+    print("wrote", dst, list(out["kernels"]))
+
+
+if __name__ == "__main__":
+    main()
