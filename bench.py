@@ -62,6 +62,25 @@ def build_scenario(cfg, nsteps):
     return sc, frac_pbl
 
 
+def measured_traffic(config, nper, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary
+    (profiles/r*/c<config>_<particles>_pmc.json, made by tools/collect_profile.sh +
+    tools/summarize_profile.py on the same command line); None if no matching profile."""
+    import glob
+    tag = f"c{config}_{nper:.0e}".replace("+", "")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{tag}_pmc.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for name, e in d["kernels"].items():
+            if kernel in name:
+                return e["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(args, sc, frac_pbl):
     """The reference itself (oracle/_ref, flang build of the unmodified Fortran) timed on this
     box's host cores on a bounded sample of the same workload; 1 core (the reference hot path
@@ -151,7 +170,8 @@ def main():
     if dist:
         dist.barrier()
     dt = time.perf_counter() - t0
-    kms, launches = eng.kernel_time(reset=True)
+    parts, launches = eng.kernel_times(reset=True)
+    kms = sum(parts)
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -176,8 +196,12 @@ def main():
     field_bytes = nfield3 * 2 * nx * ny * nz * rb
     b_state = (9 * rb + 14) + (9 * rb + 10) if rb == 8 else 112
     b_alg = b_state + field_bytes / nper
-    avg_ms = kms / max(launches, 1)
+    # dominant kernel: k_prep (stream/gather bound) for config 2, the Langevin kernel otherwise
+    dom = 0 if args.config == 2 else 1
+    dom_name = ("k_prep", "k_pbl_loop", "k_pbl_finish")[dom]
+    avg_ms = parts[dom] / max(launches, 1)
     achieved = b_alg * (nsteps_local / max(launches, 1)) / (avg_ms * 1e-3) / 1e9
+    traffic = measured_traffic(args.config, nper, dom_name)
     out = {
         "metric": "particle-steps/sec (whole node) + achieved HBM GB/s, 1e8 particles",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
@@ -193,8 +217,10 @@ def main():
                    "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
                    "sort_interval": args.sort_interval},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_advance", "avg_launch_ms": avg_ms, "launches": launches,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": dom_name, "avg_launch_ms": avg_ms, "launches": launches,
+                     "step_kernels_ms": {"k_prep": parts[0] / max(launches, 1), "k_pbl_loop": parts[1] / max(launches, 1),
+                                         "k_pbl_finish": parts[2] / max(launches, 1)},
                      "alg_bytes_per_particle_step": b_alg},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:

@@ -83,7 +83,7 @@ SYMBOLS = [
     "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_polar_maps", "fpx_set_height",
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
     "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart",
-    "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_sort_particles",
+    "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init",
 ]
@@ -123,6 +123,7 @@ def load():
     lib.fpx_sync.argtypes = [vp]
     lib.fpx_counters.argtypes = [vp, C.POINTER(FpxStepStats), C.c_int32]
     lib.fpx_kernel_time.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
+    lib.fpx_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]
     lib.fpx_sort_particles.argtypes = [vp]
     lib.fpx_seed_particles.argtypes = [vp, C.c_int64, C.c_uint64, C.c_double, C.c_double,
                                        C.c_double, C.c_int32]

@@ -587,7 +587,7 @@ struct EngineBase {
   virtual int step(int itime, fpx_step_stats *st, bool async) = 0;
   virtual int sync() = 0;
   virtual int counters(fpx_step_stats *out, int reset) = 0;
-  virtual int kernel_time(double *ms, long long *launches, int reset) = 0;
+  virtual int kernel_time(double *ms, long long *launches, int reset, double *parts) = 0;
   virtual int sort_particles() = 0;
   virtual int seed_particles(long long n, unsigned long long seed, double frac_pbl, double zmax, double lat_margin,
                              int itime0) = 0;
@@ -643,9 +643,10 @@ struct Engine : EngineBase {
   std::vector<float> h_dcas4, h_dcas14;
   std::vector<double> h_dcas8, h_dcas18;
   // timing
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  struct StepEvents { hipEvent_t e[4]; };   // before k_prep | before k_pbl_loop | after it | after k_pbl_finish
+  std::vector<StepEvents> ev_pool;
   size_t ev_used = 0;
-  double acc_ms = 0;
+  double acc_ms = 0, acc_part_ms[3] = {0, 0, 0};
   long long acc_launches = 0;
   unsigned int step_counter = 0;
 
@@ -758,7 +759,7 @@ struct Engine : EngineBase {
 
   ~Engine() override {
     if (stream) (void)hipStreamSynchronize(stream);
-    for (auto &e : ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    for (auto &e : ev_pool) for (int i = 0; i < 4; i++) (void)hipEventDestroy(e.e[i]);
     for (void *q : owned) (void)hipFree(q);
     if (staging) (void)hipFree(staging);
     if (d_sort_tmp) (void)hipFree(d_sort_tmp);
@@ -1074,10 +1075,9 @@ struct Engine : EngineBase {
       S.cbl_dcas = d_dcas4; S.cbl_dcas1 = d_dcas14; S.cbl_dcas_d = d_dcas8; S.cbl_dcas1_d = d_dcas18;
     }
     if (ev_used == ev_pool.size()) {
-      hipEvent_t a, b;
-      HIPCHK(hipEventCreate(&a));
-      HIPCHK(hipEventCreate(&b));
-      ev_pool.emplace_back(a, b);
+      StepEvents se;
+      for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&se.e[i]));
+      ev_pool.push_back(se);
     }
     auto &ev = ev_pool[ev_used++];
     const int nb = (int)((numpart + kBlock - 1) / kBlock);
@@ -1100,7 +1100,7 @@ struct Engine : EngineBase {
       }
     }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
-    HIPCHK(hipEventRecord(ev.first, stream));
+    HIPCHK(hipEventRecord(ev.e[0], stream));
     if (cfg.drydep) k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
     else k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
     {
@@ -1110,10 +1110,12 @@ struct Engine : EngineBase {
                              (size_t)numpart, stream));
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
+    HIPCHK(hipEventRecord(ev.e[1], stream));
     loop_kernel()<<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    HIPCHK(hipEventRecord(ev.e[2], stream));
     if (cfg.drydep) k_pbl_finish<R, true><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
     else k_pbl_finish<R, false><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-    HIPCHK(hipEventRecord(ev.second, stream));
+    HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
     step_counter++;
     if (async) return 0;
@@ -1123,7 +1125,7 @@ struct Engine : EngineBase {
     if (out) {
       fill_stats(out, hs, snap);
       float ms = 0;
-      HIPCHK(hipEventElapsedTime(&ms, ev.first, ev.second));
+      HIPCHK(hipEventElapsedTime(&ms, ev.e[0], ev.e[3]));
       out->kernel_ms = ms;
     }
     snap = hs;
@@ -1166,18 +1168,23 @@ struct Engine : EngineBase {
     return 0;
   }
 
-  int kernel_time(double *ms, long long *launches, int reset) override {
+  int kernel_time(double *ms, long long *launches, int reset, double *parts) override {
     HIPCHK(hipStreamSynchronize(stream));
     for (size_t i = 0; i < ev_used; i++) {
       float t = 0;
-      HIPCHK(hipEventElapsedTime(&t, ev_pool[i].first, ev_pool[i].second));
+      HIPCHK(hipEventElapsedTime(&t, ev_pool[i].e[0], ev_pool[i].e[3]));
       acc_ms += t;
+      for (int k = 0; k < 3; k++) {
+        HIPCHK(hipEventElapsedTime(&t, ev_pool[i].e[k], ev_pool[i].e[k + 1]));
+        acc_part_ms[k] += t;
+      }
       acc_launches++;
     }
     ev_used = 0;
     if (ms) *ms = acc_ms;
     if (launches) *launches = acc_launches;
-    if (reset) { acc_ms = 0; acc_launches = 0; }
+    if (parts) for (int k = 0; k < 3; k++) parts[k] = acc_part_ms[k];
+    if (reset) { acc_ms = 0; acc_launches = 0; acc_part_ms[0] = acc_part_ms[1] = acc_part_ms[2] = 0; }
     return 0;
   }
 
@@ -1419,7 +1426,15 @@ int fpx_counters(fpx_handle h, fpx_step_stats *st, int32_t reset) { FPX_GUARD(h)
 int fpx_kernel_time(fpx_handle h, double *ms, int64_t *launches, int32_t reset) {
   FPX_GUARD(h);
   long long l = 0;
-  int rc = h->impl->kernel_time(ms, &l, reset);
+  int rc = h->impl->kernel_time(ms, &l, reset, nullptr);
+  if (launches) *launches = l;
+  return rc;
+}
+int fpx_kernel_times(fpx_handle h, double ms[3], int64_t *launches, int32_t reset) {
+  FPX_GUARD(h);
+  long long l = 0;
+  double tot = 0;
+  int rc = h->impl->kernel_time(&tot, &l, reset, ms);
   if (launches) *launches = l;
   return rc;
 }

@@ -266,6 +266,13 @@ class Engine:
         check(self.lib.fpx_kernel_time(self.h, C.byref(ms), C.byref(ln), int(reset)), "fpx_kernel_time")
         return ms.value, ln.value
 
+    def kernel_times(self, reset=False):
+        """(k_prep, k_pbl_loop, k_pbl_finish) cumulative device ms and the number of steps."""
+        ms = (C.c_double * 3)()
+        ln = C.c_int64(0)
+        check(self.lib.fpx_kernel_times(self.h, ms, C.byref(ln), int(reset)), "fpx_kernel_times")
+        return list(ms), ln.value
+
     def sort(self):
         check(self.lib.fpx_sort_particles(self.h), "fpx_sort_particles")
 
