@@ -67,7 +67,7 @@ def measured_traffic(config, nper, kernel):
     (profiles/r*/c<config>_<particles>_pmc.json, made by tools/collect_profile.sh +
     tools/summarize_profile.py on the same command line); None if no matching profile."""
     import glob
-    tag = f"c{config}_{nper:.0e}".replace("+", "")
+    tag = f"c{config}_{nper:.0e}"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"{tag}_pmc.json")))
     if not files:
         return None

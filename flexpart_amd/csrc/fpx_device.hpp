@@ -865,10 +865,10 @@ FPX_DEV int boundary(const View<R> &V, const R *hgt, double &xt, double &yt, R &
 }
 
 // horizontal move by (du,dv) metres on grid `ngrid`: advance.f90:750-778 == :923-951
-template <typename R>
+template <typename R, bool POLAR = true>
 FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, R dv, R fac) {
   const R pi180 = FPX_PI_PAR / K(180.);
-  if (ngrid >= 0) {
+  if (!POLAR || ngrid >= 0) {
     R cosfact = (R)((double)V.dxconst / cos((yt * (double)V.dy + (double)V.ylat0) * (double)pi180));
     xt = xt + (double)(du * cosfact * fac);
     yt = yt + (double)(dv * V.dyconst * fac);
@@ -1404,7 +1404,8 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
 }
 
 // label 99 to the end: advance.f90:728-985.  Returns nstop (0 or 3).
-template <typename R, typename RNG>
+// POLAR = false compiles the stereographic-map branch out (grids without poles)
+template <typename R, typename RNG, bool POLAR = true>
 FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, PState<R> &P, AdvCtx<R> &A,
                        R usig, R vsig, R wsig) {
   const R eps = eps_domain<R>();
@@ -1429,7 +1430,7 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
     windalign(A.dxsave, A.dysave, A.dawsave, A.dcwsave, ux, vy);
     A.dxsave = A.dxsave + ux;
     A.dysave = A.dysave + vy;
-    move_xy(V, A.ngrid, P.xt, P.yt, A.dxsave, A.dysave, (R)V.ldirect);
+    move_xy<R, POLAR>(V, A.ngrid, P.xt, P.yt, A.dxsave, A.dysave, (R)V.ldirect);
   }
   if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) return 3;   // advance.f90:784-813
 
@@ -1455,7 +1456,7 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
   w = (w - A.w) / K(2.);
   P.zt = P.zt + w * (R)(P.ldt * V.ldirect);
   if (P.zt < K(0.)) P.zt = m_min(A.h - eps2, K(-1.) * P.zt);
-  move_xy(V, A.ngrid, P.xt, P.yt, u, v, (R)(P.ldt * V.ldirect));
+  move_xy<R, POLAR>(V, A.ngrid, P.xt, P.yt, u, v, (R)(P.ldt * V.ldirect));
   if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) return 3;   // advance.f90:956-985
   return 0;
 }

@@ -310,7 +310,8 @@ struct PblRec {
   int *nrand, *itimec, *status;   // status = rc | indz << 2
 };
 
-template <typename R, bool DRYDEP>
+// INIT: the launch may contain newly released particles (initialize()); POLAR: the grid has polar caps
+template <typename R, bool DRYDEP, bool INIT, bool POLAR>
 __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag) {
   __shared__ R hgt[kMaxNz];
@@ -337,7 +338,7 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, GridP<R> Gp, Parts<R
 
   Rng<R> G;
   make_rng(V, pid, step, G);
-  const bool is_new = (itramem == itime) || (itime == 0);   // timemanager.f90:553
+  const bool is_new = INIT && ((itramem == itime) || (itime == 0));   // timemanager.f90:553
   if (is_new) {
     int nrand_i;
     R dcas = (R)0, dcas1 = (R)0;
@@ -382,7 +383,7 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, GridP<R> Gp, Parts<R
   }
   R usig, vsig, wsig;
   above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
-  const int nstop = adv_finish(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+  const int nstop = adv_finish<R, Rng<R>, POLAR>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
   R prob[kMaxSpec];
 #pragma unroll
   for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
@@ -489,7 +490,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
 
 // completion of the PBL particles: label 700 if the particle left the PBL, sigmas for the
 // mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
-template <typename R, bool DRYDEP>
+template <typename R, bool DRYDEP, bool POLAR>
 __global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                        const unsigned int *__restrict__ pbl_list,
                                                        const unsigned int *__restrict__ pbl_count) {
@@ -527,7 +528,7 @@ __global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, GridP<R> Gp, P
       cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, (R)ps.xt, (R)ps.yt);
       level_pair_sigma(V, C, W, A.ngrid < 0 ? V.w3pol : V.w3, indz, usig, vsig, wsig);   // advance.f90:604-606
     }
-    const int nstop = adv_finish(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+    const int nstop = adv_finish<R, Rng<R>, POLAR>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
     R prob[kMaxSpec];
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (DRYDEP && ks < V.nspec) ? Q.prob[(size_t)ks * P.cap + s] : (R)0;
@@ -605,6 +606,7 @@ struct Engine : EngineBase {
   hipStream_t stream = nullptr;
   View<R> V;
   Parts<R> P;
+  bool maybe_new = true;   // particles may have been released since the last step
   bool height_set = false, window_set = false, table_set = false, slot_loaded[2] = {false, false};
   long long numpart = 0;
   // owned device memory
@@ -959,6 +961,7 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipStreamSynchronize(stream));
     numpart = std::max(numpart, first + count);
+    maybe_new = true;
     return 0;
   }
 
@@ -1003,6 +1006,7 @@ struct Engine : EngineBase {
     HIPCHK(hipStreamSynchronize(stream));
     slot_of_pid = nullptr;
     numpart = n;
+    maybe_new = true;
     return 0;
   }
 
@@ -1101,8 +1105,20 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
     HIPCHK(hipEventRecord(ev.e[0], stream));
-    if (cfg.drydep) k_prep<R, true><<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
-    else k_prep<R, false><<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
+    {
+      // specialised variants: dry deposition (aerosols), initialize() only when new particles can
+      // exist (after an upload/seed or at itime 0), polar maps only on grids with poles
+      const bool init = maybe_new || itime == 0;
+      const bool polar = cfg.nglobal || cfg.sglobal;
+      typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *);
+      prep_fn f;
+      if (cfg.drydep) f = init ? (polar ? k_prep<R, true, true, true> : k_prep<R, true, true, false>)
+                               : (polar ? k_prep<R, true, false, true> : k_prep<R, true, false, false>);
+      else f = init ? (polar ? k_prep<R, false, true, true> : k_prep<R, false, true, false>)
+                    : (polar ? k_prep<R, false, false, true> : k_prep<R, false, false, false>);
+      f<<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
+      maybe_new = false;
+    }
     {
       // ordered compaction of the flagged slots -> work list (length in d_pbl_ctr[0])
       size_t need = sel_tmp_bytes;
@@ -1113,8 +1129,16 @@ struct Engine : EngineBase {
     HIPCHK(hipEventRecord(ev.e[1], stream));
     loop_kernel()<<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
     HIPCHK(hipEventRecord(ev.e[2], stream));
-    if (cfg.drydep) k_pbl_finish<R, true><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-    else k_pbl_finish<R, false><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+    {
+      const bool polar = cfg.nglobal || cfg.sglobal;
+      if (cfg.drydep) {
+        if (polar) k_pbl_finish<R, true, true><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+        else k_pbl_finish<R, true, false><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+      } else {
+        if (polar) k_pbl_finish<R, false, true><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+        else k_pbl_finish<R, false, false><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+      }
+    }
     HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
     step_counter++;
