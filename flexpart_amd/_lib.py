@@ -72,6 +72,17 @@ class FpxOutgrid(C.Structure):
     ]
 
 
+class FpxWetConfig(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("wetdepspec", C.c_int32 * FPX_MAXSPEC)] + \
+               [(n, C.c_double * FPX_MAXSPEC) for n in ("weta_gas", "wetb_gas", "crain_aero", "csnow_aero",
+                                                         "ccn_aero", "in_aero", "henry")] + \
+               [("readclouds", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class FpxWetFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("lsprec", "convprec", "tcc", "ctwc", "tt", "clouds", "cloudsh")]
+
+
 class FpxStepStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("n_due", "n_initialized", "n_left_domain", "n_min_mass", "n_max_age",
@@ -85,7 +96,8 @@ SYMBOLS = [
     "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
-    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init",
+    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
+    "fpx_wetdepo", "fpx_get_wetgrid",
 ]
 
 _lib = None
@@ -133,6 +145,10 @@ def load():
     lib.fpx_get_grids.argtypes = [vp, vp, vp, C.c_int32, C.c_int32]
     lib.fpx_comm_unique_id.argtypes = [vp, C.c_int32]
     lib.fpx_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.fpx_wet_init.argtypes = [vp, C.POINTER(FpxWetConfig)]
+    lib.fpx_upload_wet_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxWetFields)]
+    lib.fpx_wetdepo.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.fpx_get_wetgrid.argtypes = [vp, vp, C.c_int32, C.c_int32]
     _lib = lib
     return lib
 

@@ -1477,6 +1477,7 @@ struct GridP {
   const R *outheight;                      // [numzgrid]
   R *gridunc;                              // (x, y, z, spec, pointspec, classunc, age), x fastest
   float *drygridunc;                       // (x, y, spec, pointspec, classunc, age): real(dep_prec)
+  float *wetgridunc;                       // same shape as drygridunc
 };
 
 template <typename R>
@@ -1600,6 +1601,130 @@ FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp, int nunc, fl
   if (okxp && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * (K(1.) - wy))));
   if (okxp && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * wy)));
   if (okx && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ix, (float)((R)deposit * (wx * (K(1.) - wy))));
+}
+
+// ---------------------------------------------------------------------------
+// wet deposition: wetdepo.f90, get_wetscav.f90, interpol_rain.f90, wetdepokernel.f90
+// ---------------------------------------------------------------------------
+template <typename R>
+struct WetP {
+  int wetdepspec[kMaxSpec], readclouds;
+  R weta_gas[kMaxSpec], wetb_gas[kMaxSpec], crain_aero[kMaxSpec], csnow_aero[kMaxSpec];
+  R ccn_aero[kMaxSpec], in_aero[kMaxSpec], henry[kMaxSpec];
+  const R *prec;             // [ny][nx][2 slots][3]   (lsprec, convprec, tcc)
+  const R *ctwc;             // [ny][nx][2 slots]
+  const R *ttw;              // [ny][nx][nz][2 slots]
+  const signed char *clouds; // [ny][nx][nz][2 slots]
+};
+
+FPX_DEV float m_log10(float x) { return log10f(x); }
+FPX_DEV double m_log10(double x) { return log10(x); }
+
+// get_wetscav.f90:78-314 (mother grid); returns wetscav, grfr = grfraction(1)
+template <typename R>
+FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int itime, int ltsample, double xtra1, double ytra1, R ztra1,
+                      int ks, R &grfr) {
+  const R lfr[5] = {K(0.5), K(0.65), K(0.8), K(0.9), K(0.95)};
+  const R cfr[5] = {K(0.4), K(0.55), K(0.7), K(0.8), K(0.9)};
+  const R bclr[6] = {K(274.35758), K(332839.59273), K(226656.57259), K(58005.91340), K(6588.38582), K(0.244984)};
+  const R bcls[6] = {K(22.7), K(0.0), K(0.0), K(1321.0), K(381.0), K(0.0)};
+  const R incloud_ratio = K(6.2), r_air = K(287.05);   // par_mod.f90:59,82
+  R wetscav = K(0.);
+  const int ix = (int)xtra1, jy = (int)ytra1;
+  const int interp_time = (int)lround((double)((R)itime - K(0.5) * (R)ltsample));
+  int slot = V.m2;   // n = memind(2) unless memtime(1) is nearer (get_wetscav.f90:114-116)
+  if (abs(V.memtime0 - interp_time) < abs(V.memtime1 - interp_time)) slot = V.m1;
+  // interpol_rain.f90:68-130 (no time interpolation: the nearer slot only)
+  R lsp, convp, cc;
+  {
+    R xt = (R)xtra1, yt = (R)ytra1;
+    if (xt >= (R)(V.nx - 1)) xt = (R)(V.nx - 1) - K(0.00001);
+    if (yt >= (R)(V.ny - 1)) yt = (R)(V.ny - 1) - K(0.00001);
+    const int ixr = (int)xt, jyr = (int)yt, ixp = ixr + 1, jyp = jyr + 1;
+    const R ddx = xt - (R)ixr, ddy = yt - (R)jyr, rddx = K(1.) - ddx, rddy = K(1.) - ddy;
+    const R p1 = rddx * rddy, p2 = ddx * rddy, p3 = rddx * ddy, p4 = ddx * ddy;
+    const R *a = Wp.prec + (((long long)jyr * V.nx + ixr) * 2 + slot) * 3, *b = Wp.prec + (((long long)jyr * V.nx + ixp) * 2 + slot) * 3;
+    const R *c = Wp.prec + (((long long)jyp * V.nx + ixr) * 2 + slot) * 3, *d = Wp.prec + (((long long)jyp * V.nx + ixp) * 2 + slot) * 3;
+    lsp = p1 * a[0] + p2 * b[0] + p3 * c[0] + p4 * d[0];
+    convp = p1 * a[1] + p2 * b[1] + p3 * c[1] + p4 * d[1];
+    cc = p1 * a[2] + p2 * b[2] + p3 * c[2] + p4 * d[2];
+  }
+  if (lsp < K(0.01) && convp < K(0.01)) return wetscav;
+  const int hz = find_level(hgt, V.nz, ztra1);
+  const long long cidx = (((long long)jy * V.nx + ix) * V.nz + (hz - 1)) * 2 + slot;
+  const int clouds_v = (int)Wp.clouds[cidx];
+  if (clouds_v <= 1) return wetscav;
+  int i, j;
+  if (lsp > K(20.)) i = 4; else if (lsp > K(8.)) i = 3; else if (lsp > K(3.)) i = 2; else if (lsp > K(1.)) i = 1; else i = 0;
+  if (convp > K(20.)) j = 4; else if (convp > K(8.)) j = 3; else if (convp > K(3.)) j = 2; else if (convp > K(1.)) j = 1; else j = 0;
+  const R lf = i == 4 ? lfr[4] : i == 3 ? lfr[3] : i == 2 ? lfr[2] : i == 1 ? lfr[1] : lfr[0];
+  const R cf = j == 4 ? cfr[4] : j == 3 ? cfr[3] : j == 2 ? cfr[2] : j == 1 ? cfr[1] : cfr[0];
+  grfr = m_max(K(0.05), cc * (lsp * lf + convp * cf) / (lsp + convp));
+  const R prec1 = (lsp + convp) / grfr;
+  const R act_temp = Wp.ttw[cidx];
+  if (clouds_v >= 4) {   // below cloud, get_wetscav.f90:206-246
+    if (V.dquer[ks] <= K(0.) && (Wp.weta_gas[ks] > K(0.) || Wp.wetb_gas[ks] > K(0.))) {
+      wetscav = Wp.weta_gas[ks] * m_pow(prec1, Wp.wetb_gas[ks]);
+    } else if (V.dquer[ks] > K(0.) && (Wp.crain_aero[ks] > K(0.) || Wp.csnow_aero[ks] > K(0.))) {
+      const R dquer_m = m_min(K(10.), V.dquer[ks]) / K(1000000.);
+      const R l10 = m_log10(dquer_m);
+      const R i4 = K(1.) / ((l10 * l10) * (l10 * l10)), i3 = K(1.) / (l10 * (l10 * l10)), i2 = K(1.) / (l10 * l10), i1 = K(1.) / l10;
+      if (act_temp >= K(273.) && Wp.crain_aero[ks] > K(0.))
+        wetscav = Wp.crain_aero[ks] * m_pow(K(10.), bclr[0] + (bclr[1] * i4) + (bclr[2] * i3) + (bclr[3] * i2) + (bclr[4] * i1) + bclr[5] * m_pow(prec1, K(0.5)));
+      else if (act_temp < K(273.) && Wp.csnow_aero[ks] > K(0.))
+        wetscav = Wp.csnow_aero[ks] * m_pow(K(10.), bcls[0] + (bcls[1] * i4) + (bcls[2] * i3) + (bcls[3] * i2) + (bcls[4] * i1) + bcls[5] * m_pow(prec1, K(0.5)));
+    }
+  }
+  if (clouds_v < 4) {   // in cloud, get_wetscav.f90:251-311
+    if ((Wp.ccn_aero[ks] > K(0.) || Wp.in_aero[ks] > K(0.)) || (Wp.henry[ks] > K(0.) && V.dquer[ks] <= K(0.))) {
+      R cl;
+      if (Wp.readclouds) cl = Wp.ctwc[((long long)jy * V.nx + ix) * 2 + slot] * (grfr / cc);
+      else cl = K(1E6) * K(2E-7) * m_pow(prec1, K(0.36));
+      R liq_frac, ice_frac;
+      if (act_temp <= K(253.)) { liq_frac = K(0); ice_frac = K(1); }
+      else if (act_temp >= K(273.)) { liq_frac = K(1); ice_frac = K(0); }
+      else {
+        const R t = (act_temp - K(273.)) / (K(273.) - K(253.));
+        ice_frac = t * t;
+        liq_frac = m_max(K(0.), K(1.) - ice_frac);
+      }
+      const R frac_act = liq_frac * Wp.ccn_aero[ks] + ice_frac * Wp.in_aero[ks];
+      R S_i;
+      if (V.dquer[ks] > K(0.)) S_i = frac_act / cl;
+      else {
+        const R cle = (K(1) - cl) / (Wp.henry[ks] * (r_air / K(3500.)) * act_temp) + cl;
+        S_i = K(1) / cle;
+      }
+      wetscav = incloud_ratio * S_i * (prec1 / K(3.6E6));
+    }
+  }
+  return wetscav;
+}
+
+// wetdepokernel.f90:38-108 for one species (deposit is a default real, the grid is dep_prec)
+template <typename R>
+FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp, int nunc, R deposit, int ks, R x, R y, int nage, int kp) {
+  const R xl = (x * V.dx + Gp.xoutshift) / Gp.dxout;
+  const R yl = (y * V.dy + Gp.youtshift) / Gp.dyout;
+  const int ix = (int)xl, jy = (int)yl;
+  const R ddx = xl - (R)ix, ddy = yl - (R)jy;
+  int ixp, jyp;
+  R wx, wy;
+  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+  const long long plane = (long long)Gp.numxgrid * Gp.numygrid;
+  float *g = Gp.wetgridunc + plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1))));
+  const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
+  const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
+  if (deposit == K(0.)) return;   // adding zero changes nothing
+  if (!Gp.lusekerneloutput) {
+    if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, (float)deposit);
+    return;
+  }
+  if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, (float)(deposit * (wx * wy)));
+  if (okxp && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * (K(1.) - wy))));
+  if (okxp && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * wy)));
+  if (okx && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ix, (float)(deposit * (wx * (K(1.) - wy))));
 }
 
 #undef K

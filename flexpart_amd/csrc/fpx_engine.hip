@@ -562,6 +562,40 @@ __global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V, GridP<R> Gp, Par
   conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight);
 }
 
+// wetdepo.f90:58-151: every live particle that is due or overdue
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V, GridP<R> Gp, WetP<R> Wp, Parts<R> P, long long numpart, int itime,
+                                                    int ltsample, int loutnext) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= numpart) return;
+  const int itra1 = P.itra1[s];
+  if (itra1 == kDead) return;
+  if (V.ldirect == 1) { if (itra1 > itime) return; } else { if (itra1 < itime) return; }
+  const double xt = P.xt[s], yt = P.yt[s];
+  const R zt = P.zt[s];
+  if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) return;
+  const int ldeltat = itime <= loutnext ? itime - (loutnext - Gp.loutstep) : itime - loutnext;   // wetdepo.f90:58-62
+  const int nage = ageclass(Gp, abs(itra1 - P.itramem[s]));
+  const int kp = Gp.ioutputforeachrelease == 1 ? P.npoint[s] : 1;
+  const int nunc = P.nclass[s];
+  const R smallnum = sizeof(R) == 4 ? (R)1.17549435e-38f : (R)2.2250738585072014e-308;
+  for (int ks = 0; ks < V.nspec; ks++) {
+    if (!Wp.wetdepspec[ks]) continue;
+    R grfr = (R)0;
+    const R wetscav = get_wetscav(V, Wp, hgt, itime, ltsample, xt, yt, zt, ks, grfr);
+    const R xm = P.xmass1[(size_t)ks * P.cap + s];
+    R wetdeposit = (R)0;
+    if (wetscav > (R)0) wetdeposit = xm * ((R)1 - m_exp(-wetscav * (R)abs(ltsample))) * grfr;
+    const R restmass = xm - wetdeposit;
+    P.xmass1[(size_t)ks * P.cap + s] = restmass > smallnum ? restmass : (R)0;
+    if (V.decay[ks] > (R)0) wetdeposit = wetdeposit * m_exp((R)abs(ldeltat) * V.decay[ks]);
+    if (V.ldirect == 1 && Gp.on) wetdepo_scatter(V, Gp, nunc, wetdeposit, ks, (R)xt, (R)yt, nage, kp);
+  }
+}
+
 template <typename T>
 __global__ void k_convert(const T *__restrict__ src, double *__restrict__ dst64, float *__restrict__ dst32, long long n) {
   long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -597,6 +631,10 @@ struct EngineBase {
   virtual int conccalc(int itime, double weight) = 0;
   virtual int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) = 0;
   virtual int comm_init(const void *id, int nbytes, int nranks, int rank) = 0;
+  virtual int wet_init(const fpx_wet_config *w) = 0;
+  virtual int upload_wet_fields(int slot, const fpx_wet_fields *f) = 0;
+  virtual int wetdepo(int itime, int ltsample, int loutnext) = 0;
+  virtual int get_wetgrid(void *wetgridunc, int allreduce, int clear) = 0;
   virtual void *stream_ptr() = 0;
 };
 
@@ -625,6 +663,8 @@ struct Engine : EngineBase {
   unsigned char *d_pbl_flag = nullptr;
   PblRec<R> Q;
   GridP<R> Gp;
+  WetP<R> Wp;
+  bool wet_on = false, wet_slot[2] = {false, false};
   size_t n_grid3 = 0, n_grid2 = 0;
   ncclComm_t comm = nullptr;
   int comm_ranks = 1;
@@ -1301,6 +1341,8 @@ struct Engine : EngineBase {
     Gp.outheight = oh;
     if ((rc = dalloc(&Gp.gridunc, n_grid3))) return rc;
     if ((rc = dalloc(&Gp.drygridunc, n_grid2))) return rc;
+    if ((rc = dalloc(&Gp.wetgridunc, n_grid2))) return rc;
+    HIPCHK(hipMemsetAsync(Gp.wetgridunc, 0, n_grid2 * sizeof(float), stream));
     HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
     HIPCHK(hipMemsetAsync(Gp.drygridunc, 0, n_grid2 * sizeof(float), stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -1358,6 +1400,80 @@ struct Engine : EngineBase {
       HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
       HIPCHK(hipMemsetAsync(Gp.drygridunc, 0, n_grid2 * sizeof(float), stream));
     }
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // ---- wet deposition -----------------------------------------------------------
+  int wet_init(const fpx_wet_config *w) override {
+    if (!w || w->struct_bytes != (int32_t)sizeof(fpx_wet_config)) return fail(FPX_ERR_ARG, "wet_init: null or fpx_wet_config size mismatch (ABI)");
+    if (wet_on) return fail(FPX_ERR_STATE, "wet_init: already initialised");
+    memset(&Wp, 0, sizeof(Wp));
+    for (int i = 0; i < FPX_MAXSPEC; i++) {
+      Wp.wetdepspec[i] = w->wetdepspec[i];
+      Wp.weta_gas[i] = (R)w->weta_gas[i]; Wp.wetb_gas[i] = (R)w->wetb_gas[i];
+      Wp.crain_aero[i] = (R)w->crain_aero[i]; Wp.csnow_aero[i] = (R)w->csnow_aero[i];
+      Wp.ccn_aero[i] = (R)std::max(w->ccn_aero[i], 0.0);   // get_wetscav.f90:257-258
+      Wp.in_aero[i] = (R)std::max(w->in_aero[i], 0.0);
+      Wp.henry[i] = (R)w->henry[i];
+    }
+    Wp.readclouds = w->readclouds;
+    const size_t ncol = (size_t)cfg.nx * cfg.ny, nlev = ncol * cfg.nz;
+    int rc;
+    R *p;
+    signed char *c8;
+    if ((rc = dalloc(&p, ncol * 6))) return rc; Wp.prec = p;
+    if ((rc = dalloc(&p, ncol * 2))) return rc; Wp.ctwc = p;
+    HIPCHK(hipMemsetAsync(p, 0, ncol * 2 * sizeof(R), stream));
+    if ((rc = dalloc(&p, nlev * 2))) return rc; Wp.ttw = p;
+    if ((rc = dalloc(&c8, nlev * 2))) return rc; Wp.clouds = c8;
+    HIPCHK(hipStreamSynchronize(stream));
+    wet_on = true;
+    return 0;
+  }
+  int upload_wet_fields(int slot, const fpx_wet_fields *f) override {
+    if (!wet_on) return fail(FPX_ERR_STATE, "upload_wet_fields: fpx_wet_init first");
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "upload_wet_fields: slot must be 1 or 2");
+    if (!f || !f->lsprec || !f->convprec || !f->tcc || !f->tt || !f->clouds) return fail(FPX_ERR_ARG, "upload_wet_fields: lsprec, convprec, tcc, tt, clouds are required");
+    if (Wp.readclouds && !f->ctwc) return fail(FPX_ERR_ARG, "upload_wet_fields: ctwc required with readclouds");
+    const int s = slot - 1;
+    int rc;
+    if ((rc = p2(f->lsprec, Wp.prec, 6, s * 3 + 0))) return rc;
+    if ((rc = p2(f->convprec, Wp.prec, 6, s * 3 + 1))) return rc;
+    if ((rc = p2(f->tcc, Wp.prec, 6, s * 3 + 2))) return rc;
+    if (f->ctwc && (rc = p2(f->ctwc, Wp.ctwc, 2, s))) return rc;
+    if ((rc = p3(f->tt, Wp.ttw, 2, s))) return rc;
+    {   // integer(1) cloud classes: same x<->z transpose, element type int8
+      const size_t n = (size_t)cfg.nxmax * cfg.nymax * cfg.nz;
+      if ((rc = ensure_staging(n))) return rc;
+      HIPCHK(hipMemcpyAsync(staging, f->clouds, n, hipMemcpyHostToDevice, stream));
+      dim3 grid((cfg.nx + 31) / 32, (cfg.nz + 31) / 32, cfg.ny), block(32, 8);
+      k_pack3<signed char, signed char><<<grid, block, 0, stream>>>((const signed char *)staging, (signed char *)Wp.clouds, cfg.nx, cfg.ny, cfg.nz,
+                                                                    cfg.nxmax, cfg.nymax, 2, s);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    wet_slot[s] = true;
+    return 0;
+  }
+  int wetdepo(int itime, int ltsample, int loutnext) override {
+    if (!wet_on || !wet_slot[0] || !wet_slot[1]) return fail(FPX_ERR_STATE, "wetdepo: fpx_wet_init and both slots of fpx_upload_wet_fields first");
+    if (!height_set || !window_set) return fail(FPX_ERR_STATE, "wetdepo: height / wind-time window not set");
+    if (numpart == 0) return 0;
+    const int nb = (int)((numpart + kBlock - 1) / kBlock);
+    k_wetdepo<R><<<nb, kBlock, 0, stream>>>(V, Gp, Wp, P, numpart, itime, ltsample, loutnext);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int get_wetgrid(void *wetgridunc, int allreduce, int clear) override {
+    if (!Gp.on) return fail(FPX_ERR_STATE, "get_wetgrid: fpx_outgrid_init first");
+    if (allreduce && comm_ranks > 1) {
+      if (!comm) return fail(FPX_ERR_STATE, "get_wetgrid: allreduce requested without fpx_comm_init");
+      ncclResult_t r = ncclAllReduce(Gp.wetgridunc, Gp.wetgridunc, n_grid2, ncclFloat, ncclSum, comm, stream);
+      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    }
+    if (wetgridunc) HIPCHK(hipMemcpyAsync(wetgridunc, Gp.wetgridunc, n_grid2 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (clear) HIPCHK(hipMemsetAsync(Gp.wetgridunc, 0, n_grid2 * sizeof(float), stream));
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
@@ -1480,6 +1596,10 @@ int fpx_comm_unique_id(void *id, int32_t nbytes) {
   return FPX_OK;
 }
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
+int fpx_wet_init(fpx_handle h, const fpx_wet_config *w) { FPX_GUARD(h); return h->impl->wet_init(w); }
+int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f) { FPX_GUARD(h); return h->impl->upload_wet_fields(slot, f); }
+int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext) { FPX_GUARD(h); return h->impl->wetdepo(itime, ltsample, loutnext); }
+int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_wetgrid(wetgridunc, allreduce, clear); }
 void *fpx_stream(fpx_handle h) { return (h && h->impl) ? h->impl->stream_ptr() : nullptr; }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FpxConfig, FpxFields, FpxOutgrid, FpxParticles, FpxStepStats, RNG_PHILOX,
+from ._lib import (FpxConfig, FpxFields, FpxOutgrid, FpxParticles, FpxStepStats, FpxWetConfig, FpxWetFields, RNG_PHILOX,
                    RNG_TABLE_COUNTER, RNG_TABLE_SEQ, check)
 
 # polar stereographic set-up is host work in the reference (gridcheck_ecmwf.f90:341-366 via
@@ -102,6 +102,9 @@ class Engine:
         self.gshape = None
         if "outgrid" in sc:
             self.outgrid_from_scenario(sc)
+        self.has_wet = bool(sc.get("wetdep", 0))
+        if self.has_wet:
+            self.wet_from_scenario(sc)
 
     # ---- met fields ---------------------------------------------------------
     def _host3(self, a, m):
@@ -214,6 +217,47 @@ class Engine:
                   "fpx_set_output_times")
         self.gshape = (len(lage), 1, 1, self.nspec, nzg, nyg, nxg)
 
+    def wet_from_scenario(self, sc):
+        """Wet-scavenging species parameters (readspecies.f90) + precipitation/cloud fields."""
+        w = FpxWetConfig()
+        w.struct_bytes = C.sizeof(FpxWetConfig)
+        for i in range(self.nspec):
+            w.wetdepspec[i] = int(np.asarray(sc["wetdepspec"]).ravel()[i])
+            for k in ("weta_gas", "wetb_gas", "crain_aero", "csnow_aero", "ccn_aero", "in_aero", "henry"):
+                getattr(w, k)[i] = float(np.asarray(sc[k]).ravel()[i])
+        w.readclouds = 0
+        check(self.lib.fpx_wet_init(self.h, C.byref(w)), "fpx_wet_init")
+        for m in (0, 1):
+            keep = {}
+            f = FpxWetFields()
+            for k in ("lsprec", "convprec", "tcc"):
+                keep[k] = self._host2(sc[k], m)
+                setattr(f, k, keep[k].ctypes.data)
+            keep["tt"] = self._host3(sc["tt"], m)
+            f.tt = keep["tt"].ctypes.data
+            c8 = np.zeros((self.nzmax, self.nymax, self.nxmax), np.int8)
+            c8[: self.nz, : self.ny, : self.nx] = np.asarray(sc["clouds"])[m]
+            keep["clouds"] = c8
+            f.clouds = c8.ctypes.data
+            ch = np.zeros((self.nymax, self.nxmax), np.int32)
+            ch[: self.ny, : self.nx] = np.asarray(sc["cloudsh"])[m]
+            keep["cloudsh"] = ch
+            f.cloudsh = ch.ctypes.data
+            check(self.lib.fpx_upload_wet_fields(self.h, m + 1, C.byref(f)), "fpx_upload_wet_fields")
+
+    def wetdepo(self, itime=None, ltsample=None, loutnext=None):
+        itime = self.itime if itime is None else itime
+        ltsample = self.lsynctime if ltsample is None else ltsample
+        if loutnext is None:
+            loutnext = int(self.sc["outtimes"][0]) if "outtimes" in self.sc else 0
+        check(self.lib.fpx_wetdepo(self.h, int(itime), int(ltsample), int(loutnext)), "fpx_wetdepo")
+
+    def wetgrid(self, allreduce=False, clear=False):
+        na, nc, mp, nsp, nzg, nyg, nxg = self.gshape
+        d = np.empty((na, nc, mp, nsp, nyg, nxg), np.float32)
+        check(self.lib.fpx_get_wetgrid(self.h, _vp(d), int(allreduce), int(clear)), "fpx_get_wetgrid")
+        return d.astype(np.float64)
+
     def conccalc(self, itime=None, weight=1.0):
         check(self.lib.fpx_conccalc(self.h, int(self.itime if itime is None else itime), float(weight)),
               "fpx_conccalc")
@@ -284,6 +328,8 @@ class Engine:
     def run(self, nsteps=None):
         out = []
         for _ in range(int(self.sc["nsteps"]) if nsteps is None else nsteps):
+            if self.has_wet and self.itime != 0:     # wetdepo first, timemanager.f90:164-169
+                self.wetdepo()
             self.step()
             if self.gshape is not None:
                 self.conccalc(self.itime, 1.0)     # sample at the new positions (conccalc.f90)

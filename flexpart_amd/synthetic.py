@@ -340,3 +340,43 @@ def add_outgrid(sc, nxg=36, nyg=18, nzg=5, *, outlon0=None, outlat0=None, dxout=
     itramem[old] = int(sc["itime0"]) - int(age)
     sc["itramem"] = itramem.astype(np.int32)
     return sc
+
+
+def add_wet(sc, *, gas=False):
+    """Precipitation / cloud fields and wet-scavenging species parameters (readspecies.f90 names).
+
+    clouds (int8 per level, verttransform's cloud classification): >= 4 below a precipitating
+    cloud, 2-3 inside it, 0-1 none (get_wetscav.f90:150,206,251).  gas=False: an aerosol
+    (dquer > 0, crain/csnow below cloud, ccn/in inside); gas=True: a soluble gas (weta/wetb,
+    henry)."""
+    nx, ny, nz = (int(v) for v in sc["grid"])
+    per = nx - 1
+    i = np.arange(nx, dtype=np.int64)[None, :]
+    j = np.arange(ny, dtype=np.int64)[:, None]
+    lsprec = np.empty((2, ny, nx)); convprec = np.empty((2, ny, nx)); tcc = np.empty((2, ny, nx))
+    clouds = np.zeros((2, nz, ny, nx), np.int32)
+    cloudsh = np.zeros((2, ny, nx), np.int32)
+    z = np.asarray(sc["height"])
+    for m in range(2):
+        sh = 7 * m
+        lsprec[m] = 12.0 * np.maximum(0.0, _wave(2 * (i + sh) + j, per)) ** 2
+        convprec[m] = 6.0 * np.maximum(0.0, _wave(3 * (i + sh) + 2 * j, per))
+        tcc[m] = 0.15 + 0.8 * np.abs(_wave(i + sh + 3 * j, per))
+        raining = (lsprec[m] + convprec[m]) > 0.01
+        for k in range(nz):
+            cls = 6 if z[k] < 1200.0 else (3 if z[k] < 5000.0 else 0)
+            clouds[m, k] = np.where(raining, cls, 0)
+        cloudsh[m] = np.where(raining, 3800, 0)
+    sc.update(lsprec=lsprec, convprec=convprec, tcc=tcc, clouds=clouds, cloudsh=cloudsh, wetdep=1,
+              wetdepspec=np.array([1], np.int32))
+    if gas:
+        sc.update(weta_gas=np.array([2.0e-5]), wetb_gas=np.array([0.62]), crain_aero=np.array([0.0]),
+                  csnow_aero=np.array([0.0]), ccn_aero=np.array([0.0]), in_aero=np.array([0.0]),
+                  henry=np.array([1.0e5]))
+    else:
+        sc.update(weta_gas=np.array([0.0]), wetb_gas=np.array([0.0]), crain_aero=np.array([1.0]),
+                  csnow_aero=np.array([1.0]), ccn_aero=np.array([0.9]), in_aero=np.array([0.1]),
+                  henry=np.array([0.0]))
+        if float(np.asarray(sc["dquer"])[0]) <= 0.0:
+            sc["dquer"] = np.array([8.0])
+    return sc

@@ -230,6 +230,34 @@ int fpx_get_grids(fpx_handle h, void *gridunc, void *drygridunc, int32_t allredu
 int fpx_comm_unique_id(void *id, int32_t nbytes);
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank);
 
+/* ---- wet deposition ------------------------------------------------- */
+typedef struct {
+  int32_t struct_bytes;
+  int32_t wetdepspec[FPX_MAXSPEC];                       /* com_mod.f90:589 WETDEPSPEC   */
+  double weta_gas[FPX_MAXSPEC], wetb_gas[FPX_MAXSPEC];   /* com_mod.f90:171              */
+  double crain_aero[FPX_MAXSPEC], csnow_aero[FPX_MAXSPEC];   /* :172                     */
+  double ccn_aero[FPX_MAXSPEC], in_aero[FPX_MAXSPEC];    /* :174                         */
+  double henry[FPX_MAXSPEC];                             /* :175                         */
+  int32_t readclouds;                                    /* :139                         */
+  int32_t reserved[7];
+} fpx_wet_config;
+/* one time slot of the precipitation / cloud fields: lsprec, convprec, tcc (com_mod.f90:413-419),
+ * ctwc (:384, only with readclouds), tt (:360) as host reals with strides nxmax,nymax(,nzmax);
+ * clouds integer(1) (:379), cloudsh integer (:380) */
+typedef struct {
+  const void *lsprec, *convprec, *tcc, *ctwc, *tt;
+  const int8_t *clouds;
+  const int32_t *cloudsh;
+} fpx_wet_fields;
+int fpx_wet_init(fpx_handle h, const fpx_wet_config *w);     /* after fpx_outgrid_init */
+int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f);
+/* wetdepo(itime, ltsample, loutnext), wetdepo.f90:58-151 with get_wetscav.f90:78-314,
+ * interpol_rain.f90:68-130 and wetdepokernel.f90:38-108: the separate particle loop the time
+ * manager runs before getfields (timemanager.f90:164-169). */
+int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext);
+/* wetgridunc (unc_mod.f90:27, real(dep_prec) = 4 bytes), same conventions as fpx_get_grids */
+int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear);
+
 /* raw stream handle (hipStream_t) for callers that enqueue their own work */
 void *fpx_stream(fpx_handle h);
 

@@ -117,7 +117,15 @@ typedef struct {
   int ind_samp, ioutputforeachrelease, lusekerneloutput;
   int loutnext, loutstep;
   real *gridunc;
-  dep_real *drygridunc;
+  dep_real *drygridunc, *wetgridunc;
+  /* ---- wet deposition (com_mod.f90:139,171-175,379-384,413-419) */
+  int wetdepspec[ORC_MAXSPEC], readclouds;
+  real weta_gas[ORC_MAXSPEC], wetb_gas[ORC_MAXSPEC], crain_aero[ORC_MAXSPEC], csnow_aero[ORC_MAXSPEC];
+  real ccn_aero[ORC_MAXSPEC], in_aero[ORC_MAXSPEC], henry[ORC_MAXSPEC];
+  const real *lsprec, *convprec, *tcc, *ctwc;   /* [slot][jy][ix] */
+  const signed char *clouds;                    /* [slot][level][jy][ix] */
+  const int *cloudsh;                           /* [slot][jy][ix] */
+  long blc_count[ORC_MAXSPEC], inc_count[ORC_MAXSPEC];
 } orc_ctx;
 
 #define F3(f, i, j, k, m) ((f)[(((size_t)((m) - 1) * c->nz + (size_t)((k) - 1)) * c->ny + (size_t)(j)) * c->nx + (size_t)(i)])
@@ -1437,6 +1445,165 @@ static void orc_drydepokernel(orc_ctx *c, int nunc, const dep_real *deposit, rea
   }
 }
 
+/* ------------------------------------------------------------------------- */
+/* wet deposition: wetdepo.f90:58-151, get_wetscav.f90:78-314,                  */
+/* interpol_rain.f90:68-130, wetdepokernel.f90:38-108 (mother grid)             */
+/* ------------------------------------------------------------------------- */
+static void orc_interpol_rain(orc_ctx *c, const real *yy1, const real *yy2, const real *yy3, int iwftouse,
+                              real xt, real yt, real *yint1, real *yint2, real *yint3) {
+  int ix, jy, ixp, jyp;
+  real ddx, ddy, rddx, rddy, p1, p2, p3, p4;
+  if (xt >= (real)(c->nx - 1)) xt = (real)(c->nx - 1) - K(0.00001);
+  if (yt >= (real)(c->ny - 1)) yt = (real)(c->ny - 1) - K(0.00001);
+  ix = (int)xt; jy = (int)yt; ixp = ix + 1; jyp = jy + 1;
+  ddx = xt - (real)ix; ddy = yt - (real)jy;
+  rddx = K(1.) - ddx; rddy = K(1.) - ddy;
+  p1 = rddx * rddy; p2 = ddx * rddy; p3 = rddx * ddy; p4 = ddx * ddy;
+  *yint1 = p1 * F2(yy1, ix, jy, iwftouse) + p2 * F2(yy1, ixp, jy, iwftouse) + p3 * F2(yy1, ix, jyp, iwftouse) + p4 * F2(yy1, ixp, jyp, iwftouse);
+  *yint2 = p1 * F2(yy2, ix, jy, iwftouse) + p2 * F2(yy2, ixp, jy, iwftouse) + p3 * F2(yy2, ix, jyp, iwftouse) + p4 * F2(yy2, ixp, jyp, iwftouse);
+  *yint3 = p1 * F2(yy3, ix, jy, iwftouse) + p2 * F2(yy3, ixp, jy, iwftouse) + p3 * F2(yy3, ix, jyp, iwftouse) + p4 * F2(yy3, ixp, jyp, iwftouse);
+}
+
+static real r_pow10(real x) { return r_pow(K(10.), x); }
+static real r_log10(real x) { return sizeof(real) == 4 ? (real)log10f((float)x) : (real)log10((double)x); }
+
+/* get_wetscav.f90:78-314 (ngrid = 0) */
+static real orc_get_wetscav(orc_ctx *c, int itime, int ltsample, double xtra1, double ytra1, real ztra1, int ks, real *grfraction) {
+  static const real lfr[5] = {K(0.5), K(0.65), K(0.8), K(0.9), K(0.95)};
+  static const real cfr[5] = {K(0.4), K(0.55), K(0.7), K(0.8), K(0.9)};
+  static const real bclr[6] = {K(274.35758), K(332839.59273), K(226656.57259), K(58005.91340), K(6588.38582), K(0.244984)};
+  static const real bcls[6] = {K(22.7), K(0.0), K(0.0), K(1321.0), K(381.0), K(0.0)};
+  const real incloud_ratio = K(6.2), r_air = K(287.05);
+  real wetscav = K(0.), lsp, convp, cc, prec1, act_temp, S_i, cl, cle, frac_act, liq_frac, ice_frac, dquer_m;
+  int ix, jy, hz = 1, il, interp_time, n, i, j, clouds_v;
+  ix = (int)xtra1; jy = (int)ytra1;
+  interp_time = (int)lround((double)((real)itime - K(0.5) * (real)ltsample));   /* nint(itime-0.5*ltsample) */
+  n = c->memind[1];
+  if (abs(c->memtime[0] - interp_time) < abs(c->memtime[1] - interp_time)) n = c->memind[0];
+  orc_interpol_rain(c, c->lsprec, c->convprec, c->tcc, n, (real)xtra1, (real)ytra1, &lsp, &convp, &cc);
+  if (lsp < K(0.01) && convp < K(0.01)) return wetscav;
+  for (il = 2; il <= c->nz; il++)
+    if (HGT(il) > ztra1) { hz = il - 1; break; }
+  clouds_v = (int)c->clouds[(((size_t)(n - 1) * c->nz + (size_t)(hz - 1)) * c->ny + (size_t)jy) * c->nx + (size_t)ix];
+  if (clouds_v <= 1) return wetscav;
+  if (lsp > K(20.)) i = 5; else if (lsp > K(8.)) i = 4; else if (lsp > K(3.)) i = 3; else if (lsp > K(1.)) i = 2; else i = 1;
+  if (convp > K(20.)) j = 5; else if (convp > K(8.)) j = 4; else if (convp > K(3.)) j = 3; else if (convp > K(1.)) j = 2; else j = 1;
+  grfraction[0] = r_max(K(0.05), cc * (lsp * lfr[i - 1] + convp * cfr[j - 1]) / (lsp + convp));
+  prec1 = (lsp + convp) / grfraction[0];
+  act_temp = F3(c->tt, ix, jy, hz, n);
+  if (clouds_v >= 4) {   /* below cloud */
+    if (c->dquer[ks] <= K(0.) && (c->weta_gas[ks] > K(0.) || c->wetb_gas[ks] > K(0.))) {
+      c->blc_count[ks]++;
+      wetscav = c->weta_gas[ks] * r_pow(prec1, c->wetb_gas[ks]);
+    } else if (c->dquer[ks] > K(0.) && (c->crain_aero[ks] > K(0.) || c->csnow_aero[ks] > K(0.))) {
+      real l10;
+      c->blc_count[ks]++;
+      dquer_m = r_min(K(10.), c->dquer[ks]) / K(1000000.);
+      l10 = r_log10(dquer_m);
+      if (act_temp >= K(273.) && c->crain_aero[ks] > K(0.))
+        wetscav = c->crain_aero[ks] * r_pow10(bclr[0] + (bclr[1] * (K(1.) / ((l10 * l10) * (l10 * l10)))) + (bclr[2] * (K(1.) / (l10 * (l10 * l10)))) +
+                                              (bclr[3] * (K(1.) / (l10 * l10))) + (bclr[4] * (K(1.) / l10)) + bclr[5] * r_pow(prec1, K(0.5)));
+      else if (act_temp < K(273.) && c->csnow_aero[ks] > K(0.))
+        wetscav = c->csnow_aero[ks] * r_pow10(bcls[0] + (bcls[1] * (K(1.) / ((l10 * l10) * (l10 * l10)))) + (bcls[2] * (K(1.) / (l10 * (l10 * l10)))) +
+                                              (bcls[3] * (K(1.) / (l10 * l10))) + (bcls[4] * (K(1.) / l10)) + bcls[5] * r_pow(prec1, K(0.5)));
+    }
+  }
+  if (clouds_v < 4) {   /* in cloud */
+    if ((c->ccn_aero[ks] > K(0.) || c->in_aero[ks] > K(0.)) || (c->henry[ks] > K(0.) && c->dquer[ks] <= K(0.))) {
+      c->inc_count[ks]++;
+      if (c->ccn_aero[ks] < K(0.)) c->ccn_aero[ks] = K(0.);
+      if (c->in_aero[ks] < K(0.)) c->in_aero[ks] = K(0.);
+      if (c->readclouds) cl = F2(c->ctwc, ix, jy, n) * (grfraction[0] / cc);
+      else cl = K(1E6) * K(2E-7) * r_pow(prec1, K(0.36));
+      if (act_temp <= K(253.)) { liq_frac = K(0); ice_frac = K(1); }
+      else if (act_temp >= K(273.)) { liq_frac = K(1); ice_frac = K(0); }
+      else {
+        real t = (act_temp - K(273.)) / (K(273.) - K(253.));
+        ice_frac = t * t;
+        liq_frac = r_max(K(0.), K(1.) - ice_frac);
+      }
+      frac_act = liq_frac * c->ccn_aero[ks] + ice_frac * c->in_aero[ks];
+      if (c->dquer[ks] > K(0.)) S_i = frac_act / cl;
+      else {
+        cle = (K(1) - cl) / (c->henry[ks] * (r_air / K(3500.)) * act_temp) + cl;
+        S_i = K(1) / cle;
+      }
+      wetscav = incloud_ratio * S_i * (prec1 / K(3.6E6));
+    }
+  }
+  return wetscav;
+}
+
+/* wetdepokernel.f90:38-108 */
+static void orc_wetdepokernel(orc_ctx *c, int nunc, const real *deposit, real x, real y, int nage, int kp) {
+  real xl, yl, ddx, ddy, wx, wy, w;
+  int ix, jy, ixp, jyp, ks;
+  xl = (x * c->dx + c->xoutshift) / c->dxout;
+  yl = (y * c->dy + c->youtshift) / c->dyout;
+  ix = (int)xl; jy = (int)yl;
+  ddx = xl - (real)ix; ddy = yl - (real)jy;
+  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+#define WADD(i, j, ww) c->wetgridunc[DIDX(i, j, ks, kp, nunc, nage)] = (dep_real)((real)c->wetgridunc[DIDX(i, j, ks, kp, nunc, nage)] + (ww))
+  for (ks = 1; ks <= c->nspec; ks++) {
+    if (!c->lusekerneloutput) {
+      if (ix >= 0 && jy >= 0 && ix <= c->numxgrid - 1 && jy <= c->numygrid - 1) WADD(ix, jy, deposit[ks - 1]);
+      continue;
+    }
+    if (ix >= 0 && jy >= 0 && ix <= c->numxgrid - 1 && jy <= c->numygrid - 1) { w = wx * wy; WADD(ix, jy, deposit[ks - 1] * w); }
+    if (ixp >= 0 && jyp >= 0 && ixp <= c->numxgrid - 1 && jyp <= c->numygrid - 1) { w = (K(1.) - wx) * (K(1.) - wy); WADD(ixp, jyp, deposit[ks - 1] * w); }
+    if (ixp >= 0 && jy >= 0 && ixp <= c->numxgrid - 1 && jy <= c->numygrid - 1) { w = (K(1.) - wx) * wy; WADD(ixp, jy, deposit[ks - 1] * w); }
+    if (ix >= 0 && jyp >= 0 && ix <= c->numxgrid - 1 && jyp <= c->numygrid - 1) { w = wx * (K(1.) - wy); WADD(ix, jyp, deposit[ks - 1] * w); }
+  }
+#undef WADD
+}
+
+/* wetdepo.f90:58-151 */
+void orc_wetdepo(orc_ctx *c, int itime, int ltsample, int loutnext, int npart, const double *xtra1, const double *ytra1,
+                 const real *ztra1, const int *itra1, const int *itramem, const int *npoint, const int *nclass, real *xmass1) {
+  const real smallnum = sizeof(real) == 4 ? (real)1.17549435e-38f : (real)2.2250738585072014e-308;
+  int jpart, ks, ldeltat;
+  if (itime <= loutnext) ldeltat = itime - (loutnext - c->loutstep); else ldeltat = itime - loutnext;
+  for (jpart = 0; jpart < npart; jpart++) {
+    int itage, nage, kp = 1;
+    real wetdeposit[ORC_MAXSPEC], grfraction[3], restmass;
+    if (itra1[jpart] == -999999999) continue;
+    if (c->ldirect == 1) { if (itra1[jpart] > itime) continue; } else { if (itra1[jpart] < itime) continue; }
+    itage = abs(itra1[jpart] - itramem[jpart]);
+    nage = orc_ageclass(c, itage);
+    for (ks = 0; ks < ORC_MAXSPEC; ks++) wetdeposit[ks] = K(0.);
+    for (ks = 0; ks < c->nspec; ks++) {
+      real wetscav;
+      if (!c->wetdepspec[ks]) continue;
+      grfraction[0] = K(0.);
+      wetscav = orc_get_wetscav(c, itime, ltsample, xtra1[jpart], ytra1[jpart], ztra1[jpart], ks, grfraction);
+      if (wetscav > K(0.)) wetdeposit[ks] = xmass1[(size_t)ks * npart + jpart] * (K(1.) - r_exp(-wetscav * (real)abs(ltsample))) * grfraction[0];
+      else wetdeposit[ks] = K(0.);
+      restmass = xmass1[(size_t)ks * npart + jpart] - wetdeposit[ks];
+      kp = c->ioutputforeachrelease == 1 ? npoint[jpart] : 1;
+      if (restmass > smallnum) xmass1[(size_t)ks * npart + jpart] = restmass; else xmass1[(size_t)ks * npart + jpart] = K(0.);
+      if (c->decay[ks] > K(0.)) wetdeposit[ks] = wetdeposit[ks] * r_exp((real)abs(ldeltat) * c->decay[ks]);
+    }
+    if (c->ldirect == 1 && c->wetgridunc) orc_wetdepokernel(c, nclass[jpart], wetdeposit, (real)xtra1[jpart], (real)ytra1[jpart], nage, kp);
+  }
+}
+
+void orc_set_wet(orc_ctx *c, const int *wetdepspec, const double *weta_gas, const double *wetb_gas, const double *crain_aero,
+                 const double *csnow_aero, const double *ccn_aero, const double *in_aero, const double *henry, int readclouds,
+                 const real *lsprec, const real *convprec, const real *tcc, const signed char *clouds, const int *cloudsh,
+                 const real *ctwc) {
+  int i;
+  for (i = 0; i < c->nspec && i < ORC_MAXSPEC; i++) {
+    c->wetdepspec[i] = wetdepspec[i];
+    c->weta_gas[i] = (real)weta_gas[i]; c->wetb_gas[i] = (real)wetb_gas[i]; c->crain_aero[i] = (real)crain_aero[i];
+    c->csnow_aero[i] = (real)csnow_aero[i]; c->ccn_aero[i] = (real)ccn_aero[i]; c->in_aero[i] = (real)in_aero[i];
+    c->henry[i] = (real)henry[i];
+  }
+  c->readclouds = readclouds;
+  c->lsprec = lsprec; c->convprec = convprec; c->tcc = tcc; c->clouds = clouds; c->cloudsh = cloudsh; c->ctwc = ctwc;
+}
+const dep_real *orc_wetgridunc(orc_ctx *c) { return c->wetgridunc; }
+
 void orc_set_outgrid(orc_ctx *c, int numxgrid, int numygrid, int numzgrid, double dxout, double dyout, double outlon0,
                      double outlat0, const double *outheight, int maxpointspec_act, int nclassunc, int nageclass,
                      const int *lage, int ind_samp, int ioutputforeachrelease, int lusekerneloutput, int maxspec_out) {
@@ -1456,6 +1623,8 @@ void orc_set_outgrid(orc_ctx *c, int numxgrid, int numygrid, int numzgrid, doubl
   free(c->gridunc); free(c->drygridunc);
   c->gridunc = (real *)calloc(n3, sizeof(real));
   c->drygridunc = (dep_real *)calloc(n2, sizeof(dep_real));
+  free(c->wetgridunc);
+  c->wetgridunc = (dep_real *)calloc(n2, sizeof(dep_real));
 }
 void orc_set_output_times(orc_ctx *c, int loutnext, int loutstep) { c->loutnext = loutnext; c->loutstep = loutstep; }
 const real *orc_gridunc(orc_ctx *c) { return c->gridunc; }

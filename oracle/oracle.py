@@ -117,6 +117,30 @@ class Oracle:
                                 lage.ctypes.data_as(C.POINTER(C.c_int)), ind_samp, iofr, 1, nspec)
             if "outtimes" in sc:
                 lib.orc_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1]))
+        self.has_wet = bool(sc.get("wetdep", 0))
+        if self.has_wet:
+            self._init_wet(sc)
+
+    def _init_wet(self, sc):
+        lib = self.lib
+        dp = C.POINTER(C.c_double)
+        nspec = self.nspec
+        self.wf = {k: np.ascontiguousarray(np.asarray(sc[k]).astype(self.rt)) for k in ("lsprec", "convprec", "tcc")}
+        self.wf["clouds"] = np.ascontiguousarray(np.asarray(sc["clouds"]).astype(np.int8))
+        self.wf["cloudsh"] = np.ascontiguousarray(np.asarray(sc["cloudsh"]).astype(np.int32))
+        par = [_f64(sc[k]) for k in ("weta_gas", "wetb_gas", "crain_aero", "csnow_aero", "ccn_aero", "in_aero", "henry")]
+        wds = np.ascontiguousarray(np.asarray(sc["wetdepspec"], dtype=np.int32))
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        lib.orc_set_wet(self.h, wds.ctypes.data_as(C.POINTER(C.c_int)), *[a.ctypes.data_as(dp) for a in par], 0,
+                        vp(self.wf["lsprec"]), vp(self.wf["convprec"]), vp(self.wf["tcc"]), vp(self.wf["clouds"]),
+                        vp(self.wf["cloudsh"]), C.c_void_p(0))
+        self._wetpar = (par, wds)
+
+    def wetgrid(self):
+        nage, ncu, mps, nsp, nzg, nyg, nxg = self.gshape
+        self.lib.orc_wetgridunc.restype = C.c_void_p
+        d = np.ctypeslib.as_array(C.cast(self.lib.orc_wetgridunc(self.h), C.POINTER(C.c_float)), shape=(nsp * nyg * nxg,))
+        return d.astype(np.float64).reshape(nsp, nyg, nxg)
 
     def grids(self):
         """(gridunc, drygridunc) as float64 arrays shaped (spec, z, y, x) / (spec, y, x)."""
@@ -141,6 +165,10 @@ class Oracle:
 
     def step(self):
         vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        if self.has_wet and self.itime != 0:   # timemanager.f90:164-169
+            loutnext = int(self.sc["outtimes"][0]) if "outtimes" in self.sc else 0
+            self.lib.orc_wetdepo(self.h, self.itime, int(self.sc["lsynctime"]), loutnext, self.n, vp(self.x), vp(self.y),
+                                 vp(self.z), vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1))
         nadv = self.lib.orc_step(self.h, self.itime, self.n, vp(self.x), vp(self.y), vp(self.z),
                                  vp(self.uap), vp(self.ucp), vp(self.uzp), vp(self.us), vp(self.vs),
                                  vp(self.ws), vp(self.idt), vp(self.itra1), vp(self.itramem),

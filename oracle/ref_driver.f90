@@ -175,6 +175,37 @@ program flexref
       ind_samp=ibuf(1); ioutputforeachrelease=ibuf(2)
     case ('outtimes')  ! loutnext loutstep
       loutnext_d=ibuf(1); loutstep=ibuf(2)
+    ! --- wet deposition (species parameters of readspecies.f90, precipitation/cloud fields) ---
+    case ('wetdep');     WETDEP=(ibuf(1).ne.0)
+    case ('wetdepspec'); do i=1,n; WETDEPSPEC(i)=(ibuf(i).ne.0); end do
+    case ('weta_gas');   weta_gas(1:n)=dbuf(1:n)
+    case ('wetb_gas');   wetb_gas(1:n)=dbuf(1:n)
+    case ('crain_aero'); crain_aero(1:n)=dbuf(1:n)
+    case ('csnow_aero'); csnow_aero(1:n)=dbuf(1:n)
+    case ('ccn_aero');   ccn_aero(1:n)=dbuf(1:n)
+    case ('in_aero');    in_aero(1:n)=dbuf(1:n)
+    case ('henry');      henry(1:n)=dbuf(1:n)
+    case ('lsprec');     call fill2(lsprec, dbuf)
+    case ('convprec');   call fill2(convprec, dbuf)
+    case ('tcc');        call fill2(tcc, dbuf)
+    case ('clouds')      ! compact (nx,ny,nz,2) int
+      do m=1,2
+        do k=1,gnz
+          do j=0,gny-1
+            do i=0,gnx-1
+              clouds(i,j,k,m)=int(ibuf(1+i+gnx*(j+gny*((k-1)+gnz*(m-1)))),1)
+            end do
+          end do
+        end do
+      end do
+    case ('cloudsh')     ! compact (nx,ny,2) int
+      do m=1,2
+        do j=0,gny-1
+          do i=0,gnx-1
+            cloudsh(i,j,m)=ibuf(1+i+gnx*(j+gny*(m-1)))
+          end do
+        end do
+      end do
     case ('itime0');   itime0=ibuf(1)
     ! --- 3-D fields: compact (nx,ny,nz,2), x fastest -------------------------
     case ('uu');     call fill3(uu, dbuf)
@@ -261,7 +292,8 @@ program flexref
     ! allocation as outgrid_init.f90:192-200
     allocate(gridunc(0:numxgrid-1,0:numygrid-1,numzgrid,maxspec,maxpointspec_act,nclassunc,maxageclass))
     allocate(drygridunc(0:numxgrid-1,0:numygrid-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
-    gridunc=0.; drygridunc=0.
+    allocate(wetgridunc(0:numxgrid-1,0:numygrid-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
+    gridunc=0.; drygridunc=0.; wetgridunc=0.
   end if
 
   open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')
@@ -311,6 +343,8 @@ program flexref
   call system_clock(c0, crate)
   do istep=0,nsteps-1
     itime=itime0+istep*lsynctime
+    ! wet deposition first, as timemanager.f90:164-169
+    if (WETDEP .and. itime .ne. 0 .and. numpart .gt. 0) call wetdepo(itime,lsynctime,loutnext_d)
     if (itime.lt.loutnext_d) then       ! timemanager.f90:513-517
       ldeltat=itime-(loutnext_d-loutstep)
     else
@@ -435,6 +469,8 @@ contains
     allocate(g(ng))
     g=reshape(real(drygridunc,8), [ng])
     call put_d('drygridunc', g, ng)
+    g=reshape(real(wetgridunc,8), [ng])
+    call put_d('wetgridunc', g, ng)
     deallocate(g)
   end subroutine dump_grids
 

@@ -20,14 +20,15 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
           "mdomainfill", "lsettling", "nspec", "drydep", "drydepspec", "density", "dquer",
           "vsetaver", "cunningham", "decay", "turbpar", "lage", "nsteps", "itime0",
           "outgrid", "outgeom", "outheight", "concflags", "outtimes",
+          "wetdep", "wetdepspec", "weta_gas", "wetb_gas", "crain_aero", "csnow_aero", "ccn_aero", "in_aero", "henry",
           "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol",
-          "hmix", "ustar", "wstar", "oli", "tropopause", "vdep",
+          "hmix", "ustar", "wstar", "oli", "tropopause", "vdep", "lsprec", "convprec", "tcc", "clouds", "cloudsh",
           "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
           "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass"]
 _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
         "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
         "drydep", "drydepspec", "lage", "nsteps", "itime0", "npart", "itra1", "itramem",
-        "npoint", "nclass", "idt", "cbt", "outgrid", "concflags", "outtimes"}
+        "npoint", "nclass", "idt", "cbt", "outgrid", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh"}
 
 
 def write_scenario(path, sc):
@@ -93,7 +94,7 @@ def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=F
     out = {"steps": [], "stdout": res.stdout}
     cur = None
     for name, a in recs:
-        if name in ("rannumb", "northpolemap", "southpolemap", "derived", "timing", "gridunc", "drygridunc"):
+        if name in ("rannumb", "northpolemap", "southpolemap", "derived", "timing", "gridunc", "drygridunc", "wetgridunc"):
             out[name] = a
             continue
         if name == "xtra1":
