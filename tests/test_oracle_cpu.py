@@ -19,8 +19,17 @@ def _aerosol(sc):
     return sc
 
 
+def _sampling(sc):
+    # aerosol + output grid (conccalc, drydepokernel) + wet deposition (wetdepo)
+    _aerosol(sc)
+    syn.add_outgrid(sc)
+    syn.add_wet(sc, gas=False)
+    return sc
+
+
 CASES = {
     "hanna": dict(ctl=5.0, ifine=4),
+    "sampling": dict(ctl=5.0, ifine=4, post=_sampling),
     "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
     "aerosol": dict(ctl=5.0, ifine=4, post=_aerosol),
     "hanna1_method0": dict(ctl=-5.0),
@@ -60,6 +69,20 @@ def test_oracle_matches_golden_reference_output(name, kind):
             assert np.array_equal(s[k], gold[f"s{i}_{k}"]), (name, kind, i, k)
         ref = gold[f"s{i}_xmass1"]
         assert np.abs(s["xmass1"] - ref).max() <= (1e-13 if kind == "r8" else 1e-6) * np.abs(ref).max()
+    if "gridunc" in gold.files:   # conccalc / drydepokernel / wetdepokernel grids of the reference
+        orc = Oracle(sc, kind)
+        orc.run()
+        g, d = orc.grids()
+        w = orc.wetgrid()
+        nsp = g.shape[0]
+        rg = gold["gridunc"].reshape((5,) + g.shape[1:])[:nsp]
+        rd = gold["drygridunc"].reshape((5,) + d.shape[1:])[:nsp]
+        rw = gold["wetgridunc"].reshape((5,) + w.shape[1:])[:nsp]
+        tol = 1e-13 if kind == "r8" else 1e-6
+        assert rg.sum() > 0 and rd.sum() > 0 and rw.sum() > 0
+        assert np.abs(g - rg).max() <= tol * rg.max()
+        assert np.abs(d - rd).max() <= tol * rd.max()
+        assert np.abs(w - rw).max() <= tol * rw.max()
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
