@@ -40,8 +40,17 @@ class FpxConfig(C.Structure):
         ("decay", C.c_double * FPX_MAXSPEC), ("xmass_release", C.c_double * FPX_MAXSPEC),
         ("npart_release", C.c_int32), ("lage_last", C.c_int32),
         ("rng_mode", C.c_int32), ("seed", C.c_uint64),
-        ("sort_interval", C.c_int32), ("reserved", C.c_int32 * 7),
+        ("sort_interval", C.c_int32), ("par_nxmax", C.c_int32), ("reserved", C.c_int32 * 6),
     ]
+
+
+FPX_MAXNESTS = 4
+
+
+class FpxNests(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("numbnests", C.c_int32), ("nxmaxn", C.c_int32), ("nymaxn", C.c_int32),
+                ("nxn", C.c_int32 * FPX_MAXNESTS), ("nyn", C.c_int32 * FPX_MAXNESTS)] + \
+               [(n, C.c_double * FPX_MAXNESTS) for n in ("xln", "yln", "xrn", "yrn", "xresoln", "yresoln")]
 
 
 class FpxFields(C.Structure):
@@ -97,7 +106,7 @@ SYMBOLS = [
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
-    "fpx_wetdepo", "fpx_get_wetgrid",
+    "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields",
 ]
 
 _lib = None
@@ -145,6 +154,8 @@ def load():
     lib.fpx_get_grids.argtypes = [vp, vp, vp, C.c_int32, C.c_int32]
     lib.fpx_comm_unique_id.argtypes = [vp, C.c_int32]
     lib.fpx_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
+    lib.fpx_nests_init.argtypes = [vp, C.POINTER(FpxNests)]
+    lib.fpx_upload_nest_fields.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(FpxFields)]
     lib.fpx_wet_init.argtypes = [vp, C.POINTER(FpxWetConfig)]
     lib.fpx_upload_wet_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxWetFields)]
     lib.fpx_wetdepo.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]

@@ -19,6 +19,7 @@ namespace fpx {
 #define FPX_HD __host__ __device__ __forceinline__
 
 constexpr int kMaxSpec = 5;
+constexpr int kMaxNests = 4;
 constexpr int kDead = -999999999;
 
 // ---------------------------------------------------------------------------
@@ -94,6 +95,12 @@ struct View {
   const R *tropo;    // [ny][nx]  tropopause, literal time slot 1 (advance.f90:253)
   const R *vdep;     // [ny][nx][2 slots][nspec]
   const R *rhott;    // [ny][nx][nz][2] (rho, tt) of literal slot 1 (get_settling.f90:83-84)
+  // nested grids (com_mod.f90:464-541): same packed layouts, nest extents nxn x nyn
+  int numbnests;
+  int nxn[kMaxNests], nyn[kMaxNests];
+  R xln[kMaxNests], yln[kMaxNests], xrn[kMaxNests], yrn[kMaxNests], xresoln[kMaxNests], yresoln[kMaxNests];
+  const R *w3n[kMaxNests], *r2n[kMaxNests], *sfcn[kMaxNests], *hcelln[kMaxNests], *tropon[kMaxNests], *vdepn[kMaxNests];
+  R eps;             // nxmax/3.e5 with the host's par_mod nxmax (advance.f90:107)
   // RNG
   const R *rannumb;  // [maxrand], 0-based copy of rannumb(1:maxrand)
   int maxrand, rng_mode;
@@ -216,18 +223,36 @@ FPX_DEV void cell_setup(Cell<R> &C, int ix, int jy, int ixp, int jyp, R xt, R yt
   C.ix = ix; C.jy = jy; C.ixp = ixp; C.jyp = jyp;
 }
 
+// the field arrays of the grid a particle is on: mother grid (lat-lon or polar winds) or a nest
+template <typename R>
+struct Fld {
+  int nx;
+  const R *w3, *r2, *sfc, *hcell, *tropo, *vdep;
+};
+template <typename R>
+FPX_DEV Fld<R> fld_of(const View<R> &V, int ngrid) {
+  Fld<R> F;
+  if (ngrid > 0) {
+    const int l = ngrid - 1;
+    F.nx = V.nxn[l]; F.w3 = V.w3n[l]; F.r2 = V.r2n[l]; F.sfc = V.sfcn[l]; F.hcell = V.hcelln[l]; F.tropo = V.tropon[l]; F.vdep = V.vdepn[l];
+  } else {
+    F.nx = V.nx; F.w3 = ngrid < 0 ? V.w3pol : V.w3; F.r2 = V.r2; F.sfc = V.sfc; F.hcell = V.hcell; F.tropo = V.tropo; F.vdep = V.vdep;
+  }
+  return F;
+}
+
 // element offsets of the four corner columns (ix,jy) (ixp,jy) (ix,jyp) (ixp,jyp)
 template <typename R>
 struct Cols {
   long long c00, c10, c01, c11;
 };
 template <typename R>
-FPX_DEV Cols<R> cols_of(const View<R> &V, const Cell<R> &C) {
+FPX_DEV Cols<R> cols_of(int nx, const Cell<R> &C) {
   Cols<R> Q;
-  Q.c00 = (long long)C.jy * V.nx + C.ix;
-  Q.c10 = (long long)C.jy * V.nx + C.ixp;
-  Q.c01 = (long long)C.jyp * V.nx + C.ix;
-  Q.c11 = (long long)C.jyp * V.nx + C.ixp;
+  Q.c00 = (long long)C.jy * nx + C.ix;
+  Q.c10 = (long long)C.jy * nx + C.ixp;
+  Q.c01 = (long long)C.jyp * nx + C.ix;
+  Q.c11 = (long long)C.jyp * nx + C.ixp;
   return Q;
 }
 
@@ -239,9 +264,10 @@ FPX_DEV void ld3(const R *base, long long col, int nz, int n, int slot, R &a, R 
 }
 
 template <typename R, bool WITH_WIND, bool WITH_RHO, bool WITH_SIG>
-FPX_DEV void level_profile(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, const R *w3, int n, Level<R> &L) {
+FPX_DEV void level_profile(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, int n, Level<R> &L) {
   const R eps = K(1.0e-30);
-  const Cols<R> Q = cols_of(V, C);
+  const Cols<R> Q = cols_of(F.nx, C);
+  const R *w3 = F.w3;
   R y1[2], y2[2], y3[2], rho1[2], rhograd1[2];
   R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
 #pragma unroll
@@ -268,10 +294,10 @@ FPX_DEV void level_profile(const View<R> &V, const Cell<R> &C, const TimeW<R> &W
       }
     }
     if (WITH_RHO) {
-      const R *q00 = V.r2 + ((Q.c00 * V.nz + (n - 1)) * 2 + slot) * 2;
-      const R *q10 = V.r2 + ((Q.c10 * V.nz + (n - 1)) * 2 + slot) * 2;
-      const R *q01 = V.r2 + ((Q.c01 * V.nz + (n - 1)) * 2 + slot) * 2;
-      const R *q11 = V.r2 + ((Q.c11 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q00 = F.r2 + ((Q.c00 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q10 = F.r2 + ((Q.c10 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q01 = F.r2 + ((Q.c01 * V.nz + (n - 1)) * 2 + slot) * 2;
+      const R *q11 = F.r2 + ((Q.c11 * V.nz + (n - 1)) * 2 + slot) * 2;
       rho1[m] = C.p1 * q00[0] + C.p2 * q10[0] + C.p3 * q01[0] + C.p4 * q11[0];
       rhograd1[m] = C.p1 * q00[1] + C.p2 * q10[1] + C.p3 * q01[1] + C.p4 * q11[1];
     }
@@ -826,6 +852,7 @@ FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt
 // the per-thread trajectory step
 // ---------------------------------------------------------------------------
 template <typename R> FPX_DEV int pick_grid(const View<R> &V, double xt, double yt);
+template <typename R> FPX_DEV int pick_polar(const View<R> &V, double yt);
 
 template <typename R>
 struct PState {   // one particle in registers
@@ -836,9 +863,19 @@ struct PState {   // one particle in registers
 };
 
 template <typename R>
-FPX_DEV int pick_grid(const View<R> &V, double xt, double yt) {   // advance.f90:161-175 (nests: TODO next)
+FPX_DEV int pick_polar(const View<R> &V, double yt) {   // the polar part of advance.f90:161-164
   if (V.nglobal && yt > (double)V.switchnorthg) return -1;
   if (V.sglobal && yt < (double)V.switchsouthg) return -2;
+  return 0;
+}
+// advance.f90:161-175: -1/-2 polar caps, j = highest-numbered nest containing the particle, 0 mother
+template <typename R>
+FPX_DEV int pick_grid(const View<R> &V, double xt, double yt) {
+  const int p = pick_polar(V, yt);
+  if (p != 0) return p;
+  for (int j = V.numbnests; j >= 1; j--)
+    if (xt > (double)(V.xln[j - 1] + V.eps) && xt < (double)(V.xrn[j - 1] - V.eps) &&
+        yt > (double)(V.yln[j - 1] + V.eps) && yt < (double)(V.yrn[j - 1] - V.eps)) return j;
   return 0;
 }
 
@@ -891,10 +928,11 @@ FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, 
 
 // wind at (cell, zt): interpol_wind.f90:75-214 (SIG) / interpol_wind_short.f90:67-140
 template <typename R, bool SIG>
-FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const TimeW<R> &W, const R *w3, R zt,
+FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, R zt,
                          R &u, R &v, R &w, R &usig, R &vsig, R &wsig) {
   const R eps = K(1.0e-30);
-  const Cols<R> Q = cols_of(V, C);
+  const Cols<R> Q = cols_of(F.nx, C);
+  const R *w3 = F.w3;
   int indz = find_level(hgt, V.nz, zt);
   R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
   R dz1 = (zt - hgt[indz - 1]) * dz;
@@ -944,14 +982,14 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Cell<R> &C, const
 
 // ust, wst, ol at the cell: interpol_all.f90:80-107
 template <typename R>
-FPX_DEV void interp_surface(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, Turb<R> &T) {
-  const Cols<R> Q = cols_of(V, C);
+FPX_DEV void interp_surface(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, Turb<R> &T) {
+  const Cols<R> Q = cols_of(F.nx, C);
   R ust1[2], wst1[2], oli1[2];
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     int slot = m == 0 ? V.m1 : V.m2;
-    const R *a = V.sfc + (Q.c00 * 2 + slot) * 4, *b = V.sfc + (Q.c10 * 2 + slot) * 4;
-    const R *c = V.sfc + (Q.c01 * 2 + slot) * 4, *d = V.sfc + (Q.c11 * 2 + slot) * 4;
+    const R *a = F.sfc + (Q.c00 * 2 + slot) * 4, *b = F.sfc + (Q.c10 * 2 + slot) * 4;
+    const R *c = F.sfc + (Q.c01 * 2 + slot) * 4, *d = F.sfc + (Q.c11 * 2 + slot) * 4;
     ust1[m] = C.p1 * a[0] + C.p2 * b[0] + C.p3 * c[0] + C.p4 * d[0];
     wst1[m] = C.p1 * a[1] + C.p2 * b[1] + C.p3 * c[1] + C.p4 * d[1];
     oli1[m] = C.p1 * a[2] + C.p2 * b[2] + C.p3 * c[2] + C.p4 * d[2];
@@ -964,14 +1002,14 @@ FPX_DEV void interp_surface(const View<R> &V, const Cell<R> &C, const TimeW<R> &
 
 // interpol_vdep.f90:39-54
 template <typename R>
-FPX_DEV R interp_vdep(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, int ks) {
-  const Cols<R> Q = cols_of(V, C);
+FPX_DEV R interp_vdep(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, int ks) {
+  const Cols<R> Q = cols_of(F.nx, C);
   R y[2];
 #pragma unroll
   for (int m = 0; m < 2; m++) {
     int slot = m == 0 ? V.m1 : V.m2;
-    y[m] = C.p1 * V.vdep[(Q.c00 * 2 + slot) * V.nspec + ks] + C.p2 * V.vdep[(Q.c10 * 2 + slot) * V.nspec + ks] +
-           C.p3 * V.vdep[(Q.c01 * 2 + slot) * V.nspec + ks] + C.p4 * V.vdep[(Q.c11 * 2 + slot) * V.nspec + ks];
+    y[m] = C.p1 * F.vdep[(Q.c00 * 2 + slot) * V.nspec + ks] + C.p2 * F.vdep[(Q.c10 * 2 + slot) * V.nspec + ks] +
+           C.p3 * F.vdep[(Q.c01 * 2 + slot) * V.nspec + ks] + C.p4 * F.vdep[(Q.c11 * 2 + slot) * V.nspec + ks];
   }
   return (y[0] * W.dt2 + y[1] * W.dt1) * W.dtt;
 }
@@ -989,21 +1027,21 @@ struct LevelCache {
 };
 
 template <typename R>
-FPX_DEV void cache_fetch(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, const R *w3, LevelCache<R> &LC, int indz) {
+FPX_DEV void cache_fetch(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, LevelCache<R> &LC, int indz) {
   if (LC.ilo == indz) return;
   Level<R> L;
   if (LC.ilo == indz + 1) {            // moved one level down
     LC.uhi = LC.ulo; LC.vhi = LC.vlo; LC.whi = LC.wlo; LC.rhohi = LC.rholo; LC.rhogradhi = LC.rhogradlo;
-    level_profile<R, true, true, false>(V, C, W, w3, indz, L);
+    level_profile<R, true, true, false>(V, F, C, W, indz, L);
     LC.ulo = L.u; LC.vlo = L.v; LC.wlo = L.w; LC.rholo = L.rho; LC.rhogradlo = L.rhograd;
   } else if (LC.ilo == indz - 1) {     // moved one level up
     LC.ulo = LC.uhi; LC.vlo = LC.vhi; LC.wlo = LC.whi; LC.rholo = LC.rhohi; LC.rhogradlo = LC.rhogradhi;
-    level_profile<R, true, true, false>(V, C, W, w3, indz + 1, L);
+    level_profile<R, true, true, false>(V, F, C, W, indz + 1, L);
     LC.uhi = L.u; LC.vhi = L.v; LC.whi = L.w; LC.rhohi = L.rho; LC.rhogradhi = L.rhograd;
   } else {
-    level_profile<R, true, true, false>(V, C, W, w3, indz, L);
+    level_profile<R, true, true, false>(V, F, C, W, indz, L);
     LC.ulo = L.u; LC.vlo = L.v; LC.wlo = L.w; LC.rholo = L.rho; LC.rhogradlo = L.rhograd;
-    level_profile<R, true, true, false>(V, C, W, w3, indz + 1, L);
+    level_profile<R, true, true, false>(V, F, C, W, indz + 1, L);
     LC.uhi = L.u; LC.vhi = L.v; LC.whi = L.w; LC.rhohi = L.rho; LC.rhogradhi = L.rhograd;
   }
   LC.ilo = indz;
@@ -1011,10 +1049,10 @@ FPX_DEV void cache_fetch(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, 
 
 // usig = 0.5*(usigprof(indzp)+usigprof(indz)) etc., advance.f90:604-606
 template <typename R>
-FPX_DEV void level_pair_sigma(const View<R> &V, const Cell<R> &C, const TimeW<R> &W, const R *w3, int indz, R &usig, R &vsig, R &wsig) {
+FPX_DEV void level_pair_sigma(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, int indz, R &usig, R &vsig, R &wsig) {
   Level<R> lo, hi;
-  level_profile<R, false, false, true>(V, C, W, w3, indz, lo);
-  level_profile<R, false, false, true>(V, C, W, w3, indz + 1, hi);
+  level_profile<R, false, false, true>(V, F, C, W, indz, lo);
+  level_profile<R, false, false, true>(V, F, C, W, indz + 1, hi);
   usig = K(0.5) * (hi.usig + lo.usig);
   vsig = K(0.5) * (hi.vsig + lo.vsig);
   wsig = K(0.5) * (hi.wsig + lo.wsig);
@@ -1039,14 +1077,14 @@ FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const RNG &G, i
   // The reference's initialize() reads the module variable ngrid left behind by the
   // previous particle's advance() (interpol_all.f90:144); a parallel engine has no
   // "previous particle", so the particle's own polar/lat-lon choice is used.
-  const R *w3 = pick_grid(V, P.xt, P.yt) < 0 ? V.w3pol : V.w3;
+  const Fld<R> F = fld_of(V, pick_polar(V, P.yt));
   R usig, vsig, wsig;
   if (T.zeta <= K(1.)) {
-    interp_surface(V, C, W, T);
+    interp_surface(V, F, C, W, T);
     int indz = find_level(hgt, V.nz, P.zt);
     Level<R> lo, hi;
-    level_profile<R, false, false, true>(V, C, W, w3, indz, lo);
-    level_profile<R, false, false, true>(V, C, W, w3, indz + 1, hi);
+    level_profile<R, false, false, true>(V, F, C, W, indz, lo);
+    level_profile<R, false, false, true>(V, F, C, W, indz + 1, hi);
     // (u,v,w of initialize.f90:116-118 are not used further)
     if (V.turbswitch) hanna(T, P.zt); else hanna1(T, P.zt);
     if (nrand + 2 > V.maxrand) nrand = 1;
@@ -1076,7 +1114,7 @@ FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const RNG &G, i
     wsig = (hi.wsig + lo.wsig) / K(2.);
   } else {
     R u, v, w;
-    interp_wind<R, true>(V, hgt, C, W, w3, P.zt, u, v, w, usig, vsig, wsig);
+    interp_wind<R, true>(V, hgt, F, C, W, P.zt, u, v, w, usig, vsig, wsig);
     P.ldt = abs(V.lsynctime);
     if (nrand + 1 > V.maxrand) nrand = 1;
     P.up = G.at(nrand) * K(0.3);
@@ -1103,7 +1141,7 @@ FPX_DEV int initialize_needs_cbl_draws(const View<R> &V, const R *hgt, int itime
   if (!(zt / T.h <= K(1.))) return 0;
   Cell<R> C;
   cell_setup(C, ix, jy, ix + 1, jy + 1, (R)xt, (R)yt);
-  interp_surface(V, C, time_weights(V, itime), T);
+  interp_surface(V, fld_of(V, 0), C, time_weights(V, itime), T);
   return (-T.h / T.ol > K(5)) ? 1 : 0;
 }
 
@@ -1120,6 +1158,7 @@ FPX_DEV int initialize_needs_cbl_draws(const View<R> &V, const R *hgt, int itime
 template <typename R>
 struct AdvCtx {                 // what advance() keeps between its labelled sections
   int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
+  R xr, yr;                     // position in the index space of that grid: real(xt),real(yt) or xtn,ytn
   R h;
   R dxsave, dysave, dawsave, dcwsave;
   R u, v, w;                    // interpol_mod u, v, w
@@ -1128,8 +1167,6 @@ struct AdvCtx {                 // what advance() keeps between its labelled sec
 
 enum { PBL_CONTINUE = 0, PBL_DONE = 1, PBL_ESCAPED = 2 };
 
-template <typename R>
-FPX_DEV R eps_domain() { return K(361) / K(3.e5); }   // nxmax/3.e5 with the reference's nxmax=361 (advance.f90:107)
 
 // returns true when the particle starts inside the PBL (zeta <= 1, advance.f90:276)
 template <typename R>
@@ -1139,11 +1176,24 @@ FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, 
   A.itimec = itime;
   A.nrand = nrand;
   A.ngrid = pick_grid(V, xt, yt);
-  A.ix = (int)xt; A.jy = (int)yt;
+  int nyrows = V.ny, nxcols = V.nx;
+  if (A.ngrid > 0) {   // advance.f90:191-197 nested grid coordinates
+    const int l = A.ngrid - 1;
+    A.xr = (R)((xt - (double)V.xln[l]) * (double)V.xresoln[l]);
+    A.yr = (R)((yt - (double)V.yln[l]) * (double)V.yresoln[l]);
+    A.ix = (int)A.xr; A.jy = (int)A.yr;
+    nyrows = V.nyn[l]; nxcols = V.nxn[l];
+  } else {
+    A.xr = (R)xt; A.yr = (R)yt;
+    A.ix = (int)xt; A.jy = (int)yt;
+  }
   A.ixp = A.ix + 1; A.jyp = A.jy + 1;
-  if (A.jyp >= V.ny) A.jyp = A.jyp - 1;   // advance.f90:228-231 (device rows are allocated ny, not nymax)
-  if (A.ixp >= V.nx) A.ixp = V.nx - 1;    // guard for a non-cyclic domain edge
-  A.h = V.hcell[(long long)A.jy * V.nx + A.ix];          // advance.f90:236-252 (interpolhmix=.false.)
+  if (A.jyp >= nyrows) A.jyp = A.jyp - 1;   // advance.f90:228-231 (device rows are allocated ny, not nymax)
+  if (A.ixp >= nxcols) A.ixp = nxcols - 1;  // guard for a non-cyclic domain edge
+  {
+    const Fld<R> F = fld_of(V, A.ngrid);
+    A.h = F.hcell[(long long)A.jy * F.nx + A.ix];        // advance.f90:236-262 (interpolhmix=.false.)
+  }
   return zt / A.h <= K(1.);
 }
 
@@ -1157,9 +1207,9 @@ struct PblCtx {                 // live across passes of the PBL loop
 
 template <typename R>
 FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W, const AdvCtx<R> &A, PblCtx<R> &B) {
-  cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, (R)xt, (R)yt);   // interpol_all.f90:57-64
+  cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);   // interpol_all.f90:57-64 / interpol_all_nests.f90
   Turb<R> T;
-  interp_surface(V, B.C, W, T);
+  interp_surface(V, fld_of(V, A.ngrid), B.C, W, T);
   B.ust = T.ust; B.wst = T.wst; B.ol = T.ol;
   B.transition = V.cblflag == 1 ? cbl_transition(A.h, T.ol) : K(1.);
   B.LC.ilo = -1;
@@ -1178,11 +1228,11 @@ template <typename R, bool DRYDEP, bool SETTLE, int TSW, int CBLF, typename RNG>
 FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R> &W, int itime, double xt, double yt,
                      R &zt, R &up, R &vp, R &wp, int &ldt, short &icbt, AdvCtx<R> &A, PblCtx<R> &B,
                      int &indz_last, R *prob, Stats *st) {
-  const R eps = eps_domain<R>();
+  const R eps = V.eps;
   const R eps2 = K(1.e-9);
   const R href = K(15.);            // par_mod.f90:76
   const R h = A.h;
-  const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
+  const Fld<R> F = fld_of(V, A.ngrid);
   int nrand = A.nrand;
   const bool turbswitch = sw<TSW>(V.turbswitch);
   const bool cblflag = sw<CBLF>(V.cblflag == 1);
@@ -1203,7 +1253,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const int indz = find_level(hgt, V.nz, zt);
   const int indzp = indz + 1;
   indz_last = indz;
-  cache_fetch(V, B.C, W, w3, B.LC, indz);
+  cache_fetch(V, F, B.C, W, B.LC, indz);
 
   // advance.f90:342-350
   const R dz = K(1.) / (hgt[indzp - 1] - hgt[indz - 1]);
@@ -1345,7 +1395,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) {
       if (ks < V.nspec && V.drydepspec[ks]) {
-        R vdepo = interp_vdep(V, B.C, W, ks);   // same value every pass (depoindicator cache in the reference)
+        R vdepo = interp_vdep(V, F, B.C, W, ks);   // same value every pass (depoindicator cache in the reference)
         prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_exp(-vdepo * m_abs(dt) / (K(2.) * href));
       }
     }
@@ -1362,11 +1412,14 @@ template <typename R, typename RNG>
 FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R> &W, int itime, double xt, double yt,
                         R &zt, R &wp, int &ldt, AdvCtx<R> &A, R &usig, R &vsig, R &wsig) {
   const R eps2 = K(1.e-9);
-  const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
-  const R tropop = V.tropo[(long long)((int)lround(yt)) * V.nx + (int)lround(xt)];   // advance.f90:253
+  const Fld<R> F = fld_of(V, A.ngrid);
+  // tropopause(nix,njy,1,1) / tropopausen(nix,njy,1,1,ngrid), advance.f90:253,263 (literal slot 1)
+  const int nix = A.ngrid > 0 ? (int)lround((double)A.xr) : (int)lround(xt);
+  const int njy = A.ngrid > 0 ? (int)lround((double)A.yr) : (int)lround(yt);
+  const R tropop = F.tropo[(long long)njy * F.nx + nix];
   Cell<R> C;
-  cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, (R)xt, (R)yt);
-  interp_wind<R, true>(V, hgt, C, W, w3, zt, A.u, A.v, A.w, usig, vsig, wsig);
+  cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
+  interp_wind<R, true>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig);
   ldt = abs(V.lsynctime - A.itimec + itime);
   const R dt = (R)ldt;
   int nrand = A.nrand;
@@ -1408,7 +1461,7 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
 template <typename R, typename RNG, bool POLAR = true>
 FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, PState<R> &P, AdvCtx<R> &A,
                        R usig, R vsig, R wsig) {
-  const R eps = eps_domain<R>();
+  const R eps = V.eps;
   const R eps2 = K(1.e-9);
   int nrand = A.nrand;
   // mesoscale fluctuations, advance.f90:728-739
@@ -1438,17 +1491,26 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
   if (P.ldt != abs(V.lsynctime)) return 0;
   if (abs(itime + P.ldt * V.ldirect) > abs(V.memtime1)) return 0;
   if (pick_grid(V, P.xt, P.yt) != A.ngrid) return 0;
-  int ix = (int)P.xt, jy = (int)P.yt;
+  R xr, yr;
+  int nyrows = V.ny, nxcols = V.nx;
+  if (A.ngrid > 0) {   // advance.f90:862-866
+    const int l = A.ngrid - 1;
+    xr = (R)((P.xt - (double)V.xln[l]) * (double)V.xresoln[l]);
+    yr = (R)((P.yt - (double)V.yln[l]) * (double)V.yresoln[l]);
+    nyrows = V.nyn[l]; nxcols = V.nxn[l];
+  } else {
+    xr = (R)P.xt; yr = (R)P.yt;
+  }
+  int ix = A.ngrid > 0 ? (int)xr : (int)P.xt, jy = A.ngrid > 0 ? (int)yr : (int)P.yt;
   int ixp = ix + 1, jyp = jy + 1;
-  if (jyp >= V.ny) jyp = V.ny - 1;   // guard: the reference would read the padding row nymax here
-  if (ixp >= V.nx) ixp = V.nx - 1;
-  const R *w3 = A.ngrid < 0 ? V.w3pol : V.w3;
+  if (jyp >= nyrows) jyp = nyrows - 1;   // guard: the reference would read the padding row nymax here
+  if (ixp >= nxcols) ixp = nxcols - 1;
   R u, v, w;
   {
     R d0, d1, d2;
     Cell<R> C;
-    cell_setup(C, ix, jy, ixp, jyp, (R)P.xt, (R)P.yt);
-    interp_wind<R, false>(V, hgt, C, time_weights(V, itime + P.ldt * V.ldirect), w3, P.zt, u, v, w, d0, d1, d2);
+    cell_setup(C, ix, jy, ixp, jyp, xr, yr);
+    interp_wind<R, false>(V, hgt, fld_of(V, A.ngrid), C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2);
   }
   if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:893-906
   u = (u - A.u) / K(2.);

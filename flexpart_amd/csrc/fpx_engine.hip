@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
           ldt = P.idt[s]; icbt = P.cbt[s];
           pid = P.pid[s];
           adv_begin(V, xt, yt, zt, itime, Q.nrand0[s], A);
-          cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, (R)xt, (R)yt);   // interpol_all.f90:57-64
+          cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);   // interpol_all.f90:57-64
           B.ust = Q.ust[s]; B.wst = Q.wst[s]; B.ol = Q.ol[s]; B.transition = Q.trans[s];
           B.LC.ilo = -1;
           if (!LEAN && V.drydep) {
@@ -525,8 +525,8 @@ __global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, GridP<R> Gp, P
       above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
     } else {
       Cell<R> C;
-      cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, (R)ps.xt, (R)ps.yt);
-      level_pair_sigma(V, C, W, A.ngrid < 0 ? V.w3pol : V.w3, indz, usig, vsig, wsig);   // advance.f90:604-606
+      cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
+      level_pair_sigma(V, fld_of(V, A.ngrid), C, W, indz, usig, vsig, wsig);   // advance.f90:604-606
     }
     const int nstop = adv_finish<R, Rng<R>, POLAR>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
     R prob[kMaxSpec];
@@ -631,6 +631,8 @@ struct EngineBase {
   virtual int conccalc(int itime, double weight) = 0;
   virtual int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) = 0;
   virtual int comm_init(const void *id, int nbytes, int nranks, int rank) = 0;
+  virtual int nests_init(const fpx_nests *n) = 0;
+  virtual int upload_nest_fields(int nest, int slot, const fpx_fields *f) = 0;
   virtual int wet_init(const fpx_wet_config *w) = 0;
   virtual int upload_wet_fields(int slot, const fpx_wet_fields *f) = 0;
   virtual int wetdepo(int itime, int ltsample, int loutnext) = 0;
@@ -745,6 +747,9 @@ struct Engine : EngineBase {
     }
     V.npart_rel = cfg.npart_release; V.lage_last = cfg.lage_last;
     V.rng_mode = cfg.rng_mode; V.seed = cfg.seed; V.maxrand = 1000000;
+    V.eps = (R)(cfg.par_nxmax > 0 ? cfg.par_nxmax : cfg.nxmax) / (R)3.e5;   // advance.f90:107
+    V.numbnests = 0;
+    g_nx = cfg.nx; g_ny = cfg.ny; g_nxmax = cfg.nxmax; g_nymax = cfg.nymax;
 
     const size_t ncol = (size_t)cfg.nx * cfg.ny, nlev = ncol * cfg.nz;
     R *p;
@@ -823,26 +828,28 @@ struct Engine : EngineBase {
   }
 
   // stage one host array and repack it
+  // geometry of the host array being repacked (mother grid by default, a nest during nest uploads)
+  int g_nx = 0, g_ny = 0, g_nxmax = 0, g_nymax = 0;
   template <typename H>
   int pack3(const void *host, R *out, int stride, int off) {
-    const size_t n = (size_t)cfg.nxmax * cfg.nymax * cfg.nz;   // levels beyond nz are never read
+    const size_t n = (size_t)g_nxmax * g_nymax * cfg.nz;   // levels beyond nz are never read
     int rc = ensure_staging(n * sizeof(H));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(H), hipMemcpyHostToDevice, stream));
-    dim3 grid((cfg.nx + 31) / 32, (cfg.nz + 31) / 32, cfg.ny), block(32, 8);
-    k_pack3<H, R><<<grid, block, 0, stream>>>((const H *)staging, out, cfg.nx, cfg.ny, cfg.nz, cfg.nxmax, cfg.nymax, stride, off);
+    dim3 grid((g_nx + 31) / 32, (cfg.nz + 31) / 32, g_ny), block(32, 8);
+    k_pack3<H, R><<<grid, block, 0, stream>>>((const H *)staging, out, g_nx, g_ny, cfg.nz, g_nxmax, g_nymax, stride, off);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));   // staging is reused by the next field
     return 0;
   }
   template <typename H>
   int pack2(const void *host, R *out, int stride, int off) {
-    const size_t n = (size_t)cfg.nxmax * cfg.nymax;
+    const size_t n = (size_t)g_nxmax * g_nymax;
     int rc = ensure_staging(n * sizeof(H));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(staging, host, n * sizeof(H), hipMemcpyHostToDevice, stream));
-    int tot = cfg.nx * cfg.ny;
-    k_pack2<H, R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>((const H *)staging, out, cfg.nx, cfg.ny, cfg.nxmax, stride, off);
+    int tot = g_nx * g_ny;
+    k_pack2<H, R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>((const H *)staging, out, g_nx, g_ny, g_nxmax, stride, off);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
@@ -1104,6 +1111,8 @@ struct Engine : EngineBase {
     if (!height_set || !window_set || !slot_loaded[0] || !slot_loaded[1]) return fail(FPX_ERR_STATE, "step: height, both field slots and the wind-time window must be set first");
     if (cfg.rng_mode != FPX_RNG_PHILOX && !table_set) return fail(FPX_ERR_STATE, "step: the table RNG modes need fpx_rng_fill_table/fpx_rng_set_table");
     if (V.memtime0 == V.memtime1) return fail(FPX_ERR_STATE, "step: empty wind-time window");
+    for (int l = 0; l < V.numbnests; l++)
+      if (!nest_loaded[l][0] || !nest_loaded[l][1]) return fail(FPX_ERR_STATE, "step: nest fields missing (fpx_upload_nest_fields, both slots)");
     if (out) memset(out, 0, sizeof(*out));
     if (numpart == 0) return 0;
     if (cfg.sort_interval > 0 && step_counter > 0 && step_counter % (unsigned)cfg.sort_interval == 0) {
@@ -1404,6 +1413,69 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // ---- nested grids --------------------------------------------------------------
+  int nest_nxmaxn = 0, nest_nymaxn = 0;
+  bool nest_loaded[kMaxNests][2] = {};
+  int nests_init(const fpx_nests *n) override {
+    if (!n || n->struct_bytes != (int32_t)sizeof(fpx_nests)) return fail(FPX_ERR_ARG, "nests_init: null or fpx_nests size mismatch (ABI)");
+    if (n->numbnests < 1 || n->numbnests > kMaxNests) return fail(FPX_ERR_ARG, "nests_init: numbnests out of range");
+    if (V.numbnests) return fail(FPX_ERR_STATE, "nests_init: already initialised");
+    int rc;
+    for (int l = 0; l < n->numbnests; l++) {
+      if (n->nxn[l] < 2 || n->nyn[l] < 2 || n->nxn[l] > n->nxmaxn || n->nyn[l] > n->nymaxn) return fail(FPX_ERR_ARG, "nests_init: bad nest extents");
+      if (!(n->xln[l] >= 0 && n->yln[l] >= 0 && n->xrn[l] <= cfg.nx - 1 && n->yrn[l] <= cfg.ny - 1)) return fail(FPX_ERR_ARG, "nests_init: nest outside the mother grid (gridcheck_nests.f90:381)");
+      V.nxn[l] = n->nxn[l]; V.nyn[l] = n->nyn[l];
+      V.xln[l] = (R)n->xln[l]; V.yln[l] = (R)n->yln[l]; V.xrn[l] = (R)n->xrn[l]; V.yrn[l] = (R)n->yrn[l];
+      V.xresoln[l] = (R)n->xresoln[l]; V.yresoln[l] = (R)n->yresoln[l];
+      const size_t ncol = (size_t)n->nxn[l] * n->nyn[l], nlev = ncol * cfg.nz;
+      R *p;
+      if ((rc = dalloc(&p, nlev * 6))) return rc; V.w3n[l] = p;
+      if ((rc = dalloc(&p, nlev * 4))) return rc; V.r2n[l] = p;
+      if ((rc = dalloc(&p, ncol * 8))) return rc; V.sfcn[l] = p;
+      if ((rc = dalloc(&p, ncol))) return rc; V.hcelln[l] = p;
+      if ((rc = dalloc(&p, ncol))) return rc; V.tropon[l] = p;
+      if (cfg.drydep) { if ((rc = dalloc(&p, ncol * 2 * cfg.nspec))) return rc; V.vdepn[l] = p; }
+    }
+    nest_nxmaxn = n->nxmaxn; nest_nymaxn = n->nymaxn;
+    V.numbnests = n->numbnests;
+    return 0;
+  }
+  int upload_nest_fields(int nest, int slot, const fpx_fields *f) override {
+    if (nest < 1 || nest > V.numbnests) return fail(FPX_ERR_ARG, "upload_nest_fields: nest out of range (fpx_nests_init first)");
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "upload_nest_fields: slot must be 1 or 2");
+    if (!f || !f->uu || !f->vv || !f->ww || !f->rho || !f->drhodz || !f->hmix || !f->ustar || !f->wstar || !f->oli || !f->tropopause)
+      return fail(FPX_ERR_ARG, "upload_nest_fields: uun, vvn, wwn, rhon, drhodzn, hmixn, ustarn, wstarn, olin, tropopausen are required");
+    if (cfg.drydep && !f->vdep) return fail(FPX_ERR_ARG, "upload_nest_fields: vdepn required with DRYDEP");
+    const int l = nest - 1, s = slot - 1;
+    g_nx = V.nxn[l]; g_ny = V.nyn[l]; g_nxmax = nest_nxmaxn; g_nymax = nest_nymaxn;
+    int rc = 0;
+    do {
+      if ((rc = p3(f->uu, V.w3n[l], 6, s * 3 + 0))) break;
+      if ((rc = p3(f->vv, V.w3n[l], 6, s * 3 + 1))) break;
+      if ((rc = p3(f->ww, V.w3n[l], 6, s * 3 + 2))) break;
+      if ((rc = p3(f->rho, V.r2n[l], 4, s * 2 + 0))) break;
+      if ((rc = p3(f->drhodz, V.r2n[l], 4, s * 2 + 1))) break;
+      if ((rc = p2(f->ustar, V.sfcn[l], 8, s * 4 + 0))) break;
+      if ((rc = p2(f->wstar, V.sfcn[l], 8, s * 4 + 1))) break;
+      if ((rc = p2(f->oli, V.sfcn[l], 8, s * 4 + 2))) break;
+      if ((rc = p2(f->hmix, V.sfcn[l], 8, s * 4 + 3))) break;
+      if (slot == 1 && (rc = p2(f->tropopause, V.tropon[l], 1, 0))) break;   // tropopausen(nix,njy,1,1,ngrid), advance.f90:263
+      if (V.vdepn[l]) {
+        const size_t plane = (size_t)nest_nxmaxn * nest_nymaxn * cfg.host_real_bytes;
+        for (int ks = 0; ks < cfg.nspec && !rc; ks++) rc = p2((const char *)f->vdep + plane * ks, V.vdepn[l], 2 * cfg.nspec, s * cfg.nspec + ks);
+      }
+    } while (0);
+    const int nxl = g_nx, nyl = g_ny;
+    g_nx = cfg.nx; g_ny = cfg.ny; g_nxmax = cfg.nxmax; g_nymax = cfg.nymax;
+    if (rc) return rc;
+    int tot = nxl * nyl;
+    k_hcell<R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>(V.sfcn[l], (R *)V.hcelln[l], nxl, nyl);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    nest_loaded[l][s] = true;
+    return 0;
+  }
+
   // ---- wet deposition -----------------------------------------------------------
   int wet_init(const fpx_wet_config *w) override {
     if (!w || w->struct_bytes != (int32_t)sizeof(fpx_wet_config)) return fail(FPX_ERR_ARG, "wet_init: null or fpx_wet_config size mismatch (ABI)");
@@ -1596,6 +1668,8 @@ int fpx_comm_unique_id(void *id, int32_t nbytes) {
   return FPX_OK;
 }
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
+int fpx_nests_init(fpx_handle h, const fpx_nests *n) { FPX_GUARD(h); return h->impl->nests_init(n); }
+int fpx_upload_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_fields *f) { FPX_GUARD(h); return h->impl->upload_nest_fields(nest, slot, f); }
 int fpx_wet_init(fpx_handle h, const fpx_wet_config *w) { FPX_GUARD(h); return h->impl->wet_init(w); }
 int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f) { FPX_GUARD(h); return h->impl->upload_wet_fields(slot, f); }
 int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext) { FPX_GUARD(h); return h->impl->wetdepo(itime, ltsample, loutnext); }

@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FpxConfig, FpxFields, FpxOutgrid, FpxParticles, FpxStepStats, FpxWetConfig, FpxWetFields, RNG_PHILOX,
+from ._lib import (FpxConfig, FpxFields, FpxNests, FpxOutgrid, FpxParticles, FpxStepStats, FpxWetConfig, FpxWetFields, RNG_PHILOX,
                    RNG_TABLE_COUNTER, RNG_TABLE_SEQ, check)
 
 # polar stereographic set-up is host work in the reference (gridcheck_ecmwf.f90:341-366 via
@@ -85,6 +85,9 @@ class Engine:
         cfg.rng_mode = rng_mode
         cfg.seed = seed
         cfg.sort_interval = sort_interval
+        # eps = nxmax/3.e5 uses the par_mod nxmax of the host build (advance.f90:107); scenarios carry
+        # it so that runs compare with the reference binary they were pinned against (361 or 721)
+        cfg.par_nxmax = int(sc.get("par_nxmax", 361))
         self.cfg = cfg
         self.h = C.c_void_p()
         check(self.lib.fpx_create(C.byref(self.h), C.byref(cfg)), "fpx_create")
@@ -97,6 +100,8 @@ class Engine:
             check(self.lib.fpx_rng_fill_table(self.h), "fpx_rng_fill_table")
         if "uu" in sc:
             self.upload_fields_from_scenario(sc)
+        if "nest" in sc:
+            self.upload_nests_from_scenario(sc)
         if n:
             self.upload_particles_from_scenario(sc)
         self.gshape = None
@@ -136,6 +141,38 @@ class Engine:
                 f.vdep = v.ctypes.data
             check(self.lib.fpx_upload_fields(self.h, m + 1, C.byref(f)), "fpx_upload_fields")
         self.set_windtime(sc["memtime"], sc["memind"])
+
+    def upload_nests_from_scenario(self, sc):
+        """One nested grid: geometry as gridcheck_nests.f90:362-378 derives it, fields uun, vvn, ..."""
+        rt = self.hreal
+        nxn, nyn = (int(v) for v in sc["nest"])
+        dxn, dyn, xlon0n, ylat0n = (rt(v) for v in sc["nestgeom"])
+        dx, dy, xlon0, ylat0 = (rt(self.cfg.dx), rt(self.cfg.dy), rt(self.cfg.xlon0), rt(self.cfg.ylat0))
+        n = FpxNests()
+        n.struct_bytes = C.sizeof(FpxNests)
+        n.numbnests = 1
+        n.nxmaxn, n.nymaxn = nxn, nyn
+        n.nxn[0], n.nyn[0] = nxn, nyn
+        xaux2 = xlon0n + rt(nxn - 1) * dxn
+        yaux2 = ylat0n + rt(nyn - 1) * dyn
+        n.xresoln[0] = float(dx / dxn); n.yresoln[0] = float(dy / dyn)
+        n.xln[0] = float((xlon0n - xlon0) / dx); n.xrn[0] = float((xaux2 - xlon0) / dx)
+        n.yln[0] = float((ylat0n - ylat0) / dy); n.yrn[0] = float((yaux2 - ylat0) / dy)
+        check(self.lib.fpx_nests_init(self.h, C.byref(n)), "fpx_nests_init")
+        for m in (0, 1):
+            keep = {}
+            f = FpxFields()
+            for k, kn in (("uu", "uun"), ("vv", "vvn"), ("ww", "wwn"), ("rho", "rhon"), ("drhodz", "drhodzn")):
+                keep[k] = np.ascontiguousarray(np.asarray(sc[kn])[m].astype(rt))
+                setattr(f, k, keep[k].ctypes.data)
+            for k, kn in (("hmix", "hmixn"), ("ustar", "ustarn"), ("wstar", "wstarn"), ("oli", "olin"),
+                          ("tropopause", "tropopausen")):
+                keep[k] = np.ascontiguousarray(np.asarray(sc[kn])[m].astype(rt))
+                setattr(f, k, keep[k].ctypes.data)
+            if "vdepn" in sc:
+                keep["vdep"] = np.ascontiguousarray(np.asarray(sc["vdepn"])[m].astype(rt))
+                f.vdep = keep["vdep"].ctypes.data
+            check(self.lib.fpx_upload_nest_fields(self.h, 1, m + 1, C.byref(f)), "fpx_upload_nest_fields")
 
     def set_windtime(self, memtime, memind):
         mt = (C.c_int32 * 2)(int(memtime[0]), int(memtime[1]))

@@ -25,6 +25,9 @@ module flexgpu_mod
   public :: fpx_step_stats, flexgpu_init, flexgpu_finalize, flexgpu_upload_fields, &
             flexgpu_set_windtime, flexgpu_upload_particles, flexgpu_download_particles, &
             flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error
+#ifdef FLEXGPU_NESTS
+  public :: flexgpu_upload_nests
+#endif
 
   integer, parameter :: FPX_MAXSPEC = 5
 
@@ -50,7 +53,8 @@ module flexgpu_mod
     integer(c_int32_t) :: rng_mode
     integer(c_int64_t) :: seed
     integer(c_int32_t) :: sort_interval
-    integer(c_int32_t) :: reserved(7)
+    integer(c_int32_t) :: par_nxmax
+    integer(c_int32_t) :: reserved(6)
   end type fpx_config
 
   type, bind(C) :: fpx_fields
@@ -58,6 +62,14 @@ module flexgpu_mod
     type(c_ptr) :: hmix, ustar, wstar, oli, tropopause
     type(c_ptr) :: vdep
   end type fpx_fields
+
+  integer, parameter :: FPX_MAXNESTS = 4
+  type, bind(C) :: fpx_nests
+    integer(c_int32_t) :: struct_bytes, numbnests, nxmaxn, nymaxn
+    integer(c_int32_t) :: nxn(FPX_MAXNESTS), nyn(FPX_MAXNESTS)
+    real(c_double) :: xln(FPX_MAXNESTS), yln(FPX_MAXNESTS), xrn(FPX_MAXNESTS), yrn(FPX_MAXNESTS)
+    real(c_double) :: xresoln(FPX_MAXNESTS), yresoln(FPX_MAXNESTS)
+  end type fpx_nests
 
   type, bind(C) :: fpx_particles
     type(c_ptr) :: xtra1, ytra1
@@ -96,6 +108,17 @@ module flexgpu_mod
       import :: c_ptr, c_int, c_int32_t, fpx_fields
       type(c_ptr), value :: h
       integer(c_int32_t), value :: slot
+      type(fpx_fields), intent(in) :: f
+    end function
+    integer(c_int) function fpx_nests_init(h, n) bind(C, name='fpx_nests_init')
+      import :: c_ptr, c_int, fpx_nests
+      type(c_ptr), value :: h
+      type(fpx_nests), intent(in) :: n
+    end function
+    integer(c_int) function fpx_upload_nest_fields(h, nest, slot, f) bind(C, name='fpx_upload_nest_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: nest, slot
       type(fpx_fields), intent(in) :: f
     end function
     integer(c_int) function fpx_set_windtime(h, mt, mi) bind(C, name='fpx_set_windtime')
@@ -209,6 +232,7 @@ contains
     cfg%rng_mode = 0; if (present(rng_mode)) cfg%rng_mode = rng_mode
     cfg%seed = 24301_c_int64_t; if (present(seed)) cfg%seed = seed
     cfg%sort_interval = 8
+    cfg%par_nxmax = nxmax          ! eps = nxmax/3.e5, advance.f90:107
     cfg%reserved = 0
     ierr = fpx_create(flexgpu_handle, cfg)
     if (ierr /= 0) return
@@ -240,6 +264,40 @@ contains
     f%vdep = loc_r(vdep(0,0,1,slot))
     ierr = fpx_upload_fields(flexgpu_handle, int(slot, c_int32_t), f)
   end subroutine flexgpu_upload_fields
+
+#ifdef FLEXGPU_NESTS
+  ! nested grids: geometry (gridcheck_nests.f90:362-378) and both time slots of every nest.
+  ! Compiled only against a par_mod with maxnests >= 1 (zero-sized nest arrays otherwise).
+  subroutine flexgpu_upload_nests(ierr)
+    integer, intent(out) :: ierr
+    type(fpx_nests) :: n
+    type(fpx_fields) :: f
+    integer :: l, k, slot
+    n%struct_bytes = int(c_sizeof(n), c_int32_t)
+    n%numbnests = numbnests; n%nxmaxn = nxmaxn; n%nymaxn = nymaxn
+    n%nxn = 0; n%nyn = 0; n%xln = 0; n%yln = 0; n%xrn = 0; n%yrn = 0; n%xresoln = 1; n%yresoln = 1
+    do l = 1, numbnests
+      n%nxn(l) = nxn(l); n%nyn(l) = nyn(l)
+      n%xln(l) = xln(l); n%yln(l) = yln(l); n%xrn(l) = xrn(l); n%yrn(l) = yrn(l)
+      n%xresoln(l) = xresoln(l); n%yresoln(l) = yresoln(l)
+    end do
+    ierr = fpx_nests_init(flexgpu_handle, n)
+    if (ierr /= 0) return
+    do l = 1, numbnests
+      do k = 1, 2
+        slot = memind(k)
+        f%uu = loc_r(uun(0:,0,1,slot,l)); f%vv = loc_r(vvn(0:,0,1,slot,l)); f%ww = loc_r(wwn(0:,0,1,slot,l))
+        f%uupol = c_null_ptr; f%vvpol = c_null_ptr; f%tt = c_null_ptr
+        f%rho = loc_r(rhon(0:,0,1,slot,l)); f%drhodz = loc_r(drhodzn(0:,0,1,slot,l))
+        f%hmix = loc_r(hmixn(0,0,1,slot,l)); f%ustar = loc_r(ustarn(0,0,1,slot,l)); f%wstar = loc_r(wstarn(0,0,1,slot,l))
+        f%oli = loc_r(olin(0,0,1,slot,l)); f%tropopause = loc_r(tropopausen(0,0,1,slot,l))
+        f%vdep = loc_r(vdepn(0,0,1,slot,l))
+        ierr = fpx_upload_nest_fields(flexgpu_handle, int(l, c_int32_t), int(slot, c_int32_t), f)
+        if (ierr /= 0) return
+      end do
+    end do
+  end subroutine flexgpu_upload_nests
+#endif
 
   subroutine flexgpu_set_windtime(ierr)
     integer, intent(out) :: ierr

@@ -380,3 +380,25 @@ def add_wet(sc, *, gas=False):
         if float(np.asarray(sc["dquer"])[0]) <= 0.0:
             sc["dquer"] = np.array([8.0])
     return sc
+
+
+def add_nest(sc, ix0=None, jy0=None, ix1=None, jy1=None, factor=2):
+    """One nested grid of `factor` times the mother resolution over mother cells [ix0,ix1]x[jy0,jy1]
+    (com_mod.f90:464-541 arrays uun, vvn, ... ; geometry as gridcheck_nests.f90 derives it)."""
+    nx, ny, nz = (int(v) for v in sc["grid"])
+    dx, dy, xlon0, ylat0 = (float(v) for v in sc["geom"])
+    ix0 = nx // 4 if ix0 is None else ix0
+    ix1 = (2 * nx) // 3 if ix1 is None else ix1
+    jy0 = ny // 4 if jy0 is None else jy0
+    jy1 = (3 * ny) // 4 if jy1 is None else jy1
+    nxn = factor * (ix1 - ix0) + 1
+    nyn = factor * (jy1 - jy0) + 1
+    f = make_fields(nxn, nyn, nz, sc["height"], nspec=int(sc["nspec"]))
+    sc["nest"] = np.array([nxn, nyn], np.int32)
+    sc["nestgeom"] = np.array([dx / factor, dy / factor, xlon0 + ix0 * dx, ylat0 + jy0 * dy], np.float64)
+    for k, kn in (("uu", "uun"), ("vv", "vvn"), ("ww", "wwn"), ("rho", "rhon"), ("drhodz", "drhodzn"),
+                  ("hmix", "hmixn"), ("ustar", "ustarn"), ("wstar", "wstarn"), ("oli", "olin"),
+                  ("tropopause", "tropopausen"), ("vdep", "vdepn")):
+        sc[kn] = f[k] * (1.1 if k in ("uu", "vv") else 1.0)   # not the mother's values: a wrong grid choice shows
+    sc["par_nxmax"] = 721        # the reference variant with nests is built from par_mod_meteoswiss.f90
+    return sc

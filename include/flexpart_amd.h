@@ -90,7 +90,9 @@ typedef struct {
   uint64_t seed;             /* counter modes                                           */
   /* locality: re-sort particles by grid cell every `sort_interval` steps (0 = never) */
   int32_t sort_interval;
-  int32_t reserved[7];
+  /* par_mod nxmax of the HOST build, used for eps = nxmax/3.e5 (advance.f90:107); 0: use nxmax */
+  int32_t par_nxmax;
+  int32_t reserved[6];
 } fpx_config;
 
 /* One time slot of the met fields the path gathers from (com_mod.f90:355-371,
@@ -150,6 +152,21 @@ int fpx_set_height(fpx_handle h, const void *height, int32_t n);
 int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]);
+
+/* ---- nested grids (com_mod.f90:464-541; geometry from gridcheck_nests.f90:362-378) -------- */
+typedef struct {
+  int32_t struct_bytes;
+  int32_t numbnests;
+  int32_t nxmaxn, nymaxn;                 /* allocated extents of the host nest arrays (par_mod) */
+  int32_t nxn[FPX_MAXNESTS], nyn[FPX_MAXNESTS];
+  double xln[FPX_MAXNESTS], yln[FPX_MAXNESTS], xrn[FPX_MAXNESTS], yrn[FPX_MAXNESTS];
+  double xresoln[FPX_MAXNESTS], yresoln[FPX_MAXNESTS];   /* entries 1..numbnests of the host arrays */
+} fpx_nests;
+int fpx_nests_init(fpx_handle h, const fpx_nests *n);
+/* One time slot of one nest (nest = 1..numbnests): pointers to element (0,0,1,slot,nest) of
+ * uun, vvn, wwn, rhon, drhodzn (com_mod.f90:501-502), hmixn, ustarn, wstarn, olin, tropopausen
+ * (:523-527), vdepn (:529); strides nxmaxn, nymaxn, nzmax.  uupol/vvpol/tt are ignored. */
+int fpx_upload_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_fields *f);
 
 /* ---- RNG ------------------------------------------------------------------ */
 /* Build rannumb exactly as FLEXPART.f90:47,56-59 does (seed -320, gasdev1 over

@@ -26,12 +26,15 @@ conccalc drydepokernel drydepokernel_nest wetdepo get_wetscav interpol_rain inte
 
 build_one() {
   local kind="$1"; shift
+  local parmod="$1"; shift      # which of the reference's par_mod files supplies the compile-time sizes
   local flags="$*"
   local obj="$OUT/obj_$kind"
   mkdir -p "$obj"
   ( cd "$obj"
     for m in $MODS; do
-      [ "$obj/$m.o" -nt "$REF/$m.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$m.f90" -o "$m.o"
+      src="$REF/$m.f90"
+      [ "$m" = "par_mod" ] && src="$REF/$parmod"
+      [ "$obj/$m.o" -nt "$src" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$src" -o "$m.o"
     done
     for s in $SUBS; do
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
@@ -52,5 +55,8 @@ build_one() {
 }
 
 mkdir -p "$OUT"
-build_one r4
-build_one r8 -fdefault-real-8
+build_one r4 par_mod.f90
+build_one r8 par_mod.f90 -fdefault-real-8
+# nested-grid variant: the stock par_mod.f90 has maxnests=0; the reference's own
+# par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path
+build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS

@@ -109,6 +109,7 @@ typedef struct {
      are replaced by the particle's own values -- what an order-independent (parallel)
      engine computes; see DESIGN.md "deviations" D1/D2. */
   int parallel_semantics;
+  real eps_nxmax;                  /* par_mod nxmax of the build being mirrored (eps = nxmax/3.e5) */
   /* ---- output grid (com_mod.f90:583-586, outg_mod outheight, unc_mod gridunc/drygridunc) */
   int numxgrid, numygrid, numzgrid, maxpointspec_act, nclassunc, nageclass, maxspec_out;
   int lage[8];
@@ -132,6 +133,10 @@ typedef struct {
 #define F2(f, i, j, m)    ((f)[((size_t)((m) - 1) * c->ny + (size_t)(j)) * c->nx + (size_t)(i)])
 #define FV(f, i, j, ks, m) ((f)[((((size_t)((m) - 1) * c->nspec + (size_t)((ks) - 1)) * c->ny + (size_t)(j)) * c->nx) + (size_t)(i)])
 #define HGT(k) (c->height[(k) - 1])
+/* nest l (1-based): compact [slot][level][jyn][ixn] */
+#define N3(f, i, j, k, m, l) ((f)[(((size_t)((m) - 1) * c->nz + (size_t)((k) - 1)) * c->nyn[(l) - 1] + (size_t)(j)) * c->nxn[(l) - 1] + (size_t)(i)])
+#define N2(f, i, j, m, l) ((f)[((size_t)((m) - 1) * c->nyn[(l) - 1] + (size_t)(j)) * c->nxn[(l) - 1] + (size_t)(i)])
+#define NV(f, i, j, ks, m, l) ((f)[((((size_t)((m) - 1) * c->nspec + (size_t)((ks) - 1)) * c->nyn[(l) - 1] + (size_t)(j)) * c->nxn[(l) - 1]) + (size_t)(i)])
 
 /* ------------------------------------------------------------------------- */
 /* RNG: random_mod.f90                                                         */
@@ -366,6 +371,121 @@ static void orc_interpol_vdep(orc_ctx *c, int level, real *vdepo) {
   for (m = 0; m < 2; m++) {
     int indexh = c->memind[m];
     y[m] = c->p1 * FV(c->vdep, ix, jy, level, indexh) + c->p2 * FV(c->vdep, ixp, jy, level, indexh) + c->p3 * FV(c->vdep, ix, jyp, level, indexh) + c->p4 * FV(c->vdep, ixp, jyp, level, indexh);
+  }
+  *vdepo = (y[0] * c->dt2 + y[1] * c->dt1) * c->dtt;
+  c->depoindicator[level - 1] = 0;
+}
+
+/* ---- nested-grid variants: interpol_all_nests.f90, interpol_misslev_nests.f90,
+   interpol_wind_nests.f90, interpol_wind_short_nests.f90, interpol_vdep_nests.f90.
+   Same arithmetic on the 5-D nest arrays; no polar branch. ------------------------------ */
+#define BILN(f, n, m) (c->p1 * N3(f, ix, jy, n, m, l) + c->p2 * N3(f, ixp, jy, n, m, l) + c->p3 * N3(f, ix, jyp, n, m, l) + c->p4 * N3(f, ixp, jyp, n, m, l))
+#define SUM4N(acc, f, n, m) ((((acc) + N3(f, ix, jy, n, m, l)) + N3(f, ixp, jy, n, m, l)) + N3(f, ix, jyp, n, m, l)) + N3(f, ixp, jyp, n, m, l)
+#define SQ4N(acc, f, n, m) ((((acc) + N3(f, ix, jy, n, m, l) * N3(f, ix, jy, n, m, l)) + N3(f, ixp, jy, n, m, l) * N3(f, ixp, jy, n, m, l)) + N3(f, ix, jyp, n, m, l) * N3(f, ix, jyp, n, m, l)) + N3(f, ixp, jyp, n, m, l) * N3(f, ixp, jyp, n, m, l)
+
+static void orc_profile_level_nests(orc_ctx *c, int n) {   /* interpol_misslev_nests.f90:56-129 == interpol_all_nests.f90 loop body */
+  const real eps = K(1.0e-30);
+  real y1[2], y2[2], y3[2], rho1[2], rhograd1[2];
+  real usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0, xaux;
+  int m, ix = c->ix, jy = c->jy, ixp = c->ixp, jyp = c->jyp, l = c->ngrid;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    y1[m] = BILN(c->uun[l - 1], n, indexh);
+    y2[m] = BILN(c->vvn[l - 1], n, indexh);
+    y3[m] = BILN(c->wwn[l - 1], n, indexh);
+    rhograd1[m] = BILN(c->drhodzn[l - 1], n, indexh);
+    rho1[m] = BILN(c->rhon[l - 1], n, indexh);
+    usl = SUM4N(usl, c->uun[l - 1], n, indexh);
+    vsl = SUM4N(vsl, c->vvn[l - 1], n, indexh);
+    wsl = SUM4N(wsl, c->wwn[l - 1], n, indexh);
+    usq = SQ4N(usq, c->uun[l - 1], n, indexh);
+    vsq = SQ4N(vsq, c->vvn[l - 1], n, indexh);
+    wsq = SQ4N(wsq, c->wwn[l - 1], n, indexh);
+  }
+  c->uprof[n] = (y1[0] * c->dt2 + y1[1] * c->dt1) * c->dtt;
+  c->vprof[n] = (y2[0] * c->dt2 + y2[1] * c->dt1) * c->dtt;
+  c->wprof[n] = (y3[0] * c->dt2 + y3[1] * c->dt1) * c->dtt;
+  c->rhoprof[n] = (rho1[0] * c->dt2 + rho1[1] * c->dt1) * c->dtt;
+  c->rhogradprof[n] = (rhograd1[0] * c->dt2 + rhograd1[1] * c->dt1) * c->dtt;
+  c->indzindicator[n] = 0;
+  xaux = usq - usl * usl / K(8.);
+  c->usigprof[n] = xaux < eps ? K(0.) : r_sqrt(xaux / K(7.));
+  xaux = vsq - vsl * vsl / K(8.);
+  c->vsigprof[n] = xaux < eps ? K(0.) : r_sqrt(xaux / K(7.));
+  xaux = wsq - wsl * wsl / K(8.);
+  c->wsigprof[n] = xaux < eps ? K(0.) : r_sqrt(xaux / K(7.));
+}
+
+static void orc_interpol_all_nests(orc_ctx *c, int itime, real xt, real yt, real zt) {   /* interpol_all_nests.f90:57-219 */
+  real ust1[2], wst1[2], oli1[2], oliaux;
+  int m, n, ix, jy, ixp, jyp, l = c->ngrid;
+  orc_hweights(c, itime, xt, yt);
+  ix = c->ix; jy = c->jy; ixp = c->ixp; jyp = c->jyp;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    ust1[m] = c->p1 * N2(c->ustarn[l - 1], ix, jy, indexh, l) + c->p2 * N2(c->ustarn[l - 1], ixp, jy, indexh, l) + c->p3 * N2(c->ustarn[l - 1], ix, jyp, indexh, l) + c->p4 * N2(c->ustarn[l - 1], ixp, jyp, indexh, l);
+    wst1[m] = c->p1 * N2(c->wstarn[l - 1], ix, jy, indexh, l) + c->p2 * N2(c->wstarn[l - 1], ixp, jy, indexh, l) + c->p3 * N2(c->wstarn[l - 1], ix, jyp, indexh, l) + c->p4 * N2(c->wstarn[l - 1], ixp, jyp, indexh, l);
+    oli1[m] = c->p1 * N2(c->olin[l - 1], ix, jy, indexh, l) + c->p2 * N2(c->olin[l - 1], ixp, jy, indexh, l) + c->p3 * N2(c->olin[l - 1], ix, jyp, indexh, l) + c->p4 * N2(c->olin[l - 1], ixp, jyp, indexh, l);
+  }
+  c->ust = (ust1[0] * c->dt2 + ust1[1] * c->dt1) * c->dtt;
+  c->wst = (wst1[0] * c->dt2 + wst1[1] * c->dt1) * c->dtt;
+  oliaux = (oli1[0] * c->dt2 + oli1[1] * c->dt1) * c->dtt;
+  c->ol = oliaux != K(0.) ? K(1.) / oliaux : K(99999.);
+  orc_find_level(c, zt, 1);
+  for (n = c->indz; n <= c->indz + 1; n++) orc_profile_level_nests(c, n);
+}
+
+static void orc_interpol_wind_nests(orc_ctx *c, int itime, real xt, real yt, real zt, int with_sigma) {   /* interpol_wind_nests.f90 / interpol_wind_short_nests.f90 */
+  const real eps = K(1.0e-30);
+  real dz1, dz2, dz, u1[2], v1[2], w1[2], uh[2], vh[2], wh[2];
+  real usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0, xaux;
+  int m, n, ix, jy, ixp, jyp, l = c->ngrid;
+  orc_hweights(c, itime, xt, yt);
+  ix = c->ix; jy = c->jy; ixp = c->ixp; jyp = c->jyp;
+  orc_find_level(c, zt, 0);
+  dz = K(1.) / (HGT(c->indz + 1) - HGT(c->indz));
+  dz1 = (zt - HGT(c->indz)) * dz;
+  dz2 = (HGT(c->indz + 1) - zt) * dz;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    for (n = 0; n < 2; n++) {
+      int indzh = c->indz + n;
+      u1[n] = BILN(c->uun[l - 1], indzh, indexh);
+      v1[n] = BILN(c->vvn[l - 1], indzh, indexh);
+      w1[n] = BILN(c->wwn[l - 1], indzh, indexh);
+      if (with_sigma) {
+        usl = SUM4N(usl, c->uun[l - 1], indzh, indexh);
+        vsl = SUM4N(vsl, c->vvn[l - 1], indzh, indexh);
+        wsl = SUM4N(wsl, c->wwn[l - 1], indzh, indexh);
+        usq = SQ4N(usq, c->uun[l - 1], indzh, indexh);
+        vsq = SQ4N(vsq, c->vvn[l - 1], indzh, indexh);
+        wsq = SQ4N(wsq, c->wwn[l - 1], indzh, indexh);
+      }
+    }
+    uh[m] = dz2 * u1[0] + dz1 * u1[1];
+    vh[m] = dz2 * v1[0] + dz1 * v1[1];
+    wh[m] = dz2 * w1[0] + dz1 * w1[1];
+  }
+  c->u = (uh[0] * c->dt2 + uh[1] * c->dt1) * c->dtt;
+  c->v = (vh[0] * c->dt2 + vh[1] * c->dt1) * c->dtt;
+  c->w = (wh[0] * c->dt2 + wh[1] * c->dt1) * c->dtt;
+  if (with_sigma) {
+    xaux = usq - usl * usl / K(16.);
+    c->usig = xaux < eps ? K(0.) : r_sqrt(xaux / K(15.));
+    xaux = vsq - vsl * vsl / K(16.);
+    c->vsig = xaux < eps ? K(0.) : r_sqrt(xaux / K(15.));
+    xaux = wsq - wsl * wsl / K(16.);
+    c->wsig = xaux < eps ? K(0.) : r_sqrt(xaux / K(15.));
+  }
+}
+
+static void orc_interpol_vdep_nests(orc_ctx *c, int level, real *vdepo) {   /* interpol_vdep_nests.f90:39-53 */
+  real y[2];
+  int m, ix = c->ix, jy = c->jy, ixp = c->ixp, jyp = c->jyp, l = c->ngrid;
+  for (m = 0; m < 2; m++) {
+    int indexh = c->memind[m];
+    y[m] = c->p1 * NV(c->vdepn[l - 1], ix, jy, level, indexh, l) + c->p2 * NV(c->vdepn[l - 1], ixp, jy, level, indexh, l) +
+           c->p3 * NV(c->vdepn[l - 1], ix, jyp, level, indexh, l) + c->p4 * NV(c->vdepn[l - 1], ixp, jyp, level, indexh, l);
   }
   *vdepo = (y[0] * c->dt2 + y[1] * c->dt1) * c->dtt;
   c->depoindicator[level - 1] = 0;
@@ -984,14 +1104,14 @@ static void orc_move(orc_ctx *c, double *xt, double *yt, real du, real dv, real 
 static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up, real *vp, real *wp,
                        real *usigold, real *vsigold, real *wsigold, double *xt, double *yt, real *zt,
                        real *prob, int16_t *icbt) {
-  const real eps = K(361) / K(3.e5);   /* nxmax/3.e5, par_mod.f90:144 (nxmax=361) */
+  const real eps = c->eps_nxmax / K(3.e5);   /* nxmax/3.e5: advance.f90:107 with the build's par_mod nxmax */
   const real eps2 = K(1.e-9);
   const real href = K(15.);
   int itimec, i, k, nrand, loop, ngr, nix, njy, ks, mind, flagrein;
   real xts, yts, dz, dz1, dz2, ru, rv, rw, dt, ux, vy, tropop, dxsave, dysave, dawsave, dcwsave;
   real r, rs, uold, vold, wold, vdepo[ORC_MAXSPEC], rhoa, rhograd, delz = 0, dtf, rhoaux, dtftlw, uxscale, wpscale, weight;
   real ptot_lhh, Q_lhh, phi_lhh, ath, bth, old_wp_buf, del_test;
-  double xtn = 0, ytn = 0;
+  real xtn = 0, ytn = 0;
   (void)nrelpoint;
 
   /* advance.f90:133-153 */
@@ -1007,10 +1127,10 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
 
   /* :191-231 */
   if (c->ngrid > 0) {
-    xtn = (*xt - (double)c->xln[c->ngrid - 1]) * (double)c->xresoln[c->ngrid - 1];
-    ytn = (*yt - (double)c->yln[c->ngrid - 1]) * (double)c->yresoln[c->ngrid - 1];
+    xtn = (real)((*xt - (double)c->xln[c->ngrid - 1]) * (double)c->xresoln[c->ngrid - 1]);
+    ytn = (real)((*yt - (double)c->yln[c->ngrid - 1]) * (double)c->yresoln[c->ngrid - 1]);
     c->ix = (int)xtn; c->jy = (int)ytn;
-    nix = (int)lround(xtn); njy = (int)lround(ytn);
+    nix = (int)lround((double)xtn); njy = (int)lround((double)ytn);
   } else {
     c->ix = (int)*xt; c->jy = (int)*yt;
     nix = (int)lround(*xt); njy = (int)lround(*yt);
@@ -1028,7 +1148,7 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
   c->dt1 = (real)(itime - c->memtime[0]);
   c->dt2 = (real)(c->memtime[1] - itime);
   c->dtt = K(1.) / (c->dt1 + c->dt2);
-  if (c->jyp >= c->ny) c->jyp = c->jyp - 1;   /* :228-231 (nymax == ny here: compact layout) */
+  if (c->jyp >= (c->ngrid > 0 ? c->nyn[c->ngrid - 1] : c->ny)) c->jyp = c->jyp - 1;   /* :228-231 (compact layouts: the row count of the grid in use) */
 
   /* :236-267, interpolhmix = .false. */
   c->h = K(0.);
@@ -1041,8 +1161,16 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
           if (F2(c->hmix, ii, jj, mind) > c->h) c->h = F2(c->hmix, ii, jj, mind);
     }
     tropop = F2(c->tropopause, nix, njy, 1);
-  } else {
-    tropop = K(0.);  /* nests: see orc_*_nests (not yet restated) */
+  } else {   /* :255-263 */
+    const int l = c->ngrid;
+    for (k = 0; k < 2; k++) {
+      int jj, ii;
+      mind = c->memind[k];
+      for (jj = c->jy; jj <= c->jyp; jj++)
+        for (ii = c->ix; ii <= c->ixp; ii++)
+          if (N2(c->hmixn[l - 1], ii, jj, mind, l) > c->h) c->h = N2(c->hmixn[l - 1], ii, jj, mind, l);
+    }
+    tropop = N2(c->tropopausen[l - 1], nix, njy, 1, l);
   }
   c->zeta = *zt / c->h;
 
@@ -1063,14 +1191,18 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
     c->zeta = *zt / c->h;
 
     if (loop == 1) {
-      xts = (real)*xt;
-      yts = (real)*yt;
-      orc_interpol_all(c, itime, xts, yts, *zt);
+      if (c->ngrid <= 0) {
+        xts = (real)*xt;
+        yts = (real)*yt;
+        orc_interpol_all(c, itime, xts, yts, *zt);
+      } else {
+        orc_interpol_all_nests(c, itime, xtn, ytn, *zt);
+      }
     } else {
       for (i = 2; i <= c->nz; i++)
         if (HGT(i) > *zt) { c->indz = i - 1; c->indzp = i; break; }
       for (i = c->indz; i <= c->indzp; i++)
-        if (c->indzindicator[i]) orc_profile_level(c, i);
+        if (c->indzindicator[i]) { if (c->ngrid <= 0) orc_profile_level(c, i); else orc_profile_level_nests(c, i); }
     }
 
     /* :342-350 */
@@ -1213,7 +1345,7 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
     if (c->drydep && *zt < K(2.) * href) {
       for (ks = 1; ks <= c->nspec; ks++) {
         if (c->drydepspec[ks - 1]) {
-          if (c->depoindicator[ks - 1]) orc_interpol_vdep(c, ks, &vdepo[ks - 1]);
+          if (c->depoindicator[ks - 1]) { if (c->ngrid <= 0) orc_interpol_vdep(c, ks, &vdepo[ks - 1]); else orc_interpol_vdep_nests(c, ks, &vdepo[ks - 1]); }
           prob[ks - 1] = K(1.) + (prob[ks - 1] - K(1.)) * r_exp(-vdepo[ks - 1] * r_abs(dt) / (K(2.) * href));
         }
       }
@@ -1232,9 +1364,13 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
 
 L700:
   /* :629-636 */
-  xts = (real)*xt;
-  yts = (real)*yt;
-  orc_interpol_wind(c, itime, xts, yts, *zt, 1);
+  if (c->ngrid <= 0) {
+    xts = (real)*xt;
+    yts = (real)*yt;
+    orc_interpol_wind(c, itime, xts, yts, *zt, 1);
+  } else {
+    orc_interpol_wind_nests(c, itime, xtn, ytn, *zt, 1);
+  }
 
   /* :647-673 */
   *ldt = abs(c->lsynctime - itimec + itime);
@@ -1303,8 +1439,8 @@ L99:
 
   /* :862-872 */
   if (c->ngrid > 0) {
-    xtn = (*xt - (double)c->xln[c->ngrid - 1]) * (double)c->xresoln[c->ngrid - 1];
-    ytn = (*yt - (double)c->yln[c->ngrid - 1]) * (double)c->yresoln[c->ngrid - 1];
+    xtn = (real)((*xt - (double)c->xln[c->ngrid - 1]) * (double)c->xresoln[c->ngrid - 1]);
+    ytn = (real)((*yt - (double)c->yln[c->ngrid - 1]) * (double)c->yresoln[c->ngrid - 1]);
     c->ix = (int)xtn; c->jy = (int)ytn;
   } else {
     c->ix = (int)*xt; c->jy = (int)*yt;
@@ -1314,9 +1450,13 @@ L99:
 
   /* :878-891 */
   uold = c->u; vold = c->v; wold = c->w;
-  xts = (real)*xt;
-  yts = (real)*yt;
-  orc_interpol_wind(c, itime + *ldt * c->ldirect, xts, yts, *zt, 0);
+  if (c->ngrid <= 0) {
+    xts = (real)*xt;
+    yts = (real)*yt;
+    orc_interpol_wind(c, itime + *ldt * c->ldirect, xts, yts, *zt, 0);
+  } else {
+    orc_interpol_wind_nests(c, itime + *ldt * c->ldirect, xtn, ytn, *zt, 0);
+  }
 
   /* :893-906 */
   orc_add_settling(c, itime + *ldt, *xt, *yt, *zt);
@@ -1640,6 +1780,7 @@ orc_ctx *orc_create(void) {
   c->ldirect = 1;
   c->npart_rel = 1;
   c->lage_last = 999999999;
+  c->eps_nxmax = K(361);
   orc_fill_rannumb(c);
   return c;
 }
@@ -1798,6 +1939,27 @@ long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, re
   return nadv;
 }
 
+void orc_set_eps_nxmax(orc_ctx *c, int nxmax) { c->eps_nxmax = (real)nxmax; }
+/* one nest (index 1): geometry as gridcheck_nests.f90:362-378, compact arrays [slot][level][jyn][ixn] */
+void orc_set_nest(orc_ctx *c, int nxn, int nyn, double dxn, double dyn, double xlon0n, double ylat0n,
+                  const real *uun, const real *vvn, const real *wwn, const real *rhon, const real *drhodzn,
+                  const real *hmixn, const real *ustarn, const real *wstarn, const real *olin, const real *tropopausen,
+                  const real *vdepn) {
+  real xaux1 = (real)xlon0n, yaux1 = (real)ylat0n, xaux2, yaux2;
+  c->numbnests = 1;
+  c->nxn[0] = nxn; c->nyn[0] = nyn;
+  xaux2 = xaux1 + (real)(nxn - 1) * (real)dxn;
+  yaux2 = yaux1 + (real)(nyn - 1) * (real)dyn;
+  c->xresoln[0] = c->dx / (real)dxn;
+  c->yresoln[0] = c->dy / (real)dyn;
+  c->xln[0] = (xaux1 - c->xlon0) / c->dx;
+  c->xrn[0] = (xaux2 - c->xlon0) / c->dx;
+  c->yln[0] = (yaux1 - c->ylat0) / c->dy;
+  c->yrn[0] = (yaux2 - c->ylat0) / c->dy;
+  c->uun[0] = uun; c->vvn[0] = vvn; c->wwn[0] = wwn; c->rhon[0] = rhon; c->drhodzn[0] = drhodzn;
+  c->hmixn[0] = hmixn; c->ustarn[0] = ustarn; c->wstarn[0] = wstarn; c->olin[0] = olin; c->tropopausen[0] = tropopausen;
+  c->vdepn[0] = vdepn;
+}
 void orc_set_parallel_semantics(orc_ctx *c, int on) { c->parallel_semantics = on; }
 
 long orc_nan_count(orc_ctx *c, int which) { return which == 2 ? c->nan_count2 : c->nan_count; }

@@ -83,6 +83,16 @@ class Oracle:
             else:
                 ptrs.append(C.c_void_p(0))
         lib.orc_set_fields(self.h, *ptrs)
+        lib.orc_set_eps_nxmax(self.h, int(sc.get("par_nxmax", 361)))
+        if "nest" in sc:
+            nxn, nyn = (int(v) for v in sc["nest"])
+            dxn, dyn, lon0n, lat0n = (float(v) for v in sc["nestgeom"])
+            self.nf = {}
+            nptrs = []
+            for k in ("uun", "vvn", "wwn", "rhon", "drhodzn", "hmixn", "ustarn", "wstarn", "olin", "tropopausen", "vdepn"):
+                self.nf[k] = np.ascontiguousarray(np.asarray(sc[k]).astype(self.rt))
+                nptrs.append(self.nf[k].ctypes.data_as(C.c_void_p))
+            lib.orc_set_nest(self.h, nxn, nyn, C.c_double(dxn), C.c_double(dyn), C.c_double(lon0n), C.c_double(lat0n), *nptrs)
         # particle state
         n = int(sc["npart"])
         self.n = n

@@ -216,6 +216,42 @@ program flexref
     case ('tt');     call fill3(tt, dbuf)
     case ('uupol');  call fill3(uupol, dbuf); have_pol=.true.
     case ('vvpol');  call fill3(vvpol, dbuf); have_pol=.true.
+#ifdef FLEXREF_NESTS
+    ! --- one nested grid (needs a par_mod with maxnests >= 1: the *n build variants) ----------
+    case ('nest')      ! nxn nyn
+      numbnests=1; nxn(1)=ibuf(1); nyn(1)=ibuf(2)
+      if (nxn(1).gt.nxmaxn .or. nyn(1).gt.nymaxn) stop 'nest too large'
+      call com_mod_allocate_nests
+    case ('nestgeom')  ! dxn dyn xlon0n ylat0n ; derived geometry as gridcheck_nests.f90:362-378
+      dxn(1)=dbuf(1); dyn(1)=dbuf(2); xlon0n(1)=dbuf(3); ylat0n(1)=dbuf(4)
+      xresoln(0)=1.; yresoln(0)=1.
+      xresoln(1)=dx/dxn(1)
+      yresoln(1)=dy/dyn(1)
+      xln(1)=(xlon0n(1)-xlon0)/dx
+      xrn(1)=(xlon0n(1)+real(nxn(1)-1)*dxn(1)-xlon0)/dx
+      yln(1)=(ylat0n(1)-ylat0)/dy
+      yrn(1)=(ylat0n(1)+real(nyn(1)-1)*dyn(1)-ylat0)/dy
+    case ('uun');     call fill3n(uun, dbuf)
+    case ('vvn');     call fill3n(vvn, dbuf)
+    case ('wwn');     call fill3n(wwn, dbuf)
+    case ('rhon');    call fill3n(rhon, dbuf)
+    case ('drhodzn'); call fill3n(drhodzn, dbuf)
+    case ('hmixn');   call fill2n(hmixn, dbuf)
+    case ('ustarn');  call fill2n(ustarn, dbuf)
+    case ('wstarn');  call fill2n(wstarn, dbuf)
+    case ('olin');    call fill2n(olin, dbuf)
+    case ('tropopausen'); call fill2n(tropopausen, dbuf)
+    case ('vdepn')    ! compact (nxn,nyn,nspec,2)
+      do m=1,2
+        do ks=1,nspec
+          do j=0,nyn(1)-1
+            do i=0,nxn(1)-1
+              vdepn(i,j,ks,m,1)=dbuf(1+i+nxn(1)*(j+nyn(1)*((ks-1)+nspec*(m-1))))
+            end do
+          end do
+        end do
+      end do
+#endif
     ! --- 2-D fields: compact (nx,ny,2) -----------------------------------------
     case ('hmix');   call fill2(hmix, dbuf)
     case ('ustar');  call fill2(ustar, dbuf)
@@ -318,6 +354,12 @@ program flexref
     if (gerr .ne. 0) call gpu_fail('flexgpu_upload_fields 1')
     call flexgpu_upload_fields(memind(2), gerr)
     if (gerr .ne. 0) call gpu_fail('flexgpu_upload_fields 2')
+#ifdef FLEXREF_NESTS
+    if (numbnests .gt. 0) then
+      call flexgpu_upload_nests(gerr)
+      if (gerr .ne. 0) call gpu_fail('flexgpu_upload_nests')
+    end if
+#endif
     call flexgpu_set_windtime(gerr)
     if (gerr .ne. 0) call gpu_fail('flexgpu_set_windtime')
     call flexgpu_upload_particles(1, numpart, gerr)
@@ -443,6 +485,36 @@ contains
       end do
     end do
   end subroutine fill3
+
+#ifdef FLEXREF_NESTS
+  subroutine fill3n(f, b)
+    real, intent(inout) :: f(0:nxmaxn-1,0:nymaxn-1,nzmax,numwfmem,*)
+    real(kind=8), intent(in) :: b(*)
+    integer :: ii,jj,kk,mm
+    do mm=1,2
+      do kk=1,gnz
+        do jj=0,nyn(1)-1
+          do ii=0,nxn(1)-1
+            f(ii,jj,kk,mm,1)=b(1+ii+nxn(1)*(jj+nyn(1)*((kk-1)+gnz*(mm-1))))
+          end do
+        end do
+      end do
+    end do
+  end subroutine fill3n
+
+  subroutine fill2n(f, b)
+    real, intent(inout) :: f(0:nxmaxn-1,0:nymaxn-1,1,numwfmem,*)
+    real(kind=8), intent(in) :: b(*)
+    integer :: ii,jj,mm
+    do mm=1,2
+      do jj=0,nyn(1)-1
+        do ii=0,nxn(1)-1
+          f(ii,jj,1,mm,1)=b(1+ii+nxn(1)*(jj+nyn(1)*(mm-1)))
+        end do
+      end do
+    end do
+  end subroutine fill2n
+#endif
 
   subroutine fill2(f, b)
     real, intent(inout) :: f(0:nxmax-1,0:nymax-1,1,numwfmem)

@@ -22,13 +22,15 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
           "outgrid", "outgeom", "outheight", "concflags", "outtimes",
           "wetdep", "wetdepspec", "weta_gas", "wetb_gas", "crain_aero", "csnow_aero", "ccn_aero", "in_aero", "henry",
           "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol",
-          "hmix", "ustar", "wstar", "oli", "tropopause", "vdep", "lsprec", "convprec", "tcc", "clouds", "cloudsh",
+          "hmix", "ustar", "wstar", "oli", "tropopause", "vdep",
+          "nest", "nestgeom", "uun", "vvn", "wwn", "rhon", "drhodzn", "hmixn", "ustarn", "wstarn", "olin",
+          "tropopausen", "vdepn", "lsprec", "convprec", "tcc", "clouds", "cloudsh",
           "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
           "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass"]
 _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
         "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
         "drydep", "drydepspec", "lage", "nsteps", "itime0", "npart", "itra1", "itramem",
-        "npoint", "nclass", "idt", "cbt", "outgrid", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh"}
+        "npoint", "nclass", "idt", "cbt", "outgrid", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "nest"}
 
 
 def write_scenario(path, sc):
@@ -46,7 +48,7 @@ def write_scenario(path, sc):
             fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
             fh.write(a.tobytes())
         fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
-    unknown = set(sc) - set(_ORDER)
+    unknown = set(sc) - set(_ORDER) - {"par_nxmax"}
     if unknown:
         raise KeyError(f"scenario keys not understood by the reference driver: {sorted(unknown)}")
 

@@ -63,7 +63,7 @@ def test_fp64_matches_oracle(built, name, kw):
         assert_close(g, w, 1e-9, 1e-7)
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "sampling"])
 def test_fp64_matches_oracle_golden_scenarios(built, name):
     """The scenarios the golden fixtures were made on: polar caps through the stereographic maps
     (cmapf subset), an aerosol species with settling + dry deposition + decay, CBL, Hanna."""
@@ -76,7 +76,7 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
         assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * scale
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "sampling"])
 def test_fp64_against_reference_fixtures(built, name):
     """HIP path directly against the outputs of the unmodified reference (tests/golden, flang r8
     build).  Only particles touched by the two order-dependent leaks of the serial code (DESIGN.md
@@ -188,6 +188,24 @@ def test_counter_rng_is_order_independent(built):
     rc = c.run()
     c.close()
     assert not np.array_equal(ra[-1]["ztra1"], rc[-1]["ztra1"])
+
+
+def test_fortran_host_drop_in_nests(built):
+    """Same drop-in check for the nested-grid reference variant (par_mod_meteoswiss.f90: nxmax=721,
+    maxnests=1): the shim hands the allocatable 5-D nest arrays uun, vvn, ... to the engine."""
+    from oracle import scenario_io as sio
+    if not sio.have_ref("r8n"):
+        pytest.skip("oracle/_ref/flexref_r8n not present in this snapshot")
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario("nest")
+    ref = sio.run_reference(sc, "r8n")
+    gpu = sio.run_reference(sc, "r8n", gpu=True, tag="gpun")
+    n = int(sc["npart"])
+    bad = np.zeros(n, bool)
+    for a, b in zip(gpu["steps"], ref["steps"]):
+        for k in ("xtra1", "ytra1", "ztra1"):
+            bad |= np.abs(a[k] - b[k]) > 1e-9 * np.abs(b[k]).max()
+    assert bad.sum() <= 0.01 * n, f"{bad.sum()} of {n} particles differ"
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])

