@@ -39,23 +39,125 @@ FPX_HD float m_erf(float x) { return erff(x); }
 FPX_HD double m_erf(double x) { return erf(x); }
 FPX_HD float m_pow(float x, float y) { return powf(x, y); }
 FPX_HD double m_pow(double x, double y) { return pow(x, y); }
-// x**y for the reference's non-integer exponents (0.33333, 0.66666, 0.8 ...).  fp64: exp(y*log(x)),
-// relative error <= ~|y ln x| ulp (a few 1e-16 here) at less than half the cost of the
-// correctly-rounded pow; fp32 keeps powf.  x == 0 and x < 0 behave like pow (0/inf, NaN).
-FPX_HD float m_powr(float x, float y) { return powf(x, y); }
-FPX_HD double m_powr(double x, double y) { return exp(y * log(x)); }
-// Division for the inner Langevin arithmetic.  fp64: hardware reciprocal seed + two Newton
-// steps + one residual correction (error <= 1 ulp, 8 instructions instead of the 14 of the
-// IEEE sequence).  Only used where the divisor is finite and non-zero by construction.
-FPX_DEV float m_divf(float a, float b) { return a / b; }
-FPX_DEV double m_divf(double a, double b) {
+// ---------------------------------------------------------------------------
+// Cheap fp64 building blocks for the Langevin inner loop.  Issue costs measured on MI355X
+// with tools/valu_rates.hip (cycles per wave64 instruction): add/mul/fma f64 4.4, v_rcp/v_rsq_f64 16,
+// 32-bit ALU 2.4, f32 transcendental 8; library calls: a/b 64, sqrt 89, exp 98, erf 246,
+// log 358, pow 780.  The loop is VALU-bound, so the helpers below trade the last half ulp
+// (results are within 1-2 ulp instead of correctly rounded) for 2-4x fewer cycles.
+// The float overloads keep the plain operations.
+// ---------------------------------------------------------------------------
+FPX_DEV float m_rcp(float b) { return 1.0f / b; }
+FPX_DEV double m_rcp(double b) {   // 1/b, b finite and non-zero: hardware seed + two Newton steps (34 cycles)
   double r = __builtin_amdgcn_rcp(b);
   double e = fma(-b, r, 1.0);
   r = fma(r, e, r);
   e = fma(-b, r, 1.0);
-  r = fma(r, e, r);
+  return fma(r, e, r);
+}
+// a/b where the divisor is finite and non-zero by construction: m_rcp + one residual correction
+FPX_DEV float m_divf(float a, float b) { return a / b; }
+FPX_DEV double m_divf(double a, double b) {
+  double r = m_rcp(b);
   double q = a * r;
   return fma(fma(-b, q, a), r, q);
+}
+// sqrt(x) and 1/sqrt(x) together for x > 0 (normal range): v_rsq_f64 + one coupled
+// Goldschmidt step + one residual correction each (56 cycles for both)
+FPX_DEV void m_sqrt_rsqrt(float x, float &s, float &rs) { s = sqrtf(x); rs = 1.0f / s; }
+FPX_DEV void m_sqrt_rsqrt(double x, double &s, double &rs) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  r = fma(-h, g, 0.5);
+  h = fma(h, r, h);
+  s = g;
+  rs = h + h;
+}
+FPX_DEV float m_rsqrt(float x) { return 1.0f / sqrtf(x); }
+FPX_DEV double m_rsqrt(double x) {   // x > 0
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  r = fma(-h, g, 0.5);
+  h = fma(h, r, h);
+  return h + h;
+}
+// sqrt(x) for x >= 0 (0 allowed), 47 cycles
+FPX_DEV float m_sqrtp(float x) { return sqrtf(x); }
+FPX_DEV double m_sqrtp(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  double d = fma(-g, g, x);
+  g = fma(d, h, g);
+  return x == 0.0 ? 0.0 : g;
+}
+// log(x) for the x**y = exp(y*log x) of the turbulence profiles: argument reduction to
+// [sqrt(1/2), sqrt(2)) and the degree-7 series in s = f/(2+f) (the classical fdlibm scheme);
+// absolute error < 3e-16 * max(1, |log x|).  Zero, negative, subnormal, inf and NaN take the
+// library path.
+FPX_DEV float m_logp(float x) { return logf(x); }
+FPX_DEV double m_logp(double x) {
+  if (!(x >= 2.3e-308 && x <= 1.7e308)) return log(x);
+  int e;
+  double m = frexp(x, &e);
+  const bool lo = m < 0.70710678118654752;
+  m = lo ? m + m : m;
+  e = lo ? e - 1 : e;
+  const double f = m - 1.0;
+  const double s = f * m_rcp(2.0 + f);
+  const double z = s * s, w = z * z;
+  const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+  const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01), 6.666666666666735130e-01);
+  const double Rr = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)e;
+  return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + Rr) + dk * 1.90821492927058770002e-10)) - f);
+}
+// x**y for the reference's non-integer exponents (0.33333, 0.66666, 0.8 ...).  fp64: exp(y*log(x)),
+// relative error <= ~|y ln x| ulp (a few 1e-16 here) at a fraction of the cost of the
+// correctly-rounded pow; fp32 keeps powf.  x == 0 and x < 0 behave like pow (0/inf, NaN).
+FPX_HD float m_powr(float x, float y) { return powf(x, y); }
+FPX_DEV double m_powr(double x, double y) { return exp(y * m_logp(x)); }
+// c = x**0.333333333 and ic2 = x**(-2*0.333333333) for x > 0 (the two "cuberoot" calls of cbl.f90:115-121,
+// exponent as written at cbl.f90:227).  fp64: r = x**(-1/3) from an f32 seed and two Newton steps
+// r <- r + r*(1 - x*r^3)/3, then the difference between 1/3 and 0.333333333 as the first-order
+// factor exp(-+delta*ln x) with ln x from the f32 logarithm (delta = 3.3e-10, so its 1e-7 relative
+// error is invisible).  Arguments outside the f32 exponent range take the exp/log path.
+FPX_DEV void m_cuberoot_parts(float x, float &c, float &ic2) {
+  const float l = logf(x);
+  c = expf(0.333333333f * l);
+  ic2 = expf(-2.0f * 0.333333333f * l);
+}
+FPX_DEV void m_cuberoot_parts(double x, double &c, double &ic2) {
+  if (!(x > 1.0e-37 && x < 1.0e37)) {
+    const double l = log(x);
+    c = exp(0.333333333 * l);
+    ic2 = exp(-2.0 * 0.333333333 * l);
+    return;
+  }
+  const float l2 = __log2f((float)x);
+  double r = (double)__builtin_amdgcn_exp2f(l2 * (-1.0f / 3.0f));
+  const double third = 1.0 / 3.0;
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const double e = fma(-(x * (r * r)), r, 1.0);
+    r = fma(r * third, e, r);
+  }
+  const double dl = (1.0 / 3.0 - 0.333333333) * (double)(l2 * 0.693147181f);   // delta * ln x
+  const double rc = fma(r, dl, r);              // x**(-0.333333333)
+  const double c0 = x * (r * r);                // x**(1/3)
+  c = fma(-c0, dl, c0);                         // x**(0.333333333)
+  ic2 = rc * rc;
 }
 FPX_HD float m_fmod(float x, float y) { return fmodf(x, y); }
 FPX_HD double m_fmod(double x, double y) { return fmod(x, y); }
@@ -68,6 +170,13 @@ FPX_HD double d_modulo(double a, double p) { double r = fmod(a, p); if (r != 0.0
 // ---------------------------------------------------------------------------
 // device view of everything the path reads (com_mod / par_mod variables)
 // ---------------------------------------------------------------------------
+template <typename R>
+struct NestDesc {
+  int nx, ny;                       // nxn, nyn
+  R xl, yl, xr, yr, xres, yres;     // xln, yln, xrn, yrn, xresoln, yresoln
+  const R *w3, *r2, *sfc, *hcell, *tropo, *vdep;
+};
+
 template <typename R>
 struct View {
   // grid, com_mod.f90:298-299,551-560
@@ -95,17 +204,28 @@ struct View {
   const R *tropo;    // [ny][nx]  tropopause, literal time slot 1 (advance.f90:253)
   const R *vdep;     // [ny][nx][2 slots][nspec]
   const R *rhott;    // [ny][nx][nz][2] (rho, tt) of literal slot 1 (get_settling.f90:83-84)
-  // nested grids (com_mod.f90:464-541): same packed layouts, nest extents nxn x nyn
+  // nested grids (com_mod.f90:464-541): same packed layouts, nest extents nxn x nyn.  The table
+  // is subscripted per lane, so it lives in device memory: a by-value array with a divergent
+  // subscript would drag the whole kernel argument (and every uniform scalar) out of SGPRs.
   int numbnests;
-  int nxn[kMaxNests], nyn[kMaxNests];
-  R xln[kMaxNests], yln[kMaxNests], xrn[kMaxNests], yrn[kMaxNests], xresoln[kMaxNests], yresoln[kMaxNests];
-  const R *w3n[kMaxNests], *r2n[kMaxNests], *sfcn[kMaxNests], *hcelln[kMaxNests], *tropon[kMaxNests], *vdepn[kMaxNests];
+  const NestDesc<R> *nest;   // [numbnests]
   R eps;             // nxmax/3.e5 with the host's par_mod nxmax (advance.f90:107)
   // RNG
   const R *rannumb;  // [maxrand], 0-based copy of rannumb(1:maxrand)
   int maxrand, rng_mode;
   unsigned long long seed;
 };
+
+// Per-lane (divergent) subscripts into the small by-value tables of View.  A dynamic subscript
+// would force the whole kernel argument into private (scratch) memory and with it every uniform
+// scalar into vector registers; a select chain over constant subscripts keeps View in SGPRs.
+template <typename T, int N>
+FPX_DEV T pick(const T (&a)[N], int l) {
+  T r = a[0];
+#pragma unroll
+  for (int k = 1; k < N; k++) r = (l == k) ? a[k] : r;
+  return r;
+}
 
 // particle SoA in HBM (com_mod.f90:678-695), R-typed except the position
 template <typename R>
@@ -234,7 +354,8 @@ FPX_DEV Fld<R> fld_of(const View<R> &V, int ngrid) {
   Fld<R> F;
   if (ngrid > 0) {
     const int l = ngrid - 1;
-    F.nx = V.nxn[l]; F.w3 = V.w3n[l]; F.r2 = V.r2n[l]; F.sfc = V.sfcn[l]; F.hcell = V.hcelln[l]; F.tropo = V.tropon[l]; F.vdep = V.vdepn[l];
+    const NestDesc<R> &N = V.nest[l];
+    F.nx = N.nx; F.w3 = N.w3; F.r2 = N.r2; F.sfc = N.sfc; F.hcell = N.hcell; F.tropo = N.tropo; F.vdep = N.vdep;
   } else {
     F.nx = V.nx; F.w3 = ngrid < 0 ? V.w3pol : V.w3; F.r2 = V.r2; F.sfc = V.sfc; F.hcell = V.hcell; F.tropo = V.tropo; F.vdep = V.vdep;
   }
@@ -352,10 +473,11 @@ FPX_DEV R tlw_unstable(const Turb<R> &T, R z) {   // hanna.f90:78-84
 template <typename R>
 FPX_DEV void sigw_unstable(Turb<R> &T) {   // hanna.f90:67-70 == hanna_short.f90:60-63
   // zeta**0.66666 and max(zeta,1.e-3)**(-.33333) from one logarithm
-  const R lz = m_log(T.zeta);
+  const R lz = m_logp(T.zeta);
   const R z23 = sizeof(R) == 8 ? m_exp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
-  const R zm13 = sizeof(R) == 8 ? m_exp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : m_log(K(1.e-3)))) : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
-  T.sigw = m_sqrt(K(1.2) * (T.wst * T.wst) * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * (T.ust * T.ust)) + K(1.e-2);
+  const R zm13 = sizeof(R) == 8 ? m_exp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : K(-6.907755278982137)))
+                                : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
+  T.sigw = m_sqrtp(K(1.2) * (T.wst * T.wst) * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * (T.ust * T.ust)) + K(1.e-2);
   T.dsigwdz = K(0.5) / T.sigw / T.h * (K(-1.4) * (T.ust * T.ust) + (T.wst * T.wst) * (K(0.8) * zm13 - K(1.8) * z23));
 }
 
@@ -451,21 +573,59 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
   T.tlw = m_max(K(30.), T.tlw);
 }
 
+// hanna_short runs once per fine sub-step with the same h, ol, ust: the stability regime and
+// the reciprocals of the step-invariant divisors are taken once per pass
 template <typename R>
-FPX_DEV void hanna_short(Turb<R> &T, R z) {   // hanna_short.f90:41-92
+struct HsInv {
+  R ih, iaux;    // 1/h; 1/ust (neutral) or 1/ol (unstable)
+  int regime;    // 0 neutral (hanna_short.f90:46-52), 1 unstable (:57-72), 2 stable (:77-81)
+};
+template <typename R>
+FPX_DEV HsInv<R> hanna_short_prepare(Turb<R> &T) {
+  HsInv<R> I;
+  I.ih = m_rcp(T.h);
   if (T.h / m_abs(T.ol) < K(1.)) {
+    I.regime = 0;
     T.ust = m_max(K(1.e-4), T.ust);
-    T.sigw = K(1.3) * m_exp(K(-2.e-4) * z / T.ust);
+    I.iaux = m_rcp(T.ust);
+  } else if (T.ol < K(0.)) {
+    I.regime = 1;
+    I.iaux = m_rcp(T.ol);
+  } else {
+    I.regime = 2;
+    I.iaux = K(0.);
+  }
+  return I;
+}
+
+template <typename R>
+FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I) {   // hanna_short.f90:41-92
+  if (I.regime == 0) {
+    const R corr = z * I.iaux;
+    T.sigw = K(1.3) * m_exp(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
     T.sigw = T.sigw * T.ust + K(1.e-2);
-    T.tlw = K(0.5) * z / T.sigw / (K(1.) + K(1.5e-3) * z / T.ust);
-  } else if (T.ol < K(0.)) {
-    sigw_unstable(T);
-    T.tlw = tlw_unstable(T, z);
+    T.tlw = K(0.5) * z * m_rcp(T.sigw * (K(1.) + K(1.5e-3) * corr));
+  } else if (I.regime == 1) {
+    const R lz = m_logp(T.zeta);
+    const R z23 = sizeof(R) == 8 ? m_exp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
+    const R zm13 = sizeof(R) == 8 ? m_exp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : K(-6.907755278982137)))
+                                  : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
+    const R ust2 = T.ust * T.ust, wst2 = T.wst * T.wst;
+    T.sigw = m_sqrtp(K(1.2) * wst2 * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * ust2) + K(1.e-2);
+    // tlw (hanna.f90:78-84) and dsigwdz share the reciprocal of sigw
+    const bool low = z < m_abs(T.ol);
+    const R q = low ? K(0.55) - K(0.38) * m_abs(z * I.iaux) : K(1.);
+    const R i2 = m_rcp(T.sigw * q);
+    const R isig = i2 * q;
+    T.dsigwdz = K(0.5) * isig * I.ih * (K(-1.4) * ust2 + wst2 * (K(0.8) * zm13 - K(1.8) * z23));
+    if (low) T.tlw = K(0.1) * z * i2;
+    else if (T.zeta < K(0.1)) T.tlw = K(0.59) * z * isig;
+    else T.tlw = K(0.15) * T.h * isig * (K(1.) - m_exp(K(-5) * T.zeta));
   } else {
     T.sigw = K(1.e-2) + K(1.3) * T.ust * (K(1.) - T.zeta);
-    T.dsigwdz = K(-1.3) * T.ust / T.h;
-    T.tlw = K(0.1) * T.h / T.sigw * m_powr(T.zeta, K(0.8));
+    T.dsigwdz = K(-1.3) * T.ust * I.ih;
+    T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_powr(T.zeta, K(0.8));
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -489,97 +649,98 @@ FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
 }
 
 // cbl.f90:70-210 -> drift ath, diffusion bth, blow-up flag.
-// Same algebra as the reference, evaluated the cheap way on the GPU: x**0.5 -> sqrt,
-// x**1.5 -> x*sqrt(x), x**(-0.5) -> 1/sqrt, x**2., x**3. -> products, the two cube roots
-// from one logarithm of |skew| (exponent 0.333333333 as in cbl.f90:227), each divisor
-// inverted once.  `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
+// Same algebra as the reference, arranged for a VALU-bound fp64 kernel: every quotient that
+// shares a divisor shares one reciprocal, and the square roots come with their reciprocals:
+//   w2**0.5 = sigmaw (sigmaw > 0), so skew = w3/sigmaw^3, dskew = (..)/sigmaw^6, dradw2 = dsigmawdz;
+//   den_r = ((3+f^2)^2 f^2) = den_x^2 with den_x = (3+f^2) f:  one reciprocal for rluarw, xluarw
+//   and their derivatives ((N*den - num*D)/den^2 = (N - (num/den)*D)/den);
+//   with x = aluarw*bluarw*(1+f^2) and rs = x**-0.5:  (b/(a(1+f^2)))**0.5 = b*rs, its inverse = a(1+f^2)*rs,
+//   1/(a(1+f^2)) = b*rs^2 (and the same with a and b exchanged), 1/sigmawa = (1/sigmaw)*a(1+f^2)*rs;
+//   the two cube roots of cbl.f90:115-121 from one x**(-1/3) (m_cuberoot_parts).
+// What is left is 3 reciprocals, 2 sqrt, 1 sqrt+rsqrt, 1 rsqrt, 2 exp and 2 erf per call
+// (the straightforward form has 20 divisions, 7 square roots, 1 log and 4 exp).
+// `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
 template <typename R>
 FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigmaw, R dsigmawdz, R tlw, R transition,
                  R &ath, R &bth, int &flagrein) {
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
-  const R third = K(0.333333333);
-  R dens = rhoa, ddens = rhograd, timedir = (R)ldirect;
-  R z = m_divf(zp, h);
-  R w2 = sigmaw * sigmaw;
-  R dw2 = K(2.) * sigmaw * dsigmawdz;
-  R alfa = m_divf(K(2.) * w2, C0 * tlw);
-  R wold = timedir * wp;
-  R omz = K(1.) - z;
-  R omz05 = m_sqrt(omz), omz15 = omz * omz05;
-  R wst3 = wst * wst * wst;
-  R w3 = (K(1.2) * z * omz15 + eps) * wst3 * transition;
-  R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * m_divf(K(1.), h) * transition;
-  R w205 = m_sqrt(w2), w215 = w2 * w205;
-  R skew = m_divf(w3, w215);
-  R skew2 = skew * skew;
-  R dskew = m_divf(dw3 * w215 - w3 * K(1.5) * w205 * dw2, w2 * w2 * w2);
-  R radw2 = w205;
-  R dradw2 = K(0.5) * m_divf(K(1.), w205) * dw2;
-  R lsk = m_log(m_abs(skew));
-  R fluarw = costluar4 * m_sign(m_exp(third * lsk), skew);            // costluar4*cuberoot(skew)
-  R fluarw2 = fluarw * fluarw;
-  R dfluarw, rluarw, drluarw, xluarw, dxluarw;
+  const R dens = rhoa, ddens = rhograd, timedir = (R)ldirect;
+  const R ih = m_rcp(h);
+  const R z = zp * ih;
+  const R w2 = sigmaw * sigmaw;
+  const R dw2 = K(2.) * sigmaw * dsigmawdz;
+  const R alfa = K(2.) * w2 * m_rcp(C0 * tlw);
+  const R wold = timedir * wp;
+  const R omz = K(1.) - z;
+  const R omz05 = m_sqrtp(omz), omz15 = omz * omz05;
+  const R wst3 = wst * wst * wst;
+  const R w3 = (K(1.2) * z * omz15 + eps) * wst3 * transition;
+  const R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * ih * transition;
+  const R irw = m_rcp(sigmaw);                 // w2**(-0.5)
+  const R irw2 = irw * irw, irw3 = irw2 * irw;
+  const R w215 = w2 * sigmaw;
+  const R skew = w3 * irw3;
+  const R skew2 = skew * skew;
+  const R dskew = (dw3 * w215 - w3 * K(1.5) * sigmaw * dw2) * (irw3 * irw3);
+  R fluarw = K(0.), dfluarw = K(0.), rluarw = K(0.), drluarw = K(0.), xluarw = K(0.), dxluarw = K(0.);
   if (skew != K(0)) {
-    dfluarw = costluar4 * (K(1.) / K(3.)) * m_exp(K(-2.) * third * lsk) * dskew;   // cuberoot(skew**(-2.))
-    R a1 = K(1.) + fluarw2, a3 = K(3.) + fluarw2;
-    R a105 = m_sqrt(a1);
-    R a1c = a1 * a1 * a1, a3s = a3 * a3, a115 = a1 * a105;
-    R den_r = a3s * fluarw2, den_x = a3 * fluarw;
-    rluarw = m_divf(a1c * skew2, den_r);
-    xluarw = m_divf(a115 * skew, den_x);
-    R ffd = K(2.) * fluarw * dfluarw;
-    drluarw = m_divf(((K(3.) * (a1 * a1) * ffd * skew2) + a1c * K(2.) * skew * dskew) * den_r -
-                         a1c * skew2 * ((K(2.) * a3 * ffd * fluarw2) + a3s * ffd),
-                     den_r * den_r);
-    dxluarw = m_divf(((K(1.5) * a105 * ffd * skew) + a115 * dskew) * den_x -
-                         a115 * skew * (K(3.) * dfluarw + K(3) * fluarw2 * dfluarw),
-                     den_x * den_x);
-  } else {
-    dfluarw = K(0.); rluarw = K(0.); drluarw = K(0.); xluarw = K(0.); dxluarw = K(0.);
+    R croot, icroot2;
+    m_cuberoot_parts(m_abs(skew), croot, icroot2);
+    fluarw = costluar4 * m_sign(croot, skew);                         // costluar4*cuberoot(skew)
+    dfluarw = costluar4 * (K(1.) / K(3.)) * icroot2 * dskew;          // cuberoot(skew**(-2.))
   }
-  R r4 = K(4.) + rluarw;
-  R r405 = m_sqrt(r4);
-  R ir405 = m_divf(K(1.), r405);
-  R aluarw = K(0.5) * (K(1.) - xluarw * ir405);
-  R bluarw = K(1.) - aluarw;
-  R daluarw = m_divf(K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * ir405 * drluarw)), r4);
-  R dbluarw = -daluarw;
-  R f1 = K(1.) + fluarw2, ffd2 = K(2.) * fluarw * dfluarw;
-  R t1 = aluarw * f1;
-  R qa = m_divf(bluarw, t1);
-  R qa05 = m_sqrt(qa);
-  R sigmawa = radw2 * qa05;
-  R dsigmawa = dradw2 * qa05 +
-               radw2 * ((K(0.5) * m_divf(K(1.), qa05)) * m_divf(dbluarw * t1 - bluarw * (daluarw * f1 + aluarw * ffd2), t1 * t1));
-  R t2 = bluarw * f1;
-  R qb = m_divf(aluarw, t2);
-  R qb05 = m_sqrt(qb);
-  R sigmawb = radw2 * qb05;
-  R dsigmawb = dradw2 * qb05 +
-               radw2 * ((K(0.5) * m_divf(K(1.), qb05)) * m_divf(daluarw * t2 - aluarw * (dbluarw * f1 + bluarw * ffd2), t2 * t2));
-  R wa = fluarw * sigmawa, wb = fluarw * sigmawb;
-  R dwa = dfluarw * sigmawa + fluarw * dsigmawa;
-  R dwb = dfluarw * sigmawb + fluarw * dsigmawb;
-  R deltawa = wold - wa, deltawb = wold + wb;
-  R wold2 = wold * wold;
-  R isa = m_divf(K(1.), sigmawa), isb = m_divf(K(1.), sigmawb);
-  R isa2 = isa * isa, isb2 = isb * isb;
+  const R fluarw2 = fluarw * fluarw;
+  const R a1 = K(1.) + fluarw2, a3 = K(3.) + fluarw2;
+  const R ffd = K(2.) * fluarw * dfluarw;
+  if (skew != K(0)) {
+    const R a105 = m_sqrtp(a1);
+    const R a1c = a1 * a1 * a1, a115 = a1 * a105;
+    const R ix = m_rcp(a3 * fluarw), ix2 = ix * ix;
+    rluarw = a1c * skew2 * ix2;
+    xluarw = a115 * skew * ix;
+    drluarw = ((K(3.) * (a1 * a1) * ffd * skew2 + a1c * K(2.) * skew * dskew) - rluarw * (K(2.) * a3 * ffd * fluarw2 + a3 * a3 * ffd)) * ix2;
+    dxluarw = ((K(1.5) * a105 * ffd * skew + a115 * dskew) - xluarw * (K(3.) * dfluarw * a1)) * ix;
+  }
+  const R r4 = K(4.) + rluarw;
+  R r405, ir405;
+  m_sqrt_rsqrt(r4, r405, ir405);
+  const R aluarw = K(0.5) * (K(1.) - xluarw * ir405);
+  const R bluarw = K(1.) - aluarw;
+  const R daluarw = K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * ir405 * drluarw)) * (ir405 * ir405);
+  const R dbluarw = -daluarw;
+  const R t1 = aluarw * a1, t2 = bluarw * a1;
+  const R rs = m_rsqrt(t1 * bluarw), rs2 = rs * rs;
+  const R qa05 = bluarw * rs, iqa05 = t1 * rs;     // (bluarw/t1)**0.5 and its inverse
+  const R qb05 = aluarw * rs, iqb05 = t2 * rs;     // (aluarw/t2)**0.5 and its inverse
+  const R it1 = bluarw * rs2, it2 = aluarw * rs2;  // 1/t1, 1/t2
+  const R sigmawa = sigmaw * qa05, sigmawb = sigmaw * qb05;
+  const R dsigmawa = dsigmawdz * qa05 +
+                     sigmaw * ((K(0.5) * iqa05) * ((dbluarw * t1 - bluarw * (daluarw * a1 + aluarw * ffd)) * (it1 * it1)));
+  const R dsigmawb = dsigmawdz * qb05 +
+                     sigmaw * ((K(0.5) * iqb05) * ((daluarw * t2 - aluarw * (dbluarw * a1 + bluarw * ffd)) * (it2 * it2)));
+  const R wa = fluarw * sigmawa, wb = fluarw * sigmawb;
+  const R dwa = dfluarw * sigmawa + fluarw * dsigmawa;
+  const R dwb = dfluarw * sigmawb + fluarw * dsigmawb;
+  const R deltawa = wold - wa, deltawb = wold + wb;
+  const R wold2 = wold * wold;
+  const R isa = irw * iqa05, isb = irw * iqb05;
+  const R isa2 = isa * isa, isb2 = isb * isb;
   if (m_abs(deltawa) > K(6.) * sigmawa && m_abs(deltawb) > K(6.) * sigmawb) flagrein = 1;
-  R da = deltawa * isa, db = deltawb * isb;
-  R pa = (usurad2p * isa) * m_exp(-(K(0.5) * (da * da)));
-  R pb = (usurad2p * isb) * m_exp(-(K(0.5) * (db * db)));
-  R ptot = dens * aluarw * pa + dens * bluarw * pb;
-  R aperfa = deltawa * usurad2 * isa;
-  R aperfb = deltawb * usurad2 * isb;
-  R Phi = K(-0.5) * (aluarw * dens * dwa + dens * wa * daluarw + aluarw * wa * ddens) * m_erf(aperfa) +
-          sigmawa * (aluarw * dens * dsigmawa * (wold2 * isa2 + K(1.)) + sigmawa * dens * daluarw + sigmawa * ddens * aluarw +
-                     aluarw * wold * dens * isa2 * (sigmawa * dwa - wa * dsigmawa)) * pa +
-          K(0.5) * (bluarw * dens * dwb + wb * dens * dbluarw + wb * bluarw * ddens) * m_erf(aperfb) +
-          sigmawb * (bluarw * dens * dsigmawb * (wold2 * isb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
-                     bluarw * wold * dens * isb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
-  R Q = timedir * ((aluarw * dens * deltawa * isa2) * pa + (bluarw * dens * deltawb * isb2) * pb);
-  ath = m_divf(K(1.), ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
-  bth = m_sqrt(C0 * alfa);
+  const R da = deltawa * isa, db = deltawb * isb;
+  const R pa = (usurad2p * isa) * m_exp(-(K(0.5) * (da * da)));
+  const R pb = (usurad2p * isb) * m_exp(-(K(0.5) * (db * db)));
+  const R ptot = dens * aluarw * pa + dens * bluarw * pb;
+  const R aperfa = deltawa * usurad2 * isa;
+  const R aperfb = deltawb * usurad2 * isb;
+  const R Phi = K(-0.5) * (aluarw * dens * dwa + dens * wa * daluarw + aluarw * wa * ddens) * m_erf(aperfa) +
+                sigmawa * (aluarw * dens * dsigmawa * (wold2 * isa2 + K(1.)) + sigmawa * dens * daluarw + sigmawa * ddens * aluarw +
+                           aluarw * wold * dens * isa2 * (sigmawa * dwa - wa * dsigmawa)) * pa +
+                K(0.5) * (bluarw * dens * dwb + wb * dens * dbluarw + wb * bluarw * ddens) * m_erf(aperfb) +
+                sigmawb * (bluarw * dens * dsigmawb * (wold2 * isb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
+                           bluarw * wold * dens * isb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
+  const R Q = timedir * ((aluarw * dens * deltawa * isa2) * pa + (bluarw * dens * deltawb * isb2) * pb);
+  ath = m_rcp(ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
+  bth = m_sqrtp(C0 * alfa);
 }
 
 // bi-Gaussian pdf parameters shared by re_initialize_particle.f90:47-70 and initialize_cbl_vel.f90:46-73
@@ -821,15 +982,15 @@ FPX_DEV R get_settling(const View<R> &V, const R *hgt, R xt, R yt, R zt, int nsp
   const R cc = K(120.), t_0 = K(291.15), eta_0 = K(1.827e-5);
   R vis_dyn = eta_0 * (t_0 + cc) / (temperature + cc) * m_pow(temperature / t_0, K(1.5));
   R vis_kin = vis_dyn / airdens;
-  R reynolds = V.dquer[nsp] / K(1.e6) * m_abs(V.vsetaver[nsp]) / vis_kin;
-  R settling_old = V.vsetaver[nsp], settling = K(0.), c_d;
+  R reynolds = pick(V.dquer, nsp) / K(1.e6) * m_abs(pick(V.vsetaver, nsp)) / vis_kin;
+  R settling_old = pick(V.vsetaver, nsp), settling = K(0.), c_d;
   for (int i = 1; i <= 20; i++) {
     if (reynolds < K(1.917)) c_d = K(24.) / reynolds;
     else if (reynolds < K(500.)) c_d = K(18.5) / m_pow(reynolds, K(0.6));
     else c_d = K(0.44);
-    settling = K(-1.) * m_sqrt(K(4) * ga * V.dquer[nsp] / K(1.e6) * V.density[nsp] * V.cunningham[nsp] / (K(3.) * c_d * airdens));
+    settling = K(-1.) * m_sqrt(K(4) * ga * pick(V.dquer, nsp) / K(1.e6) * pick(V.density, nsp) * pick(V.cunningham, nsp) / (K(3.) * c_d * airdens));
     if (m_abs((settling - settling_old) / settling) < K(0.01)) break;
-    reynolds = V.dquer[nsp] / K(1.e6) * m_abs(settling) / vis_kin;
+    reynolds = pick(V.dquer, nsp) / K(1.e6) * m_abs(settling) / vis_kin;
     settling_old = settling;
   }
   return settling;
@@ -842,9 +1003,9 @@ FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt
   if (V.mdomainfill != 0 || !V.lsettling) return K(0.);
   int nsp;
   for (nsp = 0; nsp < V.nspec; nsp++)
-    if (V.xmass_rel[nsp] > eps3) break;
+    if (pick(V.xmass_rel, nsp) > eps3) break;
   if (nsp >= V.nspec) nsp = V.nspec - 1;
-  if (!(V.density[nsp] > K(0.))) return K(0.);
+  if (!(pick(V.density, nsp) > K(0.))) return K(0.);
   return get_settling(V, hgt, (R)xt, (R)yt, zt, nsp);
 }
 
@@ -873,9 +1034,11 @@ template <typename R>
 FPX_DEV int pick_grid(const View<R> &V, double xt, double yt) {
   const int p = pick_polar(V, yt);
   if (p != 0) return p;
-  for (int j = V.numbnests; j >= 1; j--)
-    if (xt > (double)(V.xln[j - 1] + V.eps) && xt < (double)(V.xrn[j - 1] - V.eps) &&
-        yt > (double)(V.yln[j - 1] + V.eps) && yt < (double)(V.yrn[j - 1] - V.eps)) return j;
+  for (int j = V.numbnests; j >= 1; j--) {
+    const NestDesc<R> &N = V.nest[j - 1];
+    if (xt > (double)(N.xl + V.eps) && xt < (double)(N.xr - V.eps) &&
+        yt > (double)(N.yl + V.eps) && yt < (double)(N.yr - V.eps)) return j;
+  }
   return 0;
 }
 
@@ -1179,10 +1342,11 @@ FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, 
   int nyrows = V.ny, nxcols = V.nx;
   if (A.ngrid > 0) {   // advance.f90:191-197 nested grid coordinates
     const int l = A.ngrid - 1;
-    A.xr = (R)((xt - (double)V.xln[l]) * (double)V.xresoln[l]);
-    A.yr = (R)((yt - (double)V.yln[l]) * (double)V.yresoln[l]);
+    const NestDesc<R> &N = V.nest[l];
+    A.xr = (R)((xt - (double)N.xl) * (double)N.xres);
+    A.yr = (R)((yt - (double)N.yl) * (double)N.yres);
     A.ix = (int)A.xr; A.jy = (int)A.yr;
-    nyrows = V.nyn[l]; nxcols = V.nxn[l];
+    nyrows = V.nest[l].ny; nxcols = V.nest[l].nx;
   } else {
     A.xr = (R)xt; A.yr = (R)yt;
     A.ix = (int)xt; A.jy = (int)yt;
@@ -1256,7 +1420,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   cache_fetch(V, F, B.C, W, B.LC, indz);
 
   // advance.f90:342-350
-  const R dz = K(1.) / (hgt[indzp - 1] - hgt[indz - 1]);
+  const R dz = m_rcp(hgt[indzp - 1] - hgt[indz - 1]);
   const R dz1 = (zt - hgt[indz - 1]) * dz;
   const R dz2 = (hgt[indzp - 1] - zt) * dz;
   A.u = dz1 * B.LC.uhi + dz2 * B.LC.ulo;
@@ -1272,27 +1436,30 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   if (nrand + 1 > V.maxrand) nrand = 1;
   {
     const R g1 = G.at(nrand), g2 = G.at(nrand + 1);
-    if (dt / T.tlu < K(.5)) {
-      up = (K(1.) - dt / T.tlu) * up + g1 * T.sigu * m_sqrt(K(2.) * dt / T.tlu);
+    const R dttlu = dt * m_rcp(T.tlu), dttlv = dt * m_rcp(T.tlv);
+    if (dttlu < K(.5)) {
+      up = (K(1.) - dttlu) * up + g1 * T.sigu * m_sqrtp(K(2.) * dttlu);
     } else {
-      R ru = m_exp(-dt / T.tlu);
-      up = ru * up + g1 * T.sigu * m_sqrt(K(1.) - ru * ru);
+      R ru = m_exp(-dttlu);
+      up = ru * up + g1 * T.sigu * m_sqrtp(K(1.) - ru * ru);
     }
-    if (dt / T.tlv < K(.5)) {
-      vp = (K(1.) - dt / T.tlv) * vp + g2 * T.sigv * m_sqrt(K(2.) * dt / T.tlv);
+    if (dttlv < K(.5)) {
+      vp = (K(1.) - dttlv) * vp + g2 * T.sigv * m_sqrtp(K(2.) * dttlv);
     } else {
-      R rv = m_exp(-dt / T.tlv);
-      vp = rv * vp + g2 * T.sigv * m_sqrt(K(1.) - rv * rv);
+      R rv = m_exp(-dttlv);
+      vp = rv * vp + g2 * T.sigv * m_sqrtp(K(1.) - rv * rv);
     }
   }
   nrand = nrand + 2;
 
   if (nrand + V.ifine > V.maxrand) nrand = 1;
-  const R rhoaux = rhograd / rhoa;
+  const R irhoa = m_rcp(rhoa);
+  const R rhoaux = rhograd * irhoa;
   const R dtf = dt * V.fine;
-  const R dtftlw = dtf / T.tlw;
+  const R dtftlw = dtf * m_rcp(T.tlw);
   const bool cbl_on = cblflag && (-h / T.ol > K(5));
-  const R sqrt_dtf = m_sqrt(dtf);
+  const R sqrt_dtf = m_sqrtp(dtf);
+  const HsInv<R> HI = hanna_short_prepare(T);
 
   // vertical Langevin, ifine sub-steps, advance.f90:396-498
   for (int i = 1; i <= V.ifine; i++) {
@@ -1315,12 +1482,12 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             }
           } else {
             nrand = nrand + 1;
-            R ath = -wp / T.tlw + T.sigw * T.dsigwdz + wp * wp / T.sigw * T.dsigwdz + T.sigw * T.sigw / rhoa * rhograd;
-            R bth = T.sigw * G.at(nrand) * m_sqrt(K(2.) * dtftlw);
+            R ath = -wp * m_rcp(T.tlw) + T.sigw * T.dsigwdz + wp * wp * m_rcp(T.sigw) * T.dsigwdz + T.sigw * T.sigw * irhoa * rhograd;
+            R bth = T.sigw * G.at(nrand) * m_sqrtp(K(2.) * dtftlw);
             wp = (wp + ath * dtf + bth) * (R)icbt;
             delz = wp * dtf;
-            R del_test = (K(1.) - wp) / wp;
-            if (isnan(wp) || isnan(del_test)) {
+            // del_test=(1.-wp)/wp is NaN exactly when wp is NaN or infinite (advance.f90:440-441)
+            if (!isfinite(wp)) {
               nrand = nrand + 1;
               wp = T.sigw * G.at(nrand);
               delz = wp * dtf;
@@ -1328,17 +1495,17 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             }
           }
         } else {
-          wp = ((K(1.) - dtftlw) * wp + G.at(nrand + i) * m_sqrt(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
+          wp = ((K(1.) - dtftlw) * wp + G.at(nrand + i) * m_sqrtp(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
           delz = wp * T.sigw * dtf;
         }
       } else {
         R rw = m_exp(-dtftlw);
-        wp = (rw * wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
+        wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
         delz = wp * T.sigw * dtf;
       }
     } else {
       R rw = m_exp(-dtftlw);
-      wp = (rw * wp + G.at(nrand + i) * m_sqrt(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)icbt;
+      wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)icbt;
       delz = wp * dtf;
     }
 
@@ -1355,8 +1522,8 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
       zt = zt + delz;
     }
     if (i != V.ifine) {
-      T.zeta = zt / h;
-      hanna_short(T, zt);
+      T.zeta = zt * HI.ih;
+      hanna_short(T, zt, HI);
     }
   }
   if (!cblflag) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i", i = ifine+1 after the loop (advance.f90:499)
@@ -1495,9 +1662,10 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
   int nyrows = V.ny, nxcols = V.nx;
   if (A.ngrid > 0) {   // advance.f90:862-866
     const int l = A.ngrid - 1;
-    xr = (R)((P.xt - (double)V.xln[l]) * (double)V.xresoln[l]);
-    yr = (R)((P.yt - (double)V.yln[l]) * (double)V.yresoln[l]);
-    nyrows = V.nyn[l]; nxcols = V.nxn[l];
+    const NestDesc<R> &N = V.nest[l];
+    xr = (R)((P.xt - (double)N.xl) * (double)N.xres);
+    yr = (R)((P.yt - (double)N.yl) * (double)N.yres);
+    nyrows = V.nest[l].ny; nxcols = V.nest[l].nx;
   } else {
     xr = (R)P.xt; yr = (R)P.yt;
   }

@@ -749,6 +749,7 @@ struct Engine : EngineBase {
     V.rng_mode = cfg.rng_mode; V.seed = cfg.seed; V.maxrand = 1000000;
     V.eps = (R)(cfg.par_nxmax > 0 ? cfg.par_nxmax : cfg.nxmax) / (R)3.e5;   // advance.f90:107
     V.numbnests = 0;
+    V.nest = nullptr;
     g_nx = cfg.nx; g_ny = cfg.ny; g_nxmax = cfg.nxmax; g_nymax = cfg.nymax;
 
     const size_t ncol = (size_t)cfg.nx * cfg.ny, nlev = ncol * cfg.nz;
@@ -1416,6 +1417,7 @@ struct Engine : EngineBase {
   // ---- nested grids --------------------------------------------------------------
   int nest_nxmaxn = 0, nest_nymaxn = 0;
   bool nest_loaded[kMaxNests][2] = {};
+  NestDesc<R> h_nest[kMaxNests] = {};   // host copy of the device table V.nest
   int nests_init(const fpx_nests *n) override {
     if (!n || n->struct_bytes != (int32_t)sizeof(fpx_nests)) return fail(FPX_ERR_ARG, "nests_init: null or fpx_nests size mismatch (ABI)");
     if (n->numbnests < 1 || n->numbnests > kMaxNests) return fail(FPX_ERR_ARG, "nests_init: numbnests out of range");
@@ -1424,19 +1426,25 @@ struct Engine : EngineBase {
     for (int l = 0; l < n->numbnests; l++) {
       if (n->nxn[l] < 2 || n->nyn[l] < 2 || n->nxn[l] > n->nxmaxn || n->nyn[l] > n->nymaxn) return fail(FPX_ERR_ARG, "nests_init: bad nest extents");
       if (!(n->xln[l] >= 0 && n->yln[l] >= 0 && n->xrn[l] <= cfg.nx - 1 && n->yrn[l] <= cfg.ny - 1)) return fail(FPX_ERR_ARG, "nests_init: nest outside the mother grid (gridcheck_nests.f90:381)");
-      V.nxn[l] = n->nxn[l]; V.nyn[l] = n->nyn[l];
-      V.xln[l] = (R)n->xln[l]; V.yln[l] = (R)n->yln[l]; V.xrn[l] = (R)n->xrn[l]; V.yrn[l] = (R)n->yrn[l];
-      V.xresoln[l] = (R)n->xresoln[l]; V.yresoln[l] = (R)n->yresoln[l];
+      NestDesc<R> &N = h_nest[l];
+      N.nx = n->nxn[l]; N.ny = n->nyn[l];
+      N.xl = (R)n->xln[l]; N.yl = (R)n->yln[l]; N.xr = (R)n->xrn[l]; N.yr = (R)n->yrn[l];
+      N.xres = (R)n->xresoln[l]; N.yres = (R)n->yresoln[l];
       const size_t ncol = (size_t)n->nxn[l] * n->nyn[l], nlev = ncol * cfg.nz;
       R *p;
-      if ((rc = dalloc(&p, nlev * 6))) return rc; V.w3n[l] = p;
-      if ((rc = dalloc(&p, nlev * 4))) return rc; V.r2n[l] = p;
-      if ((rc = dalloc(&p, ncol * 8))) return rc; V.sfcn[l] = p;
-      if ((rc = dalloc(&p, ncol))) return rc; V.hcelln[l] = p;
-      if ((rc = dalloc(&p, ncol))) return rc; V.tropon[l] = p;
-      if (cfg.drydep) { if ((rc = dalloc(&p, ncol * 2 * cfg.nspec))) return rc; V.vdepn[l] = p; }
+      if ((rc = dalloc(&p, nlev * 6))) return rc; N.w3 = p;
+      if ((rc = dalloc(&p, nlev * 4))) return rc; N.r2 = p;
+      if ((rc = dalloc(&p, ncol * 8))) return rc; N.sfc = p;
+      if ((rc = dalloc(&p, ncol))) return rc; N.hcell = p;
+      if ((rc = dalloc(&p, ncol))) return rc; N.tropo = p;
+      if (cfg.drydep) { if ((rc = dalloc(&p, ncol * 2 * cfg.nspec))) return rc; N.vdep = p; }
     }
     nest_nxmaxn = n->nxmaxn; nest_nymaxn = n->nymaxn;
+    NestDesc<R> *dn;
+    if ((rc = dalloc(&dn, (size_t)n->numbnests))) return rc;
+    HIPCHK(hipMemcpyAsync(dn, h_nest, sizeof(NestDesc<R>) * n->numbnests, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    V.nest = dn;
     V.numbnests = n->numbnests;
     return 0;
   }
@@ -1447,29 +1455,29 @@ struct Engine : EngineBase {
       return fail(FPX_ERR_ARG, "upload_nest_fields: uun, vvn, wwn, rhon, drhodzn, hmixn, ustarn, wstarn, olin, tropopausen are required");
     if (cfg.drydep && !f->vdep) return fail(FPX_ERR_ARG, "upload_nest_fields: vdepn required with DRYDEP");
     const int l = nest - 1, s = slot - 1;
-    g_nx = V.nxn[l]; g_ny = V.nyn[l]; g_nxmax = nest_nxmaxn; g_nymax = nest_nymaxn;
+    g_nx = h_nest[l].nx; g_ny = h_nest[l].ny; g_nxmax = nest_nxmaxn; g_nymax = nest_nymaxn;
     int rc = 0;
     do {
-      if ((rc = p3(f->uu, V.w3n[l], 6, s * 3 + 0))) break;
-      if ((rc = p3(f->vv, V.w3n[l], 6, s * 3 + 1))) break;
-      if ((rc = p3(f->ww, V.w3n[l], 6, s * 3 + 2))) break;
-      if ((rc = p3(f->rho, V.r2n[l], 4, s * 2 + 0))) break;
-      if ((rc = p3(f->drhodz, V.r2n[l], 4, s * 2 + 1))) break;
-      if ((rc = p2(f->ustar, V.sfcn[l], 8, s * 4 + 0))) break;
-      if ((rc = p2(f->wstar, V.sfcn[l], 8, s * 4 + 1))) break;
-      if ((rc = p2(f->oli, V.sfcn[l], 8, s * 4 + 2))) break;
-      if ((rc = p2(f->hmix, V.sfcn[l], 8, s * 4 + 3))) break;
-      if (slot == 1 && (rc = p2(f->tropopause, V.tropon[l], 1, 0))) break;   // tropopausen(nix,njy,1,1,ngrid), advance.f90:263
-      if (V.vdepn[l]) {
+      if ((rc = p3(f->uu, (R *)h_nest[l].w3, 6, s * 3 + 0))) break;
+      if ((rc = p3(f->vv, (R *)h_nest[l].w3, 6, s * 3 + 1))) break;
+      if ((rc = p3(f->ww, (R *)h_nest[l].w3, 6, s * 3 + 2))) break;
+      if ((rc = p3(f->rho, (R *)h_nest[l].r2, 4, s * 2 + 0))) break;
+      if ((rc = p3(f->drhodz, (R *)h_nest[l].r2, 4, s * 2 + 1))) break;
+      if ((rc = p2(f->ustar, (R *)h_nest[l].sfc, 8, s * 4 + 0))) break;
+      if ((rc = p2(f->wstar, (R *)h_nest[l].sfc, 8, s * 4 + 1))) break;
+      if ((rc = p2(f->oli, (R *)h_nest[l].sfc, 8, s * 4 + 2))) break;
+      if ((rc = p2(f->hmix, (R *)h_nest[l].sfc, 8, s * 4 + 3))) break;
+      if (slot == 1 && (rc = p2(f->tropopause, (R *)h_nest[l].tropo, 1, 0))) break;   // tropopausen(nix,njy,1,1,ngrid), advance.f90:263
+      if ((R *)h_nest[l].vdep) {
         const size_t plane = (size_t)nest_nxmaxn * nest_nymaxn * cfg.host_real_bytes;
-        for (int ks = 0; ks < cfg.nspec && !rc; ks++) rc = p2((const char *)f->vdep + plane * ks, V.vdepn[l], 2 * cfg.nspec, s * cfg.nspec + ks);
+        for (int ks = 0; ks < cfg.nspec && !rc; ks++) rc = p2((const char *)f->vdep + plane * ks, (R *)h_nest[l].vdep, 2 * cfg.nspec, s * cfg.nspec + ks);
       }
     } while (0);
     const int nxl = g_nx, nyl = g_ny;
     g_nx = cfg.nx; g_ny = cfg.ny; g_nxmax = cfg.nxmax; g_nymax = cfg.nymax;
     if (rc) return rc;
     int tot = nxl * nyl;
-    k_hcell<R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>(V.sfcn[l], (R *)V.hcelln[l], nxl, nyl);
+    k_hcell<R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>((R *)h_nest[l].sfc, (R *)h_nest[l].hcell, nxl, nyl);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));
     nest_loaded[l][s] = true;
