@@ -1385,12 +1385,80 @@ FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W
 // TSW / CBLF: -1 = read turbswitch / cblflag at run time, 0/1 = fixed at compile time
 // (specialised hot kernels: fewer scalar registers, no dead branches).  SETTLE/DRYDEP false
 // compile the aerosol paths out.
+// ---------------------------------------------------------------------------
+// The PBL loop kernel keeps the part of a lane's state that is touched once per PASS, not
+// once per fine sub-step, in LDS instead of registers: the two cached profile levels, the
+// horizontal weights of the cell, the displacement sums, the grid-scale wind and the horizontal
+// turbulent velocities (23 values of R per lane).  The fine loop (cbl/hanna_short, ~120 live
+// registers of its own) then fits the 256-VGPR budget of two waves per SIMD without spilling
+// to scratch memory -- scratch spills of a persistent kernel are HBM traffic, LDS is not.
+// Layout: slot-major [S_COUNT][block], one column per lane; the accesses are volatile so that
+// the compiler does not forward the values through registers across the loop.
+// ---------------------------------------------------------------------------
+enum StashSlot {
+  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // LevelCache
+  S_P1, S_P2, S_P3, S_P4,                                                       // Cell weights
+  S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
+  S_U, S_V, S_W,                                                                // interpol_mod u, v, w
+  S_UP, S_VP,                                                                   // turbulent velocities along/across wind
+  S_COUNT
+};
+constexpr int kStashStride = 256;   // threads per block of the loop kernel
+template <typename R>
+struct Stash {
+  volatile R *p;   // &lds[0][threadIdx.x]
+  FPX_DEV R get(int k) const { return p[k * kStashStride]; }
+  FPX_DEV void put(int k, R v) const { p[k * kStashStride] = v; }
+  FPX_DEV void add(int k, R v) const { p[k * kStashStride] = p[k * kStashStride] + v; }
+};
+
+template <typename R>
+struct LoopCtx {                // register-resident state of a lane across passes
+  int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
+  R h;
+  int itimec, nrand;
+  int ilo;                      // level index of the cached *lo profile level (-1 = empty), see LevelCache
+  R ust, wst, ol;               // hanna_mod ust, wst, ol
+  R transition;                 // cbl.f90:79-81, constant during the step
+};
+
+template <typename R>
+FPX_DEV Cell<R> stash_cell(const LoopCtx<R> &L, const Stash<R> &S) {
+  Cell<R> C;
+  C.p1 = S.get(S_P1); C.p2 = S.get(S_P2); C.p3 = S.get(S_P3); C.p4 = S.get(S_P4);
+  C.ix = L.ix; C.jy = L.jy; C.ixp = L.ixp; C.jyp = L.jyp;
+  return C;
+}
+
+// cache_fetch with the two levels in the stash
+template <typename R>
+FPX_DEV void cache_fetch_stash(const View<R> &V, const Fld<R> &F, const TimeW<R> &W, LoopCtx<R> &L, const Stash<R> &S, int indz) {
+  if (L.ilo == indz) return;
+  const Cell<R> C = stash_cell(L, S);
+  Level<R> Lv;
+  if (L.ilo == indz + 1) {            // moved one level down
+    S.put(S_UHI, S.get(S_ULO)); S.put(S_VHI, S.get(S_VLO)); S.put(S_WHI, S.get(S_WLO)); S.put(S_RHOHI, S.get(S_RHOLO)); S.put(S_RGHI, S.get(S_RGLO));
+    level_profile<R, true, true, false>(V, F, C, W, indz, Lv);
+    S.put(S_ULO, Lv.u); S.put(S_VLO, Lv.v); S.put(S_WLO, Lv.w); S.put(S_RHOLO, Lv.rho); S.put(S_RGLO, Lv.rhograd);
+  } else if (L.ilo == indz - 1) {     // moved one level up
+    S.put(S_ULO, S.get(S_UHI)); S.put(S_VLO, S.get(S_VHI)); S.put(S_WLO, S.get(S_WHI)); S.put(S_RHOLO, S.get(S_RHOHI)); S.put(S_RGLO, S.get(S_RGHI));
+    level_profile<R, true, true, false>(V, F, C, W, indz + 1, Lv);
+    S.put(S_UHI, Lv.u); S.put(S_VHI, Lv.v); S.put(S_WHI, Lv.w); S.put(S_RHOHI, Lv.rho); S.put(S_RGHI, Lv.rhograd);
+  } else {
+    level_profile<R, true, true, false>(V, F, C, W, indz, Lv);
+    S.put(S_ULO, Lv.u); S.put(S_VLO, Lv.v); S.put(S_WLO, Lv.w); S.put(S_RHOLO, Lv.rho); S.put(S_RGLO, Lv.rhograd);
+    level_profile<R, true, true, false>(V, F, C, W, indz + 1, Lv);
+    S.put(S_UHI, Lv.u); S.put(S_VHI, Lv.v); S.put(S_WHI, Lv.w); S.put(S_RHOHI, Lv.rho); S.put(S_RGHI, Lv.rhograd);
+  }
+  L.ilo = indz;
+}
+
 template <int T>
 FPX_DEV bool sw(int runtime) { return T < 0 ? runtime != 0 : T != 0; }
 
 template <typename R, bool DRYDEP, bool SETTLE, int TSW, int CBLF, typename RNG>
 FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R> &W, int itime, double xt, double yt,
-                     R &zt, R &up, R &vp, R &wp, int &ldt, short &icbt, AdvCtx<R> &A, PblCtx<R> &B,
+                     R &zt, R &wp, int &ldt, short &icbt, LoopCtx<R> &A, const Stash<R> &S,
                      int &indz_last, R *prob, Stats *st) {
   const R eps = V.eps;
   const R eps2 = K(1.e-9);
@@ -1401,7 +1469,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const bool turbswitch = sw<TSW>(V.turbswitch);
   const bool cblflag = sw<CBLF>(V.cblflag == 1);
   Turb<R> T;
-  T.ust = B.ust; T.wst = B.wst; T.ol = B.ol; T.h = h;
+  T.ust = A.ust; T.wst = A.wst; T.ol = A.ol; T.h = h;
   T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);   // only read if hanna1 meets zeta >= 1 (see hanna1)
 
   if (V.method == 1) {
@@ -1417,26 +1485,34 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const int indz = find_level(hgt, V.nz, zt);
   const int indzp = indz + 1;
   indz_last = indz;
-  cache_fetch(V, F, B.C, W, B.LC, indz);
+  cache_fetch_stash(V, F, W, A, S, indz);
 
   // advance.f90:342-350
   const R dz = m_rcp(hgt[indzp - 1] - hgt[indz - 1]);
   const R dz1 = (zt - hgt[indz - 1]) * dz;
   const R dz2 = (hgt[indzp - 1] - zt) * dz;
-  A.u = dz1 * B.LC.uhi + dz2 * B.LC.ulo;
-  A.v = dz1 * B.LC.vhi + dz2 * B.LC.vlo;
-  A.w = dz1 * B.LC.whi + dz2 * B.LC.wlo;
-  const R rhoa = dz1 * B.LC.rhohi + dz2 * B.LC.rholo;
-  const R rhograd = dz1 * B.LC.rhogradhi + dz2 * B.LC.rhogradlo;
+  {
+    // grid-scale wind of this pass and its contribution to the displacement sums (advance.f90:539-540;
+    // the sums do not depend on the fine loop, so they are taken here and stay out of registers)
+    const R u = dz1 * S.get(S_UHI) + dz2 * S.get(S_ULO);
+    const R v = dz1 * S.get(S_VHI) + dz2 * S.get(S_VLO);
+    S.put(S_U, u); S.put(S_V, v);
+    S.put(S_W, dz1 * S.get(S_WHI) + dz2 * S.get(S_WLO));
+    S.add(S_DX, u * dt);
+    S.add(S_DY, v * dt);
+  }
+  const R rhoa = dz1 * S.get(S_RHOHI) + dz2 * S.get(S_RHOLO);
+  const R rhograd = dz1 * S.get(S_RGHI) + dz2 * S.get(S_RGLO);
 
   if (turbswitch) hanna(T, zt); else hanna1(T, zt);
-  B.ust = T.ust;   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
+  A.ust = T.ust;   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
 
   // horizontal Langevin, advance.f90:371-384
   if (nrand + 1 > V.maxrand) nrand = 1;
   {
     const R g1 = G.at(nrand), g2 = G.at(nrand + 1);
     const R dttlu = dt * m_rcp(T.tlu), dttlv = dt * m_rcp(T.tlv);
+    R up = S.get(S_UP), vp = S.get(S_VP);
     if (dttlu < K(.5)) {
       up = (K(1.) - dttlu) * up + g1 * T.sigu * m_sqrtp(K(2.) * dttlu);
     } else {
@@ -1449,6 +1525,9 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
       R rv = m_exp(-dttlv);
       vp = rv * vp + g2 * T.sigv * m_sqrtp(K(1.) - rv * rv);
     }
+    S.put(S_UP, up); S.put(S_VP, vp);
+    S.add(S_DAW, up * dt);   // advance.f90:541-542
+    S.add(S_DCW, vp * dt);
   }
   nrand = nrand + 2;
 
@@ -1471,7 +1550,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             int flagrein = 0;
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
-            cbl(V.ldirect, wp, zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, B.transition, ath, bth, flagrein);
+            cbl(V.ldirect, wp, zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, A.transition, ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
             if (flagrein == 1) {
@@ -1536,14 +1615,14 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(wp), K(1.e-5))) * V.ctl);
   ldt = max(ldt, V.mintime);
 
-  if (SETTLE && V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt);   // advance.f90:518-531
+  R w = S.get(S_W);
+  if (SETTLE && V.lsettling) {   // advance.f90:518-531
+    w = w + settling_velocity(V, hgt, xt, yt, zt);
+    S.put(S_W, w);
+  }
 
-  // advance.f90:539-547
-  A.dxsave = A.dxsave + A.u * dt;
-  A.dysave = A.dysave + A.v * dt;
-  A.dawsave = A.dawsave + up * dt;
-  A.dcwsave = A.dcwsave + vp * dt;
-  zt = zt + A.w * dt * (R)V.ldirect;
+  // advance.f90:543-547 (:539-542 are taken where u, v, up, vp are computed)
+  zt = zt + w * dt * (R)V.ldirect;
   if (zt >= hgt[V.nz - 1]) zt = hgt[V.nz - 1] - K(100.) * eps;
 
   const bool end_of_interval = A.itimec == itime + V.lsynctime;
@@ -1562,7 +1641,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) {
       if (ks < V.nspec && V.drydepspec[ks]) {
-        R vdepo = interp_vdep(V, F, B.C, W, ks);   // same value every pass (depoindicator cache in the reference)
+        R vdepo = interp_vdep(V, F, stash_cell(A, S), W, ks);   // same value every pass (depoindicator cache in the reference)
         prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_exp(-vdepo * m_abs(dt) / (K(2.) * href));
       }
     }

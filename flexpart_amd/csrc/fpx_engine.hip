@@ -313,13 +313,14 @@ struct PblRec {
 // INIT: the launch may contain newly released particles (initialize()); POLAR: the grid has polar caps
 template <typename R, bool DRYDEP, bool INIT, bool POLAR>
 __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
-                                                 unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag) {
+                                                 unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
+                                                 unsigned int *__restrict__ pbl_count) {
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= numpart) return;
-  pbl_flag[s] = 0;
+  pbl_flag[s] = 7;                                       // sort key "not a PBL particle"
   if (P.itra1[s] != itime) return;                       // timemanager.f90:537
   atomicAdd(&st->n_due, 1ull);   // one add per wave after the compiler's aggregation
 
@@ -378,7 +379,16 @@ __global__ void __launch_bounds__(kBlock) k_prep(View<R> V, GridP<R> Gp, Parts<R
     pbl_begin(V, ps.xt, ps.yt, W, A, B);
     Q.ust[s] = B.ust; Q.wst[s] = B.wst; Q.ol[s] = B.ol; Q.trans[s] = B.transition;
     Q.nrand0[s] = A.nrand;
-    pbl_flag[s] = 1;   // compacted in slot order afterwards: the work list stays sorted by cell
+    // Regime class of the particle's PBL passes (hanna.f90:42,59,91 and advance.f90:405-406).  The
+    // work list is the slots stably sorted by this 3-bit key: class by class, each class in slot
+    // (= cell) order, so the lanes of a wave run the same branch of the turbulence scheme.
+    unsigned char cls;
+    if (V.cblflag == 1 && V.turbswitch && (-A.h / B.ol > (R)5)) cls = 1;      // skewed CBL scheme
+    else if (A.h / m_abs(B.ol) < (R)1) cls = 2;                               // neutral
+    else if (B.ol < (R)0) cls = 3;                                            // unstable, Gaussian
+    else cls = 4;                                                             // stable
+    pbl_flag[s] = cls;
+    atomicAdd(pbl_count, 1u);   // aggregated per wave by the compiler
     return;
   }
   R usig, vsig, wsig;
@@ -400,8 +410,11 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
                                                      const unsigned int *__restrict__ pbl_count,
                                                      unsigned int *__restrict__ cursor) {
   __shared__ R hgt[kMaxNz];
+  __shared__ R stash_mem[S_COUNT * kStashStride];   // per-lane pass-level state, see Stash
+  static_assert(kStashStride == kBlock, "stash layout is one column per thread of the block");
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
+  const Stash<R> S{stash_mem + threadIdx.x};
   const unsigned int nlist = *pbl_count;
   const int lane = threadIdx.x & 63;
   const TimeW<R> W = time_weights(V, itime);   // wave-uniform
@@ -419,11 +432,10 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
   bool have = false;
   unsigned int s = 0, pid = 0;
   double xt = 0, yt = 0;
-  R zt = 0, up = 0, vp = 0, wp = 0;
+  R zt = 0, wp = 0;
   int ldt = 0;
   short icbt = 1;
-  AdvCtx<R> A;
-  PblCtx<R> B;
+  LoopCtx<R> A;
   R prob[kMaxSpec];
 
   for (;;) {
@@ -447,13 +459,23 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
         if (my < end) {
           s = pbl_list[my];
           xt = P.xt[s]; yt = P.yt[s]; zt = P.zt[s];
-          up = P.up[s]; vp = P.vp[s]; wp = P.wp[s];
+          wp = P.wp[s];
           ldt = P.idt[s]; icbt = P.cbt[s];
           pid = P.pid[s];
-          adv_begin(V, xt, yt, zt, itime, Q.nrand0[s], A);
-          cell_setup(B.C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);   // interpol_all.f90:57-64
-          B.ust = Q.ust[s]; B.wst = Q.wst[s]; B.ol = Q.ol[s]; B.transition = Q.trans[s];
-          B.LC.ilo = -1;
+          {
+            AdvCtx<R> A0;
+            adv_begin(V, xt, yt, zt, itime, Q.nrand0[s], A0);
+            Cell<R> C;
+            cell_setup(C, A0.ix, A0.jy, A0.ixp, A0.jyp, A0.xr, A0.yr);   // interpol_all.f90:57-64
+            A.ngrid = A0.ngrid; A.ix = A0.ix; A.jy = A0.jy; A.ixp = A0.ixp; A.jyp = A0.jyp;
+            A.h = A0.h; A.itimec = A0.itimec; A.nrand = A0.nrand;
+            S.put(S_P1, C.p1); S.put(S_P2, C.p2); S.put(S_P3, C.p3); S.put(S_P4, C.p4);
+          }
+          S.put(S_DX, (R)0); S.put(S_DY, (R)0); S.put(S_DAW, (R)0); S.put(S_DCW, (R)0);
+          S.put(S_U, (R)0); S.put(S_V, (R)0); S.put(S_W, (R)0);
+          S.put(S_UP, P.up[s]); S.put(S_VP, P.vp[s]);
+          A.ust = Q.ust[s]; A.wst = Q.wst[s]; A.ol = Q.ol[s]; A.transition = Q.trans[s];
+          A.ilo = -1;
           if (!LEAN && V.drydep) {
 #pragma unroll
             for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
@@ -471,11 +493,11 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
       Rng<R, RNGM> G;
       make_rng(V, pid, step, G);
       int indz = 1;
-      const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, up, vp, wp, ldt, icbt, A, B, indz, prob, st);
+      const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, icbt, A, S, indz, prob, st);
       if (rc != PBL_CONTINUE) {
-        P.zt[s] = zt; P.up[s] = up; P.vp[s] = vp; P.wp[s] = wp; P.idt[s] = ldt; P.cbt[s] = icbt;
-        Q.dxsave[s] = A.dxsave; Q.dysave[s] = A.dysave; Q.dawsave[s] = A.dawsave; Q.dcwsave[s] = A.dcwsave;
-        Q.u[s] = A.u; Q.v[s] = A.v; Q.w[s] = A.w;
+        P.zt[s] = zt; P.up[s] = S.get(S_UP); P.vp[s] = S.get(S_VP); P.wp[s] = wp; P.idt[s] = ldt; P.cbt[s] = icbt;
+        Q.dxsave[s] = S.get(S_DX); Q.dysave[s] = S.get(S_DY); Q.dawsave[s] = S.get(S_DAW); Q.dcwsave[s] = S.get(S_DCW);
+        Q.u[s] = S.get(S_U); Q.v[s] = S.get(S_V); Q.w[s] = S.get(S_W);
         Q.nrand[s] = A.nrand; Q.itimec[s] = A.itimec; Q.status[s] = rc | (indz << 2);
         if (!LEAN && V.drydep) {
 #pragma unroll
@@ -662,7 +684,8 @@ struct Engine : EngineBase {
   size_t sort_tmp_bytes = 0;
   Stats *d_stats = nullptr;
   unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[0] = list length, ctr[1] = chunk cursor
-  unsigned char *d_pbl_flag = nullptr;
+  unsigned char *d_pbl_flag = nullptr, *d_pbl_flag2 = nullptr;
+  unsigned int *d_iota = nullptr;
   PblRec<R> Q;
   GridP<R> Gp;
   WetP<R> Wp;
@@ -788,6 +811,8 @@ struct Engine : EngineBase {
     if ((rc = dalloc(&d_pbl_list, cap))) return rc;
     if ((rc = dalloc(&d_pbl_ctr, 2))) return rc;
     if ((rc = dalloc(&d_pbl_flag, cap))) return rc;
+    if ((rc = dalloc(&d_pbl_flag2, cap))) return rc;
+    if ((rc = dalloc(&d_iota, cap))) return rc;
     memset(&Q, 0, sizeof(Q));
     {
       R **qs[] = {&Q.ust, &Q.wst, &Q.ol, &Q.trans, &Q.dxsave, &Q.dysave, &Q.dawsave, &Q.dcwsave, &Q.u, &Q.v, &Q.w};
@@ -800,6 +825,7 @@ struct Engine : EngineBase {
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, (long long)cap, nullptr);
     k_iota_pid<<<nb, kBlock, 0, stream>>>(P.pid, 0, (long long)cap);
+    k_iota_pid<<<nb, kBlock, 0, stream>>>(d_iota, 0, (long long)cap);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
@@ -1145,8 +1171,7 @@ struct Engine : EngineBase {
     }
     {
       size_t need = 0;
-      HIPCHK(rocprim::select(nullptr, need, rocprim::counting_iterator<unsigned int>(0u), d_pbl_flag, d_pbl_list, d_pbl_ctr,
-                             (size_t)numpart, stream));
+      HIPCHK(rocprim::radix_sort_pairs(nullptr, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 3u, stream));
       if (need > sel_tmp_bytes) {
         if (d_sel_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_sel_tmp)); d_sel_tmp = nullptr; }
         HIPCHK(hipMalloc(&d_sel_tmp, need));
@@ -1160,20 +1185,20 @@ struct Engine : EngineBase {
       // exist (after an upload/seed or at itime 0), polar maps only on grids with poles
       const bool init = maybe_new || itime == 0;
       const bool polar = cfg.nglobal || cfg.sglobal;
-      typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *);
+      typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *, unsigned int *);
       prep_fn f;
       if (cfg.drydep) f = init ? (polar ? k_prep<R, true, true, true> : k_prep<R, true, true, false>)
                                : (polar ? k_prep<R, true, false, true> : k_prep<R, true, false, false>);
       else f = init ? (polar ? k_prep<R, false, true, true> : k_prep<R, false, true, false>)
                     : (polar ? k_prep<R, false, false, true> : k_prep<R, false, false, false>);
-      f<<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag);
+      f<<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag, d_pbl_ctr);
       maybe_new = false;
     }
     {
-      // ordered compaction of the flagged slots -> work list (length in d_pbl_ctr[0])
+      // work list = slots stably sorted by the 3-bit regime key (non-PBL slots, key 7, end up behind
+      // the d_pbl_ctr[0] entries that are used)
       size_t need = sel_tmp_bytes;
-      HIPCHK(rocprim::select(d_sel_tmp, need, rocprim::counting_iterator<unsigned int>(0u), d_pbl_flag, d_pbl_list, d_pbl_ctr,
-                             (size_t)numpart, stream));
+      HIPCHK(rocprim::radix_sort_pairs(d_sel_tmp, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 3u, stream));
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
     HIPCHK(hipEventRecord(ev.e[1], stream));
