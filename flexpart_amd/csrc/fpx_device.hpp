@@ -573,49 +573,82 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
   T.tlw = m_max(K(30.), T.tlw);
 }
 
+// ---------------------------------------------------------------------------
+// The PBL loop kernel keeps the part of a lane's state that is touched once per PASS, not
+// once per fine sub-step, in LDS instead of registers: the two cached profile levels, the
+// horizontal weights of the cell, the displacement sums, the grid-scale wind, the horizontal
+// turbulent velocities, and the invariants the fine loop reads once per sub-step (surface-layer
+// scales, density and its gradient): 31 values of R per lane.  The fine loop (cbl/hanna_short, ~120 live
+// registers of its own) then fits the 256-VGPR budget of two waves per SIMD without spilling
+// to scratch memory -- scratch spills of a persistent kernel are HBM traffic, LDS is not.
+// Layout: slot-major [S_COUNT][block], one column per lane; the accesses are volatile so that
+// the compiler does not forward the values through registers across the loop.
+// ---------------------------------------------------------------------------
+enum StashSlot {
+  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // LevelCache
+  S_P1, S_P2, S_P3, S_P4,                                                       // Cell weights
+  S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
+  S_U, S_V, S_W,                                                                // interpol_mod u, v, w
+  S_UP, S_VP,                                                                   // turbulent velocities along/across wind
+  S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; cbl.f90:79-81 transition
+  S_RHOA, S_RHOGRAD, S_RHOAUX, S_IAUX,                                          // per-pass invariants of the fine loop
+  S_COUNT
+};
+constexpr int kStashStride = 256;   // threads per block of the loop kernel
+template <typename R>
+struct Stash {
+  volatile R *p;   // &lds[0][threadIdx.x]
+  FPX_DEV R get(int k) const { return p[k * kStashStride]; }
+  FPX_DEV void put(int k, R v) const { p[k * kStashStride] = v; }
+  FPX_DEV void add(int k, R v) const { p[k * kStashStride] = p[k * kStashStride] + v; }
+};
+
 // hanna_short runs once per fine sub-step with the same h, ol, ust: the stability regime and
 // the reciprocals of the step-invariant divisors are taken once per pass
 template <typename R>
 struct HsInv {
-  R ih, iaux;    // 1/h; 1/ust (neutral) or 1/ol (unstable)
+  R ih;          // 1/h
   int regime;    // 0 neutral (hanna_short.f90:46-52), 1 unstable (:57-72), 2 stable (:77-81)
 };
+// iaux = 1/ust (neutral) or 1/ol (unstable) goes to the caller's store of per-pass invariants
 template <typename R>
-FPX_DEV HsInv<R> hanna_short_prepare(Turb<R> &T) {
+FPX_DEV HsInv<R> hanna_short_prepare(Turb<R> &T, R &iaux) {
   HsInv<R> I;
   I.ih = m_rcp(T.h);
   if (T.h / m_abs(T.ol) < K(1.)) {
     I.regime = 0;
     T.ust = m_max(K(1.e-4), T.ust);
-    I.iaux = m_rcp(T.ust);
+    iaux = m_rcp(T.ust);
   } else if (T.ol < K(0.)) {
     I.regime = 1;
-    I.iaux = m_rcp(T.ol);
+    iaux = m_rcp(T.ol);
   } else {
     I.regime = 2;
-    I.iaux = K(0.);
+    iaux = K(0.);
   }
   return I;
 }
 
-template <typename R>
-FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I) {   // hanna_short.f90:41-92
+// ST: where ust, wst, ol and iaux are read from (the LDS stash of the loop kernel)
+template <typename R, typename ST>
+FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   // hanna_short.f90:41-92
   if (I.regime == 0) {
-    const R corr = z * I.iaux;
+    const R corr = z * S.get(S_IAUX);
     T.sigw = K(1.3) * m_exp(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
-    T.sigw = T.sigw * T.ust + K(1.e-2);
+    T.sigw = T.sigw * S.get(S_UST) + K(1.e-2);
     T.tlw = K(0.5) * z * m_rcp(T.sigw * (K(1.) + K(1.5e-3) * corr));
   } else if (I.regime == 1) {
     const R lz = m_logp(T.zeta);
     const R z23 = sizeof(R) == 8 ? m_exp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
     const R zm13 = sizeof(R) == 8 ? m_exp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : K(-6.907755278982137)))
                                   : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
-    const R ust2 = T.ust * T.ust, wst2 = T.wst * T.wst;
+    const R ust = S.get(S_UST), wst = S.get(S_WST);
+    const R ust2 = ust * ust, wst2 = wst * wst;
     T.sigw = m_sqrtp(K(1.2) * wst2 * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * ust2) + K(1.e-2);
     // tlw (hanna.f90:78-84) and dsigwdz share the reciprocal of sigw
-    const bool low = z < m_abs(T.ol);
-    const R q = low ? K(0.55) - K(0.38) * m_abs(z * I.iaux) : K(1.);
+    const bool low = z < m_abs(S.get(S_OL));
+    const R q = low ? K(0.55) - K(0.38) * m_abs(z * S.get(S_IAUX)) : K(1.);
     const R i2 = m_rcp(T.sigw * q);
     const R isig = i2 * q;
     T.dsigwdz = K(0.5) * isig * I.ih * (K(-1.4) * ust2 + wst2 * (K(0.8) * zm13 - K(1.8) * z23));
@@ -623,8 +656,9 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I) {   // hanna_short.
     else if (T.zeta < K(0.1)) T.tlw = K(0.59) * z * isig;
     else T.tlw = K(0.15) * T.h * isig * (K(1.) - m_exp(K(-5) * T.zeta));
   } else {
-    T.sigw = K(1.e-2) + K(1.3) * T.ust * (K(1.) - T.zeta);
-    T.dsigwdz = K(-1.3) * T.ust * I.ih;
+    const R ust = S.get(S_UST);
+    T.sigw = K(1.e-2) + K(1.3) * ust * (K(1.) - T.zeta);
+    T.dsigwdz = K(-1.3) * ust * I.ih;
     T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_powr(T.zeta, K(0.8));
   }
   T.tlu = m_max(K(10.), T.tlu);
@@ -1385,41 +1419,12 @@ FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W
 // TSW / CBLF: -1 = read turbswitch / cblflag at run time, 0/1 = fixed at compile time
 // (specialised hot kernels: fewer scalar registers, no dead branches).  SETTLE/DRYDEP false
 // compile the aerosol paths out.
-// ---------------------------------------------------------------------------
-// The PBL loop kernel keeps the part of a lane's state that is touched once per PASS, not
-// once per fine sub-step, in LDS instead of registers: the two cached profile levels, the
-// horizontal weights of the cell, the displacement sums, the grid-scale wind and the horizontal
-// turbulent velocities (23 values of R per lane).  The fine loop (cbl/hanna_short, ~120 live
-// registers of its own) then fits the 256-VGPR budget of two waves per SIMD without spilling
-// to scratch memory -- scratch spills of a persistent kernel are HBM traffic, LDS is not.
-// Layout: slot-major [S_COUNT][block], one column per lane; the accesses are volatile so that
-// the compiler does not forward the values through registers across the loop.
-// ---------------------------------------------------------------------------
-enum StashSlot {
-  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // LevelCache
-  S_P1, S_P2, S_P3, S_P4,                                                       // Cell weights
-  S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
-  S_U, S_V, S_W,                                                                // interpol_mod u, v, w
-  S_UP, S_VP,                                                                   // turbulent velocities along/across wind
-  S_COUNT
-};
-constexpr int kStashStride = 256;   // threads per block of the loop kernel
-template <typename R>
-struct Stash {
-  volatile R *p;   // &lds[0][threadIdx.x]
-  FPX_DEV R get(int k) const { return p[k * kStashStride]; }
-  FPX_DEV void put(int k, R v) const { p[k * kStashStride] = v; }
-  FPX_DEV void add(int k, R v) const { p[k * kStashStride] = p[k * kStashStride] + v; }
-};
-
 template <typename R>
 struct LoopCtx {                // register-resident state of a lane across passes
   int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
   R h;
   int itimec, nrand;
   int ilo;                      // level index of the cached *lo profile level (-1 = empty), see LevelCache
-  R ust, wst, ol;               // hanna_mod ust, wst, ol
-  R transition;                 // cbl.f90:79-81, constant during the step
 };
 
 template <typename R>
@@ -1469,7 +1474,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const bool turbswitch = sw<TSW>(V.turbswitch);
   const bool cblflag = sw<CBLF>(V.cblflag == 1);
   Turb<R> T;
-  T.ust = A.ust; T.wst = A.wst; T.ol = A.ol; T.h = h;
+  T.ust = S.get(S_UST); T.wst = S.get(S_WST); T.ol = S.get(S_OL); T.h = h;
   T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);   // only read if hanna1 meets zeta >= 1 (see hanna1)
 
   if (V.method == 1) {
@@ -1501,11 +1506,15 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     S.add(S_DX, u * dt);
     S.add(S_DY, v * dt);
   }
-  const R rhoa = dz1 * S.get(S_RHOHI) + dz2 * S.get(S_RHOLO);
-  const R rhograd = dz1 * S.get(S_RGHI) + dz2 * S.get(S_RGLO);
+  {
+    const R rhoa = dz1 * S.get(S_RHOHI) + dz2 * S.get(S_RHOLO);
+    const R rhograd = dz1 * S.get(S_RGHI) + dz2 * S.get(S_RGLO);
+    S.put(S_RHOA, rhoa); S.put(S_RHOGRAD, rhograd);
+    S.put(S_RHOAUX, rhograd * m_rcp(rhoa));
+  }
 
   if (turbswitch) hanna(T, zt); else hanna1(T, zt);
-  A.ust = T.ust;   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
+  S.put(S_UST, T.ust);   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
 
   // horizontal Langevin, advance.f90:371-384
   if (nrand + 1 > V.maxrand) nrand = 1;
@@ -1532,13 +1541,13 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   nrand = nrand + 2;
 
   if (nrand + V.ifine > V.maxrand) nrand = 1;
-  const R irhoa = m_rcp(rhoa);
-  const R rhoaux = rhograd * irhoa;
   const R dtf = dt * V.fine;
   const R dtftlw = dtf * m_rcp(T.tlw);
   const bool cbl_on = cblflag && (-h / T.ol > K(5));
   const R sqrt_dtf = m_sqrtp(dtf);
-  const HsInv<R> HI = hanna_short_prepare(T);
+  R iaux;
+  const HsInv<R> HI = hanna_short_prepare(T, iaux);
+  S.put(S_IAUX, iaux);
 
   // vertical Langevin, ifine sub-steps, advance.f90:396-498
   for (int i = 1; i <= V.ifine; i++) {
@@ -1550,18 +1559,18 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             int flagrein = 0;
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
-            cbl(V.ldirect, wp, zt, T.wst, h, rhoa, rhograd, T.sigw, T.dsigwdz, T.tlw, A.transition, ath, bth, flagrein);
+            cbl(V.ldirect, wp, zt, S.get(S_WST), h, S.get(S_RHOA), S.get(S_RHOGRAD), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
             if (flagrein == 1) {
-              re_initialize_particle(V.ldirect, G, zt, T.wst, h, T.sigw, old_wp_buf, nrand, T.ol);
+              re_initialize_particle(V.ldirect, G, zt, S.get(S_WST), h, T.sigw, old_wp_buf, nrand, S.get(S_OL));
               wp = old_wp_buf;
               delz = wp * dtf;
               atomicAdd(&st->nan_count, 1ull);
             }
           } else {
             nrand = nrand + 1;
-            R ath = -wp * m_rcp(T.tlw) + T.sigw * T.dsigwdz + wp * wp * m_rcp(T.sigw) * T.dsigwdz + T.sigw * T.sigw * irhoa * rhograd;
+            R ath = -wp * m_rcp(T.tlw) + T.sigw * T.dsigwdz + wp * wp * m_rcp(T.sigw) * T.dsigwdz + T.sigw * T.sigw * S.get(S_RHOAUX);
             R bth = T.sigw * G.at(nrand) * m_sqrtp(K(2.) * dtftlw);
             wp = (wp + ath * dtf + bth) * (R)icbt;
             delz = wp * dtf;
@@ -1574,17 +1583,17 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             }
           }
         } else {
-          wp = ((K(1.) - dtftlw) * wp + G.at(nrand + i) * m_sqrtp(K(2.) * dtftlw) + dtf * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
+          wp = ((K(1.) - dtftlw) * wp + G.at(nrand + i) * m_sqrtp(K(2.) * dtftlw) + dtf * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw)) * (R)icbt;
           delz = wp * T.sigw * dtf;
         }
       } else {
         R rw = m_exp(-dtftlw);
-        wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + rhoaux * T.sigw)) * (R)icbt;
+        wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw)) * (R)icbt;
         delz = wp * T.sigw * dtf;
       }
     } else {
       R rw = m_exp(-dtftlw);
-      wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + rhoaux * (T.sigw * T.sigw))) * (R)icbt;
+      wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + S.get(S_RHOAUX) * (T.sigw * T.sigw))) * (R)icbt;
       delz = wp * dtf;
     }
 
@@ -1602,7 +1611,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     }
     if (i != V.ifine) {
       T.zeta = zt * HI.ih;
-      hanna_short(T, zt, HI);
+      hanna_short(T, zt, HI, S);
     }
   }
   if (!cblflag) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i", i = ifine+1 after the loop (advance.f90:499)

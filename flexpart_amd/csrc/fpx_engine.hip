@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
           S.put(S_DX, (R)0); S.put(S_DY, (R)0); S.put(S_DAW, (R)0); S.put(S_DCW, (R)0);
           S.put(S_U, (R)0); S.put(S_V, (R)0); S.put(S_W, (R)0);
           S.put(S_UP, P.up[s]); S.put(S_VP, P.vp[s]);
-          A.ust = Q.ust[s]; A.wst = Q.wst[s]; A.ol = Q.ol[s]; A.transition = Q.trans[s];
+          S.put(S_UST, Q.ust[s]); S.put(S_WST, Q.wst[s]); S.put(S_OL, Q.ol[s]); S.put(S_TRANS, Q.trans[s]);
           A.ilo = -1;
           if (!LEAN && V.drydep) {
 #pragma unroll
