@@ -276,19 +276,35 @@ struct Rng {
   const R *tab;
   int maxrand, mode;
   unsigned int pid, step, k0, k1;
+  // counter mode: one Philox call yields four normals (two Box-Muller pairs); the last block is
+  // kept so that consecutive draws share it.  Copies taken before the first draw start empty.
+  mutable unsigned int cblk;
+  mutable float c0, c1, c2, c3;
+  static constexpr bool kCounter = MODE == 2;
   // rannumb(idx), 1-based like the reference
   FPX_DEV R at(int idx) const {
     if ((MODE < 0 ? mode : MODE) != 2) return tab[min(idx, maxrand) - 1];   // the reference reads past the table on rare CBL re-draws; clamp instead
-    unsigned int o[4];
-    philox4x32(pid, step, (unsigned int)idx >> 1, 0x47415553u, k0, k1, o);
-    // clipped Box-Muller pair (the distribution of gasdev1, random_mod.f90:70-90)
-    float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float rr = sqrtf(-2.0f * __logf(u1));
-    float s, c;
-    __sincosf(6.2831853071795865f * u2, &s, &c);
-    float g = rr * ((idx & 1) ? s : c);
-    g = fminf(3.0f, fmaxf(-3.0f, g));
+    const unsigned int blk = (unsigned int)idx >> 2;
+    if (blk != cblk) {
+      unsigned int o[4];
+      philox4x32(pid, step, blk, 0x47415553u, k0, k1, o);
+      // clipped Box-Muller pairs (the distribution of gasdev1, random_mod.f90:70-90)
+      const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u3 = ((float)(o[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float u4 = ((float)(o[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+      const float ra = sqrtf(-2.0f * __logf(u1)), rb = sqrtf(-2.0f * __logf(u3));
+      float sa, ca, sb, cb;
+      __sincosf(6.2831853071795865f * u2, &sa, &ca);
+      __sincosf(6.2831853071795865f * u4, &sb, &cb);
+      c0 = fminf(3.0f, fmaxf(-3.0f, ra * ca));
+      c1 = fminf(3.0f, fmaxf(-3.0f, ra * sa));
+      c2 = fminf(3.0f, fmaxf(-3.0f, rb * cb));
+      c3 = fminf(3.0f, fmaxf(-3.0f, rb * sb));
+      cblk = blk;
+    }
+    const int ph = idx & 3;
+    const float g = ph == 0 ? c0 : (ph == 1 ? c1 : (ph == 2 ? c2 : c3));
     return (R)g;
   }
   // uniform [0,1) and start index for the counter modes
@@ -1516,6 +1532,9 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   if (turbswitch) hanna(T, zt); else hanna1(T, zt);
   S.put(S_UST, T.ust);   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
 
+  // counter mode: a pass starts on a block boundary of the generator, so that all lanes of a wave
+  // renew their block in the same fine sub-step (the draws of a pass are indexed alike in every lane)
+  if (RNG::kCounter) nrand = (nrand + 3) & ~3;
   // horizontal Langevin, advance.f90:371-384
   if (nrand + 1 > V.maxrand) nrand = 1;
   {

@@ -237,6 +237,7 @@ __device__ __forceinline__ void make_rng(const View<R> &V, unsigned int pid, uns
   G.tab = V.rannumb; G.maxrand = V.maxrand; G.mode = V.rng_mode;
   G.pid = pid; G.step = step;
   G.k0 = (unsigned int)V.seed; G.k1 = (unsigned int)(V.seed >> 32);
+  G.cblk = 0xffffffffu;
 }
 
 template <typename R>
