@@ -106,7 +106,7 @@ SYMBOLS = [
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
-    "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields",
+    "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
 ]
 
 _lib = None
@@ -127,6 +127,7 @@ def load():
     lib.fpx_last_error.restype = C.c_char_p
     lib.fpx_stream.restype = vp
     lib.fpx_stream.argtypes = [vp]
+    lib.fpx_math_probe.argtypes = [C.c_int32, vp, vp, C.c_int64]
     lib.fpx_create.argtypes = [C.POINTER(vp), C.POINTER(FpxConfig)]
     lib.fpx_destroy.argtypes = [vp]
     lib.fpx_polar_maps.argtypes = [C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]

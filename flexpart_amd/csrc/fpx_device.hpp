@@ -123,11 +123,35 @@ FPX_DEV double m_logp(double x) {
   const double dk = (double)e;
   return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + Rr) + dk * 1.90821492927058770002e-10)) - f);
 }
+// exp(x): k = rint(x/ln2), r = x - k*ln2 (two-part ln2), exp(r) by the degree-13 Taylor polynomial
+// split into even and odd halves (|r| <= 0.347: truncation 4e-18), scaled by ldexp.  Leaves out the
+// library's range screening: v_ldexp_f64 saturates to 0 / inf by itself, NaN propagates.
+FPX_DEV float m_expp(float x) { return expf(x); }
+FPX_DEV double m_expp(double x) {
+  const double k = rint(x * 1.4426950408889634074);
+  double r = fma(k, -6.93147180369123816490e-01, x);
+  r = fma(k, -1.90821492927058770002e-10, r);
+  const double r2 = r * r;
+  double pe = fma(r2, 1.1470745597729724714e-11, 2.0876756987868098979e-09);   // 1/14!, 1/12!
+  pe = fma(r2, pe, 2.7557319223985890653e-07);                                  // 1/10!
+  pe = fma(r2, pe, 2.4801587301587301587e-05);                                  // 1/8!
+  pe = fma(r2, pe, 1.3888888888888888889e-03);                                  // 1/6!
+  pe = fma(r2, pe, 4.1666666666666666667e-02);                                  // 1/4!
+  pe = fma(r2, pe, 0.5);                                                        // 1/2!
+  double po = fma(r2, 1.6059043836821614599e-10, 2.5052108385441718775e-08);   // 1/13!, 1/11!
+  po = fma(r2, po, 2.7557319223985890653e-06);                                  // 1/9!
+  po = fma(r2, po, 1.9841269841269841270e-04);                                  // 1/7!
+  po = fma(r2, po, 8.3333333333333333333e-03);                                  // 1/5!
+  po = fma(r2, po, 1.6666666666666666667e-01);                                  // 1/3!
+  // exp(r) = 1 + r + r2*(pe + r*po)
+  const double p = fma(r2, fma(r, po, pe), r) + 1.0;
+  return ldexp(p, (int)k);
+}
 // x**y for the reference's non-integer exponents (0.33333, 0.66666, 0.8 ...).  fp64: exp(y*log(x)),
 // relative error <= ~|y ln x| ulp (a few 1e-16 here) at a fraction of the cost of the
 // correctly-rounded pow; fp32 keeps powf.  x == 0 and x < 0 behave like pow (0/inf, NaN).
 FPX_HD float m_powr(float x, float y) { return powf(x, y); }
-FPX_DEV double m_powr(double x, double y) { return exp(y * m_logp(x)); }
+FPX_DEV double m_powr(double x, double y) { return m_expp(y * m_logp(x)); }
 // c = x**0.333333333 and ic2 = x**(-2*0.333333333) for x > 0 (the two "cuberoot" calls of cbl.f90:115-121,
 // exponent as written at cbl.f90:227).  fp64: r = x**(-1/3) from an f32 seed and two Newton steps
 // r <- r + r*(1 - x*r^3)/3, then the difference between 1/3 and 0.333333333 as the first-order
@@ -650,14 +674,14 @@ template <typename R, typename ST>
 FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   // hanna_short.f90:41-92
   if (I.regime == 0) {
     const R corr = z * S.get(S_IAUX);
-    T.sigw = K(1.3) * m_exp(K(-2.e-4) * corr);
+    T.sigw = K(1.3) * m_expp(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
     T.sigw = T.sigw * S.get(S_UST) + K(1.e-2);
     T.tlw = K(0.5) * z * m_rcp(T.sigw * (K(1.) + K(1.5e-3) * corr));
   } else if (I.regime == 1) {
     const R lz = m_logp(T.zeta);
-    const R z23 = sizeof(R) == 8 ? m_exp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
-    const R zm13 = sizeof(R) == 8 ? m_exp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : K(-6.907755278982137)))
+    const R z23 = sizeof(R) == 8 ? m_expp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
+    const R zm13 = sizeof(R) == 8 ? m_expp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : K(-6.907755278982137)))
                                   : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
     const R ust = S.get(S_UST), wst = S.get(S_WST);
     const R ust2 = ust * ust, wst2 = wst * wst;
@@ -670,7 +694,7 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     T.dsigwdz = K(0.5) * isig * I.ih * (K(-1.4) * ust2 + wst2 * (K(0.8) * zm13 - K(1.8) * z23));
     if (low) T.tlw = K(0.1) * z * i2;
     else if (T.zeta < K(0.1)) T.tlw = K(0.59) * z * isig;
-    else T.tlw = K(0.15) * T.h * isig * (K(1.) - m_exp(K(-5) * T.zeta));
+    else T.tlw = K(0.15) * T.h * isig * (K(1.) - m_expp(K(-5) * T.zeta));
   } else {
     const R ust = S.get(S_UST);
     T.sigw = K(1.e-2) + K(1.3) * ust * (K(1.) - T.zeta);
@@ -777,8 +801,8 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigma
   const R isa2 = isa * isa, isb2 = isb * isb;
   if (m_abs(deltawa) > K(6.) * sigmawa && m_abs(deltawb) > K(6.) * sigmawb) flagrein = 1;
   const R da = deltawa * isa, db = deltawb * isb;
-  const R pa = (usurad2p * isa) * m_exp(-(K(0.5) * (da * da)));
-  const R pb = (usurad2p * isb) * m_exp(-(K(0.5) * (db * db)));
+  const R pa = (usurad2p * isa) * m_expp(-(K(0.5) * (da * da)));
+  const R pb = (usurad2p * isb) * m_expp(-(K(0.5) * (db * db)));
   const R ptot = dens * aluarw * pa + dens * bluarw * pb;
   const R aperfa = deltawa * usurad2 * isa;
   const R aperfb = deltawb * usurad2 * isb;
@@ -1544,13 +1568,13 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     if (dttlu < K(.5)) {
       up = (K(1.) - dttlu) * up + g1 * T.sigu * m_sqrtp(K(2.) * dttlu);
     } else {
-      R ru = m_exp(-dttlu);
+      R ru = m_expp(-dttlu);
       up = ru * up + g1 * T.sigu * m_sqrtp(K(1.) - ru * ru);
     }
     if (dttlv < K(.5)) {
       vp = (K(1.) - dttlv) * vp + g2 * T.sigv * m_sqrtp(K(2.) * dttlv);
     } else {
-      R rv = m_exp(-dttlv);
+      R rv = m_expp(-dttlv);
       vp = rv * vp + g2 * T.sigv * m_sqrtp(K(1.) - rv * rv);
     }
     S.put(S_UP, up); S.put(S_VP, vp);
@@ -1606,12 +1630,12 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
           delz = wp * T.sigw * dtf;
         }
       } else {
-        R rw = m_exp(-dtftlw);
+        R rw = m_expp(-dtftlw);
         wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw)) * (R)icbt;
         delz = wp * T.sigw * dtf;
       }
     } else {
-      R rw = m_exp(-dtftlw);
+      R rw = m_expp(-dtftlw);
       wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + S.get(S_RHOAUX) * (T.sigw * T.sigw))) * (R)icbt;
       delz = wp * dtf;
     }
@@ -1670,7 +1694,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     for (int ks = 0; ks < kMaxSpec; ks++) {
       if (ks < V.nspec && V.drydepspec[ks]) {
         R vdepo = interp_vdep(V, F, stash_cell(A, S), W, ks);   // same value every pass (depoindicator cache in the reference)
-        prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_exp(-vdepo * m_abs(dt) / (K(2.) * href));
+        prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_expp(-vdepo * m_abs(dt) / (K(2.) * href));
       }
     }
   }

@@ -511,6 +511,24 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
   }
 }
 
+// diagnostics: the fp64 math helpers of fpx_device.hpp on plain arrays (fpx_math_probe)
+__global__ void k_math_probe(int fn, const double *__restrict__ x, double *__restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = x[i];
+  double r = 0.0, c, ic2;
+  switch (fn) {
+    case 0: r = m_expp(v); break;
+    case 1: r = m_logp(v); break;
+    case 2: r = m_sqrtp(v); break;
+    case 3: r = m_rcp(v); break;
+    case 4: r = m_rsqrt(v); break;
+    case 5: m_cuberoot_parts(v, c, ic2); r = c; break;
+    default: m_cuberoot_parts(v, c, ic2); r = ic2; break;
+  }
+  y[i] = r;
+}
+
 // completion of the PBL particles: label 700 if the particle left the PBL, sigmas for the
 // mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
 template <typename R, bool DRYDEP, bool POLAR>
@@ -1709,5 +1727,21 @@ int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f) {
 int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext) { FPX_GUARD(h); return h->impl->wetdepo(itime, ltsample, loutnext); }
 int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_wetgrid(wetgridunc, allreduce, clear); }
 void *fpx_stream(fpx_handle h) { return (h && h->impl) ? h->impl->stream_ptr() : nullptr; }
+
+int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n) {
+  if (fn < 0 || fn > 6 || !x || !y || n < 0) return FPX_ERR_ARG;
+  if (n == 0) return FPX_OK;
+  double *dx = nullptr, *dy = nullptr;
+  if (hipMalloc(&dx, n * sizeof(double)) != hipSuccess) return FPX_ERR_NOMEM;
+  if (hipMalloc(&dy, n * sizeof(double)) != hipSuccess) { (void)hipFree(dx); return FPX_ERR_NOMEM; }
+  hipError_t e = hipMemcpy(dx, x, n * sizeof(double), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    fpx::k_math_probe<<<(unsigned)((n + fpx::kBlock - 1) / fpx::kBlock), fpx::kBlock>>>(fn, dx, dy, n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(y, dy, n * sizeof(double), hipMemcpyDeviceToHost);
+  (void)hipFree(dx); (void)hipFree(dy);
+  return e == hipSuccess ? FPX_OK : FPX_ERR_DEVICE;
+}
 
 }  // extern "C"

@@ -324,3 +324,45 @@ def test_wet_deposition(built, kind, gas):
     assert bad.sum() <= (0 if kind == "r8" else 0.02 * n), bad.sum()
     assert np.abs(w - ow).max() <= (2e-5 if kind == "r8" else 5e-3) * ow.max()
     assert abs(w.sum() - ow.sum()) <= (1e-5 if kind == "r8" else 1e-3) * ow.sum()
+
+
+def test_device_math_helpers_against_libm(built):
+    """The 1-2 ulp fp64 helpers of the Langevin loop (fpx_device.hpp: m_expp, m_logp, m_sqrtp, m_rcp,
+    m_rsqrt, m_cuberoot_parts) against numpy/libm.  Tolerance 4 ulp (8.9e-16 relative); for the
+    logarithm the bound is absolute, 4e-16*max(1,|log x|), which is what x**y = exp(y*log x) needs."""
+    import ctypes as C
+    from flexpart_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(7)
+
+    def probe(fn, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        rc = lib.fpx_math_probe(fn, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.size)
+        assert rc == 0
+        return y
+
+    ulp4 = 4 * 2.0 ** -52
+    n = 200000
+    x = np.concatenate([rng.uniform(-745.0, 700.0, n), rng.uniform(-40.0, 2.0, n), [0.0, -0.0, 1e-300, -1e-300, -800.0]])
+    got, want = probe(0, x), np.exp(x)
+    norm = want > 1e-300
+    assert np.max(np.abs(got[norm] - want[norm]) / want[norm]) < ulp4
+    assert np.all(np.abs(got[~norm] - want[~norm]) <= 1e-300)
+    pos = np.concatenate([10.0 ** rng.uniform(-300, 300, n), rng.uniform(0.5, 2.0, n), 1.0 + rng.uniform(-1e-8, 1e-8, 1000), [1.0, 2.0, 0.5]])
+    got, want = probe(1, pos), np.log(pos)
+    assert np.max(np.abs(got - want) / np.maximum(1.0, np.abs(want))) < 4e-16
+    assert probe(1, np.array([0.0]))[0] == -np.inf and np.isnan(probe(1, np.array([-1.0]))[0])
+    mid = np.concatenate([10.0 ** rng.uniform(-150, 150, n), rng.uniform(0.0, 4.0, n)])
+    got, want = probe(2, np.concatenate([mid, [0.0]])), np.sqrt(np.concatenate([mid, [0.0]]))
+    assert got[-1] == 0.0
+    assert np.max(np.abs(got[:-1] - want[:-1]) / want[:-1]) < ulp4
+    sgn = mid * rng.choice([-1.0, 1.0], mid.size)
+    assert np.max(np.abs(probe(3, sgn) * sgn - 1.0)) < ulp4
+    assert np.max(np.abs(probe(4, mid) * np.sqrt(mid) - 1.0)) < ulp4
+    # the two "cube roots" of cbl.f90:115-121 keep the reference's exponent 0.333333333 (not 1/3)
+    sk = np.concatenate([10.0 ** rng.uniform(-30, 30, n), 10.0 ** rng.uniform(-60, 60, 1000)])
+    lg = np.log(sk)
+    tol = ulp4 * (1.0 + np.abs(lg))       # exp(y*log x) amplifies the rounding of log x by |y log x|
+    assert np.max(np.abs(probe(5, sk) / np.exp(0.333333333 * lg) - 1.0) / tol) < 1.0
+    assert np.max(np.abs(probe(6, sk) / np.exp(-2.0 * 0.333333333 * lg) - 1.0) / tol) < 1.0
