@@ -637,7 +637,9 @@ enum StashSlot {
 constexpr int kStashStride = 256;   // threads per block of the loop kernel
 template <typename R>
 struct Stash {
-  volatile R *p;   // &lds[0][threadIdx.x]
+  // an LDS (address space 3) pointer, so that the accesses are ds_read/ds_write and not flat memory operations
+  typedef __attribute__((address_space(3))) volatile R *lds_ptr;
+  lds_ptr p;       // &lds[0][threadIdx.x]
   FPX_DEV R get(int k) const { return p[k * kStashStride]; }
   FPX_DEV void put(int k, R v) const { p[k * kStashStride] = v; }
   FPX_DEV void add(int k, R v) const { p[k * kStashStride] = p[k * kStashStride] + v; }

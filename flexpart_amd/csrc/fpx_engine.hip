@@ -415,7 +415,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
   static_assert(kStashStride == kBlock, "stash layout is one column per thread of the block");
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
-  const Stash<R> S{stash_mem + threadIdx.x};
+  const Stash<R> S{(typename Stash<R>::lds_ptr)(stash_mem + threadIdx.x)};
   const unsigned int nlist = *pbl_count;
   const int lane = threadIdx.x & 63;
   const TimeW<R> W = time_weights(V, itime);   // wave-uniform
