@@ -618,7 +618,8 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
 // once per fine sub-step, in LDS instead of registers: the two cached profile levels, the
 // horizontal weights of the cell, the displacement sums, the grid-scale wind, the horizontal
 // turbulent velocities, and the invariants the fine loop reads once per sub-step (surface-layer
-// scales, density and its gradient): 31 values of R per lane.  The fine loop (cbl/hanna_short, ~120 live
+// scales, density and its gradient): 26 values of R per lane, which leaves room for three blocks
+// of 256 threads per CU (3 x (26 x 2 KB + height column) <= 160 KB).  The fine loop (cbl/hanna_short, ~120 live
 // registers of its own) then fits the 256-VGPR budget of two waves per SIMD without spilling
 // to scratch memory -- scratch spills of a persistent kernel are HBM traffic, LDS is not.
 // Layout: slot-major [S_COUNT][block], one column per lane; the accesses are volatile so that
@@ -626,12 +627,12 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
 // ---------------------------------------------------------------------------
 enum StashSlot {
   S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // LevelCache
-  S_P1, S_P2, S_P3, S_P4,                                                       // Cell weights
+  S_DDX, S_DDY,                                                                 // position inside the cell (interpol_all.f90:57-58); p1..p4 follow from it
   S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
-  S_U, S_V, S_W,                                                                // interpol_mod u, v, w
+  S_ZT0, S_W,                                                                   // height at the start of the pass (u, v follow from it and the cached levels); interpol_mod w
   S_UP, S_VP,                                                                   // turbulent velocities along/across wind
   S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; cbl.f90:79-81 transition
-  S_RHOA, S_RHOGRAD, S_RHOAUX, S_IAUX,                                          // per-pass invariants of the fine loop
+  S_RHOA, S_RHOAUX,                                                             // per-pass invariants of the fine loop: rhoa, rhograd/rhoa
   S_COUNT
 };
 constexpr int kStashStride = 256;   // threads per block of the loop kernel
@@ -649,33 +650,32 @@ struct Stash {
 // the reciprocals of the step-invariant divisors are taken once per pass
 template <typename R>
 struct HsInv {
-  R ih;          // 1/h
+  R ih, iaux;    // 1/h; 1/ust (neutral) or 1/ol (unstable)
   int regime;    // 0 neutral (hanna_short.f90:46-52), 1 unstable (:57-72), 2 stable (:77-81)
 };
-// iaux = 1/ust (neutral) or 1/ol (unstable) goes to the caller's store of per-pass invariants
 template <typename R>
-FPX_DEV HsInv<R> hanna_short_prepare(Turb<R> &T, R &iaux) {
+FPX_DEV HsInv<R> hanna_short_prepare(Turb<R> &T) {
   HsInv<R> I;
   I.ih = m_rcp(T.h);
   if (T.h / m_abs(T.ol) < K(1.)) {
     I.regime = 0;
     T.ust = m_max(K(1.e-4), T.ust);
-    iaux = m_rcp(T.ust);
+    I.iaux = m_rcp(T.ust);
   } else if (T.ol < K(0.)) {
     I.regime = 1;
-    iaux = m_rcp(T.ol);
+    I.iaux = m_rcp(T.ol);
   } else {
     I.regime = 2;
-    iaux = K(0.);
+    I.iaux = K(0.);
   }
   return I;
 }
 
-// ST: where ust, wst, ol and iaux are read from (the LDS stash of the loop kernel)
+// ST: where ust, wst, ol are read from (the LDS stash of the loop kernel)
 template <typename R, typename ST>
 FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   // hanna_short.f90:41-92
   if (I.regime == 0) {
-    const R corr = z * S.get(S_IAUX);
+    const R corr = z * I.iaux;
     T.sigw = K(1.3) * m_expp(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
     T.sigw = T.sigw * S.get(S_UST) + K(1.e-2);
@@ -690,7 +690,7 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     T.sigw = m_sqrtp(K(1.2) * wst2 * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * ust2) + K(1.e-2);
     // tlw (hanna.f90:78-84) and dsigwdz share the reciprocal of sigw
     const bool low = z < m_abs(S.get(S_OL));
-    const R q = low ? K(0.55) - K(0.38) * m_abs(z * S.get(S_IAUX)) : K(1.);
+    const R q = low ? K(0.55) - K(0.38) * m_abs(z * I.iaux) : K(1.);
     const R i2 = m_rcp(T.sigw * q);
     const R isig = i2 * q;
     T.dsigwdz = K(0.5) * isig * I.ih * (K(-1.4) * ust2 + wst2 * (K(0.8) * zm13 - K(1.8) * z23));
@@ -737,10 +737,10 @@ FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
 // (the straightforward form has 20 divisions, 7 square roots, 1 log and 4 exp).
 // `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
 template <typename R>
-FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhograd, R sigmaw, R dsigmawdz, R tlw, R transition,
+FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhoaux, R sigmaw, R dsigmawdz, R tlw, R transition,
                  R &ath, R &bth, int &flagrein) {
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
-  const R dens = rhoa, ddens = rhograd, timedir = (R)ldirect;
+  const R dens = rhoa, ddens = rhoaux * rhoa /* rhograd; rhoaux = rhograd/rhoa */, timedir = (R)ldirect;
   const R ih = m_rcp(h);
   const R z = zp * ih;
   const R w2 = sigmaw * sigmaw;
@@ -1472,7 +1472,9 @@ struct LoopCtx {                // register-resident state of a lane across pass
 template <typename R>
 FPX_DEV Cell<R> stash_cell(const LoopCtx<R> &L, const Stash<R> &S) {
   Cell<R> C;
-  C.p1 = S.get(S_P1); C.p2 = S.get(S_P2); C.p3 = S.get(S_P3); C.p4 = S.get(S_P4);
+  const R ddx = S.get(S_DDX), ddy = S.get(S_DDY);          // as cell_setup, interpol_all.f90:59-64
+  const R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
+  C.p1 = rddx * rddy; C.p2 = ddx * rddy; C.p3 = rddx * ddy; C.p4 = ddx * ddy;
   C.ix = L.ix; C.jy = L.jy; C.ixp = L.ixp; C.jyp = L.jyp;
   return C;
 }
@@ -1498,6 +1500,19 @@ FPX_DEV void cache_fetch_stash(const View<R> &V, const Fld<R> &F, const TimeW<R>
     S.put(S_UHI, Lv.u); S.put(S_VHI, Lv.v); S.put(S_WHI, Lv.w); S.put(S_RHOHI, Lv.rho); S.put(S_RGHI, Lv.rhograd);
   }
   L.ilo = indz;
+}
+
+// interpol_mod u, v of the pass that just ended (advance.f90:342-346), from the pass's start height
+// and the two cached levels -- the same expressions pbl_pass evaluates, so the same bits
+template <typename R>
+FPX_DEV void pass_wind(const R *hgt, const LoopCtx<R> &L, const Stash<R> &S, R &u, R &v) {
+  const int indz = L.ilo, indzp = indz + 1;
+  const R zt0 = S.get(S_ZT0);
+  const R dz = m_rcp(hgt[indzp - 1] - hgt[indz - 1]);
+  const R dz1 = (zt0 - hgt[indz - 1]) * dz;
+  const R dz2 = (hgt[indzp - 1] - zt0) * dz;
+  u = dz1 * S.get(S_UHI) + dz2 * S.get(S_ULO);
+  v = dz1 * S.get(S_VHI) + dz2 * S.get(S_VLO);
 }
 
 template <int T>
@@ -1543,7 +1558,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     // the sums do not depend on the fine loop, so they are taken here and stay out of registers)
     const R u = dz1 * S.get(S_UHI) + dz2 * S.get(S_ULO);
     const R v = dz1 * S.get(S_VHI) + dz2 * S.get(S_VLO);
-    S.put(S_U, u); S.put(S_V, v);
+    S.put(S_ZT0, zt);          // pass_wind() recomputes u, v from it when the particle leaves the loop
     S.put(S_W, dz1 * S.get(S_WHI) + dz2 * S.get(S_WLO));
     S.add(S_DX, u * dt);
     S.add(S_DY, v * dt);
@@ -1551,7 +1566,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   {
     const R rhoa = dz1 * S.get(S_RHOHI) + dz2 * S.get(S_RHOLO);
     const R rhograd = dz1 * S.get(S_RGHI) + dz2 * S.get(S_RGLO);
-    S.put(S_RHOA, rhoa); S.put(S_RHOGRAD, rhograd);
+    S.put(S_RHOA, rhoa);
     S.put(S_RHOAUX, rhograd * m_rcp(rhoa));
   }
 
@@ -1590,9 +1605,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const R dtftlw = dtf * m_rcp(T.tlw);
   const bool cbl_on = cblflag && (-h / T.ol > K(5));
   const R sqrt_dtf = m_sqrtp(dtf);
-  R iaux;
-  const HsInv<R> HI = hanna_short_prepare(T, iaux);
-  S.put(S_IAUX, iaux);
+  const HsInv<R> HI = hanna_short_prepare(T);
 
   // vertical Langevin, ifine sub-steps, advance.f90:396-498
   for (int i = 1; i <= V.ifine; i++) {
@@ -1604,7 +1617,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             int flagrein = 0;
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
-            cbl(V.ldirect, wp, zt, S.get(S_WST), h, S.get(S_RHOA), S.get(S_RHOGRAD), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
+            cbl(V.ldirect, wp, zt, S.get(S_WST), h, S.get(S_RHOA), S.get(S_RHOAUX), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
             if (flagrein == 1) {

@@ -34,7 +34,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 constexpr int kBlock = 256;
 #ifndef FPX_LOOP_WAVES
-#define FPX_LOOP_WAVES 2   // minimum waves per SIMD the Langevin kernel is register-budgeted for
+#define FPX_LOOP_WAVES 3   // waves per SIMD the Langevin kernel is register-budgeted for (<= 168 VGPRs)
 #endif
 constexpr int kMaxNz = 512;
 
@@ -410,9 +410,12 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
                                                      const unsigned int *__restrict__ pbl_list,
                                                      const unsigned int *__restrict__ pbl_count,
                                                      unsigned int *__restrict__ cursor) {
-  __shared__ R hgt[kMaxNz];
-  __shared__ R stash_mem[S_COUNT * kStashStride];   // per-lane pass-level state, see Stash
+  // dynamic LDS: [S_COUNT][kBlock] stash (per-lane pass-level state, see Stash) + the height column,
+  // sized by the host (loop_smem_bytes) so that three blocks fit one CU for the usual nz
+  extern __shared__ __align__(16) unsigned char fpx_loop_smem[];
   static_assert(kStashStride == kBlock, "stash layout is one column per thread of the block");
+  R *stash_mem = reinterpret_cast<R *>(fpx_loop_smem);
+  R *hgt = stash_mem + S_COUNT * kStashStride;
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
   const Stash<R> S{(typename Stash<R>::lds_ptr)(stash_mem + threadIdx.x)};
@@ -466,14 +469,12 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
           {
             AdvCtx<R> A0;
             adv_begin(V, xt, yt, zt, itime, Q.nrand0[s], A0);
-            Cell<R> C;
-            cell_setup(C, A0.ix, A0.jy, A0.ixp, A0.jyp, A0.xr, A0.yr);   // interpol_all.f90:57-64
             A.ngrid = A0.ngrid; A.ix = A0.ix; A.jy = A0.jy; A.ixp = A0.ixp; A.jyp = A0.jyp;
             A.h = A0.h; A.itimec = A0.itimec; A.nrand = A0.nrand;
-            S.put(S_P1, C.p1); S.put(S_P2, C.p2); S.put(S_P3, C.p3); S.put(S_P4, C.p4);
+            S.put(S_DDX, A0.xr - (R)A0.ix); S.put(S_DDY, A0.yr - (R)A0.jy);   // interpol_all.f90:57-58
           }
           S.put(S_DX, (R)0); S.put(S_DY, (R)0); S.put(S_DAW, (R)0); S.put(S_DCW, (R)0);
-          S.put(S_U, (R)0); S.put(S_V, (R)0); S.put(S_W, (R)0);
+          S.put(S_W, (R)0);
           S.put(S_UP, P.up[s]); S.put(S_VP, P.vp[s]);
           S.put(S_UST, Q.ust[s]); S.put(S_WST, Q.wst[s]); S.put(S_OL, Q.ol[s]); S.put(S_TRANS, Q.trans[s]);
           A.ilo = -1;
@@ -498,7 +499,11 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
       if (rc != PBL_CONTINUE) {
         P.zt[s] = zt; P.up[s] = S.get(S_UP); P.vp[s] = S.get(S_VP); P.wp[s] = wp; P.idt[s] = ldt; P.cbt[s] = icbt;
         Q.dxsave[s] = S.get(S_DX); Q.dysave[s] = S.get(S_DY); Q.dawsave[s] = S.get(S_DAW); Q.dcwsave[s] = S.get(S_DCW);
-        Q.u[s] = S.get(S_U); Q.v[s] = S.get(S_V); Q.w[s] = S.get(S_W);
+        {
+          R u, v;
+          pass_wind(hgt, A, S, u, v);
+          Q.u[s] = u; Q.v[s] = v; Q.w[s] = S.get(S_W);
+        }
         Q.nrand[s] = A.nrand; Q.itimec[s] = A.itimec; Q.status[s] = rc | (indz << 2);
         if (!LEAN && V.drydep) {
 #pragma unroll
@@ -1185,7 +1190,8 @@ struct Engine : EngineBase {
       hipDeviceProp_t prop;
       HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
       int per_cu = 0;
-      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, 0));
+      HIPCHK(hipFuncSetAttribute((const void *)loop_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_smem_bytes()));
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, loop_smem_bytes()));
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
     }
     {
@@ -1221,7 +1227,7 @@ struct Engine : EngineBase {
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
     HIPCHK(hipEventRecord(ev.e[1], stream));
-    loop_kernel()<<<pbl_grid, kBlock, 0, stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
     HIPCHK(hipEventRecord(ev.e[2], stream));
     {
       const bool polar = cfg.nglobal || cfg.sglobal;
@@ -1270,6 +1276,7 @@ struct Engine : EngineBase {
 
   // the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
   typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *, unsigned int *);
+  size_t loop_smem_bytes() const { return sizeof(R) * ((size_t)S_COUNT * kStashStride + (size_t)cfg.nz); }
   loop_fn loop_kernel() const {
     const bool lean = !cfg.drydep && !cfg.lsettling;
     const bool philox = cfg.rng_mode == FPX_RNG_PHILOX;
