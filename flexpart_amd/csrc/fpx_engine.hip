@@ -33,6 +33,9 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
   } while (0)
 
 constexpr int kBlock = 256;
+#ifndef FPX_PREP_WAVES
+#define FPX_PREP_WAVES 2   // register budget (waves per SIMD) of the one-thread-per-particle kernels k_prep / k_pbl_finish
+#endif
 #ifndef FPX_LOOP_WAVES
 #define FPX_LOOP_WAVES 3   // waves per SIMD the Langevin kernel is register-budgeted for (<= 168 VGPRs)
 #endif
@@ -313,7 +316,7 @@ struct PblRec {
 
 // INIT: the launch may contain newly released particles (initialize()); POLAR: the grid has polar caps
 template <typename R, bool DRYDEP, bool INIT, bool POLAR>
-__global__ void __launch_bounds__(kBlock) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
                                                  unsigned int *__restrict__ pbl_count) {
   __shared__ R hgt[kMaxNz];
@@ -537,7 +540,7 @@ __global__ void k_math_probe(int fn, const double *__restrict__ x, double *__res
 // completion of the PBL particles: label 700 if the particle left the PBL, sigmas for the
 // mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
 template <typename R, bool DRYDEP, bool POLAR>
-__global__ void __launch_bounds__(kBlock) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+__global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                        const unsigned int *__restrict__ pbl_list,
                                                        const unsigned int *__restrict__ pbl_count) {
   __shared__ R hgt[kMaxNz];
