@@ -81,6 +81,15 @@ class FpxOutgrid(C.Structure):
     ]
 
 
+class FpxOutgridNest(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_int32),
+        ("numxgridn", C.c_int32), ("numygridn", C.c_int32),
+        ("dxoutn", C.c_double), ("dyoutn", C.c_double), ("xoutshiftn", C.c_double), ("youtshiftn", C.c_double),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
 class FpxWetConfig(C.Structure):
     _fields_ = [("struct_bytes", C.c_int32), ("wetdepspec", C.c_int32 * FPX_MAXSPEC)] + \
                [(n, C.c_double * FPX_MAXSPEC) for n in ("weta_gas", "wetb_gas", "crain_aero", "csnow_aero",
@@ -107,6 +116,7 @@ SYMBOLS = [
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
+    "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors",
 ]
 
 _lib = None
@@ -128,6 +138,10 @@ def load():
     lib.fpx_stream.restype = vp
     lib.fpx_stream.argtypes = [vp]
     lib.fpx_math_probe.argtypes = [C.c_int32, vp, vp, C.c_int64]
+    lib.fpx_outgrid_nest_init.argtypes = [vp, C.POINTER(FpxOutgridNest)]
+    lib.fpx_get_grids_nest.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32]
+    lib.fpx_receptors_init.argtypes = [vp, C.c_int32, vp, vp, vp]
+    lib.fpx_get_receptors.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32]
     lib.fpx_create.argtypes = [C.POINTER(vp), C.POINTER(FpxConfig)]
     lib.fpx_destroy.argtypes = [vp]
     lib.fpx_polar_maps.argtypes = [C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]

@@ -1854,7 +1854,38 @@ struct GridP {
   R *gridunc;                              // (x, y, z, spec, pointspec, classunc, age), x fastest
   float *drygridunc;                       // (x, y, spec, pointspec, classunc, age): real(dep_prec)
   float *wetgridunc;                       // same shape as drygridunc
+  // nested output grid (com_mod.f90:585-586, unc_mod.f90:24-28): same levels and trailing dimensions
+  int nested;                              // nested_output == 1
+  int numxgridn, numygridn;
+  R dxoutn, dyoutn, xoutshiftn, youtshiftn;
+  R *griduncn;
+  float *drygriduncn, *wetgriduncn;
+  // receptor points (com_mod.f90:658-663)
+  int numreceptor;
+  const R *receptor;                       // [3][numreceptor]: xreceptor, yreceptor, receptorarea
+  R *creceptor;                            // [nspec][numreceptor]
 };
+
+// one horizontal output grid: the mother grid or the nested one
+template <typename R>
+struct OutGeom {
+  int numx, numy;
+  R dxout, dyout, xshift, yshift;
+  R *grid;
+  float *dry, *wet;
+};
+template <typename R>
+FPX_DEV OutGeom<R> out_geom(const GridP<R> &Gp, bool nest) {
+  OutGeom<R> g;
+  if (nest) {
+    g.numx = Gp.numxgridn; g.numy = Gp.numygridn; g.dxout = Gp.dxoutn; g.dyout = Gp.dyoutn;
+    g.xshift = Gp.xoutshiftn; g.yshift = Gp.youtshiftn; g.grid = Gp.griduncn; g.dry = Gp.drygriduncn; g.wet = Gp.wetgriduncn;
+  } else {
+    g.numx = Gp.numxgrid; g.numy = Gp.numygrid; g.dxout = Gp.dxout; g.dyout = Gp.dyout;
+    g.xshift = Gp.xoutshift; g.yshift = Gp.youtshift; g.grid = Gp.gridunc; g.dry = Gp.drygridunc; g.wet = Gp.wetgridunc;
+  }
+  return g;
+}
 
 template <typename R>
 FPX_DEV int ageclass(const GridP<R> &Gp, int itage) {   // conccalc.f90:54-58, timemanager.f90:545-548
@@ -1926,37 +1957,68 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
   for (; kz <= Gp.numzgrid; kz++)
     if (Gp.outheight[kz - 1] > zt) break;
   const bool inside = active && kz <= Gp.numzgrid;
-  const R xl = (R)((xt * (double)V.dx + (double)Gp.xoutshift) / (double)Gp.dxout);
-  const R yl = (R)((yt * (double)V.dy + (double)Gp.youtshift) / (double)Gp.dyout);
-  int ix = (int)xl; if (xl < K(0.)) ix = ix - 1;
-  int jy = (int)yl; if (yl < K(0.)) jy = jy - 1;
-  const bool direct = !Gp.lusekerneloutput || itage < 10800 || xl < K(0.5) || yl < K(0.5) ||
-                      xl > (R)(Gp.numxgrid - 1) - K(0.5) || yl > (R)(Gp.numygrid - 1) - K(0.5);
-  const R ddx = xl - (R)ix, ddy = yl - (R)jy;
-  int ixp, jyp;
-  R wx, wy;
-  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
-  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
-  const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
-  const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
-  const long long plane = (long long)Gp.numxgrid * Gp.numygrid;
-  const long long sstride = plane * Gp.numzgrid;
-  // offset of (.., kz, ks=1, nrelpointer, nclass, nage)
-  const long long off = plane * (kz - 1) + sstride * ((long long)Gp.maxspec * ((nrelpointer - 1) + (long long)Gp.maxpointspec_act * ((nclass - 1) + (long long)Gp.nclassunc * (nage - 1))));
-  for (int ks = 0; ks < V.nspec; ks++) {
-    const R m = active ? xmass[ks] / rhoi * weight : K(0.);
-    R *g = Gp.gridunc + off + sstride * ks;
-    wave_scatter_add<R>(g, (long long)jy * Gp.numxgrid + ix, direct ? m : m * (wx * wy), inside && okx && oky);
-    wave_scatter_add<R>(g, (long long)jyp * Gp.numxgrid + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
-    wave_scatter_add<R>(g, (long long)jyp * Gp.numxgrid + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
-    wave_scatter_add<R>(g, (long long)jy * Gp.numxgrid + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
+  for (int ig = 0; ig < (Gp.nested ? 2 : 1); ig++) {   // mother grid :145-295, nested grid :301-441
+    const OutGeom<R> G = out_geom(Gp, ig == 1);
+    const R xl = (R)((xt * (double)V.dx + (double)G.xshift) / (double)G.dxout);
+    const R yl = (R)((yt * (double)V.dy + (double)G.yshift) / (double)G.dyout);
+    int ix = (int)xl; if (xl < K(0.)) ix = ix - 1;
+    int jy = (int)yl; if (yl < K(0.)) jy = jy - 1;
+    const bool direct = !Gp.lusekerneloutput || itage < 10800 || xl < K(0.5) || yl < K(0.5) ||
+                        xl > (R)(G.numx - 1) - K(0.5) || yl > (R)(G.numy - 1) - K(0.5);
+    const R ddx = xl - (R)ix, ddy = yl - (R)jy;
+    int ixp, jyp;
+    R wx, wy;
+    if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+    if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+    const bool okx = ix >= 0 && ix <= G.numx - 1, oky = jy >= 0 && jy <= G.numy - 1;
+    const bool okxp = ixp >= 0 && ixp <= G.numx - 1, okyp = jyp >= 0 && jyp <= G.numy - 1;
+    const long long plane = (long long)G.numx * G.numy;
+    const long long sstride = plane * Gp.numzgrid;
+    // offset of (.., kz, ks=1, nrelpointer, nclass, nage)
+    const long long off = plane * (kz - 1) + sstride * ((long long)Gp.maxspec * ((nrelpointer - 1) + (long long)Gp.maxpointspec_act * ((nclass - 1) + (long long)Gp.nclassunc * (nage - 1))));
+    for (int ks = 0; ks < V.nspec; ks++) {
+      const R m = active ? xmass[ks] / rhoi * weight : K(0.);
+      R *g = G.grid + off + sstride * ks;
+      wave_scatter_add<R>(g, (long long)jy * G.numx + ix, direct ? m : m * (wx * wy), inside && okx && oky);
+      wave_scatter_add<R>(g, (long long)jyp * G.numx + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
+      wave_scatter_add<R>(g, (long long)jyp * G.numx + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
+      wave_scatter_add<R>(g, (long long)jy * G.numx + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
+    }
+  }
+  // concentrations at receptor points, parabolic kernel: conccalc.f90:451-498.  The reference sums the
+  // particles of one receptor serially; here every particle adds its share 2*weight*xmass*xkern/h/area
+  // (the sum is linear), pre-reduced over the wave.
+  for (int n = 0; n < Gp.numreceptor; n++) {
+    const R factor = K(.596831), hxmax = K(6.0), hymax = K(4.0), hzmax = K(150.);
+    const R sq = m_sqrt((R)itage);
+    const R hz = m_min(K(50.) + K(0.3) * sq, hzmax);
+    const R zd = zt / hz;
+    const R hx = m_min((K(0.29) + K(2.222e-3) * sq) * V.dx + (R)itage * K(1.2e-5), hxmax);
+    const R xd = (R)((xt - (double)Gp.receptor[n]) / (double)hx);
+    const R hy = m_min((K(0.18) + K(1.389e-3) * sq) * V.dy + (R)itage * K(7.5e-6), hymax);
+    const R yd = (R)((yt - (double)Gp.receptor[Gp.numreceptor + n]) / (double)hy);
+    const R h = hx * hy * hz;
+    const R r2 = xd * xd + yd * yd + zd * zd;
+    const bool hit = active && !(zd > K(1.)) && !(xd * xd > K(1.)) && !(yd * yd > K(1.)) && r2 < K(1.);
+    const R xkern = factor * (K(1.) - r2);
+    const R area = Gp.receptor[2 * Gp.numreceptor + n];
+    for (int ks = 0; ks < V.nspec; ks++)
+      wave_scatter_add<R>(Gp.creceptor, (long long)ks * Gp.numreceptor + n, hit ? K(2.) * weight * (xmass[ks] * xkern / h) / area : K(0.), hit);
   }
 }
 
 // drydepokernel.f90:41-116 for one species (deposit already in dep_prec = float)
 template <typename R>
-FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp, int nunc, float deposit, int ks, R x, R y, int nage, int kp) {
+FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp0, int nunc, float deposit, int ks, R x, R y, int nage, int kp, bool nest = false) {
   if (!(fabsf(deposit) > 0.f)) return;
+  // the nested variant (drydepokernel_nest.f90:38-100) always uses the kernel
+  struct { int numxgrid, numygrid, maxspec, maxpointspec_act, nclassunc, lusekerneloutput; R dxout, dyout, xoutshift, youtshift; float *drygridunc; } Gp;
+  {
+    const OutGeom<R> G = out_geom(Gp0, nest);
+    Gp.numxgrid = G.numx; Gp.numygrid = G.numy; Gp.dxout = G.dxout; Gp.dyout = G.dyout; Gp.xoutshift = G.xshift; Gp.youtshift = G.yshift;
+    Gp.drygridunc = G.dry; Gp.maxspec = Gp0.maxspec; Gp.maxpointspec_act = Gp0.maxpointspec_act; Gp.nclassunc = Gp0.nclassunc;
+    Gp.lusekerneloutput = nest ? 1 : Gp0.lusekerneloutput;
+  }
   const R xl = (x * V.dx + Gp.xoutshift) / Gp.dxout;
   const R yl = (y * V.dy + Gp.youtshift) / Gp.dyout;
   const int ix = (int)xl, jy = (int)yl;   // no correction for negative xl here, as in the reference
@@ -2079,10 +2141,18 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
 
 // wetdepokernel.f90:38-108 for one species (deposit is a default real, the grid is dep_prec)
 template <typename R>
-FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp, int nunc, R deposit, int ks, R x, R y, int nage, int kp) {
+FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp0, int nunc, R deposit, int ks, R x, R y, int nage, int kp, bool nest = false) {
+  // the nested variant (wetdepokernel_nest.f90:38-107) always uses the kernel and truncates with floor()
+  struct { int numxgrid, numygrid, maxspec, maxpointspec_act, nclassunc, lusekerneloutput; R dxout, dyout, xoutshift, youtshift; float *wetgridunc; } Gp;
+  {
+    const OutGeom<R> G = out_geom(Gp0, nest);
+    Gp.numxgrid = G.numx; Gp.numygrid = G.numy; Gp.dxout = G.dxout; Gp.dyout = G.dyout; Gp.xoutshift = G.xshift; Gp.youtshift = G.yshift;
+    Gp.wetgridunc = G.wet; Gp.maxspec = Gp0.maxspec; Gp.maxpointspec_act = Gp0.maxpointspec_act; Gp.nclassunc = Gp0.nclassunc;
+    Gp.lusekerneloutput = nest ? 1 : Gp0.lusekerneloutput;
+  }
   const R xl = (x * V.dx + Gp.xoutshift) / Gp.dxout;
   const R yl = (y * V.dy + Gp.youtshift) / Gp.dyout;
-  const int ix = (int)xl, jy = (int)yl;
+  const int ix = nest ? (int)floor((double)xl) : (int)xl, jy = nest ? (int)floor((double)yl) : (int)yl;
   const R ddx = xl - (R)ix, ddy = yl - (R)jy;
   int ixp, jyp;
   R wx, wy;

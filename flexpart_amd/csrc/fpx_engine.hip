@@ -278,6 +278,7 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
             const int nage = ageclass(Gp, abs(itime - itramem));
             const int kp = Gp.ioutputforeachrelease == 1 ? P.npoint[s] : 1;
             drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp);
+            if (Gp.nested) drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp, true);   // timemanager.f90:694-696
           }
         } else xm = xm * decfact;
         if (DRYDEP || V.decay[ks] > (R)0) P.xmass1[(size_t)ks * P.cap + s] = xm;
@@ -642,6 +643,7 @@ __global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V, GridP<R> Gp, WetP
     P.xmass1[(size_t)ks * P.cap + s] = restmass > smallnum ? restmass : (R)0;
     if (V.decay[ks] > (R)0) wetdeposit = wetdeposit * m_exp((R)abs(ldeltat) * V.decay[ks]);
     if (V.ldirect == 1 && Gp.on) wetdepo_scatter(V, Gp, nunc, wetdeposit, ks, (R)xt, (R)yt, nage, kp);
+    if (V.ldirect == 1 && Gp.on && Gp.nested) wetdepo_scatter(V, Gp, nunc, wetdeposit, ks, (R)xt, (R)yt, nage, kp, true);   // wetdepo.f90:142
   }
 }
 
@@ -686,6 +688,10 @@ struct EngineBase {
   virtual int upload_wet_fields(int slot, const fpx_wet_fields *f) = 0;
   virtual int wetdepo(int itime, int ltsample, int loutnext) = 0;
   virtual int get_wetgrid(void *wetgridunc, int allreduce, int clear) = 0;
+  virtual int outgrid_nest_init(const fpx_outgrid_nest *g) = 0;
+  virtual int get_grids_nest(void *griduncn, void *drygriduncn, void *wetgriduncn, int allreduce, int clear) = 0;
+  virtual int receptors_init(int n, const void *x, const void *y, const void *area) = 0;
+  virtual int get_receptors(void *creceptor, int ld, int allreduce, int clear) = 0;
   virtual void *stream_ptr() = 0;
 };
 
@@ -717,7 +723,7 @@ struct Engine : EngineBase {
   GridP<R> Gp;
   WetP<R> Wp;
   bool wet_on = false, wet_slot[2] = {false, false};
-  size_t n_grid3 = 0, n_grid2 = 0;
+  size_t n_grid3 = 0, n_grid2 = 0, n_grid3n = 0, n_grid2n = 0;
   ncclComm_t comm = nullptr;
   int comm_ranks = 1;
   void *d_sel_tmp = nullptr;
@@ -1410,7 +1416,111 @@ struct Engine : EngineBase {
     HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
     HIPCHK(hipMemsetAsync(Gp.drygridunc, 0, n_grid2 * sizeof(float), stream));
     HIPCHK(hipStreamSynchronize(stream));
+    Gp.nested = 0; Gp.numreceptor = 0;
     Gp.on = 1;
+    return 0;
+  }
+  // nested output grid: readoutgrid_nest.f90, outgrid_init_nest.f90 (same levels, classes, species as the mother grid)
+  int outgrid_nest_init(const fpx_outgrid_nest *g) override {
+    if (!g || g->struct_bytes != (int32_t)sizeof(fpx_outgrid_nest)) return fail(FPX_ERR_ARG, "outgrid_nest_init: null or fpx_outgrid_nest size mismatch (ABI)");
+    if (!Gp.on) return fail(FPX_ERR_STATE, "outgrid_nest_init: fpx_outgrid_init first");
+    if (Gp.nested) return fail(FPX_ERR_STATE, "outgrid_nest_init: already initialised");
+    if (g->numxgridn < 1 || g->numygridn < 1 || !(g->dxoutn > 0) || !(g->dyoutn > 0)) return fail(FPX_ERR_ARG, "outgrid_nest_init: bad grid");
+    Gp.numxgridn = g->numxgridn; Gp.numygridn = g->numygridn;
+    Gp.dxoutn = (R)g->dxoutn; Gp.dyoutn = (R)g->dyoutn; Gp.xoutshiftn = (R)g->xoutshiftn; Gp.youtshiftn = (R)g->youtshiftn;
+    n_grid2n = (size_t)g->numxgridn * g->numygridn * Gp.maxspec * Gp.maxpointspec_act * Gp.nclassunc * Gp.nageclass;
+    n_grid3n = n_grid2n * Gp.numzgrid;
+    int rc;
+    if ((rc = dalloc(&Gp.griduncn, n_grid3n))) return rc;
+    if ((rc = dalloc(&Gp.drygriduncn, n_grid2n))) return rc;
+    if ((rc = dalloc(&Gp.wetgriduncn, n_grid2n))) return rc;
+    HIPCHK(hipMemsetAsync(Gp.griduncn, 0, n_grid3n * sizeof(R), stream));
+    HIPCHK(hipMemsetAsync(Gp.drygriduncn, 0, n_grid2n * sizeof(float), stream));
+    HIPCHK(hipMemsetAsync(Gp.wetgriduncn, 0, n_grid2n * sizeof(float), stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    Gp.nested = 1;
+    return 0;
+  }
+  int download_real(void *host, const R *dev, size_t n) {   // device R -> host real kind
+    if (!host) return 0;
+    if ((size_t)cfg.host_real_bytes == sizeof(R)) {
+      HIPCHK(hipMemcpyAsync(host, dev, n * sizeof(R), hipMemcpyDeviceToHost, stream));
+      return 0;
+    }
+    int rc = ensure_staging(n * cfg.host_real_bytes);
+    if (rc) return rc;
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    k_convert<R><<<nb, kBlock, 0, stream>>>(dev, cfg.host_real_bytes == 8 ? (double *)staging : nullptr,
+                                            cfg.host_real_bytes == 4 ? (float *)staging : nullptr, (long long)n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(host, staging, n * cfg.host_real_bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));   // staging is reused
+    return 0;
+  }
+  int get_grids_nest(void *griduncn, void *drygriduncn, void *wetgriduncn, int allreduce, int clear) override {
+    if (!Gp.nested) return fail(FPX_ERR_STATE, "get_grids_nest: fpx_outgrid_nest_init first");
+    if (allreduce && comm_ranks > 1) {
+      if (!comm) return fail(FPX_ERR_STATE, "get_grids_nest: allreduce requested without fpx_comm_init");
+      // mpi_mod.f90:2543-2569 (mpif_tm_reduce_grid_nest)
+      ncclResult_t r = ncclAllReduce(Gp.griduncn, Gp.griduncn, n_grid3n, sizeof(R) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream);
+      if (r == ncclSuccess) r = ncclAllReduce(Gp.drygriduncn, Gp.drygriduncn, n_grid2n, ncclFloat, ncclSum, comm, stream);
+      if (r == ncclSuccess) r = ncclAllReduce(Gp.wetgriduncn, Gp.wetgriduncn, n_grid2n, ncclFloat, ncclSum, comm, stream);
+      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    }
+    int rc = download_real(griduncn, Gp.griduncn, n_grid3n);
+    if (rc) return rc;
+    if (drygriduncn) HIPCHK(hipMemcpyAsync(drygriduncn, Gp.drygriduncn, n_grid2n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (wetgriduncn) HIPCHK(hipMemcpyAsync(wetgriduncn, Gp.wetgriduncn, n_grid2n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (clear) {
+      HIPCHK(hipMemsetAsync(Gp.griduncn, 0, n_grid3n * sizeof(R), stream));
+      HIPCHK(hipMemsetAsync(Gp.drygriduncn, 0, n_grid2n * sizeof(float), stream));
+      HIPCHK(hipMemsetAsync(Gp.wetgriduncn, 0, n_grid2n * sizeof(float), stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  // receptor points: xreceptor, yreceptor (grid coordinates), receptorarea, readreceptors.f90:88-92
+  int receptors_init(int n, const void *x, const void *y, const void *area) override {
+    if (!Gp.on) return fail(FPX_ERR_STATE, "receptors_init: fpx_outgrid_init first");
+    if (n < 1 || n > 1000 || !x || !y || !area) return fail(FPX_ERR_ARG, "receptors_init: bad argument");
+    if (Gp.numreceptor) return fail(FPX_ERR_STATE, "receptors_init: already initialised");
+    std::vector<R> tmp(3 * (size_t)n);
+    const void *src[3] = {x, y, area};
+    for (int k = 0; k < 3; k++)
+      for (int i = 0; i < n; i++) tmp[(size_t)k * n + i] = cfg.host_real_bytes == 4 ? (R)((const float *)src[k])[i] : (R)((const double *)src[k])[i];
+    int rc;
+    R *d;
+    if ((rc = dalloc(&d, 3 * (size_t)n))) return rc;
+    HIPCHK(hipMemcpyAsync(d, tmp.data(), tmp.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+    if ((rc = dalloc(&Gp.creceptor, (size_t)n * cfg.maxspec))) return rc;
+    HIPCHK(hipMemsetAsync(Gp.creceptor, 0, (size_t)n * cfg.maxspec * sizeof(R), stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    Gp.receptor = d;
+    Gp.numreceptor = n;
+    return 0;
+  }
+  // creceptor(ld, maxspec) of the host (com_mod.f90:660): rows 1..numreceptor, columns 1..nspec are written
+  int get_receptors(void *creceptor, int ld, int allreduce, int clear) override {
+    if (!Gp.numreceptor) return fail(FPX_ERR_STATE, "get_receptors: fpx_receptors_init first");
+    if (creceptor && ld < Gp.numreceptor) return fail(FPX_ERR_ARG, "get_receptors: leading dimension smaller than numreceptor");
+    const size_t n = (size_t)Gp.numreceptor * cfg.nspec;
+    if (allreduce && comm_ranks > 1) {
+      if (!comm) return fail(FPX_ERR_STATE, "get_receptors: allreduce requested without fpx_comm_init");
+      ncclResult_t r = ncclAllReduce(Gp.creceptor, Gp.creceptor, n, sizeof(R) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream);   // mpi_mod.f90:2480-2484
+      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+    }
+    if (creceptor) {
+      std::vector<R> tmp(n);
+      HIPCHK(hipMemcpyAsync(tmp.data(), Gp.creceptor, n * sizeof(R), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      for (int ks = 0; ks < cfg.nspec; ks++)
+        for (int i = 0; i < Gp.numreceptor; i++) {
+          const R v = tmp[(size_t)ks * Gp.numreceptor + i];
+          if (cfg.host_real_bytes == 4) ((float *)creceptor)[(size_t)ks * ld + i] = (float)v; else ((double *)creceptor)[(size_t)ks * ld + i] = (double)v;
+        }
+    }
+    if (clear) HIPCHK(hipMemsetAsync(Gp.creceptor, 0, n * sizeof(R), stream));
+    HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
   int set_output_times(int loutnext, int loutstep) override {
@@ -1737,6 +1847,10 @@ int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f) {
 int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext) { FPX_GUARD(h); return h->impl->wetdepo(itime, ltsample, loutnext); }
 int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_wetgrid(wetgridunc, allreduce, clear); }
 void *fpx_stream(fpx_handle h) { return (h && h->impl) ? h->impl->stream_ptr() : nullptr; }
+int fpx_outgrid_nest_init(fpx_handle h, const fpx_outgrid_nest *g) { FPX_GUARD(h); return h->impl->outgrid_nest_init(g); }
+int fpx_get_grids_nest(fpx_handle h, void *griduncn, void *drygriduncn, void *wetgriduncn, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_grids_nest(griduncn, drygriduncn, wetgriduncn, allreduce, clear); }
+int fpx_receptors_init(fpx_handle h, int32_t numreceptor, const void *xreceptor, const void *yreceptor, const void *receptorarea) { FPX_GUARD(h); return h->impl->receptors_init(numreceptor, xreceptor, yreceptor, receptorarea); }
+int fpx_get_receptors(fpx_handle h, void *creceptor, int32_t ld, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_receptors(creceptor, ld, allreduce, clear); }
 
 int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n) {
   if (fn < 0 || fn > 6 || !x || !y || n < 0) return FPX_ERR_ARG;

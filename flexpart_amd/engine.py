@@ -14,7 +14,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import (FpxConfig, FpxFields, FpxNests, FpxOutgrid, FpxParticles, FpxStepStats, FpxWetConfig, FpxWetFields, RNG_PHILOX,
+from ._lib import (FpxConfig, FpxFields, FpxNests, FpxOutgrid, FpxOutgridNest, FpxParticles, FpxStepStats, FpxWetConfig, FpxWetFields, RNG_PHILOX,
                    RNG_TABLE_COUNTER, RNG_TABLE_SEQ, check)
 
 # polar stereographic set-up is host work in the reference (gridcheck_ecmwf.f90:341-366 via
@@ -253,6 +253,23 @@ class Engine:
             check(self.lib.fpx_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1])),
                   "fpx_set_output_times")
         self.gshape = (len(lage), 1, 1, self.nspec, nzg, nyg, nxg)
+        if "outgridn" in sc:          # OUTGRID_NEST (readoutgrid_nest.f90)
+            nxn, nyn = (int(v) for v in sc["outgridn"])
+            dxn, dyn, lon0n, lat0n = (float(v) for v in sc["outgeomn"])
+            gn = FpxOutgridNest()
+            gn.struct_bytes = C.sizeof(FpxOutgridNest)
+            gn.numxgridn, gn.numygridn = nxn, nyn
+            gn.dxoutn, gn.dyoutn = float(rt(dxn)), float(rt(dyn))
+            gn.xoutshiftn = float(rt(self.cfg.xlon0) - rt(lon0n))
+            gn.youtshiftn = float(rt(self.cfg.ylat0) - rt(lat0n))
+            check(self.lib.fpx_outgrid_nest_init(self.h, C.byref(gn)), "fpx_outgrid_nest_init")
+            self.gshape_nest = (len(lage), 1, 1, self.nspec, nzg, nyn, nxn)
+        self.nreceptor = 0
+        if "receptors" in sc:         # RECEPTORS (readreceptors.f90): x, y in grid coordinates, cell area
+            r = np.asarray(sc["receptors"], dtype=np.float64).reshape(3, -1)
+            self.nreceptor = r.shape[1]
+            rx, ry, ra = (np.ascontiguousarray(r[k].astype(rt)) for k in range(3))
+            check(self.lib.fpx_receptors_init(self.h, self.nreceptor, _vp(rx), _vp(ry), _vp(ra)), "fpx_receptors_init")
 
     def wet_from_scenario(self, sc):
         """Wet-scavenging species parameters (readspecies.f90) + precipitation/cloud fields."""
@@ -307,6 +324,22 @@ class Engine:
         d = np.empty((na, nc, mp, nsp, nyg, nxg), np.float32)
         check(self.lib.fpx_get_grids(self.h, _vp(g), _vp(d), int(allreduce), int(clear)), "fpx_get_grids")
         return g.astype(np.float64), d.astype(np.float64)
+
+    def grids_nest(self, allreduce=False, clear=False):
+        """-> (griduncn, drygriduncn, wetgriduncn) of the nested output grid, float64."""
+        na, nc, mp, nsp, nzg, nyg, nxg = self.gshape_nest
+        g = np.empty((na, nc, mp, nsp, nzg, nyg, nxg), self.hreal)
+        d = np.empty((na, nc, mp, nsp, nyg, nxg), np.float32)
+        w = np.empty((na, nc, mp, nsp, nyg, nxg), np.float32)
+        check(self.lib.fpx_get_grids_nest(self.h, _vp(g), _vp(d), _vp(w), int(allreduce), int(clear)), "fpx_get_grids_nest")
+        return g.astype(np.float64), d.astype(np.float64), w.astype(np.float64)
+
+    def receptors(self, allreduce=False, clear=False, ld=20):
+        """-> creceptor as float64 (spec, receptor); the host array is creceptor(ld=maxreceptor, maxspec)."""
+        ld = max(ld, self.nreceptor)
+        c = np.zeros((self.nspec, ld), self.hreal)
+        check(self.lib.fpx_get_receptors(self.h, _vp(c), ld, int(allreduce), int(clear)), "fpx_get_receptors")
+        return c[:, :self.nreceptor].astype(np.float64)
 
     def comm_unique_id(self):
         buf = (C.c_char * 128)()

@@ -342,6 +342,33 @@ def add_outgrid(sc, nxg=36, nyg=18, nzg=5, *, outlon0=None, outlat0=None, dxout=
     return sc
 
 
+def add_outgrid_nest(sc, nxn=30, nyn=20):
+    """Nested output grid (OUTGRID_NEST, readoutgrid_nest.f90): finer cells over the middle of the
+    mother output grid, so that particles fall inside, on its border and outside of it."""
+    nxg, nyg, _ = (int(v) for v in sc["outgrid"])
+    dxout, dyout, outlon0, outlat0 = (float(v) for v in sc["outgeom"])
+    sc["outgridn"] = np.array([nxn, nyn], np.int32)
+    sc["outgeomn"] = np.array([0.4 * nxg * dxout / nxn, 0.5 * nyg * dyout / nyn,
+                               outlon0 + 0.3 * nxg * dxout, outlat0 + 0.25 * nyg * dyout], np.float64)
+    return sc
+
+
+def add_receptors(sc, m=4):
+    """Receptor points (RECEPTORS, readreceptors.f90:88-92): positions in grid coordinates and the
+    area of a dx*dy cell there; placed on particles so that the parabolic kernel finds some."""
+    x = np.asarray(sc["xtra1"], dtype=np.float64)
+    y = np.asarray(sc["ytra1"], dtype=np.float64)
+    dx, dy, xlon0, ylat0 = (float(v) for v in sc["geom"])
+    idx = (np.arange(m, dtype=np.int64) * 7919 + 11) % x.size
+    xr = np.float32(x[idx]).astype(np.float64)
+    yr = np.float32(y[idx]).astype(np.float64)
+    r_earth, pi180 = 6.371e6, 3.14159265 / 180.0
+    ylat = ylat0 + yr * dy
+    area = (r_earth * np.cos(ylat * pi180) * dx * pi180) * (r_earth * dy * pi180)
+    sc["receptors"] = np.concatenate([xr, yr, np.float32(area).astype(np.float64)])
+    return sc
+
+
 def add_wet(sc, *, gas=False):
     """Precipitation / cloud fields and wet-scavenging species parameters (readspecies.f90 names).
 

@@ -275,6 +275,29 @@ int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext)
 /* wetgridunc (unc_mod.f90:27, real(dep_prec) = 4 bytes), same conventions as fpx_get_grids */
 int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear);
 
+/* ---- nested output grid and receptor points (conccalc.f90:301-441, :451-498;
+ *      a22/a23: drydepokernel_nest.f90, wetdepokernel_nest.f90) ------------------------------------ */
+typedef struct {
+  int32_t struct_bytes;
+  int32_t numxgridn, numygridn;                    /* com_mod.f90:585                                  */
+  double dxoutn, dyoutn, xoutshiftn, youtshiftn;   /* com_mod.f90:586; readoutgrid_nest.f90            */
+  int32_t reserved[4];
+} fpx_outgrid_nest;
+/* nested_output = 1: allocate and zero griduncn, drygriduncn, wetgriduncn (unc_mod.f90:24-28; levels, species,
+ * point-spec, class and age extents as the mother grid, outgrid_init_nest.f90).  After fpx_outgrid_init.  From then
+ * on fpx_conccalc, the step's dry-deposition epilogue and fpx_wetdepo also feed the nested grids
+ * (conccalc.f90:300, timemanager.f90:694-696, wetdepo.f90:142). */
+int fpx_outgrid_nest_init(fpx_handle h, const fpx_outgrid_nest *g);
+/* griduncn (host real kind), drygriduncn / wetgriduncn (real(dep_prec) = 4 bytes); any pointer may be NULL.
+ * allreduce: sum over the ranks of fpx_comm_init first (mpi_mod.f90:2543-2569). */
+int fpx_get_grids_nest(fpx_handle h, void *griduncn, void *drygriduncn, void *wetgriduncn, int32_t allreduce, int32_t clear);
+/* Receptor points: xreceptor, yreceptor in grid coordinates and receptorarea (readreceptors.f90:88-92,
+ * com_mod.f90:658-659), host real kind.  fpx_conccalc then also accumulates creceptor (conccalc.f90:451-498). */
+int fpx_receptors_init(fpx_handle h, int32_t numreceptor, const void *xreceptor, const void *yreceptor, const void *receptorarea);
+/* creceptor(ld, maxspec) of the host (com_mod.f90:660, ld = maxreceptor): rows 1..numreceptor of columns 1..nspec are
+ * overwritten with the accumulated values. */
+int fpx_get_receptors(fpx_handle h, void *creceptor, int32_t ld, int32_t allreduce, int32_t clear);
+
 /* raw stream handle (hipStream_t) for callers that enqueue their own work */
 void *fpx_stream(fpx_handle h);
 

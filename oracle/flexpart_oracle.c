@@ -33,6 +33,7 @@ typedef float dep_real;   /* par_mod.f90:33 dep_prec = sp: deposition grids stay
 #define K(x) ((real)(x))
 
 #define ORC_MAXSPEC 5
+#define ORC_MAXRECEPTOR 20   /* par_mod.f90:201 */
 #define ORC_NZMAX 256
 #define ORC_MAXRAND 1000000
 #define ORC_MAXNESTS 4
@@ -119,6 +120,14 @@ typedef struct {
   int loutnext, loutstep;
   real *gridunc;
   dep_real *drygridunc, *wetgridunc;
+  /* ---- nested output grid (com_mod.f90:585-586, unc_mod.f90:24-28) and receptor points (com_mod.f90:658-663) */
+  int nested_output, numxgridn, numygridn;
+  real dxoutn, dyoutn, xoutshiftn, youtshiftn;
+  real *griduncn;
+  dep_real *drygriduncn, *wetgriduncn;
+  int numreceptor;
+  real xreceptor[ORC_MAXRECEPTOR], yreceptor[ORC_MAXRECEPTOR], receptorarea[ORC_MAXRECEPTOR];
+  real creceptor[ORC_MAXRECEPTOR * ORC_MAXSPEC];   /* (n, ks), n fastest */
   /* ---- wet deposition (com_mod.f90:139,171-175,379-384,413-419) */
   int wetdepspec[ORC_MAXSPEC], readclouds;
   real weta_gas[ORC_MAXSPEC], wetb_gas[ORC_MAXSPEC], crain_aero[ORC_MAXSPEC], csnow_aero[ORC_MAXSPEC];
@@ -1477,6 +1486,8 @@ L99:
 /* ------------------------------------------------------------------------- */
 /* grid sampling: conccalc.f90:50-295 (mother output grid), drydepokernel.f90   */
 /* ------------------------------------------------------------------------- */
+#define ORC_GIDXN(ix, jy, kz, ks, kp, nc, na) ((size_t)(ix) + (size_t)c->numxgridn * ((size_t)(jy) + (size_t)c->numygridn * ((size_t)((kz) - 1) + (size_t)c->numzgrid * ((size_t)((ks) - 1) + (size_t)c->maxspec_out * ((size_t)((kp) - 1) + (size_t)c->maxpointspec_act * ((size_t)((nc) - 1) + (size_t)c->nclassunc * (size_t)((na) - 1)))))))
+#define ORC_DIDXN(ix, jy, ks, kp, nc, na) ((size_t)(ix) + (size_t)c->numxgridn * ((size_t)(jy) + (size_t)c->numygridn * ((size_t)((ks) - 1) + (size_t)c->maxspec_out * ((size_t)((kp) - 1) + (size_t)c->maxpointspec_act * ((size_t)((nc) - 1) + (size_t)c->nclassunc * (size_t)((na) - 1))))))
 #define GIDX(ix, jy, kz, ks, kp, nc, na) ((size_t)(ix) + (size_t)c->numxgrid * ((size_t)(jy) + (size_t)c->numygrid * ((size_t)((kz) - 1) + (size_t)c->numzgrid * ((size_t)((ks) - 1) + (size_t)c->maxspec_out * ((size_t)((kp) - 1) + (size_t)c->maxpointspec_act * ((size_t)((nc) - 1) + (size_t)c->nclassunc * (size_t)((na) - 1)))))))
 #define DIDX(ix, jy, ks, kp, nc, na) ((size_t)(ix) + (size_t)c->numxgrid * ((size_t)(jy) + (size_t)c->numygrid * ((size_t)((ks) - 1) + (size_t)c->maxspec_out * ((size_t)((kp) - 1) + (size_t)c->maxpointspec_act * ((size_t)((nc) - 1) + (size_t)c->nclassunc * (size_t)((na) - 1))))))
 
@@ -1557,6 +1568,75 @@ void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const doubl
         }
       }
     }
+    if (c->nested_output == 1) {   /* conccalc.f90:301-441, the same attribution on the nested output grid */
+      xl = (real)((xtra1[i] * (double)c->dx + (double)c->xoutshiftn) / (double)c->dxoutn);
+      yl = (real)((ytra1[i] * (double)c->dy + (double)c->youtshiftn) / (double)c->dyoutn);
+      ix = (int)xl; if (xl < K(0.)) ix = ix - 1;
+      jy = (int)yl; if (yl < K(0.)) jy = jy - 1;
+      if (itage < 10800 || xl < K(0.5) || yl < K(0.5) || xl > (real)(c->numxgridn - 1) - K(0.5) ||
+          yl > (real)(c->numygridn - 1) - K(0.5) || !c->lusekerneloutput) {
+        if (ix >= 0 && jy >= 0 && ix <= c->numxgridn - 1 && jy <= c->numygridn - 1)
+          for (ks = 1; ks <= c->nspec; ks++)
+            c->griduncn[ORC_GIDXN(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight;
+      } else {
+        ddx = xl - (real)ix;
+        ddy = yl - (real)jy;
+        if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+        if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+        if (ix >= 0 && ix <= c->numxgridn - 1) {
+          if (jy >= 0 && jy <= c->numygridn - 1) {
+            w = wx * wy;
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          }
+          if (jyp >= 0 && jyp <= c->numygridn - 1) {
+            w = wx * (K(1.) - wy);
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ix, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          }
+        }
+        if (ixp >= 0 && ixp <= c->numxgridn - 1) {
+          if (jyp >= 0 && jyp <= c->numygridn - 1) {
+            w = (K(1.) - wx) * (K(1.) - wy);
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ixp, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          }
+          if (jy >= 0 && jy <= c->numygridn - 1) {
+            w = (K(1.) - wx) * wy;
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ixp, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          }
+        }
+      }
+    }
+  }
+  /* 2. concentrations at receptor points, parabolic kernel: conccalc.f90:451-498 */
+  {
+    const real factor = K(.596831), hxmax = K(6.0), hymax = K(4.0), hzmax = K(150.);
+    int n;
+    for (n = 0; n < c->numreceptor; n++) {
+      real cc[ORC_MAXSPEC];
+      for (ks = 0; ks < c->nspec; ks++) cc[ks] = K(0.);
+      for (i = 0; i < npart; i++) {
+        int itage;
+        real hz, zd, hx, xd, hy, yd, h, r2;
+        if (itra1[i] != itime) continue;
+        itage = abs(itra1[i] - itramem[i]);
+        hz = r_min(K(50.) + K(0.3) * r_sqrt((real)itage), hzmax);
+        zd = ztra1[i] / hz;
+        if (zd > K(1.)) continue;
+        hx = r_min((K(0.29) + K(2.222e-3) * r_sqrt((real)itage)) * c->dx + (real)itage * K(1.2e-5), hxmax);
+        xd = (real)((xtra1[i] - (double)c->xreceptor[n]) / (double)hx);
+        if (xd * xd > K(1.)) continue;
+        hy = r_min((K(0.18) + K(1.389e-3) * r_sqrt((real)itage)) * c->dy + (real)itage * K(7.5e-6), hymax);
+        yd = (real)((ytra1[i] - (double)c->yreceptor[n]) / (double)hy);
+        if (yd * yd > K(1.)) continue;
+        h = hx * hy * hz;
+        r2 = xd * xd + yd * yd + zd * zd;
+        if (r2 < K(1.)) {
+          const real xkern = factor * (K(1.) - r2);
+          for (ks = 0; ks < c->nspec; ks++) cc[ks] = cc[ks] + xmass1[(size_t)ks * npart + i] * xkern / h;
+        }
+      }
+      for (ks = 0; ks < c->nspec; ks++)
+        c->creceptor[n + ORC_MAXRECEPTOR * ks] = c->creceptor[n + ORC_MAXRECEPTOR * ks] + K(2.) * weight * cc[ks] / c->receptorarea[n];
+    }
   }
 }
 
@@ -1583,6 +1663,29 @@ static void orc_drydepokernel(orc_ctx *c, int nunc, const dep_real *deposit, rea
     if (ixp >= 0 && jy >= 0 && ixp <= c->numxgrid - 1 && jy <= c->numygrid - 1) { w = (K(1.) - wx) * wy; c->drygridunc[DIDX(ixp, jy, ks, kp, nunc, nage)] = (dep_real)((real)c->drygridunc[DIDX(ixp, jy, ks, kp, nunc, nage)] + (real)deposit[ks - 1] * w); }
     if (ix >= 0 && jyp >= 0 && ix <= c->numxgrid - 1 && jyp <= c->numygrid - 1) { w = wx * (K(1.) - wy); c->drygridunc[DIDX(ix, jyp, ks, kp, nunc, nage)] = (dep_real)((real)c->drygridunc[DIDX(ix, jyp, ks, kp, nunc, nage)] + (real)deposit[ks - 1] * w); }
   }
+}
+
+/* drydepokernel_nest.f90:38-100: always the uniform kernel (no lusekerneloutput branch), int() truncation */
+static void orc_drydepokernel_nest(orc_ctx *c, int nunc, const dep_real *deposit, real x, real y, int nage, int kp) {
+  real xl, yl, ddx, ddy, wx, wy, w;
+  int ix, jy, ixp, jyp, ks;
+  xl = (x * c->dx + c->xoutshiftn) / c->dxoutn;
+  yl = (y * c->dy + c->youtshiftn) / c->dyoutn;
+  ix = (int)xl;
+  jy = (int)yl;
+  ddx = xl - (real)ix;
+  ddy = yl - (real)jy;
+  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+#define DNADD(i, j, ww) c->drygriduncn[ORC_DIDXN(i, j, ks, kp, nunc, nage)] = (dep_real)((real)c->drygriduncn[ORC_DIDXN(i, j, ks, kp, nunc, nage)] + (real)deposit[ks - 1] * (ww))
+  for (ks = 1; ks <= c->nspec; ks++) {
+    if (!(c->drydepspec[ks - 1] && fabsf(deposit[ks - 1]) > 0)) continue;
+    if (ix >= 0 && jy >= 0 && ix <= c->numxgridn - 1 && jy <= c->numygridn - 1) { w = wx * wy; DNADD(ix, jy, w); }
+    if (ixp >= 0 && jyp >= 0 && ixp <= c->numxgridn - 1 && jyp <= c->numygridn - 1) { w = (K(1.) - wx) * (K(1.) - wy); DNADD(ixp, jyp, w); }
+    if (ixp >= 0 && jy >= 0 && ixp <= c->numxgridn - 1 && jy <= c->numygridn - 1) { w = (K(1.) - wx) * wy; DNADD(ixp, jy, w); }
+    if (ix >= 0 && jyp >= 0 && ix <= c->numxgridn - 1 && jyp <= c->numygridn - 1) { w = wx * (K(1.) - wy); DNADD(ix, jyp, w); }
+  }
+#undef DNADD
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1698,6 +1801,26 @@ static void orc_wetdepokernel(orc_ctx *c, int nunc, const real *deposit, real x,
 #undef WADD
 }
 
+/* wetdepokernel_nest.f90:38-107: floor() instead of int(), always the uniform kernel */
+static void orc_wetdepokernel_nest(orc_ctx *c, int nunc, const real *deposit, real x, real y, int nage, int kp) {
+  real xl, yl, ddx, ddy, wx, wy, w;
+  int ix, jy, ixp, jyp, ks;
+  xl = (x * c->dx + c->xoutshiftn) / c->dxoutn;
+  yl = (y * c->dy + c->youtshiftn) / c->dyoutn;
+  ix = (int)floor((double)xl); jy = (int)floor((double)yl);
+  ddx = xl - (real)ix; ddy = yl - (real)jy;
+  if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
+  if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
+#define WNADD(i, j, ww) c->wetgriduncn[ORC_DIDXN(i, j, ks, kp, nunc, nage)] = (dep_real)((real)c->wetgriduncn[ORC_DIDXN(i, j, ks, kp, nunc, nage)] + (ww))
+  for (ks = 1; ks <= c->nspec; ks++) {
+    if (ix >= 0 && jy >= 0 && ix <= c->numxgridn - 1 && jy <= c->numygridn - 1) { w = wx * wy; WNADD(ix, jy, deposit[ks - 1] * w); }
+    if (ixp >= 0 && jyp >= 0 && ixp <= c->numxgridn - 1 && jyp <= c->numygridn - 1) { w = (K(1.) - wx) * (K(1.) - wy); WNADD(ixp, jyp, deposit[ks - 1] * w); }
+    if (ixp >= 0 && jy >= 0 && ixp <= c->numxgridn - 1 && jy <= c->numygridn - 1) { w = (K(1.) - wx) * wy; WNADD(ixp, jy, deposit[ks - 1] * w); }
+    if (ix >= 0 && jyp >= 0 && ix <= c->numxgridn - 1 && jyp <= c->numygridn - 1) { w = wx * (K(1.) - wy); WNADD(ix, jyp, deposit[ks - 1] * w); }
+  }
+#undef WNADD
+}
+
 /* wetdepo.f90:58-151 */
 void orc_wetdepo(orc_ctx *c, int itime, int ltsample, int loutnext, int npart, const double *xtra1, const double *ytra1,
                  const real *ztra1, const int *itra1, const int *itramem, const int *npoint, const int *nclass, real *xmass1) {
@@ -1725,6 +1848,7 @@ void orc_wetdepo(orc_ctx *c, int itime, int ltsample, int loutnext, int npart, c
       if (c->decay[ks] > K(0.)) wetdeposit[ks] = wetdeposit[ks] * r_exp((real)abs(ldeltat) * c->decay[ks]);
     }
     if (c->ldirect == 1 && c->wetgridunc) orc_wetdepokernel(c, nclass[jpart], wetdeposit, (real)xtra1[jpart], (real)ytra1[jpart], nage, kp);
+    if (c->ldirect == 1 && c->nested_output == 1) orc_wetdepokernel_nest(c, nclass[jpart], wetdeposit, (real)xtra1[jpart], (real)ytra1[jpart], nage, kp);   /* wetdepo.f90:142 */
   }
 }
 
@@ -1765,6 +1889,37 @@ void orc_set_outgrid(orc_ctx *c, int numxgrid, int numygrid, int numzgrid, doubl
   c->drygridunc = (dep_real *)calloc(n2, sizeof(dep_real));
   free(c->wetgridunc);
   c->wetgridunc = (dep_real *)calloc(n2, sizeof(dep_real));
+}
+/* nested output grid, readoutgrid_nest.f90 + outgrid_init_nest.f90 (after orc_set_outgrid) */
+void orc_set_outgrid_nest(orc_ctx *c, int numxgridn, int numygridn, double dxoutn, double dyoutn, double outlon0n, double outlat0n) {
+  size_t n2, n3;
+  c->nested_output = 1;
+  c->numxgridn = numxgridn; c->numygridn = numygridn;
+  c->dxoutn = (real)dxoutn; c->dyoutn = (real)dyoutn;
+  c->xoutshiftn = c->xlon0 - (real)outlon0n;
+  c->youtshiftn = c->ylat0 - (real)outlat0n;
+  n2 = (size_t)numxgridn * numygridn * c->maxspec_out * c->maxpointspec_act * c->nclassunc * c->nageclass;
+  n3 = n2 * c->numzgrid;
+  free(c->griduncn); free(c->drygriduncn); free(c->wetgriduncn);
+  c->griduncn = (real *)calloc(n3, sizeof(real));
+  c->drygriduncn = (dep_real *)calloc(n2, sizeof(dep_real));
+  c->wetgriduncn = (dep_real *)calloc(n2, sizeof(dep_real));
+}
+const real *orc_griduncn(orc_ctx *c) { return c->griduncn; }
+const dep_real *orc_drygriduncn(orc_ctx *c) { return c->drygriduncn; }
+const dep_real *orc_wetgriduncn(orc_ctx *c) { return c->wetgriduncn; }
+/* receptor points in grid coordinates (readreceptors.f90:88-92) */
+void orc_set_receptors(orc_ctx *c, int n, const double *x, const double *y, const double *area) {
+  int i;
+  c->numreceptor = n < ORC_MAXRECEPTOR ? n : ORC_MAXRECEPTOR;
+  for (i = 0; i < c->numreceptor; i++) { c->xreceptor[i] = (real)x[i]; c->yreceptor[i] = (real)y[i]; c->receptorarea[i] = (real)area[i]; }
+  for (i = 0; i < ORC_MAXRECEPTOR * ORC_MAXSPEC; i++) c->creceptor[i] = K(0.);
+}
+/* creceptor(n, ks) -> out[n + numreceptor*ks] */
+void orc_get_receptors(orc_ctx *c, double *out) {
+  int n, ks;
+  for (ks = 0; ks < c->nspec; ks++)
+    for (n = 0; n < c->numreceptor; n++) out[n + c->numreceptor * ks] = (double)c->creceptor[n + ORC_MAXRECEPTOR * ks];
 }
 void orc_set_output_times(orc_ctx *c, int loutnext, int loutstep) { c->loutnext = loutnext; c->loutstep = loutstep; }
 const real *orc_gridunc(orc_ctx *c) { return c->gridunc; }
@@ -1933,6 +2088,8 @@ long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, re
       /* timemanager.f90:690-696 (forward runs only) */
       if (c->drydep && c->ldirect == 1 && c->drygridunc && xmass1)
         orc_drydepokernel(c, nclass_arr ? nclass_arr[j] : 1, drydeposit, (real)xtra1[j], (real)ytra1[j], nage, kp);
+      if (c->drydep && c->ldirect == 1 && c->nested_output == 1 && xmass1)   /* timemanager.f90:694-696 */
+        orc_drydepokernel_nest(c, nclass_arr ? nclass_arr[j] : 1, drydeposit, (real)xtra1[j], (real)ytra1[j], nage, kp);
       if (abs(itra1[j] - itramem[j]) >= c->lage_last) itra1[j] = -999999999;
     }
   }

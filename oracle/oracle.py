@@ -127,6 +127,18 @@ class Oracle:
                                 lage.ctypes.data_as(C.POINTER(C.c_int)), ind_samp, iofr, 1, nspec)
             if "outtimes" in sc:
                 lib.orc_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1]))
+            self.has_grid_nest = "outgridn" in sc
+            if self.has_grid_nest:
+                nxn, nyn = (int(v) for v in sc["outgridn"])
+                dxn, dyn, lon0n, lat0n = (float(v) for v in sc["outgeomn"])
+                self.gshape_nest = (1, 1, 1, nspec, nzg, nyn, nxn)
+                lib.orc_set_outgrid_nest(self.h, nxn, nyn, C.c_double(dxn), C.c_double(dyn), C.c_double(lon0n), C.c_double(lat0n))
+            self.nreceptor = 0
+            if "receptors" in sc:
+                r = _f64(sc["receptors"]).reshape(3, -1)
+                self.nreceptor = r.shape[1]
+                rx, ry, ra = (np.ascontiguousarray(r[k]) for k in range(3))
+                lib.orc_set_receptors(self.h, self.nreceptor, rx.ctypes.data_as(dp), ry.ctypes.data_as(dp), ra.ctypes.data_as(dp))
         self.has_wet = bool(sc.get("wetdep", 0))
         if self.has_wet:
             self._init_wet(sc)
@@ -161,6 +173,25 @@ class Oracle:
         g = np.ctypeslib.as_array(C.cast(self.lib.orc_gridunc(self.h), C.POINTER(ct)), shape=(nsp * nzg * nyg * nxg,))
         d = np.ctypeslib.as_array(C.cast(self.lib.orc_drygridunc(self.h), C.POINTER(C.c_float)), shape=(nsp * nyg * nxg,))
         return (g.astype(np.float64).reshape(nsp, nzg, nyg, nxg), d.astype(np.float64).reshape(nsp, nyg, nxg))
+
+    def grids_nest(self):
+        """(griduncn, drygriduncn, wetgriduncn) of the nested output grid, float64, (spec, z, y, x) / (spec, y, x)."""
+        nage, ncu, mps, nsp, nzg, nyg, nxg = self.gshape_nest
+        ct = C.c_float if self.kind == "r4" else C.c_double
+        out = []
+        for fn, t, shp in (("orc_griduncn", ct, (nsp, nzg, nyg, nxg)), ("orc_drygriduncn", C.c_float, (nsp, nyg, nxg)),
+                           ("orc_wetgriduncn", C.c_float, (nsp, nyg, nxg))):
+            f = getattr(self.lib, fn)
+            f.restype = C.c_void_p
+            a = np.ctypeslib.as_array(C.cast(f(self.h), C.POINTER(t)), shape=(int(np.prod(shp)),))
+            out.append(a.astype(np.float64).reshape(shp))
+        return tuple(out)
+
+    def receptors(self):
+        """creceptor as float64 (spec, receptor)."""
+        out = np.zeros(self.nspec * self.nreceptor)
+        self.lib.orc_get_receptors(self.h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out.reshape(self.nspec, self.nreceptor)
 
     def polemaps(self):
         n = np.zeros(9); s = np.zeros(9)

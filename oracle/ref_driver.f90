@@ -63,7 +63,7 @@ program flexref
   integer, allocatable :: ibuf(:)
   real(kind=8), allocatable :: dbuf(:)
   integer :: ios, i, j, k, m, ks, n, idummy, istep, nsteps, itime0, itime
-  integer :: npart_in, gnx, gny, gnz, nstop, timing, do_conc, nage, kp
+  integer :: npart_in, gnx, gny, gnz, nstop, timing, do_conc, do_concn, nage, kp
   integer :: ldeltat, loutnext_d, itage
   integer(kind=8) :: c0, c1, crate, nadv
   real :: prob(maxspec), decfact, xmassfract, weight
@@ -104,7 +104,7 @@ program flexref
   switchnorthg=999999.; switchsouthg=999999.
   nsteps=1; itime0=0; nan_count=0; nan_count2=0
   memind(1)=1; memind(2)=2; memind(3)=3
-  numpoint=1; have_pol=.false.; do_polar_setup=.false.; do_conc=0
+  numpoint=1; have_pol=.false.; do_polar_setup=.false.; do_conc=0; do_concn=0; numreceptor=0
   numreceptor=0; loutnext_d=0
   gnx=0; gny=0; gnz=0; npart_in=0
 
@@ -171,6 +171,16 @@ program flexref
       dxout=dbuf(1); dyout=dbuf(2); outlon0=dbuf(3); outlat0=dbuf(4)
     case ('outheight')
       allocate(outheight(n), outheighthalf(n)); outheight(1:n)=dbuf(1:n)
+    ! --- nested output grid (readoutgrid_nest.f90 state) and receptor points (readreceptors.f90) ---
+    case ('outgridn')  ! numxgridn numygridn
+      numxgridn=ibuf(1); numygridn=ibuf(2); do_concn=1
+    case ('outgeomn')  ! dxoutn dyoutn outlon0n outlat0n
+      dxoutn=dbuf(1); dyoutn=dbuf(2); outlon0n=dbuf(3); outlat0n=dbuf(4)
+    case ('receptors') ! xreceptor(1:m), yreceptor(1:m), receptorarea(1:m) in grid coordinates / m2
+      numreceptor=int(n/3)
+      xreceptor(1:numreceptor)=dbuf(1:numreceptor)
+      yreceptor(1:numreceptor)=dbuf(numreceptor+1:2*numreceptor)
+      receptorarea(1:numreceptor)=dbuf(2*numreceptor+1:3*numreceptor)
     case ('concflags') ! ind_samp ioutputforeachrelease
       ind_samp=ibuf(1); ioutputforeachrelease=ibuf(2)
     case ('outtimes')  ! loutnext loutstep
@@ -330,6 +340,16 @@ program flexref
     allocate(drygridunc(0:numxgrid-1,0:numygrid-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
     allocate(wetgridunc(0:numxgrid-1,0:numygrid-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
     gridunc=0.; drygridunc=0.; wetgridunc=0.
+    creceptor=0.
+    if (do_concn .eq. 1) then
+      nested_output=1
+      xoutshiftn=xlon0-outlon0n      ! readoutgrid_nest.f90
+      youtshiftn=ylat0-outlat0n
+      allocate(griduncn(0:numxgridn-1,0:numygridn-1,numzgrid,maxspec,maxpointspec_act,nclassunc,maxageclass))
+      allocate(drygriduncn(0:numxgridn-1,0:numygridn-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
+      allocate(wetgriduncn(0:numxgridn-1,0:numygridn-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
+      griduncn=0.; drygriduncn=0.; wetgriduncn=0.
+    end if
   end if
 
   open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')
@@ -440,6 +460,8 @@ program flexref
           if (xmassfract.lt.minmass) itra1(j)=-999999999
           if (DRYDEP.and.(ldirect.eq.1).and.(do_conc.eq.1)) &
                call drydepokernel(nclass(j),drydeposit,real(xtra1(j)),real(ytra1(j)),nage,kp)
+          if (DRYDEP.and.(ldirect.eq.1).and.(do_concn.eq.1)) &      ! timemanager.f90:694-696
+               call drydepokernel_nest(nclass(j),drydeposit,real(xtra1(j)),real(ytra1(j)),nage,kp)
           if (abs(itra1(j)-itramem(j)).ge.lage(nageclass)) itra1(j)=-999999999
         endif
       endif
@@ -544,6 +566,27 @@ contains
     g=reshape(real(wetgridunc,8), [ng])
     call put_d('wetgridunc', g, ng)
     deallocate(g)
+    if (do_concn .eq. 1) then
+      ng=size(griduncn)
+      allocate(g(ng))
+      g=reshape(real(griduncn,8), [ng])
+      call put_d('griduncn', g, ng)
+      deallocate(g)
+      ng=size(drygriduncn)
+      allocate(g(ng))
+      g=reshape(real(drygriduncn,8), [ng])
+      call put_d('drygriduncn', g, ng)
+      g=reshape(real(wetgriduncn,8), [ng])
+      call put_d('wetgriduncn', g, ng)
+      deallocate(g)
+    end if
+    if (numreceptor .gt. 0) then
+      ng=numreceptor*nspec
+      allocate(g(ng))
+      g=reshape(real(creceptor(1:numreceptor,1:nspec),8), [ng])
+      call put_d('creceptor', g, ng)
+      deallocate(g)
+    end if
   end subroutine dump_grids
 
   subroutine dump_state()

@@ -19,7 +19,7 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
           "lsynctime", "method", "mintime", "ctl", "ifine", "turbswitch", "cblflag",
           "mdomainfill", "lsettling", "nspec", "drydep", "drydepspec", "density", "dquer",
           "vsetaver", "cunningham", "decay", "turbpar", "lage", "nsteps", "itime0",
-          "outgrid", "outgeom", "outheight", "concflags", "outtimes",
+          "outgrid", "outgeom", "outheight", "outgridn", "outgeomn", "receptors", "concflags", "outtimes",
           "wetdep", "wetdepspec", "weta_gas", "wetb_gas", "crain_aero", "csnow_aero", "ccn_aero", "in_aero", "henry",
           "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol",
           "hmix", "ustar", "wstar", "oli", "tropopause", "vdep",
@@ -30,7 +30,7 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
 _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
         "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
         "drydep", "drydepspec", "lage", "nsteps", "itime0", "npart", "itra1", "itramem",
-        "npoint", "nclass", "idt", "cbt", "outgrid", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "nest"}
+        "npoint", "nclass", "idt", "cbt", "outgrid", "outgridn", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "nest"}
 
 
 def write_scenario(path, sc):
@@ -96,7 +96,7 @@ def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=F
     out = {"steps": [], "stdout": res.stdout}
     cur = None
     for name, a in recs:
-        if name in ("rannumb", "northpolemap", "southpolemap", "derived", "timing", "gridunc", "drygridunc", "wetgridunc"):
+        if name in ("rannumb", "northpolemap", "southpolemap", "derived", "timing", "gridunc", "drygridunc", "wetgridunc", "griduncn", "drygriduncn", "wetgriduncn", "creceptor"):
             out[name] = a
             continue
         if name == "xtra1":

@@ -37,7 +37,7 @@ def main():
                     if kind == "r4" and a.dtype == np.float64 and k not in ("xtra1", "ytra1"):
                         a = a.astype(np.float32)      # exact: the values are f32 in the r4 build
                     out[f"s{i}_{k}"] = a
-            for gk in ("gridunc", "drygridunc", "wetgridunc"):
+            for gk in ("gridunc", "drygridunc", "wetgridunc", "griduncn", "drygriduncn", "wetgriduncn", "creceptor"):
                 if gk in ref:
                     out[gk] = ref[gk]
             if name == "polar":

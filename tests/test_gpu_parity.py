@@ -326,6 +326,38 @@ def test_wet_deposition(built, kind, gas):
     assert abs(w.sum() - ow.sum()) <= (1e-5 if kind == "r8" else 1e-3) * ow.sum()
 
 
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_nested_output_grid_and_receptors(built, kind):
+    """conccalc.f90:301-441 (griduncn), drydepokernel_nest.f90, wetdepokernel_nest.f90 (floor(), always the
+    kernel) and the receptor kernel conccalc.f90:451-498 against the oracle, which reproduces the reference's
+    griduncn/drygriduncn/wetgriduncn/creceptor bit for bit (tests/golden/sampling_nest_*.npz)."""
+    from flexpart_amd.engine import Engine
+    from oracle.oracle import Oracle
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario("sampling_nest")
+    rb = 8 if kind == "r8" else 4
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb)
+    eng.run()
+    gn, dn, wn = (a[0, 0, 0] for a in eng.grids_nest())
+    g, d = (a[0, 0, 0] for a in eng.grids())
+    rec = eng.receptors()
+    eng.close()
+    orc = Oracle(sc, kind)
+    orc.lib.orc_set_parallel_semantics(orc.h, 1)
+    orc.run()
+    og, od = orc.grids()
+    ogn, odn, own = orc.grids_nest()
+    orec = orc.receptors()
+    assert ogn.sum() > 0 and odn.sum() > 0 and own.sum() > 0 and orec.max() > 0
+    tol_g = 1e-12 if kind == "r8" else 2e-3
+    tol_d = 2e-5 if kind == "r8" else 5e-3
+    assert np.abs(g - og).max() <= tol_g * og.max()
+    assert np.abs(gn - ogn).max() <= tol_g * ogn.max(), np.abs(gn - ogn).max() / ogn.max()
+    assert np.abs(dn - odn).max() <= tol_d * odn.max(), np.abs(dn - odn).max() / odn.max()
+    assert np.abs(wn - own).max() <= tol_d * own.max(), np.abs(wn - own).max() / own.max()
+    assert np.abs(rec - orec).max() <= (1e-11 if kind == "r8" else 2e-3) * orec.max(), (rec, orec)   # f32: a few trajectories differ
+
+
 def test_device_math_helpers_against_libm(built):
     """The 1-2 ulp fp64 helpers of the Langevin loop (fpx_device.hpp: m_expp, m_logp, m_sqrtp, m_rcp,
     m_rsqrt, m_cuberoot_parts) against numpy/libm.  Tolerance 4 ulp (8.9e-16 relative); for the

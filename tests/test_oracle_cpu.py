@@ -27,6 +27,15 @@ def _sampling(sc):
     return sc
 
 
+def _sampling_nest(sc):
+    # as _sampling, plus the nested output grid (conccalc :301-441, drydepokernel_nest, wetdepokernel_nest)
+    # and receptor points (conccalc :451-498)
+    _sampling(sc)
+    syn.add_outgrid_nest(sc)
+    syn.add_receptors(sc)
+    return sc
+
+
 def _nest(sc):
     # a nested grid (interpol_*_nests path) + dry deposition through interpol_vdep_nests
     sc.update(drydep=1, drydepspec=np.array([1], np.int32))
@@ -37,6 +46,7 @@ CASES = {
     "hanna": dict(ctl=5.0, ifine=4),
     "nest": dict(ctl=5.0, ifine=4, post=_nest),
     "sampling": dict(ctl=5.0, ifine=4, post=_sampling),
+    "sampling_nest": dict(ctl=5.0, ifine=4, post=_sampling_nest),
     "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
     "aerosol": dict(ctl=5.0, ifine=4, post=_aerosol),
     "hanna1_method0": dict(ctl=-5.0),
@@ -92,6 +102,15 @@ def test_oracle_matches_golden_reference_output(name, kind):
         assert np.abs(g - rg).max() <= tol * rg.max()
         assert np.abs(d - rd).max() <= tol * rd.max()
         assert np.abs(w - rw).max() <= tol * rw.max()
+        if "griduncn" in gold.files:   # nested output grid and receptor concentrations
+            gn, dn, wn = orc.grids_nest()
+            for a, key in ((gn, "griduncn"), (dn, "drygriduncn"), (wn, "wetgriduncn")):
+                ra = gold[key].reshape((5,) + a.shape[1:])[:nsp]
+                assert ra.sum() > 0
+                assert np.abs(a - ra).max() <= tol * ra.max(), key
+            rc = gold["creceptor"].reshape(nsp, -1)
+            assert rc.max() > 0
+            assert np.abs(orc.receptors() - rc).max() <= tol * rc.max()
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
