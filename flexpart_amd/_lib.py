@@ -116,7 +116,7 @@ SYMBOLS = [
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
-    "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors",
+    "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
 ]
 
 _lib = None
@@ -138,6 +138,7 @@ def load():
     lib.fpx_stream.restype = vp
     lib.fpx_stream.argtypes = [vp]
     lib.fpx_math_probe.argtypes = [C.c_int32, vp, vp, C.c_int64]
+    lib.fpx_upload_wet_nest_fields.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(FpxWetFields), C.c_int32]
     lib.fpx_outgrid_nest_init.argtypes = [vp, C.POINTER(FpxOutgridNest)]
     lib.fpx_get_grids_nest.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32]
     lib.fpx_receptors_init.argtypes = [vp, C.c_int32, vp, vp, vp]

@@ -2045,7 +2045,14 @@ FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp0, int nunc, f
 // wet deposition: wetdepo.f90, get_wetscav.f90, interpol_rain.f90, wetdepokernel.f90
 // ---------------------------------------------------------------------------
 template <typename R>
+struct WetNest {             // the same packs for one nested grid (lsprecn, convprecn, tccn, ctwcn, ttn, cloudsn)
+  const R *prec, *ctwc, *ttw;
+  const signed char *clouds;
+  int readclouds;            // readclouds_nest(ngrid), com_mod.f90:146
+};
+template <typename R>
 struct WetP {
+  const WetNest<R> *nest;    // [numbnests] in device memory (subscripted per lane), or null
   int wetdepspec[kMaxSpec], readclouds;
   R weta_gas[kMaxSpec], wetb_gas[kMaxSpec], crain_aero[kMaxSpec], csnow_aero[kMaxSpec];
   R ccn_aero[kMaxSpec], in_aero[kMaxSpec], henry[kMaxSpec];
@@ -2068,29 +2075,50 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
   const R bcls[6] = {K(22.7), K(0.0), K(0.0), K(1321.0), K(381.0), K(0.0)};
   const R incloud_ratio = K(6.2), r_air = K(287.05);   // par_mod.f90:59,82
   R wetscav = K(0.);
-  const int ix = (int)xtra1, jy = (int)ytra1;
+  // nesting level, get_wetscav.f90:82-90: the plain nest bounds (no eps margin as in advance.f90:167-173)
+  int ngrid = 0;
+  for (int j = V.numbnests; j >= 1; j--) {
+    const NestDesc<R> &N = V.nest[j - 1];
+    if (xtra1 > (double)N.xl && xtra1 < (double)N.xr && ytra1 > (double)N.yl && ytra1 < (double)N.yr) { ngrid = j; break; }
+  }
+  int ix, jy, gnx = V.nx, gny = V.ny;
+  R xtn = (R)xtra1, ytn = (R)ytra1;
+  const R *prec = Wp.prec, *ctwc = Wp.ctwc, *ttw = Wp.ttw;
+  const signed char *clouds = Wp.clouds;
+  int readclouds = Wp.readclouds;
+  if (ngrid > 0) {   // :97-101
+    const NestDesc<R> &N = V.nest[ngrid - 1];
+    const WetNest<R> &W = Wp.nest[ngrid - 1];
+    xtn = (R)((xtra1 - (double)N.xl) * (double)N.xres);
+    ytn = (R)((ytra1 - (double)N.yl) * (double)N.yres);
+    ix = (int)xtn; jy = (int)ytn;
+    gnx = N.nx; gny = N.ny;
+    prec = W.prec; ctwc = W.ctwc; ttw = W.ttw; clouds = W.clouds; readclouds = W.readclouds;
+  } else {
+    ix = (int)xtra1; jy = (int)ytra1;
+  }
   const int interp_time = (int)lround((double)((R)itime - K(0.5) * (R)ltsample));
   int slot = V.m2;   // n = memind(2) unless memtime(1) is nearer (get_wetscav.f90:114-116)
   if (abs(V.memtime0 - interp_time) < abs(V.memtime1 - interp_time)) slot = V.m1;
-  // interpol_rain.f90:68-130 (no time interpolation: the nearer slot only)
+  // interpol_rain.f90:68-130 / interpol_rain_nests.f90:68-142 (no time interpolation: the nearer slot only)
   R lsp, convp, cc;
   {
-    R xt = (R)xtra1, yt = (R)ytra1;
-    if (xt >= (R)(V.nx - 1)) xt = (R)(V.nx - 1) - K(0.00001);
-    if (yt >= (R)(V.ny - 1)) yt = (R)(V.ny - 1) - K(0.00001);
+    R xt = xtn, yt = ytn;
+    if (xt >= (R)(gnx - 1)) xt = (R)(gnx - 1) - K(0.00001);
+    if (yt >= (R)(gny - 1)) yt = (R)(gny - 1) - K(0.00001);
     const int ixr = (int)xt, jyr = (int)yt, ixp = ixr + 1, jyp = jyr + 1;
     const R ddx = xt - (R)ixr, ddy = yt - (R)jyr, rddx = K(1.) - ddx, rddy = K(1.) - ddy;
     const R p1 = rddx * rddy, p2 = ddx * rddy, p3 = rddx * ddy, p4 = ddx * ddy;
-    const R *a = Wp.prec + (((long long)jyr * V.nx + ixr) * 2 + slot) * 3, *b = Wp.prec + (((long long)jyr * V.nx + ixp) * 2 + slot) * 3;
-    const R *c = Wp.prec + (((long long)jyp * V.nx + ixr) * 2 + slot) * 3, *d = Wp.prec + (((long long)jyp * V.nx + ixp) * 2 + slot) * 3;
+    const R *a = prec + (((long long)jyr * gnx + ixr) * 2 + slot) * 3, *b = prec + (((long long)jyr * gnx + ixp) * 2 + slot) * 3;
+    const R *c = prec + (((long long)jyp * gnx + ixr) * 2 + slot) * 3, *d = prec + (((long long)jyp * gnx + ixp) * 2 + slot) * 3;
     lsp = p1 * a[0] + p2 * b[0] + p3 * c[0] + p4 * d[0];
     convp = p1 * a[1] + p2 * b[1] + p3 * c[1] + p4 * d[1];
     cc = p1 * a[2] + p2 * b[2] + p3 * c[2] + p4 * d[2];
   }
   if (lsp < K(0.01) && convp < K(0.01)) return wetscav;
   const int hz = find_level(hgt, V.nz, ztra1);
-  const long long cidx = (((long long)jy * V.nx + ix) * V.nz + (hz - 1)) * 2 + slot;
-  const int clouds_v = (int)Wp.clouds[cidx];
+  const long long cidx = (((long long)jy * gnx + ix) * V.nz + (hz - 1)) * 2 + slot;
+  const int clouds_v = (int)clouds[cidx];
   if (clouds_v <= 1) return wetscav;
   int i, j;
   if (lsp > K(20.)) i = 4; else if (lsp > K(8.)) i = 3; else if (lsp > K(3.)) i = 2; else if (lsp > K(1.)) i = 1; else i = 0;
@@ -2099,7 +2127,7 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
   const R cf = j == 4 ? cfr[4] : j == 3 ? cfr[3] : j == 2 ? cfr[2] : j == 1 ? cfr[1] : cfr[0];
   grfr = m_max(K(0.05), cc * (lsp * lf + convp * cf) / (lsp + convp));
   const R prec1 = (lsp + convp) / grfr;
-  const R act_temp = Wp.ttw[cidx];
+  const R act_temp = ttw[cidx];
   if (clouds_v >= 4) {   // below cloud, get_wetscav.f90:206-246
     if (V.dquer[ks] <= K(0.) && (Wp.weta_gas[ks] > K(0.) || Wp.wetb_gas[ks] > K(0.))) {
       wetscav = Wp.weta_gas[ks] * m_pow(prec1, Wp.wetb_gas[ks]);
@@ -2116,7 +2144,7 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
   if (clouds_v < 4) {   // in cloud, get_wetscav.f90:251-311
     if ((Wp.ccn_aero[ks] > K(0.) || Wp.in_aero[ks] > K(0.)) || (Wp.henry[ks] > K(0.) && V.dquer[ks] <= K(0.))) {
       R cl;
-      if (Wp.readclouds) cl = Wp.ctwc[((long long)jy * V.nx + ix) * 2 + slot] * (grfr / cc);
+      if (readclouds) cl = ctwc[((long long)jy * gnx + ix) * 2 + slot] * (grfr / cc);   // ctwc / ctwcn, :257-262
       else cl = K(1E6) * K(2E-7) * m_pow(prec1, K(0.36));
       R liq_frac, ice_frac;
       if (act_temp <= K(253.)) { liq_frac = K(0); ice_frac = K(1); }

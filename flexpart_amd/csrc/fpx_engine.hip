@@ -686,6 +686,7 @@ struct EngineBase {
   virtual int upload_nest_fields(int nest, int slot, const fpx_fields *f) = 0;
   virtual int wet_init(const fpx_wet_config *w) = 0;
   virtual int upload_wet_fields(int slot, const fpx_wet_fields *f) = 0;
+  virtual int upload_wet_nest_fields(int nest, int slot, const fpx_wet_fields *f, int readclouds_nest) = 0;
   virtual int wetdepo(int itime, int ltsample, int loutnext) = 0;
   virtual int get_wetgrid(void *wetgridunc, int allreduce, int clear) = 0;
   virtual int outgrid_nest_init(const fpx_outgrid_nest *g) = 0;
@@ -723,6 +724,9 @@ struct Engine : EngineBase {
   GridP<R> Gp;
   WetP<R> Wp;
   bool wet_on = false, wet_slot[2] = {false, false};
+  WetNest<R> h_wnest[kMaxNests] = {};     // host copy of the device table Wp.nest
+  WetNest<R> *d_wnest = nullptr;
+  bool wet_nest_slot[kMaxNests][2] = {};
   size_t n_grid3 = 0, n_grid2 = 0, n_grid3n = 0, n_grid2n = 0;
   ncclComm_t comm = nullptr;
   int comm_ranks = 1;
@@ -1700,8 +1704,56 @@ struct Engine : EngineBase {
     wet_slot[s] = true;
     return 0;
   }
+  // lsprecn, convprecn, tccn, ctwcn, ttn, cloudsn of one nest and time slot (strides nxmaxn, nymaxn, nzmax)
+  int upload_wet_nest_fields(int nest, int slot, const fpx_wet_fields *f, int readclouds_nest) override {
+    if (!wet_on) return fail(FPX_ERR_STATE, "upload_wet_nest_fields: fpx_wet_init first");
+    if (nest < 1 || nest > V.numbnests) return fail(FPX_ERR_ARG, "upload_wet_nest_fields: nest out of range (fpx_nests_init first)");
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "upload_wet_nest_fields: slot must be 1 or 2");
+    if (!f || !f->lsprec || !f->convprec || !f->tcc || !f->tt || !f->clouds) return fail(FPX_ERR_ARG, "upload_wet_nest_fields: lsprecn, convprecn, tccn, ttn, cloudsn are required");
+    if (readclouds_nest && !f->ctwc) return fail(FPX_ERR_ARG, "upload_wet_nest_fields: ctwcn required with readclouds_nest");
+    const int l = nest - 1, s = slot - 1;
+    const int nxl = h_nest[l].nx, nyl = h_nest[l].ny;
+    int rc;
+    WetNest<R> &W = h_wnest[l];
+    if (!W.prec) {
+      const size_t ncol = (size_t)nxl * nyl;
+      R *p; signed char *q;
+      if ((rc = dalloc(&p, ncol * 6))) return rc; W.prec = p;
+      if ((rc = dalloc(&p, ncol * 2))) return rc; W.ctwc = p;
+      if ((rc = dalloc(&p, ncol * cfg.nz * 2))) return rc; W.ttw = p;
+      if ((rc = dalloc(&q, ncol * cfg.nz * 2))) return rc; W.clouds = q;
+      if (!d_wnest) { if ((rc = dalloc(&d_wnest, (size_t)kMaxNests))) return rc; }
+    }
+    W.readclouds = readclouds_nest ? 1 : 0;
+    g_nx = nxl; g_ny = nyl; g_nxmax = nest_nxmaxn; g_nymax = nest_nymaxn;
+    do {
+      if ((rc = p2(f->lsprec, (R *)W.prec, 6, s * 3 + 0))) break;
+      if ((rc = p2(f->convprec, (R *)W.prec, 6, s * 3 + 1))) break;
+      if ((rc = p2(f->tcc, (R *)W.prec, 6, s * 3 + 2))) break;
+      if (f->ctwc && (rc = p2(f->ctwc, (R *)W.ctwc, 2, s))) break;
+      if ((rc = p3(f->tt, (R *)W.ttw, 2, s))) break;
+    } while (0);
+    g_nx = cfg.nx; g_ny = cfg.ny; g_nxmax = cfg.nxmax; g_nymax = cfg.nymax;
+    if (rc) return rc;
+    {
+      const size_t n = (size_t)nest_nxmaxn * nest_nymaxn * cfg.nz;
+      if ((rc = ensure_staging(n))) return rc;
+      HIPCHK(hipMemcpyAsync(staging, f->clouds, n, hipMemcpyHostToDevice, stream));
+      dim3 grid((nxl + 31) / 32, (cfg.nz + 31) / 32, nyl), block(32, 8);
+      k_pack3<signed char, signed char><<<grid, block, 0, stream>>>((const signed char *)staging, (signed char *)W.clouds, nxl, nyl, cfg.nz,
+                                                                    nest_nxmaxn, nest_nymaxn, 2, s);
+      HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipMemcpyAsync(d_wnest, h_wnest, sizeof(h_wnest), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    Wp.nest = d_wnest;
+    wet_nest_slot[l][s] = true;
+    return 0;
+  }
   int wetdepo(int itime, int ltsample, int loutnext) override {
     if (!wet_on || !wet_slot[0] || !wet_slot[1]) return fail(FPX_ERR_STATE, "wetdepo: fpx_wet_init and both slots of fpx_upload_wet_fields first");
+    for (int l = 0; l < V.numbnests; l++)   // get_wetscav.f90:126-128 reads the nest's own fields for a particle inside a nest
+      if (!wet_nest_slot[l][0] || !wet_nest_slot[l][1]) return fail(FPX_ERR_STATE, "wetdepo: nested grids are configured: fpx_upload_wet_nest_fields (both slots) for every nest first");
     if (!height_set || !window_set) return fail(FPX_ERR_STATE, "wetdepo: height / wind-time window not set");
     if (numpart == 0) return 0;
     const int nb = (int)((numpart + kBlock - 1) / kBlock);
@@ -1847,6 +1899,7 @@ int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f) {
 int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext) { FPX_GUARD(h); return h->impl->wetdepo(itime, ltsample, loutnext); }
 int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_wetgrid(wetgridunc, allreduce, clear); }
 void *fpx_stream(fpx_handle h) { return (h && h->impl) ? h->impl->stream_ptr() : nullptr; }
+int fpx_upload_wet_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_wet_fields *f, int32_t readclouds_nest) { FPX_GUARD(h); return h->impl->upload_wet_nest_fields(nest, slot, f, readclouds_nest); }
 int fpx_outgrid_nest_init(fpx_handle h, const fpx_outgrid_nest *g) { FPX_GUARD(h); return h->impl->outgrid_nest_init(g); }
 int fpx_get_grids_nest(fpx_handle h, void *griduncn, void *drygriduncn, void *wetgriduncn, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_grids_nest(griduncn, drygriduncn, wetgriduncn, allreduce, clear); }
 int fpx_receptors_init(fpx_handle h, int32_t numreceptor, const void *xreceptor, const void *yreceptor, const void *receptorarea) { FPX_GUARD(h); return h->impl->receptors_init(numreceptor, xreceptor, yreceptor, receptorarea); }

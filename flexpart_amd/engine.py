@@ -298,6 +298,23 @@ class Engine:
             keep["cloudsh"] = ch
             f.cloudsh = ch.ctypes.data
             check(self.lib.fpx_upload_wet_fields(self.h, m + 1, C.byref(f)), "fpx_upload_wet_fields")
+        if "lsprecn" in sc:      # the nest's own fields (compact: nxmaxn = nxn, nymaxn = nyn as in upload_nests_from_scenario)
+            rt = self.hreal
+            for m in (0, 1):
+                keep = {}
+                f = FpxWetFields()
+                for k, kn in (("lsprec", "lsprecn"), ("convprec", "convprecn"), ("tcc", "tccn"), ("tt", "ttn")):
+                    a = np.asarray(sc[kn])[m]
+                    if kn == "ttn" and self.nzmax != self.nz:
+                        b = np.zeros((self.nzmax,) + a.shape[1:]); b[: self.nz] = a; a = b
+                    keep[k] = np.ascontiguousarray(a.astype(rt))
+                    setattr(f, k, keep[k].ctypes.data)
+                cn = np.asarray(sc["cloudsn"])[m]
+                c8 = np.zeros((self.nzmax,) + cn.shape[1:], np.int8)
+                c8[: self.nz] = cn
+                keep["clouds"] = c8
+                f.clouds = c8.ctypes.data
+                check(self.lib.fpx_upload_wet_nest_fields(self.h, 1, m + 1, C.byref(f), 0), "fpx_upload_wet_nest_fields")
 
     def wetdepo(self, itime=None, ltsample=None, loutnext=None):
         itime = self.itime if itime is None else itime

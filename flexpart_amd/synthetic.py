@@ -369,23 +369,16 @@ def add_receptors(sc, m=4):
     return sc
 
 
-def add_wet(sc, *, gas=False):
-    """Precipitation / cloud fields and wet-scavenging species parameters (readspecies.f90 names).
-
-    clouds (int8 per level, verttransform's cloud classification): >= 4 below a precipitating
-    cloud, 2-3 inside it, 0-1 none (get_wetscav.f90:150,206,251).  gas=False: an aerosol
-    (dquer > 0, crain/csnow below cloud, ccn/in inside); gas=True: a soluble gas (weta/wetb,
-    henry)."""
-    nx, ny, nz = (int(v) for v in sc["grid"])
+def _wet_fields(nx, ny, nz, z, phase):
+    """lsprec, convprec, tcc [2][ny][nx]; clouds [2][nz][ny][nx]; cloudsh [2][ny][nx] (exact arithmetic)."""
     per = nx - 1
     i = np.arange(nx, dtype=np.int64)[None, :]
     j = np.arange(ny, dtype=np.int64)[:, None]
     lsprec = np.empty((2, ny, nx)); convprec = np.empty((2, ny, nx)); tcc = np.empty((2, ny, nx))
     clouds = np.zeros((2, nz, ny, nx), np.int32)
     cloudsh = np.zeros((2, ny, nx), np.int32)
-    z = np.asarray(sc["height"])
     for m in range(2):
-        sh = 7 * m
+        sh = 7 * m + phase
         lsprec[m] = 12.0 * np.maximum(0.0, _wave(2 * (i + sh) + j, per)) ** 2
         convprec[m] = 6.0 * np.maximum(0.0, _wave(3 * (i + sh) + 2 * j, per))
         tcc[m] = 0.15 + 0.8 * np.abs(_wave(i + sh + 3 * j, per))
@@ -394,6 +387,29 @@ def add_wet(sc, *, gas=False):
             cls = 6 if z[k] < 1200.0 else (3 if z[k] < 5000.0 else 0)
             clouds[m, k] = np.where(raining, cls, 0)
         cloudsh[m] = np.where(raining, 3800, 0)
+    return lsprec, convprec, tcc, clouds, cloudsh
+
+
+def add_wet_nest(sc):
+    """The nest's own precipitation, cloud and temperature fields (lsprecn, convprecn, tccn, cloudsn,
+    cloudshn, ttn; get_wetscav.f90:126-128,150-151,197-199); after add_nest and add_wet."""
+    nxn, nyn = (int(v) for v in sc["nest"])
+    nz = int(sc["grid"][2])
+    lsp, cvp, tcc, cl, clh = _wet_fields(nxn, nyn, nz, np.asarray(sc["height"]), 3)
+    f = make_fields(nxn, nyn, nz, sc["height"], nspec=int(sc["nspec"]))
+    sc.update(lsprecn=lsp, convprecn=cvp, tccn=tcc, cloudsn=cl, cloudshn=clh, ttn=f["tt"] - 4.0)
+    return sc
+
+
+def add_wet(sc, *, gas=False):
+    """Precipitation / cloud fields and wet-scavenging species parameters (readspecies.f90 names).
+
+    clouds (int8 per level, verttransform's cloud classification): >= 4 below a precipitating
+    cloud, 2-3 inside it, 0-1 none (get_wetscav.f90:150,206,251).  gas=False: an aerosol
+    (dquer > 0, crain/csnow below cloud, ccn/in inside); gas=True: a soluble gas (weta/wetb,
+    henry)."""
+    nx, ny, nz = (int(v) for v in sc["grid"])
+    lsprec, convprec, tcc, clouds, cloudsh = _wet_fields(nx, ny, nz, np.asarray(sc["height"]), 0)
     sc.update(lsprec=lsprec, convprec=convprec, tcc=tcc, clouds=clouds, cloudsh=cloudsh, wetdep=1,
               wetdepspec=np.array([1], np.int32))
     if gas:

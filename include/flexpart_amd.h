@@ -275,6 +275,13 @@ int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext)
 /* wetgridunc (unc_mod.f90:27, real(dep_prec) = 4 bytes), same conventions as fpx_get_grids */
 int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear);
 
+/* Precipitation / cloud / temperature fields of one nested grid and time slot: lsprecn, convprecn, tccn
+ * (com_mod.f90:518-520), ctwcn (:503, only with readclouds_nest), ttn (:501), cloudsn integer(1) (:505), passed in the
+ * members of fpx_wet_fields with strides nxmaxn, nymaxn(, nzmax); each pointer is element (0,0,1,slot,nest).  A particle
+ * inside a nest is scavenged with the nest's fields (get_wetscav.f90:82-101,126-128,150-151,197-199), so with nests
+ * configured fpx_wetdepo requires both slots of every nest. */
+int fpx_upload_wet_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_wet_fields *f, int32_t readclouds_nest);
+
 /* ---- nested output grid and receptor points (conccalc.f90:301-441, :451-498;
  *      a22/a23: drydepokernel_nest.f90, wetdepokernel_nest.f90) ------------------------------------ */
 typedef struct {

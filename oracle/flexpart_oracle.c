@@ -133,6 +133,8 @@ typedef struct {
   real weta_gas[ORC_MAXSPEC], wetb_gas[ORC_MAXSPEC], crain_aero[ORC_MAXSPEC], csnow_aero[ORC_MAXSPEC];
   real ccn_aero[ORC_MAXSPEC], in_aero[ORC_MAXSPEC], henry[ORC_MAXSPEC];
   const real *lsprec, *convprec, *tcc, *ctwc;   /* [slot][jy][ix] */
+  const real *lsprecn, *convprecn, *tccn, *ttn;  /* nest 1: [slot][jy][ix] / [slot][iz][jy][ix], com_mod.f90:501,518 */
+  const signed char *cloudsn;                    /* nest 1: [slot][iz][jy][ix], com_mod.f90:505 */
   const signed char *clouds;                    /* [slot][level][jy][ix] */
   const int *cloudsh;                           /* [slot][jy][ix] */
   long blc_count[ORC_MAXSPEC], inc_count[ORC_MAXSPEC];
@@ -1707,10 +1709,26 @@ static void orc_interpol_rain(orc_ctx *c, const real *yy1, const real *yy2, cons
   *yint3 = p1 * F2(yy3, ix, jy, iwftouse) + p2 * F2(yy3, ixp, jy, iwftouse) + p3 * F2(yy3, ix, jyp, iwftouse) + p4 * F2(yy3, ixp, jyp, iwftouse);
 }
 
+/* interpol_rain_nests.f90:68-142 */
+static void orc_interpol_rain_nests(orc_ctx *c, const real *yy1, const real *yy2, const real *yy3, int ngrid, int iwftouse,
+                                    real xt, real yt, real *yint1, real *yint2, real *yint3) {
+  int ix, jy, ixp, jyp;
+  real ddx, ddy, rddx, rddy, p1, p2, p3, p4;
+  if (xt >= (real)(c->nxn[ngrid - 1] - 1)) xt = (real)(c->nxn[ngrid - 1] - 1) - K(0.00001);
+  if (yt >= (real)(c->nyn[ngrid - 1] - 1)) yt = (real)(c->nyn[ngrid - 1] - 1) - K(0.00001);
+  ix = (int)xt; jy = (int)yt; ixp = ix + 1; jyp = jy + 1;
+  ddx = xt - (real)ix; ddy = yt - (real)jy;
+  rddx = K(1.) - ddx; rddy = K(1.) - ddy;
+  p1 = rddx * rddy; p2 = ddx * rddy; p3 = rddx * ddy; p4 = ddx * ddy;
+  *yint1 = p1 * N2(yy1, ix, jy, iwftouse, ngrid) + p2 * N2(yy1, ixp, jy, iwftouse, ngrid) + p3 * N2(yy1, ix, jyp, iwftouse, ngrid) + p4 * N2(yy1, ixp, jyp, iwftouse, ngrid);
+  *yint2 = p1 * N2(yy2, ix, jy, iwftouse, ngrid) + p2 * N2(yy2, ixp, jy, iwftouse, ngrid) + p3 * N2(yy2, ix, jyp, iwftouse, ngrid) + p4 * N2(yy2, ixp, jyp, iwftouse, ngrid);
+  *yint3 = p1 * N2(yy3, ix, jy, iwftouse, ngrid) + p2 * N2(yy3, ixp, jy, iwftouse, ngrid) + p3 * N2(yy3, ix, jyp, iwftouse, ngrid) + p4 * N2(yy3, ixp, jyp, iwftouse, ngrid);
+}
+
 static real r_pow10(real x) { return r_pow(K(10.), x); }
 static real r_log10(real x) { return sizeof(real) == 4 ? (real)log10f((float)x) : (real)log10((double)x); }
 
-/* get_wetscav.f90:78-314 (ngrid = 0) */
+/* get_wetscav.f90:78-314 */
 static real orc_get_wetscav(orc_ctx *c, int itime, int ltsample, double xtra1, double ytra1, real ztra1, int ks, real *grfraction) {
   static const real lfr[5] = {K(0.5), K(0.65), K(0.8), K(0.9), K(0.95)};
   static const real cfr[5] = {K(0.4), K(0.55), K(0.7), K(0.8), K(0.9)};
@@ -1718,22 +1736,35 @@ static real orc_get_wetscav(orc_ctx *c, int itime, int ltsample, double xtra1, d
   static const real bcls[6] = {K(22.7), K(0.0), K(0.0), K(1321.0), K(381.0), K(0.0)};
   const real incloud_ratio = K(6.2), r_air = K(287.05);
   real wetscav = K(0.), lsp, convp, cc, prec1, act_temp, S_i, cl, cle, frac_act, liq_frac, ice_frac, dquer_m;
-  int ix, jy, hz = 1, il, interp_time, n, i, j, clouds_v;
-  ix = (int)xtra1; jy = (int)ytra1;
+  int ix, jy, hz = 1, il, interp_time, n, i, j, clouds_v, ngrid = 0;
+  real xtn = K(0.), ytn = K(0.);
+  /* nesting level, :82-90: the plain nest bounds, without the eps margin advance.f90:167-173 applies */
+  for (j = c->numbnests; j >= 1; j--)
+    if (xtra1 > (double)c->xln[j - 1] && xtra1 < (double)c->xrn[j - 1] && ytra1 > (double)c->yln[j - 1] && ytra1 < (double)c->yrn[j - 1]) { ngrid = j; break; }
+  if (ngrid > 0 && !c->lsprecn) ngrid = 0;   /* scenario without nest precipitation fields: mother grid only (test set-ups) */
+  if (ngrid > 0) {   /* :97-101 */
+    xtn = (real)((xtra1 - (double)c->xln[ngrid - 1]) * (double)c->xresoln[ngrid - 1]);
+    ytn = (real)((ytra1 - (double)c->yln[ngrid - 1]) * (double)c->yresoln[ngrid - 1]);
+    ix = (int)xtn; jy = (int)ytn;
+  } else {
+    ix = (int)xtra1; jy = (int)ytra1;
+  }
   interp_time = (int)lround((double)((real)itime - K(0.5) * (real)ltsample));   /* nint(itime-0.5*ltsample) */
   n = c->memind[1];
   if (abs(c->memtime[0] - interp_time) < abs(c->memtime[1] - interp_time)) n = c->memind[0];
-  orc_interpol_rain(c, c->lsprec, c->convprec, c->tcc, n, (real)xtra1, (real)ytra1, &lsp, &convp, &cc);
+  if (ngrid == 0) orc_interpol_rain(c, c->lsprec, c->convprec, c->tcc, n, (real)xtra1, (real)ytra1, &lsp, &convp, &cc);
+  else orc_interpol_rain_nests(c, c->lsprecn, c->convprecn, c->tccn, ngrid, n, xtn, ytn, &lsp, &convp, &cc);
   if (lsp < K(0.01) && convp < K(0.01)) return wetscav;
   for (il = 2; il <= c->nz; il++)
     if (HGT(il) > ztra1) { hz = il - 1; break; }
-  clouds_v = (int)c->clouds[(((size_t)(n - 1) * c->nz + (size_t)(hz - 1)) * c->ny + (size_t)jy) * c->nx + (size_t)ix];
+  if (ngrid == 0) clouds_v = (int)c->clouds[(((size_t)(n - 1) * c->nz + (size_t)(hz - 1)) * c->ny + (size_t)jy) * c->nx + (size_t)ix];
+  else clouds_v = (int)N3(c->cloudsn, ix, jy, hz, n, ngrid);
   if (clouds_v <= 1) return wetscav;
   if (lsp > K(20.)) i = 5; else if (lsp > K(8.)) i = 4; else if (lsp > K(3.)) i = 3; else if (lsp > K(1.)) i = 2; else i = 1;
   if (convp > K(20.)) j = 5; else if (convp > K(8.)) j = 4; else if (convp > K(3.)) j = 3; else if (convp > K(1.)) j = 2; else j = 1;
   grfraction[0] = r_max(K(0.05), cc * (lsp * lfr[i - 1] + convp * cfr[j - 1]) / (lsp + convp));
   prec1 = (lsp + convp) / grfraction[0];
-  act_temp = F3(c->tt, ix, jy, hz, n);
+  act_temp = ngrid > 0 ? N3(c->ttn, ix, jy, hz, n, ngrid) : F3(c->tt, ix, jy, hz, n);   /* :197-201 */
   if (clouds_v >= 4) {   /* below cloud */
     if (c->dquer[ks] <= K(0.) && (c->weta_gas[ks] > K(0.) || c->wetb_gas[ks] > K(0.))) {
       c->blc_count[ks]++;
@@ -1756,7 +1787,7 @@ static real orc_get_wetscav(orc_ctx *c, int itime, int ltsample, double xtra1, d
       c->inc_count[ks]++;
       if (c->ccn_aero[ks] < K(0.)) c->ccn_aero[ks] = K(0.);
       if (c->in_aero[ks] < K(0.)) c->in_aero[ks] = K(0.);
-      if (c->readclouds) cl = F2(c->ctwc, ix, jy, n) * (grfraction[0] / cc);
+      if (ngrid == 0 && c->readclouds) cl = F2(c->ctwc, ix, jy, n) * (grfraction[0] / cc);
       else cl = K(1E6) * K(2E-7) * r_pow(prec1, K(0.36));
       if (act_temp <= K(253.)) { liq_frac = K(0); ice_frac = K(1); }
       else if (act_temp >= K(273.)) { liq_frac = K(1); ice_frac = K(0); }
@@ -1867,6 +1898,10 @@ void orc_set_wet(orc_ctx *c, const int *wetdepspec, const double *weta_gas, cons
   c->lsprec = lsprec; c->convprec = convprec; c->tcc = tcc; c->clouds = clouds; c->cloudsh = cloudsh; c->ctwc = ctwc;
 }
 const dep_real *orc_wetgridunc(orc_ctx *c) { return c->wetgridunc; }
+/* precipitation / cloud / temperature fields of nest 1 (readclouds_nest = .false.) */
+void orc_set_wet_nest(orc_ctx *c, const real *lsprecn, const real *convprecn, const real *tccn, const signed char *cloudsn, const real *ttn) {
+  c->lsprecn = lsprecn; c->convprecn = convprecn; c->tccn = tccn; c->cloudsn = cloudsn; c->ttn = ttn;
+}
 
 void orc_set_outgrid(orc_ctx *c, int numxgrid, int numygrid, int numzgrid, double dxout, double dyout, double outlon0,
                      double outlat0, const double *outheight, int maxpointspec_act, int nclassunc, int nageclass,

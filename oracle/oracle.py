@@ -157,6 +157,12 @@ class Oracle:
                         vp(self.wf["lsprec"]), vp(self.wf["convprec"]), vp(self.wf["tcc"]), vp(self.wf["clouds"]),
                         vp(self.wf["cloudsh"]), C.c_void_p(0))
         self._wetpar = (par, wds)
+        if "lsprecn" in sc:   # the nest's own precipitation / cloud / temperature fields
+            for k in ("lsprecn", "convprecn", "tccn", "ttn"):
+                self.wf[k] = np.ascontiguousarray(np.asarray(sc[k]).astype(self.rt))
+            self.wf["cloudsn"] = np.ascontiguousarray(np.asarray(sc["cloudsn"]).astype(np.int8))
+            lib.orc_set_wet_nest(self.h, vp(self.wf["lsprecn"]), vp(self.wf["convprecn"]), vp(self.wf["tccn"]),
+                                 vp(self.wf["cloudsn"]), vp(self.wf["ttn"]))
 
     def wetgrid(self):
         nage, ncu, mps, nsp, nzg, nyg, nxg = self.gshape

@@ -232,6 +232,7 @@ program flexref
       numbnests=1; nxn(1)=ibuf(1); nyn(1)=ibuf(2)
       if (nxn(1).gt.nxmaxn .or. nyn(1).gt.nymaxn) stop 'nest too large'
       call com_mod_allocate_nests
+      readclouds_nest=.false.; sumclouds_nest=.false.
     case ('nestgeom')  ! dxn dyn xlon0n ylat0n ; derived geometry as gridcheck_nests.f90:362-378
       dxn(1)=dbuf(1); dyn(1)=dbuf(2); xlon0n(1)=dbuf(3); ylat0n(1)=dbuf(4)
       xresoln(0)=1.; yresoln(0)=1.
@@ -251,6 +252,29 @@ program flexref
     case ('wstarn');  call fill2n(wstarn, dbuf)
     case ('olin');    call fill2n(olin, dbuf)
     case ('tropopausen'); call fill2n(tropopausen, dbuf)
+    ! precipitation / cloud / temperature fields of the nest (get_wetscav.f90:126-128,150-151,197-199)
+    case ('lsprecn');   call fill2n(lsprecn, dbuf)
+    case ('convprecn'); call fill2n(convprecn, dbuf)
+    case ('tccn');      call fill2n(tccn, dbuf)
+    case ('ttn');       call fill3n(ttn, dbuf)
+    case ('cloudsn')    ! compact (nxn,nyn,nz,2) int
+      do m=1,2
+        do k=1,gnz
+          do j=0,nyn(1)-1
+            do i=0,nxn(1)-1
+              cloudsn(i,j,k,m,1)=int(ibuf(1+i+nxn(1)*(j+nyn(1)*((k-1)+gnz*(m-1)))),1)
+            end do
+          end do
+        end do
+      end do
+    case ('cloudshn')   ! compact (nxn,nyn,2) int
+      do m=1,2
+        do j=0,nyn(1)-1
+          do i=0,nxn(1)-1
+            cloudshn(i,j,m,1)=ibuf(1+i+nxn(1)*(j+nyn(1)*(m-1)))
+          end do
+        end do
+      end do
     case ('vdepn')    ! compact (nxn,nyn,nspec,2)
       do m=1,2
         do ks=1,nspec

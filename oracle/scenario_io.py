@@ -24,13 +24,13 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
           "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol",
           "hmix", "ustar", "wstar", "oli", "tropopause", "vdep",
           "nest", "nestgeom", "uun", "vvn", "wwn", "rhon", "drhodzn", "hmixn", "ustarn", "wstarn", "olin",
-          "tropopausen", "vdepn", "lsprec", "convprec", "tcc", "clouds", "cloudsh",
+          "tropopausen", "vdepn", "lsprecn", "convprecn", "tccn", "ttn", "cloudsn", "cloudshn", "lsprec", "convprec", "tcc", "clouds", "cloudsh",
           "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
           "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass"]
 _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
         "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
         "drydep", "drydepspec", "lage", "nsteps", "itime0", "npart", "itra1", "itramem",
-        "npoint", "nclass", "idt", "cbt", "outgrid", "outgridn", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "nest"}
+        "npoint", "nclass", "idt", "cbt", "outgrid", "outgridn", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "cloudsn", "cloudshn", "nest"}
 
 
 def write_scenario(path, sc):

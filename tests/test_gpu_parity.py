@@ -358,6 +358,39 @@ def test_nested_output_grid_and_receptors(built, kind):
     assert np.abs(rec - orec).max() <= (1e-11 if kind == "r8" else 2e-3) * orec.max(), (rec, orec)   # f32: a few trajectories differ
 
 
+def test_wet_deposition_on_nested_grid(built):
+    """A particle inside a met nest is scavenged with the nest's own precipitation, cloud and temperature
+    fields (get_wetscav.f90:82-101,126-128,150-151,197-199; interpol_rain_nests.f90); the deposit also goes to the
+    nested output grid.  The oracle matches the reference (r8n build) bit for bit: tests/golden/nest_wet_r8.npz."""
+    from flexpart_amd.engine import Engine
+    from oracle.oracle import Oracle
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario("nest_wet")
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8)
+    got = eng.run()
+    w = eng.wetgrid()[0, 0, 0]
+    gn, dn, wn = (a[0, 0, 0] for a in eng.grids_nest())
+    eng.close()
+    orc = Oracle(sc, "r8")
+    orc.lib.orc_set_parallel_semantics(orc.h, 1)
+    want = orc.run()
+    ow = orc.wetgrid()
+    ogn, odn, own = orc.grids_nest()
+    assert ow.sum() > 1.0 and own.sum() > 1.0 and want[-1]["xmass1"].min() < 0.9
+    bad = np.abs(got[-1]["xmass1"] - want[-1]["xmass1"]).ravel() > 1e-11
+    assert bad.sum() == 0, bad.sum()
+    assert np.abs(w - ow).max() <= 2e-5 * ow.max()
+    assert np.abs(wn - own).max() <= 2e-5 * own.max()
+    assert np.abs(gn - ogn).max() <= 1e-12 * ogn.max()
+    assert np.abs(dn - odn).max() <= 2e-5 * odn.max()
+    # without the nest's fields the engine must refuse rather than use the mother grid silently
+    sc2 = {k: v for k, v in sc.items() if k not in ("lsprecn", "convprecn", "tccn", "ttn", "cloudsn", "cloudshn")}
+    eng = Engine(sc2, compute_real_bytes=8, host_real_bytes=8)
+    with pytest.raises(RuntimeError):
+        eng.run(2)        # wetdepo runs from the second step on (timemanager.f90:164-169)
+    eng.close()
+
+
 def test_device_math_helpers_against_libm(built):
     """The 1-2 ulp fp64 helpers of the Langevin loop (fpx_device.hpp: m_expp, m_logp, m_sqrtp, m_rcp,
     m_rsqrt, m_cuberoot_parts) against numpy/libm.  Tolerance 4 ulp (8.9e-16 relative); for the

@@ -36,6 +36,17 @@ def _sampling_nest(sc):
     return sc
 
 
+def _nest_wet(sc):
+    # met nest + wet deposition through interpol_rain_nests / cloudsn / ttn, plus the nested output grid
+    _nest(sc)
+    sc.update(decay=np.array([1.0e-6]))
+    syn.add_outgrid(sc)
+    syn.add_wet(sc, gas=False)
+    syn.add_wet_nest(sc)
+    syn.add_outgrid_nest(sc)
+    return sc
+
+
 def _nest(sc):
     # a nested grid (interpol_*_nests path) + dry deposition through interpol_vdep_nests
     sc.update(drydep=1, drydepspec=np.array([1], np.int32))
@@ -45,6 +56,7 @@ def _nest(sc):
 CASES = {
     "hanna": dict(ctl=5.0, ifine=4),
     "nest": dict(ctl=5.0, ifine=4, post=_nest),
+    "nest_wet": dict(ctl=5.0, ifine=4, post=_nest_wet),
     "sampling": dict(ctl=5.0, ifine=4, post=_sampling),
     "sampling_nest": dict(ctl=5.0, ifine=4, post=_sampling_nest),
     "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
@@ -108,9 +120,10 @@ def test_oracle_matches_golden_reference_output(name, kind):
                 ra = gold[key].reshape((5,) + a.shape[1:])[:nsp]
                 assert ra.sum() > 0
                 assert np.abs(a - ra).max() <= tol * ra.max(), key
-            rc = gold["creceptor"].reshape(nsp, -1)
-            assert rc.max() > 0
-            assert np.abs(orc.receptors() - rc).max() <= tol * rc.max()
+            if "creceptor" in gold.files:
+                rc = gold["creceptor"].reshape(nsp, -1)
+                assert rc.max() > 0
+                assert np.abs(orc.receptors() - rc).max() <= tol * rc.max()
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
