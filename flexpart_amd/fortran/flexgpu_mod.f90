@@ -20,13 +20,17 @@ module flexgpu_mod
   use par_mod
   use com_mod
   use point_mod, only: xmass, npart
+  use outg_mod, only: outheight
+  use unc_mod, only: gridunc, drygridunc, wetgridunc, griduncn, drygriduncn, wetgriduncn
   implicit none
   private
   public :: fpx_step_stats, flexgpu_init, flexgpu_finalize, flexgpu_upload_fields, &
             flexgpu_set_windtime, flexgpu_upload_particles, flexgpu_download_particles, &
-            flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error
+            flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error, &
+            flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
+            flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo
 #ifdef FLEXGPU_NESTS
-  public :: flexgpu_upload_nests
+  public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields
 #endif
 
   integer, parameter :: FPX_MAXSPEC = 5
@@ -148,6 +152,111 @@ module flexgpu_mod
       type(c_ptr), value :: h
       integer(c_int32_t), value :: itime
       type(fpx_step_stats), intent(out) :: st
+    end function
+  end interface
+
+  integer, parameter :: FPX_MAXAGECLASS = 8
+  type, bind(C) :: fpx_outgrid
+    integer(c_int32_t) :: struct_bytes
+    integer(c_int32_t) :: numxgrid, numygrid, numzgrid
+    real(c_double) :: dxout, dyout, xoutshift, youtshift
+    integer(c_int32_t) :: maxpointspec_act, nclassunc, nageclass
+    integer(c_int32_t) :: lage(FPX_MAXAGECLASS)
+    integer(c_int32_t) :: ind_samp, ioutputforeachrelease
+    integer(c_int32_t) :: lusekerneloutput
+    integer(c_int32_t) :: reserved(5)
+  end type
+  type, bind(C) :: fpx_outgrid_nest
+    integer(c_int32_t) :: struct_bytes
+    integer(c_int32_t) :: numxgridn, numygridn
+    real(c_double) :: dxoutn, dyoutn, xoutshiftn, youtshiftn
+    integer(c_int32_t) :: reserved(4)
+  end type
+  type, bind(C) :: fpx_wet_config
+    integer(c_int32_t) :: struct_bytes
+    integer(c_int32_t) :: wetdepspec(FPX_MAXSPEC)
+    real(c_double) :: weta_gas(FPX_MAXSPEC), wetb_gas(FPX_MAXSPEC)
+    real(c_double) :: crain_aero(FPX_MAXSPEC), csnow_aero(FPX_MAXSPEC)
+    real(c_double) :: ccn_aero(FPX_MAXSPEC), in_aero(FPX_MAXSPEC)
+    real(c_double) :: henry(FPX_MAXSPEC)
+    integer(c_int32_t) :: readclouds
+    integer(c_int32_t) :: reserved(7)
+  end type
+  type, bind(C) :: fpx_wet_fields
+    type(c_ptr) :: lsprec, convprec, tcc, ctwc, tt
+    type(c_ptr) :: clouds, cloudsh
+  end type
+
+  interface
+    integer(c_int) function fpx_outgrid_init(h, g, oh) bind(C, name='fpx_outgrid_init')
+      import :: c_ptr, c_int, fpx_outgrid
+      type(c_ptr), value :: h
+      type(fpx_outgrid), intent(in) :: g
+      type(c_ptr), value :: oh
+    end function
+    integer(c_int) function fpx_outgrid_nest_init(h, g) bind(C, name='fpx_outgrid_nest_init')
+      import :: c_ptr, c_int, fpx_outgrid_nest
+      type(c_ptr), value :: h
+      type(fpx_outgrid_nest), intent(in) :: g
+    end function
+    integer(c_int) function fpx_receptors_init(h, n, x, y, a) bind(C, name='fpx_receptors_init')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: n
+      type(c_ptr), value :: x, y, a
+    end function
+    integer(c_int) function fpx_set_output_times(h, loutnext, loutstep) bind(C, name='fpx_set_output_times')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: loutnext, loutstep
+    end function
+    integer(c_int) function fpx_conccalc(h, itime, weight) bind(C, name='fpx_conccalc')
+      import :: c_ptr, c_int, c_int32_t, c_double
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: itime
+      real(c_double), value :: weight
+    end function
+    integer(c_int) function fpx_get_grids(h, g, d, allreduce, clear) bind(C, name='fpx_get_grids')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, g, d
+      integer(c_int32_t), value :: allreduce, clear
+    end function
+    integer(c_int) function fpx_get_wetgrid(h, w, allreduce, clear) bind(C, name='fpx_get_wetgrid')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, w
+      integer(c_int32_t), value :: allreduce, clear
+    end function
+    integer(c_int) function fpx_get_grids_nest(h, g, d, w, allreduce, clear) bind(C, name='fpx_get_grids_nest')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, g, d, w
+      integer(c_int32_t), value :: allreduce, clear
+    end function
+    integer(c_int) function fpx_get_receptors(h, c, ld, allreduce, clear) bind(C, name='fpx_get_receptors')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, c
+      integer(c_int32_t), value :: ld, allreduce, clear
+    end function
+    integer(c_int) function fpx_wet_init(h, w) bind(C, name='fpx_wet_init')
+      import :: c_ptr, c_int, fpx_wet_config
+      type(c_ptr), value :: h
+      type(fpx_wet_config), intent(in) :: w
+    end function
+    integer(c_int) function fpx_upload_wet_fields(h, slot, f) bind(C, name='fpx_upload_wet_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_wet_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: slot
+      type(fpx_wet_fields), intent(in) :: f
+    end function
+    integer(c_int) function fpx_upload_wet_nest_fields(h, nest, slot, f, rc) bind(C, name='fpx_upload_wet_nest_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_wet_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: nest, slot, rc
+      type(fpx_wet_fields), intent(in) :: f
+    end function
+    integer(c_int) function fpx_wetdepo(h, itime, ltsample, loutnext) bind(C, name='fpx_wetdepo')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: itime, ltsample, loutnext
     end function
   end interface
 
@@ -344,5 +453,136 @@ contains
     nan_count = nan_count + int(stats%nan_count)      ! com_mod counters, advance.f90:421,439
     nan_count2 = nan_count2 + int(stats%nan_count2)
   end subroutine flexgpu_step
+
+  ! ---- output grids (rows a21-a23 of the hot path): OUTGRID / OUTGRID_NEST / RECEPTORS state of com_mod ----
+  function loc_i1(x) result(p)
+    integer(kind=1), target, intent(in) :: x(*)
+    type(c_ptr) :: p
+    p = c_loc(x)
+  end function loc_i1
+  function loc_dep(x) result(p)
+    real(dep_prec), target, intent(in) :: x(*)
+    type(c_ptr) :: p
+    p = c_loc(x)
+  end function loc_dep
+
+  ! after readoutgrid/outgrid_init (and their _nest twins, readreceptors): device copies of gridunc, drygridunc,
+  ! wetgridunc (+ griduncn ... when nested_output = 1, creceptor when numreceptor > 0)
+  subroutine flexgpu_outgrid_init(loutnext, ierr)
+    integer, intent(in) :: loutnext
+    integer, intent(out) :: ierr
+    type(fpx_outgrid) :: g
+    type(fpx_outgrid_nest) :: gn
+    g%struct_bytes = int(c_sizeof(g), c_int32_t)
+    g%numxgrid = numxgrid; g%numygrid = numygrid; g%numzgrid = numzgrid
+    g%dxout = dxout; g%dyout = dyout; g%xoutshift = xoutshift; g%youtshift = youtshift
+    g%maxpointspec_act = maxpointspec_act; g%nclassunc = nclassunc; g%nageclass = nageclass
+    g%lage = 0; g%lage(1:nageclass) = lage(1:nageclass)
+    g%ind_samp = ind_samp; g%ioutputforeachrelease = ioutputforeachrelease
+    g%lusekerneloutput = merge(1, 0, lusekerneloutput)
+    g%reserved = 0
+    ierr = fpx_outgrid_init(flexgpu_handle, g, loc_r(outheight))
+    if (ierr /= 0) return
+    ierr = fpx_set_output_times(flexgpu_handle, int(loutnext, c_int32_t), int(loutstep, c_int32_t))
+    if (ierr /= 0) return
+    if (nested_output .eq. 1) then
+      gn%struct_bytes = int(c_sizeof(gn), c_int32_t)
+      gn%numxgridn = numxgridn; gn%numygridn = numygridn
+      gn%dxoutn = dxoutn; gn%dyoutn = dyoutn; gn%xoutshiftn = xoutshiftn; gn%youtshiftn = youtshiftn
+      gn%reserved = 0
+      ierr = fpx_outgrid_nest_init(flexgpu_handle, gn)
+      if (ierr /= 0) return
+    end if
+    if (numreceptor .gt. 0) then
+      ierr = fpx_receptors_init(flexgpu_handle, int(numreceptor, c_int32_t), loc_r(xreceptor), loc_r(yreceptor), &
+                                loc_r(receptorarea))
+    end if
+  end subroutine flexgpu_outgrid_init
+
+  ! replaces "call conccalc(itime,weight)" (timemanager.f90:350-365); particles stay on the device
+  subroutine flexgpu_conccalc(itime, weight, ierr)
+    integer, intent(in) :: itime
+    real, intent(in) :: weight
+    integer, intent(out) :: ierr
+    ierr = fpx_conccalc(flexgpu_handle, int(itime, c_int32_t), real(weight, c_double))
+  end subroutine flexgpu_conccalc
+
+  ! before concoutput: the accumulated sums overwrite the host's gridunc, drygridunc, wetgridunc
+  ! (+ the nested grids and creceptor); clear = 1 zeroes the device copies as concoutput zeroes the host's
+  subroutine flexgpu_get_grids(clear, ierr)
+    integer, intent(in) :: clear
+    integer, intent(out) :: ierr
+    ierr = fpx_get_grids(flexgpu_handle, loc_r(gridunc), loc_dep(drygridunc), 0_c_int32_t, int(clear, c_int32_t))
+    if (ierr /= 0) return
+    ierr = fpx_get_wetgrid(flexgpu_handle, loc_dep(wetgridunc), 0_c_int32_t, int(clear, c_int32_t))
+    if (ierr /= 0) return
+    if (nested_output .eq. 1) then
+      ierr = fpx_get_grids_nest(flexgpu_handle, loc_r(griduncn), loc_dep(drygriduncn), loc_dep(wetgriduncn), &
+                                0_c_int32_t, int(clear, c_int32_t))
+      if (ierr /= 0) return
+    end if
+    if (numreceptor .gt. 0) then
+      ierr = fpx_get_receptors(flexgpu_handle, loc_r(creceptor), int(maxreceptor, c_int32_t), 0_c_int32_t, &
+                               int(clear, c_int32_t))
+    end if
+  end subroutine flexgpu_get_grids
+
+  ! ---- wet deposition: species parameters of readspecies.f90, fields of readwind/verttransform ----
+  subroutine flexgpu_wet_init(ierr)
+    integer, intent(out) :: ierr
+    type(fpx_wet_config) :: w
+    integer :: ks
+    w%struct_bytes = int(c_sizeof(w), c_int32_t)
+    w%wetdepspec = 0; w%weta_gas = 0; w%wetb_gas = 0; w%crain_aero = 0; w%csnow_aero = 0
+    w%ccn_aero = 0; w%in_aero = 0; w%henry = 0
+    do ks = 1, nspec
+      w%wetdepspec(ks) = merge(1, 0, WETDEPSPEC(ks))
+      w%weta_gas(ks) = weta_gas(ks); w%wetb_gas(ks) = wetb_gas(ks)
+      w%crain_aero(ks) = crain_aero(ks); w%csnow_aero(ks) = csnow_aero(ks)
+      w%ccn_aero(ks) = ccn_aero(ks); w%in_aero(ks) = in_aero(ks); w%henry(ks) = henry(ks)
+    end do
+    w%readclouds = merge(1, 0, readclouds)
+    w%reserved = 0
+    ierr = fpx_wet_init(flexgpu_handle, w)
+  end subroutine flexgpu_wet_init
+
+  subroutine flexgpu_upload_wet_fields(slot, ierr)
+    integer, intent(in) :: slot
+    integer, intent(out) :: ierr
+    type(fpx_wet_fields) :: f
+    f%lsprec = loc_r(lsprec(0,0,1,slot)); f%convprec = loc_r(convprec(0,0,1,slot)); f%tcc = loc_r(tcc(0,0,1,slot))
+    f%ctwc = c_null_ptr
+    if (readclouds) f%ctwc = loc_r(ctwc(0,0,slot))
+    f%tt = loc_r(tt(0,0,1,slot))
+    f%clouds = loc_i1(clouds(0,0,1,slot)); f%cloudsh = loc_i(cloudsh(0,0,slot))
+    ierr = fpx_upload_wet_fields(flexgpu_handle, int(slot, c_int32_t), f)
+  end subroutine flexgpu_upload_wet_fields
+
+#ifdef FLEXGPU_NESTS
+  subroutine flexgpu_upload_wet_nest_fields(slot, ierr)
+    integer, intent(in) :: slot
+    integer, intent(out) :: ierr
+    type(fpx_wet_fields) :: f
+    integer :: l
+    ierr = 0
+    do l = 1, numbnests
+      f%lsprec = loc_r(lsprecn(0,0,1,slot,l)); f%convprec = loc_r(convprecn(0,0,1,slot,l)); f%tcc = loc_r(tccn(0,0,1,slot,l))
+      f%ctwc = c_null_ptr
+      if (readclouds_nest(l)) f%ctwc = loc_r(ctwcn(0:,0,slot,l))
+      f%tt = loc_r(ttn(0:,0,1,slot,l))
+      f%clouds = loc_i1(cloudsn(0:,0,1,slot,l)); f%cloudsh = loc_i(cloudshn(0:,0,slot,l))
+      ierr = fpx_upload_wet_nest_fields(flexgpu_handle, int(l, c_int32_t), int(slot, c_int32_t), f, &
+                                        int(merge(1, 0, readclouds_nest(l)), c_int32_t))
+      if (ierr /= 0) return
+    end do
+  end subroutine flexgpu_upload_wet_nest_fields
+#endif
+
+  ! replaces "call wetdepo(itime,lsynctime,loutnext)" (timemanager.f90:164-169)
+  subroutine flexgpu_wetdepo(itime, ltsample, loutnext, ierr)
+    integer, intent(in) :: itime, ltsample, loutnext
+    integer, intent(out) :: ierr
+    ierr = fpx_wetdepo(flexgpu_handle, int(itime, c_int32_t), int(ltsample, c_int32_t), int(loutnext, c_int32_t))
+  end subroutine flexgpu_wetdepo
 
 end module flexgpu_mod

@@ -408,18 +408,51 @@ program flexref
     if (gerr .ne. 0) call gpu_fail('flexgpu_set_windtime')
     call flexgpu_upload_particles(1, numpart, gerr)
     if (gerr .ne. 0) call gpu_fail('flexgpu_upload_particles')
+    if (do_conc .eq. 1) then
+      call flexgpu_outgrid_init(loutnext_d, gerr)
+      if (gerr .ne. 0) call gpu_fail('flexgpu_outgrid_init')
+      if (WETDEP) then
+        call flexgpu_wet_init(gerr)
+        if (gerr .ne. 0) call gpu_fail('flexgpu_wet_init')
+        call flexgpu_upload_wet_fields(memind(1), gerr)
+        if (gerr .ne. 0) call gpu_fail('flexgpu_upload_wet_fields 1')
+        call flexgpu_upload_wet_fields(memind(2), gerr)
+        if (gerr .ne. 0) call gpu_fail('flexgpu_upload_wet_fields 2')
+#ifdef FLEXREF_NESTS
+        if (numbnests .gt. 0) then
+          call flexgpu_upload_wet_nest_fields(memind(1), gerr)
+          if (gerr .ne. 0) call gpu_fail('flexgpu_upload_wet_nest_fields 1')
+          call flexgpu_upload_wet_nest_fields(memind(2), gerr)
+          if (gerr .ne. 0) call gpu_fail('flexgpu_upload_wet_nest_fields 2')
+        end if
+#endif
+      end if
+    end if
     nadv=0
     call system_clock(c0, crate)
     do istep=0,nsteps-1
       itime=itime0+istep*lsynctime
+      if (WETDEP .and. (do_conc .eq. 1) .and. itime .ne. 0 .and. numpart .gt. 0) then   ! timemanager.f90:164-169
+        call flexgpu_wetdepo(itime, lsynctime, loutnext_d, gerr)
+        if (gerr .ne. 0) call gpu_fail('flexgpu_wetdepo')
+      end if
       call flexgpu_step(itime, gstats, gerr)
       if (gerr .ne. 0) call gpu_fail('flexgpu_step')
+      if (do_conc .eq. 1) then
+        call flexgpu_conccalc(itime+lsynctime, 1.0, gerr)
+        if (gerr .ne. 0) call gpu_fail('flexgpu_conccalc')
+      end if
       nadv=nadv+gstats%n_due
       call flexgpu_download_particles(1, numpart, gerr)
       if (gerr .ne. 0) call gpu_fail('flexgpu_download_particles')
       call dump_state()
     end do
     call system_clock(c1)
+    if (do_conc .eq. 1) then
+      call flexgpu_get_grids(0, gerr)        ! into the host's own gridunc, drygridunc, wetgridunc (+ nested, creceptor)
+      if (gerr .ne. 0) call gpu_fail('flexgpu_get_grids')
+      call dump_grids()
+    end if
     call flexgpu_finalize()
     goto 900
   end if
