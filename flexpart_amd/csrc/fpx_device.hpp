@@ -618,8 +618,8 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
 // once per fine sub-step, in LDS instead of registers: the two cached profile levels, the
 // horizontal weights of the cell, the displacement sums, the grid-scale wind, the horizontal
 // turbulent velocities, and the invariants the fine loop reads once per sub-step (surface-layer
-// scales, density and its gradient): 26 values of R per lane, which leaves room for three blocks
-// of 256 threads per CU (3 x (26 x 2 KB + height column) <= 160 KB).  The fine loop (cbl/hanna_short, ~120 live
+// scales, density and its gradient): 25 values of R per lane, which leaves room for three blocks
+// of 256 threads per CU (3 x (25 x 2 KB + height column) <= 160 KB).  The fine loop (cbl/hanna_short, ~120 live
 // registers of its own) then fits the 256-VGPR budget of two waves per SIMD without spilling
 // to scratch memory -- scratch spills of a persistent kernel are HBM traffic, LDS is not.
 // Layout: slot-major [S_COUNT][block], one column per lane; the accesses are volatile so that
@@ -632,7 +632,7 @@ enum StashSlot {
   S_ZT0, S_W,                                                                   // height at the start of the pass (u, v follow from it and the cached levels); interpol_mod w
   S_UP, S_VP,                                                                   // turbulent velocities along/across wind
   S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; cbl.f90:79-81 transition
-  S_RHOA, S_RHOAUX,                                                             // per-pass invariants of the fine loop: rhoa, rhograd/rhoa
+  S_RHOAUX,                                                                     // per-pass invariant of the fine loop: rhograd/rhoa
   S_COUNT
 };
 constexpr int kStashStride = 256;   // threads per block of the loop kernel
@@ -737,10 +737,10 @@ FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
 // (the straightforward form has 20 divisions, 7 square roots, 1 log and 4 exp).
 // `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
 template <typename R>
-FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhoaux, R sigmaw, R dsigmawdz, R tlw, R transition,
+FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoaux /* rhograd/rhoa */, R sigmaw, R dsigmawdz, R tlw, R transition,
                  R &ath, R &bth, int &flagrein) {
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
-  const R dens = rhoa, ddens = rhoaux * rhoa /* rhograd; rhoaux = rhograd/rhoa */, timedir = (R)ldirect;
+  const R timedir = (R)ldirect;
   const R ih = m_rcp(h);
   const R z = zp * ih;
   const R w2 = sigmaw * sigmaw;
@@ -805,16 +805,18 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoa, R rhoaux, R sigmaw
   const R da = deltawa * isa, db = deltawb * isb;
   const R pa = (usurad2p * isa) * m_expp(-(K(0.5) * (da * da)));
   const R pb = (usurad2p * isb) * m_expp(-(K(0.5) * (db * db)));
-  const R ptot = dens * aluarw * pa + dens * bluarw * pb;
   const R aperfa = deltawa * usurad2 * isa;
   const R aperfb = deltawb * usurad2 * isb;
-  const R Phi = K(-0.5) * (aluarw * dens * dwa + dens * wa * daluarw + aluarw * wa * ddens) * m_erf(aperfa) +
-                sigmawa * (aluarw * dens * dsigmawa * (wold2 * isa2 + K(1.)) + sigmawa * dens * daluarw + sigmawa * ddens * aluarw +
-                           aluarw * wold * dens * isa2 * (sigmawa * dwa - wa * dsigmawa)) * pa +
-                K(0.5) * (bluarw * dens * dwb + wb * dens * dbluarw + wb * bluarw * ddens) * m_erf(aperfb) +
-                sigmawb * (bluarw * dens * dsigmawb * (wold2 * isb2 + K(1.)) + sigmawb * dens * dbluarw + sigmawb * ddens * bluarw +
-                           bluarw * wold * dens * isb2 * (-sigmawb * dwb + wb * dsigmawb)) * pb;
-  const R Q = timedir * ((aluarw * dens * deltawa * isa2) * pa + (bluarw * dens * deltawb * isb2) * pb);
+  // The air density multiplies every term of ptot, Q and Phi (cbl.f90:175-205) and cancels in
+  // ath = (-(C0/2)*alfa*Q + Phi)/ptot; what is left of it is rx = rhograd/rhoa.
+  const R rx = rhoaux;
+  const R ptot = aluarw * pa + bluarw * pb;
+  const R Ta = aluarw * (dwa + wa * rx) + wa * daluarw;
+  const R Tb = bluarw * (dwb + wb * rx) + wb * dbluarw;
+  const R Ua = sigmawa * (aluarw * (dsigmawa * (wold2 * isa2 + K(1.)) + wold * isa2 * (sigmawa * dwa - wa * dsigmawa)) + sigmawa * (daluarw + rx * aluarw));
+  const R Ub = sigmawb * (bluarw * (dsigmawb * (wold2 * isb2 + K(1.)) + wold * isb2 * (wb * dsigmawb - sigmawb * dwb)) + sigmawb * (dbluarw + rx * bluarw));
+  const R Phi = K(0.5) * (Tb * m_erf(aperfb) - Ta * m_erf(aperfa)) + Ua * pa + Ub * pb;
+  const R Q = timedir * ((aluarw * deltawa * isa2) * pa + (bluarw * deltawb * isb2) * pb);
   ath = m_rcp(ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
   bth = m_sqrtp(C0 * alfa);
 }
@@ -1566,7 +1568,6 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   {
     const R rhoa = dz1 * S.get(S_RHOHI) + dz2 * S.get(S_RHOLO);
     const R rhograd = dz1 * S.get(S_RGHI) + dz2 * S.get(S_RGLO);
-    S.put(S_RHOA, rhoa);
     S.put(S_RHOAUX, rhograd * m_rcp(rhoa));
   }
 
@@ -1617,7 +1618,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             int flagrein = 0;
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
-            cbl(V.ldirect, wp, zt, S.get(S_WST), h, S.get(S_RHOA), S.get(S_RHOAUX), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
+            cbl(V.ldirect, wp, zt, S.get(S_WST), h, S.get(S_RHOAUX), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
             if (flagrein == 1) {
