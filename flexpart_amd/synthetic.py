@@ -250,8 +250,10 @@ def base_scenario(nx=361, ny=181, nz=138, *, global_grid=True, polar=False, nspe
         globalflags=np.array([int(global_grid), int(global_grid and polar),
                               int(global_grid and polar)], np.int32),
         height=height, nmixz=nmixz_from_height(height),
-        memtime=np.array([0, 10800], np.int32), memind=np.array([1, 2], np.int32),
-        ldirect=ldirect, lsynctime=sw["lsynctime"], method=sw["method"], mintime=sw["mintime"],
+        # backward runs: lsynctime and the wind window run towards negative times (readcommand.f90:631,
+        # getfields.f90 orders wftime by ldirect); mintime stays positive (readcommand.f90:381-384 come first)
+        memtime=np.array([0, 10800 * ldirect], np.int32), memind=np.array([1, 2], np.int32),
+        ldirect=ldirect, lsynctime=sw["lsynctime"] * ldirect, method=sw["method"], mintime=sw["mintime"],
         ctl=sw["ctl"], ifine=sw["ifine"], turbswitch=sw["turbswitch"], cblflag=sw["cblflag"],
         mdomainfill=0, lsettling=0, nspec=nspec,
         drydep=0, drydepspec=np.zeros(nspec, np.int32),

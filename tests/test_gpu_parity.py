@@ -63,7 +63,7 @@ def test_fp64_matches_oracle(built, name, kw):
         assert_close(g, w, 1e-9, 1e-7)
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "sampling"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "sampling", "backward", "backward_cbl"])
 def test_fp64_matches_oracle_golden_scenarios(built, name):
     """The scenarios the golden fixtures were made on: polar caps through the stereographic maps
     (cmapf subset), an aerosol species with settling + dry deposition + decay, CBL, Hanna."""
@@ -76,7 +76,7 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
         assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * scale
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "sampling"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "sampling", "backward", "backward_cbl"])
 def test_fp64_against_reference_fixtures(built, name):
     """HIP path directly against the outputs of the unmodified reference (tests/golden, flang r8
     build).  Only particles touched by the two order-dependent leaks of the serial code (DESIGN.md
@@ -412,6 +412,48 @@ def test_wet_deposition_on_nested_grid(built):
     with pytest.raises(RuntimeError):
         eng.run(2)        # wetdepo runs from the second step on (timemanager.f90:164-169)
     eng.close()
+
+
+def test_edge_cases_empty_dead_and_not_due(built):
+    """The loop's guards, timemanager.f90:531-535: no particles at all; particles that are not due at this
+    itime (itra1 != itime) or terminated (itra1 = -999999999) are left bit-for-bit untouched; a single particle."""
+    import ctypes as C
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
+    from flexpart_amd._lib import check
+    from oracle.oracle import Oracle
+    sc = syn.small(n=300, nx=40, ny=24, nz=30, nsteps=2, ctl=5.0, ifine=4)
+    # 1) empty: numpart = 0
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ)
+    check(eng.lib.fpx_set_numpart(eng.h, C.c_int64(0)), "fpx_set_numpart")
+    st = eng.step(0)
+    assert st["n_due"] == 0 and st["n_initialized"] == 0
+    eng.close()
+    # 2) every third particle terminated, every third scheduled for a later time
+    sc2 = dict(sc)
+    itra1 = np.asarray(sc["itra1"]).copy()
+    itra1[0::3] = -999999999
+    itra1[1::3] = 900
+    sc2["itra1"] = itra1
+    eng = Engine(sc2, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ)
+    before = eng.download()
+    st = eng.step(0)
+    after = eng.download()
+    eng.close()
+    assert st["n_due"] == int((itra1 == 0).sum())
+    idle = itra1 != 0
+    for k in ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "itra1", "idt", "cbt"):
+        assert np.array_equal(before[k][idle], after[k][idle]), k
+    assert np.all(after["itra1"][~idle] != 0)            # the due ones were advanced (or terminated)
+    orc = Oracle(sc2, "r8")
+    orc.lib.orc_set_parallel_semantics(orc.h, 1)
+    want = orc.run(1)[-1]
+    assert np.array_equal(after["itra1"], want["itra1"])
+    assert np.abs(after["xtra1"] - want["xtra1"]).max() <= 1e-9 * np.abs(want["xtra1"]).max()
+    # 3) one particle
+    sc1 = syn.small(n=1, nx=40, ny=24, nz=30, nsteps=2, ctl=5.0, ifine=4)
+    got, want = run_pair(sc1, "r8")
+    for k in POS:
+        assert abs(got[-1][k][0] - want[-1][k][0]) <= 1e-9 * max(abs(want[-1][k][0]), 1.0)
 
 
 def test_device_math_helpers_against_libm(built):

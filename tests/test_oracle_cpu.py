@@ -62,6 +62,8 @@ CASES = {
     "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
     "aerosol": dict(ctl=5.0, ifine=4, post=_aerosol),
     "hanna1_method0": dict(ctl=-5.0),
+    "backward": dict(ctl=5.0, ifine=4, ldirect=-1),
+    "backward_cbl": dict(ctl=5.0, ifine=4, cblflag=1, ldirect=-1),
     "cbl": dict(ctl=5.0, ifine=4, cblflag=1),
     "above_pbl_only": dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True),
 }
