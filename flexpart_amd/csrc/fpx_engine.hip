@@ -325,9 +325,12 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
   __syncthreads();
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= numpart) return;
-  pbl_flag[s] = 7;                                       // sort key "not a PBL particle"
+  pbl_flag[s] = 7;                                       // sort key "not due"
   if (P.itra1[s] != itime) return;                       // timemanager.f90:537
-  atomicAdd(&st->n_due, 1ull);   // one add per wave after the compiler's aggregation
+  // key 6 = due, finished in this kernel (above the PBL); 1..4 = PBL particle of that regime class.
+  // The counts (particles due, length of the PBL work list) are read off the sorted keys by
+  // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
+  pbl_flag[s] = 6;
 
   PState<R> ps;
   ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
@@ -393,7 +396,6 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
     else if (B.ol < (R)0) cls = 3;                                            // unstable, Gaussian
     else cls = 4;                                                             // stable
     pbl_flag[s] = cls;
-    atomicAdd(pbl_count, 1u);   // aggregated per wave by the compiler
     return;
   }
   R usig, vsig, wsig;
@@ -403,6 +405,34 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
 #pragma unroll
   for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
   epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
+}
+
+// After the stable sort of the slots by their 3-bit key: list length = number of keys <= 4 (PBL
+// classes), particles due = number of keys <= 6.  One wave, two 64-ary searches (5 dependent
+// loads each at 1e8 keys).
+__device__ __forceinline__ long long count_le_sorted(const unsigned char *__restrict__ keys, long long lo, long long hi, unsigned char bound) {
+  const int lane = threadIdx.x & 63;
+  while (hi > lo) {   // keys[< lo] <= bound < keys[>= hi]
+    const long long step = (hi - lo + 63) / 64;
+    const long long pos = lo + lane * step;
+    const bool le = pos < hi && keys[pos] <= bound;
+    const int cnt = __popcll(__ballot(le));    // the keys are sorted: the lanes that see <= bound are the first cnt
+    if (cnt == 0) { hi = lo; break; }
+    const long long nlo = lo + (long long)(cnt - 1) * step + 1;
+    const long long nhi = lo + (long long)cnt * step;
+    lo = nlo;
+    hi = nhi < hi ? nhi : hi;
+  }
+  return lo;
+}
+__global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, long long n, unsigned int *__restrict__ pbl_count, Stats *st) {
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const long long npbl = count_le_sorted(sorted_keys, 0, n, 4);
+  const long long ndue = count_le_sorted(sorted_keys, npbl, n, 6);
+  if (threadIdx.x == 0) {
+    *pbl_count = (unsigned int)npbl;
+    st->n_due += (unsigned long long)ndue;
+  }
 }
 
 // The Langevin kernel: persistent waves, lane refill (see the header comment above).
@@ -1237,6 +1267,7 @@ struct Engine : EngineBase {
       // the d_pbl_ctr[0] entries that are used)
       size_t need = sel_tmp_bytes;
       HIPCHK(rocprim::radix_sort_pairs(d_sel_tmp, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 3u, stream));
+      k_list_counts<<<1, 64, 0, stream>>>(d_pbl_flag2, numpart, d_pbl_ctr, d_stats);
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
     HIPCHK(hipEventRecord(ev.e[1], stream));
