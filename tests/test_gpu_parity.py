@@ -490,6 +490,10 @@ def test_device_math_helpers_against_libm(built):
     sgn = mid * rng.choice([-1.0, 1.0], mid.size)
     assert np.max(np.abs(probe(3, sgn) * sgn - 1.0)) < ulp4
     assert np.max(np.abs(probe(4, mid) * np.sqrt(mid) - 1.0)) < ulp4
+    # erf from a known exp(-x^2): absolute accuracy (the value only enters O(1) sums in cbl.f90:195-204)
+    from scipy.special import erf as sp_erf
+    xe = np.concatenate([rng.uniform(-7.0, 7.0, n), rng.uniform(-1e-3, 1e-3, 1000), [0.0, 6.5, -6.5, 30.0, -30.0]])
+    assert np.max(np.abs(probe(7, xe) - sp_erf(xe))) < 1e-15
     # the two "cube roots" of cbl.f90:115-121 keep the reference's exponent 0.333333333 (not 1/3)
     sk = np.concatenate([10.0 ** rng.uniform(-30, 30, n), 10.0 ** rng.uniform(-60, 60, 1000)])
     lg = np.log(sk)
