@@ -712,10 +712,21 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     T.sigw = T.sigw * S.get(S_UST) + K(1.e-2);
     T.tlw = K(0.5) * z * m_rcp(T.sigw * (K(1.) + K(1.5e-3) * corr));
   } else if (I.regime == 1) {
-    const R lz = m_logp(T.zeta);
-    const R z23 = sizeof(R) == 8 ? m_expp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
-    const R zm13 = sizeof(R) == 8 ? m_expp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : K(-6.907755278982137)))
-                                  : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
+    // zeta**0.66666 and max(zeta,1.e-3)**(-.33333) from one logarithm and one exponential:
+    // 0.66666 = 1 - 0.33333 - 1.e-5, so zeta**0.66666 = zeta * zeta**(-.33333) * exp(-1.e-5*log(zeta)),
+    // the last factor by its cubic Taylor polynomial (|1.e-5*log zeta| < 1e-3: remainder < 1e-17)
+    R z23, zm13;
+    if (sizeof(R) == 8) {
+      const R lz = m_logp(T.zeta);
+      const R e13 = m_expp(K(-.33333) * lz);
+      const R d = ((K(1.) - K(.33333)) - K(0.66666)) * lz;       // 1.e-5 * log(zeta)
+      const R corr = K(1.) - d * (K(1.) - d * (K(0.5) - d * K(0.16666666666666666)));
+      z23 = T.zeta > K(0.) ? T.zeta * e13 * corr : K(0.);   // 0**0.66666 = 0 (log(0) = -inf would give 0*inf)
+      zm13 = T.zeta > K(1.e-3) ? e13 : K(9.9997697441416293);   // (1.e-3)**(-.33333)
+    } else {
+      z23 = m_powr(T.zeta, K(0.66666));
+      zm13 = m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
+    }
     const R ust = S.get(S_UST), wst = S.get(S_WST);
     const R ust2 = ust * ust, wst2 = wst * wst;
     T.sigw = m_sqrtp(K(1.2) * wst2 * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * ust2) + K(1.e-2);
