@@ -47,7 +47,7 @@ FPX_HD double m_pow(double x, double y) { return pow(x, y); }
 // (results are within 1-2 ulp instead of correctly rounded) for 2-4x fewer cycles.
 // The float overloads keep the plain operations.
 // ---------------------------------------------------------------------------
-FPX_DEV float m_rcp(float b) { return 1.0f / b; }
+FPX_DEV float m_rcp(float b) { return __builtin_amdgcn_rcpf(b); }   // v_rcp_f32, 1 ulp
 FPX_DEV double m_rcp(double b) {   // 1/b, b finite and non-zero: hardware seed + two Newton steps (34 cycles)
   double r = __builtin_amdgcn_rcp(b);
   double e = fma(-b, r, 1.0);
@@ -64,7 +64,7 @@ FPX_DEV double m_divf(double a, double b) {
 }
 // sqrt(x) and 1/sqrt(x) together for x > 0 (normal range): v_rsq_f64 + one coupled
 // Goldschmidt step + one residual correction each (56 cycles for both)
-FPX_DEV void m_sqrt_rsqrt(float x, float &s, float &rs) { s = sqrtf(x); rs = 1.0f / s; }
+FPX_DEV void m_sqrt_rsqrt(float x, float &s, float &rs) { s = __builtin_amdgcn_sqrtf(x); rs = __builtin_amdgcn_rsqf(x); }   // v_sqrt_f32 / v_rsq_f32, 1 ulp
 FPX_DEV void m_sqrt_rsqrt(double x, double &s, double &rs) {
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
@@ -78,7 +78,7 @@ FPX_DEV void m_sqrt_rsqrt(double x, double &s, double &rs) {
   s = g;
   rs = h + h;
 }
-FPX_DEV float m_rsqrt(float x) { return 1.0f / sqrtf(x); }
+FPX_DEV float m_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 FPX_DEV double m_rsqrt(double x) {   // x > 0
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
@@ -90,7 +90,7 @@ FPX_DEV double m_rsqrt(double x) {   // x > 0
   return h + h;
 }
 // sqrt(x) for x >= 0 (0 allowed), 47 cycles
-FPX_DEV float m_sqrtp(float x) { return sqrtf(x); }
+FPX_DEV float m_sqrtp(float x) { return __builtin_amdgcn_sqrtf(x); }
 FPX_DEV double m_sqrtp(double x) {
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y, h = 0.5 * y;
