@@ -32,7 +32,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4))
+    ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
     ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: 1e8 cfg 3, 1e7 cfg 2)")
     ap.add_argument("--real", type=int, default=8, choices=(4, 8), help="compute real bytes")
     ap.add_argument("--rng", default="philox", choices=("philox", "table_counter"))
@@ -59,6 +59,22 @@ def build_scenario(cfg, nsteps):
             syn.add_outgrid(sc, nxg=360, nyg=180, nzg=10, outlon0=-180.0, outlat0=-90.0, dxout=1.0, dyout=1.0,
                             ind_samp=-1, old_fraction=0.0)
             del sc["npart"], sc["itramem"]
+        if cfg == 5:
+            # config 5: one aerosol species (settling, dry deposition, decay), a 2x nest over the middle of
+            # the domain (interpol_*_nests), wet deposition (mother + nest precipitation/cloud fields) and
+            # the output grid every step; meant for --real 4 (fp32 mixed: positions stay fp64)
+            sc.update(lsettling=1, drydep=1, drydepspec=np.array([1], np.int32), density=np.array([2000.0]),
+                      dquer=np.array([8.0]), vsetaver=np.array([-0.004]), cunningham=np.array([1.02]),
+                      decay=np.array([1.0e-6]), xmass=np.array([1.0]))
+            sc["npart"] = 1
+            sc["itramem"] = np.zeros(1, np.int32)
+            sc["itime0"] = 0
+            syn.add_outgrid(sc, nxg=360, nyg=180, nzg=10, outlon0=-180.0, outlat0=-90.0, dxout=1.0, dyout=1.0,
+                            ind_samp=-1, old_fraction=0.0)
+            del sc["npart"], sc["itramem"]
+            syn.add_nest(sc, ix0=120, jy0=60, ix1=240, jy1=120, factor=2)
+            syn.add_wet(sc, gas=False)
+            syn.add_wet_nest(sc)
     return sc, frac_pbl
 
 
@@ -126,7 +142,7 @@ def main():
         torch.cuda.set_device(local)
 
     from flexpart_amd.engine import Engine, RNG_PHILOX, RNG_TABLE_COUNTER
-    nper = int(args.particles or (1e8 if args.config == 3 else 1e7))
+    nper = int(args.particles or (1e8 if args.config == 3 else 1e7))   # configs 4/5 are 1e8 over 8 GPUs: 1.25e7 each, 1e7 here
     total_steps = args.warmup + args.steps
     sc, frac_pbl = build_scenario(args.config, total_steps)
     rng = RNG_PHILOX if args.rng == "philox" else RNG_TABLE_COUNTER
@@ -135,7 +151,7 @@ def main():
     eng.seed_particles(nper, seed=0x5EED + 7919 * rank, frac_pbl=frac_pbl)
     if args.sort_interval > 0:
         eng.sort()          # a release normally arrives ordered; the synthetic cloud is random
-    if args.config == 4 and world > 1:
+    if args.config in (4, 5) and world > 1:
         from flexpart_amd import sharding
         uid = sharding.share_unique_id(dist, eng.comm_unique_id)
         eng.comm_init(uid, world, rank)
@@ -148,8 +164,10 @@ def main():
         itime = i * lsync
         w0 = (itime // window) * window
         eng.set_windtime((w0, w0 + window), (1, 2))
+        if args.config == 5 and itime != 0:
+            eng.wetdepo(itime, lsync, 3600)            # timemanager.f90:164-169: before the particle loop
         eng.step_async(itime)
-        if args.config == 4:
+        if args.config in (4, 5):
             eng.conccalc(itime + lsync, 1.0)
 
     for i in range(args.warmup):
@@ -163,7 +181,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         do_step(i)
-    if args.config == 4:
+    if args.config in (4, 5):
         grid, _ = eng.grids(allreduce=world > 1)     # D2H of the (summed) grid: part of the job
     eng.sync()
     torch.cuda.synchronize()
@@ -213,6 +231,8 @@ def main():
                                 + ("advance+interpol_wind only (all above PBL, turbulence off)" if args.config == 2
                                    else "Hanna turbulence + CBL (ctl=1/5, ifine=11), PBL sub-stepping")
                                 + (" + conccalc 360x180x10 every step + RCCL grid all-reduce" if args.config == 4 else "")
+                                + (" + aerosol (settling, dry deposition), 241x121 nest, wet deposition, conccalc 360x180x10 every step"
+                                   if args.config == 5 else "")
                                 + f", rng={args.rng}, lsynctime=900"),
                    "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
                    "sort_interval": args.sort_interval},
@@ -224,7 +244,7 @@ def main():
                      "alg_bytes_per_particle_step": b_alg,
                      # what actually limits the kernel; the HBM fraction is reported as the contract asks
                      "limiter": ("gather address processing at 2 waves/SIMD, not HBM bandwidth" if args.config == 2
-                                 else "fp64 VALU issue (about 3e5 fp64 lane-instructions per PBL particle-step)")},
+                                 else f"{'fp64' if rb == 8 else 'fp32'} VALU issue (about 3e5 lane-instructions per PBL particle-step)")},
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         try:

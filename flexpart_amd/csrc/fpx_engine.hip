@@ -1329,6 +1329,9 @@ struct Engine : EngineBase {
       if (cfg.turbswitch && cfg.cblflag == 1) return philox ? k_pbl_loop<R, true, 1, 1, 2> : k_pbl_loop<R, true, 1, 1, 0>;
       if (cfg.turbswitch && cfg.cblflag != 1) return philox ? k_pbl_loop<R, true, 1, 0, 2> : k_pbl_loop<R, true, 1, 0, 0>;
       if (!cfg.turbswitch && cfg.cblflag != 1) return philox ? k_pbl_loop<R, true, 0, 0, 2> : k_pbl_loop<R, true, 0, 0, 0>;
+    } else if (philox) {   // aerosols (settling / dry deposition) with the counter RNG: same switch specialisation
+      if (cfg.turbswitch && cfg.cblflag == 1) return k_pbl_loop<R, false, 1, 1, 2>;
+      if (cfg.turbswitch && cfg.cblflag != 1) return k_pbl_loop<R, false, 1, 0, 2>;
     }
     return k_pbl_loop<R, false, -1, -1, -1>;
   }
