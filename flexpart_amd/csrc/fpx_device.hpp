@@ -537,50 +537,49 @@ struct Turb {
 
 template <typename R>
 FPX_DEV R tlw_unstable(const Turb<R> &T, R z) {   // hanna.f90:78-84
-  if (z < m_abs(T.ol)) return K(0.1) * z / (T.sigw * (K(0.55) - K(0.38) * m_abs(z / T.ol)));
-  if (T.zeta < K(0.1)) return K(0.59) * z / T.sigw;
-  return K(0.15) * T.h / T.sigw * (K(1.) - m_exp(K(-5) * T.zeta));
+  if (z < m_abs(T.ol)) return K(0.1) * z * m_rcp(T.sigw * (K(0.55) - K(0.38) * m_abs(z * m_rcp(T.ol))));
+  if (T.zeta < K(0.1)) return K(0.59) * z * m_rcp(T.sigw);
+  return K(0.15) * T.h * m_rcp(T.sigw) * (K(1.) - m_expp(K(-5) * T.zeta));
 }
 
 template <typename R>
 FPX_DEV void sigw_unstable(Turb<R> &T) {   // hanna.f90:67-70 == hanna_short.f90:60-63
   // zeta**0.66666 and max(zeta,1.e-3)**(-.33333) from one logarithm
   const R lz = m_logp(T.zeta);
-  const R z23 = sizeof(R) == 8 ? m_exp(K(0.66666) * lz) : m_powr(T.zeta, K(0.66666));
-  const R zm13 = sizeof(R) == 8 ? m_exp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : K(-6.907755278982137)))
-                                : m_powr(m_max(T.zeta, K(1.e-3)), K(-.33333));
+  const R z23 = T.zeta > K(0.) ? m_expp(K(0.66666) * lz) : K(0.);
+  const R zm13 = m_expp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : m_logp(K(1.e-3))));
   T.sigw = m_sqrtp(K(1.2) * (T.wst * T.wst) * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * (T.ust * T.ust)) + K(1.e-2);
-  T.dsigwdz = K(0.5) / T.sigw / T.h * (K(-1.4) * (T.ust * T.ust) + (T.wst * T.wst) * (K(0.8) * zm13 - K(1.8) * z23));
+  T.dsigwdz = K(0.5) * m_rcp(T.sigw * T.h) * (K(-1.4) * (T.ust * T.ust) + (T.wst * T.wst) * (K(0.8) * zm13 - K(1.8) * z23));
 }
 
 template <typename R>
 FPX_DEV void hanna(Turb<R> &T, R z) {   // hanna.f90:41-106
   if (T.h / m_abs(T.ol) < K(1.)) {
     T.ust = m_max(K(1.e-4), T.ust);
-    R corr = z / T.ust;
-    T.sigu = K(1.e-2) + K(2.0) * T.ust * m_exp(K(-3.e-4) * corr);
-    T.sigw = K(1.3) * T.ust * m_exp(K(-2.e-4) * corr);
+    R corr = z * m_rcp(T.ust);
+    T.sigu = K(1.e-2) + K(2.0) * T.ust * m_expp(K(-3.e-4) * corr);
+    T.sigw = K(1.3) * T.ust * m_expp(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
     T.sigw = T.sigw + K(1.e-2);
     T.sigv = T.sigw;
-    T.tlu = K(0.5) * z / T.sigw / (K(1.) + K(1.5e-3) * corr);
+    T.tlu = K(0.5) * z * m_rcp(T.sigw * (K(1.) + K(1.5e-3) * corr));
     T.tlv = T.tlu;
     T.tlw = T.tlu;
   } else if (T.ol < K(0.)) {
-    T.sigu = K(1.e-2) + T.ust * m_powr(K(12) - K(0.5) * T.h / T.ol, K(0.33333));
+    T.sigu = K(1.e-2) + T.ust * m_powr(K(12) - K(0.5) * T.h * m_rcp(T.ol), K(0.33333));
     T.sigv = T.sigu;
     sigw_unstable(T);
-    T.tlu = K(0.15) * T.h / T.sigu;
+    T.tlu = K(0.15) * T.h * m_rcp(T.sigu);
     T.tlv = T.tlu;
     T.tlw = tlw_unstable(T, z);
   } else {
     T.sigu = K(1.e-2) + K(2.) * T.ust * (K(1.) - T.zeta);
     T.sigv = K(1.e-2) + K(1.3) * T.ust * (K(1.) - T.zeta);
     T.sigw = T.sigv;
-    T.dsigwdz = K(-1.3) * T.ust / T.h;
-    T.tlu = K(0.15) * T.h / T.sigu * m_sqrt(T.zeta);
+    T.dsigwdz = K(-1.3) * T.ust * m_rcp(T.h);
+    T.tlu = K(0.15) * T.h * m_rcp(T.sigu) * m_sqrtp(T.zeta);
     T.tlv = K(0.467) * T.tlu;
-    T.tlw = K(0.1) * T.h / T.sigw * m_powr(T.zeta, K(0.8));
+    T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_powr(T.zeta, K(0.8));
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -658,7 +657,7 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
 // the compiler does not forward the values through registers across the loop.
 // ---------------------------------------------------------------------------
 enum StashSlot {
-  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // LevelCache
+  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // the two cached profile levels
   S_DDX, S_DDY,                                                                 // position inside the cell (interpol_all.f90:57-58); p1..p4 follow from it
   S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
   S_ZT0, S_W,                                                                   // height at the start of the pass (u, v follow from it and the cached levels); interpol_mod w
@@ -781,11 +780,10 @@ FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
 // (the straightforward form has 20 divisions, 7 square roots, 1 log and 4 exp).
 // `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
 template <typename R>
-FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R h, R rhoaux /* rhograd/rhoa */, R sigmaw, R dsigmawdz, R tlw, R transition,
+FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rhograd/rhoa */, R sigmaw, R dsigmawdz, R tlw, R transition,
                  R &ath, R &bth, int &flagrein) {
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
   const R timedir = (R)ldirect;
-  const R ih = m_rcp(h);
   const R z = zp * ih;
   const R w2 = sigmaw * sigmaw;
   const R dw2 = K(2.) * sigmaw * dsigmawdz;
@@ -1304,38 +1302,11 @@ FPX_DEV R interp_vdep(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const
   return (y[0] * W.dt2 + y[1] * W.dt1) * W.dtt;
 }
 
-// two-level profile cache: the reference caches every PBL level it has touched
-// (indzindicator, interpol_mod.f90:16); values are pure functions of the level,
-// so recomputing on a miss gives the same numbers with two levels in registers.
-// The 8-point sigmas (usigprof..) are only read when the interval ends
-// (advance.f90:604-606): they are evaluated then, for the final level pair.
-template <typename R>
-struct LevelCache {
-  R ulo, vlo, wlo, rholo, rhogradlo;
-  R uhi, vhi, whi, rhohi, rhogradhi;
-  int ilo;   // level index of *lo; *hi is ilo+1; -1 = empty
-};
-
-template <typename R>
-FPX_DEV void cache_fetch(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, LevelCache<R> &LC, int indz) {
-  if (LC.ilo == indz) return;
-  Level<R> L;
-  if (LC.ilo == indz + 1) {            // moved one level down
-    LC.uhi = LC.ulo; LC.vhi = LC.vlo; LC.whi = LC.wlo; LC.rhohi = LC.rholo; LC.rhogradhi = LC.rhogradlo;
-    level_profile<R, true, true, false>(V, F, C, W, indz, L);
-    LC.ulo = L.u; LC.vlo = L.v; LC.wlo = L.w; LC.rholo = L.rho; LC.rhogradlo = L.rhograd;
-  } else if (LC.ilo == indz - 1) {     // moved one level up
-    LC.ulo = LC.uhi; LC.vlo = LC.vhi; LC.wlo = LC.whi; LC.rholo = LC.rhohi; LC.rhogradlo = LC.rhogradhi;
-    level_profile<R, true, true, false>(V, F, C, W, indz + 1, L);
-    LC.uhi = L.u; LC.vhi = L.v; LC.whi = L.w; LC.rhohi = L.rho; LC.rhogradhi = L.rhograd;
-  } else {
-    level_profile<R, true, true, false>(V, F, C, W, indz, L);
-    LC.ulo = L.u; LC.vlo = L.v; LC.wlo = L.w; LC.rholo = L.rho; LC.rhogradlo = L.rhograd;
-    level_profile<R, true, true, false>(V, F, C, W, indz + 1, L);
-    LC.uhi = L.u; LC.vhi = L.v; LC.whi = L.w; LC.rhohi = L.rho; LC.rhogradhi = L.rhograd;
-  }
-  LC.ilo = indz;
-}
+// Two-level profile cache of the PBL loop: the reference caches every PBL level it has touched
+// (indzindicator, interpol_mod.f90:16); the values are pure functions of the level, so recomputing on a
+// miss gives the same numbers with two levels kept per lane (in the LDS stash, cache_fetch_stash below).
+// The 8-point sigmas (usigprof..) are only read when the interval ends (advance.f90:604-606): they are
+// evaluated then, for the final level pair (level_pair_sigma).
 
 // usig = 0.5*(usigprof(indzp)+usigprof(indz)) etc., advance.f90:604-606
 template <typename R>
@@ -1489,10 +1460,9 @@ FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, 
 }
 
 template <typename R>
-struct PblCtx {                 // live across passes of the PBL loop
+struct PblCtx {                 // first-pass set-up handed from k_prep to the PBL loop
   Cell<R> C;
   R ust, wst, ol;               // hanna_mod ust, wst, ol
-  LevelCache<R> LC;
   R transition;                 // cbl.f90:79-81, constant during the step (depends on h/ol only)
 };
 
@@ -1503,7 +1473,6 @@ FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W
   interp_surface(V, fld_of(V, A.ngrid), B.C, W, T);
   B.ust = T.ust; B.wst = T.wst; B.ol = T.ol;
   B.transition = V.cblflag == 1 ? cbl_transition(A.h, T.ol) : K(1.);
-  B.LC.ilo = -1;
 }
 
 // One pass of the loop advance.f90:282-609.  prob: dry-deposition probabilities (DRYDEP only).
@@ -1517,7 +1486,7 @@ struct LoopCtx {                // register-resident state of a lane across pass
   int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
   R h;
   int itimec, nrand;
-  int ilo;                      // level index of the cached *lo profile level (-1 = empty), see LevelCache
+  int ilo;                      // level index of the cached *lo profile level (-1 = empty), see cache_fetch_stash
 };
 
 template <typename R>
@@ -1667,7 +1636,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             int flagrein = 0;
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
-            cbl(V.ldirect, wp, zt, S.get(S_WST), h, S.get(S_RHOAUX), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
+            cbl(V.ldirect, wp, zt, S.get(S_WST), HI.ih, S.get(S_RHOAUX), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
             if (flagrein == 1) {
