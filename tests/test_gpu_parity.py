@@ -63,7 +63,7 @@ def test_fp64_matches_oracle(built, name, kw):
         assert_close(g, w, 1e-9, 1e-7)
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "sampling", "backward", "backward_cbl"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "sampling", "backward", "backward_cbl", "limited_area"])
 def test_fp64_matches_oracle_golden_scenarios(built, name):
     """The scenarios the golden fixtures were made on: polar caps through the stereographic maps
     (cmapf subset), an aerosol species with settling + dry deposition + decay, CBL, Hanna."""
@@ -76,7 +76,7 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
         assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * scale
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "sampling", "backward", "backward_cbl"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "sampling", "backward", "backward_cbl", "limited_area"])
 def test_fp64_against_reference_fixtures(built, name):
     """HIP path directly against the outputs of the unmodified reference (tests/golden, flang r8
     build).  Only particles touched by the two order-dependent leaks of the serial code (DESIGN.md

@@ -62,6 +62,7 @@ CASES = {
     "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
     "aerosol": dict(ctl=5.0, ifine=4, post=_aerosol),
     "hanna1_method0": dict(ctl=-5.0),
+    "limited_area": dict(ctl=5.0, ifine=4, global_grid=False, lat_margin_cells=0.02),   # particles leave the domain (nstop=3)
     "backward": dict(ctl=5.0, ifine=4, ldirect=-1),
     "backward_cbl": dict(ctl=5.0, ifine=4, cblflag=1, ldirect=-1),
     "cbl": dict(ctl=5.0, ifine=4, cblflag=1),
