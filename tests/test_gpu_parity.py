@@ -456,6 +456,43 @@ def test_edge_cases_empty_dead_and_not_due(built):
         assert abs(got[-1][k][0] - want[-1][k][0]) <= 1e-9 * max(abs(want[-1][k][0]), 1.0)
 
 
+def test_release_during_the_run_after_a_locality_sort(built):
+    """releaseparticles() adds particles while the model runs (timemanager.f90:246): the second half of the
+    cloud is uploaded (fpx_upload_particles with first = numpart) after two steps and a locality sort of the
+    first half.  The oracle carries all particles from the start, the late ones scheduled for the release time,
+    which is what the reference's loop does with them (`if (itra1(j).ne.itime) cycle`, initialize() at itramem)."""
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
+    from oracle.oracle import Oracle
+    n, half, t_rel = 3000, 1500, 1800
+    sc = syn.small(n=n, nx=60, ny=40, nz=40, nsteps=4, ctl=5.0, ifine=4, seed=77)
+    itra1 = np.asarray(sc["itra1"]).copy(); itramem = np.asarray(sc["itramem"]).copy()
+    itra1[half:] = t_rel; itramem[half:] = t_rel
+    sc.update(itra1=itra1, itramem=itramem)
+    orc = Oracle(sc, "r8")
+    orc.lib.orc_set_parallel_semantics(orc.h, 1)
+    want = orc.run(4)[-1]
+
+    def part(lo, hi):
+        d = dict(sc)
+        d["npart"] = hi - lo
+        for k in ("xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt", "uap", "ucp", "uzp", "us", "vs", "ws", "cbt"):
+            if k in sc:
+                d[k] = np.asarray(sc[k])[lo:hi]
+        d["xmass1"] = np.asarray(sc["xmass1"]).reshape(-1, n)[:, lo:hi]
+        return d
+    eng = Engine(part(0, half), compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ, max_particles=n)
+    eng.step(); eng.step()
+    eng.sort()
+    eng.upload_particles_from_scenario(part(half, n), first=half)
+    eng.step(); eng.step()
+    got = eng.download()
+    eng.close()
+    assert got["xtra1"].size == n
+    assert np.array_equal(got["itra1"], want["itra1"])
+    for k in POS:
+        assert np.abs(got[k] - want[k]).max() <= 1e-9 * np.abs(want[k]).max(), k
+
+
 def test_device_math_helpers_against_libm(built):
     """The 1-2 ulp fp64 helpers of the Langevin loop (fpx_device.hpp: m_expp, m_logp, m_sqrtp, m_rcp,
     m_rsqrt, m_cuberoot_parts) against numpy/libm.  Tolerance 4 ulp (8.9e-16 relative); for the
