@@ -184,6 +184,21 @@ FPX_DEV T m_erf_e(T x, T E) {
 // correctly-rounded pow (fp32: a few ulp of powf at a third of its cost).  x == 0 and x < 0 behave like pow (0/inf, NaN).
 FPX_DEV float m_powr(float x, float y) { return x > 0.0f ? expf(y * logf(x)) : powf(x, y); }
 FPX_DEV double m_powr(double x, double y) { return m_expp(y * m_logp(x)); }
+// x**0.8 for 0 <= x (hanna.f90:97, hanna_short.f90:80: tlw = 0.1*h/sigw*zeta**0.8): 0.8 = 4/5, so x**0.8 = x*r with
+// r = x**(-1/5) from an f32 seed and two Newton steps r <- r + r*(1 - x*r^5)/5 (the literal 0.8 differs from 4/5
+// by 4e-17: invisible).  19 instructions instead of log + exp (58).
+FPX_DEV float m_pow08(float x) { return x > 0.0f ? expf(0.8f * logf(x)) : 0.0f; }
+FPX_DEV double m_pow08(double x) {
+  if (!(x > 1.0e-37 && x < 1.0e37)) return x > 0.0 ? exp(0.8 * log(x)) : (x == 0.0 ? 0.0 : pow(x, 0.8));
+  double r = (double)__builtin_amdgcn_exp2f(__log2f((float)x) * -0.2f);
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const double r2 = r * r, r5 = (r2 * r2) * r;
+    const double e = fma(-x, r5, 1.0);
+    r = fma(r * 0.2, e, r);
+  }
+  return x * r;
+}
 // c = x**0.333333333 and ic2 = x**(-2*0.333333333) for x > 0 (the two "cuberoot" calls of cbl.f90:115-121,
 // exponent as written at cbl.f90:227).  fp64: r = x**(-1/3) from an f32 seed and two Newton steps
 // r <- r + r*(1 - x*r^3)/3, then the difference between 1/3 and 0.333333333 as the first-order
@@ -579,7 +594,7 @@ FPX_DEV void hanna(Turb<R> &T, R z) {   // hanna.f90:41-106
     T.dsigwdz = K(-1.3) * T.ust * m_rcp(T.h);
     T.tlu = K(0.15) * T.h * m_rcp(T.sigu) * m_sqrtp(T.zeta);
     T.tlv = K(0.467) * T.tlu;
-    T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_powr(T.zeta, K(0.8));
+    T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_pow08(T.zeta);
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -744,7 +759,7 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     const R ust = S.get(S_UST);
     T.sigw = K(1.e-2) + K(1.3) * ust * (K(1.) - T.zeta);
     T.dsigwdz = K(-1.3) * ust * I.ih;
-    T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_powr(T.zeta, K(0.8));
+    T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_pow08(T.zeta);
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -786,7 +801,6 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rho
   const R timedir = (R)ldirect;
   const R z = zp * ih;
   const R w2 = sigmaw * sigmaw;
-  const R dw2 = K(2.) * sigmaw * dsigmawdz;
   const R alfa = K(2.) * w2 * m_rcp(C0 * tlw);
   const R wold = timedir * wp;
   const R omz = K(1.) - z;
@@ -796,10 +810,9 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rho
   const R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * ih * transition;
   const R irw = m_rcp(sigmaw);                 // w2**(-0.5)
   const R irw2 = irw * irw, irw3 = irw2 * irw;
-  const R w215 = w2 * sigmaw;
   const R skew = w3 * irw3;
   const R skew2 = skew * skew;
-  const R dskew = (dw3 * w215 - w3 * K(1.5) * sigmaw * dw2) * (irw3 * irw3);
+  const R dskew = irw3 * dw3 - K(3.) * skew * dsigmawdz * irw;   // (dw3*w2**1.5 - w3*1.5*w2**0.5*dw2)/w2**3 with w2 = sigmaw^2
   R fluarw = K(0.), dfluarw = K(0.), rluarw = K(0.), drluarw = K(0.), xluarw = K(0.), dxluarw = K(0.);
   if (skew != K(0)) {
     R croot, icroot2;
@@ -826,16 +839,19 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rho
   const R bluarw = K(1.) - aluarw;
   const R daluarw = K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * ir405 * drluarw)) * (ir405 * ir405);
   const R dbluarw = -daluarw;
-  const R t1 = aluarw * a1, t2 = bluarw * a1;
-  const R rs = m_rsqrt(t1 * bluarw), rs2 = rs * rs;
-  const R qa05 = bluarw * rs, iqa05 = t1 * rs;     // (bluarw/t1)**0.5 and its inverse
-  const R qb05 = aluarw * rs, iqb05 = t2 * rs;     // (aluarw/t2)**0.5 and its inverse
-  const R it1 = bluarw * rs2, it2 = aluarw * rs2;  // 1/t1, 1/t2
+  // With x = aluarw*bluarw*a1 and rs = x**-0.5 (a1 = 1+fluarw^2):
+  //   (bluarw/(aluarw*a1))**0.5 = bluarw*rs, its inverse = aluarw*a1*rs (and the same with a and b exchanged);
+  //   the derivative of the first quotient, dbl*t1 - bl*(dal*a1 + al*ffd) over t1^2 with dbl = -dal and al+bl = 1,
+  //   is -(dal*a1 + al*bl*ffd)*bl^2*rs^4, so 0.5/qa05 times it = -0.5*bl*rs^3*(dal*a1 + al*bl*ffd);
+  //   for the second quotient +0.5*al*rs^3*(dal*a1 - al*bl*ffd).
+  const R ab = aluarw * bluarw;
+  const R rs = m_rsqrt(ab * a1), rs3 = rs * (rs * rs);
+  const R qa05 = bluarw * rs, iqa05 = aluarw * a1 * rs;
+  const R qb05 = aluarw * rs, iqb05 = bluarw * a1 * rs;
   const R sigmawa = sigmaw * qa05, sigmawb = sigmaw * qb05;
-  const R dsigmawa = dsigmawdz * qa05 +
-                     sigmaw * ((K(0.5) * iqa05) * ((dbluarw * t1 - bluarw * (daluarw * a1 + aluarw * ffd)) * (it1 * it1)));
-  const R dsigmawb = dsigmawdz * qb05 +
-                     sigmaw * ((K(0.5) * iqb05) * ((daluarw * t2 - aluarw * (dbluarw * a1 + bluarw * ffd)) * (it2 * it2)));
+  const R da1 = daluarw * a1, abf = ab * ffd, hs3 = K(0.5) * sigmaw * rs3;
+  const R dsigmawa = dsigmawdz * qa05 - hs3 * bluarw * (da1 + abf);
+  const R dsigmawb = dsigmawdz * qb05 + hs3 * aluarw * (da1 - abf);
   const R wa = fluarw * sigmawa, wb = fluarw * sigmawb;
   const R dwa = dfluarw * sigmawa + fluarw * dsigmawa;
   const R dwb = dfluarw * sigmawb + fluarw * dsigmawb;

@@ -564,6 +564,7 @@ __global__ void k_math_probe(int fn, const double *__restrict__ x, double *__res
     case 4: r = m_rsqrt(v); break;
     case 5: m_cuberoot_parts(v, c, ic2); r = c; break;
     case 7: r = m_erf_e(v, m_expp(-(v * v))); break;
+    case 8: r = m_pow08(v); break;
     default: m_cuberoot_parts(v, c, ic2); r = ic2; break;
   }
   y[i] = r;
@@ -1941,7 +1942,7 @@ int fpx_receptors_init(fpx_handle h, int32_t numreceptor, const void *xreceptor,
 int fpx_get_receptors(fpx_handle h, void *creceptor, int32_t ld, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_receptors(creceptor, ld, allreduce, clear); }
 
 int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n) {
-  if (fn < 0 || fn > 7 || !x || !y || n < 0) return FPX_ERR_ARG;
+  if (fn < 0 || fn > 8 || !x || !y || n < 0) return FPX_ERR_ARG;
   if (n == 0) return FPX_OK;
   double *dx = nullptr, *dy = nullptr;
   if (hipMalloc(&dx, n * sizeof(double)) != hipSuccess) return FPX_ERR_NOMEM;

@@ -311,7 +311,7 @@ void *fpx_stream(fpx_handle h);
 /* Diagnostics: evaluates one of the engine's fp64 device math helpers (fpx_device.hpp: the 1-2 ulp
  * replacements of exp/log/sqrt/division used inside the Langevin loop) on n host values, on the
  * current device.  fn: 0 m_expp, 1 m_logp, 2 m_sqrtp, 3 m_rcp, 4 m_rsqrt, 5 x**0.333333333 and
- * 6 x**(-2*0.333333333) (m_cuberoot_parts), 7 m_erf_e(x, m_expp(-x*x)).  No reference counterpart; used by the parity tests to bound
+ * 6 x**(-2*0.333333333) (m_cuberoot_parts), 7 m_erf_e(x, m_expp(-x*x)), 8 m_pow08.  No reference counterpart; used by the parity tests to bound
  * the helpers against libm.  Returns 0 or a negative fpx_status. */
 int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n);
 

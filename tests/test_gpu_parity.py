@@ -527,6 +527,10 @@ def test_device_math_helpers_against_libm(built):
     sgn = mid * rng.choice([-1.0, 1.0], mid.size)
     assert np.max(np.abs(probe(3, sgn) * sgn - 1.0)) < ulp4
     assert np.max(np.abs(probe(4, mid) * np.sqrt(mid) - 1.0)) < ulp4
+    zz = np.concatenate([10.0 ** rng.uniform(-12, 0.3, n), [1.0]])
+    assert np.max(np.abs(probe(8, zz) / zz ** 0.8 - 1.0)) < 3e-15     # zeta**0.8: two Newton steps, ~6 roundings
+    edge = probe(8, np.array([0.0, 1e-300]))
+    assert edge[0] == 0.0 and abs(edge[1] / 1e-240 - 1.0) < 1e-12      # outside the f32 seed range: exp(0.8*log x)
     # erf from a known exp(-x^2): absolute accuracy (the value only enters O(1) sums in cbl.f90:195-204)
     from scipy.special import erf as sp_erf
     xe = np.concatenate([rng.uniform(-7.0, 7.0, n), rng.uniform(-1e-3, 1e-3, 1000), [0.0, 6.5, -6.5, 30.0, -30.0]])
