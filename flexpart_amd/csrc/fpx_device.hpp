@@ -1712,9 +1712,9 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 
   // next sub-step length, advance.f90:504-510
   if (turbswitch)
-    ldt = (int)(m_min(m_min(T.tlw, h / m_max(K(2.) * m_abs(wp * T.sigw), K(1.e-5))), K(0.5) / m_abs(T.dsigwdz)) * V.ctl);
+    ldt = (int)(m_min(m_min(T.tlw, h * m_rcp(m_max(K(2.) * m_abs(wp * T.sigw), K(1.e-5)))), K(0.5) * m_rcp(m_abs(T.dsigwdz))) * V.ctl);
   else
-    ldt = (int)(m_min(T.tlw, h / m_max(K(2.) * m_abs(wp), K(1.e-5))) * V.ctl);
+    ldt = (int)(m_min(T.tlw, h * m_rcp(m_max(K(2.) * m_abs(wp), K(1.e-5)))) * V.ctl);
   ldt = max(ldt, V.mintime);
 
   R w = S.get(S_W);
