@@ -134,10 +134,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     dist = None
+    # Rehearsal on a box with fewer GPUs than ranks (our own 1-GPU checks of the N > 1 code path): the ranks
+    # share the devices and talk over gloo; no RCCL communicator is made.  The driver's runs have one GPU per rank.
+    ndev = torch.cuda.device_count()
+    rehearsal = world > 1 and ndev < world
+    if rehearsal:
+        local = local % max(ndev, 1)
+    tdev = "cpu" if rehearsal else "cuda"
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(local)
 
@@ -151,7 +161,7 @@ def main():
     eng.seed_particles(nper, seed=0x5EED + 7919 * rank, frac_pbl=frac_pbl)
     if args.sort_interval > 0:
         eng.sort()          # a release normally arrives ordered; the synthetic cloud is random
-    if args.config in (4, 5) and world > 1:
+    if args.config in (4, 5) and world > 1 and not rehearsal:
         from flexpart_amd import sharding
         uid = sharding.share_unique_id(dist, eng.comm_unique_id)
         eng.comm_init(uid, world, rank)
@@ -182,7 +192,7 @@ def main():
     for i in range(args.warmup, total_steps):
         do_step(i)
     if args.config in (4, 5):
-        grid, _ = eng.grids(allreduce=world > 1)     # D2H of the (summed) grid: part of the job
+        grid, _ = eng.grids(allreduce=world > 1 and not rehearsal)     # D2H of the (summed) grid: part of the job
     eng.sync()
     torch.cuda.synchronize()
     if dist:
@@ -191,7 +201,7 @@ def main():
     parts, launches = eng.kernel_times(reset=True)
     kms = sum(parts)
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -200,7 +210,7 @@ def main():
     cnt = eng.counters()
     nsteps_local = float(cnt["n_due"])
     if dist:
-        t = torch.tensor([nsteps_local], dtype=torch.float64, device="cuda")
+        t = torch.tensor([nsteps_local], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         psteps = float(t.item())
     else:
