@@ -105,7 +105,7 @@ FPX_DEV double m_sqrtp(double x) {
 // [sqrt(1/2), sqrt(2)) and the degree-7 series in s = f/(2+f) (the classical fdlibm scheme);
 // absolute error < 3e-16 * max(1, |log x|).  Zero, negative, subnormal, inf and NaN take the
 // library path.
-FPX_DEV float m_logp(float x) { return logf(x); }
+FPX_DEV float m_logp(float x) { return __logf(x); }   // v_log_f32 based, ~2 ulp
 FPX_DEV double m_logp(double x) {
   if (!(x >= 2.3e-308 && x <= 1.7e308)) return log(x);
   int e;
@@ -126,7 +126,7 @@ FPX_DEV double m_logp(double x) {
 // exp(x): k = rint(x/ln2), r = x - k*ln2 (two-part ln2), exp(r) by the degree-13 Taylor polynomial
 // split into even and odd halves (|r| <= 0.347: truncation 4e-18), scaled by ldexp.  Leaves out the
 // library's range screening: v_ldexp_f64 saturates to 0 / inf by itself, NaN propagates.
-FPX_DEV float m_expp(float x) { return expf(x); }
+FPX_DEV float m_expp(float x) { return __expf(x); }   // v_exp_f32 based, ~2 ulp
 FPX_DEV double m_expp(double x) {
   const double k = rint(x * 1.4426950408889634074);
   double r = fma(k, -6.93147180369123816490e-01, x);
@@ -187,7 +187,7 @@ FPX_DEV double m_powr(double x, double y) { return m_expp(y * m_logp(x)); }
 // x**0.8 for 0 <= x (hanna.f90:97, hanna_short.f90:80: tlw = 0.1*h/sigw*zeta**0.8): 0.8 = 4/5, so x**0.8 = x*r with
 // r = x**(-1/5) from an f32 seed and two Newton steps r <- r + r*(1 - x*r^5)/5 (the literal 0.8 differs from 4/5
 // by 4e-17: invisible).  19 instructions instead of log + exp (58).
-FPX_DEV float m_pow08(float x) { return x > 0.0f ? expf(0.8f * logf(x)) : 0.0f; }
+FPX_DEV float m_pow08(float x) { return x > 0.0f ? __expf(0.8f * __logf(x)) : 0.0f; }
 FPX_DEV double m_pow08(double x) {
   if (!(x > 1.0e-37 && x < 1.0e37)) return x > 0.0 ? exp(0.8 * log(x)) : (x == 0.0 ? 0.0 : pow(x, 0.8));
   double r = (double)__builtin_amdgcn_exp2f(__log2f((float)x) * -0.2f);
@@ -205,9 +205,9 @@ FPX_DEV double m_pow08(double x) {
 // factor exp(-+delta*ln x) with ln x from the f32 logarithm (delta = 3.3e-10, so its 1e-7 relative
 // error is invisible).  Arguments outside the f32 exponent range take the exp/log path.
 FPX_DEV void m_cuberoot_parts(float x, float &c, float &ic2) {
-  const float l = logf(x);
-  c = expf(0.333333333f * l);
-  ic2 = expf(-2.0f * 0.333333333f * l);
+  const float l = __logf(x);
+  c = __expf(0.333333333f * l);
+  ic2 = __expf(-2.0f * 0.333333333f * l);
 }
 FPX_DEV void m_cuberoot_parts(double x, double &c, double &ic2) {
   if (!(x > 1.0e-37 && x < 1.0e37)) {
