@@ -189,7 +189,7 @@ FPX_DEV double m_powr(double x, double y) { return m_expp(y * m_logp(x)); }
 // by 4e-17: invisible).  19 instructions instead of log + exp (58).
 FPX_DEV float m_pow08(float x) { return x > 0.0f ? __expf(0.8f * __logf(x)) : 0.0f; }
 FPX_DEV double m_pow08(double x) {
-  if (!(x > 1.0e-37 && x < 1.0e37)) return x > 0.0 ? exp(0.8 * log(x)) : (x == 0.0 ? 0.0 : pow(x, 0.8));
+  if (!(x > 1.0e-37 && x < 1.0e37)) return x > 0.0 ? m_expp(0.8 * m_logp(x)) : (x == 0.0 ? 0.0 : x * __builtin_nan(""));   // x < 0: NaN like pow
   double r = (double)__builtin_amdgcn_exp2f(__log2f((float)x) * -0.2f);
 #pragma unroll
   for (int it = 0; it < 2; it++) {
@@ -887,22 +887,26 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rho
 // bi-Gaussian pdf parameters shared by re_initialize_particle.f90:47-70 and initialize_cbl_vel.f90:46-73
 template <typename R>
 FPX_DEV void cbl_pdf(R zp, R wst, R h, R sigmaw, R ol, R &aluarw, R &sigmawa, R &sigmawb, R &wa, R &wb) {
+  // x**0.5 -> sqrt, x**1.5 -> x*sqrt(x), x**2., x**3. -> products (within an ulp of pow, and a tenth of its code:
+  // this cold path sits inside the Langevin kernel)
   const R costluar4 = K(0.66667), eps = K(0.000001);
   R z = zp / h;
   R transition = cbl_transition(h, ol);
   R w2 = sigmaw * sigmaw;
-  R w3 = ((K(1.2) * z * m_pow(K(1.) - z, K(1.5)) + eps) * (wst * wst * wst)) * transition;
-  R skew = w3 / m_pow(w2, K(1.5));
-  R skew2 = skew * skew;
+  const R omz = K(1.) - z;
+  R w3 = ((K(1.2) * z * (omz * m_sqrt(omz)) + eps) * (wst * wst * wst)) * transition;
   R radw2 = m_sqrt(w2);
-  R fluarw = costluar4 * m_pow(skew, K(0.333333333333333));
+  R skew = w3 / (w2 * radw2);
+  R skew2 = skew * skew;
+  R fluarw = costluar4 * m_powr(skew, K(0.333333333333333));
   R fluarw2 = fluarw * fluarw;
-  R rluarw = m_pow(K(1.) + fluarw2, K(3.)) * skew2 / (m_pow(K(3.) + fluarw2, K(2.)) * fluarw2);
-  R xluarw = m_pow(rluarw, K(0.5));
-  aluarw = K(0.5) * (K(1.) - xluarw / m_pow(K(4.) + rluarw, K(0.5)));
+  const R a1 = K(1.) + fluarw2, a3 = K(3.) + fluarw2;
+  R rluarw = (a1 * a1 * a1) * skew2 / ((a3 * a3) * fluarw2);
+  R xluarw = m_sqrt(rluarw);
+  aluarw = K(0.5) * (K(1.) - xluarw / m_sqrt(K(4.) + rluarw));
   R bluarw = K(1.) - aluarw;
-  sigmawa = radw2 * m_pow(bluarw / (aluarw * (K(1.) + fluarw2)), K(0.5));
-  sigmawb = radw2 * m_pow(aluarw / (bluarw * (K(1.) + fluarw2)), K(0.5));
+  sigmawa = radw2 * m_sqrt(bluarw / (aluarw * a1));
+  sigmawb = radw2 * m_sqrt(aluarw / (bluarw * a1));
   wa = fluarw * sigmawa;
   wb = fluarw * sigmawb;
 }
