@@ -1223,6 +1223,10 @@ struct Engine : EngineBase {
       S.nrand_adv = d_nrand_adv; S.nrand_init = d_nrand_init;
       S.cbl_dcas = d_dcas4; S.cbl_dcas1 = d_dcas14; S.cbl_dcas_d = d_dcas8; S.cbl_dcas1_d = d_dcas18;
     }
+    if (ev_used >= 64) {   // bound the pool in long runs that never ask for the timings: fold them into the totals
+      int rc = harvest_events();
+      if (rc) return rc;
+    }
     if (ev_used == ev_pool.size()) {
       StepEvents se;
       for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&se.e[i]));
@@ -1342,7 +1346,7 @@ struct Engine : EngineBase {
     return 0;
   }
 
-  int kernel_time(double *ms, long long *launches, int reset, double *parts) override {
+  int harvest_events() {
     HIPCHK(hipStreamSynchronize(stream));
     for (size_t i = 0; i < ev_used; i++) {
       float t = 0;
@@ -1355,6 +1359,11 @@ struct Engine : EngineBase {
       acc_launches++;
     }
     ev_used = 0;
+    return 0;
+  }
+  int kernel_time(double *ms, long long *launches, int reset, double *parts) override {
+    int rc = harvest_events();
+    if (rc) return rc;
     if (ms) *ms = acc_ms;
     if (launches) *launches = acc_launches;
     if (parts) for (int k = 0; k < 3; k++) parts[k] = acc_part_ms[k];

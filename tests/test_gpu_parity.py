@@ -493,6 +493,37 @@ def test_release_during_the_run_after_a_locality_sort(built):
         assert np.abs(got[k] - want[k]).max() <= 1e-9 * np.abs(want[k]).max(), k
 
 
+def test_long_run_stays_healthy(built):
+    """80 synchronisation steps (counter RNG, CBL + Hanna, locality re-sorts, the wind window moved as getfields()
+    would, more steps than the engine's internal timing-event pool holds): every particle stays finite, inside the
+    domain and on the loop's schedule; nothing is flagged as a bad position."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    n = 20000
+    sc = syn.small(n=n, nx=60, ny=40, nz=40, nsteps=80, ctl=5.0, ifine=4, cblflag=1)
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, sort_interval=5)
+    lsync, window = int(sc["lsynctime"]), 10800
+    for i in range(80):
+        itime = i * lsync
+        w0 = (itime // window) * window
+        eng.set_windtime((w0, w0 + window), (1, 2))
+        eng.step_async(itime)
+    eng.sync()
+    cnt = eng.counters()
+    got = eng.download()
+    eng.close()
+    alive = got["itra1"] != -999999999
+    assert cnt["n_bad_position"] == 0 and cnt["n_due"] >= 79 * alive.sum()
+    assert alive.sum() >= 0.9 * n and np.all(got["itra1"][alive] == 80 * lsync)
+    nx, ny = int(sc["grid"][0]), int(sc["grid"][1])
+    for k in ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws"):
+        assert np.all(np.isfinite(got[k][alive])), k
+    assert got["xtra1"][alive].min() >= 0 and got["xtra1"][alive].max() <= nx - 1
+    assert got["ytra1"][alive].min() >= 0 and got["ytra1"][alive].max() <= ny - 1
+    assert got["ztra1"][alive].min() >= 0 and got["ztra1"][alive].max() <= float(np.asarray(sc["height"])[-1])
+    # the cloud has spread: turbulence and wind did move the particles
+    assert np.abs(got["xtra1"][alive] - np.asarray(sc["xtra1"])[alive]).max() > 1.0
+
+
 def test_device_math_helpers_against_libm(built):
     """The 1-2 ulp fp64 helpers of the Langevin loop (fpx_device.hpp: m_expp, m_logp, m_sqrtp, m_rcp,
     m_rsqrt, m_cuberoot_parts) against numpy/libm.  Tolerance 4 ulp (8.9e-16 relative); for the
