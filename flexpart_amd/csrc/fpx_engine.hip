@@ -1007,6 +1007,12 @@ struct Engine : EngineBase {
     if (mt[0] == mt[1]) return fail(FPX_ERR_ARG, "set_windtime: memtime(1) == memtime(2)");
     V.memtime0 = mt[0]; V.memtime1 = mt[1]; V.m1 = mi[0] - 1; V.m2 = mi[1] - 1;
     V.lwindinterv = std::abs(mt[1] - mt[0]);
+    {   // mesoscale autocorrelation, advance.f90:728-729: the same two numbers for every particle of a step
+      const R r = sizeof(R) == 4 ? (R)expf(-2.0f * (float)std::abs(cfg.lsynctime) / (float)V.lwindinterv)
+                                 : (R)exp(-2.0 * (double)std::abs(cfg.lsynctime) / (double)V.lwindinterv);
+      V.meso_r = r;
+      V.meso_rs = sizeof(R) == 4 ? (R)sqrtf(1.0f - (float)r * (float)r) : (R)sqrt(1.0 - (double)r * (double)r);
+    }
     window_set = true;
     return 0;
   }
