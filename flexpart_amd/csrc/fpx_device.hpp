@@ -695,7 +695,7 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
 // the compiler does not forward the values through registers across the loop.
 // ---------------------------------------------------------------------------
 enum StashSlot {
-  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // the two cached profile levels
+  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // the two profile levels of the current pass
   S_DDX, S_DDY,                                                                 // position inside the cell (interpol_all.f90:57-58); p1..p4 follow from it
   S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
   S_ZT0, S_W,                                                                   // height at the start of the pass (u, v follow from it and the cached levels); interpol_mod w
@@ -1347,8 +1347,8 @@ FPX_DEV R interp_vdep(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const
 }
 
 // Two-level profile cache of the PBL loop: the reference caches every PBL level it has touched
-// (indzindicator, interpol_mod.f90:16); the values are pure functions of the level, so recomputing on a
-// miss gives the same numbers with two levels kept per lane (in the LDS stash, cache_fetch_stash below).
+// (indzindicator, interpol_mod.f90:16); the values are pure functions of the level, so recomputing them
+// gives the same numbers (fetch_levels_stash below).
 // The 8-point sigmas (usigprof..) are only read when the interval ends (advance.f90:604-606): they are
 // evaluated then, for the final level pair (level_pair_sigma).
 
@@ -1530,7 +1530,7 @@ struct LoopCtx {                // register-resident state of a lane across pass
   int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
   R h;
   int itimec, nrand;
-  int ilo;                      // level index of the cached *lo profile level (-1 = empty), see cache_fetch_stash
+  int ilo;                      // level index of the *lo profile level in the stash (the last pass's pair)
 };
 
 template <typename R>
@@ -1543,27 +1543,20 @@ FPX_DEV Cell<R> stash_cell(const LoopCtx<R> &L, const Stash<R> &S) {
   return C;
 }
 
-// cache_fetch with the two levels in the stash
+// The two profile levels around the particle, computed every pass and parked in the stash
+// (interpol_all.f90:135-240 / interpol_misslev.f90).  The reference caches every level it has touched
+// (indzindicator); a per-lane cache of the last level pair (re-using one level when the particle moved to the
+// neighbouring pair) was built first and measured slower than recomputing: a lane crosses a level in ~20 % of
+// its passes, so nearly every pass of a wave ran the miss path anyway, with a fifth of its lanes active.
 template <typename R>
-FPX_DEV void cache_fetch_stash(const View<R> &V, const Fld<R> &F, const TimeW<R> &W, LoopCtx<R> &L, const Stash<R> &S, int indz) {
-  if (L.ilo == indz) return;
+FPX_DEV void fetch_levels_stash(const View<R> &V, const Fld<R> &F, const TimeW<R> &W, LoopCtx<R> &L, const Stash<R> &S, int indz) {
   const Cell<R> C = stash_cell(L, S);
   Level<R> Lv;
-  if (L.ilo == indz + 1) {            // moved one level down
-    S.put(S_UHI, S.get(S_ULO)); S.put(S_VHI, S.get(S_VLO)); S.put(S_WHI, S.get(S_WLO)); S.put(S_RHOHI, S.get(S_RHOLO)); S.put(S_RGHI, S.get(S_RGLO));
-    level_profile<R, true, true, false>(V, F, C, W, indz, Lv);
-    S.put(S_ULO, Lv.u); S.put(S_VLO, Lv.v); S.put(S_WLO, Lv.w); S.put(S_RHOLO, Lv.rho); S.put(S_RGLO, Lv.rhograd);
-  } else if (L.ilo == indz - 1) {     // moved one level up
-    S.put(S_ULO, S.get(S_UHI)); S.put(S_VLO, S.get(S_VHI)); S.put(S_WLO, S.get(S_WHI)); S.put(S_RHOLO, S.get(S_RHOHI)); S.put(S_RGLO, S.get(S_RGHI));
-    level_profile<R, true, true, false>(V, F, C, W, indz + 1, Lv);
-    S.put(S_UHI, Lv.u); S.put(S_VHI, Lv.v); S.put(S_WHI, Lv.w); S.put(S_RHOHI, Lv.rho); S.put(S_RGHI, Lv.rhograd);
-  } else {
-    level_profile<R, true, true, false>(V, F, C, W, indz, Lv);
-    S.put(S_ULO, Lv.u); S.put(S_VLO, Lv.v); S.put(S_WLO, Lv.w); S.put(S_RHOLO, Lv.rho); S.put(S_RGLO, Lv.rhograd);
-    level_profile<R, true, true, false>(V, F, C, W, indz + 1, Lv);
-    S.put(S_UHI, Lv.u); S.put(S_VHI, Lv.v); S.put(S_WHI, Lv.w); S.put(S_RHOHI, Lv.rho); S.put(S_RGHI, Lv.rhograd);
-  }
-  L.ilo = indz;
+  level_profile<R, true, true, false>(V, F, C, W, indz, Lv);
+  S.put(S_ULO, Lv.u); S.put(S_VLO, Lv.v); S.put(S_WLO, Lv.w); S.put(S_RHOLO, Lv.rho); S.put(S_RGLO, Lv.rhograd);
+  level_profile<R, true, true, false>(V, F, C, W, indz + 1, Lv);
+  S.put(S_UHI, Lv.u); S.put(S_VHI, Lv.v); S.put(S_WHI, Lv.w); S.put(S_RHOHI, Lv.rho); S.put(S_RGHI, Lv.rhograd);
+  L.ilo = indz;   // pass_wind() needs the level pair of the last pass
 }
 
 // interpol_mod u, v of the pass that just ended (advance.f90:342-346), from the pass's start height
@@ -1611,7 +1604,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const int indz = find_level(hgt, V.nz, zt);
   const int indzp = indz + 1;
   indz_last = indz;
-  cache_fetch_stash(V, F, W, A, S, indz);
+  fetch_levels_stash(V, F, W, A, S, indz);
 
   // advance.f90:342-350
   const R dz = m_rcp(hgt[indzp - 1] - hgt[indz - 1]);
