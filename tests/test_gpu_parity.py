@@ -190,6 +190,37 @@ def test_counter_rng_is_order_independent(built):
     assert not np.array_equal(ra[-1]["ztra1"], rc[-1]["ztra1"])
 
 
+@pytest.mark.parametrize("cblflag", [0, 1])
+def test_counter_rng_matches_table_rng_statistically(built, cblflag):
+    """The counter generator (Philox4x32-10 + clipped Box-Muller) replaces the reference's 1e6-entry Gaussian
+    table and its shared ran3 stream; individual trajectories differ by construction, the ensemble must not.
+    Same cloud, all three modes: the table modes (the reference's numbers: serial stream / per-particle start
+    index) bound the sampling noise, the counter mode has to sit inside it -- mean and spread of the
+    displacement and of the turbulent velocities after four synchronisation steps."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX, RNG_TABLE_SEQ, RNG_TABLE_COUNTER
+    n = 120000
+    sc = syn.small(n=n, nx=60, ny=40, nz=40, nsteps=4, ctl=5.0, ifine=4, cblflag=cblflag, frac_pbl=0.7)
+    x0, y0 = np.asarray(sc["xtra1"]), np.asarray(sc["ytra1"])
+    stats = {}
+    for name, mode, seed in (("table_seq", RNG_TABLE_SEQ, 1), ("table_ctr", RNG_TABLE_COUNTER, 2), ("philox", RNG_PHILOX, 3)):
+        eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=mode, seed=seed)
+        r = eng.run()[-1]
+        eng.close()
+        alive = r["itra1"] != -999999999
+        assert alive.mean() > 0.99
+        dx, dy = (r["xtra1"] - x0)[alive], (r["ytra1"] - y0)[alive]
+        dx = (dx + 29.5) % 59.0 - 29.5                      # cyclic domain
+        q = dict(dx=dx, dy=dy, z=r["ztra1"][alive], up=r["uap"][alive], wp=r["uzp"][alive])
+        stats[name] = {k: (v.mean(), v.std(), np.abs(v).mean()) for k, v in q.items()}
+    for k in ("dx", "dy", "z", "up", "wp"):
+        a, b, c = stats["table_seq"][k], stats["table_ctr"][k], stats["philox"][k]
+        for j in range(3):
+            scale = max(abs(a[1]), 1e-30)                   # the spread of the quantity sets the scale
+            noise = 5.0 * scale / np.sqrt(n)                # 5 standard errors of a mean over n particles
+            noise = max(noise, 3.0 * abs(a[j] - b[j]))      # and never tighter than table-vs-table
+            assert abs(c[j] - a[j]) <= noise + 0.01 * scale, (k, j, a, b, c)
+
+
 def test_fortran_host_drop_in_nests(built):
     """Same drop-in check for the nested-grid reference variant (par_mod_meteoswiss.f90: nxmax=721,
     maxnests=1): the shim hands the allocatable 5-D nest arrays uun, vvn, ... to the engine."""
