@@ -8,7 +8,9 @@
  *     advance()     (src/advance.f90:4)      one lsynctime of motion
  *     epilogue      (src/timemanager.f90:630-708: reschedule / terminate,
  *                    decay and dry-deposition mass split)
- * plus the concentration sampling loop conccalc() (src/conccalc.f90:4).
+ * plus the concentration sampling loop conccalc() (src/conccalc.f90:4: mother and nested
+ * output grid, receptor points), the dry-deposition kernels and the wet-deposition loop
+ * wetdepo() (src/wetdepo.f90:4) with their nested-grid variants.
  *
  * The reference has no FFI for this path: state is passed implicitly through
  * Fortran modules (com_mod, par_mod, interpol_mod, hanna_mod).  Every entry
@@ -56,7 +58,8 @@ typedef enum {
  * in particle order (advance.f90:153, initialize.f90:68).  TABLE_COUNTER keeps
  * the table but draws the start index from a counter-based generator keyed on
  * (seed, particle id, step) -- order-independent, hence shardable.  PHILOX
- * replaces the table by Philox4x32-10 + clipped Box-Muller per draw. */
+ * replaces the table by Philox4x32-10 keyed on (seed, particle id, step, draw index / 4):
+ * one call gives four clipped Box-Muller normals. */
 typedef enum { FPX_RNG_TABLE_SEQ = 0, FPX_RNG_TABLE_COUNTER = 1, FPX_RNG_PHILOX = 2 } fpx_rng_mode;
 
 typedef struct {
