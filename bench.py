@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: 1e8 cfg 3, 1e7 cfg 2)")
     ap.add_argument("--real", type=int, default=8, choices=(4, 8), help="compute real bytes")
     ap.add_argument("--rng", default="philox", choices=("philox", "table_counter"))
-    ap.add_argument("--sort-interval", type=int, default=8, help="locality re-sort every k steps (0: never)")
+    ap.add_argument("--sort-interval", type=int, default=4, help="locality re-sort every k steps (0: never); 4 puts one re-sort inside the default timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=None, help="particles in the CPU baseline sample")
     return ap.parse_args()
