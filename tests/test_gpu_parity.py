@@ -63,7 +63,7 @@ def test_fp64_matches_oracle(built, name, kw):
         assert_close(g, w, 1e-9, 1e-7)
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "sampling", "backward", "backward_cbl", "limited_area"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "sampling", "backward", "backward_cbl", "limited_area", "three_species"])
 def test_fp64_matches_oracle_golden_scenarios(built, name):
     """The scenarios the golden fixtures were made on: polar caps through the stereographic maps
     (cmapf subset), an aerosol species with settling + dry deposition + decay, CBL, Hanna."""
@@ -76,7 +76,7 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
         assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * scale
 
 
-@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "sampling", "backward", "backward_cbl", "limited_area"])
+@pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "sampling", "backward", "backward_cbl", "limited_area", "three_species"])
 def test_fp64_against_reference_fixtures(built, name):
     """HIP path directly against the outputs of the unmodified reference (tests/golden, flang r8
     build).  Only particles touched by the two order-dependent leaks of the serial code (DESIGN.md
@@ -443,6 +443,23 @@ def test_wet_deposition_on_nested_grid(built):
     with pytest.raises(RuntimeError):
         eng.run(2)        # wetdepo runs from the second step on (timemanager.f90:164-169)
     eng.close()
+
+
+def test_many_levels_and_three_species(built):
+    """Upper end of the sizes: 200 model levels (the level search and the dynamic LDS layout of the Langevin kernel
+    scale with nz) and three species of which two deposit and two decay -- the ragged species loops of the
+    epilogue (timemanager.f90:642-696) and of the dry-deposition probability (advance.f90:582-599)."""
+    sc = syn.small(n=3000, nx=40, ny=24, nz=200, nsteps=3, ctl=5.0, ifine=4, nspec=3)
+    sc.update(lsettling=1, drydep=1, drydepspec=np.array([1, 0, 1], np.int32), density=np.array([2000.0, 0.0, 1500.0]),
+              dquer=np.array([8.0, 0.0, 3.0]), vsetaver=np.array([-0.004, 0.0, -0.001]), cunningham=np.array([1.02, 1.0, 1.05]),
+              decay=np.array([1.0e-6, 0.0, 2.0e-6]), xmass=np.array([1.0, 2.0, 0.5]))
+    got, want = run_pair(sc, "r8")
+    for g, w in zip(got, want):
+        assert_close(g, w, 1e-9, 1e-7)
+        scale = np.abs(w["xmass1"]).max()
+        assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * scale
+    m0 = np.asarray(sc["xmass1"]).reshape(3, -1)
+    assert (want[-1]["xmass1"][0] < m0[0]).any() and np.array_equal(want[-1]["xmass1"][1], m0[1])   # species 2 neither deposits nor decays
 
 
 def test_edge_cases_empty_dead_and_not_due(built):

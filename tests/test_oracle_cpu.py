@@ -19,6 +19,14 @@ def _aerosol(sc):
     return sc
 
 
+def _three_species(sc):
+    # three species, two of them depositing (dry) and decaying, one passive: the ragged species loops
+    sc.update(lsettling=1, drydep=1, drydepspec=np.array([1, 0, 1], np.int32), density=np.array([2000.0, 0.0, 1500.0]),
+              dquer=np.array([8.0, 0.0, 3.0]), vsetaver=np.array([-0.004, 0.0, -0.001]),
+              cunningham=np.array([1.02, 1.0, 1.05]), decay=np.array([1.0e-6, 0.0, 2.0e-6]), xmass=np.array([1.0, 2.0, 0.5]))
+    return sc
+
+
 def _sampling(sc):
     # aerosol + output grid (conccalc, drydepokernel) + wet deposition (wetdepo)
     _aerosol(sc)
@@ -61,6 +69,7 @@ CASES = {
     "sampling_nest": dict(ctl=5.0, ifine=4, post=_sampling_nest),
     "polar": dict(ctl=5.0, ifine=4, polar=True, lat_margin_cells=0.6, grid=(72, 46, 36)),
     "aerosol": dict(ctl=5.0, ifine=4, post=_aerosol),
+    "three_species": dict(ctl=5.0, ifine=4, nspec=3, post=_three_species),
     "hanna1_method0": dict(ctl=-5.0),
     "limited_area": dict(ctl=5.0, ifine=4, global_grid=False, lat_margin_cells=0.02),   # particles leave the domain (nstop=3)
     "backward": dict(ctl=5.0, ifine=4, ldirect=-1),
