@@ -107,7 +107,7 @@ FPX_DEV double m_sqrtp(double x) {
 // library path.
 FPX_DEV float m_logp(float x) { return __logf(x); }   // v_log_f32 based, ~2 ulp
 FPX_DEV double m_logp(double x) {
-  if (!(x >= 2.3e-308 && x <= 1.7e308)) return log(x);
+  if (__builtin_expect(!(x >= 2.3e-308 && x <= 1.7e308), 0)) return log(x);
   int e;
   double m = frexp(x, &e);
   const bool lo = m < 0.70710678118654752;
@@ -211,7 +211,7 @@ FPX_DEV double m_coslat(double x) {
 // by 4e-17: invisible).  19 instructions instead of log + exp (58).
 FPX_DEV float m_pow08(float x) { return x > 0.0f ? __expf(0.8f * __logf(x)) : 0.0f; }
 FPX_DEV double m_pow08(double x) {
-  if (!(x > 1.0e-37 && x < 1.0e37)) return x > 0.0 ? m_expp(0.8 * m_logp(x)) : (x == 0.0 ? 0.0 : x * __builtin_nan(""));   // x < 0: NaN like pow
+  if (__builtin_expect(!(x > 1.0e-37 && x < 1.0e37), 0)) return x > 0.0 ? m_expp(0.8 * m_logp(x)) : (x == 0.0 ? 0.0 : x * __builtin_nan(""));   // x < 0: NaN like pow
   double r = (double)__builtin_amdgcn_exp2f(__log2f((float)x) * -0.2f);
 #pragma unroll
   for (int it = 0; it < 2; it++) {
@@ -232,7 +232,7 @@ FPX_DEV void m_cuberoot_parts(float x, float &c, float &ic2) {
   ic2 = __expf(-2.0f * 0.333333333f * l);
 }
 FPX_DEV void m_cuberoot_parts(double x, double &c, double &ic2) {
-  if (!(x > 1.0e-37 && x < 1.0e37)) {
+  if (__builtin_expect(!(x > 1.0e-37 && x < 1.0e37), 0)) {
     const double l = log(x);
     c = exp(0.333333333 * l);
     ic2 = exp(-2.0 * 0.333333333 * l);
@@ -1676,7 +1676,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             cbl(V.ldirect, wp, zt, S.get(S_WST), HI.ih, S.get(S_RHOAUX), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
-            if (flagrein == 1) {
+            if (__builtin_expect(flagrein == 1, 0)) {
               re_initialize_particle(V.ldirect, G, zt, S.get(S_WST), h, T.sigw, old_wp_buf, nrand, S.get(S_OL));
               wp = old_wp_buf;
               delz = wp * dtf;
@@ -1689,7 +1689,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             wp = (wp + ath * dtf + bth) * (R)icbt;
             delz = wp * dtf;
             // del_test=(1.-wp)/wp is NaN exactly when wp is NaN or infinite (advance.f90:440-441)
-            if (!isfinite(wp)) {
+            if (__builtin_expect(!isfinite(wp), 0)) {
               nrand = nrand + 1;
               wp = T.sigw * G.at(nrand);
               delz = wp * dtf;
@@ -1712,7 +1712,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     }
 
     // reflection at the ground / mixing height, advance.f90:476-491
-    if (m_abs(delz) > h) delz = m_fmod(delz, h);
+    if (__builtin_expect(m_abs(delz) > h, 0)) delz = m_fmod(delz, h);
     if (delz < -zt) {
       icbt = -1;
       zt = -zt - delz;
