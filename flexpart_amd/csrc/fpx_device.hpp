@@ -571,6 +571,7 @@ FPX_DEV int find_level(const R *hgt, int nz, R zt) {
 template <typename R>
 struct Turb {
   R ust, wst, ol, h, zeta, sigu, sigv, tlu, tlv, tlw, sigw, dsigwdz, dsigw2dz;
+  R isigw;   // 1/sigw, kept by hanna_short for the Langevin step that follows (PBL loop only)
 };
 
 template <typename R>
@@ -748,7 +749,10 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     T.sigw = K(1.3) * m_expp(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
     T.sigw = T.sigw * S.get(S_UST) + K(1.e-2);
-    T.tlw = K(0.5) * z * m_rcp(T.sigw * (K(1.) + K(1.5e-3) * corr));
+    const R qn = K(1.) + K(1.5e-3) * corr;
+    const R in2 = m_rcp(T.sigw * qn);
+    T.isigw = in2 * qn;
+    T.tlw = K(0.5) * z * in2;
   } else if (I.regime == 1) {
     // zeta**0.66666 and max(zeta,1.e-3)**(-.33333) from one logarithm and one exponential:
     // 0.66666 = 1 - 0.33333 - 1.e-5, so zeta**0.66666 = zeta * zeta**(-.33333) * exp(-1.e-5*log(zeta)),
@@ -774,6 +778,7 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     const R q = low ? K(0.55) - K(0.38) * m_abs(z * I.iaux) : K(1.);
     const R i2 = m_rcp(T.sigw * q);
     const R isig = i2 * q;
+    T.isigw = isig;
     T.dsigwdz = K(0.5) * isig * I.ih * (K(-1.4) * ust2 + wst2 * (K(0.8) * zm13 - K(1.8) * z23));
     if (low) T.tlw = K(0.1) * z * i2;
     else if (T.zeta < K(0.1)) T.tlw = K(0.59) * z * isig;
@@ -782,7 +787,8 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     const R ust = S.get(S_UST);
     T.sigw = K(1.e-2) + K(1.3) * ust * (K(1.) - T.zeta);
     T.dsigwdz = K(-1.3) * ust * I.ih;
-    T.tlw = K(0.1) * T.h * m_rcp(T.sigw) * m_pow08(T.zeta);
+    T.isigw = m_rcp(T.sigw);
+    T.tlw = K(0.1) * T.h * T.isigw * m_pow08(T.zeta);
   }
   T.tlu = m_max(K(10.), T.tlu);
   T.tlv = m_max(K(10.), T.tlv);
@@ -818,7 +824,7 @@ FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
 // (the straightforward form has 20 divisions, 7 square roots, 1 log and 4 exp).
 // `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
 template <typename R>
-FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rhograd/rhoa */, R sigmaw, R dsigmawdz, R tlw, R transition,
+FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rhograd/rhoa */, R sigmaw, R irw /* 1/sigmaw */, R dsigmawdz, R tlw, R transition,
                  R &ath, R &bth, int &flagrein) {
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
   const R timedir = (R)ldirect;
@@ -831,7 +837,6 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rho
   const R wst3 = wst * wst * wst;
   const R w3 = (K(1.2) * z * omz15 + eps) * wst3 * transition;
   const R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * ih * transition;
-  const R irw = m_rcp(sigmaw);                 // w2**(-0.5)
   const R irw2 = irw * irw, irw3 = irw2 * irw;
   const R skew = w3 * irw3;
   const R skew2 = skew * skew;
@@ -1628,6 +1633,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 
   if (turbswitch) hanna(T, zt); else hanna1(T, zt);
   S.put(S_UST, T.ust);   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
+  T.isigw = m_rcp(T.sigw);
 
   // counter mode: a pass starts on a block boundary of the generator, so that all lanes of a wave
   // renew their block in the same fine sub-step (the draws of a pass are indexed alike in every lane)
@@ -1673,7 +1679,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             int flagrein = 0;
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
-            cbl(V.ldirect, wp, zt, S.get(S_WST), HI.ih, S.get(S_RHOAUX), T.sigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
+            cbl(V.ldirect, wp, zt, S.get(S_WST), HI.ih, S.get(S_RHOAUX), T.sigw, T.isigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
             if (__builtin_expect(flagrein == 1, 0)) {
@@ -1684,7 +1690,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             }
           } else {
             nrand = nrand + 1;
-            R ath = -wp * m_rcp(T.tlw) + T.sigw * T.dsigwdz + wp * wp * m_rcp(T.sigw) * T.dsigwdz + T.sigw * T.sigw * S.get(S_RHOAUX);
+            R ath = -wp * m_rcp(T.tlw) + T.sigw * T.dsigwdz + wp * wp * T.isigw * T.dsigwdz + T.sigw * T.sigw * S.get(S_RHOAUX);
             R bth = T.sigw * G.at(nrand) * m_sqrtp(K(2.) * dtftlw);
             wp = (wp + ath * dtf + bth) * (R)icbt;
             delz = wp * dtf;
