@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libflexpart_amd.so")
+# FPX_LIBRARY: another build of the same library (A/B measurements of compile-time variants)
+LIB_PATH = os.environ.get("FPX_LIBRARY") or os.path.join(HERE, "csrc", "libflexpart_amd.so")
 
 FPX_MAXSPEC = 5
 DEAD = -999999999

@@ -447,3 +447,50 @@ def add_nest(sc, ix0=None, jy0=None, ix1=None, jy1=None, factor=2):
         sc[kn] = f[k] * (1.1 if k in ("uu", "vv") else 1.0)   # not the mother's values: a wrong grid choice shows
     sc["par_nxmax"] = 721        # the reference variant with nests is built from par_mod_meteoswiss.f90
     return sc
+
+
+# --------------------------------------------------------------------------
+# model-level input of verttransform_ecmwf
+# --------------------------------------------------------------------------
+def model_levels(nx=361, ny=181, nz=138, *, global_grid=True, polar=False, phase=0):
+    """ECMWF-shaped hybrid-level input as readwind_ecmwf leaves it: level 1 = surface,
+    pressure of level k = akz[k] + bkz[k]*ps, nuvz = nwz = nz (gridcheck_ecmwf.f90 adds the
+    surface level and sets nz = nuvz).  Arrays are compact [nz][ny][nx]; `phase` shifts the
+    pattern (a second time slot).  Mountains (low ps) give columns whose top lies below the
+    reference column's, which exercises the copy-the-top-level branch of the transform."""
+    per = nx - 1
+    i = np.arange(nx, dtype=np.int64)[None, None, :] + int(phase)
+    j = np.arange(ny, dtype=np.int64)[None, :, None]
+    k = np.arange(nz, dtype=np.int64)[:, None, None]
+    s = np.arange(ny, dtype=np.float64)[None, :, None] / float(ny - 1)
+    clat = 4.0 * s * (1.0 - s)
+    # hybrid coefficients: eta from 1 (surface) to exp(-7) (about 90 Pa)
+    eta = np.exp(-7.0 * np.arange(nz, dtype=np.float64) / float(nz - 1))
+    bk = eta ** 1.5
+    bk[0] = 1.0
+    ak = 101325.0 * (eta - bk)
+    ak[0] = 0.0
+    # surface pressure: a few 'mountain ranges' down to about 620 hPa, most columns above 1000 hPa
+    mount = np.maximum(0.0, _wave(2 * i[0] + 3 * j[0], per)) * np.maximum(0.0, _wave(3 * j[0] + 7, 2 * (ny - 1)))
+    ps = 101500.0 + 800.0 * _wave(i[0] + 2 * j[0], per) - 39000.0 * mount * mount
+    lnp = np.log((ak[:, None, None] + bk[:, None, None] * ps[None]) / 101325.0)       # <= ~0
+    zapprox = -7400.0 * lnp
+    tth = np.maximum(288.0 - 0.0065 * zapprox, 216.0) + 3.0 * _wave(i + j + 2 * k, per) + 10.0 * (clat - 0.5)
+    qvh = 0.012 * np.exp(-zapprox / 2500.0) * (0.6 + 0.4 * _wave(2 * i + j, per))
+    uuh = 25.0 * clat * (1.0 + 0.3 * _wave(k, nz)) + 6.0 * _wave(3 * i, per) + 0.0 * j
+    vvh = 6.0 * _wave(2 * i + 0 * j, per) * clat + 2.0 * _wave(k + 3 * j, 40)
+    wwh = 0.4 * _wave(i, per) * _wave(2 * j + 0 * i, ny - 1) * np.exp(lnp)            # eta-dot * dp/deta, Pa/s
+    pvh = 1.0e-6 * (1.0 + 0.5 * _wave(i + k, per)) * np.exp(zapprox / 12000.0) * (2.0 * s - 1.0)
+    tt2 = tth[0] + 0.5 * _wave(3 * i[0] + j[0], per)
+    td2 = tt2 - 3.0 - 2.0 * (1.0 + _wave(i[0] + 5 * j[0], per))
+    out = dict(akz=ak, bkz=bk, aknew=ak.copy(), bknew=bk.copy(), ps=ps, tt2=tt2, td2=td2,
+               tth=tth, qvh=qvh, uuh=uuh, vvh=vvh, pvh=pvh, wwh=wwh)
+    if xcyclic_ok(nx) and global_grid:
+        for key in ("ps", "tt2", "td2", "tth", "qvh", "uuh", "vvh", "pvh", "wwh"):
+            out[key][..., nx - 1] = out[key][..., 0]
+    dx = 360.0 / (nx - 1) if global_grid else 1.0
+    dy = 180.0 / (ny - 1) if global_grid else 1.0
+    out["grid"] = np.array([nx, ny, nz], np.int32)
+    out["geom"] = np.array([dx, dy, -180.0 if global_grid else -20.0, -90.0 if global_grid else 20.0], np.float64)
+    out["globalflags"] = np.array([int(global_grid), int(global_grid and polar), int(global_grid and polar)], np.int32)
+    return out

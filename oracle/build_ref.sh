@@ -54,9 +54,27 @@ build_one() {
   echo "build_ref: built $OUT/flexref_$kind"
 }
 
+# verttransform_ecmwf behind its own small driver oracle/ref_vt_driver.f90 -> vtref_rK;
+# reuses the module objects build_one left in obj_K
+build_vt() {
+  local kind="$1"; shift
+  local flags="$*"
+  local obj="$OUT/obj_$kind"
+  ( cd "$obj"
+    for s in verttransform_ecmwf ew qvsat; do
+      [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
+    done
+    "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_vt_driver.f90" -o ref_vt_driver.o
+    "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o verttransform_ecmwf.o ew.o qvsat.o par_mod.o com_mod.o cmapf_mod.o -o "$OUT/vtref_$kind"
+  )
+  echo "build_ref: built $OUT/vtref_$kind"
+}
+
 mkdir -p "$OUT"
 build_one r4 par_mod.f90
 build_one r8 par_mod.f90 -fdefault-real-8
+build_vt r4
+build_vt r8 -fdefault-real-8
 # nested-grid variant: the stock par_mod.f90 has maxnests=0; the reference's own
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path
 build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS

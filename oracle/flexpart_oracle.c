@@ -2031,6 +2031,7 @@ void orc_make_polemaps(orc_ctx *c) {
   orc_stlmbr(c->northpolemap, K(90.), K(0.));
   orc_stcm2p(c->northpolemap, K(0.), K(0.), switchnorth, K(0.), sizenorth, sizenorth, switchnorth, K(180.));
 }
+void orc_set_dy_for_polemaps(orc_ctx *c, double dy) { c->dy = (real)dy; }
 void orc_get_polemaps(orc_ctx *c, double *north, double *south) {
   int i;
   for (i = 0; i < 9; i++) { north[i] = (double)c->northpolemap[i]; south[i] = (double)c->southpolemap[i]; }

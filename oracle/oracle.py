@@ -16,12 +16,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build(force=False):
     """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
-    src = os.path.join(HERE, "flexpart_oracle.c")
-    for kind, real in (("r4", "float"), ("r8", "double")):
-        out = os.path.join(HERE, f"liboracle_{kind}.so")
-        if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
-                                   f"-DORC_REAL={real}", src, "-o", out, "-lm"])
+    for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle")):
+        src = os.path.join(HERE, stem + ".c")
+        for kind, real in (("r4", "float"), ("r8", "double")):
+            out = os.path.join(HERE, f"{lib}_{kind}.so")
+            if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+                subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
+                                       f"-DORC_REAL={real}", src, "-o", out, "-lm"])
 
 
 def _f64(a):
@@ -267,3 +268,83 @@ def compare(a, b, keys=("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "v
     for k in ("idt", "itra1", "cbt"):
         rep[k] = int(np.count_nonzero(np.asarray(a[k]) != np.asarray(b[k])))
     return rep
+
+
+# --------------------------------------------------------------------------
+# verttransform_ecmwf (oracle/verttransform_oracle.c)
+# --------------------------------------------------------------------------
+VT_OUT = ("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol")
+
+
+class _VtoArgs(C.Structure):
+    _dp = C.POINTER(C.c_double)
+    _fields_ = ([("nx", C.c_int), ("ny", C.c_int), ("nz", C.c_int),
+                 ("dx", C.c_double), ("dy", C.c_double), ("xlon0", C.c_double), ("ylat0", C.c_double),
+                 ("nglobal", C.c_int), ("sglobal", C.c_int),
+                 ("northpolemap", C.c_double * 9), ("southpolemap", C.c_double * 9),
+                 ("switchnorthg", C.c_double), ("switchsouthg", C.c_double), ("init", C.c_int)]
+                + [(k, C.POINTER(C.c_double)) for k in ("akz", "bkz", "aknew", "bknew", "ps", "tt2", "td2",
+                                                         "tth", "qvh", "uuh", "vvh", "pvh", "wwh", "height")]
+                + [("nmixz", C.POINTER(C.c_int))]
+                + [(k, C.POINTER(C.c_double)) for k in VT_OUT])
+
+
+def polemaps(dx, dy, ylat0, kind="r8"):
+    """northpolemap, southpolemap, switchnorthg, switchsouthg as gridcheck_ecmwf.f90:341-366 sets them
+    (through the restated stlmbr/stcm2p of flexpart_oracle.c)."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"liboracle_{kind}.so"))
+    lib.orc_create.restype = C.c_void_p
+    h = C.c_void_p(lib.orc_create())
+    lib.orc_set_dy_for_polemaps.argtypes = [C.c_void_p, C.c_double]
+    lib.orc_set_dy_for_polemaps(h, float(dy))
+    lib.orc_make_polemaps.argtypes = [C.c_void_p]
+    lib.orc_make_polemaps(h)
+    n = np.zeros(9); s = np.zeros(9)
+    dp = C.POINTER(C.c_double)
+    lib.orc_get_polemaps.argtypes = [C.c_void_p, dp, dp]
+    lib.orc_get_polemaps(h, n.ctypes.data_as(dp), s.ctypes.data_as(dp))
+    rt = np.float32 if kind == "r4" else np.float64
+    swn = float((rt(75.0) - rt(ylat0)) / rt(dy))
+    sws = float((rt(-75.0) - rt(ylat0)) / rt(dy))
+    return n, s, swn, sws
+
+
+def vt_oracle(m, kind="r8", height=None):
+    """Run the C restatement of verttransform_ecmwf on a synthetic.model_levels() dict.
+    height=None: first call (computes height and nmixz); else the given z levels are used."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"libvtoracle_{kind}.so"))
+    nx, ny, nz = (int(v) for v in m["grid"])
+    dx, dy, xlon0, ylat0 = (float(v) for v in m["geom"])
+    a = _VtoArgs()
+    a.nx, a.ny, a.nz = nx, ny, nz
+    a.dx, a.dy, a.xlon0, a.ylat0 = dx, dy, xlon0, ylat0
+    a.nglobal, a.sglobal = int(m["globalflags"][1]), int(m["globalflags"][2])
+    a.switchnorthg = a.switchsouthg = 999999.0
+    if a.nglobal or a.sglobal:
+        n, s, swn, sws = polemaps(dx, dy, ylat0, kind)
+        for i in range(9):
+            a.northpolemap[i] = n[i]; a.southpolemap[i] = s[i]
+        if a.nglobal: a.switchnorthg = swn
+        if a.sglobal: a.switchsouthg = sws
+    dp = C.POINTER(C.c_double)
+    keep = {}
+    for k in ("akz", "bkz", "aknew", "bknew", "ps", "tt2", "td2", "tth", "qvh", "uuh", "vvh", "pvh", "wwh"):
+        keep[k] = _f64(m[k])
+        setattr(a, k, keep[k].ctypes.data_as(dp))
+    h = np.zeros(nz) if height is None else _f64(height).copy()
+    a.init = 1 if height is None else 0
+    a.height = h.ctypes.data_as(dp)
+    nmixz = C.c_int(0)
+    a.nmixz = C.pointer(nmixz)
+    out = {}
+    for k in VT_OUT:
+        out[k] = np.zeros((nz, ny, nx))
+        setattr(a, k, out[k].ctypes.data_as(dp))
+    rc = lib.vto_verttransform(C.byref(a))
+    if rc != 0:
+        raise RuntimeError(f"vto_verttransform failed ({rc})")
+    out["height"] = h
+    out["nmixz"] = nmixz.value
+    return out

@@ -1,0 +1,195 @@
+! TEST INFRASTRUCTURE ONLY -- never linked into or called by the product path.
+!
+! ref_vt_driver: drives the *unmodified* reference routine verttransform_ecmwf
+! (/root/reference/src/verttransform_ecmwf.f90, compiled where it lies by
+! oracle/build_ref.sh) on model-level input read from a scenario file and dumps the
+! z-level fields it produces (SURVEY section 8 f1: eta -> z, rho, drhodz, polar winds).
+! This file is our own code: it contains no reference source, only calls into it and
+! assignments to its module variables.
+!
+! Usage:  vtref_rK scenario.bin out.bin
+! Record format as oracle/ref_driver.f90: {name*16, dtype i4 (1=i32, 2=f64), count i8, payload}.
+! 3-D input arrays travel compact, (nx,ny,nlev) x fastest, as f64.
+
+module vt_io
+  implicit none
+  integer, parameter :: uin=31, uout=32
+contains
+  subroutine put_i(name, a, n)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: n
+    integer, intent(in) :: a(n)
+    character(len=16) :: nm
+    nm = name
+    write(uout) nm, 1_4, int(n,8), a(1:n)
+  end subroutine put_i
+  subroutine put_d(name, a, n)
+    character(len=*), intent(in) :: name
+    integer, intent(in) :: n
+    real(kind=8), intent(in) :: a(n)
+    character(len=16) :: nm
+    nm = name
+    write(uout) nm, 2_4, int(n,8), a(1:n)
+  end subroutine put_d
+end module vt_io
+
+program vtref
+  use par_mod
+  use com_mod
+  use cmapf_mod
+  use vt_io
+  implicit none
+
+  character(len=512) :: fscen, fout
+  character(len=16) :: name
+  integer(kind=4) :: dtype
+  integer(kind=8) :: cnt
+  integer, allocatable :: ibuf(:)
+  real(kind=8), allocatable :: dbuf(:), tmp(:)
+  real, allocatable :: uuh(:,:,:), vvh(:,:,:), pvh(:,:,:), wwh(:,:,:)
+  integer :: ios, n, gnx, gny, gnz, ncalls, icall
+  real :: sizenorth, sizesouth
+  integer(kind=8) :: c0, c1, crate
+
+  call get_command_argument(1, fscen)
+  call get_command_argument(2, fout)
+
+  allocate(uuh(0:nxmax-1,0:nymax-1,nuvzmax), vvh(0:nxmax-1,0:nymax-1,nuvzmax))
+  allocate(pvh(0:nxmax-1,0:nymax-1,nuvzmax), wwh(0:nxmax-1,0:nymax-1,nwzmax))
+  uuh=0.; vvh=0.; pvh=0.; wwh=0.
+  xglobal=.false.; nglobal=.false.; sglobal=.false.
+  switchnorthg=999999.; switchsouthg=999999.
+  readclouds=.false.; sumclouds=.false.; numbnests=0
+  lsprec=0.; convprec=0.; ncalls=1
+  gnx=0; gny=0; gnz=0
+
+  open(uin, file=trim(fscen), access='stream', form='unformatted', status='old')
+  do
+    read(uin, iostat=ios) name, dtype, cnt
+    if (ios .ne. 0) exit
+    if (trim(name) .eq. 'END') exit
+    n = int(cnt)
+    if (dtype .eq. 1) then
+      if (allocated(ibuf)) deallocate(ibuf)
+      allocate(ibuf(n)); read(uin) ibuf
+    else
+      if (allocated(dbuf)) deallocate(dbuf)
+      allocate(dbuf(n)); read(uin) dbuf
+    end if
+    select case (trim(name))
+    case ('grid')      ! nx ny nz (= nuvz = nwz)
+      gnx=ibuf(1); gny=ibuf(2); gnz=ibuf(3)
+      if (gnx.gt.nxmax .or. gny.gt.nymax .or. gnz.gt.nzmax) stop 'grid too large'
+      nx=gnx; ny=gny; nz=gnz; nuvz=gnz; nwz=gnz; nxfield=gnx
+      nxmin1=nx-1; nymin1=ny-1
+    case ('geom')      ! dx dy xlon0 ylat0
+      dx=dbuf(1); dy=dbuf(2); xlon0=dbuf(3); ylat0=dbuf(4)
+      dxconst=180./(dx*r_earth*pi)      ! as gridcheck_ecmwf.f90:311-312
+      dyconst=180./(dy*r_earth*pi)
+    case ('globalflags') ! xglobal nglobal sglobal
+      xglobal=(ibuf(1).ne.0); nglobal=(ibuf(2).ne.0); sglobal=(ibuf(3).ne.0)
+    case ('ncalls');  ncalls=ibuf(1)
+    case ('akz');     akz(1:n)=dbuf(1:n)
+    case ('bkz');     bkz(1:n)=dbuf(1:n)
+    case ('aknew');   aknew(1:n)=dbuf(1:n)
+    case ('bknew');   bknew(1:n)=dbuf(1:n)
+    case ('ps');      call get2(ps(:,:,1,1))
+    case ('tt2');     call get2(tt2(:,:,1,1))
+    case ('td2');     call get2(td2(:,:,1,1))
+    case ('tth');     call get3(tth(:,:,:,1), nuvzmax)
+    case ('qvh');     call get3(qvh(:,:,:,1), nuvzmax)
+    case ('uuh');     call get3(uuh, nuvzmax)
+    case ('vvh');     call get3(vvh, nuvzmax)
+    case ('pvh');     call get3(pvh, nuvzmax)
+    case ('wwh');     call get3(wwh, nwzmax)
+    case default
+      write(*,*) 'ref_vt_driver: unknown record ', trim(name)
+      stop 1
+    end select
+  end do
+  close(uin)
+
+  ! Polar stereographic maps as the reference sets them up
+  ! (call sequence of /root/reference/src/gridcheck_ecmwf.f90:341-366).
+  if (sglobal) then
+    sizesouth=6.*(switchsouth+90.)/dy
+    call stlmbr(southpolemap,-90.,0.)
+    call stcm2p(southpolemap,0.,0.,switchsouth,0.,sizesouth,sizesouth,switchsouth,180.)
+    switchsouthg=(switchsouth-ylat0)/dy
+  end if
+  if (nglobal) then
+    sizenorth=6.*(90.-switchnorth)/dy
+    call stlmbr(northpolemap,90.,0.)
+    call stcm2p(northpolemap,0.,0.,switchnorth,0.,sizenorth,sizenorth,switchnorth,180.)
+    switchnorthg=(switchnorth-ylat0)/dy
+  end if
+
+  call system_clock(c0, crate)
+  do icall=1,ncalls
+    call verttransform_ecmwf(1,uuh,vvh,wwh,pvh)
+  end do
+  call system_clock(c1)
+
+  open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')
+  allocate(tmp(nz))
+  tmp(1:nz)=height(1:nz)
+  call put_d('height', tmp, nz)
+  call put_i('nmixz', (/nmixz/), 1)
+  call put_d('timing', (/real(c1-c0,kind=8)/real(crate,kind=8)/real(ncalls,kind=8)/), 1)
+  call put_d('polemaps', (/real(northpolemap,kind=8), real(southpolemap,kind=8), real(switchnorthg,kind=8), real(switchsouthg,kind=8)/), 20)
+  call dump3('uu', uu(:,:,:,1))
+  call dump3('vv', vv(:,:,:,1))
+  call dump3('ww', ww(:,:,:,1))
+  call dump3('tt', tt(:,:,:,1))
+  call dump3('qv', qv(:,:,:,1))
+  call dump3('pv', pv(:,:,:,1))
+  call dump3('rho', rho(:,:,:,1))
+  call dump3('drhodz', drhodz(:,:,:,1))
+  if (nglobal .or. sglobal) then
+    call dump3('uupol', uupol(:,:,:,1))
+    call dump3('vvpol', vvpol(:,:,:,1))
+  end if
+  write(uout) 'END             ', 1_4, 0_8
+  close(uout)
+
+contains
+  subroutine get2(a)
+    real, intent(inout) :: a(0:nxmax-1,0:nymax-1)
+    integer :: ix, jy
+    a=0.
+    do jy=0,gny-1
+      do ix=0,gnx-1
+        a(ix,jy)=dbuf(1+ix+gnx*jy)
+      end do
+    end do
+  end subroutine get2
+  subroutine get3(a, nl)
+    integer, intent(in) :: nl
+    real, intent(inout) :: a(0:nxmax-1,0:nymax-1,nl)
+    integer :: ix, jy, k
+    a=0.
+    do k=1,gnz
+      do jy=0,gny-1
+        do ix=0,gnx-1
+          a(ix,jy,k)=dbuf(1+ix+gnx*(jy+gny*(k-1)))
+        end do
+      end do
+    end do
+  end subroutine get3
+  subroutine dump3(nm, a)
+    character(len=*), intent(in) :: nm
+    real, intent(in) :: a(0:nxmax-1,0:nymax-1,nzmax)
+    real(kind=8), allocatable :: t(:)
+    integer :: ix, jy, k
+    allocate(t(gnx*gny*gnz))
+    do k=1,gnz
+      do jy=0,gny-1
+        do ix=0,gnx-1
+          t(1+ix+gnx*(jy+gny*(k-1)))=a(ix,jy,k)
+        end do
+      end do
+    end do
+    call put_d(nm, t, gnx*gny*gnz)
+    deallocate(t)
+  end subroutine dump3
+end program vtref

@@ -109,3 +109,44 @@ def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=F
         else:
             cur[name] = a
     return out
+
+
+# --------------------------------------------------------------------------
+# verttransform_ecmwf through oracle/_ref/vtref_rK (oracle/ref_vt_driver.f90)
+# --------------------------------------------------------------------------
+_VT_ORDER = ["grid", "geom", "globalflags", "ncalls", "akz", "bkz", "aknew", "bknew", "ps", "tt2", "td2",
+             "tth", "qvh", "uuh", "vvh", "pvh", "wwh"]
+
+
+def have_vt_ref(kind="r8"):
+    return os.access(os.path.join(HERE, "_ref", f"vtref_{kind}"), os.X_OK)
+
+
+def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1):
+    """The unmodified verttransform_ecmwf on a synthetic.model_levels() dict -> dict of fields [nz][ny][nx]."""
+    os.makedirs(workdir, exist_ok=True)
+    fs = os.path.join(workdir, f"vt_{os.getpid()}.scen")
+    fo = os.path.join(workdir, f"vt_{os.getpid()}.out")
+    mm = dict(m, ncalls=ncalls)
+    with open(fs, "wb") as fh:
+        for name in _VT_ORDER:
+            v = mm[name]
+            if name in ("grid", "globalflags", "ncalls"):
+                a = np.ascontiguousarray(np.asarray(v, dtype=np.int32).ravel()); code = 1
+            else:
+                a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel()); code = 2
+            fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
+            fh.write(a.tobytes())
+        fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
+    exe = os.path.join(HERE, "_ref", f"vtref_{kind}")
+    res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {fo}"], capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"reference verttransform driver failed: {res.stdout}\n{res.stderr}")
+    nx, ny, nz = (int(v) for v in m["grid"])
+    out = {}
+    for name, a in read_records(fo):
+        out[name] = a.reshape(nz, ny, nx) if a.size == nx * ny * nz else a
+    os.remove(fs)
+    os.remove(fo)
+    out["nmixz"] = int(out["nmixz"][0])
+    return out
