@@ -60,6 +60,18 @@ class FpxFields(C.Structure):
                  "hmix", "ustar", "wstar", "oli", "tropopause", "vdep")]
 
 
+class FpxModelLevels(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("uuh", "vvh", "pvh", "wwh", "tth", "qvh", "ps", "tt2", "td2", "akz", "bkz", "aknew", "bknew")] + \
+               [("nuvz", C.c_int32), ("nwz", C.c_int32), ("init", C.c_int32), ("reserved", C.c_int32)]
+
+
+class FpxFieldsOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol", "height")] + \
+               [("nmixz", C.POINTER(C.c_int32))]
+
+
 class FpxParticles(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws",
@@ -118,6 +130,7 @@ SYMBOLS = [
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
+    "fpx_verttransform_ecmwf", "fpx_verttransform_time",
 ]
 
 _lib = None
@@ -149,6 +162,8 @@ def load():
     lib.fpx_polar_maps.argtypes = [C.c_int32, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.fpx_set_height.argtypes = [vp, vp, C.c_int32]
     lib.fpx_upload_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxFields)]
+    lib.fpx_verttransform_ecmwf.argtypes = [vp, C.c_int32, C.POINTER(FpxModelLevels), C.POINTER(FpxFields), C.POINTER(FpxFieldsOut)]
+    lib.fpx_verttransform_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.fpx_set_windtime.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.fpx_rng_fill_table.argtypes = [vp]
     lib.fpx_rng_set_table.argtypes = [vp, vp, C.c_int32]

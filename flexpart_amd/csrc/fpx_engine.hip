@@ -18,6 +18,7 @@
 
 #include "../../include/flexpart_amd.h"
 #include "fpx_device.hpp"
+#include "fpx_verttransform.hpp"
 #include "fpx_rng_host.hpp"
 
 namespace fpx {
@@ -696,6 +697,7 @@ struct EngineBase {
   virtual ~EngineBase() {}
   virtual int set_height(const void *h, int n) = 0;
   virtual int upload_fields(int slot, const fpx_fields *f) = 0;
+  virtual int verttransform(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) = 0;
   virtual int set_windtime(const int32_t mt[2], const int32_t mi[2]) = 0;
   virtual int rng_fill_table() = 0;
   virtual int rng_set_table(const void *t, int n) = 0;
@@ -727,6 +729,7 @@ struct EngineBase {
   virtual int receptors_init(int n, const void *x, const void *y, const void *area) = 0;
   virtual int get_receptors(void *creceptor, int ld, int allreduce, int clear) = 0;
   virtual void *stream_ptr() = 0;
+  virtual double vt_ms() = 0;
 };
 
 template <typename R>
@@ -920,6 +923,8 @@ struct Engine : EngineBase {
       if (!(tmp[k] > tmp[k - 1])) return fail(FPX_ERR_ARG, "set_height: heights must increase strictly");
     HIPCHK(hipMemcpyAsync((void *)V.height, tmp.data(), n * sizeof(R), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
+    height_host.resize(n);
+    for (int k = 0; k < n; k++) height_host[k] = cfg.host_real_bytes == 4 ? (double)((const float *)h)[k] : ((const double *)h)[k];
     height_set = true;
     return 0;
   }
@@ -999,6 +1004,185 @@ struct Engine : EngineBase {
     HIPCHK(hipStreamSynchronize(stream));
     slot_loaded[s] = true;
     return 0;
+  }
+
+
+  // ---- verttransform_ecmwf on the device --------------------------------
+  // Model-level input -> z-level fields, computed in the host's real kind H in the host's own
+  // array layout on the device, then repacked like an upload (the 3-D fields never cross PCIe
+  // as z-level arrays unless the host asks for them back through `out`).
+  std::vector<double> height_host;     // height(nz) in the host's real kind, widened
+  void *vt_dev[32] = {};               // device arrays of the transform, allocated on first use
+  bool vt_ready = false;
+
+  template <typename H>
+  static H vt_ew_host(H x) {           // ew.f90:4-29
+    H y = (H)373.16 / x;
+    H a = (H)-7.90298 * (y - (H)1.);
+    a = a + ((H)5.02808 * (H)0.43429 * std::log(y));
+    H c = ((H)1. - ((H)1. / y)) * (H)11.344;
+    c = (H)-1. + std::pow((H)10., c);
+    c = (H)-1.3816 * c / (H)1.e7;
+    H d = ((H)1. - y) * (H)3.49149;
+    d = (H)-1. + std::pow((H)10., d);
+    d = (H)8.1328 * d / (H)1.e3;
+    y = a + c + d;
+    return (H)101324.6 * std::pow((H)10., y);
+  }
+
+  // first call: z levels from the first column with ps > 1000 hPa, verttransform_ecmwf.f90:134-187
+  template <typename H>
+  int vt_init_height(const fpx_model_levels *m, std::vector<H> &hgt, int &nmixz) {
+    const H *ps = (const H *)m->ps, *tt2 = (const H *)m->tt2, *td2 = (const H *)m->td2;
+    const H *tth = (const H *)m->tth, *qvh = (const H *)m->qvh, *akz = (const H *)m->akz, *bkz = (const H *)m->bkz;
+    const size_t sx = (size_t)cfg.nxmax, sxy = (size_t)cfg.nxmax * cfg.nymax;
+    long long col = -1;
+    for (int jy = 0; jy < cfg.ny && col < 0; jy++)
+      for (int ix = 0; ix < cfg.nx; ix++)
+        if (ps[ix + sx * jy] > (H)100000.) { col = (long long)(ix + sx * jy); break; }
+    if (col < 0) return fail(FPX_ERR_ARG, "verttransform: no column with ps > 100000 Pa to build the z levels from");
+    const H konst = (H)287.05 / (H)9.81;
+    H tvold = tt2[col] * ((H)1. + (H)0.378 * vt_ew_host<H>(td2[col]) / ps[col]);
+    H pold = ps[col];
+    hgt.assign(cfg.nz, (H)0);
+    for (int kz = 2; kz <= m->nuvz; kz++) {
+      const H pint = akz[kz - 1] + bkz[kz - 1] * ps[col];
+      const H tv = tth[col + sxy * (kz - 1)] * ((H)1. + (H)0.608 * qvh[col + sxy * (kz - 1)]);
+      if (std::abs(tv - tvold) > (H)0.2) hgt[kz - 1] = hgt[kz - 2] + konst * std::log(pold / pint) * (tv - tvold) / std::log(tv / tvold);
+      else hgt[kz - 1] = hgt[kz - 2] + konst * std::log(pold / pint) * tv;
+      tvold = tv;
+      pold = pint;
+    }
+    nmixz = cfg.nz;
+    for (int kz = 1; kz <= cfg.nz; kz++)
+      if (hgt[kz - 1] > (H)4500.) { nmixz = kz; break; }   // hmixmax, par_mod.f90:77
+    return 0;
+  }
+
+  template <typename H>
+  int verttransform_t(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) {
+    const int nz = cfg.nz;
+    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax, n3 = n2 * nz;
+    int rc;
+    enum { UUH, VVH, PVH, WWH, TTH, QVH, PS, TT2, TD2, AKZ, BKZ, AKN, BKN, HGT,
+           UU, VV, WW, TT, QV, PV, RHO, DRHO, UPOL, VPOL, UVZ, WZ, RHOH, PINM, NBUF };
+    if (!vt_ready) {
+      for (int i = 0; i < NBUF; i++) {
+        const size_t n = (i >= PS && i <= TD2) ? n2 : (i >= AKZ && i <= HGT) ? (size_t)nz : n3;
+        H *q = nullptr;
+        if ((rc = dalloc(&q, n))) return rc;
+        HIPCHK(hipMemsetAsync(q, 0, n * sizeof(H), stream));
+        vt_dev[i] = q;
+      }
+      vt_ready = true;
+    }
+    auto D = [&](int i) { return (H *)vt_dev[i]; };
+    // z levels: derived on the first call (or on request), else the ones the host has set
+    if (m->init || !height_set) {
+      std::vector<H> hgt;
+      int nmixz = 0;
+      if ((rc = vt_init_height<H>(m, hgt, nmixz))) return rc;
+      if ((rc = set_height(hgt.data(), nz))) return rc;
+      V.nmixz = nmixz;
+      cfg.nmixz = nmixz;
+    }
+    {
+      std::vector<H> hh(nz);
+      for (int k = 0; k < nz; k++) hh[k] = (H)height_host[k];
+      HIPCHK(hipMemcpyAsync(D(HGT), hh.data(), nz * sizeof(H), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    const void *src[13] = {m->uuh, m->vvh, m->pvh, m->wwh, m->tth, m->qvh, m->ps, m->tt2, m->td2, m->akz, m->bkz, m->aknew, m->bknew};
+    for (int i = 0; i < 13; i++) {
+      const size_t n = (i >= PS && i <= TD2) ? n2 : (i >= AKZ) ? (size_t)nz : n3;
+      HIPCHK(hipMemcpyAsync(D(i), src[i], n * sizeof(H), hipMemcpyHostToDevice, stream));
+    }
+    vt::Geo<H> G;
+    G.nx = cfg.nx; G.ny = cfg.ny; G.nz = nz; G.nuvz = m->nuvz; G.nwz = m->nwz; G.nxmax = cfg.nxmax; G.nymax = cfg.nymax;
+    G.dx = (H)cfg.dx; G.dy = (H)cfg.dy; G.xlon0 = (H)cfg.xlon0; G.ylat0 = (H)cfg.ylat0;
+    {   // gridcheck_ecmwf.f90:311-312, in the host's real kind
+      const H pi = (H)3.14159265, r_earth = (H)6.371e6;
+      G.dxconst = (H)180. / (G.dx * r_earth * pi);
+      G.dyconst = (H)180. / (G.dy * r_earth * pi);
+    }
+    G.nglobal = cfg.nglobal; G.sglobal = cfg.sglobal;
+    G.switchnorthg = (H)cfg.switchnorthg; G.switchsouthg = (H)cfg.switchsouthg;
+    for (int i = 0; i < 9; i++) { G.northpolemap[i] = (H)cfg.northpolemap[i]; G.southpolemap[i] = (H)cfg.southpolemap[i]; }
+    vt::In<H> I{D(UUH), D(VVH), D(PVH), D(WWH), D(TTH), D(QVH), D(PS), D(TT2), D(TD2), D(AKZ), D(BKZ), D(AKN), D(BKN), D(HGT)};
+    vt::Out<H> O{D(UU), D(VV), D(WW), D(TT), D(QV), D(PV), D(RHO), D(DRHO), D(UPOL), D(VPOL), D(UVZ), D(WZ), D(RHOH), D(PINM)};
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, stream));
+    const int ncol = cfg.nx * cfg.ny, nb = (ncol + 255) / 256;
+    const size_t sm = (size_t)nz * sizeof(H);
+    vt::k_vt_levels<H><<<nb, 256, 0, stream>>>(G, I, O);
+    vt::k_vt_interp<H><<<nb, 256, sm, stream>>>(G, I, O);
+    if (cfg.nx > 2 && cfg.ny > 2) vt::k_vt_slope<H><<<((cfg.nx - 2) * (cfg.ny - 2) + 255) / 256, 256, sm, stream>>>(G, I, O);
+    if (cfg.nglobal) {
+      const int jy0 = std::max(0, (int)G.switchnorthg - 2), jy1 = cfg.ny - 1;
+      if (jy1 >= jy0) vt::k_vt_polar<H><<<dim3((cfg.nx + 255) / 256, jy1 - jy0 + 1, nz), 256, 0, stream>>>(G, O, jy0, jy1, 0);
+      vt::k_vt_polerow<H><<<(nz + 63) / 64, 64, 0, stream>>>(G, O, 0);
+    }
+    if (cfg.sglobal) {
+      const int jy0 = 0, jy1 = std::min(cfg.ny - 1, (int)G.switchsouthg + 3);
+      if (jy1 >= jy0) vt::k_vt_polar<H><<<dim3((cfg.nx + 255) / 256, jy1 - jy0 + 1, nz), 256, 0, stream>>>(G, O, jy0, jy1, 1);
+      vt::k_vt_polerow<H><<<(nz + 63) / 64, 64, 0, stream>>>(G, O, 1);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, stream));
+    // repack into the gather layout, as upload_fields does from the staged host arrays
+    const int s = slot - 1;
+    auto pk = [&](const H *in, const R *outp, int stride, int off) -> int {
+      dim3 grid((cfg.nx + 31) / 32, (nz + 31) / 32, cfg.ny), block(32, 8);
+      k_pack3<H, R><<<grid, block, 0, stream>>>(in, (R *)outp, cfg.nx, cfg.ny, nz, cfg.nxmax, cfg.nymax, stride, off);
+      HIPCHK(hipGetLastError());
+      return 0;
+    };
+    if ((rc = pk(D(UU), V.w3, 6, s * 3 + 0)) || (rc = pk(D(VV), V.w3, 6, s * 3 + 1)) || (rc = pk(D(WW), V.w3, 6, s * 3 + 2))) return rc;
+    if (V.w3pol)
+      if ((rc = pk(D(UPOL), V.w3pol, 6, s * 3 + 0)) || (rc = pk(D(VPOL), V.w3pol, 6, s * 3 + 1)) || (rc = pk(D(WW), V.w3pol, 6, s * 3 + 2))) return rc;
+    if ((rc = pk(D(RHO), V.r2, 4, s * 2 + 0)) || (rc = pk(D(DRHO), V.r2, 4, s * 2 + 1))) return rc;
+    if (slot == 1 && V.rhott)
+      if ((rc = pk(D(RHO), V.rhott, 2, 0)) || (rc = pk(D(TT), V.rhott, 2, 1))) return rc;
+    if (wet_on && Wp.ttw) { if ((rc = pk(D(TT), Wp.ttw, 2, s))) return rc; }
+    // the 2-D fields calcpar leaves on the host
+    if ((rc = p2(sfc->ustar, V.sfc, 8, s * 4 + 0)) || (rc = p2(sfc->wstar, V.sfc, 8, s * 4 + 1)) ||
+        (rc = p2(sfc->oli, V.sfc, 8, s * 4 + 2)) || (rc = p2(sfc->hmix, V.sfc, 8, s * 4 + 3))) return rc;
+    if (slot == 1) { if ((rc = p2(sfc->tropopause, V.tropo, 1, 0))) return rc; }
+    if (V.vdep) {
+      const size_t plane = n2 * cfg.host_real_bytes;
+      for (int ks = 0; ks < cfg.nspec; ks++)
+        if ((rc = p2((const char *)sfc->vdep + plane * ks, V.vdep, 2 * cfg.nspec, s * cfg.nspec + ks))) return rc;
+    }
+    k_hcell<R><<<(cfg.nx * cfg.ny + kBlock - 1) / kBlock, kBlock, 0, stream>>>(V.sfc, (R *)V.hcell, cfg.nx, cfg.ny);
+    HIPCHK(hipGetLastError());
+    if (out) {   // z-level arrays the host still wants (partoutput, convection, cloud diagnostics ...)
+      void *dst[10] = {out->uu, out->vv, out->ww, out->tt, out->qv, out->pv, out->rho, out->drhodz, out->uupol, out->vvpol};
+      for (int i = 0; i < 10; i++)
+        if (dst[i]) HIPCHK(hipMemcpyAsync(dst[i], D(UU + i), n3 * sizeof(H), hipMemcpyDeviceToHost, stream));
+      if (out->height) for (int k = 0; k < nz; k++) ((H *)out->height)[k] = (H)height_host[k];
+      if (out->nmixz) *out->nmixz = V.nmixz;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    vt_last_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    slot_loaded[s] = true;
+    return 0;
+  }
+  double vt_last_ms = 0;
+  double vt_ms() override { return vt_last_ms; }
+
+  int verttransform(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) override {
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "verttransform: slot must be 1 or 2");
+    if (!m || !m->uuh || !m->vvh || !m->pvh || !m->wwh || !m->tth || !m->qvh || !m->ps || !m->tt2 || !m->td2 || !m->akz || !m->bkz || !m->aknew || !m->bknew)
+      return fail(FPX_ERR_ARG, "verttransform: uuh, vvh, pvh, wwh, tth, qvh, ps, tt2, td2, akz, bkz, aknew, bknew are required");
+    if (m->nuvz != cfg.nz || m->nwz != cfg.nz) return fail(FPX_ERR_ARG, "verttransform: nuvz = nwz = nz expected (gridcheck_ecmwf.f90 sets them equal)");
+    if (cfg.nz < 3) return fail(FPX_ERR_ARG, "verttransform: nz >= 3");
+    if (!sfc || !sfc->hmix || !sfc->ustar || !sfc->wstar || !sfc->oli || !sfc->tropopause) return fail(FPX_ERR_ARG, "verttransform: the 2-D fields hmix, ustar, wstar, oli, tropopause are required");
+    if (cfg.drydep && !sfc->vdep) return fail(FPX_ERR_ARG, "verttransform: vdep required with DRYDEP");
+    return cfg.host_real_bytes == 4 ? verttransform_t<float>(slot, m, sfc, out) : verttransform_t<double>(slot, m, sfc, out);
   }
 
   int set_windtime(const int32_t mt[2], const int32_t mi[2]) override {
@@ -1900,6 +2084,8 @@ int fpx_destroy(fpx_handle h) {
 
 int fpx_set_height(fpx_handle h, const void *height, int32_t n) { FPX_GUARD(h); return h->impl->set_height(height, n); }
 int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f) { FPX_GUARD(h); return h->impl->upload_fields(slot, f); }
+int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) { FPX_GUARD(h); return h->impl->verttransform(slot, m, sfc, out); }
+int fpx_verttransform_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_verttransform_time: null"); *ms = h->impl->vt_ms(); return FPX_OK; }
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]) { FPX_GUARD(h); return h->impl->set_windtime(memtime, memind); }
 int fpx_rng_fill_table(fpx_handle h) { FPX_GUARD(h); return h->impl->rng_fill_table(); }
 int fpx_rng_set_table(fpx_handle h, const void *t, int32_t n) { FPX_GUARD(h); return h->impl->rng_set_table(t, n); }

@@ -49,7 +49,7 @@ class Engine:
         cfg.compute_real_bytes = compute_real_bytes
         cfg.host_real_bytes = host_real_bytes
         cfg.max_particles = int(max_particles or max(n, 1))
-        cfg.nx, cfg.ny, cfg.nz, cfg.nmixz = nx, ny, nz, int(sc["nmixz"])
+        cfg.nx, cfg.ny, cfg.nz, cfg.nmixz = nx, ny, nz, int(sc.get("nmixz", nz))   # without height/nmixz: set by verttransform(init)
         cfg.nxmax, cfg.nymax, cfg.nzmax = self.nxmax, self.nymax, self.nzmax
         cfg.dx, cfg.dy, cfg.xlon0, cfg.ylat0 = dx, dy, xlon0, ylat0
         cfg.xglobal, cfg.nglobal, cfg.sglobal = xg, ng, sg
@@ -91,8 +91,9 @@ class Engine:
         self.cfg = cfg
         self.h = C.c_void_p()
         check(self.lib.fpx_create(C.byref(self.h), C.byref(cfg)), "fpx_create")
-        hgt = np.ascontiguousarray(np.asarray(sc["height"]).astype(rt))
-        check(self.lib.fpx_set_height(self.h, _vp(hgt), nz), "fpx_set_height")
+        if "height" in sc:
+            hgt = np.ascontiguousarray(np.asarray(sc["height"]).astype(rt))
+            check(self.lib.fpx_set_height(self.h, _vp(hgt), nz), "fpx_set_height")
         self.itime = int(sc.get("itime0", 0))
         self.lsynctime = int(sc["lsynctime"])
         self.n = 0
@@ -141,6 +142,58 @@ class Engine:
                 f.vdep = v.ctypes.data
             check(self.lib.fpx_upload_fields(self.h, m + 1, C.byref(f)), "fpx_upload_fields")
         self.set_windtime(sc["memtime"], sc["memind"])
+
+    def verttransform(self, slot, m, sfc, *, init=False, want=("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol")):
+        """fpx_verttransform_ecmwf: m = synthetic.model_levels() dict (compact [nz][ny][nx] arrays),
+        sfc = dict of compact 2-D fields (hmix, ustar, wstar, oli, tropopause[, vdep]) for this slot.
+        Returns the z-level arrays asked for (compact), height and nmixz."""
+        from ._lib import FpxModelLevels, FpxFieldsOut
+        rt = self.hreal
+        keep = {}
+        ml = FpxModelLevels()
+        for k in ("uuh", "vvh", "pvh", "wwh", "tth", "qvh"):
+            a = np.zeros((self.nzmax, self.nymax, self.nxmax), rt)
+            a[: self.nz, : self.ny, : self.nx] = m[k]
+            keep[k] = a
+            setattr(ml, k, a.ctypes.data)
+        for k in ("ps", "tt2", "td2"):
+            a = np.zeros((self.nymax, self.nxmax), rt)
+            a[: self.ny, : self.nx] = m[k]
+            keep[k] = a
+            setattr(ml, k, a.ctypes.data)
+        for k in ("akz", "bkz", "aknew", "bknew"):
+            keep[k] = np.ascontiguousarray(np.asarray(m[k]).astype(rt))
+            setattr(ml, k, keep[k].ctypes.data)
+        ml.nuvz = ml.nwz = self.nz
+        ml.init = int(init)
+        f = FpxFields()
+        for k in ("hmix", "ustar", "wstar", "oli", "tropopause"):
+            a = np.zeros((self.nymax, self.nxmax), rt)
+            a[: self.ny, : self.nx] = sfc[k]
+            keep["s" + k] = a
+            setattr(f, k, a.ctypes.data)
+        if "vdep" in sfc:
+            v = np.zeros((self.nspec, self.nymax, self.nxmax), rt)
+            v[:, : self.ny, : self.nx] = sfc["vdep"]
+            keep["svdep"] = v
+            f.vdep = v.ctypes.data
+        o = FpxFieldsOut()
+        res = {}
+        for k in want:
+            res[k] = np.zeros((self.nzmax, self.nymax, self.nxmax), rt)
+            setattr(o, k, res[k].ctypes.data)
+        hgt = np.zeros(self.nz, rt)
+        o.height = hgt.ctypes.data
+        nmixz = C.c_int32(0)
+        o.nmixz = C.pointer(nmixz)
+        check(self.lib.fpx_verttransform_ecmwf(self.h, int(slot), C.byref(ml), C.byref(f), C.byref(o)), "fpx_verttransform_ecmwf")
+        out = {k: v[: self.nz, : self.ny, : self.nx].astype(np.float64) for k, v in res.items()}
+        out["height"] = hgt.astype(np.float64)
+        out["nmixz"] = int(nmixz.value)
+        ms = C.c_double(0)
+        check(self.lib.fpx_verttransform_time(self.h, C.byref(ms)), "fpx_verttransform_time")
+        out["device_ms"] = ms.value
+        return out
 
     def upload_nests_from_scenario(self, sc):
         """One nested grid: geometry as gridcheck_nests.f90:362-378 derives it, fields uun, vvn, ..."""

@@ -464,8 +464,8 @@ def model_levels(nx=361, ny=181, nz=138, *, global_grid=True, polar=False, phase
     k = np.arange(nz, dtype=np.int64)[:, None, None]
     s = np.arange(ny, dtype=np.float64)[None, :, None] / float(ny - 1)
     clat = 4.0 * s * (1.0 - s)
-    # hybrid coefficients: eta from 1 (surface) to exp(-7) (about 90 Pa)
-    eta = np.exp(-7.0 * np.arange(nz, dtype=np.float64) / float(nz - 1))
+    # hybrid coefficients: eta from 1 (surface) to exp(-7) (about 90 Pa), layers thinnest at the ground
+    eta = np.exp(-7.0 * (np.arange(nz, dtype=np.float64) / float(nz - 1)) ** 1.6)
     bk = eta ** 1.5
     bk[0] = 1.0
     ak = 101325.0 * (eta - bk)

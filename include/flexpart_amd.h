@@ -153,6 +153,40 @@ int fpx_set_height(fpx_handle h, const void *height, int32_t n);
  * it into the device layout.  Replaces the implicit use of com_mod's field
  * arrays after getfields() (getfields.f90:81-225). */
 int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f);
+/* ---- verttransform_ecmwf on the device (SURVEY section 8 f, item 1) -------------------------
+ * Replaces `call verttransform_ecmwf(memind(2),uuh,vvh,wwh,pvh)` (getfields.f90:129,164,180; the
+ * routine: verttransform_ecmwf.f90:55-590) followed by fpx_upload_fields: the model-level arrays
+ * readwind_ecmwf has filled go to the device, the eta -> z transform (uvzlev/wzlev, pinmconv,
+ * vertical interpolation of u,v,T,q,pv,rho, w conversion, drhodz, eta-slope correction, polar
+ * stereographic winds) runs there and its result is repacked straight into the gather layout.
+ * The cloud diagnostics of verttransform_ecmwf.f90:604-880 and `prs` are not computed (not read
+ * by the particle path; a host that needs them keeps its own loop over `out->tt, qv, rho`).
+ * All pointers address host arrays in the reference's own shapes. */
+typedef struct {
+  const void *uuh, *vvh, *pvh;   /* (0:nxmax-1,0:nymax-1,nuvzmax), verttransform_ecmwf.f90:62  */
+  const void *wwh;               /* (0:nxmax-1,0:nymax-1,nwzmax),  :63                          */
+  const void *tth, *qvh;         /* c_loc(tth(0,0,1,n)), com_mod.f90:372-373                    */
+  const void *ps, *tt2, *td2;    /* c_loc(ps(0,0,1,n)) ..., com_mod.f90:410-417                 */
+  const void *akz, *bkz;         /* (nuvz), com_mod.f90:329                                     */
+  const void *aknew, *bknew;     /* (nz),   com_mod.f90:330                                     */
+  int32_t nuvz, nwz;             /* must equal nz (gridcheck_ecmwf.f90 sets nz = nuvz)          */
+  int32_t init;                  /* 1: derive height(nz) and nmixz from this input as the first
+                                    call of the reference does (:118-196); 0: use fpx_set_height's.
+                                    Without fpx_set_height the first call derives them anyway.  */
+  int32_t reserved;
+} fpx_model_levels;
+/* Optional copies back to the host (NULL members are skipped): the z-level arrays in the host's
+ * shapes (0:nxmax-1,0:nymax-1,nzmax) for slot n, e.g. c_loc(tt(0,0,1,n)); height(nz); nmixz. */
+typedef struct {
+  void *uu, *vv, *ww, *tt, *qv, *pv, *rho, *drhodz, *uupol, *vvpol;
+  void *height;
+  int32_t *nmixz;
+} fpx_fields_out;
+/* sfc: the 2-D members of fpx_fields (hmix, ustar, wstar, oli, tropopause, vdep) that calcpar
+ * leaves on the host; its 3-D members are ignored. */
+int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out);
+/* device time of the transform kernels of the last call, milliseconds */
+int fpx_verttransform_time(fpx_handle h, double *ms);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]);
 

@@ -1,0 +1,181 @@
+"""verttransform_ecmwf: oracle vs the reference (CPU), HIP path vs oracle (GPU).
+
+CPU (-m "not gpu"): the C restatement oracle/verttransform_oracle.c is bit-identical to the
+fixtures tests/golden/vt_*.npz, which hold outputs of the unmodified reference routine (flang
+build, made by tests/golden/make_golden_vt.py), and to the live reference where oracle/_ref exists.
+GPU (-m gpu): fpx_verttransform_ecmwf through the C ABI against the oracle on the same input.
+Tolerances: the device computes in the host's real kind with FMA contraction off, so only libm
+(log, 10**x, cos) differs: 1e-11 (f64) / 1e-4 (f32) of each field's range; observed ~1e-14 in f64, and
+in f32 ~1e-6 on the interpolated fields and 3e-5 on drhodz (a difference of neighbouring rho values,
+which amplifies the 1-ulp differences of uvzlev about forty times).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from flexpart_amd import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIELDS = ("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol")
+CASES = {
+    "global_polar": dict(nx=40, ny=24, nz=30, global_grid=True, polar=True),
+    "limited_area": dict(nx=36, ny=28, nz=40, global_grid=False, polar=False),
+}
+
+
+def polar_rows(m):
+    """Rows on which uupol/vvpol are defined (verttransform_ecmwf.f90:461,532)."""
+    ny = int(m["grid"][1])
+    dy, ylat0 = float(m["geom"][1]), float(m["geom"][3])
+    rows = np.zeros(ny, bool)
+    if int(m["globalflags"][1]):
+        rows[max(0, int((75.0 - ylat0) / dy) - 2):] = True
+    if int(m["globalflags"][2]):
+        rows[: int((-75.0 - ylat0) / dy) + 3 + 1] = True
+    return rows
+
+
+def max_rel(got, want, m):
+    worst = {}
+    rows = polar_rows(m)
+    for k in FIELDS:
+        a, b = np.asarray(got[k]), np.asarray(want[k])
+        if k in ("uupol", "vvpol"):
+            if not rows.any():
+                continue
+            a, b = a[:, rows, :], b[:, rows, :]
+        worst[k] = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+    worst["height"] = float(np.abs(np.asarray(got["height"]) - np.asarray(want["height"])).max() / np.abs(want["height"]).max())
+    return worst
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_oracle_equals_reference_fixture(case, kind):
+    from oracle import oracle as orc
+    m = syn.model_levels(**CASES[case])
+    gold = np.load(os.path.join(HERE, "golden", f"vt_{case}_{kind}.npz"))
+    got = orc.vt_oracle(m, kind)
+    assert got["nmixz"] == int(gold["nmixz"])
+    assert np.array_equal(got["height"], gold["height"])
+    rows = polar_rows(m)
+    for k in FIELDS:
+        if k in ("uupol", "vvpol"):
+            if not rows.any():
+                continue
+            assert np.array_equal(got[k][:, rows, :], gold[k][:, rows, :]), k
+        else:
+            assert np.array_equal(got[k], gold[k]), k
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_oracle_equals_live_reference(kind):
+    from oracle import oracle as orc, scenario_io as sio
+    if not sio.have_vt_ref(kind):
+        pytest.skip("flang-built reference not present (GPU box)")
+    m = syn.model_levels(nx=50, ny=30, nz=36, global_grid=True, polar=True, phase=7)
+    ref = sio.run_vt_reference(m, kind)
+    got = orc.vt_oracle(m, kind)
+    assert got["nmixz"] == ref["nmixz"]
+    assert max(max_rel(got, ref, m).values()) == 0.0
+
+
+def test_oracle_second_call_uses_given_heights():
+    """init=0 (every call after the first): the z levels are input, not recomputed."""
+    from oracle import oracle as orc
+    m = syn.model_levels(**CASES["limited_area"])
+    first = orc.vt_oracle(m, "r8")
+    m2 = syn.model_levels(**CASES["limited_area"], phase=5)
+    second = orc.vt_oracle(m2, "r8", height=first["height"])
+    assert np.array_equal(second["height"], first["height"])
+    assert np.isfinite(second["ww"]).all() and not np.array_equal(second["uu"], first["uu"])
+
+
+# ---------------------------------------------------------------------------------------------
+def _sfc(nx, ny, nz, m):
+    f = syn.make_fields(nx, ny, nz, syn.make_height(nz), polar=False)
+    return {k: f[k][m] for k in ("hmix", "ustar", "wstar", "oli", "tropopause")}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("kind,tol", [("r8", 1e-11), ("r4", 1e-4)])
+def test_hip_verttransform_matches_oracle(built, case, kind, tol):
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    from oracle import oracle as orc
+    kw = CASES[case]
+    m = syn.model_levels(**kw)
+    nx, ny, nz = kw["nx"], kw["ny"], kw["nz"]
+    rb = 8 if kind == "r8" else 4
+    sc = dict(syn.small(n=0, nx=nx, ny=ny, nz=nz, nsteps=1), grid=m["grid"], geom=m["geom"], globalflags=m["globalflags"])
+    for k in ("height", "nmixz", "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol", "hmix", "ustar", "wstar", "oli", "tropopause", "vdep"):
+        sc.pop(k, None)
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_PHILOX, pad=(3, 2, 1))
+    got = eng.verttransform(1, m, _sfc(nx, ny, nz, 0), init=True)
+    want = orc.vt_oracle(m, kind)
+    assert got["nmixz"] == want["nmixz"]
+    worst = max_rel(got, want, m)
+    assert max(worst.values()) <= tol, worst
+    # second slot on the z levels of the first call
+    m2 = syn.model_levels(**kw, phase=9)
+    got2 = eng.verttransform(2, m2, _sfc(nx, ny, nz, 1))
+    want2 = orc.vt_oracle(m2, kind, height=want["height"])
+    worst2 = max_rel(got2, want2, m2)
+    assert max(worst2.values()) <= tol, worst2
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_hip_verttransform_against_reference_fixture(built):
+    """HIP path directly against the outputs of the unmodified reference routine (tests/golden)."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    case = "global_polar"
+    kw = CASES[case]
+    m = syn.model_levels(**kw)
+    gold = np.load(os.path.join(HERE, "golden", f"vt_{case}_r8.npz"))
+    sc = dict(syn.small(n=0, nx=kw["nx"], ny=kw["ny"], nz=kw["nz"], nsteps=1), grid=m["grid"], geom=m["geom"], globalflags=m["globalflags"])
+    for k in ("height", "nmixz", "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol", "hmix", "ustar", "wstar", "oli", "tropopause", "vdep"):
+        sc.pop(k, None)
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX)
+    got = eng.verttransform(1, m, _sfc(kw["nx"], kw["ny"], kw["nz"], 0), init=True)
+    eng.close()
+    assert got["nmixz"] == int(gold["nmixz"])
+    worst = max_rel(got, {k: gold[k] for k in gold.files}, m)
+    assert max(worst.values()) <= 1e-11, worst
+
+
+@pytest.mark.gpu
+def test_trajectories_on_device_transformed_fields(built):
+    """End to end: particles advanced on fields the device transformed itself agree with the CPU
+    oracle advancing on the oracle-transformed fields (the 3-D z-level fields never visit the host)."""
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
+    from oracle import oracle as orc
+    from oracle.oracle import Oracle
+    nx, ny, nz = 40, 24, 30
+    ms = [syn.model_levels(nx=nx, ny=ny, nz=nz, global_grid=True, polar=False, phase=p) for p in (0, 6)]
+    w0 = orc.vt_oracle(ms[0], "r8")
+    w1 = orc.vt_oracle(ms[1], "r8", height=w0["height"])
+    base = syn.small(n=3000, nx=nx, ny=ny, nz=nz, nsteps=3, ctl=5.0, ifine=4)
+    sc = dict(base)
+    sc["height"] = w0["height"]; sc["nmixz"] = w0["nmixz"]
+    for k in ("uu", "vv", "ww", "rho", "drhodz", "tt"):
+        sc[k] = np.stack([w0[k], w1[k]])
+    hmix = sc["hmix"]
+    sc.update(syn.make_particles(3000, nx, ny, sc["height"], hmix, seed=11))
+    orcl = Oracle(sc, "r8")
+    orcl.lib.orc_set_parallel_semantics(orcl.h, 1)
+    want = orcl.run(3)
+    # engine: no z-level fields uploaded, both slots come from the device transform
+    sc_e = {k: v for k, v in sc.items() if k not in ("uu", "vv", "ww", "rho", "drhodz", "tt", "height", "nmixz")}
+    eng = Engine(sc_e, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ)
+    for slot in (0, 1):
+        sfc = {k: sc[k][slot] for k in ("hmix", "ustar", "wstar", "oli", "tropopause")}
+        eng.verttransform(slot + 1, ms[slot], sfc, init=(slot == 0), want=())
+    eng.set_windtime(sc["memtime"], sc["memind"])
+    got = eng.run(3)
+    eng.close()
+    from test_gpu_parity import assert_close
+    for g, w in zip(got, want):
+        assert_close(g, w, 1e-8, 1e-6)
