@@ -28,7 +28,7 @@ module flexgpu_mod
             flexgpu_set_windtime, flexgpu_upload_particles, flexgpu_download_particles, &
             flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error, &
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
-            flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo
+            flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields
 #endif
@@ -66,6 +66,17 @@ module flexgpu_mod
     type(c_ptr) :: hmix, ustar, wstar, oli, tropopause
     type(c_ptr) :: vdep
   end type fpx_fields
+
+  type, bind(C) :: fpx_model_levels
+    type(c_ptr) :: uuh, vvh, pvh, wwh, tth, qvh, ps, tt2, td2, akz, bkz, aknew, bknew
+    integer(c_int32_t) :: nuvz, nwz, init, reserved
+  end type fpx_model_levels
+
+  type, bind(C) :: fpx_fields_out
+    type(c_ptr) :: uu, vv, ww, tt, qv, pv, rho, drhodz, uupol, vvpol
+    type(c_ptr) :: height
+    type(c_ptr) :: nmixz
+  end type fpx_fields_out
 
   integer, parameter :: FPX_MAXNESTS = 4
   type, bind(C) :: fpx_nests
@@ -114,6 +125,14 @@ module flexgpu_mod
       integer(c_int32_t), value :: slot
       type(fpx_fields), intent(in) :: f
     end function
+    integer(c_int) function fpx_verttransform_ecmwf(h, slot, m, sfc, o) bind(C, name='fpx_verttransform_ecmwf')
+      import :: c_ptr, c_int, c_int32_t, fpx_model_levels, fpx_fields, fpx_fields_out
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: slot
+      type(fpx_model_levels), intent(in) :: m
+      type(fpx_fields), intent(in) :: sfc
+      type(fpx_fields_out), intent(in) :: o
+    end function fpx_verttransform_ecmwf
     integer(c_int) function fpx_nests_init(h, n) bind(C, name='fpx_nests_init')
       import :: c_ptr, c_int, fpx_nests
       type(c_ptr), value :: h
@@ -304,9 +323,11 @@ contains
   end subroutine flexgpu_last_error
 
   ! com_mod/par_mod -> fpx_config; creates the engine on `device` for `nmaxpart` particles.
-  subroutine flexgpu_init(ierr, device, nmaxpart, compute_real_bytes, rng_mode, seed)
+  ! defer_height: the z levels do not exist yet -- the first flexgpu_verttransform derives them
+  subroutine flexgpu_init(ierr, device, nmaxpart, compute_real_bytes, rng_mode, seed, defer_height)
     integer, intent(out) :: ierr
     integer, intent(in), optional :: device, nmaxpart, compute_real_bytes, rng_mode
+    logical, intent(in), optional :: defer_height
     integer(c_int64_t), intent(in), optional :: seed
     type(fpx_config) :: cfg
     integer :: ks
@@ -345,6 +366,9 @@ contains
     cfg%reserved = 0
     ierr = fpx_create(flexgpu_handle, cfg)
     if (ierr /= 0) return
+    if (present(defer_height)) then
+      if (defer_height) return
+    end if
     ierr = fpx_set_height(flexgpu_handle, loc_r(height), int(nz, c_int32_t))
   end subroutine flexgpu_init
 
@@ -359,6 +383,53 @@ contains
     integer, intent(out) :: ierr
     ierr = fpx_rng_set_table(flexgpu_handle, loc_r(rannumb), int(maxrand, c_int32_t))
   end subroutine flexgpu_use_table_rng
+
+  ! Replaces `call verttransform_ecmwf(n,uuh,vvh,wwh,pvh)` (getfields.f90:129,164,180) AND the upload of
+  ! slot n: the eta -> z transform runs on the device and lands in the engine's gather layout.
+  ! writeback (default .true.): uu, vv, ww, tt, qv, pv, rho, drhodz, uupol, vvpol of slot n are also
+  ! copied back into com_mod for the host routines that still read them (partoutput, convmix, the
+  ! cloud diagnostics); height(:) and nmixz are set on the first call as the reference does.
+  subroutine flexgpu_verttransform(n, uuh, vvh, wwh, pvh, ierr, writeback)
+    integer, intent(in) :: n
+    real, intent(in) :: uuh(0:nxmax-1,0:nymax-1,nuvzmax), vvh(0:nxmax-1,0:nymax-1,nuvzmax)
+    real, intent(in) :: pvh(0:nxmax-1,0:nymax-1,nuvzmax), wwh(0:nxmax-1,0:nymax-1,nwzmax)
+    integer, intent(out) :: ierr
+    logical, intent(in), optional :: writeback
+    logical, save :: first = .true.
+    type(fpx_model_levels) :: m
+    type(fpx_fields) :: f
+    type(fpx_fields_out) :: o
+    integer(c_int32_t), target :: nmixz_c
+    logical :: wb
+    wb = .true.; if (present(writeback)) wb = writeback
+    m%uuh = loc_r(uuh); m%vvh = loc_r(vvh); m%pvh = loc_r(pvh); m%wwh = loc_r(wwh)
+    m%tth = loc_r(tth(0,0,1,n)); m%qvh = loc_r(qvh(0,0,1,n))
+    m%ps = loc_r(ps(0,0,1,n)); m%tt2 = loc_r(tt2(0,0,1,n)); m%td2 = loc_r(td2(0,0,1,n))
+    m%akz = loc_r(akz); m%bkz = loc_r(bkz); m%aknew = loc_r(aknew); m%bknew = loc_r(bknew)
+    m%nuvz = nuvz; m%nwz = nwz; m%init = merge(1, 0, first); m%reserved = 0
+    f%uu = c_null_ptr; f%vv = c_null_ptr; f%ww = c_null_ptr; f%uupol = c_null_ptr; f%vvpol = c_null_ptr
+    f%rho = c_null_ptr; f%drhodz = c_null_ptr; f%tt = c_null_ptr
+    f%hmix = loc_r(hmix(0,0,1,n)); f%ustar = loc_r(ustar(0,0,1,n)); f%wstar = loc_r(wstar(0,0,1,n))
+    f%oli = loc_r(oli(0,0,1,n)); f%tropopause = loc_r(tropopause(0,0,1,n))
+    f%vdep = loc_r(vdep(0,0,1,n))
+    o%uu = c_null_ptr; o%vv = c_null_ptr; o%ww = c_null_ptr; o%tt = c_null_ptr; o%qv = c_null_ptr
+    o%pv = c_null_ptr; o%rho = c_null_ptr; o%drhodz = c_null_ptr; o%uupol = c_null_ptr; o%vvpol = c_null_ptr
+    if (wb) then
+      o%uu = loc_r(uu(0,0,1,n)); o%vv = loc_r(vv(0,0,1,n)); o%ww = loc_r(ww(0,0,1,n))
+      o%tt = loc_r(tt(0,0,1,n)); o%qv = loc_r(qv(0,0,1,n)); o%pv = loc_r(pv(0,0,1,n))
+      o%rho = loc_r(rho(0,0,1,n)); o%drhodz = loc_r(drhodz(0,0,1,n))
+      if (nglobal .or. sglobal) then
+        o%uupol = loc_r(uupol(0,0,1,n)); o%vvpol = loc_r(vvpol(0,0,1,n))
+      end if
+    end if
+    o%height = loc_r(height)
+    nmixz_c = nmixz
+    o%nmixz = c_loc(nmixz_c)
+    ierr = fpx_verttransform_ecmwf(flexgpu_handle, int(n, c_int32_t), m, f, o)
+    if (ierr /= 0) return
+    nmixz = nmixz_c
+    first = .false.
+  end subroutine flexgpu_verttransform
 
   ! one time slot of the com_mod fields (slot = the value found in memind(k))
   subroutine flexgpu_upload_fields(slot, ierr)

@@ -65,7 +65,11 @@ build_vt() {
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_vt_driver.f90" -o ref_vt_driver.o
-    "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o verttransform_ecmwf.o ew.o qvsat.o par_mod.o com_mod.o cmapf_mod.o -o "$OUT/vtref_$kind"
+    "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o flexgpu_mod.o verttransform_ecmwf.o ew.o qvsat.o \
+        par_mod.o com_mod.o cmapf_mod.o point_mod.o unc_mod.o outg_mod.o \
+        -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
+        -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
+        -o "$OUT/vtref_$kind"
   )
   echo "build_ref: built $OUT/vtref_$kind"
 }

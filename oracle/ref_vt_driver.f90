@@ -7,7 +7,10 @@
 ! This file is our own code: it contains no reference source, only calls into it and
 ! assignments to its module variables.
 !
-! Usage:  vtref_rK scenario.bin out.bin
+! Usage:  vtref_rK scenario.bin out.bin [gpu]
+!   gpu: the same com_mod arrays go through the MI355X engine (flexgpu_verttransform of
+!        flexpart_amd/fortran/flexgpu_mod.f90, ISO_C_BINDING) instead of the Fortran routine --
+!        the drop-in integration test (needs a GPU; run on the GPU box).
 ! Record format as oracle/ref_driver.f90: {name*16, dtype i4 (1=i32, 2=f64), count i8, payload}.
 ! 3-D input arrays travel compact, (nx,ny,nlev) x fastest, as f64.
 
@@ -37,9 +40,14 @@ program vtref
   use par_mod
   use com_mod
   use cmapf_mod
+  use point_mod
   use vt_io
+  use flexgpu_mod
   implicit none
 
+  integer :: use_gpu, gerr
+  character(len=256) :: gmsg
+  character(len=512) :: arg3
   character(len=512) :: fscen, fout
   character(len=16) :: name
   integer(kind=4) :: dtype
@@ -53,6 +61,11 @@ program vtref
 
   call get_command_argument(1, fscen)
   call get_command_argument(2, fout)
+  use_gpu = 0
+  if (command_argument_count() .ge. 3) then
+    call get_command_argument(3, arg3)
+    if (trim(arg3) .eq. 'gpu') use_gpu = 1
+  end if
 
   allocate(uuh(0:nxmax-1,0:nymax-1,nuvzmax), vvh(0:nxmax-1,0:nymax-1,nuvzmax))
   allocate(pvh(0:nxmax-1,0:nymax-1,nuvzmax), wwh(0:nxmax-1,0:nymax-1,nwzmax))
@@ -125,9 +138,28 @@ program vtref
   end if
 
   call system_clock(c0, crate)
-  do icall=1,ncalls
-    call verttransform_ecmwf(1,uuh,vvh,wwh,pvh)
-  end do
+  if (use_gpu .eq. 1) then
+    ! defaults of the run switches flexgpu_init reads (no particle step is taken here)
+    ldirect=1; lsynctime=900; method=1; mintime=1; ctl=0.2; ifine=4; turbswitch=.true.; cblflag=0
+    mdomainfill=0; lsettling=.false.; nspec=1; DRYDEP=.false.; nageclass=1; lage(1)=999999999
+    numpoint=1; allocate(xmass(1,maxspec), npart(1)); xmass=1.; npart(1)=1
+    ipout=0; call com_mod_allocate_part(1)
+    hmix(:,:,1,1)=500.; ustar(:,:,1,1)=0.3; wstar(:,:,1,1)=1.; oli(:,:,1,1)=0.01; tropopause(:,:,1,1)=10000.
+    call flexgpu_init(gerr, nmaxpart=1, defer_height=.true.)
+    if (gerr .ne. 0) then
+      call flexgpu_last_error(gmsg); write(*,*) 'flexgpu_init: ', trim(gmsg); stop 1
+    end if
+    do icall=1,ncalls
+      call flexgpu_verttransform(1,uuh,vvh,wwh,pvh,gerr)
+      if (gerr .ne. 0) then
+        call flexgpu_last_error(gmsg); write(*,*) 'flexgpu_verttransform: ', trim(gmsg); stop 1
+      end if
+    end do
+  else
+    do icall=1,ncalls
+      call verttransform_ecmwf(1,uuh,vvh,wwh,pvh)
+    end do
+  end if
   call system_clock(c1)
 
   open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')

@@ -122,7 +122,7 @@ def have_vt_ref(kind="r8"):
     return os.access(os.path.join(HERE, "_ref", f"vtref_{kind}"), os.X_OK)
 
 
-def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1):
+def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1, gpu=False):
     """The unmodified verttransform_ecmwf on a synthetic.model_levels() dict -> dict of fields [nz][ny][nx]."""
     os.makedirs(workdir, exist_ok=True)
     fs = os.path.join(workdir, f"vt_{os.getpid()}.scen")
@@ -139,7 +139,7 @@ def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1):
             fh.write(a.tobytes())
         fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
     exe = os.path.join(HERE, "_ref", f"vtref_{kind}")
-    res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {fo}"], capture_output=True, text=True)
+    res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {fo}" + (" gpu" if gpu else "")], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"reference verttransform driver failed: {res.stdout}\n{res.stderr}")
     nx, ny, nz = (int(v) for v in m["grid"])

@@ -179,3 +179,21 @@ def test_trajectories_on_device_transformed_fields(built):
     from test_gpu_parity import assert_close
     for g, w in zip(got, want):
         assert_close(g, w, 1e-8, 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,tol", [("r8", 1e-11), ("r4", 1e-4)])
+def test_fortran_host_verttransform(built, kind, tol):
+    """The real Fortran host: oracle/_ref/vtref_rK holds the reference's com_mod arrays (tth, qvh, ps ...
+    with nxmax/nymax strides) and either calls the reference's verttransform_ecmwf or hands the very same
+    arrays to the engine through flexgpu_verttransform (ISO_C_BINDING), which writes uu ... drhodz,
+    height and nmixz back into com_mod."""
+    from oracle import scenario_io as sio
+    if not sio.have_vt_ref(kind):
+        pytest.skip("oracle/_ref binaries not present in this snapshot")
+    m = syn.model_levels(nx=50, ny=30, nz=36, global_grid=True, polar=True, phase=3)
+    ref = sio.run_vt_reference(m, kind)
+    gpu = sio.run_vt_reference(m, kind, gpu=True)
+    assert gpu["nmixz"] == ref["nmixz"]
+    worst = max_rel(gpu, ref, m)
+    assert max(worst.values()) <= tol, worst
