@@ -1065,7 +1065,7 @@ struct Engine : EngineBase {
     const size_t n2 = (size_t)cfg.nxmax * cfg.nymax, n3 = n2 * nz;
     int rc;
     enum { UUH, VVH, PVH, WWH, TTH, QVH, PS, TT2, TD2, AKZ, BKZ, AKN, BKN, HGT,
-           UU, VV, WW, TT, QV, PV, RHO, DRHO, UPOL, VPOL, UVZ, WZ, RHOH, PINM, NBUF };
+           UU, VV, WW, TT, QV, PV, RHO, DRHO, UPOL, VPOL, UVZ, WZ, RHOH, PINM, KUV, KW, NBUF };
     if (!vt_ready) {
       for (int i = 0; i < NBUF; i++) {
         const size_t n = (i >= PS && i <= TD2) ? n2 : (i >= AKZ && i <= HGT) ? (size_t)nz : n3;
@@ -1115,18 +1115,23 @@ struct Engine : EngineBase {
     HIPCHK(hipEventRecord(e0, stream));
     const int ncol = cfg.nx * cfg.ny, nb = (ncol + 255) / 256;
     const size_t sm = (size_t)nz * sizeof(H);
-    vt::k_vt_levels<H><<<nb, 256, 0, stream>>>(G, I, O);
-    vt::k_vt_interp<H><<<nb, 256, sm, stream>>>(G, I, O);
-    if (cfg.nx > 2 && cfg.ny > 2) vt::k_vt_slope<H><<<((cfg.nx - 2) * (cfg.ny - 2) + 255) / 256, 256, sm, stream>>>(G, I, O);
+    const dim3 g3(nb, nz);
+    unsigned short *kuv = (unsigned short *)vt_dev[KUV], *kw = (unsigned short *)vt_dev[KW];
+    vt::k_vt_inc<H><<<g3, 256, 0, stream>>>(G, I, O);
+    vt::k_vt_column<H><<<nb, 256, 0, stream>>>(G, I, O);
+    vt::k_vt_search<H><<<dim3(nb, 2), 256, sm, stream>>>(G, I, O, kuv, kw);
+    vt::k_vt_fill<H><<<g3, 256, 0, stream>>>(G, I, O, kuv, kw);
+    vt::k_vt_post<H><<<g3, 256, 0, stream>>>(G, I, O, kuv);
+    const size_t smrow = (size_t)(cfg.nx + 3) * sizeof(H);
     if (cfg.nglobal) {
       const int jy0 = std::max(0, (int)G.switchnorthg - 2), jy1 = cfg.ny - 1;
       if (jy1 >= jy0) vt::k_vt_polar<H><<<dim3((cfg.nx + 255) / 256, jy1 - jy0 + 1, nz), 256, 0, stream>>>(G, O, jy0, jy1, 0);
-      vt::k_vt_polerow<H><<<(nz + 63) / 64, 64, 0, stream>>>(G, O, 0);
+      vt::k_vt_polerow<H><<<nz, 64, smrow, stream>>>(G, O, 0);
     }
     if (cfg.sglobal) {
       const int jy0 = 0, jy1 = std::min(cfg.ny - 1, (int)G.switchsouthg + 3);
       if (jy1 >= jy0) vt::k_vt_polar<H><<<dim3((cfg.nx + 255) / 256, jy1 - jy0 + 1, nz), 256, 0, stream>>>(G, O, jy0, jy1, 1);
-      vt::k_vt_polerow<H><<<(nz + 63) / 64, 64, 0, stream>>>(G, O, 1);
+      vt::k_vt_polerow<H><<<nz, 64, smrow, stream>>>(G, O, 1);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, stream));
@@ -1179,7 +1184,7 @@ struct Engine : EngineBase {
     if (!m || !m->uuh || !m->vvh || !m->pvh || !m->wwh || !m->tth || !m->qvh || !m->ps || !m->tt2 || !m->td2 || !m->akz || !m->bkz || !m->aknew || !m->bknew)
       return fail(FPX_ERR_ARG, "verttransform: uuh, vvh, pvh, wwh, tth, qvh, ps, tt2, td2, akz, bkz, aknew, bknew are required");
     if (m->nuvz != cfg.nz || m->nwz != cfg.nz) return fail(FPX_ERR_ARG, "verttransform: nuvz = nwz = nz expected (gridcheck_ecmwf.f90 sets them equal)");
-    if (cfg.nz < 3) return fail(FPX_ERR_ARG, "verttransform: nz >= 3");
+    if (cfg.nz < 3 || cfg.nz > 65535 || cfg.ny > 65535) return fail(FPX_ERR_ARG, "verttransform: 3 <= nz <= 65535, ny <= 65535");
     if (!sfc || !sfc->hmix || !sfc->ustar || !sfc->wstar || !sfc->oli || !sfc->tropopause) return fail(FPX_ERR_ARG, "verttransform: the 2-D fields hmix, ustar, wstar, oli, tropopause are required");
     if (cfg.drydep && !sfc->vdep) return fail(FPX_ERR_ARG, "verttransform: vdep required with DRYDEP");
     return cfg.host_real_bytes == 4 ? verttransform_t<float>(slot, m, sfc, out) : verttransform_t<double>(slot, m, sfc, out);
