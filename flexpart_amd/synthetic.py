@@ -494,3 +494,34 @@ def model_levels(nx=361, ny=181, nz=138, *, global_grid=True, polar=False, phase
     out["geom"] = np.array([dx, dy, -180.0 if global_grid else -20.0, -90.0 if global_grid else 20.0], np.float64)
     out["globalflags"] = np.array([int(global_grid), int(global_grid and polar), int(global_grid and polar)], np.int32)
     return out
+
+
+# --------------------------------------------------------------------------
+# particle dump (partoutput.f90): the extra fields it interpolates
+# --------------------------------------------------------------------------
+def add_partoutput_fields(sc, itime=None, dead_every=7):
+    """oro, pv, qv for a scenario that already has height, rho, tt, hmix, tropopause and particles; every
+    `dead_every`-th particle is made not due (terminated) so that the dump has to skip it."""
+    nx, ny, nz = (int(v) for v in sc["grid"])
+    per = nx - 1
+    i = np.arange(nx, dtype=np.int64)[None, None, :]
+    j = np.arange(ny, dtype=np.int64)[None, :, None]
+    k = np.arange(nz, dtype=np.int64)[:, None, None]
+    z = np.asarray(sc["height"], dtype=np.float64)[:, None, None]
+    sc["oro"] = 400.0 * (1.0 + _wave(2 * i[0] + 3 * j[0], per)) + 0.0 * j[0]
+    pv = np.empty((2, nz, ny, nx)); qv = np.empty((2, nz, ny, nx))
+    for m in range(2):
+        sh = 10 * m
+        pv[m] = 1.0e-6 * (1.0 + 0.5 * _wave(i + sh + k, per)) * (1.0 + z / 6000.0) * (2.0 * j / float(ny - 1) - 1.0)
+        qv[m] = 0.012 / (1.0 + z / 2500.0) ** 2 * (0.6 + 0.4 * _wave(2 * (i + sh) + j, per)) + 0.0 * k
+    if xcyclic_ok(nx):
+        pv[..., nx - 1] = pv[..., 0]; qv[..., nx - 1] = qv[..., 0]; sc["oro"][..., nx - 1] = sc["oro"][..., 0]
+    sc["pv"] = pv; sc["qv"] = qv
+    it = int(sc.get("itime0", 0)) if itime is None else int(itime)
+    sc["itime"] = it
+    itra1 = np.full(int(sc["npart"]), it, np.int32)
+    if dead_every:
+        itra1[::dead_every] = -999999999
+    sc["itra1"] = itra1
+    sc["npoint"] = (1 + np.arange(int(sc["npart"])) % 3).astype(np.int32)
+    return sc

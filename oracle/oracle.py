@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build(force=False):
     """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
-    for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle")):
+    for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"), ("partoutput_oracle", "libpooracle")):
         src = os.path.join(HERE, stem + ".c")
         for kind, real in (("r4", "float"), ("r8", "double")):
             out = os.path.join(HERE, f"{lib}_{kind}.so")
@@ -348,3 +348,47 @@ def vt_oracle(m, kind="r8", height=None):
     out["height"] = h
     out["nmixz"] = nmixz.value
     return out
+
+
+# --------------------------------------------------------------------------
+# partoutput (oracle/partoutput_oracle.c)
+# --------------------------------------------------------------------------
+class _PooArgs(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ("nx", "ny", "nz", "nymax", "nspec", "itime")]
+                + [("memtime", C.c_int * 2), ("memind", C.c_int * 2)]
+                + [(k, C.c_double) for k in ("dx", "dy", "xlon0", "ylat0")]
+                + [(k, C.POINTER(C.c_double)) for k in ("height", "oro", "pv", "qv", "tt", "rho", "hmix", "tropopause")]
+                + [("numpart", C.c_long)]
+                + [(k, C.POINTER(C.c_double)) for k in ("xtra1", "ytra1", "ztra1")]
+                + [(k, C.POINTER(C.c_int)) for k in ("itra1", "itramem", "npoint")]
+                + [("xmass1", C.POINTER(C.c_double))])
+
+
+def po_oracle(sc, kind="r8", nymax=None):
+    """File image of partposit_* for a scenario (synthetic.add_partoutput_fields), as bytes."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"libpooracle_{kind}.so"))
+    lib.poo_partoutput.restype = C.c_long
+    nx, ny, nz = (int(v) for v in sc["grid"])
+    a = _PooArgs()
+    a.nx, a.ny, a.nz = nx, ny, nz
+    a.nymax = int(nymax or 181)            # par_mod.f90:144 of the reference build the fixtures come from
+    a.nspec = int(sc["nspec"]); a.itime = int(sc["itime"])
+    a.memtime[0], a.memtime[1] = int(sc["memtime"][0]), int(sc["memtime"][1])
+    a.memind[0], a.memind[1] = int(sc["memind"][0]), int(sc["memind"][1])
+    a.dx, a.dy, a.xlon0, a.ylat0 = (float(v) for v in sc["geom"])
+    keep = {}
+    dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int)
+    for k in ("height", "oro", "pv", "qv", "tt", "rho", "hmix", "tropopause", "xtra1", "ytra1", "ztra1"):
+        keep[k] = _f64(sc[k]); setattr(a, k, keep[k].ctypes.data_as(dp))
+    for k in ("itra1", "itramem", "npoint"):
+        keep[k] = np.ascontiguousarray(np.asarray(sc[k], dtype=np.int32)); setattr(a, k, keep[k].ctypes.data_as(ip))
+    n = int(sc["npart"])
+    a.numpart = n
+    keep["xmass1"] = _f64(np.asarray(sc["xmass1"]).reshape(a.nspec, n)); a.xmass1 = keep["xmass1"].ctypes.data_as(dp)
+    cap = 12 + (n + 1) * (16 + (10 + a.nspec) * 8)
+    buf = (C.c_ubyte * cap)()
+    nb = lib.poo_partoutput(C.byref(a), buf, cap)
+    if nb < 0:
+        raise RuntimeError("poo_partoutput: buffer too small")
+    return bytes(buf[:nb])

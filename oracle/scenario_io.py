@@ -150,3 +150,42 @@ def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1, gpu=False):
     os.remove(fo)
     out["nmixz"] = int(out["nmixz"][0])
     return out
+
+
+# --------------------------------------------------------------------------
+# partoutput through oracle/_ref/poref_rK (oracle/ref_po_driver.f90)
+# --------------------------------------------------------------------------
+_PO_ORDER = ["grid", "geom", "height", "memtime", "memind", "nspec", "itime", "oro", "pv", "qv", "tt", "rho",
+             "hmix", "tropopause", "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "xmass1"]
+_PO_INT = {"grid", "memtime", "memind", "nspec", "itime", "npart", "itra1", "itramem", "npoint"}
+
+
+def have_po_ref(kind="r8"):
+    return os.access(os.path.join(HERE, "_ref", f"poref_{kind}"), os.X_OK)
+
+
+def run_po_reference(sc, kind="r8", workdir="/tmp"):
+    """The unmodified partoutput on a scenario dict -> bytes of the file partposit_end it wrote."""
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="po_", dir=workdir)
+    try:
+        fs = os.path.join(d, "po.scen")
+        with open(fs, "wb") as fh:
+            for name in _PO_ORDER:
+                v = sc[name]
+                if name in _PO_INT:
+                    a = np.ascontiguousarray(np.asarray(v, dtype=np.int32).ravel()); code = 1
+                else:
+                    a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel()); code = 2
+                fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
+                fh.write(a.tobytes())
+            fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
+        exe = os.path.join(HERE, "_ref", f"poref_{kind}")
+        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/"], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"reference partoutput driver failed: {res.stdout}\n{res.stderr}")
+        with open(os.path.join(d, "partposit_end"), "rb") as fh:
+            return fh.read()
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
