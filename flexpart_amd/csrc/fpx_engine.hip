@@ -7,6 +7,7 @@
 #include <cstring>
 #include <rccl/rccl.h>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
 #include <rocprim/iterator/counting_iterator.hpp>
 #include <algorithm>
@@ -408,6 +409,119 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
   epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
 }
 
+// ---------------------------------------------------------------------------
+// partoutput.f90:63-190 -- the binary particle dump.  The device builds the
+// record stream of the file (Fortran sequential unformatted: 4-byte length, payload, 4-byte
+// length) for the particles due at itime, in particle-number order, in the host's real kind H;
+// the host only streams the bytes to disk.  Arithmetic in H with FMA contraction off: the file
+// is byte-identical to the reference's.
+// ---------------------------------------------------------------------------
+template <typename H>
+struct DiagP {
+  const H *oro, *pv[2], *qv[2], *tt[2], *tropo[2];   // host layout (ix,jy[,level]), strides nxmax, nymax
+  int nxmax, nymax;
+  H dx, dy, xlon0, ylat0;
+};
+
+template <typename R>
+__global__ void k_po_flags(Parts<R> P, const unsigned int *__restrict__ slot_of_pid, long long n, int itime, unsigned int *__restrict__ flags) {
+  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= n) return;
+  const long long s = slot_of_pid ? slot_of_pid[pid] : pid;
+  flags[pid] = P.itra1[s] == itime ? 1u : 0u;
+}
+
+__device__ __forceinline__ unsigned int *po_put(unsigned int *w, float v) { *w = __float_as_uint(v); return w + 1; }
+__device__ __forceinline__ unsigned int *po_put(unsigned int *w, double v) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  w[0] = (unsigned int)b; w[1] = (unsigned int)(b >> 32);
+  return w + 2;
+}
+
+template <typename R, typename H>
+__global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, DiagP<H> D, const unsigned int *__restrict__ slot_of_pid,
+                                                       const unsigned int *__restrict__ flags, const unsigned int *__restrict__ recidx,
+                                                       long long n, int itime, unsigned int *__restrict__ out) {
+#pragma clang fp contract(off)
+  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= n || !flags[pid]) return;
+  const long long s = slot_of_pid ? slot_of_pid[pid] : pid;
+  const int nx = V.nx, ny = V.ny, nz = V.nz, nspec = V.nspec;
+  const int reclen = 8 + (10 + nspec) * (int)sizeof(H);
+  const H dt1 = (H)(itime - V.memtime0), dt2 = (H)(V.memtime1 - itime);   // partoutput.f90:69-71
+  const H dtt = (H)1. / (dt1 + dt2);
+  const double xt = P.xt[s], yt = P.yt[s];
+  const H zt = (H)P.zt[s];
+  const H xlon = (H)((double)D.xlon0 + xt * (double)D.dx);
+  const H ylat = (H)((double)D.ylat0 + yt * (double)D.dy);
+  const int ix = (int)xt, jy = (int)yt;
+  int ixp = ix + 1, jyp = jy + 1;
+  const H ddx = (H)(xt - (double)(H)ix), ddy = (H)(yt - (double)(H)jy);
+  const H rddx = (H)1. - ddx, rddy = (H)1. - ddy;
+  const H p1 = rddx * rddy, p2 = ddx * rddy, p3 = rddx * ddy, p4 = ddx * ddy;
+  if (jyp >= D.nymax) jyp = jyp - 1;                                      // :119-121
+  if (ixp >= D.nxmax) ixp = D.nxmax - 1;                                  // guard (weight 0 there)
+  auto h2 = [&](const H *f, int i, int j) { return f[(size_t)i + (size_t)D.nxmax * (size_t)j]; };
+  auto h3 = [&](const H *f, int i, int j, int k) { return f[(size_t)i + (size_t)D.nxmax * ((size_t)j + (size_t)D.nymax * (size_t)(k - 1))]; };
+  // rho and hmix live in the gather packs (compact nx, ny; elements of the host's padding read as 0)
+  auto rho_at = [&](int i, int j, int k, int slot) -> H {
+    if (i >= nx || j >= ny) return (H)0;
+    return (H)V.r2[(((size_t)j * nx + i) * nz + (k - 1)) * 4 + slot * 2];
+  };
+  auto hmix_at = [&](int i, int j, int slot) -> H {
+    if (i >= nx || j >= ny) return (H)0;
+    return (H)V.sfc[((size_t)j * nx + i) * 8 + slot * 4 + 3];
+  };
+  const H topo = p1 * h2(D.oro, ix, jy) + p2 * h2(D.oro, ixp, jy) + p3 * h2(D.oro, ix, jyp) + p4 * h2(D.oro, ixp, jyp);
+  int indz = nz - 1, indzp = nz;   // the reference keeps the previous particle's indices when zt >= height(nz); cannot happen after advance()
+  for (int il = 2; il <= nz; il++)
+    if ((H)V.height[il - 1] > zt) { indz = il - 1; indzp = il; break; }
+  const H dz1 = zt - (H)V.height[indz - 1], dz2 = (H)V.height[indzp - 1] - zt;
+  const H dz = (H)1. / (dz1 + dz2);
+  const int slot[2] = {V.m1, V.m2};
+  H pvprof[2], qvprof[2], ttprof[2], rhoprof[2];
+#pragma unroll
+  for (int l = 0; l < 2; l++) {
+    const int ind = indz + l;
+    H pv1[2], qv1[2], tt1[2], rho1[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+      const int h = slot[m];
+      pv1[m] = p1 * h3(D.pv[h], ix, jy, ind) + p2 * h3(D.pv[h], ixp, jy, ind) + p3 * h3(D.pv[h], ix, jyp, ind) + p4 * h3(D.pv[h], ixp, jyp, ind);
+      qv1[m] = p1 * h3(D.qv[h], ix, jy, ind) + p2 * h3(D.qv[h], ixp, jy, ind) + p3 * h3(D.qv[h], ix, jyp, ind) + p4 * h3(D.qv[h], ixp, jyp, ind);
+      tt1[m] = p1 * h3(D.tt[h], ix, jy, ind) + p2 * h3(D.tt[h], ixp, jy, ind) + p3 * h3(D.tt[h], ix, jyp, ind) + p4 * h3(D.tt[h], ixp, jyp, ind);
+      rho1[m] = p1 * rho_at(ix, jy, ind, h) + p2 * rho_at(ixp, jy, ind, h) + p3 * rho_at(ix, jyp, ind, h) + p4 * rho_at(ixp, jyp, ind, h);
+    }
+    pvprof[l] = (pv1[0] * dt2 + pv1[1] * dt1) * dtt;
+    qvprof[l] = (qv1[0] * dt2 + qv1[1] * dt1) * dtt;
+    ttprof[l] = (tt1[0] * dt2 + tt1[1] * dt1) * dtt;
+    rhoprof[l] = (rho1[0] * dt2 + rho1[1] * dt1) * dtt;
+  }
+  const H pvi = (dz1 * pvprof[1] + dz2 * pvprof[0]) * dz;
+  const H qvi = (dz1 * qvprof[1] + dz2 * qvprof[0]) * dz;
+  const H tti = (dz1 * ttprof[1] + dz2 * ttprof[0]) * dz;
+  const H rhoi = (dz1 * rhoprof[1] + dz2 * rhoprof[0]) * dz;
+  H tr[2], hm[2];
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const int h = slot[m];
+    tr[m] = p1 * h2(D.tropo[h], ix, jy) + p2 * h2(D.tropo[h], ixp, jy) + p3 * h2(D.tropo[h], ix, jyp) + p4 * h2(D.tropo[h], ixp, jyp);
+    hm[m] = p1 * hmix_at(ix, jy, h) + p2 * hmix_at(ixp, jy, h) + p3 * hmix_at(ix, jyp, h) + p4 * hmix_at(ixp, jyp, h);
+  }
+  const H hmixi = (hm[0] * dt2 + hm[1] * dt1) * dtt;
+  const H tri = (tr[0] * dt2 + tr[1] * dt1) * dtt;
+  // the record, :177-179 (32-bit words: the payload of an 8-byte build is only 4-byte aligned in the file)
+  unsigned int *w = out + (size_t)recidx[pid] * (size_t)(reclen / 4 + 2);
+  *w++ = (unsigned int)reclen;
+  *w++ = (unsigned int)P.npoint[s];
+  w = po_put(w, xlon); w = po_put(w, ylat); w = po_put(w, zt);
+  *w++ = (unsigned int)P.itramem[s];
+  w = po_put(w, topo); w = po_put(w, pvi); w = po_put(w, qvi); w = po_put(w, rhoi);
+  w = po_put(w, hmixi); w = po_put(w, tri); w = po_put(w, tti);
+  for (int ks = 0; ks < nspec; ks++) w = po_put(w, (H)P.xmass1[(size_t)ks * P.cap + s]);
+  *w++ = (unsigned int)reclen;
+}
+
 // After the stable sort of the slots by their 3-bit key: list length = number of keys <= 4 (PBL
 // classes), particles due = number of keys <= 6.  One wave, two 64-ary searches (5 dependent
 // loads each at 1e8 keys).
@@ -730,6 +844,8 @@ struct EngineBase {
   virtual int get_receptors(void *creceptor, int ld, int allreduce, int clear) = 0;
   virtual void *stream_ptr() = 0;
   virtual double vt_ms() = 0;
+  virtual int upload_diag_fields(int slot, const fpx_diag_fields *f) = 0;
+  virtual int partoutput(int itime, const char *path, int64_t *nrec) = 0;
 };
 
 template <typename R>
@@ -986,6 +1102,7 @@ struct Engine : EngineBase {
     if ((rc = p2(f->wstar, V.sfc, 8, s * 4 + 1))) return rc;
     if ((rc = p2(f->oli, V.sfc, 8, s * 4 + 2))) return rc;
     if ((rc = p2(f->hmix, V.sfc, 8, s * 4 + 3))) return rc;
+    if ((rc = diag_from_host(DG_TROPO + s, f->tropopause))) return rc;   // partoutput interpolates it in time
     if (slot == 1) {   // literal time index 1 uses: advance.f90:253, get_settling.f90:83-84
       if ((rc = p2(f->tropopause, V.tropo, 1, 0))) return rc;
       if (V.rhott) {
@@ -1154,6 +1271,9 @@ struct Engine : EngineBase {
     if ((rc = p2(sfc->ustar, V.sfc, 8, s * 4 + 0)) || (rc = p2(sfc->wstar, V.sfc, 8, s * 4 + 1)) ||
         (rc = p2(sfc->oli, V.sfc, 8, s * 4 + 2)) || (rc = p2(sfc->hmix, V.sfc, 8, s * 4 + 3))) return rc;
     if (slot == 1) { if ((rc = p2(sfc->tropopause, V.tropo, 1, 0))) return rc; }
+    if ((rc = diag_from_host(DG_TROPO + s, sfc->tropopause))) return rc;
+    // pv, qv, tt of this slot stay on the device for partoutput
+    if ((rc = diag_from_device(DG_PV + s, D(PV))) || (rc = diag_from_device(DG_QV + s, D(QV))) || (rc = diag_from_device(DG_TT + s, D(TT)))) return rc;
     if (V.vdep) {
       const size_t plane = n2 * cfg.host_real_bytes;
       for (int ks = 0; ks < cfg.nspec; ks++)
@@ -1188,6 +1308,148 @@ struct Engine : EngineBase {
     if (!sfc || !sfc->hmix || !sfc->ustar || !sfc->wstar || !sfc->oli || !sfc->tropopause) return fail(FPX_ERR_ARG, "verttransform: the 2-D fields hmix, ustar, wstar, oli, tropopause are required");
     if (cfg.drydep && !sfc->vdep) return fail(FPX_ERR_ARG, "verttransform: vdep required with DRYDEP");
     return cfg.host_real_bytes == 4 ? verttransform_t<float>(slot, m, sfc, out) : verttransform_t<double>(slot, m, sfc, out);
+  }
+
+
+  // ---- partoutput -------------------------------------------------------
+  void *diag_dev[9] = {};          // oro, pv[2], qv[2], tt[2], tropopause[2] in the host's real kind and layout
+  bool diag_have[9] = {};
+  enum { DG_ORO = 0, DG_PV = 1, DG_QV = 3, DG_TT = 5, DG_TROPO = 7 };
+  int diag_buf(int i, void **q) {
+    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax, n = (i == DG_ORO || i >= DG_TROPO) ? n2 : n2 * cfg.nz;
+    if (!diag_dev[i]) {
+      char *p = nullptr;
+      int rc = dalloc(&p, n * cfg.host_real_bytes);
+      if (rc) return rc;
+      diag_dev[i] = p;
+    }
+    *q = diag_dev[i];
+    return 0;
+  }
+  int diag_from_host(int i, const void *host) {
+    void *q;
+    int rc = diag_buf(i, &q);
+    if (rc) return rc;
+    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax, n = (i == DG_ORO || i >= DG_TROPO) ? n2 : n2 * cfg.nz;
+    HIPCHK(hipMemcpyAsync(q, host, n * cfg.host_real_bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    diag_have[i] = true;
+    return 0;
+  }
+  int diag_from_device(int i, const void *dev) {
+    void *q;
+    int rc = diag_buf(i, &q);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(q, dev, (size_t)cfg.nxmax * cfg.nymax * cfg.nz * cfg.host_real_bytes, hipMemcpyDeviceToDevice, stream));
+    diag_have[i] = true;
+    return 0;
+  }
+  int upload_diag_fields(int slot, const fpx_diag_fields *f) override {
+    if (!f || slot < 0 || slot > 2) return fail(FPX_ERR_ARG, "upload_diag_fields: slot 0 (oro only), 1 or 2");
+    int rc;
+    if (f->oro && (rc = diag_from_host(DG_ORO, f->oro))) return rc;
+    if (slot == 0) return 0;
+    const int s = slot - 1;
+    if (f->pv && (rc = diag_from_host(DG_PV + s, f->pv))) return rc;
+    if (f->qv && (rc = diag_from_host(DG_QV + s, f->qv))) return rc;
+    if (f->tt && (rc = diag_from_host(DG_TT + s, f->tt))) return rc;
+    return 0;
+  }
+
+  template <typename H>
+  int partoutput_t(int itime, const char *path, int64_t *nrec) {
+    const long long n = numpart;
+    const int reclen = 8 + (10 + cfg.nspec) * (int)sizeof(H);
+    const size_t recwords = (size_t)reclen / 4 + 2;
+    unsigned int *flags = nullptr, *idx = nullptr, *out = nullptr;
+    void *tmp = nullptr;
+    FILE *fh = fopen(path, "wb");
+    if (!fh) return fail(FPX_ERR_ARG, std::string("partoutput: cannot open ") + path);
+    auto cleanup = [&]() {
+      if (flags) (void)hipFree(flags);
+      if (idx) (void)hipFree(idx);
+      if (out) (void)hipFree(out);
+      if (tmp) (void)hipFree(tmp);
+      if (fh) fclose(fh);
+    };
+    unsigned int count = 0;
+    bool io_ok = true;
+    {
+      const int32_t hdr[3] = {4, itime, 4};              // write(unitpartout) itime, partoutput.f90:90
+      io_ok = fwrite(hdr, 4, 3, fh) == 3;
+    }
+    if (n > 0) {
+      hipError_t e;
+      if ((e = hipMalloc(&flags, n * sizeof(unsigned int))) != hipSuccess || (e = hipMalloc(&idx, n * sizeof(unsigned int))) != hipSuccess) {
+        cleanup();
+        return fail(FPX_ERR_NOMEM, std::string("partoutput: ") + hipGetErrorString(e));
+      }
+      const int nb = (int)((n + kBlock - 1) / kBlock);
+      k_po_flags<R><<<nb, kBlock, 0, stream>>>(P, slot_of_pid, n, itime, flags);
+      size_t tb = 0;
+      (void)rocprim::exclusive_scan(nullptr, tb, flags, idx, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
+      if ((e = hipMalloc(&tmp, std::max<size_t>(tb, 16))) != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, "partoutput: scan storage"); }
+      e = rocprim::exclusive_scan(tmp, tb, flags, idx, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
+      unsigned int last_idx = 0, last_flag = 0;
+      if (e == hipSuccess) e = hipMemcpyAsync(&last_idx, idx + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipMemcpyAsync(&last_flag, flags + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_DEVICE, std::string("partoutput: ") + hipGetErrorString(e)); }
+      count = last_idx + last_flag;
+      if (count > 0) {
+        const size_t words = (size_t)count * recwords;
+        if ((e = hipMalloc(&out, words * 4)) != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("partoutput: record buffer: ") + hipGetErrorString(e)); }
+        DiagP<H> D;
+        D.oro = (const H *)diag_dev[DG_ORO];
+        for (int m = 0; m < 2; m++) {
+          D.pv[m] = (const H *)diag_dev[DG_PV + m]; D.qv[m] = (const H *)diag_dev[DG_QV + m];
+          D.tt[m] = (const H *)diag_dev[DG_TT + m]; D.tropo[m] = (const H *)diag_dev[DG_TROPO + m];
+        }
+        D.nxmax = cfg.nxmax; D.nymax = cfg.nymax;
+        D.dx = (H)cfg.dx; D.dy = (H)cfg.dy; D.xlon0 = (H)cfg.xlon0; D.ylat0 = (H)cfg.ylat0;
+        k_partoutput<R, H><<<nb, kBlock, 0, stream>>>(V, P, D, slot_of_pid, flags, idx, n, itime, out);
+        e = hipGetLastError();
+        // stream the record bytes to the file through a pinned bounce buffer
+        const size_t chunk = (size_t)64 << 20;
+        void *pin = nullptr;
+        if (e == hipSuccess) e = hipHostMalloc(&pin, std::min(chunk, words * 4));
+        for (size_t off = 0; e == hipSuccess && io_ok && off < words * 4; off += chunk) {
+          const size_t nbytes = std::min(chunk, words * 4 - off);
+          e = hipMemcpyAsync(pin, (const char *)out + off, nbytes, hipMemcpyDeviceToHost, stream);
+          if (e == hipSuccess) e = hipStreamSynchronize(stream);
+          if (e == hipSuccess) io_ok = fwrite(pin, 1, nbytes, fh) == nbytes;
+        }
+        if (pin) (void)hipHostFree(pin);
+        if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_DEVICE, std::string("partoutput: ") + hipGetErrorString(e)); }
+      }
+    }
+    {   // the closing record, partoutput.f90:182-184
+      std::vector<unsigned char> rec(reclen + 8);
+      unsigned char *p = rec.data();
+      const int32_t rl = reclen, m5 = -99999;
+      const H m4 = (H)-9999.9;
+      memcpy(p, &rl, 4); p += 4;
+      memcpy(p, &m5, 4); p += 4;
+      for (int j = 0; j < 3; j++) { memcpy(p, &m4, sizeof(H)); p += sizeof(H); }
+      memcpy(p, &m5, 4); p += 4;
+      for (int j = 0; j < 7 + cfg.nspec; j++) { memcpy(p, &m4, sizeof(H)); p += sizeof(H); }
+      memcpy(p, &rl, 4);
+      io_ok = io_ok && fwrite(rec.data(), 1, rec.size(), fh) == rec.size();
+    }
+    io_ok = (fclose(fh) == 0) && io_ok;
+    fh = nullptr;
+    cleanup();
+    if (!io_ok) return fail(FPX_ERR_ARG, std::string("partoutput: write error on ") + path);
+    if (nrec) *nrec = count;
+    return 0;
+  }
+
+  int partoutput(int itime, const char *path, int64_t *nrec) override {
+    if (!path) return fail(FPX_ERR_ARG, "partoutput: null path");
+    if (!height_set || !window_set || !slot_loaded[0] || !slot_loaded[1]) return fail(FPX_ERR_STATE, "partoutput: height, both field slots and the wind-time window must be set first");
+    for (int i = 0; i < 9; i++)
+      if (!diag_have[i]) return fail(FPX_ERR_STATE, "partoutput: oro, pv, qv, tt (fpx_upload_diag_fields or fpx_verttransform_ecmwf) and tropopause of both slots are needed");
+    return cfg.host_real_bytes == 4 ? partoutput_t<float>(itime, path, nrec) : partoutput_t<double>(itime, path, nrec);
   }
 
   int set_windtime(const int32_t mt[2], const int32_t mi[2]) override {
@@ -2090,6 +2352,8 @@ int fpx_destroy(fpx_handle h) {
 int fpx_set_height(fpx_handle h, const void *height, int32_t n) { FPX_GUARD(h); return h->impl->set_height(height, n); }
 int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f) { FPX_GUARD(h); return h->impl->upload_fields(slot, f); }
 int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) { FPX_GUARD(h); return h->impl->verttransform(slot, m, sfc, out); }
+int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f) { FPX_GUARD(h); return h->impl->upload_diag_fields(slot, f); }
+int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles) { FPX_GUARD(h); return h->impl->partoutput(itime, path, nparticles); }
 int fpx_verttransform_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_verttransform_time: null"); *ms = h->impl->vt_ms(); return FPX_OK; }
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]) { FPX_GUARD(h); return h->impl->set_windtime(memtime, memind); }
 int fpx_rng_fill_table(fpx_handle h) { FPX_GUARD(h); return h->impl->rng_fill_table(); }

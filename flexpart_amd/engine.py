@@ -195,6 +195,29 @@ class Engine:
         out["device_ms"] = ms.value
         return out
 
+    def upload_diag_fields_from_scenario(self, sc):
+        """oro and, for both slots, pv, qv, tt (compact arrays) -> fpx_upload_diag_fields."""
+        from ._lib import FpxDiagFields
+        rt = self.hreal
+        oro = np.zeros((self.nymax, self.nxmax), rt)
+        oro[: self.ny, : self.nx] = sc["oro"]
+        f = FpxDiagFields()
+        f.oro = oro.ctypes.data
+        check(self.lib.fpx_upload_diag_fields(self.h, 0, C.byref(f)), "fpx_upload_diag_fields")
+        for m in (0, 1):
+            keep = {}
+            f = FpxDiagFields()
+            for k in ("pv", "qv", "tt"):
+                keep[k] = self._host3(sc[k], m)
+                setattr(f, k, keep[k].ctypes.data)
+            check(self.lib.fpx_upload_diag_fields(self.h, m + 1, C.byref(f)), "fpx_upload_diag_fields")
+
+    def partoutput(self, itime, path):
+        """fpx_partoutput: writes the reference's partposit_* dump to `path`; returns the number of particle records."""
+        n = C.c_int64(0)
+        check(self.lib.fpx_partoutput(self.h, int(itime), str(path).encode(), C.byref(n)), "fpx_partoutput")
+        return int(n.value)
+
     def upload_nests_from_scenario(self, sc):
         """One nested grid: geometry as gridcheck_nests.f90:362-378 derives it, fields uun, vvn, ..."""
         rt = self.hreal

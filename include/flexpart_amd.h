@@ -187,6 +187,24 @@ typedef struct {
 int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out);
 /* device time of the transform kernels of the last call, milliseconds */
 int fpx_verttransform_time(fpx_handle h, double *ms);
+/* ---- partoutput: the binary particle dump (SURVEY section 8 f, item 4) ----------------------
+ * Replaces `call partoutput(itime)` (timemanager.f90:454; the routine: partoutput.f90:63-190):
+ * for every particle with itra1 == itime the device interpolates oro, pv, qv, tt, rho, hmix and
+ * tropopause to the particle position exactly as the routine does and builds the records of the
+ * file partposit_<date> / partposit_end (Fortran sequential unformatted, 4-byte record markers) in
+ * particle-number order; the host streams the bytes to `path`.  The file is byte-identical to the
+ * reference's, in the host's real kind.  No particle array travels to the host.
+ * The fields the particle path itself does not use are kept on the device in the host's layout:
+ * oro (0:nxmax-1,0:nymax-1) com_mod.f90:342 and pv, qv, tt (0:nxmax-1,0:nymax-1,nzmax) of a slot,
+ * com_mod.f90:360-369.  fpx_verttransform_ecmwf retains pv, qv, tt of its slot by itself; slot 0
+ * uploads oro only.  NULL members are skipped. */
+typedef struct {
+  const void *oro;
+  const void *pv, *qv, *tt;
+} fpx_diag_fields;
+int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f);
+/* nparticles (may be NULL): number of particle records written */
+int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]);
 
