@@ -28,7 +28,8 @@ module flexgpu_mod
             flexgpu_set_windtime, flexgpu_upload_particles, flexgpu_download_particles, &
             flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error, &
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
-            flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform
+            flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
+            flexgpu_upload_diag_fields, flexgpu_partoutput
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields
 #endif
@@ -77,6 +78,10 @@ module flexgpu_mod
     type(c_ptr) :: height
     type(c_ptr) :: nmixz
   end type fpx_fields_out
+
+  type, bind(C) :: fpx_diag_fields
+    type(c_ptr) :: oro, pv, qv, tt
+  end type fpx_diag_fields
 
   integer, parameter :: FPX_MAXNESTS = 4
   type, bind(C) :: fpx_nests
@@ -133,6 +138,19 @@ module flexgpu_mod
       type(fpx_fields), intent(in) :: sfc
       type(fpx_fields_out), intent(in) :: o
     end function fpx_verttransform_ecmwf
+    integer(c_int) function fpx_upload_diag_fields(h, slot, f) bind(C, name='fpx_upload_diag_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_diag_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: slot
+      type(fpx_diag_fields), intent(in) :: f
+    end function fpx_upload_diag_fields
+    integer(c_int) function fpx_partoutput(h, itime, path, nrec) bind(C, name='fpx_partoutput')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t, c_char
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: itime
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int64_t), intent(out) :: nrec
+    end function fpx_partoutput
     integer(c_int) function fpx_nests_init(h, n) bind(C, name='fpx_nests_init')
       import :: c_ptr, c_int, fpx_nests
       type(c_ptr), value :: h
@@ -430,6 +448,43 @@ contains
     nmixz = nmixz_c
     first = .false.
   end subroutine flexgpu_verttransform
+
+  ! oro (slot = 0) or pv, qv, tt of one time slot: the fields only partoutput reads.  Not needed for
+  ! slots that went through flexgpu_verttransform (the device keeps its own pv, qv, tt then).
+  subroutine flexgpu_upload_diag_fields(slot, ierr)
+    integer, intent(in) :: slot
+    integer, intent(out) :: ierr
+    type(fpx_diag_fields) :: f
+    f%oro = loc_r(oro); f%pv = c_null_ptr; f%qv = c_null_ptr; f%tt = c_null_ptr
+    if (slot .ge. 1) then
+      f%pv = loc_r(pv(0,0,1,slot)); f%qv = loc_r(qv(0,0,1,slot)); f%tt = loc_r(tt(0,0,1,slot))
+    end if
+    ierr = fpx_upload_diag_fields(flexgpu_handle, int(slot, c_int32_t), f)
+  end subroutine flexgpu_upload_diag_fields
+
+  ! Replaces `call partoutput(itime)` (timemanager.f90:454): same file name (partoutput.f90:63-86),
+  ! same bytes; the particles stay on the device.
+  subroutine flexgpu_partoutput(itime, ierr, nrecords)
+    integer, intent(in) :: itime
+    integer, intent(out) :: ierr
+    integer(c_int64_t), intent(out), optional :: nrecords
+    real(kind=dp) :: jul
+    integer :: jjjjmmdd, ihmmss
+    character :: adate*8, atime*6
+    character(len=200) :: fname
+    integer(c_int64_t) :: nrec
+    jul = bdate + real(itime, kind=dp) / 86400._dp
+    call caldate(jul, jjjjmmdd, ihmmss)
+    write(adate, '(i8.8)') jjjjmmdd
+    write(atime, '(i6.6)') ihmmss
+    if (ipout .eq. 1 .or. ipout .eq. 3) then
+      fname = path(2)(1:length(2)) // 'partposit_' // adate // atime
+    else
+      fname = path(2)(1:length(2)) // 'partposit_end'
+    end if
+    ierr = fpx_partoutput(flexgpu_handle, int(itime, c_int32_t), trim(fname) // c_null_char, nrec)
+    if (present(nrecords)) nrecords = nrec
+  end subroutine flexgpu_partoutput
 
   ! one time slot of the com_mod fields (slot = the value found in memind(k))
   subroutine flexgpu_upload_fields(slot, ierr)

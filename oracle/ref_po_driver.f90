@@ -7,15 +7,22 @@
 ! This file is our own code: it contains no reference source, only calls into it and
 ! assignments to its module variables.
 !
-! Usage:  poref_rK scenario.bin outdir/
+! Usage:  poref_rK scenario.bin outdir/ [gpu]
+!   gpu: the same com_mod arrays go to the MI355X engine through flexpart_amd/fortran/flexgpu_mod.f90 and
+!        flexgpu_partoutput writes the file instead of the Fortran routine (needs a GPU).
 ! Record format as oracle/ref_driver.f90: {name*16, dtype i4 (1=i32, 2=f64), count i8, payload};
 ! fields travel compact, (nx,ny[,nz],slot) x fastest, as f64.
 
 program poref
   use par_mod
   use com_mod
+  use point_mod
+  use flexgpu_mod
   implicit none
 
+  integer :: use_gpu, gerr
+  character(len=256) :: gmsg
+  character(len=16) :: arg3
   integer, parameter :: uin=31
   character(len=512) :: fscen, fout
   character(len=16) :: name
@@ -28,6 +35,11 @@ program poref
 
   call get_command_argument(1, fscen)
   call get_command_argument(2, fout)
+  use_gpu = 0
+  if (command_argument_count() .ge. 3) then
+    call get_command_argument(3, arg3)
+    if (trim(arg3) .eq. 'gpu') use_gpu = 1
+  end if
   path(2) = trim(fout)
   length(2) = len_trim(fout)
   ipout = 2                      ! -> file name partposit_end (partoutput.f90:84-86)
@@ -88,7 +100,34 @@ program poref
   end do
   close(uin)
 
-  call partoutput(itime_out)
+  if (use_gpu .eq. 1) then
+    ! run switches flexgpu_init reads (no particle step is taken here)
+    ldirect=1; lsynctime=900; method=1; mintime=1; ctl=0.2; ifine=4; turbswitch=.true.; cblflag=0
+    mdomainfill=0; lsettling=.false.; DRYDEP=.false.; nageclass=1; lage(1)=999999999
+    xglobal=.false.; nglobal=.false.; sglobal=.false.; switchnorthg=999999.; switchsouthg=999999.
+    dxconst=180./(dx*r_earth*pi); dyconst=180./(dy*r_earth*pi)
+    do i=2,nz
+      if (height(i).gt.hmixmax) then
+        nmixz=i; exit
+      end if
+    end do
+    numpoint=1; allocate(xmass(1,maxspec), npart(1)); xmass=1.; npart(1)=max(np,1)
+    ustar=0.3; wstar=1.; oli=0.01
+    call flexgpu_init(gerr, nmaxpart=max(np,1))
+    if (gerr .eq. 0) call flexgpu_upload_fields(1, gerr)
+    if (gerr .eq. 0) call flexgpu_upload_fields(2, gerr)
+    if (gerr .eq. 0) call flexgpu_set_windtime(gerr)
+    if (gerr .eq. 0) call flexgpu_upload_diag_fields(0, gerr)
+    if (gerr .eq. 0) call flexgpu_upload_diag_fields(1, gerr)
+    if (gerr .eq. 0) call flexgpu_upload_diag_fields(2, gerr)
+    if (gerr .eq. 0 .and. np .gt. 0) call flexgpu_upload_particles(1, np, gerr)
+    if (gerr .eq. 0) call flexgpu_partoutput(itime_out, gerr)
+    if (gerr .ne. 0) then
+      call flexgpu_last_error(gmsg); write(*,*) 'flexgpu: ', trim(gmsg); stop 1
+    end if
+  else
+    call partoutput(itime_out)
+  end if
 
 contains
   subroutine get2(a)

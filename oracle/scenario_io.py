@@ -164,7 +164,7 @@ def have_po_ref(kind="r8"):
     return os.access(os.path.join(HERE, "_ref", f"poref_{kind}"), os.X_OK)
 
 
-def run_po_reference(sc, kind="r8", workdir="/tmp"):
+def run_po_reference(sc, kind="r8", workdir="/tmp", gpu=False):
     """The unmodified partoutput on a scenario dict -> bytes of the file partposit_end it wrote."""
     import shutil
     import tempfile
@@ -182,7 +182,7 @@ def run_po_reference(sc, kind="r8", workdir="/tmp"):
                 fh.write(a.tobytes())
             fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
         exe = os.path.join(HERE, "_ref", f"poref_{kind}")
-        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/"], capture_output=True, text=True)
+        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/" + (" gpu" if gpu else "")], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"reference partoutput driver failed: {res.stdout}\n{res.stderr}")
         with open(os.path.join(d, "partposit_end"), "rb") as fh:

@@ -103,3 +103,16 @@ def test_hip_partoutput_against_reference_file(built, tmp_path):
     eng.partoutput(3600, path)
     eng.close()
     assert path.read_bytes() == open(os.path.join(HERE, "golden", "po_s2_r8.bin"), "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_host_partoutput(built, kind):
+    """The real Fortran host: oracle/_ref/poref_rK holds the reference's com_mod arrays and either calls the
+    reference's partoutput or hands the same arrays to the engine (flexgpu_upload_fields / _diag_fields /
+    _particles, ISO_C_BINDING) and lets flexgpu_partoutput write the file: same name, same bytes."""
+    from oracle import scenario_io as sio
+    if not sio.have_po_ref(kind):
+        pytest.skip("oracle/_ref binaries not present in this snapshot")
+    sc = scenario(2, n=1200, seed=5)
+    assert sio.run_po_reference(sc, kind, gpu=True) == sio.run_po_reference(sc, kind)
