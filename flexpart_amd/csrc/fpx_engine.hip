@@ -418,17 +418,20 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
 // ---------------------------------------------------------------------------
 template <typename H>
 struct DiagP {
-  const H *oro, *pv[2], *qv[2], *tt[2], *tropo[2];   // host layout (ix,jy[,level]), strides nxmax, nymax
+  const H *oro, *tropo[2];   // host layout (ix,jy), stride nxmax
+  const H *d3;               // [jy][ix][iz][slot][3] = (pv, qv, tt): z fastest like the wind pack, one 96-byte run per corner column
   int nxmax, nymax;
   H dx, dy, xlon0, ylat0;
 };
 
+// Both kernels run over the device slots (cell-sorted after a locality sort: coalesced state reads, gathers with
+// the locality of the particle step); the file order is the particle number, so the selection flag and the
+// record position are indexed by P.pid.
 template <typename R>
-__global__ void k_po_flags(Parts<R> P, const unsigned int *__restrict__ slot_of_pid, long long n, int itime, unsigned int *__restrict__ flags) {
-  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= n) return;
-  const long long s = slot_of_pid ? slot_of_pid[pid] : pid;
-  flags[pid] = P.itra1[s] == itime ? 1u : 0u;
+__global__ void k_po_flags(Parts<R> P, long long n, int itime, unsigned int *__restrict__ flags) {
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  flags[P.pid[s]] = P.itra1[s] == itime ? 1u : 0u;
 }
 
 __device__ __forceinline__ unsigned int *po_put(unsigned int *w, float v) { *w = __float_as_uint(v); return w + 1; }
@@ -439,13 +442,12 @@ __device__ __forceinline__ unsigned int *po_put(unsigned int *w, double v) {
 }
 
 template <typename R, typename H>
-__global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, DiagP<H> D, const unsigned int *__restrict__ slot_of_pid,
-                                                       const unsigned int *__restrict__ flags, const unsigned int *__restrict__ recidx,
+__global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, DiagP<H> D, const unsigned int *__restrict__ recidx,
                                                        long long n, int itime, unsigned int *__restrict__ out) {
 #pragma clang fp contract(off)
-  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (pid >= n || !flags[pid]) return;
-  const long long s = slot_of_pid ? slot_of_pid[pid] : pid;
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n || P.itra1[s] != itime) return;
+  const unsigned int pid = P.pid[s];
   const int nx = V.nx, ny = V.ny, nz = V.nz, nspec = V.nspec;
   const int reclen = 8 + (10 + nspec) * (int)sizeof(H);
   const H dt1 = (H)(itime - V.memtime0), dt2 = (H)(V.memtime1 - itime);   // partoutput.f90:69-71
@@ -462,7 +464,11 @@ __global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, Di
   if (jyp >= D.nymax) jyp = jyp - 1;                                      // :119-121
   if (ixp >= D.nxmax) ixp = D.nxmax - 1;                                  // guard (weight 0 there)
   auto h2 = [&](const H *f, int i, int j) { return f[(size_t)i + (size_t)D.nxmax * (size_t)j]; };
-  auto h3 = [&](const H *f, int i, int j, int k) { return f[(size_t)i + (size_t)D.nxmax * ((size_t)j + (size_t)D.nymax * (size_t)(k - 1))]; };
+  // component c of (pv, qv, tt) at level k, slot h; elements of the host's padding read as 0 like rho below
+  auto d3 = [&](int c, int i, int j, int k, int h) -> H {
+    if (i >= nx || j >= ny) return (H)0;
+    return D.d3[((((size_t)j * nx + i) * nz + (k - 1)) * 2 + h) * 3 + c];
+  };
   // rho and hmix live in the gather packs (compact nx, ny; elements of the host's padding read as 0)
   auto rho_at = [&](int i, int j, int k, int slot) -> H {
     if (i >= nx || j >= ny) return (H)0;
@@ -487,9 +493,9 @@ __global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, Di
 #pragma unroll
     for (int m = 0; m < 2; m++) {
       const int h = slot[m];
-      pv1[m] = p1 * h3(D.pv[h], ix, jy, ind) + p2 * h3(D.pv[h], ixp, jy, ind) + p3 * h3(D.pv[h], ix, jyp, ind) + p4 * h3(D.pv[h], ixp, jyp, ind);
-      qv1[m] = p1 * h3(D.qv[h], ix, jy, ind) + p2 * h3(D.qv[h], ixp, jy, ind) + p3 * h3(D.qv[h], ix, jyp, ind) + p4 * h3(D.qv[h], ixp, jyp, ind);
-      tt1[m] = p1 * h3(D.tt[h], ix, jy, ind) + p2 * h3(D.tt[h], ixp, jy, ind) + p3 * h3(D.tt[h], ix, jyp, ind) + p4 * h3(D.tt[h], ixp, jyp, ind);
+      pv1[m] = p1 * d3(0, ix, jy, ind, h) + p2 * d3(0, ixp, jy, ind, h) + p3 * d3(0, ix, jyp, ind, h) + p4 * d3(0, ixp, jyp, ind, h);
+      qv1[m] = p1 * d3(1, ix, jy, ind, h) + p2 * d3(1, ixp, jy, ind, h) + p3 * d3(1, ix, jyp, ind, h) + p4 * d3(1, ixp, jyp, ind, h);
+      tt1[m] = p1 * d3(2, ix, jy, ind, h) + p2 * d3(2, ixp, jy, ind, h) + p3 * d3(2, ix, jyp, ind, h) + p4 * d3(2, ixp, jyp, ind, h);
       rho1[m] = p1 * rho_at(ix, jy, ind, h) + p2 * rho_at(ixp, jy, ind, h) + p3 * rho_at(ix, jyp, ind, h) + p4 * rho_at(ixp, jyp, ind, h);
     }
     pvprof[l] = (pv1[0] * dt2 + pv1[1] * dt1) * dtt;
@@ -844,6 +850,7 @@ struct EngineBase {
   virtual int get_receptors(void *creceptor, int ld, int allreduce, int clear) = 0;
   virtual void *stream_ptr() = 0;
   virtual double vt_ms() = 0;
+  virtual double po_ms() = 0;
   virtual int upload_diag_fields(int slot, const fpx_diag_fields *f) = 0;
   virtual int partoutput(int itime, const char *path, int64_t *nrec) = 0;
 };
@@ -1102,7 +1109,7 @@ struct Engine : EngineBase {
     if ((rc = p2(f->wstar, V.sfc, 8, s * 4 + 1))) return rc;
     if ((rc = p2(f->oli, V.sfc, 8, s * 4 + 2))) return rc;
     if ((rc = p2(f->hmix, V.sfc, 8, s * 4 + 3))) return rc;
-    if ((rc = diag_from_host(DG_TROPO + s, f->tropopause))) return rc;   // partoutput interpolates it in time
+    if ((rc = diag_alloc()) || (rc = diag2_from_host(diag_tropo[s], f->tropopause, DG_TROPO + s))) return rc;   // partoutput interpolates it in time
     if (slot == 1) {   // literal time index 1 uses: advance.f90:253, get_settling.f90:83-84
       if ((rc = p2(f->tropopause, V.tropo, 1, 0))) return rc;
       if (V.rhott) {
@@ -1271,9 +1278,9 @@ struct Engine : EngineBase {
     if ((rc = p2(sfc->ustar, V.sfc, 8, s * 4 + 0)) || (rc = p2(sfc->wstar, V.sfc, 8, s * 4 + 1)) ||
         (rc = p2(sfc->oli, V.sfc, 8, s * 4 + 2)) || (rc = p2(sfc->hmix, V.sfc, 8, s * 4 + 3))) return rc;
     if (slot == 1) { if ((rc = p2(sfc->tropopause, V.tropo, 1, 0))) return rc; }
-    if ((rc = diag_from_host(DG_TROPO + s, sfc->tropopause))) return rc;
+    if ((rc = diag_alloc()) || (rc = diag2_from_host(diag_tropo[s], sfc->tropopause, DG_TROPO + s))) return rc;
     // pv, qv, tt of this slot stay on the device for partoutput
-    if ((rc = diag_from_device(DG_PV + s, D(PV))) || (rc = diag_from_device(DG_QV + s, D(QV))) || (rc = diag_from_device(DG_TT + s, D(TT)))) return rc;
+    if ((rc = diag3(D(PV), true, 0, s)) || (rc = diag3(D(QV), true, 1, s)) || (rc = diag3(D(TT), true, 2, s))) return rc;
     if (V.vdep) {
       const size_t plane = n2 * cfg.host_real_bytes;
       for (int ks = 0; ks < cfg.nspec; ks++)
@@ -1296,7 +1303,8 @@ struct Engine : EngineBase {
     slot_loaded[s] = true;
     return 0;
   }
-  double vt_last_ms = 0;
+  double vt_last_ms = 0, po_last_ms = 0;
+  double po_ms() override { return po_last_ms; }
   double vt_ms() override { return vt_last_ms; }
 
   int verttransform(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) override {
@@ -1312,47 +1320,61 @@ struct Engine : EngineBase {
 
 
   // ---- partoutput -------------------------------------------------------
-  void *diag_dev[9] = {};          // oro, pv[2], qv[2], tt[2], tropopause[2] in the host's real kind and layout
-  bool diag_have[9] = {};
+  void *diag_oro = nullptr, *diag_tropo[2] = {nullptr, nullptr}, *diag_d3 = nullptr;   // in the host's real kind
+  bool diag_have[9] = {};          // oro | pv, qv, tt of slot 1, 2 | tropopause of slot 1, 2
   enum { DG_ORO = 0, DG_PV = 1, DG_QV = 3, DG_TT = 5, DG_TROPO = 7 };
-  int diag_buf(int i, void **q) {
-    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax, n = (i == DG_ORO || i >= DG_TROPO) ? n2 : n2 * cfg.nz;
-    if (!diag_dev[i]) {
-      char *p = nullptr;
-      int rc = dalloc(&p, n * cfg.host_real_bytes);
-      if (rc) return rc;
-      diag_dev[i] = p;
+  int diag_alloc() {
+    int rc;
+    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax * cfg.host_real_bytes;
+    char *p = nullptr;
+    if (!diag_oro) { if ((rc = dalloc(&p, n2))) return rc; diag_oro = p; HIPCHK(hipMemsetAsync(p, 0, n2, stream)); }
+    for (int m = 0; m < 2; m++)
+      if (!diag_tropo[m]) { if ((rc = dalloc(&p, n2))) return rc; diag_tropo[m] = p; HIPCHK(hipMemsetAsync(p, 0, n2, stream)); }
+    if (!diag_d3) {
+      const size_t n = (size_t)cfg.nx * cfg.ny * cfg.nz * 6 * cfg.host_real_bytes;
+      if ((rc = dalloc(&p, n))) return rc;
+      diag_d3 = p;
+      HIPCHK(hipMemsetAsync(p, 0, n, stream));
     }
-    *q = diag_dev[i];
     return 0;
   }
-  int diag_from_host(int i, const void *host) {
-    void *q;
-    int rc = diag_buf(i, &q);
-    if (rc) return rc;
-    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax, n = (i == DG_ORO || i >= DG_TROPO) ? n2 : n2 * cfg.nz;
-    HIPCHK(hipMemcpyAsync(q, host, n * cfg.host_real_bytes, hipMemcpyHostToDevice, stream));
+  int diag2_from_host(void *dev, const void *host, int have) {
+    HIPCHK(hipMemcpyAsync(dev, host, (size_t)cfg.nxmax * cfg.nymax * cfg.host_real_bytes, hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    diag_have[i] = true;
+    diag_have[have] = true;
     return 0;
   }
-  int diag_from_device(int i, const void *dev) {
-    void *q;
-    int rc = diag_buf(i, &q);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(q, dev, (size_t)cfg.nxmax * cfg.nymax * cfg.nz * cfg.host_real_bytes, hipMemcpyDeviceToDevice, stream));
-    diag_have[i] = true;
+  // one 3-D field in the host's layout (host memory, or device memory when `on_device`) -> component c of slot s of d3
+  template <typename H>
+  int diag3_pack(const void *src, bool on_device, int c, int s) {
+    const size_t n = (size_t)cfg.nxmax * cfg.nymax * cfg.nz;
+    const H *in = (const H *)src;
+    if (!on_device) {
+      int rc = ensure_staging(n * sizeof(H));
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(staging, src, n * sizeof(H), hipMemcpyHostToDevice, stream));
+      in = (const H *)staging;
+    }
+    dim3 grid((cfg.nx + 31) / 32, (cfg.nz + 31) / 32, cfg.ny), block(32, 8);
+    k_pack3<H, H><<<grid, block, 0, stream>>>(in, (H *)diag_d3, cfg.nx, cfg.ny, cfg.nz, cfg.nxmax, cfg.nymax, 6, s * 3 + c);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream));
+    diag_have[DG_PV + 2 * c + s] = true;
     return 0;
+  }
+  int diag3(const void *src, bool on_device, int c, int s) {
+    return cfg.host_real_bytes == 4 ? diag3_pack<float>(src, on_device, c, s) : diag3_pack<double>(src, on_device, c, s);
   }
   int upload_diag_fields(int slot, const fpx_diag_fields *f) override {
     if (!f || slot < 0 || slot > 2) return fail(FPX_ERR_ARG, "upload_diag_fields: slot 0 (oro only), 1 or 2");
     int rc;
-    if (f->oro && (rc = diag_from_host(DG_ORO, f->oro))) return rc;
+    if ((rc = diag_alloc())) return rc;
+    if (f->oro && (rc = diag2_from_host(diag_oro, f->oro, DG_ORO))) return rc;
     if (slot == 0) return 0;
     const int s = slot - 1;
-    if (f->pv && (rc = diag_from_host(DG_PV + s, f->pv))) return rc;
-    if (f->qv && (rc = diag_from_host(DG_QV + s, f->qv))) return rc;
-    if (f->tt && (rc = diag_from_host(DG_TT + s, f->tt))) return rc;
+    if (f->pv && (rc = diag3(f->pv, false, 0, s))) return rc;
+    if (f->qv && (rc = diag3(f->qv, false, 1, s))) return rc;
+    if (f->tt && (rc = diag3(f->tt, false, 2, s))) return rc;
     return 0;
   }
 
@@ -1385,7 +1407,10 @@ struct Engine : EngineBase {
         return fail(FPX_ERR_NOMEM, std::string("partoutput: ") + hipGetErrorString(e));
       }
       const int nb = (int)((n + kBlock - 1) / kBlock);
-      k_po_flags<R><<<nb, kBlock, 0, stream>>>(P, slot_of_pid, n, itime, flags);
+      hipEvent_t e0, e1;
+      (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, stream);
+      k_po_flags<R><<<nb, kBlock, 0, stream>>>(P, n, itime, flags);
       size_t tb = 0;
       (void)rocprim::exclusive_scan(nullptr, tb, flags, idx, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
       if ((e = hipMalloc(&tmp, std::max<size_t>(tb, 16))) != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, "partoutput: scan storage"); }
@@ -1396,19 +1421,23 @@ struct Engine : EngineBase {
       if (e == hipSuccess) e = hipStreamSynchronize(stream);
       if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_DEVICE, std::string("partoutput: ") + hipGetErrorString(e)); }
       count = last_idx + last_flag;
+      struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
       if (count > 0) {
         const size_t words = (size_t)count * recwords;
         if ((e = hipMalloc(&out, words * 4)) != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("partoutput: record buffer: ") + hipGetErrorString(e)); }
         DiagP<H> D;
-        D.oro = (const H *)diag_dev[DG_ORO];
-        for (int m = 0; m < 2; m++) {
-          D.pv[m] = (const H *)diag_dev[DG_PV + m]; D.qv[m] = (const H *)diag_dev[DG_QV + m];
-          D.tt[m] = (const H *)diag_dev[DG_TT + m]; D.tropo[m] = (const H *)diag_dev[DG_TROPO + m];
-        }
+        D.oro = (const H *)diag_oro;
+        D.tropo[0] = (const H *)diag_tropo[0]; D.tropo[1] = (const H *)diag_tropo[1];
+        D.d3 = (const H *)diag_d3;
         D.nxmax = cfg.nxmax; D.nymax = cfg.nymax;
         D.dx = (H)cfg.dx; D.dy = (H)cfg.dy; D.xlon0 = (H)cfg.xlon0; D.ylat0 = (H)cfg.ylat0;
-        k_partoutput<R, H><<<nb, kBlock, 0, stream>>>(V, P, D, slot_of_pid, flags, idx, n, itime, out);
+        k_partoutput<R, H><<<nb, kBlock, 0, stream>>>(V, P, D, idx, n, itime, out);
         e = hipGetLastError();
+        (void)hipEventRecord(e1, stream);
+        if (e == hipSuccess && hipEventSynchronize(e1) == hipSuccess) {
+          float ms = 0;
+          if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) po_last_ms = ms;
+        }
         // stream the record bytes to the file through a pinned bounce buffer
         const size_t chunk = (size_t)64 << 20;
         void *pin = nullptr;
@@ -2354,6 +2383,7 @@ int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f) { FPX_GUA
 int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) { FPX_GUARD(h); return h->impl->verttransform(slot, m, sfc, out); }
 int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f) { FPX_GUARD(h); return h->impl->upload_diag_fields(slot, f); }
 int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles) { FPX_GUARD(h); return h->impl->partoutput(itime, path, nparticles); }
+int fpx_partoutput_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_partoutput_time: null"); *ms = h->impl->po_ms(); return FPX_OK; }
 int fpx_verttransform_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_verttransform_time: null"); *ms = h->impl->vt_ms(); return FPX_OK; }
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]) { FPX_GUARD(h); return h->impl->set_windtime(memtime, memind); }
 int fpx_rng_fill_table(fpx_handle h) { FPX_GUARD(h); return h->impl->rng_fill_table(); }

@@ -216,6 +216,9 @@ class Engine:
         """fpx_partoutput: writes the reference's partposit_* dump to `path`; returns the number of particle records."""
         n = C.c_int64(0)
         check(self.lib.fpx_partoutput(self.h, int(itime), str(path).encode(), C.byref(n)), "fpx_partoutput")
+        ms = C.c_double(0)
+        check(self.lib.fpx_partoutput_time(self.h, C.byref(ms)), "fpx_partoutput_time")
+        self.partoutput_device_ms = ms.value
         return int(n.value)
 
     def upload_nests_from_scenario(self, sc):

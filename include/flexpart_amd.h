@@ -205,6 +205,8 @@ typedef struct {
 int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f);
 /* nparticles (may be NULL): number of particle records written */
 int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles);
+/* device time (selection, scan, record kernel) of the last fpx_partoutput call, milliseconds */
+int fpx_partoutput_time(fpx_handle h, double *ms);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]);
 
