@@ -23,19 +23,24 @@ def per_kernel(path):
     return agg
 
 
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: take the latest run's."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def main():
     tag, rnd = sys.argv[1], sys.argv[2]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     src = os.path.join(root, "gpurun_out", f"prof_{tag}")
     dst = os.path.join(root, "profiles", rnd)
     os.makedirs(dst, exist_ok=True)
-    st = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+    st = newest(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
     shutil.copy(st, os.path.join(dst, f"{tag}_kernel_stats.csv"))
     shutil.copy(os.path.join(src, "stats", "bench.json"), os.path.join(dst, f"{tag}_bench_under_rocprof.json"))
     out = {"note": __doc__.strip().splitlines()[2:], "kernels": {}}
-    sq = per_kernel(glob.glob(os.path.join(src, "sq", "*", "*counter_collection.csv"))[0])
-    fe = per_kernel(glob.glob(os.path.join(src, "fetch", "*", "*counter_collection.csv"))[0])
-    wr = per_kernel(glob.glob(os.path.join(src, "write", "*", "*counter_collection.csv"))[0])
+    sq = per_kernel(newest(os.path.join(src, "sq", "*", "*counter_collection.csv")))
+    fe = per_kernel(newest(os.path.join(src, "fetch", "*", "*counter_collection.csv")))
+    wr = per_kernel(newest(os.path.join(src, "write", "*", "*counter_collection.csv")))
     for k in sq:
         if "fpx::k_" not in k:
             continue
