@@ -94,6 +94,21 @@ build_po() {
   echo "build_ref: built $OUT/poref_$kind"
 }
 
+# readpartpositions (warm start) behind oracle/ref_rp_driver.f90 -> rpref_rK
+build_rp() {
+  local kind="$1"; shift
+  local flags="$*"
+  local obj="$OUT/obj_$kind"
+  ( cd "$obj"
+    for s in readpartpositions caldate juldate; do
+      [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
+    done
+    "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_rp_driver.f90" -o ref_rp_driver.o
+    "$FC" -O2 -mcmodel=medium $flags ref_rp_driver.o readpartpositions.o caldate.o juldate.o par_mod.o com_mod.o random_mod.o -o "$OUT/rpref_$kind"
+  )
+  echo "build_ref: built $OUT/rpref_$kind"
+}
+
 mkdir -p "$OUT"
 build_one r4 par_mod.f90
 build_one r8 par_mod.f90 -fdefault-real-8
@@ -101,6 +116,8 @@ build_vt r4
 build_vt r8 -fdefault-real-8
 build_po r4
 build_po r8 -fdefault-real-8
+build_rp r4
+build_rp r8 -fdefault-real-8
 # nested-grid variant: the stock par_mod.f90 has maxnests=0; the reference's own
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path
 build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build(force=False):
     """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
-    for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"), ("partoutput_oracle", "libpooracle")):
+    for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"), ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle")):
         src = os.path.join(HERE, stem + ".c")
         for kind, real in (("r4", "float"), ("r8", "double")):
             out = os.path.join(HERE, f"{lib}_{kind}.so")
@@ -392,3 +392,52 @@ def po_oracle(sc, kind="r8", nymax=None):
     if nb < 0:
         raise RuntimeError("poo_partoutput: buffer too small")
     return bytes(buf[:nb])
+
+
+# --------------------------------------------------------------------------
+# readpartpositions (oracle/readpart_oracle.c)
+# --------------------------------------------------------------------------
+class _RpoArgs(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ("nspec", "ldirect", "mintime", "itsplit", "nclassunc", "ibdatein", "ibtimein")]
+                + [(k, C.c_double) for k in ("bdate", "dx", "dy", "xlon0", "ylat0")]
+                + [("maxpart", C.c_long), ("numpart", C.c_long)]
+                + [(k, C.c_int) for k in ("numparticlecount", "itimein", "status")]
+                + [(k, C.POINTER(C.c_double)) for k in ("xtra1", "ytra1", "ztra1", "xmass1")]
+                + [(k, C.POINTER(C.c_int)) for k in ("npoint", "itramem", "nclass", "idt", "itra1", "itrasplit")])
+
+
+def juldate(yyyymmdd, hhmiss, kind="r8"):
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"librporacle_{kind}.so"))
+    lib.rpo_juldate.restype = C.c_double
+    return lib.rpo_juldate(int(yyyymmdd), int(hhmiss))
+
+
+def rp_oracle(file_bytes, rs, kind="r8"):
+    """Warm start from a dump: rs = dict(geom, nspec, restart=[ibdate, ibtime, ibdatein, ibtimein, ldirect, mintime,
+    itsplit, nclassunc, numpoint, maxpart]) -> dict of the particle arrays readpartpositions fills."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"librporacle_{kind}.so"))
+    r = [int(v) for v in rs["restart"]]
+    a = _RpoArgs()
+    a.nspec = int(rs["nspec"]); a.ldirect = r[4]; a.mintime = r[5]; a.itsplit = r[6]; a.nclassunc = r[7]
+    a.ibdatein, a.ibtimein = r[2], r[3]
+    a.bdate = juldate(r[0], r[1], kind)
+    a.dx, a.dy, a.xlon0, a.ylat0 = (float(v) for v in rs["geom"])
+    mp = r[9]
+    a.maxpart = mp
+    out = {k: np.zeros(mp) for k in ("xtra1", "ytra1", "ztra1")}
+    out["xmass1"] = np.zeros((a.nspec, mp))
+    for k in ("npoint", "itramem", "nclass", "idt", "itra1", "itrasplit"):
+        out[k] = np.zeros(mp, np.int32)
+    dp = C.POINTER(C.c_double); ip = C.POINTER(C.c_int)
+    for k, v in out.items():
+        setattr(a, k, v.ctypes.data_as(dp if v.dtype == np.float64 else ip))
+    buf = (C.c_ubyte * len(file_bytes)).from_buffer_copy(file_bytes)
+    rc = lib.rpo_readpartpositions(C.byref(a), buf, len(file_bytes))
+    if rc != 0:
+        raise RuntimeError("rpo_readpartpositions: malformed dump")
+    n = int(a.numpart)
+    res = {k: (v[:, :n] if v.ndim == 2 else v[:n]).copy() for k, v in out.items()}
+    res.update(numpart=n, numparticlecount=int(a.numparticlecount), itimein=int(a.itimein), status=int(a.status))
+    return res

@@ -189,3 +189,45 @@ def run_po_reference(sc, kind="r8", workdir="/tmp", gpu=False):
             return fh.read()
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+# --------------------------------------------------------------------------
+# readpartpositions through oracle/_ref/rpref_rK (oracle/ref_rp_driver.f90)
+# --------------------------------------------------------------------------
+def have_rp_ref(kind="r8"):
+    return os.access(os.path.join(HERE, "_ref", f"rpref_{kind}"), os.X_OK)
+
+
+def run_rp_reference(file_bytes, rs, kind="r8", workdir="/tmp"):
+    """The unmodified readpartpositions on a dump (bytes of partposit_end) -> dict of the arrays it filled."""
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="rp_", dir=workdir)
+    try:
+        with open(os.path.join(d, "partposit_end"), "wb") as fh:
+            fh.write(file_bytes)
+        fs = os.path.join(d, "rp.scen")
+        with open(fs, "wb") as fh:
+            for name, code, dt in (("geom", 2, np.float64), ("nspec", 1, np.int32), ("restart", 1, np.int32)):
+                a = np.ascontiguousarray(np.asarray(rs[name], dtype=dt).ravel())
+                fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
+                fh.write(a.tobytes())
+            fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
+        exe = os.path.join(HERE, "_ref", f"rpref_{kind}")
+        fo = os.path.join(d, "out.bin")
+        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/ {fo}"], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"reference readpartpositions driver failed: {res.stdout}\n{res.stderr}")
+        out = {}
+        xm = []
+        for name, a in read_records(fo):
+            if name == "xmass1":
+                xm.append(a)
+            elif name == "numpart":
+                out["numpart"], out["numparticlecount"] = int(a[0]), int(a[1])
+            else:
+                out[name] = a
+        out["xmass1"] = np.stack(xm)
+        return out
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
