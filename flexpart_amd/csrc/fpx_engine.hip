@@ -528,6 +528,43 @@ __global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, Di
   *w++ = (unsigned int)reclen;
 }
 
+// readpartpositions.f90:115-148 -- warm start: the records of a dump (as partoutput writes them) -> particle SoA.
+// One lane per record; arithmetic of the coordinate conversion in the host's real kind H.
+template <typename R, typename H>
+__global__ void __launch_bounds__(kBlock) k_readpart(Parts<R> P, const unsigned int *__restrict__ raw, long long n, int nspec,
+                                                     H dx, H dy, H xlon0, H ylat0, double jul_header, double bdate, int mintime,
+                                                     const int *__restrict__ nclass_in, int *__restrict__ status /* [0] error, [1] max npoint */) {
+#pragma clang fp contract(off)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int reclen = 8 + (10 + nspec) * (int)sizeof(H);
+  const unsigned int *w = raw + (size_t)i * (size_t)(reclen / 4 + 2);
+  auto get = [&](const unsigned int *q) -> H {
+    if (sizeof(H) == 4) return (H)__uint_as_float(q[0]);
+    return (H)__longlong_as_double((long long)(((unsigned long long)q[1] << 32) | (unsigned long long)q[0]));
+  };
+  const int hw = (int)sizeof(H) / 4;
+  if ((int)w[0] != reclen || (int)w[reclen / 4 + 1] != reclen) { atomicExch(&status[0], 1); return; }
+  const int npoint = (int)w[1];
+  const H xlonin = get(w + 2), ylatin = get(w + 2 + hw), zin = get(w + 2 + 2 * hw);
+  const int itramem_in = (int)w[2 + 3 * hw];
+  if (xlonin == (H)-9999.9) { atomicExch(&status[0], 2); return; }     // a closing record inside the file: several dumps
+  P.xt[i] = (double)((xlonin - xlon0) / dx);                              // :121-122
+  P.yt[i] = (double)((ylatin - ylat0) / dy);
+  P.zt[i] = (R)zin;
+  P.npoint[i] = npoint;
+  atomicMax(&status[1], npoint);                                          // numparticlecount, :123
+  const double julpartin = jul_header + (double)itramem_in / 86400.;      // :140-147
+  P.itramem[i] = (int)llround((julpartin - bdate) * (double)(H)86400.);
+  P.idt[i] = mintime;
+  P.itra1[i] = 0;
+  P.nclass[i] = nclass_in ? nclass_in[i] : 1;
+  P.up[i] = (R)0; P.vp[i] = (R)0; P.wp[i] = (R)0; P.us[i] = (R)0; P.vs[i] = (R)0; P.ws[i] = (R)0;
+  P.cbt[i] = 1; P.pid[i] = (unsigned int)i;
+  const unsigned int *x = w + 3 + 3 * hw + 7 * hw;
+  for (int ks = 0; ks < nspec; ks++) P.xmass1[(size_t)ks * P.cap + i] = (R)get(x + ks * hw);
+}
+
 // After the stable sort of the slots by their 3-bit key: list length = number of keys <= 4 (PBL
 // classes), particles due = number of keys <= 6.  One wave, two 64-ary searches (5 dependent
 // loads each at 1e8 keys).
@@ -853,6 +890,7 @@ struct EngineBase {
   virtual double po_ms() = 0;
   virtual int upload_diag_fields(int slot, const fpx_diag_fields *f) = 0;
   virtual int partoutput(int itime, const char *path, int64_t *nrec) = 0;
+  virtual int readpartpositions(const char *path, const fpx_restart *r, int64_t *numpart_out, int32_t *numparticlecount, int32_t *itimein) = 0;
 };
 
 template <typename R>
@@ -1479,6 +1517,121 @@ struct Engine : EngineBase {
     for (int i = 0; i < 9; i++)
       if (!diag_have[i]) return fail(FPX_ERR_STATE, "partoutput: oro, pv, qv, tt (fpx_upload_diag_fields or fpx_verttransform_ecmwf) and tropopause of both slots are needed");
     return cfg.host_real_bytes == 4 ? partoutput_t<float>(itime, path, nrec) : partoutput_t<double>(itime, path, nrec);
+  }
+
+
+  // ---- readpartpositions (warm start from the dump) -----------------------
+  // random_mod.f90:12-42 (ran1), for nclass when nclassunc > 1: one serial stream, seed -8
+  struct Ran1 {
+    int iv[32] = {}, iy = 0, idum = -8;
+    template <typename H>
+    H next() {
+      const int ia = 16807, im = 2147483647, iq = 127773, ir = 2836, ntab = 32, ndiv = 1 + (im - 1) / ntab;
+      const H am = (H)1. / (H)im, rnmx = (H)1. - (H)1.2e-7;
+      if (idum <= 0 || iy == 0) {
+        idum = std::max(-idum, 1);
+        for (int j = ntab + 8; j >= 1; j--) {
+          const int k = idum / iq;
+          idum = ia * (idum - k * iq) - ir * k;
+          if (idum < 0) idum += im;
+          if (j <= ntab) iv[j - 1] = idum;
+        }
+        iy = iv[0];
+      }
+      const int k = idum / iq;
+      idum = ia * (idum - k * iq) - ir * k;
+      if (idum < 0) idum += im;
+      const int j = 1 + iy / ndiv;
+      iy = iv[j - 1];
+      iv[j - 1] = idum;
+      return std::min(am * (H)iy, rnmx);
+    }
+  };
+
+  template <typename H>
+  int readpart_t(const char *path, const fpx_restart *r, int64_t *numpart_out, int32_t *numparticlecount, int32_t *itimein_out) {
+    FILE *fh = fopen(path, "rb");
+    if (!fh) return fail(FPX_ERR_ARG, std::string("readpartpositions: cannot open ") + path);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{fh};
+    if (fseek(fh, 0, SEEK_END) != 0) return fail(FPX_ERR_ARG, "readpartpositions: seek");
+    const long long size = ftell(fh);
+    rewind(fh);
+    const int reclen = 8 + (10 + cfg.nspec) * (int)sizeof(H);
+    const long long recbytes = reclen + 8;
+    int32_t hdr[3];
+    if (size < 12 + recbytes || fread(hdr, 4, 3, fh) != 3 || hdr[0] != 4 || hdr[2] != 4 || (size - 12) % recbytes != 0)
+      return fail(FPX_ERR_ARG, "readpartpositions: not a partposit dump of this build (record length = 8 + (10+nspec) reals)");
+    const int itimein = hdr[1];
+    const long long n = (size - 12) / recbytes - 1;
+    {   // the last record must be the closing one (xlonin = -9999.9, readpartpositions.f90:120)
+      std::vector<unsigned char> last((size_t)recbytes);
+      H xl;
+      if (fseek(fh, (long)(size - recbytes), SEEK_SET) != 0 || fread(last.data(), 1, (size_t)recbytes, fh) != (size_t)recbytes)
+        return fail(FPX_ERR_ARG, "readpartpositions: short read");
+      memcpy(&xl, last.data() + 8, sizeof(H));
+      if (!(xl == (H)-9999.9)) return fail(FPX_ERR_ARG, "readpartpositions: the file does not end with the closing record");
+      if (fseek(fh, 12, SEEK_SET) != 0) return fail(FPX_ERR_ARG, "readpartpositions: seek");
+    }
+    if (n > P.cap) return fail(FPX_ERR_ARG, "readpartpositions: more particles in the dump than the engine holds (maxpart)");
+    // readpartpositions.f90:133-134: the previous run must end where this one starts
+    if (std::abs(r->jul_header + (double)itimein / 86400. - r->bdate) > 1.e-5)
+      return fail(FPX_ERR_ARG, "readpartpositions: ending time of the previous run does not agree with the start of this run");
+    int *d_status = nullptr, *d_nclass = nullptr;
+    unsigned int *raw = nullptr;
+    void *pin = nullptr;
+    auto cleanup = [&]() {
+      if (d_status) (void)hipFree(d_status);
+      if (d_nclass) (void)hipFree(d_nclass);
+      if (raw) (void)hipFree(raw);
+      if (pin) (void)hipHostFree(pin);
+    };
+    hipError_t e = hipMalloc(&d_status, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemsetAsync(d_status, 0, 2 * sizeof(int), stream);
+    int status[2] = {0, 0};
+    if (n > 0 && e == hipSuccess) {
+      const size_t bytes = (size_t)(n + 1) * recbytes;
+      e = hipMalloc(&raw, bytes);
+      const size_t chunk = (size_t)64 << 20;
+      if (e == hipSuccess) e = hipHostMalloc(&pin, std::min(chunk, bytes));
+      for (size_t off = 0; e == hipSuccess && off < bytes; off += chunk) {
+        const size_t nb = std::min(chunk, bytes - off);
+        if (fread(pin, 1, nb, fh) != nb) { cleanup(); return fail(FPX_ERR_ARG, "readpartpositions: short read"); }
+        e = hipMemcpyAsync((char *)raw + off, pin, nb, hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      }
+      if (e == hipSuccess && r->nclassunc > 1) {      // nclass(i)=min(int(ran1(idummy)*real(nclassunc))+1,nclassunc), :142-143
+        std::vector<int> nc((size_t)n);
+        Ran1 g;
+        for (long long i = 0; i < n; i++) nc[i] = std::min((int)(g.template next<H>() * (H)r->nclassunc) + 1, r->nclassunc);
+        e = hipMalloc(&d_nclass, (size_t)n * sizeof(int));
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nclass, nc.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      }
+      if (e == hipSuccess) {
+        k_readpart<R, H><<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, stream>>>(P, raw, n, cfg.nspec, (H)cfg.dx, (H)cfg.dy, (H)cfg.xlon0, (H)cfg.ylat0,
+                                                                                r->jul_header, r->bdate, r->mintime, d_nclass, d_status);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipMemcpyAsync(status, d_status, sizeof status, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    cleanup();
+    if (e != hipSuccess) return fail(FPX_ERR_DEVICE, std::string("readpartpositions: ") + hipGetErrorString(e));
+    if (status[0] != 0) return fail(FPX_ERR_ARG, status[0] == 1 ? "readpartpositions: record markers do not match this build's record length"
+                                                  : "readpartpositions: the file does not hold exactly one dump (header, records, closing record)");
+    numpart = n;
+    slot_of_pid = nullptr;
+    maybe_new = true;
+    if (numpart_out) *numpart_out = n;
+    if (numparticlecount) *numparticlecount = status[1];
+    if (itimein_out) *itimein_out = itimein;
+    return 0;
+  }
+  int readpartpositions(const char *path, const fpx_restart *r, int64_t *numpart_out, int32_t *numparticlecount, int32_t *itimein) override {
+    if (!path || !r) return fail(FPX_ERR_ARG, "readpartpositions: null argument");
+    if (r->nclassunc < 1) return fail(FPX_ERR_ARG, "readpartpositions: nclassunc >= 1");
+    return cfg.host_real_bytes == 4 ? readpart_t<float>(path, r, numpart_out, numparticlecount, itimein)
+                                    : readpart_t<double>(path, r, numpart_out, numparticlecount, itimein);
   }
 
   int set_windtime(const int32_t mt[2], const int32_t mi[2]) override {
@@ -2383,6 +2536,10 @@ int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f) { FPX_GUA
 int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) { FPX_GUARD(h); return h->impl->verttransform(slot, m, sfc, out); }
 int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f) { FPX_GUARD(h); return h->impl->upload_diag_fields(slot, f); }
 int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles) { FPX_GUARD(h); return h->impl->partoutput(itime, path, nparticles); }
+int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r, int64_t *numpart, int32_t *numparticlecount, int32_t *itimein) {
+  FPX_GUARD(h);
+  return h->impl->readpartpositions(path, r, numpart, numparticlecount, itimein);
+}
 int fpx_partoutput_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_partoutput_time: null"); *ms = h->impl->po_ms(); return FPX_OK; }
 int fpx_verttransform_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_verttransform_time: null"); *ms = h->impl->vt_ms(); return FPX_OK; }
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]) { FPX_GUARD(h); return h->impl->set_windtime(memtime, memind); }

@@ -221,6 +221,16 @@ class Engine:
         self.partoutput_device_ms = ms.value
         return int(n.value)
 
+    def readpartpositions(self, path, jul_header, bdate, mintime, nclassunc=1):
+        """fpx_readpartpositions: warm start from the dump `path`; -> (numpart, numparticlecount, itimein)."""
+        from ._lib import FpxRestart
+        r = FpxRestart(float(jul_header), float(bdate), int(mintime), int(nclassunc))
+        n = C.c_int64(0); npc = C.c_int32(0); it = C.c_int32(0)
+        check(self.lib.fpx_readpartpositions(self.h, str(path).encode(), C.byref(r), C.byref(n), C.byref(npc), C.byref(it)),
+              "fpx_readpartpositions")
+        self.n = int(n.value)
+        return int(n.value), int(npc.value), int(it.value)
+
     def upload_nests_from_scenario(self, sc):
         """One nested grid: geometry as gridcheck_nests.f90:362-378 derives it, fields uun, vvn, ..."""
         rt = self.hreal

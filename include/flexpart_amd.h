@@ -207,6 +207,22 @@ int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f)
 int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles);
 /* device time (selection, scan, record kernel) of the last fpx_partoutput call, milliseconds */
 int fpx_partoutput_time(fpx_handle h, double *ms);
+/* ---- readpartpositions: warm start from a dump (SURVEY section 8 f, item 4) -------------------
+ * Replaces the part of `call readpartpositions` (FLEXPART.f90; the routine: readpartpositions.f90:115-148)
+ * that follows the `header` checks: the file partposit_end (one dump as partoutput / fpx_partoutput write
+ * it) is streamed to the device and parsed there into the particle arrays: xtra1 = (xlon-xlon0)/dx,
+ * ytra1, ztra1, npoint, xmass1, itramem re-based on this run's start, idt = mintime, itra1 = 0,
+ * nclass (ran1 stream, seed -8, when nclassunc > 1), turbulent state zero (the first step calls
+ * initialize() for every particle, timemanager.f90:553).  The host keeps reading `header`
+ * (:59-113) and passes what it found.  itrasplit stays a host array (ldirect*itsplit). */
+typedef struct {
+  double jul_header;   /* juldate(ibdatein,ibtimein) of the header file, readpartpositions.f90:133 */
+  double bdate;        /* com_mod bdate: start of this run                                        */
+  int32_t mintime;     /* com_mod.f90:112                                                          */
+  int32_t nclassunc;   /* par_mod.f90:188                                                          */
+} fpx_restart;
+int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
+                          int64_t *numpart, int32_t *numparticlecount, int32_t *itimein);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]);
 
