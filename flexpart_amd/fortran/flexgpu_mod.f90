@@ -29,7 +29,7 @@ module flexgpu_mod
             flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error, &
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
-            flexgpu_upload_diag_fields, flexgpu_partoutput
+            flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields
 #endif
@@ -82,6 +82,11 @@ module flexgpu_mod
   type, bind(C) :: fpx_diag_fields
     type(c_ptr) :: oro, pv, qv, tt
   end type fpx_diag_fields
+
+  type, bind(C) :: fpx_restart
+    real(c_double) :: jul_header, bdate
+    integer(c_int32_t) :: mintime, nclassunc
+  end type fpx_restart
 
   integer, parameter :: FPX_MAXNESTS = 4
   type, bind(C) :: fpx_nests
@@ -151,6 +156,14 @@ module flexgpu_mod
       character(kind=c_char), intent(in) :: path(*)
       integer(c_int64_t), intent(out) :: nrec
     end function fpx_partoutput
+    integer(c_int) function fpx_readpartpositions(h, path, r, np, npc, itimein) bind(C, name='fpx_readpartpositions')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t, c_char, fpx_restart
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: path(*)
+      type(fpx_restart), intent(in) :: r
+      integer(c_int64_t), intent(out) :: np
+      integer(c_int32_t), intent(out) :: npc, itimein
+    end function fpx_readpartpositions
     integer(c_int) function fpx_nests_init(h, n) bind(C, name='fpx_nests_init')
       import :: c_ptr, c_int, fpx_nests
       type(c_ptr), value :: h
@@ -485,6 +498,27 @@ contains
     ierr = fpx_partoutput(flexgpu_handle, int(itime, c_int32_t), trim(fname) // c_null_char, nrec)
     if (present(nrecords)) nrecords = nrec
   end subroutine flexgpu_partoutput
+
+  ! Replaces the second half of `call readpartpositions` (readpartpositions.f90:115-148): the host has read
+  ! the `header` file (:59-113) and passes its date and time; the dump path(2)//'partposit_end' is parsed
+  ! on the device.  Sets numpart, numparticlecount and itrasplit as the routine does.
+  subroutine flexgpu_readpartpositions(ibdatein, ibtimein, ierr)
+    integer, intent(in) :: ibdatein, ibtimein
+    integer, intent(out) :: ierr
+    type(fpx_restart) :: r
+    integer(c_int64_t) :: np
+    integer(c_int32_t) :: npc, itimein
+    real(kind=dp) :: juldate
+    r%jul_header = juldate(ibdatein, ibtimein)
+    r%bdate = bdate
+    r%mintime = mintime
+    r%nclassunc = nclassunc
+    ierr = fpx_readpartpositions(flexgpu_handle, path(2)(1:length(2)) // 'partposit_end' // c_null_char, r, np, npc, itimein)
+    if (ierr /= 0) return
+    numpart = int(np)
+    numparticlecount = npc
+    itrasplit(1:numpart) = ldirect * itsplit
+  end subroutine flexgpu_readpartpositions
 
   ! one time slot of the com_mod fields (slot = the value found in memind(k))
   subroutine flexgpu_upload_fields(slot, ierr)

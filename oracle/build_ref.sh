@@ -46,8 +46,10 @@ build_one() {
     for m in $MODS $SUBS; do objs="$objs $m.o"; done
     # links libflexpart_amd.so (the HIP engine) for the drop-in mode; found at run time
     # relative to the binary, which also lives inside the repo snapshot on the GPU box
-    [ "$obj/caldate.o" -nt "$REF/caldate.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/caldate.f90" -o caldate.o
-    "$FC" -O2 -mcmodel=medium $flags ref_driver.o flexgpu_mod.o caldate.o $objs \
+    for s in caldate juldate; do
+      [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
+    done
+    "$FC" -O2 -mcmodel=medium $flags ref_driver.o flexgpu_mod.o caldate.o juldate.o $objs \
         -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
         -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
         -o "$OUT/flexref_$kind"
@@ -66,7 +68,7 @@ build_vt() {
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_vt_driver.f90" -o ref_vt_driver.o
-    "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o flexgpu_mod.o caldate.o verttransform_ecmwf.o ew.o qvsat.o \
+    "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o flexgpu_mod.o caldate.o juldate.o verttransform_ecmwf.o ew.o qvsat.o \
         par_mod.o com_mod.o cmapf_mod.o point_mod.o unc_mod.o outg_mod.o \
         -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
         -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
@@ -104,7 +106,11 @@ build_rp() {
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_rp_driver.f90" -o ref_rp_driver.o
-    "$FC" -O2 -mcmodel=medium $flags ref_rp_driver.o readpartpositions.o caldate.o juldate.o par_mod.o com_mod.o random_mod.o -o "$OUT/rpref_$kind"
+    "$FC" -O2 -mcmodel=medium $flags ref_rp_driver.o flexgpu_mod.o readpartpositions.o caldate.o juldate.o \
+        par_mod.o com_mod.o random_mod.o point_mod.o unc_mod.o outg_mod.o \
+        -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
+        -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
+        -o "$OUT/rpref_$kind"
   )
   echo "build_ref: built $OUT/rpref_$kind"
 }

@@ -7,13 +7,20 @@
 ! calls the routine and dumps the particle arrays it filled.
 ! This file is our own code: it contains no reference source.
 !
-! Usage:  rpref_rK scenario.bin dir/ out.bin      (dir/ holds partposit_end; header is written there)
+! Usage:  rpref_rK scenario.bin dir/ out.bin [gpu]     (dir/ holds partposit_end; header is written there)
+!   gpu: flexgpu_readpartpositions (flexpart_amd/fortran/flexgpu_mod.f90) parses the dump on the MI355X and the
+!        particle arrays come back through flexgpu_download_particles (needs a GPU).
 ! Record format as oracle/ref_driver.f90.
 
 program rpref
   use par_mod
   use com_mod
+  use point_mod
+  use flexgpu_mod
   implicit none
+  integer :: use_gpu, gerr
+  character(len=256) :: gmsg
+  character(len=16) :: arg4
   integer, parameter :: uin=31, uout=32, uh=33
   character(len=512) :: fscen, fdir, fout
   character(len=16) :: name
@@ -27,6 +34,11 @@ program rpref
   call get_command_argument(1, fscen)
   call get_command_argument(2, fdir)
   call get_command_argument(3, fout)
+  use_gpu = 0
+  if (command_argument_count() .ge. 4) then
+    call get_command_argument(4, arg4)
+    if (trim(arg4) .eq. 'gpu') use_gpu = 1
+  end if
   path(2) = trim(fdir); length(2) = len_trim(fdir)
   nspec=1; ldirect=1; mintime=1; itsplit=999999999; numpoint=1; numxgrid=1
   ibdate=20200101; ibtime=0; ibdatein=20200101; ibtimein=0; maxp=1000
@@ -95,7 +107,21 @@ program rpref
   end do
   close(uh)
 
-  call readpartpositions
+  if (use_gpu .eq. 1) then
+    nx=10; ny=10; nz=3; nxmin1=9; nymin1=9; nmixz=2
+    ldirect=1; lsynctime=900; method=1; ctl=0.2; ifine=4; turbswitch=.true.; cblflag=0
+    mdomainfill=0; lsettling=.false.; DRYDEP=.false.; nageclass=1; lage(1)=999999999
+    xglobal=.false.; nglobal=.false.; sglobal=.false.; switchnorthg=999999.; switchsouthg=999999.
+    allocate(xmass(1,maxspec), npart(1)); xmass=1.; npart(1)=1
+    call flexgpu_init(gerr, nmaxpart=maxp, defer_height=.true.)
+    if (gerr .eq. 0) call flexgpu_readpartpositions(ibdatein, ibtimein, gerr)
+    if (gerr .eq. 0 .and. numpart .gt. 0) call flexgpu_download_particles(1, numpart, gerr)
+    if (gerr .ne. 0) then
+      call flexgpu_last_error(gmsg); write(*,*) 'flexgpu: ', trim(gmsg); stop 1
+    end if
+  else
+    call readpartpositions
+  end if
 
   open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')
   call put_i('numpart', (/numpart, numparticlecount/), 2)

@@ -198,7 +198,7 @@ def have_rp_ref(kind="r8"):
     return os.access(os.path.join(HERE, "_ref", f"rpref_{kind}"), os.X_OK)
 
 
-def run_rp_reference(file_bytes, rs, kind="r8", workdir="/tmp"):
+def run_rp_reference(file_bytes, rs, kind="r8", workdir="/tmp", gpu=False):
     """The unmodified readpartpositions on a dump (bytes of partposit_end) -> dict of the arrays it filled."""
     import shutil
     import tempfile
@@ -215,7 +215,7 @@ def run_rp_reference(file_bytes, rs, kind="r8", workdir="/tmp"):
             fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
         exe = os.path.join(HERE, "_ref", f"rpref_{kind}")
         fo = os.path.join(d, "out.bin")
-        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/ {fo}"], capture_output=True, text=True)
+        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/ {fo}" + (" gpu" if gpu else "")], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"reference readpartpositions driver failed: {res.stdout}\n{res.stderr}")
         out = {}

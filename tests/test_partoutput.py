@@ -197,3 +197,21 @@ def test_hip_readpartpositions_matches_oracle(built, tmp_path, kind):
     with pytest.raises(Exception):
         b.readpartpositions(path, jul, orc.juldate(20200101, 20000, kind), mintime=5)
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_host_readpartpositions(built, kind):
+    """The real Fortran host: oracle/_ref/rpref_rK either calls the reference's readpartpositions or lets the
+    engine parse the same dump (flexgpu_readpartpositions) and takes the arrays back into com_mod."""
+    from oracle import oracle as orc, scenario_io as sio
+    if not sio.have_rp_ref(kind):
+        pytest.skip("oracle/_ref binaries not present in this snapshot")
+    sc = scenario(2, n=800, seed=3)
+    dump = orc.po_oracle(sc, kind)
+    rs = restart_setup(sc, 2)
+    ref = sio.run_rp_reference(dump, rs, kind)
+    gpu = sio.run_rp_reference(dump, rs, kind, gpu=True)
+    assert gpu["numpart"] == ref["numpart"] and gpu["numparticlecount"] == ref["numparticlecount"]
+    for k in RP_KEYS + ("itrasplit",):
+        assert np.array_equal(gpu[k], ref[k]), k
