@@ -97,6 +97,28 @@ def measured_traffic(config, nper, kernel):
     return None
 
 
+def measured_valu(config, nper, kernel):
+    """VALU issue statistics of the dominant kernel from the same committed PMC summary: wave-instructions per
+    launch, lane utilisation (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU-equivalent)) and the share of
+    wave-cycles with a VALU instruction in flight.  For a VALU-bound kernel this, not the HBM fraction, is the
+    distance to the hardware limit."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"c{config}_{nper:.0e}_pmc.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        for name, e in d["kernels"].items():
+            if kernel in name:
+                sq = e["sq_last_launch"]
+                return {"insts_valu_per_launch": sq["SQ_INSTS_VALU"], "lane_utilisation": e["valu_lane_utilisation"],
+                        "valu_active_per_wave_cycle": e["valu_active_per_wave_cycle"],
+                        "source": os.path.relpath(files[-1], ROOT)}
+    except Exception:
+        return None
+    return None
+
+
 def cpu_baseline(args, sc, frac_pbl):
     """The reference itself (oracle/_ref, flang build of the unmodified Fortran) timed on this
     box's host cores on a bounded sample of the same workload; 1 core (the reference hot path
@@ -256,6 +278,9 @@ def main():
                      "limiter": ("gather address processing at 2 waves/SIMD, not HBM bandwidth" if args.config == 2
                                  else f"{'fp64' if rb == 8 else 'fp32'} VALU issue (about 3e5 lane-instructions per PBL particle-step)")},
     }
+    valu = measured_valu(args.config, nper, dom_name)
+    if valu is not None:
+        out["roofline"]["valu"] = valu
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         try:
             out["cpu_baseline"] = cpu_baseline(args, sc, frac_pbl)
