@@ -215,3 +215,35 @@ def test_fortran_host_readpartpositions(built, kind):
     assert gpu["numpart"] == ref["numpart"] and gpu["numparticlecount"] == ref["numparticlecount"]
     for k in RP_KEYS + ("itrasplit",):
         assert np.array_equal(gpu[k], ref[k]), k
+
+
+@pytest.mark.gpu
+def test_hip_partoutput_large_dump_properties(built, tmp_path):
+    """5e6 particles seeded on the device on the BASELINE grid (no host copy of them exists): the size-independent
+    properties of the dump -- file size from the number due, every record framed by its length, the closing record,
+    finite heights, and a second dump after a locality sort is byte-identical: the records are in particle-number
+    order whatever the device order is."""
+    import hashlib
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    sc = syn.base_scenario(ctl=5.0, ifine=4, nsteps=1)
+    sc["npart"] = 1
+    syn.add_partoutput_fields(sc, itime=0, dead_every=0)
+    del sc["npart"], sc["itra1"], sc["npoint"]
+    n = 5_000_000
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, max_particles=n, sort_interval=4)
+    eng.upload_diag_fields_from_scenario(sc)
+    eng.seed_particles(n, seed=0x5EED, frac_pbl=0.5)
+    p1, p2 = tmp_path / "a", tmp_path / "b"
+    assert eng.partoutput(0, p1) == n
+    eng.sort()
+    assert eng.partoutput(0, p2) == n
+    eng.close()
+    rl = 8 + 11 * 8
+    assert p1.stat().st_size == 12 + (n + 1) * (rl + 8)
+    h = [hashlib.sha256(p.read_bytes()).hexdigest() for p in (p1, p2)]
+    assert h[0] == h[1]
+    body = np.memmap(p1, np.uint8, mode="r", offset=12).reshape(n + 1, rl + 8)
+    assert (body[:, :4].view(np.int32) == rl).all() and (body[:, -4:].view(np.int32) == rl).all()
+    assert body[-1, 4:8].view(np.int32)[0] == -99999
+    z = body[:-1, 4 + 4 + 16:4 + 4 + 24].copy().view(np.float64)[:, 0]
+    assert np.isfinite(z).all() and z.min() >= 0.0

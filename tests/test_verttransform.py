@@ -197,3 +197,32 @@ def test_fortran_host_verttransform(built, kind, tol):
     assert gpu["nmixz"] == ref["nmixz"]
     worst = max_rel(gpu, ref, m)
     assert max(worst.values()) <= tol, worst
+
+
+@pytest.mark.gpu
+def test_hip_verttransform_at_the_baseline_grid(built):
+    """361x181x138 (BASELINE.json's grid), fp64, polar caps: the device against the CPU oracle at full size,
+    plus the size-independent properties of the transform: level 1 and level nz are copies of the first and
+    last eta level, drhodz(nz) = drhodz(nz-1), the pole rows of w are zonally constant, a second call on the
+    same input is idempotent."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    from oracle import oracle as orc
+    nx, ny, nz = 361, 181, 138
+    m = syn.model_levels(nx=nx, ny=ny, nz=nz, global_grid=True, polar=True)
+    sc = dict(syn.small(n=0, nx=nx, ny=ny, nz=nz, nsteps=1), grid=m["grid"], geom=m["geom"], globalflags=m["globalflags"])
+    sfc = {k: sc[k][0] for k in ("hmix", "ustar", "wstar", "oli", "tropopause")}
+    for k in ("height", "nmixz", "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol", "hmix", "ustar", "wstar", "oli", "tropopause", "vdep"):
+        sc.pop(k, None)
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX)
+    got = eng.verttransform(1, m, sfc, init=True)
+    again = eng.verttransform(1, m, sfc)
+    eng.close()
+    for k in FIELDS:
+        assert np.array_equal(got[k], again[k]), k
+    assert np.array_equal(got["uu"][0], m["uuh"][0]) and np.array_equal(got["tt"][-1], m["tth"][-1])
+    assert np.array_equal(got["drhodz"][-1], got["drhodz"][-2])
+    assert (got["ww"][:, 0, :] == got["ww"][:, 0, :1]).all() and (got["ww"][:, -1, :] == got["ww"][:, -1, :1]).all()
+    want = orc.vt_oracle(m, "r8")
+    assert got["nmixz"] == want["nmixz"]
+    worst = max_rel(got, want, m)
+    assert max(worst.values()) <= 1e-11, worst

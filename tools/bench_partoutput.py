@@ -16,6 +16,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _traffic():
+    """HBM bytes per call from the committed PMC summary (profiles/r*/po_1e+07_pmc.json), None if absent."""
+    import glob
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "po_1e+07_pmc.json")))
+    try:
+        return json.load(open(f[-1]))["hbm_bytes_per_call_raw"] if f else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--particles", type=float, default=1e7)
@@ -56,7 +66,7 @@ def main():
            "config": {"workload": f"{n:.0e} particles on the {nx}x{ny}x{nz} grid, all due, after a locality sort", "records": nrec, "file_bytes": size},
            "device_ms": dms, "wall_ms_whole_call": float(np.median(wall)) * 1e3,
            "roofline": {"bound": "hbm", "achieved": b_alg * nrec / (dms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                        "frac": b_alg * nrec / (dms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": "k_po_flags + rocprim scan + k_partoutput",
+                        "frac": b_alg * nrec / (dms * 1e-3) / 1e9 / 8000.0, "traffic": _traffic(), "kernel": "k_po_flags + rocprim scan + k_partoutput",
                         "alg_bytes_per_particle": b_alg}}
     # CPU: the C restatement of the reference's routine (file image in memory, no disk), one core
     from oracle import oracle as orc

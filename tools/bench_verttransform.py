@@ -20,6 +20,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def _traffic():
+    """HBM bytes per call from the committed PMC summary (profiles/r*/vt_361x181x138_pmc.json), None if absent."""
+    import glob
+    f = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "vt_361x181x138_pmc.json")))
+    try:
+        return json.load(open(f[-1]))["hbm_bytes_per_call"] if f else None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--nx", type=int, default=361)
@@ -57,7 +67,7 @@ def main():
         "config": {"workload": f"{nx}x{ny}x{nz} hybrid-level input -> z levels, polar caps on", "reps": a.reps},
         "wall_ms_whole_call": float(np.median(wall)) * 1e3,
         "roofline": {"bound": "hbm", "achieved": alg / (dms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": alg / (dms * 1e-3) / 1e9 / 8000.0, "traffic": None, "kernel": "k_vt_inc + k_vt_column + k_vt_search + k_vt_fill + k_vt_post + k_vt_polar + k_vt_polerow",
+                     "frac": alg / (dms * 1e-3) / 1e9 / 8000.0, "traffic": _traffic(), "kernel": "k_vt_inc + k_vt_column + k_vt_search + k_vt_fill + k_vt_post + k_vt_polar + k_vt_polerow",
                      "alg_bytes": alg},
     }
     if not a.no_cpu_baseline:
