@@ -63,7 +63,7 @@ class FpxFields(C.Structure):
 class FpxModelLevels(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("uuh", "vvh", "pvh", "wwh", "tth", "qvh", "ps", "tt2", "td2", "akz", "bkz", "aknew", "bknew")] + \
-               [("nuvz", C.c_int32), ("nwz", C.c_int32), ("init", C.c_int32), ("reserved", C.c_int32)]
+               [("nuvz", C.c_int32), ("nwz", C.c_int32), ("init", C.c_int32), ("pin_host", C.c_int32)]
 
 
 class FpxFieldsOut(C.Structure):

@@ -1067,6 +1067,7 @@ struct Engine : EngineBase {
 
   ~Engine() override {
     if (stream) (void)hipStreamSynchronize(stream);
+    for (auto &e : pinned_host) (void)hipHostUnregister(const_cast<void *>(e.first));
     for (auto &e : ev_pool) for (int i = 0; i < 4; i++) (void)hipEventDestroy(e.e[i]);
     for (void *q : owned) (void)hipFree(q);
     if (staging) (void)hipFree(staging);
@@ -1174,6 +1175,13 @@ struct Engine : EngineBase {
   // array layout on the device, then repacked like an upload (the 3-D fields never cross PCIe
   // as z-level arrays unless the host asks for them back through `out`).
   std::vector<double> height_host;     // height(nz) in the host's real kind, widened
+  // host arrays registered for DMA on request (fpx_model_levels.pin_host): address -> bytes; released in the destructor
+  std::vector<std::pair<const void *, size_t>> pinned_host;
+  void pin_host_range(const void *p, size_t bytes) {
+    for (auto &e : pinned_host) if (e.first == p && e.second >= bytes) return;
+    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) pinned_host.emplace_back(p, bytes);
+    else (void)hipGetLastError();      // not fatal: the copy falls back to the pageable path
+  }
   void *vt_dev[32] = {};               // device arrays of the transform, allocated on first use
   bool vt_ready = false;
 
@@ -1257,6 +1265,7 @@ struct Engine : EngineBase {
     const void *src[13] = {m->uuh, m->vvh, m->pvh, m->wwh, m->tth, m->qvh, m->ps, m->tt2, m->td2, m->akz, m->bkz, m->aknew, m->bknew};
     for (int i = 0; i < 13; i++) {
       const size_t n = (i >= PS && i <= TD2) ? n2 : (i >= AKZ) ? (size_t)nz : n3;
+      if (m->pin_host && n >= n2) pin_host_range(src[i], n * sizeof(H));
       HIPCHK(hipMemcpyAsync(D(i), src[i], n * sizeof(H), hipMemcpyHostToDevice, stream));
     }
     vt::Geo<H> G;

@@ -143,24 +143,26 @@ class Engine:
             check(self.lib.fpx_upload_fields(self.h, m + 1, C.byref(f)), "fpx_upload_fields")
         self.set_windtime(sc["memtime"], sc["memind"])
 
-    def verttransform(self, slot, m, sfc, *, init=False, want=("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol")):
+    def verttransform(self, slot, m, sfc, *, init=False, want=("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol"),
+                      host_arrays=None):
         """fpx_verttransform_ecmwf: m = synthetic.model_levels() dict (compact [nz][ny][nx] arrays),
         sfc = dict of compact 2-D fields (hmix, ustar, wstar, oli, tropopause[, vdep]) for this slot.
         Returns the z-level arrays asked for (compact), height and nmixz."""
         from ._lib import FpxModelLevels, FpxFieldsOut
         rt = self.hreal
-        keep = {}
+        keep = {} if host_arrays is None else host_arrays     # host_arrays: a dict the caller keeps alive -> arrays stay put and are pinned
         ml = FpxModelLevels()
+        ml.pin_host = 0 if host_arrays is None else 1
         for k in ("uuh", "vvh", "pvh", "wwh", "tth", "qvh"):
-            a = np.zeros((self.nzmax, self.nymax, self.nxmax), rt)
-            a[: self.nz, : self.ny, : self.nx] = m[k]
-            keep[k] = a
-            setattr(ml, k, a.ctypes.data)
+            if k not in keep:
+                keep[k] = np.zeros((self.nzmax, self.nymax, self.nxmax), rt)
+            keep[k][: self.nz, : self.ny, : self.nx] = m[k]
+            setattr(ml, k, keep[k].ctypes.data)
         for k in ("ps", "tt2", "td2"):
-            a = np.zeros((self.nymax, self.nxmax), rt)
-            a[: self.ny, : self.nx] = m[k]
-            keep[k] = a
-            setattr(ml, k, a.ctypes.data)
+            if k not in keep:
+                keep[k] = np.zeros((self.nymax, self.nxmax), rt)
+            keep[k][: self.ny, : self.nx] = m[k]
+            setattr(ml, k, keep[k].ctypes.data)
         for k in ("akz", "bkz", "aknew", "bknew"):
             keep[k] = np.ascontiguousarray(np.asarray(m[k]).astype(rt))
             setattr(ml, k, keep[k].ctypes.data)
@@ -186,13 +188,17 @@ class Engine:
         o.height = hgt.ctypes.data
         nmixz = C.c_int32(0)
         o.nmixz = C.pointer(nmixz)
+        import time as _time
+        t0 = _time.perf_counter()
         check(self.lib.fpx_verttransform_ecmwf(self.h, int(slot), C.byref(ml), C.byref(f), C.byref(o)), "fpx_verttransform_ecmwf")
+        call_s = _time.perf_counter() - t0          # the C call alone (the marshalling above is the mirror's, not the host's)
         out = {k: v[: self.nz, : self.ny, : self.nx].astype(np.float64) for k, v in res.items()}
         out["height"] = hgt.astype(np.float64)
         out["nmixz"] = int(nmixz.value)
         ms = C.c_double(0)
         check(self.lib.fpx_verttransform_time(self.h, C.byref(ms)), "fpx_verttransform_time")
         out["device_ms"] = ms.value
+        out["call_ms"] = call_s * 1e3
         return out
 
     def upload_diag_fields_from_scenario(self, sc):

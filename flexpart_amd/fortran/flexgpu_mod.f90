@@ -70,7 +70,7 @@ module flexgpu_mod
 
   type, bind(C) :: fpx_model_levels
     type(c_ptr) :: uuh, vvh, pvh, wwh, tth, qvh, ps, tt2, td2, akz, bkz, aknew, bknew
-    integer(c_int32_t) :: nuvz, nwz, init, reserved
+    integer(c_int32_t) :: nuvz, nwz, init, pin_host
   end type fpx_model_levels
 
   type, bind(C) :: fpx_fields_out
@@ -420,12 +420,13 @@ contains
   ! writeback (default .true.): uu, vv, ww, tt, qv, pv, rho, drhodz, uupol, vvpol of slot n are also
   ! copied back into com_mod for the host routines that still read them (partoutput, convmix, the
   ! cloud diagnostics); height(:) and nmixz are set on the first call as the reference does.
-  subroutine flexgpu_verttransform(n, uuh, vvh, wwh, pvh, ierr, writeback)
+  ! pin_host = .true.: uuh ... td2 keep their addresses for the whole run (static arrays): registered once for DMA.
+  subroutine flexgpu_verttransform(n, uuh, vvh, wwh, pvh, ierr, writeback, pin_host)
     integer, intent(in) :: n
     real, intent(in) :: uuh(0:nxmax-1,0:nymax-1,nuvzmax), vvh(0:nxmax-1,0:nymax-1,nuvzmax)
     real, intent(in) :: pvh(0:nxmax-1,0:nymax-1,nuvzmax), wwh(0:nxmax-1,0:nymax-1,nwzmax)
     integer, intent(out) :: ierr
-    logical, intent(in), optional :: writeback
+    logical, intent(in), optional :: writeback, pin_host
     logical, save :: first = .true.
     type(fpx_model_levels) :: m
     type(fpx_fields) :: f
@@ -437,7 +438,8 @@ contains
     m%tth = loc_r(tth(0,0,1,n)); m%qvh = loc_r(qvh(0,0,1,n))
     m%ps = loc_r(ps(0,0,1,n)); m%tt2 = loc_r(tt2(0,0,1,n)); m%td2 = loc_r(td2(0,0,1,n))
     m%akz = loc_r(akz); m%bkz = loc_r(bkz); m%aknew = loc_r(aknew); m%bknew = loc_r(bknew)
-    m%nuvz = nuvz; m%nwz = nwz; m%init = merge(1, 0, first); m%reserved = 0
+    m%nuvz = nuvz; m%nwz = nwz; m%init = merge(1, 0, first)
+    m%pin_host = 0; if (present(pin_host)) m%pin_host = merge(1, 0, pin_host)
     f%uu = c_null_ptr; f%vv = c_null_ptr; f%ww = c_null_ptr; f%uupol = c_null_ptr; f%vvpol = c_null_ptr
     f%rho = c_null_ptr; f%drhodz = c_null_ptr; f%tt = c_null_ptr
     f%hmix = loc_r(hmix(0,0,1,n)); f%ustar = loc_r(ustar(0,0,1,n)); f%wstar = loc_r(wstar(0,0,1,n))

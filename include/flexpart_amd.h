@@ -173,7 +173,9 @@ typedef struct {
   int32_t init;                  /* 1: derive height(nz) and nmixz from this input as the first
                                     call of the reference does (:118-196); 0: use fpx_set_height's.
                                     Without fpx_set_height the first call derives them anyway.  */
-  int32_t reserved;
+  int32_t pin_host;              /* 1: the input arrays keep their addresses until fpx_destroy (static com_mod
+                                    arrays): register them once for DMA (hipHostRegister) -- the 433 MB
+                                    host-to-device copy then runs at PCIe speed instead of the pageable path */
 } fpx_model_levels;
 /* Optional copies back to the host (NULL members are skipped): the z-level arrays in the host's
  * shapes (0:nxmax-1,0:nymax-1,nzmax) for slot n, e.g. c_loc(tt(0,0,1,n)); height(nz); nmixz. */
