@@ -41,6 +41,7 @@ template <typename H>
 struct Geo {
   int nx, ny, nz, nuvz, nwz, nxmax, nymax;
   H dx, dy, xlon0, ylat0, dxconst, dyconst;
+  H xres, yres;               // 1 on the mother grid; xresoln(l), yresoln(l) on a nest (verttransform_nests.f90:384-385)
   int nglobal, sglobal;
   H switchnorthg, switchsouthg;
   H northpolemap[9], southpolemap[9];
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256) k_vt_post(Geo<H> G, In<H> I, Out<H> O, co
   const H dzdy1 = (O.uvzlev[G.at(ix, jy + 1, kz - 1)] - O.uvzlev[G.at(ix, jy - 1, kz - 1)]) / VK(2.);
   const H dzdy2 = (O.uvzlev[G.at(ix, jy + 1, kz)] - O.uvzlev[G.at(ix, jy - 1, kz)]) / VK(2.);
   const H dzdy = (dzdy1 * dz2 + dzdy2 * dz1) / dz;
-  O.ww[o] = O.ww[o] + (dzdx * O.uu[o] * G.dxconst * cosf + dzdy * O.vv[o] * G.dyconst);
+  O.ww[o] = O.ww[o] + (dzdx * O.uu[o] * G.dxconst * G.xres * cosf + dzdy * O.vv[o] * G.dyconst * G.yres);
 }
 
 // polar-stereographic winds on the rows of a polar cap, :459-470 / :530-541

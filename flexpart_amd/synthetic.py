@@ -525,3 +525,17 @@ def add_partoutput_fields(sc, itime=None, dead_every=7):
     sc["itra1"] = itra1
     sc["npoint"] = (1 + np.arange(int(sc["npart"])) % 3).astype(np.int32)
     return sc
+
+
+def nest_model_levels(m, ix0=10, jy0=6, ix1=25, jy1=16, factor=2, phase=3):
+    """Model-level input on one nested grid covering mother cells [ix0,ix1] x [jy0,jy1] at `factor` times the
+    resolution (verttransform_nests.f90); same hybrid coefficients as the mother, its own smooth patterns."""
+    nx, ny, nz = (int(v) for v in m["grid"])
+    dx, dy, xlon0, ylat0 = (float(v) for v in m["geom"])
+    nxn, nyn = (ix1 - ix0) * factor + 1, (jy1 - jy0) * factor + 1
+    n = model_levels(nx=nxn, ny=nyn, nz=nz, global_grid=False, polar=False, phase=phase)
+    for k in ("akz", "bkz", "aknew", "bknew"):
+        n[k] = m[k].copy()
+    n["geom"] = np.array([dx / factor, dy / factor, xlon0 + ix0 * dx, ylat0 + jy0 * dy], np.float64)
+    n["globalflags"] = np.array([0, 0, 0], np.int32)
+    return n

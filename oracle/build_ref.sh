@@ -64,11 +64,14 @@ build_vt() {
   local flags="$*"
   local obj="$OUT/obj_$kind"
   ( cd "$obj"
-    for s in verttransform_ecmwf ew qvsat; do
+    local extra=""
+    case "$flags" in *FLEXREF_NESTS*) extra="verttransform_nests";; esac
+    for s in verttransform_ecmwf ew qvsat $extra; do
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
+    [ -z "$extra" ] || extra="$extra.o"
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_vt_driver.f90" -o ref_vt_driver.o
-    "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o flexgpu_mod.o caldate.o juldate.o verttransform_ecmwf.o ew.o qvsat.o \
+    "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o flexgpu_mod.o caldate.o juldate.o verttransform_ecmwf.o $extra ew.o qvsat.o \
         par_mod.o com_mod.o cmapf_mod.o point_mod.o unc_mod.o outg_mod.o \
         -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
         -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
@@ -127,3 +130,4 @@ build_rp r8 -fdefault-real-8
 # nested-grid variant: the stock par_mod.f90 has maxnests=0; the reference's own
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path
 build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
+build_vt r8n -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS

@@ -282,7 +282,8 @@ class _VtoArgs(C.Structure):
                  ("dx", C.c_double), ("dy", C.c_double), ("xlon0", C.c_double), ("ylat0", C.c_double),
                  ("nglobal", C.c_int), ("sglobal", C.c_int),
                  ("northpolemap", C.c_double * 9), ("southpolemap", C.c_double * 9),
-                 ("switchnorthg", C.c_double), ("switchsouthg", C.c_double), ("init", C.c_int)]
+                 ("switchnorthg", C.c_double), ("switchsouthg", C.c_double), ("init", C.c_int),
+                 ("cos_dy", C.c_double), ("cos_ylat0", C.c_double), ("xres", C.c_double), ("yres", C.c_double)]
                 + [(k, C.POINTER(C.c_double)) for k in ("akz", "bkz", "aknew", "bknew", "ps", "tt2", "td2",
                                                          "tth", "qvh", "uuh", "vvh", "pvh", "wwh", "height")]
                 + [("nmixz", C.POINTER(C.c_int))]
@@ -310,7 +311,7 @@ def polemaps(dx, dy, ylat0, kind="r8"):
     return n, s, swn, sws
 
 
-def vt_oracle(m, kind="r8", height=None):
+def vt_oracle(m, kind="r8", height=None, nest_of=None):
     """Run the C restatement of verttransform_ecmwf on a synthetic.model_levels() dict.
     height=None: first call (computes height and nmixz); else the given z levels are used."""
     build()
@@ -320,6 +321,15 @@ def vt_oracle(m, kind="r8", height=None):
     a = _VtoArgs()
     a.nx, a.ny, a.nz = nx, ny, nz
     a.dx, a.dy, a.xlon0, a.ylat0 = dx, dy, xlon0, ylat0
+    a.xres = a.yres = 1.0
+    a.cos_dy, a.cos_ylat0 = dy, ylat0
+    if nest_of is not None:
+        # verttransform_nests.f90: the nest's own dyn/ylat0n in cosf (:346), the MOTHER's dxconst/dyconst times
+        # xresoln = dx/dxn, yresoln = dy/dyn (gridcheck_nests.f90:359-360, in the host's real kind) in the slope term (:384-385)
+        rt = np.float32 if kind == "r4" else np.float64
+        mdx, mdy = (rt(v) for v in nest_of["geom"][:2])
+        a.xres = float(mdx / rt(dx)); a.yres = float(mdy / rt(dy))
+        a.dx, a.dy = float(mdx), float(mdy)
     a.nglobal, a.sglobal = int(m["globalflags"][1]), int(m["globalflags"][2])
     a.switchnorthg = a.switchsouthg = 999999.0
     if a.nglobal or a.sglobal:

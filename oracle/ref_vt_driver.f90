@@ -55,6 +55,10 @@ program vtref
   integer, allocatable :: ibuf(:)
   real(kind=8), allocatable :: dbuf(:), tmp(:)
   real, allocatable :: uuh(:,:,:), vvh(:,:,:), pvh(:,:,:), wwh(:,:,:)
+#ifdef FLEXREF_NESTS
+  real, allocatable :: uuhn(:,:,:,:), vvhn(:,:,:,:), pvhn(:,:,:,:), wwhn(:,:,:,:)
+  integer :: gnxn, gnyn
+#endif
   integer :: ios, n, gnx, gny, gnz, ncalls, icall
   real :: sizenorth, sizesouth
   integer(kind=8) :: c0, c1, crate
@@ -70,6 +74,11 @@ program vtref
   allocate(uuh(0:nxmax-1,0:nymax-1,nuvzmax), vvh(0:nxmax-1,0:nymax-1,nuvzmax))
   allocate(pvh(0:nxmax-1,0:nymax-1,nuvzmax), wwh(0:nxmax-1,0:nymax-1,nwzmax))
   uuh=0.; vvh=0.; pvh=0.; wwh=0.
+#ifdef FLEXREF_NESTS
+  allocate(uuhn(0:nxmaxn-1,0:nymaxn-1,nuvzmax,maxnests), vvhn(0:nxmaxn-1,0:nymaxn-1,nuvzmax,maxnests))
+  allocate(pvhn(0:nxmaxn-1,0:nymaxn-1,nuvzmax,maxnests), wwhn(0:nxmaxn-1,0:nymaxn-1,nwzmax,maxnests))
+  uuhn=0.; vvhn=0.; pvhn=0.; wwhn=0.; gnxn=0; gnyn=0
+#endif
   xglobal=.false.; nglobal=.false.; sglobal=.false.
   switchnorthg=999999.; switchsouthg=999999.
   readclouds=.false.; sumclouds=.false.; numbnests=0
@@ -115,6 +124,28 @@ program vtref
     case ('vvh');     call get3(vvh, nuvzmax)
     case ('pvh');     call get3(pvh, nuvzmax)
     case ('wwh');     call get3(wwh, nwzmax)
+#ifdef FLEXREF_NESTS
+    ! one nest (verttransform_nests.f90); geometry as gridcheck_nests.f90:359-372
+    case ('nestgrid')
+      gnxn=ibuf(1); gnyn=ibuf(2)
+      if (gnxn.gt.nxmaxn .or. gnyn.gt.nymaxn) stop 'nest too large'
+      numbnests=1; nxn(1)=gnxn; nyn(1)=gnyn
+      call com_mod_allocate_nests
+      uun=0.; vvn=0.; wwn=0.; ttn=0.; qvn=0.; pvn=0.; rhon=0.; drhodzn=0.; tthn=0.; qvhn=0.
+      psn=0.; tt2n=0.; td2n=0.; lsprecn=0.; convprecn=0.
+    case ('nestgeom')
+      dxn(1)=dbuf(1); dyn(1)=dbuf(2); xlon0n(1)=dbuf(3); ylat0n(1)=dbuf(4)
+      xresoln(1)=dx/dxn(1); yresoln(1)=dy/dyn(1)
+    case ('psn');     call getn2(psn(:,:,1,1,1))
+    case ('tt2n');    call getn2(tt2n(:,:,1,1,1))
+    case ('td2n');    call getn2(td2n(:,:,1,1,1))
+    case ('tthn');    call getn3(tthn(:,:,:,1,1), nuvzmax)
+    case ('qvhn');    call getn3(qvhn(:,:,:,1,1), nuvzmax)
+    case ('uuhn');    call getn3(uuhn(:,:,:,1), nuvzmax)
+    case ('vvhn');    call getn3(vvhn(:,:,:,1), nuvzmax)
+    case ('pvhn');    call getn3(pvhn(:,:,:,1), nuvzmax)
+    case ('wwhn');    call getn3(wwhn(:,:,:,1), nwzmax)
+#endif
     case default
       write(*,*) 'ref_vt_driver: unknown record ', trim(name)
       stop 1
@@ -161,6 +192,9 @@ program vtref
     end do
   end if
   call system_clock(c1)
+#ifdef FLEXREF_NESTS
+  if (numbnests .ge. 1 .and. use_gpu .eq. 0) call verttransform_nests(1,uuhn,vvhn,wwhn,pvhn)
+#endif
 
   open(uout, file=trim(fout), access='stream', form='unformatted', status='replace')
   allocate(tmp(nz))
@@ -181,10 +215,63 @@ program vtref
     call dump3('uupol', uupol(:,:,:,1))
     call dump3('vvpol', vvpol(:,:,:,1))
   end if
+#ifdef FLEXREF_NESTS
+  if (numbnests .ge. 1) then
+    call dumpn3('uun', uun(:,:,:,1,1))
+    call dumpn3('vvn', vvn(:,:,:,1,1))
+    call dumpn3('wwn', wwn(:,:,:,1,1))
+    call dumpn3('ttn', ttn(:,:,:,1,1))
+    call dumpn3('qvn', qvn(:,:,:,1,1))
+    call dumpn3('pvn', pvn(:,:,:,1,1))
+    call dumpn3('rhon', rhon(:,:,:,1,1))
+    call dumpn3('drhodzn', drhodzn(:,:,:,1,1))
+  end if
+#endif
   write(uout) 'END             ', 1_4, 0_8
   close(uout)
 
 contains
+#ifdef FLEXREF_NESTS
+  subroutine getn2(a)
+    real, intent(inout) :: a(0:nxmaxn-1,0:nymaxn-1)
+    integer :: ix, jy
+    a=0.
+    do jy=0,gnyn-1
+      do ix=0,gnxn-1
+        a(ix,jy)=dbuf(1+ix+gnxn*jy)
+      end do
+    end do
+  end subroutine getn2
+  subroutine getn3(a, nl)
+    integer, intent(in) :: nl
+    real, intent(inout) :: a(0:nxmaxn-1,0:nymaxn-1,nl)
+    integer :: ix, jy, k
+    a=0.
+    do k=1,gnz
+      do jy=0,gnyn-1
+        do ix=0,gnxn-1
+          a(ix,jy,k)=dbuf(1+ix+gnxn*(jy+gnyn*(k-1)))
+        end do
+      end do
+    end do
+  end subroutine getn3
+  subroutine dumpn3(nm, a)
+    character(len=*), intent(in) :: nm
+    real, intent(in) :: a(0:nxmaxn-1,0:nymaxn-1,nzmax)
+    real(kind=8), allocatable :: t(:)
+    integer :: ix, jy, k
+    allocate(t(gnxn*gnyn*gnz))
+    do k=1,gnz
+      do jy=0,gnyn-1
+        do ix=0,gnxn-1
+          t(1+ix+gnxn*(jy+gnyn*(k-1)))=a(ix,jy,k)
+        end do
+      end do
+    end do
+    call put_d(nm, t, gnxn*gnyn*gnz)
+    deallocate(t)
+  end subroutine dumpn3
+#endif
   subroutine get2(a)
     real, intent(inout) :: a(0:nxmax-1,0:nymax-1)
     integer :: ix, jy

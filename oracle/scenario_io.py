@@ -122,7 +122,7 @@ def have_vt_ref(kind="r8"):
     return os.access(os.path.join(HERE, "_ref", f"vtref_{kind}"), os.X_OK)
 
 
-def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1, gpu=False):
+def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1, gpu=False, nest=None):
     """The unmodified verttransform_ecmwf on a synthetic.model_levels() dict -> dict of fields [nz][ny][nx]."""
     os.makedirs(workdir, exist_ok=True)
     fs = os.path.join(workdir, f"vt_{os.getpid()}.scen")
@@ -137,6 +137,13 @@ def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1, gpu=False):
                 a = np.ascontiguousarray(np.asarray(v, dtype=np.float64).ravel()); code = 2
             fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
             fh.write(a.tobytes())
+        if nest is not None:      # one nest (kind r8n: the reference's par_mod_meteoswiss.f90 has maxnests=1)
+            recs = [("nestgrid", nest["grid"][:2], 1), ("nestgeom", nest["geom"], 2)]
+            recs += [(k + "n", nest[k], 2) for k in ("ps", "tt2", "td2", "tth", "qvh", "uuh", "vvh", "pvh", "wwh")]
+            for name, v, code in recs:
+                a = np.ascontiguousarray(np.asarray(v, dtype=np.int32 if code == 1 else np.float64).ravel())
+                fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
+                fh.write(a.tobytes())
         fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
     exe = os.path.join(HERE, "_ref", f"vtref_{kind}")
     res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {fo}" + (" gpu" if gpu else "")], capture_output=True, text=True)
@@ -144,8 +151,12 @@ def run_vt_reference(m, kind="r8", workdir="/tmp", ncalls=1, gpu=False):
         raise RuntimeError(f"reference verttransform driver failed: {res.stdout}\n{res.stderr}")
     nx, ny, nz = (int(v) for v in m["grid"])
     out = {}
+    nn = (int(nest["grid"][0]), int(nest["grid"][1])) if nest is not None else (0, 0)
     for name, a in read_records(fo):
-        out[name] = a.reshape(nz, ny, nx) if a.size == nx * ny * nz else a
+        if nest is not None and name in ("uun", "vvn", "wwn", "ttn", "qvn", "pvn", "rhon", "drhodzn"):
+            out[name] = a.reshape(nz, nn[1], nn[0])
+        else:
+            out[name] = a.reshape(nz, ny, nx) if a.size == nx * ny * nz else a
     os.remove(fs)
     os.remove(fo)
     out["nmixz"] = int(out["nmixz"][0])

@@ -41,6 +41,10 @@ typedef struct {
   int nglobal, sglobal;
   double northpolemap[9], southpolemap[9], switchnorthg, switchsouthg;
   int init;                   /* 1: compute height/nmixz (first call), 0: use height[] as given */
+  double cos_dy, cos_ylat0;   /* grid spacing and origin used in cosf (:405): the grid's own -- on a nest dyn(l), ylat0n(l), while
+                                 dx, dy above stay the MOTHER's (dxconst, dyconst) */
+  double xres, yres;          /* 1 on the mother grid; xresoln(l), yresoln(l) for verttransform_nests.f90 (same algorithm
+                                 on the nest's arrays, no poles, no height initialisation: :384-385) */
   const double *akz, *bkz, *aknew, *bknew;          /* [nz] */
   const double *ps, *tt2, *td2;                     /* [ny][nx] */
   const double *tth, *qvh, *uuh, *vvh, *pvh, *wwh;  /* [nz][ny][nx] */
@@ -128,6 +132,7 @@ int vto_verttransform(vto_args *I) {
   int *idx = (int *)calloc(n2, sizeof(int));
   real northpolemap[9], southpolemap[9];
   const real switchnorthg = (real)I->switchnorthg, switchsouthg = (real)I->switchsouthg;
+  const real xres = (real)I->xres, yres = (real)I->yres;
   int ix, jy, kz, iz, i;
   for (i = 0; i < 9; i++) { northpolemap[i] = (real)I->northpolemap[i]; southpolemap[i] = (real)I->southpolemap[i]; }
 
@@ -290,7 +295,7 @@ int vto_verttransform(vto_args *I) {
             break;
           }
     for (jy = 1; jy <= ny - 2; jy++) {
-      const real cosf = K(1.) / r_cos(((real)jy * dy + ylat0) * pi180);
+      const real cosf = K(1.) / r_cos(((real)jy * (real)I->cos_dy + (real)I->cos_ylat0) * pi180);
       for (ix = 1; ix <= nx - 2; ix++) {
         real dz1, dz2, dz, dzdx1, dzdx2, dzdx, dzdy1, dzdy2, dzdy;
         const int ix1 = ix - 1, jy1 = jy - 1, ixp = ix + 1, jyp = jy + 1;
@@ -304,7 +309,7 @@ int vto_verttransform(vto_args *I) {
         dzdy1 = (A3(uvzlev, ix, jyp, kz - 1) - A3(uvzlev, ix, jy1, kz - 1)) / K(2.);
         dzdy2 = (A3(uvzlev, ix, jyp, kz) - A3(uvzlev, ix, jy1, kz)) / K(2.);
         dzdy = (dzdy1 * dz2 + dzdy2 * dz1) / dz;
-        A3(ww, ix, jy, iz) = A3(ww, ix, jy, iz) + (dzdx * A3(uu, ix, jy, iz) * dxconst * cosf + dzdy * A3(vv, ix, jy, iz) * dyconst);
+        A3(ww, ix, jy, iz) = A3(ww, ix, jy, iz) + (dzdx * A3(uu, ix, jy, iz) * dxconst * xres * cosf + dzdy * A3(vv, ix, jy, iz) * dyconst * yres);
       }
     }
   }
