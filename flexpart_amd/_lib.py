@@ -63,7 +63,8 @@ class FpxFields(C.Structure):
 class FpxModelLevels(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("uuh", "vvh", "pvh", "wwh", "tth", "qvh", "ps", "tt2", "td2", "akz", "bkz", "aknew", "bknew")] + \
-               [("nuvz", C.c_int32), ("nwz", C.c_int32), ("init", C.c_int32), ("pin_host", C.c_int32)]
+               [("nuvz", C.c_int32), ("nwz", C.c_int32), ("init", C.c_int32), ("pin_host", C.c_int32),
+                ("nest_dy", C.c_double), ("nest_ylat0", C.c_double)]
 
 
 class FpxFieldsOut(C.Structure):
@@ -138,7 +139,7 @@ SYMBOLS = [
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
-    "fpx_verttransform_ecmwf", "fpx_verttransform_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions",
+    "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions",
 ]
 
 _lib = None
@@ -171,6 +172,7 @@ def load():
     lib.fpx_set_height.argtypes = [vp, vp, C.c_int32]
     lib.fpx_upload_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxFields)]
     lib.fpx_verttransform_ecmwf.argtypes = [vp, C.c_int32, C.POINTER(FpxModelLevels), C.POINTER(FpxFields), C.POINTER(FpxFieldsOut)]
+    lib.fpx_verttransform_nest.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(FpxModelLevels), C.POINTER(FpxFields), C.POINTER(FpxFieldsOut)]
     lib.fpx_verttransform_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.fpx_upload_diag_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxDiagFields)]
     lib.fpx_partoutput.argtypes = [vp, C.c_int32, C.c_char_p, C.POINTER(C.c_int64)]

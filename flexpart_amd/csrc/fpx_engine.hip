@@ -855,6 +855,7 @@ struct EngineBase {
   virtual int set_height(const void *h, int n) = 0;
   virtual int upload_fields(int slot, const fpx_fields *f) = 0;
   virtual int verttransform(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) = 0;
+  virtual int verttransform_nest(int nest, int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) = 0;
   virtual int set_windtime(const int32_t mt[2], const int32_t mi[2]) = 0;
   virtual int rng_fill_table() = 0;
   virtual int rng_set_table(const void *t, int n) = 0;
@@ -1182,8 +1183,8 @@ struct Engine : EngineBase {
     if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) pinned_host.emplace_back(p, bytes);
     else (void)hipGetLastError();      // not fatal: the copy falls back to the pageable path
   }
-  void *vt_dev[32] = {};               // device arrays of the transform, allocated on first use
-  bool vt_ready = false;
+  void *vt_sets[1 + kMaxNests][32] = {};   // device arrays of the transform per grid (0 = mother, l = nest l), allocated on first use
+  bool vt_set_ready[1 + kMaxNests] = {};
 
   template <typename H>
   static H vt_ew_host(H x) {           // ew.f90:4-29
@@ -1230,9 +1231,16 @@ struct Engine : EngineBase {
   }
 
   template <typename H>
-  int verttransform_t(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) {
+  int verttransform_t(int nest, int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) {
+    // nest = 0: the mother grid (verttransform_ecmwf.f90); nest = l >= 1: nested grid l (verttransform_nests.f90: the same
+    // algorithm on the nest's arrays -- no height initialisation, no polar caps, the nest's own dyn/ylat0n in cosf and
+    // the mother's dxconst, dyconst times xresoln, yresoln in the slope term, :346,384-385)
     const int nz = cfg.nz;
-    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax, n3 = n2 * nz;
+    const int gnx = nest ? h_nest[nest - 1].nx : cfg.nx, gny = nest ? h_nest[nest - 1].ny : cfg.ny;
+    const int gnxmax = nest ? nest_nxmaxn : cfg.nxmax, gnymax = nest ? nest_nymaxn : cfg.nymax;
+    void **vt_dev = vt_sets[nest];
+    bool &vt_ready = vt_set_ready[nest];
+    const size_t n2 = (size_t)gnxmax * gnymax, n3 = n2 * nz;
     int rc;
     enum { UUH, VVH, PVH, WWH, TTH, QVH, PS, TT2, TD2, AKZ, BKZ, AKN, BKN, HGT,
            UU, VV, WW, TT, QV, PV, RHO, DRHO, UPOL, VPOL, UVZ, WZ, RHOH, PINM, KUV, KW, NBUF };
@@ -1248,7 +1256,7 @@ struct Engine : EngineBase {
     }
     auto D = [&](int i) { return (H *)vt_dev[i]; };
     // z levels: derived on the first call (or on request), else the ones the host has set
-    if (m->init || !height_set) {
+    if (!nest && (m->init || !height_set)) {
       std::vector<H> hgt;
       int nmixz = 0;
       if ((rc = vt_init_height<H>(m, hgt, nmixz))) return rc;
@@ -1269,14 +1277,19 @@ struct Engine : EngineBase {
       HIPCHK(hipMemcpyAsync(D(i), src[i], n * sizeof(H), hipMemcpyHostToDevice, stream));
     }
     vt::Geo<H> G;
-    G.nx = cfg.nx; G.ny = cfg.ny; G.nz = nz; G.nuvz = m->nuvz; G.nwz = m->nwz; G.nxmax = cfg.nxmax; G.nymax = cfg.nymax;
+    G.nx = gnx; G.ny = gny; G.nz = nz; G.nuvz = m->nuvz; G.nwz = m->nwz; G.nxmax = gnxmax; G.nymax = gnymax;
     G.dx = (H)cfg.dx; G.dy = (H)cfg.dy; G.xlon0 = (H)cfg.xlon0; G.ylat0 = (H)cfg.ylat0;
     {   // gridcheck_ecmwf.f90:311-312, in the host's real kind
       const H pi = (H)3.14159265, r_earth = (H)6.371e6;
       G.dxconst = (H)180. / (G.dx * r_earth * pi);
       G.dyconst = (H)180. / (G.dy * r_earth * pi);
     }
-    G.nglobal = cfg.nglobal; G.sglobal = cfg.sglobal;
+    G.xres = (H)1.; G.yres = (H)1.;
+    if (nest) {   // after dxconst, dyconst (the mother's): the nest's own spacing and origin for cosf
+      G.dy = (H)m->nest_dy; G.ylat0 = (H)m->nest_ylat0;
+      G.xres = (H)h_nest[nest - 1].xres; G.yres = (H)h_nest[nest - 1].yres;
+    }
+    G.nglobal = nest ? 0 : cfg.nglobal; G.sglobal = nest ? 0 : cfg.sglobal;
     G.switchnorthg = (H)cfg.switchnorthg; G.switchsouthg = (H)cfg.switchsouthg;
     for (int i = 0; i < 9; i++) { G.northpolemap[i] = (H)cfg.northpolemap[i]; G.southpolemap[i] = (H)cfg.southpolemap[i]; }
     vt::In<H> I{D(UUH), D(VVH), D(PVH), D(WWH), D(TTH), D(QVH), D(PS), D(TT2), D(TD2), D(AKZ), D(BKZ), D(AKN), D(BKN), D(HGT)};
@@ -1284,7 +1297,7 @@ struct Engine : EngineBase {
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, stream));
-    const int ncol = cfg.nx * cfg.ny, nb = (ncol + 255) / 256;
+    const int ncol = gnx * gny, nb = (ncol + 255) / 256;
     const size_t sm = (size_t)nz * sizeof(H);
     const dim3 g3(nb, nz);
     unsigned short *kuv = (unsigned short *)vt_dev[KUV], *kw = (unsigned short *)vt_dev[KW];
@@ -1293,47 +1306,57 @@ struct Engine : EngineBase {
     vt::k_vt_search<H><<<dim3(nb, 2), 256, sm, stream>>>(G, I, O, kuv, kw);
     vt::k_vt_fill<H><<<g3, 256, 0, stream>>>(G, I, O, kuv, kw);
     vt::k_vt_post<H><<<g3, 256, 0, stream>>>(G, I, O, kuv);
-    const size_t smrow = (size_t)(cfg.nx + 3) * sizeof(H);
-    if (cfg.nglobal) {
+    const size_t smrow = (size_t)(gnx + 3) * sizeof(H);
+    if (G.nglobal) {
       const int jy0 = std::max(0, (int)G.switchnorthg - 2), jy1 = cfg.ny - 1;
       if (jy1 >= jy0) vt::k_vt_polar<H><<<dim3((cfg.nx + 255) / 256, jy1 - jy0 + 1, nz), 256, 0, stream>>>(G, O, jy0, jy1, 0);
       vt::k_vt_polerow<H><<<nz, 64, smrow, stream>>>(G, O, 0);
     }
-    if (cfg.sglobal) {
+    if (G.sglobal) {
       const int jy0 = 0, jy1 = std::min(cfg.ny - 1, (int)G.switchsouthg + 3);
       if (jy1 >= jy0) vt::k_vt_polar<H><<<dim3((cfg.nx + 255) / 256, jy1 - jy0 + 1, nz), 256, 0, stream>>>(G, O, jy0, jy1, 1);
       vt::k_vt_polerow<H><<<nz, 64, smrow, stream>>>(G, O, 1);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(e1, stream));
-    // repack into the gather layout, as upload_fields does from the staged host arrays
+    // repack into the gather layout, as upload_fields / upload_nest_fields do from the staged host arrays
     const int s = slot - 1;
     auto pk = [&](const H *in, const R *outp, int stride, int off) -> int {
-      dim3 grid((cfg.nx + 31) / 32, (nz + 31) / 32, cfg.ny), block(32, 8);
-      k_pack3<H, R><<<grid, block, 0, stream>>>(in, (R *)outp, cfg.nx, cfg.ny, nz, cfg.nxmax, cfg.nymax, stride, off);
+      dim3 grid((gnx + 31) / 32, (nz + 31) / 32, gny), block(32, 8);
+      k_pack3<H, R><<<grid, block, 0, stream>>>(in, (R *)outp, gnx, gny, nz, gnxmax, gnymax, stride, off);
       HIPCHK(hipGetLastError());
       return 0;
     };
-    if ((rc = pk(D(UU), V.w3, 6, s * 3 + 0)) || (rc = pk(D(VV), V.w3, 6, s * 3 + 1)) || (rc = pk(D(WW), V.w3, 6, s * 3 + 2))) return rc;
-    if (V.w3pol)
+    const R *t_w3 = nest ? h_nest[nest - 1].w3 : V.w3, *t_r2 = nest ? h_nest[nest - 1].r2 : V.r2;
+    const R *t_sfc = nest ? h_nest[nest - 1].sfc : V.sfc, *t_tropo = nest ? h_nest[nest - 1].tropo : V.tropo;
+    const R *t_vdep = nest ? h_nest[nest - 1].vdep : V.vdep, *t_hcell = nest ? h_nest[nest - 1].hcell : V.hcell;
+    if ((rc = pk(D(UU), t_w3, 6, s * 3 + 0)) || (rc = pk(D(VV), t_w3, 6, s * 3 + 1)) || (rc = pk(D(WW), t_w3, 6, s * 3 + 2))) return rc;
+    if (!nest && V.w3pol)
       if ((rc = pk(D(UPOL), V.w3pol, 6, s * 3 + 0)) || (rc = pk(D(VPOL), V.w3pol, 6, s * 3 + 1)) || (rc = pk(D(WW), V.w3pol, 6, s * 3 + 2))) return rc;
-    if ((rc = pk(D(RHO), V.r2, 4, s * 2 + 0)) || (rc = pk(D(DRHO), V.r2, 4, s * 2 + 1))) return rc;
-    if (slot == 1 && V.rhott)
+    if ((rc = pk(D(RHO), t_r2, 4, s * 2 + 0)) || (rc = pk(D(DRHO), t_r2, 4, s * 2 + 1))) return rc;
+    if (!nest && slot == 1 && V.rhott)
       if ((rc = pk(D(RHO), V.rhott, 2, 0)) || (rc = pk(D(TT), V.rhott, 2, 1))) return rc;
-    if (wet_on && Wp.ttw) { if ((rc = pk(D(TT), Wp.ttw, 2, s))) return rc; }
-    // the 2-D fields calcpar leaves on the host
-    if ((rc = p2(sfc->ustar, V.sfc, 8, s * 4 + 0)) || (rc = p2(sfc->wstar, V.sfc, 8, s * 4 + 1)) ||
-        (rc = p2(sfc->oli, V.sfc, 8, s * 4 + 2)) || (rc = p2(sfc->hmix, V.sfc, 8, s * 4 + 3))) return rc;
-    if (slot == 1) { if ((rc = p2(sfc->tropopause, V.tropo, 1, 0))) return rc; }
-    if ((rc = diag_alloc()) || (rc = diag2_from_host(diag_tropo[s], sfc->tropopause, DG_TROPO + s))) return rc;
-    // pv, qv, tt of this slot stay on the device for partoutput
-    if ((rc = diag3(D(PV), true, 0, s)) || (rc = diag3(D(QV), true, 1, s)) || (rc = diag3(D(TT), true, 2, s))) return rc;
-    if (V.vdep) {
-      const size_t plane = n2 * cfg.host_real_bytes;
-      for (int ks = 0; ks < cfg.nspec; ks++)
-        if ((rc = p2((const char *)sfc->vdep + plane * ks, V.vdep, 2 * cfg.nspec, s * cfg.nspec + ks))) return rc;
+    if (!nest && wet_on && Wp.ttw) { if ((rc = pk(D(TT), Wp.ttw, 2, s))) return rc; }
+    // the 2-D fields calcpar / calcpar_nests leave on the host
+    g_nx = gnx; g_ny = gny; g_nxmax = gnxmax; g_nymax = gnymax;
+    rc = 0;
+    do {
+      if ((rc = p2(sfc->ustar, t_sfc, 8, s * 4 + 0)) || (rc = p2(sfc->wstar, t_sfc, 8, s * 4 + 1)) ||
+          (rc = p2(sfc->oli, t_sfc, 8, s * 4 + 2)) || (rc = p2(sfc->hmix, t_sfc, 8, s * 4 + 3))) break;
+      if (slot == 1 && (rc = p2(sfc->tropopause, t_tropo, 1, 0))) break;
+      if (t_vdep) {
+        const size_t plane = n2 * cfg.host_real_bytes;
+        for (int ks = 0; ks < cfg.nspec && !rc; ks++) rc = p2((const char *)sfc->vdep + plane * ks, t_vdep, 2 * cfg.nspec, s * cfg.nspec + ks);
+      }
+    } while (0);
+    g_nx = cfg.nx; g_ny = cfg.ny; g_nxmax = cfg.nxmax; g_nymax = cfg.nymax;
+    if (rc) return rc;
+    if (!nest) {
+      if ((rc = diag_alloc()) || (rc = diag2_from_host(diag_tropo[s], sfc->tropopause, DG_TROPO + s))) return rc;
+      // pv, qv, tt of this slot stay on the device for partoutput
+      if ((rc = diag3(D(PV), true, 0, s)) || (rc = diag3(D(QV), true, 1, s)) || (rc = diag3(D(TT), true, 2, s))) return rc;
     }
-    k_hcell<R><<<(cfg.nx * cfg.ny + kBlock - 1) / kBlock, kBlock, 0, stream>>>(V.sfc, (R *)V.hcell, cfg.nx, cfg.ny);
+    k_hcell<R><<<(gnx * gny + kBlock - 1) / kBlock, kBlock, 0, stream>>>(t_sfc, (R *)t_hcell, gnx, gny);
     HIPCHK(hipGetLastError());
     if (out) {   // z-level arrays the host still wants (partoutput, convection, cloud diagnostics ...)
       void *dst[10] = {out->uu, out->vv, out->ww, out->tt, out->qv, out->pv, out->rho, out->drhodz, out->uupol, out->vvpol};
@@ -1347,7 +1370,7 @@ struct Engine : EngineBase {
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     vt_last_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    slot_loaded[s] = true;
+    if (nest) nest_loaded[nest - 1][s] = true; else slot_loaded[s] = true;
     return 0;
   }
   double vt_last_ms = 0, po_last_ms = 0;
@@ -1362,7 +1385,19 @@ struct Engine : EngineBase {
     if (cfg.nz < 3 || cfg.nz > 65535 || cfg.ny > 65535) return fail(FPX_ERR_ARG, "verttransform: 3 <= nz <= 65535, ny <= 65535");
     if (!sfc || !sfc->hmix || !sfc->ustar || !sfc->wstar || !sfc->oli || !sfc->tropopause) return fail(FPX_ERR_ARG, "verttransform: the 2-D fields hmix, ustar, wstar, oli, tropopause are required");
     if (cfg.drydep && !sfc->vdep) return fail(FPX_ERR_ARG, "verttransform: vdep required with DRYDEP");
-    return cfg.host_real_bytes == 4 ? verttransform_t<float>(slot, m, sfc, out) : verttransform_t<double>(slot, m, sfc, out);
+    return cfg.host_real_bytes == 4 ? verttransform_t<float>(0, slot, m, sfc, out) : verttransform_t<double>(0, slot, m, sfc, out);
+  }
+  int verttransform_nest(int nest, int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) override {
+    if (nest < 1 || nest > V.numbnests) return fail(FPX_ERR_ARG, "verttransform_nest: nest out of range (fpx_nests_init first)");
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "verttransform_nest: slot must be 1 or 2");
+    if (!height_set) return fail(FPX_ERR_STATE, "verttransform_nest: the z levels come from the mother grid's first transform (or fpx_set_height)");
+    if (!m || !m->uuh || !m->vvh || !m->pvh || !m->wwh || !m->tth || !m->qvh || !m->ps || !m->tt2 || !m->td2 || !m->akz || !m->bkz || !m->aknew || !m->bknew)
+      return fail(FPX_ERR_ARG, "verttransform_nest: uuhn, vvhn, pvhn, wwhn, tthn, qvhn, psn, tt2n, td2n, akz, bkz, aknew, bknew are required");
+    if (m->nuvz != cfg.nz || m->nwz != cfg.nz) return fail(FPX_ERR_ARG, "verttransform_nest: nuvz = nwz = nz expected");
+    if (!(m->nest_dy > 0)) return fail(FPX_ERR_ARG, "verttransform_nest: nest_dy (dyn) and nest_ylat0 (ylat0n) of fpx_model_levels are required");
+    if (!sfc || !sfc->hmix || !sfc->ustar || !sfc->wstar || !sfc->oli || !sfc->tropopause) return fail(FPX_ERR_ARG, "verttransform_nest: hmixn, ustarn, wstarn, olin, tropopausen are required");
+    if (cfg.drydep && !sfc->vdep) return fail(FPX_ERR_ARG, "verttransform_nest: vdepn required with DRYDEP");
+    return cfg.host_real_bytes == 4 ? verttransform_t<float>(nest, slot, m, sfc, out) : verttransform_t<double>(nest, slot, m, sfc, out);
   }
 
 
@@ -2543,6 +2578,7 @@ int fpx_destroy(fpx_handle h) {
 int fpx_set_height(fpx_handle h, const void *height, int32_t n) { FPX_GUARD(h); return h->impl->set_height(height, n); }
 int fpx_upload_fields(fpx_handle h, int32_t slot, const fpx_fields *f) { FPX_GUARD(h); return h->impl->upload_fields(slot, f); }
 int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) { FPX_GUARD(h); return h->impl->verttransform(slot, m, sfc, out); }
+int fpx_verttransform_nest(fpx_handle h, int32_t nest, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) { FPX_GUARD(h); return h->impl->verttransform_nest(nest, slot, m, sfc, out); }
 int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f) { FPX_GUARD(h); return h->impl->upload_diag_fields(slot, f); }
 int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles) { FPX_GUARD(h); return h->impl->partoutput(itime, path, nparticles); }
 int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r, int64_t *numpart, int32_t *numparticlecount, int32_t *itimein) {

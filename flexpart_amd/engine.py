@@ -144,12 +144,14 @@ class Engine:
         self.set_windtime(sc["memtime"], sc["memind"])
 
     def verttransform(self, slot, m, sfc, *, init=False, want=("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol"),
-                      host_arrays=None):
+                      host_arrays=None, nest=None):
         """fpx_verttransform_ecmwf: m = synthetic.model_levels() dict (compact [nz][ny][nx] arrays),
         sfc = dict of compact 2-D fields (hmix, ustar, wstar, oli, tropopause[, vdep]) for this slot.
         Returns the z-level arrays asked for (compact), height and nmixz."""
         from ._lib import FpxModelLevels, FpxFieldsOut
         rt = self.hreal
+        if nest is not None:      # m is the nest's input (synthetic.nest_model_levels): fpx_verttransform_nest, nest 1
+            return self._verttransform_nest(slot, m, sfc, want)
         keep = {} if host_arrays is None else host_arrays     # host_arrays: a dict the caller keeps alive -> arrays stay put and are pinned
         ml = FpxModelLevels()
         ml.pin_host = 0 if host_arrays is None else 1
@@ -201,6 +203,38 @@ class Engine:
         out["call_ms"] = call_s * 1e3
         return out
 
+    def _verttransform_nest(self, slot, n, sfc, want):
+        from ._lib import FpxModelLevels, FpxFieldsOut
+        rt = self.hreal
+        nxn, nyn = int(n["grid"][0]), int(n["grid"][1])
+        keep = {}
+        ml = FpxModelLevels()
+        for k in ("uuh", "vvh", "pvh", "wwh", "tth", "qvh"):
+            keep[k] = np.ascontiguousarray(np.zeros((self.nzmax, nyn, nxn), rt))
+            keep[k][: self.nz] = n[k]
+            setattr(ml, k, keep[k].ctypes.data)
+        for k in ("ps", "tt2", "td2"):
+            keep[k] = np.ascontiguousarray(np.asarray(n[k]).astype(rt))
+            setattr(ml, k, keep[k].ctypes.data)
+        for k in ("akz", "bkz", "aknew", "bknew"):
+            keep[k] = np.ascontiguousarray(np.asarray(n[k]).astype(rt))
+            setattr(ml, k, keep[k].ctypes.data)
+        ml.nuvz = ml.nwz = self.nz
+        ml.nest_dy, ml.nest_ylat0 = float(rt(n["geom"][1])), float(rt(n["geom"][3]))
+        f = FpxFields()
+        for k in ("hmix", "ustar", "wstar", "oli", "tropopause"):
+            keep["s" + k] = np.ascontiguousarray(np.asarray(sfc[k]).astype(rt))
+            setattr(f, k, keep["s" + k].ctypes.data)
+        o = FpxFieldsOut()
+        res = {}
+        for k in want:
+            if k in ("uupol", "vvpol"):
+                continue
+            res[k] = np.zeros((self.nzmax, nyn, nxn), rt)
+            setattr(o, k, res[k].ctypes.data)
+        check(self.lib.fpx_verttransform_nest(self.h, 1, int(slot), C.byref(ml), C.byref(f), C.byref(o)), "fpx_verttransform_nest")
+        return {k: v[: self.nz].astype(np.float64) for k, v in res.items()}
+
     def upload_diag_fields_from_scenario(self, sc):
         """oro and, for both slots, pv, qv, tt (compact arrays) -> fpx_upload_diag_fields."""
         from ._lib import FpxDiagFields
@@ -240,8 +274,15 @@ class Engine:
     def upload_nests_from_scenario(self, sc):
         """One nested grid: geometry as gridcheck_nests.f90:362-378 derives it, fields uun, vvn, ..."""
         rt = self.hreal
-        nxn, nyn = (int(v) for v in sc["nest"])
-        dxn, dyn, xlon0n, ylat0n = (rt(v) for v in sc["nestgeom"])
+        self.init_nest(sc["nest"], sc["nestgeom"])
+        for m in (0, 1):
+            self._upload_nest_slot(sc, m)
+
+    def init_nest(self, nest, nestgeom):
+        """fpx_nests_init for one nested grid: geometry as gridcheck_nests.f90:359-372 derives it."""
+        rt = self.hreal
+        nxn, nyn = (int(v) for v in nest)
+        dxn, dyn, xlon0n, ylat0n = (rt(v) for v in nestgeom)
         dx, dy, xlon0, ylat0 = (rt(self.cfg.dx), rt(self.cfg.dy), rt(self.cfg.xlon0), rt(self.cfg.ylat0))
         n = FpxNests()
         n.struct_bytes = C.sizeof(FpxNests)
@@ -254,7 +295,10 @@ class Engine:
         n.xln[0] = float((xlon0n - xlon0) / dx); n.xrn[0] = float((xaux2 - xlon0) / dx)
         n.yln[0] = float((ylat0n - ylat0) / dy); n.yrn[0] = float((yaux2 - ylat0) / dy)
         check(self.lib.fpx_nests_init(self.h, C.byref(n)), "fpx_nests_init")
-        for m in (0, 1):
+
+    def _upload_nest_slot(self, sc, m):
+        rt = self.hreal
+        if True:
             keep = {}
             f = FpxFields()
             for k, kn in (("uu", "uun"), ("vv", "vvn"), ("ww", "wwn"), ("rho", "rhon"), ("drhodz", "drhodzn")):

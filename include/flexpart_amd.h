@@ -176,6 +176,8 @@ typedef struct {
   int32_t pin_host;              /* 1: the input arrays keep their addresses until fpx_destroy (static com_mod
                                     arrays): register them once for DMA (hipHostRegister) -- the 433 MB
                                     host-to-device copy then runs at PCIe speed instead of the pageable path */
+  double nest_dy, nest_ylat0;    /* fpx_verttransform_nest only: dyn(l), ylat0n(l) of the nest (com_mod.f90:477-479),
+                                    used in cosf (verttransform_nests.f90:346)                       */
 } fpx_model_levels;
 /* Optional copies back to the host (NULL members are skipped): the z-level arrays in the host's
  * shapes (0:nxmax-1,0:nymax-1,nzmax) for slot n, e.g. c_loc(tt(0,0,1,n)); height(nz); nmixz. */
@@ -187,6 +189,11 @@ typedef struct {
 /* sfc: the 2-D members of fpx_fields (hmix, ustar, wstar, oli, tropopause, vdep) that calcpar
  * leaves on the host; its 3-D members are ignored. */
 int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out);
+/* The same for nested grid `nest` (1-based, after fpx_nests_init): replaces `call verttransform_nests(memind(k),
+ * uuhn,vvhn,wwhn,pvhn)` (getfields.f90:133,168,184; verttransform_nests.f90:55-420 without its cloud diagnostics) and the
+ * fpx_upload_nest_fields of that slot.  Pointers address the nest's arrays of that nest, e.g. c_loc(uuhn(0,0,1,l)),
+ * c_loc(tthn(0,0,1,n,l)), strides nxmaxn, nymaxn; the z levels are the mother grid's. */
+int fpx_verttransform_nest(fpx_handle h, int32_t nest, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out);
 /* device time of the transform kernels of the last call, milliseconds */
 int fpx_verttransform_time(fpx_handle h, double *ms);
 /* ---- partoutput: the binary particle dump (SURVEY section 8 f, item 4) ----------------------

@@ -28,3 +28,10 @@ for case, kw in CASES.items():
         out["nmixz"] = np.int32(ref["nmixz"])
         np.savez_compressed(os.path.join(HERE, f"vt_{case}_{kind}.npz"), **out)
         print(case, kind, {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim == 3}.popitem())
+
+# nested grid: the unmodified verttransform_nests (reference built with par_mod_meteoswiss.f90, maxnests = 1)
+from test_verttransform import nest_case  # noqa: E402
+m, n = nest_case()
+ref = sio.run_vt_reference(m, "r8n", nest=n)
+np.savez_compressed(os.path.join(HERE, "vt_nest_r8.npz"), **{k: ref[k] for k in ("uun", "vvn", "wwn", "ttn", "qvn", "pvn", "rhon", "drhodzn")})
+print("nest", ref["uun"].shape)

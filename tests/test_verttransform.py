@@ -226,3 +226,64 @@ def test_hip_verttransform_at_the_baseline_grid(built):
     assert got["nmixz"] == want["nmixz"]
     worst = max_rel(got, want, m)
     assert max(worst.values()) <= 1e-11, worst
+
+
+# ---------------------------------------------------------------------------------------------
+# nested grids: verttransform_nests
+# ---------------------------------------------------------------------------------------------
+NEST_FIELDS = ("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz")
+
+
+def nest_case():
+    m = syn.model_levels(40, 24, 30, global_grid=False)
+    return m, syn.nest_model_levels(m)
+
+
+def test_nest_oracle_equals_reference_fixture():
+    """The restatement in nest mode == what the unmodified verttransform_nests produced (tests/golden/vt_nest_r8.npz,
+    flang build of the reference with par_mod_meteoswiss.f90, maxnests = 1)."""
+    from oracle import oracle as orc
+    m, n = nest_case()
+    gold = np.load(os.path.join(HERE, "golden", "vt_nest_r8.npz"))
+    mo = orc.vt_oracle(m, "r8")
+    no = orc.vt_oracle(n, "r8", height=mo["height"], nest_of=m)
+    for k in NEST_FIELDS:
+        assert np.array_equal(no[k], gold[k + "n"]), k
+
+
+@pytest.mark.ref
+def test_nest_oracle_equals_live_reference():
+    from oracle import oracle as orc, scenario_io as sio
+    if not sio.have_vt_ref("r8n"):
+        pytest.skip("flang-built reference not present (GPU box)")
+    m = syn.model_levels(50, 30, 36, global_grid=False, phase=2)
+    n = syn.nest_model_levels(m, ix0=5, jy0=4, ix1=30, jy1=20, factor=3, phase=11)
+    ref = sio.run_vt_reference(m, "r8n", nest=n)
+    mo = orc.vt_oracle(m, "r8")
+    no = orc.vt_oracle(n, "r8", height=mo["height"], nest_of=m)
+    for k in NEST_FIELDS:
+        assert np.array_equal(no[k], ref[k + "n"]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,tol", [("r8", 1e-11), ("r4", 1e-4)])
+def test_hip_verttransform_nest_matches_oracle(built, kind, tol):
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    from oracle import oracle as orc
+    m, n = nest_case()
+    nx, ny, nz = (int(v) for v in m["grid"])
+    rb = 8 if kind == "r8" else 4
+    sc = dict(syn.small(n=0, nx=nx, ny=ny, nz=nz, nsteps=1), grid=m["grid"], geom=m["geom"], globalflags=m["globalflags"])
+    for k in ("height", "nmixz", "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol", "hmix", "ustar", "wstar", "oli", "tropopause", "vdep"):
+        sc.pop(k, None)
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_PHILOX)
+    eng.verttransform(1, m, _sfc(nx, ny, nz, 0), init=True, want=())
+    eng.init_nest(n["grid"][:2], n["geom"])
+    nxn, nyn = int(n["grid"][0]), int(n["grid"][1])
+    sfcn = {k: np.full((nyn, nxn), v) for k, v in (("hmix", 800.0), ("ustar", 0.3), ("wstar", 1.0), ("oli", 0.01), ("tropopause", 11000.0))}
+    got = eng.verttransform(1, n, sfcn, nest=1, want=NEST_FIELDS)
+    eng.close()
+    mo = orc.vt_oracle(m, kind)
+    want = orc.vt_oracle(n, kind, height=mo["height"], nest_of=m)
+    worst = {k: float(np.abs(got[k] - want[k]).max() / max(np.abs(want[k]).max(), 1e-300)) for k in NEST_FIELDS}
+    assert max(worst.values()) <= tol, worst
