@@ -31,7 +31,7 @@ module flexgpu_mod
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions
 #ifdef FLEXGPU_NESTS
-  public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields
+  public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
 
   integer, parameter :: FPX_MAXSPEC = 5
@@ -71,6 +71,7 @@ module flexgpu_mod
   type, bind(C) :: fpx_model_levels
     type(c_ptr) :: uuh, vvh, pvh, wwh, tth, qvh, ps, tt2, td2, akz, bkz, aknew, bknew
     integer(c_int32_t) :: nuvz, nwz, init, pin_host
+    real(c_double) :: nest_dy, nest_ylat0
   end type fpx_model_levels
 
   type, bind(C) :: fpx_fields_out
@@ -164,6 +165,14 @@ module flexgpu_mod
       integer(c_int64_t), intent(out) :: np
       integer(c_int32_t), intent(out) :: npc, itimein
     end function fpx_readpartpositions
+    integer(c_int) function fpx_verttransform_nest(h, nest, slot, m, sfc, o) bind(C, name='fpx_verttransform_nest')
+      import :: c_ptr, c_int, c_int32_t, fpx_model_levels, fpx_fields, fpx_fields_out
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: nest, slot
+      type(fpx_model_levels), intent(in) :: m
+      type(fpx_fields), intent(in) :: sfc
+      type(fpx_fields_out), intent(in) :: o
+    end function fpx_verttransform_nest
     integer(c_int) function fpx_nests_init(h, n) bind(C, name='fpx_nests_init')
       import :: c_ptr, c_int, fpx_nests
       type(c_ptr), value :: h
@@ -440,6 +449,7 @@ contains
     m%akz = loc_r(akz); m%bkz = loc_r(bkz); m%aknew = loc_r(aknew); m%bknew = loc_r(bknew)
     m%nuvz = nuvz; m%nwz = nwz; m%init = merge(1, 0, first)
     m%pin_host = 0; if (present(pin_host)) m%pin_host = merge(1, 0, pin_host)
+    m%nest_dy = 0; m%nest_ylat0 = 0
     f%uu = c_null_ptr; f%vv = c_null_ptr; f%ww = c_null_ptr; f%uupol = c_null_ptr; f%vvpol = c_null_ptr
     f%rho = c_null_ptr; f%drhodz = c_null_ptr; f%tt = c_null_ptr
     f%hmix = loc_r(hmix(0,0,1,n)); f%ustar = loc_r(ustar(0,0,1,n)); f%wstar = loc_r(wstar(0,0,1,n))
@@ -539,8 +549,10 @@ contains
 #ifdef FLEXGPU_NESTS
   ! nested grids: geometry (gridcheck_nests.f90:362-378) and both time slots of every nest.
   ! Compiled only against a par_mod with maxnests >= 1 (zero-sized nest arrays otherwise).
-  subroutine flexgpu_upload_nests(ierr)
+  ! geometry_only = .true.: only fpx_nests_init (the fields then come from flexgpu_verttransform_nests)
+  subroutine flexgpu_upload_nests(ierr, geometry_only)
     integer, intent(out) :: ierr
+    logical, intent(in), optional :: geometry_only
     type(fpx_nests) :: n
     type(fpx_fields) :: f
     integer :: l, k, slot
@@ -554,6 +566,9 @@ contains
     end do
     ierr = fpx_nests_init(flexgpu_handle, n)
     if (ierr /= 0) return
+    if (present(geometry_only)) then
+      if (geometry_only) return
+    end if
     do l = 1, numbnests
       do k = 1, 2
         slot = memind(k)
@@ -568,6 +583,51 @@ contains
       end do
     end do
   end subroutine flexgpu_upload_nests
+
+  subroutine flexgpu_nests_init(ierr)
+    integer, intent(out) :: ierr
+    call flexgpu_upload_nests(ierr, geometry_only=.true.)
+  end subroutine flexgpu_nests_init
+
+  ! Replaces `call verttransform_nests(n,uuhn,vvhn,wwhn,pvhn)` (getfields.f90:133,168,184) and the upload of slot n of
+  ! every nest; writeback as in flexgpu_verttransform (uun ... drhodzn of slot n).
+  subroutine flexgpu_verttransform_nests(n, uuhn, vvhn, wwhn, pvhn, ierr, writeback)
+    integer, intent(in) :: n
+    real, intent(in) :: uuhn(0:nxmaxn-1,0:nymaxn-1,nuvzmax,maxnests), vvhn(0:nxmaxn-1,0:nymaxn-1,nuvzmax,maxnests)
+    real, intent(in) :: pvhn(0:nxmaxn-1,0:nymaxn-1,nuvzmax,maxnests), wwhn(0:nxmaxn-1,0:nymaxn-1,nwzmax,maxnests)
+    integer, intent(out) :: ierr
+    logical, intent(in), optional :: writeback
+    type(fpx_model_levels) :: m
+    type(fpx_fields) :: f
+    type(fpx_fields_out) :: o
+    integer :: l
+    logical :: wb
+    wb = .true.; if (present(writeback)) wb = writeback
+    ierr = 0
+    do l = 1, numbnests
+      m%uuh = loc_r(uuhn(0:,0,1,l)); m%vvh = loc_r(vvhn(0:,0,1,l)); m%pvh = loc_r(pvhn(0:,0,1,l)); m%wwh = loc_r(wwhn(0:,0,1,l))
+      m%tth = loc_r(tthn(0:,0,1,n,l)); m%qvh = loc_r(qvhn(0:,0,1,n,l))
+      m%ps = loc_r(psn(0:,0,1,n,l)); m%tt2 = loc_r(tt2n(0:,0,1,n,l)); m%td2 = loc_r(td2n(0:,0,1,n,l))
+      m%akz = loc_r(akz); m%bkz = loc_r(bkz); m%aknew = loc_r(aknew); m%bknew = loc_r(bknew)
+      m%nuvz = nuvz; m%nwz = nwz; m%init = 0; m%pin_host = 0
+      m%nest_dy = dyn(l); m%nest_ylat0 = ylat0n(l)
+      f%uu = c_null_ptr; f%vv = c_null_ptr; f%ww = c_null_ptr; f%uupol = c_null_ptr; f%vvpol = c_null_ptr
+      f%rho = c_null_ptr; f%drhodz = c_null_ptr; f%tt = c_null_ptr
+      f%hmix = loc_r(hmixn(0:,0,1,n,l)); f%ustar = loc_r(ustarn(0:,0,1,n,l)); f%wstar = loc_r(wstarn(0:,0,1,n,l))
+      f%oli = loc_r(olin(0:,0,1,n,l)); f%tropopause = loc_r(tropopausen(0:,0,1,n,l))
+      f%vdep = loc_r(vdepn(0:,0,1,n,l))
+      o%uu = c_null_ptr; o%vv = c_null_ptr; o%ww = c_null_ptr; o%tt = c_null_ptr; o%qv = c_null_ptr
+      o%pv = c_null_ptr; o%rho = c_null_ptr; o%drhodz = c_null_ptr; o%uupol = c_null_ptr; o%vvpol = c_null_ptr
+      o%height = c_null_ptr; o%nmixz = c_null_ptr
+      if (wb) then
+        o%uu = loc_r(uun(0:,0,1,n,l)); o%vv = loc_r(vvn(0:,0,1,n,l)); o%ww = loc_r(wwn(0:,0,1,n,l))
+        o%tt = loc_r(ttn(0:,0,1,n,l)); o%qv = loc_r(qvn(0:,0,1,n,l)); o%pv = loc_r(pvn(0:,0,1,n,l))
+        o%rho = loc_r(rhon(0:,0,1,n,l)); o%drhodz = loc_r(drhodzn(0:,0,1,n,l))
+      end if
+      ierr = fpx_verttransform_nest(flexgpu_handle, int(l, c_int32_t), int(n, c_int32_t), m, f, o)
+      if (ierr /= 0) return
+    end do
+  end subroutine flexgpu_verttransform_nests
 #endif
 
   subroutine flexgpu_set_windtime(ierr)

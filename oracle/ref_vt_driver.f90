@@ -186,6 +186,18 @@ program vtref
         call flexgpu_last_error(gmsg); write(*,*) 'flexgpu_verttransform: ', trim(gmsg); stop 1
       end if
     end do
+#ifdef FLEXREF_NESTS
+    if (numbnests .ge. 1) then
+      xln(1)=(xlon0n(1)-xlon0)/dx; xrn(1)=(xlon0n(1)+real(nxn(1)-1)*dxn(1)-xlon0)/dx      ! gridcheck_nests.f90:362-372
+      yln(1)=(ylat0n(1)-ylat0)/dy; yrn(1)=(ylat0n(1)+real(nyn(1)-1)*dyn(1)-ylat0)/dy
+      hmixn=500.; ustarn=0.3; wstarn=1.; olin=0.01; tropopausen=10000.
+      call flexgpu_nests_init(gerr)
+      if (gerr .eq. 0) call flexgpu_verttransform_nests(1,uuhn,vvhn,wwhn,pvhn,gerr)
+      if (gerr .ne. 0) then
+        call flexgpu_last_error(gmsg); write(*,*) 'flexgpu_verttransform_nests: ', trim(gmsg); stop 1
+      end if
+    end if
+#endif
   else
     do icall=1,ncalls
       call verttransform_ecmwf(1,uuh,vvh,wwh,pvh)

@@ -287,3 +287,20 @@ def test_hip_verttransform_nest_matches_oracle(built, kind, tol):
     want = orc.vt_oracle(n, kind, height=mo["height"], nest_of=m)
     worst = {k: float(np.abs(got[k] - want[k]).max() / max(np.abs(want[k]).max(), 1e-300)) for k in NEST_FIELDS}
     assert max(worst.values()) <= tol, worst
+
+
+@pytest.mark.gpu
+def test_fortran_host_verttransform_nests(built):
+    """The real Fortran host with one nest (reference built with maxnests = 1): vtref_r8n either calls
+    verttransform_ecmwf + verttransform_nests or flexgpu_verttransform + flexgpu_verttransform_nests on the same
+    com_mod arrays; uun ... drhodzn come back into com_mod."""
+    from oracle import scenario_io as sio
+    if not sio.have_vt_ref("r8n"):
+        pytest.skip("oracle/_ref binaries not present in this snapshot")
+    m, n = nest_case()
+    ref = sio.run_vt_reference(m, "r8n", nest=n)
+    gpu = sio.run_vt_reference(m, "r8n", nest=n, gpu=True)
+    worst = {k: float(np.abs(gpu[k + "n"] - ref[k + "n"]).max() / max(np.abs(ref[k + "n"]).max(), 1e-300)) for k in NEST_FIELDS}
+    assert max(worst.values()) <= 1e-11, worst
+    for k in NEST_FIELDS:      # the mother grid of the same run
+        assert np.abs(gpu[k] - ref[k]).max() <= 1e-11 * np.abs(ref[k]).max(), k
