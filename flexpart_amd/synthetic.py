@@ -539,3 +539,45 @@ def nest_model_levels(m, ix0=10, jy0=6, ix1=25, jy1=16, factor=2, phase=3):
     n["geom"] = np.array([dx / factor, dy / factor, xlon0 + ix0 * dx, ylat0 + jy0 * dy], np.float64)
     n["globalflags"] = np.array([0, 0, 0], np.int32)
     return n
+
+
+# --------------------------------------------------------------------------
+# concoutput: output grids with the run structure the sparse writer compresses
+# --------------------------------------------------------------------------
+def concoutput_case(nxg=24, nyg=16, nzg=4, nspec=2, wet=True, dry=True, itime=3600, seed=5):
+    """gridunc / wetgridunc / drygridunc with empty stretches, single cells and long runs (float32 values, as the
+    sampling kernels leave them), plus area/volume as outgrid_init.f90:59-95 computes them."""
+    u = _uniform01(nspec * nzg * nyg * nxg, seed).reshape(nspec, nzg, nyg, nxg)
+    blob = _wave(np.arange(nxg)[None, None, None, :] * 3 + np.arange(nyg)[None, None, :, None] * 5, 4 * nxg)
+    g = np.where((u > 0.55) & (blob > -0.2), (u * 1.0e-3).astype(np.float32), np.float32(0.0)).astype(np.float64)
+    g[:, :, 0, :] = 0.0                      # a whole empty row
+    g[:, 1, 3, :] = 2.0e-4                   # a whole full row
+    w2 = np.where(u[:, 0] > 0.7, (u[:, 0] * 1.0e-5).astype(np.float32), np.float32(0.0)).astype(np.float64)
+    d2 = np.where(u[:, 1] > 0.4, (u[:, 1] * 1.0e-6).astype(np.float32), np.float32(0.0)).astype(np.float64)
+    outheight = np.array([100.0, 500.0, 1000.0, 5000.0, 10000.0][:nzg])
+    dxout, dyout, outlon0, outlat0 = 1.0, 1.0, -10.0, 30.0
+    f32 = np.float32
+    pi, r_earth = f32(3.14159265), f32(6.371e6)
+    pi180 = pi / f32(180.0)
+    area = np.zeros((nyg, nxg)); volume = np.zeros((nzg, nyg, nxg))
+    for jy in range(nyg):                    # outgrid_init.f90:59-95 in the reference's own real kind (f32)
+        ylat = f32(outlat0) + (f32(jy) + f32(0.5)) * f32(dyout)
+        ylatp = ylat + f32(0.5) * f32(dyout); ylatm = ylat - f32(0.5) * f32(dyout)
+        if ylatm < 0 and ylatp > 0:
+            hzone = f32(dyout) * r_earth * pi180
+        else:
+            cp = f32(np.cos(ylatp * pi180)); cm = f32(np.cos(ylatm * pi180))
+            a_, b_ = (cp, cm) if cp < cm else (cm, cp)
+            hzone = (f32(np.sqrt(f32(1) - a_ * a_)) - f32(np.sqrt(f32(1) - b_ * b_))) * r_earth
+        ga = f32(2.0) * pi * r_earth * hzone * f32(dxout) / f32(360.0)
+        area[jy, :] = ga
+        volume[0, jy, :] = ga * f32(outheight[0])
+        for kz in range(1, nzg):
+            volume[kz, jy, :] = ga * (f32(outheight[kz]) - f32(outheight[kz - 1]))
+    co = dict(outgrid=np.array([nxg, nyg, nzg, nspec, int(wet), int(dry), itime], np.int32),
+              outgeom=np.array([dxout, dyout, outlon0, outlat0, 4.0]), outheight=outheight, area=area, volume=volume, gridunc=g)
+    if wet:
+        co["wetgridunc"] = w2
+    if dry:
+        co["drygridunc"] = d2
+    return co

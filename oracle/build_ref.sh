@@ -118,6 +118,22 @@ build_rp() {
   echo "build_ref: built $OUT/rpref_$kind"
 }
 
+# concoutput (the sparse grid_conc writer) behind oracle/ref_co_driver.f90 -> coref_rK
+build_co() {
+  local kind="$1"; shift
+  local flags="$*"
+  local obj="$OUT/obj_$kind"
+  ( cd "$obj"
+    [ "$obj/mean_mod.o" -nt "$REF/mean_mod.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/mean_mod.f90" -o mean_mod.o
+    for s in concoutput caldate juldate; do
+      [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
+    done
+    "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_co_driver.f90" -o ref_co_driver.o
+    "$FC" -O2 -mcmodel=medium $flags ref_co_driver.o concoutput.o mean_mod.o caldate.o juldate.o par_mod.o com_mod.o unc_mod.o outg_mod.o point_mod.o -o "$OUT/coref_$kind"
+  )
+  echo "build_ref: built $OUT/coref_$kind"
+}
+
 mkdir -p "$OUT"
 build_one r4 par_mod.f90
 build_one r8 par_mod.f90 -fdefault-real-8
@@ -127,6 +143,7 @@ build_po r4
 build_po r8 -fdefault-real-8
 build_rp r4
 build_rp r8 -fdefault-real-8
+build_co r4      # (with -fdefault-real-8 concoutput.f90 itself does not compile: no specific of mean_mod's generic matches)
 # nested-grid variant: the stock par_mod.f90 has maxnests=0; the reference's own
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path
 build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS

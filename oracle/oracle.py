@@ -16,13 +16,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build(force=False):
     """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
-    for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"), ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle")):
+    for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"),
+                      ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle")):
         src = os.path.join(HERE, stem + ".c")
         for kind, real in (("r4", "float"), ("r8", "double")):
             out = os.path.join(HERE, f"{lib}_{kind}.so")
             if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
                 subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off",
                                        f"-DORC_REAL={real}", src, "-o", out, "-lm"])
+    _build_co()
+
+
+def _build_co():
+    src = os.path.join(HERE, "concoutput_oracle.c")
+    out = os.path.join(HERE, "libcooracle_r4.so")
+    if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-ffp-contract=off", src, "-o", out, "-lm"])
+    return out
 
 
 def _f64(a):
@@ -451,3 +461,36 @@ def rp_oracle(file_bytes, rs, kind="r8"):
     res = {k: (v[:, :n] if v.ndim == 2 else v[:n]).copy() for k, v in out.items()}
     res.update(numpart=n, numparticlecount=int(a.numparticlecount), itimein=int(a.itimein), status=int(a.status))
     return res
+
+
+# --------------------------------------------------------------------------
+# concoutput (oracle/concoutput_oracle.c; float only, like the reference)
+# --------------------------------------------------------------------------
+class _CooArgs(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ("nxg", "nyg", "nzg", "nspec", "nclassunc", "wetdep", "drydep", "itime")]
+                + [("outnum", C.c_float)]
+                + [(k, C.POINTER(C.c_float)) for k in ("area", "volume", "gridunc", "wetgridunc", "drygridunc")])
+
+
+def co_oracle(co):
+    """{file name suffix _<species>: bytes} of the grid_conc files for a synthetic.concoutput_case() dict."""
+    lib = C.CDLL(_build_co())
+    lib.coo_concoutput.restype = C.c_long
+    nxg, nyg, nzg, nspec, wet, dry, itime = (int(v) for v in co["outgrid"])
+    a = _CooArgs()
+    a.nxg, a.nyg, a.nzg, a.nspec, a.nclassunc, a.wetdep, a.drydep, a.itime = nxg, nyg, nzg, nspec, 1, wet, dry, itime
+    a.outnum = float(co["outgeom"][4])
+    keep = {}
+    fp = C.POINTER(C.c_float)
+    for k in ("area", "volume", "gridunc", "wetgridunc", "drygridunc"):
+        keep[k] = np.ascontiguousarray(np.asarray(co.get(k, np.zeros(1)), dtype=np.float32))
+        setattr(a, k, keep[k].ctypes.data_as(fp))
+    n3 = nxg * nyg * nzg
+    wi = np.zeros(n3 + 1, np.int32); wr = np.zeros(n3 + 1, np.float32); g = np.zeros(n3, np.float32); f3 = np.zeros(n3, np.float32)
+    buf = (C.c_ubyte * (64 + 3 * 16 + 3 * 8 * (n3 + 2)))()
+    out = {}
+    for ks in range(nspec):
+        nb = lib.coo_concoutput(C.byref(a), ks, buf, wi.ctypes.data_as(C.POINTER(C.c_int32)), wr.ctypes.data_as(fp),
+                                g.ctypes.data_as(fp), f3.ctypes.data_as(fp))
+        out[f"_{ks + 1:03d}"] = bytes(buf[:nb])
+    return out

@@ -242,3 +242,37 @@ def run_rp_reference(file_bytes, rs, kind="r8", workdir="/tmp", gpu=False):
         return out
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+# --------------------------------------------------------------------------
+# concoutput through oracle/_ref/coref_r4 (oracle/ref_co_driver.f90)
+# --------------------------------------------------------------------------
+def have_co_ref(kind="r4"):
+    return os.access(os.path.join(HERE, "_ref", f"coref_{kind}"), os.X_OK)
+
+
+def run_co_reference(co, kind="r4", workdir="/tmp"):
+    """The unmodified concoutput on a dict (outgrid, outgeom, outheight, area, volume, gridunc[, wetgridunc, drygridunc])
+    -> {file name: bytes} of the grid_conc_* files it wrote."""
+    import glob
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="co_", dir=workdir)
+    try:
+        fs = os.path.join(d, "co.scen")
+        with open(fs, "wb") as fh:
+            for name in ("outgrid", "outgeom", "outheight", "area", "volume", "gridunc", "wetgridunc", "drygridunc"):
+                if name not in co:
+                    continue
+                code = 1 if name == "outgrid" else 2
+                a = np.ascontiguousarray(np.asarray(co[name], dtype=np.int32 if code == 1 else np.float64).ravel())
+                fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
+                fh.write(a.tobytes())
+            fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
+        exe = os.path.join(HERE, "_ref", f"coref_{kind}")
+        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/"], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"reference concoutput driver failed: {res.stdout}\n{res.stderr}")
+        return {os.path.basename(f): open(f, "rb").read() for f in sorted(glob.glob(os.path.join(d, "grid_conc_*")))}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
