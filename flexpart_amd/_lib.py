@@ -81,6 +81,10 @@ class FpxRestart(C.Structure):
     _fields_ = [("jul_header", C.c_double), ("bdate", C.c_double), ("mintime", C.c_int32), ("nclassunc", C.c_int32)]
 
 
+class FpxConcout(C.Structure):
+    _fields_ = [("area", C.c_void_p), ("volume", C.c_void_p), ("outnum", C.c_double), ("wetdep", C.c_int32), ("drydep", C.c_int32)]
+
+
 class FpxParticles(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws",
@@ -139,7 +143,7 @@ SYMBOLS = [
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
-    "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions",
+    "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
 ]
 
 _lib = None
@@ -177,6 +181,7 @@ def load():
     lib.fpx_upload_diag_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxDiagFields)]
     lib.fpx_partoutput.argtypes = [vp, C.c_int32, C.c_char_p, C.POINTER(C.c_int64)]
     lib.fpx_partoutput_time.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.fpx_concoutput.argtypes = [vp, C.c_int32, C.POINTER(FpxConcout), C.c_char_p, C.c_int32]
     lib.fpx_readpartpositions.argtypes = [vp, C.c_char_p, C.POINTER(FpxRestart), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.fpx_set_windtime.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.fpx_rng_fill_table.argtypes = [vp]

@@ -565,6 +565,50 @@ __global__ void __launch_bounds__(kBlock) k_readpart(Parts<R> P, const unsigned 
   for (int ks = 0; ks < nspec; ks++) P.xmass1[(size_t)ks * P.cap + i] = (R)get(x + ks * hw);
 }
 
+// ---------------------------------------------------------------------------
+// concoutput.f90:296-447 -- the sparse grid_conc writer.  For one (species, pointspec,
+// age class): class mean of the sampling grid, the non-zero test, and the run-length compression (start index
+// of every run of non-zero cells; values with a sign that flips from run to run) as two scans and two
+// element-wise kernels.  Arithmetic in float, the reference's own kind for this routine, contraction off.
+// ---------------------------------------------------------------------------
+template <typename G>
+__global__ void __launch_bounds__(kBlock) k_co_values(const G *__restrict__ grid, size_t class_stride, int nclass, long long n,
+                                                      float *__restrict__ val, unsigned int *__restrict__ nz, unsigned int *__restrict__ rs) {
+#pragma clang fp contract(off)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  auto value = [&](long long j) -> float {          // mean_mod.f90:mean_sp, times nclassunc (concoutput.f90:323-325)
+    float xl = 0.f;
+    for (int l = 0; l < nclass; l++) xl = xl + (float)grid[(size_t)l * class_stride + j];
+    return (xl / (float)nclass) * (float)nclass;
+  };
+  const float v = value(i);
+  const bool on = v > 1.17549435e-38f;               // smallnum = tiny(0.0)
+  const bool prev = i > 0 && value(i - 1) > 1.17549435e-38f;
+  val[i] = v;
+  nz[i] = on ? 1u : 0u;
+  rs[i] = (on && !prev) ? 1u : 0u;                   // sp_zer: a run starts here
+}
+
+__global__ void __launch_bounds__(kBlock) k_co_write(const float *__restrict__ val, const unsigned int *__restrict__ nz, const unsigned int *__restrict__ rs,
+                                                     const unsigned int *__restrict__ rpos /* exclusive scan of nz */,
+                                                     const unsigned int *__restrict__ runid /* inclusive scan of rs */, long long n,
+                                                     const float *__restrict__ scale /* volume (conc) or area, per cell */, int conc, float outnum, float tot_mu,
+                                                     int idx0, int *__restrict__ wi, float *__restrict__ wr) {
+#pragma clang fp contract(off)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !nz[i]) return;
+  const unsigned int run = runid[i];
+  const float sp_fact = (run & 1u) ? 1.f : -1.f;     // sp_fact starts at -1 and flips at every run start
+  if (rs[i]) wi[run - 1] = (int)i + idx0;
+  float r;
+  if (conc) {
+    const float f3 = 1.e12f / scale[i] / outnum;     // factor3d, concoutput.f90:226 (ldirect = 1)
+    r = sp_fact * val[i] * f3 / tot_mu;
+  } else r = sp_fact * 1.e12f * val[i] / scale[i];
+  wr[rpos[i]] = r;
+}
+
 // After the stable sort of the slots by their 3-bit key: list length = number of keys <= 4 (PBL
 // classes), particles due = number of keys <= 6.  One wave, two 64-ary searches (5 dependent
 // loads each at 1e8 keys).
@@ -891,6 +935,7 @@ struct EngineBase {
   virtual double po_ms() = 0;
   virtual int upload_diag_fields(int slot, const fpx_diag_fields *f) = 0;
   virtual int partoutput(int itime, const char *path, int64_t *nrec) = 0;
+  virtual int concoutput(int itime, const fpx_concout *c, const char *prefix, int clear) = 0;
   virtual int readpartpositions(const char *path, const fpx_restart *r, int64_t *numpart_out, int32_t *numparticlecount, int32_t *itimein) = 0;
 };
 
@@ -1676,6 +1721,102 @@ struct Engine : EngineBase {
     if (r->nclassunc < 1) return fail(FPX_ERR_ARG, "readpartpositions: nclassunc >= 1");
     return cfg.host_real_bytes == 4 ? readpart_t<float>(path, r, numpart_out, numparticlecount, itimein)
                                     : readpart_t<double>(path, r, numpart_out, numparticlecount, itimein);
+  }
+
+
+  // ---- concoutput: the grid_conc files ------------------------------------
+  int concoutput(int itime, const fpx_concout *c, const char *prefix, int clear) override {
+    if (!Gp.on) return fail(FPX_ERR_STATE, "concoutput: fpx_outgrid_init first");
+    if (!c || !c->area || !c->volume || !prefix) return fail(FPX_ERR_ARG, "concoutput: area, volume and the file name prefix are required");
+    if (cfg.host_real_bytes != 4) return fail(FPX_ERR_ARG, "concoutput: only for hosts with a 4-byte default real (the reference's concoutput.f90 does not compile with 8)");
+    if (cfg.ldirect != 1) return fail(FPX_ERR_ARG, "concoutput: forward runs only (ldirect = 1)");
+    if (!(c->outnum > 0)) return fail(FPX_ERR_ARG, "concoutput: outnum > 0");
+    const long long n2 = (long long)Gp.numxgrid * Gp.numygrid, n3 = n2 * Gp.numzgrid;
+    float *d_area = nullptr, *d_vol = nullptr, *val = nullptr, *wr = nullptr;
+    unsigned int *nz = nullptr, *rs = nullptr, *rpos = nullptr, *runid = nullptr;
+    int *wi = nullptr;
+    void *tmp = nullptr;
+    std::vector<void *> mine;
+    auto cleanup = [&]() { for (void *q : mine) (void)hipFree(q); if (tmp) (void)hipFree(tmp); };
+    auto mal = [&](auto **q, size_t bytes) -> hipError_t { hipError_t e = hipMalloc((void **)q, bytes); if (e == hipSuccess) mine.push_back(*q); return e; };
+    hipError_t e = mal(&d_area, n2 * 4);
+    if (e == hipSuccess) e = mal(&d_vol, n3 * 4);
+    if (e == hipSuccess) e = mal(&val, n3 * 4);
+    if (e == hipSuccess) e = mal(&wr, n3 * 4);
+    if (e == hipSuccess) e = mal(&nz, n3 * 4);
+    if (e == hipSuccess) e = mal(&rs, n3 * 4);
+    if (e == hipSuccess) e = mal(&rpos, n3 * 4);
+    if (e == hipSuccess) e = mal(&runid, n3 * 4);
+    if (e == hipSuccess) e = mal(&wi, n3 * 4);
+    size_t tb = 0;
+    if (e == hipSuccess) {
+      (void)rocprim::exclusive_scan(nullptr, tb, nz, rpos, 0u, (size_t)n3, rocprim::plus<unsigned int>(), stream);
+      size_t tb2 = 0;
+      (void)rocprim::inclusive_scan(nullptr, tb2, rs, runid, (size_t)n3, rocprim::plus<unsigned int>(), stream);
+      tb = std::max(tb, tb2);
+      e = hipMalloc(&tmp, std::max<size_t>(tb, 16));
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(d_area, c->area, n2 * 4, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_vol, c->volume, n3 * 4, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("concoutput: ") + hipGetErrorString(e)); }
+    std::vector<int> h_wi((size_t)n3);
+    std::vector<float> h_wr((size_t)n3);
+    // one compressed dump: device work, then the four records (count, indices, count, values)
+    auto dump = [&](auto *grid, size_t class_stride, long long n, const float *scale, int conc, int idx0, FILE *fh) -> int {
+      const int nb = (int)((n + kBlock - 1) / kBlock);
+      int32_t ci = 0, cr = 0;
+      if (grid) {
+        k_co_values<<<nb, kBlock, 0, stream>>>(grid, class_stride, Gp.nclassunc, n, val, nz, rs);
+        size_t t1 = tb;
+        hipError_t e2 = rocprim::exclusive_scan(tmp, t1, nz, rpos, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
+        t1 = tb;
+        if (e2 == hipSuccess) e2 = rocprim::inclusive_scan(tmp, t1, rs, runid, (size_t)n, rocprim::plus<unsigned int>(), stream);
+        k_co_write<<<nb, kBlock, 0, stream>>>(val, nz, rs, rpos, runid, n, scale, conc, (float)c->outnum, 1.f, idx0, wi, wr);
+        unsigned int last[3] = {0, 0, 0};
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&last[0], rpos + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&last[1], nz + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+        if (e2 == hipSuccess) e2 = hipMemcpyAsync(&last[2], runid + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(stream);
+        cr = (int32_t)(last[0] + last[1]); ci = (int32_t)last[2];
+        if (e2 == hipSuccess && ci > 0) e2 = hipMemcpyAsync(h_wi.data(), wi, (size_t)ci * 4, hipMemcpyDeviceToHost, stream);
+        if (e2 == hipSuccess && cr > 0) e2 = hipMemcpyAsync(h_wr.data(), wr, (size_t)cr * 4, hipMemcpyDeviceToHost, stream);
+        if (e2 == hipSuccess) e2 = hipStreamSynchronize(stream);
+        if (e2 != hipSuccess) return fail(FPX_ERR_DEVICE, std::string("concoutput: ") + hipGetErrorString(e2));
+      }
+      const int32_t four = 4, li = 4 * ci, lr = 4 * cr;
+      bool ok = fwrite(&four, 4, 1, fh) == 1 && fwrite(&ci, 4, 1, fh) == 1 && fwrite(&four, 4, 1, fh) == 1;
+      ok = ok && fwrite(&li, 4, 1, fh) == 1 && (ci == 0 || fwrite(h_wi.data(), 4, (size_t)ci, fh) == (size_t)ci) && fwrite(&li, 4, 1, fh) == 1;
+      ok = ok && fwrite(&four, 4, 1, fh) == 1 && fwrite(&cr, 4, 1, fh) == 1 && fwrite(&four, 4, 1, fh) == 1;
+      ok = ok && fwrite(&lr, 4, 1, fh) == 1 && (cr == 0 || fwrite(h_wr.data(), 4, (size_t)cr, fh) == (size_t)cr) && fwrite(&lr, 4, 1, fh) == 1;
+      return ok ? 0 : fail(FPX_ERR_ARG, "concoutput: write error");
+    };
+    int rc = 0;
+    for (int ks = 0; ks < cfg.nspec && !rc; ks++) {
+      char name[1024];
+      snprintf(name, sizeof name, "%s%03d", prefix, ks + 1);
+      FILE *fh = fopen(name, "wb");
+      if (!fh) { rc = fail(FPX_ERR_ARG, std::string("concoutput: cannot open ") + name); break; }
+      const int32_t hdr[3] = {4, itime, 4};
+      if (fwrite(hdr, 4, 3, fh) != 3) rc = fail(FPX_ERR_ARG, "concoutput: write error");
+      for (int kp = 0; kp < Gp.maxpointspec_act && !rc; kp++)
+        for (int nage = 0; nage < Gp.nageclass && !rc; nage++) {
+          // element (0,0,[1,]ks,kp,class 0,nage) of the 6-D / 7-D arrays; consecutive classes are class_stride apart
+          const size_t o2 = ((((size_t)nage * Gp.nclassunc) * Gp.maxpointspec_act + kp) * Gp.maxspec + ks) * (size_t)n2;
+          const size_t cs2 = (size_t)Gp.maxpointspec_act * Gp.maxspec * (size_t)n2;
+          const size_t o3 = o2 * Gp.numzgrid, cs3 = cs2 * Gp.numzgrid;
+          rc = dump(c->wetdep && Gp.wetgridunc ? Gp.wetgridunc + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
+          if (!rc) rc = dump(c->drydep ? Gp.drygridunc + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
+          if (!rc) rc = dump(Gp.gridunc + o3, cs3, n3, d_vol, 1, (int)n2 /* kz is 1-based in the index, :425 */, fh);
+        }
+      if (fclose(fh) != 0 && !rc) rc = fail(FPX_ERR_ARG, "concoutput: write error");
+    }
+    cleanup();
+    if (rc) return rc;
+    if (clear) {   // gridunc(:,:,:,:,:,:,:)=0., concoutput.f90:714 (the deposition grids keep accumulating)
+      HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    return 0;
   }
 
   int set_windtime(const int32_t mt[2], const int32_t mi[2]) override {
@@ -2585,6 +2726,7 @@ int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r, 
   FPX_GUARD(h);
   return h->impl->readpartpositions(path, r, numpart, numparticlecount, itimein);
 }
+int fpx_concoutput(fpx_handle h, int32_t itime, const fpx_concout *c, const char *prefix, int32_t clear) { FPX_GUARD(h); return h->impl->concoutput(itime, c, prefix, clear); }
 int fpx_partoutput_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_partoutput_time: null"); *ms = h->impl->po_ms(); return FPX_OK; }
 int fpx_verttransform_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_verttransform_time: null"); *ms = h->impl->vt_ms(); return FPX_OK; }
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]) { FPX_GUARD(h); return h->impl->set_windtime(memtime, memind); }

@@ -271,6 +271,14 @@ class Engine:
         self.n = int(n.value)
         return int(n.value), int(npc.value), int(it.value)
 
+    def concoutput(self, itime, prefix, area, volume, outnum, wetdep=False, drydep=False, clear=False):
+        """fpx_concoutput: writes <prefix><nnn> (the reference's grid_conc_* files) for every species."""
+        from ._lib import FpxConcout
+        a = np.ascontiguousarray(np.asarray(area, dtype=np.float32))
+        v = np.ascontiguousarray(np.asarray(volume, dtype=np.float32))
+        c = FpxConcout(a.ctypes.data, v.ctypes.data, float(outnum), int(wetdep), int(drydep))
+        check(self.lib.fpx_concoutput(self.h, int(itime), C.byref(c), str(prefix).encode(), int(clear)), "fpx_concoutput")
+
     def upload_nests_from_scenario(self, sc):
         """One nested grid: geometry as gridcheck_nests.f90:362-378 derives it, fields uun, vvn, ..."""
         rt = self.hreal

@@ -232,6 +232,25 @@ typedef struct {
 } fpx_restart;
 int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
                           int64_t *numpart, int32_t *numparticlecount, int32_t *itimein);
+/* ---- concoutput: the sparse concentration files (SURVEY section 8 f, item 4) -----------------
+ * Replaces the part of `call concoutput(itime,outnum,...)` (timemanager.f90:384; the routine:
+ * concoutput.f90:226-228,296-447) that writes grid_conc_<date><time>_<species> for a forward run with
+ * iout = 1: per species, point-release class and age class the class mean of wetgridunc, drygridunc and
+ * gridunc and their run-length compressed dumps, computed on the device from the grids the sampling kernels
+ * filled; only the compressed indices and values travel to the host, which writes the records.
+ * Byte-identical to the reference's file for the same grids.  Hosts with a 4-byte default real only (the
+ * reference's concoutput.f90 does not compile with -fdefault-real-8).  Not written: dates, grid_pptv_*,
+ * factor_drygrid, the receptor files (host side, from fpx_get_receptors).  For the sum over ranks call
+ * fpx_get_grids(h, NULL, NULL, 1, 0) / fpx_get_wetgrid(h, NULL, 1, 0) first.
+ * prefix: the file name without the species number, e.g. "<path>grid_conc_20200101010000_".
+ * clear = 1 zeroes gridunc afterwards as the routine does (:714). */
+typedef struct {
+  const void *area;      /* area(0:numxgrid-1,0:numygrid-1), outg_mod (outgrid_init.f90:59-84)          */
+  const void *volume;    /* volume(0:numxgrid-1,0:numygrid-1,numzgrid)                                  */
+  double outnum;         /* sum of the sampling weights of the averaging interval (timemanager.f90:363)  */
+  int32_t wetdep, drydep;
+} fpx_concout;
+int fpx_concoutput(fpx_handle h, int32_t itime, const fpx_concout *c, const char *prefix, int32_t clear);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]);
 

@@ -1,0 +1,85 @@
+"""concoutput: the sparse concentration files grid_conc_<date><time>_<species>.
+
+CPU (-m "not gpu"): the C restatement oracle/concoutput_oracle.c reproduces byte for byte the files the
+unmodified reference routine wrote (tests/golden/co_*.bin, made by tests/golden/make_golden_co.py with the
+flang build; float only -- concoutput.f90 does not compile with -fdefault-real-8) and the live reference.
+GPU (-m gpu): particles are sampled into the output grid by the device (conccalc, dry and wet deposition),
+fpx_concoutput compresses those grids on the device and writes the files; the oracle gets the very same grids
+(downloaded through fpx_get_grids) and must produce the same bytes.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from flexpart_amd import synthetic as syn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = {"two_species": dict(), "no_deposition": dict(wet=False, dry=False, nspec=1), "odd_sizes": dict(nxg=37, nyg=19, nzg=3, nspec=3, seed=11)}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_oracle_equals_reference_files(case):
+    from oracle import oracle as orc
+    got = orc.co_oracle(syn.concoutput_case(**CASES[case]))
+    for suffix, b in got.items():
+        assert b == open(os.path.join(HERE, "golden", f"co_{case}{suffix}.bin"), "rb").read(), suffix
+
+
+@pytest.mark.ref
+def test_oracle_equals_live_reference():
+    from oracle import oracle as orc, scenario_io as sio
+    if not sio.have_co_ref():
+        pytest.skip("flang-built reference not present (GPU box)")
+    co = syn.concoutput_case(nxg=50, nyg=31, nzg=5, nspec=2, seed=99)
+    ref = sio.run_co_reference(co)
+    got = orc.co_oracle(co)
+    assert len(ref) == 2
+    for name, b in ref.items():
+        assert got["_" + name[-3:]] == b, name
+
+
+def test_runs_and_signs():
+    """The compression itself on a hand-made row: runs start where a non-zero cell follows a zero one, the
+    sign of the values flips from run to run, indices of the 3-D dump are offset by one level."""
+    import struct
+    from oracle import oracle as orc
+    co = syn.concoutput_case(nxg=8, nyg=4, nzg=2, nspec=1, wet=False, dry=False)
+    co["gridunc"] = np.zeros((1, 2, 4, 8))
+    co["gridunc"][0, 0, 0, :] = np.array([0, 1, 2, 0, 0, 3, 0, 4]) * 1e-3
+    b = orc.co_oracle(co)["_001"]
+    p = 12 + 2 * (12 + 8 + 12 + 8)              # itime record, empty wet and dry dumps
+    ci = struct.unpack("<i", b[p + 4:p + 8])[0]
+    idx = struct.unpack(f"<{ci}i", b[p + 16:p + 16 + 4 * ci])
+    q = p + 12 + 8 + 4 * ci
+    cr = struct.unpack("<i", b[q + 4:q + 8])[0]
+    vals = np.frombuffer(b[q + 16:q + 16 + 4 * cr], np.float32)
+    assert (ci, cr) == (3, 4) and idx == (32 + 1, 32 + 5, 32 + 7)      # + numxgrid*numygrid: kz is 1-based in the index
+    assert list(np.sign(vals)) == [1, 1, -1, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compute", [8, 4])
+def test_hip_concoutput_files_are_byte_identical(built, tmp_path, compute):
+    from flexpart_amd.engine import Engine
+    from oracle import oracle as orc
+    from test_oracle_cpu import golden_scenario
+    sc = syn.add_wet(syn.add_outgrid(golden_scenario("aerosol")))
+    eng = Engine(sc, compute_real_bytes=compute, host_real_bytes=4)
+    eng.run()
+    g, d = eng.grids()
+    w = eng.wetgrid()
+    na, nc, mp, nsp, nzg, nyg, nxg = eng.gshape
+    assert (na, nc, mp) == (1, 1, 1) and (g > 0).sum() > 300 and (d > 0).sum() > 50
+    case = syn.concoutput_case(nxg=nxg, nyg=nyg, nzg=nzg, nspec=nsp)
+    area, volume = case["area"], case["volume"]
+    prefix = str(tmp_path / "grid_conc_20200101010000_")
+    eng.concoutput(3600, prefix, area, volume, outnum=4.0, wetdep=True, drydep=True, clear=True)
+    g2, _ = eng.grids()
+    eng.close()
+    assert not g2.any()                                   # gridunc is zeroed after the output, concoutput.f90:714
+    co = dict(outgrid=np.array([nxg, nyg, nzg, nsp, 1, 1, 3600], np.int32), outgeom=case["outgeom"], outheight=case["outheight"],
+              area=area, volume=volume, gridunc=g[0, 0, 0], wetgridunc=w[0, 0, 0], drygridunc=d[0, 0, 0])
+    want = orc.co_oracle(co)
+    for suffix, b in want.items():
+        assert open(prefix + suffix[1:], "rb").read() == b, suffix
