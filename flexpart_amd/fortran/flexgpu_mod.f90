@@ -20,7 +20,7 @@ module flexgpu_mod
   use par_mod
   use com_mod
   use point_mod, only: xmass, npart
-  use outg_mod, only: outheight
+  use outg_mod, only: outheight, area, volume
   use unc_mod, only: gridunc, drygridunc, wetgridunc, griduncn, drygriduncn, wetgriduncn
   implicit none
   private
@@ -29,7 +29,8 @@ module flexgpu_mod
             flexgpu_step, flexgpu_use_table_rng, flexgpu_handle, flexgpu_last_error, &
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
-            flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions
+            flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
+            flexgpu_concoutput
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -88,6 +89,12 @@ module flexgpu_mod
     real(c_double) :: jul_header, bdate
     integer(c_int32_t) :: mintime, nclassunc
   end type fpx_restart
+
+  type, bind(C) :: fpx_concout
+    type(c_ptr) :: area, volume
+    real(c_double) :: outnum
+    integer(c_int32_t) :: wetdep, drydep
+  end type fpx_concout
 
   integer, parameter :: FPX_MAXNESTS = 4
   type, bind(C) :: fpx_nests
@@ -173,6 +180,13 @@ module flexgpu_mod
       type(fpx_fields), intent(in) :: sfc
       type(fpx_fields_out), intent(in) :: o
     end function fpx_verttransform_nest
+    integer(c_int) function fpx_concoutput(h, itime, c, prefix, clear) bind(C, name='fpx_concoutput')
+      import :: c_ptr, c_int, c_int32_t, c_char, fpx_concout
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: itime, clear
+      type(fpx_concout), intent(in) :: c
+      character(kind=c_char), intent(in) :: prefix(*)
+    end function fpx_concoutput
     integer(c_int) function fpx_nests_init(h, n) bind(C, name='fpx_nests_init')
       import :: c_ptr, c_int, fpx_nests
       type(c_ptr), value :: h
@@ -531,6 +545,29 @@ contains
     numparticlecount = npc
     itrasplit(1:numpart) = ldirect * itsplit
   end subroutine flexgpu_readpartpositions
+
+  ! Writes the grid_conc_<date><time>_<species> files of `call concoutput(itime,outnum,...)` (timemanager.f90:384;
+  ! forward runs, iout = 1 or 3 or 5) from the device's sampling grids and zeroes gridunc as the routine does.
+  ! dates, grid_pptv_*, factor_drygrid and the receptor files remain with the host.  4-byte default real only.
+  subroutine flexgpu_concoutput(itime, outnum, ierr)
+    integer, intent(in) :: itime
+    real, intent(in) :: outnum
+    integer, intent(out) :: ierr
+    type(fpx_concout) :: c
+    real(kind=dp) :: jul
+    integer :: jjjjmmdd, ihmmss
+    character :: adate*8, atime*6
+    character(len=200) :: prefix
+    jul = bdate + real(itime, kind=dp) / 86400._dp
+    call caldate(jul, jjjjmmdd, ihmmss)
+    write(adate, '(i8.8)') jjjjmmdd
+    write(atime, '(i6.6)') ihmmss
+    prefix = path(2)(1:length(2)) // 'grid_conc_' // adate // atime // '_'
+    c%area = loc_r(area); c%volume = loc_r(volume)
+    c%outnum = outnum
+    c%wetdep = merge(1, 0, WETDEP); c%drydep = merge(1, 0, DRYDEP)
+    ierr = fpx_concoutput(flexgpu_handle, int(itime, c_int32_t), c, trim(prefix) // c_null_char, 1_c_int32_t)
+  end subroutine flexgpu_concoutput
 
   ! one time slot of the com_mod fields (slot = the value found in memind(k))
   subroutine flexgpu_upload_fields(slot, ierr)
