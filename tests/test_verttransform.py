@@ -253,7 +253,11 @@ def test_nest_oracle_equals_reference_fixture():
 
 @pytest.mark.ref
 def test_nest_oracle_equals_live_reference():
+    """Opt-in (FPX_SLOW_REF=1): the maxnests=1 build of the reference has nxmax=721, nymax=361 and spends about a minute
+    on whole-array operations over its padded arrays; the fixture test above pins the same parity in a second."""
     from oracle import oracle as orc, scenario_io as sio
+    if not os.environ.get("FPX_SLOW_REF"):
+        pytest.skip("slow (about 1 min): set FPX_SLOW_REF=1")
     if not sio.have_vt_ref("r8n"):
         pytest.skip("flang-built reference not present (GPU box)")
     m = syn.model_levels(50, 30, 36, global_grid=False, phase=2)
