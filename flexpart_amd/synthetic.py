@@ -554,7 +554,7 @@ def concoutput_case(nxg=24, nyg=16, nzg=4, nspec=2, wet=True, dry=True, itime=36
     g[:, 1, 3, :] = 2.0e-4                   # a whole full row
     w2 = np.where(u[:, 0] > 0.7, (u[:, 0] * 1.0e-5).astype(np.float32), np.float32(0.0)).astype(np.float64)
     d2 = np.where(u[:, 1] > 0.4, (u[:, 1] * 1.0e-6).astype(np.float32), np.float32(0.0)).astype(np.float64)
-    outheight = np.array([100.0, 500.0, 1000.0, 5000.0, 10000.0][:nzg])
+    outheight = np.array([100.0, 500.0, 1000.0, 5000.0, 10000.0, 15000.0, 20000.0, 25000.0, 30000.0, 40000.0, 50000.0, 60000.0][:nzg])
     dxout, dyout, outlon0, outlat0 = 1.0, 1.0, -10.0, 30.0
     f32 = np.float32
     pi, r_earth = f32(3.14159265), f32(6.371e6)
