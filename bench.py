@@ -89,9 +89,10 @@ def measured_traffic(config, nper, kernel):
         return None
     try:
         d = json.load(open(files[-1]))
-        for name, e in d["kernels"].items():
-            if kernel in name:
-                return e["hbm_bytes_per_launch"]
+        # several template variants may match (k_prep with/without initialize()): the steady-state one ran most often
+        best = max((e for name, e in d["kernels"].items() if kernel in name), key=lambda e: e["launches_profiled"], default=None)
+        if best is not None:
+            return best["hbm_bytes_per_launch"]
     except Exception:
         return None
     return None
@@ -108,12 +109,12 @@ def measured_valu(config, nper, kernel):
         return None
     try:
         d = json.load(open(files[-1]))
-        for name, e in d["kernels"].items():
-            if kernel in name:
-                sq = e["sq_last_launch"]
-                return {"insts_valu_per_launch": sq["SQ_INSTS_VALU"], "lane_utilisation": e["valu_lane_utilisation"],
-                        "valu_active_per_wave_cycle": e["valu_active_per_wave_cycle"],
-                        "source": os.path.relpath(files[-1], ROOT)}
+        e = max((e for name, e in d["kernels"].items() if kernel in name), key=lambda e: e["launches_profiled"], default=None)
+        if e is not None:
+            sq = e["sq_last_launch"]
+            return {"insts_valu_per_launch": sq["SQ_INSTS_VALU"], "lane_utilisation": e["valu_lane_utilisation"],
+                    "valu_active_per_wave_cycle": e["valu_active_per_wave_cycle"],
+                    "source": os.path.relpath(files[-1], ROOT)}
     except Exception:
         return None
     return None
