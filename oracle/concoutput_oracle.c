@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the part of the reference's concoutput that
  * writes the sparse concentration files grid_conc_<date><time>_<species>.
- * Only tests/ may load this; the product path (flexpart_amd/) never does.
+ * Only tests/ and the cpu_baseline / checker leg of tools/bench_*.py may load this; the product path (flexpart_amd/) never does.
  *
  * Plain C restatement of /root/reference/src/concoutput.f90:226-228 (factor3d), :296-345 (class mean of
  * wetgridunc, drygridunc, gridunc; mean_mod.f90:mean_sp) and :349-447 (the three run-length compressed

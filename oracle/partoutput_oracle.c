@@ -1,6 +1,6 @@
 /*
  * TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the reference's partoutput
- * (the binary particle dump partposit_*).  Only tests/ may load this;
+ * (the binary particle dump partposit_*).  Only tests/ and the cpu_baseline / checker leg of tools/bench_*.py may load this;
  * the product path (flexpart_amd/) never does.
  *
  * Plain C restatement of /root/reference/src/partoutput.f90:63-190: for every particle due at

@@ -1,6 +1,6 @@
 /*
  * TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the reference's readpartpositions
- * (the warm start from the particle dump partposit_end).  Only tests/ may
+ * (the warm start from the particle dump partposit_end).  Only tests/ and the cpu_baseline / checker leg of tools/bench_*.py may
  * load this; the product path (flexpart_amd/) never does.
  *
  * Plain C restatement of /root/reference/src/readpartpositions.f90:115-148 (the part after the

@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE ONLY -- CPU restatement ("oracle") of the reference's
  * verttransform_ecmwf (eta levels -> terrain-following z levels).
- * Only tests/ and bench.py's cpu_baseline leg may load this; the product path
+ * Only tests/ and the cpu_baseline / checker leg of bench.py and tools/bench_*.py may load this; the product path
  * (flexpart_amd/) never does.
  *
  * Plain C restatement of /root/reference/src/verttransform_ecmwf.f90:118-590 (height
