@@ -82,7 +82,8 @@ class FpxRestart(C.Structure):
 
 
 class FpxConcout(C.Structure):
-    _fields_ = [("area", C.c_void_p), ("volume", C.c_void_p), ("outnum", C.c_double), ("wetdep", C.c_int32), ("drydep", C.c_int32)]
+    _fields_ = [("area", C.c_void_p), ("volume", C.c_void_p), ("outnum", C.c_double), ("wetdep", C.c_int32), ("drydep", C.c_int32),
+                ("nest", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FpxParticles(C.Structure):

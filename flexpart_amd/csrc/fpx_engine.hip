@@ -1731,7 +1731,11 @@ struct Engine : EngineBase {
     if (cfg.host_real_bytes != 4) return fail(FPX_ERR_ARG, "concoutput: only for hosts with a 4-byte default real (the reference's concoutput.f90 does not compile with 8)");
     if (cfg.ldirect != 1) return fail(FPX_ERR_ARG, "concoutput: forward runs only (ldirect = 1)");
     if (!(c->outnum > 0)) return fail(FPX_ERR_ARG, "concoutput: outnum > 0");
-    const long long n2 = (long long)Gp.numxgrid * Gp.numygrid, n3 = n2 * Gp.numzgrid;
+    if (c->nest && !Gp.nested) return fail(FPX_ERR_STATE, "concoutput: nested output grid requested without fpx_outgrid_nest_init");
+    // nest = 1: the nested output grid (concoutput_nest.f90: the same algorithm on griduncn, wetgriduncn, drygriduncn, arean, volumen)
+    const long long n2 = c->nest ? (long long)Gp.numxgridn * Gp.numygridn : (long long)Gp.numxgrid * Gp.numygrid, n3 = n2 * Gp.numzgrid;
+    R *g3 = c->nest ? Gp.griduncn : Gp.gridunc;
+    float *gwet = c->nest ? Gp.wetgriduncn : Gp.wetgridunc, *gdry = c->nest ? Gp.drygriduncn : Gp.drygridunc;
     float *d_area = nullptr, *d_vol = nullptr, *val = nullptr, *wr = nullptr;
     unsigned int *nz = nullptr, *rs = nullptr, *rpos = nullptr, *runid = nullptr;
     int *wi = nullptr;
@@ -1804,16 +1808,16 @@ struct Engine : EngineBase {
           const size_t o2 = ((((size_t)nage * Gp.nclassunc) * Gp.maxpointspec_act + kp) * Gp.maxspec + ks) * (size_t)n2;
           const size_t cs2 = (size_t)Gp.maxpointspec_act * Gp.maxspec * (size_t)n2;
           const size_t o3 = o2 * Gp.numzgrid, cs3 = cs2 * Gp.numzgrid;
-          rc = dump(c->wetdep && Gp.wetgridunc ? Gp.wetgridunc + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
-          if (!rc) rc = dump(c->drydep ? Gp.drygridunc + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
-          if (!rc) rc = dump(Gp.gridunc + o3, cs3, n3, d_vol, 1, (int)n2 /* kz is 1-based in the index, :425 */, fh);
+          rc = dump(c->wetdep && gwet ? gwet + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
+          if (!rc) rc = dump(c->drydep && gdry ? gdry + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
+          if (!rc) rc = dump(g3 + o3, cs3, n3, d_vol, 1, (int)n2 /* kz is 1-based in the index, :425 */, fh);
         }
       if (fclose(fh) != 0 && !rc) rc = fail(FPX_ERR_ARG, "concoutput: write error");
     }
     cleanup();
     if (rc) return rc;
-    if (clear) {   // gridunc(:,:,:,:,:,:,:)=0., concoutput.f90:714 (the deposition grids keep accumulating)
-      HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
+    if (clear) {   // gridunc(:,:,:,:,:,:,:)=0., concoutput.f90:714 / griduncn, concoutput_nest.f90 (the deposition grids keep accumulating)
+      HIPCHK(hipMemsetAsync(g3, 0, (c->nest ? n_grid3n : n_grid3) * sizeof(R), stream));
       HIPCHK(hipStreamSynchronize(stream));
     }
     return 0;

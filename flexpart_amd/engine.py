@@ -271,12 +271,12 @@ class Engine:
         self.n = int(n.value)
         return int(n.value), int(npc.value), int(it.value)
 
-    def concoutput(self, itime, prefix, area, volume, outnum, wetdep=False, drydep=False, clear=False):
+    def concoutput(self, itime, prefix, area, volume, outnum, wetdep=False, drydep=False, clear=False, nest=False):
         """fpx_concoutput: writes <prefix><nnn> (the reference's grid_conc_* files) for every species."""
         from ._lib import FpxConcout
         a = np.ascontiguousarray(np.asarray(area, dtype=np.float32))
         v = np.ascontiguousarray(np.asarray(volume, dtype=np.float32))
-        c = FpxConcout(a.ctypes.data, v.ctypes.data, float(outnum), int(wetdep), int(drydep))
+        c = FpxConcout(a.ctypes.data, v.ctypes.data, float(outnum), int(wetdep), int(drydep), int(nest), 0)
         check(self.lib.fpx_concoutput(self.h, int(itime), C.byref(c), str(prefix).encode(), int(clear)), "fpx_concoutput")
 
     def upload_nests_from_scenario(self, sc):

@@ -249,6 +249,9 @@ typedef struct {
   const void *volume;    /* volume(0:numxgrid-1,0:numygrid-1,numzgrid)                                  */
   double outnum;         /* sum of the sampling weights of the averaging interval (timemanager.f90:363)  */
   int32_t wetdep, drydep;
+  int32_t nest;          /* 1: the nested output grid (`call concoutput_nest`, timemanager.f90:418; concoutput_nest.f90): area and
+                            volume are arean, volumen; the prefix is "<path>grid_conc_nest_<date><time>_"                          */
+  int32_t reserved;
 } fpx_concout;
 int fpx_concoutput(fpx_handle h, int32_t itime, const fpx_concout *c, const char *prefix, int32_t clear);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */

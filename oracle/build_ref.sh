@@ -125,11 +125,11 @@ build_co() {
   local obj="$OUT/obj_$kind"
   ( cd "$obj"
     [ "$obj/mean_mod.o" -nt "$REF/mean_mod.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/mean_mod.f90" -o mean_mod.o
-    for s in concoutput caldate juldate; do
+    for s in concoutput concoutput_nest caldate juldate; do
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_co_driver.f90" -o ref_co_driver.o
-    "$FC" -O2 -mcmodel=medium $flags ref_co_driver.o concoutput.o mean_mod.o caldate.o juldate.o par_mod.o com_mod.o unc_mod.o outg_mod.o point_mod.o -o "$OUT/coref_$kind"
+    "$FC" -O2 -mcmodel=medium $flags ref_co_driver.o concoutput.o concoutput_nest.o mean_mod.o caldate.o juldate.o par_mod.o com_mod.o unc_mod.o outg_mod.o point_mod.o -o "$OUT/coref_$kind"
   )
   echo "build_ref: built $OUT/coref_$kind"
 }

@@ -7,7 +7,9 @@
 ! This file is our own code: it contains no reference source, only calls into it, assignments to its
 ! module variables and the allocations outgrid_init.f90:192-290 would make.
 !
-! Usage:  coref_rK scenario.bin outdir/
+! Usage:  coref_rK scenario.bin outdir/ [nest]
+!   nest: the grids go to the nested output grid's arrays (griduncn, arean, volumen ...) and concoutput_nest writes
+!         grid_conc_nest_<date><time>_<species> (concoutput_nest.f90).
 ! Record format as oracle/ref_driver.f90; grids travel compact, x fastest, as f64.
 
 program coref
@@ -24,13 +26,19 @@ program coref
   integer(kind=8) :: cnt
   integer, allocatable :: ibuf(:)
   real(kind=8), allocatable :: dbuf(:)
-  integer :: ios, n, itime_out, nxg, nyg, nzg, i, ix, jy, kz, ks
+  integer :: ios, n, itime_out, nxg, nyg, nzg, i, ix, jy, kz, ks, use_nest
+  character(len=16) :: arg3
   real :: outnum, gtu
   real(dep_prec) :: wtu, dtu
   real(kind=dp) :: juldate
 
   call get_command_argument(1, fscen)
   call get_command_argument(2, fout)
+  use_nest = 0
+  if (command_argument_count() .ge. 3) then
+    call get_command_argument(3, arg3)
+    if (trim(arg3) .eq. 'nest') use_nest = 1
+  end if
   path(2) = trim(fout); length(2) = len_trim(fout)
   bdate = juldate(20200101, 0)
   ldirect=1; iout=1; nspec=1; maxpointspec_act=1; nageclass=1; numreceptor=0
@@ -68,8 +76,17 @@ program coref
       allocate(wetgridunc(0:nxg-1,0:nyg-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
       allocate(drygridunc(0:nxg-1,0:nyg-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
       gridunc=0.; wetgridunc=0.; drygridunc=0.
+      if (use_nest .eq. 1) then      ! the nested output grid shares the work arrays (outgrid_init.f90:245-290 sizes them by max)
+        numxgridn=nxg; numygridn=nyg; nested_output=1
+        allocate(arean(0:nxg-1,0:nyg-1), volumen(0:nxg-1,0:nyg-1,nzg))
+        allocate(griduncn(0:nxg-1,0:nyg-1,nzg,maxspec,maxpointspec_act,nclassunc,maxageclass))
+        allocate(wetgriduncn(0:nxg-1,0:nyg-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
+        allocate(drygriduncn(0:nxg-1,0:nyg-1,maxspec,maxpointspec_act,nclassunc,maxageclass))
+        griduncn=0.; wetgriduncn=0.; drygriduncn=0.
+      end if
     case ('outgeom')   ! dxout dyout outlon0 outlat0 outnum
       dxout=dbuf(1); dyout=dbuf(2); outlon0=dbuf(3); outlat0=dbuf(4); outnum=dbuf(5)
+      dxoutn=dxout; dyoutn=dyout; outlon0n=outlon0; outlat0n=outlat0
     case ('outheight'); outheight(1:n)=dbuf(1:n)
     case ('area')
       do jy=0,nyg-1
@@ -117,5 +134,11 @@ program coref
   end do
   close(uin)
 
-  call concoutput(itime_out, outnum, gtu, wtu, dtu)
+  if (use_nest .eq. 1) then
+    arean=area; volumen=volume
+    griduncn=gridunc; wetgriduncn=wetgridunc; drygriduncn=drygridunc
+    call concoutput_nest(itime_out, outnum)
+  else
+    call concoutput(itime_out, outnum, gtu, wtu, dtu)
+  end if
 end program coref

@@ -251,7 +251,7 @@ def have_co_ref(kind="r4"):
     return os.access(os.path.join(HERE, "_ref", f"coref_{kind}"), os.X_OK)
 
 
-def run_co_reference(co, kind="r4", workdir="/tmp"):
+def run_co_reference(co, kind="r4", workdir="/tmp", nest=False):
     """The unmodified concoutput on a dict (outgrid, outgeom, outheight, area, volume, gridunc[, wetgridunc, drygridunc])
     -> {file name: bytes} of the grid_conc_* files it wrote."""
     import glob
@@ -270,7 +270,7 @@ def run_co_reference(co, kind="r4", workdir="/tmp"):
                 fh.write(a.tobytes())
             fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
         exe = os.path.join(HERE, "_ref", f"coref_{kind}")
-        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/"], capture_output=True, text=True)
+        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/" + (" nest" if nest else "")], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"reference concoutput driver failed: {res.stdout}\n{res.stderr}")
         return {os.path.basename(f): open(f, "rb").read() for f in sorted(glob.glob(os.path.join(d, "grid_conc_*")))}

@@ -17,3 +17,8 @@ for case, kw in CASES.items():
     for name, b in sio.run_co_reference(syn.concoutput_case(**kw)).items():
         open(os.path.join(HERE, f"co_{case}_{name[-3:]}.bin"), "wb").write(b)
         print(case, name, len(b))
+
+# the nested output grid: the unmodified concoutput_nest
+for name, b in sio.run_co_reference(syn.concoutput_case(nxg=30, nyg=20, nzg=3, nspec=2, seed=21), nest=True).items():
+    open(os.path.join(HERE, f"co_nest_{name[-3:]}.bin"), "wb").write(b)
+    print("nest", name, len(b))

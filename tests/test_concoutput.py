@@ -83,3 +83,37 @@ def test_hip_concoutput_files_are_byte_identical(built, tmp_path, compute):
     want = orc.co_oracle(co)
     for suffix, b in want.items():
         assert open(prefix + suffix[1:], "rb").read() == b, suffix
+
+
+def test_oracle_equals_reference_files_of_concoutput_nest():
+    """The nested output grid: concoutput_nest.f90 is the same algorithm on griduncn / arean / volumen; the fixture is
+    the file the unmodified routine wrote (tests/golden/co_nest_*.bin)."""
+    from oracle import oracle as orc
+    got = orc.co_oracle(syn.concoutput_case(nxg=30, nyg=20, nzg=3, nspec=2, seed=21))
+    for suffix, b in got.items():
+        assert b == open(os.path.join(HERE, "golden", f"co_nest{suffix}.bin"), "rb").read(), suffix
+
+
+@pytest.mark.gpu
+def test_hip_concoutput_nested_output_grid(built, tmp_path):
+    """Mother and nested output grid sampled by the device; fpx_concoutput(nest=1) against the oracle on the
+    downloaded griduncn / drygriduncn / wetgriduncn."""
+    from flexpart_amd.engine import Engine
+    from oracle import oracle as orc
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario("sampling_nest")
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=4)
+    eng.run()
+    g, d, w = eng.grids_nest()
+    na, nc, mp, nsp, nzg, nyn, nxn = eng.gshape_nest
+    assert (g > 0).sum() > 100
+    case = syn.concoutput_case(nxg=nxn, nyg=nyn, nzg=nzg, nspec=nsp)
+    prefix = str(tmp_path / "grid_conc_nest_20200101010000_")
+    wet = bool(sc.get("wetdep", 0)); dry = bool(sc.get("drydep", 0))
+    eng.concoutput(3600, prefix, case["area"], case["volume"], outnum=2.0, wetdep=wet, drydep=dry, nest=True)
+    eng.close()
+    geom = case["outgeom"].copy(); geom[4] = 2.0
+    co = dict(outgrid=np.array([nxn, nyn, nzg, nsp, int(wet), int(dry), 3600], np.int32), outgeom=geom, outheight=case["outheight"],
+              area=case["area"], volume=case["volume"], gridunc=g[0, 0, 0], wetgridunc=w[0, 0, 0], drygridunc=d[0, 0, 0])
+    for suffix, b in orc.co_oracle(co).items():
+        assert open(prefix + suffix[1:], "rb").read() == b, suffix
