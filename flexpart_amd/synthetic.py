@@ -581,3 +581,19 @@ def concoutput_case(nxg=24, nyg=16, nzg=4, nspec=2, wet=True, dry=True, itime=36
     if dry:
         co["drygridunc"] = d2
     return co
+
+
+def add_pptv(co, nx=40, ny=24, nz=12):
+    """Mixing-ratio output (iout = 3) for a concoutput_case(): a met grid that covers the output grid, z levels, the air
+    density of slot memind(2) and molar weights (concoutput.f90:176-205,482-590)."""
+    nxg, nyg = int(co["outgrid"][0]), int(co["outgrid"][1])
+    dxout, dyout, outlon0, outlat0 = (float(v) for v in co["outgeom"][:4])
+    co["iout"] = 3
+    co["met"] = np.array([nx, ny, nz], np.int32)
+    co["metgeom"] = np.array([(nxg * dxout + 2.0) / (nx - 1), (nyg * dyout + 2.0) / (ny - 1), outlon0 - 1.0, outlat0 - 1.0])
+    co["height"] = make_height(nz, top=30000.0, lin=0.15)
+    i = np.arange(nx, dtype=np.int64)[None, None, :]; j = np.arange(ny, dtype=np.int64)[None, :, None]
+    z = np.asarray(co["height"])[:, None, None]
+    co["rho2"] = (1.2 / (1.0 + z / 8000.0 + 0.5 * (z / 8000.0) ** 2) * (1.0 + 0.02 * _wave(i + 2 * j, nx - 1))).astype(np.float32).astype(np.float64)
+    co["weightmolar"] = np.array([350.0, 28.0, 64.0, 100.0, 46.0][: int(co["outgrid"][3])])
+    return co

@@ -469,7 +469,10 @@ def rp_oracle(file_bytes, rs, kind="r8"):
 class _CooArgs(C.Structure):
     _fields_ = ([(k, C.c_int) for k in ("nxg", "nyg", "nzg", "nspec", "nclassunc", "wetdep", "drydep", "itime")]
                 + [("outnum", C.c_float)]
-                + [(k, C.POINTER(C.c_float)) for k in ("area", "volume", "gridunc", "wetgridunc", "drygridunc")])
+                + [(k, C.POINTER(C.c_float)) for k in ("area", "volume", "gridunc", "wetgridunc", "drygridunc")]
+                + [(k, C.c_int) for k in ("nx", "ny", "nz")]
+                + [(k, C.c_float) for k in ("dx", "dy", "xlon0", "ylat0", "dxout", "dyout", "outlon0", "outlat0")]
+                + [(k, C.POINTER(C.c_float)) for k in ("height", "outheight", "rho", "weightmolar")])
 
 
 def co_oracle(co):
@@ -485,6 +488,14 @@ def co_oracle(co):
     for k in ("area", "volume", "gridunc", "wetgridunc", "drygridunc"):
         keep[k] = np.ascontiguousarray(np.asarray(co.get(k, np.zeros(1)), dtype=np.float32))
         setattr(a, k, keep[k].ctypes.data_as(fp))
+    pptv = "rho2" in co
+    if pptv:      # mixing-ratio files as well (iout = 3)
+        a.nx, a.ny, a.nz = (int(v) for v in co["met"])
+        a.dx, a.dy, a.xlon0, a.ylat0 = (float(np.float32(v)) for v in co["metgeom"])
+        a.dxout, a.dyout, a.outlon0, a.outlat0 = (float(np.float32(v)) for v in co["outgeom"][:4])
+        for k, src in (("height", "height"), ("outheight", "outheight"), ("rho", "rho2"), ("weightmolar", "weightmolar")):
+            keep[k] = np.ascontiguousarray(np.asarray(co[src], dtype=np.float32))
+            setattr(a, k, keep[k].ctypes.data_as(fp))
     n3 = nxg * nyg * nzg
     wi = np.zeros(n3 + 1, np.int32); wr = np.zeros(n3 + 1, np.float32); g = np.zeros(n3, np.float32); f3 = np.zeros(n3, np.float32)
     buf = (C.c_ubyte * (64 + 3 * 16 + 3 * 8 * (n3 + 2)))()
@@ -493,4 +504,9 @@ def co_oracle(co):
         nb = lib.coo_concoutput(C.byref(a), ks, buf, wi.ctypes.data_as(C.POINTER(C.c_int32)), wr.ctypes.data_as(fp),
                                 g.ctypes.data_as(fp), f3.ctypes.data_as(fp))
         out[f"_{ks + 1:03d}"] = bytes(buf[:nb])
+        if pptv:
+            lib.coo_pptvoutput.restype = C.c_long
+            nb = lib.coo_pptvoutput(C.byref(a), ks, buf, wi.ctypes.data_as(C.POINTER(C.c_int32)), wr.ctypes.data_as(fp),
+                                    g.ctypes.data_as(fp), f3.ctypes.data_as(fp))
+            out[f"pptv_{ks + 1:03d}"] = bytes(buf[:nb])
     return out

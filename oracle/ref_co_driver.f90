@@ -88,6 +88,22 @@ program coref
       dxout=dbuf(1); dyout=dbuf(2); outlon0=dbuf(3); outlat0=dbuf(4); outnum=dbuf(5)
       dxoutn=dxout; dyoutn=dyout; outlon0n=outlon0; outlat0n=outlat0
     case ('outheight'); outheight(1:n)=dbuf(1:n)
+    ! mixing-ratio output (iout = 2, 3): the met grid the air density comes from, concoutput.f90:176-205
+    case ('iout');      iout=ibuf(1)
+    case ('met')
+      nx=ibuf(1); ny=ibuf(2); nz=ibuf(3); nxmin1=nx-1; nymin1=ny-1
+    case ('metgeom');   dx=dbuf(1); dy=dbuf(2); xlon0=dbuf(3); ylat0=dbuf(4)
+    case ('height');    height(1:n)=dbuf(1:n)
+    case ('weightmolar'); weightmolar(1:n)=dbuf(1:n)
+    case ('rho2')       ! rho(:,:,:,memind(2)), compact [nz][ny][nx]
+      rho=0.
+      do kz=1,nz
+        do jy=0,ny-1
+          do ix=0,nx-1
+            rho(ix,jy,kz,2)=dbuf(1+ix+nx*(jy+ny*(kz-1)))
+          end do
+        end do
+      end do
     case ('area')
       do jy=0,nyg-1
         do ix=0,nxg-1

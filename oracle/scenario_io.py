@@ -261,10 +261,11 @@ def run_co_reference(co, kind="r4", workdir="/tmp", nest=False):
     try:
         fs = os.path.join(d, "co.scen")
         with open(fs, "wb") as fh:
-            for name in ("outgrid", "outgeom", "outheight", "area", "volume", "gridunc", "wetgridunc", "drygridunc"):
+            for name in ("outgrid", "outgeom", "outheight", "iout", "met", "metgeom", "height", "weightmolar", "rho2",
+                         "area", "volume", "gridunc", "wetgridunc", "drygridunc"):
                 if name not in co:
                     continue
-                code = 1 if name == "outgrid" else 2
+                code = 1 if name in ("outgrid", "iout", "met") else 2
                 a = np.ascontiguousarray(np.asarray(co[name], dtype=np.int32 if code == 1 else np.float64).ravel())
                 fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
                 fh.write(a.tobytes())
@@ -273,6 +274,7 @@ def run_co_reference(co, kind="r4", workdir="/tmp", nest=False):
         res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {d}/" + (" nest" if nest else "")], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"reference concoutput driver failed: {res.stdout}\n{res.stderr}")
-        return {os.path.basename(f): open(f, "rb").read() for f in sorted(glob.glob(os.path.join(d, "grid_conc_*")))}
+        return {os.path.basename(f): open(f, "rb").read()
+                for f in sorted(glob.glob(os.path.join(d, "grid_conc_*")) + glob.glob(os.path.join(d, "grid_pptv_*")))}
     finally:
         shutil.rmtree(d, ignore_errors=True)
