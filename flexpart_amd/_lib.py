@@ -83,7 +83,8 @@ class FpxRestart(C.Structure):
 
 class FpxConcout(C.Structure):
     _fields_ = [("area", C.c_void_p), ("volume", C.c_void_p), ("outnum", C.c_double), ("wetdep", C.c_int32), ("drydep", C.c_int32),
-                ("nest", C.c_int32), ("reserved", C.c_int32)]
+                ("nest", C.c_int32), ("iout", C.c_int32), ("prefix_pptv", C.c_char_p), ("outheight", C.c_void_p),
+                ("outlon0", C.c_double), ("outlat0", C.c_double), ("weightmolar", C.c_double * 5)]
 
 
 class FpxParticles(C.Structure):

@@ -593,8 +593,9 @@ __global__ void __launch_bounds__(kBlock) k_co_values(const G *__restrict__ grid
 __global__ void __launch_bounds__(kBlock) k_co_write(const float *__restrict__ val, const unsigned int *__restrict__ nz, const unsigned int *__restrict__ rs,
                                                      const unsigned int *__restrict__ rpos /* exclusive scan of nz */,
                                                      const unsigned int *__restrict__ runid /* inclusive scan of rs */, long long n,
-                                                     const float *__restrict__ scale /* volume (conc) or area, per cell */, int conc, float outnum, float tot_mu,
-                                                     int idx0, int *__restrict__ wi, float *__restrict__ wr) {
+                                                     const float *__restrict__ scale /* volume (conc, pptv) or area, per cell */, int conc, float outnum, float tot_mu,
+                                                     int idx0, int *__restrict__ wi, float *__restrict__ wr,
+                                                     const float *__restrict__ dens = nullptr, float weightmolar = 1.f) {
 #pragma clang fp contract(off)
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n || !nz[i]) return;
@@ -602,11 +603,38 @@ __global__ void __launch_bounds__(kBlock) k_co_write(const float *__restrict__ v
   const float sp_fact = (run & 1u) ? 1.f : -1.f;     // sp_fact starts at -1 and flips at every run start
   if (rs[i]) wi[run - 1] = (int)i + idx0;
   float r;
-  if (conc) {
+  if (conc == 2) {                                     // mixing ratio, concoutput.f90:575-579
+    r = sp_fact * 1.e12f * val[i] / scale[i] / outnum * 28.97f / weightmolar / dens[i];
+  } else if (conc) {
     const float f3 = 1.e12f / scale[i] / outnum;     // factor3d, concoutput.f90:226 (ldirect = 1)
     r = sp_fact * val[i] * f3 / tot_mu;
   } else r = sp_fact * 1.e12f * val[i] / scale[i];
   wr[rpos[i]] = r;
+}
+
+// densityoutgrid, concoutput.f90:176-205: air density at the centre of every output cell from the met density of slot
+// memind(2) (the r2 pack), nearest column, linear between the two z levels around the mid height of the output layer
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_co_density(View<R> V, int nxg, int nyg, int nzg, const float *__restrict__ outheight,
+                                                       float dxout, float dyout, float outlon0, float outlat0, float dx, float dy, float xlon0, float ylat0,
+                                                       float *__restrict__ dens) {
+#pragma clang fp contract(off)
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)nxg * nyg * nzg) return;
+  const int ix = (int)(i % nxg), jy = (int)((i / nxg) % nyg), kz = 1 + (int)(i / ((long long)nxg * nyg));
+  const float halfheight = kz == 1 ? outheight[0] / 2.f : (outheight[kz - 1] + outheight[kz - 2]) / 2.f;
+  int kzz;
+  for (kzz = 2; kzz <= V.nz; kzz++)
+    if ((float)V.height[kzz - 2] < halfheight && (float)V.height[kzz - 1] > halfheight) break;
+  kzz = max(min(kzz, V.nz), 2);
+  const float dz1 = halfheight - (float)V.height[kzz - 2], dz2 = (float)V.height[kzz - 1] - halfheight, dz = dz1 + dz2;
+  float xl = outlon0 + (float)ix * dxout, yl = outlat0 + (float)jy * dyout;
+  xl = (xl - xlon0) / dx;
+  yl = (yl - ylat0) / dy;
+  const int iix = max(min((int)lroundf(xl), V.nxmin1), 0), jjy = max(min((int)lroundf(yl), V.nymin1), 0);
+  const size_t col = ((size_t)jjy * V.nx + iix) * V.nz;
+  const float r1 = (float)V.r2[(col + (kzz - 1)) * 4 + V.m2 * 2], r0 = (float)V.r2[(col + (kzz - 2)) * 4 + V.m2 * 2];
+  dens[i] = (r1 * dz1 + r0 * dz2) / dz;
 }
 
 // After the stable sort of the slots by their 3-bit key: list length = number of keys <= 4 (PBL
@@ -1745,6 +1773,12 @@ struct Engine : EngineBase {
     if (cfg.host_real_bytes != 4) return fail(FPX_ERR_ARG, "concoutput: only for hosts with a 4-byte default real (the reference's concoutput.f90 does not compile with 8)");
     if (cfg.ldirect != 1) return fail(FPX_ERR_ARG, "concoutput: forward runs only (ldirect = 1)");
     if (!(c->outnum > 0)) return fail(FPX_ERR_ARG, "concoutput: outnum > 0");
+    const int iout = c->iout ? c->iout : 1;
+    if (iout < 1 || iout > 3) return fail(FPX_ERR_ARG, "concoutput: iout 1 (concentration), 2 (mixing ratio) or 3 (both)");
+    const bool want_conc = iout == 1 || iout == 3, want_ppt = iout == 2 || iout == 3;
+    if (want_ppt && (!c->prefix_pptv || !c->outheight)) return fail(FPX_ERR_ARG, "concoutput: prefix_pptv and outheight are required for iout 2, 3");
+    if (want_ppt && (!slot_loaded[0] || !slot_loaded[1] || !window_set || !height_set)) return fail(FPX_ERR_STATE, "concoutput: mixing ratios need the met fields and the wind-time window");
+    if (want_ppt && c->nest) return fail(FPX_ERR_ARG, "concoutput: mixing-ratio files of the nested output grid are not implemented");
     if (c->nest && !Gp.nested) return fail(FPX_ERR_STATE, "concoutput: nested output grid requested without fpx_outgrid_nest_init");
     // nest = 1: the nested output grid (concoutput_nest.f90: the same algorithm on griduncn, wetgriduncn, drygriduncn, arean, volumen)
     const long long n2 = c->nest ? (long long)Gp.numxgridn * Gp.numygridn : (long long)Gp.numxgrid * Gp.numygrid, n3 = n2 * Gp.numzgrid;
@@ -1757,8 +1791,11 @@ struct Engine : EngineBase {
     std::vector<void *> mine;
     auto cleanup = [&]() { for (void *q : mine) (void)hipFree(q); if (tmp) (void)hipFree(tmp); };
     auto mal = [&](auto **q, size_t bytes) -> hipError_t { hipError_t e = hipMalloc((void **)q, bytes); if (e == hipSuccess) mine.push_back(*q); return e; };
+    float *d_dens = nullptr, *d_outh = nullptr;
     hipError_t e = mal(&d_area, n2 * 4);
     if (e == hipSuccess) e = mal(&d_vol, n3 * 4);
+    if (e == hipSuccess && want_ppt) e = mal(&d_dens, n3 * 4);
+    if (e == hipSuccess && want_ppt) e = mal(&d_outh, (size_t)Gp.numzgrid * 4);
     if (e == hipSuccess) e = mal(&val, n3 * 4);
     if (e == hipSuccess) e = mal(&wr, n3 * 4);
     if (e == hipSuccess) e = mal(&nz, n3 * 4);
@@ -1776,11 +1813,19 @@ struct Engine : EngineBase {
     }
     if (e == hipSuccess) e = hipMemcpyAsync(d_area, c->area, n2 * 4, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_vol, c->volume, n3 * 4, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess && want_ppt) {
+      e = hipMemcpyAsync(d_outh, c->outheight, (size_t)Gp.numzgrid * 4, hipMemcpyHostToDevice, stream);
+      if (e == hipSuccess) {
+        k_co_density<R><<<(int)((n3 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, Gp.numxgrid, Gp.numygrid, Gp.numzgrid, d_outh, (float)Gp.dxout, (float)Gp.dyout,
+                                                                                (float)c->outlon0, (float)c->outlat0, (float)cfg.dx, (float)cfg.dy, (float)cfg.xlon0, (float)cfg.ylat0, d_dens);
+        e = hipGetLastError();
+      }
+    }
     if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("concoutput: ") + hipGetErrorString(e)); }
     std::vector<int> h_wi((size_t)n3);
     std::vector<float> h_wr((size_t)n3);
     // one compressed dump: device work, then the four records (count, indices, count, values)
-    auto dump = [&](auto *grid, size_t class_stride, long long n, const float *scale, int conc, int idx0, FILE *fh) -> int {
+    auto dump = [&](auto *grid, size_t class_stride, long long n, const float *scale, int conc, int idx0, FILE *fh, float wm = 1.f) -> int {
       const int nb = (int)((n + kBlock - 1) / kBlock);
       int32_t ci = 0, cr = 0;
       if (grid) {
@@ -1789,7 +1834,7 @@ struct Engine : EngineBase {
         hipError_t e2 = rocprim::exclusive_scan(tmp, t1, nz, rpos, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
         t1 = tb;
         if (e2 == hipSuccess) e2 = rocprim::inclusive_scan(tmp, t1, rs, runid, (size_t)n, rocprim::plus<unsigned int>(), stream);
-        k_co_write<<<nb, kBlock, 0, stream>>>(val, nz, rs, rpos, runid, n, scale, conc, (float)c->outnum, 1.f, idx0, wi, wr);
+        k_co_write<<<nb, kBlock, 0, stream>>>(val, nz, rs, rpos, runid, n, scale, conc, (float)c->outnum, 1.f, idx0, wi, wr, d_dens, wm);
         unsigned int last[3] = {0, 0, 0};
         if (e2 == hipSuccess) e2 = hipMemcpyAsync(&last[0], rpos + (n - 1), 4, hipMemcpyDeviceToHost, stream);
         if (e2 == hipSuccess) e2 = hipMemcpyAsync(&last[1], nz + (n - 1), 4, hipMemcpyDeviceToHost, stream);
@@ -1809,25 +1854,28 @@ struct Engine : EngineBase {
       return ok ? 0 : fail(FPX_ERR_ARG, "concoutput: write error");
     };
     int rc = 0;
-    for (int ks = 0; ks < cfg.nspec && !rc; ks++) {
-      char name[1024];
-      snprintf(name, sizeof name, "%s%03d", prefix, ks + 1);
-      FILE *fh = fopen(name, "wb");
-      if (!fh) { rc = fail(FPX_ERR_ARG, std::string("concoutput: cannot open ") + name); break; }
-      const int32_t hdr[3] = {4, itime, 4};
-      if (fwrite(hdr, 4, 3, fh) != 3) rc = fail(FPX_ERR_ARG, "concoutput: write error");
-      for (int kp = 0; kp < Gp.maxpointspec_act && !rc; kp++)
-        for (int nage = 0; nage < Gp.nageclass && !rc; nage++) {
-          // element (0,0,[1,]ks,kp,class 0,nage) of the 6-D / 7-D arrays; consecutive classes are class_stride apart
-          const size_t o2 = ((((size_t)nage * Gp.nclassunc) * Gp.maxpointspec_act + kp) * Gp.maxspec + ks) * (size_t)n2;
-          const size_t cs2 = (size_t)Gp.maxpointspec_act * Gp.maxspec * (size_t)n2;
-          const size_t o3 = o2 * Gp.numzgrid, cs3 = cs2 * Gp.numzgrid;
-          rc = dump(c->wetdep && gwet ? gwet + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
-          if (!rc) rc = dump(c->drydep && gdry ? gdry + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
-          if (!rc) rc = dump(g3 + o3, cs3, n3, d_vol, 1, (int)n2 /* kz is 1-based in the index, :425 */, fh);
-        }
-      if (fclose(fh) != 0 && !rc) rc = fail(FPX_ERR_ARG, "concoutput: write error");
-    }
+    for (int ks = 0; ks < cfg.nspec && !rc; ks++)
+      for (int pass = 0; pass < 2 && !rc; pass++) {          // 0: grid_conc (:349-447), 1: grid_pptv (:482-590)
+        if ((pass == 0 && !want_conc) || (pass == 1 && !want_ppt)) continue;
+        char name[1024];
+        snprintf(name, sizeof name, "%s%03d", pass == 0 ? prefix : c->prefix_pptv, ks + 1);
+        FILE *fh = fopen(name, "wb");
+        if (!fh) { rc = fail(FPX_ERR_ARG, std::string("concoutput: cannot open ") + name); break; }
+        const int32_t hdr[3] = {4, itime, 4};
+        if (fwrite(hdr, 4, 3, fh) != 3) rc = fail(FPX_ERR_ARG, "concoutput: write error");
+        for (int kp = 0; kp < Gp.maxpointspec_act && !rc; kp++)
+          for (int nage = 0; nage < Gp.nageclass && !rc; nage++) {
+            // element (0,0,[1,]ks,kp,class 0,nage) of the 6-D / 7-D arrays; consecutive classes are class_stride apart
+            const size_t o2 = ((((size_t)nage * Gp.nclassunc) * Gp.maxpointspec_act + kp) * Gp.maxspec + ks) * (size_t)n2;
+            const size_t cs2 = (size_t)Gp.maxpointspec_act * Gp.maxspec * (size_t)n2;
+            const size_t o3 = o2 * Gp.numzgrid, cs3 = cs2 * Gp.numzgrid;
+            rc = dump(c->wetdep && gwet ? gwet + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
+            if (!rc) rc = dump(c->drydep && gdry ? gdry + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
+            if (!rc) rc = dump(g3 + o3, cs3, n3, d_vol, pass == 0 ? 1 : 2, (int)n2 /* kz is 1-based in the index, :425 */, fh,
+                               pass == 1 ? (float)c->weightmolar[ks] : 1.f);
+          }
+        if (fclose(fh) != 0 && !rc) rc = fail(FPX_ERR_ARG, "concoutput: write error");
+      }
     cleanup();
     if (rc) return rc;
     if (clear) {   // gridunc(:,:,:,:,:,:,:)=0., concoutput.f90:714 / griduncn, concoutput_nest.f90 (the deposition grids keep accumulating)

@@ -271,12 +271,19 @@ class Engine:
         self.n = int(n.value)
         return int(n.value), int(npc.value), int(it.value)
 
-    def concoutput(self, itime, prefix, area, volume, outnum, wetdep=False, drydep=False, clear=False, nest=False):
+    def concoutput(self, itime, prefix, area, volume, outnum, wetdep=False, drydep=False, clear=False, nest=False,
+                   iout=1, prefix_pptv=None, outheight=None, outlon0=0.0, outlat0=0.0, weightmolar=()):
         """fpx_concoutput: writes <prefix><nnn> (the reference's grid_conc_* files) for every species."""
         from ._lib import FpxConcout
         a = np.ascontiguousarray(np.asarray(area, dtype=np.float32))
         v = np.ascontiguousarray(np.asarray(volume, dtype=np.float32))
-        c = FpxConcout(a.ctypes.data, v.ctypes.data, float(outnum), int(wetdep), int(drydep), int(nest), 0)
+        c = FpxConcout(a.ctypes.data, v.ctypes.data, float(outnum), int(wetdep), int(drydep), int(nest), int(iout))
+        if prefix_pptv is not None:
+            oh = np.ascontiguousarray(np.asarray(outheight, dtype=np.float32))
+            c.prefix_pptv = str(prefix_pptv).encode(); c.outheight = oh.ctypes.data
+            c.outlon0, c.outlat0 = float(outlon0), float(outlat0)
+            for i, w in enumerate(weightmolar):
+                c.weightmolar[i] = float(w)
         check(self.lib.fpx_concoutput(self.h, int(itime), C.byref(c), str(prefix).encode(), int(clear)), "fpx_concoutput")
 
     def upload_nests_from_scenario(self, sc):

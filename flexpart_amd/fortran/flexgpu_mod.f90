@@ -93,7 +93,10 @@ module flexgpu_mod
   type, bind(C) :: fpx_concout
     type(c_ptr) :: area, volume
     real(c_double) :: outnum
-    integer(c_int32_t) :: wetdep, drydep, nest, reserved
+    integer(c_int32_t) :: wetdep, drydep, nest, iout
+    type(c_ptr) :: prefix_pptv, outheight
+    real(c_double) :: outlon0, outlat0
+    real(c_double) :: weightmolar(FPX_MAXSPEC)
   end type fpx_concout
 
   integer, parameter :: FPX_MAXNESTS = 4
@@ -565,7 +568,8 @@ contains
     prefix = path(2)(1:length(2)) // 'grid_conc_' // adate // atime // '_'
     c%area = loc_r(area); c%volume = loc_r(volume)
     c%outnum = outnum
-    c%wetdep = merge(1, 0, WETDEP); c%drydep = merge(1, 0, DRYDEP); c%nest = 0; c%reserved = 0
+    c%wetdep = merge(1, 0, WETDEP); c%drydep = merge(1, 0, DRYDEP); c%nest = 0; c%iout = 1
+    c%prefix_pptv = c_null_ptr; c%outheight = c_null_ptr; c%outlon0 = 0; c%outlat0 = 0; c%weightmolar = 1   ! grid_pptv_*: through the C ABI
     ierr = fpx_concoutput(flexgpu_handle, int(itime, c_int32_t), c, trim(prefix) // c_null_char, 1_c_int32_t)
   end subroutine flexgpu_concoutput
 

@@ -239,7 +239,7 @@ int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
  * gridunc and their run-length compressed dumps, computed on the device from the grids the sampling kernels
  * filled; only the compressed indices and values travel to the host, which writes the records.
  * Byte-identical to the reference's file for the same grids.  Hosts with a 4-byte default real only (the
- * reference's concoutput.f90 does not compile with -fdefault-real-8).  Not written: dates, grid_pptv_*,
+ * reference's concoutput.f90 does not compile with -fdefault-real-8).  Not written: dates,
  * factor_drygrid, the receptor files (host side, from fpx_get_receptors).  For the sum over ranks call
  * fpx_get_grids(h, NULL, NULL, 1, 0) / fpx_get_wetgrid(h, NULL, 1, 0) first.
  * prefix: the file name without the species number, e.g. "<path>grid_conc_20200101010000_".
@@ -251,7 +251,14 @@ typedef struct {
   int32_t wetdep, drydep;
   int32_t nest;          /* 1: the nested output grid (`call concoutput_nest`, timemanager.f90:418; concoutput_nest.f90): area and
                             volume are arean, volumen; the prefix is "<path>grid_conc_nest_<date><time>_"                          */
-  int32_t reserved;
+  int32_t iout;          /* 0 or 1: grid_conc_* only; 2: grid_pptv_* only; 3: both (com_mod iout, concoutput.f90:265,482)     */
+  /* mixing-ratio files (iout 2, 3; mother output grid): "<path>grid_pptv_<date><time>_", outheight(numzgrid),
+   * outlon0, outlat0 (com_mod.f90:583-584) and weightmolar(1:nspec) (com_mod.f90:177); the air density comes from the
+   * met fields of slot memind(2) on the device (densityoutgrid, concoutput.f90:176-205) */
+  const char *prefix_pptv;
+  const void *outheight;
+  double outlon0, outlat0;
+  double weightmolar[FPX_MAXSPEC];
 } fpx_concout;
 int fpx_concoutput(fpx_handle h, int32_t itime, const fpx_concout *c, const char *prefix, int32_t clear);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */

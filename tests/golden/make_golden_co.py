@@ -22,3 +22,9 @@ for case, kw in CASES.items():
 for name, b in sio.run_co_reference(syn.concoutput_case(nxg=30, nyg=20, nzg=3, nspec=2, seed=21), nest=True).items():
     open(os.path.join(HERE, f"co_nest_{name[-3:]}.bin"), "wb").write(b)
     print("nest", name, len(b))
+
+# iout = 3: concentration and mixing-ratio files
+for name, b in sio.run_co_reference(syn.add_pptv(syn.concoutput_case(nxg=30, nyg=20, nzg=4, nspec=2, seed=8))).items():
+    key = ("pptv_" if "pptv" in name else "") + name[-3:]
+    open(os.path.join(HERE, f"co_pptv_{key}.bin"), "wb").write(b)
+    print("pptv", name, len(b))

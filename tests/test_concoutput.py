@@ -117,3 +117,41 @@ def test_hip_concoutput_nested_output_grid(built, tmp_path):
               area=case["area"], volume=case["volume"], gridunc=g[0, 0, 0], wetgridunc=w[0, 0, 0], drygridunc=d[0, 0, 0])
     for suffix, b in orc.co_oracle(co).items():
         assert open(prefix + suffix[1:], "rb").read() == b, suffix
+
+
+def test_oracle_equals_reference_pptv_files():
+    """iout = 3: grid_conc_* and grid_pptv_* (mixing ratio: densityoutgrid from the met density of slot memind(2), molar
+    weights) against the files the unmodified routine wrote (tests/golden/co_pptv_*.bin)."""
+    from oracle import oracle as orc
+    got = orc.co_oracle(syn.add_pptv(syn.concoutput_case(nxg=30, nyg=20, nzg=4, nspec=2, seed=8)))
+    assert sorted(got) == ["_001", "_002", "pptv_001", "pptv_002"]
+    for key, b in got.items():
+        assert b == open(os.path.join(HERE, "golden", f"co_pptv_{key.strip('_')}.bin"), "rb").read(), key
+
+
+@pytest.mark.gpu
+def test_hip_concoutput_mixing_ratio_files(built, tmp_path):
+    """iout = 3 on the device: the air density of the output cells comes from the device's own met pack."""
+    from flexpart_amd.engine import Engine
+    from oracle import oracle as orc
+    from test_oracle_cpu import golden_scenario
+    sc = syn.add_outgrid(golden_scenario("aerosol"))
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=4)
+    eng.run()
+    g, d = eng.grids()
+    na, nc, mp, nsp, nzg, nyg, nxg = eng.gshape
+    dxo, dyo, lon0, lat0 = (float(v) for v in sc["outgeom"])
+    case = syn.concoutput_case(nxg=nxg, nyg=nyg, nzg=nzg, nspec=nsp)
+    outheight = np.asarray(sc["outheight"], np.float64)
+    wm = [350.0]
+    pc, pp = str(tmp_path / "grid_conc_x_"), str(tmp_path / "grid_pptv_x_")
+    eng.concoutput(3600, pc, case["area"], case["volume"], outnum=4.0, drydep=True, iout=3, prefix_pptv=pp, outheight=outheight,
+                   outlon0=lon0, outlat0=lat0, weightmolar=wm)
+    eng.close()
+    m2 = int(sc["memind"][1]) - 1
+    co = dict(outgrid=np.array([nxg, nyg, nzg, nsp, 0, 1, 3600], np.int32), outgeom=np.array([dxo, dyo, lon0, lat0, 4.0]), outheight=outheight,
+              area=case["area"], volume=case["volume"], gridunc=g[0, 0, 0], drygridunc=d[0, 0, 0],
+              iout=3, met=sc["grid"], metgeom=sc["geom"], height=sc["height"], rho2=np.asarray(sc["rho"])[m2], weightmolar=np.array(wm))
+    want = orc.co_oracle(co)
+    assert open(pc + "001", "rb").read() == want["_001"]
+    assert open(pp + "001", "rb").read() == want["pptv_001"]
