@@ -1778,7 +1778,6 @@ struct Engine : EngineBase {
     const bool want_conc = iout == 1 || iout == 3, want_ppt = iout == 2 || iout == 3;
     if (want_ppt && (!c->prefix_pptv || !c->outheight)) return fail(FPX_ERR_ARG, "concoutput: prefix_pptv and outheight are required for iout 2, 3");
     if (want_ppt && (!slot_loaded[0] || !slot_loaded[1] || !window_set || !height_set)) return fail(FPX_ERR_STATE, "concoutput: mixing ratios need the met fields and the wind-time window");
-    if (want_ppt && c->nest) return fail(FPX_ERR_ARG, "concoutput: mixing-ratio files of the nested output grid are not implemented");
     if (c->nest && !Gp.nested) return fail(FPX_ERR_STATE, "concoutput: nested output grid requested without fpx_outgrid_nest_init");
     // nest = 1: the nested output grid (concoutput_nest.f90: the same algorithm on griduncn, wetgriduncn, drygriduncn, arean, volumen)
     const long long n2 = c->nest ? (long long)Gp.numxgridn * Gp.numygridn : (long long)Gp.numxgrid * Gp.numygrid, n3 = n2 * Gp.numzgrid;
@@ -1816,7 +1815,8 @@ struct Engine : EngineBase {
     if (e == hipSuccess && want_ppt) {
       e = hipMemcpyAsync(d_outh, c->outheight, (size_t)Gp.numzgrid * 4, hipMemcpyHostToDevice, stream);
       if (e == hipSuccess) {
-        k_co_density<R><<<(int)((n3 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, Gp.numxgrid, Gp.numygrid, Gp.numzgrid, d_outh, (float)Gp.dxout, (float)Gp.dyout,
+        k_co_density<R><<<(int)((n3 + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, c->nest ? Gp.numxgridn : Gp.numxgrid, c->nest ? Gp.numygridn : Gp.numygrid, Gp.numzgrid, d_outh,
+                                                                                (float)(c->nest ? Gp.dxoutn : Gp.dxout), (float)(c->nest ? Gp.dyoutn : Gp.dyout),
                                                                                 (float)c->outlon0, (float)c->outlat0, (float)cfg.dx, (float)cfg.dy, (float)cfg.xlon0, (float)cfg.ylat0, d_dens);
         e = hipGetLastError();
       }

@@ -252,8 +252,8 @@ typedef struct {
   int32_t nest;          /* 1: the nested output grid (`call concoutput_nest`, timemanager.f90:418; concoutput_nest.f90): area and
                             volume are arean, volumen; the prefix is "<path>grid_conc_nest_<date><time>_"                          */
   int32_t iout;          /* 0 or 1: grid_conc_* only; 2: grid_pptv_* only; 3: both (com_mod iout, concoutput.f90:265,482)     */
-  /* mixing-ratio files (iout 2, 3; mother output grid): "<path>grid_pptv_<date><time>_", outheight(numzgrid),
-   * outlon0, outlat0 (com_mod.f90:583-584) and weightmolar(1:nspec) (com_mod.f90:177); the air density comes from the
+  /* mixing-ratio files (iout 2, 3): "<path>grid_pptv_[nest_]<date><time>_", outheight(numzgrid),
+   * outlon0, outlat0 (com_mod.f90:583-584; outlon0n, outlat0n with nest = 1) and weightmolar(1:nspec) (com_mod.f90:177); the air density comes from the
    * met fields of slot memind(2) on the device (densityoutgrid, concoutput.f90:176-205) */
   const char *prefix_pptv;
   const void *outheight;

@@ -155,3 +155,30 @@ def test_hip_concoutput_mixing_ratio_files(built, tmp_path):
     want = orc.co_oracle(co)
     assert open(pc + "001", "rb").read() == want["_001"]
     assert open(pp + "001", "rb").read() == want["pptv_001"]
+
+
+@pytest.mark.gpu
+def test_hip_concoutput_nested_mixing_ratio(built, tmp_path):
+    """grid_pptv_nest_*: iout = 2 on the nested output grid (concoutput_nest.f90 with outlon0n, dxoutn ...)."""
+    from flexpart_amd.engine import Engine
+    from oracle import oracle as orc
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario("sampling_nest")
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=4)
+    eng.run()
+    g, d, w = eng.grids_nest()
+    na, nc, mp, nsp, nzg, nyn, nxn = eng.gshape_nest
+    dxn, dyn, lon0n, lat0n = (float(v) for v in sc["outgeomn"])
+    case = syn.concoutput_case(nxg=nxn, nyg=nyn, nzg=nzg, nspec=nsp)
+    outheight = np.asarray(sc["outheight"], np.float64)
+    pp = str(tmp_path / "grid_pptv_nest_x_")
+    eng.concoutput(3600, str(tmp_path / "unused_"), case["area"], case["volume"], outnum=2.0, nest=True, iout=2, prefix_pptv=pp,
+                   outheight=outheight, outlon0=lon0n, outlat0=lat0n, weightmolar=[120.0] * nsp)
+    eng.close()
+    m2 = int(sc["memind"][1]) - 1
+    co = dict(outgrid=np.array([nxn, nyn, nzg, nsp, 0, 0, 3600], np.int32), outgeom=np.array([dxn, dyn, lon0n, lat0n, 2.0]), outheight=outheight,
+              area=case["area"], volume=case["volume"], gridunc=g[0, 0, 0],
+              iout=3, met=sc["grid"], metgeom=sc["geom"], height=sc["height"], rho2=np.asarray(sc["rho"])[m2], weightmolar=np.array([120.0] * nsp))
+    want = orc.co_oracle(co)
+    for ks in range(nsp):
+        assert open(pp + f"{ks + 1:03d}", "rb").read() == want[f"pptv_{ks + 1:03d}"]
