@@ -61,3 +61,23 @@ def test_null_handle_is_rejected(built):
     lib = _lib.load()
     assert lib.fpx_sync(None) == -1
     assert lib.fpx_step(None, 0, None) == -1
+
+
+def test_ctypes_mirror_matches_the_c_header(tmp_path):
+    """include/flexpart_amd.h is valid C99 and every struct the Python mirror marshals has the size the C compiler gives it."""
+    import subprocess
+    from flexpart_amd import _lib
+    pairs = [("fpx_config", _lib.FpxConfig), ("fpx_fields", _lib.FpxFields), ("fpx_particles", _lib.FpxParticles),
+             ("fpx_step_stats", _lib.FpxStepStats), ("fpx_model_levels", _lib.FpxModelLevels), ("fpx_fields_out", _lib.FpxFieldsOut),
+             ("fpx_diag_fields", _lib.FpxDiagFields), ("fpx_restart", _lib.FpxRestart), ("fpx_concout", _lib.FpxConcout),
+             ("fpx_nests", _lib.FpxNests), ("fpx_outgrid", _lib.FpxOutgrid), ("fpx_wet_config", _lib.FpxWetConfig),
+             ("fpx_wet_fields", _lib.FpxWetFields)]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include "flexpart_amd.h"\n#include <stdio.h>\nint main(void) {\n'
+                   + "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n, _ in pairs) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, str(src), "-o", str(exe)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
+    for n, t in pairs:
+        assert int(got[n]) == C.sizeof(t), (n, got[n], C.sizeof(t))
