@@ -30,7 +30,7 @@ module flexgpu_mod
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
-            flexgpu_concoutput
+            flexgpu_concoutput, flexgpu_abi_sizes
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -363,6 +363,24 @@ contains
     type(c_ptr) :: p
     p = c_loc(x)
   end function loc_i2
+
+  ! c_sizeof of every bind(C) type of this module, in the order config, fields, particles, step_stats, model_levels,
+  ! fields_out, diag_fields, restart, concout, nests -- compared with the C compiler's sizeof by the tests
+  subroutine flexgpu_abi_sizes(sizes)
+    integer, intent(out) :: sizes(10)
+    type(fpx_config) :: a
+    type(fpx_fields) :: b
+    type(fpx_particles) :: c
+    type(fpx_step_stats) :: d
+    type(fpx_model_levels) :: e
+    type(fpx_fields_out) :: f
+    type(fpx_diag_fields) :: g
+    type(fpx_restart) :: h
+    type(fpx_concout) :: i
+    type(fpx_nests) :: j
+    sizes = (/ int(c_sizeof(a)), int(c_sizeof(b)), int(c_sizeof(c)), int(c_sizeof(d)), int(c_sizeof(e)), &
+               int(c_sizeof(f)), int(c_sizeof(g)), int(c_sizeof(h)), int(c_sizeof(i)), int(c_sizeof(j)) /)
+  end subroutine flexgpu_abi_sizes
 
   subroutine flexgpu_last_error(msg)
     character(len=*), intent(out) :: msg

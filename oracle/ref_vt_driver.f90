@@ -45,7 +45,7 @@ program vtref
   use flexgpu_mod
   implicit none
 
-  integer :: use_gpu, gerr
+  integer :: use_gpu, gerr, abi_sizes(10)
   character(len=256) :: gmsg
   character(len=512) :: arg3
   character(len=512) :: fscen, fout
@@ -64,6 +64,11 @@ program vtref
   integer(kind=8) :: c0, c1, crate
 
   call get_command_argument(1, fscen)
+  if (trim(fscen) .eq. 'abi') then      ! vtref_rK abi: sizes of the Fortran bind(C) types, for the ABI test
+    call flexgpu_abi_sizes(abi_sizes)
+    write(*,'(10i6)') abi_sizes
+    stop
+  end if
   call get_command_argument(2, fout)
   use_gpu = 0
   if (command_argument_count() .ge. 3) then

@@ -81,3 +81,19 @@ def test_ctypes_mirror_matches_the_c_header(tmp_path):
     got = dict(line.split() for line in subprocess.check_output([str(exe)], text=True).splitlines())
     for n, t in pairs:
         assert int(got[n]) == C.sizeof(t), (n, got[n], C.sizeof(t))
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("kind", ["r4", "r8"])
+def test_fortran_bind_c_types_match_the_c_header(kind):
+    """flexpart_amd/fortran/flexgpu_mod.f90: c_sizeof of every bind(C) type (printed by the flang-built driver) equals
+    the ctypes mirror's size, which the test above ties to the C header."""
+    import subprocess
+    from flexpart_amd import _lib
+    exe = os.path.join(ROOT, "oracle", "_ref", f"vtref_{kind}")
+    if not os.access(exe, os.X_OK):
+        pytest.skip("flang-built drivers not present")
+    got = [int(v) for v in subprocess.check_output([exe, "abi"], text=True).split()]
+    want = [C.sizeof(t) for t in (_lib.FpxConfig, _lib.FpxFields, _lib.FpxParticles, _lib.FpxStepStats, _lib.FpxModelLevels,
+                                  _lib.FpxFieldsOut, _lib.FpxDiagFields, _lib.FpxRestart, _lib.FpxConcout, _lib.FpxNests)]
+    assert got == want
