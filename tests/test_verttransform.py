@@ -19,8 +19,8 @@ from flexpart_amd import synthetic as syn
 HERE = os.path.dirname(os.path.abspath(__file__))
 FIELDS = ("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz", "uupol", "vvpol")
 CASES = {
-    "global_polar": dict(nx=40, ny=24, nz=30, global_grid=True, polar=True),
-    "limited_area": dict(nx=36, ny=28, nz=40, global_grid=False, polar=False),
+    "global_polar": dict(nx=30, ny=20, nz=22, global_grid=True, polar=True),
+    "limited_area": dict(nx=26, ny=22, nz=26, global_grid=False, polar=False),
 }
 
 
@@ -235,8 +235,8 @@ NEST_FIELDS = ("uu", "vv", "ww", "tt", "qv", "pv", "rho", "drhodz")
 
 
 def nest_case():
-    m = syn.model_levels(40, 24, 30, global_grid=False)
-    return m, syn.nest_model_levels(m)
+    m = syn.model_levels(30, 20, 22, global_grid=False)
+    return m, syn.nest_model_levels(m, ix0=8, jy0=5, ix1=18, jy1=12)
 
 
 def test_nest_oracle_equals_reference_fixture():
