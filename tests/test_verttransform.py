@@ -308,3 +308,48 @@ def test_fortran_host_verttransform_nests(built):
     assert max(worst.values()) <= 1e-11, worst
     for k in NEST_FIELDS:      # the mother grid of the same run
         assert np.abs(gpu[k] - ref[k]).max() <= 1e-11 * np.abs(ref[k]).max(), k
+
+
+@pytest.mark.gpu
+def test_trajectories_on_device_transformed_nest_fields(built):
+    """End to end with a nested grid: mother and nest fields of both time slots come from the device transforms
+    (fpx_verttransform_ecmwf, fpx_verttransform_nest); the particles -- a good part of them inside the nest -- agree with the
+    CPU oracle advancing on the oracle-transformed fields."""
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
+    from oracle import oracle as orc
+    from oracle.oracle import Oracle
+    from test_gpu_parity import assert_close
+    nx, ny, nz = 40, 24, 30
+    box = dict(ix0=10, jy0=6, ix1=26, jy1=18, factor=2)
+    ms = [syn.model_levels(nx=nx, ny=ny, nz=nz, global_grid=True, polar=False, phase=p) for p in (0, 6)]
+    ns = [syn.nest_model_levels(ms[s], phase=3 + 5 * s, **box) for s in (0, 1)]
+    w = [orc.vt_oracle(ms[0], "r8")]
+    w.append(orc.vt_oracle(ms[1], "r8", height=w[0]["height"]))
+    wn = [orc.vt_oracle(ns[s], "r8", height=w[0]["height"], nest_of=ms[s]) for s in (0, 1)]
+    sc = dict(syn.small(n=3000, nx=nx, ny=ny, nz=nz, nsteps=3, ctl=5.0, ifine=4))
+    sc["height"] = w[0]["height"]; sc["nmixz"] = w[0]["nmixz"]
+    for k in ("uu", "vv", "ww", "rho", "drhodz", "tt"):
+        sc[k] = np.stack([w[0][k], w[1][k]])
+    syn.add_nest(sc, **box)
+    assert tuple(sc["nest"]) == tuple(ns[0]["grid"][:2]) and np.array_equal(sc["nestgeom"], ns[0]["geom"])
+    for k, kn in (("uu", "uun"), ("vv", "vvn"), ("ww", "wwn"), ("rho", "rhon"), ("drhodz", "drhodzn")):
+        sc[kn] = np.stack([wn[0][k], wn[1][k]])
+    sc.update(syn.make_particles(3000, nx, ny, sc["height"], sc["hmix"], seed=23))
+    orcl = Oracle(sc, "r8")
+    orcl.lib.orc_set_parallel_semantics(orcl.h, 1)
+    want = orcl.run(3)
+    drop = ("uu", "vv", "ww", "rho", "drhodz", "tt", "height", "nmixz", "nest", "nestgeom", "uun", "vvn", "wwn", "rhon", "drhodzn",
+            "hmixn", "ustarn", "wstarn", "olin", "tropopausen", "vdepn")
+    eng = Engine({k: v for k, v in sc.items() if k not in drop}, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ)
+    for s in (0, 1):
+        eng.verttransform(s + 1, ms[s], {k: sc[k][s] for k in ("hmix", "ustar", "wstar", "oli", "tropopause")}, init=(s == 0), want=())
+    eng.init_nest(sc["nest"], sc["nestgeom"])
+    for s in (0, 1):
+        eng.verttransform(s + 1, ns[s], {k: sc[k + "n"][s] for k in ("hmix", "ustar", "wstar", "oli", "tropopause")}, nest=1, want=())
+    eng.set_windtime(sc["memtime"], sc["memind"])
+    got = eng.run(3)
+    eng.close()
+    inside = (sc["xtra1"] > 10.5) & (sc["xtra1"] < 25.5) & (sc["ytra1"] > 6.5) & (sc["ytra1"] < 17.5)
+    assert inside.sum() > 300
+    for g, wv in zip(got, want):
+        assert_close(g, wv, 1e-8, 1e-6)
