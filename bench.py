@@ -5,9 +5,13 @@ One "step" = one pass of the particle loop (reference timemanager.f90:531-712)
 over every particle resident on the GPU(s): one k_advance launch per GPU.
 Default workload (N=1): BASELINE config 3 -- 1e8 particles on the synthetic
 361x181x138 ECMWF-shaped grid, Hanna turbulence + CBL scheme, counter RNG, fp64.
-With --gpus N>1 (launched by torch.distributed.run, one rank per GPU) every rank
-holds its own shard of the same size: weak scaling, no data-path collective
-(particles are independent).
+With --gpus N>1 (launched by torch.distributed.run, one rank per GPU) the ranks
+share ONE cloud of --particles particles (BASELINE configs 3-5: 1e8): rank g owns
+the contiguous range [g*P/N, (g+1)*P/N) of particle numbers (the reference's MPI
+layout, README_PARALLEL.md:60-67) -- strong scaling, no data-path collective
+(particles are independent); the counter RNG is keyed on the
+global particle number, so the result does not depend on N.  --weak keeps the
+per-GPU count fixed instead.
 
 Prints ONE JSON line on rank 0.
 """
@@ -33,7 +37,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", type=int, default=3, choices=(2, 3, 4, 5))
-    ap.add_argument("--particles", type=float, default=None, help="particles per GPU (default: 1e8 cfg 3, 1e7 cfg 2)")
+    ap.add_argument("--particles", type=float, default=None, help="particles of the whole job (default: 1e7 config 2, 1e8 configs 3-5), shared by the ranks")
+    ap.add_argument("--weak", action="store_true", help="weak scaling: --particles per GPU instead of in total")
     ap.add_argument("--real", type=int, default=8, choices=(4, 8), help="compute real bytes")
     ap.add_argument("--rng", default="philox", choices=("philox", "table_counter"))
     ap.add_argument("--sort-interval", type=int, default=4, help="locality re-sort every k steps (0: never); 4 puts one re-sort inside the default timed region")
@@ -175,19 +180,27 @@ def main():
         torch.cuda.set_device(local)
 
     from flexpart_amd.engine import Engine, RNG_PHILOX, RNG_TABLE_COUNTER
-    nper = int(args.particles or (1e8 if args.config == 3 else 1e7))   # configs 4/5 are 1e8 over 8 GPUs: 1.25e7 each, 1e7 here
+    from flexpart_amd import sharding
+    ntot = int(args.particles or (1e7 if args.config == 2 else 1e8))
+    if args.weak:
+        ntot *= world
+    lo, hi = sharding.shard_bounds(ntot, world, rank)      # this rank's range of the global particle numbers
+    nper = hi - lo
     total_steps = args.warmup + args.steps
     sc, frac_pbl = build_scenario(args.config, total_steps)
+    sc["npart_rel"] = np.array([ntot], np.int32)           # npart(1): particles of the release on ALL ranks
     rng = RNG_PHILOX if args.rng == "philox" else RNG_TABLE_COUNTER
     eng = Engine(sc, compute_real_bytes=args.real, host_real_bytes=args.real, rng_mode=rng,
-                 seed=0x5EED + rank, max_particles=nper, device=local, sort_interval=args.sort_interval)
-    eng.seed_particles(nper, seed=0x5EED + 7919 * rank, frac_pbl=frac_pbl)
+                 seed=0x5EED, max_particles=nper, device=local, sort_interval=args.sort_interval, particle_base=lo)
+    eng.seed_particles(nper, seed=0x5EED, frac_pbl=frac_pbl)   # slice [lo, hi) of the one global synthetic cloud
     if args.sort_interval > 0:
         eng.sort()          # a release normally arrives ordered; the synthetic cloud is random
-    if args.config in (4, 5) and world > 1 and not rehearsal:
-        from flexpart_amd import sharding
-        uid = sharding.share_unique_id(dist, eng.comm_unique_id)
-        eng.comm_init(uid, world, rank)
+    if args.config in (4, 5) and world > 1:
+        if rehearsal:       # ranks share a device: RCCL refuses that, the host transport (gloo) carries the reduction
+            eng.comm_init_host(dist, world, rank)
+        else:
+            uid = sharding.share_unique_id(dist, eng.comm_unique_id)
+            eng.comm_init(uid, world, rank)
     lsync = int(sc["lsynctime"])
     window = 10800
 
@@ -215,7 +228,7 @@ def main():
     for i in range(args.warmup, total_steps):
         do_step(i)
     if args.config in (4, 5):
-        grid, _ = eng.grids(allreduce=world > 1 and not rehearsal)     # D2H of the (summed) grid: part of the job
+        grid, _ = eng.grids(allreduce=world > 1)     # the grid reduction over the ranks + D2H of the sums: part of the job
     eng.sync()
     torch.cuda.synchronize()
     if dist:
@@ -257,9 +270,10 @@ def main():
         "metric": "particle-steps/sec (whole node) + achieved HBM GB/s, 1e8 particles",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64" if rb == 8 else "f32",
+        "scaling": "weak" if args.weak else "strong", "vs_baseline": None, "dtype": "f64" if rb == 8 else "f32",
         "data": "synthetic",
-        "config": {"workload": (f"BASELINE config {args.config}: {nper:.0e} particles/GPU, synthetic "
+        "config": {"workload": (f"BASELINE config {args.config}: {ntot:.0e} particles"
+                                + (f" sharded over {world} GPUs ({nper} on rank 0)" if world > 1 else "") + ", synthetic "
                                 f"{nx}x{ny}x{nz} ECMWF-shaped fields, "
                                 + ("advance+interpol_wind only (all above PBL, turbulence off)" if args.config == 2
                                    else "Hanna turbulence + CBL (ctl=1/5, ifine=11), PBL sub-stepping")
@@ -267,7 +281,7 @@ def main():
                                 + (" + aerosol (settling, dry deposition), 241x121 nest, wet deposition, conccalc 360x180x10 every step"
                                    if args.config == 5 else "")
                                 + f", rng={args.rng}, lsynctime=900"),
-                   "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
+                   "particles_total": ntot, "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
                    "sort_interval": args.sort_interval},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

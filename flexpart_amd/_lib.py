@@ -38,10 +38,10 @@ class FpxConfig(C.Structure):
         ("drydep", C.c_int32), ("drydepspec", C.c_int32 * FPX_MAXSPEC),
         ("density", C.c_double * FPX_MAXSPEC), ("dquer", C.c_double * FPX_MAXSPEC),
         ("vsetaver", C.c_double * FPX_MAXSPEC), ("cunningham", C.c_double * FPX_MAXSPEC),
-        ("decay", C.c_double * FPX_MAXSPEC), ("xmass_release", C.c_double * FPX_MAXSPEC),
-        ("npart_release", C.c_int32), ("lage_last", C.c_int32),
+        ("decay", C.c_double * FPX_MAXSPEC),
+        ("mquasilag", C.c_int32), ("lage_last", C.c_int32),
         ("rng_mode", C.c_int32), ("seed", C.c_uint64),
-        ("sort_interval", C.c_int32), ("par_nxmax", C.c_int32), ("reserved", C.c_int32 * 6),
+        ("sort_interval", C.c_int32), ("par_nxmax", C.c_int32), ("particle_base", C.c_int64), ("reserved", C.c_int32 * 4),
     ]
 
 
@@ -84,7 +84,8 @@ class FpxRestart(C.Structure):
 class FpxConcout(C.Structure):
     _fields_ = [("area", C.c_void_p), ("volume", C.c_void_p), ("outnum", C.c_double), ("wetdep", C.c_int32), ("drydep", C.c_int32),
                 ("nest", C.c_int32), ("iout", C.c_int32), ("prefix_pptv", C.c_char_p), ("outheight", C.c_void_p),
-                ("outlon0", C.c_double), ("outlat0", C.c_double), ("weightmolar", C.c_double * 5)]
+                ("outlon0", C.c_double), ("outlat0", C.c_double), ("weightmolar", C.c_double * 5),
+                ("reduced", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FpxParticles(C.Structure):
@@ -135,14 +136,17 @@ class FpxStepStats(C.Structure):
                  "nan_count", "nan_count2", "n_bad_position")] + [("kernel_ms", C.c_double)]
 
 
+# fpx_allreduce_fn: int fn(void *user, const void *send, void *recv, int64_t count, int32_t dtype)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32)
+
 # every symbol include/flexpart_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_polar_maps", "fpx_set_height",
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
-    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart",
+    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
-    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_wet_init", "fpx_upload_wet_fields",
+    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
     "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
@@ -192,6 +196,7 @@ def load():
     lib.fpx_upload_particles.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(FpxParticles)]
     lib.fpx_download_particles.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(FpxParticles)]
     lib.fpx_set_numpart.argtypes = [vp, C.c_int64]
+    lib.fpx_set_release_points.argtypes = [vp, C.c_int32, vp, C.POINTER(C.c_int32)]
     lib.fpx_step.argtypes = [vp, C.c_int32, C.POINTER(FpxStepStats)]
     lib.fpx_step_async.argtypes = [vp, C.c_int32]
     lib.fpx_sync.argtypes = [vp]
@@ -212,7 +217,8 @@ def load():
     lib.fpx_wet_init.argtypes = [vp, C.POINTER(FpxWetConfig)]
     lib.fpx_upload_wet_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxWetFields)]
     lib.fpx_wetdepo.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
-    lib.fpx_get_wetgrid.argtypes = [vp, vp, C.c_int32, C.c_int32]
+    lib.fpx_get_wetgrid.argtypes = [vp, vp, C.c_int32]
+    lib.fpx_comm_init_host.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, vp]
     _lib = lib
     return lib
 

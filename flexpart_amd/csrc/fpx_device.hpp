@@ -286,8 +286,12 @@ struct View {
   int nspec, drydep, drydepspec[kMaxSpec];
   R ctl, fine, d_trop, d_strat, turbmesoscale;
   R density[kMaxSpec], dquer[kMaxSpec], vsetaver[kMaxSpec], cunningham[kMaxSpec], decay[kMaxSpec];
-  R xmass_rel[kMaxSpec];
-  int npart_rel, lage_last;
+  // release-point tables of point_mod (fpx_set_release_points), indexed per lane by npoint(j): device memory
+  int numpoint, mquasilag;
+  const R *rel_xmass;            // [maxspec][numpoint]: xmass(numpoint, maxspec), column-major like the host's
+  const int *rel_npart;          // [numpoint]
+  const signed char *rel_nsp;    // [numpoint] 0-based species of the settling pick (advance.f90:518-524), precomputed on the host
+  int lage_last;
   // fields, device layout (see DESIGN.md "data layout in HBM"):
   const R *height;   // [nz]
   const R *w3;       // [ny][nx][nz][2 slots][3]  (uu, vv, ww)
@@ -308,6 +312,7 @@ struct View {
   const R *rannumb;  // [maxrand], 0-based copy of rannumb(1:maxrand)
   int maxrand, rng_mode;
   unsigned long long seed;
+  unsigned int pid_base;   // global number of this rank's particle 0 (fpx_config.particle_base): key of the counter RNG
 };
 
 // Per-lane (divergent) subscripts into the small by-value tables of View.  A dynamic subscript
@@ -1170,15 +1175,22 @@ FPX_DEV R get_settling(const View<R> &V, const R *hgt, R xt, R yt, R zt, int nsp
   return settling;
 }
 
-// species pick + settling velocity, the block repeated at advance.f90:518-531,686-699,893-906
+// 0-based release point of a particle, clamped into the tables (the reference would read outside them)
 template <typename R>
-FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt, R zt) {
-  const R eps3 = sizeof(R) == 4 ? (R)1.17549435e-38f : (R)2.2250738585072014e-308;
+FPX_DEV int release_index(const View<R> &V, int npoint) { return min(max(npoint, 1), max(V.numpoint, 1)) - 1; }
+
+// species pick of advance.f90:518-524 for a particle of release point `npoint`: the first species with
+// xmass(nrelpoint,nsp) > eps3, else nspec (the table is evaluated once on the host, in the host's real kind)
+template <typename R>
+FPX_DEV int settling_species(const View<R> &V, int npoint) {
+  if (!V.lsettling || !V.rel_nsp) return 0;
+  return (int)V.rel_nsp[release_index(V, npoint)];
+}
+
+// settling velocity of species nsp, the block repeated at advance.f90:518-531,686-699,893-906
+template <typename R>
+FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt, R zt, int nsp) {
   if (V.mdomainfill != 0 || !V.lsettling) return K(0.);
-  int nsp;
-  for (nsp = 0; nsp < V.nspec; nsp++)
-    if (pick(V.xmass_rel, nsp) > eps3) break;
-  if (nsp >= V.nspec) nsp = V.nspec - 1;
   if (!(pick(V.density, nsp) > K(0.))) return K(0.);
   return get_settling(V, hgt, (R)xt, (R)yt, zt, nsp);
 }
@@ -1473,6 +1485,7 @@ struct AdvCtx {                 // what advance() keeps between its labelled sec
   R dxsave, dysave, dawsave, dcwsave;
   R u, v, w;                    // interpol_mod u, v, w
   int itimec, nrand;
+  int nsp;                      // species of the settling pick for this particle's release point (set by the caller)
 };
 
 enum { PBL_CONTINUE = 0, PBL_DONE = 1, PBL_ESCAPED = 2 };
@@ -1485,6 +1498,7 @@ FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, 
   A.u = K(0.); A.v = K(0.); A.w = K(0.);
   A.itimec = itime;
   A.nrand = nrand;
+  A.nsp = 0;
   A.ngrid = pick_grid(V, xt, yt);
   int nyrows = V.ny, nxcols = V.nx;
   if (A.ngrid > 0) {   // advance.f90:191-197 nested grid coordinates
@@ -1536,6 +1550,7 @@ struct LoopCtx {                // register-resident state of a lane across pass
   R h;
   int itimec, nrand;
   int ilo;                      // level index of the *lo profile level in the stash (the last pass's pair)
+  int nsp;                      // species of the settling pick (aerosol kernels only)
 };
 
 template <typename R>
@@ -1746,7 +1761,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 
   R w = S.get(S_W);
   if (SETTLE && V.lsettling) {   // advance.f90:518-531
-    w = w + settling_velocity(V, hgt, xt, yt, zt);
+    w = w + settling_velocity(V, hgt, xt, yt, zt, A.nsp);
     S.put(S_W, w);
   }
 
@@ -1824,7 +1839,7 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
     nrand = nrand + 1;
   }
   A.nrand = nrand;
-  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt);   // advance.f90:686-699
+  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt, A.nsp);   // advance.f90:686-699
   A.dxsave = A.dxsave + (A.u + ux) * dt;
   A.dysave = A.dysave + (A.v + vy) * dt;
   zt = zt + (A.w + wp) * dt * (R)V.ldirect;
@@ -1887,7 +1902,7 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
     cell_setup(C, ix, jy, ixp, jyp, xr, yr);
     interp_wind<R, false>(V, hgt, fld_of(V, A.ngrid), C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2);
   }
-  if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt);   // advance.f90:893-906
+  if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt, A.nsp);   // advance.f90:893-906
   u = (u - A.u) / K(2.);
   v = (v - A.v) / K(2.);
   w = (w - A.w) / K(2.);
@@ -1985,11 +2000,20 @@ FPX_DEV void wave_scatter_add(T *base, long long idx, T val, bool valid) {
   }
 }
 
+// Guard without a counterpart in the reference: a particle older than lage(nageclass) (nage = nageclass+1 after the
+// loop; possible only before its first epilogue, e.g. after a warm start), an uncertainty class outside 1..nclassunc
+// or a release point outside 1..maxpointspec_act would address planes outside the grids; such a particle is not sampled.
+template <typename R>
+FPX_DEV bool grid_planes_ok(const GridP<R> &Gp, int nage, int nclass, int kp) {
+  return nage >= 1 && nage <= Gp.nageclass && nclass >= 1 && nclass <= Gp.nclassunc && kp >= 1 && kp <= Gp.maxpointspec_act;
+}
+
 // conccalc.f90:50-295 for one particle (active == this lane holds a particle that is due)
 template <typename R>
 FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hgt, bool active, double xt, double yt, R zt,
                                int itage, int npoint, int nclass, const R *xmass, R weight) {
   const int nage = ageclass(Gp, itage);
+  const bool planes_ok = grid_planes_ok(Gp, nage, nclass, (Gp.ioutputforeachrelease == 0 || V.mdomainfill == 1) ? 1 : npoint);
   R rhoi = K(1.);
   if (active && Gp.ind_samp == -1) {   // conccalc.f90:80-122, density at the particle
     int ix = (int)xt, jy = (int)yt;
@@ -2017,7 +2041,7 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
   int kz = 1;
   for (; kz <= Gp.numzgrid; kz++)
     if (Gp.outheight[kz - 1] > zt) break;
-  const bool inside = active && kz <= Gp.numzgrid;
+  const bool inside = active && planes_ok && kz <= Gp.numzgrid;
   for (int ig = 0; ig < (Gp.nested ? 2 : 1); ig++) {   // mother grid :145-295, nested grid :301-441
     const OutGeom<R> G = out_geom(Gp, ig == 1);
     const R xl = (R)((xt * (double)V.dx + (double)G.xshift) / (double)G.dxout);
@@ -2039,11 +2063,13 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
     const long long off = plane * (kz - 1) + sstride * ((long long)Gp.maxspec * ((nrelpointer - 1) + (long long)Gp.maxpointspec_act * ((nclass - 1) + (long long)Gp.nclassunc * (nage - 1))));
     for (int ks = 0; ks < V.nspec; ks++) {
       const R m = active ? xmass[ks] / rhoi * weight : K(0.);
-      R *g = G.grid + off + sstride * ks;
-      wave_scatter_add<R>(g, (long long)jy * G.numx + ix, direct ? m : m * (wx * wy), inside && okx && oky);
-      wave_scatter_add<R>(g, (long long)jyp * G.numx + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
-      wave_scatter_add<R>(g, (long long)jyp * G.numx + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
-      wave_scatter_add<R>(g, (long long)jy * G.numx + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
+      // the base is wave-uniform, the whole (cell, level, species, point, class, age) offset is the per-lane index:
+      // lanes are merged into one atomic only when all of it agrees
+      const long long o = off + sstride * ks;
+      wave_scatter_add<R>(G.grid, o + (long long)jy * G.numx + ix, direct ? m : m * (wx * wy), inside && okx && oky);
+      wave_scatter_add<R>(G.grid, o + (long long)jyp * G.numx + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
+      wave_scatter_add<R>(G.grid, o + (long long)jyp * G.numx + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
+      wave_scatter_add<R>(G.grid, o + (long long)jy * G.numx + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
     }
   }
   // concentrations at receptor points, parabolic kernel: conccalc.f90:451-498.  The reference sums the
@@ -2072,6 +2098,7 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
 template <typename R>
 FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp0, int nunc, float deposit, int ks, R x, R y, int nage, int kp, bool nest = false) {
   if (!(fabsf(deposit) > 0.f)) return;
+  if (!grid_planes_ok(Gp0, nage, nunc, kp)) return;
   // the nested variant (drydepokernel_nest.f90:38-100) always uses the kernel
   struct { int numxgrid, numygrid, maxspec, maxpointspec_act, nclassunc, lusekerneloutput; R dxout, dyout, xoutshift, youtshift; float *drygridunc; } Gp;
   {
@@ -2231,6 +2258,7 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
 // wetdepokernel.f90:38-108 for one species (deposit is a default real, the grid is dep_prec)
 template <typename R>
 FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp0, int nunc, R deposit, int ks, R x, R y, int nage, int kp, bool nest = false) {
+  if (!grid_planes_ok(Gp0, nage, nunc, kp)) return;
   // the nested variant (wetdepokernel_nest.f90:38-107) always uses the kernel and truncates with floor()
   struct { int numxgrid, numygrid, maxspec, maxpointspec_act, nclassunc, lusekerneloutput; R dxout, dyout, xoutshift, youtshift; float *wetgridunc; } Gp;
   {

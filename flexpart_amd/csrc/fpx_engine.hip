@@ -187,8 +187,9 @@ __global__ void k_seed(View<R> V, Parts<R> P, long long n, unsigned long long se
   if (i >= n) return;
   {
 #pragma clang fp contract(off)
-  double ux = splitmix_u01(i + 1, seed + 1), uy = splitmix_u01(i + 1, seed + 2);
-  double uz = splitmix_u01(i + 1, seed + 3), us = splitmix_u01(i + 1, seed + 4);
+  const unsigned long long gi = (unsigned long long)i + V.pid_base + 1ull;   // number in the global cloud
+  double ux = splitmix_u01(gi, seed + 1), uy = splitmix_u01(gi, seed + 2);
+  double uz = splitmix_u01(gi, seed + 3), us = splitmix_u01(gi, seed + 4);
   const double eps = 361.0 / 3.0e5;
   double x = eps + ux * ((double)(V.nx - 1) - 2.0 * eps);
   double y = lat_margin + uy * ((double)(V.ny - 1) - 2.0 * lat_margin);
@@ -240,7 +241,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(View<R> V, Parts<R> P, long
 template <typename R, typename RNG>
 __device__ __forceinline__ void make_rng(const View<R> &V, unsigned int pid, unsigned int step, RNG &G) {
   G.tab = V.rannumb; G.maxrand = V.maxrand; G.mode = V.rng_mode;
-  G.pid = pid; G.step = step;
+  G.pid = pid + V.pid_base; G.step = step;
   G.k0 = (unsigned int)V.seed; G.k1 = (unsigned int)(V.seed >> 32);
   G.cblk = 0xffffffffu;
 }
@@ -263,6 +264,11 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
   } else {
     itra1 = itime + V.lsynctime;
     R xmassfract = (R)0;
+    // release point of the particle: xmass(npoint(j),ks), npart(npoint(j)), timemanager.f90:663-666
+    const bool massfract = V.mdomainfill == 0 && V.mquasilag == 0;
+    const int npoint = (massfract || (DRYDEP && Gp.on)) ? P.npoint[s] : 1;
+    const int kr = release_index(V, npoint);
+    const R npart_r = massfract ? (R)V.rel_npart[kr] : (R)0;
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) {
       if (ks < V.nspec) {
@@ -278,14 +284,15 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
               drydeposit = (float)((R)drydeposit * m_exp((R)abs(ldeltat) * V.decay[ks]));
             }
             const int nage = ageclass(Gp, abs(itime - itramem));
-            const int kp = Gp.ioutputforeachrelease == 1 ? P.npoint[s] : 1;
+            const int kp = Gp.ioutputforeachrelease == 1 ? npoint : 1;
             drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp);
             if (Gp.nested) drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp, true);   // timemanager.f90:694-696
           }
         } else xm = xm * decfact;
         if (DRYDEP || V.decay[ks] > (R)0) P.xmass1[(size_t)ks * P.cap + s] = xm;
-        if (V.mdomainfill == 0) {
-          if (V.xmass_rel[ks] > (R)0) xmassfract = m_max(xmassfract, (R)V.npart_rel * xm / V.xmass_rel[ks]);
+        if (massfract) {   // timemanager.f90:663-666
+          const R xmr = V.rel_xmass[(size_t)ks * V.numpoint + kr];
+          if (xmr > (R)0) xmassfract = m_max(xmassfract, npart_r * xm / xmr);
         } else {
           xmassfract = (R)1;
         }
@@ -377,6 +384,7 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
   AdvCtx<R> A;
   const TimeW<R> W = time_weights(V, itime);
   const bool in_pbl = adv_begin(V, ps.xt, ps.yt, ps.zt, itime, advance_start_index(V, S, G, pid), A);
+  if (V.lsettling) A.nsp = settling_species(V, P.npoint[s]);   // advance.f90:518-524 with nrelpoint = npoint(j)
   if (in_pbl) {
     if (is_new) {   // the PBL kernels re-read the state from HBM
       P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
@@ -736,6 +744,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
             adv_begin(V, xt, yt, zt, itime, Q.nrand0[s], A0);
             A.ngrid = A0.ngrid; A.ix = A0.ix; A.jy = A0.jy; A.ixp = A0.ixp; A.jyp = A0.jyp;
             A.h = A0.h; A.itimec = A0.itimec; A.nrand = A0.nrand;
+            A.nsp = (!LEAN && V.lsettling) ? settling_species(V, P.npoint[s]) : 0;
             S.put(S_DDX, A0.xr - (R)A0.ix); S.put(S_DDY, A0.yr - (R)A0.jy);   // interpol_all.f90:57-58
           }
           S.put(S_DX, (R)0); S.put(S_DY, (R)0); S.put(S_DAW, (R)0); S.put(S_DCW, (R)0);
@@ -828,6 +837,7 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_pbl_finish(View<R> V
       adv_begin(V, ps.xt, ps.yt, ps.zt, itime, 0, A0);
       A = A0;
     }
+    if (V.lsettling) A.nsp = settling_species(V, P.npoint[s]);
     A.dxsave = Q.dxsave[s]; A.dysave = Q.dysave[s]; A.dawsave = Q.dawsave[s]; A.dcwsave = Q.dcwsave[s];
     A.u = Q.u[s]; A.v = Q.v[s]; A.w = Q.w[s];
     A.nrand = Q.nrand[s]; A.itimec = Q.itimec[s];
@@ -935,6 +945,7 @@ struct EngineBase {
   virtual int upload_particles(long long first, long long count, const fpx_particles *p) = 0;
   virtual int download_particles(long long first, long long count, const fpx_particles *p) = 0;
   virtual int set_numpart(long long n) = 0;
+  virtual int set_release_points(int numpoint, const void *xmass, const int32_t *npart) = 0;
   virtual int step(int itime, fpx_step_stats *st, bool async) = 0;
   virtual int sync() = 0;
   virtual int counters(fpx_step_stats *out, int reset) = 0;
@@ -947,13 +958,14 @@ struct EngineBase {
   virtual int conccalc(int itime, double weight) = 0;
   virtual int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) = 0;
   virtual int comm_init(const void *id, int nbytes, int nranks, int rank) = 0;
+  virtual int comm_init_host(int nranks, int rank, fpx_allreduce_fn fn, void *user) = 0;
   virtual int nests_init(const fpx_nests *n) = 0;
   virtual int upload_nest_fields(int nest, int slot, const fpx_fields *f) = 0;
   virtual int wet_init(const fpx_wet_config *w) = 0;
   virtual int upload_wet_fields(int slot, const fpx_wet_fields *f) = 0;
   virtual int upload_wet_nest_fields(int nest, int slot, const fpx_wet_fields *f, int readclouds_nest) = 0;
   virtual int wetdepo(int itime, int ltsample, int loutnext) = 0;
-  virtual int get_wetgrid(void *wetgridunc, int allreduce, int clear) = 0;
+  virtual int get_wetgrid(void *wetgridunc, int allreduce) = 0;
   virtual int outgrid_nest_init(const fpx_outgrid_nest *g) = 0;
   virtual int get_grids_nest(void *griduncn, void *drygriduncn, void *wetgriduncn, int allreduce, int clear) = 0;
   virtual int receptors_init(int n, const void *x, const void *y, const void *area) = 0;
@@ -1001,6 +1013,19 @@ struct Engine : EngineBase {
   size_t n_grid3 = 0, n_grid2 = 0, n_grid3n = 0, n_grid2n = 0;
   ncclComm_t comm = nullptr;
   int comm_ranks = 1;
+  // host-supplied all-reduce (fpx_comm_init_host): the transport of an MPI host, or gloo in the tests
+  fpx_allreduce_fn host_allreduce = nullptr;
+  void *host_allreduce_user = nullptr;
+  void *red_pin = nullptr;               // pinned bounce buffer of the host transport: [send | recv]
+  size_t red_pin_bytes = 0;
+  // Receive buffers of the grid reduction (the reference's gridunc0, drygridunc0, wetgridunc0, griduncn0, ... and
+  // creceptor0: mpi_mod.f90:2451-2492,2543-2569; allocated in outgrid_init.f90:220-225).  The per-rank partial sums
+  // stay untouched in Gp.*: drygridunc / wetgridunc accumulate over the whole run and are reduced again at every
+  // output time.  Allocated on the first reduction.
+  R *gridunc0 = nullptr, *griduncn0 = nullptr, *creceptor0 = nullptr;
+  float *drygridunc0 = nullptr, *wetgridunc0 = nullptr, *drygriduncn0 = nullptr, *wetgriduncn0 = nullptr;
+  bool red_valid[7] = {};                // which receive buffers hold the sums of the last reduction
+  enum { RG_GRID = 0, RG_DRY, RG_WET, RG_GRIDN, RG_DRYN, RG_WETN, RG_REC };
   void *d_sel_tmp = nullptr;
   size_t sel_tmp_bytes = 0;
   int pbl_grid = 0;
@@ -1074,10 +1099,14 @@ struct Engine : EngineBase {
     for (int i = 0; i < FPX_MAXSPEC; i++) {
       V.drydepspec[i] = cfg.drydepspec[i];
       V.density[i] = (R)cfg.density[i]; V.dquer[i] = (R)cfg.dquer[i]; V.vsetaver[i] = (R)cfg.vsetaver[i];
-      V.cunningham[i] = (R)cfg.cunningham[i]; V.decay[i] = (R)cfg.decay[i]; V.xmass_rel[i] = (R)cfg.xmass_release[i];
+      V.cunningham[i] = (R)cfg.cunningham[i]; V.decay[i] = (R)cfg.decay[i];
     }
-    V.npart_rel = cfg.npart_release; V.lage_last = cfg.lage_last;
+    V.lage_last = cfg.lage_last; V.mquasilag = cfg.mquasilag;
+    V.numpoint = 0; V.rel_xmass = nullptr; V.rel_npart = nullptr; V.rel_nsp = nullptr;
     V.rng_mode = cfg.rng_mode; V.seed = cfg.seed; V.maxrand = 1000000;
+    if (cfg.particle_base < 0 || cfg.particle_base + cfg.max_particles > 0xFFFFFFF0ll) return fail(FPX_ERR_ARG, "particle_base + max_particles must fit 32 bits");
+    if (cfg.particle_base != 0 && cfg.rng_mode == FPX_RNG_TABLE_SEQ) return fail(FPX_ERR_ARG, "particle_base: the serial-stream RNG mode (TABLE_SEQ) is a single-rank mode");
+    V.pid_base = (unsigned int)cfg.particle_base;
     V.eps = (R)(cfg.par_nxmax > 0 ? cfg.par_nxmax : cfg.nxmax) / (R)3.e5;   // advance.f90:107
     V.numbnests = 0;
     V.nest = nullptr;
@@ -1147,6 +1176,7 @@ struct Engine : EngineBase {
     if (staging) (void)hipFree(staging);
     if (d_sort_tmp) (void)hipFree(d_sort_tmp);
     if (d_sel_tmp) (void)hipFree(d_sel_tmp);
+    if (red_pin) (void)hipHostFree(red_pin);
     if (comm) (void)ncclCommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
   }
@@ -1781,8 +1811,21 @@ struct Engine : EngineBase {
     if (c->nest && !Gp.nested) return fail(FPX_ERR_STATE, "concoutput: nested output grid requested without fpx_outgrid_nest_init");
     // nest = 1: the nested output grid (concoutput_nest.f90: the same algorithm on griduncn, wetgriduncn, drygriduncn, arean, volumen)
     const long long n2 = c->nest ? (long long)Gp.numxgridn * Gp.numygridn : (long long)Gp.numxgrid * Gp.numygrid, n3 = n2 * Gp.numzgrid;
-    R *g3 = c->nest ? Gp.griduncn : Gp.gridunc;
+    R *g3 = c->nest ? Gp.griduncn : Gp.gridunc;            // the rank's own partial sums (zeroed afterwards with clear = 1)
     float *gwet = c->nest ? Gp.wetgriduncn : Gp.wetgridunc, *gdry = c->nest ? Gp.drygriduncn : Gp.drygridunc;
+    const R *s3 = g3;                                      // what is written
+    if (c->reduced) {
+      // the sums over all ranks that fpx_get_grids / fpx_get_wetgrid / fpx_get_grids_nest (allreduce = 1) left in the
+      // receive buffers -- concoutput_mpi.f90:279,298 writes from gridunc0 / drygridunc0 / wetgridunc0
+      const int ig = c->nest ? RG_GRIDN : RG_GRID, id = c->nest ? RG_DRYN : RG_DRY, iw = c->nest ? RG_WETN : RG_WET;
+      if (comm_ranks > 1) {
+        if (!red_valid[ig] || (c->drydep && !red_valid[id]) || (c->wetdep && !red_valid[iw]))
+          return fail(FPX_ERR_STATE, "concoutput: reduced = 1 needs fpx_get_grids / fpx_get_wetgrid / fpx_get_grids_nest with allreduce = 1 first");
+        s3 = c->nest ? griduncn0 : gridunc0;
+        if (c->drydep) gdry = c->nest ? drygriduncn0 : drygridunc0;
+        if (c->wetdep) gwet = c->nest ? wetgriduncn0 : wetgridunc0;
+      }
+    }
     float *d_area = nullptr, *d_vol = nullptr, *val = nullptr, *wr = nullptr;
     unsigned int *nz = nullptr, *rs = nullptr, *rpos = nullptr, *runid = nullptr;
     int *wi = nullptr;
@@ -1871,7 +1914,7 @@ struct Engine : EngineBase {
             const size_t o3 = o2 * Gp.numzgrid, cs3 = cs2 * Gp.numzgrid;
             rc = dump(c->wetdep && gwet ? gwet + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
             if (!rc) rc = dump(c->drydep && gdry ? gdry + o2 : (float *)nullptr, cs2, n2, d_area, 0, 0, fh);
-            if (!rc) rc = dump(g3 + o3, cs3, n3, d_vol, pass == 0 ? 1 : 2, (int)n2 /* kz is 1-based in the index, :425 */, fh,
+            if (!rc) rc = dump(s3 + o3, cs3, n3, d_vol, pass == 0 ? 1 : 2, (int)n2 /* kz is 1-based in the index, :425 */, fh,
                                pass == 1 ? (float)c->weightmolar[ks] : 1.f);
           }
         if (fclose(fh) != 0 && !rc) rc = fail(FPX_ERR_ARG, "concoutput: write error");
@@ -2026,6 +2069,35 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // point_mod xmass(numpoint,maxspec), npart(numpoint): device tables indexed by npoint(j)
+  int set_release_points(int numpoint, const void *xmass, const int32_t *npart) override {
+    if (numpoint < 1 || !xmass || !npart) return fail(FPX_ERR_ARG, "set_release_points: numpoint >= 1, xmass and npart are required");
+    std::vector<R> xm((size_t)numpoint * cfg.nspec);
+    std::vector<signed char> nsp((size_t)numpoint);
+    for (int kp = 0; kp < numpoint; kp++) {
+      // advance.f90:518-524: first species with xmass(nrelpoint,nsp) > eps3 = tiny(1.0) of the host's real kind, else nspec
+      int pick = cfg.nspec - 1;
+      for (int ks = cfg.nspec - 1; ks >= 0; ks--) {
+        const size_t i = (size_t)ks * numpoint + kp;
+        bool above;
+        if (cfg.host_real_bytes == 4) { const float v = ((const float *)xmass)[i]; xm[i] = (R)v; above = v > 1.17549435e-38f; }
+        else { const double v = ((const double *)xmass)[i]; xm[i] = (R)v; above = v > 2.2250738585072014e-308; }
+        if (above) pick = ks;
+      }
+      nsp[kp] = (signed char)pick;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    R *d_x; int *d_n; signed char *d_s;
+    int rc;
+    if ((rc = dalloc(&d_x, xm.size())) || (rc = dalloc(&d_n, (size_t)numpoint)) || (rc = dalloc(&d_s, (size_t)numpoint))) return rc;
+    HIPCHK(hipMemcpyAsync(d_x, xm.data(), xm.size() * sizeof(R), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_n, npart, (size_t)numpoint * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_s, nsp.data(), (size_t)numpoint, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    V.rel_xmass = d_x; V.rel_npart = d_n; V.rel_nsp = d_s; V.numpoint = numpoint;
+    return 0;
+  }
+
   int set_numpart(long long n) override {
     if (n < 0 || n > P.cap) return fail(FPX_ERR_ARG, "set_numpart: outside capacity");
     numpart = n;
@@ -2098,10 +2170,13 @@ struct Engine : EngineBase {
     if (!height_set || !window_set || !slot_loaded[0] || !slot_loaded[1]) return fail(FPX_ERR_STATE, "step: height, both field slots and the wind-time window must be set first");
     if (cfg.rng_mode != FPX_RNG_PHILOX && !table_set) return fail(FPX_ERR_STATE, "step: the table RNG modes need fpx_rng_fill_table/fpx_rng_set_table");
     if (V.memtime0 == V.memtime1) return fail(FPX_ERR_STATE, "step: empty wind-time window");
+    if (V.numpoint == 0 && cfg.mdomainfill == 0 && cfg.mquasilag == 0)
+      return fail(FPX_ERR_STATE, "step: the release-point tables xmass, npart are needed for the mass-fraction test (fpx_set_release_points)");
     for (int l = 0; l < V.numbnests; l++)
       if (!nest_loaded[l][0] || !nest_loaded[l][1]) return fail(FPX_ERR_STATE, "step: nest fields missing (fpx_upload_nest_fields, both slots)");
     if (out) memset(out, 0, sizeof(*out));
     if (numpart == 0) return 0;
+    if (cfg.drydep) red_valid[RG_DRY] = red_valid[RG_DRYN] = false;
     if (cfg.sort_interval > 0 && step_counter > 0 && step_counter % (unsigned)cfg.sort_interval == 0) {
       int rc = sort_particles();
       if (rc) return rc;
@@ -2399,23 +2474,22 @@ struct Engine : EngineBase {
   }
   int get_grids_nest(void *griduncn, void *drygriduncn, void *wetgriduncn, int allreduce, int clear) override {
     if (!Gp.nested) return fail(FPX_ERR_STATE, "get_grids_nest: fpx_outgrid_nest_init first");
+    const R *g3 = Gp.griduncn;
+    const float *gd = Gp.drygriduncn, *gw = Gp.wetgriduncn;
     if (allreduce && comm_ranks > 1) {
-      if (!comm) return fail(FPX_ERR_STATE, "get_grids_nest: allreduce requested without fpx_comm_init");
-      // mpi_mod.f90:2543-2569 (mpif_tm_reduce_grid_nest)
-      ncclResult_t r = ncclAllReduce(Gp.griduncn, Gp.griduncn, n_grid3n, sizeof(R) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream);
-      if (r == ncclSuccess) r = ncclAllReduce(Gp.drygriduncn, Gp.drygriduncn, n_grid2n, ncclFloat, ncclSum, comm, stream);
-      if (r == ncclSuccess) r = ncclAllReduce(Gp.wetgriduncn, Gp.wetgriduncn, n_grid2n, ncclFloat, ncclSum, comm, stream);
-      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+      // mpi_mod.f90:2543-2569 (mpif_tm_reduce_grid_nest): into the receive buffers, the partial sums stay
+      int rc;
+      if ((rc = reduce_into(Gp.griduncn, &griduncn0, n_grid3n, "get_grids_nest")) || (rc = reduce_into(Gp.drygriduncn, &drygriduncn0, n_grid2n, "get_grids_nest")) ||
+          (rc = reduce_into(Gp.wetgriduncn, &wetgriduncn0, n_grid2n, "get_grids_nest"))) return rc;
+      red_valid[RG_GRIDN] = red_valid[RG_DRYN] = red_valid[RG_WETN] = true;
+      g3 = griduncn0; gd = drygriduncn0; gw = wetgriduncn0;
     }
-    int rc = download_real(griduncn, Gp.griduncn, n_grid3n);
+    int rc = download_real(griduncn, g3, n_grid3n);
     if (rc) return rc;
-    if (drygriduncn) HIPCHK(hipMemcpyAsync(drygriduncn, Gp.drygriduncn, n_grid2n * sizeof(float), hipMemcpyDeviceToHost, stream));
-    if (wetgriduncn) HIPCHK(hipMemcpyAsync(wetgriduncn, Gp.wetgriduncn, n_grid2n * sizeof(float), hipMemcpyDeviceToHost, stream));
-    if (clear) {
-      HIPCHK(hipMemsetAsync(Gp.griduncn, 0, n_grid3n * sizeof(R), stream));
-      HIPCHK(hipMemsetAsync(Gp.drygriduncn, 0, n_grid2n * sizeof(float), stream));
-      HIPCHK(hipMemsetAsync(Gp.wetgriduncn, 0, n_grid2n * sizeof(float), stream));
-    }
+    if (drygriduncn) HIPCHK(hipMemcpyAsync(drygriduncn, gd, n_grid2n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (wetgriduncn) HIPCHK(hipMemcpyAsync(wetgriduncn, gw, n_grid2n * sizeof(float), hipMemcpyDeviceToHost, stream));
+    // concoutput_nest.f90 zeroes griduncn only; drygriduncn / wetgriduncn accumulate over the run
+    if (clear) HIPCHK(hipMemsetAsync(Gp.griduncn, 0, n_grid3n * sizeof(R), stream));
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
@@ -2444,14 +2518,16 @@ struct Engine : EngineBase {
     if (!Gp.numreceptor) return fail(FPX_ERR_STATE, "get_receptors: fpx_receptors_init first");
     if (creceptor && ld < Gp.numreceptor) return fail(FPX_ERR_ARG, "get_receptors: leading dimension smaller than numreceptor");
     const size_t n = (size_t)Gp.numreceptor * cfg.nspec;
+    const R *src = Gp.creceptor;
     if (allreduce && comm_ranks > 1) {
-      if (!comm) return fail(FPX_ERR_STATE, "get_receptors: allreduce requested without fpx_comm_init");
-      ncclResult_t r = ncclAllReduce(Gp.creceptor, Gp.creceptor, n, sizeof(R) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream);   // mpi_mod.f90:2480-2484
-      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+      int rc = reduce_into(Gp.creceptor, &creceptor0, n, "get_receptors");   // mpi_mod.f90:2480-2484, into creceptor0
+      if (rc) return rc;
+      red_valid[RG_REC] = true;
+      src = creceptor0;
     }
     if (creceptor) {
       std::vector<R> tmp(n);
-      HIPCHK(hipMemcpyAsync(tmp.data(), Gp.creceptor, n * sizeof(R), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipMemcpyAsync(tmp.data(), src, n * sizeof(R), hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
       for (int ks = 0; ks < cfg.nspec; ks++)
         for (int i = 0; i < Gp.numreceptor; i++) {
@@ -2472,13 +2548,46 @@ struct Engine : EngineBase {
     if (!height_set || (Gp.ind_samp == -1 && (!slot_loaded[0] || !slot_loaded[1]))) return fail(FPX_ERR_STATE, "conccalc: height / fields not set");
     if (numpart == 0) return 0;
     const int nb = (int)((numpart + kBlock - 1) / kBlock);
+    red_valid[RG_GRID] = red_valid[RG_GRIDN] = red_valid[RG_REC] = false;   // the partial sums move on: earlier reductions are stale
     k_conccalc<R><<<nb, kBlock, 0, stream>>>(V, Gp, P, numpart, itime, (R)weight);
     HIPCHK(hipGetLastError());
     return 0;
   }
+  // sum over the ranks of `send` into `recv` (device pointers, distinct buffers), on the handle's stream
+  template <typename T>
+  int reduce_into(const T *send, T **recv, size_t n, const char *who) {
+    if (!comm && !host_allreduce) return fail(FPX_ERR_STATE, std::string(who) + ": allreduce requested without fpx_comm_init / fpx_comm_init_host");
+    int rc;
+    if (!*recv && (rc = dalloc(recv, n))) return rc;
+    if (comm) {
+      ncclResult_t r = ncclAllReduce(send, *recv, n, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream);
+      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+      return 0;
+    }
+    const size_t bytes = n * sizeof(T);
+    if (2 * bytes > red_pin_bytes) {
+      if (red_pin) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipHostFree(red_pin)); red_pin = nullptr; red_pin_bytes = 0; }
+      HIPCHK(hipHostMalloc(&red_pin, 2 * bytes));
+      red_pin_bytes = 2 * bytes;
+    }
+    HIPCHK(hipMemcpyAsync(red_pin, send, bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    if (host_allreduce(host_allreduce_user, red_pin, (char *)red_pin + bytes, (int64_t)n, sizeof(T) == 8 ? 1 : 0) != 0)
+      return fail(FPX_ERR_DEVICE, std::string(who) + ": the host's all-reduce callback failed");
+    HIPCHK(hipMemcpyAsync(*recv, (char *)red_pin + bytes, bytes, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));    // the bounce buffer is reused by the next grid
+    return 0;
+  }
+  int comm_init_host(int nranks, int rank, fpx_allreduce_fn fn, void *user) override {
+    if (nranks < 1 || rank < 0 || rank >= nranks || !fn) return fail(FPX_ERR_ARG, "comm_init_host: bad argument");
+    if (comm || host_allreduce) return fail(FPX_ERR_STATE, "comm_init_host: communicator exists");
+    host_allreduce = fn; host_allreduce_user = user;
+    comm_ranks = nranks;
+    return 0;
+  }
   int comm_init(const void *id, int nbytes, int nranks, int rank) override {
     if (!id || nbytes != (int)sizeof(ncclUniqueId) || nranks < 1 || rank < 0 || rank >= nranks) return fail(FPX_ERR_ARG, "comm_init: bad argument");
-    if (comm) return fail(FPX_ERR_STATE, "comm_init: communicator exists");
+    if (comm || host_allreduce) return fail(FPX_ERR_STATE, "comm_init: communicator exists");
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
     HIPCHK(hipSetDevice(cfg.device));
@@ -2489,31 +2598,22 @@ struct Engine : EngineBase {
   }
   int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) override {
     if (!Gp.on) return fail(FPX_ERR_STATE, "get_grids: fpx_outgrid_init first");
+    const R *g3 = Gp.gridunc;
+    const float *gd = Gp.drygridunc;
     if (allreduce && comm_ranks > 1) {
-      if (!comm) return fail(FPX_ERR_STATE, "get_grids: allreduce requested without fpx_comm_init");
-      // the one collective of the path (mpi_mod.f90:2471-2492): sum of the sampling grids
-      ncclResult_t r = ncclAllReduce(Gp.gridunc, Gp.gridunc, n_grid3, sizeof(R) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream);
-      if (r == ncclSuccess) r = ncclAllReduce(Gp.drygridunc, Gp.drygridunc, n_grid2, ncclFloat, ncclSum, comm, stream);
-      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+      // the one collective of the path (mpi_mod.f90:2471-2492): the sums land in gridunc0 / drygridunc0, the
+      // partial sums stay where they are -- drygridunc keeps accumulating and is reduced again at the next output
+      int rc;
+      if ((rc = reduce_into(Gp.gridunc, &gridunc0, n_grid3, "get_grids")) || (rc = reduce_into(Gp.drygridunc, &drygridunc0, n_grid2, "get_grids"))) return rc;
+      red_valid[RG_GRID] = red_valid[RG_DRY] = true;
+      g3 = gridunc0; gd = drygridunc0;
     }
-    if (gridunc) {
-      if ((size_t)cfg.host_real_bytes == sizeof(R)) {
-        HIPCHK(hipMemcpyAsync(gridunc, Gp.gridunc, n_grid3 * sizeof(R), hipMemcpyDeviceToHost, stream));
-      } else {
-        int rc = ensure_staging(n_grid3 * cfg.host_real_bytes);
-        if (rc) return rc;
-        const int nb = (int)((n_grid3 + kBlock - 1) / kBlock);
-        k_convert<R><<<nb, kBlock, 0, stream>>>(Gp.gridunc, cfg.host_real_bytes == 8 ? (double *)staging : nullptr,
-                                                cfg.host_real_bytes == 4 ? (float *)staging : nullptr, (long long)n_grid3);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(gridunc, staging, n_grid3 * cfg.host_real_bytes, hipMemcpyDeviceToHost, stream));
-      }
-    }
-    if (drygridunc) HIPCHK(hipMemcpyAsync(drygridunc, Gp.drygridunc, n_grid2 * sizeof(float), hipMemcpyDeviceToHost, stream));
-    if (clear) {
-      HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
-      HIPCHK(hipMemsetAsync(Gp.drygridunc, 0, n_grid2 * sizeof(float), stream));
-    }
+    int rc = download_real(gridunc, g3, n_grid3);
+    if (rc) return rc;
+    if (drygridunc) HIPCHK(hipMemcpyAsync(drygridunc, gd, n_grid2 * sizeof(float), hipMemcpyDeviceToHost, stream));
+    // concoutput.f90:719-720 zeroes gridunc (and creceptor: fpx_get_receptors) only; the deposition grids are
+    // cumulative over the run (zeroed once, outgrid_init.f90:317-318)
+    if (clear) HIPCHK(hipMemsetAsync(Gp.gridunc, 0, n_grid3 * sizeof(R), stream));
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
@@ -2693,19 +2793,21 @@ struct Engine : EngineBase {
     if (!height_set || !window_set) return fail(FPX_ERR_STATE, "wetdepo: height / wind-time window not set");
     if (numpart == 0) return 0;
     const int nb = (int)((numpart + kBlock - 1) / kBlock);
+    red_valid[RG_WET] = red_valid[RG_WETN] = false;
     k_wetdepo<R><<<nb, kBlock, 0, stream>>>(V, Gp, Wp, P, numpart, itime, ltsample, loutnext);
     HIPCHK(hipGetLastError());
     return 0;
   }
-  int get_wetgrid(void *wetgridunc, int allreduce, int clear) override {
+  int get_wetgrid(void *wetgridunc, int allreduce) override {
     if (!Gp.on) return fail(FPX_ERR_STATE, "get_wetgrid: fpx_outgrid_init first");
+    const float *gw = Gp.wetgridunc;
     if (allreduce && comm_ranks > 1) {
-      if (!comm) return fail(FPX_ERR_STATE, "get_wetgrid: allreduce requested without fpx_comm_init");
-      ncclResult_t r = ncclAllReduce(Gp.wetgridunc, Gp.wetgridunc, n_grid2, ncclFloat, ncclSum, comm, stream);
-      if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+      int rc = reduce_into(Gp.wetgridunc, &wetgridunc0, n_grid2, "get_wetgrid");   // mpi_mod.f90:2486-2488, into wetgridunc0
+      if (rc) return rc;
+      red_valid[RG_WET] = true;
+      gw = wetgridunc0;
     }
-    if (wetgridunc) HIPCHK(hipMemcpyAsync(wetgridunc, Gp.wetgridunc, n_grid2 * sizeof(float), hipMemcpyDeviceToHost, stream));
-    if (clear) HIPCHK(hipMemsetAsync(Gp.wetgridunc, 0, n_grid2 * sizeof(float), stream));
+    if (wetgridunc) HIPCHK(hipMemcpyAsync(wetgridunc, gw, n_grid2 * sizeof(float), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
   }
@@ -2727,7 +2829,7 @@ struct fpx_engine {
 
 extern "C" {
 
-int fpx_abi_version(void) { return 1; }
+int fpx_abi_version(void) { return 2; }
 
 int fpx_polar_maps(int32_t host_real_bytes, double dy, double north[9], double south[9]) {
   if (!north || !south || !(dy > 0)) return fpx::fail(FPX_ERR_ARG, "fpx_polar_maps: bad argument");
@@ -2802,6 +2904,7 @@ int fpx_rng_get_table(fpx_handle h, void *t, int32_t n) { FPX_GUARD(h); return h
 int fpx_upload_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p) { FPX_GUARD(h); return h->impl->upload_particles(first, count, p); }
 int fpx_download_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p) { FPX_GUARD(h); return h->impl->download_particles(first, count, p); }
 int fpx_set_numpart(fpx_handle h, int64_t n) { FPX_GUARD(h); return h->impl->set_numpart(n); }
+int fpx_set_release_points(fpx_handle h, int32_t numpoint, const void *xmass, const int32_t *npart) { FPX_GUARD(h); return h->impl->set_release_points(numpoint, xmass, npart); }
 int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *st) { FPX_GUARD(h); return h->impl->step(itime, st, false); }
 int fpx_step_async(fpx_handle h, int32_t itime) { FPX_GUARD(h); return h->impl->step(itime, nullptr, true); }
 int fpx_sync(fpx_handle h) { FPX_GUARD(h); return h->impl->sync(); }
@@ -2839,12 +2942,13 @@ int fpx_comm_unique_id(void *id, int32_t nbytes) {
   return FPX_OK;
 }
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
+int fpx_comm_init_host(fpx_handle h, int32_t nranks, int32_t rank, fpx_allreduce_fn fn, void *user) { FPX_GUARD(h); return h->impl->comm_init_host(nranks, rank, fn, user); }
 int fpx_nests_init(fpx_handle h, const fpx_nests *n) { FPX_GUARD(h); return h->impl->nests_init(n); }
 int fpx_upload_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_fields *f) { FPX_GUARD(h); return h->impl->upload_nest_fields(nest, slot, f); }
 int fpx_wet_init(fpx_handle h, const fpx_wet_config *w) { FPX_GUARD(h); return h->impl->wet_init(w); }
 int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f) { FPX_GUARD(h); return h->impl->upload_wet_fields(slot, f); }
 int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext) { FPX_GUARD(h); return h->impl->wetdepo(itime, ltsample, loutnext); }
-int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_wetgrid(wetgridunc, allreduce, clear); }
+int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce) { FPX_GUARD(h); return h->impl->get_wetgrid(wetgridunc, allreduce); }
 void *fpx_stream(fpx_handle h) { return (h && h->impl) ? h->impl->stream_ptr() : nullptr; }
 int fpx_upload_wet_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_wet_fields *f, int32_t readclouds_nest) { FPX_GUARD(h); return h->impl->upload_wet_nest_fields(nest, slot, f, readclouds_nest); }
 int fpx_outgrid_nest_init(fpx_handle h, const fpx_outgrid_nest *g) { FPX_GUARD(h); return h->impl->outgrid_nest_init(g); }

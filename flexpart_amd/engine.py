@@ -26,10 +26,20 @@ def _vp(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+def release_tables(sc):
+    """(xmass [nspec][numpoint], npart [numpoint]) of a scenario: keys numpoint, xmass, npart_rel; the default is
+    the single release point of unit mass holding every particle."""
+    nspec = int(sc["nspec"])
+    numpoint = int(sc.get("numpoint", 1))
+    xm = np.asarray(sc.get("xmass", np.ones(nspec * numpoint)), dtype=np.float64).reshape(nspec, numpoint)
+    npt = np.asarray(sc.get("npart_rel", np.full(numpoint, max(int(sc.get("npart", 0)), 1))), dtype=np.int32).ravel()
+    return xm, npt
+
+
 class Engine:
     def __init__(self, sc, *, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ,
                  seed=0x5EED, max_particles=None, device=0, pad=(0, 0, 0), sort_interval=0,
-                 polemaps=None):
+                 polemaps=None, particle_base=0):
         """sc: scenario dict (flexpart_amd.synthetic).  pad: extra allocated (nxmax-nx,
         nymax-ny, nzmax-nz) to exercise the reference's padded-array convention."""
         self.lib = _lib.load()
@@ -79,8 +89,7 @@ class Engine:
             cfg.density[i] = float(sc["density"][i]); cfg.dquer[i] = float(sc["dquer"][i])
             cfg.vsetaver[i] = float(sc["vsetaver"][i]); cfg.cunningham[i] = float(sc["cunningham"][i])
             cfg.decay[i] = float(sc["decay"][i])
-            cfg.xmass_release[i] = float(np.asarray(sc.get("xmass", np.ones(nspec))).ravel()[i])
-        cfg.npart_release = max(n, 1)
+        cfg.mquasilag = int(sc.get("mquasilag", 0))
         cfg.lage_last = int(np.asarray(sc["lage"]).ravel()[-1])
         cfg.rng_mode = rng_mode
         cfg.seed = seed
@@ -88,6 +97,7 @@ class Engine:
         # eps = nxmax/3.e5 uses the par_mod nxmax of the host build (advance.f90:107); scenarios carry
         # it so that runs compare with the reference binary they were pinned against (361 or 721)
         cfg.par_nxmax = int(sc.get("par_nxmax", 361))
+        cfg.particle_base = int(particle_base or sc.get("particle_base", 0))
         self.cfg = cfg
         self.h = C.c_void_p()
         check(self.lib.fpx_create(C.byref(self.h), C.byref(cfg)), "fpx_create")
@@ -97,6 +107,7 @@ class Engine:
         self.itime = int(sc.get("itime0", 0))
         self.lsynctime = int(sc["lsynctime"])
         self.n = 0
+        self.set_release_points(*release_tables(sc))
         if rng_mode != RNG_PHILOX:
             check(self.lib.fpx_rng_fill_table(self.h), "fpx_rng_fill_table")
         if "uu" in sc:
@@ -272,7 +283,7 @@ class Engine:
         return int(n.value), int(npc.value), int(it.value)
 
     def concoutput(self, itime, prefix, area, volume, outnum, wetdep=False, drydep=False, clear=False, nest=False,
-                   iout=1, prefix_pptv=None, outheight=None, outlon0=0.0, outlat0=0.0, weightmolar=()):
+                   iout=1, prefix_pptv=None, outheight=None, outlon0=0.0, outlat0=0.0, weightmolar=(), reduced=False):
         """fpx_concoutput: writes <prefix><nnn> (the reference's grid_conc_* files) for every species."""
         from ._lib import FpxConcout
         a = np.ascontiguousarray(np.asarray(area, dtype=np.float32))
@@ -284,6 +295,7 @@ class Engine:
             c.outlon0, c.outlat0 = float(outlon0), float(outlat0)
             for i, w in enumerate(weightmolar):
                 c.weightmolar[i] = float(w)
+        c.reduced = int(reduced)
         check(self.lib.fpx_concoutput(self.h, int(itime), C.byref(c), str(prefix).encode(), int(clear)), "fpx_concoutput")
 
     def upload_nests_from_scenario(self, sc):
@@ -327,6 +339,15 @@ class Engine:
                 keep["vdep"] = np.ascontiguousarray(np.asarray(sc["vdepn"])[m].astype(rt))
                 f.vdep = keep["vdep"].ctypes.data
             check(self.lib.fpx_upload_nest_fields(self.h, 1, m + 1, C.byref(f)), "fpx_upload_nest_fields")
+
+    def set_release_points(self, xmass, npart):
+        """point_mod xmass(numpoint,maxspec) (given as [nspec][numpoint]) and npart(numpoint)."""
+        xm = np.ascontiguousarray(np.asarray(xmass, dtype=np.float64).reshape(self.nspec, -1).astype(self.hreal))
+        npt = np.ascontiguousarray(np.asarray(npart, dtype=np.int32).ravel())
+        assert xm.shape[1] == npt.size
+        check(self.lib.fpx_set_release_points(self.h, int(npt.size), _vp(xm), npt.ctypes.data_as(C.POINTER(C.c_int32))),
+              "fpx_set_release_points")
+        self.numpoint = int(npt.size)
 
     def set_windtime(self, memtime, memind):
         mt = (C.c_int32 * 2)(int(memtime[0]), int(memtime[1]))
@@ -394,8 +415,11 @@ class Engine:
         # xoutshift=xlon0-outlon0 in the host's real kind (readoutgrid.f90:199-200)
         g.xoutshift = float(rt(self.cfg.xlon0) - rt(lon0))
         g.youtshift = float(rt(self.cfg.ylat0) - rt(lat0))
-        g.maxpointspec_act, g.nclassunc = 1, 1
         lage = np.asarray(sc["lage"]).ravel()
+        iofr = int(np.asarray(sc["concflags"]).ravel()[1])
+        mps = int(sc.get("numpoint", 1)) if iofr == 1 else 1      # maxpointspec_act, readreleases.f90 / outgrid_init.f90
+        ncu = int(sc.get("nclassunc", 1))
+        g.maxpointspec_act, g.nclassunc = mps, ncu
         g.nageclass = len(lage)
         for i, v in enumerate(lage):
             g.lage[i] = int(v)
@@ -406,7 +430,7 @@ class Engine:
         if "outtimes" in sc:
             check(self.lib.fpx_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1])),
                   "fpx_set_output_times")
-        self.gshape = (len(lage), 1, 1, self.nspec, nzg, nyg, nxg)
+        self.gshape = (len(lage), ncu, mps, self.nspec, nzg, nyg, nxg)
         if "outgridn" in sc:          # OUTGRID_NEST (readoutgrid_nest.f90)
             nxn, nyn = (int(v) for v in sc["outgridn"])
             dxn, dyn, lon0n, lat0n = (float(v) for v in sc["outgeomn"])
@@ -417,7 +441,7 @@ class Engine:
             gn.xoutshiftn = float(rt(self.cfg.xlon0) - rt(lon0n))
             gn.youtshiftn = float(rt(self.cfg.ylat0) - rt(lat0n))
             check(self.lib.fpx_outgrid_nest_init(self.h, C.byref(gn)), "fpx_outgrid_nest_init")
-            self.gshape_nest = (len(lage), 1, 1, self.nspec, nzg, nyn, nxn)
+            self.gshape_nest = (len(lage), ncu, mps, self.nspec, nzg, nyn, nxn)
         self.nreceptor = 0
         if "receptors" in sc:         # RECEPTORS (readreceptors.f90): x, y in grid coordinates, cell area
             r = np.asarray(sc["receptors"], dtype=np.float64).reshape(3, -1)
@@ -477,10 +501,10 @@ class Engine:
             loutnext = int(self.sc["outtimes"][0]) if "outtimes" in self.sc else 0
         check(self.lib.fpx_wetdepo(self.h, int(itime), int(ltsample), int(loutnext)), "fpx_wetdepo")
 
-    def wetgrid(self, allreduce=False, clear=False):
+    def wetgrid(self, allreduce=False):
         na, nc, mp, nsp, nzg, nyg, nxg = self.gshape
         d = np.empty((na, nc, mp, nsp, nyg, nxg), np.float32)
-        check(self.lib.fpx_get_wetgrid(self.h, _vp(d), int(allreduce), int(clear)), "fpx_get_wetgrid")
+        check(self.lib.fpx_get_wetgrid(self.h, _vp(d), int(allreduce)), "fpx_get_wetgrid")
         return d.astype(np.float64)
 
     def conccalc(self, itime=None, weight=1.0):
@@ -516,6 +540,24 @@ class Engine:
         buf = (C.c_char * 128)()
         check(self.lib.fpx_comm_unique_id(buf, 128), "fpx_comm_unique_id")
         return bytes(buf)
+
+    def comm_init_host(self, dist, nranks, rank):
+        """fpx_comm_init_host with a torch.distributed process group as the transport (what an MPI host does with
+        MPI_Allreduce): the engine hands host buffers to the callback, which sums them over the ranks."""
+        import torch
+
+        def _allreduce(user, send, recv, count, dtype):
+            try:
+                ct = C.c_double if dtype == 1 else C.c_float
+                a = np.ctypeslib.as_array(C.cast(send, C.POINTER(ct)), shape=(count,))
+                t = torch.from_numpy(np.array(a, copy=True))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                np.ctypeslib.as_array(C.cast(recv, C.POINTER(ct)), shape=(count,))[:] = t.numpy()
+                return 0
+            except Exception:      # never let an exception cross the C boundary
+                return 1
+        self._allreduce_cb = _lib.ALLREDUCE_FN(_allreduce)      # keep the thunk alive as long as the engine
+        check(self.lib.fpx_comm_init_host(self.h, int(nranks), int(rank), self._allreduce_cb, None), "fpx_comm_init_host")
 
     def comm_init(self, uid, nranks, rank):
         buf = (C.c_char * 128).from_buffer_copy(uid)

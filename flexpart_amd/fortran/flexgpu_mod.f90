@@ -30,7 +30,7 @@ module flexgpu_mod
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
-            flexgpu_concoutput, flexgpu_abi_sizes
+            flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -53,14 +53,14 @@ module flexgpu_mod
     integer(c_int32_t) :: drydep, drydepspec(FPX_MAXSPEC)
     real(c_double) :: density(FPX_MAXSPEC), dquer(FPX_MAXSPEC), vsetaver(FPX_MAXSPEC), cunningham(FPX_MAXSPEC)
     real(c_double) :: decay(FPX_MAXSPEC)
-    real(c_double) :: xmass_release(FPX_MAXSPEC)
-    integer(c_int32_t) :: npart_release
+    integer(c_int32_t) :: mquasilag
     integer(c_int32_t) :: lage_last
     integer(c_int32_t) :: rng_mode
     integer(c_int64_t) :: seed
     integer(c_int32_t) :: sort_interval
     integer(c_int32_t) :: par_nxmax
-    integer(c_int32_t) :: reserved(6)
+    integer(c_int64_t) :: particle_base
+    integer(c_int32_t) :: reserved(4)
   end type fpx_config
 
   type, bind(C) :: fpx_fields
@@ -97,6 +97,7 @@ module flexgpu_mod
     type(c_ptr) :: prefix_pptv, outheight
     real(c_double) :: outlon0, outlat0
     real(c_double) :: weightmolar(FPX_MAXSPEC)
+    integer(c_int32_t) :: reduced, reserved
   end type fpx_concout
 
   integer, parameter :: FPX_MAXNESTS = 4
@@ -131,6 +132,11 @@ module flexgpu_mod
     integer(c_int) function fpx_destroy(h) bind(C, name='fpx_destroy')
       import :: c_ptr, c_int
       type(c_ptr), value :: h
+    end function
+    integer(c_int) function fpx_set_release_points(h, numpoint, xmass, npart) bind(C, name='fpx_set_release_points')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, xmass, npart
+      integer(c_int32_t), value :: numpoint
     end function
     type(c_ptr) function fpx_last_error() bind(C, name='fpx_last_error')
       import :: c_ptr
@@ -297,10 +303,16 @@ module flexgpu_mod
       type(c_ptr), value :: h, g, d
       integer(c_int32_t), value :: allreduce, clear
     end function
-    integer(c_int) function fpx_get_wetgrid(h, w, allreduce, clear) bind(C, name='fpx_get_wetgrid')
+    integer(c_int) function fpx_comm_init_host(h, nranks, rank, fn, user) bind(C, name='fpx_comm_init_host')
+      import :: c_ptr, c_funptr, c_int, c_int32_t
+      type(c_ptr), value :: h, user
+      type(c_funptr), value :: fn
+      integer(c_int32_t), value :: nranks, rank
+    end function
+    integer(c_int) function fpx_get_wetgrid(h, w, allreduce) bind(C, name='fpx_get_wetgrid')
       import :: c_ptr, c_int, c_int32_t
       type(c_ptr), value :: h, w
-      integer(c_int32_t), value :: allreduce, clear
+      integer(c_int32_t), value :: allreduce
     end function
     integer(c_int) function fpx_get_grids_nest(h, g, d, w, allreduce, clear) bind(C, name='fpx_get_grids_nest')
       import :: c_ptr, c_int, c_int32_t
@@ -399,11 +411,13 @@ contains
 
   ! com_mod/par_mod -> fpx_config; creates the engine on `device` for `nmaxpart` particles.
   ! defer_height: the z levels do not exist yet -- the first flexgpu_verttransform derives them
-  subroutine flexgpu_init(ierr, device, nmaxpart, compute_real_bytes, rng_mode, seed, defer_height)
+  ! particle_base (MPI host): global number of this rank's first particle, so that the counter RNG does not depend on the
+  ! number of ranks
+  subroutine flexgpu_init(ierr, device, nmaxpart, compute_real_bytes, rng_mode, seed, defer_height, particle_base)
     integer, intent(out) :: ierr
     integer, intent(in), optional :: device, nmaxpart, compute_real_bytes, rng_mode
     logical, intent(in), optional :: defer_height
-    integer(c_int64_t), intent(in), optional :: seed
+    integer(c_int64_t), intent(in), optional :: seed, particle_base
     type(fpx_config) :: cfg
     integer :: ks
     cfg%struct_bytes = int(c_sizeof(cfg), c_int32_t)
@@ -425,22 +439,28 @@ contains
     cfg%nspec = nspec; cfg%maxspec = maxspec
     cfg%drydep = merge(1, 0, DRYDEP)
     cfg%drydepspec = 0; cfg%density = 0; cfg%dquer = 0; cfg%vsetaver = 0; cfg%cunningham = 1
-    cfg%decay = 0; cfg%xmass_release = 1
+    cfg%decay = 0
     do ks = 1, nspec
       cfg%drydepspec(ks) = merge(1, 0, DRYDEPSPEC(ks))
       cfg%density(ks) = density(ks); cfg%dquer(ks) = dquer(ks); cfg%vsetaver(ks) = vsetaver(ks)
       cfg%cunningham(ks) = cunningham(ks); cfg%decay(ks) = decay(ks)
-      cfg%xmass_release(ks) = xmass(1, ks)
     end do
-    cfg%npart_release = npart(1)
+    cfg%mquasilag = mquasilag
     cfg%lage_last = lage(nageclass)
     cfg%rng_mode = 0; if (present(rng_mode)) cfg%rng_mode = rng_mode
     cfg%seed = 24301_c_int64_t; if (present(seed)) cfg%seed = seed
     cfg%sort_interval = 8
     cfg%par_nxmax = nxmax          ! eps = nxmax/3.e5, advance.f90:107
+    cfg%particle_base = 0; if (present(particle_base)) cfg%particle_base = particle_base
     cfg%reserved = 0
     ierr = fpx_create(flexgpu_handle, cfg)
     if (ierr /= 0) return
+    ! point_mod xmass(numpoint,maxspec), npart(numpoint): indexed by npoint(j) in the particle loop
+    ! (timemanager.f90:663-666, advance.f90:518-531)
+    if (allocated(xmass) .and. allocated(npart)) then
+      ierr = fpx_set_release_points(flexgpu_handle, int(size(npart), c_int32_t), loc_r(xmass), loc_i(npart))
+      if (ierr /= 0) return
+    end if
     if (present(defer_height)) then
       if (defer_height) return
     end if
@@ -570,10 +590,13 @@ contains
   ! Writes the grid_conc_<date><time>_<species> files of `call concoutput(itime,outnum,...)` (timemanager.f90:384;
   ! forward runs, iout = 1 or 3 or 5) from the device's sampling grids and zeroes gridunc as the routine does.
   ! dates, grid_pptv_*, factor_drygrid and the receptor files remain with the host.  4-byte default real only.
-  subroutine flexgpu_concoutput(itime, outnum, ierr)
+  ! reduced = .true. (MPI host, after flexgpu_get_grids(clear, ierr, allreduce=.true.)): the files hold the sums over all
+  ! ranks, as concoutput_mpi.f90 writes them from gridunc0 / drygridunc0 / wetgridunc0 on the root process.
+  subroutine flexgpu_concoutput(itime, outnum, ierr, reduced)
     integer, intent(in) :: itime
     real, intent(in) :: outnum
     integer, intent(out) :: ierr
+    logical, intent(in), optional :: reduced
     type(fpx_concout) :: c
     real(kind=dp) :: jul
     integer :: jjjjmmdd, ihmmss
@@ -588,6 +611,8 @@ contains
     c%outnum = outnum
     c%wetdep = merge(1, 0, WETDEP); c%drydep = merge(1, 0, DRYDEP); c%nest = 0; c%iout = 1
     c%prefix_pptv = c_null_ptr; c%outheight = c_null_ptr; c%outlon0 = 0; c%outlat0 = 0; c%weightmolar = 1   ! grid_pptv_*: through the C ABI
+    c%reduced = 0; c%reserved = 0
+    if (present(reduced)) c%reduced = merge(1, 0, reduced)
     ierr = fpx_concoutput(flexgpu_handle, int(itime, c_int32_t), c, trim(prefix) // c_null_char, 1_c_int32_t)
   end subroutine flexgpu_concoutput
 
@@ -788,25 +813,46 @@ contains
     ierr = fpx_conccalc(flexgpu_handle, int(itime, c_int32_t), real(weight, c_double))
   end subroutine flexgpu_conccalc
 
-  ! before concoutput: the accumulated sums overwrite the host's gridunc, drygridunc, wetgridunc
-  ! (+ the nested grids and creceptor); clear = 1 zeroes the device copies as concoutput zeroes the host's
-  subroutine flexgpu_get_grids(clear, ierr)
+  ! Before the host's own concoutput: the device's sums overwrite the host's gridunc, drygridunc, wetgridunc
+  ! (+ the nested grids and creceptor).  clear = 1 zeroes the device's gridunc / griduncn / creceptor, as
+  ! concoutput.f90:719-720 zeroes the host's after writing; the deposition grids keep accumulating on the device
+  ! exactly as drygridunc / wetgridunc do on the host (zeroed once, outgrid_init.f90:317-318), so every call hands
+  ! the host the cumulative values its concoutput expects.  allreduce = .true. (several ranks, after
+  ! flexgpu_comm_init_host or fpx_comm_init): the arrays receive the sums over all ranks (what
+  ! mpif_tm_reduce_grid leaves in gridunc0 ... on the root, mpi_mod.f90:2451-2492); the ranks' partial sums stay
+  ! on the device.
+  subroutine flexgpu_get_grids(clear, ierr, allreduce)
     integer, intent(in) :: clear
     integer, intent(out) :: ierr
-    ierr = fpx_get_grids(flexgpu_handle, loc_r(gridunc), loc_dep(drygridunc), 0_c_int32_t, int(clear, c_int32_t))
+    logical, intent(in), optional :: allreduce
+    integer(c_int32_t) :: ar
+    ar = 0
+    if (present(allreduce)) ar = merge(1, 0, allreduce)
+    ierr = fpx_get_grids(flexgpu_handle, loc_r(gridunc), loc_dep(drygridunc), ar, int(clear, c_int32_t))
     if (ierr /= 0) return
-    ierr = fpx_get_wetgrid(flexgpu_handle, loc_dep(wetgridunc), 0_c_int32_t, int(clear, c_int32_t))
+    ierr = fpx_get_wetgrid(flexgpu_handle, loc_dep(wetgridunc), ar)
     if (ierr /= 0) return
     if (nested_output .eq. 1) then
       ierr = fpx_get_grids_nest(flexgpu_handle, loc_r(griduncn), loc_dep(drygriduncn), loc_dep(wetgriduncn), &
-                                0_c_int32_t, int(clear, c_int32_t))
+                                ar, int(clear, c_int32_t))
       if (ierr /= 0) return
     end if
     if (numreceptor .gt. 0) then
-      ierr = fpx_get_receptors(flexgpu_handle, loc_r(creceptor), int(maxreceptor, c_int32_t), 0_c_int32_t, &
+      ierr = fpx_get_receptors(flexgpu_handle, loc_r(creceptor), int(maxreceptor, c_int32_t), ar, &
                                int(clear, c_int32_t))
     end if
   end subroutine flexgpu_get_grids
+
+  ! The grid reduction over the ranks of an MPI host through the host's own all-reduce (the transport
+  ! mpi_mod.f90:2471-2492 uses): fn = c_funloc of a bind(C) function
+  !   integer(c_int) function f(user, send, recv, count, dtype)   ! dtype 0: 4-byte reals, 1: 8-byte reals
+  ! that calls MPI_Allreduce(send, recv, count, MPI_REAL4|MPI_REAL8, MPI_SUM, comm) and returns 0.
+  subroutine flexgpu_comm_init_host(nranks, rank, fn, ierr)
+    integer, intent(in) :: nranks, rank
+    type(c_funptr), intent(in) :: fn
+    integer, intent(out) :: ierr
+    ierr = fpx_comm_init_host(flexgpu_handle, int(nranks, c_int32_t), int(rank, c_int32_t), fn, c_null_ptr)
+  end subroutine flexgpu_comm_init_host
 
   ! ---- wet deposition: species parameters of readspecies.f90, fields of readwind/verttransform ----
   subroutine flexgpu_wet_init(ierr)

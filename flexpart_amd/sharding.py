@@ -30,6 +30,11 @@ def shard_scenario(sc: dict, world: int, rank: int) -> dict:
             out[k] = np.asarray(sc[k])[lo:hi]
     if "xmass1" in sc:
         out["xmass1"] = np.asarray(sc["xmass1"]).reshape(int(sc["nspec"]), n)[:, lo:hi]
+    # the release-point tables describe the whole run (npart(kp) = particles of point kp on ALL ranks): the
+    # mass-fraction termination must not depend on the number of ranks
+    if "npart_rel" not in sc:
+        out["npart_rel"] = np.full(int(sc.get("numpoint", 1)), max(n, 1), np.int32)
+    out["particle_base"] = lo
     return out
 
 
@@ -38,6 +43,14 @@ def share_unique_id(dist, make_id, src: int = 0) -> bytes:
     obj = [make_id() if dist.get_rank() == src else None]
     dist.broadcast_object_list(obj, src=src)
     return obj[0]
+
+
+def reduce_output_grids(dist, partial: dict) -> dict:
+    """The grid reduction at an output time for a host that keeps the per-rank grids in host arrays (the protocol
+    of `mpi_mod.f90:2451-2492` / `fpx_get_grids(allreduce=1)`): every array of `partial` is summed over the ranks
+    into a NEW array -- the partial sums are left untouched, because the deposition grids keep accumulating and are
+    reduced again at the next output time; only gridunc (and creceptor) are zeroed by the caller after writing."""
+    return {k: allreduce_sum_numpy(dist, v) for k, v in partial.items()}
 
 
 def allreduce_sum_numpy(dist, a: np.ndarray) -> np.ndarray:

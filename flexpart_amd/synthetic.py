@@ -344,6 +344,47 @@ def add_outgrid(sc, nxg=36, nyg=18, nzg=5, *, outlon0=None, outlat0=None, dxout=
     return sc
 
 
+def add_release_points(sc, xmass, npart_rel, *, ioutputforeachrelease=1, lage=None, max_age=None,
+                       nclassunc=1, tiny_every=0, tiny_factor=5.0e-5, near_every=0, near_factor=1.03e-4):
+    """Several release points (RELEASES with more than one &RELEASE block): point_mod xmass(numpoint,nspec)
+    (given as [nspec][numpoint]) and npart(numpoint); every particle gets a release point npoint(j), the mass
+    xmass(kp,ks)/npart(kp) of its point (readreleases.f90 / releaseparticles.f90:148-155), an uncertainty class
+    nclass(j) in 1..nclassunc and -- with max_age -- a release time up to max_age seconds before the start, so
+    that particles fall into several age classes and some exceed lage(nageclass) (timemanager.f90:701-707).
+    tiny_every / near_every: every k-th particle carries tiny_factor / near_factor of its nominal mass, i.e. lies
+    below / just above minmass = 1e-4 (par_mod.f90:213) of it: terminated at once / after some decay
+    (timemanager.f90:681-686)."""
+    nspec = int(sc["nspec"])
+    xm = np.asarray(xmass, dtype=np.float64).reshape(nspec, -1)
+    numpoint = xm.shape[1]
+    npt = np.asarray(npart_rel, dtype=np.int32).ravel()
+    assert npt.size == numpoint
+    n = int(sc["npart"])
+    h = _splitmix64(n, 0xBEEF)
+    kp = (h % np.uint64(numpoint)).astype(np.int64)                  # 0-based release point
+    sc["numpoint"] = numpoint
+    sc["xmass"] = xm
+    sc["npart_rel"] = npt
+    sc["npoint"] = (kp + 1).astype(np.int32)
+    m = xm[:, kp] / npt[kp].astype(np.float64)[None, :]
+    idx = np.arange(n)
+    if tiny_every:
+        m[:, idx % tiny_every == 1] *= tiny_factor
+    if near_every:
+        m[:, idx % near_every == 2] *= near_factor
+    sc["xmass1"] = m
+    sc["nclassunc"] = int(nclassunc)
+    sc["nclass"] = (1 + ((h >> np.uint64(20)) % np.uint64(nclassunc)).astype(np.int64)).astype(np.int32)
+    if lage is not None:
+        sc["lage"] = np.asarray(lage, np.int32)
+    if max_age:
+        age = ((h >> np.uint64(32)) % np.uint64(int(max_age))).astype(np.int64)
+        sc["itramem"] = (int(sc["itime0"]) - age * int(sc["ldirect"])).astype(np.int32)
+    if "concflags" in sc:
+        sc["concflags"] = np.array([int(sc["concflags"][0]), int(ioutputforeachrelease)], np.int32)
+    return sc
+
+
 def add_outgrid_nest(sc, nxn=30, nyn=20):
     """Nested output grid (OUTGRID_NEST, readoutgrid_nest.f90): finer cells over the middle of the
     mother output grid, so that particles fall inside, on its border and outside of it."""

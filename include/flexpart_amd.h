@@ -80,13 +80,12 @@ typedef struct {
   int32_t ldirect, lsynctime, method, mintime, ifine, turbswitch, cblflag, mdomainfill, lsettling;
   double ctl;                /* com_mod ctl, i.e. already 1/CTL                         */
   double d_trop, d_strat, turbmesoscale;   /* par_mod.f90:79                           */
-  /* species: com_mod.f90:170-189,589 ; point_mod xmass(1,:), npart(1) */
+  /* species: com_mod.f90:170-189,589 (the release-point tables xmass, npart: fpx_set_release_points) */
   int32_t nspec, maxspec;    /* maxspec = species stride count of host xmass1           */
   int32_t drydep, drydepspec[FPX_MAXSPEC];
   double density[FPX_MAXSPEC], dquer[FPX_MAXSPEC], vsetaver[FPX_MAXSPEC], cunningham[FPX_MAXSPEC];
   double decay[FPX_MAXSPEC];
-  double xmass_release[FPX_MAXSPEC];
-  int32_t npart_release;
+  int32_t mquasilag;         /* com_mod.f90:74,101: /= 0 skips the mass-fraction test, timemanager.f90:663 */
   int32_t lage_last;         /* lage(nageclass), com_mod.f90:129                        */
   /* RNG */
   int32_t rng_mode;          /* fpx_rng_mode                                            */
@@ -95,7 +94,12 @@ typedef struct {
   int32_t sort_interval;
   /* par_mod nxmax of the HOST build, used for eps = nxmax/3.e5 (advance.f90:107); 0: use nxmax */
   int32_t par_nxmax;
-  int32_t reserved[6];
+  /* Several ranks (one handle per GPU, each holding a contiguous range of the run's particles, mpi_mod.f90:323):
+   * number of this rank's first particle in the run's global numbering (0 on a single rank).  The counter RNG modes
+   * key on the global number, and fpx_seed_particles generates that slice of the global synthetic cloud, so results
+   * do not depend on how many ranks share the particles.  Particle indices at the boundary (first, count) stay local. */
+  int64_t particle_base;
+  int32_t reserved[4];
 } fpx_config;
 
 /* One time slot of the met fields the path gathers from (com_mod.f90:355-371,
@@ -240,8 +244,10 @@ int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
  * filled; only the compressed indices and values travel to the host, which writes the records.
  * Byte-identical to the reference's file for the same grids.  Hosts with a 4-byte default real only (the
  * reference's concoutput.f90 does not compile with -fdefault-real-8).  Not written: dates,
- * factor_drygrid, the receptor files (host side, from fpx_get_receptors).  For the sum over ranks call
- * fpx_get_grids(h, NULL, NULL, 1, 0) / fpx_get_wetgrid(h, NULL, 1, 0) first.
+ * factor_drygrid, the receptor files (host side, from fpx_get_receptors).  For the sums over all ranks call
+ * fpx_get_grids(h, NULL, NULL, 1, 0) / fpx_get_wetgrid(h, NULL, 1) (/ fpx_get_grids_nest) first and set
+ * fpx_concout.reduced = 1: the files are then written from the receive buffers of those reductions
+ * (concoutput_mpi.f90:279,298 reads gridunc0, drygridunc0, wetgridunc0), on the rank(s) that call this.
  * prefix: the file name without the species number, e.g. "<path>grid_conc_20200101010000_".
  * clear = 1 zeroes gridunc afterwards as the routine does (:714). */
 typedef struct {
@@ -259,6 +265,8 @@ typedef struct {
   const void *outheight;
   double outlon0, outlat0;
   double weightmolar[FPX_MAXSPEC];
+  int32_t reduced;       /* 1: write the sums over all ranks left by the preceding allreduce calls (see above); 0: this rank's own grids */
+  int32_t reserved;
 } fpx_concout;
 int fpx_concoutput(fpx_handle h, int32_t itime, const fpx_concout *c, const char *prefix, int32_t clear);
 /* memtime(1:2), memind(1:2) of com_mod.f90:286; lwindinterv = |memtime(2)-memtime(1)|. */
@@ -296,6 +304,16 @@ int fpx_rng_get_table(fpx_handle h, void *rannumb, int32_t maxrand);
 int fpx_upload_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p);
 int fpx_download_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p);
 int fpx_set_numpart(fpx_handle h, int64_t numpart);   /* com_mod numpart */
+/* The release-point tables of point_mod (point_mod.f90:10,20; allocated and filled by readreleases.f90:239-243,419-421,450-455):
+ * xmass(numpoint, maxspec) in the host's real kind (column-major: species stride = numpoint) and
+ * npart(numpoint).  The particle loop indexes both by the particle's release point npoint(j):
+ * the mass-fraction termination real(npart(npoint(j)))*xmass1(j,ks)/xmass(npoint(j),ks) < minmass
+ * (timemanager.f90:663-666,681-686) and the species whose settling velocity a particle takes,
+ * the first with xmass(nrelpoint,nsp) > eps3 (advance.f90:518-531,686-699,893-906).  Required before
+ * fpx_step unless mdomainfill /= 0 or mquasilag /= 0 (then only the settling pick reads it; without
+ * the tables every particle takes species 1).  A particle whose npoint lies outside 1..numpoint
+ * (the reference would read outside the arrays) is treated as a particle of the nearest point. */
+int fpx_set_release_points(fpx_handle h, int32_t numpoint, const void *xmass, const int32_t *npart);
 
 /* ---- the hot path --------------------------------------------------------- */
 /* One pass of the particle loop timemanager.f90:531-712 at time itime. */
@@ -348,15 +366,27 @@ int fpx_set_output_times(fpx_handle h, int32_t loutnext, int32_t loutstep);
  * itra1 == itime into the device gridunc.  Dry-deposited mass is accumulated into drygridunc by
  * fpx_step itself (drydepokernel.f90:41-116, called at timemanager.f90:690-696). */
 int fpx_conccalc(fpx_handle h, int32_t itime, double weight);
-/* Copy the grids to the host (gridunc: host_real_bytes per value, drygridunc: 4 bytes; either
- * may be NULL).  allreduce != 0: sum over all ranks of the communicator first (the
- * MPI_Reduce of mpi_mod.f90:2471-2492, as one RCCL all-reduce over xGMI).  clear != 0: zero the
- * device grids afterwards (concoutput does this after writing, concoutput.f90). */
+/* Copy the grids to the host (gridunc: host_real_bytes per value, drygridunc: 4 bytes; either may be NULL).
+ * allreduce != 0: the sum over all ranks of the communicator (the MPI_Reduce of mpi_mod.f90:2471-2492, as one
+ * RCCL all-reduce over xGMI per grid, or through the host's own all-reduce: fpx_comm_init_host).  Like the reference
+ * (gridunc0, drygridunc0, wetgridunc0: mpi_mod.f90:2484-2492, outgrid_init.f90:220-225) the engine reduces into
+ * receive buffers of its own and copies out from those: every rank's partial sums stay untouched, because
+ * drygridunc and wetgridunc accumulate over the whole run and are reduced again at the next output time.
+ * clear != 0: zero the rank's gridunc afterwards, as concoutput does after writing (concoutput.f90:719-720: gridunc
+ * and creceptor only -- the deposition grids are zeroed once, outgrid_init.f90:317-318, and never again). */
 int fpx_get_grids(fpx_handle h, void *gridunc, void *drygridunc, int32_t allreduce, int32_t clear);
-/* RCCL communicator for the grid reduction: rank 0 obtains an id (128 bytes), the host
- * distributes it (MPI_Bcast / torch.distributed / a file), every rank calls fpx_comm_init. */
+/* Communicator for the grid reduction, one of:
+ * (a) RCCL: rank 0 obtains an id (128 bytes), the host distributes it (MPI_Bcast / torch.distributed / a file), every
+ *     rank calls fpx_comm_init; the reduction then runs device to device on the handle's stream. */
 int fpx_comm_unique_id(void *id, int32_t nbytes);
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank);
+/* (b) the host's own all-reduce, e.g. MPI_Allreduce of the reference's MPI build (the transport mpi_mod.f90:2471-2492
+ *     itself uses; works across nodes): fn(user, send, recv, count, dtype) sums `count` values of send over all ranks
+ *     into recv (host buffers; dtype 0 = 4-byte real, 1 = 8-byte real) and returns 0 on success.  The engine stages
+ *     the grids through pinned host memory.  Called once per grid from inside fpx_get_grids / fpx_get_wetgrid /
+ *     fpx_get_grids_nest / fpx_get_receptors, in the same order on every rank. */
+typedef int (*fpx_allreduce_fn)(void *user, const void *send, void *recv, int64_t count, int32_t dtype);
+int fpx_comm_init_host(fpx_handle h, int32_t nranks, int32_t rank, fpx_allreduce_fn fn, void *user);
 
 /* ---- wet deposition ------------------------------------------------- */
 typedef struct {
@@ -383,8 +413,9 @@ int fpx_upload_wet_fields(fpx_handle h, int32_t slot, const fpx_wet_fields *f);
  * interpol_rain.f90:68-130 and wetdepokernel.f90:38-108: the separate particle loop the time
  * manager runs before getfields (timemanager.f90:164-169). */
 int fpx_wetdepo(fpx_handle h, int32_t itime, int32_t ltsample, int32_t loutnext);
-/* wetgridunc (unc_mod.f90:27, real(dep_prec) = 4 bytes), same conventions as fpx_get_grids */
-int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce, int32_t clear);
+/* wetgridunc (unc_mod.f90:27, real(dep_prec) = 4 bytes), allreduce as fpx_get_grids (into wetgridunc0,
+ * mpi_mod.f90:2486-2488).  Never cleared: it accumulates over the run. */
+int fpx_get_wetgrid(fpx_handle h, void *wetgridunc, int32_t allreduce);
 
 /* Precipitation / cloud / temperature fields of one nested grid and time slot: lsprecn, convprecn, tccn
  * (com_mod.f90:518-520), ctwcn (:503, only with readclouds_nest), ttn (:501), cloudsn integer(1) (:505), passed in the
@@ -407,13 +438,15 @@ typedef struct {
  * (conccalc.f90:300, timemanager.f90:694-696, wetdepo.f90:142). */
 int fpx_outgrid_nest_init(fpx_handle h, const fpx_outgrid_nest *g);
 /* griduncn (host real kind), drygriduncn / wetgriduncn (real(dep_prec) = 4 bytes); any pointer may be NULL.
- * allreduce: sum over the ranks of fpx_comm_init first (mpi_mod.f90:2543-2569). */
+ * allreduce: the sums over the ranks (mpi_mod.f90:2543-2569), through receive buffers as in fpx_get_grids;
+ * clear: zero the rank's griduncn only (concoutput_nest.f90). */
 int fpx_get_grids_nest(fpx_handle h, void *griduncn, void *drygriduncn, void *wetgriduncn, int32_t allreduce, int32_t clear);
 /* Receptor points: xreceptor, yreceptor in grid coordinates and receptorarea (readreceptors.f90:88-92,
  * com_mod.f90:658-659), host real kind.  fpx_conccalc then also accumulates creceptor (conccalc.f90:451-498). */
 int fpx_receptors_init(fpx_handle h, int32_t numreceptor, const void *xreceptor, const void *yreceptor, const void *receptorarea);
 /* creceptor(ld, maxspec) of the host (com_mod.f90:660, ld = maxreceptor): rows 1..numreceptor of columns 1..nspec are
- * overwritten with the accumulated values. */
+ * overwritten with the accumulated values (allreduce: summed over the ranks into creceptor0, mpi_mod.f90:2480-2484;
+ * clear: zero the rank's creceptor, concoutput.f90:720). */
 int fpx_get_receptors(fpx_handle h, void *creceptor, int32_t ld, int32_t allreduce, int32_t clear);
 
 /* raw stream handle (hipStream_t) for callers that enqueue their own work */

@@ -24,6 +24,11 @@ interpol_all_nests interpol_wind_nests interpol_wind_short_nests interpol_missle
 hanna hanna1 hanna_short cbl re_initialize_particle initialize_cbl_vel windalign get_settling dynamic_viscosity \
 conccalc drydepokernel drydepokernel_nest wetdepo get_wetscav interpol_rain interpol_rain_nests wetdepokernel wetdepokernel_nest"
 
+# The class counts maxageclass and nclassunc are compile-time sizes of par_mod ("maximum number of age classes used
+# for output", "number of classes used to calculate the uncertainty", par_mod.f90:187-192), both 1 as shipped -- a
+# user who wants age classes edits that line.  The 'c' variants are built with maxageclass=4, nclassunc=3 so that the
+# age / class / release-point indexing of conccalc, drydepokernel, wetdepokernel can be pinned: the one assignment is
+# rewritten in a pipe into the compiler's stdin (FLEXREF_CLASSES="4 3"); no edited source is ever written anywhere.
 build_one() {
   local kind="$1"; shift
   local parmod="$1"; shift      # which of the reference's par_mod files supplies the compile-time sizes
@@ -34,7 +39,14 @@ build_one() {
     for m in $MODS; do
       src="$REF/$m.f90"
       [ "$m" = "par_mod" ] && src="$REF/$parmod"
-      [ "$obj/$m.o" -nt "$src" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$src" -o "$m.o"
+      [ "$obj/$m.o" -nt "$src" ] && continue
+      if [ "$m" = "par_mod" ] && [ -n "${FLEXREF_CLASSES:-}" ]; then
+        set -- $FLEXREF_CLASSES
+        grep -q 'maxageclass=1,nclassunc=1$' "$src" || { echo "build_ref: par_mod has no 'maxageclass=1,nclassunc=1' line"; exit 1; }
+        sed "s/maxageclass=1,nclassunc=1\$/maxageclass=$1,nclassunc=$2/" "$src" | "$FC" -c -cpp -O2 -mcmodel=medium $flags -x f95-cpp-input - -o "$m.o"
+      else
+        "$FC" -c -cpp -O2 -mcmodel=medium $flags "$src" -o "$m.o"
+      fi
     done
     for s in $SUBS; do
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
@@ -148,3 +160,8 @@ build_co r4      # (with -fdefault-real-8 concoutput.f90 itself does not compile
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path
 build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
 build_vt r8n -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
+# ... and in the reference's own precision (BASELINE config 5: nests + deposition in f32)
+build_one r4n par_mod_meteoswiss.f90 -DFLEXREF_NESTS -DFLEXGPU_NESTS
+# several age classes / uncertainty classes (see build_one)
+FLEXREF_CLASSES="4 3" build_one r4c par_mod.f90
+FLEXREF_CLASSES="4 3" build_one r8c par_mod.f90 -fdefault-real-8

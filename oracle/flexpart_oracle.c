@@ -71,8 +71,10 @@ typedef struct {
   real ctl, fine, d_trop, d_strat, turbmesoscale;
   real density[ORC_MAXSPEC], dquer[ORC_MAXSPEC], vsetaver[ORC_MAXSPEC], cunningham[ORC_MAXSPEC];
   real decay[ORC_MAXSPEC];
-  real xmass_rel[ORC_MAXSPEC];     /* point_mod xmass(1,:) */
-  int npart_rel;                   /* point_mod npart(1)   */
+  /* point_mod.f90:10,20: xmass(numpoint,maxspec), npart(numpoint) -- column-major, species stride = numpoint */
+  int numpoint, mquasilag;
+  real *xmass_pt;
+  int *npart_pt;
   int lage_last;                   /* lage(nageclass)      */
   /* nests (com_mod.f90:464-541) */
   int numbnests;
@@ -110,6 +112,11 @@ typedef struct {
      are replaced by the particle's own values -- what an order-independent (parallel)
      engine computes; see DESIGN.md "deviations" D1/D2. */
   int parallel_semantics;
+  /* optional bookkeeping for the tests (orc_set_leak_flags): which particles the two leaks touch.  flags[j] |= 1 when
+     particle j takes advance.f90:550 (D1), |= 2 when initialize() runs for it with an ngrid left by its predecessor
+     that selects the other wind arrays (polar vs. lat-lon) than the particle's own position would (D2). */
+  unsigned char *leak_flags;
+  int cur_particle;
   real eps_nxmax;                  /* par_mod nxmax of the build being mirrored (eps = nxmax/3.e5) */
   /* ---- output grid (com_mod.f90:583-586, outg_mod outheight, unc_mod gridunc/drygridunc) */
   int numxgrid, numygrid, numzgrid, maxpointspec_act, nclassunc, nageclass, maxspec_out;
@@ -968,12 +975,13 @@ static void orc_get_settling(orc_ctx *c, int itime, real xt, real yt, real zt, i
 }
 
 /* the species pick + settling add repeated at advance.f90:518-531,686-699,893-906 */
-static void orc_add_settling(orc_ctx *c, int itime, double xt, double yt, real zt) {
+#define XMASS_PT(kp, ks) c->xmass_pt[(size_t)((ks) - 1) * c->numpoint + ((kp) - 1)]   /* xmass(kp,ks), 1-based */
+static void orc_add_settling(orc_ctx *c, int itime, int nrelpoint, double xt, double yt, real zt) {
   const real eps3 = sizeof(real) == 4 ? (real)1.17549435e-38f : (real)2.2250738585072014e-308;
   int nsp;
   if (c->mdomainfill == 0 && c->lsettling) {
     for (nsp = 1; nsp <= c->nspec; nsp++)
-      if (c->xmass_rel[nsp - 1] > eps3) break;
+      if (XMASS_PT(nrelpoint, nsp) > eps3) break;
     if (nsp > c->nspec) nsp = c->nspec;
     if (c->density[nsp - 1] > K(0.)) {
       orc_get_settling(c, itime, (real)xt, (real)yt, zt, nsp, &c->settling);
@@ -1006,10 +1014,12 @@ static void orc_initialize(orc_ctx *c, int itime, int *ldt, real *up, real *vp, 
   c->zeta = zt / c->h;
   /* D2: initialize.f90 never sets ngrid -- interpol_all/interpol_wind read the value the
      previous particle's advance() left in interpol_mod. */
-  if (c->parallel_semantics) {
-    if (c->nglobal && yt > (double)c->switchnorthg) c->ngrid = -1;
-    else if (c->sglobal && yt < (double)c->switchsouthg) c->ngrid = -2;
-    else c->ngrid = 0;
+  {
+    int own = 0;
+    if (c->nglobal && yt > (double)c->switchnorthg) own = -1;
+    else if (c->sglobal && yt < (double)c->switchsouthg) own = -2;
+    if (c->leak_flags && ((own < 0) != (c->ngrid < 0))) c->leak_flags[c->cur_particle] |= 2;
+    if (c->parallel_semantics) c->ngrid = own;
   }
   if (c->zeta <= K(1.)) {
     orc_interpol_all(c, itime, (real)xt, (real)yt, zt);
@@ -1327,7 +1337,7 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
     if (*ldt < c->mintime) *ldt = c->mintime;
 
     /* :518-531 */
-    orc_add_settling(c, itime, *xt, *yt, *zt);
+    orc_add_settling(c, itime, nrelpoint, *xt, *yt, *zt);
 
     /* :539-547 */
     dxsave = dxsave + c->u * dt;
@@ -1342,6 +1352,7 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
       if (itimec == itime + c->lsynctime) {
         /* D1: the reference jumps to 99 with usig/vsig/wsig left over from an earlier
            particle (advance.f90:550 skips :604-606). */
+        if (c->leak_flags) c->leak_flags[c->cur_particle] |= 1;
         if (c->parallel_semantics) {
           c->usig = K(0.5) * (c->usigprof[c->indzp] + c->usigprof[c->indz]);
           c->vsig = K(0.5) * (c->vsigprof[c->indzp] + c->vsigprof[c->indz]);
@@ -1412,7 +1423,7 @@ L700:
   }
 
   /* :686-699 */
-  orc_add_settling(c, itime, *xt, *yt, *zt);
+  orc_add_settling(c, itime, nrelpoint, *xt, *yt, *zt);
 
   /* :705-708 */
   dxsave = dxsave + (c->u + ux) * dt;
@@ -1470,7 +1481,7 @@ L99:
   }
 
   /* :893-906 */
-  orc_add_settling(c, itime + *ldt, *xt, *yt, *zt);
+  orc_add_settling(c, itime + *ldt, nrelpoint, *xt, *yt, *zt);
 
   /* :913-951 */
   c->u = (c->u - uold) / K(2.);
@@ -1512,6 +1523,7 @@ void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const doubl
     if (itra1[i] != itime) continue;
     itage = abs(itra1[i] - itramem[i]);
     nage = orc_ageclass(c, itage);
+    if (nage > c->nageclass) continue;   /* guard, as in the kernels above: no plane for this age */
     if (c->ind_samp == -1) {   /* :80-122 */
       real rddx, rddy, p1, p2, p3, p4, dz1, dz2, dz, rhoprof[2];
       ix = (int)xtra1[i]; jy = (int)ytra1[i];
@@ -1644,6 +1656,7 @@ void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const doubl
 
 /* drydepokernel.f90:41-116 */
 static void orc_drydepokernel(orc_ctx *c, int nunc, const dep_real *deposit, real x, real y, int nage, int kp) {
+  if (nage > c->nageclass) return;   /* guard: the reference would write past the last age plane (particle older than lage(nageclass)) */
   real xl, yl, ddx, ddy, wx, wy, w;
   int ix, jy, ixp, jyp, ks;
   xl = (x * c->dx + c->xoutshift) / c->dxout;
@@ -1669,6 +1682,7 @@ static void orc_drydepokernel(orc_ctx *c, int nunc, const dep_real *deposit, rea
 
 /* drydepokernel_nest.f90:38-100: always the uniform kernel (no lusekerneloutput branch), int() truncation */
 static void orc_drydepokernel_nest(orc_ctx *c, int nunc, const dep_real *deposit, real x, real y, int nage, int kp) {
+  if (nage > c->nageclass) return;   /* guard: the reference would write past the last age plane (particle older than lage(nageclass)) */
   real xl, yl, ddx, ddy, wx, wy, w;
   int ix, jy, ixp, jyp, ks;
   xl = (x * c->dx + c->xoutshiftn) / c->dxoutn;
@@ -1810,6 +1824,7 @@ static real orc_get_wetscav(orc_ctx *c, int itime, int ltsample, double xtra1, d
 
 /* wetdepokernel.f90:38-108 */
 static void orc_wetdepokernel(orc_ctx *c, int nunc, const real *deposit, real x, real y, int nage, int kp) {
+  if (nage > c->nageclass) return;   /* guard: the reference would write past the last age plane (particle older than lage(nageclass)) */
   real xl, yl, ddx, ddy, wx, wy, w;
   int ix, jy, ixp, jyp, ks;
   xl = (x * c->dx + c->xoutshift) / c->dxout;
@@ -1834,6 +1849,7 @@ static void orc_wetdepokernel(orc_ctx *c, int nunc, const real *deposit, real x,
 
 /* wetdepokernel_nest.f90:38-107: floor() instead of int(), always the uniform kernel */
 static void orc_wetdepokernel_nest(orc_ctx *c, int nunc, const real *deposit, real x, real y, int nage, int kp) {
+  if (nage > c->nageclass) return;   /* guard: the reference would write past the last age plane (particle older than lage(nageclass)) */
   real xl, yl, ddx, ddy, wx, wy, w;
   int ix, jy, ixp, jyp, ks;
   xl = (x * c->dx + c->xoutshiftn) / c->dxoutn;
@@ -1957,6 +1973,16 @@ void orc_get_receptors(orc_ctx *c, double *out) {
     for (n = 0; n < c->numreceptor; n++) out[n + c->numreceptor * ks] = (double)c->creceptor[n + ORC_MAXRECEPTOR * ks];
 }
 void orc_set_output_times(orc_ctx *c, int loutnext, int loutstep) { c->loutnext = loutnext; c->loutstep = loutstep; }
+/* what concoutput.f90:719-720 (concoutput_nest.f90) does after writing: gridunc, griduncn and creceptor start again
+   from zero, the deposition grids keep accumulating */
+void orc_clear_gridunc(orc_ctx *c) {
+  size_t n2 = (size_t)c->numxgrid * c->numygrid * c->maxspec_out * c->maxpointspec_act * c->nclassunc * c->nageclass;
+  int i;
+  if (c->gridunc) memset(c->gridunc, 0, sizeof(real) * n2 * c->numzgrid);
+  if (c->nested_output && c->griduncn)
+    memset(c->griduncn, 0, sizeof(real) * (size_t)c->numxgridn * c->numygridn * c->maxspec_out * c->maxpointspec_act * c->nclassunc * c->nageclass * c->numzgrid);
+  for (i = 0; i < ORC_MAXRECEPTOR * ORC_MAXSPEC; i++) c->creceptor[i] = K(0.);
+}
 const real *orc_gridunc(orc_ctx *c) { return c->gridunc; }
 const dep_real *orc_drygridunc(orc_ctx *c) { return c->drygridunc; }
 
@@ -1968,13 +1994,13 @@ orc_ctx *orc_create(void) {
   c->idummy_init = -7;
   c->idummy_adv = -7;
   c->ldirect = 1;
-  c->npart_rel = 1;
+  c->numpoint = 0; c->xmass_pt = NULL; c->npart_pt = NULL; c->mquasilag = 0;
   c->lage_last = 999999999;
   c->eps_nxmax = K(361);
   orc_fill_rannumb(c);
   return c;
 }
-void orc_destroy(orc_ctx *c) { free(c); }
+void orc_destroy(orc_ctx *c) { free(c->xmass_pt); free(c->npart_pt); free(c); }
 int orc_real_size(void) { return (int)sizeof(real); }
 const real *orc_rannumb(orc_ctx *c) { return &c->rannumb[1]; }
 
@@ -2056,13 +2082,23 @@ void orc_set_switches(orc_ctx *c, int ldirect, int lsynctime, int method, int mi
   c->d_trop = (real)d_trop; c->d_strat = (real)d_strat; c->turbmesoscale = (real)turbmesoscale;
 }
 void orc_set_species(orc_ctx *c, const double *density, const double *dquer, const double *vsetaver,
-                     const double *cunningham, const double *decay, const double *xmass_rel, int npart_rel, int lage_last) {
+                     const double *cunningham, const double *decay, int lage_last, int mquasilag) {
   int i;
   for (i = 0; i < c->nspec && i < ORC_MAXSPEC; i++) {
     c->density[i] = (real)density[i]; c->dquer[i] = (real)dquer[i]; c->vsetaver[i] = (real)vsetaver[i];
-    c->cunningham[i] = (real)cunningham[i]; c->decay[i] = (real)decay[i]; c->xmass_rel[i] = (real)xmass_rel[i];
+    c->cunningham[i] = (real)cunningham[i]; c->decay[i] = (real)decay[i];
   }
-  c->npart_rel = npart_rel; c->lage_last = lage_last;
+  c->lage_last = lage_last; c->mquasilag = mquasilag;
+}
+/* point_mod xmass(numpoint,maxspec) (given [nspec][numpoint]) and npart(numpoint), readreleases.f90:239-243,419-421 */
+void orc_set_release_points(orc_ctx *c, int numpoint, const double *xmass, const int *npart) {
+  int i;
+  free(c->xmass_pt); free(c->npart_pt);
+  c->numpoint = numpoint;
+  c->xmass_pt = (real *)malloc(sizeof(real) * (size_t)numpoint * c->nspec);
+  c->npart_pt = (int *)malloc(sizeof(int) * (size_t)numpoint);
+  for (i = 0; i < numpoint * c->nspec; i++) c->xmass_pt[i] = (real)xmass[i];
+  for (i = 0; i < numpoint; i++) c->npart_pt[i] = npart[i];
 }
 /* field pointers (arrays stay owned by the caller, in the oracle's precision) */
 void orc_set_fields(orc_ctx *c, const real *uu, const real *vv, const real *ww, const real *rho, const real *drhodz,
@@ -2086,6 +2122,7 @@ long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, re
   real prob[ORC_MAXSPEC];
   for (j = 0; j < npart; j++) {
     if (itra1[j] != itime) continue;
+    c->cur_particle = j;
     if (itramem[j] == itime || itime == 0)
       orc_initialize(c, itime, &idt[j], &uap[j], &ucp[j], &uzp[j], &us[j], &vs[j], &ws[j], xtra1[j], ytra1[j], ztra1[j], &cbt[j]);
     for (ks = 0; ks < ORC_MAXSPEC; ks++) prob[ks] = K(0.);
@@ -2115,8 +2152,9 @@ long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, re
             xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * (K(1.) - prob[ks]) * decfact;
             if (c->decay[ks] > K(0.)) drydeposit[ks] = (dep_real)((real)drydeposit[ks] * r_exp((real)abs(ldeltat) * c->decay[ks]));
           } else xmass1[(size_t)ks * npart + j] = xmass1[(size_t)ks * npart + j] * decfact;
-          if (c->mdomainfill == 0) {
-            if (c->xmass_rel[ks] > K(0.)) xmassfract = r_max(xmassfract, (real)c->npart_rel * xmass1[(size_t)ks * npart + j] / c->xmass_rel[ks]);
+          if (c->mdomainfill == 0 && c->mquasilag == 0) {   /* timemanager.f90:663-666 */
+            const int kr = npoint ? npoint[j] : 1;
+            if (XMASS_PT(kr, ks + 1) > K(0.)) xmassfract = r_max(xmassfract, (real)c->npart_pt[kr - 1] * xmass1[(size_t)ks * npart + j] / XMASS_PT(kr, ks + 1));
           } else xmassfract = K(1.0);
         } else xmassfract = K(1.0);
       }
@@ -2154,6 +2192,7 @@ void orc_set_nest(orc_ctx *c, int nxn, int nyn, double dxn, double dyn, double x
   c->vdepn[0] = vdepn;
 }
 void orc_set_parallel_semantics(orc_ctx *c, int on) { c->parallel_semantics = on; }
+void orc_set_leak_flags(orc_ctx *c, unsigned char *flags) { c->leak_flags = flags; }
 
 long orc_nan_count(orc_ctx *c, int which) { return which == 2 ? c->nan_count2 : c->nan_count; }
 

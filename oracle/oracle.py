@@ -80,9 +80,14 @@ class Oracle:
                              dds.ctypes.data_as(C.POINTER(C.c_int)), C.c_double(float(tp[0])),
                              C.c_double(float(tp[1])), C.c_double(float(tp[2])))
         arrs = [_f64(sc[k]) for k in ("density", "dquer", "vsetaver", "cunningham", "decay")]
-        xm = _f64(sc.get("xmass", np.ones(nspec)))
-        lib.orc_set_species(self.h, *[a.ctypes.data_as(dp) for a in arrs], xm.ctypes.data_as(dp),
-                            int(sc["npart"]), int(np.asarray(sc["lage"]).ravel()[-1]))
+        lib.orc_set_species(self.h, *[a.ctypes.data_as(dp) for a in arrs],
+                            int(np.asarray(sc["lage"]).ravel()[-1]), int(sc.get("mquasilag", 0)))
+        # release-point tables: xmass [nspec][numpoint], npart_rel [numpoint]; default = one point of unit mass
+        numpoint = int(sc.get("numpoint", 1))
+        self.numpoint = numpoint
+        xm = _f64(np.asarray(sc.get("xmass", np.ones(nspec * numpoint)), dtype=np.float64).reshape(nspec, numpoint))
+        npt = np.ascontiguousarray(np.asarray(sc.get("npart_rel", np.full(numpoint, max(int(sc["npart"]), 1))), dtype=np.int32).ravel())
+        lib.orc_set_release_points(self.h, numpoint, xm.ctypes.data_as(dp), npt.ctypes.data_as(C.POINTER(C.c_int)))
         # fields in the oracle's precision (kept alive on self)
         self.f = {}
         ptrs = []
@@ -132,9 +137,11 @@ class Oracle:
             oh = _f64(sc["outheight"])
             lage = np.ascontiguousarray(np.asarray(sc["lage"], dtype=np.int32).ravel())
             ind_samp, iofr = (int(v) for v in sc["concflags"])
-            self.gshape = (1, 1, 1, nspec, nzg, nyg, nxg)   # (nage, nclassunc, maxpointspec, spec, z, y, x)
+            mps = self.numpoint if iofr == 1 else 1          # maxpointspec_act
+            ncu = int(sc.get("nclassunc", 1))
+            self.gshape = (len(lage), ncu, mps, nspec, nzg, nyg, nxg)   # (nage, nclassunc, maxpointspec, spec, z, y, x)
             lib.orc_set_outgrid(self.h, nxg, nyg, nzg, C.c_double(dxo), C.c_double(dyo), C.c_double(lon0),
-                                C.c_double(lat0), oh.ctypes.data_as(dp), 1, 1, len(lage),
+                                C.c_double(lat0), oh.ctypes.data_as(dp), mps, ncu, len(lage),
                                 lage.ctypes.data_as(C.POINTER(C.c_int)), ind_samp, iofr, 1, nspec)
             if "outtimes" in sc:
                 lib.orc_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1]))
@@ -142,7 +149,7 @@ class Oracle:
             if self.has_grid_nest:
                 nxn, nyn = (int(v) for v in sc["outgridn"])
                 dxn, dyn, lon0n, lat0n = (float(v) for v in sc["outgeomn"])
-                self.gshape_nest = (1, 1, 1, nspec, nzg, nyn, nxn)
+                self.gshape_nest = (len(lage), ncu, mps, nspec, nzg, nyn, nxn)
                 lib.orc_set_outgrid_nest(self.h, nxn, nyn, C.c_double(dxn), C.c_double(dyn), C.c_double(lon0n), C.c_double(lat0n))
             self.nreceptor = 0
             if "receptors" in sc:
@@ -178,8 +185,15 @@ class Oracle:
     def wetgrid(self):
         nage, ncu, mps, nsp, nzg, nyg, nxg = self.gshape
         self.lib.orc_wetgridunc.restype = C.c_void_p
-        d = np.ctypeslib.as_array(C.cast(self.lib.orc_wetgridunc(self.h), C.POINTER(C.c_float)), shape=(nsp * nyg * nxg,))
-        return d.astype(np.float64).reshape(nsp, nyg, nxg)
+        lead = self._lead(self.gshape)
+        d = np.ctypeslib.as_array(C.cast(self.lib.orc_wetgridunc(self.h), C.POINTER(C.c_float)), shape=(int(np.prod(lead)) * nsp * nyg * nxg,))
+        return d.astype(np.float64).reshape(lead + (nsp, nyg, nxg))
+
+    @staticmethod
+    def _lead(gshape):
+        """Leading (age, class, pointspec) extents of the reference's grids; dropped when all are 1 (the single-class
+        fixtures of round 1 compare (spec, [z,] y, x) arrays)."""
+        return () if gshape[0] * gshape[1] * gshape[2] == 1 else tuple(gshape[:3])
 
     def grids(self):
         """(gridunc, drygridunc) as float64 arrays shaped (spec, z, y, x) / (spec, y, x)."""
@@ -187,17 +201,20 @@ class Oracle:
         self.lib.orc_gridunc.restype = C.c_void_p
         self.lib.orc_drygridunc.restype = C.c_void_p
         ct = C.c_float if self.kind == "r4" else C.c_double
-        g = np.ctypeslib.as_array(C.cast(self.lib.orc_gridunc(self.h), C.POINTER(ct)), shape=(nsp * nzg * nyg * nxg,))
-        d = np.ctypeslib.as_array(C.cast(self.lib.orc_drygridunc(self.h), C.POINTER(C.c_float)), shape=(nsp * nyg * nxg,))
-        return (g.astype(np.float64).reshape(nsp, nzg, nyg, nxg), d.astype(np.float64).reshape(nsp, nyg, nxg))
+        lead = self._lead(self.gshape)
+        nl = int(np.prod(lead))
+        g = np.ctypeslib.as_array(C.cast(self.lib.orc_gridunc(self.h), C.POINTER(ct)), shape=(nl * nsp * nzg * nyg * nxg,))
+        d = np.ctypeslib.as_array(C.cast(self.lib.orc_drygridunc(self.h), C.POINTER(C.c_float)), shape=(nl * nsp * nyg * nxg,))
+        return (g.astype(np.float64).reshape(lead + (nsp, nzg, nyg, nxg)), d.astype(np.float64).reshape(lead + (nsp, nyg, nxg)))
 
     def grids_nest(self):
         """(griduncn, drygriduncn, wetgriduncn) of the nested output grid, float64, (spec, z, y, x) / (spec, y, x)."""
         nage, ncu, mps, nsp, nzg, nyg, nxg = self.gshape_nest
         ct = C.c_float if self.kind == "r4" else C.c_double
         out = []
-        for fn, t, shp in (("orc_griduncn", ct, (nsp, nzg, nyg, nxg)), ("orc_drygriduncn", C.c_float, (nsp, nyg, nxg)),
-                           ("orc_wetgriduncn", C.c_float, (nsp, nyg, nxg))):
+        lead = self._lead(self.gshape_nest)
+        for fn, t, shp in (("orc_griduncn", ct, lead + (nsp, nzg, nyg, nxg)), ("orc_drygriduncn", C.c_float, lead + (nsp, nyg, nxg)),
+                           ("orc_wetgriduncn", C.c_float, lead + (nsp, nyg, nxg))):
             f = getattr(self.lib, fn)
             f.restype = C.c_void_p
             a = np.ctypeslib.as_array(C.cast(f(self.h), C.POINTER(t)), shape=(int(np.prod(shp)),))
@@ -257,6 +274,18 @@ class Oracle:
             self.step()
             out.append(self.state())
         return out
+
+    def clear_gridunc(self):
+        """gridunc, griduncn, creceptor = 0 as concoutput.f90:719-720 leaves them; the deposition grids accumulate on."""
+        self.lib.orc_clear_gridunc(self.h)
+
+    def track_leaks(self):
+        """Start recording which particles the serial code's two order-dependent leaks touch:
+        returns a uint8 array the oracle ORs 1 (advance.f90:550 taken) / 2 (initialize() with the predecessor's
+        polar-or-not wind choice) into, per particle number, over all following steps."""
+        self._leaks = np.zeros(self.n, np.uint8)
+        self.lib.orc_set_leak_flags(self.h, self._leaks.ctypes.data_as(C.c_void_p))
+        return self._leaks
 
     def nan_counts(self):
         return self.lib.orc_nan_count(self.h, 1), self.lib.orc_nan_count(self.h, 2)

@@ -162,8 +162,14 @@ program flexref
     case ('decay');    decay(1:n)=dbuf(1:n)
     case ('turbpar')   ! d_trop d_strat turbmesoscale
       d_trop=dbuf(1); d_strat=dbuf(2); turbmesoscale=dbuf(3)
-    case ('lage');     nageclass=n; lage(1:n)=ibuf(1:n)
+    case ('lage')
+      if (n.gt.maxageclass) stop 'more age classes than this build holds (par_mod maxageclass)'
+      nageclass=n; lage(1:n)=ibuf(1:n)
     case ('nsteps');   nsteps=ibuf(1)
+    case ('mquasilag'); mquasilag=ibuf(1)
+    case ('numpoint');  numpoint=ibuf(1)          ! before 'npart': xmass(numpoint,maxspec), npart(numpoint)
+    case ('nclassunc')                            ! a compile-time size of the reference (par_mod): must match this build
+      if (ibuf(1).gt.nclassunc) stop 'nclassunc of the scenario exceeds this build'
     ! --- output grid (readoutgrid.f90 / outgrid_init.f90 state) ---------------------------
     case ('outgrid')   ! numxgrid numygrid numzgrid
       numxgrid=ibuf(1); numygrid=ibuf(2); numzgrid=ibuf(3); do_conc=1
@@ -330,8 +336,12 @@ program flexref
       do ks=1,nspec
         xmass1(1:npart_in,ks)=dbuf(1+(ks-1)*npart_in:ks*npart_in)
       end do
-    case ('xmass')    ! release mass per species (point 1)
-      xmass(1,1:n)=dbuf(1:n)
+    case ('xmass')    ! release masses xmass(numpoint,nspec), species-major like the Fortran array
+      do ks=1,nspec
+        xmass(1:numpoint,ks)=dbuf(1+(ks-1)*numpoint:ks*numpoint)
+      end do
+    case ('npart_rel') ! npart(numpoint)
+      npart(1:numpoint)=ibuf(1:numpoint)
     case default
       write(*,*) 'ref_driver: unknown record ', trim(name)
       stop 1
@@ -471,7 +481,11 @@ program flexref
     endif
     do j=1,numpart
       if (itra1(j).eq.itime) then
-        kp=1
+        if (ioutputforeachrelease.eq.1) then      ! timemanager.f90:538-542
+          kp=npoint(j)
+        else
+          kp=1
+        endif
         itage=abs(itra1(j)-itramem(j))
         do nage=1,nageclass
           if (itage.lt.lage(nage)) exit
@@ -611,12 +625,13 @@ contains
   subroutine dump_grids()
     real(kind=8), allocatable :: g(:)
     integer :: ng
-    ng=size(gridunc)
+    ! the last dimension is allocated maxageclass (outgrid_init.f90:192): the nageclass planes in use
+    ng=size(gridunc)/maxageclass*nageclass
     allocate(g(ng))
     g=reshape(real(gridunc,8), [ng])
     call put_d('gridunc', g, ng)
     deallocate(g)
-    ng=size(drygridunc)
+    ng=size(drygridunc)/maxageclass*nageclass
     allocate(g(ng))
     g=reshape(real(drygridunc,8), [ng])
     call put_d('drygridunc', g, ng)
@@ -624,12 +639,12 @@ contains
     call put_d('wetgridunc', g, ng)
     deallocate(g)
     if (do_concn .eq. 1) then
-      ng=size(griduncn)
+      ng=size(griduncn)/maxageclass*nageclass
       allocate(g(ng))
       g=reshape(real(griduncn,8), [ng])
       call put_d('griduncn', g, ng)
       deallocate(g)
-      ng=size(drygriduncn)
+      ng=size(drygriduncn)/maxageclass*nageclass
       allocate(g(ng))
       g=reshape(real(drygriduncn,8), [ng])
       call put_d('drygriduncn', g, ng)

@@ -18,18 +18,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind", "ldirect",
           "lsynctime", "method", "mintime", "ctl", "ifine", "turbswitch", "cblflag",
           "mdomainfill", "lsettling", "nspec", "drydep", "drydepspec", "density", "dquer",
-          "vsetaver", "cunningham", "decay", "turbpar", "lage", "nsteps", "itime0",
+          "vsetaver", "cunningham", "decay", "turbpar", "lage", "nclassunc", "mquasilag", "nsteps", "itime0",
           "outgrid", "outgeom", "outheight", "outgridn", "outgeomn", "receptors", "concflags", "outtimes",
           "wetdep", "wetdepspec", "weta_gas", "wetb_gas", "crain_aero", "csnow_aero", "ccn_aero", "in_aero", "henry",
           "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol",
           "hmix", "ustar", "wstar", "oli", "tropopause", "vdep",
           "nest", "nestgeom", "uun", "vvn", "wwn", "rhon", "drhodzn", "hmixn", "ustarn", "wstarn", "olin",
           "tropopausen", "vdepn", "lsprecn", "convprecn", "tccn", "ttn", "cloudsn", "cloudshn", "lsprec", "convprec", "tcc", "clouds", "cloudsh",
-          "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
-          "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass"]
+          "numpoint", "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
+          "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass", "npart_rel"]
 _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
         "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
-        "drydep", "drydepspec", "lage", "nsteps", "itime0", "npart", "itra1", "itramem",
+        "drydep", "drydepspec", "lage", "nclassunc", "mquasilag", "numpoint", "npart_rel", "nsteps", "itime0", "npart", "itra1", "itramem",
         "npoint", "nclass", "idt", "cbt", "outgrid", "outgridn", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "cloudsn", "cloudshn", "nest"}
 
 
@@ -48,7 +48,7 @@ def write_scenario(path, sc):
             fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
             fh.write(a.tobytes())
         fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
-    unknown = set(sc) - set(_ORDER) - {"par_nxmax"}
+    unknown = set(sc) - set(_ORDER) - {"par_nxmax", "particle_base"}
     if unknown:
         raise KeyError(f"scenario keys not understood by the reference driver: {sorted(unknown)}")
 

@@ -18,18 +18,19 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from oracle import scenario_io as sio  # noqa: E402
-from test_oracle_cpu import CASES, golden_scenario  # noqa: E402
+from test_oracle_cpu import CASES, REF_VARIANT, golden_scenario  # noqa: E402
 
 KEYS = ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt", "xmass1")
 
 
 def main():
+    only = set(sys.argv[1:])
     for name in sorted(CASES):
+        if only and name not in only:
+            continue
         sc = golden_scenario(name)
         for kind in ("r8", "r4"):
-            if name in ("nest", "nest_wet") and kind == "r4":
-                continue                      # the nested-grid variant (par_mod_meteoswiss) is built as r8n only
-            ref = sio.run_reference(sc, "r8n" if name in ("nest", "nest_wet") else kind)
+            ref = sio.run_reference(sc, kind + REF_VARIANT.get(name, ""))
             out = {}
             for i, s in enumerate(ref["steps"]):
                 for k in KEYS:

@@ -1,0 +1,117 @@
+"""GPU: the engine's own multi-rank protocol with two processes on ONE GPU.
+
+RCCL refuses two ranks on the same device, so on a one-GPU box the reduction runs through the engine's second
+transport, the host-supplied all-reduce of fpx_comm_init_host (what an MPI host passes; here gloo).  Everything else
+is the code the 8-GPU run executes: particle shards with global particle numbers as RNG keys, per-rank partial sums in
+device memory, receive buffers for the reduced grids, two output times with cumulative deposition grids."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+COMMON = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    from flexpart_amd import sharding, synthetic as syn
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+
+    def scenario():
+        sc = syn.small(n=6000, nx=48, ny=32, nz=36, nsteps=4, ctl=5.0, ifine=4, cblflag=1)
+        sc.update(lsettling=1, drydep=1, drydepspec=np.array([1], np.int32), density=np.array([2000.0]),
+                  dquer=np.array([8.0]), vsetaver=np.array([-0.004]), cunningham=np.array([1.02]),
+                  decay=np.array([1.0e-6]), xmass=np.array([1.0]))
+        syn.add_outgrid(sc)
+        syn.add_wet(sc, gas=False)
+        syn.add_outgrid_nest(sc)
+        syn.add_receptors(sc)
+        return sc
+
+    def run(eng, allreduce, sort_at=None):
+        outs = []
+        for out_time in range(2):               # two output times, two synchronisation steps each
+            for k in range(2):
+                if eng.itime != 0:
+                    eng.wetdepo()
+                eng.step()
+                eng.conccalc(eng.itime, 1.0)
+            if sort_at == out_time:
+                eng.sort()
+            g, d = eng.grids(allreduce=allreduce, clear=True)     # clear: gridunc only (concoutput.f90:719-720)
+            w = eng.wetgrid(allreduce=allreduce)
+            gn, dn, wn = eng.grids_nest(allreduce=allreduce, clear=True)
+            r = eng.receptors(allreduce=allreduce, clear=True)
+            outs.append(dict(gridunc=g, drygridunc=d, wetgridunc=w, griduncn=gn, drygriduncn=dn, wetgriduncn=wn, creceptor=r))
+        return outs
+""")
+
+WORKER = COMMON + textwrap.dedent("""
+    import torch.distributed as dist
+    rank = int(sys.argv[1])
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+    sc = scenario()
+    mine = sharding.shard_scenario(sc, 2, rank)
+    eng = Engine(mine, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, seed=4711)   # particle_base from the shard
+    eng.comm_init_host(dist, 2, rank)
+    outs = run(eng, True, sort_at=0 if rank == 1 else None)
+    state = eng.download()
+    np.savez(%(out)r + f"_rank{rank}.npz", x=state["xtra1"], z=state["ztra1"], itra1=state["itra1"], m=state["xmass1"],
+             **{f"o{i}_{k}": v for i, o in enumerate(outs) for k, v in o.items()})
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+SERIAL = COMMON + textwrap.dedent("""
+    sc = scenario()
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, seed=4711)
+    outs = run(eng, False)
+    state = eng.download()
+    np.savez(%(out)r + "_serial.npz", x=state["xtra1"], z=state["ztra1"], itra1=state["itra1"], m=state["xmass1"],
+             **{f"o{i}_{k}": v for i, o in enumerate(outs) for k, v in o.items()})
+    eng.close()
+""")
+
+
+def test_two_ranks_one_gpu_two_output_times(built, tmp_path):
+    """mpi_mod.f90:2451-2492 through the engine: two ranks share one cloud (contiguous ranges of particle numbers,
+    README_PARALLEL.md:60-67), reduce gridunc / drygridunc / wetgridunc (+ nested grids, creceptor) at two output
+    times into receive buffers and keep accumulating their partial sums in between.  (i) With the counter RNG keyed on
+    the global particle number every particle ends exactly where the single-rank run puts it.  (ii) The sums at BOTH
+    output times equal the single-rank grids: an in-place reduction (round 1) fails the second one by the first total."""
+    out = str(tmp_path / "mr")
+    port = 33500 + (os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ws = tmp_path / "worker.py"
+    ws.write_text(WORKER % dict(root=ROOT, port=port, out=out))
+    ss = tmp_path / "serial.py"
+    ss.write_text(SERIAL % dict(root=ROOT, out=out))
+    procs = [subprocess.Popen([sys.executable, str(ws), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    r = subprocess.run([sys.executable, str(ss)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    a, b, s = (np.load(out + f"_{t}.npz") for t in ("rank0", "rank1", "serial"))
+    # (i) sharding does not change any particle (counter RNG keyed on the global number; rank 1 even re-sorted its slots)
+    for k in ("x", "z", "itra1"):
+        assert np.array_equal(np.concatenate([a[k], b[k]]), s[k]), k
+    assert np.array_equal(np.concatenate([a["m"], b["m"]], axis=1), s["m"])
+    # (ii) both output times; every rank received the same sums
+    for i in range(2):
+        for k in ("gridunc", "drygridunc", "wetgridunc", "griduncn", "drygriduncn", "wetgriduncn", "creceptor"):
+            want, g0, g1 = s[f"o{i}_{k}"], a[f"o{i}_{k}"], b[f"o{i}_{k}"]
+            assert want.sum() > 0, (i, k)
+            assert np.array_equal(g0, g1), (i, k)
+            tol = 1e-12 if k in ("gridunc", "griduncn", "creceptor") else 2e-5     # f32 atomics sum in another order
+            assert np.abs(g0 - want).max() <= tol * want.max(), (i, k, np.abs(g0 - want).max() / want.max())
+    for k in ("drygridunc", "wetgridunc", "drygriduncn", "wetgriduncn"):
+        assert s[f"o1_{k}"].sum() > 1.2 * s[f"o0_{k}"].sum(), k        # the deposition grids did accumulate over the run
+    assert s["o1_gridunc"].sum() < 1.5 * s["o0_gridunc"].sum()          # gridunc was zeroed after the first output

@@ -55,6 +55,38 @@ def _nest_wet(sc):
     return sc
 
 
+def _multi_release(sc):
+    # four release points with different masses and particle numbers (per-point xmass/npart in the mass-fraction
+    # test and in the settling species pick, advance.f90:518-531: point 1 -> species 1, point 2 -> species 3,
+    # point 3 -> species 2 (a gas: no settling), point 4 -> no mass at all: nsp = nspec, terminated at once);
+    # kp = npoint(j) in the deposition grids and in conccalc; max-age and min-mass terminations (no particle starts
+    # older than lage(nageclass): drydepokernel would then be handed nage = nageclass+1 and write past the grid)
+    _three_species(sc)
+    sc.update(decay=np.array([2.0e-5, 0.0, 2.0e-5]))
+    syn.add_outgrid(sc, old_fraction=0.0)
+    syn.add_wet(sc, gas=False)
+    # every species is scavenged (species 2 as a soluble gas): wetdepo.f90:52,140 hands an uninitialised wetdeposit(ks) to
+    # wetdepokernel for a species with WETDEPSPEC = .false., so the reference's own wetgridunc is undefined there
+    sc.update(wetdepspec=np.array([1, 1, 1], np.int32), weta_gas=np.array([0.0, 2.0e-5, 0.0]), wetb_gas=np.array([0.0, 0.62, 0.0]),
+              crain_aero=np.array([1.0, 0.0, 1.0]), csnow_aero=np.array([1.0, 0.0, 1.0]),
+              ccn_aero=np.array([0.9, 0.0, 0.9]), in_aero=np.array([0.1, 0.0, 0.1]), henry=np.array([0.0, 1.0e5, 0.0]))
+    syn.add_release_points(sc, xmass=[[1.0, 0.0, 0.0, 0.0], [2.0, 0.0, 4.0, 0.0], [0.5, 0.7, 0.0, 0.0]],
+                           npart_rel=[500, 700, 300, 100], lage=[7200], max_age=7000, tiny_every=17, near_every=13)
+    return sc
+
+
+def _age_classes(sc):
+    # four age classes (the oldest particles pass lage(nageclass) during the run and are terminated; none starts
+    # older than that: the reference itself would then write past the last age plane of the deposition grids), three uncertainty classes, three release
+    # points with their own output planes: every trailing index of the 7-D gridunc / 6-D deposition grids, on the
+    # mother and the nested output grid.  Needs a reference build with maxageclass >= 4, nclassunc = 3 (the 'c'
+    # variants of oracle/build_ref.sh; both are compile-time sizes of par_mod, 1 as shipped).
+    _sampling_nest(sc)
+    syn.add_release_points(sc, xmass=[[1.0, 3.0, 0.25]], npart_rel=[600, 400, 500], lage=[3600, 7200, 20000, 30000],
+                           max_age=29500, nclassunc=3)
+    return sc
+
+
 def _nest(sc):
     # a nested grid (interpol_*_nests path) + dry deposition through interpol_vdep_nests
     sc.update(drydep=1, drydepspec=np.array([1], np.int32))
@@ -76,7 +108,12 @@ CASES = {
     "backward_cbl": dict(ctl=5.0, ifine=4, cblflag=1, ldirect=-1),
     "cbl": dict(ctl=5.0, ifine=4, cblflag=1),
     "above_pbl_only": dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True),
+    "multi_release": dict(ctl=5.0, ifine=4, nspec=3, post=_multi_release),
+    "age_classes": dict(ctl=5.0, ifine=4, post=_age_classes),
 }
+# which flang build of the reference a scenario needs (oracle/build_ref.sh): the stock par_mod.f90 (r4 / r8), the
+# reference's own par_mod_meteoswiss.f90 with maxnests = 1 (r4n / r8n), or enlarged class counts (r4c / r8c)
+REF_VARIANT = {"nest": "n", "nest_wet": "n", "age_classes": "c"}
 
 
 def golden_scenario(name):
@@ -117,25 +154,35 @@ def test_oracle_matches_golden_reference_output(name, kind):
         orc.run()
         g, d = orc.grids()
         w = orc.wetgrid()
-        nsp = g.shape[0]
-        rg = gold["gridunc"].reshape((5,) + g.shape[1:])[:nsp]
-        rd = gold["drygridunc"].reshape((5,) + d.shape[1:])[:nsp]
-        rw = gold["wetgridunc"].reshape((5,) + w.shape[1:])[:nsp]
+        nsp = int(sc["nspec"])
+        lead = g.shape[:-4]          # (age, class, pointspec) when any of them exceeds 1, else ()
+
+        def ref(key, like):          # the reference's arrays carry maxspec = 5 species planes
+            a = gold[key].reshape(lead + (5,) + like.shape[len(lead) + 1:])
+            return a[..., :nsp, :, :, :] if like.ndim - len(lead) == 4 else a[..., :nsp, :, :]
+        rg, rd, rw = ref("gridunc", g), ref("drygridunc", d), ref("wetgridunc", w)
         tol = 1e-13 if kind == "r8" else 1e-6
         assert rg.sum() > 0 and rd.sum() > 0 and rw.sum() > 0
         assert np.abs(g - rg).max() <= tol * rg.max()
         assert np.abs(d - rd).max() <= tol * rd.max()
         assert np.abs(w - rw).max() <= tol * rw.max()
+        if name == "age_classes":     # every age class, uncertainty class and release point holds mass
+            for ax in range(3):
+                other = tuple(i for i in range(g.ndim) if i != ax)
+                assert np.all(rg.sum(axis=other) > 0), ("empty plane along axis", ax)
         if "griduncn" in gold.files:   # nested output grid and receptor concentrations
             gn, dn, wn = orc.grids_nest()
             for a, key in ((gn, "griduncn"), (dn, "drygriduncn"), (wn, "wetgriduncn")):
-                ra = gold[key].reshape((5,) + a.shape[1:])[:nsp]
+                ra = ref(key, a)
                 assert ra.sum() > 0
                 assert np.abs(a - ra).max() <= tol * ra.max(), key
             if "creceptor" in gold.files:
                 rc = gold["creceptor"].reshape(nsp, -1)
                 assert rc.max() > 0
                 assert np.abs(orc.receptors() - rc).max() <= tol * rc.max()
+    if name in ("multi_release", "age_classes"):   # the terminations the fixture is there for (timemanager.f90:681-707)
+        dead = [int(np.count_nonzero(gold[f"s{i}_itra1"] == -999999999)) for i in range(len(st))]
+        assert dead[0] > 0 and dead[-1] > dead[0], dead
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])

@@ -75,3 +75,72 @@ def test_two_rank_gloo_grid_reduction(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+WORKER2 = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from flexpart_amd import sharding, synthetic as syn
+    from oracle.oracle import Oracle
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=int(sys.argv[1]), world_size=2)
+    rank = dist.get_rank()
+    # all particles above the mixing layer, turbulence parameters zero, released before the start (no initialize(),
+    # whose mesoscale draw initialize.f90:207-209 is not scaled by turbmesoscale): trajectories do not depend on the
+    # shared random stream, so a shard computes exactly what the serial run computes for its particles
+    sc = syn.small(n=800, nx=30, ny=20, nz=16, nsteps=4, ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True)
+    sc.update(decay=np.array([1.0e-6]), xmass=np.array([1.0]), itime0=900, itra1=np.full(800, 900, np.int32),
+              itramem=np.zeros(800, np.int32))
+    syn.add_wet(syn.add_outgrid(sc, nxg=12, nyg=8, nzg=3), gas=False)
+
+    def run(scn, reduce):
+        o = Oracle(scn, "r8")
+        outs = []
+        for out_time in range(2):           # two output times, two steps each
+            o.step(); o.step()
+            g, d = o.grids()
+            part = {"gridunc": g, "wetgridunc": o.wetgrid()}
+            outs.append(reduce(part))
+            o.clear_gridunc()               # concoutput.f90:719-720: gridunc only; wetgridunc accumulates on
+        return outs
+    mine = run(sharding.shard_scenario(sc, 2, rank), lambda p: sharding.reduce_output_grids(dist, p))
+    # what an in-place reduction does (the defect of round 1): after the first output every rank's accumulator holds
+    # the TOTAL; it goes on accumulating the rank's own deposits and is summed over the ranks again
+    o = Oracle(sharding.shard_scenario(sc, 2, rank), "r8")
+    o.step(); o.step()
+    w1 = o.wetgrid()
+    acc = sharding.allreduce_sum_numpy(dist, w1)
+    o.step(); o.step()
+    acc = acc + (o.wetgrid() - w1)
+    w_inplace = sharding.allreduce_sum_numpy(dist, acc)
+    if rank == 0:
+        full = run(sc, lambda p: p)
+        for a, b in zip(mine, full):
+            for k in ("gridunc", "wetgridunc"):
+                assert b[k].sum() > 0
+                assert np.abs(a[k] - b[k]).max() <= 1e-6 * b[k].max(), (k, np.abs(a[k] - b[k]).max() / b[k].max())
+        assert full[1]["wetgridunc"].sum() > 1.2 * full[0]["wetgridunc"].sum()      # cumulative over the run
+        assert full[1]["gridunc"].sum() < 1.5 * full[0]["gridunc"].sum()            # per output interval, not cumulative
+        # the double count this test guards against: the first total counted once per rank
+        assert w_inplace.sum() > full[1]["wetgridunc"].sum() + 0.9 * full[0]["wetgridunc"].sum()
+        print("OK")
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_two_rank_two_output_times_keep_partial_sums(tmp_path):
+    """mpi_mod.f90:2451-2492: the grids are reduced into receive arrays at EVERY output time; the deposition grids
+    are cumulative over the run (zeroed only in outgrid_init.f90:317-318), gridunc is zeroed after each output
+    (concoutput.f90:719-720).  Two ranks, two output times, wet deposition: the sums at both output times equal the
+    serial run's.  (The engine's own implementation of this protocol -- receive buffers inside fpx_get_grids -- is
+    exercised by tests/test_multirank_gpu.py with two processes on one GPU.)"""
+    port = 31500 + (os.getpid() % 2000)
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2 % dict(root=ROOT, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]
