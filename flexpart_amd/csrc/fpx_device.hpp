@@ -1198,7 +1198,7 @@ FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt
 // ---------------------------------------------------------------------------
 // the per-thread trajectory step
 // ---------------------------------------------------------------------------
-template <typename R> FPX_DEV int pick_grid(const View<R> &V, double xt, double yt);
+template <typename R, bool MOTHER = false> FPX_DEV int pick_grid(const View<R> &V, double xt, double yt);
 template <typename R> FPX_DEV int pick_polar(const View<R> &V, double yt);
 
 template <typename R>
@@ -1215,9 +1215,11 @@ FPX_DEV int pick_polar(const View<R> &V, double yt) {   // the polar part of adv
   if (V.sglobal && yt < (double)V.switchsouthg) return -2;
   return 0;
 }
-// advance.f90:161-175: -1/-2 polar caps, j = highest-numbered nest containing the particle, 0 mother
-template <typename R>
+// advance.f90:161-175: -1/-2 polar caps, j = highest-numbered nest containing the particle, 0 mother.
+// MOTHER: the caller knows that the run has neither polar caps nor nests (compile-time ngrid = 0)
+template <typename R, bool MOTHER>
 FPX_DEV int pick_grid(const View<R> &V, double xt, double yt) {
+  if (MOTHER) return 0;
   const int p = pick_polar(V, yt);
   if (p != 0) return p;
   for (int j = V.numbnests; j >= 1; j--) {
@@ -1275,46 +1277,66 @@ FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, 
   }
 }
 
-// wind at (cell, zt): interpol_wind.f90:75-214 (SIG) / interpol_wind_short.f90:67-140
-template <typename R, bool SIG>
+struct NoLate { FPX_DEV void operator()() const {} };
+
+// wind at (cell, zt): interpol_wind.f90:75-214 (SIG) / interpol_wind_short.f90:67-140.
+// The 48 values are taken corner column by corner column -- the 12 values of a column (2 levels x 2 slots x (u,v,w))
+// are one contiguous run of the w3 pack -- and folded into the running sums as they arrive: 12 loaded values are live
+// instead of 48 (k_prep's register budget).  The horizontal sums p1*y(ix,jy) + p2*y(ixp,jy) + p3*y(ix,jyp) + p4*y(ixp,jyp)
+// keep the reference's left-to-right order; the 16-point sums of the standard deviation (:194-214) are taken in
+// corner order instead of (slot, level) order: the same 16 terms, a different rounding.
+template <typename R, bool SIG, typename LATE = NoLate>
 FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, R zt,
-                         R &u, R &v, R &w, R &usig, R &vsig, R &wsig) {
+                         R &u, R &v, R &w, R &usig, R &vsig, R &wsig, const LATE &late = LATE()) {
   const R eps = K(1.0e-30);
-  const Cols<R> Q = cols_of(F.nx, C);
   const R *w3 = F.w3;
-  int indz = find_level(hgt, V.nz, zt);
-  R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
-  R dz1 = (zt - hgt[indz - 1]) * dz;
-  R dz2 = (hgt[indz] - zt) * dz;
-  R uh[2], vh[2], wh[2];
+  const int indz = find_level(hgt, V.nz, zt);
+  R au[2][2], av[2][2], aw[2][2];   // [physical slot][level]
   R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
+  // software pipeline over the four columns, FPX_GATHER_DEPTH of them in flight (1: one dependent memory round trip
+  // per column, 12 loaded values live; 2: two round trips, 24 live; 4: one round trip, 48 live)
+#ifndef FPX_GATHER_DEPTH
+#define FPX_GATHER_DEPTH 2
+#endif
+  R x[4][12];
+  auto issue = [&](int c) {
+    const long long col = (long long)((c & 2) ? C.jyp : C.jy) * F.nx + ((c & 1) ? C.ixp : C.ix);
+    const R *p = w3 + (col * V.nz + (indz - 1)) * 6;
 #pragma unroll
-  for (int m = 0; m < 2; m++) {
-    int slot = m == 0 ? V.m1 : V.m2;
-    R u1[2], v1[2], w1[2];
+    for (int i = 0; i < 12; i++) x[c][i] = p[i];
+  };
+#pragma unroll
+  for (int c = 0; c < FPX_GATHER_DEPTH && c < 4; c++) issue(c);
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from issuing all 24 loads first
+    const R pw = c == 0 ? C.p1 : c == 1 ? C.p2 : c == 2 ? C.p3 : C.p4;
 #pragma unroll
     for (int n = 0; n < 2; n++) {
-      int indzh = indz + n;
-      R u00, v00, w00, u10, v10, w10, u01, v01, w01, u11, v11, w11;
-      ld3(w3, Q.c00, V.nz, indzh, slot, u00, v00, w00);
-      ld3(w3, Q.c10, V.nz, indzh, slot, u10, v10, w10);
-      ld3(w3, Q.c01, V.nz, indzh, slot, u01, v01, w01);
-      ld3(w3, Q.c11, V.nz, indzh, slot, u11, v11, w11);
-      u1[n] = C.p1 * u00 + C.p2 * u10 + C.p3 * u01 + C.p4 * u11;
-      v1[n] = C.p1 * v00 + C.p2 * v10 + C.p3 * v01 + C.p4 * v11;
-      w1[n] = C.p1 * w00 + C.p2 * w10 + C.p3 * w01 + C.p4 * w11;
-      if (SIG) {
-        usl = usl + u00 + u10 + u01 + u11;
-        vsl = vsl + v00 + v10 + v01 + v11;
-        wsl = wsl + w00 + w10 + w01 + w11;
-        usq = usq + u00 * u00 + u10 * u10 + u01 * u01 + u11 * u11;
-        vsq = vsq + v00 * v00 + v10 * v10 + v01 * v01 + v11 * v11;
-        wsq = wsq + w00 * w00 + w10 * w10 + w01 * w01 + w11 * w11;
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+        const R uu = x[c][(n * 2 + sl) * 3 + 0], vv = x[c][(n * 2 + sl) * 3 + 1], ww = x[c][(n * 2 + sl) * 3 + 2];
+        if (c == 0) { au[sl][n] = pw * uu; av[sl][n] = pw * vv; aw[sl][n] = pw * ww; }
+        else { au[sl][n] = au[sl][n] + pw * uu; av[sl][n] = av[sl][n] + pw * vv; aw[sl][n] = aw[sl][n] + pw * ww; }
+        if (SIG) {
+          usl = usl + uu; vsl = vsl + vv; wsl = wsl + ww;
+          usq = usq + uu * uu; vsq = vsq + vv * vv; wsq = wsq + ww * ww;
+        }
       }
     }
-    uh[m] = dz2 * u1[0] + dz1 * u1[1];
-    vh[m] = dz2 * v1[0] + dz1 * v1[1];
-    wh[m] = dz2 * w1[0] + dz1 * w1[1];
+    if (c + FPX_GATHER_DEPTH < 4) issue(c + FPX_GATHER_DEPTH);
+    if (c + FPX_GATHER_DEPTH == 3) late();   // with the last column's loads: the caller's late loads share their round trip
+  }
+  const R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
+  const R dz1 = (zt - hgt[indz - 1]) * dz;
+  const R dz2 = (hgt[indz] - zt) * dz;
+  R uh[2], vh[2], wh[2];
+#pragma unroll
+  for (int m = 0; m < 2; m++) {
+    const bool hi = (m == 0 ? V.m1 : V.m2) != 0;       // wave-uniform
+    uh[m] = dz2 * (hi ? au[1][0] : au[0][0]) + dz1 * (hi ? au[1][1] : au[0][1]);
+    vh[m] = dz2 * (hi ? av[1][0] : av[0][0]) + dz1 * (hi ? av[1][1] : av[0][1]);
+    wh[m] = dz2 * (hi ? aw[1][0] : aw[0][0]) + dz1 * (hi ? aw[1][1] : aw[0][1]);
   }
   u = (uh[0] * W.dt2 + uh[1] * W.dt1) * W.dtt;
   v = (vh[0] * W.dt2 + vh[1] * W.dt1) * W.dtt;
@@ -1486,20 +1508,22 @@ struct AdvCtx {                 // what advance() keeps between its labelled sec
   R u, v, w;                    // interpol_mod u, v, w
   int itimec, nrand;
   int nsp;                      // species of the settling pick for this particle's release point (set by the caller)
+  R tropop;                     // tropopause height at the nearest grid point (advance.f90:253,263), with TROPO only
 };
 
 enum { PBL_CONTINUE = 0, PBL_DONE = 1, PBL_ESCAPED = 2 };
 
 
 // returns true when the particle starts inside the PBL (zeta <= 1, advance.f90:276)
-template <typename R>
+// TROPO: also fetch the tropopause height of advance.f90:253,263 -- in the same memory round trip as the mixing height
+template <typename R, bool MOTHER = false, bool TROPO = false>
 FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, int nrand, AdvCtx<R> &A) {
   A.dxsave = K(0.); A.dysave = K(0.); A.dawsave = K(0.); A.dcwsave = K(0.);
   A.u = K(0.); A.v = K(0.); A.w = K(0.);
   A.itimec = itime;
   A.nrand = nrand;
   A.nsp = 0;
-  A.ngrid = pick_grid(V, xt, yt);
+  A.ngrid = pick_grid<R, MOTHER>(V, xt, yt);
   int nyrows = V.ny, nxcols = V.nx;
   if (A.ngrid > 0) {   // advance.f90:191-197 nested grid coordinates
     const int l = A.ngrid - 1;
@@ -1518,6 +1542,12 @@ FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, 
   {
     const Fld<R> F = fld_of(V, A.ngrid);
     A.h = F.hcell[(long long)A.jy * F.nx + A.ix];        // advance.f90:236-262 (interpolhmix=.false.)
+    if (TROPO) {
+      // tropopause(nix,njy,1,1) / tropopausen(nix,njy,1,1,ngrid), advance.f90:253,263 (literal slot 1)
+      const int nix = A.ngrid > 0 ? (int)lround((double)A.xr) : (int)lround(xt);
+      const int njy = A.ngrid > 0 ? (int)lround((double)A.yr) : (int)lround(yt);
+      A.tropop = F.tropo[(long long)njy * F.nx + nix];
+    }
   }
   return zt / A.h <= K(1.);
 }
@@ -1798,23 +1828,41 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 }
 
 // the single step above the PBL, advance.f90:629-708 (label 700)
-template <typename R, typename RNG>
+// HAVE_TROPO: adv_begin<.., TROPO = true> has fetched A.tropop already; LATE: a callable that issues the caller's loads
+// which are only needed after the gather (they then travel with the gather's last round trip)
+template <typename R, typename RNG, bool HAVE_TROPO = false, typename LATE = NoLate>
 FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R> &W, int itime, double xt, double yt,
-                        R &zt, R &wp, int &ldt, AdvCtx<R> &A, R &usig, R &vsig, R &wsig) {
+                        R &zt, R &wp, int &ldt, AdvCtx<R> &A, R &usig, R &vsig, R &wsig, const LATE &late = LATE()) {
   const R eps2 = K(1.e-9);
   const Fld<R> F = fld_of(V, A.ngrid);
-  // tropopause(nix,njy,1,1) / tropopausen(nix,njy,1,1,ngrid), advance.f90:253,263 (literal slot 1)
-  const int nix = A.ngrid > 0 ? (int)lround((double)A.xr) : (int)lround(xt);
-  const int njy = A.ngrid > 0 ? (int)lround((double)A.yr) : (int)lround(yt);
-  const R tropop = F.tropo[(long long)njy * F.nx + nix];
+  R tropop;
+  if (HAVE_TROPO) tropop = A.tropop;
+  else {
+    // tropopause(nix,njy,1,1) / tropopausen(nix,njy,1,1,ngrid), advance.f90:253,263 (literal slot 1)
+    const int nix = A.ngrid > 0 ? (int)lround((double)A.xr) : (int)lround(xt);
+    const int njy = A.ngrid > 0 ? (int)lround((double)A.yr) : (int)lround(yt);
+    tropop = F.tropo[(long long)njy * F.nx + nix];
+  }
   Cell<R> C;
   cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
-  interp_wind<R, true>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig);
+  if (V.turbmesoscale == K(0.)) {   // the standard deviations only feed the mesoscale term (advance.f90:728-739)
+    usig = K(0.); vsig = K(0.); wsig = K(0.);
+    interp_wind<R, false>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late);
+  } else {
+    interp_wind<R, true>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late);
+  }
   ldt = abs(V.lsynctime - A.itimec + itime);
   const R dt = (R)ldt;
   int nrand = A.nrand;
   R ux, vy;
-  if (zt < tropop) {
+  if (V.d_trop == K(0.) && V.d_strat == K(0.)) {
+    // diffusivities switched off (wave-uniform): every random term below is multiplied by zero, so no random numbers
+    // are generated; nrand advances as in the three branches
+    ux = K(0.); vy = K(0.); wp = K(0.);
+    if (zt < tropop) { if (nrand + 1 > V.maxrand) nrand = 1; nrand = nrand + 2; }
+    else if (zt < tropop + K(1000.)) { if (nrand + 2 > V.maxrand) nrand = 1; nrand = nrand + 3; }
+    else { if (nrand > V.maxrand) nrand = 1; nrand = nrand + 1; }
+  } else if (zt < tropop) {
     R uxscale = m_sqrt(K(2.) * V.d_trop / dt);
     if (nrand + 1 > V.maxrand) nrand = 1;
     ux = G.at(nrand) * uxscale;
@@ -1848,7 +1896,7 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
 
 // label 99 to the end: advance.f90:728-985.  Returns nstop (0 or 3).
 // POLAR = false compiles the stereographic-map branch out (grids without poles)
-template <typename R, typename RNG, bool POLAR = true>
+template <typename R, typename RNG, bool POLAR = true, bool MOTHER = false>
 FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, PState<R> &P, AdvCtx<R> &A,
                        R usig, R vsig, R wsig) {
   const R eps = V.eps;
@@ -1858,9 +1906,13 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
   {
     const R r = V.meso_r, rs = V.meso_rs;
     if (nrand + 2 > V.maxrand) nrand = 1;
-    P.usigold = r * P.usigold + rs * G.at(nrand) * usig * V.turbmesoscale;
-    P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * vsig * V.turbmesoscale;
-    P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * wsig * V.turbmesoscale;
+    if (V.turbmesoscale == K(0.)) {   // mesoscale fluctuations switched off (wave-uniform): the random terms vanish
+      P.usigold = r * P.usigold; P.vsigold = r * P.vsigold; P.wsigold = r * P.wsigold;
+    } else {
+      P.usigold = r * P.usigold + rs * G.at(nrand) * usig * V.turbmesoscale;
+      P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * vsig * V.turbmesoscale;
+      P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * wsig * V.turbmesoscale;
+    }
     A.dxsave = A.dxsave + P.usigold * (R)V.lsynctime;
     A.dysave = A.dysave + P.vsigold * (R)V.lsynctime;
     P.zt = P.zt + P.wsigold * (R)V.lsynctime;
@@ -1879,7 +1931,7 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
   // Petterssen correction, advance.f90:829-985
   if (P.ldt != abs(V.lsynctime)) return 0;
   if (abs(itime + P.ldt * V.ldirect) > abs(V.memtime1)) return 0;
-  if (pick_grid(V, P.xt, P.yt) != A.ngrid) return 0;
+  if (pick_grid<R, MOTHER>(V, P.xt, P.yt) != A.ngrid) return 0;
   R xr, yr;
   int nyrows = V.ny, nxcols = V.nx;
   if (A.ngrid > 0) {   // advance.f90:862-866

@@ -36,7 +36,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 
 constexpr int kBlock = 256;
 #ifndef FPX_PREP_WAVES
-#define FPX_PREP_WAVES 2   // register budget (waves per SIMD) of the one-thread-per-particle kernels k_prep / k_pbl_finish
+#define FPX_PREP_WAVES 3   // register budget (waves per SIMD) of k_prep (<= 168 VGPRs)
+#endif
+#ifndef FPX_FINISH_WAVES
+#define FPX_FINISH_WAVES 2 // register budget of k_pbl_finish
 #endif
 #ifndef FPX_LOOP_WAVES
 #define FPX_LOOP_WAVES 3   // waves per SIMD the Langevin kernel is register-budgeted for (<= 168 VGPRs)
@@ -254,7 +257,9 @@ __device__ __forceinline__ int advance_start_index(const View<R> &V, const SeqRn
 }
 
 // epilogue timemanager.f90:630-708 + write-back of the particle
-template <typename R, bool DRYDEP>
+// TURB: also write up, vp, cbt -- changed only by initialize() and by the Langevin loop; a particle that
+// was above the mixing layer for the whole step keeps them (advance.f90:629-708 does not touch them)
+template <typename R, bool DRYDEP, bool TURB = true>
 __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> &Gp, Parts<R> &P, long long s, int itime, int itramem,
                                                int nstop, const PState<R> &ps, const R *prob, Stats *st) {
   int itra1;
@@ -307,49 +312,61 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
     }
   }
   P.xt[s] = ps.xt; P.yt[s] = ps.yt; P.zt[s] = ps.zt;
-  P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
+  if (TURB) { P.up[s] = ps.up; P.vp[s] = ps.vp; P.cbt[s] = ps.icbt; }
+  P.wp[s] = ps.wp;
   P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
-  P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt; P.itra1[s] = itra1;
+  P.idt[s] = ps.ldt; P.itra1[s] = itra1;
 }
 
-// per-slot hand-over records between the three PBL kernels (SoA in HBM)
+// Per-slot hand-over record between the three PBL kernels: ONE contiguous, aligned record per particle (128 bytes in the
+// fp64 build = one cache line, 64 bytes in f32), so that a lane that retires its particle in the Langevin kernel -- about
+// two lanes of a wave per pass -- writes one line instead of a sector in each of sixteen arrays, and a refilling lane
+// reads one.  k_prep fills the surface-layer part (in), k_pbl_loop overwrites the record with the particle's state at the
+// end of its last pass (out), k_pbl_finish reads it and writes the particle arrays, coalesced.
+template <typename R>
+struct alignas(16 * sizeof(R)) PblRecord {
+  // in : v[0..3] = ust, wst, ol, CBL transition (interpol_all.f90:80-107, cbl.f90:79-81); i[0] = nrand at entry
+  // out: v[0..3] = dxsave, dysave, dawsave, dcwsave; v[4..6] = interpol_mod u, v, w of the last pass;
+  //      v[7..10] = zt, up, vp, wp; i[0] = nrand, i[1] = itimec, i[2] = rc | indz << 2, i[3] = ldt, i[4] = icbt
+  R v[11];
+  int i[5];
+};
+static_assert(sizeof(PblRecord<double>) == 128 && sizeof(PblRecord<float>) == 64, "one cache line / half a line per record");
 template <typename R>
 struct PblRec {
-  // k_prep -> k_pbl_loop
-  R *ust, *wst, *ol, *trans;
-  int *nrand0;
-  // k_pbl_loop -> k_pbl_finish
-  R *dxsave, *dysave, *dawsave, *dcwsave, *u, *v, *w;
-  R *prob;                 // [nspec][cap], DRYDEP only
-  int *nrand, *itimec, *status;   // status = rc | indz << 2
+  PblRecord<R> *rec;       // [cap]
+  R *prob;                 // [nspec][cap], DRYDEP only: dry-deposition probabilities of the step (advance.f90:582-599)
 };
 
-// INIT: the launch may contain newly released particles (initialize()); POLAR: the grid has polar caps
-template <typename R, bool DRYDEP, bool INIT, bool POLAR>
-__global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+// Register budget: the steady-state kernel of a run on the mother lat-lon grid is built for FPX_PREP_WAVES waves per SIMD
+// (<= 168 VGPRs, no scratch); the variants that also carry initialize(), the polar maps or the nest table would spill at
+// that budget and keep two waves.
+template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
+__global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
                                                  unsigned int *__restrict__ pbl_count) {
+  constexpr bool MOTHER = !POLAR && !NEST;
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
-  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= numpart) return;
-  pbl_flag[s] = 7;                                       // sort key "not due"
-  if (P.itra1[s] != itime) return;                       // timemanager.f90:537
-  // key 6 = due, finished in this kernel (above the PBL); 1..4 = PBL particle of that regime class.
-  // The counts (particles due, length of the PBL work list) are read off the sorted keys by
-  // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
-  pbl_flag[s] = 6;
-
+  // the position travels in the same memory round trip as the due test (nearly every particle is due)
   PState<R> ps;
+  const int itra1_in = P.itra1[s];
   ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
   const int itramem = P.itramem[s];
   const unsigned int pid = P.pid[s];
+  // key 7 = not due; 6 = due, finished in this kernel (above the PBL); 1..4 = PBL particle of that regime class.
+  // The counts (particles due, length of the PBL work list) are read off the sorted keys by
+  // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
+  if (itra1_in != itime) { pbl_flag[s] = 7; return; }    // timemanager.f90:537
 
   // a non-finite or out-of-grid position would index outside the fields (the reference
   // would read arbitrary memory): terminate the particle instead
   if (!(ps.xt >= 0. && ps.xt <= (double)V.nxmin1 && ps.yt >= 0. && ps.yt <= (double)V.nymin1) || !(ps.zt == ps.zt)) {
     P.itra1[s] = kDead;
+    pbl_flag[s] = 6;
     atomicAdd(&st->n_badpos, 1ull);
     return;
   }
@@ -375,18 +392,14 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
     }
     initialize_particle(V, hgt, Gi, nrand_i, itime, ps, dcas, dcas1);
     atomicAdd(&st->n_init, 1ull);
-  } else {
-    ps.up = P.up[s]; ps.vp = P.vp[s]; ps.wp = P.wp[s];
-    ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
-    ps.ldt = P.idt[s]; ps.icbt = P.cbt[s];
   }
 
   AdvCtx<R> A;
   const TimeW<R> W = time_weights(V, itime);
-  const bool in_pbl = adv_begin(V, ps.xt, ps.yt, ps.zt, itime, advance_start_index(V, S, G, pid), A);
+  const bool in_pbl = adv_begin<R, MOTHER, true>(V, ps.xt, ps.yt, ps.zt, itime, advance_start_index(V, S, G, pid), A);
   if (V.lsettling) A.nsp = settling_species(V, P.npoint[s]);   // advance.f90:518-524 with nrelpoint = npoint(j)
   if (in_pbl) {
-    if (is_new) {   // the PBL kernels re-read the state from HBM
+    if (is_new) {   // the PBL kernels read the state from HBM (an old particle's is there already)
       P.up[s] = ps.up; P.vp[s] = ps.vp; P.wp[s] = ps.wp;
       P.us[s] = ps.usigold; P.vs[s] = ps.vsigold; P.ws[s] = ps.wsigold;
       P.idt[s] = ps.ldt; P.cbt[s] = ps.icbt;
@@ -395,8 +408,11 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
     // the lanes are convergent; the Langevin kernel then starts from five numbers per particle
     PblCtx<R> B;
     pbl_begin(V, ps.xt, ps.yt, W, A, B);
-    Q.ust[s] = B.ust; Q.wst[s] = B.wst; Q.ol[s] = B.ol; Q.trans[s] = B.transition;
-    Q.nrand0[s] = A.nrand;
+    {
+      PblRecord<R> &r = Q.rec[s];
+      r.v[0] = B.ust; r.v[1] = B.wst; r.v[2] = B.ol; r.v[3] = B.transition;
+      r.i[0] = A.nrand;
+    }
     // Regime class of the particle's PBL passes (hanna.f90:42,59,91 and advance.f90:405-406).  The
     // work list is the slots stably sorted by this 3-bit key: class by class, each class in slot
     // (= cell) order, so the lanes of a wave run the same branch of the turbulence scheme.
@@ -408,13 +424,24 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_prep(View<R> V, Grid
     pbl_flag[s] = cls;
     return;
   }
+  // Above the mixing layer for the whole step (advance.f90:629-708 -> 99): wp and ldt are set, not read; up, vp and cbt
+  // are not touched; the mesoscale velocities are fetched with the last column of the 48-value gather (same round
+  // trip, not live across the gather: the asm ties the loads to that point of the program).
   R usig, vsig, wsig;
-  above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
-  const int nstop = adv_finish<R, Rng<R>, POLAR>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+  pbl_flag[s] = 6;
+  auto late = [&]() {
+    if (!is_new) {
+      asm volatile("" : "+v"(s));
+      ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
+    }
+  };
+  above_step<R, Rng<R>, true>(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig, late);
+  const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
   R prob[kMaxSpec];
 #pragma unroll
   for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
-  epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
+  if (is_new) epilogue_store<R, DRYDEP, true>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
+  else epilogue_store<R, DRYDEP, false>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
 }
 
 // ---------------------------------------------------------------------------
@@ -741,7 +768,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
           pid = P.pid[s];
           {
             AdvCtx<R> A0;
-            adv_begin(V, xt, yt, zt, itime, Q.nrand0[s], A0);
+            adv_begin(V, xt, yt, zt, itime, Q.rec[s].i[0], A0);
             A.ngrid = A0.ngrid; A.ix = A0.ix; A.jy = A0.jy; A.ixp = A0.ixp; A.jyp = A0.jyp;
             A.h = A0.h; A.itimec = A0.itimec; A.nrand = A0.nrand;
             A.nsp = (!LEAN && V.lsettling) ? settling_species(V, P.npoint[s]) : 0;
@@ -750,7 +777,10 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
           S.put(S_DX, (R)0); S.put(S_DY, (R)0); S.put(S_DAW, (R)0); S.put(S_DCW, (R)0);
           S.put(S_W, (R)0);
           S.put(S_UP, P.up[s]); S.put(S_VP, P.vp[s]);
-          S.put(S_UST, Q.ust[s]); S.put(S_WST, Q.wst[s]); S.put(S_OL, Q.ol[s]); S.put(S_TRANS, Q.trans[s]);
+          {
+            const PblRecord<R> &r = Q.rec[s];
+            S.put(S_UST, r.v[0]); S.put(S_WST, r.v[1]); S.put(S_OL, r.v[2]); S.put(S_TRANS, r.v[3]);
+          }
           A.ilo = -1;
           if (!LEAN && V.drydep) {
 #pragma unroll
@@ -771,14 +801,18 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
       int indz = 1;
       const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, icbt, A, S, indz, prob, st);
       if (rc != PBL_CONTINUE) {
-        P.zt[s] = zt; P.up[s] = S.get(S_UP); P.vp[s] = S.get(S_VP); P.wp[s] = wp; P.idt[s] = ldt; P.cbt[s] = icbt;
-        Q.dxsave[s] = S.get(S_DX); Q.dysave[s] = S.get(S_DY); Q.dawsave[s] = S.get(S_DAW); Q.dcwsave[s] = S.get(S_DCW);
         {
+          // the particle's state at the end of its last pass goes into its hand-over record: one contiguous line;
+          // k_pbl_finish writes the particle arrays from it
+          PblRecord<R> r;
+          r.v[0] = S.get(S_DX); r.v[1] = S.get(S_DY); r.v[2] = S.get(S_DAW); r.v[3] = S.get(S_DCW);
           R u, v;
           pass_wind(hgt, A, S, u, v);
-          Q.u[s] = u; Q.v[s] = v; Q.w[s] = S.get(S_W);
+          r.v[4] = u; r.v[5] = v; r.v[6] = S.get(S_W);
+          r.v[7] = zt; r.v[8] = S.get(S_UP); r.v[9] = S.get(S_VP); r.v[10] = wp;
+          r.i[0] = A.nrand; r.i[1] = A.itimec; r.i[2] = rc | (indz << 2); r.i[3] = ldt; r.i[4] = icbt;
+          Q.rec[s] = r;
         }
-        Q.nrand[s] = A.nrand; Q.itimec[s] = A.itimec; Q.status[s] = rc | (indz << 2);
         if (!LEAN && V.drydep) {
 #pragma unroll
           for (int ks = 0; ks < kMaxSpec; ks++)
@@ -812,21 +846,23 @@ __global__ void k_math_probe(int fn, const double *__restrict__ x, double *__res
 
 // completion of the PBL particles: label 700 if the particle left the PBL, sigmas for the
 // mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
-template <typename R, bool DRYDEP, bool POLAR>
-__global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+template <typename R, bool DRYDEP, bool POLAR, bool NEST>
+__global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                        const unsigned int *__restrict__ pbl_list,
                                                        const unsigned int *__restrict__ pbl_count) {
+  constexpr bool MOTHER = !POLAR && !NEST;
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
   const unsigned int nlist = *pbl_count;
   for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < nlist; i += gridDim.x * blockDim.x) {
     const unsigned int s = pbl_list[i];
+    const PblRecord<R> rec = Q.rec[s];
     PState<R> ps;
-    ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
-    ps.up = P.up[s]; ps.vp = P.vp[s]; ps.wp = P.wp[s];
+    ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = rec.v[7];
+    ps.up = rec.v[8]; ps.vp = rec.v[9]; ps.wp = rec.v[10];
     ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
-    ps.ldt = P.idt[s]; ps.icbt = P.cbt[s];
+    ps.ldt = rec.i[3]; ps.icbt = (short)rec.i[4];
     Rng<R> G;
     make_rng(V, P.pid[s], step, G);
     const TimeW<R> W = time_weights(V, itime);
@@ -834,14 +870,14 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_pbl_finish(View<R> V
     {
       // same cell as at entry: the horizontal position does not change inside the loop
       AdvCtx<R> A0;
-      adv_begin(V, ps.xt, ps.yt, ps.zt, itime, 0, A0);
+      adv_begin<R, MOTHER>(V, ps.xt, ps.yt, ps.zt, itime, 0, A0);
       A = A0;
     }
     if (V.lsettling) A.nsp = settling_species(V, P.npoint[s]);
-    A.dxsave = Q.dxsave[s]; A.dysave = Q.dysave[s]; A.dawsave = Q.dawsave[s]; A.dcwsave = Q.dcwsave[s];
-    A.u = Q.u[s]; A.v = Q.v[s]; A.w = Q.w[s];
-    A.nrand = Q.nrand[s]; A.itimec = Q.itimec[s];
-    const int status = Q.status[s];
+    A.dxsave = rec.v[0]; A.dysave = rec.v[1]; A.dawsave = rec.v[2]; A.dcwsave = rec.v[3];
+    A.u = rec.v[4]; A.v = rec.v[5]; A.w = rec.v[6];
+    A.nrand = rec.i[0]; A.itimec = rec.i[1];
+    const int status = rec.i[2];
     const int rc = status & 3, indz = status >> 2;
     R usig = (R)0, vsig = (R)0, wsig = (R)0;
     if (rc == PBL_ESCAPED) {
@@ -851,7 +887,7 @@ __global__ void __launch_bounds__(kBlock, FPX_PREP_WAVES) k_pbl_finish(View<R> V
       cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
       level_pair_sigma(V, fld_of(V, A.ngrid), C, W, indz, usig, vsig, wsig);   // advance.f90:604-606
     }
-    const int nstop = adv_finish<R, Rng<R>, POLAR>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+    const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
     R prob[kMaxSpec];
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (DRYDEP && ks < V.nspec) ? Q.prob[(size_t)ks * P.cap + s] : (R)0;
@@ -1043,10 +1079,10 @@ struct Engine : EngineBase {
   std::vector<float> h_dcas4, h_dcas14;
   std::vector<double> h_dcas8, h_dcas18;
   // timing
-  struct StepEvents { hipEvent_t e[4]; };   // before k_prep | before k_pbl_loop | after it | after k_pbl_finish
+  struct StepEvents { hipEvent_t e[5]; };   // before k_prep | before k_pbl_loop | after it | after k_pbl_finish | after k_prep (before the work-list sort)
   std::vector<StepEvents> ev_pool;
   size_t ev_used = 0;
-  double acc_ms = 0, acc_part_ms[3] = {0, 0, 0};
+  double acc_ms = 0, acc_part_ms[4] = {0, 0, 0, 0};   // k_prep + work list | k_pbl_loop | k_pbl_finish | k_prep alone
   long long acc_launches = 0;
   unsigned int step_counter = 0;
 
@@ -1152,10 +1188,7 @@ struct Engine : EngineBase {
     if ((rc = dalloc(&d_iota, cap))) return rc;
     memset(&Q, 0, sizeof(Q));
     {
-      R **qs[] = {&Q.ust, &Q.wst, &Q.ol, &Q.trans, &Q.dxsave, &Q.dysave, &Q.dawsave, &Q.dcwsave, &Q.u, &Q.v, &Q.w};
-      for (auto q : qs) if ((rc = dalloc(q, cap))) return rc;
-      int **qi[] = {&Q.nrand0, &Q.nrand, &Q.itimec, &Q.status};
-      for (auto q : qi) if ((rc = dalloc(q, cap))) return rc;
+      if ((rc = dalloc(&Q.rec, cap))) return rc;
       if (cfg.drydep && (rc = dalloc(&Q.prob, cap * cfg.nspec))) return rc;
     }
     // every slot starts dead (FLEXPART.f90:315-317) with identity numbering
@@ -1171,7 +1204,7 @@ struct Engine : EngineBase {
   ~Engine() override {
     if (stream) (void)hipStreamSynchronize(stream);
     for (auto &e : pinned_host) (void)hipHostUnregister(const_cast<void *>(e.first));
-    for (auto &e : ev_pool) for (int i = 0; i < 4; i++) (void)hipEventDestroy(e.e[i]);
+    for (auto &e : ev_pool) for (int i = 0; i < 5; i++) (void)hipEventDestroy(e.e[i]);
     for (void *q : owned) (void)hipFree(q);
     if (staging) (void)hipFree(staging);
     if (d_sort_tmp) (void)hipFree(d_sort_tmp);
@@ -2195,7 +2228,7 @@ struct Engine : EngineBase {
     }
     if (ev_used == ev_pool.size()) {
       StepEvents se;
-      for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&se.e[i]));
+      for (int i = 0; i < 5; i++) HIPCHK(hipEventCreate(&se.e[i]));
       ev_pool.push_back(se);
     }
     auto &ev = ev_pool[ev_used++];
@@ -2226,14 +2259,17 @@ struct Engine : EngineBase {
       const bool init = maybe_new || itime == 0;
       const bool polar = cfg.nglobal || cfg.sglobal;
       typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *, unsigned int *);
+      const bool nest = V.numbnests > 0;
       prep_fn f;
-      if (cfg.drydep) f = init ? (polar ? k_prep<R, true, true, true> : k_prep<R, true, true, false>)
-                               : (polar ? k_prep<R, true, false, true> : k_prep<R, true, false, false>);
-      else f = init ? (polar ? k_prep<R, false, true, true> : k_prep<R, false, true, false>)
-                    : (polar ? k_prep<R, false, false, true> : k_prep<R, false, false, false>);
+#define FPX_PREP(DD, II) (polar ? (nest ? k_prep<R, DD, II, true, true> : k_prep<R, DD, II, true, false>) \
+                                : (nest ? k_prep<R, DD, II, false, true> : k_prep<R, DD, II, false, false>))
+      if (cfg.drydep) f = init ? FPX_PREP(true, true) : FPX_PREP(true, false);
+      else f = init ? FPX_PREP(false, true) : FPX_PREP(false, false);
+#undef FPX_PREP
       f<<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag, d_pbl_ctr);
       maybe_new = false;
     }
+    HIPCHK(hipEventRecord(ev.e[4], stream));
     {
       // work list = slots stably sorted by the 3-bit regime key (non-PBL slots, key 7, end up behind
       // the d_pbl_ctr[0] entries that are used)
@@ -2246,14 +2282,14 @@ struct Engine : EngineBase {
     loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
     HIPCHK(hipEventRecord(ev.e[2], stream));
     {
-      const bool polar = cfg.nglobal || cfg.sglobal;
-      if (cfg.drydep) {
-        if (polar) k_pbl_finish<R, true, true><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-        else k_pbl_finish<R, true, false><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-      } else {
-        if (polar) k_pbl_finish<R, false, true><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-        else k_pbl_finish<R, false, false><<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
-      }
+      const bool polar = cfg.nglobal || cfg.sglobal, nest = V.numbnests > 0;
+      typedef void (*fin_fn)(View<R>, GridP<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *);
+      fin_fn f;
+      if (cfg.drydep) f = polar ? (nest ? k_pbl_finish<R, true, true, true> : k_pbl_finish<R, true, true, false>)
+                                : (nest ? k_pbl_finish<R, true, false, true> : k_pbl_finish<R, true, false, false>);
+      else f = polar ? (nest ? k_pbl_finish<R, false, true, true> : k_pbl_finish<R, false, true, false>)
+                     : (nest ? k_pbl_finish<R, false, false, true> : k_pbl_finish<R, false, false, false>);
+      f<<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
     }
     HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
@@ -2322,6 +2358,8 @@ struct Engine : EngineBase {
         HIPCHK(hipEventElapsedTime(&t, ev_pool[i].e[k], ev_pool[i].e[k + 1]));
         acc_part_ms[k] += t;
       }
+      HIPCHK(hipEventElapsedTime(&t, ev_pool[i].e[0], ev_pool[i].e[4]));
+      acc_part_ms[3] += t;
       acc_launches++;
     }
     ev_used = 0;
@@ -2332,8 +2370,8 @@ struct Engine : EngineBase {
     if (rc) return rc;
     if (ms) *ms = acc_ms;
     if (launches) *launches = acc_launches;
-    if (parts) for (int k = 0; k < 3; k++) parts[k] = acc_part_ms[k];
-    if (reset) { acc_ms = 0; acc_launches = 0; acc_part_ms[0] = acc_part_ms[1] = acc_part_ms[2] = 0; }
+    if (parts) for (int k = 0; k < 4; k++) parts[k] = acc_part_ms[k];
+    if (reset) { acc_ms = 0; acc_launches = 0; acc_part_ms[0] = acc_part_ms[1] = acc_part_ms[2] = acc_part_ms[3] = 0; }
     return 0;
   }
 
@@ -2916,7 +2954,7 @@ int fpx_kernel_time(fpx_handle h, double *ms, int64_t *launches, int32_t reset) 
   if (launches) *launches = l;
   return rc;
 }
-int fpx_kernel_times(fpx_handle h, double ms[3], int64_t *launches, int32_t reset) {
+int fpx_kernel_times(fpx_handle h, double ms[4], int64_t *launches, int32_t reset) {
   FPX_GUARD(h);
   long long l = 0;
   double tot = 0;

@@ -594,8 +594,8 @@ class Engine:
         return ms.value, ln.value
 
     def kernel_times(self, reset=False):
-        """(k_prep, k_pbl_loop, k_pbl_finish) cumulative device ms and the number of steps."""
-        ms = (C.c_double * 3)()
+        """(k_prep + work-list sort, k_pbl_loop, k_pbl_finish, k_prep alone) cumulative device ms and the number of steps."""
+        ms = (C.c_double * 4)()
         ln = C.c_int64(0)
         check(self.lib.fpx_kernel_times(self.h, ms, C.byref(ln), int(reset)), "fpx_kernel_times")
         return list(ms), ln.value

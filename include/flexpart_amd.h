@@ -327,9 +327,9 @@ int fpx_counters(fpx_handle h, fpx_step_stats *stats, int32_t reset);
 /* cumulative device time (ms) and launch count of the advance kernel since the
  * last reset, measured with HIP events on the handle's stream */
 int fpx_kernel_time(fpx_handle h, double *advance_ms, int64_t *launches, int32_t reset);
-/* the same split per kernel: ms[0] = k_prep (+ work-list compaction), ms[1] = k_pbl_loop,
- * ms[2] = k_pbl_finish */
-int fpx_kernel_times(fpx_handle h, double ms[3], int64_t *launches, int32_t reset);
+/* the same split per kernel: ms[0] = k_prep + the work-list sort, ms[1] = k_pbl_loop, ms[2] = k_pbl_finish,
+ * ms[3] = k_prep alone (part of ms[0]) */
+int fpx_kernel_times(fpx_handle h, double ms[4], int64_t *launches, int32_t reset);
 
 /* Force a locality re-sort now (normally driven by cfg.sort_interval). */
 int fpx_sort_particles(fpx_handle h);
