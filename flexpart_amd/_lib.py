@@ -78,7 +78,8 @@ class FpxDiagFields(C.Structure):
 
 
 class FpxRestart(C.Structure):
-    _fields_ = [("jul_header", C.c_double), ("bdate", C.c_double), ("mintime", C.c_int32), ("nclassunc", C.c_int32)]
+    _fields_ = [("jul_header", C.c_double), ("bdate", C.c_double), ("mintime", C.c_int32), ("nclassunc", C.c_int32),
+                ("itrasplit", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FpxConcout(C.Structure):
@@ -92,7 +93,15 @@ class FpxParticles(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws",
                  "itra1", "itramem", "idt", "npoint", "nclass", "cbt", "xmass1")] + \
-               [("xmass1_ld", C.c_int64)]
+               [("xmass1_ld", C.c_int64), ("itrasplit", C.c_void_p)]
+
+
+class FpxRelease(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("numpoint", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("ireleasestart", "ireleaseend", "kindz", "xpoint1", "xpoint2", "ypoint1", "ypoint2",
+                                          "zpoint1", "zpoint2", "point_hour", "area_hour", "point_dow", "area_dow")] + \
+               [("bdate", C.c_double), ("itsplit", C.c_int32), ("ind_rel", C.c_int32), ("nclassunc", C.c_int32),
+                ("reserved", C.c_int32 * 5)]
 
 
 FPX_MAXAGECLASS = 8
@@ -143,7 +152,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 SYMBOLS = [
     "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_polar_maps", "fpx_set_height",
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
-    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points",
+    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points", "fpx_release_init", "fpx_releaseparticles", "fpx_split_particles",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_wet_init", "fpx_upload_wet_fields",
@@ -197,6 +206,9 @@ def load():
     lib.fpx_download_particles.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(FpxParticles)]
     lib.fpx_set_numpart.argtypes = [vp, C.c_int64]
     lib.fpx_set_release_points.argtypes = [vp, C.c_int32, vp, C.POINTER(C.c_int32)]
+    lib.fpx_release_init.argtypes = [vp, C.POINTER(FpxRelease)]
+    lib.fpx_releaseparticles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp, vp, C.POINTER(C.c_int64)]
+    lib.fpx_split_particles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
     lib.fpx_step.argtypes = [vp, C.c_int32, C.POINTER(FpxStepStats)]
     lib.fpx_step_async.argtypes = [vp, C.c_int32]
     lib.fpx_sync.argtypes = [vp]

@@ -332,6 +332,7 @@ struct Parts {
   double *xt, *yt;
   R *zt, *up, *vp, *wp, *us, *vs, *ws;
   int *idt, *itra1, *itramem, *npoint, *nclass;
+  int *itrasplit;        // com_mod.f90:683 (release + splitting on the device)
   short *cbt;
   R *xmass1;             // [nspec][cap]
   unsigned int *pid;     // reference particle number - 1 (stable across locality sorts)

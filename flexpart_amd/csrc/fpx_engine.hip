@@ -164,7 +164,7 @@ __global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict
   B.up[i] = A.up[j]; B.vp[i] = A.vp[j]; B.wp[i] = A.wp[j];
   B.us[i] = A.us[j]; B.vs[i] = A.vs[j]; B.ws[i] = A.ws[j];
   B.idt[i] = A.idt[j]; B.itra1[i] = A.itra1[j]; B.itramem[i] = A.itramem[j];
-  B.npoint[i] = A.npoint[j]; B.nclass[i] = A.nclass[j]; B.cbt[i] = A.cbt[j];
+  B.npoint[i] = A.npoint[j]; B.nclass[i] = A.nclass[j]; B.cbt[i] = A.cbt[j]; B.itrasplit[i] = A.itrasplit[j];
   const unsigned int pid = A.pid[j];
   B.pid[i] = pid;
   slot_of_pid[pid] = (unsigned int)i;
@@ -201,7 +201,7 @@ __global__ void k_seed(View<R> V, Parts<R> P, long long n, unsigned long long se
   double z = us < frac_pbl ? 10.0 + uz * fmax(hloc - 20.0, 1.0) : hloc + 10.0 + uz * (zmax - hloc - 10.0);
   P.xt[i] = x; P.yt[i] = y; P.zt[i] = (R)z;
   P.up[i] = 0; P.vp[i] = 0; P.wp[i] = 0; P.us[i] = 0; P.vs[i] = 0; P.ws[i] = 0;
-  P.idt[i] = 0; P.itra1[i] = itime0; P.itramem[i] = itime0; P.npoint[i] = 1; P.nclass[i] = 1;
+  P.idt[i] = 0; P.itra1[i] = itime0; P.itramem[i] = itime0; P.npoint[i] = 1; P.nclass[i] = 1; P.itrasplit[i] = 999999999;
   P.cbt[i] = 1; P.pid[i] = (unsigned int)i;
   for (int ks = 0; ks < V.nspec; ks++) P.xmass1[(size_t)ks * P.cap + i] = (R)1;
   }
@@ -563,11 +563,174 @@ __global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, Di
   *w++ = (unsigned int)reclen;
 }
 
+// ---------------------------------------------------------------------------
+// releaseparticles.f90:133-375 and the splitting block timemanager.f90:473-504
+// ---------------------------------------------------------------------------
+// per release point and call, prepared by the host in the host's real kind H (releaseparticles.f90:63-131)
+template <typename H>
+struct RelPoints {
+  const long long *first;    // [numpoint+1] exclusive prefix of numrel: particle k of this call belongs to point i with first[i] <= k < first[i+1]
+  const H *xp1, *xaux, *yp1, *yaux, *zp1, *zaux;   // [numpoint]
+  const H *mass;             // [nspec][numpoint]: xmass(i,k)/real(npart(i))*timecorrect(k)/average_timecorrect
+  const short *kindz;        // [numpoint]
+  int numpoint;
+};
+
+// free[pid] = the storage space of particle number pid+1 is vacant: itra1 /= itime (:135)
+template <typename R>
+__global__ void k_rel_flags(Parts<R> P, const unsigned int *__restrict__ slot_of_pid, long long cap, int itime, unsigned int *__restrict__ flags) {
+  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= cap) return;
+  const long long s = slot_of_pid ? (long long)slot_of_pid[pid] : pid;
+  flags[pid] = P.itra1[s] != itime ? 1u : 0u;
+}
+// target[k] = particle number (0-based) of the k-th vacant storage space
+__global__ void k_rel_targets(const unsigned int *__restrict__ flags, const unsigned int *__restrict__ rank, long long cap, long long ntotal,
+                              unsigned int *__restrict__ target) {
+  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= cap || !flags[pid]) return;
+  const unsigned int r = rank[pid];
+  if ((long long)r < ntotal) target[r] = (unsigned int)pid;
+}
+
+template <typename R, typename H>
+__global__ void __launch_bounds__(kBlock) k_release(View<R> V, Parts<R> P, DiagP<H> D, RelPoints<H> RP, const unsigned int *__restrict__ target,
+                                                    const unsigned int *__restrict__ slot_of_pid, long long ntotal, int itime,
+                                                    const H *__restrict__ uniforms /* [4][ntotal] serial ran1 stream, or NULL: counter RNG */,
+                                                    int numparticlecount0, int mintime, int itsplit, int ind_rel, int nclassunc, int mquasilag,
+                                                    H *__restrict__ rho_rel, unsigned int *__restrict__ maxpid) {
+#pragma clang fp contract(off)
+  const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= ntotal) return;
+  // release point of particle k: last i with first[i] <= k
+  int lo = 0, hi = RP.numpoint;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (RP.first[mid] <= k) lo = mid; else hi = mid; }
+  const int i = lo;
+  const unsigned int pid = target[k];
+  const long long s = slot_of_pid ? (long long)slot_of_pid[pid] : (long long)pid;
+  H u[4];
+  if (uniforms) {
+#pragma unroll
+    for (int d = 0; d < 4; d++) u[d] = uniforms[(size_t)d * ntotal + k];
+  } else {   // four uniforms in [0,1) keyed on (seed, number of the particle in the run's release count)
+    unsigned int o[4];
+    philox4x32((unsigned int)(numparticlecount0 + k) + V.pid_base, 0x52454c45u /* "RELE" */, (unsigned int)((numparticlecount0 + k) >> 32), 0u,
+               (unsigned int)V.seed, (unsigned int)(V.seed >> 32), o);
+#pragma unroll
+    for (int d = 0; d < 4; d++) u[d] = (H)((float)(o[d] >> 8) * (1.0f / 16777216.0f));
+  }
+  const int nx = V.nx, ny = V.ny, nz = V.nz;
+  double xt = (double)(RP.xp1[i] + u[0] * RP.xaux[i]);                       // :139
+  if (V.xglobal) {
+    if (xt > (double)(H)V.nxmin1) xt = xt - (double)(H)V.nxmin1;
+    if (xt < 0.) xt = xt + (double)(H)V.nxmin1;
+  }
+  const double yt = (double)(RP.yp1[i] + u[1] * RP.yaux[i]);                 // :146
+  int nc = (int)(u[2] * (H)nclassunc) + 1;                                   // :168-169
+  nc = nc < nclassunc ? nc : nclassunc;
+  H zt = RP.zp1[i] + u[3] * RP.zaux[i];                                      // :183
+  // :206-226 (mother grid)
+  int ix = (int)xt, jy = (int)yt;
+  const H ddy = (H)(yt - (double)(H)jy), ddx = (H)(xt - (double)(H)ix);
+  int ixp = ix + 1, jyp = jy + 1;
+  // guards (the reference would read outside its arrays): a position on the upper edges
+  ix = min(max(ix, 0), nx - 1); jy = min(max(jy, 0), ny - 1); ixp = min(max(ixp, 0), D.nxmax - 1); jyp = min(max(jyp, 0), D.nymax - 1);
+  const H rddx = (H)1. - ddx, rddy = (H)1. - ddy;
+  const H p1 = rddx * rddy, p2 = ddx * rddy, p3 = rddx * ddy, p4 = ddx * ddy;
+  auto oro = [&](int a, int b) { return D.oro[(size_t)a + (size_t)D.nxmax * (size_t)b]; };
+  const H topo = p1 * oro(ix, jy) + p2 * oro(ixp, jy) + p3 * oro(ix, jyp) + p4 * oro(ixp, jyp);
+  // rho(.,.,kz,2): the r2 pack, physical slot 2; tt(.,.,kz,2): component 2 of the d3 pack; host padding reads as 0
+  auto rho2 = [&](int a, int b, int kz) -> H { return (a >= nx || b >= ny) ? (H)0 : (H)V.r2[(((size_t)b * nx + a) * nz + (kz - 1)) * 4 + 2]; };
+  auto tt2 = [&](int a, int b, int kz) -> H { return (a >= nx || b >= ny) ? (H)0 : D.d3[((((size_t)b * nx + a) * nz + (kz - 1)) * 2 + 1) * 3 + 2]; };
+  const int kz3 = RP.kindz[i];
+  if (kz3 == 3) {                                                            // :231-273
+    const H presspart = zt;
+    H pressold = (H)0;
+    for (int kz = 1; kz <= nz; kz++) {
+      const H r = p1 * rho2(ix, jy, kz) + p2 * rho2(ixp, jy, kz) + p3 * rho2(ix, jyp, kz) + p4 * rho2(ixp, jyp, kz);
+      const H t = p1 * tt2(ix, jy, kz) + p2 * tt2(ixp, jy, kz) + p3 * tt2(ix, jyp, kz) + p4 * tt2(ixp, jyp, kz);
+      const H press = r * (H)287.05 * t / (H)100.;
+      if (kz == 1) pressold = press;
+      if (press < presspart) {
+        if (kz == 1) zt = (H)V.height[0] / (H)2.;
+        else {
+          const H dz1 = pressold - presspart, dz2 = presspart - press;
+          zt = ((H)V.height[kz - 2] * dz2 + (H)V.height[kz - 1] * dz1) / (dz1 + dz2);
+        }
+        break;
+      }
+      pressold = press;
+    }
+  }
+  if (kz3 == 2) zt = zt - topo;                                              // :278
+  if (zt < (H)1.e-6) zt = (H)1.e-6;
+  if (zt > (H)V.height[nz - 1] - (H)0.5) zt = (H)V.height[nz - 1] - (H)0.5;
+  H rhoout = (H)1.;
+  const bool dens = ind_rel == 1 || ind_rel == 3 || ind_rel == 4;
+  if (dens) {                                                                // :300-341
+    int indz = nz - 1, indzp = nz;
+    for (int ii = 2; ii <= nz; ii++)
+      if ((H)V.height[ii - 1] > zt) { indz = ii - 1; indzp = ii; break; }
+    const H dz1 = zt - (H)V.height[indz - 1], dz2 = (H)V.height[indzp - 1] - zt, dz = (H)1. / (dz1 + dz2);
+    H rhoaux[2];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+      rhoaux[n] = p1 * rho2(ix, jy, indz + n) + p2 * rho2(ixp, jy, indz + n) + p3 * rho2(ix, jyp, indz + n) + p4 * rho2(ixp, jyp, indz + n);
+    rhoout = (dz2 * rhoaux[0] + dz1 * rhoaux[1]) * dz;
+    if (rho_rel && k == RP.first[i + 1] - 1) rho_rel[i] = rhoout;            // rho_rel(i) keeps the last particle's value
+  }
+  for (int ks = 0; ks < V.nspec; ks++) {
+    H m = RP.mass[(size_t)ks * RP.numpoint + i];
+    if (dens) m = m * rhoout;
+    P.xmass1[(size_t)ks * P.cap + s] = (R)m;
+  }
+  P.xt[s] = xt; P.yt[s] = yt; P.zt[s] = (R)zt;
+  P.nclass[s] = nc;
+  P.npoint[s] = mquasilag == 0 ? i + 1 : (int)(numparticlecount0 + k + 1);   // :171-175
+  P.idt[s] = mintime; P.itra1[s] = itime; P.itramem[s] = itime;
+  P.itrasplit[s] = itime + V.ldirect * itsplit;
+  // the turbulent state of the storage space is whatever its last owner left; initialize() overwrites it
+  // before the first advance() (timemanager.f90:553), as in the reference
+  atomicMax(maxpid, pid);
+}
+
+// splitting, timemanager.f90:473-504
+template <typename R>
+__global__ void k_split_flags(Parts<R> P, const unsigned int *__restrict__ slot_of_pid, long long numpart, int itime, int ldirect,
+                              unsigned int *__restrict__ flags) {
+  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= numpart) return;
+  const long long s = slot_of_pid ? (long long)slot_of_pid[pid] : pid;
+  flags[pid] = (ldirect * itime >= ldirect * P.itrasplit[s]) ? 1u : 0u;
+}
+template <typename R>
+__global__ void k_split(Parts<R> P, const unsigned int *__restrict__ slot_of_pid, const unsigned int *__restrict__ flags,
+                        const unsigned int *__restrict__ rank, long long numpart, long long room, int nspec) {
+#pragma clang fp contract(off)
+  const long long pid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pid >= numpart || !flags[pid] || (long long)rank[pid] >= room) return;
+  const long long j = slot_of_pid ? (long long)slot_of_pid[pid] : pid;
+  const long long n = numpart + rank[pid];          // storage spaces behind numpart are identity-numbered
+  const int itm = P.itramem[j];
+  const int its = 2 * (P.itrasplit[j] - itm) + itm;
+  P.itrasplit[j] = its; P.itrasplit[n] = its;
+  P.itramem[n] = itm; P.itra1[n] = P.itra1[j]; P.idt[n] = P.idt[j]; P.npoint[n] = P.npoint[j]; P.nclass[n] = P.nclass[j];
+  P.xt[n] = P.xt[j]; P.yt[n] = P.yt[j]; P.zt[n] = P.zt[j];
+  P.up[n] = P.up[j]; P.vp[n] = P.vp[j]; P.wp[n] = P.wp[j];
+  P.us[n] = P.us[j]; P.vs[n] = P.vs[j]; P.ws[n] = P.ws[j];
+  P.cbt[n] = P.cbt[j];
+  for (int ks = 0; ks < nspec; ks++) {
+    const R m = P.xmass1[(size_t)ks * P.cap + j] / (R)2;
+    P.xmass1[(size_t)ks * P.cap + j] = m;
+    P.xmass1[(size_t)ks * P.cap + n] = m;
+  }
+}
+
 // readpartpositions.f90:115-148 -- warm start: the records of a dump (as partoutput writes them) -> particle SoA.
 // One lane per record; arithmetic of the coordinate conversion in the host's real kind H.
 template <typename R, typename H>
 __global__ void __launch_bounds__(kBlock) k_readpart(Parts<R> P, const unsigned int *__restrict__ raw, long long n, int nspec,
-                                                     H dx, H dy, H xlon0, H ylat0, double jul_header, double bdate, int mintime,
+                                                     H dx, H dy, H xlon0, H ylat0, double jul_header, double bdate, int mintime, int itrasplit0,
                                                      const int *__restrict__ nclass_in, int *__restrict__ status /* [0] error, [1] max npoint */) {
 #pragma clang fp contract(off)
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -592,6 +755,7 @@ __global__ void __launch_bounds__(kBlock) k_readpart(Parts<R> P, const unsigned 
   const double julpartin = jul_header + (double)itramem_in / 86400.;      // :140-147
   P.itramem[i] = (int)llround((julpartin - bdate) * (double)(H)86400.);
   P.idt[i] = mintime;
+  P.itrasplit[i] = itrasplit0;                                            // :117
   P.itra1[i] = 0;
   P.nclass[i] = nclass_in ? nclass_in[i] : 1;
   P.up[i] = (R)0; P.vp[i] = (R)0; P.wp[i] = (R)0; P.us[i] = (R)0; P.vs[i] = (R)0; P.ws[i] = (R)0;
@@ -982,6 +1146,9 @@ struct EngineBase {
   virtual int download_particles(long long first, long long count, const fpx_particles *p) = 0;
   virtual int set_numpart(long long n) = 0;
   virtual int set_release_points(int numpoint, const void *xmass, const int32_t *npart) = 0;
+  virtual int release_init(const fpx_release *r) = 0;
+  virtual int releaseparticles(int itime, int64_t *numpart, int32_t *numparticlecount, void *xmasssave, void *rho_rel, int64_t *nreleased) = 0;
+  virtual int split_particles(int itime, int64_t *numpart) = 0;
   virtual int step(int itime, fpx_step_stats *st, bool async) = 0;
   virtual int sync() = 0;
   virtual int counters(fpx_step_stats *out, int reset) = 0;
@@ -1176,7 +1343,7 @@ struct Engine : EngineBase {
     if ((rc = dalloc(&P.yt, cap))) return rc;
     R **rs[] = {&P.zt, &P.up, &P.vp, &P.wp, &P.us, &P.vs, &P.ws};
     for (auto q : rs) if ((rc = dalloc(q, cap))) return rc;
-    int **is[] = {&P.idt, &P.itra1, &P.itramem, &P.npoint, &P.nclass};
+    int **is[] = {&P.idt, &P.itra1, &P.itramem, &P.npoint, &P.nclass, &P.itrasplit};
     for (auto q : is) if ((rc = dalloc(q, cap))) return rc;
     if ((rc = dalloc(&P.cbt, cap))) return rc;
     if ((rc = dalloc(&P.xmass1, cap * cfg.nspec))) return rc;
@@ -1191,9 +1358,22 @@ struct Engine : EngineBase {
       if ((rc = dalloc(&Q.rec, cap))) return rc;
       if (cfg.drydep && (rc = dalloc(&Q.prob, cap * cfg.nspec))) return rc;
     }
-    // every slot starts dead (FLEXPART.f90:315-317) with identity numbering
+    // every storage space starts zeroed (releaseparticles leaves the turbulent state of a space it takes as it finds it;
+    // the host's arrays start from zero too), dead (FLEXPART.f90:315-317) and identity-numbered
+    {
+      R *rz[] = {P.zt, P.up, P.vp, P.wp, P.us, P.vs, P.ws};
+      for (R *q : rz) HIPCHK(hipMemsetAsync(q, 0, cap * sizeof(R), stream));
+      HIPCHK(hipMemsetAsync(P.xt, 0, cap * sizeof(double), stream));
+      HIPCHK(hipMemsetAsync(P.yt, 0, cap * sizeof(double), stream));
+      HIPCHK(hipMemsetAsync(P.xmass1, 0, cap * cfg.nspec * sizeof(R), stream));
+      int *iz[] = {P.idt, P.itramem, P.npoint, P.nclass};
+      for (int *q : iz) HIPCHK(hipMemsetAsync(q, 0, cap * sizeof(int), stream));
+      HIPCHK(hipMemsetAsync(P.cbt, 0, cap * sizeof(short), stream));
+    }
+
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, (long long)cap, nullptr);
+    k_fill<int><<<nb, kBlock, 0, stream>>>(P.itrasplit, 999999999, 0, (long long)cap, nullptr);
     k_iota_pid<<<nb, kBlock, 0, stream>>>(P.pid, 0, (long long)cap);
     k_iota_pid<<<nb, kBlock, 0, stream>>>(d_iota, 0, (long long)cap);
     HIPCHK(hipGetLastError());
@@ -1803,7 +1983,7 @@ struct Engine : EngineBase {
       }
       if (e == hipSuccess) {
         k_readpart<R, H><<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, stream>>>(P, raw, n, cfg.nspec, (H)cfg.dx, (H)cfg.dy, (H)cfg.xlon0, (H)cfg.ylat0,
-                                                                                r->jul_header, r->bdate, r->mintime, d_nclass, d_status);
+                                                                                r->jul_header, r->bdate, r->mintime, r->itrasplit, d_nclass, d_status);
         e = hipGetLastError();
       }
       if (e == hipSuccess) e = hipMemcpyAsync(status, d_status, sizeof status, hipMemcpyDeviceToHost, stream);
@@ -1828,6 +2008,258 @@ struct Engine : EngineBase {
                                     : readpart_t<double>(path, r, numpart_out, numparticlecount, itimein);
   }
 
+
+  // ---- releaseparticles + splitting ------------------------------------------------
+  struct ReleaseTables {
+    bool set = false;
+    int numpoint = 0, itsplit = 0, ind_rel = 0, nclassunc = 1;
+    double bdate = 0;
+    std::vector<int> start, end;
+    std::vector<short> kindz;
+    std::vector<double> xp1, xp2, yp1, yp2, zp1, zp2;          // values of the host's real kind, widened
+    std::vector<double> point_hour, area_hour, point_dow, area_dow;   // [24|7][nspec]
+  } rel;
+  std::vector<double> rel_xmass_h;       // [nspec][numpoint], host copy of the table of fpx_set_release_points
+  std::vector<int> rel_npart_h;
+  Ran1 rel_ran1 = [] { Ran1 r; r.idum = -7; return r; }();   // releaseparticles.f90:59: integer :: idummy = -7 (SAVE'd): the stream persists between calls
+
+  int release_init(const fpx_release *r) override {
+    if (!r || r->struct_bytes != (int32_t)sizeof(fpx_release)) return fail(FPX_ERR_ARG, "release_init: null or fpx_release size mismatch (ABI)");
+    if (r->numpoint < 1 || r->numpoint != V.numpoint) return fail(FPX_ERR_ARG, "release_init: numpoint must equal that of fpx_set_release_points (call it first)");
+    if (!r->ireleasestart || !r->ireleaseend || !r->kindz || !r->xpoint1 || !r->xpoint2 || !r->ypoint1 || !r->ypoint2 || !r->zpoint1 || !r->zpoint2)
+      return fail(FPX_ERR_ARG, "release_init: the release-point arrays are required");
+    if (r->nclassunc < 1) return fail(FPX_ERR_ARG, "release_init: nclassunc >= 1");
+    const int np = r->numpoint, ms = cfg.maxspec, ns = cfg.nspec;
+    auto rd = [&](const void *p, size_t i) -> double { return cfg.host_real_bytes == 4 ? (double)((const float *)p)[i] : ((const double *)p)[i]; };
+    rel.numpoint = np; rel.itsplit = r->itsplit; rel.ind_rel = r->ind_rel; rel.nclassunc = r->nclassunc; rel.bdate = r->bdate;
+    rel.start.assign(r->ireleasestart, r->ireleasestart + np); rel.end.assign(r->ireleaseend, r->ireleaseend + np);
+    rel.kindz.assign(r->kindz, r->kindz + np);
+    std::vector<double> *dst[6] = {&rel.xp1, &rel.xp2, &rel.yp1, &rel.yp2, &rel.zp1, &rel.zp2};
+    const void *src[6] = {r->xpoint1, r->xpoint2, r->ypoint1, r->ypoint2, r->zpoint1, r->zpoint2};
+    for (int a = 0; a < 6; a++) { dst[a]->resize(np); for (int i = 0; i < np; i++) (*dst[a])[i] = rd(src[a], i); }
+    // (maxspec, 24|7) column-major -> [hour|day][species]; absent tables mean "no variation" (factor 1)
+    auto table = [&](const void *p, int n2, std::vector<double> &out) {
+      out.assign((size_t)n2 * ns, 1.0);
+      if (p) for (int k = 0; k < n2; k++) for (int sp = 0; sp < ns; sp++) out[(size_t)k * ns + sp] = rd(p, (size_t)k * ms + sp);
+    };
+    table(r->point_hour, 24, rel.point_hour); table(r->area_hour, 24, rel.area_hour);
+    table(r->point_dow, 7, rel.point_dow); table(r->area_dow, 7, rel.area_dow);
+    rel.set = true;
+    return 0;
+  }
+
+  // juldate.f90 / caldate.f90 (the date part) in the host's real kind H
+  template <typename H>
+  static double jul_of(int yyyymmdd, int hhmiss) {
+    const int igreg = 15 + 31 * (10 + 12 * 1582);
+    int yyyy = yyyymmdd / 10000, mm = (yyyymmdd - 10000 * yyyy) / 100, dd = yyyymmdd - 10000 * yyyy - 100 * mm;
+    const int hh = hhmiss / 10000, mi = (hhmiss - 10000 * hh) / 100, ss = hhmiss - 10000 * hh - 100 * mi;
+    int jy, jm;
+    if (yyyy < 0) yyyy = yyyy + 1;
+    if (mm > 2) { jy = yyyy; jm = mm + 1; } else { jy = yyyy - 1; jm = mm + 13; }
+    int julday = (int)((H)365.25 * (H)jy) + (int)((H)30.6001 * (H)jm) + dd + 1720995;
+    if (dd + 31 * (mm + 12 * yyyy) >= igreg) {
+      const int ja = (int)((H)0.01 * (H)jy);
+      julday = julday + 2 - ja + (int)((H)0.25 * (H)ja);
+    }
+    return (double)julday + (double)hh / 24. + (double)mi / 1440. + (double)ss / 86400.;
+  }
+  template <typename H>
+  static int month_of(double juldate) {
+    const int igreg = 2299161;
+    int julday = (int)juldate, ja;
+    if ((juldate - julday) * 86400. >= 86399.5) { juldate = juldate + juldate - julday - 86399.5 / 86400.; julday = (int)juldate; }
+    if (julday >= igreg) {
+      const int jalpha = (int)((((H)(julday - 1867216)) - (H)0.25) / (H)36524.25);
+      ja = julday + 1 + jalpha - (int)((H)0.25 * (H)jalpha);
+    } else ja = julday;
+    const int jb = ja + 1524;
+    const int jc = (int)((H)6680. + (((H)(jb - 2439870)) - (H)122.1) / (H)365.25);
+    const int jd = 365 * jc + (int)((H)0.25 * (H)jc);
+    const int je = (int)((H)(jb - jd) / (H)30.6001);
+    int mm = je - 1;
+    if (mm > 12) mm = mm - 12;
+    return mm;
+  }
+
+  template <typename H>
+  int release_t(int itime, int64_t *numpart_io, int32_t *npc_io, H *xmasssave, H *rho_rel, int64_t *nreleased) {
+    const int np = rel.numpoint, ns = cfg.nspec;
+    // ---- releaseparticles.f90:63-131 on the host, in the host's real kind -------------------------------
+    const double julmonday = jul_of<H>(19000101, 0);
+    double jul = rel.bdate + (double)itime / 86400.;
+    { const int mm = month_of<H>(jul); if (mm >= 4 && mm <= 9) jul = jul + 1. / 24.; }
+    std::vector<long long> first(np + 1, 0);
+    std::vector<H> mass((size_t)ns * np, (H)0), xp1(np), xaux(np), yp1(np), yaux(np), zp1(np), zaux(np);
+    bool any_p3 = false;
+    for (int i = 0; i < np; i++) {
+      long long numrel = 0;
+      xp1[i] = (H)rel.xp1[i]; yp1[i] = (H)rel.yp1[i]; zp1[i] = (H)rel.zp1[i];
+      xaux[i] = (H)rel.xp2[i] - (H)rel.xp1[i]; yaux[i] = (H)rel.yp2[i] - (H)rel.yp1[i]; zaux[i] = (H)rel.zp2[i] - (H)rel.zp1[i];
+      if (itime >= rel.start[i] && itime <= rel.end[i]) {
+        H xlonav = (H)cfg.xlon0 + ((H)rel.xp2[i] + (H)rel.xp1[i]) / (H)2. * (H)cfg.dx;
+        if (xlonav < (H)-180.) xlonav = xlonav + (H)360.;
+        if (xlonav > (H)180.) xlonav = xlonav - (H)360.;
+        const double jullocal = jul + (double)xlonav / 360.;
+        double juldiff = jullocal - julmonday;
+        const int nweeks = (int)(juldiff / 7.);
+        juldiff = juldiff - (double)nweeks * 7.;
+        int ndayofweek = (int)juldiff + 1;
+        int nhour = (int)std::lround((juldiff - (double)(ndayofweek - 1)) * 24.);
+        if (nhour == 0) { nhour = 24; ndayofweek = ndayofweek - 1; if (ndayofweek == 0) ndayofweek = 7; }
+        const bool point_source = std::fabs((double)((H)rel.xp2[i] - (H)rel.xp1[i])) < 1.e-4 && std::fabs((double)((H)rel.yp2[i] - (H)rel.yp1[i])) < 1.e-4;
+        std::vector<H> tc(ns);
+        H avg = (H)0;
+        for (int k = 0; k < ns; k++) {
+          tc[k] = point_source ? (H)rel.point_hour[(size_t)(nhour - 1) * ns + k] * (H)rel.point_dow[(size_t)(ndayofweek - 1) * ns + k]
+                               : (H)rel.area_hour[(size_t)(nhour - 1) * ns + k] * (H)rel.area_dow[(size_t)(ndayofweek - 1) * ns + k];
+          avg = avg + tc[k];
+        }
+        avg = avg / (H)ns;
+        if (rel.start[i] != rel.end[i]) {
+          H rfraction = (H)std::fabs((double)((H)rel_npart_h[i] * (H)cfg.lsynctime / (H)(rel.end[i] - rel.start[i])));
+          if (itime == rel.start[i] || itime == rel.end[i]) rfraction = rfraction / (H)2.;
+          rfraction = rfraction * avg;
+          rfraction = rfraction + xmasssave[i];
+          numrel = (long long)(int)rfraction;
+          xmasssave[i] = rfraction - (H)(int)numrel;
+        } else numrel = rel_npart_h[i];
+        for (int k = 0; k < ns; k++) mass[(size_t)k * np + i] = (H)rel_xmass_h[(size_t)k * np + i] / (H)rel_npart_h[i] * tc[k] / avg;
+        if (numrel > 0 && rel.kindz[i] == 3) any_p3 = true;
+      }
+      first[i + 1] = first[i] + std::max<long long>(numrel, 0);
+    }
+    const long long ntotal = first[np];
+    if (nreleased) *nreleased = ntotal;
+    if (ntotal == 0) return 0;
+    const bool dens = rel.ind_rel == 1 || rel.ind_rel == 3 || rel.ind_rel == 4;
+    if (V.numbnests > 0) return fail(FPX_ERR_UNSUPPORTED, "releaseparticles: nested met grids are configured (oron, rhon, ttn of releaseparticles.f90:206-341 are not wired)");
+    if (!height_set || !diag_have[DG_ORO]) return fail(FPX_ERR_STATE, "releaseparticles: height and oro (fpx_upload_diag_fields slot 0) are needed");
+    if ((any_p3 || dens) && !slot_loaded[1]) return fail(FPX_ERR_STATE, "releaseparticles: rho of time slot 2 is needed (kindz = 3 or ind_rel = 1, 3, 4)");
+    if (any_p3 && !diag_have[DG_TT + 1]) return fail(FPX_ERR_STATE, "releaseparticles: tt of time slot 2 is needed for kindz = 3 (fpx_upload_diag_fields slot 2)");
+    numpart = *numpart_io;
+    // ---- the k-th particle takes the k-th vacant storage space in particle-number order (:133-137) --------
+    const long long cap = P.cap;
+    std::vector<void *> mine;
+    auto cleanup = [&]() { for (void *q : mine) (void)hipFree(q); };
+    auto mal = [&](auto **q, size_t n) -> hipError_t { hipError_t e = hipMalloc((void **)q, std::max<size_t>(n, 1) * sizeof(**q)); if (e == hipSuccess) mine.push_back(*q); return e; };
+    unsigned int *flags = nullptr, *rank = nullptr, *target = nullptr, *d_max = nullptr;
+    long long *d_first = nullptr;
+    H *d_pts = nullptr, *d_mass = nullptr, *d_uni = nullptr, *d_rho = nullptr;
+    short *d_kindz = nullptr;
+    void *tmp = nullptr;
+    hipError_t e = mal(&flags, (size_t)cap);
+    if (e == hipSuccess) e = mal(&rank, (size_t)cap);
+    if (e == hipSuccess) e = mal(&target, (size_t)ntotal);
+    if (e == hipSuccess) e = mal(&d_max, 1);
+    if (e == hipSuccess) e = mal(&d_first, (size_t)np + 1);
+    if (e == hipSuccess) e = mal(&d_pts, (size_t)6 * np);
+    if (e == hipSuccess) e = mal(&d_mass, (size_t)ns * np);
+    if (e == hipSuccess) e = mal(&d_kindz, (size_t)np);
+    if (e == hipSuccess) e = mal(&d_rho, (size_t)np);
+    size_t tb = 0;
+    if (e == hipSuccess) {
+      (void)rocprim::exclusive_scan(nullptr, tb, flags, rank, 0u, (size_t)cap, rocprim::plus<unsigned int>(), stream);
+      e = hipMalloc(&tmp, std::max<size_t>(tb, 16));
+      if (e == hipSuccess) mine.push_back(tmp);
+    }
+    if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("releaseparticles: ") + hipGetErrorString(e)); }
+    const int nbc = (int)((cap + kBlock - 1) / kBlock);
+    k_rel_flags<R><<<nbc, kBlock, 0, stream>>>(P, slot_of_pid, cap, itime, flags);
+    e = rocprim::exclusive_scan(tmp, tb, flags, rank, 0u, (size_t)cap, rocprim::plus<unsigned int>(), stream);
+    unsigned int last[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[0], rank + (cap - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], flags + (cap - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_DEVICE, std::string("releaseparticles: ") + hipGetErrorString(e)); }
+    if ((long long)last[0] + last[1] < ntotal) {
+      cleanup();
+      return fail(FPX_ERR_NOMEM, "releaseparticles: total number of particles required exceeds the maximum allowed number (releaseparticles.f90:369-378)");
+    }
+    k_rel_targets<<<nbc, kBlock, 0, stream>>>(flags, rank, cap, ntotal, target);
+    // ---- the four uniforms of every particle: serial ran1 stream (x, y, class, z per particle) or counter RNG ----
+    std::vector<H> uni;
+    if (cfg.rng_mode == FPX_RNG_TABLE_SEQ) {
+      uni.resize((size_t)4 * ntotal);
+      for (long long k = 0; k < ntotal; k++)
+        for (int d = 0; d < 4; d++) uni[(size_t)d * ntotal + k] = rel_ran1.template next<H>();
+      e = mal(&d_uni, (size_t)4 * ntotal);
+      if (e == hipSuccess) e = hipMemcpyAsync(d_uni, uni.data(), uni.size() * sizeof(H), hipMemcpyHostToDevice, stream);
+    }
+    std::vector<H> pts((size_t)6 * np);
+    for (int i = 0; i < np; i++) { pts[i] = xp1[i]; pts[np + i] = xaux[i]; pts[2 * np + i] = yp1[i]; pts[3 * np + i] = yaux[i]; pts[4 * np + i] = zp1[i]; pts[5 * np + i] = zaux[i]; }
+    std::vector<H> rho_h(np, (H)0);
+    if (rho_rel) for (int i = 0; i < np; i++) rho_h[i] = rho_rel[i];
+    if (e == hipSuccess) e = hipMemcpyAsync(d_first, first.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_pts, pts.data(), pts.size() * sizeof(H), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_mass, mass.data(), mass.size() * sizeof(H), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_kindz, rel.kindz.data(), np * sizeof(short), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rho, rho_h.data(), np * sizeof(H), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, 4, stream);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(stream); cleanup(); return fail(FPX_ERR_DEVICE, std::string("releaseparticles: ") + hipGetErrorString(e)); }
+    RelPoints<H> RP{d_first, d_pts, d_pts + np, d_pts + 2 * np, d_pts + 3 * np, d_pts + 4 * np, d_pts + 5 * np, d_mass, d_kindz, np};
+    DiagP<H> D;
+    D.oro = (const H *)diag_oro; D.tropo[0] = (const H *)diag_tropo[0]; D.tropo[1] = (const H *)diag_tropo[1]; D.d3 = (const H *)diag_d3;
+    D.nxmax = cfg.nxmax; D.nymax = cfg.nymax; D.dx = (H)cfg.dx; D.dy = (H)cfg.dy; D.xlon0 = (H)cfg.xlon0; D.ylat0 = (H)cfg.ylat0;
+    k_release<R, H><<<(int)((ntotal + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, P, D, RP, target, slot_of_pid, ntotal, itime, d_uni, (int)*npc_io,
+                                                                                  cfg.mintime, rel.itsplit, rel.ind_rel, rel.nclassunc, cfg.mquasilag,
+                                                                                  dens ? d_rho : (H *)nullptr, d_max);
+    e = hipGetLastError();
+    unsigned int maxpid = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&maxpid, d_max, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && rho_rel && dens) e = hipMemcpyAsync(rho_h.data(), d_rho, np * sizeof(H), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); else (void)hipStreamSynchronize(stream);
+    cleanup();
+    if (e != hipSuccess) return fail(FPX_ERR_DEVICE, std::string("releaseparticles: ") + hipGetErrorString(e));
+    if (rho_rel && dens) for (int i = 0; i < np; i++) rho_rel[i] = rho_h[i];
+    numpart = std::max<long long>(numpart, (long long)maxpid + 1);          // :362
+    *numpart_io = numpart;
+    *npc_io = (int32_t)(*npc_io + ntotal);
+    maybe_new = true;
+    return 0;
+  }
+  int releaseparticles(int itime, int64_t *numpart_io, int32_t *npc_io, void *xmasssave, void *rho_rel, int64_t *nreleased) override {
+    if (!rel.set) return fail(FPX_ERR_STATE, "releaseparticles: fpx_release_init first");
+    if (!numpart_io || !npc_io || !xmasssave) return fail(FPX_ERR_ARG, "releaseparticles: numpart, numparticlecount and xmasssave are required");
+    if (*numpart_io < 0 || *numpart_io > P.cap) return fail(FPX_ERR_ARG, "releaseparticles: numpart outside capacity");
+    return cfg.host_real_bytes == 4 ? release_t<float>(itime, numpart_io, npc_io, (float *)xmasssave, (float *)rho_rel, nreleased)
+                                    : release_t<double>(itime, numpart_io, npc_io, (double *)xmasssave, (double *)rho_rel, nreleased);
+  }
+  int split_particles(int itime, int64_t *numpart_io) override {
+    if (!rel.set) return fail(FPX_ERR_STATE, "split_particles: fpx_release_init first (itsplit)");
+    if (!numpart_io || *numpart_io < 0 || *numpart_io > P.cap) return fail(FPX_ERR_ARG, "split_particles: numpart outside capacity");
+    numpart = *numpart_io;
+    if (!(cfg.ldirect * itime >= cfg.ldirect * rel.itsplit) || numpart == 0 || numpart == P.cap) return 0;   // timemanager.f90:473
+    const long long n = numpart, room = P.cap - n;
+    unsigned int *flags = nullptr, *rank = nullptr;
+    void *tmp = nullptr;
+    auto cleanup = [&]() { if (flags) (void)hipFree(flags); if (rank) (void)hipFree(rank); if (tmp) (void)hipFree(tmp); };
+    hipError_t e = hipMalloc(&flags, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc(&rank, (size_t)n * 4);
+    size_t tb = 0;
+    if (e == hipSuccess) {
+      (void)rocprim::exclusive_scan(nullptr, tb, flags, rank, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
+      e = hipMalloc(&tmp, std::max<size_t>(tb, 16));
+    }
+    if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("split_particles: ") + hipGetErrorString(e)); }
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    k_split_flags<R><<<nb, kBlock, 0, stream>>>(P, slot_of_pid, n, itime, cfg.ldirect, flags);
+    e = rocprim::exclusive_scan(tmp, tb, flags, rank, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
+    unsigned int last[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[0], rank + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], flags + (n - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e == hipSuccess) {
+      k_split<R><<<nb, kBlock, 0, stream>>>(P, slot_of_pid, flags, rank, n, room, cfg.nspec);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); else (void)hipStreamSynchronize(stream);
+    cleanup();
+    if (e != hipSuccess) return fail(FPX_ERR_DEVICE, std::string("split_particles: ") + hipGetErrorString(e));
+    numpart = n + std::min<long long>((long long)last[0] + last[1], room);
+    *numpart_io = numpart;
+    return 0;
+  }
 
   // ---- concoutput: the grid_conc files ------------------------------------
   int concoutput(int itime, const fpx_concout *c, const char *prefix, int clear) override {
@@ -2061,6 +2493,7 @@ struct Engine : EngineBase {
     if (p->idt) { if ((rc = put<int, int>(p->idt, P.idt, first, count))) return rc; } else if ((rc = fill<int>(P.idt, 0, first, count))) return rc;
     if (p->npoint) { if ((rc = put<int, int>(p->npoint, P.npoint, first, count))) return rc; } else if ((rc = fill<int>(P.npoint, 1, first, count))) return rc;
     if (p->nclass) { if ((rc = put<int, int>(p->nclass, P.nclass, first, count))) return rc; } else if ((rc = fill<int>(P.nclass, 1, first, count))) return rc;
+    if (p->itrasplit && (rc = put<int, int>(p->itrasplit, P.itrasplit, first, count))) return rc;
     if (p->cbt) { if ((rc = put<short, short>(p->cbt, P.cbt, first, count))) return rc; } else if ((rc = fill<short>(P.cbt, (short)1, first, count))) return rc;
     for (int ks = 0; ks < cfg.nspec; ks++) {
       R *dst = P.xmass1 + (size_t)ks * P.cap;
@@ -2093,6 +2526,7 @@ struct Engine : EngineBase {
     if (p->idt && (rc = get<int, int>(p->idt, P.idt, first, count))) return rc;
     if (p->npoint && (rc = get<int, int>(p->npoint, P.npoint, first, count))) return rc;
     if (p->nclass && (rc = get<int, int>(p->nclass, P.nclass, first, count))) return rc;
+    if (p->itrasplit && (rc = get<int, int>(p->itrasplit, P.itrasplit, first, count))) return rc;
     if (p->cbt && (rc = get<short, short>(p->cbt, P.cbt, first, count))) return rc;
     if (p->xmass1)
       for (int ks = 0; ks < cfg.nspec; ks++) {
@@ -2128,6 +2562,10 @@ struct Engine : EngineBase {
     HIPCHK(hipMemcpyAsync(d_s, nsp.data(), (size_t)numpoint, hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
     V.rel_xmass = d_x; V.rel_npart = d_n; V.rel_nsp = d_s; V.numpoint = numpoint;
+    rel_xmass_h.resize(xm.size());
+    for (size_t i = 0; i < xm.size(); i++) rel_xmass_h[i] = cfg.host_real_bytes == 4 ? (double)((const float *)xmass)[i] : ((const double *)xmass)[i];
+    rel_npart_h.assign(npart, npart + numpoint);
+    rel.set = false;         // the release tables refer to these points: fpx_release_init again
     return 0;
   }
 
@@ -2384,11 +2822,21 @@ struct Engine : EngineBase {
     if ((rc = dalloc(&Q.yt, cap))) return rc;
     R **rs[] = {&Q.zt, &Q.up, &Q.vp, &Q.wp, &Q.us, &Q.vs, &Q.ws};
     for (auto q : rs) if ((rc = dalloc(q, cap))) return rc;
-    int **is[] = {&Q.idt, &Q.itra1, &Q.itramem, &Q.npoint, &Q.nclass};
+    int **is[] = {&Q.idt, &Q.itra1, &Q.itramem, &Q.npoint, &Q.nclass, &Q.itrasplit};
     for (auto q : is) if ((rc = dalloc(q, cap))) return rc;
     if ((rc = dalloc(&Q.cbt, cap))) return rc;
     if ((rc = dalloc(&Q.xmass1, cap * cfg.nspec))) return rc;
     if ((rc = dalloc(&Q.pid, cap))) return rc;
+    {   // zeroed like the first set (storage spaces behind numpart keep their contents across the ping-pong)
+      R *rz[] = {Q.zt, Q.up, Q.vp, Q.wp, Q.us, Q.vs, Q.ws};
+      for (R *q : rz) HIPCHK(hipMemsetAsync(q, 0, cap * sizeof(R), stream));
+      HIPCHK(hipMemsetAsync(Q.xt, 0, cap * sizeof(double), stream));
+      HIPCHK(hipMemsetAsync(Q.yt, 0, cap * sizeof(double), stream));
+      HIPCHK(hipMemsetAsync(Q.xmass1, 0, cap * cfg.nspec * sizeof(R), stream));
+      int *iz[] = {Q.idt, Q.itramem, Q.npoint, Q.nclass, Q.itrasplit};
+      for (int *q : iz) HIPCHK(hipMemsetAsync(q, 0, cap * sizeof(int), stream));
+      HIPCHK(hipMemsetAsync(Q.cbt, 0, cap * sizeof(short), stream));
+    }
     return 0;
   }
 
@@ -2943,6 +3391,12 @@ int fpx_upload_particles(fpx_handle h, int64_t first, int64_t count, const fpx_p
 int fpx_download_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p) { FPX_GUARD(h); return h->impl->download_particles(first, count, p); }
 int fpx_set_numpart(fpx_handle h, int64_t n) { FPX_GUARD(h); return h->impl->set_numpart(n); }
 int fpx_set_release_points(fpx_handle h, int32_t numpoint, const void *xmass, const int32_t *npart) { FPX_GUARD(h); return h->impl->set_release_points(numpoint, xmass, npart); }
+int fpx_release_init(fpx_handle h, const fpx_release *r) { FPX_GUARD(h); return h->impl->release_init(r); }
+int fpx_releaseparticles(fpx_handle h, int32_t itime, int64_t *numpart, int32_t *numparticlecount, void *xmasssave, void *rho_rel, int64_t *nreleased) {
+  FPX_GUARD(h);
+  return h->impl->releaseparticles(itime, numpart, numparticlecount, xmasssave, rho_rel, nreleased);
+}
+int fpx_split_particles(fpx_handle h, int32_t itime, int64_t *numpart) { FPX_GUARD(h); return h->impl->split_particles(itime, numpart); }
 int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *st) { FPX_GUARD(h); return h->impl->step(itime, st, false); }
 int fpx_step_async(fpx_handle h, int32_t itime) { FPX_GUARD(h); return h->impl->step(itime, nullptr, true); }
 int fpx_sync(fpx_handle h) { FPX_GUARD(h); return h->impl->sync(); }

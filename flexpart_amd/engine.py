@@ -272,10 +272,10 @@ class Engine:
         self.partoutput_device_ms = ms.value
         return int(n.value)
 
-    def readpartpositions(self, path, jul_header, bdate, mintime, nclassunc=1):
+    def readpartpositions(self, path, jul_header, bdate, mintime, nclassunc=1, itrasplit=999999999):
         """fpx_readpartpositions: warm start from the dump `path`; -> (numpart, numparticlecount, itimein)."""
         from ._lib import FpxRestart
-        r = FpxRestart(float(jul_header), float(bdate), int(mintime), int(nclassunc))
+        r = FpxRestart(float(jul_header), float(bdate), int(mintime), int(nclassunc), int(itrasplit), 0)
         n = C.c_int64(0); npc = C.c_int32(0); it = C.c_int32(0)
         check(self.lib.fpx_readpartpositions(self.h, str(path).encode(), C.byref(r), C.byref(n), C.byref(npc), C.byref(it)),
               "fpx_readpartpositions")
@@ -349,6 +349,46 @@ class Engine:
               "fpx_set_release_points")
         self.numpoint = int(npt.size)
 
+    # ---- releaseparticles + splitting on the device ------------------------------------------------------
+    def release_init(self, rs):
+        """fpx_release_init from a release scenario dict (synthetic.release_case): the point_mod / com_mod tables."""
+        from ._lib import FpxRelease
+        rt = self.hreal
+        nsp, np_ = self.nspec, int(rs["numpoint"])
+        self.set_release_points(np.asarray(rs["xmass"]).reshape(nsp, np_), rs["npart_rel"])
+        keep = {}
+        r = FpxRelease()
+        r.struct_bytes = C.sizeof(FpxRelease)
+        r.numpoint = np_
+        for k in ("ireleasestart", "ireleaseend"):
+            keep[k] = np.ascontiguousarray(np.asarray(rs[k], dtype=np.int32)); setattr(r, k, keep[k].ctypes.data)
+        keep["kindz"] = np.ascontiguousarray(np.asarray(rs["kindz"], dtype=np.int16)); r.kindz = keep["kindz"].ctypes.data
+        for k in ("xpoint1", "xpoint2", "ypoint1", "ypoint2", "zpoint1", "zpoint2"):
+            keep[k] = np.ascontiguousarray(np.asarray(rs[k]).astype(rt)); setattr(r, k, keep[k].ctypes.data)
+        for k, n2 in (("point_hour", 24), ("area_hour", 24), ("point_dow", 7), ("area_dow", 7)):
+            if k in rs:       # given compact [n2][nspec]; the host arrays are (maxspec, n2) column-major with maxspec = nspec here
+                keep[k] = np.ascontiguousarray(np.asarray(rs[k]).reshape(n2, nsp).astype(rt)); setattr(r, k, keep[k].ctypes.data)
+        r.bdate = float(rs["bdate_jul"])
+        sw = [int(v) for v in rs["switches"]]
+        r.itsplit, r.ind_rel, r.nclassunc = sw[3], sw[4], int(rs.get("nclassunc", 1))
+        check(self.lib.fpx_release_init(self.h, C.byref(r)), "fpx_release_init")
+        self.xmasssave = np.zeros(np_, rt)
+        self.rho_rel = np.zeros(np_, rt)
+        self.numparticlecount = 0
+
+    def releaseparticles(self, itime):
+        """fpx_releaseparticles; returns the number of particles released; self.n (numpart) follows."""
+        n = C.c_int64(self.n); npc = C.c_int32(self.numparticlecount); nrel = C.c_int64(0)
+        check(self.lib.fpx_releaseparticles(self.h, int(itime), C.byref(n), C.byref(npc), _vp(self.xmasssave), _vp(self.rho_rel),
+                                            C.byref(nrel)), "fpx_releaseparticles")
+        self.n, self.numparticlecount = int(n.value), int(npc.value)
+        return int(nrel.value)
+
+    def split_particles(self, itime):
+        n = C.c_int64(self.n)
+        check(self.lib.fpx_split_particles(self.h, int(itime), C.byref(n)), "fpx_split_particles")
+        self.n = int(n.value)
+
     def set_windtime(self, memtime, memind):
         mt = (C.c_int32 * 2)(int(memtime[0]), int(memtime[1]))
         mi = (C.c_int32 * 2)(int(memind[0]), int(memind[1]))
@@ -368,7 +408,7 @@ class Engine:
         put("xtra1", "xtra1", np.float64); put("ytra1", "ytra1", np.float64); put("ztra1", "ztra1", rt)
         for k in ("uap", "ucp", "uzp", "us", "vs", "ws"):
             put(k, k, rt)
-        for k in ("itra1", "itramem", "idt", "npoint", "nclass"):
+        for k in ("itra1", "itramem", "idt", "npoint", "nclass", "itrasplit"):
             put(k, k, np.int32)
         put("cbt", "cbt", np.int16)
         if "xmass1" in sc:
@@ -392,7 +432,7 @@ class Engine:
                    uap=np.empty(n, rt), ucp=np.empty(n, rt), uzp=np.empty(n, rt), us=np.empty(n, rt),
                    vs=np.empty(n, rt), ws=np.empty(n, rt), itra1=np.empty(n, np.int32),
                    itramem=np.empty(n, np.int32), idt=np.empty(n, np.int32), npoint=np.empty(n, np.int32),
-                   nclass=np.empty(n, np.int32), cbt=np.empty(n, np.int16),
+                   nclass=np.empty(n, np.int32), itrasplit=np.empty(n, np.int32), cbt=np.empty(n, np.int16),
                    xmass1=np.empty((self.nspec, n), rt))
         p = FpxParticles()
         for k, a in out.items():

@@ -19,7 +19,8 @@ module flexgpu_mod
   use iso_c_binding
   use par_mod
   use com_mod
-  use point_mod, only: xmass, npart
+  use point_mod, only: xmass, npart, ireleasestart, ireleaseend, kindz, xpoint1, xpoint2, ypoint1, ypoint2, zpoint1, zpoint2, rho_rel
+  use xmass_mod, only: xmasssave
   use outg_mod, only: outheight, area, volume
   use unc_mod, only: gridunc, drygridunc, wetgridunc, griduncn, drygriduncn, wetgriduncn
   implicit none
@@ -30,7 +31,8 @@ module flexgpu_mod
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
-            flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host
+            flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, &
+            flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -87,7 +89,7 @@ module flexgpu_mod
 
   type, bind(C) :: fpx_restart
     real(c_double) :: jul_header, bdate
-    integer(c_int32_t) :: mintime, nclassunc
+    integer(c_int32_t) :: mintime, nclassunc, itrasplit, reserved
   end type fpx_restart
 
   type, bind(C) :: fpx_concout
@@ -115,7 +117,18 @@ module flexgpu_mod
     type(c_ptr) :: cbt
     type(c_ptr) :: xmass1
     integer(c_int64_t) :: xmass1_ld
+    type(c_ptr) :: itrasplit
   end type fpx_particles
+
+  type, bind(C) :: fpx_release
+    integer(c_int32_t) :: struct_bytes, numpoint
+    type(c_ptr) :: ireleasestart, ireleaseend, kindz
+    type(c_ptr) :: xpoint1, xpoint2, ypoint1, ypoint2, zpoint1, zpoint2
+    type(c_ptr) :: point_hour, area_hour, point_dow, area_dow
+    real(c_double) :: bdate
+    integer(c_int32_t) :: itsplit, ind_rel, nclassunc
+    integer(c_int32_t) :: reserved(5)
+  end type fpx_release
 
   type, bind(C) :: fpx_step_stats
     integer(c_int64_t) :: n_due, n_initialized, n_left_domain, n_min_mass, n_max_age
@@ -132,6 +145,24 @@ module flexgpu_mod
     integer(c_int) function fpx_destroy(h) bind(C, name='fpx_destroy')
       import :: c_ptr, c_int
       type(c_ptr), value :: h
+    end function
+    integer(c_int) function fpx_release_init(h, r) bind(C, name='fpx_release_init')
+      import :: c_ptr, c_int, fpx_release
+      type(c_ptr), value :: h
+      type(fpx_release), intent(in) :: r
+    end function
+    integer(c_int) function fpx_releaseparticles(h, itime, numpart, npc, xmasssave, rho_rel, nreleased) bind(C, name='fpx_releaseparticles')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t
+      type(c_ptr), value :: h, xmasssave, rho_rel, nreleased
+      integer(c_int32_t), value :: itime
+      integer(c_int64_t), intent(inout) :: numpart
+      integer(c_int32_t), intent(inout) :: npc
+    end function
+    integer(c_int) function fpx_split_particles(h, itime, numpart) bind(C, name='fpx_split_particles')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: itime
+      integer(c_int64_t), intent(inout) :: numpart
     end function
     integer(c_int) function fpx_set_release_points(h, numpoint, xmass, npart) bind(C, name='fpx_set_release_points')
       import :: c_ptr, c_int, c_int32_t
@@ -580,6 +611,7 @@ contains
     r%bdate = bdate
     r%mintime = mintime
     r%nclassunc = nclassunc
+    r%itrasplit = ldirect * itsplit; r%reserved = 0
     ierr = fpx_readpartpositions(flexgpu_handle, path(2)(1:length(2)) // 'partposit_end' // c_null_char, r, np, npc, itimein)
     if (ierr /= 0) return
     numpart = int(np)
@@ -731,9 +763,51 @@ contains
     p%npoint = loc_i(npoint(j1:)); p%nclass = loc_i(nclass(j1:)); p%cbt = loc_i2(cbt(j1:))
     p%xmass1 = loc_r(xmass1(j1:,1))
     p%xmass1_ld = size(xmass1, 1)
+    p%itrasplit = loc_i(itrasplit(j1:))
   end subroutine particle_ptrs
 
   ! particles j1..j2 (Fortran numbering) host -> device / device -> host
+  ! ---- releaseparticles + the splitting block on the device (SURVEY section 8 f2) ----------------------------
+  ! after readreleases (point_mod arrays) and flexgpu_init: hands the release tables to the engine
+  subroutine flexgpu_release_init(ierr)
+    integer, intent(out) :: ierr
+    type(fpx_release) :: r
+    r%struct_bytes = int(c_sizeof(r), c_int32_t)
+    r%numpoint = numpoint
+    r%ireleasestart = loc_i(ireleasestart); r%ireleaseend = loc_i(ireleaseend); r%kindz = loc_i2(kindz)
+    r%xpoint1 = loc_r(xpoint1); r%xpoint2 = loc_r(xpoint2); r%ypoint1 = loc_r(ypoint1); r%ypoint2 = loc_r(ypoint2)
+    r%zpoint1 = loc_r(zpoint1); r%zpoint2 = loc_r(zpoint2)
+    r%point_hour = loc_r(point_hour); r%area_hour = loc_r(area_hour); r%point_dow = loc_r(point_dow); r%area_dow = loc_r(area_dow)
+    r%bdate = bdate
+    r%itsplit = itsplit; r%ind_rel = ind_rel; r%nclassunc = nclassunc
+    r%reserved = 0
+    ierr = fpx_release_init(flexgpu_handle, r)
+  end subroutine flexgpu_release_init
+
+  ! replaces `call releaseparticles(itime)` (timemanager.f90:246): numpart, numparticlecount (com_mod), xmasssave
+  ! (xmass_mod) and rho_rel (point_mod) are updated in place, the new particles exist on the device only
+  subroutine flexgpu_releaseparticles(itime, ierr)
+    integer, intent(in) :: itime
+    integer, intent(out) :: ierr
+    integer(c_int64_t) :: np
+    integer(c_int32_t) :: npc
+    np = numpart; npc = numparticlecount
+    ierr = fpx_releaseparticles(flexgpu_handle, int(itime, c_int32_t), np, npc, loc_r(xmasssave), loc_r(rho_rel), c_null_ptr)
+    if (ierr /= 0) return
+    numpart = int(np); numparticlecount = npc
+  end subroutine flexgpu_releaseparticles
+
+  ! replaces the splitting block of the time manager (timemanager.f90:473-504); itrasplit lives on the device
+  subroutine flexgpu_split_particles(itime, ierr)
+    integer, intent(in) :: itime
+    integer, intent(out) :: ierr
+    integer(c_int64_t) :: np
+    np = numpart
+    ierr = fpx_split_particles(flexgpu_handle, int(itime, c_int32_t), np)
+    if (ierr /= 0) return
+    numpart = int(np)
+  end subroutine flexgpu_split_particles
+
   subroutine flexgpu_upload_particles(j1, j2, ierr)
     integer, intent(in) :: j1, j2
     integer, intent(out) :: ierr

@@ -638,3 +638,53 @@ def add_pptv(co, nx=40, ny=24, nz=12):
     co["rho2"] = (1.2 / (1.0 + z / 8000.0 + 0.5 * (z / 8000.0) ** 2) * (1.0 + 0.02 * _wave(i + 2 * j, nx - 1))).astype(np.float32).astype(np.float64)
     co["weightmolar"] = np.array([350.0, 28.0, 64.0, 100.0, 46.0][: int(co["outgrid"][3])])
     return co
+
+
+# --------------------------------------------------------------------------
+# releaseparticles + particle splitting
+# --------------------------------------------------------------------------
+def release_case(nx=48, ny=32, nz=24, *, nspec=2, ind_rel=1, mquasilag=0, maxpart=100000, itsplit=1800, existing=400,
+                 times=(0, 900, 1800, 2700, 3600), global_grid=True, ibdate=20200615, ibtime=120000):
+    """RELEASES with five release points of every kind the routine distinguishes: a point source released at one
+    instant (kindz 1), a box released over an interval (area source, metres above ground), a box in metres above sea
+    level (kindz 2: topography subtracted), a box given in pressure (kindz 3: converted with rho and tt of time slot
+    2), and a box across the date line of a global grid (the xglobal wrap).  Particles of a run in progress occupy
+    the first storage spaces, some of them terminated (vacant), some due for splitting.  Local-time emission factors
+    (point_hour, area_dow ...) differ per species."""
+    height = make_height(nz, top=30000.0, lin=0.15)
+    dx = 360.0 / (nx - 1) if global_grid else 1.0
+    dy = 180.0 / (ny - 1) if global_grid else 1.0
+    xlon0, ylat0 = (-180.0, -90.0) if global_grid else (-20.0, 20.0)
+    f = make_fields(nx, ny, nz, height, nspec=nspec)
+    per = nx - 1
+    i = np.arange(nx, dtype=np.int64)[None, :]
+    j = np.arange(ny, dtype=np.int64)[:, None]
+    oro = 300.0 * (1.0 + _wave(2 * i + 3 * j, per)) + 0.0 * j
+    oro[:, nx - 1] = oro[:, 0]
+    rs = dict(grid=np.array([nx, ny, nz], np.int32), geom=np.array([dx, dy, xlon0, ylat0]), xglobal=int(global_grid),
+              height=height, nspec=nspec, bdate=np.array([ibdate, ibtime], np.int32),
+              switches=np.array([1, 900, 1, itsplit, ind_rel, mquasilag, maxpart, 1], np.int32),
+              times=np.asarray(times, np.int32), oro=oro, rho2=f["rho"][1], tt2=f["tt"][1])
+    # release points in grid coordinates (readreleases.f90 converts lon/lat with (x-xlon0)/dx)
+    xm = nx - 1.0 if global_grid else nx - 4.0      # the last box crosses the date line of a global grid only
+    rs.update(numpoint=5,
+              ireleasestart=np.array([0, 0, 900, 0, 900], np.int32), ireleaseend=np.array([0, 3600, 2700, 3600, 900], np.int32),
+              npart_rel=np.array([300, 1000, 800, 600, 500], np.int32), kindz=np.array([1, 1, 2, 3, 1], np.int32),
+              xpoint1=np.array([10.25, 14.0, 20.5, 30.0, xm - 1.5]), xpoint2=np.array([10.25, 17.5, 24.0, 33.0, xm + 1.5]),
+              ypoint1=np.array([12.5, 8.0, 18.0, 10.0, 15.0]), ypoint2=np.array([12.5, 11.0, 21.5, 13.0, 17.0]),
+              zpoint1=np.array([50.0, 0.0, 900.0, 850.0, 100.0]), zpoint2=np.array([50.0, 800.0, 2500.0, 500.0, 3000.0]),
+              xmass=np.array([[1.0, 5.0, 2.0, 1.5, 0.8], [0.5, 0.0, 4.0, 1.0, 0.3]][:nspec]))
+    hour = 1.0 + 0.5 * _wave(np.arange(24)[:, None] * 2 + np.arange(nspec)[None, :] * 5, 24)
+    dow = 1.0 + 0.25 * _wave(np.arange(7)[:, None] * 3 + np.arange(nspec)[None, :], 7)
+    rs.update(point_hour=hour, area_hour=hour[::-1].copy(), point_dow=dow, area_dow=dow[::-1].copy())
+    if existing:
+        n = int(existing)
+        u = _uniform01(n, 77)
+        itra1 = np.zeros(n, np.int32)                      # all synchronised at the first release time ...
+        itra1[::5] = -999999999                            # ... except the terminated ones: vacant storage spaces
+        itramem = -(900 * (1 + (np.arange(n) % 4))).astype(np.int32)
+        rs.update(npart=n, xtra1=2.0 + u * (nx - 5.0), ytra1=2.0 + _uniform01(n, 78) * (ny - 5.0), ztra1=10.0 + 3000.0 * _uniform01(n, 79),
+                  itra1=itra1, itramem=itramem, itrasplit=(itramem + itsplit).astype(np.int32),
+                  npoint=np.ones(n, np.int32), nclass=np.ones(n, np.int32), idt=np.full(n, 1, np.int32),
+                  uap=_uniform01(n, 80) - 0.5, xmass1=np.ones((nspec, n)) * 0.01)
+    return rs

@@ -123,6 +123,7 @@ typedef struct {
   int16_t *cbt;
   void *xmass1;            /* (count or ld, nspec) species-major, leading dim xmass1_ld */
   int64_t xmass1_ld;
+  int32_t *itrasplit;      /* com_mod.f90:683: next time the particle is split (NULL: left alone; 999999999 on a fresh engine) */
 } fpx_particles;
 
 typedef struct {
@@ -226,13 +227,15 @@ int fpx_partoutput_time(fpx_handle h, double *ms);
  * it) is streamed to the device and parsed there into the particle arrays: xtra1 = (xlon-xlon0)/dx,
  * ytra1, ztra1, npoint, xmass1, itramem re-based on this run's start, idt = mintime, itra1 = 0,
  * nclass (ran1 stream, seed -8, when nclassunc > 1), turbulent state zero (the first step calls
- * initialize() for every particle, timemanager.f90:553).  The host keeps reading `header`
- * (:59-113) and passes what it found.  itrasplit stays a host array (ldirect*itsplit). */
+ * initialize() for every particle, timemanager.f90:553), itrasplit = ldirect*itsplit (:117).  The host keeps
+ * reading `header` (:59-113) and passes what it found. */
 typedef struct {
   double jul_header;   /* juldate(ibdatein,ibtimein) of the header file, readpartpositions.f90:133 */
   double bdate;        /* com_mod bdate: start of this run                                        */
   int32_t mintime;     /* com_mod.f90:112                                                          */
   int32_t nclassunc;   /* par_mod.f90:188                                                          */
+  int32_t itrasplit;   /* ldirect*itsplit: the value readpartpositions.f90:117 gives itrasplit(i)   */
+  int32_t reserved;
 } fpx_restart;
 int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
                           int64_t *numpart, int32_t *numparticlecount, int32_t *itimein);
@@ -314,6 +317,48 @@ int fpx_set_numpart(fpx_handle h, int64_t numpart);   /* com_mod numpart */
  * the tables every particle takes species 1).  A particle whose npoint lies outside 1..numpoint
  * (the reference would read outside the arrays) is treated as a particle of the nearest point. */
 int fpx_set_release_points(fpx_handle h, int32_t numpoint, const void *xmass, const int32_t *npart);
+
+/* ---- releaseparticles and particle splitting on the device (SURVEY section 8 f, item 2) --------------------
+ * fpx_releaseparticles replaces `call releaseparticles(itime)` (timemanager.f90:246; the routine:
+ * releaseparticles.f90:63-375): for every release point that is active at itime the number of particles of this
+ * step (local-time emission factors, rfraction / xmasssave bookkeeping: :63-128, on the host in the host's real kind),
+ * then, on the device, per new particle: the k-th particle released takes the k-th storage space with
+ * itra1 /= itime in particle-number order (:133-137,363-367), a random position in the release volume (:139-146,183),
+ * its mass per species (:156-157), nclass, npoint, idt, itra1, itramem, itrasplit (:168-181), topography under the
+ * particle and the conversions for kindz = 2 and 3 (:206-280, rho and tt of the literal time slot 2) and the density
+ * factor for ind_rel = 1, 3, 4 (:300-341).  Arithmetic in the host's real kind without contraction: with the serial
+ * random stream (rng mode FPX_RNG_TABLE_SEQ: ran1, seed -7, four draws per particle replayed on the host) every
+ * array equals the reference's bit for bit; in the counter modes the four uniforms of a particle come from
+ * Philox keyed on (seed, numparticlecount of the particle).  Particles never visit the host.
+ * Needs: fpx_set_release_points (xmass, npart), oro (fpx_upload_diag_fields slot 0); for kindz = 3 also tt of
+ * slot 2 (fpx_upload_diag_fields slot 2 or fpx_verttransform_ecmwf); rho comes from the met fields of slot 2.
+ * Nested met grids: a release inside a nest is refused (FPX_ERR_UNSUPPORTED; oron, rhon, ttn are not wired).
+ * xscav_frac1 (backward deposition runs, :161-166) is not a particle array of the engine. */
+typedef struct {
+  int32_t struct_bytes;
+  int32_t numpoint;
+  const int32_t *ireleasestart, *ireleaseend;            /* (numpoint) point_mod.f90:8-9                      */
+  const int16_t *kindz;                                  /* (numpoint) integer*2, point_mod.f90:11            */
+  const void *xpoint1, *xpoint2, *ypoint1, *ypoint2;     /* (numpoint) grid coordinates, point_mod.f90:13-16  */
+  const void *zpoint1, *zpoint2;                         /* (numpoint) point_mod.f90:17-18                    */
+  const void *point_hour, *area_hour;                    /* (maxspec,24) com_mod.f90:184                      */
+  const void *point_dow, *area_dow;                      /* (maxspec,7)  com_mod.f90:185                      */
+  double bdate;                                          /* com_mod.f90:45 (juldate of the run's start)       */
+  int32_t itsplit, ind_rel, nclassunc;                   /* com_mod.f90:112,75; par_mod.f90:188               */
+  int32_t reserved[5];
+} fpx_release;
+/* The tables are copied; fpx_set_release_points must have been called with the same numpoint. */
+int fpx_release_init(fpx_handle h, const fpx_release *r);
+/* numpart, numparticlecount (com_mod.f90:676,678) and xmasssave(numpoint) (xmass_mod) are the host's own variables,
+ * read and updated like the routine does; rho_rel(numpoint) (point_mod.f90:21) is written for the points that
+ * released with ind_rel = 1, 3, 4 (may be NULL).  nreleased (may be NULL): particles released by this call.
+ * More particles than free storage spaces: FPX_ERR_NOMEM and nothing is released (the reference stops, :369-378). */
+int fpx_releaseparticles(fpx_handle h, int32_t itime, int64_t *numpart, int32_t *numparticlecount, void *xmasssave,
+                         void *rho_rel, int64_t *nreleased);
+/* The splitting block of the time manager, timemanager.f90:473-504: every particle j <= numpart with
+ * ldirect*itime >= ldirect*itrasplit(j) is copied to the next storage space behind numpart (in the order of j, while
+ * there is room), both halves carry half the mass and the doubled splitting interval.  numpart in/out. */
+int fpx_split_particles(fpx_handle h, int32_t itime, int64_t *numpart);
 
 /* ---- the hot path --------------------------------------------------------- */
 /* One pass of the particle loop timemanager.f90:531-712 at time itime. */

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def build(force=False):
     """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
     for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"),
-                      ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle")):
+                      ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle"), ("release_oracle", "librloracle")):
         src = os.path.join(HERE, stem + ".c")
         for kind, real in (("r4", "float"), ("r8", "double")):
             out = os.path.join(HERE, f"{lib}_{kind}.so")
@@ -539,3 +539,88 @@ def co_oracle(co):
                                     g.ctypes.data_as(fp), f3.ctypes.data_as(fp))
             out[f"pptv_{ks + 1:03d}"] = bytes(buf[:nb])
     return out
+
+
+# --------------------------------------------------------------------------
+# releaseparticles + splitting (oracle/release_oracle.c)
+# --------------------------------------------------------------------------
+class _RloArgs(C.Structure):
+    _dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    _fields_ = ([(k, C.c_int) for k in ("nx", "ny", "nz", "xglobal")]
+                + [(k, C.c_double) for k in ("dx", "dy", "xlon0", "ylat0")]
+                + [(k, C.POINTER(C.c_double)) for k in ("height", "oro", "rho2", "tt2")]
+                + [(k, C.c_int) for k in ("nspec", "ldirect", "lsynctime", "mintime", "itsplit", "ind_rel", "mquasilag", "nclassunc", "ibdate", "ibtime")]
+                + [("eps_nxmax", C.c_double), ("numpoint", C.c_int)]
+                + [(k, C.POINTER(C.c_int)) for k in ("ireleasestart", "ireleaseend", "npart", "kindz")]
+                + [(k, C.POINTER(C.c_double)) for k in ("xpoint1", "xpoint2", "ypoint1", "ypoint2", "zpoint1", "zpoint2", "xmass",
+                                                         "point_hour", "area_hour", "point_dow", "area_dow")]
+                + [("maxpart", C.c_long), ("numpart", C.c_long), ("numparticlecount", C.c_int)]
+                + [(k, C.POINTER(C.c_double)) for k in ("xtra1", "ytra1", "ztra1", "uap", "xmass1")]
+                + [(k, C.POINTER(C.c_int)) for k in ("itra1", "itramem", "itrasplit", "idt", "npoint", "nclass")]
+                + [(k, C.POINTER(C.c_double)) for k in ("xmasssave", "rho_rel")]
+                + [("ran1_idum", C.c_int), ("ran1_iy", C.c_int), ("ran1_iv", C.c_int * 32), ("status", C.c_int)])
+
+
+def rl_juldate(yyyymmdd, hhmiss, kind="r8"):
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"librloracle_{kind}.so"))
+    lib.rlo_juldate_pub.restype = C.c_double
+    return lib.rlo_juldate_pub(int(yyyymmdd), int(hhmiss))
+
+
+def rl_oracle(rs, kind="r8"):
+    """The C restatement of releaseparticles + the splitting block on a synthetic.release_case() dict -> list of
+    per-call dicts like scenario_io.run_rel_reference."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"librloracle_{kind}.so"))
+    a = _RloArgs()
+    a.nx, a.ny, a.nz = (int(v) for v in rs["grid"])
+    a.xglobal = int(rs["xglobal"])
+    a.dx, a.dy, a.xlon0, a.ylat0 = (float(v) for v in rs["geom"])
+    sw = [int(v) for v in rs["switches"]]
+    a.nspec = int(rs["nspec"])
+    a.ldirect, a.lsynctime, a.mintime, a.itsplit, a.ind_rel, a.mquasilag = sw[:6]
+    maxpart, do_split = sw[6], sw[7]
+    a.nclassunc = int(rs.get("nclassunc", 1))
+    a.ibdate, a.ibtime = int(rs["bdate"][0]), int(rs["bdate"][1])
+    a.numpoint = int(rs["numpoint"])
+    keep = {}
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    for k in ("height", "oro", "rho2", "tt2", "xpoint1", "xpoint2", "ypoint1", "ypoint2", "zpoint1", "zpoint2", "xmass",
+              "point_hour", "area_hour", "point_dow", "area_dow"):
+        keep[k] = _f64(rs[k]); setattr(a, k, keep[k].ctypes.data_as(dp))
+    for k, kk in (("ireleasestart", "ireleasestart"), ("ireleaseend", "ireleaseend"), ("npart", "npart_rel"), ("kindz", "kindz")):
+        keep[k] = np.ascontiguousarray(np.asarray(rs[kk], dtype=np.int32)); setattr(a, k, keep[k].ctypes.data_as(ip))
+    nsp = a.nspec
+    P = {k: np.zeros(maxpart) for k in ("xtra1", "ytra1", "ztra1", "uap")}
+    P["xmass1"] = np.zeros((nsp, maxpart))
+    for k in ("itra1", "itramem", "itrasplit", "idt", "npoint", "nclass"):
+        P[k] = np.zeros(maxpart, np.int32)
+    P["itra1"][:] = -999999999; P["itrasplit"][:] = 999999999
+    n0 = int(rs.get("npart", 0))
+    rt = np.float32 if kind == "r4" else np.float64      # the host arrays hold default reals (xtra1, ytra1: always 8 bytes)
+    for k in ("xtra1", "ytra1", "ztra1", "uap", "itra1", "itramem", "itrasplit", "idt", "npoint", "nclass"):
+        if k in rs:
+            P[k][:n0] = np.asarray(rs[k]).astype(rt) if k in ("ztra1", "uap") else np.asarray(rs[k])
+    if "xmass1" in rs:
+        P["xmass1"][:, :n0] = np.asarray(rs["xmass1"]).reshape(nsp, n0).astype(rt)
+    for k, v in P.items():
+        setattr(a, k, v.ctypes.data_as(dp if v.dtype == np.float64 else ip))
+    xs, rr = np.zeros(a.numpoint), np.zeros(a.numpoint)
+    a.xmasssave, a.rho_rel = xs.ctypes.data_as(dp), rr.ctypes.data_as(dp)
+    a.maxpart, a.numpart, a.numparticlecount = maxpart, n0, 0
+    lib.rlo_init(C.byref(a))
+    calls = []
+    for itime in (int(t) for t in rs["times"]):
+        lib.rlo_releaseparticles(C.byref(a), itime)
+        if a.status:
+            raise RuntimeError("rlo_releaseparticles: no free storage space left")
+        if do_split:
+            lib.rlo_split(C.byref(a), itime)
+        m = int(a.numpart)
+        c = {k: v[:m].copy() for k, v in P.items() if k != "xmass1"}
+        c["xmass1"] = P["xmass1"][:, :m].copy()
+        c["state"] = np.array([itime, m, int(a.numparticlecount)], np.int32)
+        c["xmasssave"], c["rho_rel"] = xs.copy(), rr.copy()
+        calls.append(c)
+    return calls

@@ -278,3 +278,54 @@ def run_co_reference(co, kind="r4", workdir="/tmp", nest=False):
                 for f in sorted(glob.glob(os.path.join(d, "grid_conc_*")) + glob.glob(os.path.join(d, "grid_pptv_*")))}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+# --------------------------------------------------------------------------
+# releaseparticles + splitting through oracle/_ref/relref_rK (oracle/ref_rel_driver.f90)
+# --------------------------------------------------------------------------
+_REL_ORDER = ["grid", "geom", "xglobal", "height", "nspec", "bdate", "switches", "times", "oro", "rho2", "tt2",
+              "numpoint", "ireleasestart", "ireleaseend", "npart_rel", "kindz", "xpoint1", "xpoint2", "ypoint1", "ypoint2",
+              "zpoint1", "zpoint2", "xmass", "point_hour", "area_hour", "point_dow", "area_dow",
+              "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "itrasplit", "npoint", "nclass", "idt", "uap", "xmass1"]
+_REL_INT = {"grid", "xglobal", "nspec", "bdate", "switches", "times", "numpoint", "ireleasestart", "ireleaseend", "npart_rel", "kindz",
+            "npart", "itra1", "itramem", "itrasplit", "npoint", "nclass", "idt"}
+
+
+def have_rel_ref(kind="r8"):
+    return os.access(os.path.join(HERE, "_ref", f"relref_{kind}"), os.X_OK)
+
+
+def run_rel_reference(rs, kind="r8", workdir="/tmp", gpu=False):
+    """The unmodified releaseparticles (+ our restatement of the splitting block) on a synthetic.release_case() dict
+    -> list of per-call dicts (state = [itime, numpart, numparticlecount], the particle arrays 1..numpart,
+    xmasssave, rho_rel)."""
+    import tempfile
+    os.makedirs(workdir, exist_ok=True)
+    with tempfile.TemporaryDirectory(prefix="rel_", dir=workdir) as d:
+        fs, fo = os.path.join(d, "rel.scen"), os.path.join(d, "rel.out")
+        with open(fs, "wb") as fh:
+            for name in _REL_ORDER:
+                if name not in rs:
+                    continue
+                code = 1 if name in _REL_INT else 2
+                a = np.ascontiguousarray(np.asarray(rs[name], dtype=np.int32 if code == 1 else np.float64).ravel())
+                fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
+                fh.write(a.tobytes())
+            fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
+        exe = os.path.join(HERE, "_ref", f"relref_{kind}")
+        res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {fo}" + (" gpu" if gpu else "")], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"reference releaseparticles driver failed: {res.stdout}\n{res.stderr}")
+        nspec = int(rs["nspec"])
+        calls, cur = [], None
+        for name, a in read_records(fo):
+            if name == "state":
+                cur = {"state": a, "xmass1": []}
+                calls.append(cur)
+            elif name == "xmass1":
+                cur["xmass1"].append(a)
+            else:
+                cur[name] = a
+        for c in calls:
+            c["xmass1"] = np.stack(c["xmass1"]) if c["xmass1"] else np.zeros((nspec, 0))
+        return calls

@@ -1,0 +1,177 @@
+"""releaseparticles + the particle-splitting block of the time manager on the device.
+
+CPU: the C restatement (oracle/release_oracle.c) against the flang build of the unmodified routine
+(oracle/_ref/relref_rK, where present) and against the committed fixtures tests/golden/rel_*.npz.
+GPU: fpx_releaseparticles / fpx_split_particles through the C ABI against the oracle -- bit for bit in the serial
+random-stream mode -- and through the Fortran host."""
+import os
+
+import numpy as np
+import pytest
+
+from flexpart_amd import synthetic as syn
+from oracle import scenario_io as sio
+from oracle.oracle import rl_juldate, rl_oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+KEYS = ("state", "xtra1", "ytra1", "ztra1", "uap", "itra1", "itramem", "itrasplit", "idt", "npoint", "nclass", "xmass1")
+
+CASES = {
+    "global_density": dict(),                                                      # ind_rel = 1, two species, date line
+    "quasilag_mass": dict(ind_rel=0, mquasilag=1, nspec=1),                        # npoint = particle count, no density factor
+    "limited_winter": dict(global_grid=False, ibdate=20201224, ibtime=233000),     # no daylight saving, day-of-week roll-over
+}
+
+
+def case(name):
+    return syn.release_case(**CASES[name])
+
+
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_release_fixtures(name, kind):
+    """tests/golden/rel_<case>_<kind>.npz hold what the unmodified releaseparticles.f90 (flang build) left in the
+    particle arrays after each of five calls (+ the splitting block); the oracle must reproduce every array exactly."""
+    gold = np.load(os.path.join(GOLD, f"rel_{name}_{kind}.npz"))
+    calls = rl_oracle(case(name), kind)
+    assert len(calls) == int(gold["ncalls"])
+    for i, c in enumerate(calls):
+        for k in KEYS + ("xmasssave", "rho_rel"):
+            assert np.array_equal(np.asarray(c[k]), gold[f"c{i}_{k}"]), (name, kind, i, k)
+    # the scenario does what it is there for: vacant spaces re-used, particles split, numpart grown
+    first, last = calls[0], calls[-1]
+    assert first["state"][1] > int(case(name)["npart"]) and last["state"][1] > first["state"][1]
+    assert last["state"][2] > 2000 and len(np.unique(first["itrasplit"])) > 3
+
+
+@pytest.mark.ref
+@pytest.mark.skipif(not sio.have_rel_ref("r8"), reason="flang-built reference not present (GPU box)")
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_oracle_matches_live_release_reference(kind):
+    rs = syn.release_case(nspec=1, ind_rel=3, itsplit=900, ibdate=20210331, ibtime=30000)
+    ref = sio.run_rel_reference(rs, kind)
+    orc = rl_oracle(rs, kind)
+    for c, o in zip(ref, orc):
+        for k in KEYS + ("xmasssave", "rho_rel"):
+            assert np.array_equal(np.asarray(c[k]), np.asarray(o[k])), (kind, c["state"], k)
+
+
+def _engine(rs, kind, rng_mode):
+    from flexpart_amd.engine import Engine
+    rb = 8 if kind == "r8" else 4
+    nx, ny, nz = (int(v) for v in rs["grid"])
+    f = syn.make_fields(nx, ny, nz, rs["height"], nspec=int(rs["nspec"]))
+    sc = syn.base_scenario(nx, ny, nz, global_grid=bool(rs["xglobal"]), nspec=int(rs["nspec"]))
+    sc.update(f)
+    sc["height"] = rs["height"]
+    sc["nmixz"] = syn.nmixz_from_height(rs["height"])
+    sc["rho"] = np.stack([f["rho"][0], np.asarray(rs["rho2"])])
+    sc["tt"] = np.stack([f["tt"][0], np.asarray(rs["tt2"])])
+    sc["oro"] = rs["oro"]
+    sc["pv"] = np.zeros_like(sc["tt"]); sc["qv"] = np.zeros_like(sc["tt"])
+    n0 = int(rs.get("npart", 0))
+    if n0:
+        for k in ("npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "itrasplit", "npoint", "nclass", "idt", "uap", "xmass1"):
+            sc[k] = rs[k]
+    sw = [int(v) for v in rs["switches"]]
+    sc["mquasilag"] = sw[5]
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=rng_mode, max_particles=sw[6])
+    eng.upload_diag_fields_from_scenario(sc)
+    rs = dict(rs, bdate_jul=rl_juldate(int(rs["bdate"][0]), int(rs["bdate"][1]), kind))
+    eng.release_init(rs)
+    return eng
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_release_and_split_match_the_oracle(built, name, kind):
+    """fpx_releaseparticles + fpx_split_particles with the serial ran1 stream: every particle array equals the
+    oracle's (= the reference's) bit for bit after each of the five calls -- vacant storage spaces taken in
+    particle-number order, positions, masses with the local-time emission factors and the density factor, kindz 1/2/3,
+    the date-line wrap, xmasssave, numparticlecount, rho_rel; the splitting copies."""
+    from flexpart_amd.engine import RNG_TABLE_SEQ
+    rs = case(name)
+    want = rl_oracle(rs, kind)
+    eng = _engine(rs, kind, RNG_TABLE_SEQ)
+    for i, itime in enumerate(int(t) for t in rs["times"]):
+        eng.releaseparticles(itime)
+        eng.split_particles(itime)
+        got = eng.download()
+        w = want[i]
+        assert (itime, eng.n, eng.numparticlecount) == tuple(int(v) for v in w["state"])
+        for k in ("xtra1", "ytra1", "ztra1", "uap", "itra1", "itramem", "itrasplit", "idt", "npoint", "nclass", "xmass1"):
+            assert np.array_equal(np.asarray(got[k], dtype=np.float64), np.asarray(w[k], dtype=np.float64)), (name, kind, itime, k)
+        assert np.array_equal(eng.xmasssave.astype(np.float64), w["xmasssave"])
+        assert np.array_equal(eng.rho_rel.astype(np.float64), w["rho_rel"])
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_device_release_after_a_locality_sort_and_with_the_counter_rng(built):
+    """The storage spaces are found by particle number also after the slots were re-ordered by a locality sort; with
+    the counter RNG the positions differ from the serial stream's but every particle lies inside its release volume,
+    masses and bookkeeping are those of the oracle."""
+    from flexpart_amd.engine import RNG_TABLE_SEQ, RNG_PHILOX
+    rs = case("global_density")
+    want = rl_oracle(rs, "r8")
+    eng = _engine(rs, "r8", RNG_TABLE_SEQ)
+    eng.sort()
+    for itime in (int(t) for t in rs["times"]):
+        eng.releaseparticles(itime)
+        eng.split_particles(itime)
+        eng.sort()
+    got = eng.download()
+    eng.close()
+    for k in ("xtra1", "ztra1", "itra1", "itrasplit", "npoint", "xmass1"):
+        assert np.array_equal(np.asarray(got[k], dtype=np.float64), np.asarray(want[-1][k], dtype=np.float64)), k
+    eng = _engine(rs, "r8", RNG_PHILOX)
+    nrel = eng.releaseparticles(0)
+    got = eng.download()
+    eng.close()
+    w = want[0]
+    assert nrel == int(w["state"][2]) and eng.n == int(w["state"][1])
+    new = got["itramem"] == 0
+    assert np.array_equal(new, w["itramem"] == 0) and np.array_equal(got["npoint"], w["npoint"])
+    assert not np.array_equal(got["xtra1"][new], w["xtra1"][new])
+    for p in range(int(rs["numpoint"])):
+        m = new & (got["npoint"] == p + 1)
+        if not m.any():
+            continue       # this point releases later
+        if p < 4:      # the fifth box crosses the date line
+            assert got["xtra1"][m].min() >= rs["xpoint1"][p] - 1e-9 and got["xtra1"][m].max() <= rs["xpoint2"][p] + 1e-9
+        assert got["ytra1"][m].min() >= rs["ypoint1"][p] - 1e-9 and got["ytra1"][m].max() <= rs["ypoint2"][p] + 1e-9
+
+
+@pytest.mark.gpu
+def test_release_refuses_more_particles_than_storage_spaces(built):
+    """More particles than vacant storage spaces: the reference stops (releaseparticles.f90:369-378); the engine returns
+    an error and leaves every array as it was."""
+    from flexpart_amd.engine import RNG_TABLE_SEQ
+    from flexpart_amd._lib import FpxError
+    rs = syn.release_case(maxpart=450)        # 474 particles at itime 0 against 80 vacant + 50 unused spaces
+    eng = _engine(rs, "r8", RNG_TABLE_SEQ)
+    before = eng.download()
+    with pytest.raises(FpxError):
+        eng.releaseparticles(0)
+    after = eng.download()
+    eng.close()
+    assert eng.n == 400 and eng.numparticlecount == 0
+    for k in ("xtra1", "itra1", "npoint", "xmass1"):
+        assert np.array_equal(before[k], after[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_host_releaseparticles(built, kind):
+    """The real Fortran host: relref_rK either calls the reference's releaseparticles and the splitting block, or
+    hands point_mod / com_mod to flexgpu_release_init / flexgpu_releaseparticles / flexgpu_split_particles and
+    downloads the particle arrays -- identical, array for array."""
+    if not sio.have_rel_ref(kind):
+        pytest.skip("oracle/_ref/relref binaries not present in this snapshot")
+    rs = case("global_density")
+    ref = sio.run_rel_reference(rs, kind)
+    gpu = sio.run_rel_reference(rs, kind, gpu=True)
+    for a, b in zip(gpu, ref):
+        for k in KEYS:
+            assert np.array_equal(a[k], b[k]), (kind, b["state"], k)
