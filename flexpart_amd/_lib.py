@@ -73,6 +73,15 @@ class FpxFieldsOut(C.Structure):
                [("nmixz", C.POINTER(C.c_int32))]
 
 
+class FpxCalcparIn(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("surfstr", "sshf", "akm", "bkm", "excessoro", "vdep")] + \
+               [("lsubgrid", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class FpxCalcparOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ustar", "wstar", "oli", "hmix", "tropopause")]
+
+
 class FpxDiagFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("oro", "pv", "qv", "tt")]
 
@@ -158,7 +167,7 @@ SYMBOLS = [
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
-    "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
+    "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_calcpar", "fpx_calcpar_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
 ]
 
 _lib = None
@@ -193,6 +202,8 @@ def load():
     lib.fpx_verttransform_ecmwf.argtypes = [vp, C.c_int32, C.POINTER(FpxModelLevels), C.POINTER(FpxFields), C.POINTER(FpxFieldsOut)]
     lib.fpx_verttransform_nest.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(FpxModelLevels), C.POINTER(FpxFields), C.POINTER(FpxFieldsOut)]
     lib.fpx_verttransform_time.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.fpx_calcpar.argtypes = [vp, C.c_int32, C.POINTER(FpxCalcparIn), C.POINTER(FpxCalcparOut)]
+    lib.fpx_calcpar_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.fpx_upload_diag_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxDiagFields)]
     lib.fpx_partoutput.argtypes = [vp, C.c_int32, C.c_char_p, C.POINTER(C.c_int64)]
     lib.fpx_partoutput_time.argtypes = [vp, C.POINTER(C.c_double)]

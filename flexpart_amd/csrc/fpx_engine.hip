@@ -20,6 +20,7 @@
 #include "../../include/flexpart_amd.h"
 #include "fpx_device.hpp"
 #include "fpx_verttransform.hpp"
+#include "fpx_calcpar.hpp"
 #include "fpx_rng_host.hpp"
 
 namespace fpx {
@@ -1138,6 +1139,8 @@ struct EngineBase {
   virtual int upload_fields(int slot, const fpx_fields *f) = 0;
   virtual int verttransform(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) = 0;
   virtual int verttransform_nest(int nest, int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) = 0;
+  virtual int calcpar(int slot, const fpx_calcpar_in *c, const fpx_calcpar_out *out) = 0;
+  virtual double cp_ms() = 0;
   virtual int set_windtime(const int32_t mt[2], const int32_t mi[2]) = 0;
   virtual int rng_fill_table() = 0;
   virtual int rng_set_table(const void *t, int n) = 0;
@@ -1656,7 +1659,7 @@ struct Engine : EngineBase {
     // the 2-D fields calcpar / calcpar_nests leave on the host
     g_nx = gnx; g_ny = gny; g_nxmax = gnxmax; g_nymax = gnymax;
     rc = 0;
-    do {
+    if (sfc) do {
       if ((rc = p2(sfc->ustar, t_sfc, 8, s * 4 + 0)) || (rc = p2(sfc->wstar, t_sfc, 8, s * 4 + 1)) ||
           (rc = p2(sfc->oli, t_sfc, 8, s * 4 + 2)) || (rc = p2(sfc->hmix, t_sfc, 8, s * 4 + 3))) break;
       if (slot == 1 && (rc = p2(sfc->tropopause, t_tropo, 1, 0))) break;
@@ -1668,11 +1671,12 @@ struct Engine : EngineBase {
     g_nx = cfg.nx; g_ny = cfg.ny; g_nxmax = cfg.nxmax; g_nymax = cfg.nymax;
     if (rc) return rc;
     if (!nest) {
-      if ((rc = diag_alloc()) || (rc = diag2_from_host(diag_tropo[s], sfc->tropopause, DG_TROPO + s))) return rc;
+      if ((rc = diag_alloc())) return rc;
+      if (sfc && (rc = diag2_from_host(diag_tropo[s], sfc->tropopause, DG_TROPO + s))) return rc;
       // pv, qv, tt of this slot stay on the device for partoutput
       if ((rc = diag3(D(PV), true, 0, s)) || (rc = diag3(D(QV), true, 1, s)) || (rc = diag3(D(TT), true, 2, s))) return rc;
     }
-    k_hcell<R><<<(gnx * gny + kBlock - 1) / kBlock, kBlock, 0, stream>>>(t_sfc, (R *)t_hcell, gnx, gny);
+    if (sfc) k_hcell<R><<<(gnx * gny + kBlock - 1) / kBlock, kBlock, 0, stream>>>(t_sfc, (R *)t_hcell, gnx, gny);
     HIPCHK(hipGetLastError());
     if (out) {   // z-level arrays the host still wants (partoutput, convection, cloud diagnostics ...)
       void *dst[10] = {out->uu, out->vv, out->ww, out->tt, out->qv, out->pv, out->rho, out->drhodz, out->uupol, out->vvpol};
@@ -1686,12 +1690,96 @@ struct Engine : EngineBase {
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     vt_last_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (nest) nest_loaded[nest - 1][s] = true; else slot_loaded[s] = true;
+    if (nest) nest_loaded[nest - 1][s] = true; else if (sfc) slot_loaded[s] = true;
+    if (!nest) vt_slot_on_device = slot;      // whose model-level arrays the buffers hold (fpx_calcpar)
     return 0;
+  }
+  int vt_slot_on_device = 0;
+
+  // ---- calcpar on the device ----------------------------------------------------------
+  template <typename H>
+  int calcpar_t(int slot, const fpx_calcpar_in *c, const fpx_calcpar_out *out) {
+    enum { UUH, VVH, PVH, WWH, TTH, QVH, PS, TT2, TD2, AKZ, BKZ, AKN, BKN, HGT,
+           UU, VV, WW, TT, QV, PV, RHO, DRHO, UPOL, VPOL, UVZ, WZ, RHOH, PINM, KUV, KW, NBUF };
+    void **vt_dev = vt_sets[0];
+    auto D = [&](int i) { return (H *)vt_dev[i]; };
+    const int nz = cfg.nz, s = slot - 1;
+    const size_t n2 = (size_t)cfg.nxmax * cfg.nymax;
+    int rc;
+    if (!cp_buf) {
+      H *q = nullptr;
+      if ((rc = dalloc(&q, 8 * n2 + 2 * (size_t)nz))) return rc;       // surfstr, sshf, excessoro, ustar, wstar, oli, hmix, tropopause | akm, bkm
+      HIPCHK(hipMemsetAsync(q, 0, (8 * n2 + 2 * (size_t)nz) * sizeof(H), stream));
+      cp_buf = q;
+    }
+    H *B = (H *)cp_buf;
+    H *d_str = B, *d_shf = B + n2, *d_exc = B + 2 * n2, *d_ust = B + 3 * n2, *d_wst = B + 4 * n2, *d_oli = B + 5 * n2, *d_hmix = B + 6 * n2, *d_akm = B + 8 * n2, *d_bkm = d_akm + nz;
+    H *d_trop = (H *)diag_tropo[s];            // the slot's tropopause in the host's layout (kept for partoutput); stale values persist as in the reference
+    if ((rc = diag_alloc())) return rc;
+    d_trop = (H *)diag_tropo[s];
+    HIPCHK(hipMemcpyAsync(d_str, c->surfstr, n2 * sizeof(H), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_shf, c->sshf, n2 * sizeof(H), hipMemcpyHostToDevice, stream));
+    if (c->lsubgrid == 1) HIPCHK(hipMemcpyAsync(d_exc, c->excessoro, n2 * sizeof(H), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_akm, c->akm, (size_t)nz * sizeof(H), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_bkm, c->bkm, (size_t)nz * sizeof(H), hipMemcpyHostToDevice, stream));
+    cp::Args<H> A;
+    A.G.nx = cfg.nx; A.G.ny = cfg.ny; A.G.nz = nz; A.G.nuvz = nz; A.G.nwz = nz; A.G.nxmax = cfg.nxmax; A.G.nymax = cfg.nymax;
+    A.G.dx = (H)cfg.dx; A.G.dy = (H)cfg.dy; A.G.xlon0 = (H)cfg.xlon0; A.G.ylat0 = (H)cfg.ylat0;
+    A.I = vt::In<H>{D(UUH), D(VVH), D(PVH), D(WWH), D(TTH), D(QVH), D(PS), D(TT2), D(TD2), D(AKZ), D(BKZ), D(AKN), D(BKN), D(HGT)};
+    A.surfstr = d_str; A.sshf = d_shf; A.excessoro = d_exc; A.akm = d_akm; A.bkm = d_bkm; A.lsubgrid = c->lsubgrid;
+    A.zlev = D(RHOH);                          // scratch of the transform, free between calls
+    A.ustar = d_ust; A.wstar = d_wst; A.oli = d_oli; A.hmix = d_hmix; A.tropopause = d_trop;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, stream));
+    cp::k_calcpar<H><<<(cfg.nx * cfg.ny + 255) / 256, 256, 0, stream>>>(A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, stream));
+    // into the gather packs, as upload_fields does from the host's arrays
+    auto pk2 = [&](const H *in, const R *outp, int stride, int off) -> int {
+      const int tot = cfg.nx * cfg.ny;
+      k_pack2<H, R><<<(tot + kBlock - 1) / kBlock, kBlock, 0, stream>>>(in, (R *)outp, cfg.nx, cfg.ny, cfg.nxmax, stride, off);
+      HIPCHK(hipGetLastError());
+      return 0;
+    };
+    if ((rc = pk2(d_ust, V.sfc, 8, s * 4 + 0)) || (rc = pk2(d_wst, V.sfc, 8, s * 4 + 1)) || (rc = pk2(d_oli, V.sfc, 8, s * 4 + 2)) || (rc = pk2(d_hmix, V.sfc, 8, s * 4 + 3))) return rc;
+    if (slot == 1 && (rc = pk2(d_trop, V.tropo, 1, 0))) return rc;        // literal time index 1, advance.f90:253
+    diag_have[DG_TROPO + s] = true;
+    if (V.vdep) {
+      const size_t plane = n2 * cfg.host_real_bytes;
+      for (int ks = 0; ks < cfg.nspec; ks++)
+        if ((rc = p2((const char *)c->vdep + plane * ks, V.vdep, 2 * cfg.nspec, s * cfg.nspec + ks))) return rc;
+    }
+    k_hcell<R><<<(cfg.nx * cfg.ny + kBlock - 1) / kBlock, kBlock, 0, stream>>>(V.sfc, (R *)V.hcell, cfg.nx, cfg.ny);
+    HIPCHK(hipGetLastError());
+    if (out) {
+      void *dst[5] = {out->ustar, out->wstar, out->oli, out->hmix, out->tropopause};
+      const H *src[5] = {d_ust, d_wst, d_oli, d_hmix, d_trop};
+      for (int i = 0; i < 5; i++)
+        if (dst[i]) HIPCHK(hipMemcpyAsync(dst[i], src[i], n2 * sizeof(H), hipMemcpyDeviceToHost, stream));
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    cp_last_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    slot_loaded[s] = true;
+    return 0;
+  }
+  void *cp_buf = nullptr;
+  double cp_last_ms = 0;
+  int calcpar(int slot, const fpx_calcpar_in *c, const fpx_calcpar_out *out) override {
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "calcpar: slot must be 1 or 2");
+    if (!c || !c->surfstr || !c->sshf || !c->akm || !c->bkm) return fail(FPX_ERR_ARG, "calcpar: surfstr, sshf, akm, bkm are required");
+    if (c->lsubgrid == 1 && !c->excessoro) return fail(FPX_ERR_ARG, "calcpar: excessoro required with lsubgrid = 1");
+    if (cfg.drydep && !c->vdep) return fail(FPX_ERR_ARG, "calcpar: vdep (the host's getvdep) required with DRYDEP");
+    if (!vt_set_ready[0] || vt_slot_on_device != slot) return fail(FPX_ERR_STATE, "calcpar: fpx_verttransform_ecmwf of this slot first (its model-level arrays are read on the device)");
+    return cfg.host_real_bytes == 4 ? calcpar_t<float>(slot, c, out) : calcpar_t<double>(slot, c, out);
   }
   double vt_last_ms = 0, po_last_ms = 0;
   double po_ms() override { return po_last_ms; }
   double vt_ms() override { return vt_last_ms; }
+  double cp_ms() override { return cp_last_ms; }
 
   int verttransform(int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) override {
     if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "verttransform: slot must be 1 or 2");
@@ -1699,8 +1787,8 @@ struct Engine : EngineBase {
       return fail(FPX_ERR_ARG, "verttransform: uuh, vvh, pvh, wwh, tth, qvh, ps, tt2, td2, akz, bkz, aknew, bknew are required");
     if (m->nuvz != cfg.nz || m->nwz != cfg.nz) return fail(FPX_ERR_ARG, "verttransform: nuvz = nwz = nz expected (gridcheck_ecmwf.f90 sets them equal)");
     if (cfg.nz < 3 || cfg.nz > 65535 || cfg.ny > 65535) return fail(FPX_ERR_ARG, "verttransform: 3 <= nz <= 65535, ny <= 65535");
-    if (!sfc || !sfc->hmix || !sfc->ustar || !sfc->wstar || !sfc->oli || !sfc->tropopause) return fail(FPX_ERR_ARG, "verttransform: the 2-D fields hmix, ustar, wstar, oli, tropopause are required");
-    if (cfg.drydep && !sfc->vdep) return fail(FPX_ERR_ARG, "verttransform: vdep required with DRYDEP");
+    if (sfc && (!sfc->hmix || !sfc->ustar || !sfc->wstar || !sfc->oli || !sfc->tropopause)) return fail(FPX_ERR_ARG, "verttransform: the 2-D fields hmix, ustar, wstar, oli, tropopause are required (or sfc = NULL and fpx_calcpar)");
+    if (sfc && cfg.drydep && !sfc->vdep) return fail(FPX_ERR_ARG, "verttransform: vdep required with DRYDEP");
     return cfg.host_real_bytes == 4 ? verttransform_t<float>(0, slot, m, sfc, out) : verttransform_t<double>(0, slot, m, sfc, out);
   }
   int verttransform_nest(int nest, int slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out) override {
@@ -3382,6 +3470,8 @@ int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r, 
 }
 int fpx_concoutput(fpx_handle h, int32_t itime, const fpx_concout *c, const char *prefix, int32_t clear) { FPX_GUARD(h); return h->impl->concoutput(itime, c, prefix, clear); }
 int fpx_partoutput_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_partoutput_time: null"); *ms = h->impl->po_ms(); return FPX_OK; }
+int fpx_calcpar(fpx_handle h, int32_t slot, const fpx_calcpar_in *c, const fpx_calcpar_out *out) { FPX_GUARD(h); return h->impl->calcpar(slot, c, out); }
+int fpx_calcpar_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_calcpar_time: null"); *ms = h->impl->cp_ms(); return FPX_OK; }
 int fpx_verttransform_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return fpx::fail(FPX_ERR_ARG, "fpx_verttransform_time: null"); *ms = h->impl->vt_ms(); return FPX_OK; }
 int fpx_set_windtime(fpx_handle h, const int32_t memtime[2], const int32_t memind[2]) { FPX_GUARD(h); return h->impl->set_windtime(memtime, memind); }
 int fpx_rng_fill_table(fpx_handle h) { FPX_GUARD(h); return h->impl->rng_fill_table(); }

@@ -183,11 +183,13 @@ class Engine:
         ml.init = int(init)
         f = FpxFields()
         for k in ("hmix", "ustar", "wstar", "oli", "tropopause"):
+            if sfc is None:
+                break
             a = np.zeros((self.nymax, self.nxmax), rt)
             a[: self.ny, : self.nx] = sfc[k]
             keep["s" + k] = a
             setattr(f, k, a.ctypes.data)
-        if "vdep" in sfc:
+        if sfc is not None and "vdep" in sfc:
             v = np.zeros((self.nspec, self.nymax, self.nxmax), rt)
             v[:, : self.ny, : self.nx] = sfc["vdep"]
             keep["svdep"] = v
@@ -203,7 +205,8 @@ class Engine:
         o.nmixz = C.pointer(nmixz)
         import time as _time
         t0 = _time.perf_counter()
-        check(self.lib.fpx_verttransform_ecmwf(self.h, int(slot), C.byref(ml), C.byref(f), C.byref(o)), "fpx_verttransform_ecmwf")
+        check(self.lib.fpx_verttransform_ecmwf(self.h, int(slot), C.byref(ml), C.byref(f) if sfc is not None else None, C.byref(o)),
+              "fpx_verttransform_ecmwf")
         call_s = _time.perf_counter() - t0          # the C call alone (the marshalling above is the mirror's, not the host's)
         out = {k: v[: self.nz, : self.ny, : self.nx].astype(np.float64) for k, v in res.items()}
         out["height"] = hgt.astype(np.float64)
@@ -212,6 +215,39 @@ class Engine:
         check(self.lib.fpx_verttransform_time(self.h, C.byref(ms)), "fpx_verttransform_time")
         out["device_ms"] = ms.value
         out["call_ms"] = call_s * 1e3
+        return out
+
+    def calcpar(self, slot, cin, vdep=None):
+        """fpx_calcpar after verttransform(slot, m, None): cin = synthetic.calcpar_inputs(m).  Returns the five 2-D fields
+        (compact [ny][nx]) and the device time."""
+        from ._lib import FpxCalcparIn, FpxCalcparOut
+        rt = self.hreal
+        keep = {}
+        c = FpxCalcparIn()
+        for k in ("surfstr", "sshf", "excessoro"):
+            a = np.zeros((self.nymax, self.nxmax), rt)
+            a[: self.ny, : self.nx] = cin[k]
+            keep[k] = a
+            setattr(c, k, a.ctypes.data)
+        for k in ("akm", "bkm"):
+            keep[k] = np.ascontiguousarray(np.asarray(cin[k]).astype(rt))
+            setattr(c, k, keep[k].ctypes.data)
+        c.lsubgrid = int(cin["lsubgrid"])
+        if vdep is not None:
+            v = np.zeros((self.nspec, self.nymax, self.nxmax), rt)
+            v[:, : self.ny, : self.nx] = vdep
+            keep["vdep"] = v
+            c.vdep = v.ctypes.data
+        o = FpxCalcparOut()
+        res = {}
+        for k in ("ustar", "wstar", "oli", "hmix", "tropopause"):
+            res[k] = np.zeros((self.nymax, self.nxmax), rt)
+            setattr(o, k, res[k].ctypes.data)
+        check(self.lib.fpx_calcpar(self.h, int(slot), C.byref(c), C.byref(o)), "fpx_calcpar")
+        out = {k: v[: self.ny, : self.nx].astype(np.float64) for k, v in res.items()}
+        ms = C.c_double(0)
+        check(self.lib.fpx_calcpar_time(self.h, C.byref(ms)), "fpx_calcpar_time")
+        out["device_ms"] = ms.value
         return out
 
     def _verttransform_nest(self, slot, n, sfc, want):

@@ -32,7 +32,7 @@ module flexgpu_mod
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
             flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, &
-            flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles
+            flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -120,6 +120,15 @@ module flexgpu_mod
     type(c_ptr) :: itrasplit
   end type fpx_particles
 
+  type, bind(C) :: fpx_calcpar_in
+    type(c_ptr) :: surfstr, sshf, akm, bkm, excessoro, vdep
+    integer(c_int32_t) :: lsubgrid
+    integer(c_int32_t) :: reserved(3)
+  end type fpx_calcpar_in
+  type, bind(C) :: fpx_calcpar_out
+    type(c_ptr) :: ustar, wstar, oli, hmix, tropopause
+  end type fpx_calcpar_out
+
   type, bind(C) :: fpx_release
     integer(c_int32_t) :: struct_bytes, numpoint
     type(c_ptr) :: ireleasestart, ireleaseend, kindz
@@ -145,6 +154,13 @@ module flexgpu_mod
     integer(c_int) function fpx_destroy(h) bind(C, name='fpx_destroy')
       import :: c_ptr, c_int
       type(c_ptr), value :: h
+    end function
+    integer(c_int) function fpx_calcpar(h, slot, c, o) bind(C, name='fpx_calcpar')
+      import :: c_ptr, c_int, c_int32_t, fpx_calcpar_in, fpx_calcpar_out
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: slot
+      type(fpx_calcpar_in), intent(in) :: c
+      type(fpx_calcpar_out), intent(in) :: o
     end function
     integer(c_int) function fpx_release_init(h, r) bind(C, name='fpx_release_init')
       import :: c_ptr, c_int, fpx_release
@@ -188,7 +204,7 @@ module flexgpu_mod
       type(c_ptr), value :: h
       integer(c_int32_t), value :: slot
       type(fpx_model_levels), intent(in) :: m
-      type(fpx_fields), intent(in) :: sfc
+      type(c_ptr), value :: sfc            ! c_loc of a type(fpx_fields), or c_null_ptr: flexgpu_calcpar follows
       type(fpx_fields_out), intent(in) :: o
     end function fpx_verttransform_ecmwf
     integer(c_int) function fpx_upload_diag_fields(h, slot, f) bind(C, name='fpx_upload_diag_fields')
@@ -516,16 +532,18 @@ contains
   ! copied back into com_mod for the host routines that still read them (partoutput, convmix, the
   ! cloud diagnostics); height(:) and nmixz are set on the first call as the reference does.
   ! pin_host = .true.: uuh ... td2 keep their addresses for the whole run (static arrays): registered once for DMA.
-  subroutine flexgpu_verttransform(n, uuh, vvh, wwh, pvh, ierr, writeback, pin_host)
+  ! device_calcpar = .true.: the 2-D fields of calcpar are not taken from com_mod; flexgpu_calcpar(n, ierr) computes them.
+  subroutine flexgpu_verttransform(n, uuh, vvh, wwh, pvh, ierr, writeback, pin_host, device_calcpar)
     integer, intent(in) :: n
     real, intent(in) :: uuh(0:nxmax-1,0:nymax-1,nuvzmax), vvh(0:nxmax-1,0:nymax-1,nuvzmax)
     real, intent(in) :: pvh(0:nxmax-1,0:nymax-1,nuvzmax), wwh(0:nxmax-1,0:nymax-1,nwzmax)
     integer, intent(out) :: ierr
-    logical, intent(in), optional :: writeback, pin_host
+    logical, intent(in), optional :: writeback, pin_host, device_calcpar
     logical, save :: first = .true.
     type(fpx_model_levels) :: m
-    type(fpx_fields) :: f
+    type(fpx_fields), target :: f
     type(fpx_fields_out) :: o
+    type(c_ptr) :: fp
     integer(c_int32_t), target :: nmixz_c
     logical :: wb
     wb = .true.; if (present(writeback)) wb = writeback
@@ -554,7 +572,11 @@ contains
     o%height = loc_r(height)
     nmixz_c = nmixz
     o%nmixz = c_loc(nmixz_c)
-    ierr = fpx_verttransform_ecmwf(flexgpu_handle, int(n, c_int32_t), m, f, o)
+    fp = c_loc(f)
+    if (present(device_calcpar)) then
+      if (device_calcpar) fp = c_null_ptr
+    end if
+    ierr = fpx_verttransform_ecmwf(flexgpu_handle, int(n, c_int32_t), m, fp, o)
     if (ierr /= 0) return
     nmixz = nmixz_c
     first = .false.
@@ -767,6 +789,33 @@ contains
   end subroutine particle_ptrs
 
   ! particles j1..j2 (Fortran numbering) host -> device / device -> host
+  ! Replaces `call calcpar(n,uuh,vvh,pvh)` (getfields.f90:128,163,179) for ustar, wstar, oli, hmix, tropopause of slot n
+  ! (ECMWF fields): call after flexgpu_verttransform(n, ...) with its sfc argument omitted.  vdep (getvdep) and pv
+  ! (calcpv) stay with the host: with DRYDEP the host's vdep(:,:,:,n) must have been computed before this call.
+  ! writeback (default .true.): the five fields are also copied into com_mod for host routines that read them.
+  ! (No Fortran-host test: calcpar.f90 itself cannot be compiled in the build image -- class_gribfile needs ecCodes.)
+  subroutine flexgpu_calcpar(n, ierr, writeback)
+    integer, intent(in) :: n
+    integer, intent(out) :: ierr
+    logical, intent(in), optional :: writeback
+    type(fpx_calcpar_in) :: c
+    type(fpx_calcpar_out) :: o
+    logical :: wb
+    wb = .true.; if (present(writeback)) wb = writeback
+    c%surfstr = loc_r(surfstr(0,0,1,n)); c%sshf = loc_r(sshf(0,0,1,n))
+    c%akm = loc_r(akm); c%bkm = loc_r(bkm)
+    c%excessoro = loc_r(excessoro); c%lsubgrid = lsubgrid
+    c%vdep = c_null_ptr
+    if (DRYDEP) c%vdep = loc_r(vdep(0,0,1,n))
+    c%reserved = 0
+    o%ustar = c_null_ptr; o%wstar = c_null_ptr; o%oli = c_null_ptr; o%hmix = c_null_ptr; o%tropopause = c_null_ptr
+    if (wb) then
+      o%ustar = loc_r(ustar(0,0,1,n)); o%wstar = loc_r(wstar(0,0,1,n)); o%oli = loc_r(oli(0,0,1,n))
+      o%hmix = loc_r(hmix(0,0,1,n)); o%tropopause = loc_r(tropopause(0,0,1,n))
+    end if
+    ierr = fpx_calcpar(flexgpu_handle, int(n, c_int32_t), c, o)
+  end subroutine flexgpu_calcpar
+
   ! ---- releaseparticles + the splitting block on the device (SURVEY section 8 f2) ----------------------------
   ! after readreleases (point_mod arrays) and flexgpu_init: hands the release tables to the engine
   subroutine flexgpu_release_init(ierr)

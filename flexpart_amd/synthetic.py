@@ -688,3 +688,25 @@ def release_case(nx=48, ny=32, nz=24, *, nspec=2, ind_rel=1, mquasilag=0, maxpar
                   npoint=np.ones(n, np.int32), nclass=np.ones(n, np.int32), idt=np.full(n, 1, np.int32),
                   uap=_uniform01(n, 80) - 0.5, xmass1=np.ones((nspec, n)) * 0.01)
     return rs
+
+
+# --------------------------------------------------------------------------
+# calcpar: the surface analysis it reads besides the model levels
+# --------------------------------------------------------------------------
+def calcpar_inputs(m, lsubgrid=1):
+    """surfstr, sshf (both signs: stable and convective columns), excessoro and the half-level coefficients akm, bkm for a
+    synthetic.model_levels() dict (compact [ny][nx] arrays)."""
+    nx, ny, nz = (int(v) for v in m["grid"])
+    per = nx - 1
+    i = np.arange(nx, dtype=np.int64)[None, :]
+    j = np.arange(ny, dtype=np.int64)[:, None]
+    surfstr = 0.02 + 0.5 * (0.5 + 0.5 * _wave(3 * i + j, per)) ** 2 + 0.0 * j
+    sshf = -180.0 * _wave(2 * i + 3 * j, per) + 15.0 * _wave(5 * i, per) + 0.0 * j      # W/m2, negative = upward (convective)
+    sshf = np.where(np.abs(sshf) < 4.0, 0.0, sshf)                                        # some columns with zero heat flux
+    exc = 250.0 * np.maximum(0.0, _wave(i + 2 * j, per)) + 0.0 * j
+    for a in (surfstr, sshf, exc):
+        a[:, nx - 1] = a[:, 0]
+    ak, bk = np.asarray(m["akz"]), np.asarray(m["bkz"])
+    akm = np.concatenate([[ak[0]], 0.5 * (ak[1:] + ak[:-1])])          # half levels between the full levels (akm(1) = surface)
+    bkm = np.concatenate([[bk[0]], 0.5 * (bk[1:] + bk[:-1])])
+    return dict(surfstr=surfstr, sshf=sshf, excessoro=exc, akm=akm, bkm=bkm, lsubgrid=int(lsubgrid))

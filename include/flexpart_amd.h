@@ -191,8 +191,8 @@ typedef struct {
   void *height;
   int32_t *nmixz;
 } fpx_fields_out;
-/* sfc: the 2-D members of fpx_fields (hmix, ustar, wstar, oli, tropopause, vdep) that calcpar
- * leaves on the host; its 3-D members are ignored. */
+/* sfc: the 2-D members of fpx_fields (hmix, ustar, wstar, oli, tropopause, vdep) when calcpar runs on the host; its
+ * 3-D members are ignored.  sfc = NULL: fpx_calcpar(h, slot, ..) follows and computes them on the device. */
 int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out);
 /* The same for nested grid `nest` (1-based, after fpx_nests_init): replaces `call verttransform_nests(memind(k),
  * uuhn,vvhn,wwhn,pvhn)` (getfields.f90:133,168,184; verttransform_nests.f90:55-420 without its cloud diagnostics) and the
@@ -201,6 +201,28 @@ int fpx_verttransform_ecmwf(fpx_handle h, int32_t slot, const fpx_model_levels *
 int fpx_verttransform_nest(fpx_handle h, int32_t nest, int32_t slot, const fpx_model_levels *m, const fpx_fields *sfc, const fpx_fields_out *out);
 /* device time of the transform kernels of the last call, milliseconds */
 int fpx_verttransform_time(fpx_handle h, double *ms);
+/* ---- calcpar on the device (SURVEY section 8 f, item 1, second half) -------------------------------------
+ * Replaces `call calcpar(n,uuh,vvh,pvh)` (getfields.f90:128,163,179; the routine: calcpar.f90:76-265, ECMWF branch) for the
+ * fields the particle path reads: ustar (scalev.f90), oli (obukhov.f90), hmix and wstar (richardson.f90 with qvsat.f90,
+ * hmixmin/hmixmax, the subgrid-orography excess with lsubgrid = 1) and the thermal tropopause (:199-265).  It runs on the
+ * model-level arrays fpx_verttransform_ecmwf(h, slot, m, sfc, ..) uploaded for this slot -- call that first, with
+ * sfc = NULL (then the 2-D fields come from here and nothing but ps, tt2, td2, surfstr, sshf crosses PCIe) -- and
+ * writes the gather packs of the slot directly.  Not computed: vdep (getvdep, calcpar.f90:174-193: the land-use tables
+ * stay with the host; with DRYDEP pass the host's vdep of this slot) and the potential vorticity (calcpv, :270).
+ * The reference calls calcpar before verttransform; the two are independent of each other's results. */
+typedef struct {
+  const void *surfstr, *sshf;    /* c_loc(surfstr(0,0,1,n)), c_loc(sshf(0,0,1,n)), com_mod.f90:420-422          */
+  const void *akm, *bkm;         /* (nwz) com_mod.f90:328                                                       */
+  const void *excessoro;         /* (0:nxmax-1,0:nymax-1) com_mod.f90:343, read with lsubgrid = 1 (else NULL)   */
+  const void *vdep;              /* c_loc(vdep(0,0,1,n)) from the host's getvdep, required with DRYDEP          */
+  int32_t lsubgrid;              /* com_mod.f90:117                                                             */
+  int32_t reserved[3];
+} fpx_calcpar_in;
+/* optional copies back into the host's arrays of slot n (NULL members are skipped), e.g. c_loc(hmix(0,0,1,n)) */
+typedef struct { void *ustar, *wstar, *oli, *hmix, *tropopause; } fpx_calcpar_out;
+int fpx_calcpar(fpx_handle h, int32_t slot, const fpx_calcpar_in *c, const fpx_calcpar_out *out);
+/* device time of the kernel of the last fpx_calcpar call, milliseconds */
+int fpx_calcpar_time(fpx_handle h, double *ms);
 /* ---- partoutput: the binary particle dump (SURVEY section 8 f, item 4) ----------------------
  * Replaces `call partoutput(itime)` (timemanager.f90:454; the routine: partoutput.f90:63-190):
  * for every particle with itra1 == itime the device interpolates oro, pv, qv, tt, rho, hmix and

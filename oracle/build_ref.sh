@@ -149,6 +149,21 @@ build_rel() {
   echo "build_ref: built $OUT/relref_$kind"
 }
 
+# the leaf routines of calcpar that compile here: scalev, ew, f_qvsat behind oracle/ref_cp_driver.f90 -> cpref_rK
+build_cp() {
+  local kind="$1"; shift
+  local flags="$*"
+  local obj="$OUT/obj_$kind"
+  ( cd "$obj"
+    for s in scalev ew qvsat; do
+      [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
+    done
+    "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_cp_driver.f90" -o ref_cp_driver.o
+    "$FC" -O2 -mcmodel=medium $flags ref_cp_driver.o scalev.o ew.o qvsat.o par_mod.o -o "$OUT/cpref_$kind"
+  )
+  echo "build_ref: built $OUT/cpref_$kind"
+}
+
 # concoutput (the sparse grid_conc writer) behind oracle/ref_co_driver.f90 -> coref_rK
 build_co() {
   local kind="$1"; shift
@@ -176,6 +191,8 @@ build_rp r4
 build_rp r8 -fdefault-real-8
 build_rel r4
 build_rel r8 -fdefault-real-8
+build_cp r4
+build_cp r8 -fdefault-real-8
 build_co r4      # (with -fdefault-real-8 concoutput.f90 itself does not compile: no specific of mean_mod's generic matches)
 # nested-grid variant: the stock par_mod.f90 has maxnests=0; the reference's own
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path

@@ -17,7 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def build(force=False):
     """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
     for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"),
-                      ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle"), ("release_oracle", "librloracle")):
+                      ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle"), ("release_oracle", "librloracle"),
+                      ("calcpar_oracle", "libcporacle")):
         src = os.path.join(HERE, stem + ".c")
         for kind, real in (("r4", "float"), ("r8", "double")):
             out = os.path.join(HERE, f"{lib}_{kind}.so")
@@ -624,3 +625,50 @@ def rl_oracle(rs, kind="r8"):
         c["xmasssave"], c["rho_rel"] = xs.copy(), rr.copy()
         calls.append(c)
     return calls
+
+
+# --------------------------------------------------------------------------
+# calcpar (oracle/calcpar_oracle.c)
+# --------------------------------------------------------------------------
+class _CpoArgs(C.Structure):
+    _fields_ = ([(k, C.c_int) for k in ("nx", "ny", "nuvz", "lsubgrid")] + [("dy", C.c_double), ("ylat0", C.c_double)]
+                + [(k, C.POINTER(C.c_double)) for k in ("ps", "tt2", "td2", "surfstr", "sshf", "excessoro", "tth", "qvh", "uuh", "vvh",
+                                                         "akz", "bkz", "akm", "bkm", "ustar", "wstar", "oli", "hmix", "tropopause")])
+
+
+def cp_oracle(m, cin, kind="r8"):
+    """The C restatement of calcpar (ECMWF branch, without getvdep / calcpv) on a synthetic.model_levels() dict and
+    synthetic.calcpar_inputs(): -> dict of ustar, wstar, oli, hmix, tropopause [ny][nx]."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"libcporacle_{kind}.so"))
+    nx, ny, nz = (int(v) for v in m["grid"])
+    a = _CpoArgs()
+    a.nx, a.ny, a.nuvz, a.lsubgrid = nx, ny, nz, int(cin["lsubgrid"])
+    a.dy, a.ylat0 = float(m["geom"][1]), float(m["geom"][3])
+    keep = {}
+    dp = C.POINTER(C.c_double)
+    rt = np.float32 if kind == "r4" else np.float64
+    for k, src in (("ps", m), ("tt2", m), ("td2", m), ("tth", m), ("qvh", m), ("uuh", m), ("vvh", m), ("akz", m), ("bkz", m),
+                   ("surfstr", cin), ("sshf", cin), ("excessoro", cin), ("akm", cin), ("bkm", cin)):
+        keep[k] = _f64(np.asarray(src[k]).astype(rt)); setattr(a, k, keep[k].ctypes.data_as(dp))
+    out = {k: np.zeros((ny, nx)) for k in ("ustar", "wstar", "oli", "hmix", "tropopause")}
+    for k, v in out.items():
+        setattr(a, k, v.ctypes.data_as(dp))
+    lib.cpo_calcpar(C.byref(a))
+    return out
+
+
+def cp_leaves(ps, t, td, stress, kind="r8"):
+    """scalev(ps,t,td,stress), ew(td), f_qvsat(ps,t) of the restatement, element by element -> (n,3) float64."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"libcporacle_{kind}.so"))
+    ct = C.c_float if kind == "r4" else C.c_double
+    for f in ("cpo_scalev", "cpo_ew", "cpo_f_qvsat"):
+        getattr(lib, f).restype = ct
+    lib.cpo_scalev.argtypes = [ct] * 4; lib.cpo_ew.argtypes = [ct]; lib.cpo_f_qvsat.argtypes = [ct] * 2
+    rt = np.float32 if kind == "r4" else np.float64
+    ps, t, td, stress = (np.asarray(v).astype(rt) for v in (ps, t, td, stress))
+    o = np.empty((ps.size, 3))
+    for i in range(ps.size):
+        o[i] = (lib.cpo_scalev(ps[i], t[i], td[i], stress[i]), lib.cpo_ew(td[i]), lib.cpo_f_qvsat(ps[i], t[i]))
+    return o

@@ -329,3 +329,26 @@ def run_rel_reference(rs, kind="r8", workdir="/tmp", gpu=False):
         for c in calls:
             c["xmass1"] = np.stack(c["xmass1"]) if c["xmass1"] else np.zeros((nspec, 0))
         return calls
+
+
+# --------------------------------------------------------------------------
+# the leaf routines of calcpar through oracle/_ref/cpref_rK (oracle/ref_cp_driver.f90)
+# --------------------------------------------------------------------------
+def have_cp_ref(kind="r8"):
+    return os.access(os.path.join(HERE, "_ref", f"cpref_{kind}"), os.X_OK)
+
+
+def run_cp_leaf_reference(ps, t, td, stress, kind="r8", workdir="/tmp"):
+    """The unmodified scalev, ew, f_qvsat on arrays of arguments -> (n,3) float64: scalev(ps,t,td,stress), ew(td), f_qvsat(ps,t)."""
+    import tempfile
+    n = len(ps)
+    with tempfile.TemporaryDirectory(prefix="cp_", dir=workdir) as d:
+        fi, fo = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fi, "wb") as fh:
+            fh.write(struct.pack("<i", n))
+            fh.write(np.ascontiguousarray(np.stack([ps, t, td, stress]).astype(np.float64)).tobytes())     # column-major a(n,4)
+        exe = os.path.join(HERE, "_ref", f"cpref_{kind}")
+        res = subprocess.run([exe, fi, fo], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"reference calcpar leaf driver failed: {res.stdout}\n{res.stderr}")
+        return np.frombuffer(open(fo, "rb").read(), dtype=np.float64).reshape(3, n).T.copy()
