@@ -154,11 +154,14 @@ __global__ void k_sort_keys(View<R> V, Parts<R> P, long long n, unsigned int *__
   vals[i] = (unsigned int)i;
 }
 
-// out[i] = in[perm[i]] for every particle array at once
+// out[i] = in[perm[i]] for every particle array at once.  Between two re-sorts a particle stays in or next to its grid
+// column, so the sources of neighbouring destination blocks share cache lines: workgroups are dealt to the eight XCDs
+// round-robin, therefore block b takes tile (b % 8) * tiles_per_xcd + b / 8 -- each XCD's L2 then sees one contiguous
+// eighth of the destination range and every source line is fetched from HBM by one XCD instead of by up to eight.
 template <typename R>
-__global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict__ perm, long long n, int nspec,
-                          unsigned int *__restrict__ slot_of_pid) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict__ perm, long long n, int nspec, int tiles_per_xcd) {
+  const long long tile = (long long)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
+  long long i = tile * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned int j = perm[i];
   B.xt[i] = A.xt[j]; B.yt[i] = A.yt[j]; B.zt[i] = A.zt[j];
@@ -166,10 +169,65 @@ __global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict
   B.us[i] = A.us[j]; B.vs[i] = A.vs[j]; B.ws[i] = A.ws[j];
   B.idt[i] = A.idt[j]; B.itra1[i] = A.itra1[j]; B.itramem[i] = A.itramem[j];
   B.npoint[i] = A.npoint[j]; B.nclass[i] = A.nclass[j]; B.cbt[i] = A.cbt[j]; B.itrasplit[i] = A.itrasplit[j];
-  const unsigned int pid = A.pid[j];
-  B.pid[i] = pid;
-  slot_of_pid[pid] = (unsigned int)i;
+  B.pid[i] = A.pid[j];
   for (int ks = 0; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
+}
+
+// A permutation without locality (the first sort of a freshly seeded or uploaded cloud) would fetch one memory
+// transaction per 8-byte element through the direct gather (18 arrays: > 1 kB per particle).  Such a permutation goes
+// through one 128-byte record per particle instead: pack (coalesced reads, whole-line writes), then gather whole
+// lines and store coalesced.  Species beyond the first keep the direct gather.
+template <typename R>
+struct alignas(128) SortRecord {
+  double xt, yt;
+  R v[8];                // zt up vp wp us vs ws xmass1(1)
+  int i[6];              // idt itra1 itramem npoint nclass itrasplit
+  unsigned int pid;
+  int cbt;
+};
+template <typename R>
+__global__ void k_permute_pack(Parts<R> A, SortRecord<R> *__restrict__ rec, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  SortRecord<R> r;
+  r.xt = A.xt[i]; r.yt = A.yt[i];
+  r.v[0] = A.zt[i]; r.v[1] = A.up[i]; r.v[2] = A.vp[i]; r.v[3] = A.wp[i]; r.v[4] = A.us[i]; r.v[5] = A.vs[i]; r.v[6] = A.ws[i];
+  r.v[7] = A.xmass1[i];
+  r.i[0] = A.idt[i]; r.i[1] = A.itra1[i]; r.i[2] = A.itramem[i]; r.i[3] = A.npoint[i]; r.i[4] = A.nclass[i]; r.i[5] = A.itrasplit[i];
+  r.pid = A.pid[i]; r.cbt = A.cbt[i];
+  rec[i] = r;
+}
+template <typename R>
+__global__ void k_permute_unpack(const SortRecord<R> *__restrict__ rec, Parts<R> A, Parts<R> B, const unsigned int *__restrict__ perm,
+                                 long long n, int nspec) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned int j = perm[i];
+  const SortRecord<R> r = rec[j];
+  B.xt[i] = r.xt; B.yt[i] = r.yt;
+  B.zt[i] = r.v[0]; B.up[i] = r.v[1]; B.vp[i] = r.v[2]; B.wp[i] = r.v[3]; B.us[i] = r.v[4]; B.vs[i] = r.v[5]; B.ws[i] = r.v[6];
+  B.xmass1[i] = r.v[7];
+  B.idt[i] = r.i[0]; B.itra1[i] = r.i[1]; B.itramem[i] = r.i[2]; B.npoint[i] = r.i[3]; B.nclass[i] = r.i[4]; B.itrasplit[i] = r.i[5];
+  B.pid[i] = r.pid; B.cbt[i] = (short)r.cbt;
+  for (int ks = 1; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
+}
+// number of neighbours in the new order whose sources lie more than `window` storage spaces apart
+__global__ void k_perm_disorder(const unsigned int *__restrict__ perm, long long n, unsigned int window, unsigned long long *__restrict__ count) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool far = false;
+  if (i > 0 && i < n) {
+    const long long d = (long long)perm[i] - (long long)perm[i - 1];
+    far = (d < 0 ? -d : d) > (long long)window;
+  }
+  const unsigned long long m = __ballot(far);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+}
+
+// particle number -> storage space; built on demand (release, splitting, up/download by particle number), not by
+// every re-sort: a random 4-byte scatter costs a whole memory transaction per particle
+__global__ void k_slot_map(const unsigned int *__restrict__ pid, long long cap, unsigned int *__restrict__ slot_of_pid) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap) slot_of_pid[pid[i]] = (unsigned int)i;
 }
 
 // ---------------------------------------------------------------------------
@@ -1198,7 +1256,15 @@ struct Engine : EngineBase {
   std::vector<void *> owned;
   void *staging = nullptr;
   size_t staging_bytes = 0;
-  unsigned int *slot_of_pid = nullptr;   // only after a locality sort
+  unsigned int *slot_of_pid = nullptr;   // only after a locality sort; read it through slot_map()
+  bool slot_map_dirty = false;
+  const unsigned int *slot_map() {
+    if (slot_of_pid && slot_map_dirty) {
+      k_slot_map<<<(int)((P.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(P.pid, P.cap, d_slot_of_pid);
+      slot_map_dirty = false;
+    }
+    return slot_of_pid;
+  }
   unsigned int *d_slot_of_pid = nullptr;
   Parts<R> P2;                           // second particle buffer set (sort ping-pong), allocated lazily
   bool have_p2 = false;
@@ -1620,11 +1686,31 @@ struct Engine : EngineBase {
     const size_t sm = (size_t)nz * sizeof(H);
     const dim3 g3(nb, nz);
     unsigned short *kuv = (unsigned short *)vt_dev[KUV], *kw = (unsigned short *)vt_dev[KW];
-    vt::k_vt_inc<H><<<g3, 256, 0, stream>>>(G, I, O);
-    vt::k_vt_column<H><<<nb, 256, 0, stream>>>(G, I, O);
-    vt::k_vt_search<H><<<dim3(nb, 2), 256, sm, stream>>>(G, I, O, kuv, kw);
-    vt::k_vt_fill<H><<<g3, 256, 0, stream>>>(G, I, O, kuv, kw);
-    vt::k_vt_post<H><<<g3, 256, 0, stream>>>(G, I, O, kuv);
+    // fused path: the ECMWF level structure (nuvz = nwz = nz) and a tile's uvzlev fits the LDS of a CU twice
+    constexpr int kVtWaves = FPX_VT_WAVES;
+    const size_t sm_lev = (size_t)nz * vt::kVtCols * sizeof(H), sm_fused = sm_lev + (size_t)5 * nz * sizeof(H);
+    const char *vt_force = getenv("FPX_VT_UNFUSED");
+    const bool fused = m->nuvz == nz && m->nwz == nz && nz >= 3 && sm_fused <= (size_t)80 * 1024 && n3 < ((size_t)1 << 31) && !(vt_force && vt_force[0] == '1');
+    if (fused) {
+      vt::Tiles T;
+      T.tiles_y = (gny + vt::kVtTy - 1) / vt::kVtTy;
+      T.ntiles = T.tiles_y * ((gnx + vt::kVtTx - 1) / vt::kVtTx);
+      T.tiles_per_xcd = (T.ntiles + 7) / 8;
+      static bool attr_set = false;
+      if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute((const void *)vt::k_vt_levels<H>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void *)vt::k_vt_fused<H, kVtWaves>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+        attr_set = true;
+      }
+      vt::k_vt_levels<H><<<8 * T.tiles_per_xcd, 512, sm_lev, stream>>>(G, I, O, T);
+      vt::k_vt_fused<H, kVtWaves><<<8 * T.tiles_per_xcd, kVtWaves * 64, sm_fused, stream>>>(G, I, O, T);
+    } else {
+      vt::k_vt_inc<H><<<g3, 256, 0, stream>>>(G, I, O);
+      vt::k_vt_column<H><<<nb, 256, 0, stream>>>(G, I, O);
+      vt::k_vt_search<H><<<dim3(nb, 2), 256, sm, stream>>>(G, I, O, kuv, kw);
+      vt::k_vt_fill<H><<<g3, 256, 0, stream>>>(G, I, O, kuv, kw);
+      vt::k_vt_post<H><<<g3, 256, 0, stream>>>(G, I, O, kuv);
+    }
     const size_t smrow = (size_t)(gnx + 3) * sizeof(H);
     if (G.nglobal) {
       const int jy0 = std::max(0, (int)G.switchnorthg - 2), jy1 = cfg.ny - 1;
@@ -2253,7 +2339,7 @@ struct Engine : EngineBase {
     }
     if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("releaseparticles: ") + hipGetErrorString(e)); }
     const int nbc = (int)((cap + kBlock - 1) / kBlock);
-    k_rel_flags<R><<<nbc, kBlock, 0, stream>>>(P, slot_of_pid, cap, itime, flags);
+    k_rel_flags<R><<<nbc, kBlock, 0, stream>>>(P, slot_map(), cap, itime, flags);
     e = rocprim::exclusive_scan(tmp, tb, flags, rank, 0u, (size_t)cap, rocprim::plus<unsigned int>(), stream);
     unsigned int last[2] = {0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(&last[0], rank + (cap - 1), 4, hipMemcpyDeviceToHost, stream);
@@ -2289,7 +2375,7 @@ struct Engine : EngineBase {
     DiagP<H> D;
     D.oro = (const H *)diag_oro; D.tropo[0] = (const H *)diag_tropo[0]; D.tropo[1] = (const H *)diag_tropo[1]; D.d3 = (const H *)diag_d3;
     D.nxmax = cfg.nxmax; D.nymax = cfg.nymax; D.dx = (H)cfg.dx; D.dy = (H)cfg.dy; D.xlon0 = (H)cfg.xlon0; D.ylat0 = (H)cfg.ylat0;
-    k_release<R, H><<<(int)((ntotal + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, P, D, RP, target, slot_of_pid, ntotal, itime, d_uni, (int)*npc_io,
+    k_release<R, H><<<(int)((ntotal + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, P, D, RP, target, slot_map(), ntotal, itime, d_uni, (int)*npc_io,
                                                                                   cfg.mintime, rel.itsplit, rel.ind_rel, rel.nclassunc, cfg.mquasilag,
                                                                                   dens ? d_rho : (H *)nullptr, d_max);
     e = hipGetLastError();
@@ -2331,14 +2417,14 @@ struct Engine : EngineBase {
     }
     if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("split_particles: ") + hipGetErrorString(e)); }
     const int nb = (int)((n + kBlock - 1) / kBlock);
-    k_split_flags<R><<<nb, kBlock, 0, stream>>>(P, slot_of_pid, n, itime, cfg.ldirect, flags);
+    k_split_flags<R><<<nb, kBlock, 0, stream>>>(P, slot_map(), n, itime, cfg.ldirect, flags);
     e = rocprim::exclusive_scan(tmp, tb, flags, rank, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
     unsigned int last[2] = {0, 0};
     if (e == hipSuccess) e = hipMemcpyAsync(&last[0], rank + (n - 1), 4, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(&last[1], flags + (n - 1), 4, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e == hipSuccess) {
-      k_split<R><<<nb, kBlock, 0, stream>>>(P, slot_of_pid, flags, rank, n, room, cfg.nspec);
+      k_split<R><<<nb, kBlock, 0, stream>>>(P, slot_map(), flags, rank, n, room, cfg.nspec);
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream); else (void)hipStreamSynchronize(stream);
@@ -2532,7 +2618,7 @@ struct Engine : EngineBase {
     int rc = ensure_staging((size_t)count * sizeof(H));
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(staging, host, (size_t)count * sizeof(H), hipMemcpyHostToDevice, stream));
-    k_scatter_in<H, D><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>((const H *)staging, dev, slot_of_pid, first, count);
+    k_scatter_in<H, D><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>((const H *)staging, dev, slot_map(), first, count);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(stream));
     return 0;
@@ -2541,7 +2627,7 @@ struct Engine : EngineBase {
   int get(H *host, const D *dev, long long first, long long count) {
     int rc = ensure_staging((size_t)count * sizeof(H));
     if (rc) return rc;
-    k_gather_out<D, H><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dev, (H *)staging, slot_of_pid, first, count);
+    k_gather_out<D, H><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dev, (H *)staging, slot_map(), first, count);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host, staging, (size_t)count * sizeof(H), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -2549,7 +2635,7 @@ struct Engine : EngineBase {
   }
   template <typename D>
   int fill(D *dev, D val, long long first, long long count) {
-    k_fill<D><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dev, val, first, count, slot_of_pid);
+    k_fill<D><<<(int)((count + kBlock - 1) / kBlock), kBlock, 0, stream>>>(dev, val, first, count, slot_map());
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -2901,6 +2987,10 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  SortRecord<R> *d_sort_rec = nullptr;
+  size_t sort_rec_cap = 0;
+  unsigned long long *d_disorder = nullptr;
+  bool last_permute_staged = false;
   int alloc_parts(Parts<R> &Q) {
     const size_t cap = (size_t)P.cap;
     int rc;
@@ -2941,6 +3031,7 @@ struct Engine : EngineBase {
       if ((rc = dalloc(&d_vals, cap))) return rc;
       if ((rc = dalloc(&d_vals2, cap))) return rc;
       if ((rc = dalloc(&d_slot_of_pid, cap))) return rc;
+      if ((rc = dalloc(&d_disorder, (size_t)1))) return rc;
       have_p2 = true;
     }
     const unsigned long long nkeys = (unsigned long long)cfg.nx * cfg.ny * cfg.nz + 1ull;
@@ -2958,7 +3049,36 @@ struct Engine : EngineBase {
       sort_tmp_bytes = need;
     }
     HIPCHK(rocprim::radix_sort_pairs(d_sort_tmp, need, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0u, bits, stream));
-    k_permute<R><<<nb, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, d_slot_of_pid);
+    // which gather: by the locality of the permutation (FPX_PERMUTE=direct|staged overrides, for tests)
+    bool staged = false;
+    {
+      const char *force = getenv("FPX_PERMUTE");
+      if (force && !strcmp(force, "staged")) staged = true;
+      else if (!(force && !strcmp(force, "direct")) && n >= (1 << 16)) {
+        HIPCHK(hipMemsetAsync(d_disorder, 0, sizeof(unsigned long long), stream));
+        k_perm_disorder<<<nb, kBlock, 0, stream>>>(d_vals2, n, 1u << 14, d_disorder);
+        unsigned long long far = 0;
+        HIPCHK(hipMemcpyAsync(&far, d_disorder, sizeof(far), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        staged = far * 2ull > (unsigned long long)n;
+      }
+    }
+    last_permute_staged = staged;
+    if (staged) {
+      if ((size_t)n > sort_rec_cap) {
+        if (d_sort_rec) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_sort_rec)); d_sort_rec = nullptr; sort_rec_cap = 0; }
+        HIPCHK(hipMalloc(&d_sort_rec, (size_t)n * sizeof(SortRecord<R>)));
+        sort_rec_cap = (size_t)n;
+      }
+      k_permute_pack<R><<<nb, kBlock, 0, stream>>>(P, d_sort_rec, n);
+      k_permute_unpack<R><<<nb, kBlock, 0, stream>>>(d_sort_rec, P, P2, d_vals2, n, cfg.nspec);
+      // 12.8 GB at 1e8 particles, needed once in a run: give it back
+      HIPCHK(hipStreamSynchronize(stream));
+      HIPCHK(hipFree(d_sort_rec)); d_sort_rec = nullptr; sort_rec_cap = 0;
+    } else {
+      const int tiles_per_xcd = (nb + 7) / 8;
+      k_permute<R><<<8 * tiles_per_xcd, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, tiles_per_xcd);
+    }
     HIPCHK(hipGetLastError());
     // slots >= n keep their (dead) contents in both sets; swap roles
     std::swap(P, P2);
@@ -2968,10 +3088,10 @@ struct Engine : EngineBase {
       const int nbr = (int)((rest + kBlock - 1) / kBlock);
       k_fill<int><<<nbr, kBlock, 0, stream>>>(P.itra1, kDead, n, rest, nullptr);
       k_iota_pid<<<nbr, kBlock, 0, stream>>>(P.pid, n, rest);
-      k_iota_pid<<<nbr, kBlock, 0, stream>>>(d_slot_of_pid, n, rest);
       HIPCHK(hipGetLastError());
     }
     slot_of_pid = d_slot_of_pid;
+    slot_map_dirty = true;
     return 0;
   }
 

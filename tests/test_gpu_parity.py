@@ -254,24 +254,30 @@ def test_config1_closed_form(built):
     assert np.all(out[1]["itra1"] == 1800)
 
 
-def test_locality_sort_does_not_change_results(built):
+@pytest.mark.parametrize("gather", ["direct", "staged"])
+@pytest.mark.parametrize("rb", [8, 4])
+def test_locality_sort_does_not_change_results(built, monkeypatch, gather, rb):
     """Sorting permutes device slots only: particle numbering at the boundary and every
-    result (table RNG is indexed by particle number) must be unchanged -- bitwise."""
+    result (table RNG is indexed by particle number) must be unchanged -- bitwise.  Both gathers of the re-sort
+    (direct per array; through one 128-byte record per particle, chosen for permutations without locality), two
+    species with different masses, and particles uploaded by number after a sort."""
     from flexpart_amd.engine import Engine
-    sc = syn.small(n=3000, nx=40, ny=24, nz=30, nsteps=3, ctl=5.0, ifine=4)
-    a = Engine(sc)
+    monkeypatch.setenv("FPX_PERMUTE", gather)
+    sc = syn.small(n=3000, nx=40, ny=24, nz=30, nsteps=3, ctl=5.0, ifine=4, nspec=2)
+    sc["xmass1"] = np.stack([np.linspace(1.0, 2.0, 3000), np.linspace(5.0, 3.0, 3000)])
+    a = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb)
     ra = a.run()
     a.close()
-    b = Engine(sc)
+    b = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb)
     b.sort()
     b.step()
     b.sort()
     b.step()
     b.step()
-    rb = b.download()
+    rb_ = b.download()
     b.close()
-    for k in ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt"):
-        assert np.array_equal(ra[-1][k], rb[k]), k
+    for k in ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt", "xmass1", "npoint", "nclass", "itramem"):
+        assert np.array_equal(ra[-1][k], rb_[k]), k
 
 
 def test_counter_rng_is_order_independent(built):

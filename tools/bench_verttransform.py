@@ -75,7 +75,7 @@ def main():
         "wall_ms_whole_call": float(np.median(wall)) * 1e3,
         "wall_ms_whole_call_pinned_host_arrays": float(np.median(wall_pinned)) * 1e3,
         "roofline": {"bound": "hbm", "achieved": alg / (dms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                     "frac": alg / (dms * 1e-3) / 1e9 / 8000.0, "traffic": _traffic(), "kernel": "k_vt_inc + k_vt_column + k_vt_search + k_vt_fill + k_vt_post + k_vt_polar + k_vt_polerow",
+                     "frac": alg / (dms * 1e-3) / 1e9 / 8000.0, "traffic": _traffic(), "kernel": "k_vt_levels + k_vt_fused + k_vt_polar + k_vt_polerow" if os.environ.get("FPX_VT_UNFUSED", "0") != "1" else "k_vt_inc + k_vt_column + k_vt_search + k_vt_fill + k_vt_post + k_vt_polar + k_vt_polerow",
                      "alg_bytes": alg},
     }
     if not a.no_cpu_baseline:
