@@ -168,6 +168,7 @@ SYMBOLS = [
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
     "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_calcpar", "fpx_calcpar_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
+    "fpx_checkpoint_write", "fpx_checkpoint_read",
 ]
 
 _lib = None
@@ -209,6 +210,8 @@ def load():
     lib.fpx_partoutput_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.fpx_concoutput.argtypes = [vp, C.c_int32, C.POINTER(FpxConcout), C.c_char_p, C.c_int32]
     lib.fpx_readpartpositions.argtypes = [vp, C.c_char_p, C.POINTER(FpxRestart), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.fpx_checkpoint_write.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
+    lib.fpx_checkpoint_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.fpx_set_windtime.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.fpx_rng_fill_table.argtypes = [vp]
     lib.fpx_rng_set_table.argtypes = [vp, vp, C.c_int32]

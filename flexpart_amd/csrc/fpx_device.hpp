@@ -31,6 +31,10 @@ FPX_HD float m_log(float x) { return logf(x); }
 FPX_HD double m_log(double x) { return log(x); }
 FPX_HD float m_sqrt(float x) { return sqrtf(x); }
 FPX_HD double m_sqrt(double x) { return sqrt(x); }
+// a*b + c with the contraction spelled out: for a*b + c*d the compiler may fuse either product, and two instantiations of
+// the same template (k_prep with and without the branch for new particles) did choose differently
+FPX_HD float m_fma(float a, float b, float c) { return fmaf(a, b, c); }
+FPX_HD double m_fma(double a, double b, double c) { return fma(a, b, c); }
 FPX_HD float m_sin(float x) { return sinf(x); }
 FPX_HD double m_sin(double x) { return sin(x); }
 FPX_HD float m_cos(float x) { return cosf(x); }
@@ -525,9 +529,11 @@ FPX_DEV void level_profile(const View<R> &V, const Fld<R> &F, const Cell<R> &C, 
         usl = usl + u00 + u10 + u01 + u11;
         vsl = vsl + v00 + v10 + v01 + v11;
         wsl = wsl + w00 + w10 + w01 + w11;
-        usq = usq + u00 * u00 + u10 * u10 + u01 * u01 + u11 * u11;
-        vsq = vsq + v00 * v00 + v10 * v10 + v01 * v01 + v11 * v11;
-        wsq = wsq + w00 * w00 + w10 * w10 + w01 * w01 + w11 * w11;
+        // fused multiply-adds spelled out (the variance usq - usl^2/8 cancels to rounding noise in smooth wind:
+        // which product the compiler fuses must not depend on the kernel variant)
+        usq = m_fma(u11, u11, m_fma(u01, u01, m_fma(u10, u10, m_fma(u00, u00, usq))));
+        vsq = m_fma(v11, v11, m_fma(v01, v01, m_fma(v10, v10, m_fma(v00, v00, vsq))));
+        wsq = m_fma(w11, w11, m_fma(w01, w01, m_fma(w10, w10, m_fma(w00, w00, wsq))));
       }
     }
     if (WITH_RHO) {
@@ -1321,7 +1327,7 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const 
         else { au[sl][n] = au[sl][n] + pw * uu; av[sl][n] = av[sl][n] + pw * vv; aw[sl][n] = aw[sl][n] + pw * ww; }
         if (SIG) {
           usl = usl + uu; vsl = vsl + vv; wsl = wsl + ww;
-          usq = usq + uu * uu; vsq = vsq + vv * vv; wsq = wsq + ww * ww;
+          usq = m_fma(uu, uu, usq); vsq = m_fma(vv, vv, vsq); wsq = m_fma(ww, ww, wsq);   // spelled out: usq - usl^2/16 cancels to rounding noise
         }
       }
     }
@@ -1910,9 +1916,9 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
     if (V.turbmesoscale == K(0.)) {   // mesoscale fluctuations switched off (wave-uniform): the random terms vanish
       P.usigold = r * P.usigold; P.vsigold = r * P.vsigold; P.wsigold = r * P.wsigold;
     } else {
-      P.usigold = r * P.usigold + rs * G.at(nrand) * usig * V.turbmesoscale;
-      P.vsigold = r * P.vsigold + rs * G.at(nrand + 1) * vsig * V.turbmesoscale;
-      P.wsigold = r * P.wsigold + rs * G.at(nrand + 2) * wsig * V.turbmesoscale;
+      P.usigold = m_fma(r, P.usigold, rs * G.at(nrand) * usig * V.turbmesoscale);
+      P.vsigold = m_fma(r, P.vsigold, rs * G.at(nrand + 1) * vsig * V.turbmesoscale);
+      P.wsigold = m_fma(r, P.wsigold, rs * G.at(nrand + 2) * wsig * V.turbmesoscale);
     }
     A.dxsave = A.dxsave + P.usigold * (R)V.lsynctime;
     A.dysave = A.dysave + P.vsigold * (R)V.lsynctime;

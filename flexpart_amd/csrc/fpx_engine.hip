@@ -158,19 +158,24 @@ __global__ void k_sort_keys(View<R> V, Parts<R> P, long long n, unsigned int *__
 // column, so the sources of neighbouring destination blocks share cache lines: workgroups are dealt to the eight XCDs
 // round-robin, therefore block b takes tile (b % 8) * tiles_per_xcd + b / 8 -- each XCD's L2 then sees one contiguous
 // eighth of the destination range and every source line is fetched from HBM by one XCD instead of by up to eight.
-template <typename R>
+// The arrays go in four groups, one launch each: the source lines a workgroup touches are shared with its neighbours
+// (a grid column's particles are re-shuffled among its levels), and only with a few arrays in flight does that
+// working set stay in the 4 MB L2 of an XCD until the neighbours have used it (all 18 arrays in one launch: twice the
+// compulsory reads).
+template <typename R, int GROUP>
 __global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict__ perm, long long n, int nspec, int tiles_per_xcd) {
   const long long tile = (long long)(blockIdx.x & 7) * tiles_per_xcd + (blockIdx.x >> 3);
   long long i = tile * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const unsigned int j = perm[i];
-  B.xt[i] = A.xt[j]; B.yt[i] = A.yt[j]; B.zt[i] = A.zt[j];
-  B.up[i] = A.up[j]; B.vp[i] = A.vp[j]; B.wp[i] = A.wp[j];
-  B.us[i] = A.us[j]; B.vs[i] = A.vs[j]; B.ws[i] = A.ws[j];
-  B.idt[i] = A.idt[j]; B.itra1[i] = A.itra1[j]; B.itramem[i] = A.itramem[j];
-  B.npoint[i] = A.npoint[j]; B.nclass[i] = A.nclass[j]; B.cbt[i] = A.cbt[j]; B.itrasplit[i] = A.itrasplit[j];
-  B.pid[i] = A.pid[j];
-  for (int ks = 0; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
+  if (GROUP == 0) { B.xt[i] = A.xt[j]; B.yt[i] = A.yt[j]; B.zt[i] = A.zt[j]; B.idt[i] = A.idt[j]; }
+  if (GROUP == 1) { B.up[i] = A.up[j]; B.vp[i] = A.vp[j]; B.wp[i] = A.wp[j]; B.itra1[i] = A.itra1[j]; }
+  if (GROUP == 2) { B.us[i] = A.us[j]; B.vs[i] = A.vs[j]; B.ws[i] = A.ws[j]; B.itramem[i] = A.itramem[j]; }
+  if (GROUP == 3) {
+    B.npoint[i] = A.npoint[j]; B.nclass[i] = A.nclass[j]; B.cbt[i] = A.cbt[j]; B.itrasplit[i] = A.itrasplit[j];
+    B.pid[i] = A.pid[j];
+    for (int ks = 0; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
+  }
 }
 
 // A permutation without locality (the first sort of a freshly seeded or uploaded cloud) would fetch one memory
@@ -213,14 +218,22 @@ __global__ void k_permute_unpack(const SortRecord<R> *__restrict__ rec, Parts<R>
 }
 // number of neighbours in the new order whose sources lie more than `window` storage spaces apart
 __global__ void k_perm_disorder(const unsigned int *__restrict__ perm, long long n, unsigned int window, unsigned long long *__restrict__ count) {
-  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  bool far = false;
-  if (i > 0 && i < n) {
-    const long long d = (long long)perm[i] - (long long)perm[i - 1];
-    far = (d < 0 ? -d : d) > (long long)window;
+  __shared__ unsigned int part[kBlock / 64];
+  unsigned int mine = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    if (i > 0) {
+      const long long d = (long long)perm[i] - (long long)perm[i - 1];
+      mine += (d < 0 ? -d : d) > (long long)window;
+    }
   }
-  const unsigned long long m = __ballot(far);
-  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long t = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); k++) t += part[k];
+    if (t) atomicAdd(count, t);
+  }
 }
 
 // particle number -> storage space; built on demand (release, splitting, up/download by particle number), not by
@@ -1241,6 +1254,8 @@ struct EngineBase {
   virtual int partoutput(int itime, const char *path, int64_t *nrec) = 0;
   virtual int concoutput(int itime, const fpx_concout *c, const char *prefix, int clear) = 0;
   virtual int readpartpositions(const char *path, const fpx_restart *r, int64_t *numpart_out, int32_t *numparticlecount, int32_t *itimein) = 0;
+  virtual int checkpoint_write(const char *path, int itime, int numparticlecount) = 0;
+  virtual int checkpoint_read(const char *path, int32_t *itime, int64_t *numpart_out, int32_t *numparticlecount) = 0;
 };
 
 template <typename R>
@@ -2710,6 +2725,154 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // ---- lossless checkpoint (last clause) ------------------------------------------------------
+  // partoutput / readpartpositions keep position, mass and age of a particle, rounded to the dump's real kind; the
+  // turbulent velocity memory (up, vp, wp), the mesoscale components (us, vs, ws), cbt, idt, itramem, itrasplit,
+  // nclass are re-initialised by a warm start (readpartpositions.f90:118-148), so the reference's restart is a
+  // different realisation of the run.  This pair writes and reads everything the loop carries: all particle arrays in
+  // the compute precision and in particle-number order, the step counter the counter RNG is keyed on, the state of
+  // the serial ran3 / ran1 streams of the parity mode, and the accumulating output grids.  A run continued from it
+  // is the run that was never interrupted, bit for bit.
+  struct CkptHeader {
+    char magic[8];
+    int32_t version, real_bytes, nspec, rng_mode;
+    int64_t numpart, particle_base;
+    uint64_t seed;
+    uint32_t step_counter;
+    int32_t itime, numparticlecount, reserved;
+    uint64_t n_grid3, n_grid2, n_grid3n, n_grid2n, n_receptor, rng_bytes;
+  };
+  static constexpr long long kCkptChunk = 1ll << 22;
+  template <typename T>
+  int ckpt_put_array(FILE *fh, const T *dev, long long n, std::vector<unsigned char> &buf) {
+    for (long long f = 0; f < n; f += kCkptChunk) {
+      const long long c = std::min(kCkptChunk, n - f);
+      int rc = get<T, T>((T *)buf.data(), dev, f, c);
+      if (rc) return rc;
+      if (fwrite(buf.data(), sizeof(T), (size_t)c, fh) != (size_t)c) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
+    }
+    return 0;
+  }
+  template <typename T>
+  int ckpt_get_array(FILE *fh, T *dev, long long n, std::vector<unsigned char> &buf) {
+    for (long long f = 0; f < n; f += kCkptChunk) {
+      const long long c = std::min(kCkptChunk, n - f);
+      if (fread(buf.data(), sizeof(T), (size_t)c, fh) != (size_t)c) return fail(FPX_ERR_ARG, "checkpoint_read: file too short");
+      int rc = put<T, T>((const T *)buf.data(), dev, f, c);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  template <typename T>
+  int ckpt_put_plain(FILE *fh, const T *dev, size_t n, std::vector<unsigned char> &buf) {
+    for (size_t f = 0; f < n; f += (size_t)kCkptChunk) {
+      const size_t c = std::min((size_t)kCkptChunk, n - f);
+      HIPCHK(hipMemcpyAsync(buf.data(), dev + f, c * sizeof(T), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      if (fwrite(buf.data(), sizeof(T), c, fh) != c) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
+    }
+    return 0;
+  }
+  template <typename T>
+  int ckpt_get_plain(FILE *fh, T *dev, size_t n, std::vector<unsigned char> &buf) {
+    for (size_t f = 0; f < n; f += (size_t)kCkptChunk) {
+      const size_t c = std::min((size_t)kCkptChunk, n - f);
+      if (fread(buf.data(), sizeof(T), c, fh) != c) return fail(FPX_ERR_ARG, "checkpoint_read: file too short");
+      HIPCHK(hipMemcpyAsync(dev + f, buf.data(), c * sizeof(T), hipMemcpyHostToDevice, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    return 0;
+  }
+  struct CkptRng { HostRng<float> r4; HostRng<double> r8; Ran1 rel; };
+
+  int checkpoint_write(const char *path, int itime, int numparticlecount) override {
+    if (!path) return fail(FPX_ERR_ARG, "checkpoint_write: path is required");
+    FILE *fh = fopen(path, "wb");
+    if (!fh) return fail(FPX_ERR_ARG, std::string("checkpoint_write: cannot open ") + path);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{fh};
+    CkptHeader h;
+    memset(&h, 0, sizeof(h));
+    memcpy(h.magic, "FPXCKPT1", 8);
+    h.version = 1; h.real_bytes = (int)sizeof(R); h.nspec = cfg.nspec; h.rng_mode = cfg.rng_mode;
+    h.numpart = numpart; h.particle_base = cfg.particle_base; h.seed = V.seed; h.step_counter = step_counter;
+    h.itime = itime; h.numparticlecount = numparticlecount;
+    h.n_grid3 = Gp.on ? n_grid3 : 0; h.n_grid2 = Gp.on ? n_grid2 : 0;
+    h.n_grid3n = Gp.on && Gp.nested ? n_grid3n : 0; h.n_grid2n = Gp.on && Gp.nested ? n_grid2n : 0;
+    h.n_receptor = Gp.creceptor ? (uint64_t)Gp.numreceptor * cfg.maxspec : 0;
+    h.rng_bytes = sizeof(CkptRng);
+    if (fwrite(&h, sizeof(h), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
+    CkptRng rs{rng4, rng8, rel_ran1};
+    if (fwrite(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
+    std::vector<unsigned char> buf((size_t)kCkptChunk * 8);
+    const long long n = numpart;
+    int rc;
+    if ((rc = ckpt_put_array(fh, P.xt, n, buf)) || (rc = ckpt_put_array(fh, P.yt, n, buf))) return rc;
+    for (R *a : {P.zt, P.up, P.vp, P.wp, P.us, P.vs, P.ws}) if ((rc = ckpt_put_array(fh, a, n, buf))) return rc;
+    for (int *a : {P.idt, P.itra1, P.itramem, P.npoint, P.nclass, P.itrasplit}) if ((rc = ckpt_put_array(fh, a, n, buf))) return rc;
+    if ((rc = ckpt_put_array(fh, P.cbt, n, buf))) return rc;
+    for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_put_array(fh, P.xmass1 + (size_t)ks * P.cap, n, buf))) return rc;
+    if (h.n_grid3 && ((rc = ckpt_put_plain(fh, Gp.gridunc, n_grid3, buf)) || (rc = ckpt_put_plain(fh, Gp.drygridunc, n_grid2, buf)) ||
+                      (rc = ckpt_put_plain(fh, Gp.wetgridunc, n_grid2, buf)))) return rc;
+    if (h.n_grid3n && ((rc = ckpt_put_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_put_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
+                       (rc = ckpt_put_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return rc;
+    if (h.n_receptor && (rc = ckpt_put_plain(fh, Gp.creceptor, (size_t)h.n_receptor, buf))) return rc;
+    closer.f = nullptr;
+    if (fclose(fh) != 0) return fail(FPX_ERR_ARG, std::string("checkpoint_write: write error on ") + path);
+    return 0;
+  }
+
+  int checkpoint_read(const char *path, int32_t *itime, int64_t *numpart_out, int32_t *numparticlecount) override {
+    if (!path) return fail(FPX_ERR_ARG, "checkpoint_read: path is required");
+    FILE *fh = fopen(path, "rb");
+    if (!fh) return fail(FPX_ERR_ARG, std::string("checkpoint_read: cannot open ") + path);
+    struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{fh};
+    CkptHeader h;
+    if (fread(&h, sizeof(h), 1, fh) != 1 || memcmp(h.magic, "FPXCKPT1", 8) != 0 || h.version != 1)
+      return fail(FPX_ERR_ARG, "checkpoint_read: not a checkpoint of this engine");
+    if (h.real_bytes != (int)sizeof(R) || h.nspec != cfg.nspec || h.rng_mode != cfg.rng_mode || h.rng_bytes != sizeof(CkptRng))
+      return fail(FPX_ERR_ARG, "checkpoint_read: written with another precision, species count or random-number mode");
+    if (h.numpart < 0 || h.numpart > P.cap) return fail(FPX_ERR_ARG, "checkpoint_read: more particles than storage spaces");
+    if (h.particle_base != cfg.particle_base || h.seed != V.seed) return fail(FPX_ERR_ARG, "checkpoint_read: another shard or seed");
+    const uint64_t g3 = Gp.on ? n_grid3 : 0, g2 = Gp.on ? n_grid2 : 0, g3n = Gp.on && Gp.nested ? n_grid3n : 0, g2n = Gp.on && Gp.nested ? n_grid2n : 0;
+    const uint64_t nr = Gp.creceptor ? (uint64_t)Gp.numreceptor * cfg.maxspec : 0;
+    if (h.n_grid3 != g3 || h.n_grid2 != g2 || h.n_grid3n != g3n || h.n_grid2n != g2n || h.n_receptor != nr)
+      return fail(FPX_ERR_STATE, "checkpoint_read: the output grids of the checkpoint are not the ones configured (call fpx_outgrid_init ... first)");
+    CkptRng rs;
+    if (fread(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_read: file too short");
+    // storage spaces in particle-number order again
+    HIPCHK(hipStreamSynchronize(stream));
+    slot_of_pid = nullptr;
+    slot_map_dirty = false;
+    {
+      const int nb = (int)((P.cap + kBlock - 1) / kBlock);
+      k_iota_pid<<<nb, kBlock, 0, stream>>>(P.pid, 0, P.cap);
+      k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, P.cap, nullptr);
+      HIPCHK(hipGetLastError());
+    }
+    std::vector<unsigned char> buf((size_t)kCkptChunk * 8);
+    const long long n = h.numpart;
+    int rc;
+    if ((rc = ckpt_get_array(fh, P.xt, n, buf)) || (rc = ckpt_get_array(fh, P.yt, n, buf))) return rc;
+    for (R *a : {P.zt, P.up, P.vp, P.wp, P.us, P.vs, P.ws}) if ((rc = ckpt_get_array(fh, a, n, buf))) return rc;
+    for (int *a : {P.idt, P.itra1, P.itramem, P.npoint, P.nclass, P.itrasplit}) if ((rc = ckpt_get_array(fh, a, n, buf))) return rc;
+    if ((rc = ckpt_get_array(fh, P.cbt, n, buf))) return rc;
+    for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_get_array(fh, P.xmass1 + (size_t)ks * P.cap, n, buf))) return rc;
+    if (g3 && ((rc = ckpt_get_plain(fh, Gp.gridunc, n_grid3, buf)) || (rc = ckpt_get_plain(fh, Gp.drygridunc, n_grid2, buf)) ||
+               (rc = ckpt_get_plain(fh, Gp.wetgridunc, n_grid2, buf)))) return rc;
+    if (g3n && ((rc = ckpt_get_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_get_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
+                (rc = ckpt_get_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return rc;
+    if (nr && (rc = ckpt_get_plain(fh, Gp.creceptor, (size_t)nr, buf))) return rc;
+    for (bool &v : red_valid) v = false;
+    rng4 = rs.r4; rng8 = rs.r8; rel_ran1 = rs.rel;
+    step_counter = h.step_counter;
+    numpart = n;
+    maybe_new = true;
+    if (itime) *itime = h.itime;
+    if (numpart_out) *numpart_out = n;
+    if (numparticlecount) *numparticlecount = h.numparticlecount;
+    return 0;
+  }
+
   // point_mod xmass(numpoint,maxspec), npart(numpoint): device tables indexed by npoint(j)
   int set_release_points(int numpoint, const void *xmass, const int32_t *npart) override {
     if (numpoint < 1 || !xmass || !npart) return fail(FPX_ERR_ARG, "set_release_points: numpoint >= 1, xmass and npart are required");
@@ -3056,7 +3219,7 @@ struct Engine : EngineBase {
       if (force && !strcmp(force, "staged")) staged = true;
       else if (!(force && !strcmp(force, "direct")) && n >= (1 << 16)) {
         HIPCHK(hipMemsetAsync(d_disorder, 0, sizeof(unsigned long long), stream));
-        k_perm_disorder<<<nb, kBlock, 0, stream>>>(d_vals2, n, 1u << 14, d_disorder);
+        k_perm_disorder<<<std::min(nb, 4096), kBlock, 0, stream>>>(d_vals2, n, 1u << 14, d_disorder);
         unsigned long long far = 0;
         HIPCHK(hipMemcpyAsync(&far, d_disorder, sizeof(far), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -3077,7 +3240,10 @@ struct Engine : EngineBase {
       HIPCHK(hipFree(d_sort_rec)); d_sort_rec = nullptr; sort_rec_cap = 0;
     } else {
       const int tiles_per_xcd = (nb + 7) / 8;
-      k_permute<R><<<8 * tiles_per_xcd, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, tiles_per_xcd);
+      k_permute<R, 0><<<8 * tiles_per_xcd, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, tiles_per_xcd);
+      k_permute<R, 1><<<8 * tiles_per_xcd, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, tiles_per_xcd);
+      k_permute<R, 2><<<8 * tiles_per_xcd, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, tiles_per_xcd);
+      k_permute<R, 3><<<8 * tiles_per_xcd, kBlock, 0, stream>>>(P, P2, d_vals2, n, cfg.nspec, tiles_per_xcd);
     }
     HIPCHK(hipGetLastError());
     // slots >= n keep their (dead) contents in both sets; swap roles
@@ -3627,6 +3793,14 @@ int fpx_kernel_times(fpx_handle h, double ms[4], int64_t *launches, int32_t rese
   return rc;
 }
 int fpx_sort_particles(fpx_handle h) { FPX_GUARD(h); return h->impl->sort_particles(); }
+int fpx_checkpoint_write(fpx_handle h, const char *path, int32_t itime, int32_t numparticlecount) {
+  FPX_GUARD(h);
+  return h->impl->checkpoint_write(path, itime, numparticlecount);
+}
+int fpx_checkpoint_read(fpx_handle h, const char *path, int32_t *itime, int64_t *numpart, int32_t *numparticlecount) {
+  FPX_GUARD(h);
+  return h->impl->checkpoint_read(path, itime, numpart, numparticlecount);
+}
 int fpx_seed_particles(fpx_handle h, int64_t n, uint64_t seed, double frac_pbl, double zmax, double lat_margin_cells, int32_t itime0) {
   FPX_GUARD(h);
   return h->impl->seed_particles(n, seed, frac_pbl, zmax, lat_margin_cells, itime0);

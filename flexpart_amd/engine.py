@@ -318,6 +318,21 @@ class Engine:
         self.n = int(n.value)
         return int(n.value), int(npc.value), int(it.value)
 
+    def checkpoint_write(self, path, itime=None, numparticlecount=None):
+        """fpx_checkpoint_write: everything the particle loop carries (lossless, unlike partoutput)."""
+        check(self.lib.fpx_checkpoint_write(self.h, str(path).encode(), int(self.itime if itime is None else itime),
+                                            int(getattr(self, "numparticlecount", 0) if numparticlecount is None else numparticlecount)),
+              "fpx_checkpoint_write")
+
+    def checkpoint_read(self, path):
+        """fpx_checkpoint_read: -> (itime, numpart, numparticlecount); the engine continues from there."""
+        it = C.c_int32(0); n = C.c_int64(0); npc = C.c_int32(0)
+        check(self.lib.fpx_checkpoint_read(self.h, str(path).encode(), C.byref(it), C.byref(n), C.byref(npc)), "fpx_checkpoint_read")
+        self.n = int(n.value)
+        self.itime = int(it.value)
+        self.numparticlecount = int(npc.value)
+        return self.itime, self.n, self.numparticlecount
+
     def concoutput(self, itime, prefix, area, volume, outnum, wetdep=False, drydep=False, clear=False, nest=False,
                    iout=1, prefix_pptv=None, outheight=None, outlon0=0.0, outlat0=0.0, weightmolar=(), reduced=False):
         """fpx_concoutput: writes <prefix><nnn> (the reference's grid_conc_* files) for every species."""

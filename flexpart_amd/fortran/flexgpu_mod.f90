@@ -32,7 +32,8 @@ module flexgpu_mod
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
             flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, &
-            flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar
+            flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar, &
+            flexgpu_checkpoint_write, flexgpu_checkpoint_read
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -220,6 +221,19 @@ module flexgpu_mod
       character(kind=c_char), intent(in) :: path(*)
       integer(c_int64_t), intent(out) :: nrec
     end function fpx_partoutput
+    integer(c_int) function fpx_checkpoint_write(h, path, itime, npc) bind(C, name='fpx_checkpoint_write')
+      import :: c_ptr, c_int, c_int32_t, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int32_t), value :: itime, npc
+    end function fpx_checkpoint_write
+    integer(c_int) function fpx_checkpoint_read(h, path, itime, np, npc) bind(C, name='fpx_checkpoint_read')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: path(*)
+      integer(c_int32_t), intent(out) :: itime, npc
+      integer(c_int64_t), intent(out) :: np
+    end function fpx_checkpoint_read
     integer(c_int) function fpx_readpartpositions(h, path, r, np, npc, itimein) bind(C, name='fpx_readpartpositions')
       import :: c_ptr, c_int, c_int32_t, c_int64_t, c_char, fpx_restart
       type(c_ptr), value :: h
@@ -640,6 +654,27 @@ contains
     numparticlecount = npc
     itrasplit(1:numpart) = ldirect * itsplit
   end subroutine flexgpu_readpartpositions
+
+  ! Lossless restart file path(2)//'flexgpu_checkpoint' (no reference counterpart: partoutput / readpartpositions lose the
+  ! turbulent state, DESIGN.md section 11): everything the particle loop carries.  A run continued with
+  ! flexgpu_checkpoint_read is the uninterrupted run.
+  subroutine flexgpu_checkpoint_write(itime, ierr)
+    integer, intent(in) :: itime
+    integer, intent(out) :: ierr
+    ierr = fpx_checkpoint_write(flexgpu_handle, path(2)(1:length(2)) // 'flexgpu_checkpoint' // c_null_char, int(itime, c_int32_t), &
+                                int(numparticlecount, c_int32_t))
+  end subroutine flexgpu_checkpoint_write
+
+  subroutine flexgpu_checkpoint_read(itime, ierr)
+    integer, intent(out) :: itime, ierr
+    integer(c_int64_t) :: np
+    integer(c_int32_t) :: npc, it
+    ierr = fpx_checkpoint_read(flexgpu_handle, path(2)(1:length(2)) // 'flexgpu_checkpoint' // c_null_char, it, np, npc)
+    if (ierr /= 0) return
+    itime = it
+    numpart = int(np)
+    numparticlecount = npc
+  end subroutine flexgpu_checkpoint_read
 
   ! Writes the grid_conc_<date><time>_<species> files of `call concoutput(itime,outnum,...)` (timemanager.f90:384;
   ! forward runs, iout = 1 or 3 or 5) from the device's sampling grids and zeroes gridunc as the routine does.

@@ -261,6 +261,19 @@ typedef struct {
 } fpx_restart;
 int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
                           int64_t *numpart, int32_t *numparticlecount, int32_t *itimein);
+/* ---- lossless checkpoint (SURVEY section 8 f, item 4, last clause) -----------------------------
+ * The reference's restart is lossy: partoutput.f90:63-190 writes position, mass and age in the dump's
+ * real kind and omits uap..uzp, us..ws, cbt, idt, itramem, nclass; readpartpositions.f90:118-148 sets
+ * them anew, so a warm-started run is another realisation of the run.  This pair has no reference
+ * counterpart: fpx_checkpoint_write stores every array of the particle loop (com_mod.f90:678-695) in the
+ * compute precision and in particle-number order, the step counter the counter RNG is keyed on, the state
+ * of the serial ran3 / ran1 streams of the parity mode and the accumulating grids (gridunc, drygridunc,
+ * wetgridunc, the nested ones, creceptor); fpx_checkpoint_read restores them into an engine created with
+ * the same fpx_config (+ fpx_outgrid_init ... if the run samples), also after a locality sort.  A run continued
+ * from the file is bit-identical to the uninterrupted one.  itime and numparticlecount are the host's values
+ * and come back unchanged.  The met fields are not in the file (the host uploads them as at start-up). */
+int fpx_checkpoint_write(fpx_handle h, const char *path, int32_t itime, int32_t numparticlecount);
+int fpx_checkpoint_read(fpx_handle h, const char *path, int32_t *itime, int64_t *numpart, int32_t *numparticlecount);
 /* ---- concoutput: the sparse concentration files (SURVEY section 8 f, item 4) -----------------
  * Replaces the part of `call concoutput(itime,outnum,...)` (timemanager.f90:384; the routine:
  * concoutput.f90:226-228,296-447) that writes grid_conc_<date><time>_<species> for a forward run with
