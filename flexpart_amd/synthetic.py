@@ -710,3 +710,57 @@ def calcpar_inputs(m, lsubgrid=1):
     akm = np.concatenate([[ak[0]], 0.5 * (ak[1:] + ak[:-1])])          # half levels between the full levels (akm(1) = surface)
     bkm = np.concatenate([[bk[0]], 0.5 * (bk[1:] + bk[:-1])])
     return dict(surfstr=surfstr, sshf=sshf, excessoro=exc, akm=akm, bkm=bkm, lsubgrid=int(lsubgrid))
+
+
+# --------------------------------------------------------------------------
+# convective mixing (convmix.f90): soundings with and without CAPE
+# --------------------------------------------------------------------------
+def convection_case(nx=24, ny=16, nuvz=46, n=4000, ncalls=3, ldirect=1, lsynctime=900, seed=11):
+    """ECMWF-shaped input of the convection scheme on a small grid: hybrid half levels akm, bkm (akm(1) = surface) with
+    the full levels akz, bkz between them (level 1 = surface), two time slots of ps, tt2, td2, tth, qvh [2][nuvz][ny][nx]
+    whose soundings range from warm, moist and conditionally unstable (deep convection: most of the matrix is used)
+    over shallow and marginal cases to dry or cold columns in which CONVECT leaves through each of its early exits;
+    `n` particles between the ground and 16 km, a tenth of them not due, `ncalls` consecutive calls one lsynctime apart
+    (the cloud-base mass flux cbaseflux relaxes from call to call)."""
+    per = nx
+    i = np.arange(nx, dtype=np.int64)[None, None, :]
+    j = np.arange(ny, dtype=np.int64)[None, :, None]
+    k = np.arange(nuvz, dtype=np.float64)
+    eta_h = np.exp(-3.3 * (k / float(nuvz - 1)) ** 1.25)                 # half levels: 1 ... about 0.037 (37 hPa)
+    bkm = eta_h ** 1.6
+    bkm[0] = 1.0
+    akm = 101325.0 * (eta_h - bkm)
+    akm[0] = 0.0
+    akz = np.concatenate([[0.0], 0.5 * (akm[:-1] + akm[1:])])
+    bkz = np.concatenate([[1.0], 0.5 * (bkm[:-1] + bkm[1:])])
+    out = dict(akz=akz, bkz=bkz, akm=akm, bkm=bkm)
+    slots = {}
+    for slot in range(2):
+        ii = i + 3 * slot
+        warm = 0.5 + 0.5 * _wave(ii[0] + 2 * j[0], per)                  # 0 ... 1: cold/dry ... warm/moist
+        ps = 101300.0 + 600.0 * _wave(2 * ii[0] + j[0], per) - 14000.0 * np.maximum(0.0, _wave(3 * ii[0] + 5 * j[0], 2 * per)) ** 3
+        p = akz[:, None, None] + bkz[:, None, None] * ps[None]
+        z = -7600.0 * np.log(p / ps[None])
+        tsfc = 271.0 + 31.0 * warm + 0.0 * ps
+        lapse = 0.0055 + 0.0015 * warm
+        tth = np.maximum(tsfc[None] - lapse[None] * z, 198.0 + 8.0 * warm[None]) + 0.4 * _wave(ii + j + 3 * np.arange(nuvz)[:, None, None], per)
+        rh = (0.25 + 0.65 * warm[None]) * np.exp(-z / (5000.0 + 4000.0 * warm[None])) + 0.05
+        tc = tth - 273.15
+        es = 611.2 * np.exp(17.67 * tc / (tc + 243.5))
+        qs = 0.622 * es / np.maximum(p - 0.378 * es, 1.0)
+        qvh = np.minimum(rh, 0.98) * qs
+        tt2 = tth[0] + 0.6
+        td2 = tt2 - (2.0 + 14.0 * (1.0 - warm))
+        slots[slot] = (ps, tt2, td2, tth, qvh)
+    for idx, key in enumerate(("ps", "tt2", "td2", "tth", "qvh")):
+        out[key] = np.stack([slots[0][idx], slots[1][idx]])
+    # a run in progress: the cloud-base mass flux of the warm columns has built up (it starts from zero in others)
+    warm0 = 0.5 + 0.5 * _wave(i[0] + 2 * j[0], per)
+    cb0 = np.where(warm0 > 0.55, 0.12 * warm0 ** 2, 0.0)
+    u = [_splitmix64(n, seed + q).astype(np.float64) / 2.0 ** 64 for q in range(4)]
+    out.update(grid=np.array([nx, ny, nuvz], np.int32), nconvlev=nuvz - 2, ldirect=int(ldirect), lsynctime=int(lsynctime),
+               memtime=np.array([0, 10800], np.int32), itimes=np.arange(ncalls, dtype=np.int32) * int(lsynctime) * int(ldirect) + (0 if ldirect == 1 else 10800),
+               height_nz=19000.0, cbaseflux=cb0,
+               xtra1=0.3 + u[0] * (nx - 1.6), ytra1=0.3 + u[1] * (ny - 1.6), ztra1=16000.0 * u[2] ** 1.5,
+               due=(u[3][:, None] + 0.013 * np.arange(ncalls)[None, :]) % 1.0 > 0.1, npart=n)
+    return out

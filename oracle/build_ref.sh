@@ -191,8 +191,25 @@ build_rp r4
 build_rp r8 -fdefault-real-8
 build_rel r4
 build_rel r8 -fdefault-real-8
+# the routines of the convective mixing that compile here: CONVECT/TLIFT, redist, sort2, f_qvsat, ew, ran3
+# behind oracle/ref_conv_driver.f90 -> convref_rK (convmix.f90 and calcmatrix.f90 need ecCodes' grib_api: not built)
+build_conv() {
+  local kind="$1"; shift
+  local flags="$*"
+  local obj="$OUT/obj_$kind"
+  ( cd "$obj"
+    for s in conv_mod convect43c redist sort2 qvsat ew; do
+      [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
+    done
+    "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_conv_driver.f90" -o ref_conv_driver.o
+    "$FC" -O2 -mcmodel=medium $flags ref_conv_driver.o conv_mod.o convect43c.o redist.o sort2.o qvsat.o ew.o random_mod.o com_mod.o par_mod.o -o "$OUT/convref_$kind"
+  )
+  echo "build_ref: built $OUT/convref_$kind"
+}
 build_cp r4
 build_cp r8 -fdefault-real-8
+build_conv r4
+build_conv r8 -fdefault-real-8
 build_co r4      # (with -fdefault-real-8 concoutput.f90 itself does not compile: no specific of mean_mod's generic matches)
 # nested-grid variant: the stock par_mod.f90 has maxnests=0; the reference's own
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path

@@ -1,0 +1,846 @@
+/* TEST INFRASTRUCTURE ONLY -- the checker for flexpart_amd's fpx_convmix.
+ * Nothing under flexpart_amd/ links, loads or calls this file.
+ *
+ * Plain-C restatement of the reference's convective mixing of particles, each part citing the
+ * lines it follows:
+ *   convect43c.f90:79-1092   CONVECT and TLIFT (Emanuel's scheme, version 4.3c, as the reference ships it)
+ *   calcmatrix.f90:56-137    the redistribution matrix fmassfrac of one grid column (ECMWF branch)
+ *   redist.f90:49-236        the displacement of one particle (+ random_mod.f90 ran3)
+ *   convmix.f90:61-196       the driver: particles by grid column (sort2.f90), mother grid
+ *   qvsat.f90, ew.f90        saturation specific humidity / vapour pressure
+ * `real` is the reference's default real kind (compile with -DORC_REAL=float|double).  Pinned against the flang build of
+ * the unmodified convect43c.f90, redist.f90, sort2.f90, qvsat.f90, ew.f90, random_mod.f90 behind
+ * oracle/ref_conv_driver.f90 (oracle/_ref/convref_rK) by tests/test_convection.py.  calcmatrix.f90 and convmix.f90
+ * themselves `use class_gribfile` (ecCodes) and cannot be compiled here: for these two (60 and 100 lines of glue) the
+ * restatement is PARITY UNPINNED; the driver carries the same glue around the real CONVECT and REDIST.
+ * Arrays are 1-based here as in the Fortran (element 0 unused); matrices are column-major A(i,j) = a[i + j*LD]. */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef ORC_REAL
+#define ORC_REAL double
+#endif
+typedef ORC_REAL real;
+#define K(x) ((real)(x))
+#define R_POW(a, b) ((real)(sizeof(real) == 4 ? powf((float)(a), (float)(b)) : pow((double)(a), (double)(b))))
+#define R_EXP(a) ((real)(sizeof(real) == 4 ? expf((float)(a)) : exp((double)(a))))
+#define R_LOG(a) ((real)(sizeof(real) == 4 ? logf((float)(a)) : log((double)(a))))
+#define R_SQRT(a) ((real)(sizeof(real) == 4 ? sqrtf((float)(a)) : sqrt((double)(a))))
+#define R_ABS(a) ((a) < 0 ? -(a) : (a))
+#define R_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define R_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define I_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define I_MIN(a, b) ((a) < (b) ? (a) : (b))
+
+#define NAD 200                       /* >= na + 1 of any build (par_mod.f90:166-167) */
+#define A2(a, i, j) a[(i) + (j) * NAD]
+
+/* conv_mod.f90 */
+typedef struct {
+  real pconv[NAD], phconv[NAD], dpr[NAD], pconv_hpa[NAD], phconv_hpa[NAD];
+  real ft[NAD], fq[NAD], sub[NAD];
+  real fmass[NAD * NAD], fmassfrac[NAD * NAD];
+  real tconv[NAD], qconv[NAD], qsconv[NAD];
+  real psconv, tt2conv, td2conv;
+  int nconvlev, nconvtop;
+  real uvzlev[NAD];                   /* redist.f90:59: real,save :: uvzlev */
+  /* ran3 (random_mod.f90:46-113), one stream shared by every caller of the module function */
+  int ma[56], inext, inextp, iff;
+  int iseed;                          /* redist.f90:69: integer :: iseed = -88 (SAVE'd by the initialisation) */
+} cvo_state;
+
+/* ew.f90:4-29 */
+static real cvo_ew(real x) {
+  real y, a, c, d;
+  y = K(373.16) / x;
+  a = K(-7.90298) * (y - K(1.));
+  a = a + (K(5.02808) * K(0.43429) * R_LOG(y));
+  c = (K(1.) - (K(1.) / y)) * K(11.344);
+  c = K(-1.) + R_POW(K(10.), c);
+  c = K(-1.3816) * c / R_POW(K(10.), K(7));     /* 10.**7: integer power */
+  d = (K(1.) - y) * K(3.49149);
+  d = K(-1.) + R_POW(K(10.), d);
+  d = K(8.1328) * d / R_POW(K(10.), K(3));
+  y = a + c + d;
+  return K(101324.6) * R_POW(K(10.), y);
+}
+
+/* qvsat.f90 */
+static real f_esl(real p, real t) { real f = K(1.0007) + K(3.46e-8) * p; return f * K(611.21) * R_EXP(K(17.502) * (t - K(273.15)) / (t - K(32.18))); }
+static real f_esi(real p, real t) { real f = K(1.0003) + K(4.18e-8) * p; return f * K(611.15) * R_EXP(K(22.452) * (t - K(273.15)) / (t - K(0.6))); }
+static real cvo_f_qvsat(real p, real t) {
+  const real rddrv = K(287.0) / K(461.0);
+  real fespt = t >= K(253.15) ? f_esl(p, t) : f_esi(p, t);
+  if (p - (K(1.0) - rddrv) * fespt == K(0.)) return K(1.);
+  return rddrv * fespt / (p - (K(1.0) - rddrv) * fespt);
+}
+
+/* random_mod.f90:46-113 (Numerical Recipes ran3; integer arithmetic) */
+static real cvo_ran3(cvo_state *S, int *idum) {
+  const int mbig = 1000000000, mseed = 161803398, mz = 0;
+  const real fac = K(1.) / (real)mbig;
+  int i, ii, k, mj, mk;
+  if (*idum < 0 || S->iff == 0) {
+    S->iff = 1;
+    mj = mseed - abs(*idum);
+    mj = mj % mbig;
+    S->ma[55] = mj;
+    mk = 1;
+    for (i = 1; i <= 54; i++) {
+      ii = (21 * i) % 55;
+      S->ma[ii] = mk;
+      mk = mj - mk;
+      if (mk < mz) mk = mk + mbig;
+      mj = S->ma[ii];
+    }
+    for (k = 1; k <= 4; k++)
+      for (i = 1; i <= 55; i++) {
+        S->ma[i] = S->ma[i] - S->ma[1 + (i + 30) % 55];
+        if (S->ma[i] < mz) S->ma[i] = S->ma[i] + mbig;
+      }
+    S->inext = 0;
+    S->inextp = 31;
+    *idum = 1;
+  }
+  S->inext = S->inext + 1;
+  if (S->inext == 56) S->inext = 1;
+  S->inextp = S->inextp + 1;
+  if (S->inextp == 56) S->inextp = 1;
+  mj = S->ma[S->inext] - S->ma[S->inextp];
+  if (mj < mz) mj = mj + mbig;
+  S->ma[S->inext] = mj;
+  return (real)mj * fac;
+}
+
+/* convect43c.f90:943-1092 */
+static void cvo_tlift(cvo_state *S, const real *gz, int icb, int nk, real *tvp, real *tpk, real *clw, int nl, int kk) {
+  const real cpd = K(1005.7), cpv = K(1870.0), cl = K(2500.0), rv = K(461.5), rd = K(287.04), lv0 = K(2.501e6);
+  const real cpvmcl = cl - cpv, eps0 = rd / rv, epsi = K(1.) / eps0;
+  const real *tconv = S->tconv, *qconv = S->qconv, *qsconv = S->qsconv, *pconv_hpa = S->pconv_hpa;
+  real ah0, ahg, alv, cpinv, cpp, denom, es, qg, rg, s, tc, tg;
+  int i, j, nsb, nst;
+  ah0 = (cpd * (K(1.) - qconv[nk]) + cl * qconv[nk]) * tconv[nk] + qconv[nk] * (lv0 - cpvmcl * (tconv[nk] - K(273.15))) + gz[nk];
+  cpp = cpd * (K(1.) - qconv[nk]) + qconv[nk] * cpv;
+  cpinv = K(1.) / cpp;
+  if (kk == 1) {
+    for (i = 1; i <= icb - 1; i++) clw[i] = K(0.0);
+    for (i = nk; i <= icb - 1; i++) {
+      tpk[i] = tconv[nk] - (gz[i] - gz[nk]) * cpinv;
+      tvp[i] = tpk[i] * (K(1.) + qconv[nk] * epsi);
+    }
+  }
+  nst = icb;
+  nsb = icb;
+  if (kk == 2) { nst = nl; nsb = icb + 1; }
+  for (i = nsb; i <= nst; i++) {
+    tg = tconv[i];
+    qg = qsconv[i];
+    alv = lv0 - cpvmcl * (tconv[i] - K(273.15));
+    for (j = 1; j <= 2; j++) {
+      s = cpd + alv * alv * qg / (rv * tconv[i] * tconv[i]);
+      s = K(1.) / s;
+      ahg = cpd * tg + (cl - cpd) * qconv[nk] * tconv[i] + alv * qg + gz[i];
+      tg = tg + s * (ah0 - ahg);
+      tg = R_MAX(tg, K(35.0));
+      tc = tg - K(273.15);
+      denom = K(243.5) + tc;
+      if (tc >= K(0.0)) es = K(6.112) * R_EXP(K(17.67) * tc / denom);
+      else es = R_EXP(K(23.33086) - K(6111.72784) / tg + K(0.15215) * R_LOG(tg));
+      qg = eps0 * es / (pconv_hpa[i] - es * (K(1.) - eps0));
+    }
+    alv = lv0 - cpvmcl * (tconv[i] - K(273.15));
+    tpk[i] = (ah0 - (cl - cpd) * qconv[nk] * tconv[i] - gz[i] - alv * qg) / cpd;
+    clw[i] = qconv[nk] - qg;
+    clw[i] = R_MAX(K(0.0), clw[i]);
+    rg = qg / (K(1.) - qconv[nk]);
+    tvp[i] = tpk[i] * (K(1.) + rg * epsi);
+  }
+}
+
+/* convect43c.f90:79-941 */
+static void cvo_convect(cvo_state *S, int nl, real delt, int *iflag_, real *precip_, real *wd_, real *tprime_, real *qprime_, real *cbmf_) {
+  const real elcrit = K(.0011), tlcrit = K(-55.0), entp = K(1.5), sigd = K(0.05), sigs = K(0.12), omtrain = K(50.0), omtsnow = K(5.5);
+  const real coeffr = K(1.0), coeffs = K(0.8), beta = K(10.0), dtmax = K(0.9), alpha = K(0.025), damp = K(0.1);
+  const real cpd = K(1005.7), cpv = K(1870.0), cl = K(2500.0), rv = K(461.5), rd = K(287.04), lv0 = K(2.501e6), g = K(9.81), rowl = K(1000.0);
+  const real cpvmcl = cl - cpv, eps0 = rd / rv, epsi = K(1.) / eps0, ginv = K(1.0) / g, epsilon = K(1.e-20);
+  const int minorig = 1;
+  real *tconv = S->tconv, *qconv = S->qconv, *qsconv = S->qsconv, *pconv_hpa = S->pconv_hpa, *phconv_hpa = S->phconv_hpa;
+  real *ft = S->ft, *fq = S->fq, *sub = S->sub, *fmass = S->fmass;
+  static real fup[NAD], fdown[NAD], m[NAD], mp[NAD], ment[NAD * NAD], qent[NAD * NAD], elij[NAD * NAD], sij[NAD * NAD];
+  static real tvp[NAD], tv[NAD], water[NAD], qp[NAD], ep[NAD], th[NAD], wt[NAD], evap[NAD], clw[NAD], sigp[NAD], tp[NAD], cpn[NAD];
+  static real lv[NAD], lvcp[NAD], h[NAD], hp[NAD], gz[NAD], hm[NAD];
+  static int nent[NAD];
+  int iflag = *iflag_, i, icb, ihmin, inb, inb1, j, jtt, k, nk;
+  real cbmf = *cbmf_, precip, wd, tprime, qprime;
+  real ad, afac, ahmax, ahmin, alt, altem, am, amp1, anum, asij, awat, b6, bf2, bsum, by, byp, c6, cape, capem, cbmfold, chi, coeff;
+  real cpinv, cwat, damps, dbo, dbosum, defrac, dei, delm, delp, delt0, delti, denom, dhdp, dpinv, dtma, dtmin, dtpbl, elacrit, ents;
+  real epmax, fac, fqold, frac, ftold, plcl, qp1, qsm, qstm, qti, rat, rdcp, revap, rh, scrit, sigt, sjmax, sjmin, smid, smin, stemp, tca;
+  real tvaplcl, tvpplcl, tvx, tvy, wdtrain;
+
+  delti = K(1.0) / delt;
+  for (i = 1; i <= nl + 1; i++) {
+    ft[i] = K(0.0); fq[i] = K(0.0); fdown[i] = K(0.0); sub[i] = K(0.0); fup[i] = K(0.0); m[i] = K(0.0); mp[i] = K(0.0);
+    for (j = 1; j <= nl + 1; j++) { A2(fmass, i, j) = K(0.0); A2(ment, i, j) = K(0.0); }
+  }
+  for (i = 1; i <= nl + 1; i++) {
+    rdcp = (rd * (K(1.) - qconv[i]) + qconv[i] * rv) / (cpd * (K(1.) - qconv[i]) + qconv[i] * cpv);
+    th[i] = tconv[i] * R_POW(K(1000.0) / pconv_hpa[i], rdcp);
+  }
+  precip = K(0.0); wd = K(0.0); tprime = K(0.0); qprime = K(0.0);
+  iflag = 0;
+#define RETURN_ do { *iflag_ = iflag; *precip_ = precip; *wd_ = wd; *tprime_ = tprime; *qprime_ = qprime; *cbmf_ = cbmf; return; } while (0)
+  gz[1] = K(0.0);
+  cpn[1] = cpd * (K(1.) - qconv[1]) + qconv[1] * cpv;
+  h[1] = tconv[1] * cpn[1];
+  lv[1] = lv0 - cpvmcl * (tconv[1] - K(273.15));
+  hm[1] = lv[1] * qconv[1];
+  tv[1] = tconv[1] * (K(1.) + qconv[1] * epsi - qconv[1]);
+  ahmin = K(1.0e12);
+  ihmin = nl;
+  for (i = 2; i <= nl + 1; i++) {
+    tvx = tconv[i] * (K(1.) + qconv[i] * epsi - qconv[i]);
+    tvy = tconv[i - 1] * (K(1.) + qconv[i - 1] * epsi - qconv[i - 1]);
+    gz[i] = gz[i - 1] + K(0.5) * rd * (tvx + tvy) * (pconv_hpa[i - 1] - pconv_hpa[i]) / phconv_hpa[i];
+    cpn[i] = cpd * (K(1.) - qconv[i]) + cpv * qconv[i];
+    h[i] = tconv[i] * cpn[i] + gz[i];
+    lv[i] = lv0 - cpvmcl * (tconv[i] - K(273.15));
+    hm[i] = (cpd * (K(1.) - qconv[i]) + cl * qconv[i]) * (tconv[i] - tconv[1]) + lv[i] * qconv[i] + gz[i];
+    tv[i] = tconv[i] * (K(1.) + qconv[i] * epsi - qconv[i]);
+    if (i >= minorig && hm[i] < ahmin && hm[i] < hm[i - 1]) { ahmin = hm[i]; ihmin = i; }
+  }
+  ihmin = I_MIN(ihmin, nl - 1);
+  ahmax = K(0.0);
+  nk = minorig;
+  for (i = minorig; i <= ihmin; i++)
+    if (hm[i] > ahmax) { nk = i; ahmax = hm[i]; }
+  if (tconv[nk] < K(250.0) || qconv[nk] <= K(0.0) || ihmin == (nl - 1)) { iflag = 0; cbmf = K(0.0); RETURN_; }
+  rh = qconv[nk] / qsconv[nk];
+  chi = tconv[nk] / (K(1669.0) - K(122.0) * rh - tconv[nk]);
+  plcl = pconv_hpa[nk] * R_POW(rh, chi);
+  if (plcl < K(200.0) || plcl >= K(2000.0)) { iflag = 2; cbmf = K(0.0); RETURN_; }
+  icb = nl - 1;
+  for (i = nk + 1; i <= nl; i++)
+    if (pconv_hpa[i] < plcl) icb = I_MIN(icb, i);
+  if (icb >= (nl - 1)) { iflag = 3; cbmf = K(0.0); RETURN_; }
+  cvo_tlift(S, gz, icb, nk, tvp, tp, clw, nl, 1);
+  for (i = nk; i <= icb; i++) tvp[i] = tvp[i] - tp[i] * qconv[nk];
+  if (cbmf == K(0.0) && tvp[icb] <= (tv[icb] - dtmax)) { iflag = 0; RETURN_; }
+  if (iflag != 4) iflag = 1;
+  cvo_tlift(S, gz, icb, nk, tvp, tp, clw, nl, 2);
+  for (i = 1; i <= nk; i++) { ep[i] = K(0.0); sigp[i] = sigs; }
+  for (i = nk + 1; i <= nl; i++) {
+    tca = tp[i] - K(273.15);
+    if (tca >= K(0.0)) elacrit = elcrit; else elacrit = elcrit * (K(1.0) - tca / tlcrit);
+    elacrit = R_MAX(elacrit, K(0.0));
+    epmax = K(0.999);
+    ep[i] = epmax * (K(1.0) - elacrit / R_MAX(clw[i], K(1.0e-8)));
+    ep[i] = R_MAX(ep[i], K(0.0));
+    ep[i] = R_MIN(ep[i], epmax);
+    sigp[i] = sigs;
+  }
+  for (i = icb + 1; i <= nl; i++) tvp[i] = tvp[i] - tp[i] * qconv[nk];
+  tvp[nl + 1] = tvp[nl] - (gz[nl + 1] - gz[nl]) / cpd;
+  for (i = 1; i <= nl + 1; i++) {
+    hp[i] = h[i]; nent[i] = 0; water[i] = K(0.0); evap[i] = K(0.0); wt[i] = omtsnow; lvcp[i] = lv[i] / cpn[i];
+    for (j = 1; j <= nl + 1; j++) { A2(qent, i, j) = qconv[j]; A2(elij, i, j) = K(0.0); A2(sij, i, j) = K(0.0); }
+  }
+  qp[1] = qconv[1];
+  for (i = 2; i <= nl + 1; i++) qp[i] = qconv[i - 1];
+  cape = K(0.0); capem = K(0.0);
+  inb = icb + 1; inb1 = inb;
+  byp = K(0.0);
+  for (i = icb + 1; i <= nl - 1; i++) {
+    by = (tvp[i] - tv[i]) * (phconv_hpa[i] - phconv_hpa[i + 1]) / pconv_hpa[i];
+    cape = cape + by;
+    if (by >= K(0.0)) inb1 = i + 1;
+    if (cape > K(0.0)) {
+      inb = i + 1;
+      byp = (tvp[i + 1] - tv[i + 1]) * (phconv_hpa[i + 1] - phconv_hpa[i + 2]) / pconv_hpa[i + 1];
+      capem = cape;
+    }
+  }
+  inb = I_MAX(inb, inb1);
+  cape = capem + byp;
+  defrac = capem - cape;
+  defrac = R_MAX(defrac, K(0.001));
+  frac = -cape / defrac;
+  frac = R_MIN(frac, K(1.0));
+  frac = R_MAX(frac, K(0.0));
+  for (i = icb; i <= inb; i++) hp[i] = h[nk] + (lv[i] + (cpd - cpv) * tconv[i]) * ep[i] * clw[i];
+  dbosum = K(0.0);
+  tvpplcl = tvp[icb - 1] - rd * tvp[icb - 1] * (pconv_hpa[icb - 1] - plcl) / (cpn[icb - 1] * pconv_hpa[icb - 1]);
+  tvaplcl = tv[icb] + (tvp[icb] - tvp[icb + 1]) * (plcl - pconv_hpa[icb]) / (pconv_hpa[icb] - pconv_hpa[icb + 1]);
+  dtpbl = K(0.0);
+  for (i = nk; i <= icb - 1; i++) dtpbl = dtpbl + (tvp[i] - tv[i]) * (phconv_hpa[i] - phconv_hpa[i + 1]);
+  dtpbl = dtpbl / (phconv_hpa[nk] - phconv_hpa[icb]);
+  dtmin = tvpplcl - tvaplcl + dtmax + dtpbl;
+  dtma = dtmin;
+  cbmfold = cbmf;
+  delt0 = delt / K(3.);
+  damps = damp * delt / delt0;
+  cbmf = (K(1.) - damps) * cbmf + K(0.1) * alpha * dtma;
+  cbmf = R_MAX(cbmf, K(0.0));
+  if (cbmf == K(0.0) && cbmfold == K(0.0)) RETURN_;
+  m[icb] = K(0.0);
+  for (i = icb + 1; i <= inb; i++) {
+    k = I_MIN(i, inb1);
+    dbo = R_ABS(tv[k] - tvp[k]) + entp * K(0.02) * (phconv_hpa[k] - phconv_hpa[k + 1]);
+    dbosum = dbosum + dbo;
+    m[i] = cbmf * dbo;
+  }
+  for (i = icb + 1; i <= inb; i++) m[i] = m[i] / dbosum;
+  for (i = icb + 1; i <= inb; i++) {
+    qti = qconv[nk] - ep[i] * clw[i];
+    for (j = icb; j <= inb; j++) {
+      bf2 = K(1.) + lv[j] * lv[j] * qsconv[j] / (rv * tconv[j] * tconv[j] * cpd);
+      anum = h[j] - hp[i] + (cpv - cpd) * tconv[j] * (qti - qconv[j]);
+      denom = h[i] - hp[i] + (cpd - cpv) * (qconv[i] - qti) * tconv[j];
+      dei = denom;
+      if (R_ABS(dei) < K(0.01)) dei = K(0.01);
+      A2(sij, i, j) = anum / dei;
+      A2(sij, i, i) = K(1.0);
+      altem = A2(sij, i, j) * qconv[i] + (K(1.) - A2(sij, i, j)) * qti - qsconv[j];
+      altem = altem / bf2;
+      cwat = clw[j] * (K(1.) - ep[j]);
+      stemp = A2(sij, i, j);
+      if ((stemp < K(0.0) || stemp > K(1.0) || altem > cwat) && j > i) {
+        anum = anum - lv[j] * (qti - qsconv[j] - cwat * bf2);
+        denom = denom + lv[j] * (qconv[i] - qti);
+        if (R_ABS(denom) < K(0.01)) denom = K(0.01);
+        A2(sij, i, j) = anum / denom;
+        altem = A2(sij, i, j) * qconv[i] + (K(1.) - A2(sij, i, j)) * qti - qsconv[j];
+        altem = altem - (bf2 - K(1.)) * cwat;
+      }
+      if (A2(sij, i, j) > K(0.0) && A2(sij, i, j) < K(0.9)) {
+        A2(qent, i, j) = A2(sij, i, j) * qconv[i] + (K(1.) - A2(sij, i, j)) * qti;
+        A2(elij, i, j) = altem;
+        A2(elij, i, j) = R_MAX(K(0.0), A2(elij, i, j));
+        A2(ment, i, j) = m[i] / (K(1.) - A2(sij, i, j));
+        nent[i] = nent[i] + 1;
+      }
+      A2(sij, i, j) = R_MAX(K(0.0), A2(sij, i, j));
+      A2(sij, i, j) = R_MIN(K(1.0), A2(sij, i, j));
+    }
+    if (nent[i] == 0) {
+      A2(ment, i, i) = m[i];
+      A2(qent, i, i) = qconv[nk] - ep[i] * clw[i];
+      A2(elij, i, i) = clw[i];
+      A2(sij, i, i) = K(1.0);
+    }
+  }
+  A2(sij, inb, inb) = K(1.0);
+  for (i = icb + 1; i <= inb; i++) {
+    if (nent[i] != 0) {
+      qp1 = qconv[nk] - ep[i] * clw[i];
+      anum = h[i] - hp[i] - lv[i] * (qp1 - qsconv[i]);
+      denom = h[i] - hp[i] + lv[i] * (qconv[i] - qp1);
+      if (R_ABS(denom) < K(0.01)) denom = K(0.01);
+      scrit = anum / denom;
+      alt = qp1 - qsconv[i] + scrit * (qconv[i] - qp1);
+      if (alt < K(0.0)) scrit = K(1.0);
+      scrit = R_MAX(scrit, K(0.0));
+      asij = K(0.0);
+      smin = K(1.0);
+      for (j = icb; j <= inb; j++) {
+        if (A2(sij, i, j) > K(0.0) && A2(sij, i, j) < K(0.9)) {
+          if (j > i) {
+            smid = R_MIN(A2(sij, i, j), scrit);
+            sjmax = smid;
+            sjmin = smid;
+            if (smid < smin && A2(sij, i, j + 1) < smid) {
+              smin = smid;
+              sjmax = R_MIN(R_MIN(A2(sij, i, j + 1), A2(sij, i, j)), scrit);
+              sjmin = R_MAX(A2(sij, i, j - 1), A2(sij, i, j));
+              sjmin = R_MIN(sjmin, scrit);
+            }
+          } else {
+            sjmax = R_MAX(A2(sij, i, j + 1), scrit);
+            smid = R_MAX(A2(sij, i, j), scrit);
+            sjmin = K(0.0);
+            if (j > 1) sjmin = A2(sij, i, j - 1);
+            sjmin = R_MAX(sjmin, scrit);
+          }
+          delp = R_ABS(sjmax - smid);
+          delm = R_ABS(sjmin - smid);
+          asij = asij + (delp + delm) * (phconv_hpa[j] - phconv_hpa[j + 1]);
+          A2(ment, i, j) = A2(ment, i, j) * (delp + delm) * (phconv_hpa[j] - phconv_hpa[j + 1]);
+        }
+      }
+      asij = R_MAX(K(1.0e-21), asij);
+      asij = K(1.0) / asij;
+      for (j = icb; j <= inb; j++) A2(ment, i, j) = A2(ment, i, j) * asij;
+      bsum = K(0.0);
+      for (j = icb; j <= inb; j++) bsum = bsum + A2(ment, i, j);
+      if (bsum < K(1.0e-18)) {
+        nent[i] = 0;
+        A2(ment, i, i) = m[i];
+        A2(qent, i, i) = qconv[nk] - ep[i] * clw[i];
+        A2(elij, i, i) = clw[i];
+        A2(sij, i, i) = K(1.0);
+      }
+    }
+  }
+  if (!(ep[inb] < K(0.0001))) {
+    jtt = 2;
+    for (i = inb; i >= 1; i--) {
+      wdtrain = g * ep[i] * m[i] * clw[i];
+      if (i > 1)
+        for (j = 1; j <= i - 1; j++) {
+          awat = A2(elij, j, i) - (K(1.) - ep[i]) * clw[i];
+          awat = R_MAX(K(0.0), awat);
+          wdtrain = wdtrain + g * awat * A2(ment, j, i);
+        }
+      coeff = coeffs;
+      wt[i] = omtsnow;
+      if (tconv[i] > K(273.0)) { coeff = coeffr; wt[i] = omtrain; }
+      qsm = K(0.5) * (qconv[i] + qp[i + 1]);
+      afac = coeff * phconv_hpa[i] * (qsconv[i] - qsm) / (K(1.0e4) + K(2.0e3) * phconv_hpa[i] * qsconv[i]);
+      afac = R_MAX(afac, K(0.0));
+      sigt = sigp[i];
+      sigt = R_MAX(K(0.0), sigt);
+      sigt = R_MIN(K(1.0), sigt);
+      b6 = K(100.) * (phconv_hpa[i] - phconv_hpa[i + 1]) * sigt * afac / wt[i];
+      c6 = (water[i + 1] * wt[i + 1] + wdtrain / sigd) / wt[i];
+      revap = K(0.5) * (-b6 + R_SQRT(b6 * b6 + K(4.) * c6));
+      evap[i] = sigt * afac * revap;
+      water[i] = revap * revap;
+      if (i != 1) {
+        dhdp = (h[i] - h[i - 1]) / (pconv_hpa[i - 1] - pconv_hpa[i]);
+        dhdp = R_MAX(dhdp, K(10.0));
+        mp[i] = K(100.) * ginv * lv[i] * sigd * evap[i] / dhdp;
+        mp[i] = R_MAX(mp[i], K(0.0));
+        fac = K(20.0) / (phconv_hpa[i - 1] - phconv_hpa[i]);
+        mp[i] = (fac * mp[i + 1] + mp[i]) / (K(1.) + fac);
+        if (pconv_hpa[i] > (K(0.949) * pconv_hpa[1])) {
+          jtt = I_MAX(jtt, i);
+          mp[i] = mp[jtt] * (pconv_hpa[1] - pconv_hpa[i]) / (pconv_hpa[1] - pconv_hpa[jtt]);
+        }
+      }
+      if (i == inb) continue;
+      if (i == 1) qstm = qsconv[1]; else qstm = qsconv[i - 1];
+      if (mp[i] > mp[i + 1]) {
+        rat = mp[i + 1] / mp[i];
+        qp[i] = qp[i + 1] * rat + qconv[i] * (K(1.0) - rat) + K(100.) * ginv * sigd * (phconv_hpa[i] - phconv_hpa[i + 1]) * (evap[i] / mp[i]);
+      } else {
+        if (mp[i + 1] > K(0.0))
+          qp[i] = (gz[i + 1] - gz[i] + qp[i + 1] * (lv[i + 1] + tconv[i + 1] * (cl - cpd)) + cpd * (tconv[i + 1] - tconv[i])) / (lv[i] + tconv[i] * (cl - cpd));
+      }
+      qp[i] = R_MIN(qp[i], qstm);
+      qp[i] = R_MAX(qp[i], K(0.0));
+    }
+    precip = precip + wt[1] * sigd * water[1] * K(3600.) * K(24000.) / (rowl * g);
+  }
+  wd = beta * R_ABS(mp[icb]) * K(0.01) * rd * tconv[icb] / (sigd * pconv_hpa[icb]);
+  qprime = K(0.5) * (qp[1] - qconv[1]);
+  tprime = lv0 * qprime / cpd;
+  dpinv = K(0.01) / (phconv_hpa[1] - phconv_hpa[2]);
+  am = K(0.0);
+  if (nk == 1)
+    for (k = 2; k <= inb; k++) am = am + m[k];
+  fup[1] = am;
+  if ((K(2.) * g * dpinv * am) >= delti) iflag = 4;
+  ft[1] = ft[1] + g * dpinv * am * (tconv[2] - tconv[1] + (gz[2] - gz[1]) / cpn[1]);
+  ft[1] = ft[1] - lvcp[1] * sigd * evap[1];
+  ft[1] = ft[1] + sigd * wt[2] * (cl - cpd) * water[2] * (tconv[2] - tconv[1]) * dpinv / cpn[1];
+  fq[1] = fq[1] + g * mp[2] * (qp[2] - qconv[1]) * dpinv + sigd * evap[1];
+  fq[1] = fq[1] + g * am * (qconv[2] - qconv[1]) * dpinv;
+  for (j = 2; j <= inb; j++) fq[1] = fq[1] + g * dpinv * A2(ment, j, 1) * (A2(qent, j, 1) - qconv[1]);
+  for (i = 2; i <= inb; i++) {
+    dpinv = K(0.01) / (phconv_hpa[i] - phconv_hpa[i + 1]);
+    cpinv = K(1.0) / cpn[i];
+    amp1 = K(0.0);
+    ad = K(0.0);
+    if (i >= nk)
+      for (k = i + 1; k <= inb + 1; k++) amp1 = amp1 + m[k];
+    for (k = 1; k <= i; k++)
+      for (j = i + 1; j <= inb + 1; j++) amp1 = amp1 + A2(ment, k, j);
+    fup[i] = amp1;
+    if ((K(2.) * g * dpinv * amp1) >= delti) iflag = 4;
+    for (k = 1; k <= i - 1; k++)
+      for (j = i; j <= inb; j++) ad = ad + A2(ment, j, k);
+    fdown[i] = ad;
+    ft[i] = ft[i] + g * dpinv * (amp1 * (tconv[i + 1] - tconv[i] + (gz[i + 1] - gz[i]) * cpinv) - ad * (tconv[i] - tconv[i - 1] + (gz[i] - gz[i - 1]) * cpinv)) -
+            sigd * lvcp[i] * evap[i];
+    ft[i] = ft[i] + g * dpinv * A2(ment, i, i) * (hp[i] - h[i] + tconv[i] * (cpv - cpd) * (qconv[i] - A2(qent, i, i))) * cpinv;
+    ft[i] = ft[i] + sigd * wt[i + 1] * (cl - cpd) * water[i + 1] * (tconv[i + 1] - tconv[i]) * dpinv * cpinv;
+    fq[i] = fq[i] + g * dpinv * (amp1 * (qconv[i + 1] - qconv[i]) - ad * (qconv[i] - qconv[i - 1]));
+    for (k = 1; k <= i - 1; k++) {
+      awat = A2(elij, k, i) - (K(1.) - ep[i]) * clw[i];
+      awat = R_MAX(awat, K(0.0));
+      fq[i] = fq[i] + g * dpinv * A2(ment, k, i) * (A2(qent, k, i) - awat - qconv[i]);
+    }
+    for (k = i; k <= inb; k++) fq[i] = fq[i] + g * dpinv * A2(ment, k, i) * (A2(qent, k, i) - qconv[i]);
+    fq[i] = fq[i] + sigd * evap[i] + g * (mp[i + 1] * (qp[i + 1] - qconv[i]) - mp[i] * (qp[i] - qconv[i - 1])) * dpinv;
+  }
+  fqold = fq[inb];
+  fq[inb] = fq[inb] * (K(1.) - frac);
+  fq[inb - 1] = fq[inb - 1] + frac * fqold * ((phconv_hpa[inb] - phconv_hpa[inb + 1]) / (phconv_hpa[inb - 1] - phconv_hpa[inb])) * lv[inb] / lv[inb - 1];
+  ftold = ft[inb];
+  ft[inb] = ft[inb] * (K(1.) - frac);
+  ft[inb - 1] = ft[inb - 1] + frac * ftold * ((phconv_hpa[inb] - phconv_hpa[inb + 1]) / (phconv_hpa[inb - 1] - phconv_hpa[inb])) * cpn[inb] / cpn[inb - 1];
+  ents = K(0.0);
+  for (i = 1; i <= inb; i++) ents = ents + (cpn[i] * ft[i] + lv[i] * fq[i]) * (phconv_hpa[i] - phconv_hpa[i + 1]);
+  ents = ents / (phconv_hpa[1] - phconv_hpa[inb + 1]);
+  for (i = 1; i <= inb; i++) ft[i] = ft[i] - ents / cpn[i];
+  sub[1] = K(0.);
+  S->nconvtop = 1;
+  for (i = 1; i <= inb + 1; i++) {
+    for (j = 1; j <= inb + 1; j++) {
+      if (j == nk) A2(fmass, j, i) = A2(fmass, j, i) + m[i];
+      A2(fmass, j, i) = A2(fmass, j, i) + A2(ment, j, i);
+      if (A2(fmass, j, i) > epsilon) S->nconvtop = I_MAX(S->nconvtop, I_MAX(i, j));
+    }
+    if (i > 1) sub[i] = fup[i - 1] - fdown[i];
+  }
+  S->nconvtop = S->nconvtop + 1;
+  (void)th;
+  RETURN_;
+#undef RETURN_
+}
+
+/* calcmatrix.f90:56-137, ECMWF branch.  akz, bkz, akm, bkm 1-based [nuvz].  Returns lconv. */
+static int cvo_calcmatrix(cvo_state *S, int nuvz, const real *akz, const real *bkz, const real *akm, const real *bkm, real delt, real *cbmf) {
+  const real ga = K(9.81);
+  int iflag = 0, k, kk, kuvz, lconv = 0;
+  real cbmfold, precip, qprime, tprime, wd, rlevmass, summe;
+  S->phconv[1] = S->psconv;
+  for (kuvz = 2; kuvz <= nuvz; kuvz++) {
+    k = kuvz - 1;
+    S->pconv[k] = (akz[kuvz] + bkz[kuvz] * S->psconv);
+    S->phconv[kuvz] = (akm[kuvz] + bkm[kuvz] * S->psconv);
+    S->dpr[k] = S->phconv[k] - S->phconv[kuvz];
+    S->qsconv[k] = cvo_f_qvsat(S->pconv[k], S->tconv[k]);
+    for (kk = 1; kk <= S->nconvlev; kk++) A2(S->fmassfrac, k, kk) = K(0.);
+  }
+  cbmfold = *cbmf;
+  for (k = 1; k <= S->nconvlev + 1; k++) {
+    S->pconv_hpa[k] = S->pconv[k] / K(100.);
+    S->phconv_hpa[k] = S->phconv[k] / K(100.);
+  }
+  S->phconv_hpa[S->nconvlev + 1] = S->phconv[S->nconvlev + 1] / K(100.);
+  cvo_convect(S, S->nconvlev, delt, &iflag, &precip, &wd, &tprime, &qprime, cbmf);
+  if (iflag != 1 && iflag != 4) { *cbmf = cbmfold; return 0; }
+  if (*cbmf <= K(0.) && cbmfold <= K(0.)) { *cbmf = cbmfold; return 0; }
+  lconv = 1;
+  for (k = 1; k <= S->nconvtop; k++) {
+    rlevmass = S->dpr[k] / ga;
+    summe = K(0.);
+    for (kk = 1; kk <= S->nconvtop; kk++) {
+      A2(S->fmassfrac, k, kk) = delt * A2(S->fmass, k, kk);
+      summe = summe + A2(S->fmassfrac, k, kk);
+    }
+    A2(S->fmassfrac, k, k) = A2(S->fmassfrac, k, k) + rlevmass - summe;
+  }
+  return lconv;
+}
+
+/* redist.f90:49-236.  zt: the particle's height (in/out); ktop in/out; returns whether a random number was drawn. */
+static int cvo_redist(cvo_state *S, real *zt, int *ktop, int ldirect, int lsynctime, real height_nz, real *rn_out) {
+  const real r_air = K(287.05), ga = K(9.81);
+  const real konst = r_air / ga;
+  real *uvzlev = S->uvzlev, *tconv = S->tconv, *qconv = S->qconv, *pconv = S->pconv, *phconv = S->phconv, *dpr = S->dpr, *sub = S->sub;
+  real wsub_lo, wsub_hi;
+  real totlevmass, wsubpart, temp_levold, temp_levold1, sub_levold, sub_levold1;
+  real pint, pold, rn, tv, tvold, dlevfrac = K(0.), ztold, ffraction, tv1, tv2, dlogp, dz, dz1, dz2;
+  int k, kz, levnew, levold = 0, found = 0, drew = 0;
+  if (*ktop <= 1) {
+    tvold = S->tt2conv * (K(1.) + K(0.378) * cvo_ew(S->td2conv) / S->psconv);
+    pold = S->psconv;
+    uvzlev[1] = K(0.);
+    pint = phconv[2];
+    tv1 = tconv[1] * (K(1.) + K(0.608) * qconv[1]);
+    tv2 = tconv[2] * (K(1.) + K(0.608) * qconv[2]);
+    tv = tv1 + (tv2 - tv1) * (pconv[1] - phconv[2]) / (pconv[1] - pconv[2]);
+    if (R_ABS(tv - tvold) > K(0.2)) uvzlev[2] = uvzlev[1] + konst * R_LOG(pold / pint) * (tv - tvold) / R_LOG(tv / tvold);
+    else uvzlev[2] = uvzlev[1] + konst * R_LOG(pold / pint) * tv;
+    tvold = tv; tv1 = tv2; pold = pint;
+    for (kz = 3; kz <= S->nconvtop + 1; kz++) {
+      pint = phconv[kz];
+      tv2 = tconv[kz] * (K(1.) + K(0.608) * qconv[kz]);
+      tv = tv1 + (tv2 - tv1) * (pconv[kz - 1] - phconv[kz]) / (pconv[kz - 1] - pconv[kz]);
+      if (R_ABS(tv - tvold) > K(0.2)) uvzlev[kz] = uvzlev[kz - 1] + konst * R_LOG(pold / pint) * (tv - tvold) / R_LOG(tv / tvold);
+      else uvzlev[kz] = uvzlev[kz - 1] + konst * R_LOG(pold / pint) * tv;
+      tvold = tv; tv1 = tv2; pold = pint;
+    }
+    *ktop = 2;
+  }
+  ztold = *zt;
+  for (kz = 2; kz <= S->nconvtop; kz++)
+    if (uvzlev[kz] >= ztold) { levold = kz - 1; found = 1; break; }
+  if (found) {
+    rn = cvo_ran3(S, &S->iseed);
+    drew = 1;
+    if (rn_out) *rn_out = rn;
+    levnew = levold;
+    ffraction = K(0.);
+    totlevmass = dpr[levold] / ga;
+    for (k = 1; k <= S->nconvtop; k++) {
+      if (ldirect == 1) ffraction = ffraction + A2(S->fmassfrac, levold, k) / totlevmass;
+      else ffraction = ffraction + A2(S->fmassfrac, k, levold) / totlevmass;
+      if (rn <= ffraction) {
+        levnew = k;
+        if (ffraction > K(1.e-20)) {
+          if (ldirect == 1) dlevfrac = (ffraction - rn) / A2(S->fmassfrac, levold, k) * totlevmass;
+          else dlevfrac = (ffraction - rn) / A2(S->fmassfrac, k, levold) * totlevmass;
+        } else dlevfrac = K(0.5);
+        break;
+      }
+    }
+    if (levnew <= S->nconvtop) {
+      if (levnew == levold) *zt = ztold;
+      else {
+        dlogp = (K(1.) - dlevfrac) * (R_LOG(phconv[levnew + 1]) - R_LOG(phconv[levnew]));
+        pint = R_LOG(phconv[levnew]) + dlogp;
+        dz1 = pint - R_LOG(phconv[levnew]);
+        dz2 = R_LOG(phconv[levnew + 1]) - pint;
+        dz = dz1 + dz2;
+        *zt = (uvzlev[levnew] * dz2 + uvzlev[levnew + 1] * dz1) / dz;
+        if (*zt < K(0.)) *zt = K(-1.) * *zt;
+      }
+    }
+    if (levnew <= S->nconvtop && levnew == levold) {
+      ztold = *zt;
+      if (levold > 1) {
+        temp_levold = tconv[levold - 1] + (tconv[levold] - tconv[levold - 1]) * (pconv[levold - 1] - phconv[levold]) / (pconv[levold - 1] - pconv[levold]);
+        sub_levold = sub[levold] / (K(1.) - sub[levold] / dpr[levold] * ga);
+        wsub_lo = K(-1.) * sub_levold * r_air * temp_levold / (phconv[levold]);
+      } else wsub_lo = K(0.);
+      temp_levold1 = tconv[levold] + (tconv[levold + 1] - tconv[levold]) * (pconv[levold] - phconv[levold + 1]) / (pconv[levold] - pconv[levold + 1]);
+      sub_levold1 = sub[levold + 1] / (K(1.) - sub[levold + 1] / dpr[levold + 1] * ga);
+      wsub_hi = K(-1.) * sub_levold1 * r_air * temp_levold1 / (phconv[levold + 1]);
+      dz1 = ztold - uvzlev[levold];
+      dz2 = uvzlev[levold + 1] - ztold;
+      dz = dz1 + dz2;
+      wsubpart = (dz2 * wsub_lo + dz1 * wsub_hi) / dz;
+      *zt = ztold + wsubpart * (real)lsynctime;
+      if (*zt < K(0.)) *zt = K(-1.) * *zt;
+    }
+  }
+  if (*zt > height_nz - K(0.5)) *zt = height_nz - K(0.5);
+  return drew;
+}
+
+/* sort2.f90 (Numerical Recipes quicksort of arr with the companion brr, insertion sort below 7 elements); 1-based [n].
+ * Not a stable sort: the order of the particles of one column is what this algorithm leaves, and redist draws its
+ * random numbers in that order. */
+static void cvo_sort2(int n, int *arr, int *brr) {
+  enum { M = 7, NSTACK = 50 };
+  int i, ir, j, jstack, k, l, istack[NSTACK + 1];
+  int a, b, temp;
+  jstack = 0;
+  l = 1;
+  ir = n;
+  for (;;) {
+    if (ir - l < M) {
+      for (j = l + 1; j <= ir; j++) {
+        a = arr[j];
+        b = brr[j];
+        for (i = j - 1; i >= 1; i--) {
+          if (arr[i] <= a) break;
+          arr[i + 1] = arr[i];
+          brr[i + 1] = brr[i];
+        }
+        if (i < 1) i = 0;
+        arr[i + 1] = a;
+        brr[i + 1] = b;
+      }
+      if (jstack == 0) return;
+      ir = istack[jstack];
+      l = istack[jstack - 1];
+      jstack = jstack - 2;
+    } else {
+      k = (l + ir) / 2;
+      temp = arr[k]; arr[k] = arr[l + 1]; arr[l + 1] = temp;
+      temp = brr[k]; brr[k] = brr[l + 1]; brr[l + 1] = temp;
+      if (arr[l + 1] > arr[ir]) {
+        temp = arr[l + 1]; arr[l + 1] = arr[ir]; arr[ir] = temp;
+        temp = brr[l + 1]; brr[l + 1] = brr[ir]; brr[ir] = temp;
+      }
+      if (arr[l] > arr[ir]) {
+        temp = arr[l]; arr[l] = arr[ir]; arr[ir] = temp;
+        temp = brr[l]; brr[l] = brr[ir]; brr[ir] = temp;
+      }
+      if (arr[l + 1] > arr[l]) {
+        temp = arr[l + 1]; arr[l + 1] = arr[l]; arr[l] = temp;
+        temp = brr[l + 1]; brr[l + 1] = brr[l]; brr[l] = temp;
+      }
+      i = l + 1;
+      j = ir;
+      a = arr[l];
+      b = brr[l];
+      for (;;) {
+        do i = i + 1; while (arr[i] < a);
+        do j = j - 1; while (arr[j] > a);
+        if (j < i) break;
+        temp = arr[i]; arr[i] = arr[j]; arr[j] = temp;
+        temp = brr[i]; brr[i] = brr[j]; brr[j] = temp;
+      }
+      arr[l] = arr[j];
+      arr[j] = a;
+      brr[l] = brr[j];
+      brr[j] = b;
+      jstack = jstack + 2;
+      if (jstack > NSTACK) return;
+      if (ir - i + 1 >= j - l) {
+        istack[jstack] = ir;
+        istack[jstack - 1] = i;
+        ir = j - 1;
+      } else {
+        istack[jstack] = j - 1;
+        istack[jstack - 1] = l;
+        l = i;
+      }
+    }
+  }
+}
+
+/* ---- the driver: convmix.f90:61-196 (mother grid, ECMWF) ------------------------------------------------------------ */
+typedef struct {
+  int nx, ny, nuvz, nconvlev, ldirect, lsynctime, itime, memtime1, memtime2;
+  const double *akz, *bkz, *akm, *bkm;          /* [nuvz], 0-based */
+  const double *ps, *tt2, *td2;                 /* [2][ny][nx]     */
+  const double *tth, *qvh;                      /* [2][nuvz][ny][nx] */
+  double height_nz;
+  double *cbaseflux;                            /* [ny][nx], in/out */
+  long numpart;
+  const double *xtra1, *ytra1;
+  double *ztra1;
+  const int32_t *itra1;
+  /* diagnostics (may be NULL): per particle the random number drawn (-1: none); per column lconv (-1: not visited) */
+  double *rn;
+  int32_t *lconv_col;
+  int32_t *nconvtop_col;
+  double *fmassfrac_col;                        /* [ncap][nconvlev][nconvlev] of the first ncap convective columns, (k,kk) -> [kk][k] */
+  int32_t *fm_col_id;                           /* [ncap] column index of each stored matrix */
+  int32_t fm_cap, fm_count;
+  int32_t ran3_seeded;                          /* in/out: the shared stream is already initialised (second call) */
+  int32_t state_words[60];                      /* in/out: ma[1..55], inext, inextp, iff, iseed */
+  int32_t status;
+} cvo_args;
+
+static int cvo_nint(double x) { return (int)(x < 0 ? x - 0.5 : x + 0.5); }
+
+void cvo_convmix(cvo_args *A) {
+  cvo_state *S = (cvo_state *)calloc(1, sizeof(cvo_state));
+  const long n = A->numpart;
+  const int nx = A->nx, ny = A->ny, nuvz = A->nuvz;
+  int *igrid = (int *)malloc((n + 1) * sizeof(int)), *ipoint = (int *)malloc((n + 1) * sizeof(int));
+  real *akz = (real *)malloc((nuvz + 1) * sizeof(real)), *bkz = (real *)malloc((nuvz + 1) * sizeof(real));
+  real *akm = (real *)malloc((nuvz + 1) * sizeof(real)), *bkm = (real *)malloc((nuvz + 1) * sizeof(real));
+  const size_t n2 = (size_t)nx * ny, n3 = n2 * nuvz;
+  real dt1, dt2, dtt, delt;
+  int lconv = 0, ktop = 0, igrold, igr, ix = 0, jy = 0, kz;
+  long ipart, kpart;
+  A->status = 0;
+  A->fm_count = 0;
+  for (kz = 1; kz <= nuvz; kz++) { akz[kz] = (real)A->akz[kz - 1]; bkz[kz] = (real)A->bkz[kz - 1]; akm[kz] = (real)A->akm[kz - 1]; bkm[kz] = (real)A->bkm[kz - 1]; }
+  S->nconvlev = A->nconvlev;
+  S->iseed = -88;
+  if (A->ran3_seeded) {
+    for (kz = 1; kz <= 55; kz++) S->ma[kz] = A->state_words[kz];
+    S->inext = A->state_words[56]; S->inextp = A->state_words[57]; S->iff = A->state_words[58]; S->iseed = A->state_words[59];
+  }
+  dt1 = (real)(A->itime - A->memtime1);
+  dt2 = (real)(A->memtime2 - A->itime);
+  dtt = K(1.) / (dt1 + dt2);
+  delt = (real)abs(A->lsynctime);
+  if (n <= 0) goto done;
+  for (ipart = 1; ipart <= n; ipart++) {
+    igrid[ipart] = -1;
+    ipoint[ipart] = (int)ipart;
+    if (A->rn) A->rn[ipart - 1] = -1.0;
+    if (A->itra1[ipart - 1] != A->itime) continue;
+    {
+      /* convmix.f90:100-101: x = xtra1(ipart) into a default real */
+      const real x = (real)A->xtra1[ipart - 1], y = (real)A->ytra1[ipart - 1];
+      ix = cvo_nint((double)x);
+      jy = cvo_nint((double)y);
+      igrid[ipart] = 1 + jy * nx + ix;
+    }
+  }
+  if (A->lconv_col) for (size_t c = 0; c < n2; c++) A->lconv_col[c] = -1;
+  cvo_sort2((int)n, igrid, ipoint);
+  igrold = -1;
+  for (kpart = 1; kpart <= n; kpart++) {
+    igr = igrid[kpart];
+    if (igr == -1) continue;
+    ipart = ipoint[kpart];
+    if (igr != igrold) {
+      jy = (igr - 1) / nx;
+      ix = igr - jy * nx - 1;
+      {
+        const size_t c = (size_t)jy * nx + ix;
+        S->psconv = ((real)A->ps[c] * dt2 + (real)A->ps[n2 + c] * dt1) * dtt;
+        S->tt2conv = ((real)A->tt2[c] * dt2 + (real)A->tt2[n2 + c] * dt1) * dtt;
+        S->td2conv = ((real)A->td2[c] * dt2 + (real)A->td2[n2 + c] * dt1) * dtt;
+        for (kz = 1; kz <= nuvz - 1; kz++) {
+          S->tconv[kz] = ((real)A->tth[(size_t)kz * n2 + c] * dt2 + (real)A->tth[n3 + (size_t)kz * n2 + c] * dt1) * dtt;
+          S->qconv[kz] = ((real)A->qvh[(size_t)kz * n2 + c] * dt2 + (real)A->qvh[n3 + (size_t)kz * n2 + c] * dt1) * dtt;
+        }
+        {
+          real cb = (real)A->cbaseflux[c];
+          lconv = cvo_calcmatrix(S, nuvz, akz, bkz, akm, bkm, delt, &cb);
+          A->cbaseflux[c] = (double)cb;
+        }
+        if (A->lconv_col) A->lconv_col[c] = lconv;
+        if (A->nconvtop_col) A->nconvtop_col[c] = lconv ? S->nconvtop : 0;
+        if (lconv && A->fmassfrac_col && A->fm_count < A->fm_cap) {
+          const int nl = S->nconvlev;
+          double *dst = A->fmassfrac_col + (size_t)A->fm_count * nl * nl;
+          for (int kk = 1; kk <= nl; kk++)
+            for (int k = 1; k <= nl; k++) dst[(size_t)(kk - 1) * nl + (k - 1)] = (k <= S->nconvtop && kk <= S->nconvtop) ? (double)A2(S->fmassfrac, k, kk) : 0.0;
+          A->fm_col_id[A->fm_count++] = (int32_t)c;
+        }
+      }
+      igrold = igr;
+      ktop = 0;
+    }
+    if (lconv) {
+      real zt = (real)A->ztra1[ipart - 1], rn = K(-1.);
+      const int drew = cvo_redist(S, &zt, &ktop, A->ldirect, A->lsynctime, (real)A->height_nz, &rn);
+      A->ztra1[ipart - 1] = (double)zt;
+      if (A->rn && drew) A->rn[ipart - 1] = (double)rn;
+    }
+  }
+done:
+  for (kz = 1; kz <= 55; kz++) A->state_words[kz] = S->ma[kz];
+  A->state_words[56] = S->inext; A->state_words[57] = S->inextp; A->state_words[58] = S->iff; A->state_words[59] = S->iseed;
+  A->ran3_seeded = 1;
+  free(igrid); free(ipoint); free(akz); free(bkz); free(akm); free(bkm); free(S);
+}
+
+/* one column, for unit tests of CONVECT against the flang build: profiles in, iflag / cbmf / nconvtop / fmass / sub out */
+typedef struct {
+  int nuvz, nconvlev;
+  const double *akz, *bkz, *akm, *bkm;   /* [nuvz] */
+  double psconv, delt, cbmf;
+  const double *tconv, *qconv;           /* [nuvz-1] */
+  int32_t lconv, nconvtop;
+  double *fmassfrac;                     /* [nconvlev][nconvlev], (k,kk) -> [kk-1][k-1] */
+  double *sub;                           /* [nconvlev+1] */
+} cvo_column;
+
+void cvo_column_matrix(cvo_column *C) {
+  cvo_state *S = (cvo_state *)calloc(1, sizeof(cvo_state));
+  const int nuvz = C->nuvz;
+  real *akz = (real *)malloc((nuvz + 1) * sizeof(real)), *bkz = (real *)malloc((nuvz + 1) * sizeof(real));
+  real *akm = (real *)malloc((nuvz + 1) * sizeof(real)), *bkm = (real *)malloc((nuvz + 1) * sizeof(real));
+  real cb = (real)C->cbmf;
+  int kz;
+  for (kz = 1; kz <= nuvz; kz++) { akz[kz] = (real)C->akz[kz - 1]; bkz[kz] = (real)C->bkz[kz - 1]; akm[kz] = (real)C->akm[kz - 1]; bkm[kz] = (real)C->bkm[kz - 1]; }
+  S->nconvlev = C->nconvlev;
+  S->psconv = (real)C->psconv;
+  for (kz = 1; kz <= nuvz - 1; kz++) { S->tconv[kz] = (real)C->tconv[kz - 1]; S->qconv[kz] = (real)C->qconv[kz - 1]; }
+  C->lconv = cvo_calcmatrix(S, nuvz, akz, bkz, akm, bkm, (real)C->delt, &cb);
+  C->cbmf = (double)cb;
+  C->nconvtop = C->lconv ? S->nconvtop : 0;
+  {
+    const int nl = S->nconvlev;
+    for (int kk = 1; kk <= nl; kk++)
+      for (int k = 1; k <= nl; k++) C->fmassfrac[(size_t)(kk - 1) * nl + (k - 1)] = (double)A2(S->fmassfrac, k, kk);
+    for (int k = 1; k <= nl + 1; k++) C->sub[k - 1] = (double)S->sub[k];
+  }
+  free(akz); free(bkz); free(akm); free(bkm); free(S);
+}

@@ -18,7 +18,7 @@ def build(force=False):
     """Compile liboracle_r4.so / liboracle_r8.so with gcc (a few seconds)."""
     for stem, lib in (("flexpart_oracle", "liboracle"), ("verttransform_oracle", "libvtoracle"),
                       ("partoutput_oracle", "libpooracle"), ("readpart_oracle", "librporacle"), ("release_oracle", "librloracle"),
-                      ("calcpar_oracle", "libcporacle")):
+                      ("calcpar_oracle", "libcporacle"), ("convect_oracle", "libcvoracle")):
         src = os.path.join(HERE, stem + ".c")
         for kind, real in (("r4", "float"), ("r8", "double")):
             out = os.path.join(HERE, f"{lib}_{kind}.so")
@@ -672,3 +672,57 @@ def cp_leaves(ps, t, td, stress, kind="r8"):
     for i in range(ps.size):
         o[i] = (lib.cpo_scalev(ps[i], t[i], td[i], stress[i]), lib.cpo_ew(td[i]), lib.cpo_f_qvsat(ps[i], t[i]))
     return o
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convective mixing (convmix / calcmatrix / convect43c / redist): oracle/convect_oracle.c
+# ---------------------------------------------------------------------------------------------------------
+class _CvoArgs(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("nuvz", C.c_int), ("nconvlev", C.c_int), ("ldirect", C.c_int), ("lsynctime", C.c_int),
+                ("itime", C.c_int), ("memtime1", C.c_int), ("memtime2", C.c_int),
+                ("akz", C.c_void_p), ("bkz", C.c_void_p), ("akm", C.c_void_p), ("bkm", C.c_void_p),
+                ("ps", C.c_void_p), ("tt2", C.c_void_p), ("td2", C.c_void_p), ("tth", C.c_void_p), ("qvh", C.c_void_p),
+                ("height_nz", C.c_double), ("cbaseflux", C.c_void_p), ("numpart", C.c_long),
+                ("xtra1", C.c_void_p), ("ytra1", C.c_void_p), ("ztra1", C.c_void_p), ("itra1", C.c_void_p),
+                ("rn", C.c_void_p), ("lconv_col", C.c_void_p), ("nconvtop_col", C.c_void_p), ("fmassfrac_col", C.c_void_p),
+                ("fm_col_id", C.c_void_p), ("fm_cap", C.c_int32), ("fm_count", C.c_int32), ("ran3_seeded", C.c_int32),
+                ("state_words", C.c_int32 * 60), ("status", C.c_int32)]
+
+
+def conv_oracle(cs, kind="r8", fm_cap=8):
+    """convmix on a synthetic.convection_case() dict, one entry per call: ztra1, cbaseflux, lconv / nconvtop per column,
+    the random number each particle drew (-1: none), the redistribution matrices of the first fm_cap convective columns."""
+    build()
+    lib = C.CDLL(os.path.join(HERE, f"libcvoracle_{kind}.so"))
+    nx, ny, nuvz = (int(v) for v in cs["grid"])
+    n = int(cs["npart"])
+    nl = int(cs["nconvlev"])
+    keep = {k: _f64(cs[k]) for k in ("akz", "bkz", "akm", "bkm", "ps", "tt2", "td2", "tth", "qvh", "xtra1", "ytra1")}
+    z = _f64(cs["ztra1"]).copy()
+    rt = np.float32 if kind == "r4" else np.float64
+    z = z.astype(rt).astype(np.float64)                      # com_mod ztra1 is a default real
+    cb = _f64(cs["cbaseflux"]).astype(rt).astype(np.float64)          # conv_mod cbaseflux likewise
+    a = _CvoArgs()
+    a.nx, a.ny, a.nuvz, a.nconvlev, a.ldirect, a.lsynctime = nx, ny, nuvz, nl, int(cs["ldirect"]), int(cs["lsynctime"])
+    a.memtime1, a.memtime2 = int(cs["memtime"][0]), int(cs["memtime"][1])
+    for k in ("akz", "bkz", "akm", "bkm", "ps", "tt2", "td2", "tth", "qvh", "xtra1", "ytra1"):
+        setattr(a, k, keep[k].ctypes.data)
+    a.height_nz = float(cs["height_nz"])
+    a.cbaseflux = cb.ctypes.data
+    a.numpart = n
+    a.ztra1 = z.ctypes.data
+    a.fm_cap = fm_cap
+    a.ran3_seeded = 0
+    out = []
+    for ic, itime in enumerate(int(t) for t in cs["itimes"]):
+        itra1 = np.where(np.asarray(cs["due"])[:, ic], itime, itime + 12345).astype(np.int32)
+        rn = np.zeros(n)
+        lc = np.zeros((ny, nx), np.int32); nt = np.zeros((ny, nx), np.int32)
+        fm = np.zeros((fm_cap, nl, nl)); fid = np.full(fm_cap, -1, np.int32)
+        a.itime = itime
+        a.itra1 = itra1.ctypes.data
+        a.rn, a.lconv_col, a.nconvtop_col = rn.ctypes.data, lc.ctypes.data, nt.ctypes.data
+        a.fmassfrac_col, a.fm_col_id = fm.ctypes.data, fid.ctypes.data
+        lib.cvo_convmix(C.byref(a))
+        out.append(dict(ztra1=z.copy(), cbaseflux=cb.copy(), lconv=lc, nconvtop=nt, rn=rn, fmassfrac=fm, fm_col=fid, fm_count=int(a.fm_count)))
+    return out

@@ -1,0 +1,176 @@
+! TEST INFRASTRUCTURE ONLY -- never linked into or called by the product path.
+!
+! ref_conv_driver: runs the *unmodified* reference routines of the convective mixing that compile in this image --
+! CONVECT / TLIFT (convect43c.f90), redist (redist.f90), sort2 (sort2.f90), f_qvsat (qvsat.f90), ew (ew.f90), ran3
+! (random_mod.f90), with par_mod / com_mod / conv_mod, all compiled where they lie by oracle/build_ref.sh -- over a
+! scenario file, so that oracle/convect_oracle.c can be pinned against them (SURVEY section 8 f3).
+! convmix.f90 and calcmatrix.f90 themselves `use class_gribfile` (ecCodes' grib_api) and cannot be built here; the two
+! subroutines below, glue_calcmatrix and the particle loop of the main program, are OUR restatement of their ECMWF branch
+! (calcmatrix.f90:56-137, convmix.f90:61-196) around the real CONVECT and REDIST.  This file is our own code: it
+! contains no reference source.
+!
+! Usage:  convref_rK in.bin out.bin
+program convref
+  use par_mod
+  use com_mod
+  use conv_mod
+  implicit none
+  character(len=512) :: fin, fout
+  integer(kind=4) :: hdr(12)
+  integer :: nxl, nyl, nuvzl, ncalls, fmcap, n, ic, i, j, k, kk
+  real(kind=8) :: hnz
+  real(kind=8), allocatable :: akz8(:), bkz8(:), akm8(:), bkm8(:), ps8(:,:,:), tt28(:,:,:), td28(:,:,:)
+  real(kind=8), allocatable :: tth8(:,:,:,:), qvh8(:,:,:,:), cb8(:,:), x8(:), y8(:), z8(:), fm8(:,:,:)
+  integer(kind=4), allocatable :: itimes(:), due(:,:), lconvcol(:,:), ntopcol(:,:), fmcol(:)
+  integer, allocatable :: igrid(:), ipoint(:)
+  real, allocatable :: cbl(:,:)
+  integer(kind=4) :: fmcount
+  integer :: itime, igr, igrold, ipart, kpart, ix, jy, ktop, ipconv, kz
+  logical :: lconv
+  real :: x, y, dt1, dt2, dtt, delt
+  integer :: mt1, mt2
+
+  call get_command_argument(1, fin)
+  call get_command_argument(2, fout)
+  open(31, file=trim(fin), access='stream', form='unformatted', status='old')
+  read(31) hdr
+  nxl = hdr(1); nyl = hdr(2); nuvzl = hdr(3); nconvlev = hdr(4); ldirect = hdr(5); lsynctime = hdr(6)
+  mt1 = hdr(7); mt2 = hdr(8); n = hdr(9); ncalls = hdr(10); fmcap = hdr(11); nz = hdr(12)
+  if (nuvzl > nuvzmax .or. nconvlev > nconvlevmax - 1 .or. n > maxpart .or. nz > nzmax) then
+    print *, 'convref: scenario larger than the compile-time sizes of par_mod'
+    stop 2
+  end if
+  read(31) hnz
+  allocate(akz8(nuvzl), bkz8(nuvzl), akm8(nuvzl), bkm8(nuvzl), ps8(nxl,nyl,2), tt28(nxl,nyl,2), td28(nxl,nyl,2))
+  allocate(tth8(nxl,nyl,nuvzl,2), qvh8(nxl,nyl,nuvzl,2), cb8(nxl,nyl), x8(n), y8(n), z8(n))
+  allocate(itimes(ncalls), due(n,ncalls), lconvcol(nxl,nyl), ntopcol(nxl,nyl), fmcol(fmcap), fm8(nconvlev,nconvlev,fmcap))
+  allocate(igrid(n), ipoint(n), cbl(nxl,nyl))
+  read(31) akz8, bkz8, akm8, bkm8, ps8, tt28, td28, tth8, qvh8, cb8, x8, y8, z8, itimes, due
+  close(31)
+  nuvz = nuvzl
+  do k = 1, nuvzl
+    akz(k) = real(akz8(k)); bkz(k) = real(bkz8(k)); akm(k) = real(akm8(k)); bkm(k) = real(bkm8(k))
+  end do
+  height(nz) = real(hnz)
+  numpart = n
+  call com_mod_allocate_part(n)
+  do i = 1, n
+    xtra1(i) = x8(i); ytra1(i) = y8(i); ztra1(i) = real(z8(i))
+  end do
+  cbl = real(cb8)
+
+  open(32, file=trim(fout), access='stream', form='unformatted', status='replace')
+  do ic = 1, ncalls
+    itime = itimes(ic)
+    dt1 = real(itime - mt1)
+    dt2 = real(mt2 - itime)
+    dtt = 1. / (dt1 + dt2)
+    delt = real(abs(lsynctime))
+    lconvcol = -1; ntopcol = 0; fmcount = 0; fm8 = 0.d0; fmcol = -1
+    lconv = .false.
+    ! convmix.f90:92-135 (mother grid)
+    do ipart = 1, n
+      igrid(ipart) = -1
+      ipoint(ipart) = ipart
+      if (due(ipart, ic) == 0) cycle
+      x = xtra1(ipart)
+      y = ytra1(ipart)
+      ix = nint(x)
+      jy = nint(y)
+      igrid(ipart) = 1 + jy * nxl + ix
+    end do
+    call sort2(n, igrid, ipoint)
+    igrold = -1
+    ktop = 0
+    do kpart = 1, n
+      igr = igrid(kpart)
+      if (igr == -1) cycle
+      ipart = ipoint(kpart)
+      if (igr /= igrold) then
+        jy = (igr - 1) / nxl
+        ix = igr - jy * nxl - 1
+        ! convmix.f90:154-166: the column's profiles at the particle time
+        psconv = (real(ps8(ix+1,jy+1,1)) * dt2 + real(ps8(ix+1,jy+1,2)) * dt1) * dtt
+        tt2conv = (real(tt28(ix+1,jy+1,1)) * dt2 + real(tt28(ix+1,jy+1,2)) * dt1) * dtt
+        td2conv = (real(td28(ix+1,jy+1,1)) * dt2 + real(td28(ix+1,jy+1,2)) * dt1) * dtt
+        do kz = 1, nuvzl - 1
+          tconv(kz) = (real(tth8(ix+1,jy+1,kz+1,1)) * dt2 + real(tth8(ix+1,jy+1,kz+1,2)) * dt1) * dtt
+          qconv(kz) = (real(qvh8(ix+1,jy+1,kz+1,1)) * dt2 + real(qvh8(ix+1,jy+1,kz+1,2)) * dt1) * dtt
+        end do
+        call glue_calcmatrix(lconv, delt, cbl(ix+1,jy+1))
+        lconvcol(ix+1,jy+1) = merge(1, 0, lconv)
+        if (lconv) ntopcol(ix+1,jy+1) = nconvtop
+        if (lconv .and. fmcount < fmcap) then
+          fmcount = fmcount + 1
+          fmcol(fmcount) = jy * nxl + ix
+          do kk = 1, nconvlev
+            do k = 1, nconvlev
+              if (k <= nconvtop .and. kk <= nconvtop) fm8(k, kk, fmcount) = fmassfrac(k, kk)
+            end do
+          end do
+        end if
+        igrold = igr
+        ktop = 0
+      end if
+      if (lconv) then
+        itra1(ipart) = itime
+        call redist(ipart, ktop, ipconv)
+      end if
+    end do
+    do i = 1, n
+      z8(i) = ztra1(i)
+    end do
+    cb8 = cbl
+    write(32) z8, cb8, lconvcol, ntopcol, fmcount, fmcol, fm8
+  end do
+  close(32)
+
+contains
+
+  ! our restatement of calcmatrix.f90:56-137 (ECMWF branch) around the reference's CONVECT
+  subroutine glue_calcmatrix(lconv, delt, cbmf)
+    logical, intent(out) :: lconv
+    real, intent(in) :: delt
+    real, intent(inout) :: cbmf
+    real :: rlevmass, summe, cbmfold, precip, qprime, tprime, wd, f_qvsat
+    integer :: iflag, k, kk, kuvz
+    lconv = .false.
+    phconv(1) = psconv
+    do kuvz = 2, nuvz
+      k = kuvz - 1
+      pconv(k) = (akz(kuvz) + bkz(kuvz) * psconv)
+      phconv(kuvz) = (akm(kuvz) + bkm(kuvz) * psconv)
+      dpr(k) = phconv(k) - phconv(kuvz)
+      qsconv(k) = f_qvsat(pconv(k), tconv(k))
+      do kk = 1, nconvlev
+        fmassfrac(k, kk) = 0.
+      end do
+    end do
+    cbmfold = cbmf
+    do k = 1, nconvlev + 1
+      pconv_hpa(k) = pconv(k) / 100.
+      phconv_hpa(k) = phconv(k) / 100.
+    end do
+    phconv_hpa(nconvlev + 1) = phconv(nconvlev + 1) / 100.
+    call convect(nconvlevmax, nconvlev, delt, iflag, precip, wd, tprime, qprime, cbmf)
+    if (iflag /= 1 .and. iflag /= 4) then
+      cbmf = cbmfold
+      return
+    end if
+    if (cbmf <= 0. .and. cbmfold <= 0.) then
+      cbmf = cbmfold
+      return
+    end if
+    lconv = .true.
+    do k = 1, nconvtop
+      rlevmass = dpr(k) / ga
+      summe = 0.
+      do kk = 1, nconvtop
+        fmassfrac(k, kk) = delt * fmass(k, kk)
+        summe = summe + fmassfrac(k, kk)
+      end do
+      fmassfrac(k, k) = fmassfrac(k, k) + rlevmass - summe
+    end do
+  end subroutine glue_calcmatrix
+
+end program convref

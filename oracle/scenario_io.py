@@ -352,3 +352,44 @@ def run_cp_leaf_reference(ps, t, td, stress, kind="r8", workdir="/tmp"):
         if res.returncode != 0:
             raise RuntimeError(f"reference calcpar leaf driver failed: {res.stdout}\n{res.stderr}")
         return np.frombuffer(open(fo, "rb").read(), dtype=np.float64).reshape(3, n).T.copy()
+
+
+def have_conv_ref(kind="r8"):
+    return os.access(os.path.join(HERE, "_ref", f"convref_{kind}"), os.X_OK)
+
+
+def run_conv_reference(cs, kind="r8", workdir="/tmp", fm_cap=8):
+    """The unmodified CONVECT / TLIFT, redist, sort2, f_qvsat, ew, ran3 (behind oracle/ref_conv_driver.f90, which carries our
+    restatement of the calcmatrix / convmix glue) on a synthetic.convection_case() dict -> one dict per call."""
+    import tempfile
+    nx, ny, nuvz = (int(v) for v in cs["grid"])
+    n, nl = int(cs["npart"]), int(cs["nconvlev"])
+    ncalls = len(cs["itimes"])
+    f8 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64)).tobytes()
+    with tempfile.TemporaryDirectory(prefix="conv_", dir=workdir) as d:
+        fi, fo = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fi, "wb") as fh:
+            fh.write(struct.pack("<12i", nx, ny, nuvz, nl, int(cs["ldirect"]), int(cs["lsynctime"]), int(cs["memtime"][0]), int(cs["memtime"][1]),
+                                 n, ncalls, fm_cap, 10))
+            fh.write(struct.pack("<d", float(cs["height_nz"])))
+            for k in ("akz", "bkz", "akm", "bkm", "ps", "tt2", "td2", "tth", "qvh", "cbaseflux", "xtra1", "ytra1", "ztra1"):
+                fh.write(f8(cs[k]))           # C order [slot][level][jy][ix] == Fortran (ix,jy,level,slot)
+            fh.write(np.asarray(cs["itimes"], dtype=np.int32).tobytes())
+            fh.write(np.ascontiguousarray(np.asarray(cs["due"]).T.astype(np.int32)).tobytes())     # due(n,ncalls) column-major
+        exe = os.path.join(HERE, "_ref", f"convref_{kind}")
+        res = subprocess.run([exe, fi, fo], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError(f"reference convection driver failed: {res.stdout}\n{res.stderr}")
+        raw = open(fo, "rb").read()
+    out, off = [], 0
+    def take(dt, shape):
+        nonlocal off
+        cnt = int(np.prod(shape))
+        a = np.frombuffer(raw, dtype=dt, count=cnt, offset=off).reshape(shape).copy()
+        off += a.nbytes
+        return a
+    for _ in range(ncalls):
+        z = take(np.float64, (n,)); cb = take(np.float64, (ny, nx)); lc = take(np.int32, (ny, nx)); nt = take(np.int32, (ny, nx))
+        cnt = int(take(np.int32, (1,))[0]); fid = take(np.int32, (fm_cap,)); fm = take(np.float64, (fm_cap, nl, nl))
+        out.append(dict(ztra1=z, cbaseflux=cb, lconv=lc, nconvtop=nt, fm_count=cnt, fm_col=fid, fmassfrac=fm))
+    return out
