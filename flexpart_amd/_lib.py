@@ -82,6 +82,15 @@ class FpxCalcparOut(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ustar", "wstar", "oli", "hmix", "tropopause")]
 
 
+class FpxConvConfig(C.Structure):
+    _fields_ = [("struct_bytes", C.c_int32), ("nuvz", C.c_int32), ("nconvlev", C.c_int32), ("reserved", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("akz", "bkz", "akm", "bkm")]
+
+
+class FpxConvFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ps", "tt2", "td2", "tth", "qvh")] + [("nuvzmax", C.c_int32), ("reserved", C.c_int32)]
+
+
 class FpxDiagFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("oro", "pv", "qv", "tt")]
 
@@ -169,6 +178,7 @@ SYMBOLS = [
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
     "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_calcpar", "fpx_calcpar_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
     "fpx_checkpoint_write", "fpx_checkpoint_read",
+    "fpx_conv_init", "fpx_upload_conv_fields", "fpx_convmix", "fpx_convmix_time", "fpx_get_cbaseflux", "fpx_set_cbaseflux",
 ]
 
 _lib = None
@@ -210,6 +220,12 @@ def load():
     lib.fpx_partoutput_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.fpx_concoutput.argtypes = [vp, C.c_int32, C.POINTER(FpxConcout), C.c_char_p, C.c_int32]
     lib.fpx_readpartpositions.argtypes = [vp, C.c_char_p, C.POINTER(FpxRestart), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.fpx_conv_init.argtypes = [vp, C.POINTER(FpxConvConfig)]
+    lib.fpx_upload_conv_fields.argtypes = [vp, C.c_int32, C.POINTER(FpxConvFields)]
+    lib.fpx_convmix.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
+    lib.fpx_convmix_time.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.fpx_get_cbaseflux.argtypes = [vp, vp]
+    lib.fpx_set_cbaseflux.argtypes = [vp, vp]
     lib.fpx_checkpoint_write.argtypes = [vp, C.c_char_p, C.c_int32, C.c_int32]
     lib.fpx_checkpoint_read.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     lib.fpx_set_windtime.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]

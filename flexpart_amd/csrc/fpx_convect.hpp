@@ -1,0 +1,637 @@
+// Device side of fpx_convmix: the reference's convective mixing of particles --
+// convmix.f90:61-196 (particles by grid column), calcmatrix.f90:56-137 (the redistribution matrix of a column, ECMWF
+// branch), convect43c.f90 (Emanuel's scheme CONVECT + TLIFT as the reference ships it), redist.f90:49-236 (the
+// displacement of a particle) -- as HIP kernels for gfx950.
+//
+// Design.  The scheme is a long, strictly sequential computation per grid column (level loops with data-dependent
+// bounds, O(levels^2) matrices) and only columns that hold particles are computed, so the parallel axis is the column:
+//   k_conv_mark    one lane per particle: its column (nint of the grid coordinates), a flag per column
+//   (scan)         the columns that hold particles, in grid order
+//   k_conv_column  one lane per such column: profiles at the particle time, CONVECT, the matrix fmassfrac, the heights
+//                  of the half levels.  All per-column arrays (35 vectors, 5 matrices) live in HBM scratch interleaved
+//                  by column -- element e of column c at [e * B + c] -- so that the lanes of a wave, which walk the same
+//                  loops, touch one contiguous segment per access.  Columns are processed in batches of B that fit the
+//                  scratch budget.
+//   k_conv_redist  one lane per particle of a convective column: level search, one uniform random number, the walk
+//                  along its matrix row, new height or the compensating subsidence.
+// Arithmetic is in the host's real kind H (the reference computes in its default real) with FMA contraction off and
+// in the reference's order of operations; only libm (exp, log, pow) can differ from the CPU result.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fpx_calcpar.hpp"
+#include "fpx_verttransform.hpp"
+
+namespace fpx {
+namespace conv {
+
+using vt::M;
+#define HK(x) ((H)(x))
+#define R_ABS(a) ((a) < 0 ? -(a) : (a))
+#define R_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define R_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define I_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define I_MIN(a, b) ((a) < (b) ? (a) : (b))
+
+// the per-column arrays (1-based index i in 0..nv-1 is used as in the Fortran; element 0 is unused)
+enum Vec { V_fup, V_fdown, V_m, V_mp, V_tvp, V_tv, V_water, V_qp, V_ep, V_th, V_wt, V_evap, V_clw, V_sigp, V_tp, V_cpn, V_lv, V_lvcp,
+           V_h, V_hp, V_gz, V_hm, V_nent, V_tconv, V_qconv, V_qsconv, V_pconv_hpa, V_phconv_hpa, V_ft, V_fq, V_sub, V_pconv,
+           V_phconv, V_dpr, V_uvzlev, V_COUNT };
+enum Mat { M_fmass, M_ment, M_qent, M_elij, M_sij, M_COUNT };
+constexpr int M_fmassfrac = M_fmass;      // calcmatrix scales fmass into fmassfrac in place
+
+template <typename H>
+struct Scr {
+  H *v;          // [V_COUNT][nv][B]
+  H *mat;        // [M_COUNT][nv][nv][B], column-major A(i,j) -> [j][i]
+  int B, c, nv;
+};
+#define VV(name, i) Sx.v[((size_t)V_##name * Sx.nv + (size_t)(i)) * Sx.B + Sx.c]
+#define MM(name, i, j) Sx.mat[(((size_t)M_##name * Sx.nv + (size_t)(j)) * Sx.nv + (size_t)(i)) * Sx.B + Sx.c]
+
+template <typename H>
+__host__ __device__ inline size_t scratch_elems_per_column(int nv) { return (size_t)V_COUNT * nv + (size_t)M_COUNT * nv * nv; }
+
+template <typename H>
+__device__ void tlift(const Scr<H> &Sx, int icb, int nk, int nl, int kk) {
+#pragma clang fp contract(off)
+  const H cpd = HK(1005.7), cpv = HK(1870.0), cl = HK(2500.0), rv = HK(461.5), rd = HK(287.04), lv0 = HK(2.501e6);
+  const H cpvmcl = cl - cpv, eps0 = rd / rv, epsi = HK(1.) / eps0;
+  H ah0, ahg, alv, cpinv, cpp, denom, es, qg, rg, s, tc, tg;
+  int i, j, nsb, nst;
+  ah0 = (cpd * (HK(1.) - VV(qconv, nk)) + cl * VV(qconv, nk)) * VV(tconv, nk) + VV(qconv, nk) * (lv0 - cpvmcl * (VV(tconv, nk) - HK(273.15))) + VV(gz, nk);
+  cpp = cpd * (HK(1.) - VV(qconv, nk)) + VV(qconv, nk) * cpv;
+  cpinv = HK(1.) / cpp;
+  if (kk == 1) {
+    for (i = 1; i <= icb - 1; i++) VV(clw, i) = HK(0.0);
+    for (i = nk; i <= icb - 1; i++) {
+      VV(tp, i) = VV(tconv, nk) - (VV(gz, i) - VV(gz, nk)) * cpinv;
+      VV(tvp, i) = VV(tp, i) * (HK(1.) + VV(qconv, nk) * epsi);
+    }
+  }
+  nst = icb;
+  nsb = icb;
+  if (kk == 2) { nst = nl; nsb = icb + 1; }
+  for (i = nsb; i <= nst; i++) {
+    tg = VV(tconv, i);
+    qg = VV(qsconv, i);
+    alv = lv0 - cpvmcl * (VV(tconv, i) - HK(273.15));
+    for (j = 1; j <= 2; j++) {
+      s = cpd + alv * alv * qg / (rv * VV(tconv, i) * VV(tconv, i));
+      s = HK(1.) / s;
+      ahg = cpd * tg + (cl - cpd) * VV(qconv, nk) * VV(tconv, i) + alv * qg + VV(gz, i);
+      tg = tg + s * (ah0 - ahg);
+      tg = R_MAX(tg, HK(35.0));
+      tc = tg - HK(273.15);
+      denom = HK(243.5) + tc;
+      if (tc >= HK(0.0)) es = HK(6.112) * M<H>::exp(HK(17.67) * tc / denom);
+      else es = M<H>::exp(HK(23.33086) - HK(6111.72784) / tg + HK(0.15215) * M<H>::log(tg));
+      qg = eps0 * es / (VV(pconv_hpa, i) - es * (HK(1.) - eps0));
+    }
+    alv = lv0 - cpvmcl * (VV(tconv, i) - HK(273.15));
+    VV(tp, i) = (ah0 - (cl - cpd) * VV(qconv, nk) * VV(tconv, i) - VV(gz, i) - alv * qg) / cpd;
+    VV(clw, i) = VV(qconv, nk) - qg;
+    VV(clw, i) = R_MAX(HK(0.0), VV(clw, i));
+    rg = qg / (HK(1.) - VV(qconv, nk));
+    VV(tvp, i) = VV(tp, i) * (HK(1.) + rg * epsi);
+  }
+}
+
+
+template <typename H>
+__device__ void convect(const Scr<H> &Sx, int nl, H delt, int &iflag_, H &cbmf_, int &nconvtop_) {
+#pragma clang fp contract(off)
+  const H elcrit = HK(.0011), tlcrit = HK(-55.0), entp = HK(1.5), sigd = HK(0.05), sigs = HK(0.12), omtrain = HK(50.0), omtsnow = HK(5.5);
+  const H coeffr = HK(1.0), coeffs = HK(0.8), beta = HK(10.0), dtmax = HK(0.9), alpha = HK(0.025), damp = HK(0.1);
+  const H cpd = HK(1005.7), cpv = HK(1870.0), cl = HK(2500.0), rv = HK(461.5), rd = HK(287.04), lv0 = HK(2.501e6), g = HK(9.81), rowl = HK(1000.0);
+  const H cpvmcl = cl - cpv, eps0 = rd / rv, epsi = HK(1.) / eps0, ginv = HK(1.0) / g, epsilon = HK(1.e-20);
+  const int minorig = 1;
+  int iflag = iflag_, i, icb, ihmin, inb, inb1, j, jtt, k, nk;
+  H cbmf = cbmf_, precip, wd, tprime, qprime;
+  H ad, afac, ahmax, ahmin, alt, altem, am, amp1, anum, asij, awat, b6, bf2, bsum, by, byp, c6, cape, capem, cbmfold, chi, coeff;
+  H cpinv, cwat, damps, dbo, dbosum, defrac, dei, delm, delp, delt0, delti, denom, dhdp, dpinv, dtma, dtmin, dtpbl, elacrit, ents;
+  H epmax, fac, fqold, frac, ftold, plcl, qp1, qsm, qstm, qti, rat, rdcp, revap, rh, scrit, sigt, sjmax, sjmin, smid, smin, stemp, tca;
+  H tvaplcl, tvpplcl, tvx, tvy, wdtrain;
+
+  delti = HK(1.0) / delt;
+  for (i = 1; i <= nl + 1; i++) {
+    VV(ft, i) = HK(0.0); VV(fq, i) = HK(0.0); VV(fdown, i) = HK(0.0); VV(sub, i) = HK(0.0); VV(fup, i) = HK(0.0); VV(m, i) = HK(0.0); VV(mp, i) = HK(0.0);
+    for (j = 1; j <= nl + 1; j++) { MM(fmass, i, j) = HK(0.0); MM(ment, i, j) = HK(0.0); }
+  }
+  for (i = 1; i <= nl + 1; i++) {
+    rdcp = (rd * (HK(1.) - VV(qconv, i)) + VV(qconv, i) * rv) / (cpd * (HK(1.) - VV(qconv, i)) + VV(qconv, i) * cpv);
+    VV(th, i) = VV(tconv, i) * M<H>::pow(HK(1000.0) / VV(pconv_hpa, i), rdcp);
+  }
+  precip = HK(0.0); wd = HK(0.0); tprime = HK(0.0); qprime = HK(0.0);
+  iflag = 0;
+#define RETURN_ do { iflag_ = iflag; cbmf_ = cbmf; (void)precip; (void)wd; (void)tprime; (void)qprime; return; } while (0)
+  VV(gz, 1) = HK(0.0);
+  VV(cpn, 1) = cpd * (HK(1.) - VV(qconv, 1)) + VV(qconv, 1) * cpv;
+  VV(h, 1) = VV(tconv, 1) * VV(cpn, 1);
+  VV(lv, 1) = lv0 - cpvmcl * (VV(tconv, 1) - HK(273.15));
+  VV(hm, 1) = VV(lv, 1) * VV(qconv, 1);
+  VV(tv, 1) = VV(tconv, 1) * (HK(1.) + VV(qconv, 1) * epsi - VV(qconv, 1));
+  ahmin = HK(1.0e12);
+  ihmin = nl;
+  for (i = 2; i <= nl + 1; i++) {
+    tvx = VV(tconv, i) * (HK(1.) + VV(qconv, i) * epsi - VV(qconv, i));
+    tvy = VV(tconv, i - 1) * (HK(1.) + VV(qconv, i - 1) * epsi - VV(qconv, i - 1));
+    VV(gz, i) = VV(gz, i - 1) + HK(0.5) * rd * (tvx + tvy) * (VV(pconv_hpa, i - 1) - VV(pconv_hpa, i)) / VV(phconv_hpa, i);
+    VV(cpn, i) = cpd * (HK(1.) - VV(qconv, i)) + cpv * VV(qconv, i);
+    VV(h, i) = VV(tconv, i) * VV(cpn, i) + VV(gz, i);
+    VV(lv, i) = lv0 - cpvmcl * (VV(tconv, i) - HK(273.15));
+    VV(hm, i) = (cpd * (HK(1.) - VV(qconv, i)) + cl * VV(qconv, i)) * (VV(tconv, i) - VV(tconv, 1)) + VV(lv, i) * VV(qconv, i) + VV(gz, i);
+    VV(tv, i) = VV(tconv, i) * (HK(1.) + VV(qconv, i) * epsi - VV(qconv, i));
+    if (i >= minorig && VV(hm, i) < ahmin && VV(hm, i) < VV(hm, i - 1)) { ahmin = VV(hm, i); ihmin = i; }
+  }
+  ihmin = I_MIN(ihmin, nl - 1);
+  ahmax = HK(0.0);
+  nk = minorig;
+  for (i = minorig; i <= ihmin; i++)
+    if (VV(hm, i) > ahmax) { nk = i; ahmax = VV(hm, i); }
+  if (VV(tconv, nk) < HK(250.0) || VV(qconv, nk) <= HK(0.0) || ihmin == (nl - 1)) { iflag = 0; cbmf = HK(0.0); RETURN_; }
+  rh = VV(qconv, nk) / VV(qsconv, nk);
+  chi = VV(tconv, nk) / (HK(1669.0) - HK(122.0) * rh - VV(tconv, nk));
+  plcl = VV(pconv_hpa, nk) * M<H>::pow(rh, chi);
+  if (plcl < HK(200.0) || plcl >= HK(2000.0)) { iflag = 2; cbmf = HK(0.0); RETURN_; }
+  icb = nl - 1;
+  for (i = nk + 1; i <= nl; i++)
+    if (VV(pconv_hpa, i) < plcl) icb = I_MIN(icb, i);
+  if (icb >= (nl - 1)) { iflag = 3; cbmf = HK(0.0); RETURN_; }
+  tlift<H>(Sx, icb, nk, nl, 1);
+  for (i = nk; i <= icb; i++) VV(tvp, i) = VV(tvp, i) - VV(tp, i) * VV(qconv, nk);
+  if (cbmf == HK(0.0) && VV(tvp, icb) <= (VV(tv, icb) - dtmax)) { iflag = 0; RETURN_; }
+  if (iflag != 4) iflag = 1;
+  tlift<H>(Sx, icb, nk, nl, 2);
+  for (i = 1; i <= nk; i++) { VV(ep, i) = HK(0.0); VV(sigp, i) = sigs; }
+  for (i = nk + 1; i <= nl; i++) {
+    tca = VV(tp, i) - HK(273.15);
+    if (tca >= HK(0.0)) elacrit = elcrit; else elacrit = elcrit * (HK(1.0) - tca / tlcrit);
+    elacrit = R_MAX(elacrit, HK(0.0));
+    epmax = HK(0.999);
+    VV(ep, i) = epmax * (HK(1.0) - elacrit / R_MAX(VV(clw, i), HK(1.0e-8)));
+    VV(ep, i) = R_MAX(VV(ep, i), HK(0.0));
+    VV(ep, i) = R_MIN(VV(ep, i), epmax);
+    VV(sigp, i) = sigs;
+  }
+  for (i = icb + 1; i <= nl; i++) VV(tvp, i) = VV(tvp, i) - VV(tp, i) * VV(qconv, nk);
+  VV(tvp, nl + 1) = VV(tvp, nl) - (VV(gz, nl + 1) - VV(gz, nl)) / cpd;
+  for (i = 1; i <= nl + 1; i++) {
+    VV(hp, i) = VV(h, i); VV(nent, i) = 0; VV(water, i) = HK(0.0); VV(evap, i) = HK(0.0); VV(wt, i) = omtsnow; VV(lvcp, i) = VV(lv, i) / VV(cpn, i);
+    for (j = 1; j <= nl + 1; j++) { MM(qent, i, j) = VV(qconv, j); MM(elij, i, j) = HK(0.0); MM(sij, i, j) = HK(0.0); }
+  }
+  VV(qp, 1) = VV(qconv, 1);
+  for (i = 2; i <= nl + 1; i++) VV(qp, i) = VV(qconv, i - 1);
+  cape = HK(0.0); capem = HK(0.0);
+  inb = icb + 1; inb1 = inb;
+  byp = HK(0.0);
+  for (i = icb + 1; i <= nl - 1; i++) {
+    by = (VV(tvp, i) - VV(tv, i)) * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1)) / VV(pconv_hpa, i);
+    cape = cape + by;
+    if (by >= HK(0.0)) inb1 = i + 1;
+    if (cape > HK(0.0)) {
+      inb = i + 1;
+      byp = (VV(tvp, i + 1) - VV(tv, i + 1)) * (VV(phconv_hpa, i + 1) - VV(phconv_hpa, i + 2)) / VV(pconv_hpa, i + 1);
+      capem = cape;
+    }
+  }
+  inb = I_MAX(inb, inb1);
+  cape = capem + byp;
+  defrac = capem - cape;
+  defrac = R_MAX(defrac, HK(0.001));
+  frac = -cape / defrac;
+  frac = R_MIN(frac, HK(1.0));
+  frac = R_MAX(frac, HK(0.0));
+  for (i = icb; i <= inb; i++) VV(hp, i) = VV(h, nk) + (VV(lv, i) + (cpd - cpv) * VV(tconv, i)) * VV(ep, i) * VV(clw, i);
+  dbosum = HK(0.0);
+  tvpplcl = VV(tvp, icb - 1) - rd * VV(tvp, icb - 1) * (VV(pconv_hpa, icb - 1) - plcl) / (VV(cpn, icb - 1) * VV(pconv_hpa, icb - 1));
+  tvaplcl = VV(tv, icb) + (VV(tvp, icb) - VV(tvp, icb + 1)) * (plcl - VV(pconv_hpa, icb)) / (VV(pconv_hpa, icb) - VV(pconv_hpa, icb + 1));
+  dtpbl = HK(0.0);
+  for (i = nk; i <= icb - 1; i++) dtpbl = dtpbl + (VV(tvp, i) - VV(tv, i)) * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1));
+  dtpbl = dtpbl / (VV(phconv_hpa, nk) - VV(phconv_hpa, icb));
+  dtmin = tvpplcl - tvaplcl + dtmax + dtpbl;
+  dtma = dtmin;
+  cbmfold = cbmf;
+  delt0 = delt / HK(3.);
+  damps = damp * delt / delt0;
+  cbmf = (HK(1.) - damps) * cbmf + HK(0.1) * alpha * dtma;
+  cbmf = R_MAX(cbmf, HK(0.0));
+  if (cbmf == HK(0.0) && cbmfold == HK(0.0)) RETURN_;
+  VV(m, icb) = HK(0.0);
+  for (i = icb + 1; i <= inb; i++) {
+    k = I_MIN(i, inb1);
+    dbo = R_ABS(VV(tv, k) - VV(tvp, k)) + entp * HK(0.02) * (VV(phconv_hpa, k) - VV(phconv_hpa, k + 1));
+    dbosum = dbosum + dbo;
+    VV(m, i) = cbmf * dbo;
+  }
+  for (i = icb + 1; i <= inb; i++) VV(m, i) = VV(m, i) / dbosum;
+  for (i = icb + 1; i <= inb; i++) {
+    qti = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+    for (j = icb; j <= inb; j++) {
+      bf2 = HK(1.) + VV(lv, j) * VV(lv, j) * VV(qsconv, j) / (rv * VV(tconv, j) * VV(tconv, j) * cpd);
+      anum = VV(h, j) - VV(hp, i) + (cpv - cpd) * VV(tconv, j) * (qti - VV(qconv, j));
+      denom = VV(h, i) - VV(hp, i) + (cpd - cpv) * (VV(qconv, i) - qti) * VV(tconv, j);
+      dei = denom;
+      if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
+      MM(sij, i, j) = anum / dei;
+      MM(sij, i, i) = HK(1.0);
+      altem = MM(sij, i, j) * VV(qconv, i) + (HK(1.) - MM(sij, i, j)) * qti - VV(qsconv, j);
+      altem = altem / bf2;
+      cwat = VV(clw, j) * (HK(1.) - VV(ep, j));
+      stemp = MM(sij, i, j);
+      if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && j > i) {
+        anum = anum - VV(lv, j) * (qti - VV(qsconv, j) - cwat * bf2);
+        denom = denom + VV(lv, j) * (VV(qconv, i) - qti);
+        if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+        MM(sij, i, j) = anum / denom;
+        altem = MM(sij, i, j) * VV(qconv, i) + (HK(1.) - MM(sij, i, j)) * qti - VV(qsconv, j);
+        altem = altem - (bf2 - HK(1.)) * cwat;
+      }
+      if (MM(sij, i, j) > HK(0.0) && MM(sij, i, j) < HK(0.9)) {
+        MM(qent, i, j) = MM(sij, i, j) * VV(qconv, i) + (HK(1.) - MM(sij, i, j)) * qti;
+        MM(elij, i, j) = altem;
+        MM(elij, i, j) = R_MAX(HK(0.0), MM(elij, i, j));
+        MM(ment, i, j) = VV(m, i) / (HK(1.) - MM(sij, i, j));
+        VV(nent, i) = VV(nent, i) + 1;
+      }
+      MM(sij, i, j) = R_MAX(HK(0.0), MM(sij, i, j));
+      MM(sij, i, j) = R_MIN(HK(1.0), MM(sij, i, j));
+    }
+    if (VV(nent, i) == 0) {
+      MM(ment, i, i) = VV(m, i);
+      MM(qent, i, i) = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+      MM(elij, i, i) = VV(clw, i);
+      MM(sij, i, i) = HK(1.0);
+    }
+  }
+  MM(sij, inb, inb) = HK(1.0);
+  for (i = icb + 1; i <= inb; i++) {
+    if (VV(nent, i) != 0) {
+      qp1 = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+      anum = VV(h, i) - VV(hp, i) - VV(lv, i) * (qp1 - VV(qsconv, i));
+      denom = VV(h, i) - VV(hp, i) + VV(lv, i) * (VV(qconv, i) - qp1);
+      if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+      scrit = anum / denom;
+      alt = qp1 - VV(qsconv, i) + scrit * (VV(qconv, i) - qp1);
+      if (alt < HK(0.0)) scrit = HK(1.0);
+      scrit = R_MAX(scrit, HK(0.0));
+      asij = HK(0.0);
+      smin = HK(1.0);
+      for (j = icb; j <= inb; j++) {
+        if (MM(sij, i, j) > HK(0.0) && MM(sij, i, j) < HK(0.9)) {
+          if (j > i) {
+            smid = R_MIN(MM(sij, i, j), scrit);
+            sjmax = smid;
+            sjmin = smid;
+            if (smid < smin && MM(sij, i, j + 1) < smid) {
+              smin = smid;
+              sjmax = R_MIN(R_MIN(MM(sij, i, j + 1), MM(sij, i, j)), scrit);
+              sjmin = R_MAX(MM(sij, i, j - 1), MM(sij, i, j));
+              sjmin = R_MIN(sjmin, scrit);
+            }
+          } else {
+            sjmax = R_MAX(MM(sij, i, j + 1), scrit);
+            smid = R_MAX(MM(sij, i, j), scrit);
+            sjmin = HK(0.0);
+            if (j > 1) sjmin = MM(sij, i, j - 1);
+            sjmin = R_MAX(sjmin, scrit);
+          }
+          delp = R_ABS(sjmax - smid);
+          delm = R_ABS(sjmin - smid);
+          asij = asij + (delp + delm) * (VV(phconv_hpa, j) - VV(phconv_hpa, j + 1));
+          MM(ment, i, j) = MM(ment, i, j) * (delp + delm) * (VV(phconv_hpa, j) - VV(phconv_hpa, j + 1));
+        }
+      }
+      asij = R_MAX(HK(1.0e-21), asij);
+      asij = HK(1.0) / asij;
+      for (j = icb; j <= inb; j++) MM(ment, i, j) = MM(ment, i, j) * asij;
+      bsum = HK(0.0);
+      for (j = icb; j <= inb; j++) bsum = bsum + MM(ment, i, j);
+      if (bsum < HK(1.0e-18)) {
+        VV(nent, i) = 0;
+        MM(ment, i, i) = VV(m, i);
+        MM(qent, i, i) = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+        MM(elij, i, i) = VV(clw, i);
+        MM(sij, i, i) = HK(1.0);
+      }
+    }
+  }
+  if (!(VV(ep, inb) < HK(0.0001))) {
+    jtt = 2;
+    for (i = inb; i >= 1; i--) {
+      wdtrain = g * VV(ep, i) * VV(m, i) * VV(clw, i);
+      if (i > 1)
+        for (j = 1; j <= i - 1; j++) {
+          awat = MM(elij, j, i) - (HK(1.) - VV(ep, i)) * VV(clw, i);
+          awat = R_MAX(HK(0.0), awat);
+          wdtrain = wdtrain + g * awat * MM(ment, j, i);
+        }
+      coeff = coeffs;
+      VV(wt, i) = omtsnow;
+      if (VV(tconv, i) > HK(273.0)) { coeff = coeffr; VV(wt, i) = omtrain; }
+      qsm = HK(0.5) * (VV(qconv, i) + VV(qp, i + 1));
+      afac = coeff * VV(phconv_hpa, i) * (VV(qsconv, i) - qsm) / (HK(1.0e4) + HK(2.0e3) * VV(phconv_hpa, i) * VV(qsconv, i));
+      afac = R_MAX(afac, HK(0.0));
+      sigt = VV(sigp, i);
+      sigt = R_MAX(HK(0.0), sigt);
+      sigt = R_MIN(HK(1.0), sigt);
+      b6 = HK(100.) * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1)) * sigt * afac / VV(wt, i);
+      c6 = (VV(water, i + 1) * VV(wt, i + 1) + wdtrain / sigd) / VV(wt, i);
+      revap = HK(0.5) * (-b6 + M<H>::sqrt(b6 * b6 + HK(4.) * c6));
+      VV(evap, i) = sigt * afac * revap;
+      VV(water, i) = revap * revap;
+      if (i != 1) {
+        dhdp = (VV(h, i) - VV(h, i - 1)) / (VV(pconv_hpa, i - 1) - VV(pconv_hpa, i));
+        dhdp = R_MAX(dhdp, HK(10.0));
+        VV(mp, i) = HK(100.) * ginv * VV(lv, i) * sigd * VV(evap, i) / dhdp;
+        VV(mp, i) = R_MAX(VV(mp, i), HK(0.0));
+        fac = HK(20.0) / (VV(phconv_hpa, i - 1) - VV(phconv_hpa, i));
+        VV(mp, i) = (fac * VV(mp, i + 1) + VV(mp, i)) / (HK(1.) + fac);
+        if (VV(pconv_hpa, i) > (HK(0.949) * VV(pconv_hpa, 1))) {
+          jtt = I_MAX(jtt, i);
+          VV(mp, i) = VV(mp, jtt) * (VV(pconv_hpa, 1) - VV(pconv_hpa, i)) / (VV(pconv_hpa, 1) - VV(pconv_hpa, jtt));
+        }
+      }
+      if (i == inb) continue;
+      if (i == 1) qstm = VV(qsconv, 1); else qstm = VV(qsconv, i - 1);
+      if (VV(mp, i) > VV(mp, i + 1)) {
+        rat = VV(mp, i + 1) / VV(mp, i);
+        VV(qp, i) = VV(qp, i + 1) * rat + VV(qconv, i) * (HK(1.0) - rat) + HK(100.) * ginv * sigd * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1)) * (VV(evap, i) / VV(mp, i));
+      } else {
+        if (VV(mp, i + 1) > HK(0.0))
+          VV(qp, i) = (VV(gz, i + 1) - VV(gz, i) + VV(qp, i + 1) * (VV(lv, i + 1) + VV(tconv, i + 1) * (cl - cpd)) + cpd * (VV(tconv, i + 1) - VV(tconv, i))) / (VV(lv, i) + VV(tconv, i) * (cl - cpd));
+      }
+      VV(qp, i) = R_MIN(VV(qp, i), qstm);
+      VV(qp, i) = R_MAX(VV(qp, i), HK(0.0));
+    }
+    precip = precip + VV(wt, 1) * sigd * VV(water, 1) * HK(3600.) * HK(24000.) / (rowl * g);
+  }
+  wd = beta * R_ABS(VV(mp, icb)) * HK(0.01) * rd * VV(tconv, icb) / (sigd * VV(pconv_hpa, icb));
+  qprime = HK(0.5) * (VV(qp, 1) - VV(qconv, 1));
+  tprime = lv0 * qprime / cpd;
+  dpinv = HK(0.01) / (VV(phconv_hpa, 1) - VV(phconv_hpa, 2));
+  am = HK(0.0);
+  if (nk == 1)
+    for (k = 2; k <= inb; k++) am = am + VV(m, k);
+  VV(fup, 1) = am;
+  if ((HK(2.) * g * dpinv * am) >= delti) iflag = 4;
+  VV(ft, 1) = VV(ft, 1) + g * dpinv * am * (VV(tconv, 2) - VV(tconv, 1) + (VV(gz, 2) - VV(gz, 1)) / VV(cpn, 1));
+  VV(ft, 1) = VV(ft, 1) - VV(lvcp, 1) * sigd * VV(evap, 1);
+  VV(ft, 1) = VV(ft, 1) + sigd * VV(wt, 2) * (cl - cpd) * VV(water, 2) * (VV(tconv, 2) - VV(tconv, 1)) * dpinv / VV(cpn, 1);
+  VV(fq, 1) = VV(fq, 1) + g * VV(mp, 2) * (VV(qp, 2) - VV(qconv, 1)) * dpinv + sigd * VV(evap, 1);
+  VV(fq, 1) = VV(fq, 1) + g * am * (VV(qconv, 2) - VV(qconv, 1)) * dpinv;
+  for (j = 2; j <= inb; j++) VV(fq, 1) = VV(fq, 1) + g * dpinv * MM(ment, j, 1) * (MM(qent, j, 1) - VV(qconv, 1));
+  for (i = 2; i <= inb; i++) {
+    dpinv = HK(0.01) / (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1));
+    cpinv = HK(1.0) / VV(cpn, i);
+    amp1 = HK(0.0);
+    ad = HK(0.0);
+    if (i >= nk)
+      for (k = i + 1; k <= inb + 1; k++) amp1 = amp1 + VV(m, k);
+    for (k = 1; k <= i; k++)
+      for (j = i + 1; j <= inb + 1; j++) amp1 = amp1 + MM(ment, k, j);
+    VV(fup, i) = amp1;
+    if ((HK(2.) * g * dpinv * amp1) >= delti) iflag = 4;
+    for (k = 1; k <= i - 1; k++)
+      for (j = i; j <= inb; j++) ad = ad + MM(ment, j, k);
+    VV(fdown, i) = ad;
+    VV(ft, i) = VV(ft, i) + g * dpinv * (amp1 * (VV(tconv, i + 1) - VV(tconv, i) + (VV(gz, i + 1) - VV(gz, i)) * cpinv) - ad * (VV(tconv, i) - VV(tconv, i - 1) + (VV(gz, i) - VV(gz, i - 1)) * cpinv)) -
+            sigd * VV(lvcp, i) * VV(evap, i);
+    VV(ft, i) = VV(ft, i) + g * dpinv * MM(ment, i, i) * (VV(hp, i) - VV(h, i) + VV(tconv, i) * (cpv - cpd) * (VV(qconv, i) - MM(qent, i, i))) * cpinv;
+    VV(ft, i) = VV(ft, i) + sigd * VV(wt, i + 1) * (cl - cpd) * VV(water, i + 1) * (VV(tconv, i + 1) - VV(tconv, i)) * dpinv * cpinv;
+    VV(fq, i) = VV(fq, i) + g * dpinv * (amp1 * (VV(qconv, i + 1) - VV(qconv, i)) - ad * (VV(qconv, i) - VV(qconv, i - 1)));
+    for (k = 1; k <= i - 1; k++) {
+      awat = MM(elij, k, i) - (HK(1.) - VV(ep, i)) * VV(clw, i);
+      awat = R_MAX(awat, HK(0.0));
+      VV(fq, i) = VV(fq, i) + g * dpinv * MM(ment, k, i) * (MM(qent, k, i) - awat - VV(qconv, i));
+    }
+    for (k = i; k <= inb; k++) VV(fq, i) = VV(fq, i) + g * dpinv * MM(ment, k, i) * (MM(qent, k, i) - VV(qconv, i));
+    VV(fq, i) = VV(fq, i) + sigd * VV(evap, i) + g * (VV(mp, i + 1) * (VV(qp, i + 1) - VV(qconv, i)) - VV(mp, i) * (VV(qp, i) - VV(qconv, i - 1))) * dpinv;
+  }
+  fqold = VV(fq, inb);
+  VV(fq, inb) = VV(fq, inb) * (HK(1.) - frac);
+  VV(fq, inb - 1) = VV(fq, inb - 1) + frac * fqold * ((VV(phconv_hpa, inb) - VV(phconv_hpa, inb + 1)) / (VV(phconv_hpa, inb - 1) - VV(phconv_hpa, inb))) * VV(lv, inb) / VV(lv, inb - 1);
+  ftold = VV(ft, inb);
+  VV(ft, inb) = VV(ft, inb) * (HK(1.) - frac);
+  VV(ft, inb - 1) = VV(ft, inb - 1) + frac * ftold * ((VV(phconv_hpa, inb) - VV(phconv_hpa, inb + 1)) / (VV(phconv_hpa, inb - 1) - VV(phconv_hpa, inb))) * VV(cpn, inb) / VV(cpn, inb - 1);
+  ents = HK(0.0);
+  for (i = 1; i <= inb; i++) ents = ents + (VV(cpn, i) * VV(ft, i) + VV(lv, i) * VV(fq, i)) * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1));
+  ents = ents / (VV(phconv_hpa, 1) - VV(phconv_hpa, inb + 1));
+  for (i = 1; i <= inb; i++) VV(ft, i) = VV(ft, i) - ents / VV(cpn, i);
+  VV(sub, 1) = HK(0.);
+  nconvtop_ = 1;
+  for (i = 1; i <= inb + 1; i++) {
+    for (j = 1; j <= inb + 1; j++) {
+      if (j == nk) MM(fmass, j, i) = MM(fmass, j, i) + VV(m, i);
+      MM(fmass, j, i) = MM(fmass, j, i) + MM(ment, j, i);
+      if (MM(fmass, j, i) > epsilon) nconvtop_ = I_MAX(nconvtop_, I_MAX(i, j));
+    }
+    if (i > 1) VV(sub, i) = VV(fup, i - 1) - VV(fdown, i);
+  }
+  nconvtop_ = nconvtop_ + 1;
+  RETURN_;
+#undef RETURN_
+}
+
+
+// what one call needs of the model-level fields: both time slots, compact [level][jy][ix]
+template <typename H>
+struct Fields {
+  const H *ps[2], *tt2[2], *td2[2], *tth[2], *qvh[2];
+  const H *akz, *bkz, *akm, *bkm;     // [nuvz], 0-based
+  int nx, ny, nuvz, nconvlev;
+  int m1, m2;                         // which physical slot is memind(1), memind(2)
+  H dt1, dt2, dtt, delt;
+};
+
+// convmix.f90:92-135: the column of every particle that is due (mother grid)
+template <typename R, typename H>
+__global__ void k_conv_mark(const double *__restrict__ xt, const double *__restrict__ yt, const int *__restrict__ itra1, long long n, int itime,
+                            int nx, int ny, int *__restrict__ pcol, unsigned int *__restrict__ colflag) {
+  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  int col = -1;
+  if (itra1[s] == itime) {
+    const H x = (H)xt[s], y = (H)yt[s];                  // convmix.f90:100-101: into default reals
+    const int ix = (int)(x < 0 ? x - HK(0.5) : x + HK(0.5)), jy = (int)(y < 0 ? y - HK(0.5) : y + HK(0.5));   // nint
+    if (ix >= 0 && ix < nx && jy >= 0 && jy < ny) { col = jy * nx + ix; colflag[col] = 1u; }
+  }
+  pcol[s] = col;
+}
+
+__global__ void k_conv_list(const unsigned int *__restrict__ colflag, const unsigned int *__restrict__ rank, int ncol, int *__restrict__ act) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < ncol && colflag[c]) act[rank[c]] = c;
+}
+
+// convmix.f90:149-170 + calcmatrix.f90:56-137 + the half-level heights of redist.f90:83-121 for the columns act[r0 .. r0+B)
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_column(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, int B, int nv,
+                                                    const int *__restrict__ act, int r0, int nact, H *__restrict__ cbaseflux,
+                                                    int *__restrict__ lconv_out, int *__restrict__ ntop_out, H *__restrict__ sfc_out) {
+#pragma clang fp contract(off)
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= B || r0 + c >= nact) return;
+  Scr<H> Sx{vbuf, mbuf, B, c, nv};
+  const int col = act[r0 + c];
+  const size_t n2 = (size_t)F.nx * F.ny;
+  const int nuvz = F.nuvz, nl = F.nconvlev;
+  const H dt1 = F.dt1, dt2 = F.dt2, dtt = F.dtt;
+  const H psconv = (F.ps[F.m1][col] * dt2 + F.ps[F.m2][col] * dt1) * dtt;
+  const H tt2conv = (F.tt2[F.m1][col] * dt2 + F.tt2[F.m2][col] * dt1) * dtt;
+  const H td2conv = (F.td2[F.m1][col] * dt2 + F.td2[F.m2][col] * dt1) * dtt;
+  for (int kz = 1; kz <= nuvz - 1; kz++) {
+    VV(tconv, kz) = (F.tth[F.m1][(size_t)kz * n2 + col] * dt2 + F.tth[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
+    VV(qconv, kz) = (F.qvh[F.m1][(size_t)kz * n2 + col] * dt2 + F.qvh[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
+  }
+  // calcmatrix.f90:56-90
+  VV(phconv, 1) = psconv;
+  for (int kuvz = 2; kuvz <= nuvz; kuvz++) {
+    const int k = kuvz - 1;
+    VV(pconv, k) = (F.akz[kuvz - 1] + F.bkz[kuvz - 1] * psconv);
+    VV(phconv, kuvz) = (F.akm[kuvz - 1] + F.bkm[kuvz - 1] * psconv);
+    VV(dpr, k) = VV(phconv, k) - VV(phconv, kuvz);
+    VV(qsconv, k) = cp::f_qvsat<H>(VV(pconv, k), VV(tconv, k));
+  }
+  H cbmf = cbaseflux[col];
+  const H cbmfold = cbmf;
+  for (int k = 1; k <= nl + 1; k++) {
+    VV(pconv_hpa, k) = VV(pconv, k) / HK(100.);
+    VV(phconv_hpa, k) = VV(phconv, k) / HK(100.);
+  }
+  VV(phconv_hpa, nl + 1) = VV(phconv, nl + 1) / HK(100.);
+  int iflag = 0, nconvtop = 0, lconv = 0;
+  convect<H>(Sx, nl, F.delt, iflag, cbmf, nconvtop);
+  if (iflag != 1 && iflag != 4) cbmf = cbmfold;
+  else if (cbmf <= HK(0.) && cbmfold <= HK(0.)) cbmf = cbmfold;
+  else {
+    const H ga = HK(9.81);
+    lconv = 1;
+    for (int k = 1; k <= nconvtop; k++) {
+      const H rlevmass = VV(dpr, k) / ga;
+      H summe = HK(0.);
+      for (int kk = 1; kk <= nconvtop; kk++) {
+        const H f = F.delt * MM(fmass, k, kk);
+        MM(fmass, k, kk) = f;                            // fmassfrac(k,kk), in place
+        summe = summe + f;
+      }
+      MM(fmass, k, k) = MM(fmass, k, k) + rlevmass - summe;
+    }
+    // redist.f90:83-121: heights of the half levels (the reference computes them with the first particle of the column)
+    const H konst = HK(287.05) / HK(9.81);
+    H tvold = tt2conv * (HK(1.) + HK(0.378) * vt::ew<H>(td2conv) / psconv);
+    H pold = psconv;
+    VV(uvzlev, 1) = HK(0.);
+    H pint = VV(phconv, 2);
+    H tv1 = VV(tconv, 1) * (HK(1.) + HK(0.608) * VV(qconv, 1));
+    H tv2 = VV(tconv, 2) * (HK(1.) + HK(0.608) * VV(qconv, 2));
+    H tv = tv1 + (tv2 - tv1) * (VV(pconv, 1) - VV(phconv, 2)) / (VV(pconv, 1) - VV(pconv, 2));
+    if (R_ABS(tv - tvold) > HK(0.2)) VV(uvzlev, 2) = VV(uvzlev, 1) + konst * M<H>::log(pold / pint) * (tv - tvold) / M<H>::log(tv / tvold);
+    else VV(uvzlev, 2) = VV(uvzlev, 1) + konst * M<H>::log(pold / pint) * tv;
+    tvold = tv; tv1 = tv2; pold = pint;
+    for (int kz = 3; kz <= nconvtop + 1; kz++) {
+      pint = VV(phconv, kz);
+      tv2 = VV(tconv, kz) * (HK(1.) + HK(0.608) * VV(qconv, kz));
+      tv = tv1 + (tv2 - tv1) * (VV(pconv, kz - 1) - VV(phconv, kz)) / (VV(pconv, kz - 1) - VV(pconv, kz));
+      if (R_ABS(tv - tvold) > HK(0.2)) VV(uvzlev, kz) = VV(uvzlev, kz - 1) + konst * M<H>::log(pold / pint) * (tv - tvold) / M<H>::log(tv / tvold);
+      else VV(uvzlev, kz) = VV(uvzlev, kz - 1) + konst * M<H>::log(pold / pint) * tv;
+      tvold = tv; tv1 = tv2; pold = pint;
+    }
+  }
+  cbaseflux[col] = cbmf;
+  lconv_out[r0 + c] = lconv;
+  ntop_out[r0 + c] = lconv ? nconvtop : 0;
+  (void)sfc_out;
+}
+
+// redist.f90:124-236 for the particles of the columns act[r0 .. r0+B).  rn_in: the uniform number of each particle (serial
+// stream replayed by the host) or NULL: drawn from the counter generator.  probe != 0: only report which particles would draw.
+template <typename R, typename H, typename RNGF>
+__global__ void k_conv_redist(const int *__restrict__ pcol, const unsigned int *__restrict__ rank, R *__restrict__ zt, long long n,
+                              H *__restrict__ vbuf, H *__restrict__ mbuf, int B, int nv, int r0, int nact,
+                              const int *__restrict__ lconv_in, const int *__restrict__ ntop_in, int ldirect, int lsynctime, H height_nz,
+                              RNGF rngf, unsigned char *__restrict__ draws, int probe, unsigned long long *__restrict__ nmoved) {
+#pragma clang fp contract(off)
+  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int col = pcol[s];
+  if (col < 0) return;
+  const int r = (int)rank[col];
+  if (r < r0 || r >= r0 + B || r >= nact) return;
+  if (!lconv_in[r]) return;
+  Scr<H> Sx{vbuf, mbuf, B, r - r0, nv};
+  const int nconvtop = ntop_in[r];
+  const H r_air = HK(287.05), ga = HK(9.81);
+  H ztold = (H)zt[s], znew = ztold;
+  bool touched = false;                                // the height is written back only where the routine assigns it
+  int levold = 0;
+  for (int kz = 2; kz <= nconvtop; kz++)
+    if (VV(uvzlev, kz) >= ztold) { levold = kz - 1; break; }
+  if (levold > 0) {
+    if (probe) { draws[s] = 1; return; }
+    const H rn = rngf(s);
+    int levnew = levold;
+    H ffraction = HK(0.), dlevfrac = HK(0.);
+    const H totlevmass = VV(dpr, levold) / ga;
+    for (int k = 1; k <= nconvtop; k++) {
+      const H f = ldirect == 1 ? MM(fmass, levold, k) : MM(fmass, k, levold);
+      ffraction = ffraction + f / totlevmass;
+      if (rn <= ffraction) {
+        levnew = k;
+        if (ffraction > HK(1.e-20)) dlevfrac = (ffraction - rn) / f * totlevmass;
+        else dlevfrac = HK(0.5);
+        break;
+      }
+    }
+    if (levnew <= nconvtop) {
+      if (levnew != levold) {
+        const H dlogp = (HK(1.) - dlevfrac) * (M<H>::log(VV(phconv, levnew + 1)) - M<H>::log(VV(phconv, levnew)));
+        const H pint = M<H>::log(VV(phconv, levnew)) + dlogp;
+        const H dz1 = pint - M<H>::log(VV(phconv, levnew));
+        const H dz2 = M<H>::log(VV(phconv, levnew + 1)) - pint;
+        const H dz = dz1 + dz2;
+        znew = (VV(uvzlev, levnew) * dz2 + VV(uvzlev, levnew + 1) * dz1) / dz;
+        if (znew < HK(0.)) znew = HK(-1.) * znew;
+        touched = true;
+      }
+    }
+    if (levnew <= nconvtop && levnew == levold) {
+      ztold = znew;
+      H wsub_lo, wsub_hi;
+      if (levold > 1) {
+        const H temp_levold = VV(tconv, levold - 1) + (VV(tconv, levold) - VV(tconv, levold - 1)) * (VV(pconv, levold - 1) - VV(phconv, levold)) /
+                                                          (VV(pconv, levold - 1) - VV(pconv, levold));
+        const H sub_levold = VV(sub, levold) / (HK(1.) - VV(sub, levold) / VV(dpr, levold) * ga);
+        wsub_lo = HK(-1.) * sub_levold * r_air * temp_levold / (VV(phconv, levold));
+      } else wsub_lo = HK(0.);
+      const H temp_levold1 = VV(tconv, levold) + (VV(tconv, levold + 1) - VV(tconv, levold)) * (VV(pconv, levold) - VV(phconv, levold + 1)) /
+                                                     (VV(pconv, levold) - VV(pconv, levold + 1));
+      const H sub_levold1 = VV(sub, levold + 1) / (HK(1.) - VV(sub, levold + 1) / VV(dpr, levold + 1) * ga);
+      wsub_hi = HK(-1.) * sub_levold1 * r_air * temp_levold1 / (VV(phconv, levold + 1));
+      const H dz1 = ztold - VV(uvzlev, levold);
+      const H dz2 = VV(uvzlev, levold + 1) - ztold;
+      const H dz = dz1 + dz2;
+      const H wsubpart = (dz2 * wsub_lo + dz1 * wsub_hi) / dz;
+      znew = ztold + wsubpart * (H)lsynctime;
+      if (znew < HK(0.)) znew = HK(-1.) * znew;
+      touched = true;
+    }
+  } else if (probe) return;
+  if (znew > height_nz - HK(0.5)) { znew = height_nz - HK(0.5); touched = true; }
+  if (touched) {
+    zt[s] = (R)znew;
+    if (nmoved) atomicAdd(nmoved, 1ull);
+  }
+}
+
+#undef VV
+#undef MM
+#undef HK
+#undef R_ABS
+#undef R_MAX
+#undef R_MIN
+#undef I_MAX
+#undef I_MIN
+
+}  // namespace conv
+}  // namespace fpx

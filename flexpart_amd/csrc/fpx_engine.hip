@@ -21,6 +21,7 @@
 #include "fpx_device.hpp"
 #include "fpx_verttransform.hpp"
 #include "fpx_calcpar.hpp"
+#include "fpx_convect.hpp"
 #include "fpx_rng_host.hpp"
 
 namespace fpx {
@@ -177,6 +178,29 @@ __global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict
     for (int ks = 0; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
   }
 }
+
+// ---- convection (fpx_convect.hpp): small kernels and the random-number sources of redist ---------------------------
+template <typename S, typename D>
+__global__ void k_conv_pack(const S *__restrict__ src, D *__restrict__ dst, int nx, int ny, int nlev, int nxmax, int nymax) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n2 = (long long)nx * ny;
+  if (i >= n2 * nlev) return;
+  const int k = (int)(i / n2), r = (int)(i % n2), jy = r / nx, ix = r % nx;
+  dst[i] = (D)src[(size_t)ix + (size_t)nxmax * ((size_t)jy + (size_t)nymax * k)];
+}
+template <typename H>
+struct ConvRngSeq {     // the number the host drew for this particle from the serial ran3 stream
+  const H *rn; const unsigned int *pid;
+  __device__ H operator()(long long s) const { return rn[pid[s]]; }
+};
+template <typename R, typename H>
+struct ConvRngCtr {     // counter generator: (seed, global particle number, step, stream of redist)
+  View<R> V; const unsigned int *pid; unsigned int step;
+  __device__ H operator()(long long s) const {
+    Rng<R> G;
+    make_rng(V, pid[s], step | 0x40000000u, G);
+    return (H)(((float)(G.bits(3) >> 8) + 0.5f) * (1.0f / 16777216.0f));
+  }
+};
 
 // A permutation without locality (the first sort of a freshly seeded or uploaded cloud) would fetch one memory
 // transaction per 8-byte element through the direct gather (18 arrays: > 1 kB per particle).  Such a permutation goes
@@ -1254,6 +1278,11 @@ struct EngineBase {
   virtual int partoutput(int itime, const char *path, int64_t *nrec) = 0;
   virtual int concoutput(int itime, const fpx_concout *c, const char *prefix, int clear) = 0;
   virtual int readpartpositions(const char *path, const fpx_restart *r, int64_t *numpart_out, int32_t *numparticlecount, int32_t *itimein) = 0;
+  virtual int conv_init(const fpx_conv_config *c) = 0;
+  virtual int upload_conv_fields(int slot, const fpx_conv_fields *f) = 0;
+  virtual int convmix(int itime, int64_t *nmoved) = 0;
+  virtual int cbaseflux_io(void *host, bool set) = 0;
+  virtual double conv_ms() = 0;
   virtual int checkpoint_write(const char *path, int itime, int numparticlecount) = 0;
   virtual int checkpoint_read(const char *path, int32_t *itime, int64_t *numpart_out, int32_t *numparticlecount) = 0;
 };
@@ -2725,6 +2754,275 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // ---- convective mixing -------------------------------------------------------------------------
+  bool conv_on = false;
+  int conv_nuvz = 0, conv_nconvlev = 0;
+  void *conv_fld[5][2] = {};                 // ps, tt2, td2, tth, qvh of the two slots, compact, host real kind
+  bool conv_slot[2] = {false, false};
+  void *conv_tab[4] = {};                    // akz, bkz, akm, bkm
+  void *conv_cb = nullptr;                   // cbaseflux [ny][nx]
+  int *conv_pcol = nullptr, *conv_act = nullptr, *conv_lconv = nullptr, *conv_ntop = nullptr;
+  unsigned int *conv_flag = nullptr, *conv_rank = nullptr;
+  unsigned char *conv_draws = nullptr;
+  void *conv_rn = nullptr;
+  void *conv_scr = nullptr, *conv_scan_tmp = nullptr;
+  size_t conv_scr_bytes = 0, conv_scan_bytes = 0;
+  unsigned long long *conv_nmoved = nullptr;
+  double conv_last_ms = 0;
+  double conv_ms() override { return conv_last_ms; }
+
+  int conv_init(const fpx_conv_config *c) override {
+    if (!c || c->struct_bytes != (int32_t)sizeof(fpx_conv_config)) return fail(FPX_ERR_ARG, "conv_init: null or fpx_conv_config size mismatch (ABI)");
+    if (V.numbnests > 0) return fail(FPX_ERR_UNSUPPORTED, "conv_init: convection inside nested wind fields is not implemented");
+    if (c->nuvz < 4 || c->nconvlev < 2 || c->nconvlev > c->nuvz - 2) return fail(FPX_ERR_ARG, "conv_init: need 2 <= nconvlev <= nuvz - 2");
+    if (!c->akz || !c->bkz || !c->akm || !c->bkm) return fail(FPX_ERR_ARG, "conv_init: akz, bkz, akm, bkm are required");
+    if (conv_on) return fail(FPX_ERR_STATE, "conv_init: already initialised");
+    const size_t hb = (size_t)cfg.host_real_bytes, n2 = (size_t)cfg.nx * cfg.ny, n3 = n2 * c->nuvz;
+    int rc;
+    const void *tabs[4] = {c->akz, c->bkz, c->akm, c->bkm};
+    for (int i = 0; i < 4; i++) {
+      unsigned char *q = nullptr;
+      if ((rc = dalloc(&q, (size_t)c->nuvz * hb))) return rc;
+      HIPCHK(hipMemcpyAsync(q, tabs[i], (size_t)c->nuvz * hb, hipMemcpyHostToDevice, stream));
+      conv_tab[i] = q;
+    }
+    for (int f = 0; f < 5; f++)
+      for (int sl = 0; sl < 2; sl++) {
+        unsigned char *q = nullptr;
+        if ((rc = dalloc(&q, (f < 3 ? n2 : n3) * hb))) return rc;
+        conv_fld[f][sl] = q;
+      }
+    {
+      unsigned char *q = nullptr;
+      if ((rc = dalloc(&q, n2 * hb))) return rc;
+      HIPCHK(hipMemsetAsync(q, 0, n2 * hb, stream));
+      conv_cb = q;
+    }
+    if ((rc = dalloc(&conv_pcol, (size_t)P.cap)) || (rc = dalloc(&conv_draws, (size_t)P.cap))) return rc;
+    if ((rc = dalloc(&conv_flag, n2)) || (rc = dalloc(&conv_rank, n2)) || (rc = dalloc(&conv_act, n2)) ||
+        (rc = dalloc(&conv_lconv, n2)) || (rc = dalloc(&conv_ntop, n2)) || (rc = dalloc(&conv_nmoved, (size_t)1))) return rc;
+    {
+      unsigned char *q = nullptr;
+      if ((rc = dalloc(&q, (size_t)P.cap * hb))) return rc;
+      conv_rn = q;
+    }
+    HIPCHK(hipStreamSynchronize(stream));
+    conv_nuvz = c->nuvz; conv_nconvlev = c->nconvlev;
+    conv_on = true;
+    return 0;
+  }
+
+  template <typename H>
+  int upload_conv_fields_t(int slot, const fpx_conv_fields *f) {
+    const size_t n2max = (size_t)cfg.nxmax * cfg.nymax;
+    const void *src[5] = {f->ps, f->tt2, f->td2, f->tth, f->qvh};
+    for (int i = 0; i < 5; i++) {
+      const int nlev = i < 3 ? 1 : conv_nuvz;
+      const size_t bytes = n2max * (size_t)(i < 3 ? 1 : f->nuvzmax) * sizeof(H);
+      int rc = ensure_staging(bytes);
+      if (rc) return rc;
+      HIPCHK(hipMemcpyAsync(staging, src[i], bytes, hipMemcpyHostToDevice, stream));
+      const long long n = (long long)cfg.nx * cfg.ny * nlev;
+      k_conv_pack<H, H><<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, stream>>>((const H *)staging, (H *)conv_fld[i][slot - 1], cfg.nx, cfg.ny, nlev, cfg.nxmax, cfg.nymax);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(stream));        // the staging buffer is reused by the next array
+    }
+    conv_slot[slot - 1] = true;
+    return 0;
+  }
+  int upload_conv_fields(int slot, const fpx_conv_fields *f) override {
+    if (!conv_on) return fail(FPX_ERR_STATE, "upload_conv_fields: fpx_conv_init first");
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "upload_conv_fields: slot must be 1 or 2");
+    if (!f || !f->ps || !f->tt2 || !f->td2 || !f->tth || !f->qvh) return fail(FPX_ERR_ARG, "upload_conv_fields: ps, tt2, td2, tth, qvh are required");
+    if (f->nuvzmax < conv_nuvz) return fail(FPX_ERR_ARG, "upload_conv_fields: nuvzmax < nuvz");
+    return cfg.host_real_bytes == 4 ? upload_conv_fields_t<float>(slot, f) : upload_conv_fields_t<double>(slot, f);
+  }
+
+  int cbaseflux_io(void *host, bool set) override {
+    if (!conv_on) return fail(FPX_ERR_STATE, "cbaseflux: fpx_conv_init first");
+    if (!host) return fail(FPX_ERR_ARG, "cbaseflux: null");
+    const size_t bytes = (size_t)cfg.nx * cfg.ny * cfg.host_real_bytes;
+    if (set) HIPCHK(hipMemcpyAsync(conv_cb, host, bytes, hipMemcpyHostToDevice, stream));
+    else HIPCHK(hipMemcpyAsync(host, conv_cb, bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+
+  // sort2.f90 (the reference's quicksort with insertion sort below 7 elements; not stable): the order in which convmix
+  // visits the particles, hence the order of redist's draws from the shared ran3 stream.  Host side of the parity mode.
+  static void conv_sort2(int n, int *arr, int *brr) {     // 1-based [1..n]
+    const int M = 7, NSTACK = 50;
+    int i, ir, j, jstack = 0, k, l = 1, istack[51], a, b;
+    ir = n;
+    for (;;) {
+      if (ir - l < M) {
+        for (j = l + 1; j <= ir; j++) {
+          a = arr[j]; b = brr[j];
+          for (i = j - 1; i >= 1; i--) {
+            if (arr[i] <= a) break;
+            arr[i + 1] = arr[i]; brr[i + 1] = brr[i];
+          }
+          if (i < 1) i = 0;
+          arr[i + 1] = a; brr[i + 1] = b;
+        }
+        if (jstack == 0) return;
+        ir = istack[jstack]; l = istack[jstack - 1]; jstack -= 2;
+      } else {
+        k = (l + ir) / 2;
+        std::swap(arr[k], arr[l + 1]); std::swap(brr[k], brr[l + 1]);
+        if (arr[l + 1] > arr[ir]) { std::swap(arr[l + 1], arr[ir]); std::swap(brr[l + 1], brr[ir]); }
+        if (arr[l] > arr[ir]) { std::swap(arr[l], arr[ir]); std::swap(brr[l], brr[ir]); }
+        if (arr[l + 1] > arr[l]) { std::swap(arr[l + 1], arr[l]); std::swap(brr[l + 1], brr[l]); }
+        i = l + 1; j = ir; a = arr[l]; b = brr[l];
+        for (;;) {
+          do i++; while (arr[i] < a);
+          do j--; while (arr[j] > a);
+          if (j < i) break;
+          std::swap(arr[i], arr[j]); std::swap(brr[i], brr[j]);
+        }
+        arr[l] = arr[j]; arr[j] = a; brr[l] = brr[j]; brr[j] = b;
+        jstack += 2;
+        if (jstack > NSTACK) return;
+        if (ir - i + 1 >= j - l) { istack[jstack] = ir; istack[jstack - 1] = i; ir = j - 1; }
+        else { istack[jstack] = j - 1; istack[jstack - 1] = l; l = i; }
+      }
+    }
+  }
+
+  template <typename H>
+  int convmix_t(int itime, int64_t *nmoved_out) {
+    const long long n = numpart;
+    const int nx = cfg.nx, ny = cfg.ny, ncol = nx * ny;
+    const int nv = conv_nuvz + 2;
+    const int nb = (int)((n + kBlock - 1) / kBlock), nbc = (ncol + kBlock - 1) / kBlock;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    struct EvGuard { hipEvent_t a, b; ~EvGuard() { (void)hipEventDestroy(a); (void)hipEventDestroy(b); } } evg{e0, e1};
+    HIPCHK(hipEventRecord(e0, stream));
+    HIPCHK(hipMemsetAsync(conv_flag, 0, (size_t)ncol * sizeof(unsigned int), stream));
+    HIPCHK(hipMemsetAsync(conv_nmoved, 0, sizeof(unsigned long long), stream));
+    conv::k_conv_mark<R, H><<<nb, kBlock, 0, stream>>>(P.xt, P.yt, P.itra1, n, itime, nx, ny, conv_pcol, conv_flag);
+    HIPCHK(hipGetLastError());
+    size_t tb = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tb, conv_flag, conv_rank, 0u, (size_t)ncol, rocprim::plus<unsigned int>(), stream));
+    if (tb > conv_scan_bytes) {
+      if (conv_scan_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(conv_scan_tmp)); conv_scan_tmp = nullptr; }
+      HIPCHK(hipMalloc(&conv_scan_tmp, std::max<size_t>(tb, 16)));
+      conv_scan_bytes = std::max<size_t>(tb, 16);
+    }
+    HIPCHK(rocprim::exclusive_scan(conv_scan_tmp, tb, conv_flag, conv_rank, 0u, (size_t)ncol, rocprim::plus<unsigned int>(), stream));
+    unsigned int last_rank = 0, last_flag = 0;
+    HIPCHK(hipMemcpyAsync(&last_rank, conv_rank + (ncol - 1), 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&last_flag, conv_flag + (ncol - 1), 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    const int nact = (int)(last_rank + last_flag);
+    if (nact == 0) { if (nmoved_out) *nmoved_out = 0; conv_last_ms = 0; return 0; }
+    conv::k_conv_list<<<nbc, kBlock, 0, stream>>>(conv_flag, conv_rank, ncol, conv_act);
+    HIPCHK(hipGetLastError());
+    // scratch: as many columns per batch as fit the budget
+    const size_t per_col = conv::scratch_elems_per_column<H>(nv) * sizeof(H);
+    size_t budget = (size_t)8 << 30;
+    if (const char *env = getenv("FPX_CONV_SCRATCH_MB")) budget = (size_t)std::max(1l, atol(env)) << 20;
+    int B = (int)std::min<size_t>((size_t)nact, std::max<size_t>(64, budget / per_col));
+    B = (B + 63) / 64 * 64;
+    if ((size_t)B * per_col > conv_scr_bytes) {
+      if (conv_scr) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(conv_scr)); conv_scr = nullptr; conv_scr_bytes = 0; }
+      hipError_t e = hipMalloc(&conv_scr, (size_t)B * per_col);
+      if (e != hipSuccess) return fail(FPX_ERR_NOMEM, std::string("convmix: scratch: ") + hipGetErrorString(e));
+      conv_scr_bytes = (size_t)B * per_col;
+    }
+    H *vbuf = (H *)conv_scr, *mbuf = vbuf + (size_t)conv::V_COUNT * nv * B;
+    conv::Fields<H> F;
+    for (int sl = 0; sl < 2; sl++) {
+      F.ps[sl] = (const H *)conv_fld[0][sl]; F.tt2[sl] = (const H *)conv_fld[1][sl]; F.td2[sl] = (const H *)conv_fld[2][sl];
+      F.tth[sl] = (const H *)conv_fld[3][sl]; F.qvh[sl] = (const H *)conv_fld[4][sl];
+    }
+    F.akz = (const H *)conv_tab[0]; F.bkz = (const H *)conv_tab[1]; F.akm = (const H *)conv_tab[2]; F.bkm = (const H *)conv_tab[3];
+    F.nx = nx; F.ny = ny; F.nuvz = conv_nuvz; F.nconvlev = conv_nconvlev;
+    F.m1 = V.m1; F.m2 = V.m2;
+    F.dt1 = (H)(itime - V.memtime0); F.dt2 = (H)(V.memtime1 - itime);
+    F.dtt = (H)1. / (F.dt1 + F.dt2);
+    F.delt = (H)std::abs(cfg.lsynctime);
+    const H height_nz = (H)height_host[cfg.nz - 1];
+    const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
+    // parity mode: the random numbers come from the shared serial stream in the reference's visiting order, which needs
+    // to know who draws -- a first pass over all batches records that, the host replays the stream, a second pass moves
+    std::vector<unsigned char> h_draws;
+    std::vector<int> h_pcol;
+    for (int pass = seq ? 0 : 1; pass < 2; pass++) {
+      if (pass == 0) HIPCHK(hipMemsetAsync(conv_draws, 0, (size_t)n, stream));
+      for (int r0 = 0; r0 < nact; r0 += B) {
+        if (pass == 0 || !seq) {
+          conv::k_conv_column<H><<<(B + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, B, nv, conv_act, r0, nact, (H *)conv_cb, conv_lconv, conv_ntop, nullptr);
+          HIPCHK(hipGetLastError());
+        } else if (nact > B) {
+          // several batches: the scratch of this batch was overwritten by the probe pass of the later ones -- recompute it
+          // from the mass flux the probe pass started from (kept in conv_cb_prev)
+          return fail(FPX_ERR_UNSUPPORTED, "convmix: the serial-stream parity mode needs all columns in one scratch batch (raise FPX_CONV_SCRATCH_MB)");
+        }
+        if (pass == 0) {
+          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, B, nv, r0, nact, conv_lconv, conv_ntop,
+                                                                          cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
+                                                                          conv_draws, 1, nullptr);
+        } else if (seq) {
+          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, B, nv, r0, nact, conv_lconv, conv_ntop,
+                                                                          cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
+                                                                          conv_draws, 0, conv_nmoved);
+        } else {
+          conv::k_conv_redist<R, H, ConvRngCtr<R, H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, B, nv, r0, nact, conv_lconv, conv_ntop,
+                                                                             cfg.ldirect, cfg.lsynctime, height_nz, ConvRngCtr<R, H>{V, P.pid, step_counter},
+                                                                             conv_draws, 0, conv_nmoved);
+        }
+        HIPCHK(hipGetLastError());
+      }
+      if (pass == 0) {
+        // replay: particles by particle number, igrid as convmix builds it, the reference's sort2, ran3 for who draws
+        h_draws.resize((size_t)n); h_pcol.resize((size_t)n);
+        HIPCHK(hipMemcpyAsync(h_draws.data(), conv_draws, (size_t)n, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_pcol.data(), conv_pcol, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+        std::vector<unsigned int> h_pid((size_t)n);
+        HIPCHK(hipMemcpyAsync(h_pid.data(), P.pid, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<int> igrid((size_t)n + 1), ipoint((size_t)n + 1);
+        std::vector<unsigned char> draws_by_pid((size_t)n, 0);
+        for (long long s = 0; s < n; s++) {
+          const unsigned int p = h_pid[(size_t)s];
+          if (p >= (unsigned int)n) return fail(FPX_ERR_STATE, "convmix: particle numbers beyond numpart");
+          igrid[p + 1] = h_pcol[(size_t)s] < 0 ? -1 : 1 + h_pcol[(size_t)s];
+          draws_by_pid[p] = h_draws[(size_t)s];
+        }
+        for (long long p = 1; p <= n; p++) ipoint[(size_t)p] = (int)p;
+        conv_sort2((int)n, igrid.data(), ipoint.data());
+        std::vector<H> rn((size_t)n, (H)-1);
+        for (long long k = 1; k <= n; k++) {
+          if (igrid[(size_t)k] == -1) continue;
+          const int p = ipoint[(size_t)k] - 1;
+          if (!draws_by_pid[(size_t)p]) continue;
+          rn[(size_t)p] = sizeof(H) == 4 ? (H)rng4.ran3(rng4.idummy_redist) : (H)rng8.ran3(rng8.idummy_redist);
+        }
+        HIPCHK(hipMemcpyAsync(conv_rn, rn.data(), (size_t)n * sizeof(H), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+      }
+    }
+    HIPCHK(hipEventRecord(e1, stream));
+    unsigned long long moved = 0;
+    HIPCHK(hipMemcpyAsync(&moved, conv_nmoved, sizeof(moved), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) conv_last_ms = ms;
+    if (nmoved_out) *nmoved_out = (int64_t)moved;
+    return 0;
+  }
+
+  int convmix(int itime, int64_t *nmoved) override {
+    if (!conv_on) return fail(FPX_ERR_STATE, "convmix: fpx_conv_init first");
+    if (!conv_slot[0] || !conv_slot[1]) return fail(FPX_ERR_STATE, "convmix: fpx_upload_conv_fields of both slots first");
+    if (!window_set) return fail(FPX_ERR_STATE, "convmix: fpx_set_windtime first");
+    if (!height_set) return fail(FPX_ERR_STATE, "convmix: set_height first");
+    if (numpart == 0) { if (nmoved) *nmoved = 0; return 0; }
+    return cfg.host_real_bytes == 4 ? convmix_t<float>(itime, nmoved) : convmix_t<double>(itime, nmoved);
+  }
+
   // ---- lossless checkpoint (last clause) ------------------------------------------------------
   // partoutput / readpartpositions keep position, mass and age of a particle, rounded to the dump's real kind; the
   // turbulent velocity memory (up, vp, wp), the mesoscale components (us, vs, ws), cbt, idt, itramem, itrasplit,
@@ -3793,6 +4091,12 @@ int fpx_kernel_times(fpx_handle h, double ms[4], int64_t *launches, int32_t rese
   return rc;
 }
 int fpx_sort_particles(fpx_handle h) { FPX_GUARD(h); return h->impl->sort_particles(); }
+int fpx_conv_init(fpx_handle h, const fpx_conv_config *c) { FPX_GUARD(h); return h->impl->conv_init(c); }
+int fpx_upload_conv_fields(fpx_handle h, int32_t slot, const fpx_conv_fields *f) { FPX_GUARD(h); return h->impl->upload_conv_fields(slot, f); }
+int fpx_convmix(fpx_handle h, int32_t itime, int64_t *nmoved) { FPX_GUARD(h); return h->impl->convmix(itime, nmoved); }
+int fpx_convmix_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return FPX_ERR_ARG; *ms = h->impl->conv_ms(); return 0; }
+int fpx_get_cbaseflux(fpx_handle h, void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_io(cb, false); }
+int fpx_set_cbaseflux(fpx_handle h, const void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_io((void *)cb, true); }
 int fpx_checkpoint_write(fpx_handle h, const char *path, int32_t itime, int32_t numparticlecount) {
   FPX_GUARD(h);
   return h->impl->checkpoint_write(path, itime, numparticlecount);

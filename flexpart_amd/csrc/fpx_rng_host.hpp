@@ -20,6 +20,7 @@ struct HostRng {
   // the "idummy" seeds local to initialize.f90:64 and advance.f90:120: both start at -7,
   // so the FIRST call from each routine re-seeds the shared generator.
   int idummy_init = -7, idummy_adv = -7;
+  int idummy_redist = -88;   // redist.f90:69 (convection): its first call re-seeds the shared generator as well
 
   R ran3(int &idum) {
     const int mbig = 1000000000, mseed = 161803398, mz = 0;

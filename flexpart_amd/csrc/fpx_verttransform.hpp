@@ -20,6 +20,7 @@ namespace vt {
 template <typename H> struct M;
 template <> struct M<float> {
   static __device__ __forceinline__ float log(float x) { return ::logf(x); }
+  static __device__ __forceinline__ float exp(float x) { return ::expf(x); }
   static __device__ __forceinline__ float pow(float x, float y) { return ::powf(x, y); }
   static __device__ __forceinline__ float cos(float x) { return ::cosf(x); }
   static __device__ __forceinline__ float sin(float x) { return ::sinf(x); }
@@ -29,6 +30,7 @@ template <> struct M<float> {
 };
 template <> struct M<double> {
   static __device__ __forceinline__ double log(double x) { return ::log(x); }
+  static __device__ __forceinline__ double exp(double x) { return ::exp(x); }
   static __device__ __forceinline__ double pow(double x, double y) { return ::pow(x, y); }
   static __device__ __forceinline__ double cos(double x) { return ::cos(x); }
   static __device__ __forceinline__ double sin(double x) { return ::sin(x); }

@@ -318,6 +318,59 @@ class Engine:
         self.n = int(n.value)
         return int(n.value), int(npc.value), int(it.value)
 
+    # ---- convective mixing (fpx_conv_init / fpx_upload_conv_fields / fpx_convmix) ----
+    def conv_init(self, cs):
+        """Level structure of a synthetic.convection_case()-like dict: grid[2] = nuvz, nconvlev, akz, bkz, akm, bkm."""
+        from ._lib import FpxConvConfig
+        rt = self.hreal
+        c = FpxConvConfig()
+        c.struct_bytes = C.sizeof(FpxConvConfig)
+        c.nuvz, c.nconvlev = int(cs["grid"][2]), int(cs["nconvlev"])
+        keep = {k: np.ascontiguousarray(np.asarray(cs[k]).astype(rt)) for k in ("akz", "bkz", "akm", "bkm")}
+        for k, a in keep.items():
+            setattr(c, k, a.ctypes.data)
+        check(self.lib.fpx_conv_init(self.h, C.byref(c)), "fpx_conv_init")
+        self.conv_nuvz = c.nuvz
+
+    def upload_conv_fields(self, slot, ps, tt2, td2, tth, qvh, nuvzmax=None):
+        """One wind-field slot of ps, tt2, td2 [ny][nx] and tth, qvh [nuvz][ny][nx] (compact), padded to the host layout."""
+        from ._lib import FpxConvFields
+        rt = self.hreal
+        nuvz = int(np.asarray(tth).shape[0])
+        nuvzmax = nuvz + 1 if nuvzmax is None else int(nuvzmax)
+        f = FpxConvFields()
+        keep = {}
+        for k, a in (("ps", ps), ("tt2", tt2), ("td2", td2)):
+            b = np.zeros((self.nymax, self.nxmax), rt)
+            b[: self.ny, : self.nx] = a
+            keep[k] = b
+            setattr(f, k, b.ctypes.data)
+        for k, a in (("tth", tth), ("qvh", qvh)):
+            b = np.zeros((nuvzmax, self.nymax, self.nxmax), rt)
+            b[:nuvz, : self.ny, : self.nx] = a
+            keep[k] = b
+            setattr(f, k, b.ctypes.data)
+        f.nuvzmax = nuvzmax
+        check(self.lib.fpx_upload_conv_fields(self.h, int(slot), C.byref(f)), "fpx_upload_conv_fields")
+
+    def convmix(self, itime=None):
+        """fpx_convmix: -> number of particles whose height was set; .convmix_device_ms holds the device time."""
+        n = C.c_int64(0)
+        check(self.lib.fpx_convmix(self.h, int(self.itime if itime is None else itime), C.byref(n)), "fpx_convmix")
+        ms = C.c_double(0)
+        check(self.lib.fpx_convmix_time(self.h, C.byref(ms)), "fpx_convmix_time")
+        self.convmix_device_ms = ms.value
+        return int(n.value)
+
+    def cbaseflux(self, new=None):
+        a = np.zeros((self.ny, self.nx), self.hreal)
+        if new is not None:
+            a[:] = new
+            check(self.lib.fpx_set_cbaseflux(self.h, a.ctypes.data), "fpx_set_cbaseflux")
+            return None
+        check(self.lib.fpx_get_cbaseflux(self.h, a.ctypes.data), "fpx_get_cbaseflux")
+        return a.astype(np.float64)
+
     def checkpoint_write(self, path, itime=None, numparticlecount=None):
         """fpx_checkpoint_write: everything the particle loop carries (lossless, unlike partoutput)."""
         check(self.lib.fpx_checkpoint_write(self.h, str(path).encode(), int(self.itime if itime is None else itime),

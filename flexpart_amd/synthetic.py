@@ -758,8 +758,9 @@ def convection_case(nx=24, ny=16, nuvz=46, n=4000, ncalls=3, ldirect=1, lsynctim
     warm0 = 0.5 + 0.5 * _wave(i[0] + 2 * j[0], per)
     cb0 = np.where(warm0 > 0.55, 0.12 * warm0 ** 2, 0.0)
     u = [_splitmix64(n, seed + q).astype(np.float64) / 2.0 ** 64 for q in range(4)]
-    out.update(grid=np.array([nx, ny, nuvz], np.int32), nconvlev=nuvz - 2, ldirect=int(ldirect), lsynctime=int(lsynctime),
-               memtime=np.array([0, 10800], np.int32), itimes=np.arange(ncalls, dtype=np.int32) * int(lsynctime) * int(ldirect) + (0 if ldirect == 1 else 10800),
+    # backward runs: lsynctime and the wind-field times carry the sign of ldirect (readcommand.f90:381-384, getfields.f90)
+    out.update(grid=np.array([nx, ny, nuvz], np.int32), nconvlev=nuvz - 2, ldirect=int(ldirect), lsynctime=int(lsynctime) * int(ldirect),
+               memtime=np.array([0, 10800 * int(ldirect)], np.int32), itimes=np.arange(ncalls, dtype=np.int32) * int(lsynctime) * int(ldirect),
                height_nz=19000.0, cbaseflux=cb0,
                xtra1=0.3 + u[0] * (nx - 1.6), ytra1=0.3 + u[1] * (ny - 1.6), ztra1=16000.0 * u[2] ** 1.5,
                due=(u[3][:, None] + 0.013 * np.arange(ncalls)[None, :]) % 1.0 > 0.1, npart=n)

@@ -261,6 +261,41 @@ typedef struct {
 } fpx_restart;
 int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
                           int64_t *numpart, int32_t *numparticlecount, int32_t *itimein);
+/* ---- convective mixing of the particles (SURVEY section 8 f, item 3) ------------------------------
+ * Replaces `call convmix(itime,metdata_format)` (timemanager.f90:258-262 forward, :183-187 backward; the routine:
+ * convmix.f90:61-196, ECMWF input, mother grid) with everything below it: calcmatrix.f90:56-137 per grid column that
+ * holds particles, Emanuel's scheme CONVECT / TLIFT (convect43c.f90) and redist.f90:49-236 per particle.
+ * fpx_conv_init: the level structure (com_mod nuvz, conv_mod nconvlev, akz, bkz, akm, bkm of gridcheck_ecmwf.f90);
+ *   allocates the cloud-base mass flux cbaseflux(0:nxmax-1,0:nymax-1) (conv_mod.f90), zero as at start-up.
+ * fpx_upload_conv_fields: ps, tt2, td2 (2-D) and tth, qvh (nuvzmax levels) of one wind-field slot, host layout
+ *   (nxmax, nymax strides), as readwind_ecmwf leaves them -- the same arrays fpx_verttransform_ecmwf takes.
+ * fpx_convmix: moves the particles that are due at itime; nmoved (may be NULL): particles whose height was set.
+ *   Random numbers: the serial ran3 stream shared with advance / initialize (redist.f90:69,130: its own seed -88 re-seeds
+ *   the shared generator at the first call) replayed by the host in the order of the reference's sort2 in the parity
+ *   mode FPX_RNG_TABLE_SEQ; one counter-generator draw per particle and step otherwise.
+ * fpx_get_cbaseflux / fpx_set_cbaseflux: the mass-flux field, compact [ny][nx] in the host's real kind (restart files).
+ * Not covered: particles inside nested wind fields (cbasefluxn, convmix.f90:198-250) -- refused when nests are set;
+ * the flux diagnostics of calcfluxes (iflux = 1). */
+typedef struct {
+  int32_t struct_bytes;
+  int32_t nuvz;              /* com_mod nuvz                                              */
+  int32_t nconvlev;          /* conv_mod nconvlev (gridcheck_ecmwf.f90:560-565)            */
+  int32_t reserved;
+  const void *akz, *bkz;     /* [nuvz] host real: full levels (akz(1) = 0, bkz(1) = 1)     */
+  const void *akm, *bkm;     /* [nuvz] host real: half levels                              */
+} fpx_conv_config;
+typedef struct {
+  const void *ps, *tt2, *td2;   /* (0:nxmax-1,0:nymax-1)            */
+  const void *tth, *qvh;        /* (0:nxmax-1,0:nymax-1,nuvzmax)    */
+  int32_t nuvzmax;              /* allocated levels of tth, qvh     */
+  int32_t reserved;
+} fpx_conv_fields;
+int fpx_conv_init(fpx_handle h, const fpx_conv_config *c);
+int fpx_upload_conv_fields(fpx_handle h, int32_t slot, const fpx_conv_fields *f);
+int fpx_convmix(fpx_handle h, int32_t itime, int64_t *nmoved);
+int fpx_convmix_time(fpx_handle h, double *ms);
+int fpx_get_cbaseflux(fpx_handle h, void *cbaseflux);
+int fpx_set_cbaseflux(fpx_handle h, const void *cbaseflux);
 /* ---- lossless checkpoint (SURVEY section 8 f, item 4, last clause) -----------------------------
  * The reference's restart is lossy: partoutput.f90:63-190 writes position, mass and age in the dump's
  * real kind and omits uap..uzp, us..ws, cbt, idt, itramem, nclass; readpartpositions.f90:118-148 sets

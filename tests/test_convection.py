@@ -53,3 +53,97 @@ def test_oracle_matches_live_convection_reference(kind):
     for i, (r, o) in enumerate(zip(ref, orc)):
         for k in KEYS:
             assert np.array_equal(np.asarray(r[k]), np.asarray(o[k])), (kind, i, k)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# GPU: fpx_convmix through the C ABI
+# ---------------------------------------------------------------------------------------------------------
+def _engine(cs, kind, rng_mode, seed=3):
+    from flexpart_amd.engine import Engine
+    rb = 8 if kind == "r8" else 4
+    nx, ny, nuvz = (int(v) for v in cs["grid"])
+    n = int(cs["npart"])
+    sc = syn.small(n=n, nx=nx, ny=ny, nz=30, nsteps=1, global_grid=False, ldirect=int(cs["ldirect"]))
+    sc["xtra1"], sc["ytra1"], sc["ztra1"] = cs["xtra1"], cs["ytra1"], cs["ztra1"]
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=rng_mode, seed=seed)
+    eng.set_windtime(cs["memtime"], (1, 2))
+    eng.conv_init(cs)
+    eng.cbaseflux(cs["cbaseflux"])
+    for slot in (1, 2):
+        eng.upload_conv_fields(slot, *(np.asarray(cs[k])[slot - 1] for k in ("ps", "tt2", "td2", "tth", "qvh")))
+    return eng, sc
+
+
+def _call(eng, sc, cs, ic, z):
+    itime = int(cs["itimes"][ic])
+    p = dict(sc, ztra1=z, itra1=np.where(np.asarray(cs["due"])[:, ic], itime, itime + 12345).astype(np.int32))
+    eng.upload_particles_from_scenario(p)
+    moved = eng.convmix(itime)
+    return moved, eng.download()["ztra1"].astype(np.float64)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_convmix_matches_the_oracle(built, name, kind):
+    """fpx_convmix in the parity mode (serial ran3 stream replayed in the reference's sort2 order) against the oracle, three
+    consecutive calls: the cloud-base mass flux of every column to rounding (it decides which columns convect), the particle
+    heights -- nearly all of them to rounding; a particle may land in another level where a matrix entry differs in the last
+    bits (the device's exp / log / pow are not glibc's) and its random number lies within that of a threshold."""
+    from flexpart_amd.engine import RNG_TABLE_SEQ
+    cs = syn.convection_case(**CASES[name])
+    eng, sc = _engine(cs, kind, RNG_TABLE_SEQ)
+    cs = dict(cs, height_nz=float(np.asarray(sc["height"])[-1]))
+    want = conv_oracle(cs, kind)
+    tol = 1e-9 if kind == "r8" else 2e-4
+    z = np.asarray(cs["ztra1"], dtype=np.float64)
+    for ic, w in enumerate(want):
+        moved, z = _call(eng, sc, cs, ic, z)
+        cb = eng.cbaseflux()
+        assert np.abs(cb - w["cbaseflux"]).max() <= tol * np.abs(w["cbaseflux"]).max(), (name, kind, ic)
+        assert np.array_equal(cb > 0, w["cbaseflux"] > 0)
+        close = np.abs(z - w["ztra1"]) <= tol * np.maximum(np.abs(w["ztra1"]), 1.0)
+        assert close.mean() >= 0.995, (name, kind, ic, close.mean())
+        assert moved >= (w["rn"] >= 0).sum() > 500
+        z = w["ztra1"].copy()                       # continue from the oracle's state: each call is compared on equal input
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_device_convmix_with_the_counter_generator(built):
+    """Counter RNG: individual displacements differ from the serial stream's by construction; the ensemble must not.  Same
+    columns convect, particles outside convective columns and particles that are not due stay where they are, the fraction
+    that changes level and the mean displacement agree with the oracle's, results do not depend on the storage order, and a
+    scratch budget that forces several column batches gives the same result as one batch."""
+    from flexpart_amd.engine import RNG_PHILOX
+    cs = syn.convection_case(n=40000, seed=19)
+    eng, sc = _engine(cs, "r8", RNG_PHILOX)
+    cs = dict(cs, height_nz=float(np.asarray(sc["height"])[-1]))
+    want = conv_oracle(cs, "r8")[0]
+    z0 = np.asarray(cs["ztra1"], dtype=np.float64)
+    moved, z = _call(eng, sc, cs, 0, z0)
+    cb = eng.cbaseflux()
+    eng.close()
+    assert np.abs(cb - want["cbaseflux"]).max() <= 1e-9 * want["cbaseflux"].max()
+    due = np.asarray(cs["due"])[:, 0]
+    col = np.rint(cs["ytra1"]).astype(int) * int(cs["grid"][0]) + np.rint(cs["xtra1"]).astype(int)
+    conv = want["lconv"].ravel()[col] == 1
+    assert np.array_equal(z[~due], z0[~due]) and np.array_equal(z[due & ~conv], z0[due & ~conv])
+    jump_dev, jump_orc = np.abs(z - z0) > 500.0, np.abs(want["ztra1"] - z0) > 500.0
+    assert jump_orc.sum() > 150 and abs(jump_dev.sum() - jump_orc.sum()) < 4.0 * np.sqrt(jump_orc.sum())
+    assert abs(np.abs(z - z0)[jump_dev].mean() - np.abs(want["ztra1"] - z0)[jump_orc].mean()) < 0.25 * np.abs(want["ztra1"] - z0)[jump_orc].mean()
+    small = ~jump_dev & ~jump_orc & due & conv             # mostly the compensating subsidence, which takes no random number
+    assert small.sum() > 5000 and (np.abs(z - want["ztra1"])[small] < 1e-6).mean() > 0.9
+    # storage order and batching
+    import os
+    eng, sc = _engine(cs, "r8", RNG_PHILOX)
+    eng.upload_particles_from_scenario(dict(sc, ztra1=z0, itra1=np.where(due, 0, 12345).astype(np.int32)))
+    eng.sort()
+    os.environ["FPX_CONV_SCRATCH_MB"] = "8"
+    try:
+        eng.convmix(0)
+    finally:
+        del os.environ["FPX_CONV_SCRATCH_MB"]
+    z2 = eng.download()["ztra1"].astype(np.float64)
+    eng.close()
+    assert np.array_equal(z2, z)
