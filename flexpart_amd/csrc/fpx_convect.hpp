@@ -42,15 +42,21 @@ constexpr int M_fmassfrac = M_fmass;      // calcmatrix scales fmass into fmassf
 
 template <typename H>
 struct Scr {
-  H *v;          // [V_COUNT][nv][B]
-  H *mat;        // [M_COUNT][nv][nv][B], column-major A(i,j) -> [j][i]
+  H *v;          // [V_COUNT][nv][B]: every column that holds particles
+  H *mat;        // [M_COUNT][nv][nv][Bm], column-major A(i,j) -> [j][i]: only the columns that reach the mixing computation
   int B, c, nv;
+  int Bm, cm;    // matrix batch size and this column's slot in it
 };
+// what the first part of CONVECT (up to its early exits) hands to the second
+template <typename H>
+struct CvState { int nk, icb, iflag; H plcl, cbmf; };
 #define VV(name, i) Sx.v[((size_t)V_##name * Sx.nv + (size_t)(i)) * Sx.B + Sx.c]
-#define MM(name, i, j) Sx.mat[(((size_t)M_##name * Sx.nv + (size_t)(j)) * Sx.nv + (size_t)(i)) * Sx.B + Sx.c]
+#define MM(name, i, j) Sx.mat[(((size_t)M_##name * Sx.nv + (size_t)(j)) * Sx.nv + (size_t)(i)) * Sx.Bm + Sx.cm]
 
 template <typename H>
-__host__ __device__ inline size_t scratch_elems_per_column(int nv) { return (size_t)V_COUNT * nv + (size_t)M_COUNT * nv * nv; }
+__host__ __device__ inline size_t vec_elems_per_column(int nv) { return (size_t)V_COUNT * nv; }
+template <typename H>
+__host__ __device__ inline size_t mat_elems_per_column(int nv) { return (size_t)M_COUNT * nv * nv; }
 
 template <typename H>
 __device__ void tlift(const Scr<H> &Sx, int icb, int nk, int nl, int kk) {
@@ -98,33 +104,32 @@ __device__ void tlift(const Scr<H> &Sx, int icb, int nk, int nl, int kk) {
 }
 
 
-template <typename H>
-__device__ void convect(const Scr<H> &Sx, int nl, H delt, int &iflag_, H &cbmf_, int &nconvtop_) {
+// PHASE 1: up to the early exits (:79-~420: sounding, lifting condensation level, first TLIFT); returns whether the mixing
+// computation is needed.  PHASE 2: the rest, with the matrices.  (TH, computed and never used by the scheme, is left out.)
+template <typename H, int PHASE>
+__device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &nconvtop_) {
 #pragma clang fp contract(off)
   const H elcrit = HK(.0011), tlcrit = HK(-55.0), entp = HK(1.5), sigd = HK(0.05), sigs = HK(0.12), omtrain = HK(50.0), omtsnow = HK(5.5);
   const H coeffr = HK(1.0), coeffs = HK(0.8), beta = HK(10.0), dtmax = HK(0.9), alpha = HK(0.025), damp = HK(0.1);
   const H cpd = HK(1005.7), cpv = HK(1870.0), cl = HK(2500.0), rv = HK(461.5), rd = HK(287.04), lv0 = HK(2.501e6), g = HK(9.81), rowl = HK(1000.0);
   const H cpvmcl = cl - cpv, eps0 = rd / rv, epsi = HK(1.) / eps0, ginv = HK(1.0) / g, epsilon = HK(1.e-20);
   const int minorig = 1;
-  int iflag = iflag_, i, icb, ihmin, inb, inb1, j, jtt, k, nk;
-  H cbmf = cbmf_, precip, wd, tprime, qprime;
+  int iflag = st.iflag, i, icb = 0, ihmin, inb, inb1, j, jtt, k, nk = 0;
+  H cbmf = st.cbmf, precip, wd, tprime, qprime;
   H ad, afac, ahmax, ahmin, alt, altem, am, amp1, anum, asij, awat, b6, bf2, bsum, by, byp, c6, cape, capem, cbmfold, chi, coeff;
   H cpinv, cwat, damps, dbo, dbosum, defrac, dei, delm, delp, delt0, delti, denom, dhdp, dpinv, dtma, dtmin, dtpbl, elacrit, ents;
   H epmax, fac, fqold, frac, ftold, plcl, qp1, qsm, qstm, qti, rat, rdcp, revap, rh, scrit, sigt, sjmax, sjmin, smid, smin, stemp, tca;
   H tvaplcl, tvpplcl, tvx, tvy, wdtrain;
 
   delti = HK(1.0) / delt;
+  precip = HK(0.0); wd = HK(0.0); tprime = HK(0.0); qprime = HK(0.0);
+  plcl = HK(0.);
+  if (PHASE == 1) {
   for (i = 1; i <= nl + 1; i++) {
     VV(ft, i) = HK(0.0); VV(fq, i) = HK(0.0); VV(fdown, i) = HK(0.0); VV(sub, i) = HK(0.0); VV(fup, i) = HK(0.0); VV(m, i) = HK(0.0); VV(mp, i) = HK(0.0);
-    for (j = 1; j <= nl + 1; j++) { MM(fmass, i, j) = HK(0.0); MM(ment, i, j) = HK(0.0); }
   }
-  for (i = 1; i <= nl + 1; i++) {
-    rdcp = (rd * (HK(1.) - VV(qconv, i)) + VV(qconv, i) * rv) / (cpd * (HK(1.) - VV(qconv, i)) + VV(qconv, i) * cpv);
-    VV(th, i) = VV(tconv, i) * M<H>::pow(HK(1000.0) / VV(pconv_hpa, i), rdcp);
-  }
-  precip = HK(0.0); wd = HK(0.0); tprime = HK(0.0); qprime = HK(0.0);
   iflag = 0;
-#define RETURN_ do { iflag_ = iflag; cbmf_ = cbmf; (void)precip; (void)wd; (void)tprime; (void)qprime; return; } while (0)
+#define RETURN_ do { st.iflag = iflag; st.cbmf = cbmf; (void)precip; (void)wd; (void)tprime; (void)qprime; return PHASE == 2; } while (0)
   VV(gz, 1) = HK(0.0);
   VV(cpn, 1) = cpd * (HK(1.) - VV(qconv, 1)) + VV(qconv, 1) * cpv;
   VV(h, 1) = VV(tconv, 1) * VV(cpn, 1);
@@ -162,6 +167,12 @@ __device__ void convect(const Scr<H> &Sx, int nl, H delt, int &iflag_, H &cbmf_,
   for (i = nk; i <= icb; i++) VV(tvp, i) = VV(tvp, i) - VV(tp, i) * VV(qconv, nk);
   if (cbmf == HK(0.0) && VV(tvp, icb) <= (VV(tv, icb) - dtmax)) { iflag = 0; RETURN_; }
   if (iflag != 4) iflag = 1;
+  st.nk = nk; st.icb = icb; st.plcl = plcl; st.iflag = iflag; st.cbmf = cbmf;
+  return true;
+  }   // PHASE 1
+  nk = st.nk; icb = st.icb; plcl = st.plcl;
+  for (i = 1; i <= nl + 1; i++)
+    for (j = 1; j <= nl + 1; j++) { MM(fmass, i, j) = HK(0.0); MM(ment, i, j) = HK(0.0); }
   tlift<H>(Sx, icb, nk, nl, 2);
   for (i = 1; i <= nk; i++) { VV(ep, i) = HK(0.0); VV(sigp, i) = sigs; }
   for (i = nk + 1; i <= nl; i++) {
@@ -388,12 +399,26 @@ __device__ void convect(const Scr<H> &Sx, int nl, H delt, int &iflag_, H &cbmf_,
     ad = HK(0.0);
     if (i >= nk)
       for (k = i + 1; k <= inb + 1; k++) amp1 = amp1 + VV(m, k);
+    // (the O(levels^3) sums of the scheme: the loads of sixteen terms are issued together, the additions keep the reference's
+    // order; a padding term adds +0.0, which leaves the sum unchanged)
     for (k = 1; k <= i; k++)
-      for (j = i + 1; j <= inb + 1; j++) amp1 = amp1 + MM(ment, k, j);
+      for (j = i + 1; j <= inb + 1; j += 16) {
+        H t8[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) t8[u] = j + u <= inb + 1 ? MM(ment, k, j + u) : HK(0.);
+#pragma unroll
+        for (int u = 0; u < 16; u++) amp1 = amp1 + t8[u];
+      }
     VV(fup, i) = amp1;
     if ((HK(2.) * g * dpinv * amp1) >= delti) iflag = 4;
     for (k = 1; k <= i - 1; k++)
-      for (j = i; j <= inb; j++) ad = ad + MM(ment, j, k);
+      for (j = i; j <= inb; j += 16) {
+        H t8[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) t8[u] = j + u <= inb ? MM(ment, j + u, k) : HK(0.);
+#pragma unroll
+        for (int u = 0; u < 16; u++) ad = ad + t8[u];
+      }
     VV(fdown, i) = ad;
     VV(ft, i) = VV(ft, i) + g * dpinv * (amp1 * (VV(tconv, i + 1) - VV(tconv, i) + (VV(gz, i + 1) - VV(gz, i)) * cpinv) - ad * (VV(tconv, i) - VV(tconv, i - 1) + (VV(gz, i) - VV(gz, i - 1)) * cpinv)) -
             sigd * VV(lvcp, i) * VV(evap, i);
@@ -464,27 +489,29 @@ __global__ void k_conv_list(const unsigned int *__restrict__ colflag, const unsi
   if (c < ncol && colflag[c]) act[rank[c]] = c;
 }
 
-// convmix.f90:149-170 + calcmatrix.f90:56-137 + the half-level heights of redist.f90:83-121 for the columns act[r0 .. r0+B)
+// per-column scalars kept between the two column kernels
+enum Cst { C_psconv, C_tt2conv, C_td2conv, C_cbmf, C_cbmfold, C_plcl, C_nk, C_icb, C_iflag, C_COUNT };
+
+// convmix.f90:149-170 + calcmatrix.f90:56-90 + CONVECT up to its early exits, for every column that holds particles
 template <typename H>
-__global__ void __launch_bounds__(64) k_conv_column(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, int B, int nv,
-                                                    const int *__restrict__ act, int r0, int nact, H *__restrict__ cbaseflux,
-                                                    int *__restrict__ lconv_out, int *__restrict__ ntop_out, H *__restrict__ sfc_out) {
+__global__ void __launch_bounds__(64) k_conv_column_a(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ cst, int nv, const int *__restrict__ act,
+                                                      int nact, const H *__restrict__ cbaseflux, unsigned int *__restrict__ alive) {
 #pragma clang fp contract(off)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= B || r0 + c >= nact) return;
-  Scr<H> Sx{vbuf, mbuf, B, c, nv};
-  const int col = act[r0 + c];
+  if (c >= nact) return;
+  Scr<H> Sx{vbuf, nullptr, nact, c, nv, 0, 0};
+  const int col = act[c];
   const size_t n2 = (size_t)F.nx * F.ny;
   const int nuvz = F.nuvz, nl = F.nconvlev;
   const H dt1 = F.dt1, dt2 = F.dt2, dtt = F.dtt;
   const H psconv = (F.ps[F.m1][col] * dt2 + F.ps[F.m2][col] * dt1) * dtt;
-  const H tt2conv = (F.tt2[F.m1][col] * dt2 + F.tt2[F.m2][col] * dt1) * dtt;
-  const H td2conv = (F.td2[F.m1][col] * dt2 + F.td2[F.m2][col] * dt1) * dtt;
+  cst[(size_t)C_psconv * nact + c] = psconv;
+  cst[(size_t)C_tt2conv * nact + c] = (F.tt2[F.m1][col] * dt2 + F.tt2[F.m2][col] * dt1) * dtt;
+  cst[(size_t)C_td2conv * nact + c] = (F.td2[F.m1][col] * dt2 + F.td2[F.m2][col] * dt1) * dtt;
   for (int kz = 1; kz <= nuvz - 1; kz++) {
     VV(tconv, kz) = (F.tth[F.m1][(size_t)kz * n2 + col] * dt2 + F.tth[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
     VV(qconv, kz) = (F.qvh[F.m1][(size_t)kz * n2 + col] * dt2 + F.qvh[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
   }
-  // calcmatrix.f90:56-90
   VV(phconv, 1) = psconv;
   for (int kuvz = 2; kuvz <= nuvz; kuvz++) {
     const int k = kuvz - 1;
@@ -493,16 +520,54 @@ __global__ void __launch_bounds__(64) k_conv_column(Fields<H> F, H *__restrict__
     VV(dpr, k) = VV(phconv, k) - VV(phconv, kuvz);
     VV(qsconv, k) = cp::f_qvsat<H>(VV(pconv, k), VV(tconv, k));
   }
-  H cbmf = cbaseflux[col];
-  const H cbmfold = cbmf;
   for (int k = 1; k <= nl + 1; k++) {
     VV(pconv_hpa, k) = VV(pconv, k) / HK(100.);
     VV(phconv_hpa, k) = VV(phconv, k) / HK(100.);
   }
   VV(phconv_hpa, nl + 1) = VV(phconv, nl + 1) / HK(100.);
-  int iflag = 0, nconvtop = 0, lconv = 0;
-  convect<H>(Sx, nl, F.delt, iflag, cbmf, nconvtop);
-  if (iflag != 1 && iflag != 4) cbmf = cbmfold;
+  CvState<H> st;
+  st.nk = 0; st.icb = 0; st.iflag = 0; st.plcl = HK(0.);
+  st.cbmf = cbaseflux[col];
+  cst[(size_t)C_cbmfold * nact + c] = st.cbmf;
+  int dummy = 0;
+  const bool go = convect<H, 1>(Sx, nl, F.delt, st, dummy);
+  cst[(size_t)C_cbmf * nact + c] = st.cbmf;
+  cst[(size_t)C_plcl * nact + c] = st.plcl;
+  cst[(size_t)C_nk * nact + c] = (H)st.nk;
+  cst[(size_t)C_icb * nact + c] = (H)st.icb;
+  cst[(size_t)C_iflag * nact + c] = (H)st.iflag;
+  alive[c] = go ? 1u : 0u;
+}
+
+__global__ void k_conv_survivors(const unsigned int *__restrict__ alive, const unsigned int *__restrict__ srank, int nact, int *__restrict__ surv) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < nact && alive[c]) surv[srank[c]] = c;
+}
+
+// the mixing part of CONVECT, calcmatrix.f90:92-137 and the half-level heights of redist.f90:83-121 for the surviving columns
+// surv[m0 .. m0+Bm)
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_column_b(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, H *__restrict__ cst, int nv, int nact,
+                                                      const int *__restrict__ act, const int *__restrict__ surv, int m0, int Bm, int nsurv,
+                                                      H *__restrict__ cbaseflux, int *__restrict__ lconv_out, int *__restrict__ ntop_out) {
+#pragma clang fp contract(off)
+  const int cm = blockIdx.x * blockDim.x + threadIdx.x;
+  if (cm >= Bm || m0 + cm >= nsurv) return;
+  const int c = surv[m0 + cm];
+  Scr<H> Sx{vbuf, mbuf, nact, c, nv, Bm, cm};
+  const int nl = F.nconvlev;
+  CvState<H> st;
+  st.cbmf = cst[(size_t)C_cbmf * nact + c];
+  st.plcl = cst[(size_t)C_plcl * nact + c];
+  st.nk = (int)cst[(size_t)C_nk * nact + c];
+  st.icb = (int)cst[(size_t)C_icb * nact + c];
+  st.iflag = (int)cst[(size_t)C_iflag * nact + c];
+  const H cbmfold = cst[(size_t)C_cbmfold * nact + c];
+  const H psconv = cst[(size_t)C_psconv * nact + c], tt2conv = cst[(size_t)C_tt2conv * nact + c], td2conv = cst[(size_t)C_td2conv * nact + c];
+  int nconvtop = 0, lconv = 0;
+  convect<H, 2>(Sx, nl, F.delt, st, nconvtop);
+  H cbmf = st.cbmf;
+  if (st.iflag != 1 && st.iflag != 4) cbmf = cbmfold;
   else if (cbmf <= HK(0.) && cbmfold <= HK(0.)) cbmf = cbmfold;
   else {
     const H ga = HK(9.81);
@@ -538,17 +603,17 @@ __global__ void __launch_bounds__(64) k_conv_column(Fields<H> F, H *__restrict__
       tvold = tv; tv1 = tv2; pold = pint;
     }
   }
-  cbaseflux[col] = cbmf;
-  lconv_out[r0 + c] = lconv;
-  ntop_out[r0 + c] = lconv ? nconvtop : 0;
-  (void)sfc_out;
+  cbaseflux[act[c]] = cbmf;
+  lconv_out[c] = lconv;
+  ntop_out[c] = lconv ? nconvtop : 0;
 }
 
-// redist.f90:124-236 for the particles of the columns act[r0 .. r0+B).  rn_in: the uniform number of each particle (serial
+// redist.f90:124-236 for the particles of the surviving columns surv[m0 .. m0+Bm).  rn_in: the uniform number of each particle (serial
 // stream replayed by the host) or NULL: drawn from the counter generator.  probe != 0: only report which particles would draw.
 template <typename R, typename H, typename RNGF>
 __global__ void k_conv_redist(const int *__restrict__ pcol, const unsigned int *__restrict__ rank, R *__restrict__ zt, long long n,
-                              H *__restrict__ vbuf, H *__restrict__ mbuf, int B, int nv, int r0, int nact,
+                              H *__restrict__ vbuf, H *__restrict__ mbuf, int nv, int nact, const unsigned int *__restrict__ alive,
+                              const unsigned int *__restrict__ srank, int m0, int Bm,
                               const int *__restrict__ lconv_in, const int *__restrict__ ntop_in, int ldirect, int lsynctime, H height_nz,
                               RNGF rngf, unsigned char *__restrict__ draws, int probe, unsigned long long *__restrict__ nmoved) {
 #pragma clang fp contract(off)
@@ -557,9 +622,11 @@ __global__ void k_conv_redist(const int *__restrict__ pcol, const unsigned int *
   const int col = pcol[s];
   if (col < 0) return;
   const int r = (int)rank[col];
-  if (r < r0 || r >= r0 + B || r >= nact) return;
+  if (!alive[r]) return;
+  const int ms = (int)srank[r] - m0;
+  if (ms < 0 || ms >= Bm) return;
   if (!lconv_in[r]) return;
-  Scr<H> Sx{vbuf, mbuf, B, r - r0, nv};
+  Scr<H> Sx{vbuf, mbuf, nact, r, nv, Bm, ms};
   const int nconvtop = ntop_in[r];
   const H r_air = HK(287.05), ga = HK(9.81);
   H ztold = (H)zt[s], znew = ztold;

@@ -2889,6 +2889,42 @@ struct Engine : EngineBase {
     }
   }
 
+  // replay of the serial stream: particles by particle number, igrid as convmix builds it, the reference's sort2, ran3 for
+  // the particles the probe pass found drawing
+  template <typename H>
+  int conv_replay(long long n) {
+    std::vector<unsigned char> h_draws((size_t)n);
+    std::vector<int> h_pcol((size_t)n);
+    std::vector<unsigned int> h_pid((size_t)n);
+    HIPCHK(hipMemcpyAsync(h_draws.data(), conv_draws, (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_pcol.data(), conv_pcol, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_pid.data(), P.pid, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    std::vector<int> igrid((size_t)n + 1), ipoint((size_t)n + 1);
+    std::vector<unsigned char> draws_by_pid((size_t)n, 0);
+    for (long long s = 0; s < n; s++) {
+      const unsigned int p = h_pid[(size_t)s];
+      if (p >= (unsigned int)n) return fail(FPX_ERR_STATE, "convmix: particle numbers beyond numpart");
+      igrid[p + 1] = h_pcol[(size_t)s] < 0 ? -1 : 1 + h_pcol[(size_t)s];
+      draws_by_pid[p] = h_draws[(size_t)s];
+    }
+    for (long long p = 1; p <= n; p++) ipoint[(size_t)p] = (int)p;
+    conv_sort2((int)n, igrid.data(), ipoint.data());
+    std::vector<H> rn((size_t)n, (H)-1);
+    for (long long k = 1; k <= n; k++) {
+      if (igrid[(size_t)k] == -1) continue;
+      const int p = ipoint[(size_t)k] - 1;
+      if (!draws_by_pid[(size_t)p]) continue;
+      rn[(size_t)p] = sizeof(H) == 4 ? (H)rng4.ran3(rng4.idummy_redist) : (H)rng8.ran3(rng8.idummy_redist);
+    }
+    HIPCHK(hipMemcpyAsync(conv_rn, rn.data(), (size_t)n * sizeof(H), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
+  unsigned int *conv_alive = nullptr;
+  size_t conv_alive_cap = 0;
+  int conv_last_active = 0, conv_last_survivors = 0;
+
   template <typename H>
   int convmix_t(int itime, int64_t *nmoved_out) {
     const long long n = numpart;
@@ -2919,19 +2955,37 @@ struct Engine : EngineBase {
     if (nact == 0) { if (nmoved_out) *nmoved_out = 0; conv_last_ms = 0; return 0; }
     conv::k_conv_list<<<nbc, kBlock, 0, stream>>>(conv_flag, conv_rank, ncol, conv_act);
     HIPCHK(hipGetLastError());
-    // scratch: as many columns per batch as fit the budget
-    const size_t per_col = conv::scratch_elems_per_column<H>(nv) * sizeof(H);
-    size_t budget = (size_t)8 << 30;
-    if (const char *env = getenv("FPX_CONV_SCRATCH_MB")) budget = (size_t)std::max(1l, atol(env)) << 20;
-    int B = (int)std::min<size_t>((size_t)nact, std::max<size_t>(64, budget / per_col));
-    B = (B + 63) / 64 * 64;
-    if ((size_t)B * per_col > conv_scr_bytes) {
-      if (conv_scr) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(conv_scr)); conv_scr = nullptr; conv_scr_bytes = 0; }
-      hipError_t e = hipMalloc(&conv_scr, (size_t)B * per_col);
-      if (e != hipSuccess) return fail(FPX_ERR_NOMEM, std::string("convmix: scratch: ") + hipGetErrorString(e));
-      conv_scr_bytes = (size_t)B * per_col;
+    // scratch: the vectors of every column that holds particles; the matrices only for the columns that get past CONVECT's
+    // early exits, in batches that fit the budget (default: a quarter of the free device memory)
+    const size_t vec_bytes = (conv::vec_elems_per_column<H>(nv) + conv::C_COUNT) * sizeof(H) * (size_t)nact;
+    const size_t per_mat = conv::mat_elems_per_column<H>(nv) * sizeof(H);
+    size_t budget;
+    {
+      size_t free_b = 0, total_b = 0;
+      HIPCHK(hipMemGetInfo(&free_b, &total_b));
+      budget = (free_b + conv_scr_bytes) / 4;
+      if (const char *env = getenv("FPX_CONV_SCRATCH_MB")) budget = (size_t)std::max(1l, atol(env)) << 20;
     }
-    H *vbuf = (H *)conv_scr, *mbuf = vbuf + (size_t)conv::V_COUNT * nv * B;
+    if ((size_t)nact > conv_alive_cap) {
+      if (conv_alive) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(conv_alive)); conv_alive = nullptr; }
+      HIPCHK(hipMalloc(&conv_alive, (size_t)nact * 3 * sizeof(unsigned int)));
+      conv_alive_cap = (size_t)nact;
+    }
+    unsigned int *alive = conv_alive, *srank = conv_alive + nact;
+    int *surv = (int *)(conv_alive + 2 * (size_t)nact);
+    auto ensure_scratch = [&](size_t bytes) -> int {
+      if (bytes <= conv_scr_bytes) return 0;
+      if (conv_scr) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(conv_scr)); conv_scr = nullptr; conv_scr_bytes = 0; }
+      hipError_t e = hipMalloc(&conv_scr, bytes);
+      if (e != hipSuccess) return fail(FPX_ERR_NOMEM, std::string("convmix: scratch: ") + hipGetErrorString(e));
+      conv_scr_bytes = bytes;
+      return 0;
+    };
+    // upper bound of the matrix batch before the survivors are known: all active columns, capped by the budget
+    int Bm_cap = (int)std::min<size_t>((size_t)nact, std::max<size_t>(64, budget / per_mat));
+    int rc = ensure_scratch(vec_bytes + (size_t)Bm_cap * per_mat);
+    if (rc) return rc;
+    H *vbuf = (H *)conv_scr, *cst = vbuf + conv::vec_elems_per_column<H>(nv) * (size_t)nact, *mbuf = cst + (size_t)conv::C_COUNT * nact;
     conv::Fields<H> F;
     for (int sl = 0; sl < 2; sl++) {
       F.ps[sl] = (const H *)conv_fld[0][sl]; F.tt2[sl] = (const H *)conv_fld[1][sl]; F.td2[sl] = (const H *)conv_fld[2][sl];
@@ -2945,63 +2999,45 @@ struct Engine : EngineBase {
     F.delt = (H)std::abs(cfg.lsynctime);
     const H height_nz = (H)height_host[cfg.nz - 1];
     const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
-    // parity mode: the random numbers come from the shared serial stream in the reference's visiting order, which needs
-    // to know who draws -- a first pass over all batches records that, the host replays the stream, a second pass moves
-    std::vector<unsigned char> h_draws;
-    std::vector<int> h_pcol;
-    for (int pass = seq ? 0 : 1; pass < 2; pass++) {
-      if (pass == 0) HIPCHK(hipMemsetAsync(conv_draws, 0, (size_t)n, stream));
-      for (int r0 = 0; r0 < nact; r0 += B) {
-        if (pass == 0 || !seq) {
-          conv::k_conv_column<H><<<(B + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, B, nv, conv_act, r0, nact, (H *)conv_cb, conv_lconv, conv_ntop, nullptr);
-          HIPCHK(hipGetLastError());
-        } else if (nact > B) {
-          // several batches: the scratch of this batch was overwritten by the probe pass of the later ones -- recompute it
-          // from the mass flux the probe pass started from (kept in conv_cb_prev)
-          return fail(FPX_ERR_UNSUPPORTED, "convmix: the serial-stream parity mode needs all columns in one scratch batch (raise FPX_CONV_SCRATCH_MB)");
-        }
-        if (pass == 0) {
-          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, B, nv, r0, nact, conv_lconv, conv_ntop,
+    const int nba = (nact + 63) / 64;
+    conv::k_conv_column_a<H><<<nba, 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, (const H *)conv_cb, alive);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(conv_lconv, 0, (size_t)nact * sizeof(int), stream));
+    HIPCHK(hipMemsetAsync(conv_ntop, 0, (size_t)nact * sizeof(int), stream));
+    tb = conv_scan_bytes;
+    HIPCHK(rocprim::exclusive_scan(conv_scan_tmp, tb, alive, srank, 0u, (size_t)nact, rocprim::plus<unsigned int>(), stream));
+    HIPCHK(hipMemcpyAsync(&last_rank, srank + (nact - 1), 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(&last_flag, alive + (nact - 1), 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    const int nsurv = (int)(last_rank + last_flag);
+    conv_last_active = nact; conv_last_survivors = nsurv;
+    if (nsurv > 0) {
+      conv::k_conv_survivors<<<(nact + kBlock - 1) / kBlock, kBlock, 0, stream>>>(alive, srank, nact, surv);
+      HIPCHK(hipGetLastError());
+      const int Bm = std::min(nsurv, Bm_cap);
+      if (seq && nsurv > Bm) return fail(FPX_ERR_UNSUPPORTED, "convmix: the serial-stream parity mode needs all convective columns in one scratch batch (raise FPX_CONV_SCRATCH_MB)");
+      // parity mode: the random numbers come from the shared serial stream in the reference's visiting order, which needs to
+      // know who draws -- a probe pass records that, the host replays the stream, then the particles are moved
+      for (int m0 = 0; m0 < nsurv; m0 += Bm) {
+        conv::k_conv_column_b<H><<<(Bm + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, (H *)conv_cb, conv_lconv, conv_ntop);
+        HIPCHK(hipGetLastError());
+        if (seq) {
+          HIPCHK(hipMemsetAsync(conv_draws, 0, (size_t)n, stream));
+          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, nv, nact, alive, srank, m0, Bm, conv_lconv, conv_ntop,
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
                                                                           conv_draws, 1, nullptr);
-        } else if (seq) {
-          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, B, nv, r0, nact, conv_lconv, conv_ntop,
+          HIPCHK(hipGetLastError());
+          int rrc = conv_replay<H>(n);
+          if (rrc) return rrc;
+          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, nv, nact, alive, srank, m0, Bm, conv_lconv, conv_ntop,
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
                                                                           conv_draws, 0, conv_nmoved);
         } else {
-          conv::k_conv_redist<R, H, ConvRngCtr<R, H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, B, nv, r0, nact, conv_lconv, conv_ntop,
+          conv::k_conv_redist<R, H, ConvRngCtr<R, H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, nv, nact, alive, srank, m0, Bm, conv_lconv, conv_ntop,
                                                                              cfg.ldirect, cfg.lsynctime, height_nz, ConvRngCtr<R, H>{V, P.pid, step_counter},
                                                                              conv_draws, 0, conv_nmoved);
         }
         HIPCHK(hipGetLastError());
-      }
-      if (pass == 0) {
-        // replay: particles by particle number, igrid as convmix builds it, the reference's sort2, ran3 for who draws
-        h_draws.resize((size_t)n); h_pcol.resize((size_t)n);
-        HIPCHK(hipMemcpyAsync(h_draws.data(), conv_draws, (size_t)n, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipMemcpyAsync(h_pcol.data(), conv_pcol, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
-        std::vector<unsigned int> h_pid((size_t)n);
-        HIPCHK(hipMemcpyAsync(h_pid.data(), P.pid, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        std::vector<int> igrid((size_t)n + 1), ipoint((size_t)n + 1);
-        std::vector<unsigned char> draws_by_pid((size_t)n, 0);
-        for (long long s = 0; s < n; s++) {
-          const unsigned int p = h_pid[(size_t)s];
-          if (p >= (unsigned int)n) return fail(FPX_ERR_STATE, "convmix: particle numbers beyond numpart");
-          igrid[p + 1] = h_pcol[(size_t)s] < 0 ? -1 : 1 + h_pcol[(size_t)s];
-          draws_by_pid[p] = h_draws[(size_t)s];
-        }
-        for (long long p = 1; p <= n; p++) ipoint[(size_t)p] = (int)p;
-        conv_sort2((int)n, igrid.data(), ipoint.data());
-        std::vector<H> rn((size_t)n, (H)-1);
-        for (long long k = 1; k <= n; k++) {
-          if (igrid[(size_t)k] == -1) continue;
-          const int p = ipoint[(size_t)k] - 1;
-          if (!draws_by_pid[(size_t)p]) continue;
-          rn[(size_t)p] = sizeof(H) == 4 ? (H)rng4.ran3(rng4.idummy_redist) : (H)rng8.ran3(rng8.idummy_redist);
-        }
-        HIPCHK(hipMemcpyAsync(conv_rn, rn.data(), (size_t)n * sizeof(H), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));
       }
     }
     HIPCHK(hipEventRecord(e1, stream));
@@ -3039,6 +3075,7 @@ struct Engine : EngineBase {
     uint32_t step_counter;
     int32_t itime, numparticlecount, reserved;
     uint64_t n_grid3, n_grid2, n_grid3n, n_grid2n, n_receptor, rng_bytes;
+    uint64_t cbase_bytes;        // conv_mod cbaseflux (the convection scheme relaxes it from call to call)
   };
   static constexpr long long kCkptChunk = 1ll << 22;
   template <typename T>
@@ -3098,6 +3135,7 @@ struct Engine : EngineBase {
     h.n_grid3n = Gp.on && Gp.nested ? n_grid3n : 0; h.n_grid2n = Gp.on && Gp.nested ? n_grid2n : 0;
     h.n_receptor = Gp.creceptor ? (uint64_t)Gp.numreceptor * cfg.maxspec : 0;
     h.rng_bytes = sizeof(CkptRng);
+    h.cbase_bytes = conv_on ? (uint64_t)cfg.nx * cfg.ny * cfg.host_real_bytes : 0;
     if (fwrite(&h, sizeof(h), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
     CkptRng rs{rng4, rng8, rel_ran1};
     if (fwrite(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
@@ -3114,6 +3152,7 @@ struct Engine : EngineBase {
     if (h.n_grid3n && ((rc = ckpt_put_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_put_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
                        (rc = ckpt_put_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return rc;
     if (h.n_receptor && (rc = ckpt_put_plain(fh, Gp.creceptor, (size_t)h.n_receptor, buf))) return rc;
+    if (h.cbase_bytes && (rc = ckpt_put_plain(fh, (const unsigned char *)conv_cb, (size_t)h.cbase_bytes, buf))) return rc;
     closer.f = nullptr;
     if (fclose(fh) != 0) return fail(FPX_ERR_ARG, std::string("checkpoint_write: write error on ") + path);
     return 0;
@@ -3135,6 +3174,8 @@ struct Engine : EngineBase {
     const uint64_t nr = Gp.creceptor ? (uint64_t)Gp.numreceptor * cfg.maxspec : 0;
     if (h.n_grid3 != g3 || h.n_grid2 != g2 || h.n_grid3n != g3n || h.n_grid2n != g2n || h.n_receptor != nr)
       return fail(FPX_ERR_STATE, "checkpoint_read: the output grids of the checkpoint are not the ones configured (call fpx_outgrid_init ... first)");
+    if (h.cbase_bytes != (conv_on ? (uint64_t)cfg.nx * cfg.ny * cfg.host_real_bytes : 0))
+      return fail(FPX_ERR_STATE, "checkpoint_read: the checkpoint was written with (without) convection; call fpx_conv_init first (or not at all)");
     CkptRng rs;
     if (fread(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_read: file too short");
     // storage spaces in particle-number order again
@@ -3160,6 +3201,7 @@ struct Engine : EngineBase {
     if (g3n && ((rc = ckpt_get_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_get_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
                 (rc = ckpt_get_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return rc;
     if (nr && (rc = ckpt_get_plain(fh, Gp.creceptor, (size_t)nr, buf))) return rc;
+    if (h.cbase_bytes && (rc = ckpt_get_plain(fh, (unsigned char *)conv_cb, (size_t)h.cbase_bytes, buf))) return rc;
     for (bool &v : red_valid) v = false;
     rng4 = rs.r4; rng8 = rs.r8; rel_ran1 = rs.rel;
     step_counter = h.step_counter;

@@ -23,6 +23,7 @@ module flexgpu_mod
   use xmass_mod, only: xmasssave
   use outg_mod, only: outheight, area, volume
   use unc_mod, only: gridunc, drygridunc, wetgridunc, griduncn, drygriduncn, wetgriduncn
+  use conv_mod, only: nconvlev, cbaseflux
   implicit none
   private
   public :: fpx_step_stats, flexgpu_init, flexgpu_finalize, flexgpu_upload_fields, &
@@ -33,7 +34,8 @@ module flexgpu_mod
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
             flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, &
             flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar, &
-            flexgpu_checkpoint_write, flexgpu_checkpoint_read
+            flexgpu_checkpoint_write, flexgpu_checkpoint_read, &
+            flexgpu_conv_init, flexgpu_upload_conv_fields, flexgpu_convmix
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -129,6 +131,14 @@ module flexgpu_mod
   type, bind(C) :: fpx_calcpar_out
     type(c_ptr) :: ustar, wstar, oli, hmix, tropopause
   end type fpx_calcpar_out
+  type, bind(C) :: fpx_conv_config
+    integer(c_int32_t) :: struct_bytes, nuvz, nconvlev, reserved
+    type(c_ptr) :: akz, bkz, akm, bkm
+  end type fpx_conv_config
+  type, bind(C) :: fpx_conv_fields
+    type(c_ptr) :: ps, tt2, td2, tth, qvh
+    integer(c_int32_t) :: nuvzmax, reserved
+  end type fpx_conv_fields
 
   type, bind(C) :: fpx_release
     integer(c_int32_t) :: struct_bytes, numpoint
@@ -221,6 +231,23 @@ module flexgpu_mod
       character(kind=c_char), intent(in) :: path(*)
       integer(c_int64_t), intent(out) :: nrec
     end function fpx_partoutput
+    integer(c_int) function fpx_conv_init(h, c) bind(C, name='fpx_conv_init')
+      import :: c_ptr, c_int, fpx_conv_config
+      type(c_ptr), value :: h
+      type(fpx_conv_config), intent(in) :: c
+    end function fpx_conv_init
+    integer(c_int) function fpx_upload_conv_fields(h, slot, f) bind(C, name='fpx_upload_conv_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_conv_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: slot
+      type(fpx_conv_fields), intent(in) :: f
+    end function fpx_upload_conv_fields
+    integer(c_int) function fpx_convmix(h, itime, nmoved) bind(C, name='fpx_convmix')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: itime
+      type(c_ptr), value :: nmoved
+    end function fpx_convmix
     integer(c_int) function fpx_checkpoint_write(h, path, itime, npc) bind(C, name='fpx_checkpoint_write')
       import :: c_ptr, c_int, c_int32_t, c_char
       type(c_ptr), value :: h
@@ -654,6 +681,35 @@ contains
     numparticlecount = npc
     itrasplit(1:numpart) = ldirect * itsplit
   end subroutine flexgpu_readpartpositions
+
+  ! ---- convective mixing on the device (SURVEY section 8 f3) -----------------------------------------------------------
+  ! after gridcheck_ecmwf (nuvz, nconvlev, akz, bkz, akm, bkm): level structure; cbaseflux starts from zero as in the reference
+  subroutine flexgpu_conv_init(ierr)
+    integer, intent(out) :: ierr
+    type(fpx_conv_config) :: c
+    c%struct_bytes = int(c_sizeof(c), c_int32_t)
+    c%nuvz = nuvz; c%nconvlev = nconvlev; c%reserved = 0
+    c%akz = loc_r(akz); c%bkz = loc_r(bkz); c%akm = loc_r(akm); c%bkm = loc_r(bkm)
+    ierr = fpx_conv_init(flexgpu_handle, c)
+  end subroutine flexgpu_conv_init
+
+  ! after readwind_ecmwf filled slot n = memind(k) (getfields.f90): ps, tt2, td2, tth, qvh of that slot
+  subroutine flexgpu_upload_conv_fields(n, ierr)
+    integer, intent(in) :: n
+    integer, intent(out) :: ierr
+    type(fpx_conv_fields) :: f
+    f%ps = loc_r(ps(0,0,1,n)); f%tt2 = loc_r(tt2(0,0,1,n)); f%td2 = loc_r(td2(0,0,1,n))
+    f%tth = loc_r(tth(0,0,1,n)); f%qvh = loc_r(qvh(0,0,1,n))
+    f%nuvzmax = nuvzmax; f%reserved = 0
+    ierr = fpx_upload_conv_fields(flexgpu_handle, int(n, c_int32_t), f)
+  end subroutine flexgpu_upload_conv_fields
+
+  ! replaces `call convmix(itime,metdata_format)` (timemanager.f90:258-262; backward runs :183-187)
+  subroutine flexgpu_convmix(itime, ierr)
+    integer, intent(in) :: itime
+    integer, intent(out) :: ierr
+    ierr = fpx_convmix(flexgpu_handle, int(itime, c_int32_t), c_null_ptr)
+  end subroutine flexgpu_convmix
 
   ! Lossless restart file path(2)//'flexgpu_checkpoint' (no reference counterpart: partoutput / readpartpositions lose the
   ! turbulent state, DESIGN.md section 11): everything the particle loop carries.  A run continued with

@@ -303,7 +303,7 @@ int fpx_set_cbaseflux(fpx_handle h, const void *cbaseflux);
  * counterpart: fpx_checkpoint_write stores every array of the particle loop (com_mod.f90:678-695) in the
  * compute precision and in particle-number order, the step counter the counter RNG is keyed on, the state
  * of the serial ran3 / ran1 streams of the parity mode and the accumulating grids (gridunc, drygridunc,
- * wetgridunc, the nested ones, creceptor); fpx_checkpoint_read restores them into an engine created with
+ * wetgridunc, the nested ones, creceptor) and the convection scheme's cbaseflux; fpx_checkpoint_read restores them into an engine created with
  * the same fpx_config (+ fpx_outgrid_init ... if the run samples), also after a locality sort.  A run continued
  * from the file is bit-identical to the uninterrupted one.  itime and numparticlecount are the host's values
  * and come back unchanged.  The met fields are not in the file (the host uploads them as at start-up). */

@@ -18,7 +18,7 @@ FC="${FC:-/opt/rocm/lib/llvm/bin/flang}"
 if [ ! -d "$REF" ]; then echo "build_ref: no reference tree at $REF (skipping)"; exit 0; fi
 if [ ! -x "$FC" ]; then echo "build_ref: no flang at $FC (skipping)"; exit 0; fi
 
-MODS="par_mod com_mod interpol_mod hanna_mod cmapf_mod point_mod xmass_mod random_mod unc_mod outg_mod"
+MODS="par_mod com_mod interpol_mod hanna_mod cmapf_mod point_mod xmass_mod random_mod unc_mod outg_mod conv_mod"
 SUBS="advance initialize interpol_all interpol_wind interpol_wind_short interpol_misslev interpol_vdep \
 interpol_all_nests interpol_wind_nests interpol_wind_short_nests interpol_misslev_nests interpol_vdep_nests \
 hanna hanna1 hanna_short cbl re_initialize_particle initialize_cbl_vel windalign get_settling dynamic_viscosity \
@@ -84,7 +84,7 @@ build_vt() {
     [ -z "$extra" ] || extra="$extra.o"
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_vt_driver.f90" -o ref_vt_driver.o
     "$FC" -O2 -mcmodel=medium $flags ref_vt_driver.o flexgpu_mod.o caldate.o juldate.o verttransform_ecmwf.o $extra ew.o qvsat.o \
-        par_mod.o com_mod.o cmapf_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o \
+        par_mod.o com_mod.o cmapf_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o conv_mod.o \
         -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
         -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
         -o "$OUT/vtref_$kind"
@@ -103,7 +103,7 @@ build_po() {
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_po_driver.f90" -o ref_po_driver.o
     "$FC" -O2 -mcmodel=medium $flags ref_po_driver.o flexgpu_mod.o partoutput.o caldate.o juldate.o \
-        par_mod.o com_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o \
+        par_mod.o com_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o conv_mod.o \
         -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
         -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
         -o "$OUT/poref_$kind"
@@ -122,7 +122,7 @@ build_rp() {
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_rp_driver.f90" -o ref_rp_driver.o
     "$FC" -O2 -mcmodel=medium $flags ref_rp_driver.o flexgpu_mod.o readpartpositions.o caldate.o juldate.o \
-        par_mod.o com_mod.o random_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o \
+        par_mod.o com_mod.o random_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o conv_mod.o \
         -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
         -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
         -o "$OUT/rpref_$kind"
@@ -141,7 +141,7 @@ build_rel() {
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_rel_driver.f90" -o ref_rel_driver.o
     "$FC" -O2 -mcmodel=medium $flags ref_rel_driver.o flexgpu_mod.o releaseparticles.o caldate.o juldate.o \
-        par_mod.o com_mod.o random_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o \
+        par_mod.o com_mod.o random_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o conv_mod.o \
         -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
         -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
         -o "$OUT/relref_$kind"
