@@ -35,7 +35,7 @@ module flexgpu_mod
             flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, &
             flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar, &
             flexgpu_checkpoint_write, flexgpu_checkpoint_read, &
-            flexgpu_conv_init, flexgpu_upload_conv_fields, flexgpu_convmix
+            flexgpu_conv_init, flexgpu_upload_conv_fields, flexgpu_convmix, flexgpu_cbaseflux
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
 #endif
@@ -248,6 +248,14 @@ module flexgpu_mod
       integer(c_int32_t), value :: itime
       type(c_ptr), value :: nmoved
     end function fpx_convmix
+    integer(c_int) function fpx_get_cbaseflux(h, cb) bind(C, name='fpx_get_cbaseflux')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, cb
+    end function fpx_get_cbaseflux
+    integer(c_int) function fpx_set_cbaseflux(h, cb) bind(C, name='fpx_set_cbaseflux')
+      import :: c_ptr, c_int
+      type(c_ptr), value :: h, cb
+    end function fpx_set_cbaseflux
     integer(c_int) function fpx_checkpoint_write(h, path, itime, npc) bind(C, name='fpx_checkpoint_write')
       import :: c_ptr, c_int, c_int32_t, c_char
       type(c_ptr), value :: h
@@ -710,6 +718,22 @@ contains
     integer, intent(out) :: ierr
     ierr = fpx_convmix(flexgpu_handle, int(itime, c_int32_t), c_null_ptr)
   end subroutine flexgpu_convmix
+
+  ! conv_mod cbaseflux(0:nxmax-1,0:nymax-1) <-> the engine's field (set = .true.: host -> device, e.g. from a restart file)
+  subroutine flexgpu_cbaseflux(set, ierr)
+    logical, intent(in) :: set
+    integer, intent(out) :: ierr
+    real, allocatable, target :: buf(:,:)
+    allocate(buf(0:nx-1,0:ny-1))
+    if (set) then
+      buf = cbaseflux(0:nx-1,0:ny-1)
+      ierr = fpx_set_cbaseflux(flexgpu_handle, c_loc(buf))
+    else
+      ierr = fpx_get_cbaseflux(flexgpu_handle, c_loc(buf))
+      if (ierr == 0) cbaseflux(0:nx-1,0:ny-1) = buf
+    end if
+    deallocate(buf)
+  end subroutine flexgpu_cbaseflux
 
   ! Lossless restart file path(2)//'flexgpu_checkpoint' (no reference counterpart: partoutput / readpartpositions lose the
   ! turbulent state, DESIGN.md section 11): everything the particle loop carries.  A run continued with

@@ -202,7 +202,11 @@ build_conv() {
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_conv_driver.f90" -o ref_conv_driver.o
-    "$FC" -O2 -mcmodel=medium $flags ref_conv_driver.o conv_mod.o convect43c.o redist.o sort2.o qvsat.o ew.o random_mod.o com_mod.o par_mod.o -o "$OUT/convref_$kind"
+    "$FC" -O2 -mcmodel=medium $flags ref_conv_driver.o flexgpu_mod.o conv_mod.o convect43c.o redist.o sort2.o qvsat.o ew.o caldate.o juldate.o \
+        par_mod.o com_mod.o random_mod.o point_mod.o xmass_mod.o unc_mod.o outg_mod.o \
+        -L"$HERE/../flexpart_amd/csrc" -lflexpart_amd \
+        -Wl,-rpath,'$ORIGIN/../../flexpart_amd/csrc' -Wl,-rpath,/opt/rocm/lib \
+        -o "$OUT/convref_$kind"
   )
   echo "build_ref: built $OUT/convref_$kind"
 }

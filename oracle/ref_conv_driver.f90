@@ -9,13 +9,17 @@
 ! (calcmatrix.f90:56-137, convmix.f90:61-196) around the real CONVECT and REDIST.  This file is our own code: it
 ! contains no reference source.
 !
-! Usage:  convref_rK in.bin out.bin
+! Usage:  convref_rK in.bin out.bin [gpu]
+!   gpu: the same com_mod / conv_mod arrays go to the MI355X engine through flexpart_amd/fortran/flexgpu_mod.f90
+!        (flexgpu_conv_init / flexgpu_upload_conv_fields / flexgpu_convmix replace the loop below), serial-stream parity mode.
 program convref
   use par_mod
   use com_mod
   use conv_mod
+  use flexgpu_mod
   implicit none
-  character(len=512) :: fin, fout
+  character(len=512) :: fin, fout, arg3, gmsg
+  integer :: use_gpu, gerr
   integer(kind=4) :: hdr(12)
   integer :: nxl, nyl, nuvzl, ncalls, fmcap, n, ic, i, j, k, kk
   real(kind=8) :: hnz
@@ -32,6 +36,11 @@ program convref
 
   call get_command_argument(1, fin)
   call get_command_argument(2, fout)
+  use_gpu = 0
+  if (command_argument_count() >= 3) then
+    call get_command_argument(3, arg3)
+    if (trim(arg3) == 'gpu') use_gpu = 1
+  end if
   open(31, file=trim(fin), access='stream', form='unformatted', status='old')
   read(31) hdr
   nxl = hdr(1); nyl = hdr(2); nuvzl = hdr(3); nconvlev = hdr(4); ldirect = hdr(5); lsynctime = hdr(6)
@@ -60,8 +69,58 @@ program convref
   cbl = real(cb8)
 
   open(32, file=trim(fout), access='stream', form='unformatted', status='replace')
+  if (use_gpu == 1) then
+    ! what flexgpu_init reads of com_mod (no trajectory step is taken): a limited-area grid of nxl x nyl cells, nz levels
+    nx = nxl; ny = nyl; nxmin1 = nx - 1; nymin1 = ny - 1
+    dx = 1.; dy = 1.; xlon0 = -20.; ylat0 = 20.; xglobal = .false.; nglobal = .false.; sglobal = .false.
+    switchnorthg = 999999.; switchsouthg = 999999.
+    do k = 1, nz
+      height(k) = real(hnz) * real(k - 1) / real(nz - 1)
+    end do
+    nmixz = nz
+    method = 1; ctl = 0.2; ifine = 4; turbswitch = .true.; cblflag = 0; mintime = 1
+    mdomainfill = 0; lsettling = .false.; DRYDEP = .false.; nageclass = 1; lage(1) = 999999999; nspec = 1; mquasilag = 0
+    memtime(1) = mt1; memtime(2) = mt2; memind(1) = 1; memind(2) = 2; lwindinterv = abs(mt2 - mt1)
+    do j = 1, nyl
+      do i = 1, nxl
+        do k = 1, 2
+          ps(i-1,j-1,1,k) = real(ps8(i,j,k)); tt2(i-1,j-1,1,k) = real(tt28(i,j,k)); td2(i-1,j-1,1,k) = real(td28(i,j,k))
+          tth(i-1,j-1,1:nuvzl,k) = real(tth8(i,j,1:nuvzl,k)); qvh(i-1,j-1,1:nuvzl,k) = real(qvh8(i,j,1:nuvzl,k))
+        end do
+      end do
+    end do
+    itra1(:) = -999999999; itramem(:) = 0; idt(:) = 1; npoint(:) = 1; nclass(:) = 1; itrasplit(:) = 999999999
+    uap(:) = 0.; ucp(:) = 0.; uzp(:) = 0.; us(:) = 0.; vs(:) = 0.; ws(:) = 0.; cbt(:) = 1; xmass1(:,:) = 1.
+    call flexgpu_init(gerr, nmaxpart=n)
+    if (gerr == 0) call flexgpu_use_table_rng(gerr)
+    if (gerr == 0) call flexgpu_set_windtime(gerr)
+    if (gerr == 0) call flexgpu_conv_init(gerr)
+    if (gerr == 0) call flexgpu_upload_conv_fields(1, gerr)
+    if (gerr == 0) call flexgpu_upload_conv_fields(2, gerr)
+    if (gerr /= 0) call gpu_fail('set-up')
+    cbaseflux(0:nxl-1,0:nyl-1) = cbl
+    call flexgpu_cbaseflux(.true., gerr)
+    if (gerr /= 0) call gpu_fail('flexgpu_cbaseflux')
+  end if
   do ic = 1, ncalls
     itime = itimes(ic)
+    if (use_gpu == 1) then
+      do i = 1, n
+        itra1(i) = merge(itime, itime + 12345, due(i, ic) /= 0)
+      end do
+      call flexgpu_upload_particles(1, n, gerr)
+      if (gerr == 0) call flexgpu_convmix(itime, gerr)
+      if (gerr == 0) call flexgpu_download_particles(1, n, gerr)
+      if (gerr == 0) call flexgpu_cbaseflux(.false., gerr)
+      if (gerr /= 0) call gpu_fail('flexgpu_convmix')
+      do i = 1, n
+        z8(i) = ztra1(i)
+      end do
+      cb8 = cbaseflux(0:nxl-1,0:nyl-1)
+      lconvcol = -1; ntopcol = 0; fmcount = 0; fm8 = 0.d0; fmcol = -1
+      write(32) z8, cb8, lconvcol, ntopcol, fmcount, fmcol, fm8
+      cycle
+    end if
     dt1 = real(itime - mt1)
     dt2 = real(mt2 - itime)
     dtt = 1. / (dt1 + dt2)
@@ -124,8 +183,16 @@ program convref
     write(32) z8, cb8, lconvcol, ntopcol, fmcount, fmcol, fm8
   end do
   close(32)
+  if (use_gpu == 1) call flexgpu_finalize()
 
 contains
+
+  subroutine gpu_fail(where)
+    character(len=*), intent(in) :: where
+    call flexgpu_last_error(gmsg)
+    write(*,*) 'convref gpu: ', where, ': ', trim(gmsg)
+    stop 3
+  end subroutine gpu_fail
 
   ! our restatement of calcmatrix.f90:56-137 (ECMWF branch) around the reference's CONVECT
   subroutine glue_calcmatrix(lconv, delt, cbmf)

@@ -358,7 +358,7 @@ def have_conv_ref(kind="r8"):
     return os.access(os.path.join(HERE, "_ref", f"convref_{kind}"), os.X_OK)
 
 
-def run_conv_reference(cs, kind="r8", workdir="/tmp", fm_cap=8):
+def run_conv_reference(cs, kind="r8", workdir="/tmp", fm_cap=8, gpu=False):
     """The unmodified CONVECT / TLIFT, redist, sort2, f_qvsat, ew, ran3 (behind oracle/ref_conv_driver.f90, which carries our
     restatement of the calcmatrix / convmix glue) on a synthetic.convection_case() dict -> one dict per call."""
     import tempfile
@@ -377,7 +377,7 @@ def run_conv_reference(cs, kind="r8", workdir="/tmp", fm_cap=8):
             fh.write(np.asarray(cs["itimes"], dtype=np.int32).tobytes())
             fh.write(np.ascontiguousarray(np.asarray(cs["due"]).T.astype(np.int32)).tobytes())     # due(n,ncalls) column-major
         exe = os.path.join(HERE, "_ref", f"convref_{kind}")
-        res = subprocess.run([exe, fi, fo], capture_output=True, text=True)
+        res = subprocess.run([exe, fi, fo] + (["gpu"] if gpu else []), capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"reference convection driver failed: {res.stdout}\n{res.stderr}")
         raw = open(fo, "rb").read()

@@ -147,3 +147,26 @@ def test_device_convmix_with_the_counter_generator(built):
     z2 = eng.download()["ztra1"].astype(np.float64)
     eng.close()
     assert np.array_equal(z2, z)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_fortran_host_convmix(built, kind):
+    """The real Fortran host: convref_rK either runs the reference's CONVECT / redist around our calcmatrix / convmix glue, or
+    hands com_mod / conv_mod (tth, qvh, ps, tt2, td2 with their nxmax strides, akz ... bkm, cbaseflux, the particle arrays) to
+    flexgpu_conv_init / flexgpu_upload_conv_fields / flexgpu_convmix in the serial-stream parity mode and downloads the particles
+    -- the same heights and mass fluxes, to the tolerances of the C-ABI test."""
+    if not sio.have_conv_ref(kind):
+        pytest.skip("oracle/_ref/convref binaries not present in this snapshot")
+    cs = syn.convection_case(ncalls=2)
+    ref = sio.run_conv_reference(cs, kind)
+    gpu = sio.run_conv_reference(cs, kind, gpu=True)
+    tol = 1e-9 if kind == "r8" else 2e-4
+    # the second call starts from each run's own first result: compare it on the particles that agreed after the first
+    agreed = np.ones(int(cs["npart"]), bool)
+    for ic, (g, r) in enumerate(zip(gpu, ref)):
+        assert np.abs(g["cbaseflux"] - r["cbaseflux"]).max() <= tol * r["cbaseflux"].max(), (kind, ic)
+        close = np.abs(g["ztra1"] - r["ztra1"]) <= tol * np.maximum(np.abs(r["ztra1"]), 1.0)
+        assert close[agreed].mean() >= 0.99, (kind, ic, close[agreed].mean())
+        agreed &= close
+    assert (ref[0]["ztra1"] != np.asarray(cs["ztra1"], dtype=np.float32 if kind == "r4" else np.float64)).sum() > 500
