@@ -34,10 +34,10 @@ using vt::M;
 #define I_MIN(a, b) ((a) < (b) ? (a) : (b))
 
 // the per-column arrays (1-based index i in 0..nv-1 is used as in the Fortran; element 0 is unused)
-enum Vec { V_fup, V_fdown, V_m, V_mp, V_tvp, V_tv, V_water, V_qp, V_ep, V_th, V_wt, V_evap, V_clw, V_sigp, V_tp, V_cpn, V_lv, V_lvcp,
-           V_h, V_hp, V_gz, V_hm, V_nent, V_tconv, V_qconv, V_qsconv, V_pconv_hpa, V_phconv_hpa, V_ft, V_fq, V_sub, V_pconv,
+enum Vec { V_fup, V_fdown, V_m, V_tvp, V_tv, V_ep, V_clw, V_sigp, V_tp, V_cpn, V_lv,
+           V_h, V_hp, V_gz, V_hm, V_nent, V_tconv, V_qconv, V_qsconv, V_pconv_hpa, V_phconv_hpa, V_sub, V_pconv,
            V_phconv, V_dpr, V_uvzlev, V_COUNT };
-enum Mat { M_fmass, M_ment, M_qent, M_elij, M_sij, M_COUNT };
+enum Mat { M_fmass, M_ment, M_sij, M_COUNT };
 constexpr int M_fmassfrac = M_fmass;      // calcmatrix scales fmass into fmassfrac in place
 
 template <typename H>
@@ -49,7 +49,7 @@ struct Scr {
 };
 // what the first part of CONVECT (up to its early exits) hands to the second
 template <typename H>
-struct CvState { int nk, icb, iflag; H plcl, cbmf; };
+struct CvState { int nk, icb, inb, iflag; H plcl, cbmf; };
 #define VV(name, i) Sx.v[((size_t)V_##name * Sx.nv + (size_t)(i)) * Sx.B + Sx.c]
 #define MM(name, i, j) Sx.mat[(((size_t)M_##name * Sx.nv + (size_t)(j)) * Sx.nv + (size_t)(i)) * Sx.Bm + Sx.cm]
 
@@ -126,7 +126,7 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   plcl = HK(0.);
   if (PHASE == 1) {
   for (i = 1; i <= nl + 1; i++) {
-    VV(ft, i) = HK(0.0); VV(fq, i) = HK(0.0); VV(fdown, i) = HK(0.0); VV(sub, i) = HK(0.0); VV(fup, i) = HK(0.0); VV(m, i) = HK(0.0); VV(mp, i) = HK(0.0);
+    VV(fdown, i) = HK(0.0); VV(sub, i) = HK(0.0); VV(fup, i) = HK(0.0); VV(m, i) = HK(0.0);
   }
   iflag = 0;
 #define RETURN_ do { st.iflag = iflag; st.cbmf = cbmf; (void)precip; (void)wd; (void)tprime; (void)qprime; return PHASE == 2; } while (0)
@@ -171,8 +171,6 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   return true;
   }   // PHASE 1
   nk = st.nk; icb = st.icb; plcl = st.plcl;
-  for (i = 1; i <= nl + 1; i++)
-    for (j = 1; j <= nl + 1; j++) { MM(fmass, i, j) = HK(0.0); MM(ment, i, j) = HK(0.0); }
   tlift<H>(Sx, icb, nk, nl, 2);
   for (i = 1; i <= nk; i++) { VV(ep, i) = HK(0.0); VV(sigp, i) = sigs; }
   for (i = nk + 1; i <= nl; i++) {
@@ -188,11 +186,8 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   for (i = icb + 1; i <= nl; i++) VV(tvp, i) = VV(tvp, i) - VV(tp, i) * VV(qconv, nk);
   VV(tvp, nl + 1) = VV(tvp, nl) - (VV(gz, nl + 1) - VV(gz, nl)) / cpd;
   for (i = 1; i <= nl + 1; i++) {
-    VV(hp, i) = VV(h, i); VV(nent, i) = 0; VV(water, i) = HK(0.0); VV(evap, i) = HK(0.0); VV(wt, i) = omtsnow; VV(lvcp, i) = VV(lv, i) / VV(cpn, i);
-    for (j = 1; j <= nl + 1; j++) { MM(qent, i, j) = VV(qconv, j); MM(elij, i, j) = HK(0.0); MM(sij, i, j) = HK(0.0); }
+    VV(hp, i) = VV(h, i); VV(nent, i) = 0;
   }
-  VV(qp, 1) = VV(qconv, 1);
-  for (i = 2; i <= nl + 1; i++) VV(qp, i) = VV(qconv, i - 1);
   cape = HK(0.0); capem = HK(0.0);
   inb = icb + 1; inb1 = inb;
   byp = HK(0.0);
@@ -207,6 +202,15 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
     }
   }
   inb = I_MAX(inb, inb1);
+  st.inb = inb;
+  // MENT is assigned in rows icb+1..inb, columns icb..inb only, SIJ read one column beyond on either side: the reference
+  // zeroes (nl+1)^2 elements of five matrices per column, here the region that is read is zeroed (adding the exact zeros of
+  // the rest changes no sum)
+  for (i = icb + 1; i <= inb; i++)
+    for (j = icb - 1; j <= inb + 1; j++) {
+      MM(sij, i, j) = HK(0.0);
+      if (j >= icb && j <= inb) MM(ment, i, j) = HK(0.0);
+    }
   cape = capem + byp;
   defrac = capem - cape;
   defrac = R_MAX(defrac, HK(0.001));
@@ -236,42 +240,54 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
     VV(m, i) = cbmf * dbo;
   }
   for (i = icb + 1; i <= inb; i++) VV(m, i) = VV(m, i) / dbosum;
+  // (in this and the next loop nest the operands of kJ consecutive j are requested together -- the kernel runs one wave per SIMD
+  // at most, registers are plentiful, memory latency is what it waits for; the arithmetic of each j is the reference's)
+  constexpr int kJ = 8;
   for (i = icb + 1; i <= inb; i++) {
     qti = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
-    for (j = icb; j <= inb; j++) {
-      bf2 = HK(1.) + VV(lv, j) * VV(lv, j) * VV(qsconv, j) / (rv * VV(tconv, j) * VV(tconv, j) * cpd);
-      anum = VV(h, j) - VV(hp, i) + (cpv - cpd) * VV(tconv, j) * (qti - VV(qconv, j));
-      denom = VV(h, i) - VV(hp, i) + (cpd - cpv) * (VV(qconv, i) - qti) * VV(tconv, j);
-      dei = denom;
-      if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
-      MM(sij, i, j) = anum / dei;
-      MM(sij, i, i) = HK(1.0);
-      altem = MM(sij, i, j) * VV(qconv, i) + (HK(1.) - MM(sij, i, j)) * qti - VV(qsconv, j);
-      altem = altem / bf2;
-      cwat = VV(clw, j) * (HK(1.) - VV(ep, j));
-      stemp = MM(sij, i, j);
-      if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && j > i) {
-        anum = anum - VV(lv, j) * (qti - VV(qsconv, j) - cwat * bf2);
-        denom = denom + VV(lv, j) * (VV(qconv, i) - qti);
-        if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
-        MM(sij, i, j) = anum / denom;
-        altem = MM(sij, i, j) * VV(qconv, i) + (HK(1.) - MM(sij, i, j)) * qti - VV(qsconv, j);
-        altem = altem - (bf2 - HK(1.)) * cwat;
+    const H h_i = VV(h, i), hp_i = VV(hp, i), qc_i = VV(qconv, i), m_i = VV(m, i);
+    int nent_i = 0;
+    for (j = icb; j <= inb; j += kJ) {
+      H lvj[kJ], qsj[kJ], tcj[kJ], hj[kJ], qcj[kJ], clwj[kJ], epj[kJ];
+#pragma unroll
+      for (int u = 0; u < kJ; u++) {
+        const int jj = I_MIN(j + u, inb);
+        lvj[u] = VV(lv, jj); qsj[u] = VV(qsconv, jj); tcj[u] = VV(tconv, jj); hj[u] = VV(h, jj); qcj[u] = VV(qconv, jj);
+        clwj[u] = VV(clw, jj); epj[u] = VV(ep, jj);
       }
-      if (MM(sij, i, j) > HK(0.0) && MM(sij, i, j) < HK(0.9)) {
-        MM(qent, i, j) = MM(sij, i, j) * VV(qconv, i) + (HK(1.) - MM(sij, i, j)) * qti;
-        MM(elij, i, j) = altem;
-        MM(elij, i, j) = R_MAX(HK(0.0), MM(elij, i, j));
-        MM(ment, i, j) = VV(m, i) / (HK(1.) - MM(sij, i, j));
-        VV(nent, i) = VV(nent, i) + 1;
+#pragma unroll
+      for (int u = 0; u < kJ; u++) {
+        const int jj = j + u;
+        if (jj > inb) break;
+        bf2 = HK(1.) + lvj[u] * lvj[u] * qsj[u] / (rv * tcj[u] * tcj[u] * cpd);
+        anum = hj[u] - hp_i + (cpv - cpd) * tcj[u] * (qti - qcj[u]);
+        denom = h_i - hp_i + (cpd - cpv) * (qc_i - qti) * tcj[u];
+        dei = denom;
+        if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
+        H sv = anum / dei;
+        if (jj == i) sv = HK(1.0);                      // SIJ(I,I)=1.0 is set inside the j loop of the reference (:604)
+        altem = sv * qc_i + (HK(1.) - sv) * qti - qsj[u];
+        altem = altem / bf2;
+        cwat = clwj[u] * (HK(1.) - epj[u]);
+        stemp = sv;
+        if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && jj > i) {
+          anum = anum - lvj[u] * (qti - qsj[u] - cwat * bf2);
+          denom = denom + lvj[u] * (qc_i - qti);
+          if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+          sv = anum / denom;
+        }
+        if (sv > HK(0.0) && sv < HK(0.9)) {
+          MM(ment, i, jj) = m_i / (HK(1.) - sv);
+          nent_i = nent_i + 1;
+        }
+        sv = R_MAX(HK(0.0), sv);
+        sv = R_MIN(HK(1.0), sv);
+        MM(sij, i, jj) = sv;
       }
-      MM(sij, i, j) = R_MAX(HK(0.0), MM(sij, i, j));
-      MM(sij, i, j) = R_MIN(HK(1.0), MM(sij, i, j));
     }
-    if (VV(nent, i) == 0) {
-      MM(ment, i, i) = VV(m, i);
-      MM(qent, i, i) = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
-      MM(elij, i, i) = VV(clw, i);
+    VV(nent, i) = (H)nent_i;
+    if (nent_i == 0) {
+      MM(ment, i, i) = m_i;
       MM(sij, i, i) = HK(1.0);
     }
   }
@@ -288,170 +304,144 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
       scrit = R_MAX(scrit, HK(0.0));
       asij = HK(0.0);
       smin = HK(1.0);
-      for (j = icb; j <= inb; j++) {
-        if (MM(sij, i, j) > HK(0.0) && MM(sij, i, j) < HK(0.9)) {
-          if (j > i) {
-            smid = R_MIN(MM(sij, i, j), scrit);
-            sjmax = smid;
-            sjmin = smid;
-            if (smid < smin && MM(sij, i, j + 1) < smid) {
-              smin = smid;
-              sjmax = R_MIN(R_MIN(MM(sij, i, j + 1), MM(sij, i, j)), scrit);
-              sjmin = R_MAX(MM(sij, i, j - 1), MM(sij, i, j));
-              sjmin = R_MIN(sjmin, scrit);
+      for (j = icb; j <= inb; j += kJ) {
+        H sw[kJ + 2], me[kJ], ph[kJ + 1];                // SIJ(i, j-1 .. j+kJ), MENT(i, j .. j+kJ-1), PHCONV_HPA(j .. j+kJ)
+#pragma unroll
+        for (int u = 0; u < kJ + 2; u++) sw[u] = MM(sij, i, I_MIN(j - 1 + u, inb + 1));
+#pragma unroll
+        for (int u = 0; u < kJ; u++) me[u] = MM(ment, i, I_MIN(j + u, inb));
+#pragma unroll
+        for (int u = 0; u < kJ + 1; u++) ph[u] = VV(phconv_hpa, I_MIN(j + u, inb + 1));
+#pragma unroll
+        for (int u = 0; u < kJ; u++) {
+          const int jj = j + u;
+          if (jj > inb) break;
+          const H s0 = sw[u], s1 = sw[u + 1], s2 = sw[u + 2];      // SIJ(i,jj-1), SIJ(i,jj), SIJ(i,jj+1)
+          if (s1 > HK(0.0) && s1 < HK(0.9)) {
+            if (jj > i) {
+              smid = R_MIN(s1, scrit);
+              sjmax = smid;
+              sjmin = smid;
+              if (smid < smin && s2 < smid) {
+                smin = smid;
+                sjmax = R_MIN(R_MIN(s2, s1), scrit);
+                sjmin = R_MAX(s0, s1);
+                sjmin = R_MIN(sjmin, scrit);
+              }
+            } else {
+              sjmax = R_MAX(s2, scrit);
+              smid = R_MAX(s1, scrit);
+              sjmin = HK(0.0);
+              if (jj > 1) sjmin = s0;
+              sjmin = R_MAX(sjmin, scrit);
             }
-          } else {
-            sjmax = R_MAX(MM(sij, i, j + 1), scrit);
-            smid = R_MAX(MM(sij, i, j), scrit);
-            sjmin = HK(0.0);
-            if (j > 1) sjmin = MM(sij, i, j - 1);
-            sjmin = R_MAX(sjmin, scrit);
+            delp = R_ABS(sjmax - smid);
+            delm = R_ABS(sjmin - smid);
+            asij = asij + (delp + delm) * (ph[u] - ph[u + 1]);
+            MM(ment, i, jj) = me[u] * (delp + delm) * (ph[u] - ph[u + 1]);
           }
-          delp = R_ABS(sjmax - smid);
-          delm = R_ABS(sjmin - smid);
-          asij = asij + (delp + delm) * (VV(phconv_hpa, j) - VV(phconv_hpa, j + 1));
-          MM(ment, i, j) = MM(ment, i, j) * (delp + delm) * (VV(phconv_hpa, j) - VV(phconv_hpa, j + 1));
         }
       }
       asij = R_MAX(HK(1.0e-21), asij);
       asij = HK(1.0) / asij;
-      for (j = icb; j <= inb; j++) MM(ment, i, j) = MM(ment, i, j) * asij;
       bsum = HK(0.0);
-      for (j = icb; j <= inb; j++) bsum = bsum + MM(ment, i, j);
+      for (j = icb; j <= inb; j += 8) {
+        H me[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (j + u <= inb) { const H v = me[u] * asij; MM(ment, i, j + u) = v; bsum = bsum + v; }
+      }
       if (bsum < HK(1.0e-18)) {
         VV(nent, i) = 0;
         MM(ment, i, i) = VV(m, i);
-        MM(qent, i, i) = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
-        MM(elij, i, i) = VV(clw, i);
         MM(sij, i, i) = HK(1.0);
       }
     }
   }
-  if (!(VV(ep, inb) < HK(0.0001))) {
-    jtt = 2;
-    for (i = inb; i >= 1; i--) {
-      wdtrain = g * VV(ep, i) * VV(m, i) * VV(clw, i);
-      if (i > 1)
-        for (j = 1; j <= i - 1; j++) {
-          awat = MM(elij, j, i) - (HK(1.) - VV(ep, i)) * VV(clw, i);
-          awat = R_MAX(HK(0.0), awat);
-          wdtrain = wdtrain + g * awat * MM(ment, j, i);
-        }
-      coeff = coeffs;
-      VV(wt, i) = omtsnow;
-      if (VV(tconv, i) > HK(273.0)) { coeff = coeffr; VV(wt, i) = omtrain; }
-      qsm = HK(0.5) * (VV(qconv, i) + VV(qp, i + 1));
-      afac = coeff * VV(phconv_hpa, i) * (VV(qsconv, i) - qsm) / (HK(1.0e4) + HK(2.0e3) * VV(phconv_hpa, i) * VV(qsconv, i));
-      afac = R_MAX(afac, HK(0.0));
-      sigt = VV(sigp, i);
-      sigt = R_MAX(HK(0.0), sigt);
-      sigt = R_MIN(HK(1.0), sigt);
-      b6 = HK(100.) * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1)) * sigt * afac / VV(wt, i);
-      c6 = (VV(water, i + 1) * VV(wt, i + 1) + wdtrain / sigd) / VV(wt, i);
-      revap = HK(0.5) * (-b6 + M<H>::sqrt(b6 * b6 + HK(4.) * c6));
-      VV(evap, i) = sigt * afac * revap;
-      VV(water, i) = revap * revap;
-      if (i != 1) {
-        dhdp = (VV(h, i) - VV(h, i - 1)) / (VV(pconv_hpa, i - 1) - VV(pconv_hpa, i));
-        dhdp = R_MAX(dhdp, HK(10.0));
-        VV(mp, i) = HK(100.) * ginv * VV(lv, i) * sigd * VV(evap, i) / dhdp;
-        VV(mp, i) = R_MAX(VV(mp, i), HK(0.0));
-        fac = HK(20.0) / (VV(phconv_hpa, i - 1) - VV(phconv_hpa, i));
-        VV(mp, i) = (fac * VV(mp, i + 1) + VV(mp, i)) / (HK(1.) + fac);
-        if (VV(pconv_hpa, i) > (HK(0.949) * VV(pconv_hpa, 1))) {
-          jtt = I_MAX(jtt, i);
-          VV(mp, i) = VV(mp, jtt) * (VV(pconv_hpa, 1) - VV(pconv_hpa, i)) / (VV(pconv_hpa, 1) - VV(pconv_hpa, jtt));
-        }
-      }
-      if (i == inb) continue;
-      if (i == 1) qstm = VV(qsconv, 1); else qstm = VV(qsconv, i - 1);
-      if (VV(mp, i) > VV(mp, i + 1)) {
-        rat = VV(mp, i + 1) / VV(mp, i);
-        VV(qp, i) = VV(qp, i + 1) * rat + VV(qconv, i) * (HK(1.0) - rat) + HK(100.) * ginv * sigd * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1)) * (VV(evap, i) / VV(mp, i));
-      } else {
-        if (VV(mp, i + 1) > HK(0.0))
-          VV(qp, i) = (VV(gz, i + 1) - VV(gz, i) + VV(qp, i + 1) * (VV(lv, i + 1) + VV(tconv, i + 1) * (cl - cpd)) + cpd * (VV(tconv, i + 1) - VV(tconv, i))) / (VV(lv, i) + VV(tconv, i) * (cl - cpd));
-      }
-      VV(qp, i) = R_MIN(VV(qp, i), qstm);
-      VV(qp, i) = R_MAX(VV(qp, i), HK(0.0));
-    }
-    precip = precip + VV(wt, 1) * sigd * VV(water, 1) * HK(3600.) * HK(24000.) / (rowl * g);
-  }
-  wd = beta * R_ABS(VV(mp, icb)) * HK(0.01) * rd * VV(tconv, icb) / (sigd * VV(pconv_hpa, icb));
-  qprime = HK(0.5) * (VV(qp, 1) - VV(qconv, 1));
-  tprime = lv0 * qprime / cpd;
+  // (the precipitation / unsaturated-downdraught part, :686-790, and the tendencies FT, FQ with their entropy correction,
+  // :800-900, feed PRECIP, WD, TPRIME, QPRIME, FT, FQ only: nothing of that reaches the particles -- left out, together
+  // with the matrices QENT and ELIJ they alone read)
   dpinv = HK(0.01) / (VV(phconv_hpa, 1) - VV(phconv_hpa, 2));
   am = HK(0.0);
   if (nk == 1)
     for (k = 2; k <= inb; k++) am = am + VV(m, k);
   VV(fup, 1) = am;
   if ((HK(2.) * g * dpinv * am) >= delti) iflag = 4;
-  VV(ft, 1) = VV(ft, 1) + g * dpinv * am * (VV(tconv, 2) - VV(tconv, 1) + (VV(gz, 2) - VV(gz, 1)) / VV(cpn, 1));
-  VV(ft, 1) = VV(ft, 1) - VV(lvcp, 1) * sigd * VV(evap, 1);
-  VV(ft, 1) = VV(ft, 1) + sigd * VV(wt, 2) * (cl - cpd) * VV(water, 2) * (VV(tconv, 2) - VV(tconv, 1)) * dpinv / VV(cpn, 1);
-  VV(fq, 1) = VV(fq, 1) + g * VV(mp, 2) * (VV(qp, 2) - VV(qconv, 1)) * dpinv + sigd * VV(evap, 1);
-  VV(fq, 1) = VV(fq, 1) + g * am * (VV(qconv, 2) - VV(qconv, 1)) * dpinv;
-  for (j = 2; j <= inb; j++) VV(fq, 1) = VV(fq, 1) + g * dpinv * MM(ment, j, 1) * (MM(qent, j, 1) - VV(qconv, 1));
-  for (i = 2; i <= inb; i++) {
-    dpinv = HK(0.01) / (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1));
-    cpinv = HK(1.0) / VV(cpn, i);
-    amp1 = HK(0.0);
-    ad = HK(0.0);
-    if (i >= nk)
-      for (k = i + 1; k <= inb + 1; k++) amp1 = amp1 + VV(m, k);
-    // (the O(levels^3) sums of the scheme: the loads of sixteen terms are issued together, the additions keep the reference's
-    // order; a padding term adds +0.0, which leaves the sum unchanged)
-    for (k = 1; k <= i; k++)
-      for (j = i + 1; j <= inb + 1; j += 16) {
+  // FUP(i) = [i >= nk] sum_{k>i} M(k) + sum_{k<=i} sum_{j>i} MENT(k,j) and FDOWN(i) = sum_{k<i} sum_{j>=i} MENT(j,k): the reference
+  // forms them with two O(levels^3) loop nests per column.  Here: one descending sweep with the column sums S_k = sum_{j>=i}
+  // MENT(j,k) and one ascending sweep with C_j = sum_{k<=i} MENT(k,j) -- O(levels^2), the additions in another order (the only
+  // place where this kernel departs from the reference's order of operations; it moves FUP, FDOWN by rounding).
+  // S lives in tp (last read when EP was formed), C in hm (last read in the first part).
+  {
+    const int r0 = icb + 1, c0 = icb;
+    for (k = c0; k <= inb; k++) { VV(tp, k) = HK(0.); VV(hm, k) = HK(0.); }
+    for (i = inb; i >= 2; i--) {
+      if (i >= r0)
+        for (k = c0; k <= inb; k += 16) {
+          H a8[16], b8[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) { a8[u] = k + u <= inb ? VV(tp, k + u) : HK(0.); b8[u] = k + u <= inb ? MM(ment, i, k + u) : HK(0.); }
+#pragma unroll
+          for (int u = 0; u < 16; u++) if (k + u <= inb) VV(tp, k + u) = a8[u] + b8[u];
+        }
+      ad = HK(0.0);
+      const int kend = I_MIN(i - 1, inb);
+      for (k = c0; k <= kend; k += 16) {
         H t8[16];
 #pragma unroll
-        for (int u = 0; u < 16; u++) t8[u] = j + u <= inb + 1 ? MM(ment, k, j + u) : HK(0.);
-#pragma unroll
-        for (int u = 0; u < 16; u++) amp1 = amp1 + t8[u];
-      }
-    VV(fup, i) = amp1;
-    if ((HK(2.) * g * dpinv * amp1) >= delti) iflag = 4;
-    for (k = 1; k <= i - 1; k++)
-      for (j = i; j <= inb; j += 16) {
-        H t8[16];
-#pragma unroll
-        for (int u = 0; u < 16; u++) t8[u] = j + u <= inb ? MM(ment, j + u, k) : HK(0.);
+        for (int u = 0; u < 16; u++) t8[u] = k + u <= kend ? VV(tp, k + u) : HK(0.);
 #pragma unroll
         for (int u = 0; u < 16; u++) ad = ad + t8[u];
       }
-    VV(fdown, i) = ad;
-    VV(ft, i) = VV(ft, i) + g * dpinv * (amp1 * (VV(tconv, i + 1) - VV(tconv, i) + (VV(gz, i + 1) - VV(gz, i)) * cpinv) - ad * (VV(tconv, i) - VV(tconv, i - 1) + (VV(gz, i) - VV(gz, i - 1)) * cpinv)) -
-            sigd * VV(lvcp, i) * VV(evap, i);
-    VV(ft, i) = VV(ft, i) + g * dpinv * MM(ment, i, i) * (VV(hp, i) - VV(h, i) + VV(tconv, i) * (cpv - cpd) * (VV(qconv, i) - MM(qent, i, i))) * cpinv;
-    VV(ft, i) = VV(ft, i) + sigd * VV(wt, i + 1) * (cl - cpd) * VV(water, i + 1) * (VV(tconv, i + 1) - VV(tconv, i)) * dpinv * cpinv;
-    VV(fq, i) = VV(fq, i) + g * dpinv * (amp1 * (VV(qconv, i + 1) - VV(qconv, i)) - ad * (VV(qconv, i) - VV(qconv, i - 1)));
-    for (k = 1; k <= i - 1; k++) {
-      awat = MM(elij, k, i) - (HK(1.) - VV(ep, i)) * VV(clw, i);
-      awat = R_MAX(awat, HK(0.0));
-      VV(fq, i) = VV(fq, i) + g * dpinv * MM(ment, k, i) * (MM(qent, k, i) - awat - VV(qconv, i));
+      VV(fdown, i) = ad;
     }
-    for (k = i; k <= inb; k++) VV(fq, i) = VV(fq, i) + g * dpinv * MM(ment, k, i) * (MM(qent, k, i) - VV(qconv, i));
-    VV(fq, i) = VV(fq, i) + sigd * VV(evap, i) + g * (VV(mp, i + 1) * (VV(qp, i + 1) - VV(qconv, i)) - VV(mp, i) * (VV(qp, i) - VV(qconv, i - 1))) * dpinv;
-  }
-  fqold = VV(fq, inb);
-  VV(fq, inb) = VV(fq, inb) * (HK(1.) - frac);
-  VV(fq, inb - 1) = VV(fq, inb - 1) + frac * fqold * ((VV(phconv_hpa, inb) - VV(phconv_hpa, inb + 1)) / (VV(phconv_hpa, inb - 1) - VV(phconv_hpa, inb))) * VV(lv, inb) / VV(lv, inb - 1);
-  ftold = VV(ft, inb);
-  VV(ft, inb) = VV(ft, inb) * (HK(1.) - frac);
-  VV(ft, inb - 1) = VV(ft, inb - 1) + frac * ftold * ((VV(phconv_hpa, inb) - VV(phconv_hpa, inb + 1)) / (VV(phconv_hpa, inb - 1) - VV(phconv_hpa, inb))) * VV(cpn, inb) / VV(cpn, inb - 1);
-  ents = HK(0.0);
-  for (i = 1; i <= inb; i++) ents = ents + (VV(cpn, i) * VV(ft, i) + VV(lv, i) * VV(fq, i)) * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1));
-  ents = ents / (VV(phconv_hpa, 1) - VV(phconv_hpa, inb + 1));
-  for (i = 1; i <= inb; i++) VV(ft, i) = VV(ft, i) - ents / VV(cpn, i);
-  VV(sub, 1) = HK(0.);
-  nconvtop_ = 1;
-  for (i = 1; i <= inb + 1; i++) {
-    for (j = 1; j <= inb + 1; j++) {
-      if (j == nk) MM(fmass, j, i) = MM(fmass, j, i) + VV(m, i);
-      MM(fmass, j, i) = MM(fmass, j, i) + MM(ment, j, i);
-      if (MM(fmass, j, i) > epsilon) nconvtop_ = I_MAX(nconvtop_, I_MAX(i, j));
+    for (i = 2; i <= inb; i++) {
+      dpinv = HK(0.01) / (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1));
+      amp1 = HK(0.0);
+      if (i >= nk)
+        for (k = i + 1; k <= inb + 1; k += 16) {
+          H t8[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) t8[u] = k + u <= inb + 1 ? VV(m, k + u) : HK(0.);
+#pragma unroll
+          for (int u = 0; u < 16; u++) amp1 = amp1 + t8[u];
+        }
+      if (i >= r0)
+        for (j = c0; j <= inb; j += 16) {
+          H a8[16], b8[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) { a8[u] = j + u <= inb ? VV(hm, j + u) : HK(0.); b8[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.); }
+#pragma unroll
+          for (int u = 0; u < 16; u++) if (j + u <= inb) VV(hm, j + u) = a8[u] + b8[u];
+        }
+      for (j = I_MAX(i + 1, c0); j <= inb; j += 16) {
+        H t8[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) t8[u] = j + u <= inb ? VV(hm, j + u) : HK(0.);
+#pragma unroll
+        for (int u = 0; u < 16; u++) amp1 = amp1 + t8[u];
+      }
+      VV(fup, i) = amp1;
+      if ((HK(2.) * g * dpinv * amp1) >= delti) iflag = 4;
     }
-    if (i > 1) VV(sub, i) = VV(fup, i - 1) - VV(fdown, i);
+    // FMASS(j,i) = [j == nk] M(i) + MENT(j,i) is not stored: calcmatrix scales it into fmassfrac on the fly (fmass_at below);
+    // here only nconvtop, the largest index with a mass flux above epsilon, and SUB
+    VV(sub, 1) = HK(0.);
+    nconvtop_ = 1;
+    for (i = 1; i <= inb + 1; i++) {
+      if (VV(m, i) > epsilon) nconvtop_ = I_MAX(nconvtop_, I_MAX(i, nk));
+      if (i >= c0 && i <= inb)
+        for (j = r0; j <= inb; j += 16) {
+          H t8[16];
+#pragma unroll
+          for (int u = 0; u < 16; u++) t8[u] = j + u <= inb ? MM(ment, j + u, i) : HK(0.);
+#pragma unroll
+          for (int u = 0; u < 16; u++) if (t8[u] > epsilon) nconvtop_ = I_MAX(nconvtop_, I_MAX(i, j + u));
+        }
+      if (i > 1) VV(sub, i) = VV(fup, i - 1) - VV(fdown, i);
+    }
   }
   nconvtop_ = nconvtop_ + 1;
   RETURN_;
@@ -526,7 +516,7 @@ __global__ void __launch_bounds__(64) k_conv_column_a(Fields<H> F, H *__restrict
   }
   VV(phconv_hpa, nl + 1) = VV(phconv, nl + 1) / HK(100.);
   CvState<H> st;
-  st.nk = 0; st.icb = 0; st.iflag = 0; st.plcl = HK(0.);
+  st.nk = 0; st.icb = 0; st.inb = 0; st.iflag = 0; st.plcl = HK(0.);
   st.cbmf = cbaseflux[col];
   cst[(size_t)C_cbmfold * nact + c] = st.cbmf;
   int dummy = 0;
@@ -562,6 +552,7 @@ __global__ void __launch_bounds__(64) k_conv_column_b(Fields<H> F, H *__restrict
   st.nk = (int)cst[(size_t)C_nk * nact + c];
   st.icb = (int)cst[(size_t)C_icb * nact + c];
   st.iflag = (int)cst[(size_t)C_iflag * nact + c];
+  st.inb = 0;
   const H cbmfold = cst[(size_t)C_cbmfold * nact + c];
   const H psconv = cst[(size_t)C_psconv * nact + c], tt2conv = cst[(size_t)C_tt2conv * nact + c], td2conv = cst[(size_t)C_td2conv * nact + c];
   int nconvtop = 0, lconv = 0;
@@ -575,10 +566,21 @@ __global__ void __launch_bounds__(64) k_conv_column_b(Fields<H> F, H *__restrict
     for (int k = 1; k <= nconvtop; k++) {
       const H rlevmass = VV(dpr, k) / ga;
       H summe = HK(0.);
-      for (int kk = 1; kk <= nconvtop; kk++) {
-        const H f = F.delt * MM(fmass, k, kk);
-        MM(fmass, k, kk) = f;                            // fmassfrac(k,kk), in place
-        summe = summe + f;
+      for (int kk = 1; kk <= nconvtop; kk += 16) {
+        H f8[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int q = kk + u;
+          H v = HK(0.);
+          if (q <= nconvtop) {
+            if (k > st.icb && k <= st.inb && q >= st.icb && q <= st.inb) v = MM(ment, k, q);
+            if (k == st.nk) v = VV(m, q) + v;                  // FMASS(nk,i) = M(i) + MENT(nk,i), convect43c.f90:925-930
+          }
+          f8[u] = F.delt * v;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          if (kk + u <= nconvtop) { MM(fmass, k, kk + u) = f8[u]; summe = summe + f8[u]; }     // fmassfrac(k,kk)
       }
       MM(fmass, k, k) = MM(fmass, k, k) + rlevmass - summe;
     }
