@@ -449,27 +449,49 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
 }
 
 
-// what one call needs of the model-level fields: both time slots, compact [level][jy][ix]
+// what one call needs of the model-level fields: both time slots, compact [level][jy][ix], per wind-field domain
+// (0 = mother grid, l = nest l); columns are numbered through all domains: off + jy * nx + ix
+constexpr int kConvMaxDom = 5;
+template <typename H>
+struct Dom {
+  const H *ps[2], *tt2[2], *td2[2], *tth[2], *qvh[2];
+  H *cb;                              // cbaseflux / cbasefluxn(:,:,l)
+  int nx, ny, off;
+  H xl, yl, xr, yr, xres, yres;       // nests: xln, yln, xrn, yrn, xresoln, yresoln
+};
 template <typename H>
 struct Fields {
-  const H *ps[2], *tt2[2], *td2[2], *tth[2], *qvh[2];
+  Dom<H> dom[kConvMaxDom];
+  int ndom;
   const H *akz, *bkz, *akm, *bkm;     // [nuvz], 0-based
-  int nx, ny, nuvz, nconvlev;
+  int nuvz, nconvlev;
   int m1, m2;                         // which physical slot is memind(1), memind(2)
-  H dt1, dt2, dtt, delt;
+  H dt1, dt2, dtt, delt, eps;         // eps = nxmax/3.e5 (convmix.f90:79)
+  __device__ __forceinline__ int domain_of(int col) const {
+    int d = 0;
+    while (d + 1 < ndom && col >= dom[d + 1].off) d++;
+    return d;
+  }
 };
 
-// convmix.f90:92-135: the column of every particle that is due (mother grid)
+// convmix.f90:92-135: the grid (innermost nest that contains the particle, tested with eps as for ECMWF input) and the
+// column of every particle that is due
 template <typename R, typename H>
-__global__ void k_conv_mark(const double *__restrict__ xt, const double *__restrict__ yt, const int *__restrict__ itra1, long long n, int itime,
-                            int nx, int ny, int *__restrict__ pcol, unsigned int *__restrict__ colflag) {
+__global__ void k_conv_mark(Fields<H> F, const double *__restrict__ xt, const double *__restrict__ yt, const int *__restrict__ itra1, long long n,
+                            int itime, int *__restrict__ pcol, unsigned int *__restrict__ colflag) {
+#pragma clang fp contract(off)
   long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   int col = -1;
   if (itra1[s] == itime) {
     const H x = (H)xt[s], y = (H)yt[s];                  // convmix.f90:100-101: into default reals
-    const int ix = (int)(x < 0 ? x - HK(0.5) : x + HK(0.5)), jy = (int)(y < 0 ? y - HK(0.5) : y + HK(0.5));   // nint
-    if (ix >= 0 && ix < nx && jy >= 0 && jy < ny) { col = jy * nx + ix; colflag[col] = 1u; }
+    int d = 0;
+    for (int j = F.ndom - 1; j >= 1; j--)
+      if (x > F.dom[j].xl + F.eps && x < F.dom[j].xr - F.eps && y > F.dom[j].yl + F.eps && y < F.dom[j].yr - F.eps) { d = j; break; }
+    H xg = x, yg = y;
+    if (d > 0) { xg = (x - F.dom[d].xl) * F.dom[d].xres; yg = (y - F.dom[d].yl) * F.dom[d].yres; }
+    const int ix = (int)(xg < 0 ? xg - HK(0.5) : xg + HK(0.5)), jy = (int)(yg < 0 ? yg - HK(0.5) : yg + HK(0.5));   // nint
+    if (ix >= 0 && ix < F.dom[d].nx && jy >= 0 && jy < F.dom[d].ny) { col = F.dom[d].off + jy * F.dom[d].nx + ix; colflag[col] = 1u; }
   }
   pcol[s] = col;
 }
@@ -485,22 +507,23 @@ enum Cst { C_psconv, C_tt2conv, C_td2conv, C_cbmf, C_cbmfold, C_plcl, C_nk, C_ic
 // convmix.f90:149-170 + calcmatrix.f90:56-90 + CONVECT up to its early exits, for every column that holds particles
 template <typename H>
 __global__ void __launch_bounds__(64) k_conv_column_a(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ cst, int nv, const int *__restrict__ act,
-                                                      int nact, const H *__restrict__ cbaseflux, unsigned int *__restrict__ alive) {
+                                                      int nact, unsigned int *__restrict__ alive) {
 #pragma clang fp contract(off)
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= nact) return;
   Scr<H> Sx{vbuf, nullptr, nact, c, nv, 0, 0};
-  const int col = act[c];
-  const size_t n2 = (size_t)F.nx * F.ny;
+  const Dom<H> &D = F.dom[F.domain_of(act[c])];
+  const int col = act[c] - D.off;
+  const size_t n2 = (size_t)D.nx * D.ny;
   const int nuvz = F.nuvz, nl = F.nconvlev;
   const H dt1 = F.dt1, dt2 = F.dt2, dtt = F.dtt;
-  const H psconv = (F.ps[F.m1][col] * dt2 + F.ps[F.m2][col] * dt1) * dtt;
+  const H psconv = (D.ps[F.m1][col] * dt2 + D.ps[F.m2][col] * dt1) * dtt;
   cst[(size_t)C_psconv * nact + c] = psconv;
-  cst[(size_t)C_tt2conv * nact + c] = (F.tt2[F.m1][col] * dt2 + F.tt2[F.m2][col] * dt1) * dtt;
-  cst[(size_t)C_td2conv * nact + c] = (F.td2[F.m1][col] * dt2 + F.td2[F.m2][col] * dt1) * dtt;
+  cst[(size_t)C_tt2conv * nact + c] = (D.tt2[F.m1][col] * dt2 + D.tt2[F.m2][col] * dt1) * dtt;
+  cst[(size_t)C_td2conv * nact + c] = (D.td2[F.m1][col] * dt2 + D.td2[F.m2][col] * dt1) * dtt;
   for (int kz = 1; kz <= nuvz - 1; kz++) {
-    VV(tconv, kz) = (F.tth[F.m1][(size_t)kz * n2 + col] * dt2 + F.tth[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
-    VV(qconv, kz) = (F.qvh[F.m1][(size_t)kz * n2 + col] * dt2 + F.qvh[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
+    VV(tconv, kz) = (D.tth[F.m1][(size_t)kz * n2 + col] * dt2 + D.tth[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
+    VV(qconv, kz) = (D.qvh[F.m1][(size_t)kz * n2 + col] * dt2 + D.qvh[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
   }
   VV(phconv, 1) = psconv;
   for (int kuvz = 2; kuvz <= nuvz; kuvz++) {
@@ -517,7 +540,7 @@ __global__ void __launch_bounds__(64) k_conv_column_a(Fields<H> F, H *__restrict
   VV(phconv_hpa, nl + 1) = VV(phconv, nl + 1) / HK(100.);
   CvState<H> st;
   st.nk = 0; st.icb = 0; st.inb = 0; st.iflag = 0; st.plcl = HK(0.);
-  st.cbmf = cbaseflux[col];
+  st.cbmf = D.cb[col];
   cst[(size_t)C_cbmfold * nact + c] = st.cbmf;
   int dummy = 0;
   const bool go = convect<H, 1>(Sx, nl, F.delt, st, dummy);
@@ -539,7 +562,7 @@ __global__ void k_conv_survivors(const unsigned int *__restrict__ alive, const u
 template <typename H>
 __global__ void __launch_bounds__(64) k_conv_column_b(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, H *__restrict__ cst, int nv, int nact,
                                                       const int *__restrict__ act, const int *__restrict__ surv, int m0, int Bm, int nsurv,
-                                                      H *__restrict__ cbaseflux, int *__restrict__ lconv_out, int *__restrict__ ntop_out) {
+                                                      int *__restrict__ lconv_out, int *__restrict__ ntop_out) {
 #pragma clang fp contract(off)
   const int cm = blockIdx.x * blockDim.x + threadIdx.x;
   if (cm >= Bm || m0 + cm >= nsurv) return;
@@ -605,7 +628,10 @@ __global__ void __launch_bounds__(64) k_conv_column_b(Fields<H> F, H *__restrict
       tvold = tv; tv1 = tv2; pold = pint;
     }
   }
-  cbaseflux[act[c]] = cbmf;
+  {
+    const Dom<H> &D = F.dom[F.domain_of(act[c])];
+    D.cb[act[c] - D.off] = cbmf;
+  }
   lconv_out[c] = lconv;
   ntop_out[c] = lconv ? nconvtop : 0;
 }

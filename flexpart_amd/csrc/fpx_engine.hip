@@ -1282,6 +1282,8 @@ struct EngineBase {
   virtual int upload_conv_fields(int slot, const fpx_conv_fields *f) = 0;
   virtual int convmix(int itime, int64_t *nmoved) = 0;
   virtual int cbaseflux_io(void *host, bool set) = 0;
+  virtual int upload_conv_nest_fields(int nest, int slot, const fpx_conv_fields *f) = 0;
+  virtual int cbaseflux_nest_io(int nest, void *host, bool set) = 0;
   virtual double conv_ms() = 0;
   virtual int checkpoint_write(const char *path, int itime, int numparticlecount) = 0;
   virtual int checkpoint_read(const char *path, int32_t *itime, int64_t *numpart_out, int32_t *numparticlecount) = 0;
@@ -1502,6 +1504,10 @@ struct Engine : EngineBase {
     if (staging) (void)hipFree(staging);
     if (d_sort_tmp) (void)hipFree(d_sort_tmp);
     if (d_sel_tmp) (void)hipFree(d_sel_tmp);
+    if (conv_scr) (void)hipFree(conv_scr);
+    if (conv_scan_tmp) (void)hipFree(conv_scan_tmp);
+    if (conv_alive) (void)hipFree(conv_alive);
+    if (d_sort_rec) (void)hipFree(d_sort_rec);
     if (red_pin) (void)hipHostFree(red_pin);
     if (comm) (void)ncclCommDestroy(comm);
     if (stream) (void)hipStreamDestroy(stream);
@@ -2761,6 +2767,10 @@ struct Engine : EngineBase {
   bool conv_slot[2] = {false, false};
   void *conv_tab[4] = {};                    // akz, bkz, akm, bkm
   void *conv_cb = nullptr;                   // cbaseflux [ny][nx]
+  void *conv_fld_n[kMaxNests][5][2] = {};    // the same five arrays of every nested wind field, compact [nyn][nxn]
+  bool conv_slot_n[kMaxNests][2] = {};
+  void *conv_cb_n[kMaxNests] = {};           // cbasefluxn(:,:,l)
+  size_t conv_ncol_alloc = 0;                // columns (all domains) the per-column arrays are sized for
   int *conv_pcol = nullptr, *conv_act = nullptr, *conv_lconv = nullptr, *conv_ntop = nullptr;
   unsigned int *conv_flag = nullptr, *conv_rank = nullptr;
   unsigned char *conv_draws = nullptr;
@@ -2773,7 +2783,6 @@ struct Engine : EngineBase {
 
   int conv_init(const fpx_conv_config *c) override {
     if (!c || c->struct_bytes != (int32_t)sizeof(fpx_conv_config)) return fail(FPX_ERR_ARG, "conv_init: null or fpx_conv_config size mismatch (ABI)");
-    if (V.numbnests > 0) return fail(FPX_ERR_UNSUPPORTED, "conv_init: convection inside nested wind fields is not implemented");
     if (c->nuvz < 4 || c->nconvlev < 2 || c->nconvlev > c->nuvz - 2) return fail(FPX_ERR_ARG, "conv_init: need 2 <= nconvlev <= nuvz - 2");
     if (!c->akz || !c->bkz || !c->akm || !c->bkm) return fail(FPX_ERR_ARG, "conv_init: akz, bkz, akm, bkm are required");
     if (conv_on) return fail(FPX_ERR_STATE, "conv_init: already initialised");
@@ -2799,8 +2808,7 @@ struct Engine : EngineBase {
       conv_cb = q;
     }
     if ((rc = dalloc(&conv_pcol, (size_t)P.cap)) || (rc = dalloc(&conv_draws, (size_t)P.cap))) return rc;
-    if ((rc = dalloc(&conv_flag, n2)) || (rc = dalloc(&conv_rank, n2)) || (rc = dalloc(&conv_act, n2)) ||
-        (rc = dalloc(&conv_lconv, n2)) || (rc = dalloc(&conv_ntop, n2)) || (rc = dalloc(&conv_nmoved, (size_t)1))) return rc;
+    if ((rc = dalloc(&conv_nmoved, (size_t)1))) return rc;
     {
       unsigned char *q = nullptr;
       if ((rc = dalloc(&q, (size_t)P.cap * hb))) return rc;
@@ -2836,6 +2844,57 @@ struct Engine : EngineBase {
     if (!f || !f->ps || !f->tt2 || !f->td2 || !f->tth || !f->qvh) return fail(FPX_ERR_ARG, "upload_conv_fields: ps, tt2, td2, tth, qvh are required");
     if (f->nuvzmax < conv_nuvz) return fail(FPX_ERR_ARG, "upload_conv_fields: nuvzmax < nuvz");
     return cfg.host_real_bytes == 4 ? upload_conv_fields_t<float>(slot, f) : upload_conv_fields_t<double>(slot, f);
+  }
+
+  template <typename H>
+  int upload_conv_nest_fields_t(int nest, int slot, const fpx_conv_fields *f) {
+    const int l = nest - 1;
+    const int nxn = h_nest[l].nx, nyn = h_nest[l].ny;
+    const size_t n2 = (size_t)nxn * nyn, n2max = (size_t)nest_nxmaxn * nest_nymaxn;
+    int rc;
+    if (!conv_cb_n[l]) {
+      for (int i = 0; i < 5; i++)
+        for (int sl = 0; sl < 2; sl++) {
+          H *q = nullptr;
+          if ((rc = dalloc(&q, i < 3 ? n2 : n2 * conv_nuvz))) return rc;
+          conv_fld_n[l][i][sl] = q;
+        }
+      H *q = nullptr;
+      if ((rc = dalloc(&q, n2))) return rc;
+      HIPCHK(hipMemsetAsync(q, 0, n2 * sizeof(H), stream));
+      conv_cb_n[l] = q;
+    }
+    const void *src[5] = {f->ps, f->tt2, f->td2, f->tth, f->qvh};
+    for (int i = 0; i < 5; i++) {
+      const int nlev = i < 3 ? 1 : conv_nuvz;
+      const size_t bytes = n2max * (size_t)(i < 3 ? 1 : f->nuvzmax) * sizeof(H);
+      if ((rc = ensure_staging(bytes))) return rc;
+      HIPCHK(hipMemcpyAsync(staging, src[i], bytes, hipMemcpyHostToDevice, stream));
+      const long long n = (long long)n2 * nlev;
+      k_conv_pack<H, H><<<(int)((n + kBlock - 1) / kBlock), kBlock, 0, stream>>>((const H *)staging, (H *)conv_fld_n[l][i][slot - 1], nxn, nyn, nlev, nest_nxmaxn, nest_nymaxn);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    conv_slot_n[l][slot - 1] = true;
+    return 0;
+  }
+  int upload_conv_nest_fields(int nest, int slot, const fpx_conv_fields *f) override {
+    if (!conv_on) return fail(FPX_ERR_STATE, "upload_conv_nest_fields: fpx_conv_init first");
+    if (nest < 1 || nest > V.numbnests) return fail(FPX_ERR_ARG, "upload_conv_nest_fields: nest out of range (fpx_nests_init first)");
+    if (slot != 1 && slot != 2) return fail(FPX_ERR_ARG, "upload_conv_nest_fields: slot must be 1 or 2");
+    if (!f || !f->ps || !f->tt2 || !f->td2 || !f->tth || !f->qvh) return fail(FPX_ERR_ARG, "upload_conv_nest_fields: ps, tt2, td2, tth, qvh are required");
+    if (f->nuvzmax < conv_nuvz) return fail(FPX_ERR_ARG, "upload_conv_nest_fields: nuvzmax < nuvz");
+    return cfg.host_real_bytes == 4 ? upload_conv_nest_fields_t<float>(nest, slot, f) : upload_conv_nest_fields_t<double>(nest, slot, f);
+  }
+  int cbaseflux_nest_io(int nest, void *host, bool set) override {
+    if (!conv_on) return fail(FPX_ERR_STATE, "cbaseflux_nest: fpx_conv_init first");
+    if (nest < 1 || nest > V.numbnests || !conv_cb_n[nest - 1]) return fail(FPX_ERR_STATE, "cbaseflux_nest: fpx_upload_conv_nest_fields of this nest first");
+    if (!host) return fail(FPX_ERR_ARG, "cbaseflux_nest: null");
+    const size_t bytes = (size_t)h_nest[nest - 1].nx * h_nest[nest - 1].ny * cfg.host_real_bytes;
+    if (set) HIPCHK(hipMemcpyAsync(conv_cb_n[nest - 1], host, bytes, hipMemcpyHostToDevice, stream));
+    else HIPCHK(hipMemcpyAsync(host, conv_cb_n[nest - 1], bytes, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
   }
 
   int cbaseflux_io(void *host, bool set) override {
@@ -2892,7 +2951,7 @@ struct Engine : EngineBase {
   // replay of the serial stream: particles by particle number, igrid as convmix builds it, the reference's sort2, ran3 for
   // the particles the probe pass found drawing
   template <typename H>
-  int conv_replay(long long n) {
+  int conv_replay(long long n, int ndom, const int *off) {
     std::vector<unsigned char> h_draws((size_t)n);
     std::vector<int> h_pcol((size_t)n);
     std::vector<unsigned int> h_pid((size_t)n);
@@ -2900,22 +2959,28 @@ struct Engine : EngineBase {
     HIPCHK(hipMemcpyAsync(h_pcol.data(), conv_pcol, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(h_pid.data(), P.pid, (size_t)n * sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipStreamSynchronize(stream));
-    std::vector<int> igrid((size_t)n + 1), ipoint((size_t)n + 1);
+    std::vector<int> col_by_pid((size_t)n, -1), igrid((size_t)n + 1), ipoint((size_t)n + 1);
     std::vector<unsigned char> draws_by_pid((size_t)n, 0);
     for (long long s = 0; s < n; s++) {
       const unsigned int p = h_pid[(size_t)s];
       if (p >= (unsigned int)n) return fail(FPX_ERR_STATE, "convmix: particle numbers beyond numpart");
-      igrid[p + 1] = h_pcol[(size_t)s] < 0 ? -1 : 1 + h_pcol[(size_t)s];
+      col_by_pid[p] = h_pcol[(size_t)s];
       draws_by_pid[p] = h_draws[(size_t)s];
     }
-    for (long long p = 1; p <= n; p++) ipoint[(size_t)p] = (int)p;
-    conv_sort2((int)n, igrid.data(), ipoint.data());
     std::vector<H> rn((size_t)n, (H)-1);
-    for (long long k = 1; k <= n; k++) {
-      if (igrid[(size_t)k] == -1) continue;
-      const int p = ipoint[(size_t)k] - 1;
-      if (!draws_by_pid[(size_t)p]) continue;
-      rn[(size_t)p] = sizeof(H) == 4 ? (H)rng4.ran3(rng4.idummy_redist) : (H)rng8.ran3(rng8.idummy_redist);
+    for (int d = 0; d < ndom; d++) {          // the mother grid first, then nest by nest (convmix.f90:139-196, 198-250)
+      for (long long p = 1; p <= n; p++) {
+        const int c = col_by_pid[(size_t)p - 1];
+        igrid[(size_t)p] = (c >= off[d] && c < off[d + 1]) ? 1 + c - off[d] : -1;
+        ipoint[(size_t)p] = (int)p;
+      }
+      conv_sort2((int)n, igrid.data(), ipoint.data());
+      for (long long k = 1; k <= n; k++) {
+        if (igrid[(size_t)k] == -1) continue;
+        const int p = ipoint[(size_t)k] - 1;
+        if (!draws_by_pid[(size_t)p]) continue;
+        rn[(size_t)p] = sizeof(H) == 4 ? (H)rng4.ran3(rng4.idummy_redist) : (H)rng8.ran3(rng8.idummy_redist);
+      }
     }
     HIPCHK(hipMemcpyAsync(conv_rn, rn.data(), (size_t)n * sizeof(H), hipMemcpyHostToDevice, stream));
     HIPCHK(hipStreamSynchronize(stream));
@@ -2928,8 +2993,43 @@ struct Engine : EngineBase {
   template <typename H>
   int convmix_t(int itime, int64_t *nmoved_out) {
     const long long n = numpart;
-    const int nx = cfg.nx, ny = cfg.ny, ncol = nx * ny;
+    const int nx = cfg.nx, ny = cfg.ny;
     const int nv = conv_nuvz + 2;
+    // wind-field domains: the mother grid and the nests (fpx_nests_init); columns numbered through all of them
+    conv::Fields<H> F;
+    int off[conv::kConvMaxDom + 1];
+    F.ndom = 1 + V.numbnests;
+    off[0] = 0;
+    for (int d = 0; d < F.ndom; d++) {
+      conv::Dom<H> &D = F.dom[d];
+      void *(*fld)[2] = d == 0 ? conv_fld : conv_fld_n[d - 1];
+      for (int sl = 0; sl < 2; sl++) {
+        D.ps[sl] = (const H *)fld[0][sl]; D.tt2[sl] = (const H *)fld[1][sl]; D.td2[sl] = (const H *)fld[2][sl];
+        D.tth[sl] = (const H *)fld[3][sl]; D.qvh[sl] = (const H *)fld[4][sl];
+      }
+      D.cb = (H *)(d == 0 ? conv_cb : conv_cb_n[d - 1]);
+      D.nx = d == 0 ? nx : h_nest[d - 1].nx; D.ny = d == 0 ? ny : h_nest[d - 1].ny;
+      D.off = off[d];
+      off[d + 1] = off[d] + D.nx * D.ny;
+      if (d > 0) {
+        const NestDesc<R> &N = h_nest[d - 1];
+        D.xl = (H)N.xl; D.yl = (H)N.yl; D.xr = (H)N.xr; D.yr = (H)N.yr; D.xres = (H)N.xres; D.yres = (H)N.yres;
+      } else { D.xl = D.yl = D.xr = D.yr = (H)0; D.xres = D.yres = (H)1; }
+    }
+    const int ncol = off[F.ndom];
+    F.akz = (const H *)conv_tab[0]; F.bkz = (const H *)conv_tab[1]; F.akm = (const H *)conv_tab[2]; F.bkm = (const H *)conv_tab[3];
+    F.nuvz = conv_nuvz; F.nconvlev = conv_nconvlev;
+    F.m1 = V.m1; F.m2 = V.m2;
+    F.dt1 = (H)(itime - V.memtime0); F.dt2 = (H)(V.memtime1 - itime);
+    F.dtt = (H)1. / (F.dt1 + F.dt2);
+    F.delt = (H)std::abs(cfg.lsynctime);
+    F.eps = (H)cfg.par_nxmax / (H)3.e5;
+    if ((size_t)ncol > conv_ncol_alloc) {
+      int rc2;
+      if ((rc2 = dalloc(&conv_flag, (size_t)ncol)) || (rc2 = dalloc(&conv_rank, (size_t)ncol)) || (rc2 = dalloc(&conv_act, (size_t)ncol)) ||
+          (rc2 = dalloc(&conv_lconv, (size_t)ncol)) || (rc2 = dalloc(&conv_ntop, (size_t)ncol))) return rc2;
+      conv_ncol_alloc = (size_t)ncol;
+    }
     const int nb = (int)((n + kBlock - 1) / kBlock), nbc = (ncol + kBlock - 1) / kBlock;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -2937,7 +3037,7 @@ struct Engine : EngineBase {
     HIPCHK(hipEventRecord(e0, stream));
     HIPCHK(hipMemsetAsync(conv_flag, 0, (size_t)ncol * sizeof(unsigned int), stream));
     HIPCHK(hipMemsetAsync(conv_nmoved, 0, sizeof(unsigned long long), stream));
-    conv::k_conv_mark<R, H><<<nb, kBlock, 0, stream>>>(P.xt, P.yt, P.itra1, n, itime, nx, ny, conv_pcol, conv_flag);
+    conv::k_conv_mark<R, H><<<nb, kBlock, 0, stream>>>(F, P.xt, P.yt, P.itra1, n, itime, conv_pcol, conv_flag);
     HIPCHK(hipGetLastError());
     size_t tb = 0;
     HIPCHK(rocprim::exclusive_scan(nullptr, tb, conv_flag, conv_rank, 0u, (size_t)ncol, rocprim::plus<unsigned int>(), stream));
@@ -2986,21 +3086,10 @@ struct Engine : EngineBase {
     int rc = ensure_scratch(vec_bytes + (size_t)Bm_cap * per_mat);
     if (rc) return rc;
     H *vbuf = (H *)conv_scr, *cst = vbuf + conv::vec_elems_per_column<H>(nv) * (size_t)nact, *mbuf = cst + (size_t)conv::C_COUNT * nact;
-    conv::Fields<H> F;
-    for (int sl = 0; sl < 2; sl++) {
-      F.ps[sl] = (const H *)conv_fld[0][sl]; F.tt2[sl] = (const H *)conv_fld[1][sl]; F.td2[sl] = (const H *)conv_fld[2][sl];
-      F.tth[sl] = (const H *)conv_fld[3][sl]; F.qvh[sl] = (const H *)conv_fld[4][sl];
-    }
-    F.akz = (const H *)conv_tab[0]; F.bkz = (const H *)conv_tab[1]; F.akm = (const H *)conv_tab[2]; F.bkm = (const H *)conv_tab[3];
-    F.nx = nx; F.ny = ny; F.nuvz = conv_nuvz; F.nconvlev = conv_nconvlev;
-    F.m1 = V.m1; F.m2 = V.m2;
-    F.dt1 = (H)(itime - V.memtime0); F.dt2 = (H)(V.memtime1 - itime);
-    F.dtt = (H)1. / (F.dt1 + F.dt2);
-    F.delt = (H)std::abs(cfg.lsynctime);
     const H height_nz = (H)height_host[cfg.nz - 1];
     const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
     const int nba = (nact + 63) / 64;
-    conv::k_conv_column_a<H><<<nba, 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, (const H *)conv_cb, alive);
+    conv::k_conv_column_a<H><<<nba, 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, alive);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(conv_lconv, 0, (size_t)nact * sizeof(int), stream));
     HIPCHK(hipMemsetAsync(conv_ntop, 0, (size_t)nact * sizeof(int), stream));
@@ -3019,7 +3108,7 @@ struct Engine : EngineBase {
       // parity mode: the random numbers come from the shared serial stream in the reference's visiting order, which needs to
       // know who draws -- a probe pass records that, the host replays the stream, then the particles are moved
       for (int m0 = 0; m0 < nsurv; m0 += Bm) {
-        conv::k_conv_column_b<H><<<(Bm + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, (H *)conv_cb, conv_lconv, conv_ntop);
+        conv::k_conv_column_b<H><<<(Bm + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, conv_lconv, conv_ntop);
         HIPCHK(hipGetLastError());
         if (seq) {
           HIPCHK(hipMemsetAsync(conv_draws, 0, (size_t)n, stream));
@@ -3027,7 +3116,7 @@ struct Engine : EngineBase {
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
                                                                           conv_draws, 1, nullptr);
           HIPCHK(hipGetLastError());
-          int rrc = conv_replay<H>(n);
+          int rrc = conv_replay<H>(n, F.ndom, off);
           if (rrc) return rrc;
           conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, nv, nact, alive, srank, m0, Bm, conv_lconv, conv_ntop,
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
@@ -3053,6 +3142,9 @@ struct Engine : EngineBase {
   int convmix(int itime, int64_t *nmoved) override {
     if (!conv_on) return fail(FPX_ERR_STATE, "convmix: fpx_conv_init first");
     if (!conv_slot[0] || !conv_slot[1]) return fail(FPX_ERR_STATE, "convmix: fpx_upload_conv_fields of both slots first");
+    for (int l = 0; l < V.numbnests; l++)
+      if (!conv_slot_n[l][0] || !conv_slot_n[l][1]) return fail(FPX_ERR_STATE, "convmix: fpx_upload_conv_nest_fields of both slots of every nest first");
+    if (1 + V.numbnests > conv::kConvMaxDom) return fail(FPX_ERR_UNSUPPORTED, "convmix: too many nests");
     if (!window_set) return fail(FPX_ERR_STATE, "convmix: fpx_set_windtime first");
     if (!height_set) return fail(FPX_ERR_STATE, "convmix: set_height first");
     if (numpart == 0) { if (nmoved) *nmoved = 0; return 0; }
@@ -3119,6 +3211,13 @@ struct Engine : EngineBase {
     return 0;
   }
   struct CkptRng { HostRng<float> r4; HostRng<double> r8; Ran1 rel; };
+  uint64_t conv_cbase_bytes() const {      // cbaseflux of the mother grid and of every nest that has convection fields
+    if (!conv_on) return 0;
+    uint64_t b = (uint64_t)cfg.nx * cfg.ny * cfg.host_real_bytes;
+    for (int l = 0; l < V.numbnests; l++)
+      if (conv_cb_n[l]) b += (uint64_t)h_nest[l].nx * h_nest[l].ny * cfg.host_real_bytes;
+    return b;
+  }
 
   int checkpoint_write(const char *path, int itime, int numparticlecount) override {
     if (!path) return fail(FPX_ERR_ARG, "checkpoint_write: path is required");
@@ -3135,7 +3234,7 @@ struct Engine : EngineBase {
     h.n_grid3n = Gp.on && Gp.nested ? n_grid3n : 0; h.n_grid2n = Gp.on && Gp.nested ? n_grid2n : 0;
     h.n_receptor = Gp.creceptor ? (uint64_t)Gp.numreceptor * cfg.maxspec : 0;
     h.rng_bytes = sizeof(CkptRng);
-    h.cbase_bytes = conv_on ? (uint64_t)cfg.nx * cfg.ny * cfg.host_real_bytes : 0;
+    h.cbase_bytes = conv_cbase_bytes();
     if (fwrite(&h, sizeof(h), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
     CkptRng rs{rng4, rng8, rel_ran1};
     if (fwrite(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
@@ -3152,7 +3251,11 @@ struct Engine : EngineBase {
     if (h.n_grid3n && ((rc = ckpt_put_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_put_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
                        (rc = ckpt_put_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return rc;
     if (h.n_receptor && (rc = ckpt_put_plain(fh, Gp.creceptor, (size_t)h.n_receptor, buf))) return rc;
-    if (h.cbase_bytes && (rc = ckpt_put_plain(fh, (const unsigned char *)conv_cb, (size_t)h.cbase_bytes, buf))) return rc;
+    if (h.cbase_bytes) {
+      if ((rc = ckpt_put_plain(fh, (const unsigned char *)conv_cb, (size_t)cfg.nx * cfg.ny * cfg.host_real_bytes, buf))) return rc;
+      for (int l = 0; l < V.numbnests; l++)
+        if (conv_cb_n[l] && (rc = ckpt_put_plain(fh, (const unsigned char *)conv_cb_n[l], (size_t)h_nest[l].nx * h_nest[l].ny * cfg.host_real_bytes, buf))) return rc;
+    }
     closer.f = nullptr;
     if (fclose(fh) != 0) return fail(FPX_ERR_ARG, std::string("checkpoint_write: write error on ") + path);
     return 0;
@@ -3174,7 +3277,7 @@ struct Engine : EngineBase {
     const uint64_t nr = Gp.creceptor ? (uint64_t)Gp.numreceptor * cfg.maxspec : 0;
     if (h.n_grid3 != g3 || h.n_grid2 != g2 || h.n_grid3n != g3n || h.n_grid2n != g2n || h.n_receptor != nr)
       return fail(FPX_ERR_STATE, "checkpoint_read: the output grids of the checkpoint are not the ones configured (call fpx_outgrid_init ... first)");
-    if (h.cbase_bytes != (conv_on ? (uint64_t)cfg.nx * cfg.ny * cfg.host_real_bytes : 0))
+    if (h.cbase_bytes != conv_cbase_bytes())
       return fail(FPX_ERR_STATE, "checkpoint_read: the checkpoint was written with (without) convection; call fpx_conv_init first (or not at all)");
     CkptRng rs;
     if (fread(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_read: file too short");
@@ -3201,7 +3304,11 @@ struct Engine : EngineBase {
     if (g3n && ((rc = ckpt_get_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_get_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
                 (rc = ckpt_get_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return rc;
     if (nr && (rc = ckpt_get_plain(fh, Gp.creceptor, (size_t)nr, buf))) return rc;
-    if (h.cbase_bytes && (rc = ckpt_get_plain(fh, (unsigned char *)conv_cb, (size_t)h.cbase_bytes, buf))) return rc;
+    if (h.cbase_bytes) {
+      if ((rc = ckpt_get_plain(fh, (unsigned char *)conv_cb, (size_t)cfg.nx * cfg.ny * cfg.host_real_bytes, buf))) return rc;
+      for (int l = 0; l < V.numbnests; l++)
+        if (conv_cb_n[l] && (rc = ckpt_get_plain(fh, (unsigned char *)conv_cb_n[l], (size_t)h_nest[l].nx * h_nest[l].ny * cfg.host_real_bytes, buf))) return rc;
+    }
     for (bool &v : red_valid) v = false;
     rng4 = rs.r4; rng8 = rs.r8; rel_ran1 = rs.rel;
     step_counter = h.step_counter;
@@ -4137,6 +4244,9 @@ int fpx_conv_init(fpx_handle h, const fpx_conv_config *c) { FPX_GUARD(h); return
 int fpx_upload_conv_fields(fpx_handle h, int32_t slot, const fpx_conv_fields *f) { FPX_GUARD(h); return h->impl->upload_conv_fields(slot, f); }
 int fpx_convmix(fpx_handle h, int32_t itime, int64_t *nmoved) { FPX_GUARD(h); return h->impl->convmix(itime, nmoved); }
 int fpx_convmix_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return FPX_ERR_ARG; *ms = h->impl->conv_ms(); return 0; }
+int fpx_upload_conv_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_conv_fields *f) { FPX_GUARD(h); return h->impl->upload_conv_nest_fields(nest, slot, f); }
+int fpx_get_cbaseflux_nest(fpx_handle h, int32_t nest, void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_nest_io(nest, cb, false); }
+int fpx_set_cbaseflux_nest(fpx_handle h, int32_t nest, const void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_nest_io(nest, (void *)cb, true); }
 int fpx_get_cbaseflux(fpx_handle h, void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_io(cb, false); }
 int fpx_set_cbaseflux(fpx_handle h, const void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_io((void *)cb, true); }
 int fpx_checkpoint_write(fpx_handle h, const char *path, int32_t itime, int32_t numparticlecount) {

@@ -353,6 +353,36 @@ class Engine:
         f.nuvzmax = nuvzmax
         check(self.lib.fpx_upload_conv_fields(self.h, int(slot), C.byref(f)), "fpx_upload_conv_fields")
 
+    def upload_conv_nest_fields(self, nest, slot, ps, tt2, td2, tth, qvh, nuvzmax=None):
+        """The same five arrays of nested wind field `nest` [nyn][nxn] / [nuvz][nyn][nxn] (this mirror declares compact nests:
+        nxmaxn = nxn, nymaxn = nyn)."""
+        from ._lib import FpxConvFields
+        rt = self.hreal
+        nuvz, nyn, nxn = (int(v) for v in np.asarray(tth).shape)
+        nuvzmax = nuvz + 1 if nuvzmax is None else int(nuvzmax)
+        f = FpxConvFields()
+        keep = {}
+        for k, a in (("ps", ps), ("tt2", tt2), ("td2", td2)):
+            b = np.ascontiguousarray(np.asarray(a).astype(rt))
+            keep[k] = b
+            setattr(f, k, b.ctypes.data)
+        for k, a in (("tth", tth), ("qvh", qvh)):
+            b = np.zeros((nuvzmax, nyn, nxn), rt)
+            b[:nuvz] = a
+            keep[k] = b
+            setattr(f, k, b.ctypes.data)
+        f.nuvzmax = nuvzmax
+        check(self.lib.fpx_upload_conv_nest_fields(self.h, int(nest), int(slot), C.byref(f)), "fpx_upload_conv_nest_fields")
+
+    def cbaseflux_nest(self, nest, shape, new=None):
+        a = np.zeros(shape, self.hreal)
+        if new is not None:
+            a[:] = new
+            check(self.lib.fpx_set_cbaseflux_nest(self.h, int(nest), a.ctypes.data), "fpx_set_cbaseflux_nest")
+            return None
+        check(self.lib.fpx_get_cbaseflux_nest(self.h, int(nest), a.ctypes.data), "fpx_get_cbaseflux_nest")
+        return a.astype(np.float64)
+
     def convmix(self, itime=None):
         """fpx_convmix: -> number of particles whose height was set; .convmix_device_ms holds the device time."""
         n = C.c_int64(0)

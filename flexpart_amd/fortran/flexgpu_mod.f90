@@ -23,7 +23,7 @@ module flexgpu_mod
   use xmass_mod, only: xmasssave
   use outg_mod, only: outheight, area, volume
   use unc_mod, only: gridunc, drygridunc, wetgridunc, griduncn, drygriduncn, wetgriduncn
-  use conv_mod, only: nconvlev, cbaseflux
+  use conv_mod, only: nconvlev, cbaseflux, cbasefluxn
   implicit none
   private
   public :: fpx_step_stats, flexgpu_init, flexgpu_finalize, flexgpu_upload_fields, &
@@ -37,7 +37,8 @@ module flexgpu_mod
             flexgpu_checkpoint_write, flexgpu_checkpoint_read, &
             flexgpu_conv_init, flexgpu_upload_conv_fields, flexgpu_convmix, flexgpu_cbaseflux
 #ifdef FLEXGPU_NESTS
-  public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests
+  public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests, &
+            flexgpu_upload_conv_nest_fields, flexgpu_cbaseflux_nests
 #endif
 
   integer, parameter :: FPX_MAXSPEC = 5
@@ -248,6 +249,22 @@ module flexgpu_mod
       integer(c_int32_t), value :: itime
       type(c_ptr), value :: nmoved
     end function fpx_convmix
+    integer(c_int) function fpx_upload_conv_nest_fields(h, nest, slot, f) bind(C, name='fpx_upload_conv_nest_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_conv_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: nest, slot
+      type(fpx_conv_fields), intent(in) :: f
+    end function fpx_upload_conv_nest_fields
+    integer(c_int) function fpx_get_cbaseflux_nest(h, nest, cb) bind(C, name='fpx_get_cbaseflux_nest')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, cb
+      integer(c_int32_t), value :: nest
+    end function fpx_get_cbaseflux_nest
+    integer(c_int) function fpx_set_cbaseflux_nest(h, nest, cb) bind(C, name='fpx_set_cbaseflux_nest')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, cb
+      integer(c_int32_t), value :: nest
+    end function fpx_set_cbaseflux_nest
     integer(c_int) function fpx_get_cbaseflux(h, cb) bind(C, name='fpx_get_cbaseflux')
       import :: c_ptr, c_int
       type(c_ptr), value :: h, cb
@@ -841,6 +858,44 @@ contains
     integer, intent(out) :: ierr
     call flexgpu_upload_nests(ierr, geometry_only=.true.)
   end subroutine flexgpu_nests_init
+
+  ! convection inside nested wind fields (convmix.f90:198-250): psn, tt2n, td2n, tthn, qvhn of slot n of every nest, after
+  ! readwind_nests filled it and after flexgpu_nests_init / flexgpu_conv_init
+  subroutine flexgpu_upload_conv_nest_fields(n, ierr)
+    integer, intent(in) :: n
+    integer, intent(out) :: ierr
+    type(fpx_conv_fields) :: f
+    integer :: l
+    ierr = 0
+    do l = 1, numbnests
+      f%ps = loc_r(psn(0,0,1,n,l)); f%tt2 = loc_r(tt2n(0,0,1,n,l)); f%td2 = loc_r(td2n(0,0,1,n,l))
+      f%tth = loc_r(tthn(0:,0,1,n,l)); f%qvh = loc_r(qvhn(0:,0,1,n,l))
+      f%nuvzmax = nuvzmax; f%reserved = 0
+      ierr = fpx_upload_conv_nest_fields(flexgpu_handle, int(l, c_int32_t), int(n, c_int32_t), f)
+      if (ierr /= 0) return
+    end do
+  end subroutine flexgpu_upload_conv_nest_fields
+
+  ! conv_mod cbasefluxn(0:nxmaxn-1,0:nymaxn-1,l) <-> the engine's nest fields
+  subroutine flexgpu_cbaseflux_nests(set, ierr)
+    logical, intent(in) :: set
+    integer, intent(out) :: ierr
+    real, allocatable, target :: buf(:,:)
+    integer :: l
+    ierr = 0
+    do l = 1, numbnests
+      allocate(buf(0:nxn(l)-1,0:nyn(l)-1))
+      if (set) then
+        buf = cbasefluxn(0:nxn(l)-1,0:nyn(l)-1,l)
+        ierr = fpx_set_cbaseflux_nest(flexgpu_handle, int(l, c_int32_t), c_loc(buf))
+      else
+        ierr = fpx_get_cbaseflux_nest(flexgpu_handle, int(l, c_int32_t), c_loc(buf))
+        if (ierr == 0) cbasefluxn(0:nxn(l)-1,0:nyn(l)-1,l) = buf
+      end if
+      deallocate(buf)
+      if (ierr /= 0) return
+    end do
+  end subroutine flexgpu_cbaseflux_nests
 
   ! Replaces `call verttransform_nests(n,uuhn,vvhn,wwhn,pvhn)` (getfields.f90:133,168,184) and the upload of slot n of
   ! every nest; writeback as in flexgpu_verttransform (uun ... drhodzn of slot n).

@@ -715,13 +715,14 @@ def calcpar_inputs(m, lsubgrid=1):
 # --------------------------------------------------------------------------
 # convective mixing (convmix.f90): soundings with and without CAPE
 # --------------------------------------------------------------------------
-def convection_case(nx=24, ny=16, nuvz=46, n=4000, ncalls=3, ldirect=1, lsynctime=900, seed=11):
+def convection_case(nx=24, ny=16, nuvz=46, n=4000, ncalls=3, ldirect=1, lsynctime=900, seed=11, nest=False):
     """ECMWF-shaped input of the convection scheme on a small grid: hybrid half levels akm, bkm (akm(1) = surface) with
     the full levels akz, bkz between them (level 1 = surface), two time slots of ps, tt2, td2, tth, qvh [2][nuvz][ny][nx]
     whose soundings range from warm, moist and conditionally unstable (deep convection: most of the matrix is used)
     over shallow and marginal cases to dry or cold columns in which CONVECT leaves through each of its early exits;
     `n` particles between the ground and 16 km, a tenth of them not due, `ncalls` consecutive calls one lsynctime apart
-    (the cloud-base mass flux cbaseflux relaxes from call to call)."""
+    (the cloud-base mass flux cbaseflux relaxes from call to call).  nest=True adds one nested wind field of twice the
+    resolution over the middle of the domain with soundings of its own (a wrong grid choice shows) and its own mass flux."""
     per = nx
     i = np.arange(nx, dtype=np.int64)[None, None, :]
     j = np.arange(ny, dtype=np.int64)[None, :, None]
@@ -734,26 +735,43 @@ def convection_case(nx=24, ny=16, nuvz=46, n=4000, ncalls=3, ldirect=1, lsynctim
     akz = np.concatenate([[0.0], 0.5 * (akm[:-1] + akm[1:])])
     bkz = np.concatenate([[1.0], 0.5 * (bkm[:-1] + bkm[1:])])
     out = dict(akz=akz, bkz=bkz, akm=akm, bkm=bkm)
-    slots = {}
-    for slot in range(2):
-        ii = i + 3 * slot
-        warm = 0.5 + 0.5 * _wave(ii[0] + 2 * j[0], per)                  # 0 ... 1: cold/dry ... warm/moist
-        ps = 101300.0 + 600.0 * _wave(2 * ii[0] + j[0], per) - 14000.0 * np.maximum(0.0, _wave(3 * ii[0] + 5 * j[0], 2 * per)) ** 3
-        p = akz[:, None, None] + bkz[:, None, None] * ps[None]
-        z = -7600.0 * np.log(p / ps[None])
-        tsfc = 271.0 + 31.0 * warm + 0.0 * ps
-        lapse = 0.0055 + 0.0015 * warm
-        tth = np.maximum(tsfc[None] - lapse[None] * z, 198.0 + 8.0 * warm[None]) + 0.4 * _wave(ii + j + 3 * np.arange(nuvz)[:, None, None], per)
-        rh = (0.25 + 0.65 * warm[None]) * np.exp(-z / (5000.0 + 4000.0 * warm[None])) + 0.05
-        tc = tth - 273.15
-        es = 611.2 * np.exp(17.67 * tc / (tc + 243.5))
-        qs = 0.622 * es / np.maximum(p - 0.378 * es, 1.0)
-        qvh = np.minimum(rh, 0.98) * qs
-        tt2 = tth[0] + 0.6
-        td2 = tt2 - (2.0 + 14.0 * (1.0 - warm))
-        slots[slot] = (ps, tt2, td2, tth, qvh)
-    for idx, key in enumerate(("ps", "tt2", "td2", "tth", "qvh")):
-        out[key] = np.stack([slots[0][idx], slots[1][idx]])
+    def soundings(gnx, gny, shift, scale):
+        """ps, tt2, td2 [2][gny][gnx], tth, qvh [2][nuvz][gny][gnx]; `scale` grid cells of this grid per mother cell."""
+        gi = np.arange(gnx, dtype=np.int64)[None, None, :]
+        gj = np.arange(gny, dtype=np.int64)[None, :, None]
+        gper = per * scale
+        res = {}
+        for slot in range(2):
+            ii = gi + 3 * slot * scale + shift
+            warm = 0.5 + 0.5 * _wave(ii[0] + 2 * gj[0], gper)            # 0 ... 1: cold/dry ... warm/moist
+            ps = 101300.0 + 600.0 * _wave(2 * ii[0] + gj[0], gper) - 14000.0 * np.maximum(0.0, _wave(3 * ii[0] + 5 * gj[0], 2 * gper)) ** 3
+            p = akz[:, None, None] + bkz[:, None, None] * ps[None]
+            z = -7600.0 * np.log(p / ps[None])
+            tsfc = 271.0 + 31.0 * warm + 0.0 * ps
+            lapse = 0.0055 + 0.0015 * warm
+            tth = np.maximum(tsfc[None] - lapse[None] * z, 198.0 + 8.0 * warm[None]) + 0.4 * _wave(ii + gj + 3 * np.arange(nuvz)[:, None, None], gper)
+            rh = (0.25 + 0.65 * warm[None]) * np.exp(-z / (5000.0 + 4000.0 * warm[None])) + 0.05
+            tc = tth - 273.15
+            es = 611.2 * np.exp(17.67 * tc / (tc + 243.5))
+            qs = 0.622 * es / np.maximum(p - 0.378 * es, 1.0)
+            qvh = np.minimum(rh, 0.98) * qs
+            tt2 = tth[0] + 0.6
+            td2 = tt2 - (2.0 + 14.0 * (1.0 - warm))
+            res[slot] = (ps, tt2, td2, tth, qvh)
+        return {key: np.stack([res[0][idx], res[1][idx]]) for idx, key in enumerate(("ps", "tt2", "td2", "tth", "qvh"))}
+
+    out.update(soundings(nx, ny, 0, 1))
+    if nest:
+        ix0, jy0, ix1, jy1, fac = nx // 4, ny // 4, (2 * nx) // 3, (2 * ny) // 3, 2
+        nxn, nyn = (ix1 - ix0) * fac + 1, (jy1 - jy0) * fac + 1
+        sn = soundings(nxn, nyn, 5, fac)
+        out.update({k + "n": v for k, v in sn.items()})
+        gi = np.arange(nxn, dtype=np.int64)[None, :]
+        gj = np.arange(nyn, dtype=np.int64)[:, None]
+        warmn = 0.5 + 0.5 * _wave(gi + 5 + 2 * gj, per * fac)
+        # xln, yln, xrn, yrn in mother grid units, xresoln, yresoln (gridcheck_nests.f90)
+        out.update(nest=np.array([nxn, nyn], np.int32), nestgeom=np.array([ix0, jy0, ix1, jy1, fac, fac], np.float64), par_nxmax=721,
+                   cbasefluxn=np.where(warmn > 0.5, 0.1 * warmn ** 2, 0.0))
     # a run in progress: the cloud-base mass flux of the warm columns has built up (it starts from zero in others)
     warm0 = 0.5 + 0.5 * _wave(i[0] + 2 * j[0], per)
     cb0 = np.where(warm0 > 0.55, 0.12 * warm0 ** 2, 0.0)

@@ -274,8 +274,10 @@ int fpx_readpartpositions(fpx_handle h, const char *path, const fpx_restart *r,
  *   the shared generator at the first call) replayed by the host in the order of the reference's sort2 in the parity
  *   mode FPX_RNG_TABLE_SEQ; one counter-generator draw per particle and step otherwise.
  * fpx_get_cbaseflux / fpx_set_cbaseflux: the mass-flux field, compact [ny][nx] in the host's real kind (restart files).
- * Not covered: particles inside nested wind fields (cbasefluxn, convmix.f90:198-250) -- refused when nests are set;
- * the flux diagnostics of calcfluxes (iflux = 1). */
+ * Nested wind fields (convmix.f90:100-119,198-250; after fpx_nests_init): a particle inside a nest takes the nest's columns,
+ *   soundings and mass-flux field cbasefluxn(:,:,l); fpx_upload_conv_nest_fields(nest, slot, ...) with the strides nxmaxn,
+ *   nymaxn of fpx_nests_init is then required for every nest, fpx_get/set_cbaseflux_nest move [nyn][nxn].
+ * Not covered: the flux diagnostics of calcfluxes (iflux = 1). */
 typedef struct {
   int32_t struct_bytes;
   int32_t nuvz;              /* com_mod nuvz                                              */
@@ -294,6 +296,9 @@ int fpx_conv_init(fpx_handle h, const fpx_conv_config *c);
 int fpx_upload_conv_fields(fpx_handle h, int32_t slot, const fpx_conv_fields *f);
 int fpx_convmix(fpx_handle h, int32_t itime, int64_t *nmoved);
 int fpx_convmix_time(fpx_handle h, double *ms);
+int fpx_upload_conv_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_conv_fields *f);
+int fpx_get_cbaseflux_nest(fpx_handle h, int32_t nest, void *cbasefluxn);
+int fpx_set_cbaseflux_nest(fpx_handle h, int32_t nest, const void *cbasefluxn);
 int fpx_get_cbaseflux(fpx_handle h, void *cbaseflux);
 int fpx_set_cbaseflux(fpx_handle h, const void *cbaseflux);
 /* ---- lossless checkpoint (SURVEY section 8 f, item 4, last clause) -----------------------------

@@ -198,7 +198,7 @@ build_conv() {
   local flags="$*"
   local obj="$OUT/obj_$kind"
   ( cd "$obj"
-    for s in conv_mod convect43c redist sort2 qvsat ew; do
+    for s in conv_mod convect43c redist sort2 qvsat ew caldate juldate; do
       [ "$obj/$s.o" -nt "$REF/$s.f90" ] || "$FC" -c -cpp -O2 -mcmodel=medium $flags "$REF/$s.f90" -o "$s.o"
     done
     "$FC" -c -cpp -O2 -mcmodel=medium $flags "$HERE/ref_conv_driver.f90" -o ref_conv_driver.o
@@ -219,8 +219,10 @@ build_co r4      # (with -fdefault-real-8 concoutput.f90 itself does not compile
 # par_mod_meteoswiss.f90 (nxmax=721, maxnests=1, nxmaxn=571, nymaxn=301) enables the *_nests path
 build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
 build_vt r8n -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
+build_conv r8n -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
 # ... and in the reference's own precision (BASELINE config 5: nests + deposition in f32)
 build_one r4n par_mod_meteoswiss.f90 -DFLEXREF_NESTS -DFLEXGPU_NESTS
+build_conv r4n -DFLEXREF_NESTS -DFLEXGPU_NESTS
 # several age classes / uncertainty classes (see build_one)
 FLEXREF_CLASSES="4 3" build_one r4c par_mod.f90
 FLEXREF_CLASSES="4 3" build_one r8c par_mod.f90 -fdefault-real-8

@@ -718,6 +718,12 @@ typedef struct {
   int32_t ran3_seeded;                          /* in/out: the shared stream is already initialised (second call) */
   int32_t state_words[60];                      /* in/out: ma[1..55], inext, inextp, iff, iseed */
   int32_t status;
+  /* one nested wind field (convmix.f90:100-119,198-250): grid, corners and resolution factors in mother grid units */
+  int32_t nest_on, nxn, nyn, pad_;
+  double xln, yln, xrn, yrn, xresoln, yresoln, eps;   /* eps = nxmax/3.e5 of the build (convmix.f90:79) */
+  const double *psn, *tt2n, *td2n;              /* [2][nyn][nxn] */
+  const double *tthn, *qvhn;                    /* [2][nuvz][nyn][nxn] */
+  double *cbasefluxn;                           /* [nyn][nxn], in/out */
 } cvo_args;
 
 static int cvo_nint(double x) { return (int)(x < 0 ? x - 0.5 : x + 0.5); }
@@ -729,7 +735,7 @@ void cvo_convmix(cvo_args *A) {
   int *igrid = (int *)malloc((n + 1) * sizeof(int)), *ipoint = (int *)malloc((n + 1) * sizeof(int));
   real *akz = (real *)malloc((nuvz + 1) * sizeof(real)), *bkz = (real *)malloc((nuvz + 1) * sizeof(real));
   real *akm = (real *)malloc((nuvz + 1) * sizeof(real)), *bkm = (real *)malloc((nuvz + 1) * sizeof(real));
-  const size_t n2 = (size_t)nx * ny, n3 = n2 * nuvz;
+  const size_t n2 = (size_t)nx * ny;
   real dt1, dt2, dtt, delt;
   int lconv = 0, ktop = 0, igrold, igr, ix = 0, jy = 0, kz;
   long ipart, kpart;
@@ -747,62 +753,89 @@ void cvo_convmix(cvo_args *A) {
   dtt = K(1.) / (dt1 + dt2);
   delt = (real)abs(A->lsynctime);
   if (n <= 0) goto done;
-  for (ipart = 1; ipart <= n; ipart++) {
-    igrid[ipart] = -1;
-    ipoint[ipart] = (int)ipart;
-    if (A->rn) A->rn[ipart - 1] = -1.0;
-    if (A->itra1[ipart - 1] != A->itime) continue;
-    {
-      /* convmix.f90:100-101: x = xtra1(ipart) into a default real */
-      const real x = (real)A->xtra1[ipart - 1], y = (real)A->ytra1[ipart - 1];
-      ix = cvo_nint((double)x);
-      jy = cvo_nint((double)y);
-      igrid[ipart] = 1 + jy * nx + ix;
-    }
-  }
-  if (A->lconv_col) for (size_t c = 0; c < n2; c++) A->lconv_col[c] = -1;
-  cvo_sort2((int)n, igrid, ipoint);
-  igrold = -1;
-  for (kpart = 1; kpart <= n; kpart++) {
-    igr = igrid[kpart];
-    if (igr == -1) continue;
-    ipart = ipoint[kpart];
-    if (igr != igrold) {
-      jy = (igr - 1) / nx;
-      ix = igr - jy * nx - 1;
+  {
+    int *igridn = (int *)malloc((n + 1) * sizeof(int));
+    for (ipart = 1; ipart <= n; ipart++) {
+      igrid[ipart] = -1;
+      igridn[ipart] = -1;
+      ipoint[ipart] = (int)ipart;
+      if (A->rn) A->rn[ipart - 1] = -1.0;
+      if (A->itra1[ipart - 1] != A->itime) continue;
       {
-        const size_t c = (size_t)jy * nx + ix;
-        S->psconv = ((real)A->ps[c] * dt2 + (real)A->ps[n2 + c] * dt1) * dtt;
-        S->tt2conv = ((real)A->tt2[c] * dt2 + (real)A->tt2[n2 + c] * dt1) * dtt;
-        S->td2conv = ((real)A->td2[c] * dt2 + (real)A->td2[n2 + c] * dt1) * dtt;
-        for (kz = 1; kz <= nuvz - 1; kz++) {
-          S->tconv[kz] = ((real)A->tth[(size_t)kz * n2 + c] * dt2 + (real)A->tth[n3 + (size_t)kz * n2 + c] * dt1) * dtt;
-          S->qconv[kz] = ((real)A->qvh[(size_t)kz * n2 + c] * dt2 + (real)A->qvh[n3 + (size_t)kz * n2 + c] * dt1) * dtt;
+        /* convmix.f90:100-135: x = xtra1(ipart) into a default real; the nest test with eps (ECMWF input) */
+        const real x = (real)A->xtra1[ipart - 1], y = (real)A->ytra1[ipart - 1];
+        int ngrid = 0;
+        if (A->nest_on) {
+          const real eps = (real)A->eps;
+          if (x > (real)A->xln + eps && x < (real)A->xrn - eps && y > (real)A->yln + eps && y < (real)A->yrn - eps) ngrid = 1;
         }
-        {
-          real cb = (real)A->cbaseflux[c];
-          lconv = cvo_calcmatrix(S, nuvz, akz, bkz, akm, bkm, delt, &cb);
-          A->cbaseflux[c] = (double)cb;
-        }
-        if (A->lconv_col) A->lconv_col[c] = lconv;
-        if (A->nconvtop_col) A->nconvtop_col[c] = lconv ? S->nconvtop : 0;
-        if (lconv && A->fmassfrac_col && A->fm_count < A->fm_cap) {
-          const int nl = S->nconvlev;
-          double *dst = A->fmassfrac_col + (size_t)A->fm_count * nl * nl;
-          for (int kk = 1; kk <= nl; kk++)
-            for (int k = 1; k <= nl; k++) dst[(size_t)(kk - 1) * nl + (k - 1)] = (k <= S->nconvtop && kk <= S->nconvtop) ? (double)A2(S->fmassfrac, k, kk) : 0.0;
-          A->fm_col_id[A->fm_count++] = (int32_t)c;
+        if (ngrid > 0) {
+          const real xtn = (x - (real)A->xln) * (real)A->xresoln, ytn = (y - (real)A->yln) * (real)A->yresoln;
+          ix = cvo_nint((double)xtn);
+          jy = cvo_nint((double)ytn);
+          igridn[ipart] = 1 + jy * A->nxn + ix;
+        } else {
+          ix = cvo_nint((double)x);
+          jy = cvo_nint((double)y);
+          igrid[ipart] = 1 + jy * nx + ix;
         }
       }
-      igrold = igr;
-      ktop = 0;
     }
-    if (lconv) {
-      real zt = (real)A->ztra1[ipart - 1], rn = K(-1.);
-      const int drew = cvo_redist(S, &zt, &ktop, A->ldirect, A->lsynctime, (real)A->height_nz, &rn);
-      A->ztra1[ipart - 1] = (double)zt;
-      if (A->rn && drew) A->rn[ipart - 1] = (double)rn;
+    if (A->lconv_col) for (size_t c = 0; c < n2; c++) A->lconv_col[c] = -1;
+    for (int pass = 0; pass <= (A->nest_on ? 1 : 0); pass++) {
+      const int gnx = pass ? A->nxn : nx, gny = pass ? A->nyn : ny;
+      const size_t g2 = (size_t)gnx * gny, g3 = g2 * nuvz;
+      const double *ps = pass ? A->psn : A->ps, *tt2 = pass ? A->tt2n : A->tt2, *td2 = pass ? A->td2n : A->td2;
+      const double *tth = pass ? A->tthn : A->tth, *qvh = pass ? A->qvhn : A->qvh;
+      double *cbf = pass ? A->cbasefluxn : A->cbaseflux;
+      if (pass) for (ipart = 1; ipart <= n; ipart++) { ipoint[ipart] = (int)ipart; igrid[ipart] = igridn[ipart]; }   /* :199-203 */
+      cvo_sort2((int)n, igrid, ipoint);
+      igrold = -1;
+      for (kpart = 1; kpart <= n; kpart++) {
+        igr = igrid[kpart];
+        if (igr == -1) continue;
+        ipart = ipoint[kpart];
+        if (igr != igrold) {
+          jy = (igr - 1) / gnx;
+          ix = igr - jy * gnx - 1;
+          {
+            const size_t c = (size_t)jy * gnx + ix;
+            S->psconv = ((real)ps[c] * dt2 + (real)ps[g2 + c] * dt1) * dtt;
+            S->tt2conv = ((real)tt2[c] * dt2 + (real)tt2[g2 + c] * dt1) * dtt;
+            S->td2conv = ((real)td2[c] * dt2 + (real)td2[g2 + c] * dt1) * dtt;
+            for (kz = 1; kz <= nuvz - 1; kz++) {
+              S->tconv[kz] = ((real)tth[(size_t)kz * g2 + c] * dt2 + (real)tth[g3 + (size_t)kz * g2 + c] * dt1) * dtt;
+              S->qconv[kz] = ((real)qvh[(size_t)kz * g2 + c] * dt2 + (real)qvh[g3 + (size_t)kz * g2 + c] * dt1) * dtt;
+            }
+            {
+              real cb = (real)cbf[c];
+              lconv = cvo_calcmatrix(S, nuvz, akz, bkz, akm, bkm, delt, &cb);
+              cbf[c] = (double)cb;
+            }
+            if (!pass) {
+              if (A->lconv_col) A->lconv_col[c] = lconv;
+              if (A->nconvtop_col) A->nconvtop_col[c] = lconv ? S->nconvtop : 0;
+              if (lconv && A->fmassfrac_col && A->fm_count < A->fm_cap) {
+                const int nl = S->nconvlev;
+                double *dst = A->fmassfrac_col + (size_t)A->fm_count * nl * nl;
+                for (int kk = 1; kk <= nl; kk++)
+                  for (int k = 1; k <= nl; k++) dst[(size_t)(kk - 1) * nl + (k - 1)] = (k <= S->nconvtop && kk <= S->nconvtop) ? (double)A2(S->fmassfrac, k, kk) : 0.0;
+                A->fm_col_id[A->fm_count++] = (int32_t)c;
+              }
+            }
+          }
+          igrold = igr;
+          ktop = 0;
+        }
+        if (lconv) {
+          real zt = (real)A->ztra1[ipart - 1], rn = K(-1.);
+          const int drew = cvo_redist(S, &zt, &ktop, A->ldirect, A->lsynctime, (real)A->height_nz, &rn);
+          A->ztra1[ipart - 1] = (double)zt;
+          if (A->rn && drew) A->rn[ipart - 1] = (double)rn;
+        }
+      }
     }
+    free(igridn);
   }
 done:
   for (kz = 1; kz <= 55; kz++) A->state_words[kz] = S->ma[kz];

@@ -686,7 +686,11 @@ class _CvoArgs(C.Structure):
                 ("xtra1", C.c_void_p), ("ytra1", C.c_void_p), ("ztra1", C.c_void_p), ("itra1", C.c_void_p),
                 ("rn", C.c_void_p), ("lconv_col", C.c_void_p), ("nconvtop_col", C.c_void_p), ("fmassfrac_col", C.c_void_p),
                 ("fm_col_id", C.c_void_p), ("fm_cap", C.c_int32), ("fm_count", C.c_int32), ("ran3_seeded", C.c_int32),
-                ("state_words", C.c_int32 * 60), ("status", C.c_int32)]
+                ("state_words", C.c_int32 * 60), ("status", C.c_int32),
+                ("nest_on", C.c_int32), ("nxn", C.c_int32), ("nyn", C.c_int32), ("pad_", C.c_int32),
+                ("xln", C.c_double), ("yln", C.c_double), ("xrn", C.c_double), ("yrn", C.c_double), ("xresoln", C.c_double), ("yresoln", C.c_double),
+                ("eps", C.c_double), ("psn", C.c_void_p), ("tt2n", C.c_void_p), ("td2n", C.c_void_p), ("tthn", C.c_void_p), ("qvhn", C.c_void_p),
+                ("cbasefluxn", C.c_void_p)]
 
 
 def conv_oracle(cs, kind="r8", fm_cap=8):
@@ -713,6 +717,17 @@ def conv_oracle(cs, kind="r8", fm_cap=8):
     a.ztra1 = z.ctypes.data
     a.fm_cap = fm_cap
     a.ran3_seeded = 0
+    cbn = None
+    if "nest" in cs:
+        a.nest_on = 1
+        a.nxn, a.nyn = (int(v) for v in cs["nest"])
+        a.xln, a.yln, a.xrn, a.yrn, a.xresoln, a.yresoln = (float(rt(v)) for v in cs["nestgeom"])
+        a.eps = float(rt(rt(cs["par_nxmax"]) / rt(3.e5)))
+        for k in ("psn", "tt2n", "td2n", "tthn", "qvhn"):
+            keep[k] = _f64(cs[k])
+            setattr(a, k, keep[k].ctypes.data)
+        cbn = _f64(cs["cbasefluxn"]).astype(rt).astype(np.float64)
+        a.cbasefluxn = cbn.ctypes.data
     out = []
     for ic, itime in enumerate(int(t) for t in cs["itimes"]):
         itra1 = np.where(np.asarray(cs["due"])[:, ic], itime, itime + 12345).astype(np.int32)
@@ -725,4 +740,6 @@ def conv_oracle(cs, kind="r8", fm_cap=8):
         a.fmassfrac_col, a.fm_col_id = fm.ctypes.data, fid.ctypes.data
         lib.cvo_convmix(C.byref(a))
         out.append(dict(ztra1=z.copy(), cbaseflux=cb.copy(), lconv=lc, nconvtop=nt, rn=rn, fmassfrac=fm, fm_col=fid, fm_count=int(a.fm_count)))
+        if cbn is not None:
+            out[-1]["cbasefluxn"] = cbn.copy()
     return out

@@ -20,6 +20,14 @@ program convref
   implicit none
   character(len=512) :: fin, fout, arg3, gmsg
   integer :: use_gpu, gerr
+  integer(kind=4) :: nest_on, nxnl, nynl
+  real(kind=8) :: ngeom(6)
+  real(kind=8), allocatable :: psn8(:,:,:), tt2n8(:,:,:), td2n8(:,:,:), tthn8(:,:,:,:), qvhn8(:,:,:,:), cbn8(:,:)
+  integer, allocatable :: igridn(:)
+  real, allocatable :: cbln(:,:)
+  real :: xtn, ytn
+  real, parameter :: epsn = nxmax / 3.e5
+  integer :: ngrid, pass, gnx
   integer(kind=4) :: hdr(12)
   integer :: nxl, nyl, nuvzl, ncalls, fmcap, n, ic, i, j, k, kk
   real(kind=8) :: hnz
@@ -55,6 +63,21 @@ program convref
   allocate(itimes(ncalls), due(n,ncalls), lconvcol(nxl,nyl), ntopcol(nxl,nyl), fmcol(fmcap), fm8(nconvlev,nconvlev,fmcap))
   allocate(igrid(n), ipoint(n), cbl(nxl,nyl))
   read(31) akz8, bkz8, akm8, bkm8, ps8, tt28, td28, tth8, qvh8, cb8, x8, y8, z8, itimes, due
+  nest_on = 0
+  read(31, iostat=i) nest_on
+  if (i /= 0) nest_on = 0
+  allocate(igridn(n))
+  if (nest_on == 1) then
+    read(31) nxnl, nynl
+    read(31) ngeom
+    allocate(psn8(nxnl,nynl,2), tt2n8(nxnl,nynl,2), td2n8(nxnl,nynl,2), tthn8(nxnl,nynl,nuvzl,2), qvhn8(nxnl,nynl,nuvzl,2), cbn8(nxnl,nynl), cbln(nxnl,nynl))
+    read(31) psn8, tt2n8, td2n8, tthn8, qvhn8, cbn8
+    cbln = real(cbn8)
+#ifndef FLEXREF_NESTS
+    print *, 'convref: this build has no nests (par_mod maxnests = 0)'
+    stop 2
+#endif
+  end if
   close(31)
   nuvz = nuvzl
   do k = 1, nuvzl
@@ -130,14 +153,37 @@ program convref
     ! convmix.f90:92-135 (mother grid)
     do ipart = 1, n
       igrid(ipart) = -1
+      igridn(ipart) = -1
       ipoint(ipart) = ipart
       if (due(ipart, ic) == 0) cycle
       x = xtra1(ipart)
       y = ytra1(ipart)
-      ix = nint(x)
-      jy = nint(y)
-      igrid(ipart) = 1 + jy * nxl + ix
+      ngrid = 0
+      ! convmix.f90:104-111 (ECMWF input: with eps)
+      if (nest_on == 1) then
+        if (x > real(ngeom(1)) + epsn .and. x < real(ngeom(3)) - epsn .and. y > real(ngeom(2)) + epsn .and. y < real(ngeom(4)) - epsn) ngrid = 1
+      end if
+      if (ngrid > 0) then
+        xtn = (x - real(ngeom(1))) * real(ngeom(5))
+        ytn = (y - real(ngeom(2))) * real(ngeom(6))
+        ix = nint(xtn)
+        jy = nint(ytn)
+        igridn(ipart) = 1 + jy * nxnl + ix
+      else
+        ix = nint(x)
+        jy = nint(y)
+        igrid(ipart) = 1 + jy * nxl + ix
+      end if
     end do
+    do pass = 0, nest_on
+    gnx = nxl
+    if (pass == 1) then      ! convmix.f90:198-203
+      gnx = nxnl
+      do ipart = 1, n
+        ipoint(ipart) = ipart
+        igrid(ipart) = igridn(ipart)
+      end do
+    end if
     call sort2(n, igrid, ipoint)
     igrold = -1
     ktop = 0
@@ -145,7 +191,21 @@ program convref
       igr = igrid(kpart)
       if (igr == -1) cycle
       ipart = ipoint(kpart)
-      if (igr /= igrold) then
+      if (igr /= igrold .and. pass == 1) then
+        jy = (igr - 1) / gnx
+        ix = igr - jy * gnx - 1
+        ! convmix.f90:214-228: the nest's profiles
+        psconv = (real(psn8(ix+1,jy+1,1)) * dt2 + real(psn8(ix+1,jy+1,2)) * dt1) * dtt
+        tt2conv = (real(tt2n8(ix+1,jy+1,1)) * dt2 + real(tt2n8(ix+1,jy+1,2)) * dt1) * dtt
+        td2conv = (real(td2n8(ix+1,jy+1,1)) * dt2 + real(td2n8(ix+1,jy+1,2)) * dt1) * dtt
+        do kz = 1, nuvzl - 1
+          tconv(kz) = (real(tthn8(ix+1,jy+1,kz+1,1)) * dt2 + real(tthn8(ix+1,jy+1,kz+1,2)) * dt1) * dtt
+          qconv(kz) = (real(qvhn8(ix+1,jy+1,kz+1,1)) * dt2 + real(qvhn8(ix+1,jy+1,kz+1,2)) * dt1) * dtt
+        end do
+        call glue_calcmatrix(lconv, delt, cbln(ix+1,jy+1))
+        igrold = igr
+        ktop = 0
+      else if (igr /= igrold) then
         jy = (igr - 1) / nxl
         ix = igr - jy * nxl - 1
         ! convmix.f90:154-166: the column's profiles at the particle time
@@ -176,11 +236,16 @@ program convref
         call redist(ipart, ktop, ipconv)
       end if
     end do
+    end do     ! pass
     do i = 1, n
       z8(i) = ztra1(i)
     end do
     cb8 = cbl
     write(32) z8, cb8, lconvcol, ntopcol, fmcount, fmcol, fm8
+    if (nest_on == 1) then
+      cbn8 = cbln
+      write(32) cbn8
+    end if
   end do
   close(32)
   if (use_gpu == 1) call flexgpu_finalize()

@@ -354,8 +354,8 @@ def run_cp_leaf_reference(ps, t, td, stress, kind="r8", workdir="/tmp"):
         return np.frombuffer(open(fo, "rb").read(), dtype=np.float64).reshape(3, n).T.copy()
 
 
-def have_conv_ref(kind="r8"):
-    return os.access(os.path.join(HERE, "_ref", f"convref_{kind}"), os.X_OK)
+def have_conv_ref(kind="r8", nest=False):
+    return os.access(os.path.join(HERE, "_ref", f"convref_{kind}" + ("n" if nest else "")), os.X_OK)
 
 
 def run_conv_reference(cs, kind="r8", workdir="/tmp", fm_cap=8, gpu=False):
@@ -376,7 +376,12 @@ def run_conv_reference(cs, kind="r8", workdir="/tmp", fm_cap=8, gpu=False):
                 fh.write(f8(cs[k]))           # C order [slot][level][jy][ix] == Fortran (ix,jy,level,slot)
             fh.write(np.asarray(cs["itimes"], dtype=np.int32).tobytes())
             fh.write(np.ascontiguousarray(np.asarray(cs["due"]).T.astype(np.int32)).tobytes())     # due(n,ncalls) column-major
-        exe = os.path.join(HERE, "_ref", f"convref_{kind}")
+            if "nest" in cs:
+                fh.write(struct.pack("<3i", 1, int(cs["nest"][0]), int(cs["nest"][1])))
+                fh.write(f8(cs["nestgeom"]))
+                for k in ("psn", "tt2n", "td2n", "tthn", "qvhn", "cbasefluxn"):
+                    fh.write(f8(cs[k]))
+        exe = os.path.join(HERE, "_ref", f"convref_{kind}" + ("n" if "nest" in cs else ""))
         res = subprocess.run([exe, fi, fo] + (["gpu"] if gpu else []), capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"reference convection driver failed: {res.stdout}\n{res.stderr}")
@@ -392,4 +397,6 @@ def run_conv_reference(cs, kind="r8", workdir="/tmp", fm_cap=8, gpu=False):
         z = take(np.float64, (n,)); cb = take(np.float64, (ny, nx)); lc = take(np.int32, (ny, nx)); nt = take(np.int32, (ny, nx))
         cnt = int(take(np.int32, (1,))[0]); fid = take(np.int32, (fm_cap,)); fm = take(np.float64, (fm_cap, nl, nl))
         out.append(dict(ztra1=z, cbaseflux=cb, lconv=lc, nconvtop=nt, fm_count=cnt, fm_col=fid, fmassfrac=fm))
+        if "nest" in cs:
+            out[-1]["cbasefluxn"] = take(np.float64, (int(cs["nest"][1]), int(cs["nest"][0])))
     return out

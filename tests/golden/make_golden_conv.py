@@ -13,7 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from flexpart_amd import synthetic as syn          # noqa: E402
 from oracle import scenario_io as sio              # noqa: E402
 
-CASES = {"forward": dict(), "backward": dict(ldirect=-1, seed=23)}
+CASES = {"forward": dict(), "backward": dict(ldirect=-1, seed=23), "nested": dict(nest=True, seed=31)}
 
 if __name__ == "__main__":
     for name, kw in CASES.items():
@@ -22,7 +22,7 @@ if __name__ == "__main__":
             calls = sio.run_conv_reference(cs, kind)
             out = {"ncalls": len(calls)}
             for i, c in enumerate(calls):
-                for k in ("ztra1", "cbaseflux", "lconv", "nconvtop", "fm_col", "fmassfrac"):
+                for k in ("ztra1", "cbaseflux", "lconv", "nconvtop", "fm_col", "fmassfrac") + (("cbasefluxn",) if "cbasefluxn" in c else ()):
                     out[f"c{i}_{k}"] = c[k] if k != "fmassfrac" else c[k].astype(np.float64)
             path = os.path.join(HERE, f"conv_{name}_{kind}.npz")
             np.savez_compressed(path, **out)

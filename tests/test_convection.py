@@ -16,7 +16,7 @@ from oracle import scenario_io as sio
 from oracle.oracle import conv_oracle
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-CASES = {"forward": dict(), "backward": dict(ldirect=-1, seed=23)}
+CASES = {"forward": dict(), "backward": dict(ldirect=-1, seed=23), "nested": dict(nest=True, seed=31)}
 KEYS = ("ztra1", "cbaseflux", "lconv", "nconvtop", "fm_col", "fmassfrac")
 
 
@@ -29,8 +29,13 @@ def test_oracle_matches_convection_fixtures(name, kind):
     assert len(calls) == int(gold["ncalls"])
     z0 = np.asarray(cs["ztra1"], dtype=np.float32 if kind == "r4" else np.float64).astype(np.float64)
     for i, c in enumerate(calls):
-        for k in KEYS:
+        for k in KEYS + (("cbasefluxn",) if "nest" in cs else ()):
             assert np.array_equal(np.asarray(c[k]), gold[f"c{i}_{k}"]), (name, kind, i, k)
+    if "nest" in cs:      # particles inside the nest take the nest's soundings and its own mass-flux field
+        g = cs["nestgeom"]
+        inn = (cs["xtra1"] > g[0] + 0.01) & (cs["xtra1"] < g[2] - 0.01) & (cs["ytra1"] > g[1] + 0.01) & (cs["ytra1"] < g[3] - 0.01)
+        assert inn.sum() > 500 and (calls[0]["ztra1"] != z0)[inn].sum() > 100
+        assert not np.array_equal(calls[0]["cbasefluxn"], np.asarray(cs["cbasefluxn"]))
     # the scenario does what it is there for: a quarter of the visited columns convect, deep ones reach the top of the matrix,
     # the cloud-base mass flux relaxes from call to call, several hundred particles are displaced per call, dozens of them by kilometres
     first, last = calls[0], calls[-1]
@@ -65,12 +70,20 @@ def _engine(cs, kind, rng_mode, seed=3):
     n = int(cs["npart"])
     sc = syn.small(n=n, nx=nx, ny=ny, nz=30, nsteps=1, global_grid=False, ldirect=int(cs["ldirect"]))
     sc["xtra1"], sc["ytra1"], sc["ztra1"] = cs["xtra1"], cs["ytra1"], cs["ztra1"]
+    if "nest" in cs:      # the same nested wind field for the trajectory part of the engine (fpx_nests_init)
+        g = cs["nestgeom"]
+        syn.add_nest(sc, int(g[0]), int(g[1]), int(g[2]), int(g[3]), factor=int(g[4]))
+        assert tuple(sc["nest"]) == tuple(cs["nest"])
     eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=rng_mode, seed=seed)
     eng.set_windtime(cs["memtime"], (1, 2))
     eng.conv_init(cs)
     eng.cbaseflux(cs["cbaseflux"])
     for slot in (1, 2):
         eng.upload_conv_fields(slot, *(np.asarray(cs[k])[slot - 1] for k in ("ps", "tt2", "td2", "tth", "qvh")))
+        if "nest" in cs:
+            eng.upload_conv_nest_fields(1, slot, *(np.asarray(cs[k + "n"])[slot - 1] for k in ("ps", "tt2", "td2", "tth", "qvh")))
+    if "nest" in cs:
+        eng.cbaseflux_nest(1, np.asarray(cs["cbasefluxn"]).shape, cs["cbasefluxn"])
     return eng, sc
 
 
@@ -102,6 +115,9 @@ def test_device_convmix_matches_the_oracle(built, name, kind):
         cb = eng.cbaseflux()
         assert np.abs(cb - w["cbaseflux"]).max() <= tol * np.abs(w["cbaseflux"]).max(), (name, kind, ic)
         assert np.array_equal(cb > 0, w["cbaseflux"] > 0)
+        if "nest" in cs:
+            cbn = eng.cbaseflux_nest(1, w["cbasefluxn"].shape)
+            assert np.abs(cbn - w["cbasefluxn"]).max() <= tol * np.abs(w["cbasefluxn"]).max(), (name, kind, ic)
         close = np.abs(z - w["ztra1"]) <= tol * np.maximum(np.abs(w["ztra1"]), 1.0)
         assert close.mean() >= 0.995, (name, kind, ic, close.mean())
         assert moved >= (w["rn"] >= 0).sum() > 500
