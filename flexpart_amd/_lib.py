@@ -179,7 +179,7 @@ SYMBOLS = [
     "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_calcpar", "fpx_calcpar_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
     "fpx_checkpoint_write", "fpx_checkpoint_read",
     "fpx_conv_init", "fpx_upload_conv_fields", "fpx_convmix", "fpx_convmix_time", "fpx_get_cbaseflux", "fpx_set_cbaseflux",
-    "fpx_upload_conv_nest_fields", "fpx_get_cbaseflux_nest", "fpx_set_cbaseflux_nest",
+    "fpx_upload_conv_nest_fields", "fpx_get_cbaseflux_nest", "fpx_set_cbaseflux_nest", "fpx_upload_diag_nest_fields",
 ]
 
 _lib = None
@@ -226,6 +226,7 @@ def load():
     lib.fpx_convmix.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
     lib.fpx_convmix_time.argtypes = [vp, C.POINTER(C.c_double)]
     lib.fpx_upload_conv_nest_fields.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(FpxConvFields)]
+    lib.fpx_upload_diag_nest_fields.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(FpxDiagFields)]
     lib.fpx_get_cbaseflux_nest.argtypes = [vp, C.c_int32, vp]
     lib.fpx_set_cbaseflux_nest.argtypes = [vp, C.c_int32, vp]
     lib.fpx_get_cbaseflux.argtypes = [vp, vp]

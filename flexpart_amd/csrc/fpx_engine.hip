@@ -689,8 +689,17 @@ __global__ void k_rel_targets(const unsigned int *__restrict__ flags, const unsi
   if ((long long)r < ntotal) target[r] = (unsigned int)pid;
 }
 
+// a nested wind field as releaseparticles reads it (:196-226,231-341): orography and tt of time slot 2 in the host's real
+// kind, compact; rho of slot 2 from the nest's gather pack
 template <typename R, typename H>
-__global__ void __launch_bounds__(kBlock) k_release(View<R> V, Parts<R> P, DiagP<H> D, RelPoints<H> RP, const unsigned int *__restrict__ target,
+struct RelNests {
+  int n;
+  H eps;                              // nxmax/3.e5 (:61)
+  struct { int nx, ny; H xl, yl, xr, yr, xres, yres; const H *oro, *tt2; const R *r2; } g[kMaxNests];
+};
+
+template <typename R, typename H>
+__global__ void __launch_bounds__(kBlock) k_release(View<R> V, Parts<R> P, DiagP<H> D, RelNests<R, H> NS, RelPoints<H> RP, const unsigned int *__restrict__ target,
                                                     const unsigned int *__restrict__ slot_of_pid, long long ntotal, int itime,
                                                     const H *__restrict__ uniforms /* [4][ntotal] serial ran1 stream, or NULL: counter RNG */,
                                                     int numparticlecount0, int mintime, int itsplit, int ind_rel, int nclassunc, int mquasilag,
@@ -725,19 +734,44 @@ __global__ void __launch_bounds__(kBlock) k_release(View<R> V, Parts<R> P, DiagP
   int nc = (int)(u[2] * (H)nclassunc) + 1;                                   // :168-169
   nc = nc < nclassunc ? nc : nclassunc;
   H zt = RP.zp1[i] + u[3] * RP.zaux[i];                                      // :183
-  // :206-226 (mother grid)
-  int ix = (int)xt, jy = (int)yt;
-  const H ddy = (H)(yt - (double)(H)jy), ddx = (H)(xt - (double)(H)ix);
+  // the nest we are in (:196-206), grid coordinates and weights (:211-226)
+  int ngrid = 0;
+  for (int q = NS.n; q >= 1; q--)
+    if (xt > (double)(NS.g[q - 1].xl + NS.eps) && xt < (double)(NS.g[q - 1].xr - NS.eps) && yt > (double)(NS.g[q - 1].yl + NS.eps) &&
+        yt < (double)(NS.g[q - 1].yr - NS.eps)) { ngrid = q; break; }
+  int ix, jy, gnx = nx, gny = ny, gnxmax = D.nxmax, gnymax = D.nymax;
+  H ddx, ddy;
+  const H *g_oro = D.oro, *g_tt = nullptr;
+  const R *g_r2 = V.r2;
+  if (ngrid > 0) {
+    const auto &N = NS.g[ngrid - 1];
+    const H xtn = (H)((xt - (double)N.xl) * (double)N.xres), ytn = (H)((yt - (double)N.yl) * (double)N.yres);
+    ix = (int)xtn; jy = (int)ytn;
+    ddy = ytn - (H)jy; ddx = xtn - (H)ix;
+    gnx = N.nx; gny = N.ny; gnxmax = N.nx + 1; gnymax = N.ny + 1;      // one padding column / row reads as 0
+    g_oro = N.oro; g_tt = N.tt2; g_r2 = N.r2;
+  } else {
+    ix = (int)xt; jy = (int)yt;
+    ddy = (H)(yt - (double)(H)jy); ddx = (H)(xt - (double)(H)ix);
+  }
   int ixp = ix + 1, jyp = jy + 1;
   // guards (the reference would read outside its arrays): a position on the upper edges
-  ix = min(max(ix, 0), nx - 1); jy = min(max(jy, 0), ny - 1); ixp = min(max(ixp, 0), D.nxmax - 1); jyp = min(max(jyp, 0), D.nymax - 1);
+  ix = min(max(ix, 0), gnx - 1); jy = min(max(jy, 0), gny - 1); ixp = min(max(ixp, 0), gnxmax - 1); jyp = min(max(jyp, 0), gnymax - 1);
   const H rddx = (H)1. - ddx, rddy = (H)1. - ddy;
   const H p1 = rddx * rddy, p2 = ddx * rddy, p3 = rddx * ddy, p4 = ddx * ddy;
-  auto oro = [&](int a, int b) { return D.oro[(size_t)a + (size_t)D.nxmax * (size_t)b]; };
+  // mother: host layout with stride nxmax; nest: compact [nyn][nxn], the padding reads as 0
+  auto oro = [&](int a, int b) -> H {
+    if (ngrid > 0) return (a >= gnx || b >= gny) ? (H)0 : g_oro[(size_t)a + (size_t)gnx * (size_t)b];
+    return g_oro[(size_t)a + (size_t)D.nxmax * (size_t)b];
+  };
   const H topo = p1 * oro(ix, jy) + p2 * oro(ixp, jy) + p3 * oro(ix, jyp) + p4 * oro(ixp, jyp);
-  // rho(.,.,kz,2): the r2 pack, physical slot 2; tt(.,.,kz,2): component 2 of the d3 pack; host padding reads as 0
-  auto rho2 = [&](int a, int b, int kz) -> H { return (a >= nx || b >= ny) ? (H)0 : (H)V.r2[(((size_t)b * nx + a) * nz + (kz - 1)) * 4 + 2]; };
-  auto tt2 = [&](int a, int b, int kz) -> H { return (a >= nx || b >= ny) ? (H)0 : D.d3[((((size_t)b * nx + a) * nz + (kz - 1)) * 2 + 1) * 3 + 2]; };
+  // rho(.,.,kz,2): the r2 pack, physical slot 2; tt(.,.,kz,2): component 2 of the d3 pack (mother) / the nest's compact array
+  auto rho2 = [&](int a, int b, int kz) -> H { return (a >= gnx || b >= gny) ? (H)0 : (H)g_r2[(((size_t)b * gnx + a) * nz + (kz - 1)) * 4 + 2]; };
+  auto tt2 = [&](int a, int b, int kz) -> H {
+    if (a >= gnx || b >= gny) return (H)0;
+    if (ngrid > 0) return g_tt[(size_t)a + (size_t)gnx * ((size_t)b + (size_t)gny * (size_t)(kz - 1))];
+    return D.d3[((((size_t)b * nx + a) * nz + (kz - 1)) * 2 + 1) * 3 + 2];
+  };
   const int kz3 = RP.kindz[i];
   if (kz3 == 3) {                                                            // :231-273
     const H presspart = zt;
@@ -1275,6 +1309,7 @@ struct EngineBase {
   virtual double vt_ms() = 0;
   virtual double po_ms() = 0;
   virtual int upload_diag_fields(int slot, const fpx_diag_fields *f) = 0;
+  virtual int upload_diag_nest_fields(int nest, int slot, const fpx_diag_fields *f) = 0;
   virtual int partoutput(int itime, const char *path, int64_t *nrec) = 0;
   virtual int concoutput(int itime, const fpx_concout *c, const char *prefix, int clear) = 0;
   virtual int readpartpositions(const char *path, const fpx_restart *r, int64_t *numpart_out, int32_t *numparticlecount, int32_t *itimein) = 0;
@@ -1987,6 +2022,38 @@ struct Engine : EngineBase {
   int diag3(const void *src, bool on_device, int c, int s) {
     return cfg.host_real_bytes == 4 ? diag3_pack<float>(src, on_device, c, s) : diag3_pack<double>(src, on_device, c, s);
   }
+  // oron and ttn of a nested wind field for releaseparticles (:216-273): compact copies in the host's real kind
+  void *rel_nest_oro[kMaxNests] = {}, *rel_nest_tt2[kMaxNests] = {};
+  template <typename H>
+  int upload_diag_nest_fields_t(int nest, int slot, const fpx_diag_fields *f) {
+    const int l = nest - 1, nxn = h_nest[l].nx, nyn = h_nest[l].ny;
+    const size_t n2 = (size_t)nxn * nyn, n2max = (size_t)nest_nxmaxn * nest_nymaxn;
+    int rc;
+    if (f->oro) {
+      if (!rel_nest_oro[l]) { H *q = nullptr; if ((rc = dalloc(&q, n2))) return rc; rel_nest_oro[l] = q; }
+      if ((rc = ensure_staging(n2max * sizeof(H)))) return rc;
+      HIPCHK(hipMemcpyAsync(staging, f->oro, n2max * sizeof(H), hipMemcpyHostToDevice, stream));
+      k_conv_pack<H, H><<<(int)((n2 + kBlock - 1) / kBlock), kBlock, 0, stream>>>((const H *)staging, (H *)rel_nest_oro[l], nxn, nyn, 1, nest_nxmaxn, nest_nymaxn);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    if (slot == 2 && f->tt) {
+      const size_t n3 = n2 * cfg.nz;
+      if (!rel_nest_tt2[l]) { H *q = nullptr; if ((rc = dalloc(&q, n3))) return rc; rel_nest_tt2[l] = q; }
+      if ((rc = ensure_staging(n2max * cfg.nz * sizeof(H)))) return rc;
+      HIPCHK(hipMemcpyAsync(staging, f->tt, n2max * cfg.nz * sizeof(H), hipMemcpyHostToDevice, stream));
+      k_conv_pack<H, H><<<(int)((n3 + kBlock - 1) / kBlock), kBlock, 0, stream>>>((const H *)staging, (H *)rel_nest_tt2[l], nxn, nyn, cfg.nz, nest_nxmaxn, nest_nymaxn);
+      HIPCHK(hipGetLastError());
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    return 0;
+  }
+  int upload_diag_nest_fields(int nest, int slot, const fpx_diag_fields *f) override {
+    if (nest < 1 || nest > V.numbnests) return fail(FPX_ERR_ARG, "upload_diag_nest_fields: nest out of range (fpx_nests_init first)");
+    if (!f || slot < 0 || slot > 2) return fail(FPX_ERR_ARG, "upload_diag_nest_fields: slot 0 (oron only), 1 or 2");
+    return cfg.host_real_bytes == 4 ? upload_diag_nest_fields_t<float>(nest, slot, f) : upload_diag_nest_fields_t<double>(nest, slot, f);
+  }
+
   int upload_diag_fields(int slot, const fpx_diag_fields *f) override {
     if (!f || slot < 0 || slot > 2) return fail(FPX_ERR_ARG, "upload_diag_fields: slot 0 (oro only), 1 or 2");
     int rc;
@@ -2357,7 +2424,11 @@ struct Engine : EngineBase {
     if (nreleased) *nreleased = ntotal;
     if (ntotal == 0) return 0;
     const bool dens = rel.ind_rel == 1 || rel.ind_rel == 3 || rel.ind_rel == 4;
-    if (V.numbnests > 0) return fail(FPX_ERR_UNSUPPORTED, "releaseparticles: nested met grids are configured (oron, rhon, ttn of releaseparticles.f90:206-341 are not wired)");
+    for (int l = 0; l < V.numbnests; l++) {
+      if (!rel_nest_oro[l]) return fail(FPX_ERR_STATE, "releaseparticles: oron of every nest is needed (fpx_upload_diag_nest_fields slot 0)");
+      if ((any_p3 || dens) && !nest_loaded[l][1]) return fail(FPX_ERR_STATE, "releaseparticles: rhon of time slot 2 is needed (fpx_upload_nest_fields)");
+      if (any_p3 && !rel_nest_tt2[l]) return fail(FPX_ERR_STATE, "releaseparticles: ttn of time slot 2 is needed for kindz = 3 (fpx_upload_diag_nest_fields slot 2)");
+    }
     if (!height_set || !diag_have[DG_ORO]) return fail(FPX_ERR_STATE, "releaseparticles: height and oro (fpx_upload_diag_fields slot 0) are needed");
     if ((any_p3 || dens) && !slot_loaded[1]) return fail(FPX_ERR_STATE, "releaseparticles: rho of time slot 2 is needed (kindz = 3 or ind_rel = 1, 3, 4)");
     if (any_p3 && !diag_have[DG_TT + 1]) return fail(FPX_ERR_STATE, "releaseparticles: tt of time slot 2 is needed for kindz = 3 (fpx_upload_diag_fields slot 2)");
@@ -2425,7 +2496,16 @@ struct Engine : EngineBase {
     DiagP<H> D;
     D.oro = (const H *)diag_oro; D.tropo[0] = (const H *)diag_tropo[0]; D.tropo[1] = (const H *)diag_tropo[1]; D.d3 = (const H *)diag_d3;
     D.nxmax = cfg.nxmax; D.nymax = cfg.nymax; D.dx = (H)cfg.dx; D.dy = (H)cfg.dy; D.xlon0 = (H)cfg.xlon0; D.ylat0 = (H)cfg.ylat0;
-    k_release<R, H><<<(int)((ntotal + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, P, D, RP, target, slot_map(), ntotal, itime, d_uni, (int)*npc_io,
+    RelNests<R, H> NS;
+    NS.n = V.numbnests;
+    NS.eps = (H)cfg.par_nxmax / (H)3.e5;
+    for (int l = 0; l < V.numbnests; l++) {
+      const NestDesc<R> &N = h_nest[l];
+      NS.g[l].nx = N.nx; NS.g[l].ny = N.ny;
+      NS.g[l].xl = (H)N.xl; NS.g[l].yl = (H)N.yl; NS.g[l].xr = (H)N.xr; NS.g[l].yr = (H)N.yr; NS.g[l].xres = (H)N.xres; NS.g[l].yres = (H)N.yres;
+      NS.g[l].oro = (const H *)rel_nest_oro[l]; NS.g[l].tt2 = (const H *)rel_nest_tt2[l]; NS.g[l].r2 = N.r2;
+    }
+    k_release<R, H><<<(int)((ntotal + kBlock - 1) / kBlock), kBlock, 0, stream>>>(V, P, D, NS, RP, target, slot_map(), ntotal, itime, d_uni, (int)*npc_io,
                                                                                   cfg.mintime, rel.itsplit, rel.ind_rel, rel.nclassunc, cfg.mquasilag,
                                                                                   dens ? d_rho : (H *)nullptr, d_max);
     e = hipGetLastError();
@@ -4244,6 +4324,7 @@ int fpx_conv_init(fpx_handle h, const fpx_conv_config *c) { FPX_GUARD(h); return
 int fpx_upload_conv_fields(fpx_handle h, int32_t slot, const fpx_conv_fields *f) { FPX_GUARD(h); return h->impl->upload_conv_fields(slot, f); }
 int fpx_convmix(fpx_handle h, int32_t itime, int64_t *nmoved) { FPX_GUARD(h); return h->impl->convmix(itime, nmoved); }
 int fpx_convmix_time(fpx_handle h, double *ms) { FPX_GUARD(h); if (!ms) return FPX_ERR_ARG; *ms = h->impl->conv_ms(); return 0; }
+int fpx_upload_diag_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_diag_fields *f) { FPX_GUARD(h); return h->impl->upload_diag_nest_fields(nest, slot, f); }
 int fpx_upload_conv_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_conv_fields *f) { FPX_GUARD(h); return h->impl->upload_conv_nest_fields(nest, slot, f); }
 int fpx_get_cbaseflux_nest(fpx_handle h, int32_t nest, void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_nest_io(nest, cb, false); }
 int fpx_set_cbaseflux_nest(fpx_handle h, int32_t nest, const void *cb) { FPX_GUARD(h); return h->impl->cbaseflux_nest_io(nest, (void *)cb, true); }

@@ -299,6 +299,20 @@ class Engine:
                 setattr(f, k, keep[k].ctypes.data)
             check(self.lib.fpx_upload_diag_fields(self.h, m + 1, C.byref(f)), "fpx_upload_diag_fields")
 
+    def upload_diag_nest_fields(self, nest, oron, ttn2=None):
+        """oron [nyn][nxn] and ttn of time slot 2 [nz][nyn][nxn] of a nested wind field (compact nests in this mirror)."""
+        from ._lib import FpxDiagFields
+        rt = self.hreal
+        f = FpxDiagFields()
+        o = np.ascontiguousarray(np.asarray(oron).astype(rt))
+        f.oro = o.ctypes.data
+        t = None
+        if ttn2 is not None:
+            t = np.zeros((self.nzmax,) + tuple(np.asarray(ttn2).shape[1:]), rt)
+            t[: np.asarray(ttn2).shape[0]] = ttn2
+            f.tt = t.ctypes.data
+        check(self.lib.fpx_upload_diag_nest_fields(self.h, int(nest), 2 if ttn2 is not None else 0, C.byref(f)), "fpx_upload_diag_nest_fields")
+
     def partoutput(self, itime, path):
         """fpx_partoutput: writes the reference's partposit_* dump to `path`; returns the number of particle records."""
         n = C.c_int64(0)

@@ -38,7 +38,7 @@ module flexgpu_mod
             flexgpu_conv_init, flexgpu_upload_conv_fields, flexgpu_convmix, flexgpu_cbaseflux
 #ifdef FLEXGPU_NESTS
   public :: flexgpu_upload_nests, flexgpu_upload_wet_nest_fields, flexgpu_nests_init, flexgpu_verttransform_nests, &
-            flexgpu_upload_conv_nest_fields, flexgpu_cbaseflux_nests
+            flexgpu_upload_conv_nest_fields, flexgpu_cbaseflux_nests, flexgpu_upload_diag_nest_fields
 #endif
 
   integer, parameter :: FPX_MAXSPEC = 5
@@ -249,6 +249,12 @@ module flexgpu_mod
       integer(c_int32_t), value :: itime
       type(c_ptr), value :: nmoved
     end function fpx_convmix
+    integer(c_int) function fpx_upload_diag_nest_fields(h, nest, slot, f) bind(C, name='fpx_upload_diag_nest_fields')
+      import :: c_ptr, c_int, c_int32_t, fpx_diag_fields
+      type(c_ptr), value :: h
+      integer(c_int32_t), value :: nest, slot
+      type(fpx_diag_fields), intent(in) :: f
+    end function fpx_upload_diag_nest_fields
     integer(c_int) function fpx_upload_conv_nest_fields(h, nest, slot, f) bind(C, name='fpx_upload_conv_nest_fields')
       import :: c_ptr, c_int, c_int32_t, fpx_conv_fields
       type(c_ptr), value :: h
@@ -858,6 +864,20 @@ contains
     integer, intent(out) :: ierr
     call flexgpu_upload_nests(ierr, geometry_only=.true.)
   end subroutine flexgpu_nests_init
+
+  ! what releaseparticles reads of the nests besides rhon (releaseparticles.f90:216-273): oron and ttn of time slot 2
+  subroutine flexgpu_upload_diag_nest_fields(ierr)
+    integer, intent(out) :: ierr
+    type(fpx_diag_fields) :: f
+    integer :: l
+    ierr = 0
+    do l = 1, numbnests
+      f%oro = loc_r(oron(0:,0,l)); f%pv = c_null_ptr; f%qv = c_null_ptr
+      f%tt = loc_r(ttn(0:,0,1,2,l))
+      ierr = fpx_upload_diag_nest_fields(flexgpu_handle, int(l, c_int32_t), 2_c_int32_t, f)
+      if (ierr /= 0) return
+    end do
+  end subroutine flexgpu_upload_diag_nest_fields
 
   ! convection inside nested wind fields (convmix.f90:198-250): psn, tt2n, td2n, tthn, qvhn of slot n of every nest, after
   ! readwind_nests filled it and after flexgpu_nests_init / flexgpu_conv_init

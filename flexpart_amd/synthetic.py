@@ -644,13 +644,15 @@ def add_pptv(co, nx=40, ny=24, nz=12):
 # releaseparticles + particle splitting
 # --------------------------------------------------------------------------
 def release_case(nx=48, ny=32, nz=24, *, nspec=2, ind_rel=1, mquasilag=0, maxpart=100000, itsplit=1800, existing=400,
-                 times=(0, 900, 1800, 2700, 3600), global_grid=True, ibdate=20200615, ibtime=120000):
+                 times=(0, 900, 1800, 2700, 3600), global_grid=True, ibdate=20200615, ibtime=120000, nest=False):
     """RELEASES with five release points of every kind the routine distinguishes: a point source released at one
     instant (kindz 1), a box released over an interval (area source, metres above ground), a box in metres above sea
     level (kindz 2: topography subtracted), a box given in pressure (kindz 3: converted with rho and tt of time slot
     2), and a box across the date line of a global grid (the xglobal wrap).  Particles of a run in progress occupy
     the first storage spaces, some of them terminated (vacant), some due for splitting.  Local-time emission factors
-    (point_hour, area_dow ...) differ per species."""
+    (point_hour, area_dow ...) differ per species.  nest=True: a nested wind field of twice the resolution over mother cells
+    [16,32] x [6,22] with its own orography, density and temperature: the second box straddles its western edge, the box above
+    sea level lies inside it, the pressure box straddles its eastern edge (releaseparticles.f90:196-226)."""
     height = make_height(nz, top=30000.0, lin=0.15)
     dx = 360.0 / (nx - 1) if global_grid else 1.0
     dy = 180.0 / (ny - 1) if global_grid else 1.0
@@ -677,6 +679,14 @@ def release_case(nx=48, ny=32, nz=24, *, nspec=2, ind_rel=1, mquasilag=0, maxpar
     hour = 1.0 + 0.5 * _wave(np.arange(24)[:, None] * 2 + np.arange(nspec)[None, :] * 5, 24)
     dow = 1.0 + 0.25 * _wave(np.arange(7)[:, None] * 3 + np.arange(nspec)[None, :], 7)
     rs.update(point_hour=hour, area_hour=hour[::-1].copy(), point_dow=dow, area_dow=dow[::-1].copy())
+    if nest:
+        ix0, ix1, jy0, jy1, fac = 16, 32, 6, 22, 2
+        nxn, nyn = fac * (ix1 - ix0) + 1, fac * (jy1 - jy0) + 1
+        fn = make_fields(nxn, nyn, nz, height, nspec=nspec)
+        gi = np.arange(nxn, dtype=np.int64)[None, :]
+        gj = np.arange(nyn, dtype=np.int64)[:, None]
+        rs.update(nest=np.array([nxn, nyn], np.int32), nestcorners=np.array([ix0, jy0, ix1, jy1, fac, fac], np.float64), par_nxmax=721,
+                  oron=420.0 * (1.0 + _wave(3 * gi + gj, 2 * per)) + 0.0 * gj, rhon2=fn["rho"][1] * 1.03, ttn2=fn["tt"][1] - 2.5)
     if existing:
         n = int(existing)
         u = _uniform01(n, 77)

@@ -239,6 +239,10 @@ typedef struct {
   const void *pv, *qv, *tt;
 } fpx_diag_fields;
 int fpx_upload_diag_fields(fpx_handle h, int32_t slot, const fpx_diag_fields *f);
+/* the same for nested wind field `nest` (after fpx_nests_init; strides nxmaxn, nymaxn): oron(0:nxmaxn-1,0:nymaxn-1,nest) with any
+ * slot, ttn(:,:,:,2,nest) with slot 2 -- what releaseparticles.f90:216-273 reads for a particle released inside a nest (its rhon
+ * comes from fpx_upload_nest_fields / fpx_verttransform_nest); pv, qv are ignored */
+int fpx_upload_diag_nest_fields(fpx_handle h, int32_t nest, int32_t slot, const fpx_diag_fields *f);
 /* nparticles (may be NULL): number of particle records written */
 int fpx_partoutput(fpx_handle h, int32_t itime, const char *path, int64_t *nparticles);
 /* device time (selection, scan, record kernel) of the last fpx_partoutput call, milliseconds */
@@ -407,7 +411,8 @@ int fpx_set_release_points(fpx_handle h, int32_t numpoint, const void *xmass, co
  * Philox keyed on (seed, numparticlecount of the particle).  Particles never visit the host.
  * Needs: fpx_set_release_points (xmass, npart), oro (fpx_upload_diag_fields slot 0); for kindz = 3 also tt of
  * slot 2 (fpx_upload_diag_fields slot 2 or fpx_verttransform_ecmwf); rho comes from the met fields of slot 2.
- * Nested met grids: a release inside a nest is refused (FPX_ERR_UNSUPPORTED; oron, rhon, ttn are not wired).
+ * Nested met grids (releaseparticles.f90:196-226): a particle released inside a nest takes the nest's orography, density and
+ * temperature (fpx_upload_diag_nest_fields + the nest's field pack).
  * xscav_frac1 (backward deposition runs, :161-166) is not a particle array of the engine. */
 typedef struct {
   int32_t struct_bytes;

@@ -220,9 +220,11 @@ build_co r4      # (with -fdefault-real-8 concoutput.f90 itself does not compile
 build_one r8n par_mod_meteoswiss.f90 -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
 build_vt r8n -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
 build_conv r8n -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
+build_rel r8n -fdefault-real-8 -DFLEXREF_NESTS -DFLEXGPU_NESTS
 # ... and in the reference's own precision (BASELINE config 5: nests + deposition in f32)
 build_one r4n par_mod_meteoswiss.f90 -DFLEXREF_NESTS -DFLEXGPU_NESTS
 build_conv r4n -DFLEXREF_NESTS -DFLEXGPU_NESTS
+build_rel r4n -DFLEXREF_NESTS -DFLEXGPU_NESTS
 # several age classes / uncertainty classes (see build_one)
 FLEXREF_CLASSES="4 3" build_one r4c par_mod.f90
 FLEXREF_CLASSES="4 3" build_one r8c par_mod.f90 -fdefault-real-8

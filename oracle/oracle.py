@@ -559,7 +559,10 @@ class _RloArgs(C.Structure):
                 + [(k, C.POINTER(C.c_double)) for k in ("xtra1", "ytra1", "ztra1", "uap", "xmass1")]
                 + [(k, C.POINTER(C.c_int)) for k in ("itra1", "itramem", "itrasplit", "idt", "npoint", "nclass")]
                 + [(k, C.POINTER(C.c_double)) for k in ("xmasssave", "rho_rel")]
-                + [("ran1_idum", C.c_int), ("ran1_iy", C.c_int), ("ran1_iv", C.c_int * 32), ("status", C.c_int)])
+                + [("ran1_idum", C.c_int), ("ran1_iy", C.c_int), ("ran1_iv", C.c_int * 32), ("status", C.c_int)]
+                + [(k, C.c_int) for k in ("nest_on", "nxn", "nyn", "pad_")]
+                + [(k, C.c_double) for k in ("xln", "yln", "xrn", "yrn", "xresoln", "yresoln")]
+                + [(k, C.POINTER(C.c_double)) for k in ("oron", "rhon2", "ttn2")])
 
 
 def rl_juldate(yyyymmdd, hhmiss, kind="r8"):
@@ -592,6 +595,13 @@ def rl_oracle(rs, kind="r8"):
         keep[k] = _f64(rs[k]); setattr(a, k, keep[k].ctypes.data_as(dp))
     for k, kk in (("ireleasestart", "ireleasestart"), ("ireleaseend", "ireleaseend"), ("npart", "npart_rel"), ("kindz", "kindz")):
         keep[k] = np.ascontiguousarray(np.asarray(rs[kk], dtype=np.int32)); setattr(a, k, keep[k].ctypes.data_as(ip))
+    if "nest" in rs:
+        a.nest_on = 1
+        a.nxn, a.nyn = (int(v) for v in rs["nest"])
+        a.xln, a.yln, a.xrn, a.yrn, a.xresoln, a.yresoln = (float(v) for v in rs["nestcorners"])
+        a.eps_nxmax = float(rs["par_nxmax"])
+        for k in ("oron", "rhon2", "ttn2"):
+            keep[k] = _f64(rs[k]); setattr(a, k, keep[k].ctypes.data_as(dp))
     nsp = a.nspec
     P = {k: np.zeros(maxpart) for k in ("xtra1", "ytra1", "ztra1", "uap")}
     P["xmass1"] = np.zeros((nsp, maxpart))

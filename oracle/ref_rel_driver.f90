@@ -32,7 +32,7 @@ program relref
   integer(kind=8) :: cnt
   integer, allocatable :: ibuf(:), times(:)
   real(kind=8), allocatable :: dbuf(:), tmp(:)
-  integer :: ios, n, gnx, gny, gnz, np, ks, i, j, k, it, ntimes, itime, maxp, do_split
+  integer :: ios, n, gnx, gny, gnz, np, ks, i, j, k, it, ntimes, itime, maxp, do_split, ii1, jj1
   real(kind=dp) :: juldate
 
   call get_command_argument(1, fscen)
@@ -82,6 +82,30 @@ program relref
     case ('oro');      call get2(oro)
     case ('rho2');     call get3(rho(:,:,:,2))      ! releaseparticles reads the literal slot 2 (:233-257,:315-325)
     case ('tt2');      call get3(tt(:,:,:,2))
+#ifdef FLEXREF_NESTS
+    ! --- one nested wind field (releaseparticles.f90:196-226,231-341) ------------------------------
+    case ('nest')
+      numbnests=1; nxn(1)=ibuf(1); nyn(1)=ibuf(2)
+      if (nxn(1).gt.nxmaxn .or. nyn(1).gt.nymaxn) stop 'nest too large'
+      call com_mod_allocate_nests
+      uun=0.; vvn=0.; wwn=0.; ttn=0.; rhon=0.; drhodzn=0.
+    case ('nestcorners')
+      xln(1)=dbuf(1); yln(1)=dbuf(2); xrn(1)=dbuf(3); yrn(1)=dbuf(4); xresoln(1)=dbuf(5); yresoln(1)=dbuf(6)
+      xresoln(0)=1.; yresoln(0)=1.
+    case ('oron')
+      do jj1=0,nyn(1)-1
+        do ii1=0,nxn(1)-1
+          oron(ii1,jj1,1)=dbuf(1+ii1+nxn(1)*jj1)
+        end do
+      end do
+    case ('rhon2'); call get3n(rhon(:,:,:,2,1))
+    case ('ttn2');  call get3n(ttn(:,:,:,2,1))
+    case ('par_nxmax')
+      if (ibuf(1).ne.nxmax) stop 'the scenario par_nxmax differs from par_mod nxmax'
+#else
+    case ('nest', 'nestcorners', 'oron', 'rhon2', 'ttn2', 'par_nxmax')
+      stop 'this build has no nests (par_mod maxnests = 0)'
+#endif
     ! --- release points: point_mod arrays as readreleases.f90 allocates them ---------------------
     case ('numpoint')
       numpoint=ibuf(1)
@@ -164,6 +188,14 @@ program relref
     if (gerr .eq. 0) call flexgpu_set_windtime(gerr)
     if (gerr .eq. 0) call flexgpu_upload_diag_fields(0, gerr)   ! oro
     if (gerr .eq. 0) call flexgpu_upload_diag_fields(2, gerr)   ! tt of slot 2 (kindz = 3)
+#ifdef FLEXREF_NESTS
+    if (numbnests .gt. 0) then
+      rhon(:,:,:,1,:)=rhon(:,:,:,2,:); ttn(:,:,:,1,:)=ttn(:,:,:,2,:)
+      hmixn=500.; ustarn=0.3; wstarn=1.; olin=0.01; tropopausen=10000.; vdepn=0.
+      if (gerr .eq. 0) call flexgpu_upload_nests(gerr)
+      if (gerr .eq. 0) call flexgpu_upload_diag_nest_fields(gerr)
+    end if
+#endif
     if (gerr .eq. 0 .and. numpart .gt. 0) call flexgpu_upload_particles(1, numpart, gerr)
     if (gerr .eq. 0) call flexgpu_release_init(gerr)
     if (gerr .ne. 0) call gpu_fail('set-up')
@@ -292,6 +324,20 @@ contains
       end do
     end do
   end subroutine get2
+
+#ifdef FLEXREF_NESTS
+  subroutine get3n(f)
+    real, intent(inout) :: f(0:nxmaxn-1,0:nymaxn-1,nzmax)
+    integer :: ii,jj,kk
+    do kk=1,gnz
+      do jj=0,nyn(1)-1
+        do ii=0,nxn(1)-1
+          f(ii,jj,kk)=dbuf(1+ii+nxn(1)*(jj+nyn(1)*(kk-1)))
+        end do
+      end do
+    end do
+  end subroutine get3n
+#endif
 
   subroutine get3(f)
     real, intent(inout) :: f(0:nxmax-1,0:nymax-1,nzmax)

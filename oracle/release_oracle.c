@@ -44,6 +44,11 @@ typedef struct {
   double *xmasssave, *rho_rel;   /* [numpoint] */
   int ran1_idum, ran1_iy, ran1_iv[32];
   int status;                    /* 1: no free storage space left (the routine stops, :369-378) */
+  /* one nested wind field (releaseparticles.f90:196-226,231-341): corners and resolution factors in mother grid units,
+   * orography oron [nyn][nxn], rhon / ttn of the literal time slot 2 [nz][nyn][nxn] */
+  int nest_on, nxn, nyn, pad_;
+  double xln, yln, xrn, yrn, xresoln, yresoln;
+  const double *oron, *rhon2, *ttn2;
 } rlo_args;
 
 /* juldate.f90 in the build's real kind */
@@ -195,21 +200,41 @@ void rlo_releaseparticles(rlo_args *A, int itime) {
           A->itramem[ipart - 1] = itime;
           A->itrasplit[ipart - 1] = itime + A->ldirect * A->itsplit;
           zt = (real)A->zpoint1[i - 1] + rlo_ran1(A) * zaux;                /* :183 */
-          /* no nests here (ngrid = 0): :206-226 */
-          ix = (int)xt; jy = (int)yt;
-          ddy = (real)(yt - (double)(real)jy);
-          ddx = (real)(xt - (double)(real)ix);
+          /* the nest we are in, :196-206; grid coordinates and weights, :211-226 */
+          int ngrid = 0;
+          const double *g_oro = A->oro, *g_rho = A->rho2, *g_tt = A->tt2;
+          size_t gnx = (size_t)A->nx, gny = (size_t)A->ny;
+          if (A->nest_on) {
+            const real eps = (real)A->eps_nxmax / K(3.e5);
+            if (xt > (double)((real)A->xln + eps) && xt < (double)((real)A->xrn - eps) && yt > (double)((real)A->yln + eps) && yt < (double)((real)A->yrn - eps)) ngrid = 1;
+          }
+          if (ngrid > 0) {
+            const real xtn = (real)((xt - (double)(real)A->xln) * (double)(real)A->xresoln);
+            const real ytn = (real)((yt - (double)(real)A->yln) * (double)(real)A->yresoln);
+            ix = (int)xtn; jy = (int)ytn;
+            ddy = ytn - (real)jy;
+            ddx = xtn - (real)ix;
+            g_oro = A->oron; g_rho = A->rhon2; g_tt = A->ttn2; gnx = (size_t)A->nxn; gny = (size_t)A->nyn;
+          } else {
+            ix = (int)xt; jy = (int)yt;
+            ddy = (real)(yt - (double)(real)jy);
+            ddx = (real)(xt - (double)(real)ix);
+          }
+#undef F2
+#undef F3
+#define F2(f, i, j) ((real)(f)[(size_t)(i) + gnx * (size_t)(j)])
+#define F3(f, i, j, k) ((real)(f)[(size_t)(i) + gnx * ((size_t)(j) + gny * (size_t)((k) - 1))])
           ixp = ix + 1; jyp = jy + 1;
           rddx = K(1.) - ddx; rddy = K(1.) - ddy;
           p1 = rddx * rddy; p2 = ddx * rddy; p3 = rddx * ddy; p4 = ddx * ddy;
-          topo = p1 * F2(A->oro, ix, jy) + p2 * F2(A->oro, ixp, jy) + p3 * F2(A->oro, ix, jyp) + p4 * F2(A->oro, ixp, jyp);
+          topo = p1 * F2(g_oro, ix, jy) + p2 * F2(g_oro, ixp, jy) + p3 * F2(g_oro, ix, jyp) + p4 * F2(g_oro, ixp, jyp);
           if (A->kindz[i - 1] == 3) {                                       /* :231-273 */
             const real presspart = zt;
             real press, pressold = K(0.);
             int kz;
             for (kz = 1; kz <= A->nz; kz++) {
-              const real r = p1 * F3(A->rho2, ix, jy, kz) + p2 * F3(A->rho2, ixp, jy, kz) + p3 * F3(A->rho2, ix, jyp, kz) + p4 * F3(A->rho2, ixp, jyp, kz);
-              const real t = p1 * F3(A->tt2, ix, jy, kz) + p2 * F3(A->tt2, ixp, jy, kz) + p3 * F3(A->tt2, ix, jyp, kz) + p4 * F3(A->tt2, ixp, jyp, kz);
+              const real r = p1 * F3(g_rho, ix, jy, kz) + p2 * F3(g_rho, ixp, jy, kz) + p3 * F3(g_rho, ix, jyp, kz) + p4 * F3(g_rho, ixp, jyp, kz);
+              const real t = p1 * F3(g_tt, ix, jy, kz) + p2 * F3(g_tt, ixp, jy, kz) + p3 * F3(g_tt, ix, jyp, kz) + p4 * F3(g_tt, ixp, jyp, kz);
               press = r * r_air * t / K(100.);
               if (kz == 1) pressold = press;
               if (press < presspart) {
@@ -233,8 +258,8 @@ void rlo_releaseparticles(rlo_args *A, int itime) {
               if (HGT(ii) > zt) { indz = ii - 1; indzp = ii; break; }
             dz1 = zt - HGT(indz); dz2 = HGT(indzp) - zt; dz = K(1.) / (dz1 + dz2);
             for (n = 1; n <= 2; n++)
-              rhoaux[n - 1] = p1 * F3(A->rho2, ix, jy, indz + n - 1) + p2 * F3(A->rho2, ixp, jy, indz + n - 1) +
-                              p3 * F3(A->rho2, ix, jyp, indz + n - 1) + p4 * F3(A->rho2, ixp, jyp, indz + n - 1);
+              rhoaux[n - 1] = p1 * F3(g_rho, ix, jy, indz + n - 1) + p2 * F3(g_rho, ixp, jy, indz + n - 1) +
+                              p3 * F3(g_rho, ix, jyp, indz + n - 1) + p4 * F3(g_rho, ixp, jyp, indz + n - 1);
             rhoout = (dz2 * rhoaux[0] + dz1 * rhoaux[1]) * dz;
             A->rho_rel[i - 1] = (double)rhoout;
             for (k = 1; k <= nspec; k++) {

@@ -284,15 +284,16 @@ def run_co_reference(co, kind="r4", workdir="/tmp", nest=False):
 # releaseparticles + splitting through oracle/_ref/relref_rK (oracle/ref_rel_driver.f90)
 # --------------------------------------------------------------------------
 _REL_ORDER = ["grid", "geom", "xglobal", "height", "nspec", "bdate", "switches", "times", "oro", "rho2", "tt2",
+              "par_nxmax", "nest", "nestcorners", "oron", "rhon2", "ttn2",
               "numpoint", "ireleasestart", "ireleaseend", "npart_rel", "kindz", "xpoint1", "xpoint2", "ypoint1", "ypoint2",
               "zpoint1", "zpoint2", "xmass", "point_hour", "area_hour", "point_dow", "area_dow",
               "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "itrasplit", "npoint", "nclass", "idt", "uap", "xmass1"]
-_REL_INT = {"grid", "xglobal", "nspec", "bdate", "switches", "times", "numpoint", "ireleasestart", "ireleaseend", "npart_rel", "kindz",
+_REL_INT = {"par_nxmax", "nest", "grid", "xglobal", "nspec", "bdate", "switches", "times", "numpoint", "ireleasestart", "ireleaseend", "npart_rel", "kindz",
             "npart", "itra1", "itramem", "itrasplit", "npoint", "nclass", "idt"}
 
 
-def have_rel_ref(kind="r8"):
-    return os.access(os.path.join(HERE, "_ref", f"relref_{kind}"), os.X_OK)
+def have_rel_ref(kind="r8", nest=False):
+    return os.access(os.path.join(HERE, "_ref", f"relref_{kind}" + ("n" if nest else "")), os.X_OK)
 
 
 def run_rel_reference(rs, kind="r8", workdir="/tmp", gpu=False):
@@ -312,7 +313,7 @@ def run_rel_reference(rs, kind="r8", workdir="/tmp", gpu=False):
                 fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
                 fh.write(a.tobytes())
             fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
-        exe = os.path.join(HERE, "_ref", f"relref_{kind}")
+        exe = os.path.join(HERE, "_ref", f"relref_{kind}" + ("n" if "nest" in rs else ""))
         res = subprocess.run(["bash", "-c", f"ulimit -s unlimited; exec {exe} {fs} {fo}" + (" gpu" if gpu else "")], capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"reference releaseparticles driver failed: {res.stdout}\n{res.stderr}")

@@ -17,6 +17,7 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 KEYS = ("state", "xtra1", "ytra1", "ztra1", "uap", "itra1", "itramem", "itrasplit", "idt", "npoint", "nclass", "xmass1")
 
 CASES = {
+    "nested": dict(global_grid=False, nest=True, maxpart=200000),                 # release boxes inside and across a nested wind field
     "global_density": dict(),                                                      # ind_rel = 1, two species, date line
     "quasilag_mass": dict(ind_rel=0, mquasilag=1, nspec=1),                        # npoint = particle count, no density factor
     "limited_winter": dict(global_grid=False, ibdate=20201224, ibtime=233000),     # no daylight saving, day-of-week roll-over
@@ -69,6 +70,11 @@ def _engine(rs, kind, rng_mode):
     sc["tt"] = np.stack([f["tt"][0], np.asarray(rs["tt2"])])
     sc["oro"] = rs["oro"]
     sc["pv"] = np.zeros_like(sc["tt"]); sc["qv"] = np.zeros_like(sc["tt"])
+    if "nest" in rs:      # the same nested wind field for the engine: rhon of slot 2 from the release scenario
+        g = rs["nestcorners"]
+        syn.add_nest(sc, int(g[0]), int(g[1]), int(g[2]), int(g[3]), factor=int(g[4]))
+        assert tuple(sc["nest"]) == tuple(rs["nest"])
+        sc["rhon"] = np.stack([np.asarray(sc["rhon"])[0], np.asarray(rs["rhon2"])])
     n0 = int(rs.get("npart", 0))
     if n0:
         for k in ("npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "itrasplit", "npoint", "nclass", "idt", "uap", "xmass1"):
@@ -77,6 +83,8 @@ def _engine(rs, kind, rng_mode):
     sc["mquasilag"] = sw[5]
     eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=rng_mode, max_particles=sw[6])
     eng.upload_diag_fields_from_scenario(sc)
+    if "nest" in rs:
+        eng.upload_diag_nest_fields(1, rs["oron"], rs["ttn2"])
     rs = dict(rs, bdate_jul=rl_juldate(int(rs["bdate"][0]), int(rs["bdate"][1]), kind))
     eng.release_init(rs)
     return eng
@@ -162,14 +170,15 @@ def test_release_refuses_more_particles_than_storage_spaces(built):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["global_density", "nested"])
 @pytest.mark.parametrize("kind", ["r8", "r4"])
-def test_fortran_host_releaseparticles(built, kind):
+def test_fortran_host_releaseparticles(built, kind, name):
     """The real Fortran host: relref_rK either calls the reference's releaseparticles and the splitting block, or
     hands point_mod / com_mod to flexgpu_release_init / flexgpu_releaseparticles / flexgpu_split_particles and
     downloads the particle arrays -- identical, array for array."""
-    if not sio.have_rel_ref(kind):
+    if not sio.have_rel_ref(kind, nest=name == "nested"):
         pytest.skip("oracle/_ref/relref binaries not present in this snapshot")
-    rs = case("global_density")
+    rs = case(name)
     ref = sio.run_rel_reference(rs, kind)
     gpu = sio.run_rel_reference(rs, kind, gpu=True)
     for a, b in zip(gpu, ref):
