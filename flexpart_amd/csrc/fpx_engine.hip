@@ -666,6 +666,7 @@ __global__ void __launch_bounds__(kBlock) k_partoutput(View<R> V, Parts<R> P, Di
 template <typename H>
 struct RelPoints {
   const long long *first;    // [numpoint+1] exclusive prefix of numrel: particle k of this call belongs to point i with first[i] <= k < first[i+1]
+  const long long *gfirst;   // [numpoint] number, in the release count of the whole run over ALL ranks, of this rank's first particle of point i
   const H *xp1, *xaux, *yp1, *yaux, *zp1, *zaux;   // [numpoint]
   const H *mass;             // [nspec][numpoint]: xmass(i,k)/real(npart(i))*timecorrect(k)/average_timecorrect
   const short *kindz;        // [numpoint]
@@ -717,9 +718,10 @@ __global__ void __launch_bounds__(kBlock) k_release(View<R> V, Parts<R> P, DiagP
   if (uniforms) {
 #pragma unroll
     for (int d = 0; d < 4; d++) u[d] = uniforms[(size_t)d * ntotal + k];
-  } else {   // four uniforms in [0,1) keyed on (seed, number of the particle in the run's release count)
+  } else {   // four uniforms in [0,1) keyed on (seed, number of the particle in the run's release count over all ranks)
     unsigned int o[4];
-    philox4x32((unsigned int)(numparticlecount0 + k) + V.pid_base, 0x52454c45u /* "RELE" */, (unsigned int)((numparticlecount0 + k) >> 32), 0u,
+    const unsigned long long gk = (unsigned long long)(RP.gfirst[i] + (k - RP.first[i]));
+    philox4x32((unsigned int)gk, 0x52454c45u /* "RELE" */, (unsigned int)(gk >> 32), 0u,
                (unsigned int)V.seed, (unsigned int)(V.seed >> 32), o);
 #pragma unroll
     for (int d = 0; d < 4; d++) u[d] = (H)((float)(o[d] >> 8) * (1.0f / 16777216.0f));
@@ -1365,7 +1367,8 @@ struct Engine : EngineBase {
   bool wet_nest_slot[kMaxNests][2] = {};
   size_t n_grid3 = 0, n_grid2 = 0, n_grid3n = 0, n_grid2n = 0;
   ncclComm_t comm = nullptr;
-  int comm_ranks = 1;
+  int comm_ranks = 1, comm_rank = 0;
+  long long rel_global_count = 0;        // particles released so far by all ranks (key of the release's counter RNG)
   // host-supplied all-reduce (fpx_comm_init_host): the transport of an MPI host, or gloo in the tests
   fpx_allreduce_fn host_allreduce = nullptr;
   void *host_allreduce_user = nullptr;
@@ -2380,7 +2383,8 @@ struct Engine : EngineBase {
     const double julmonday = jul_of<H>(19000101, 0);
     double jul = rel.bdate + (double)itime / 86400.;
     { const int mm = month_of<H>(jul); if (mm >= 4 && mm <= 9) jul = jul + 1. / 24.; }
-    std::vector<long long> first(np + 1, 0);
+    std::vector<long long> first(np + 1, 0), gfirst(np, 0);
+    long long gcount = rel_global_count;
     std::vector<H> mass((size_t)ns * np, (H)0), xp1(np), xaux(np), yp1(np), yaux(np), zp1(np), zaux(np);
     bool any_p3 = false;
     for (int i = 0; i < np; i++) {
@@ -2418,11 +2422,23 @@ struct Engine : EngineBase {
         for (int k = 0; k < ns; k++) mass[(size_t)k * np + i] = (H)rel_xmass_h[(size_t)k * np + i] / (H)rel_npart_h[i] * tc[k] / avg;
         if (numrel > 0 && rel.kindz[i] == 3) any_p3 = true;
       }
-      first[i + 1] = first[i] + std::max<long long>(numrel, 0);
+      // several ranks (releaseparticles_mpi.f90:139-162): every rank takes numrel / nranks particles of the point, the first
+      // mod(numrel, nranks) ranks one more; the particles of all ranks together are those of the single-rank run (the counter
+      // RNG is keyed on the particle's number in the release count of the whole run)
+      long long numrel_all = std::max<long long>(numrel, 0), roff = 0;
+      numrel = numrel_all;
+      if (comm_ranks > 1) {
+        const long long base = numrel_all / comm_ranks, rem = numrel_all % comm_ranks;
+        numrel = base + (comm_rank < rem ? 1 : 0);
+        roff = (long long)comm_rank * base + std::min<long long>(comm_rank, rem);
+      }
+      gfirst[i] = gcount + roff;
+      gcount += numrel_all;
+      first[i + 1] = first[i] + numrel;
     }
     const long long ntotal = first[np];
     if (nreleased) *nreleased = ntotal;
-    if (ntotal == 0) return 0;
+    if (ntotal == 0) { rel_global_count = gcount; return 0; }
     const bool dens = rel.ind_rel == 1 || rel.ind_rel == 3 || rel.ind_rel == 4;
     for (int l = 0; l < V.numbnests; l++) {
       if (!rel_nest_oro[l]) return fail(FPX_ERR_STATE, "releaseparticles: oron of every nest is needed (fpx_upload_diag_nest_fields slot 0)");
@@ -2439,7 +2455,7 @@ struct Engine : EngineBase {
     auto cleanup = [&]() { for (void *q : mine) (void)hipFree(q); };
     auto mal = [&](auto **q, size_t n) -> hipError_t { hipError_t e = hipMalloc((void **)q, std::max<size_t>(n, 1) * sizeof(**q)); if (e == hipSuccess) mine.push_back(*q); return e; };
     unsigned int *flags = nullptr, *rank = nullptr, *target = nullptr, *d_max = nullptr;
-    long long *d_first = nullptr;
+    long long *d_first = nullptr, *d_gfirst = nullptr;
     H *d_pts = nullptr, *d_mass = nullptr, *d_uni = nullptr, *d_rho = nullptr;
     short *d_kindz = nullptr;
     void *tmp = nullptr;
@@ -2448,6 +2464,7 @@ struct Engine : EngineBase {
     if (e == hipSuccess) e = mal(&target, (size_t)ntotal);
     if (e == hipSuccess) e = mal(&d_max, 1);
     if (e == hipSuccess) e = mal(&d_first, (size_t)np + 1);
+    if (e == hipSuccess) e = mal(&d_gfirst, (size_t)np);
     if (e == hipSuccess) e = mal(&d_pts, (size_t)6 * np);
     if (e == hipSuccess) e = mal(&d_mass, (size_t)ns * np);
     if (e == hipSuccess) e = mal(&d_kindz, (size_t)np);
@@ -2486,13 +2503,14 @@ struct Engine : EngineBase {
     std::vector<H> rho_h(np, (H)0);
     if (rho_rel) for (int i = 0; i < np; i++) rho_h[i] = rho_rel[i];
     if (e == hipSuccess) e = hipMemcpyAsync(d_first, first.data(), (np + 1) * sizeof(long long), hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_gfirst, gfirst.data(), np * sizeof(long long), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_pts, pts.data(), pts.size() * sizeof(H), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_mass, mass.data(), mass.size() * sizeof(H), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_kindz, rel.kindz.data(), np * sizeof(short), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_rho, rho_h.data(), np * sizeof(H), hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, 4, stream);
     if (e != hipSuccess) { (void)hipStreamSynchronize(stream); cleanup(); return fail(FPX_ERR_DEVICE, std::string("releaseparticles: ") + hipGetErrorString(e)); }
-    RelPoints<H> RP{d_first, d_pts, d_pts + np, d_pts + 2 * np, d_pts + 3 * np, d_pts + 4 * np, d_pts + 5 * np, d_mass, d_kindz, np};
+    RelPoints<H> RP{d_first, d_gfirst, d_pts, d_pts + np, d_pts + 2 * np, d_pts + 3 * np, d_pts + 4 * np, d_pts + 5 * np, d_mass, d_kindz, np};
     DiagP<H> D;
     D.oro = (const H *)diag_oro; D.tropo[0] = (const H *)diag_tropo[0]; D.tropo[1] = (const H *)diag_tropo[1]; D.d3 = (const H *)diag_d3;
     D.nxmax = cfg.nxmax; D.nymax = cfg.nymax; D.dx = (H)cfg.dx; D.dy = (H)cfg.dy; D.xlon0 = (H)cfg.xlon0; D.ylat0 = (H)cfg.ylat0;
@@ -2519,6 +2537,7 @@ struct Engine : EngineBase {
     numpart = std::max<long long>(numpart, (long long)maxpid + 1);          // :362
     *numpart_io = numpart;
     *npc_io = (int32_t)(*npc_io + ntotal);
+    rel_global_count = gcount;
     maybe_new = true;
     return 0;
   }
@@ -3248,6 +3267,7 @@ struct Engine : EngineBase {
     int32_t itime, numparticlecount, reserved;
     uint64_t n_grid3, n_grid2, n_grid3n, n_grid2n, n_receptor, rng_bytes;
     uint64_t cbase_bytes;        // conv_mod cbaseflux (the convection scheme relaxes it from call to call)
+    int64_t rel_global_count;    // particles released so far by all ranks
   };
   static constexpr long long kCkptChunk = 1ll << 22;
   template <typename T>
@@ -3315,6 +3335,7 @@ struct Engine : EngineBase {
     h.n_receptor = Gp.creceptor ? (uint64_t)Gp.numreceptor * cfg.maxspec : 0;
     h.rng_bytes = sizeof(CkptRng);
     h.cbase_bytes = conv_cbase_bytes();
+    h.rel_global_count = rel_global_count;
     if (fwrite(&h, sizeof(h), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
     CkptRng rs{rng4, rng8, rel_ran1};
     if (fwrite(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
@@ -3392,6 +3413,7 @@ struct Engine : EngineBase {
     for (bool &v : red_valid) v = false;
     rng4 = rs.r4; rng8 = rs.r8; rel_ran1 = rs.rel;
     step_counter = h.step_counter;
+    rel_global_count = h.rel_global_count;
     numpart = n;
     maybe_new = true;
     if (itime) *itime = h.itime;
@@ -3969,7 +3991,7 @@ struct Engine : EngineBase {
     if (nranks < 1 || rank < 0 || rank >= nranks || !fn) return fail(FPX_ERR_ARG, "comm_init_host: bad argument");
     if (comm || host_allreduce) return fail(FPX_ERR_STATE, "comm_init_host: communicator exists");
     host_allreduce = fn; host_allreduce_user = user;
-    comm_ranks = nranks;
+    comm_ranks = nranks; comm_rank = rank;
     return 0;
   }
   int comm_init(const void *id, int nbytes, int nranks, int rank) override {
@@ -3980,7 +4002,7 @@ struct Engine : EngineBase {
     HIPCHK(hipSetDevice(cfg.device));
     ncclResult_t r = ncclCommInitRank(&comm, nranks, uid, rank);
     if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r));
-    comm_ranks = nranks;
+    comm_ranks = nranks; comm_rank = rank;
     return 0;
   }
   int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) override {

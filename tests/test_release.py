@@ -184,3 +184,45 @@ def test_fortran_host_releaseparticles(built, kind, name):
     for a, b in zip(gpu, ref):
         for k in KEYS:
             assert np.array_equal(a[k], b[k]), (kind, b["state"], k)
+
+
+@pytest.mark.gpu
+def test_release_split_over_ranks_gives_the_single_rank_particles(built):
+    """Several ranks (releaseparticles_mpi.f90:139-162): every rank releases numrel / nranks particles of a point, the first
+    mod(numrel, nranks) ranks one more.  With the counter RNG keyed on the particle's number in the release count of the whole
+    run, the particles of the two ranks together are exactly the particles of the single-rank run (positions, masses, release
+    point), call after call, also for the interval releases whose fractional remainder xmasssave carries over."""
+    import ctypes as C
+    from flexpart_amd.engine import RNG_PHILOX
+    from flexpart_amd._lib import ALLREDUCE_FN, check
+    rs = case("quasilag_mass")
+    rs = dict(rs, switches=np.asarray(rs["switches"]).copy())
+    rs["switches"][5] = 0                      # npoint = release point (not the per-rank running count)
+    noop = ALLREDUCE_FN(lambda user, send, recv, count, dtype: 0)
+
+    def run(nranks, rank):
+        eng = _engine(rs, "r8", RNG_PHILOX)
+        if nranks > 1:
+            check(eng.lib.fpx_comm_init_host(eng.h, nranks, rank, noop, None), "fpx_comm_init_host")
+        rows = []
+        n_before = eng.n
+        for itime in (int(t) for t in rs["times"][:3]):
+            eng.releaseparticles(itime)
+            got = eng.download()
+            new = np.arange(eng.n) >= n_before
+            new |= (got["itramem"] == itime) & (got["itra1"] == itime)
+            sel = (got["itramem"] == itime)
+            rows.append(np.stack([got["npoint"][sel].astype(np.float64), got["xtra1"][sel], got["ytra1"][sel], got["ztra1"][sel].astype(np.float64),
+                                  got["xmass1"][0][sel].astype(np.float64)], axis=1))
+        eng.close()
+        return rows
+
+    one = run(1, 0)
+    two = [run(2, 0), run(2, 1)]
+    for ic in range(3):
+        a = one[ic]
+        b = np.concatenate([two[0][ic], two[1][ic]])
+        assert len(a) == len(b) > 100 and abs(len(two[0][ic]) - len(two[1][ic])) <= int(rs["numpoint"])
+        a = a[np.lexsort(a.T[::-1])]
+        b = b[np.lexsort(b.T[::-1])]
+        assert np.array_equal(a, b), ic
