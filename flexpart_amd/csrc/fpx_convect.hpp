@@ -3,17 +3,21 @@
 // branch), convect43c.f90 (Emanuel's scheme CONVECT + TLIFT as the reference ships it), redist.f90:49-236 (the
 // displacement of a particle) -- as HIP kernels for gfx950.
 //
-// Design.  The scheme is a long, strictly sequential computation per grid column (level loops with data-dependent
-// bounds, O(levels^2) matrices) and only columns that hold particles are computed, so the parallel axis is the column:
-//   k_conv_mark    one lane per particle: its column (nint of the grid coordinates), a flag per column
-//   (scan)         the columns that hold particles, in grid order
-//   k_conv_column  one lane per such column: profiles at the particle time, CONVECT, the matrix fmassfrac, the heights
-//                  of the half levels.  All per-column arrays (35 vectors, 5 matrices) live in HBM scratch interleaved
-//                  by column -- element e of column c at [e * B + c] -- so that the lanes of a wave, which walk the same
-//                  loops, touch one contiguous segment per access.  Columns are processed in batches of B that fit the
-//                  scratch budget.
-//   k_conv_redist  one lane per particle of a convective column: level search, one uniform random number, the walk
-//                  along its matrix row, new height or the compensating subsidence.
+// Design.  The scheme is a long computation per grid column (level loops with data-dependent bounds, O(levels^2)
+// matrices) and only columns that hold particles are computed:
+//   k_conv_mark      one lane per particle: its column (nint of the grid coordinates), a flag per column
+//   (scan)           the columns that hold particles, in grid order
+//   k_conv_column_a  one lane per such column: profiles at the particle time, CONVECT up to its early exits
+//   (scan)           the columns that go on
+//   k_conv_prelude, k_conv_rows, k_conv_cols, k_conv_flux, k_conv_matrix
+//                    the mixing part of CONVECT, the matrix fmassfrac and the heights of the half levels: the part that is
+//                    sequential along the sounding with a lane per column, the matrices with a lane per (column, level)
+//                    (k_conv_column_b: all of it with one lane per column -- the check of the level kernels)
+//   k_conv_redist    one lane per particle of a convective column: level search, one uniform random number, the walk
+//                    along its matrix row, new height or the compensating subsidence.
+// All per-column arrays (26 vectors, 3 matrices) live in HBM scratch interleaved in groups of 64 columns (struct Scr), so
+// that the lanes of a wave, which walk the same loops, touch one contiguous segment per access.  The matrices exist for
+// batches of surviving columns that fit the scratch budget.
 // Arithmetic is in the host's real kind H (the reference computes in its default real) with FMA contraction off and
 // in the reference's order of operations; only libm (exp, log, pow) can differ from the CPU result.
 #pragma once
@@ -40,19 +44,28 @@ enum Vec { V_fup, V_fdown, V_m, V_tvp, V_tv, V_ep, V_clw, V_sigp, V_tp, V_cpn, V
 enum Mat { M_fmass, M_ment, M_sij, M_COUNT };
 constexpr int M_fmassfrac = M_fmass;      // calcmatrix scales fmass into fmassfrac in place
 
+// Scratch layout: columns are interleaved in groups of kGroup = 64 (one wave): element e of column c lives at
+// [(c / 64) * elems_per_column * 64 + e * 64 + c % 64].  The lanes of a wave, which walk the same loops, touch one 256 / 512
+// byte segment per access, and all arrays of a group lie within a few MB (29 MB for the three fp64 matrices of 138 levels)
+// -- interleaving over the whole batch instead put consecutive levels 32 MB apart and every access on another page.
+constexpr int kGroup = 64;
 template <typename H>
 struct Scr {
-  H *v;          // [V_COUNT][nv][B]: every column that holds particles
-  H *mat;        // [M_COUNT][nv][nv][Bm], column-major A(i,j) -> [j][i]: only the columns that reach the mixing computation
-  int B, c, nv;
-  int Bm, cm;    // matrix batch size and this column's slot in it
+  H *vb;         // this column's element 0 of the vectors  [group][V_COUNT][nv][64]: every column that holds particles
+  H *mb;         // this column's element 0 of the matrices [group][M_COUNT][nv][nv][64], column-major A(i,j) -> [j][i]: only
+                 // the columns that reach the mixing computation
+  int nv;
+  __device__ Scr(H *v, H *mat, int /*B*/, int c, int nv_, int /*Bm*/, int cm)
+      : vb(v + (size_t)(c / kGroup) * V_COUNT * nv_ * kGroup + (c % kGroup)),
+        mb(mat ? mat + (size_t)(cm / kGroup) * M_COUNT * nv_ * nv_ * kGroup + (cm % kGroup) : nullptr), nv(nv_) {}
 };
 // what the first part of CONVECT (up to its early exits) hands to the second
 template <typename H>
 struct CvState { int nk, icb, inb, iflag; H plcl, cbmf; };
-#define VV(name, i) Sx.v[((size_t)V_##name * Sx.nv + (size_t)(i)) * Sx.B + Sx.c]
-#define MM(name, i, j) Sx.mat[(((size_t)M_##name * Sx.nv + (size_t)(j)) * Sx.nv + (size_t)(i)) * Sx.Bm + Sx.cm]
+#define VV(name, i) Sx.vb[((size_t)V_##name * Sx.nv + (size_t)(i)) * kGroup]
+#define MM(name, i, j) Sx.mb[(((size_t)M_##name * Sx.nv + (size_t)(j)) * Sx.nv + (size_t)(i)) * kGroup]
 
+__host__ __device__ inline size_t group_round(size_t n) { return (n + kGroup - 1) / kGroup * kGroup; }   // columns of whole groups
 template <typename H>
 __host__ __device__ inline size_t vec_elems_per_column(int nv) { return (size_t)V_COUNT * nv; }
 template <typename H>
@@ -104,8 +117,264 @@ __device__ void tlift(const Scr<H> &Sx, int icb, int nk, int nl, int kk) {
 }
 
 
+// The two row-wise parts of the mixing computation, convect43c.f90:590-655 and :660-720: row i of SIJ / MENT depends on
+// the column's vectors only, never on another row -- the serial kernel calls them in loops over i, the parallel one
+// gives every row its own lane.  The operands of kJ consecutive j are requested together; the arithmetic of each j is
+// the reference's.
+constexpr int kJ = 8;
+template <typename H>
+__device__ void sij_row(const Scr<H> &Sx, int nk, int icb, int inb, int i) {
+#pragma clang fp contract(off)
+  const H cpd = HK(1005.7), cpv = HK(1870.0), rv = HK(461.5);
+  H qti, bf2, anum, denom, dei, altem, cwat, stemp;
+  int j;
+  // MENT is assigned in rows icb+1..inb, columns icb..inb only, SIJ read one column beyond on either side: the reference
+  // zeroes (nl+1)^2 elements of five matrices per column, here the region that is read is zeroed (adding the exact zeros of
+  // the rest changes no sum)
+  for (j = icb - 1; j <= inb + 1; j++) {
+    MM(sij, i, j) = HK(0.0);
+    if (j >= icb && j <= inb) MM(ment, i, j) = HK(0.0);
+  }
+    qti = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+    const H h_i = VV(h, i), hp_i = VV(hp, i), qc_i = VV(qconv, i), m_i = VV(m, i);
+    int nent_i = 0;
+    for (j = icb; j <= inb; j += kJ) {
+      H lvj[kJ], qsj[kJ], tcj[kJ], hj[kJ], qcj[kJ], clwj[kJ], epj[kJ];
+#pragma unroll
+      for (int u = 0; u < kJ; u++) {
+        const int jj = I_MIN(j + u, inb);
+        lvj[u] = VV(lv, jj); qsj[u] = VV(qsconv, jj); tcj[u] = VV(tconv, jj); hj[u] = VV(h, jj); qcj[u] = VV(qconv, jj);
+        clwj[u] = VV(clw, jj); epj[u] = VV(ep, jj);
+      }
+#pragma unroll
+      for (int u = 0; u < kJ; u++) {
+        const int jj = j + u;
+        if (jj > inb) break;
+        bf2 = HK(1.) + lvj[u] * lvj[u] * qsj[u] / (rv * tcj[u] * tcj[u] * cpd);
+        anum = hj[u] - hp_i + (cpv - cpd) * tcj[u] * (qti - qcj[u]);
+        denom = h_i - hp_i + (cpd - cpv) * (qc_i - qti) * tcj[u];
+        dei = denom;
+        if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
+        H sv = anum / dei;
+        if (jj == i) sv = HK(1.0);                      // SIJ(I,I)=1.0 is set inside the j loop of the reference (:604)
+        altem = sv * qc_i + (HK(1.) - sv) * qti - qsj[u];
+        altem = altem / bf2;
+        cwat = clwj[u] * (HK(1.) - epj[u]);
+        stemp = sv;
+        if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && jj > i) {
+          anum = anum - lvj[u] * (qti - qsj[u] - cwat * bf2);
+          denom = denom + lvj[u] * (qc_i - qti);
+          if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+          sv = anum / denom;
+        }
+        if (sv > HK(0.0) && sv < HK(0.9)) {
+          MM(ment, i, jj) = m_i / (HK(1.) - sv);
+          nent_i = nent_i + 1;
+        }
+        sv = R_MAX(HK(0.0), sv);
+        sv = R_MIN(HK(1.0), sv);
+        MM(sij, i, jj) = sv;
+      }
+    }
+    VV(nent, i) = (H)nent_i;
+    if (nent_i == 0) {
+      MM(ment, i, i) = m_i;
+      MM(sij, i, i) = HK(1.0);
+    }
+}
+
+template <typename H>
+__device__ void norm_row(const Scr<H> &Sx, int nk, int icb, int inb, int i) {
+#pragma clang fp contract(off)
+  H qp1, anum, denom, scrit, alt, asij, smin, smid, sjmax, sjmin, delp, delm, bsum;
+  int j;
+    if (VV(nent, i) != 0) {
+      qp1 = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+      anum = VV(h, i) - VV(hp, i) - VV(lv, i) * (qp1 - VV(qsconv, i));
+      denom = VV(h, i) - VV(hp, i) + VV(lv, i) * (VV(qconv, i) - qp1);
+      if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+      scrit = anum / denom;
+      alt = qp1 - VV(qsconv, i) + scrit * (VV(qconv, i) - qp1);
+      if (alt < HK(0.0)) scrit = HK(1.0);
+      scrit = R_MAX(scrit, HK(0.0));
+      asij = HK(0.0);
+      smin = HK(1.0);
+      for (j = icb; j <= inb; j += kJ) {
+        H sw[kJ + 2], me[kJ], ph[kJ + 1];                // SIJ(i, j-1 .. j+kJ), MENT(i, j .. j+kJ-1), PHCONV_HPA(j .. j+kJ)
+#pragma unroll
+        for (int u = 0; u < kJ + 2; u++) sw[u] = MM(sij, i, I_MIN(j - 1 + u, inb + 1));
+#pragma unroll
+        for (int u = 0; u < kJ; u++) me[u] = MM(ment, i, I_MIN(j + u, inb));
+#pragma unroll
+        for (int u = 0; u < kJ + 1; u++) ph[u] = VV(phconv_hpa, I_MIN(j + u, inb + 1));
+#pragma unroll
+        for (int u = 0; u < kJ; u++) {
+          const int jj = j + u;
+          if (jj > inb) break;
+          const H s0 = sw[u], s1 = sw[u + 1], s2 = sw[u + 2];      // SIJ(i,jj-1), SIJ(i,jj), SIJ(i,jj+1)
+          if (s1 > HK(0.0) && s1 < HK(0.9)) {
+            if (jj > i) {
+              smid = R_MIN(s1, scrit);
+              sjmax = smid;
+              sjmin = smid;
+              if (smid < smin && s2 < smid) {
+                smin = smid;
+                sjmax = R_MIN(R_MIN(s2, s1), scrit);
+                sjmin = R_MAX(s0, s1);
+                sjmin = R_MIN(sjmin, scrit);
+              }
+            } else {
+              sjmax = R_MAX(s2, scrit);
+              smid = R_MAX(s1, scrit);
+              sjmin = HK(0.0);
+              if (jj > 1) sjmin = s0;
+              sjmin = R_MAX(sjmin, scrit);
+            }
+            delp = R_ABS(sjmax - smid);
+            delm = R_ABS(sjmin - smid);
+            asij = asij + (delp + delm) * (ph[u] - ph[u + 1]);
+            MM(ment, i, jj) = me[u] * (delp + delm) * (ph[u] - ph[u + 1]);
+          }
+        }
+      }
+      asij = R_MAX(HK(1.0e-21), asij);
+      asij = HK(1.0) / asij;
+      bsum = HK(0.0);
+      for (j = icb; j <= inb; j += 8) {
+        H me[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (j + u <= inb) { const H v = me[u] * asij; MM(ment, i, j + u) = v; bsum = bsum + v; }
+      }
+      if (bsum < HK(1.0e-18)) {
+        VV(nent, i) = 0;
+        MM(ment, i, i) = VV(m, i);
+        MM(sij, i, i) = HK(1.0);
+      }
+    }
+}
+
+// sij_row + norm_row in one sweep over j, for the level-parallel path: SIJ(i, .) is consumed by the normalisation of the
+// same row only (a window of three neighbours), so it stays in registers -- the normalisation of entry j-1 follows the
+// mixing fraction of entry j -- and MENT is written once before the final scaling instead of being written, re-read and
+// rewritten: 24 instead of 56 bytes of HBM traffic per matrix entry (fp64).  A row without entrainment (nent = 0) has no
+// SIJ in (0, 0.9), hence nothing for the normalisation to act on: running it unconditionally changes nothing.  Same
+// operations on the same operands in the same order as the two functions above.
+template <typename H>
+__device__ void mix_row(const Scr<H> &Sx, int nk, int icb, int inb, int i) {
+#pragma clang fp contract(off)
+  const H cpd = HK(1005.7), cpv = HK(1870.0), rv = HK(461.5);
+  H bf2, anum, denom, dei, altem, cwat, stemp, scrit, alt, asij, smin, smid, sjmax, sjmin, delp, delm, bsum;
+  const H qti = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+  const H h_i = VV(h, i), hp_i = VV(hp, i), qc_i = VV(qconv, i), m_i = VV(m, i), lv_i = VV(lv, i), qs_i = VV(qsconv, i);
+  anum = h_i - hp_i - lv_i * (qti - qs_i);
+  denom = h_i - hp_i + lv_i * (qc_i - qti);
+  if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+  scrit = anum / denom;
+  alt = qti - qs_i + scrit * (qc_i - qti);
+  if (alt < HK(0.0)) scrit = HK(1.0);
+  scrit = R_MAX(scrit, HK(0.0));
+  asij = HK(0.0);
+  smin = HK(1.0);
+  int nent_i = 0;
+  H s_a = HK(0.), s_b = HK(0.), me_b = HK(0.);            // SIJ(i,jj-2), SIJ(i,jj-1), MENT(i,jj-1) before the normalisation
+  for (int j = icb; j <= inb + 1; j += kJ) {
+    H lvj[kJ], qsj[kJ], tcj[kJ], hj[kJ], qcj[kJ], clwj[kJ], epj[kJ], ph[kJ + 1];
+#pragma unroll
+    for (int u = 0; u < kJ; u++) {
+      const int jj = I_MIN(j + u, inb);
+      lvj[u] = VV(lv, jj); qsj[u] = VV(qsconv, jj); tcj[u] = VV(tconv, jj); hj[u] = VV(h, jj); qcj[u] = VV(qconv, jj);
+      clwj[u] = VV(clw, jj); epj[u] = VV(ep, jj);
+    }
+#pragma unroll
+    for (int u = 0; u < kJ + 1; u++) ph[u] = VV(phconv_hpa, I_MIN(j - 1 + u, inb + 1));      // PHCONV_HPA(j-1 .. j+kJ-1)
+#pragma unroll
+    for (int u = 0; u < kJ; u++) {
+      const int jj = j + u;
+      if (jj > inb + 1) break;
+      H sv = HK(0.), me = HK(0.);
+      if (jj <= inb) {
+        bf2 = HK(1.) + lvj[u] * lvj[u] * qsj[u] / (rv * tcj[u] * tcj[u] * cpd);
+        anum = hj[u] - hp_i + (cpv - cpd) * tcj[u] * (qti - qcj[u]);
+        denom = h_i - hp_i + (cpd - cpv) * (qc_i - qti) * tcj[u];
+        dei = denom;
+        if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
+        sv = anum / dei;
+        if (jj == i) sv = HK(1.0);
+        altem = sv * qc_i + (HK(1.) - sv) * qti - qsj[u];
+        altem = altem / bf2;
+        cwat = clwj[u] * (HK(1.) - epj[u]);
+        stemp = sv;
+        if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && jj > i) {
+          anum = anum - lvj[u] * (qti - qsj[u] - cwat * bf2);
+          denom = denom + lvj[u] * (qc_i - qti);
+          if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+          sv = anum / denom;
+        }
+        if (sv > HK(0.0) && sv < HK(0.9)) {
+          me = m_i / (HK(1.) - sv);
+          nent_i = nent_i + 1;
+        }
+        sv = R_MAX(HK(0.0), sv);
+        sv = R_MIN(HK(1.0), sv);
+      }
+      if (jj > icb) {                                      // normalisation of entry jn = jj - 1
+        const int jn = jj - 1;
+        const H s0 = s_a, s1 = s_b, s2 = sv;
+        H out = me_b;
+        if (s1 > HK(0.0) && s1 < HK(0.9)) {
+          if (jn > i) {
+            smid = R_MIN(s1, scrit);
+            sjmax = smid;
+            sjmin = smid;
+            if (smid < smin && s2 < smid) {
+              smin = smid;
+              sjmax = R_MIN(R_MIN(s2, s1), scrit);
+              sjmin = R_MAX(s0, s1);
+              sjmin = R_MIN(sjmin, scrit);
+            }
+          } else {
+            sjmax = R_MAX(s2, scrit);
+            smid = R_MAX(s1, scrit);
+            sjmin = HK(0.0);
+            if (jn > 1) sjmin = s0;
+            sjmin = R_MAX(sjmin, scrit);
+          }
+          delp = R_ABS(sjmax - smid);
+          delm = R_ABS(sjmin - smid);
+          asij = asij + (delp + delm) * (ph[u] - ph[u + 1]);
+          out = me_b * (delp + delm) * (ph[u] - ph[u + 1]);
+        }
+        MM(ment, i, jn) = out;
+      }
+      s_a = s_b; s_b = sv; me_b = me;
+    }
+  }
+  if (nent_i == 0) {
+    VV(nent, i) = 0;
+    MM(ment, i, i) = m_i;
+    return;
+  }
+  asij = R_MAX(HK(1.0e-21), asij);
+  asij = HK(1.0) / asij;
+  bsum = HK(0.0);
+  for (int j = icb; j <= inb; j += 8) {
+    H me[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (j + u <= inb) { const H v = me[u] * asij; MM(ment, i, j + u) = v; bsum = bsum + v; }
+  }
+  if (bsum < HK(1.0e-18)) { nent_i = 0; MM(ment, i, i) = m_i; }
+  VV(nent, i) = (H)nent_i;
+}
+
 // PHASE 1: up to the early exits (:79-~420: sounding, lifting condensation level, first TLIFT); returns whether the mixing
-// computation is needed.  PHASE 2: the rest, with the matrices.  (TH, computed and never used by the scheme, is left out.)
+// computation is needed.  PHASE 2: the rest, with the matrices.  PHASE 3: the rest up to the normalised M (the part that is
+// sequential along the column); returns whether the column goes on.  (TH, computed and never used by the scheme, is left out.)
 template <typename H, int PHASE>
 __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &nconvtop_) {
 #pragma clang fp contract(off)
@@ -203,14 +472,6 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   }
   inb = I_MAX(inb, inb1);
   st.inb = inb;
-  // MENT is assigned in rows icb+1..inb, columns icb..inb only, SIJ read one column beyond on either side: the reference
-  // zeroes (nl+1)^2 elements of five matrices per column, here the region that is read is zeroed (adding the exact zeros of
-  // the rest changes no sum)
-  for (i = icb + 1; i <= inb; i++)
-    for (j = icb - 1; j <= inb + 1; j++) {
-      MM(sij, i, j) = HK(0.0);
-      if (j >= icb && j <= inb) MM(ment, i, j) = HK(0.0);
-    }
   cape = capem + byp;
   defrac = capem - cape;
   defrac = R_MAX(defrac, HK(0.001));
@@ -240,135 +501,20 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
     VV(m, i) = cbmf * dbo;
   }
   for (i = icb + 1; i <= inb; i++) VV(m, i) = VV(m, i) / dbosum;
-  // (in this and the next loop nest the operands of kJ consecutive j are requested together -- the kernel runs one wave per SIMD
-  // at most, registers are plentiful, memory latency is what it waits for; the arithmetic of each j is the reference's)
-  constexpr int kJ = 8;
-  for (i = icb + 1; i <= inb; i++) {
-    qti = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
-    const H h_i = VV(h, i), hp_i = VV(hp, i), qc_i = VV(qconv, i), m_i = VV(m, i);
-    int nent_i = 0;
-    for (j = icb; j <= inb; j += kJ) {
-      H lvj[kJ], qsj[kJ], tcj[kJ], hj[kJ], qcj[kJ], clwj[kJ], epj[kJ];
-#pragma unroll
-      for (int u = 0; u < kJ; u++) {
-        const int jj = I_MIN(j + u, inb);
-        lvj[u] = VV(lv, jj); qsj[u] = VV(qsconv, jj); tcj[u] = VV(tconv, jj); hj[u] = VV(h, jj); qcj[u] = VV(qconv, jj);
-        clwj[u] = VV(clw, jj); epj[u] = VV(ep, jj);
-      }
-#pragma unroll
-      for (int u = 0; u < kJ; u++) {
-        const int jj = j + u;
-        if (jj > inb) break;
-        bf2 = HK(1.) + lvj[u] * lvj[u] * qsj[u] / (rv * tcj[u] * tcj[u] * cpd);
-        anum = hj[u] - hp_i + (cpv - cpd) * tcj[u] * (qti - qcj[u]);
-        denom = h_i - hp_i + (cpd - cpv) * (qc_i - qti) * tcj[u];
-        dei = denom;
-        if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
-        H sv = anum / dei;
-        if (jj == i) sv = HK(1.0);                      // SIJ(I,I)=1.0 is set inside the j loop of the reference (:604)
-        altem = sv * qc_i + (HK(1.) - sv) * qti - qsj[u];
-        altem = altem / bf2;
-        cwat = clwj[u] * (HK(1.) - epj[u]);
-        stemp = sv;
-        if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && jj > i) {
-          anum = anum - lvj[u] * (qti - qsj[u] - cwat * bf2);
-          denom = denom + lvj[u] * (qc_i - qti);
-          if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
-          sv = anum / denom;
-        }
-        if (sv > HK(0.0) && sv < HK(0.9)) {
-          MM(ment, i, jj) = m_i / (HK(1.) - sv);
-          nent_i = nent_i + 1;
-        }
-        sv = R_MAX(HK(0.0), sv);
-        sv = R_MIN(HK(1.0), sv);
-        MM(sij, i, jj) = sv;
-      }
-    }
-    VV(nent, i) = (H)nent_i;
-    if (nent_i == 0) {
-      MM(ment, i, i) = m_i;
-      MM(sij, i, i) = HK(1.0);
-    }
-  }
-  MM(sij, inb, inb) = HK(1.0);
-  for (i = icb + 1; i <= inb; i++) {
-    if (VV(nent, i) != 0) {
-      qp1 = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
-      anum = VV(h, i) - VV(hp, i) - VV(lv, i) * (qp1 - VV(qsconv, i));
-      denom = VV(h, i) - VV(hp, i) + VV(lv, i) * (VV(qconv, i) - qp1);
-      if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
-      scrit = anum / denom;
-      alt = qp1 - VV(qsconv, i) + scrit * (VV(qconv, i) - qp1);
-      if (alt < HK(0.0)) scrit = HK(1.0);
-      scrit = R_MAX(scrit, HK(0.0));
-      asij = HK(0.0);
-      smin = HK(1.0);
-      for (j = icb; j <= inb; j += kJ) {
-        H sw[kJ + 2], me[kJ], ph[kJ + 1];                // SIJ(i, j-1 .. j+kJ), MENT(i, j .. j+kJ-1), PHCONV_HPA(j .. j+kJ)
-#pragma unroll
-        for (int u = 0; u < kJ + 2; u++) sw[u] = MM(sij, i, I_MIN(j - 1 + u, inb + 1));
-#pragma unroll
-        for (int u = 0; u < kJ; u++) me[u] = MM(ment, i, I_MIN(j + u, inb));
-#pragma unroll
-        for (int u = 0; u < kJ + 1; u++) ph[u] = VV(phconv_hpa, I_MIN(j + u, inb + 1));
-#pragma unroll
-        for (int u = 0; u < kJ; u++) {
-          const int jj = j + u;
-          if (jj > inb) break;
-          const H s0 = sw[u], s1 = sw[u + 1], s2 = sw[u + 2];      // SIJ(i,jj-1), SIJ(i,jj), SIJ(i,jj+1)
-          if (s1 > HK(0.0) && s1 < HK(0.9)) {
-            if (jj > i) {
-              smid = R_MIN(s1, scrit);
-              sjmax = smid;
-              sjmin = smid;
-              if (smid < smin && s2 < smid) {
-                smin = smid;
-                sjmax = R_MIN(R_MIN(s2, s1), scrit);
-                sjmin = R_MAX(s0, s1);
-                sjmin = R_MIN(sjmin, scrit);
-              }
-            } else {
-              sjmax = R_MAX(s2, scrit);
-              smid = R_MAX(s1, scrit);
-              sjmin = HK(0.0);
-              if (jj > 1) sjmin = s0;
-              sjmin = R_MAX(sjmin, scrit);
-            }
-            delp = R_ABS(sjmax - smid);
-            delm = R_ABS(sjmin - smid);
-            asij = asij + (delp + delm) * (ph[u] - ph[u + 1]);
-            MM(ment, i, jj) = me[u] * (delp + delm) * (ph[u] - ph[u + 1]);
-          }
-        }
-      }
-      asij = R_MAX(HK(1.0e-21), asij);
-      asij = HK(1.0) / asij;
-      bsum = HK(0.0);
-      for (j = icb; j <= inb; j += 8) {
-        H me[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
-#pragma unroll
-        for (int u = 0; u < 8; u++)
-          if (j + u <= inb) { const H v = me[u] * asij; MM(ment, i, j + u) = v; bsum = bsum + v; }
-      }
-      if (bsum < HK(1.0e-18)) {
-        VV(nent, i) = 0;
-        MM(ment, i, i) = VV(m, i);
-        MM(sij, i, i) = HK(1.0);
-      }
-    }
-  }
-  // (the precipitation / unsaturated-downdraught part, :686-790, and the tendencies FT, FQ with their entropy correction,
-  // :800-900, feed PRECIP, WD, TPRIME, QPRIME, FT, FQ only: nothing of that reaches the particles -- left out, together
-  // with the matrices QENT and ELIJ they alone read)
+  // FUP(1), :800-810 (needs M only; the reference has it after the two loop nests below)
   dpinv = HK(0.01) / (VV(phconv_hpa, 1) - VV(phconv_hpa, 2));
   am = HK(0.0);
   if (nk == 1)
     for (k = 2; k <= inb; k++) am = am + VV(m, k);
   VV(fup, 1) = am;
   if ((HK(2.) * g * dpinv * am) >= delti) iflag = 4;
+  if (PHASE == 3) { st.iflag = iflag; st.cbmf = cbmf; return true; }   // the level-parallel path continues in k_conv_rows ...
+  for (i = icb + 1; i <= inb; i++) sij_row<H>(Sx, nk, icb, inb, i);
+  MM(sij, inb, inb) = HK(1.0);
+  for (i = icb + 1; i <= inb; i++) norm_row<H>(Sx, nk, icb, inb, i);
+  // (the precipitation / unsaturated-downdraught part, :686-790, and the tendencies FT, FQ with their entropy correction,
+  // :800-900, feed PRECIP, WD, TPRIME, QPRIME, FT, FQ only: nothing of that reaches the particles -- left out, together
+  // with the matrices QENT and ELIJ they alone read)
   // FUP(i) = [i >= nk] sum_{k>i} M(k) + sum_{k<=i} sum_{j>i} MENT(k,j) and FDOWN(i) = sum_{k<i} sum_{j>=i} MENT(j,k): the reference
   // forms them with two O(levels^3) loop nests per column.  Here: one descending sweep with the column sums S_k = sum_{j>=i}
   // MENT(j,k) and one ascending sweep with C_j = sum_{k<=i} MENT(k,j) -- O(levels^2), the additions in another order (the only
@@ -502,7 +648,7 @@ __global__ void k_conv_list(const unsigned int *__restrict__ colflag, const unsi
 }
 
 // per-column scalars kept between the two column kernels
-enum Cst { C_psconv, C_tt2conv, C_td2conv, C_cbmf, C_cbmfold, C_plcl, C_nk, C_icb, C_iflag, C_COUNT };
+enum Cst { C_psconv, C_tt2conv, C_td2conv, C_cbmf, C_cbmfold, C_plcl, C_nk, C_icb, C_iflag, C_inb, C_COUNT };
 
 // convmix.f90:149-170 + calcmatrix.f90:56-90 + CONVECT up to its early exits, for every column that holds particles
 template <typename H>
@@ -557,6 +703,31 @@ __global__ void k_conv_survivors(const unsigned int *__restrict__ alive, const u
   if (c < nact && alive[c]) surv[srank[c]] = c;
 }
 
+// redist.f90:83-121: heights of the half levels (the reference computes them with the first particle of the column)
+template <typename H>
+__device__ void half_level_heights(const Scr<H> &Sx, int nconvtop, H psconv, H tt2conv, H td2conv) {
+#pragma clang fp contract(off)
+  const H konst = HK(287.05) / HK(9.81);
+  H tvold = tt2conv * (HK(1.) + HK(0.378) * vt::ew<H>(td2conv) / psconv);
+  H pold = psconv;
+  VV(uvzlev, 1) = HK(0.);
+  H pint = VV(phconv, 2);
+  H tv1 = VV(tconv, 1) * (HK(1.) + HK(0.608) * VV(qconv, 1));
+  H tv2 = VV(tconv, 2) * (HK(1.) + HK(0.608) * VV(qconv, 2));
+  H tv = tv1 + (tv2 - tv1) * (VV(pconv, 1) - VV(phconv, 2)) / (VV(pconv, 1) - VV(pconv, 2));
+  if (R_ABS(tv - tvold) > HK(0.2)) VV(uvzlev, 2) = VV(uvzlev, 1) + konst * M<H>::log(pold / pint) * (tv - tvold) / M<H>::log(tv / tvold);
+  else VV(uvzlev, 2) = VV(uvzlev, 1) + konst * M<H>::log(pold / pint) * tv;
+  tvold = tv; tv1 = tv2; pold = pint;
+  for (int kz = 3; kz <= nconvtop + 1; kz++) {
+    pint = VV(phconv, kz);
+    tv2 = VV(tconv, kz) * (HK(1.) + HK(0.608) * VV(qconv, kz));
+    tv = tv1 + (tv2 - tv1) * (VV(pconv, kz - 1) - VV(phconv, kz)) / (VV(pconv, kz - 1) - VV(pconv, kz));
+    if (R_ABS(tv - tvold) > HK(0.2)) VV(uvzlev, kz) = VV(uvzlev, kz - 1) + konst * M<H>::log(pold / pint) * (tv - tvold) / M<H>::log(tv / tvold);
+    else VV(uvzlev, kz) = VV(uvzlev, kz - 1) + konst * M<H>::log(pold / pint) * tv;
+    tvold = tv; tv1 = tv2; pold = pint;
+  }
+}
+
 // the mixing part of CONVECT, calcmatrix.f90:92-137 and the half-level heights of redist.f90:83-121 for the surviving columns
 // surv[m0 .. m0+Bm)
 template <typename H>
@@ -607,26 +778,7 @@ __global__ void __launch_bounds__(64) k_conv_column_b(Fields<H> F, H *__restrict
       }
       MM(fmass, k, k) = MM(fmass, k, k) + rlevmass - summe;
     }
-    // redist.f90:83-121: heights of the half levels (the reference computes them with the first particle of the column)
-    const H konst = HK(287.05) / HK(9.81);
-    H tvold = tt2conv * (HK(1.) + HK(0.378) * vt::ew<H>(td2conv) / psconv);
-    H pold = psconv;
-    VV(uvzlev, 1) = HK(0.);
-    H pint = VV(phconv, 2);
-    H tv1 = VV(tconv, 1) * (HK(1.) + HK(0.608) * VV(qconv, 1));
-    H tv2 = VV(tconv, 2) * (HK(1.) + HK(0.608) * VV(qconv, 2));
-    H tv = tv1 + (tv2 - tv1) * (VV(pconv, 1) - VV(phconv, 2)) / (VV(pconv, 1) - VV(pconv, 2));
-    if (R_ABS(tv - tvold) > HK(0.2)) VV(uvzlev, 2) = VV(uvzlev, 1) + konst * M<H>::log(pold / pint) * (tv - tvold) / M<H>::log(tv / tvold);
-    else VV(uvzlev, 2) = VV(uvzlev, 1) + konst * M<H>::log(pold / pint) * tv;
-    tvold = tv; tv1 = tv2; pold = pint;
-    for (int kz = 3; kz <= nconvtop + 1; kz++) {
-      pint = VV(phconv, kz);
-      tv2 = VV(tconv, kz) * (HK(1.) + HK(0.608) * VV(qconv, kz));
-      tv = tv1 + (tv2 - tv1) * (VV(pconv, kz - 1) - VV(phconv, kz)) / (VV(pconv, kz - 1) - VV(pconv, kz));
-      if (R_ABS(tv - tvold) > HK(0.2)) VV(uvzlev, kz) = VV(uvzlev, kz - 1) + konst * M<H>::log(pold / pint) * (tv - tvold) / M<H>::log(tv / tvold);
-      else VV(uvzlev, kz) = VV(uvzlev, kz - 1) + konst * M<H>::log(pold / pint) * tv;
-      tvold = tv; tv1 = tv2; pold = pint;
-    }
+    half_level_heights<H>(Sx, nconvtop, psconv, tt2conv, td2conv);
   }
   {
     const Dom<H> &D = F.dom[F.domain_of(act[c])];
@@ -635,6 +787,213 @@ __global__ void __launch_bounds__(64) k_conv_column_b(Fields<H> F, H *__restrict
   lconv_out[c] = lconv;
   ntop_out[c] = lconv ? nconvtop : 0;
 }
+
+// ---- the mixing computation with a lane per (column, level) --------------------------------------------------------------
+// k_conv_column_b gives every column one lane and is bound by the latency chain of the longest column (a few hundred waves
+// on 1024 SIMDs).  Past the normalised M everything is a row- or column-wise pass over the matrices with no dependence
+// between rows (columns), so these kernels take blockIdx.y + 1 as the level and keep the column on threadIdx.x (the
+// interleaved scratch stays coalesced: the lanes of a wave share the level).  Every sum is formed in the order of the
+// one-lane kernel: the two paths agree bit for bit (tests/test_convection.py).
+//   k_conv_prelude  (column)        CONVECT from the second TLIFT to the normalised M, FUP(1)
+//   k_conv_rows     (column, i)     SIJ / MENT row i and its normalisation in one sweep (mix_row)
+//   k_conv_cols     (column, k)     running sums of column k of MENT: C_k(i) = sum_{r<=i} MENT(r,k) into FMASS(i,k), i < k;
+//                                   S_k(i) = sum_{r>=i} MENT(r,k) into SIJ(i,k), i > k; the column's part of nconvtop
+//   k_conv_flux     (column, i)     FDOWN(i) = sum_{k<i} S_k(i), FUP(i) = [i>=nk] sum_{k>i} M(k) + sum_{j>i} C_j(i), iflag 4
+//   k_conv_matrix   (column, k)     row k of fmassfrac, SUB(k); the lane of level 1 also: cbaseflux, lconv, half-level heights
+#define CONV_LANE_                                                           \
+  const int cm = blockIdx.x * blockDim.x + threadIdx.x;                     \
+  if (cm >= Bm || m0 + cm >= nsurv) return;                                 \
+  const int c = surv[m0 + cm];                                              \
+  Scr<H> Sx{vbuf, mbuf, nact, c, nv, Bm, cm};
+// The (group of 64 columns, level) of a block of the level kernels.  All levels of a group re-read the group's vectors (360 KB
+// at 100 levels), so they should run at the same time on the same XCD (its L2 holds 4 MB): consecutive workgroup ids go
+// round the 8 XCDs, id % 8 picks the XCD, and within an XCD the levels of one group are consecutive.  (With the group as
+// the fast index the resident blocks spanned all groups -- 160 MB of vectors -- and the kernel ran at the fabric's bandwidth.)
+#define CONV_LEVEL_LANE_(nlev)                                               \
+  const int q_ = blockIdx.x >> 3;                                           \
+  const int cm = (int)(((blockIdx.x & 7) + 8 * (q_ / (nlev))) * kGroup + threadIdx.x); \
+  const int lev = q_ % (nlev) + 1;                                          \
+  if (cm >= Bm || m0 + cm >= nsurv) return;                                 \
+  const int c = surv[m0 + cm];                                              \
+  Scr<H> Sx{vbuf, mbuf, nact, c, nv, Bm, cm};
+__host__ inline unsigned int level_grid(int ncolumns, int nlev) { return (unsigned int)(((ncolumns + kGroup - 1) / kGroup + 7) / 8 * 8 * nlev); }
+
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_prelude(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, H *__restrict__ cst, int nv, int nact,
+                                                     const int *__restrict__ surv, int m0, int Bm, int nsurv, int *__restrict__ cflag,
+                                                     int *__restrict__ ntop_raw) {
+#pragma clang fp contract(off)
+  CONV_LANE_
+  CvState<H> st;
+  st.cbmf = cst[(size_t)C_cbmf * nact + c];
+  st.plcl = cst[(size_t)C_plcl * nact + c];
+  st.nk = (int)cst[(size_t)C_nk * nact + c];
+  st.icb = (int)cst[(size_t)C_icb * nact + c];
+  st.iflag = (int)cst[(size_t)C_iflag * nact + c];
+  st.inb = 0;
+  int dummy = 0;
+  const bool go = convect<H, 3>(Sx, F.nconvlev, F.delt, st, dummy);
+  cst[(size_t)C_cbmf * nact + c] = st.cbmf;
+  cst[(size_t)C_inb * nact + c] = go ? (H)st.inb : HK(0.);     // inb 0: no level passes the range tests of the kernels below
+  cflag[c] = st.iflag;
+  ntop_raw[c] = 1;
+}
+
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_rows(H *__restrict__ vbuf, H *__restrict__ mbuf, const H *__restrict__ cst, int nv, int nact,
+                                                  const int *__restrict__ surv, int m0, int Bm, int nsurv, int nlev) {
+#pragma clang fp contract(off)
+  CONV_LEVEL_LANE_(nlev)
+  const int i = lev;
+  const int icb = (int)cst[(size_t)C_icb * nact + c], inb = (int)cst[(size_t)C_inb * nact + c];
+  if (i < icb + 1 || i > inb) return;
+  const int nk = (int)cst[(size_t)C_nk * nact + c];
+  mix_row<H>(Sx, nk, icb, inb, i);
+}
+
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_cols(H *__restrict__ vbuf, H *__restrict__ mbuf, const H *__restrict__ cst, int nv, int nact,
+                                                  const int *__restrict__ surv, int m0, int Bm, int nsurv, int nlev, int *__restrict__ ntop_raw) {
+#pragma clang fp contract(off)
+  CONV_LEVEL_LANE_(nlev)
+  const int k = lev;
+  const int icb = (int)cst[(size_t)C_icb * nact + c], inb = (int)cst[(size_t)C_inb * nact + c];
+  if (k < icb || k > inb) return;
+  const int nk = (int)cst[(size_t)C_nk * nact + c];
+  const int r0 = icb + 1;
+  const H epsilon = HK(1.e-20);
+  int top = 1;
+  if (VV(m, k) > epsilon) top = I_MAX(k, nk);
+  // (rows r0..k upwards, inb..k+1 downwards: every entry is read once)
+  H run = HK(0.);
+  const int kup = I_MIN(k, inb);
+  for (int i = r0; i <= kup; i += 8) {                  // upwards: C_k(i), needed for i < k
+    H b[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) b[u] = i + u <= kup ? MM(ment, i + u, k) : HK(0.);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i + u <= kup) {
+        if (b[u] > epsilon) top = I_MAX(top, k);        // max(k, i + u) = k
+        run = run + b[u];
+        if (i + u < k) MM(fmass, i + u, k) = run;
+      }
+  }
+  run = HK(0.);
+  const int rdn = I_MAX(r0, k + 1);
+  for (int i = inb; i >= rdn; i -= 8) {                 // downwards: S_k(i), needed for i > k
+    H b[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) b[u] = i - u >= rdn ? MM(ment, i - u, k) : HK(0.);
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i - u >= rdn) {
+        if (b[u] > epsilon) top = I_MAX(top, i - u);    // max(k, i - u) = i - u
+        run = run + b[u];
+        MM(sij, i - u, k) = run;
+      }
+  }
+  if (top > 1) atomicMax(&ntop_raw[c], top);
+}
+
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_flux(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, const H *__restrict__ cst, int nv, int nact,
+                                                  const int *__restrict__ surv, int m0, int Bm, int nsurv, int nlev, int *__restrict__ cflag) {
+#pragma clang fp contract(off)
+  CONV_LEVEL_LANE_(nlev)
+  const int i = lev;
+  const int icb = (int)cst[(size_t)C_icb * nact + c], inb = (int)cst[(size_t)C_inb * nact + c];
+  if (i < 2 || i > inb) return;
+  const int nk = (int)cst[(size_t)C_nk * nact + c];
+  const int r0 = icb + 1, c0 = icb;
+  const H g = HK(9.81), delti = HK(1.0) / F.delt;
+  H ad = HK(0.0);
+  if (i >= r0) {
+    const int kend = I_MIN(i - 1, inb);
+    for (int k = c0; k <= kend; k += 16) {
+      H t8[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) t8[u] = k + u <= kend ? MM(sij, i, k + u) : HK(0.);
+#pragma unroll
+      for (int u = 0; u < 16; u++) ad = ad + t8[u];
+    }
+  }
+  VV(fdown, i) = ad;
+  const H dpinv = HK(0.01) / (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1));
+  H amp1 = HK(0.0);
+  if (i >= nk)
+    for (int k = i + 1; k <= inb + 1; k += 16) {
+      H t8[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) t8[u] = k + u <= inb + 1 ? VV(m, k + u) : HK(0.);
+#pragma unroll
+      for (int u = 0; u < 16; u++) amp1 = amp1 + t8[u];
+    }
+  if (i >= r0)
+    for (int j = i + 1; j <= inb; j += 16) {
+      H t8[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) t8[u] = j + u <= inb ? MM(fmass, i, j + u) : HK(0.);
+#pragma unroll
+      for (int u = 0; u < 16; u++) amp1 = amp1 + t8[u];
+    }
+  VV(fup, i) = amp1;
+  if ((HK(2.) * g * dpinv * amp1) >= delti) atomicMax(&cflag[c], 4);
+}
+
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_matrix(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, const H *__restrict__ cst, int nv, int nact,
+                                                    const int *__restrict__ act, const int *__restrict__ surv, int m0, int Bm, int nsurv, int nlev,
+                                                    const int *__restrict__ cflag, const int *__restrict__ ntop_raw,
+                                                    int *__restrict__ lconv_out, int *__restrict__ ntop_out) {
+#pragma clang fp contract(off)
+  CONV_LEVEL_LANE_(nlev)
+  const int k = lev;
+  const int iflag = cflag[c];
+  const H cbmfold = cst[(size_t)C_cbmfold * nact + c];
+  H cbmf = cst[(size_t)C_cbmf * nact + c];
+  int lconv = 0;
+  if (iflag != 1 && iflag != 4) cbmf = cbmfold;
+  else if (cbmf <= HK(0.) && cbmfold <= HK(0.)) cbmf = cbmfold;
+  else lconv = 1;
+  const int nconvtop = ntop_raw[c] + 1;
+  if (lconv) {
+    const int icb = (int)cst[(size_t)C_icb * nact + c], inb = (int)cst[(size_t)C_inb * nact + c], nk = (int)cst[(size_t)C_nk * nact + c];
+    const H ga = HK(9.81);
+    if (k <= inb + 1) VV(sub, k) = k > 1 ? VV(fup, k - 1) - VV(fdown, k) : HK(0.);
+    if (k <= nconvtop) {
+      const H rlevmass = VV(dpr, k) / ga;
+      H summe = HK(0.);
+      for (int kk = 1; kk <= nconvtop; kk += 16) {
+        H f8[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+          const int q = kk + u;
+          H v = HK(0.);
+          if (q <= nconvtop) {
+            if (k > icb && k <= inb && q >= icb && q <= inb) v = MM(ment, k, q);
+            if (k == nk) v = VV(m, q) + v;                  // FMASS(nk,i) = M(i) + MENT(nk,i), convect43c.f90:925-930
+          }
+          f8[u] = F.delt * v;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+          if (kk + u <= nconvtop) { MM(fmass, k, kk + u) = f8[u]; summe = summe + f8[u]; }     // fmassfrac(k,kk)
+      }
+      MM(fmass, k, k) = MM(fmass, k, k) + rlevmass - summe;
+    }
+  }
+  if (k != 1) return;
+  if (lconv) half_level_heights<H>(Sx, nconvtop, cst[(size_t)C_psconv * nact + c], cst[(size_t)C_tt2conv * nact + c], cst[(size_t)C_td2conv * nact + c]);
+  {
+    const Dom<H> &D = F.dom[F.domain_of(act[c])];
+    D.cb[act[c] - D.off] = cbmf;
+  }
+  lconv_out[c] = lconv;
+  ntop_out[c] = lconv ? nconvtop : 0;
+}
+#undef CONV_LANE_
+#undef CONV_LEVEL_LANE_
 
 // redist.f90:124-236 for the particles of the surviving columns surv[m0 .. m0+Bm).  rn_in: the uniform number of each particle (serial
 // stream replayed by the host) or NULL: drawn from the counter generator.  probe != 0: only report which particles would draw.
@@ -659,23 +1018,42 @@ __global__ void k_conv_redist(const int *__restrict__ pcol, const unsigned int *
   const H r_air = HK(287.05), ga = HK(9.81);
   H ztold = (H)zt[s], znew = ztold;
   bool touched = false;                                // the height is written back only where the routine assigns it
+  // (both searches below request the operands of several steps together: one lane per particle, every lane in another column
+  // -- the loops are chains of memory latencies otherwise)
   int levold = 0;
-  for (int kz = 2; kz <= nconvtop; kz++)
-    if (VV(uvzlev, kz) >= ztold) { levold = kz - 1; break; }
+  for (int kz = 2; kz <= nconvtop && !levold; kz += 16) {
+    H uz[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) uz[u] = VV(uvzlev, I_MIN(kz + u, nconvtop));
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+      if (!levold && kz + u <= nconvtop && uz[u] >= ztold) levold = kz + u - 1;
+  }
   if (levold > 0) {
     if (probe) { draws[s] = 1; return; }
     const H rn = rngf(s);
     int levnew = levold;
     H ffraction = HK(0.), dlevfrac = HK(0.);
     const H totlevmass = VV(dpr, levold) / ga;
-    for (int k = 1; k <= nconvtop; k++) {
-      const H f = ldirect == 1 ? MM(fmass, levold, k) : MM(fmass, k, levold);
-      ffraction = ffraction + f / totlevmass;
-      if (rn <= ffraction) {
-        levnew = k;
-        if (ffraction > HK(1.e-20)) dlevfrac = (ffraction - rn) / f * totlevmass;
-        else dlevfrac = HK(0.5);
-        break;
+    bool found = false;
+    for (int k = 1; k <= nconvtop && !found; k += 8) {
+      H f8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int q = I_MIN(k + u, nconvtop);
+        f8[u] = ldirect == 1 ? MM(fmass, levold, q) : MM(fmass, q, levold);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (found || k + u > nconvtop) break;
+        const H f = f8[u];
+        ffraction = ffraction + f / totlevmass;
+        if (rn <= ffraction) {
+          levnew = k + u;
+          if (ffraction > HK(1.e-20)) dlevfrac = (ffraction - rn) / f * totlevmass;
+          else dlevfrac = HK(0.5);
+          found = true;
+        }
       }
     }
     if (levnew <= nconvtop) {

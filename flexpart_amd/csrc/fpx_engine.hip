@@ -2870,7 +2870,7 @@ struct Engine : EngineBase {
   bool conv_slot_n[kMaxNests][2] = {};
   void *conv_cb_n[kMaxNests] = {};           // cbasefluxn(:,:,l)
   size_t conv_ncol_alloc = 0;                // columns (all domains) the per-column arrays are sized for
-  int *conv_pcol = nullptr, *conv_act = nullptr, *conv_lconv = nullptr, *conv_ntop = nullptr;
+  int *conv_pcol = nullptr, *conv_act = nullptr, *conv_lconv = nullptr, *conv_ntop = nullptr, *conv_cflag = nullptr, *conv_ntop_raw = nullptr;
   unsigned int *conv_flag = nullptr, *conv_rank = nullptr;
   unsigned char *conv_draws = nullptr;
   void *conv_rn = nullptr;
@@ -3126,7 +3126,8 @@ struct Engine : EngineBase {
     if ((size_t)ncol > conv_ncol_alloc) {
       int rc2;
       if ((rc2 = dalloc(&conv_flag, (size_t)ncol)) || (rc2 = dalloc(&conv_rank, (size_t)ncol)) || (rc2 = dalloc(&conv_act, (size_t)ncol)) ||
-          (rc2 = dalloc(&conv_lconv, (size_t)ncol)) || (rc2 = dalloc(&conv_ntop, (size_t)ncol))) return rc2;
+          (rc2 = dalloc(&conv_lconv, (size_t)ncol)) || (rc2 = dalloc(&conv_ntop, (size_t)ncol)) || (rc2 = dalloc(&conv_cflag, (size_t)ncol)) ||
+          (rc2 = dalloc(&conv_ntop_raw, (size_t)ncol))) return rc2;
       conv_ncol_alloc = (size_t)ncol;
     }
     const int nb = (int)((n + kBlock - 1) / kBlock), nbc = (ncol + kBlock - 1) / kBlock;
@@ -3156,7 +3157,9 @@ struct Engine : EngineBase {
     HIPCHK(hipGetLastError());
     // scratch: the vectors of every column that holds particles; the matrices only for the columns that get past CONVECT's
     // early exits, in batches that fit the budget (default: a quarter of the free device memory)
-    const size_t vec_bytes = (conv::vec_elems_per_column<H>(nv) + conv::C_COUNT) * sizeof(H) * (size_t)nact;
+    const size_t vec_elems = conv::vec_elems_per_column<H>(nv) * conv::group_round((size_t)nact);
+    const size_t cst_elems = conv::group_round((size_t)conv::C_COUNT * nact);
+    const size_t vec_bytes = (vec_elems + cst_elems) * sizeof(H);
     const size_t per_mat = conv::mat_elems_per_column<H>(nv) * sizeof(H);
     size_t budget;
     {
@@ -3181,12 +3184,13 @@ struct Engine : EngineBase {
       return 0;
     };
     // upper bound of the matrix batch before the survivors are known: all active columns, capped by the budget
-    int Bm_cap = (int)std::min<size_t>((size_t)nact, std::max<size_t>(64, budget / per_mat));
+    int Bm_cap = (int)std::min<size_t>(conv::group_round((size_t)nact), std::max<size_t>(64, budget / per_mat / conv::kGroup * conv::kGroup));
     int rc = ensure_scratch(vec_bytes + (size_t)Bm_cap * per_mat);
     if (rc) return rc;
-    H *vbuf = (H *)conv_scr, *cst = vbuf + conv::vec_elems_per_column<H>(nv) * (size_t)nact, *mbuf = cst + (size_t)conv::C_COUNT * nact;
+    H *vbuf = (H *)conv_scr, *cst = vbuf + vec_elems, *mbuf = cst + cst_elems;
     const H height_nz = (H)height_host[cfg.nz - 1];
     const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
+    const bool conv_one_lane = getenv("FPX_CONV_ONE_LANE") != nullptr;     // the one-lane-per-column kernel (kept as the check of the level-parallel ones)
     const int nba = (nact + 63) / 64;
     conv::k_conv_column_a<H><<<nba, 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, alive);
     HIPCHK(hipGetLastError());
@@ -3207,7 +3211,17 @@ struct Engine : EngineBase {
       // parity mode: the random numbers come from the shared serial stream in the reference's visiting order, which needs to
       // know who draws -- a probe pass records that, the host replays the stream, then the particles are moved
       for (int m0 = 0; m0 < nsurv; m0 += Bm) {
-        conv::k_conv_column_b<H><<<(Bm + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, conv_lconv, conv_ntop);
+        if (conv_one_lane) {
+          conv::k_conv_column_b<H><<<(Bm + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, conv_lconv, conv_ntop);
+        } else {
+          const int nlev = F.nconvlev + 1;
+          const unsigned int gl = conv::level_grid(Bm, nlev);
+          conv::k_conv_prelude<H><<<(Bm + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, conv_cflag, conv_ntop_raw);
+          conv::k_conv_rows<H><<<gl, 64, 0, stream>>>(vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev);
+          conv::k_conv_cols<H><<<gl, 64, 0, stream>>>(vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev, conv_ntop_raw);
+          conv::k_conv_flux<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev, conv_cflag);
+          conv::k_conv_matrix<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
+        }
         HIPCHK(hipGetLastError());
         if (seq) {
           HIPCHK(hipMemsetAsync(conv_draws, 0, (size_t)n, stream));

@@ -126,6 +126,41 @@ def test_device_convmix_matches_the_oracle(built, name, kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+@pytest.mark.parametrize("name", ["forward", "nested"])
+def test_level_parallel_kernels_equal_the_one_lane_kernel(built, name, kind):
+    """The mixing computation with a lane per (column, level) -- k_conv_prelude / rows / cols / flux / matrix -- forms every
+    sum in the order of the one-lane-per-column kernel (FPX_CONV_ONE_LANE): heights and cloud-base mass fluxes bit for bit,
+    over three calls (the mass flux of one call is the input of the next)."""
+    import os
+    from flexpart_amd.engine import RNG_PHILOX
+    cs = syn.convection_case(**CASES[name])
+    got = {}
+    for mode in ("levels", "one_lane"):
+        if mode == "one_lane":
+            os.environ["FPX_CONV_ONE_LANE"] = "1"
+        try:
+            eng, sc = _engine(cs, kind, RNG_PHILOX)
+            z = np.asarray(cs["ztra1"], dtype=np.float64)
+            out = []
+            for ic in range(len(cs["itimes"])):
+                moved, z = _call(eng, sc, cs, ic, z)
+                out.append((moved, z.copy(), eng.cbaseflux().copy()))
+                if "nest" in cs:
+                    out.append(eng.cbaseflux_nest(1, np.asarray(cs["cbasefluxn"]).shape).copy())
+            eng.close()
+        finally:
+            os.environ.pop("FPX_CONV_ONE_LANE", None)
+        got[mode] = out
+    assert got["levels"][0][0] > 500
+    for a, b in zip(got["levels"], got["one_lane"]):
+        if isinstance(a, tuple):
+            assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+        else:
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
 def test_device_convmix_with_the_counter_generator(built):
     """Counter RNG: individual displacements differ from the serial stream's by construction; the ensemble must not.  Same
     columns convect, particles outside convective columns and particles that are not due stay where they are, the fraction

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--real", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unsorted", action="store_true", help="leave the particles in their random seeding order (default: fpx_sort_particles "
+                    "first -- the order a run keeps them in)")
     a = ap.parse_args()
     from flexpart_amd import synthetic as syn
     from flexpart_amd.engine import Engine, RNG_PHILOX
@@ -43,6 +45,8 @@ def main():
     for slot in (1, 2):
         eng.upload_conv_fields(slot, *(np.asarray(cs[k])[slot - 1] for k in ("ps", "tt2", "td2", "tth", "qvh")))
     cb0 = eng.cbaseflux()
+    if not a.unsorted:
+        eng.sort()
     ms, moved = [], 0
     for r in range(a.reps + 1):
         eng.cbaseflux(cb0)                 # every repetition does the same work
@@ -57,7 +61,8 @@ def main():
     nconv = int((cb1 > 0).sum())
     out = {"metric": "convmix, one call", "value": dms, "unit": "ms (device)", "higher_is_better": False,
            "dtype": "f64" if a.real == 8 else "f32", "data": "synthetic",
-           "config": {"workload": f"{a.nx}x{a.ny} columns x {a.nuvz} levels, {n:.0e} particles, every column holds particles", "reps": a.reps},
+           "config": {"workload": f"{a.nx}x{a.ny} columns x {a.nuvz} levels, {n:.0e} particles, every column holds particles, " +
+                                  ("random storage order" if a.unsorted else "cell-sorted storage order"), "reps": a.reps},
            "wall_ms_whole_call": float(np.median([m[1] for m in ms])), "particles_moved": int(moved), "columns": a.nx * a.ny,
            "columns_with_mass_flux_after": nconv, "us_per_column": dms * 1e3 / (a.nx * a.ny)}
     if not a.no_cpu_baseline:
