@@ -263,23 +263,122 @@ __device__ void norm_row(const Scr<H> &Sx, int nk, int icb, int inb, int i) {
 // SIJ in (0, 0.9), hence nothing for the normalisation to act on: running it unconditionally changes nothing.  Same
 // operations on the same operands in the same order as the two functions above.
 template <typename H>
+struct MixRow {
+  H qti, h_i, hp_i, qc_i, m_i, scrit, asij, smin;
+  H s_a, s_b, me_b;                                      // SIJ(i,jj-2), SIJ(i,jj-1), MENT(i,jj-1) before the normalisation
+  int nent_i, i, icb, inb;
+
+  __device__ void init(const Scr<H> &Sx, int nk, int icb_, int inb_, int i_) {
+#pragma clang fp contract(off)
+    i = i_; icb = icb_; inb = inb_;
+    qti = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
+    h_i = VV(h, i); hp_i = VV(hp, i); qc_i = VV(qconv, i); m_i = VV(m, i);
+    const H lv_i = VV(lv, i), qs_i = VV(qsconv, i);
+    H anum = h_i - hp_i - lv_i * (qti - qs_i);
+    H denom = h_i - hp_i + lv_i * (qc_i - qti);
+    if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+    scrit = anum / denom;
+    const H alt = qti - qs_i + scrit * (qc_i - qti);
+    if (alt < HK(0.0)) scrit = HK(1.0);
+    scrit = R_MAX(scrit, HK(0.0));
+    asij = HK(0.0);
+    smin = HK(1.0);
+    nent_i = 0;
+    s_a = HK(0.); s_b = HK(0.); me_b = HK(0.);
+  }
+
+  // entry jj, icb <= jj <= inb + 1: the mixing fraction of (i, jj), then the normalisation of (i, jj - 1).
+  // lvj .. epj: LV, QSCONV, TCONV, H, QCONV, CLW, EP at level min(jj, inb); ph0, ph1: PHCONV_HPA(jj - 1), PHCONV_HPA(jj)
+  __device__ void step(const Scr<H> &Sx, int jj, H lvj, H qsj, H tcj, H hj, H qcj, H clwj, H epj, H ph0, H ph1) {
+#pragma clang fp contract(off)
+    const H cpd = HK(1005.7), cpv = HK(1870.0), rv = HK(461.5);
+    H bf2, anum, denom, dei, altem, cwat, stemp, smid, sjmax, sjmin, delp, delm;
+    H sv = HK(0.), me = HK(0.);
+    if (jj <= inb) {
+      bf2 = HK(1.) + lvj * lvj * qsj / (rv * tcj * tcj * cpd);
+      anum = hj - hp_i + (cpv - cpd) * tcj * (qti - qcj);
+      denom = h_i - hp_i + (cpd - cpv) * (qc_i - qti) * tcj;
+      dei = denom;
+      if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
+      sv = anum / dei;
+      if (jj == i) sv = HK(1.0);
+      altem = sv * qc_i + (HK(1.) - sv) * qti - qsj;
+      altem = altem / bf2;
+      cwat = clwj * (HK(1.) - epj);
+      stemp = sv;
+      if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && jj > i) {
+        anum = anum - lvj * (qti - qsj - cwat * bf2);
+        denom = denom + lvj * (qc_i - qti);
+        if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
+        sv = anum / denom;
+      }
+      if (sv > HK(0.0) && sv < HK(0.9)) {
+        me = m_i / (HK(1.) - sv);
+        nent_i = nent_i + 1;
+      }
+      sv = R_MAX(HK(0.0), sv);
+      sv = R_MIN(HK(1.0), sv);
+    }
+    if (jj > icb) {                                        // normalisation of entry jn = jj - 1
+      const int jn = jj - 1;
+      const H s0 = s_a, s1 = s_b, s2 = sv;
+      H out = me_b;
+      if (s1 > HK(0.0) && s1 < HK(0.9)) {
+        if (jn > i) {
+          smid = R_MIN(s1, scrit);
+          sjmax = smid;
+          sjmin = smid;
+          if (smid < smin && s2 < smid) {
+            smin = smid;
+            sjmax = R_MIN(R_MIN(s2, s1), scrit);
+            sjmin = R_MAX(s0, s1);
+            sjmin = R_MIN(sjmin, scrit);
+          }
+        } else {
+          sjmax = R_MAX(s2, scrit);
+          smid = R_MAX(s1, scrit);
+          sjmin = HK(0.0);
+          if (jn > 1) sjmin = s0;
+          sjmin = R_MAX(sjmin, scrit);
+        }
+        delp = R_ABS(sjmax - smid);
+        delm = R_ABS(sjmin - smid);
+        asij = asij + (delp + delm) * (ph0 - ph1);
+        out = me_b * (delp + delm) * (ph0 - ph1);
+      }
+      MM(ment, i, jn) = out;
+    }
+    s_a = s_b; s_b = sv; me_b = me;
+  }
+
+  __device__ void finish(const Scr<H> &Sx) {
+#pragma clang fp contract(off)
+    if (nent_i == 0) {
+      VV(nent, i) = 0;
+      MM(ment, i, i) = m_i;
+      return;
+    }
+    asij = R_MAX(HK(1.0e-21), asij);
+    asij = HK(1.0) / asij;
+    H bsum = HK(0.0);
+    for (int j = icb; j <= inb; j += 8) {
+      H me[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (j + u <= inb) { const H v = me[u] * asij; MM(ment, i, j + u) = v; bsum = bsum + v; }
+    }
+    if (bsum < HK(1.0e-18)) { nent_i = 0; MM(ment, i, i) = m_i; }
+    VV(nent, i) = (H)nent_i;
+  }
+};
+
+template <typename H>
 __device__ void mix_row(const Scr<H> &Sx, int nk, int icb, int inb, int i) {
 #pragma clang fp contract(off)
-  const H cpd = HK(1005.7), cpv = HK(1870.0), rv = HK(461.5);
-  H bf2, anum, denom, dei, altem, cwat, stemp, scrit, alt, asij, smin, smid, sjmax, sjmin, delp, delm, bsum;
-  const H qti = VV(qconv, nk) - VV(ep, i) * VV(clw, i);
-  const H h_i = VV(h, i), hp_i = VV(hp, i), qc_i = VV(qconv, i), m_i = VV(m, i), lv_i = VV(lv, i), qs_i = VV(qsconv, i);
-  anum = h_i - hp_i - lv_i * (qti - qs_i);
-  denom = h_i - hp_i + lv_i * (qc_i - qti);
-  if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
-  scrit = anum / denom;
-  alt = qti - qs_i + scrit * (qc_i - qti);
-  if (alt < HK(0.0)) scrit = HK(1.0);
-  scrit = R_MAX(scrit, HK(0.0));
-  asij = HK(0.0);
-  smin = HK(1.0);
-  int nent_i = 0;
-  H s_a = HK(0.), s_b = HK(0.), me_b = HK(0.);            // SIJ(i,jj-2), SIJ(i,jj-1), MENT(i,jj-1) before the normalisation
+  MixRow<H> row;
+  row.init(Sx, nk, icb, inb, i);
   for (int j = icb; j <= inb + 1; j += kJ) {
     H lvj[kJ], qsj[kJ], tcj[kJ], hj[kJ], qcj[kJ], clwj[kJ], epj[kJ], ph[kJ + 1];
 #pragma unroll
@@ -292,84 +391,11 @@ __device__ void mix_row(const Scr<H> &Sx, int nk, int icb, int inb, int i) {
     for (int u = 0; u < kJ + 1; u++) ph[u] = VV(phconv_hpa, I_MIN(j - 1 + u, inb + 1));      // PHCONV_HPA(j-1 .. j+kJ-1)
 #pragma unroll
     for (int u = 0; u < kJ; u++) {
-      const int jj = j + u;
-      if (jj > inb + 1) break;
-      H sv = HK(0.), me = HK(0.);
-      if (jj <= inb) {
-        bf2 = HK(1.) + lvj[u] * lvj[u] * qsj[u] / (rv * tcj[u] * tcj[u] * cpd);
-        anum = hj[u] - hp_i + (cpv - cpd) * tcj[u] * (qti - qcj[u]);
-        denom = h_i - hp_i + (cpd - cpv) * (qc_i - qti) * tcj[u];
-        dei = denom;
-        if (R_ABS(dei) < HK(0.01)) dei = HK(0.01);
-        sv = anum / dei;
-        if (jj == i) sv = HK(1.0);
-        altem = sv * qc_i + (HK(1.) - sv) * qti - qsj[u];
-        altem = altem / bf2;
-        cwat = clwj[u] * (HK(1.) - epj[u]);
-        stemp = sv;
-        if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && jj > i) {
-          anum = anum - lvj[u] * (qti - qsj[u] - cwat * bf2);
-          denom = denom + lvj[u] * (qc_i - qti);
-          if (R_ABS(denom) < HK(0.01)) denom = HK(0.01);
-          sv = anum / denom;
-        }
-        if (sv > HK(0.0) && sv < HK(0.9)) {
-          me = m_i / (HK(1.) - sv);
-          nent_i = nent_i + 1;
-        }
-        sv = R_MAX(HK(0.0), sv);
-        sv = R_MIN(HK(1.0), sv);
-      }
-      if (jj > icb) {                                      // normalisation of entry jn = jj - 1
-        const int jn = jj - 1;
-        const H s0 = s_a, s1 = s_b, s2 = sv;
-        H out = me_b;
-        if (s1 > HK(0.0) && s1 < HK(0.9)) {
-          if (jn > i) {
-            smid = R_MIN(s1, scrit);
-            sjmax = smid;
-            sjmin = smid;
-            if (smid < smin && s2 < smid) {
-              smin = smid;
-              sjmax = R_MIN(R_MIN(s2, s1), scrit);
-              sjmin = R_MAX(s0, s1);
-              sjmin = R_MIN(sjmin, scrit);
-            }
-          } else {
-            sjmax = R_MAX(s2, scrit);
-            smid = R_MAX(s1, scrit);
-            sjmin = HK(0.0);
-            if (jn > 1) sjmin = s0;
-            sjmin = R_MAX(sjmin, scrit);
-          }
-          delp = R_ABS(sjmax - smid);
-          delm = R_ABS(sjmin - smid);
-          asij = asij + (delp + delm) * (ph[u] - ph[u + 1]);
-          out = me_b * (delp + delm) * (ph[u] - ph[u + 1]);
-        }
-        MM(ment, i, jn) = out;
-      }
-      s_a = s_b; s_b = sv; me_b = me;
+      if (j + u > inb + 1) break;
+      row.step(Sx, j + u, lvj[u], qsj[u], tcj[u], hj[u], qcj[u], clwj[u], epj[u], ph[u], ph[u + 1]);
     }
   }
-  if (nent_i == 0) {
-    VV(nent, i) = 0;
-    MM(ment, i, i) = m_i;
-    return;
-  }
-  asij = R_MAX(HK(1.0e-21), asij);
-  asij = HK(1.0) / asij;
-  bsum = HK(0.0);
-  for (int j = icb; j <= inb; j += 8) {
-    H me[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (j + u <= inb) { const H v = me[u] * asij; MM(ment, i, j + u) = v; bsum = bsum + v; }
-  }
-  if (bsum < HK(1.0e-18)) { nent_i = 0; MM(ment, i, i) = m_i; }
-  VV(nent, i) = (H)nent_i;
+  row.finish(Sx);
 }
 
 // PHASE 1: up to the early exits (:79-~420: sounding, lifting condensation level, first TLIFT); returns whether the mixing
@@ -849,6 +875,77 @@ __global__ void __launch_bounds__(64) k_conv_rows(H *__restrict__ vbuf, H *__res
   if (i < icb + 1 || i > inb) return;
   const int nk = (int)cst[(size_t)C_nk * nact + c];
   mix_row<H>(Sx, nk, icb, inb, i);
+}
+
+// k_conv_rows with the operands shared: the rows of a group of columns all walk the same seven vectors (and PHCONV_HPA) of
+// that group, level by level.  A block holds kRowsPerBlock rows (waves) of one group; each batch of kJ levels is fetched once
+// per block -- every wave a share of the 65 segments -- and parked in LDS [item][lane], from where every row reads its own
+// column's values (conflict-free: consecutive lanes, consecutive words).  The next batch is in flight while this one is
+// computed.  Same MixRow steps as mix_row: bit-identical.
+constexpr int kRowsPerBlock = 8;
+constexpr int kStageItems = 7 * kJ + kJ + 1;
+template <typename H>
+__global__ void __launch_bounds__(64 * kRowsPerBlock) k_conv_rows_lds(H *__restrict__ vbuf, H *__restrict__ mbuf, const H *__restrict__ cst, int nv,
+                                                                      int nact, const int *__restrict__ surv, int m0, int Bm, int nsurv, int nlev) {
+#pragma clang fp contract(off)
+  __shared__ H stage[kStageItems][kGroup];
+  const int nrb = (nlev + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int q_ = blockIdx.x >> 3;
+  const int lane = threadIdx.x, w = threadIdx.y;
+  const int cm = (int)(((blockIdx.x & 7) + 8 * (q_ / nrb)) * kGroup + lane);
+  const int row0 = (q_ % nrb) * kRowsPerBlock + 1;           // the block's rows: row0 .. row0 + kRowsPerBlock - 1
+  const int i = row0 + w;
+  const bool valid = cm < Bm && m0 + cm < nsurv;
+  const int c = valid ? surv[m0 + cm] : 0;
+  Scr<H> Sx{vbuf, mbuf, nact, c, nv, Bm, valid ? cm : 0};
+  int icb = 0, inb = 0, nk = 1;
+  if (valid) { icb = (int)cst[(size_t)C_icb * nact + c]; inb = (int)cst[(size_t)C_inb * nact + c]; nk = (int)cst[(size_t)C_nk * nact + c]; }
+  // a column takes part when one of the block's rows lies in icb+1 .. inb; the same in every wave of the block
+  const bool col_on = valid && row0 <= inb && row0 + kRowsPerBlock - 1 >= icb + 1;
+  int nb = col_on ? (inb + 1 - icb) / kJ + 1 : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(nb, o); nb = I_MAX(nb, other); }   // (the macro would shuffle twice, once under a condition)
+  if (nb == 0) return;                                       // (uniform over the block)
+  const bool row_on = col_on && i >= icb + 1 && i <= inb;
+  MixRow<H> row;
+  if (row_on) row.init(Sx, nk, icb, inb, i);
+  constexpr int kShare = (kStageItems + kRowsPerBlock - 1) / kRowsPerBlock;
+  const int vec_of[7] = {V_lv, V_qsconv, V_tconv, V_h, V_qconv, V_clw, V_ep};
+  H pre[kShare];
+  auto fetch = [&](int b) {
+    const int j = icb + b * kJ;
+#pragma unroll
+    for (int q = 0; q < kShare; q++) {
+      const int t = w + q * kRowsPerBlock;
+      H v = HK(0.);
+      if (col_on && t < kStageItems) {
+        if (t < 7 * kJ) v = Sx.vb[((size_t)vec_of[t / kJ] * nv + (size_t)I_MIN(j + t % kJ, inb)) * kGroup];
+        else v = VV(phconv_hpa, I_MIN(j - 1 + (t - 7 * kJ), inb + 1));
+      }
+      pre[q] = v;
+    }
+  };
+  fetch(0);
+  for (int b = 0; b < nb; b++) {
+    __syncthreads();                                         // the previous batch has been consumed
+#pragma unroll
+    for (int q = 0; q < kShare; q++) {
+      const int t = w + q * kRowsPerBlock;
+      if (t < kStageItems) stage[t][lane] = pre[q];
+    }
+    __syncthreads();
+    if (b + 1 < nb) fetch(b + 1);
+    const int j = icb + b * kJ;
+    if (row_on && j <= inb + 1) {
+#pragma unroll
+      for (int u = 0; u < kJ; u++) {
+        if (j + u > inb + 1) break;
+        row.step(Sx, j + u, stage[0 * kJ + u][lane], stage[1 * kJ + u][lane], stage[2 * kJ + u][lane], stage[3 * kJ + u][lane],
+                 stage[4 * kJ + u][lane], stage[5 * kJ + u][lane], stage[6 * kJ + u][lane], stage[7 * kJ + u][lane], stage[7 * kJ + u + 1][lane]);
+      }
+    }
+  }
+  if (row_on) row.finish(Sx);
 }
 
 template <typename H>
