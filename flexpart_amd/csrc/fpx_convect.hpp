@@ -1094,24 +1094,31 @@ __global__ void __launch_bounds__(64) k_conv_matrix(Fields<H> F, H *__restrict__
 
 // redist.f90:124-236 for the particles of the surviving columns surv[m0 .. m0+Bm).  rn_in: the uniform number of each particle (serial
 // stream replayed by the host) or NULL: drawn from the counter generator.  probe != 0: only report which particles would draw.
+// colslot[column] = {active-column index, matrix slot in this batch, nconvtop, 1} for the convective columns of the batch, zero
+// otherwise: a particle finds out with one gather whether it has anything to do
+__global__ void k_conv_slots(const int *__restrict__ act, const unsigned int *__restrict__ alive, const unsigned int *__restrict__ srank,
+                             const int *__restrict__ lconv, const int *__restrict__ ntop, int nact, int m0, int Bm, int4 *__restrict__ colslot) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nact || !alive[r]) return;
+  const int ms = (int)srank[r] - m0;
+  if (ms < 0 || ms >= Bm || !lconv[r]) return;
+  colslot[act[r]] = make_int4(r, ms, ntop[r], 1);
+}
+
 template <typename R, typename H, typename RNGF>
-__global__ void k_conv_redist(const int *__restrict__ pcol, const unsigned int *__restrict__ rank, R *__restrict__ zt, long long n,
-                              H *__restrict__ vbuf, H *__restrict__ mbuf, int nv, int nact, const unsigned int *__restrict__ alive,
-                              const unsigned int *__restrict__ srank, int m0, int Bm,
-                              const int *__restrict__ lconv_in, const int *__restrict__ ntop_in, int ldirect, int lsynctime, H height_nz,
+__global__ void k_conv_redist(const int *__restrict__ pcol, const int4 *__restrict__ colslot, R *__restrict__ zt, long long n,
+                              H *__restrict__ vbuf, H *__restrict__ mbuf, int nv, int nact, int Bm, int ldirect, int lsynctime, H height_nz,
                               RNGF rngf, unsigned char *__restrict__ draws, int probe, unsigned long long *__restrict__ nmoved) {
 #pragma clang fp contract(off)
   long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
   const int col = pcol[s];
   if (col < 0) return;
-  const int r = (int)rank[col];
-  if (!alive[r]) return;
-  const int ms = (int)srank[r] - m0;
-  if (ms < 0 || ms >= Bm) return;
-  if (!lconv_in[r]) return;
+  const int4 slot = colslot[col];
+  if (!slot.w) return;
+  const int r = slot.x, ms = slot.y;
   Scr<H> Sx{vbuf, mbuf, nact, r, nv, Bm, ms};
-  const int nconvtop = ntop_in[r];
+  const int nconvtop = slot.z;
   const H r_air = HK(287.05), ga = HK(9.81);
   H ztold = (H)zt[s], znew = ztold;
   bool touched = false;                                // the height is written back only where the routine assigns it

@@ -2871,6 +2871,7 @@ struct Engine : EngineBase {
   void *conv_cb_n[kMaxNests] = {};           // cbasefluxn(:,:,l)
   size_t conv_ncol_alloc = 0;                // columns (all domains) the per-column arrays are sized for
   int *conv_pcol = nullptr, *conv_act = nullptr, *conv_lconv = nullptr, *conv_ntop = nullptr, *conv_cflag = nullptr, *conv_ntop_raw = nullptr;
+  int4 *conv_colslot = nullptr;
   unsigned int *conv_flag = nullptr, *conv_rank = nullptr;
   unsigned char *conv_draws = nullptr;
   void *conv_rn = nullptr;
@@ -3127,7 +3128,7 @@ struct Engine : EngineBase {
       int rc2;
       if ((rc2 = dalloc(&conv_flag, (size_t)ncol)) || (rc2 = dalloc(&conv_rank, (size_t)ncol)) || (rc2 = dalloc(&conv_act, (size_t)ncol)) ||
           (rc2 = dalloc(&conv_lconv, (size_t)ncol)) || (rc2 = dalloc(&conv_ntop, (size_t)ncol)) || (rc2 = dalloc(&conv_cflag, (size_t)ncol)) ||
-          (rc2 = dalloc(&conv_ntop_raw, (size_t)ncol))) return rc2;
+          (rc2 = dalloc(&conv_ntop_raw, (size_t)ncol)) || (rc2 = dalloc(&conv_colslot, (size_t)ncol))) return rc2;
       conv_ncol_alloc = (size_t)ncol;
     }
     const int nb = (int)((n + kBlock - 1) / kBlock), nbc = (ncol + kBlock - 1) / kBlock;
@@ -3226,19 +3227,21 @@ struct Engine : EngineBase {
           conv::k_conv_matrix<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
         }
         HIPCHK(hipGetLastError());
+        HIPCHK(hipMemsetAsync(conv_colslot, 0, (size_t)ncol * sizeof(int4), stream));
+        conv::k_conv_slots<<<(nact + kBlock - 1) / kBlock, kBlock, 0, stream>>>(conv_act, alive, srank, conv_lconv, conv_ntop, nact, m0, Bm, conv_colslot);
         if (seq) {
           HIPCHK(hipMemsetAsync(conv_draws, 0, (size_t)n, stream));
-          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, nv, nact, alive, srank, m0, Bm, conv_lconv, conv_ntop,
+          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_colslot, P.zt, n, vbuf, mbuf, nv, nact, Bm,
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
                                                                           conv_draws, 1, nullptr);
           HIPCHK(hipGetLastError());
           int rrc = conv_replay<H>(n, F.ndom, off);
           if (rrc) return rrc;
-          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, nv, nact, alive, srank, m0, Bm, conv_lconv, conv_ntop,
+          conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_colslot, P.zt, n, vbuf, mbuf, nv, nact, Bm,
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
                                                                           conv_draws, 0, conv_nmoved);
         } else {
-          conv::k_conv_redist<R, H, ConvRngCtr<R, H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_rank, P.zt, n, vbuf, mbuf, nv, nact, alive, srank, m0, Bm, conv_lconv, conv_ntop,
+          conv::k_conv_redist<R, H, ConvRngCtr<R, H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_colslot, P.zt, n, vbuf, mbuf, nv, nact, Bm,
                                                                              cfg.ldirect, cfg.lsynctime, height_nz, ConvRngCtr<R, H>{V, P.pid, step_counter},
                                                                              conv_draws, 0, conv_nmoved);
         }
@@ -3581,6 +3584,7 @@ struct Engine : EngineBase {
       int per_cu = 0;
       HIPCHK(hipFuncSetAttribute((const void *)loop_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_smem_bytes()));
       HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, loop_smem_bytes()));
+      if (const char *env = getenv("FPX_PBL_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, atoi(env)));   // experiments: fewer resident waves
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
     }
     {
