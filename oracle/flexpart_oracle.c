@@ -2198,4 +2198,17 @@ long orc_nan_count(orc_ctx *c, int which) { return which == 2 ? c->nan_count2 : 
 
 /* expose the shared ran3 stream (tests of the host-side replica in the product) */
 double orc_ran3_next(orc_ctx *c, int *idum) { return (double)orc_ran3(c, idum); }
+/* the module's one ran3 state (random_mod.f90:46-52, 93-139) out of / into the context, in the layout of convect_oracle.c's
+   cvo_args.state_words -- words[1..55] = ma, [56] inext, [57] inextp, [58] iff -- so that a test can hand the stream from
+   advance to redist and back, as the two routines share it in the reference */
+void orc_get_ran3_state(orc_ctx *c, int *words) {
+  int i;
+  for (i = 1; i <= 55; i++) words[i] = c->ran3_ma[i];
+  words[56] = c->ran3_inext; words[57] = c->ran3_inextp; words[58] = c->ran3_iff;
+}
+void orc_set_ran3_state(orc_ctx *c, const int *words) {
+  int i;
+  for (i = 1; i <= 55; i++) c->ran3_ma[i] = words[i];
+  c->ran3_inext = words[56]; c->ran3_inextp = words[57]; c->ran3_iff = words[58];
+}
 void orc_reset_rng(orc_ctx *c) { c->ran3_iff = 0; c->idummy_init = -7; c->idummy_adv = -7; c->gasdev_iset = 0; c->gasdev_gset = 0; }

@@ -239,6 +239,16 @@ class Oracle:
         ct = C.c_float if self.kind == "r4" else C.c_double
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(ct)), shape=(1000000,)).copy()
 
+    def ran3_words(self):
+        """The shared ran3 state as 60 int32 words (layout of conv_oracle's ran3_words; [59], redist's own seed, is not ours)."""
+        w = np.zeros(60, np.int32)
+        self.lib.orc_get_ran3_state(self.h, w.ctypes.data_as(C.c_void_p))
+        return w
+
+    def set_ran3_words(self, w):
+        w = np.ascontiguousarray(w, dtype=np.int32)
+        self.lib.orc_set_ran3_state(self.h, w.ctypes.data_as(C.c_void_p))
+
     def step(self):
         vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         if self.has_wet and self.itime != 0:   # timemanager.f90:164-169
@@ -703,15 +713,21 @@ class _CvoArgs(C.Structure):
                 ("cbasefluxn", C.c_void_p)]
 
 
-def conv_oracle(cs, kind="r8", fm_cap=8):
+def conv_oracle(cs, kind="r8", fm_cap=8, ran3_words=None, between=None):
     """convmix on a synthetic.convection_case() dict, one entry per call: ztra1, cbaseflux, lconv / nconvtop per column,
-    the random number each particle drew (-1: none), the redistribution matrices of the first fm_cap convective columns."""
+    the random number each particle drew (-1: none), the redistribution matrices of the first fm_cap convective columns.
+    ran3_words: the state of the module's ran3 stream to start from (Oracle.ran3_words(); redist's own seed, word 59, is
+    set to its initial -88); default: an unseeded stream.  between(ic, arrays, words): called after every call with the
+    particle arrays {x, y, z} and the stream state, all of which it may change in place (a test runs the trajectory step
+    there, on the same stream, as timemanager does between two calls of convmix)."""
     build()
     lib = C.CDLL(os.path.join(HERE, f"libcvoracle_{kind}.so"))
     nx, ny, nuvz = (int(v) for v in cs["grid"])
     n = int(cs["npart"])
     nl = int(cs["nconvlev"])
     keep = {k: _f64(cs[k]) for k in ("akz", "bkz", "akm", "bkm", "ps", "tt2", "td2", "tth", "qvh", "xtra1", "ytra1")}
+    if between is not None:                                  # the callback moves the particles: not in the caller's arrays
+        keep["xtra1"], keep["ytra1"] = keep["xtra1"].copy(), keep["ytra1"].copy()
     z = _f64(cs["ztra1"]).copy()
     rt = np.float32 if kind == "r4" else np.float64
     z = z.astype(rt).astype(np.float64)                      # com_mod ztra1 is a default real
@@ -727,6 +743,11 @@ def conv_oracle(cs, kind="r8", fm_cap=8):
     a.ztra1 = z.ctypes.data
     a.fm_cap = fm_cap
     a.ran3_seeded = 0
+    if ran3_words is not None:
+        a.ran3_seeded = 1
+        for i in range(59):
+            a.state_words[i] = int(ran3_words[i])
+        a.state_words[59] = -88
     cbn = None
     if "nest" in cs:
         a.nest_on = 1
@@ -752,4 +773,9 @@ def conv_oracle(cs, kind="r8", fm_cap=8):
         out.append(dict(ztra1=z.copy(), cbaseflux=cb.copy(), lconv=lc, nconvtop=nt, rn=rn, fmassfrac=fm, fm_col=fid, fm_count=int(a.fm_count)))
         if cbn is not None:
             out[-1]["cbasefluxn"] = cbn.copy()
+        if between is not None:
+            words = np.array(a.state_words[:], np.int32)
+            between(ic, dict(x=keep["xtra1"], y=keep["ytra1"], z=z), words)
+            for i in range(60):
+                a.state_words[i] = int(words[i])
     return out
