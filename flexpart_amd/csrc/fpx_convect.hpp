@@ -673,6 +673,12 @@ __global__ void k_conv_list(const unsigned int *__restrict__ colflag, const unsi
   if (c < ncol && colflag[c]) act[rank[c]] = c;
 }
 
+// Columns per wave of the kernels that walk a sounding with one lane per column (k_conv_column_a, k_conv_prelude).  Fewer
+// than 64 (the other lanes leave at once) multiplies the waves in flight; measured with 16: column_a 1.15 -> 1.40 ms, prelude
+// 0.85 -> 0.90 ms at 61760 / 29248 columns -- the kernels are bound by the number of memory instructions, not by exposed latency.
+constexpr int kSerialLanes = 64;
+__host__ inline unsigned int serial_grid(int ncolumns) { return (unsigned int)((ncolumns + kSerialLanes - 1) / kSerialLanes); }
+
 // per-column scalars kept between the two column kernels
 enum Cst { C_psconv, C_tt2conv, C_td2conv, C_cbmf, C_cbmfold, C_plcl, C_nk, C_icb, C_iflag, C_inb, C_COUNT };
 
@@ -681,7 +687,8 @@ template <typename H>
 __global__ void __launch_bounds__(64) k_conv_column_a(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ cst, int nv, const int *__restrict__ act,
                                                       int nact, unsigned int *__restrict__ alive) {
 #pragma clang fp contract(off)
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((int)threadIdx.x >= kSerialLanes) return;
+  const int c = blockIdx.x * kSerialLanes + threadIdx.x;
   if (c >= nact) return;
   Scr<H> Sx{vbuf, nullptr, nact, c, nv, 0, 0};
   const Dom<H> &D = F.dom[F.domain_of(act[c])];
@@ -849,7 +856,11 @@ __global__ void __launch_bounds__(64) k_conv_prelude(Fields<H> F, H *__restrict_
                                                      const int *__restrict__ surv, int m0, int Bm, int nsurv, int *__restrict__ cflag,
                                                      int *__restrict__ ntop_raw) {
 #pragma clang fp contract(off)
-  CONV_LANE_
+  if ((int)threadIdx.x >= kSerialLanes) return;
+  const int cm = blockIdx.x * kSerialLanes + threadIdx.x;
+  if (cm >= Bm || m0 + cm >= nsurv) return;
+  const int c = surv[m0 + cm];
+  Scr<H> Sx{vbuf, mbuf, nact, c, nv, Bm, cm};
   CvState<H> st;
   st.cbmf = cst[(size_t)C_cbmf * nact + c];
   st.plcl = cst[(size_t)C_plcl * nact + c];

@@ -3193,8 +3193,7 @@ struct Engine : EngineBase {
     const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
     const bool conv_one_lane = getenv("FPX_CONV_ONE_LANE") != nullptr;     // the one-lane-per-column kernel (kept as the check of the level-parallel ones)
     const bool conv_rows_plain = getenv("FPX_CONV_ROWS_PLAIN") != nullptr;  // k_conv_rows without the LDS staging of its operands
-    const int nba = (nact + 63) / 64;
-    conv::k_conv_column_a<H><<<nba, 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, alive);
+    conv::k_conv_column_a<H><<<conv::serial_grid(nact), 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, alive);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(conv_lconv, 0, (size_t)nact * sizeof(int), stream));
     HIPCHK(hipMemsetAsync(conv_ntop, 0, (size_t)nact * sizeof(int), stream));
@@ -3218,7 +3217,7 @@ struct Engine : EngineBase {
         } else {
           const int nlev = F.nconvlev + 1;
           const unsigned int gl = conv::level_grid(Bm, nlev);
-          conv::k_conv_prelude<H><<<(Bm + 63) / 64, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, conv_cflag, conv_ntop_raw);
+          conv::k_conv_prelude<H><<<conv::serial_grid(Bm), 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, conv_cflag, conv_ntop_raw);
           if (conv_rows_plain) conv::k_conv_rows<H><<<gl, 64, 0, stream>>>(vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev);
           else conv::k_conv_rows_lds<H><<<conv::level_grid(Bm, (nlev + conv::kRowsPerBlock - 1) / conv::kRowsPerBlock), dim3(64, conv::kRowsPerBlock), 0, stream>>>(
                    vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev);

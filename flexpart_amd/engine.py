@@ -120,6 +120,7 @@ class Engine:
         if "outgrid" in sc:
             self.outgrid_from_scenario(sc)
         self.has_wet = bool(sc.get("wetdep", 0))
+        self.has_conv = False                        # set by conv_init: run() then calls convmix where timemanager does
         if self.has_wet:
             self.wet_from_scenario(sc)
 
@@ -345,6 +346,7 @@ class Engine:
             setattr(c, k, a.ctypes.data)
         check(self.lib.fpx_conv_init(self.h, C.byref(c)), "fpx_conv_init")
         self.conv_nuvz = c.nuvz
+        self.has_conv = True
 
     def upload_conv_fields(self, slot, ps, tt2, td2, tth, qvh, nuvzmax=None):
         """One wind-field slot of ps, tt2, td2 [ny][nx] and tth, qvh [nuvz][ny][nx] (compact), padded to the host layout."""
@@ -801,6 +803,8 @@ class Engine:
         for _ in range(int(self.sc["nsteps"]) if nsteps is None else nsteps):
             if self.has_wet and self.itime != 0:     # wetdepo first, timemanager.f90:164-169
                 self.wetdepo()
+            if self.has_conv:                        # timemanager.f90:258-262 (lconvection = 1)
+                self.convmix(self.itime)
             self.step()
             if self.gshape is not None:
                 self.conccalc(self.itime, 1.0)     # sample at the new positions (conccalc.f90)
