@@ -125,6 +125,62 @@ def test_device_convmix_matches_the_oracle(built, name, kind):
     eng.close()
 
 
+def _edge_cases():
+    base = syn.convection_case(n=1200, ncalls=1, seed=41)
+    n = int(base["npart"])
+    out = {}
+    out["nothing_due"] = dict(base, due=np.zeros((n, 1), bool))
+    cold = dict(base)                                              # no column gets past CONVECT's early exits; a mass flux from before
+    cold["tth"] = np.asarray(base["tth"]) - 45.0
+    cold["tt2"] = np.asarray(base["tt2"]) - 45.0
+    cold["td2"] = np.asarray(base["td2"]) - 60.0
+    cold["qvh"] = np.asarray(base["qvh"]) * 1e-3
+    out["no_column_convects"] = cold
+    drew = int(np.flatnonzero(conv_oracle(dict(base, height_nz=30000.0), "r8")[0]["rn"] >= 0)[0])      # a particle that is lifted
+    out["one_particle"] = dict(base, npart=1, due=np.ones((1, 1), bool), **{k: np.asarray(base[k])[drew:drew + 1] for k in ("xtra1", "ytra1", "ztra1")})
+    high = dict(base, ztra1=np.where(np.arange(n) % 3 == 0, 29999.9, np.asarray(base["ztra1"])))     # a third of them at the model top
+    out["particles_at_the_top"] = high
+    corner = dict(base, xtra1=np.where(np.arange(n) % 2 == 0, 0.2, float(base["grid"][0]) - 1.2),          # all in the outermost columns
+                  ytra1=np.where(np.arange(n) % 4 < 2, 0.2, float(base["grid"][1]) - 1.2))
+    out["outermost_columns"] = corner
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_device_convmix_edge_cases(built, kind):
+    """No particle due; no column that gets past CONVECT's early exits (the mass fluxes of before are still relaxed or reset); a
+    single particle; particles at the top of the model (the clamp below height(nz)); all particles in the four outermost
+    columns -- against the oracle, in parity mode."""
+    from flexpart_amd.engine import RNG_TABLE_SEQ
+    tol = 1e-9 if kind == "r8" else 2e-4
+    for name, cs in _edge_cases().items():
+        eng, sc = _engine(cs, kind, RNG_TABLE_SEQ)
+        cs = dict(cs, height_nz=float(np.asarray(sc["height"])[-1]))
+        w = conv_oracle(cs, kind)[0]
+        z0 = np.asarray(cs["ztra1"], dtype=np.float64)
+        moved, z = _call(eng, sc, cs, 0, z0)
+        cb = eng.cbaseflux()
+        eng.close()
+        assert np.abs(cb - w["cbaseflux"]).max() <= tol * max(np.abs(w["cbaseflux"]).max(), 1e-30), (name, kind)
+        assert np.array_equal(cb > 0, w["cbaseflux"] > 0), (name, kind)
+        close = np.abs(z - w["ztra1"]) <= tol * np.maximum(np.abs(w["ztra1"]), 1.0)
+        assert close.mean() >= (0.995 if len(z) > 1 else 1.0), (name, kind, close.mean())
+        rt = np.float32 if kind == "r4" else np.float64
+        z0r = z0.astype(rt).astype(np.float64)
+        if name == "nothing_due":
+            assert moved == 0 and np.array_equal(z, z0r) and np.array_equal(w["ztra1"], z0r)
+            assert np.array_equal(cb, np.asarray(cs["cbaseflux"]).astype(rt).astype(np.float64))
+        if name == "no_column_convects":
+            assert (w["lconv"] == 1).sum() == 0 and np.array_equal(w["ztra1"], z0r) and np.array_equal(z, z0r)
+        if name == "particles_at_the_top":
+            top = (np.arange(len(z)) % 3 == 0) & np.asarray(cs["due"])[:, 0]
+            conv_cols = w["lconv"].ravel()[np.rint(cs["ytra1"]).astype(int) * int(cs["grid"][0]) + np.rint(cs["xtra1"]).astype(int)] == 1
+            assert (top & conv_cols).sum() > 20 and np.all(w["ztra1"][top & conv_cols] == float(cs["height_nz"]) - 0.5)
+        if name == "outermost_columns":
+            assert (w["lconv"] >= 0).sum() == 4
+
+
 def _coupled_oracle(cs, sc, kind, ncalls):
     """timemanager's order on the restatements: convmix (convect_oracle.c), then the particle loop (flexpart_oracle.c), on the
     one ran3 stream random_mod gives both -- redist's seed -88 restarts it at the first call of convmix, advance's -7 at the
