@@ -54,10 +54,14 @@ struct Scr {
   H *vb;         // this column's element 0 of the vectors  [group][V_COUNT][nv][64]: every column that holds particles
   H *mb;         // this column's element 0 of the matrices [group][M_COUNT][nv][nv][64], column-major A(i,j) -> [j][i]: only
                  // the columns that reach the mixing computation
-  int nv;
+  int nv, ml;    // ml: this column's lane in its matrix group
   __device__ Scr(H *v, H *mat, int /*B*/, int c, int nv_, int /*Bm*/, int cm)
       : vb(v + (size_t)(c / kGroup) * V_COUNT * nv_ * kGroup + (c % kGroup)),
-        mb(mat ? mat + (size_t)(cm / kGroup) * M_COUNT * nv_ * nv_ * kGroup + (cm % kGroup) : nullptr), nv(nv_) {}
+        mb(mat ? mat + (size_t)(cm / kGroup) * M_COUNT * nv_ * nv_ * kGroup + (cm % kGroup) : nullptr), nv(nv_), ml(cm % kGroup) {}
+  // fmassfrac in walk-major form (k_conv_matrix_walk): the group's FMASS block re-used as 64 matrices [column][row][nv], so that
+  // the entries a particle walks along -- row levold of a forward run -- are consecutive in memory
+  __device__ H *fm_walk_group() const { return mb - ml + (size_t)M_fmass * nv * nv * kGroup; }
+  __device__ H *fm_walk() const { return fm_walk_group() + (size_t)ml * nv * nv; }
 };
 // what the first part of CONVECT (up to its early exits) hands to the second
 template <typename H>
@@ -1100,6 +1104,83 @@ __global__ void __launch_bounds__(64) k_conv_matrix(Fields<H> F, H *__restrict__
   lconv_out[c] = lconv;
   ntop_out[c] = lconv ? nconvtop : 0;
 }
+// k_conv_matrix for forward runs, with fmassfrac stored walk-major (Scr::fm_walk): k_conv_redist walks along row levold, and in
+// the interleaved layout every entry of a row is another cache line (the kernel moved 1.5 KB per particle, 85 % of the HBM
+// peak).  A lane still forms row k of its column; sixteen entries of each of the 64 columns are parked in LDS and written
+// out as 128-byte runs.  The diagonal entry, which takes the row sum, is written by its owner at the end.
+template <typename H>
+__global__ void __launch_bounds__(64) k_conv_matrix_walk(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, const H *__restrict__ cst, int nv, int nact,
+                                                         const int *__restrict__ act, const int *__restrict__ surv, int m0, int Bm, int nsurv, int nlev,
+                                                         const int *__restrict__ cflag, const int *__restrict__ ntop_raw,
+                                                         int *__restrict__ lconv_out, int *__restrict__ ntop_out) {
+#pragma clang fp contract(off)
+  __shared__ H tile[kGroup][17];
+  __shared__ int s_top[kGroup];
+  const int q_ = blockIdx.x >> 3;
+  const int lane = threadIdx.x;
+  const int cm = (int)(((blockIdx.x & 7) + 8 * (q_ / nlev)) * kGroup + lane);
+  const int k = q_ % nlev + 1;
+  const bool valid = cm < Bm && m0 + cm < nsurv;
+  if (!__syncthreads_or(valid)) return;
+  const int c = valid ? surv[m0 + cm] : 0;
+  Scr<H> Sx{vbuf, mbuf, nact, c, nv, Bm, valid ? cm : (int)(((blockIdx.x & 7) + 8 * (q_ / nlev)) * kGroup)};
+  int lconv = 0, nconvtop = 0, icb = 0, inb = 0, nk = 0;
+  H cbmf = HK(0.);
+  if (valid) {
+    const int iflag = cflag[c];
+    const H cbmfold = cst[(size_t)C_cbmfold * nact + c];
+    cbmf = cst[(size_t)C_cbmf * nact + c];
+    if (iflag != 1 && iflag != 4) cbmf = cbmfold;
+    else if (cbmf <= HK(0.) && cbmfold <= HK(0.)) cbmf = cbmfold;
+    else lconv = 1;
+    nconvtop = ntop_raw[c] + 1;
+    icb = (int)cst[(size_t)C_icb * nact + c]; inb = (int)cst[(size_t)C_inb * nact + c]; nk = (int)cst[(size_t)C_nk * nact + c];
+  }
+  const bool row_on = lconv && k <= nconvtop;
+  s_top[lane] = row_on ? nconvtop : 0;
+  int top_max = row_on ? nconvtop : 0;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(top_max, o); top_max = I_MAX(top_max, other); }
+  const H ga = HK(9.81);
+  if (lconv && k <= inb + 1) VV(sub, k) = k > 1 ? VV(fup, k - 1) - VV(fdown, k) : HK(0.);
+  H summe = HK(0.), fkk = HK(0.);
+  H *const blk = Sx.fm_walk_group();
+  const size_t nvnv = (size_t)nv * nv;
+  for (int kk = 1; kk <= top_max; kk += 16) {
+    H f8[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int q = kk + u;
+      H v = HK(0.);
+      if (row_on && q <= nconvtop) {
+        if (k > icb && k <= inb && q >= icb && q <= inb) v = MM(ment, k, q);
+        if (k == nk) v = VV(m, q) + v;                  // FMASS(nk,i) = M(i) + MENT(nk,i), convect43c.f90:925-930
+      }
+      f8[u] = F.delt * v;
+    }
+    __syncthreads();                                     // the previous tile has been written out
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      tile[lane][u] = f8[u];
+      if (row_on && kk + u <= nconvtop) { summe = summe + f8[u]; if (kk + u == k) fkk = f8[u]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int e = r * kGroup + lane, col = e >> 4, u = e & 15, q = kk + u;
+      if (q <= s_top[col] && q != k) blk[(size_t)col * nvnv + (size_t)k * nv + q] = tile[col][u];     // fmassfrac(k,q) of column col
+    }
+  }
+  if (row_on) blk[(size_t)lane * nvnv + (size_t)k * nv + k] = fkk + VV(dpr, k) / ga - summe;
+  if (k != 1 || !valid) return;
+  if (lconv) half_level_heights<H>(Sx, nconvtop, cst[(size_t)C_psconv * nact + c], cst[(size_t)C_tt2conv * nact + c], cst[(size_t)C_td2conv * nact + c]);
+  {
+    const Dom<H> &D = F.dom[F.domain_of(act[c])];
+    D.cb[act[c] - D.off] = cbmf;
+  }
+  lconv_out[c] = lconv;
+  ntop_out[c] = lconv ? nconvtop : 0;
+}
 #undef CONV_LANE_
 #undef CONV_LEVEL_LANE_
 
@@ -1119,7 +1200,7 @@ __global__ void k_conv_slots(const int *__restrict__ act, const unsigned int *__
 template <typename R, typename H, typename RNGF>
 __global__ void k_conv_redist(const int *__restrict__ pcol, const int4 *__restrict__ colslot, R *__restrict__ zt, long long n,
                               H *__restrict__ vbuf, H *__restrict__ mbuf, int nv, int nact, int Bm, int ldirect, int lsynctime, H height_nz,
-                              RNGF rngf, unsigned char *__restrict__ draws, int probe, unsigned long long *__restrict__ nmoved) {
+                              RNGF rngf, unsigned char *__restrict__ draws, int probe, unsigned long long *__restrict__ nmoved, int walk) {
 #pragma clang fp contract(off)
   long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n) return;
@@ -1133,16 +1214,18 @@ __global__ void k_conv_redist(const int *__restrict__ pcol, const int4 *__restri
   const H r_air = HK(287.05), ga = HK(9.81);
   H ztold = (H)zt[s], znew = ztold;
   bool touched = false;                                // the height is written back only where the routine assigns it
-  // (both searches below request the operands of several steps together: one lane per particle, every lane in another column
-  // -- the loops are chains of memory latencies otherwise)
+  // redist.f90:124-131 takes the first kz in 2..nconvtop with uvzlev(kz) >= ztold by a linear scan.  The half-level heights
+  // increase strictly with kz (every step adds konst * log(pold / pint) * tv > 0: pressure falls, temperatures are positive),
+  // so a bisection finds the same kz with seven gathers instead of up to nconvtop (the scan was a third of this kernel's
+  // HBM traffic: every level of the interleaved scratch is another cache line).
   int levold = 0;
-  for (int kz = 2; kz <= nconvtop && !levold; kz += 16) {
-    H uz[16];
-#pragma unroll
-    for (int u = 0; u < 16; u++) uz[u] = VV(uvzlev, I_MIN(kz + u, nconvtop));
-#pragma unroll
-    for (int u = 0; u < 16; u++)
-      if (!levold && kz + u <= nconvtop && uz[u] >= ztold) levold = kz + u - 1;
+  if (nconvtop >= 2 && VV(uvzlev, nconvtop) >= ztold) {
+    int lo = 2, hi = nconvtop;                           // invariant: uvzlev(hi) >= ztold, uvzlev(kz) < ztold for 2 <= kz < lo
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (VV(uvzlev, mid) >= ztold) hi = mid; else lo = mid + 1;
+    }
+    levold = lo - 1;
   }
   if (levold > 0) {
     if (probe) { draws[s] = 1; return; }
@@ -1151,12 +1234,13 @@ __global__ void k_conv_redist(const int *__restrict__ pcol, const int4 *__restri
     H ffraction = HK(0.), dlevfrac = HK(0.);
     const H totlevmass = VV(dpr, levold) / ga;
     bool found = false;
+    const H *fmw = walk ? Sx.fm_walk() + (size_t)levold * Sx.nv : nullptr;      // walk != 0: row levold of a forward run, consecutive
     for (int k = 1; k <= nconvtop && !found; k += 8) {
       H f8[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int q = I_MIN(k + u, nconvtop);
-        f8[u] = ldirect == 1 ? MM(fmass, levold, q) : MM(fmass, q, levold);
+        f8[u] = walk ? fmw[q] : ldirect == 1 ? MM(fmass, levold, q) : MM(fmass, q, levold);
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {

@@ -3192,6 +3192,8 @@ struct Engine : EngineBase {
     const H height_nz = (H)height_host[cfg.nz - 1];
     const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
     const bool conv_one_lane = getenv("FPX_CONV_ONE_LANE") != nullptr;     // the one-lane-per-column kernel (kept as the check of the level-parallel ones)
+    // forward runs: fmassfrac stored along the rows the particles walk (k_conv_matrix_walk); FPX_CONV_NO_WALK=1: the interleaved form
+    const bool conv_walk = !conv_one_lane && cfg.ldirect == 1 && getenv("FPX_CONV_NO_WALK") == nullptr;
     const bool conv_rows_plain = getenv("FPX_CONV_ROWS_PLAIN") != nullptr;  // k_conv_rows without the LDS staging of its operands
     conv::k_conv_column_a<H><<<conv::serial_grid(nact), 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, alive);
     HIPCHK(hipGetLastError());
@@ -3223,7 +3225,8 @@ struct Engine : EngineBase {
                    vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev);
           conv::k_conv_cols<H><<<gl, 64, 0, stream>>>(vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev, conv_ntop_raw);
           conv::k_conv_flux<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev, conv_cflag);
-          conv::k_conv_matrix<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
+          if (conv_walk) conv::k_conv_matrix_walk<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
+          else conv::k_conv_matrix<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
         }
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemsetAsync(conv_colslot, 0, (size_t)ncol * sizeof(int4), stream));
@@ -3232,17 +3235,17 @@ struct Engine : EngineBase {
           HIPCHK(hipMemsetAsync(conv_draws, 0, (size_t)n, stream));
           conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_colslot, P.zt, n, vbuf, mbuf, nv, nact, Bm,
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
-                                                                          conv_draws, 1, nullptr);
+                                                                          conv_draws, 1, nullptr, conv_walk ? 1 : 0);
           HIPCHK(hipGetLastError());
           int rrc = conv_replay<H>(n, F.ndom, off);
           if (rrc) return rrc;
           conv::k_conv_redist<R, H, ConvRngSeq<H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_colslot, P.zt, n, vbuf, mbuf, nv, nact, Bm,
                                                                           cfg.ldirect, cfg.lsynctime, height_nz, ConvRngSeq<H>{(const H *)conv_rn, P.pid},
-                                                                          conv_draws, 0, conv_nmoved);
+                                                                          conv_draws, 0, conv_nmoved, conv_walk ? 1 : 0);
         } else {
           conv::k_conv_redist<R, H, ConvRngCtr<R, H>><<<nb, kBlock, 0, stream>>>(conv_pcol, conv_colslot, P.zt, n, vbuf, mbuf, nv, nact, Bm,
                                                                              cfg.ldirect, cfg.lsynctime, height_nz, ConvRngCtr<R, H>{V, P.pid, step_counter},
-                                                                             conv_draws, 0, conv_nmoved);
+                                                                             conv_draws, 0, conv_nmoved, conv_walk ? 1 : 0);
         }
         HIPCHK(hipGetLastError());
       }
