@@ -58,8 +58,8 @@ struct Scr {
   __device__ Scr(H *v, H *mat, int /*B*/, int c, int nv_, int /*Bm*/, int cm)
       : vb(v + (size_t)(c / kGroup) * V_COUNT * nv_ * kGroup + (c % kGroup)),
         mb(mat ? mat + (size_t)(cm / kGroup) * M_COUNT * nv_ * nv_ * kGroup + (cm % kGroup) : nullptr), nv(nv_), ml(cm % kGroup) {}
-  // fmassfrac in walk-major form (k_conv_matrix_walk): the group's FMASS block re-used as 64 matrices [column][row][nv], so that
-  // the entries a particle walks along -- row levold of a forward run -- are consecutive in memory
+  // fmassfrac in walk-major form (k_conv_matrix_walk, _walk_t): the group's FMASS block re-used as 64 matrices [column][levold][nv], so
+  // that the entries a particle walks along -- row levold of a forward run, column levold of a backward one -- are consecutive in memory
   __device__ H *fm_walk_group() const { return mb - ml + (size_t)M_fmass * nv * nv * kGroup; }
   __device__ H *fm_walk() const { return fm_walk_group() + (size_t)ml * nv * nv; }
 };
@@ -1181,6 +1181,95 @@ __global__ void __launch_bounds__(64) k_conv_matrix_walk(Fields<H> F, H *__restr
   lconv_out[c] = lconv;
   ntop_out[c] = lconv ? nconvtop : 0;
 }
+// The same for backward runs, where k_conv_redist walks down column levold: the block holds sixteen consecutive rows k of its
+// 64 columns, so that the entries (k .. k+15, q) of a column -- consecutive in the transposed walk-major form
+// [column][q][k] -- leave as one 128-byte run.  Four q at a time go through the LDS tile.
+constexpr int kWalkRows = 16, kWalkQ = 4;
+template <typename H>
+__global__ void __launch_bounds__(64 * kWalkRows) k_conv_matrix_walk_t(Fields<H> F, H *__restrict__ vbuf, H *__restrict__ mbuf, const H *__restrict__ cst,
+                                                                       int nv, int nact, const int *__restrict__ act, const int *__restrict__ surv, int m0,
+                                                                       int Bm, int nsurv, int nlev, const int *__restrict__ cflag,
+                                                                       const int *__restrict__ ntop_raw, int *__restrict__ lconv_out,
+                                                                       int *__restrict__ ntop_out) {
+#pragma clang fp contract(off)
+  __shared__ H tile[kGroup][kWalkQ][kWalkRows + 1];
+  __shared__ int s_top[kGroup];
+  __shared__ int s_max;
+  const int nrb = (nlev + kWalkRows - 1) / kWalkRows;
+  const int q_ = blockIdx.x >> 3;
+  const int lane = threadIdx.x, w = threadIdx.y;
+  const int grp0 = (int)(((blockIdx.x & 7) + 8 * (q_ / nrb)) * kGroup);
+  const int cm = grp0 + lane;
+  const int k0 = (q_ % nrb) * kWalkRows + 1;
+  const int k = k0 + w;
+  const bool valid = cm < Bm && m0 + cm < nsurv;
+  if (!__syncthreads_or(valid)) return;
+  const int c = valid ? surv[m0 + cm] : 0;
+  Scr<H> Sx{vbuf, mbuf, nact, c, nv, Bm, valid ? cm : grp0};
+  int lconv = 0, nconvtop = 0, icb = 0, inb = 0, nk = 0;
+  H cbmf = HK(0.);
+  if (valid) {
+    const int iflag = cflag[c];
+    const H cbmfold = cst[(size_t)C_cbmfold * nact + c];
+    cbmf = cst[(size_t)C_cbmf * nact + c];
+    if (iflag != 1 && iflag != 4) cbmf = cbmfold;
+    else if (cbmf <= HK(0.) && cbmfold <= HK(0.)) cbmf = cbmfold;
+    else lconv = 1;
+    nconvtop = ntop_raw[c] + 1;
+    icb = (int)cst[(size_t)C_icb * nact + c]; inb = (int)cst[(size_t)C_inb * nact + c]; nk = (int)cst[(size_t)C_nk * nact + c];
+  }
+  const bool row_on = lconv && k <= nconvtop && k <= nlev;
+  if (w == 0) {
+    s_top[lane] = lconv && k0 <= nconvtop ? nconvtop : 0;       // columns with at least one of the block's rows
+    int top_max = s_top[lane];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const int other = __shfl_xor(top_max, o); top_max = I_MAX(top_max, other); }
+    if (lane == 0) s_max = top_max;
+  }
+  __syncthreads();
+  const int top_max = s_max;
+  const H ga = HK(9.81);
+  if (lconv && k <= nlev && k <= inb + 1) VV(sub, k) = k > 1 ? VV(fup, k - 1) - VV(fdown, k) : HK(0.);
+  H summe = HK(0.), fkk = HK(0.);
+  H *const blk = Sx.fm_walk_group();
+  const size_t nvnv = (size_t)nv * nv;
+  const int t = w * kGroup + lane;                                  // 0 .. 1023
+  for (int kk = 1; kk <= top_max; kk += kWalkQ) {
+    H f4[kWalkQ];
+#pragma unroll
+    for (int u = 0; u < kWalkQ; u++) {
+      const int q = kk + u;
+      H v = HK(0.);
+      if (row_on && q <= nconvtop) {
+        if (k > icb && k <= inb && q >= icb && q <= inb) v = MM(ment, k, q);
+        if (k == nk) v = VV(m, q) + v;                  // FMASS(nk,i) = M(i) + MENT(nk,i), convect43c.f90:925-930
+      }
+      f4[u] = F.delt * v;
+    }
+    __syncthreads();                                     // the previous tile has been written out
+#pragma unroll
+    for (int u = 0; u < kWalkQ; u++) {
+      tile[lane][u][w] = f4[u];
+      if (row_on && kk + u <= nconvtop) { summe = summe + f4[u]; if (kk + u == k) fkk = f4[u]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < kWalkQ; p++) {
+      const int pair = p * kGroup + (t >> 4), col = pair >> 2, u = pair & 3, kr = t & 15;
+      const int q = kk + u, kx = k0 + kr;
+      if (q <= s_top[col] && kx <= s_top[col] && q != kx) blk[(size_t)col * nvnv + (size_t)q * nv + kx] = tile[col][u][kr];   // fmassfrac(kx,q) of column col
+    }
+  }
+  if (row_on) blk[(size_t)lane * nvnv + (size_t)k * nv + k] = fkk + VV(dpr, k) / ga - summe;
+  if (k != 1 || !valid) return;
+  if (lconv) half_level_heights<H>(Sx, nconvtop, cst[(size_t)C_psconv * nact + c], cst[(size_t)C_tt2conv * nact + c], cst[(size_t)C_td2conv * nact + c]);
+  {
+    const Dom<H> &D = F.dom[F.domain_of(act[c])];
+    D.cb[act[c] - D.off] = cbmf;
+  }
+  lconv_out[c] = lconv;
+  ntop_out[c] = lconv ? nconvtop : 0;
+}
 #undef CONV_LANE_
 #undef CONV_LEVEL_LANE_
 
@@ -1234,7 +1323,7 @@ __global__ void k_conv_redist(const int *__restrict__ pcol, const int4 *__restri
     H ffraction = HK(0.), dlevfrac = HK(0.);
     const H totlevmass = VV(dpr, levold) / ga;
     bool found = false;
-    const H *fmw = walk ? Sx.fm_walk() + (size_t)levold * Sx.nv : nullptr;      // walk != 0: row levold of a forward run, consecutive
+    const H *fmw = walk ? Sx.fm_walk() + (size_t)levold * Sx.nv : nullptr;      // walk != 0: row (forward run) / column (backward) levold, consecutive
     for (int k = 1; k <= nconvtop && !found; k += 8) {
       H f8[8];
 #pragma unroll

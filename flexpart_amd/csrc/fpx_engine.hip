@@ -3192,8 +3192,9 @@ struct Engine : EngineBase {
     const H height_nz = (H)height_host[cfg.nz - 1];
     const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
     const bool conv_one_lane = getenv("FPX_CONV_ONE_LANE") != nullptr;     // the one-lane-per-column kernel (kept as the check of the level-parallel ones)
-    // forward runs: fmassfrac stored along the rows the particles walk (k_conv_matrix_walk); FPX_CONV_NO_WALK=1: the interleaved form
-    const bool conv_walk = !conv_one_lane && cfg.ldirect == 1 && getenv("FPX_CONV_NO_WALK") == nullptr;
+    // fmassfrac stored along the rows (forward runs) / columns (backward) the particles walk (k_conv_matrix_walk, _walk_t);
+    // FPX_CONV_NO_WALK=1: the interleaved form
+    const bool conv_walk = !conv_one_lane && getenv("FPX_CONV_NO_WALK") == nullptr;
     const bool conv_rows_plain = getenv("FPX_CONV_ROWS_PLAIN") != nullptr;  // k_conv_rows without the LDS staging of its operands
     conv::k_conv_column_a<H><<<conv::serial_grid(nact), 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, alive);
     HIPCHK(hipGetLastError());
@@ -3225,7 +3226,9 @@ struct Engine : EngineBase {
                    vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev);
           conv::k_conv_cols<H><<<gl, 64, 0, stream>>>(vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev, conv_ntop_raw);
           conv::k_conv_flux<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, surv, m0, Bm, nsurv, nlev, conv_cflag);
-          if (conv_walk) conv::k_conv_matrix_walk<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
+          if (conv_walk && cfg.ldirect == 1) conv::k_conv_matrix_walk<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
+          else if (conv_walk) conv::k_conv_matrix_walk_t<H><<<conv::level_grid(Bm, (nlev + conv::kWalkRows - 1) / conv::kWalkRows), dim3(64, conv::kWalkRows), 0, stream>>>(
+                                  F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
           else conv::k_conv_matrix<H><<<gl, 64, 0, stream>>>(F, vbuf, mbuf, cst, nv, nact, conv_act, surv, m0, Bm, nsurv, nlev, conv_cflag, conv_ntop_raw, conv_lconv, conv_ntop);
         }
         HIPCHK(hipGetLastError());

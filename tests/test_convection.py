@@ -263,7 +263,7 @@ def test_convmix_and_the_particle_loop_share_the_serial_stream(built, kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["r8", "r4"])
-@pytest.mark.parametrize("name", ["forward", "nested"])
+@pytest.mark.parametrize("name", ["forward", "backward", "nested"])
 def test_level_parallel_kernels_equal_the_one_lane_kernel(built, name, kind):
     """The mixing computation with a lane per (column, level) -- k_conv_prelude / rows / cols / flux / matrix -- forms every
     sum in the order of the one-lane-per-column kernel (FPX_CONV_ONE_LANE): heights and cloud-base mass fluxes bit for bit,

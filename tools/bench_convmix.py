@@ -29,14 +29,15 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--real", type=int, default=8, choices=(4, 8))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backward", action="store_true", help="a backward run (ldirect = -1): redist walks down the columns of fmassfrac")
     ap.add_argument("--unsorted", action="store_true", help="leave the particles in their random seeding order (default: fpx_sort_particles "
                     "first -- the order a run keeps them in)")
     a = ap.parse_args()
     from flexpart_amd import synthetic as syn
     from flexpart_amd.engine import Engine, RNG_PHILOX
     n = int(a.particles)
-    cs = syn.convection_case(nx=a.nx, ny=a.ny, nuvz=a.nuvz, n=1000, ncalls=1)
-    sc = syn.base_scenario(a.nx, a.ny, 30, global_grid=False, nsteps=1)
+    cs = syn.convection_case(nx=a.nx, ny=a.ny, nuvz=a.nuvz, n=1000, ncalls=1, ldirect=-1 if a.backward else 1)
+    sc = syn.base_scenario(a.nx, a.ny, 30, global_grid=False, nsteps=1, ldirect=-1 if a.backward else 1)
     eng = Engine(sc, compute_real_bytes=a.real, host_real_bytes=a.real, rng_mode=RNG_PHILOX, max_particles=n)
     eng.seed_particles(n, zmax=16000.0, itime0=0)
     eng.set_windtime(cs["memtime"], (1, 2))
@@ -62,13 +63,13 @@ def main():
     out = {"metric": "convmix, one call", "value": dms, "unit": "ms (device)", "higher_is_better": False,
            "dtype": "f64" if a.real == 8 else "f32", "data": "synthetic",
            "config": {"workload": f"{a.nx}x{a.ny} columns x {a.nuvz} levels, {n:.0e} particles, every column holds particles, " +
-                                  ("random storage order" if a.unsorted else "cell-sorted storage order"), "reps": a.reps},
+                                  ("random storage order" if a.unsorted else "cell-sorted storage order") + (", backward run" if a.backward else ""), "reps": a.reps},
            "wall_ms_whole_call": float(np.median([m[1] for m in ms])), "particles_moved": int(moved), "columns": a.nx * a.ny,
            "columns_with_mass_flux_after": nconv, "us_per_column": dms * 1e3 / (a.nx * a.ny)}
     # the dominant kernel against the HBM roofline, from the committed counter summary of this workload (tools/pmc_conv.sh)
     import glob
     pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"conv_{a.nx}x{a.ny}x{a.nuvz}_pmc.json")))
-    if pm and a.real == 8 and n == 10000000 and not a.unsorted:
+    if pm and a.real == 8 and n == 10000000 and not a.unsorted and not a.backward:
         ks = json.load(open(pm[-1]))["kernels"]
         name = max(ks, key=lambda k: ks[k]["avg_us"] or 0.0)
         e = ks[name]
