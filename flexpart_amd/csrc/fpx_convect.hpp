@@ -292,14 +292,14 @@ struct MixRow {
   }
 
   // entry jj, icb <= jj <= inb + 1: the mixing fraction of (i, jj), then the normalisation of (i, jj - 1).
-  // lvj .. epj: LV, QSCONV, TCONV, H, QCONV, CLW, EP at level min(jj, inb); ph0, ph1: PHCONV_HPA(jj - 1), PHCONV_HPA(jj)
-  __device__ void step(const Scr<H> &Sx, int jj, H lvj, H qsj, H tcj, H hj, H qcj, H clwj, H epj, H ph0, H ph1) {
+  // lvj .. qcj: LV, QSCONV, TCONV, H, QCONV at level min(jj, inb); bf2, cwat: the two level-only factors the prelude left in TP, HM;
+  // ph0, ph1: PHCONV_HPA(jj - 1), PHCONV_HPA(jj)
+  __device__ void step(const Scr<H> &Sx, int jj, H lvj, H qsj, H tcj, H hj, H qcj, H bf2, H cwat, H ph0, H ph1) {
 #pragma clang fp contract(off)
-    const H cpd = HK(1005.7), cpv = HK(1870.0), rv = HK(461.5);
-    H bf2, anum, denom, dei, altem, cwat, stemp, smid, sjmax, sjmin, delp, delm;
+    const H cpd = HK(1005.7), cpv = HK(1870.0);
+    H anum, denom, dei, altem, stemp, smid, sjmax, sjmin, delp, delm;
     H sv = HK(0.), me = HK(0.);
     if (jj <= inb) {
-      bf2 = HK(1.) + lvj * lvj * qsj / (rv * tcj * tcj * cpd);
       anum = hj - hp_i + (cpv - cpd) * tcj * (qti - qcj);
       denom = h_i - hp_i + (cpd - cpv) * (qc_i - qti) * tcj;
       dei = denom;
@@ -308,7 +308,6 @@ struct MixRow {
       if (jj == i) sv = HK(1.0);
       altem = sv * qc_i + (HK(1.) - sv) * qti - qsj;
       altem = altem / bf2;
-      cwat = clwj * (HK(1.) - epj);
       stemp = sv;
       if ((stemp < HK(0.0) || stemp > HK(1.0) || altem > cwat) && jj > i) {
         anum = anum - lvj * (qti - qsj - cwat * bf2);
@@ -389,7 +388,7 @@ __device__ void mix_row(const Scr<H> &Sx, int nk, int icb, int inb, int i) {
     for (int u = 0; u < kJ; u++) {
       const int jj = I_MIN(j + u, inb);
       lvj[u] = VV(lv, jj); qsj[u] = VV(qsconv, jj); tcj[u] = VV(tconv, jj); hj[u] = VV(h, jj); qcj[u] = VV(qconv, jj);
-      clwj[u] = VV(clw, jj); epj[u] = VV(ep, jj);
+      clwj[u] = VV(tp, jj); epj[u] = VV(hm, jj);           // BF2(jj), CWAT(jj)
     }
 #pragma unroll
     for (int u = 0; u < kJ + 1; u++) ph[u] = VV(phconv_hpa, I_MIN(j - 1 + u, inb + 1));      // PHCONV_HPA(j-1 .. j+kJ-1)
@@ -538,7 +537,17 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
     for (k = 2; k <= inb; k++) am = am + VV(m, k);
   VV(fup, 1) = am;
   if ((HK(2.) * g * dpinv * am) >= delti) iflag = 4;
-  if (PHASE == 3) { st.iflag = iflag; st.cbmf = cbmf; return true; }   // the level-parallel path continues in k_conv_rows ...
+  if (PHASE == 3) {                                     // the level-parallel path continues in k_conv_rows ...
+    // two factors of the mixing computation that depend on the level j only (convect43c.f90:594, :612), once per column instead
+    // of once per matrix entry: BF2(j) into TP, CWAT(j) into HM (both free from here on in this path)
+    for (i = icb; i <= inb; i++) {
+      const H lvj = VV(lv, i), qsj = VV(qsconv, i), tcj = VV(tconv, i), clwj = VV(clw, i), epj = VV(ep, i);
+      VV(tp, i) = HK(1.) + lvj * lvj * qsj / (rv * tcj * tcj * cpd);
+      VV(hm, i) = clwj * (HK(1.) - epj);
+    }
+    st.iflag = iflag; st.cbmf = cbmf;
+    return true;
+  }
   for (i = icb + 1; i <= inb; i++) sij_row<H>(Sx, nk, icb, inb, i);
   MM(sij, inb, inb) = HK(1.0);
   for (i = icb + 1; i <= inb; i++) norm_row<H>(Sx, nk, icb, inb, i);
@@ -925,7 +934,7 @@ __global__ void __launch_bounds__(64 * kRowsPerBlock) k_conv_rows_lds(H *__restr
   MixRow<H> row;
   if (row_on) row.init(Sx, nk, icb, inb, i);
   constexpr int kShare = (kStageItems + kRowsPerBlock - 1) / kRowsPerBlock;
-  const int vec_of[7] = {V_lv, V_qsconv, V_tconv, V_h, V_qconv, V_clw, V_ep};
+  const int vec_of[7] = {V_lv, V_qsconv, V_tconv, V_h, V_qconv, V_tp, V_hm};         // TP, HM: BF2(j), CWAT(j) from the prelude
   H pre[kShare];
   auto fetch = [&](int b) {
     const int j = icb + b * kJ;
