@@ -364,12 +364,13 @@ struct MixRow {
     asij = R_MAX(HK(1.0e-21), asij);
     asij = HK(1.0) / asij;
     H bsum = HK(0.0);
-    for (int j = icb; j <= inb; j += 8) {
-      H me[8];
+    constexpr int kF = 8;                                 // entries requested together (16, 32: slower -- registers of the whole block)
+    for (int j = icb; j <= inb; j += kF) {
+      H me[kF];
 #pragma unroll
-      for (int u = 0; u < 8; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
+      for (int u = 0; u < kF; u++) me[u] = j + u <= inb ? MM(ment, i, j + u) : HK(0.);
 #pragma unroll
-      for (int u = 0; u < 8; u++)
+      for (int u = 0; u < kF; u++)
         if (j + u <= inb) { const H v = me[u] * asij; MM(ment, i, j + u) = v; bsum = bsum + v; }
     }
     if (bsum < HK(1.0e-18)) { nent_i = 0; MM(ment, i, i) = m_i; }
@@ -985,15 +986,16 @@ __global__ void __launch_bounds__(64) k_conv_cols(H *__restrict__ vbuf, H *__res
   const H epsilon = HK(1.e-20);
   int top = 1;
   if (VV(m, k) > epsilon) top = I_MAX(k, nk);
-  // (rows r0..k upwards, inb..k+1 downwards: every entry is read once)
+  // (rows r0..k upwards, inb..k+1 downwards: every entry is read once; kC rows requested together)
+  constexpr int kC = 32;
   H run = HK(0.);
   const int kup = I_MIN(k, inb);
-  for (int i = r0; i <= kup; i += 8) {                  // upwards: C_k(i), needed for i < k
-    H b[8];
+  for (int i = r0; i <= kup; i += kC) {                  // upwards: C_k(i), needed for i < k
+    H b[kC];
 #pragma unroll
-    for (int u = 0; u < 8; u++) b[u] = i + u <= kup ? MM(ment, i + u, k) : HK(0.);
+    for (int u = 0; u < kC; u++) b[u] = i + u <= kup ? MM(ment, i + u, k) : HK(0.);
 #pragma unroll
-    for (int u = 0; u < 8; u++)
+    for (int u = 0; u < kC; u++)
       if (i + u <= kup) {
         if (b[u] > epsilon) top = I_MAX(top, k);        // max(k, i + u) = k
         run = run + b[u];
@@ -1002,12 +1004,12 @@ __global__ void __launch_bounds__(64) k_conv_cols(H *__restrict__ vbuf, H *__res
   }
   run = HK(0.);
   const int rdn = I_MAX(r0, k + 1);
-  for (int i = inb; i >= rdn; i -= 8) {                 // downwards: S_k(i), needed for i > k
-    H b[8];
+  for (int i = inb; i >= rdn; i -= kC) {                 // downwards: S_k(i), needed for i > k
+    H b[kC];
 #pragma unroll
-    for (int u = 0; u < 8; u++) b[u] = i - u >= rdn ? MM(ment, i - u, k) : HK(0.);
+    for (int u = 0; u < kC; u++) b[u] = i - u >= rdn ? MM(ment, i - u, k) : HK(0.);
 #pragma unroll
-    for (int u = 0; u < 8; u++)
+    for (int u = 0; u < kC; u++)
       if (i - u >= rdn) {
         if (b[u] > epsilon) top = I_MAX(top, i - u);    // max(k, i - u) = i - u
         run = run + b[u];
