@@ -1125,7 +1125,8 @@ __global__ void __launch_bounds__(64) k_conv_matrix_walk(Fields<H> F, H *__restr
                                                          const int *__restrict__ cflag, const int *__restrict__ ntop_raw,
                                                          int *__restrict__ lconv_out, int *__restrict__ ntop_out) {
 #pragma clang fp contract(off)
-  __shared__ H tile[kGroup][17];
+  constexpr int kWQ = 32, kWQs = 5;                      // entries of a row per tile (2^kWQs)
+  __shared__ H tile[kGroup][kWQ + 1];
   __shared__ int s_top[kGroup];
   const int q_ = blockIdx.x >> 3;
   const int lane = threadIdx.x;
@@ -1157,10 +1158,10 @@ __global__ void __launch_bounds__(64) k_conv_matrix_walk(Fields<H> F, H *__restr
   H summe = HK(0.), fkk = HK(0.);
   H *const blk = Sx.fm_walk_group();
   const size_t nvnv = (size_t)nv * nv;
-  for (int kk = 1; kk <= top_max; kk += 16) {
-    H f8[16];
+  for (int kk = 1; kk <= top_max; kk += kWQ) {
+    H f8[kWQ];
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
+    for (int u = 0; u < kWQ; u++) {
       const int q = kk + u;
       H v = HK(0.);
       if (row_on && q <= nconvtop) {
@@ -1171,14 +1172,14 @@ __global__ void __launch_bounds__(64) k_conv_matrix_walk(Fields<H> F, H *__restr
     }
     __syncthreads();                                     // the previous tile has been written out
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
+    for (int u = 0; u < kWQ; u++) {
       tile[lane][u] = f8[u];
       if (row_on && kk + u <= nconvtop) { summe = summe + f8[u]; if (kk + u == k) fkk = f8[u]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int e = r * kGroup + lane, col = e >> 4, u = e & 15, q = kk + u;
+    for (int r = 0; r < kWQ; r++) {
+      const int e = r * kGroup + lane, col = e >> kWQs, u = e & (kWQ - 1), q = kk + u;
       if (q <= s_top[col] && q != k) blk[(size_t)col * nvnv + (size_t)k * nv + q] = tile[col][u];     // fmassfrac(k,q) of column col
     }
   }
