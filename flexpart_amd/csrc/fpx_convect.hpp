@@ -437,16 +437,39 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   VV(tv, 1) = VV(tconv, 1) * (HK(1.) + VV(qconv, 1) * epsi - VV(qconv, 1));
   ahmin = HK(1.0e12);
   ihmin = nl;
-  for (i = 2; i <= nl + 1; i++) {
-    tvx = VV(tconv, i) * (HK(1.) + VV(qconv, i) * epsi - VV(qconv, i));
-    tvy = VV(tconv, i - 1) * (HK(1.) + VV(qconv, i - 1) * epsi - VV(qconv, i - 1));
-    VV(gz, i) = VV(gz, i - 1) + HK(0.5) * rd * (tvx + tvy) * (VV(pconv_hpa, i - 1) - VV(pconv_hpa, i)) / VV(phconv_hpa, i);
-    VV(cpn, i) = cpd * (HK(1.) - VV(qconv, i)) + cpv * VV(qconv, i);
-    VV(h, i) = VV(tconv, i) * VV(cpn, i) + VV(gz, i);
-    VV(lv, i) = lv0 - cpvmcl * (VV(tconv, i) - HK(273.15));
-    VV(hm, i) = (cpd * (HK(1.) - VV(qconv, i)) + cl * VV(qconv, i)) * (VV(tconv, i) - VV(tconv, 1)) + VV(lv, i) * VV(qconv, i) + VV(gz, i);
-    VV(tv, i) = VV(tconv, i) * (HK(1.) + VV(qconv, i) * epsi - VV(qconv, i));
-    if (i >= minorig && VV(hm, i) < ahmin && VV(hm, i) < VV(hm, i - 1)) { ahmin = VV(hm, i); ihmin = i; }
+  {
+    // (the running values of level i - 1 stay in registers, the inputs of eight levels are requested together: as written the
+    // loop reads back what it stored one iteration earlier, a memory round trip per level)
+    const H t_1 = VV(tconv, 1);
+    H t_p = t_1, q_p = VV(qconv, 1), p_p = VV(pconv_hpa, 1), gz_p = HK(0.0), hm_p = VV(lv, 1) * VV(qconv, 1);
+    for (int i0 = 2; i0 <= nl + 1; i0 += 8) {
+      H tb[8], qb[8], pb[8], phb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int ii = I_MIN(i0 + u, nl + 1);
+        tb[u] = VV(tconv, ii); qb[u] = VV(qconv, ii); pb[u] = VV(pconv_hpa, ii); phb[u] = VV(phconv_hpa, ii);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        i = i0 + u;
+        if (i > nl + 1) break;
+        const H t_i = tb[u], q_i = qb[u];
+        tvx = t_i * (HK(1.) + q_i * epsi - q_i);
+        tvy = t_p * (HK(1.) + q_p * epsi - q_p);
+        const H gz_i = gz_p + HK(0.5) * rd * (tvx + tvy) * (p_p - pb[u]) / phb[u];
+        const H cpn_i = cpd * (HK(1.) - q_i) + cpv * q_i;
+        const H lv_i = lv0 - cpvmcl * (t_i - HK(273.15));
+        const H hm_i = (cpd * (HK(1.) - q_i) + cl * q_i) * (t_i - t_1) + lv_i * q_i + gz_i;
+        VV(gz, i) = gz_i;
+        VV(cpn, i) = cpn_i;
+        VV(h, i) = t_i * cpn_i + gz_i;
+        VV(lv, i) = lv_i;
+        VV(hm, i) = hm_i;
+        VV(tv, i) = t_i * (HK(1.) + q_i * epsi - q_i);
+        if (i >= minorig && hm_i < ahmin && hm_i < hm_p) { ahmin = hm_i; ihmin = i; }
+        t_p = t_i; q_p = q_i; p_p = pb[u]; gz_p = gz_i; hm_p = hm_i;
+      }
+    }
   }
   ihmin = I_MIN(ihmin, nl - 1);
   ahmax = HK(0.0);
@@ -714,23 +737,38 @@ __global__ void __launch_bounds__(64) k_conv_column_a(Fields<H> F, H *__restrict
   cst[(size_t)C_psconv * nact + c] = psconv;
   cst[(size_t)C_tt2conv * nact + c] = (D.tt2[F.m1][col] * dt2 + D.tt2[F.m2][col] * dt1) * dtt;
   cst[(size_t)C_td2conv * nact + c] = (D.td2[F.m1][col] * dt2 + D.td2[F.m2][col] * dt1) * dtt;
-  for (int kz = 1; kz <= nuvz - 1; kz++) {
-    VV(tconv, kz) = (D.tth[F.m1][(size_t)kz * n2 + col] * dt2 + D.tth[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
-    VV(qconv, kz) = (D.qvh[F.m1][(size_t)kz * n2 + col] * dt2 + D.qvh[F.m2][(size_t)kz * n2 + col] * dt1) * dtt;
-  }
+  // convmix.f90:149-160 and calcmatrix.f90:56-90 level by level.  The reference fills its arrays in three loops; here one loop
+  // carries the values in registers (a value stored to the scratch and read back in the next loop, or the next iteration,
+  // costs a memory round trip each time) and the field values of eight levels are requested together.
   VV(phconv, 1) = psconv;
-  for (int kuvz = 2; kuvz <= nuvz; kuvz++) {
-    const int k = kuvz - 1;
-    VV(pconv, k) = (F.akz[kuvz - 1] + F.bkz[kuvz - 1] * psconv);
-    VV(phconv, kuvz) = (F.akm[kuvz - 1] + F.bkm[kuvz - 1] * psconv);
-    VV(dpr, k) = VV(phconv, k) - VV(phconv, kuvz);
-    VV(qsconv, k) = cp::f_qvsat<H>(VV(pconv, k), VV(tconv, k));
+  H ph_lo = psconv;                                        // phconv(k)
+  for (int k0 = 1; k0 <= nuvz - 1; k0 += 8) {
+    H t1[8], t2[8], q1[8], q2[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const size_t o = (size_t)I_MIN(k0 + u, nuvz - 1) * n2 + col;
+      t1[u] = D.tth[F.m1][o]; t2[u] = D.tth[F.m2][o]; q1[u] = D.qvh[F.m1][o]; q2[u] = D.qvh[F.m2][o];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int k = k0 + u;
+      if (k > nuvz - 1) break;
+      const H tc = (t1[u] * dt2 + t2[u] * dt1) * dtt;
+      VV(tconv, k) = tc;
+      VV(qconv, k) = (q1[u] * dt2 + q2[u] * dt1) * dtt;
+      const H pc = (F.akz[k] + F.bkz[k] * psconv);           // pconv(k), phconv(k+1): level kuvz = k + 1 of the 0-based tables
+      const H ph_hi = (F.akm[k] + F.bkm[k] * psconv);
+      VV(pconv, k) = pc;
+      VV(phconv, k + 1) = ph_hi;
+      VV(dpr, k) = ph_lo - ph_hi;
+      VV(qsconv, k) = cp::f_qvsat<H>(pc, tc);
+      if (k <= nl + 1) {
+        VV(pconv_hpa, k) = pc / HK(100.);
+        VV(phconv_hpa, k) = ph_lo / HK(100.);
+      }
+      ph_lo = ph_hi;
+    }
   }
-  for (int k = 1; k <= nl + 1; k++) {
-    VV(pconv_hpa, k) = VV(pconv, k) / HK(100.);
-    VV(phconv_hpa, k) = VV(phconv, k) / HK(100.);
-  }
-  VV(phconv_hpa, nl + 1) = VV(phconv, nl + 1) / HK(100.);
   CvState<H> st;
   st.nk = 0; st.icb = 0; st.inb = 0; st.iflag = 0; st.plcl = HK(0.);
   st.cbmf = D.cb[col];
