@@ -95,28 +95,44 @@ __device__ void tlift(const Scr<H> &Sx, int icb, int nk, int nl, int kk) {
   nst = icb;
   nsb = icb;
   if (kk == 2) { nst = nl; nsb = icb + 1; }
-  for (i = nsb; i <= nst; i++) {
-    tg = VV(tconv, i);
-    qg = VV(qsconv, i);
-    alv = lv0 - cpvmcl * (VV(tconv, i) - HK(273.15));
-    for (j = 1; j <= 2; j++) {
-      s = cpd + alv * alv * qg / (rv * VV(tconv, i) * VV(tconv, i));
-      s = HK(1.) / s;
-      ahg = cpd * tg + (cl - cpd) * VV(qconv, nk) * VV(tconv, i) + alv * qg + VV(gz, i);
-      tg = tg + s * (ah0 - ahg);
-      tg = R_MAX(tg, HK(35.0));
-      tc = tg - HK(273.15);
-      denom = HK(243.5) + tc;
-      if (tc >= HK(0.0)) es = HK(6.112) * M<H>::exp(HK(17.67) * tc / denom);
-      else es = M<H>::exp(HK(23.33086) - HK(6111.72784) / tg + HK(0.15215) * M<H>::log(tg));
-      qg = eps0 * es / (VV(pconv_hpa, i) - es * (HK(1.) - eps0));
+  // (values that the reference stores and reads back at once stay in registers, the inputs of eight levels are requested together)
+  const H q_nk = VV(qconv, nk);
+  for (int i0 = nsb; i0 <= nst; i0 += 8) {
+    H tcv[8], qsv[8], gzv[8], ppv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int ii = I_MIN(i0 + u, nst);
+      tcv[u] = VV(tconv, ii); qsv[u] = VV(qsconv, ii); gzv[u] = VV(gz, ii); ppv[u] = VV(pconv_hpa, ii);
     }
-    alv = lv0 - cpvmcl * (VV(tconv, i) - HK(273.15));
-    VV(tp, i) = (ah0 - (cl - cpd) * VV(qconv, nk) * VV(tconv, i) - VV(gz, i) - alv * qg) / cpd;
-    VV(clw, i) = VV(qconv, nk) - qg;
-    VV(clw, i) = R_MAX(HK(0.0), VV(clw, i));
-    rg = qg / (HK(1.) - VV(qconv, nk));
-    VV(tvp, i) = VV(tp, i) * (HK(1.) + rg * epsi);
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      i = i0 + u;
+      if (i > nst) break;
+      const H t_i = tcv[u], gz_i = gzv[u];
+      tg = t_i;
+      qg = qsv[u];
+      alv = lv0 - cpvmcl * (t_i - HK(273.15));
+      for (j = 1; j <= 2; j++) {
+        s = cpd + alv * alv * qg / (rv * t_i * t_i);
+        s = HK(1.) / s;
+        ahg = cpd * tg + (cl - cpd) * q_nk * t_i + alv * qg + gz_i;
+        tg = tg + s * (ah0 - ahg);
+        tg = R_MAX(tg, HK(35.0));
+        tc = tg - HK(273.15);
+        denom = HK(243.5) + tc;
+        if (tc >= HK(0.0)) es = HK(6.112) * M<H>::exp(HK(17.67) * tc / denom);
+        else es = M<H>::exp(HK(23.33086) - HK(6111.72784) / tg + HK(0.15215) * M<H>::log(tg));
+        qg = eps0 * es / (ppv[u] - es * (HK(1.) - eps0));
+      }
+      alv = lv0 - cpvmcl * (t_i - HK(273.15));
+      const H tp_i = (ah0 - (cl - cpd) * q_nk * t_i - gz_i - alv * qg) / cpd;
+      VV(tp, i) = tp_i;
+      H clw_i = q_nk - qg;
+      clw_i = R_MAX(HK(0.0), clw_i);
+      VV(clw, i) = clw_i;
+      rg = qg / (HK(1.) - q_nk);
+      VV(tvp, i) = tp_i * (HK(1.) + rg * epsi);
+    }
   }
 }
 
@@ -495,32 +511,74 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   nk = st.nk; icb = st.icb; plcl = st.plcl;
   tlift<H>(Sx, icb, nk, nl, 2);
   for (i = 1; i <= nk; i++) { VV(ep, i) = HK(0.0); VV(sigp, i) = sigs; }
-  for (i = nk + 1; i <= nl; i++) {
-    tca = VV(tp, i) - HK(273.15);
-    if (tca >= HK(0.0)) elacrit = elcrit; else elacrit = elcrit * (HK(1.0) - tca / tlcrit);
-    elacrit = R_MAX(elacrit, HK(0.0));
-    epmax = HK(0.999);
-    VV(ep, i) = epmax * (HK(1.0) - elacrit / R_MAX(VV(clw, i), HK(1.0e-8)));
-    VV(ep, i) = R_MAX(VV(ep, i), HK(0.0));
-    VV(ep, i) = R_MIN(VV(ep, i), epmax);
-    VV(sigp, i) = sigs;
+  // (in the level loops from here to the normalised M the inputs of eight levels are requested together and values the
+  // reference stores and reads back at once stay in registers: as written every level costs one to three memory round trips)
+  epmax = HK(0.999);
+  for (int i0 = nk + 1; i0 <= nl; i0 += 8) {
+    H tpv[8], clv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { const int ii = I_MIN(i0 + u, nl); tpv[u] = VV(tp, ii); clv[u] = VV(clw, ii); }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      i = i0 + u;
+      if (i > nl) break;
+      tca = tpv[u] - HK(273.15);
+      if (tca >= HK(0.0)) elacrit = elcrit; else elacrit = elcrit * (HK(1.0) - tca / tlcrit);
+      elacrit = R_MAX(elacrit, HK(0.0));
+      H ep_i = epmax * (HK(1.0) - elacrit / R_MAX(clv[u], HK(1.0e-8)));
+      ep_i = R_MAX(ep_i, HK(0.0));
+      ep_i = R_MIN(ep_i, epmax);
+      VV(ep, i) = ep_i;
+      VV(sigp, i) = sigs;
+    }
   }
-  for (i = icb + 1; i <= nl; i++) VV(tvp, i) = VV(tvp, i) - VV(tp, i) * VV(qconv, nk);
-  VV(tvp, nl + 1) = VV(tvp, nl) - (VV(gz, nl + 1) - VV(gz, nl)) / cpd;
-  for (i = 1; i <= nl + 1; i++) {
-    VV(hp, i) = VV(h, i); VV(nent, i) = 0;
+  {
+    const H q_nk = VV(qconv, nk);
+    H tvp_nl = HK(0.);
+    for (int i0 = icb + 1; i0 <= nl; i0 += 8) {
+      H a8[8], b8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int ii = I_MIN(i0 + u, nl); a8[u] = VV(tvp, ii); b8[u] = VV(tp, ii); }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        i = i0 + u;
+        if (i > nl) break;
+        tvp_nl = a8[u] - b8[u] * q_nk;
+        VV(tvp, i) = tvp_nl;
+      }
+    }
+    if (icb + 1 > nl) tvp_nl = VV(tvp, nl);
+    VV(tvp, nl + 1) = tvp_nl - (VV(gz, nl + 1) - VV(gz, nl)) / cpd;
+  }
+  for (int i0 = 1; i0 <= nl + 1; i0 += 8) {
+    H h8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) h8[u] = VV(h, I_MIN(i0 + u, nl + 1));
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + u <= nl + 1) { VV(hp, i0 + u) = h8[u]; VV(nent, i0 + u) = 0; }
   }
   cape = HK(0.0); capem = HK(0.0);
   inb = icb + 1; inb1 = inb;
   byp = HK(0.0);
-  for (i = icb + 1; i <= nl - 1; i++) {
-    by = (VV(tvp, i) - VV(tv, i)) * (VV(phconv_hpa, i) - VV(phconv_hpa, i + 1)) / VV(pconv_hpa, i);
-    cape = cape + by;
-    if (by >= HK(0.0)) inb1 = i + 1;
-    if (cape > HK(0.0)) {
-      inb = i + 1;
-      byp = (VV(tvp, i + 1) - VV(tv, i + 1)) * (VV(phconv_hpa, i + 1) - VV(phconv_hpa, i + 2)) / VV(pconv_hpa, i + 1);
-      capem = cape;
+  for (int i0 = icb + 1; i0 <= nl - 1; i0 += 8) {
+    H tvpv[9], tvv[9], phv[10], ppv[9];                    // levels i0 .. i0 + 8 (+ 9 for PHCONV_HPA); nl + 1 is the last that exists
+#pragma unroll
+    for (int u = 0; u < 9; u++) { const int ii = I_MIN(i0 + u, nl); tvpv[u] = VV(tvp, ii); tvv[u] = VV(tv, ii); ppv[u] = VV(pconv_hpa, ii); }
+#pragma unroll
+    for (int u = 0; u < 10; u++) phv[u] = VV(phconv_hpa, I_MIN(i0 + u, nl + 1));
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      i = i0 + u;
+      if (i > nl - 1) break;
+      by = (tvpv[u] - tvv[u]) * (phv[u] - phv[u + 1]) / ppv[u];
+      cape = cape + by;
+      if (by >= HK(0.0)) inb1 = i + 1;
+      if (cape > HK(0.0)) {
+        inb = i + 1;
+        byp = (tvpv[u + 1] - tvv[u + 1]) * (phv[u + 1] - phv[u + 2]) / ppv[u + 1];
+        capem = cape;
+      }
     }
   }
   inb = I_MAX(inb, inb1);
@@ -531,7 +589,17 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   frac = -cape / defrac;
   frac = R_MIN(frac, HK(1.0));
   frac = R_MAX(frac, HK(0.0));
-  for (i = icb; i <= inb; i++) VV(hp, i) = VV(h, nk) + (VV(lv, i) + (cpd - cpv) * VV(tconv, i)) * VV(ep, i) * VV(clw, i);
+  {
+    const H h_nk = VV(h, nk);
+    for (int i0 = icb; i0 <= inb; i0 += 8) {
+      H a8[8], b8[8], c8[8], d8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { const int ii = I_MIN(i0 + u, inb); a8[u] = VV(lv, ii); b8[u] = VV(tconv, ii); c8[u] = VV(ep, ii); d8[u] = VV(clw, ii); }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i0 + u <= inb) VV(hp, i0 + u) = h_nk + (a8[u] + (cpd - cpv) * b8[u]) * c8[u] * d8[u];
+    }
+  }
   dbosum = HK(0.0);
   tvpplcl = VV(tvp, icb - 1) - rd * VV(tvp, icb - 1) * (VV(pconv_hpa, icb - 1) - plcl) / (VV(cpn, icb - 1) * VV(pconv_hpa, icb - 1));
   tvaplcl = VV(tv, icb) + (VV(tvp, icb) - VV(tvp, icb + 1)) * (plcl - VV(pconv_hpa, icb)) / (VV(pconv_hpa, icb) - VV(pconv_hpa, icb + 1));
@@ -547,13 +615,29 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   cbmf = R_MAX(cbmf, HK(0.0));
   if (cbmf == HK(0.0) && cbmfold == HK(0.0)) RETURN_;
   VV(m, icb) = HK(0.0);
-  for (i = icb + 1; i <= inb; i++) {
-    k = I_MIN(i, inb1);
-    dbo = R_ABS(VV(tv, k) - VV(tvp, k)) + entp * HK(0.02) * (VV(phconv_hpa, k) - VV(phconv_hpa, k + 1));
-    dbosum = dbosum + dbo;
-    VV(m, i) = cbmf * dbo;
+  for (int i0 = icb + 1; i0 <= inb; i0 += 8) {
+    H a8[8], b8[8], c8[8], d8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      k = I_MIN(I_MIN(i0 + u, inb), inb1);
+      a8[u] = VV(tv, k); b8[u] = VV(tvp, k); c8[u] = VV(phconv_hpa, k); d8[u] = VV(phconv_hpa, k + 1);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      if (i0 + u > inb) break;
+      dbo = R_ABS(a8[u] - b8[u]) + entp * HK(0.02) * (c8[u] - d8[u]);
+      dbosum = dbosum + dbo;
+      VV(m, i0 + u) = cbmf * dbo;
+    }
   }
-  for (i = icb + 1; i <= inb; i++) VV(m, i) = VV(m, i) / dbosum;
+  for (int i0 = icb + 1; i0 <= inb; i0 += 8) {
+    H a8[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) a8[u] = VV(m, I_MIN(i0 + u, inb));
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (i0 + u <= inb) VV(m, i0 + u) = a8[u] / dbosum;
+  }
   // FUP(1), :800-810 (needs M only; the reference has it after the two loop nests below)
   dpinv = HK(0.01) / (VV(phconv_hpa, 1) - VV(phconv_hpa, 2));
   am = HK(0.0);
@@ -564,10 +648,19 @@ __device__ bool convect(const Scr<H> &Sx, int nl, H delt, CvState<H> &st, int &n
   if (PHASE == 3) {                                     // the level-parallel path continues in k_conv_rows ...
     // two factors of the mixing computation that depend on the level j only (convect43c.f90:594, :612), once per column instead
     // of once per matrix entry: BF2(j) into TP, CWAT(j) into HM (both free from here on in this path)
-    for (i = icb; i <= inb; i++) {
-      const H lvj = VV(lv, i), qsj = VV(qsconv, i), tcj = VV(tconv, i), clwj = VV(clw, i), epj = VV(ep, i);
-      VV(tp, i) = HK(1.) + lvj * lvj * qsj / (rv * tcj * tcj * cpd);
-      VV(hm, i) = clwj * (HK(1.) - epj);
+    for (int i0 = icb; i0 <= inb; i0 += 8) {
+      H a8[8], b8[8], c8[8], d8[8], e8[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int ii = I_MIN(i0 + u, inb);
+        a8[u] = VV(lv, ii); b8[u] = VV(qsconv, ii); c8[u] = VV(tconv, ii); d8[u] = VV(clw, ii); e8[u] = VV(ep, ii);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (i0 + u <= inb) {
+          VV(tp, i0 + u) = HK(1.) + a8[u] * a8[u] * b8[u] / (rv * c8[u] * c8[u] * cpd);
+          VV(hm, i0 + u) = d8[u] * (HK(1.) - e8[u]);
+        }
     }
     st.iflag = iflag; st.cbmf = cbmf;
     return true;
