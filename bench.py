@@ -5,8 +5,9 @@ One "step" = one pass of the particle loop (reference timemanager.f90:531-712)
 over every particle resident on the GPU(s): one k_advance launch per GPU.
 Default workload (N=1): BASELINE config 3 -- 1e8 particles on the synthetic
 361x181x138 ECMWF-shaped grid, Hanna turbulence + CBL scheme, counter RNG, fp64.
-With --gpus N>1 (launched by torch.distributed.run, one rank per GPU) the ranks
-share ONE cloud of --particles particles (BASELINE configs 3-5: 1e8): rank g owns
+With --gpus N>1 the ranks (one per GPU; launched by torch.distributed.run, or by bench.py itself
+when WORLD_SIZE is not set -- a launcher hop before anything touches the GPU) share ONE cloud of
+--particles particles (BASELINE configs 3-5: 1e8): rank g owns
 the contiguous range [g*P/N, (g+1)*P/N) of particle numbers (the reference's MPI
 layout, README_PARALLEL.md:60-67) -- strong scaling, no data-path collective
 (particles are independent); the counter RNG is keyed on the
@@ -108,6 +109,55 @@ def measured_traffic(config, nper, kernel):
 N_SIMD = 256 * 4        # MI355X: 256 CUs x 4 SIMDs
 
 
+def relaunch_argv(ngpus, argv, port):
+    """The command `python bench.py --gpus N ...` re-launches itself as when it was not started by a launcher
+    (WORLD_SIZE unset): the driver's own form, one rank per GPU of this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def child_bench_cmd(args):
+    return [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(args.config), "--real", str(args.real),
+            "--rng", args.rng, "--sort-interval", str(args.sort_interval), "--steps", "3", "--warmup", "1",
+            "--no-cpu-baseline", "--no-pmc"] + (["--particles", repr(args.particles)] if args.particles else [])
+
+
+def live_traffic(args, kernel):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: two child `rocprofv3 --pmc` passes over the same
+    command, FETCH_SIZE and WRITE_SIZE in a pass each (MI355X_MICROARCH.md, HBM section: both count KiB, separate passes;
+    on gfx950 FETCH_SIZE reports half the bytes of wide reads, so it is doubled; the raw counters are kept next to it)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, {"error": "rocprofv3 not found"}
+    raw = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="fpx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "--"] + child_bench_cmd(args)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, {"error": f"{ctr} pass failed (rc {r.returncode}): {r.stderr[-300:]}"}
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if kernel + "<" in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            if not vals:
+                return None, {"error": f"no dispatch of {kernel} in the {ctr} pass"}
+            vals.sort()
+            raw[ctr + "_KiB"] = vals[len(vals) // 2 if len(vals) > 2 else 0]      # a steady-state launch
+        except Exception as ex:
+            return None, {"error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return (2.0 * raw["FETCH_SIZE_KiB"] + raw["WRITE_SIZE_KiB"]) * 1024.0, raw
+
+
 def live_valu(args, kernel, avg_ms, launch_work):
     """VALU issue time of the dominant kernel, measured in THIS run: a child `rocprofv3 --pmc` pass over the same
     command (same workload, seeds and sizes; one warm-up and two timed steps) counts the wave-instructions the kernel
@@ -120,10 +170,7 @@ def live_valu(args, kernel, avg_ms, launch_work):
         return {"error": "rocprofv3 not found"}
     d = tempfile.mkdtemp(prefix="fpx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
     cmd = ["rocprofv3", "--pmc", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
-           "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(args.config), "--real", str(args.real),
-           "--rng", args.rng, "--sort-interval", str(args.sort_interval), "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--no-pmc"] + (["--particles", repr(args.particles)] if args.particles else [])
+           "GRBM_GUI_ACTIVE", "--output-format", "csv", "-d", d, "--"] + child_bench_cmd(args)
     try:
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
         files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
@@ -168,13 +215,15 @@ def cpu_baseline(args, sc, frac_pbl):
     nx, ny, nz = (int(v) for v in sc["grid"])
     s2.update(syn.make_particles(n, nx, ny, sc["height"], sc["hmix"], seed=0x5EED, frac_pbl=frac_pbl))
     kind = "r8" if args.real == 8 else "r4"
+    if "nest" in sc:
+        kind += "n"     # the reference built from its own par_mod_meteoswiss.f90 (maxnests = 1): oracle/build_ref.sh
     if sio.have_ref(kind):
         out = sio.run_reference(s2, kind, workdir=os.environ.get("TMPDIR", "/tmp"), timing=True, tag="bench")
         tsec, nadv = float(out["timing"][0]), float(out["timing"][1])
         which = "reference"
     else:
         from oracle.oracle import Oracle
-        o = Oracle(s2, kind)
+        o = Oracle(s2, kind[:2])
         t0 = time.time()
         nadv = 0
         for _ in range(2):
@@ -188,9 +237,15 @@ def cpu_baseline(args, sc, frac_pbl):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: start the N ranks ourselves, as a child process, before torch / HIP is touched here
+        import subprocess
+        raise SystemExit(subprocess.run(relaunch_argv(args.gpus, sys.argv[1:], free_port())).returncode)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE); they must agree")
     import torch
     dist = None
     # Rehearsal on a box with fewer GPUs than ranks (our own 1-GPU checks of the N > 1 code path): the ranks
@@ -226,12 +281,17 @@ def main():
     eng.seed_particles(nper, seed=0x5EED, frac_pbl=frac_pbl)   # slice [lo, hi) of the one global synthetic cloud
     if args.sort_interval > 0:
         eng.sort()          # a release normally arrives ordered; the synthetic cloud is random
-    if args.config in (4, 5) and world > 1:
+    transport = None
+    if world > 1:
+        # every multi-rank run has the communicator of the reference's MPI build: it carries the particle count the root
+        # reduces at every output (timemanager_mpi.f90:552-562) and, in configs 4-5, the grid sums (mpi_mod.f90:2451-2492)
         if rehearsal:       # ranks share a device: RCCL refuses that, the host transport (gloo) carries the reduction
             eng.comm_init_host(dist, world, rank)
+            transport = "host callback over gloo (rehearsal: ranks share a GPU)"
         else:
             uid = sharding.share_unique_id(dist, eng.comm_unique_id)
             eng.comm_init(uid, world, rank)
+            transport = "rccl"
     lsync = int(sc["lsynctime"])
     window = 10800
 
@@ -260,6 +320,8 @@ def main():
         do_step(i)
     if args.config in (4, 5):
         grid, _ = eng.grids(allreduce=world > 1)     # the grid reduction over the ranks + D2H of the sums: part of the job
+    # the end of the timed region is an output time: the particle count over the ranks, as the reference's root reduces it
+    (nlive_local, _), (nlive_total, numpart_total) = eng.count_particles(allreduce=world > 1)
     eng.sync()
     torch.cuda.synchronize()
     if dist:
@@ -296,7 +358,7 @@ def main():
     dom_name = {3: "k_prep", 1: "k_pbl_loop"}[dom]
     avg_ms = parts[dom] / max(launches, 1)
     achieved = b_alg * (nsteps_local / max(launches, 1)) / (avg_ms * 1e-3) / 1e9
-    traffic = measured_traffic(args.config, nper, dom_name)
+    traffic, traffic_src = measured_traffic(args.config, nper, dom_name), "committed PMC summary under profiles/ (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of the same command)"
     out = {
         "metric": "particle-steps/sec (whole node) + achieved HBM GB/s, 1e8 particles",
         "value": value, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps,
@@ -313,7 +375,8 @@ def main():
                                    if args.config == 5 else "")
                                 + f", rng={args.rng}, lsynctime=900"),
                    "particles_total": ntot, "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
-                   "sort_interval": args.sort_interval},
+                   "sort_interval": args.sort_interval, "live_particles_all_ranks": nlive_total, "numpart_all_ranks": numpart_total,
+                   "rccl_nranks": world if transport == "rccl" else 0, "reduction_transport": transport},
         # achieved / peak / frac: the HBM roofline on ALGORITHMIC bytes, as the bench contract defines it.  `bound` names what
         # actually limits the dominant kernel: config 2's k_prep is memory-latency bound at three waves per SIMD (gathers
         # and state streaming); the Langevin kernel of configs 3-5 is VALU-issue bound -- its HBM fraction is small by
@@ -321,7 +384,7 @@ def main():
         # the fraction that measures its distance to the hardware limit, from a counter pass of this very run.
         "roofline": {"bound": "hbm" if args.config == 2 else "valu", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "committed PMC summary under profiles/ (rocprofv3 FETCH_SIZE/WRITE_SIZE passes of the same command)" if traffic else None,
+                     "traffic_source": traffic_src if traffic else None,
                      "kernel": dom_name, "avg_launch_ms": avg_ms, "launches": launches,
                      "step_kernels_ms": {"k_prep": parts[3] / max(launches, 1), "worklist_sort": (parts[0] - parts[3]) / max(launches, 1),
                                          "k_pbl_loop": parts[1] / max(launches, 1), "k_pbl_finish": parts[2] / max(launches, 1)},
@@ -342,6 +405,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_pmc:
         # after the engine has released the GPU: the counter pass runs the same workload in a child process
         out["roofline"]["valu"] = live_valu(args, dom_name, avg_ms, nsteps_local / max(launches, 1))
+        t_live, raw = live_traffic(args, dom_name)
+        if t_live is not None:
+            out["roofline"]["traffic"] = t_live
+            out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (child processes, same workload); 2*FETCH + WRITE"
+        out["roofline"]["traffic_raw"] = raw
     if dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -9,10 +9,12 @@
 // Not computed: the dry-deposition velocities (getvdep, calcpar.f90:174-193: land-use tables stay with the host, vdep is
 // an input) and the potential vorticity (calcpv, :270).
 #pragma once
+#include "fpx_tu.hpp"
 #include <hip/hip_runtime.h>
 #include "fpx_verttransform.hpp"
 
 namespace fpx {
+FPX_TU_OPEN
 namespace cp {
 
 #define CK(x) ((H)(x))
@@ -175,4 +177,5 @@ __global__ void __launch_bounds__(256) k_calcpar(Args<H> A) {
 }
 
 }  // namespace cp
+FPX_TU_CLOSE
 }  // namespace fpx

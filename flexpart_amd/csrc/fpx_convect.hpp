@@ -21,12 +21,14 @@
 // Arithmetic is in the host's real kind H (the reference computes in its default real) with FMA contraction off and
 // in the reference's order of operations; only libm (exp, log, pow) can differ from the CPU result.
 #pragma once
+#include "fpx_tu.hpp"
 #include <hip/hip_runtime.h>
 
 #include "fpx_calcpar.hpp"
 #include "fpx_verttransform.hpp"
 
 namespace fpx {
+FPX_TU_OPEN
 namespace conv {
 
 using vt::M;
@@ -1538,4 +1540,5 @@ __global__ void k_conv_redist(const int *__restrict__ pcol, const int4 *__restri
 #undef I_MIN
 
 }  // namespace conv
+FPX_TU_CLOSE
 }  // namespace fpx

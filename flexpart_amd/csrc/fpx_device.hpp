@@ -9,10 +9,12 @@
 // horizontal position is 8-byte).  Constants are written K(x) so that they
 // round like the Fortran literals of a default-real-R build.
 #pragma once
+#include "fpx_tu.hpp"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace fpx {
+FPX_TU_OPEN
 
 #define K(x) ((R)(x))
 #define FPX_DEV __device__ __forceinline__
@@ -2350,4 +2352,5 @@ FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp0, int nunc, R 
 }
 
 #undef K
+FPX_TU_CLOSE
 }  // namespace fpx

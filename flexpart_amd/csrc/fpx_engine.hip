@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/flexpart_amd.h"
+#include "fpx_tu.hpp"
 #include "fpx_device.hpp"
 #include "fpx_verttransform.hpp"
 #include "fpx_calcpar.hpp"
@@ -26,8 +27,14 @@
 
 namespace fpx {
 
-static thread_local std::string g_err;
+// shared by the translation units (fpx_tu.hpp): the message behind fpx_last_error()
+#if FPX_TU_REAL == 4 || FPX_TU_PART > 0
+extern thread_local std::string g_err;
+#else
+thread_local std::string g_err;
+#endif
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
+FPX_TU_OPEN
 
 #define HIPCHK(expr)                                                                      \
   do {                                                                                    \
@@ -297,7 +304,7 @@ __global__ void k_seed(View<R> V, Parts<R> P, long long n, unsigned long long se
   double z = us < frac_pbl ? 10.0 + uz * fmax(hloc - 20.0, 1.0) : hloc + 10.0 + uz * (zmax - hloc - 10.0);
   P.xt[i] = x; P.yt[i] = y; P.zt[i] = (R)z;
   P.up[i] = 0; P.vp[i] = 0; P.wp[i] = 0; P.us[i] = 0; P.vs[i] = 0; P.ws[i] = 0;
-  P.idt[i] = 0; P.itra1[i] = itime0; P.itramem[i] = itime0; P.npoint[i] = 1; P.nclass[i] = 1; P.itrasplit[i] = 999999999;
+  P.idt[i] = 0; P.itra1[i] = itime0; P.itramem[i] = itime0; P.npoint[i] = 1; P.nclass[i] = 1; P.itrasplit[i] = V.ldirect * 999999999;   // "never", signed like itra1 + ldirect*itsplit (releaseparticles.f90:181)
   P.cbt[i] = 1; P.pid[i] = (unsigned int)i;
   for (int ks = 0; ks < V.nspec; ks++) P.xmass1[(size_t)ks * P.cap + i] = (R)1;
   }
@@ -844,7 +851,11 @@ __global__ void k_split(Parts<R> P, const unsigned int *__restrict__ slot_of_pid
   const long long j = slot_of_pid ? (long long)slot_of_pid[pid] : pid;
   const long long n = numpart + rank[pid];          // storage spaces behind numpart are identity-numbered
   const int itm = P.itramem[j];
-  const int its = 2 * (P.itrasplit[j] - itm) + itm;
+  // itrasplit(j) = 2*(itrasplit(j)-itramem(j))+itramem(j), timemanager.f90:486 -- in 64 bits, saturated at the "never" value
+  // (the reference's default integer would overflow once the doubled interval passes 2^31 s)
+  long long its64 = 2ll * ((long long)P.itrasplit[j] - itm) + itm;
+  its64 = its64 > 999999999ll ? 999999999ll : (its64 < -999999999ll ? -999999999ll : its64);
+  const int its = (int)its64;
   P.itrasplit[j] = its; P.itrasplit[n] = its;
   P.itramem[n] = itm; P.itra1[n] = P.itra1[j]; P.idt[n] = P.idt[j]; P.npoint[n] = P.npoint[j]; P.nclass[n] = P.nclass[j];
   P.xt[n] = P.xt[j]; P.yt[n] = P.yt[j]; P.zt[n] = P.zt[j];
@@ -985,6 +996,16 @@ __device__ __forceinline__ long long count_le_sorted(const unsigned char *__rest
     hi = nhi < hi ? nhi : hi;
   }
   return lo;
+}
+// live particles (itra1 /= -999999999) among the first n storage spaces: one atomic per block
+__global__ void __launch_bounds__(256) k_count_live(const int *__restrict__ itra1, long long n, unsigned long long *__restrict__ out) {
+  __shared__ unsigned int part[4];
+  unsigned int c = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) c += itra1[i] != kDead;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
 }
 __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, long long n, unsigned int *__restrict__ pbl_count, Stats *st) {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
@@ -1264,6 +1285,7 @@ __global__ void k_convert(const T *__restrict__ src, double *__restrict__ dst64,
 // engine
 // ---------------------------------------------------------------------------
 // ---------------------------------------------------------------------------
+FPX_TU_CLOSE   // one type for all translation units
 struct EngineBase {
   virtual ~EngineBase() {}
   virtual int set_height(const void *h, int n) = 0;
@@ -1294,6 +1316,7 @@ struct EngineBase {
   virtual int set_output_times(int loutnext, int loutstep) = 0;
   virtual int conccalc(int itime, double weight) = 0;
   virtual int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) = 0;
+  virtual int count_particles(int64_t *local, int64_t *total, int allreduce) = 0;
   virtual int comm_init(const void *id, int nbytes, int nranks, int rank) = 0;
   virtual int comm_init_host(int nranks, int rank, fpx_allreduce_fn fn, void *user) = 0;
   virtual int nests_init(const fpx_nests *n) = 0;
@@ -1325,6 +1348,14 @@ struct EngineBase {
   virtual int checkpoint_write(const char *path, int itime, int numparticlecount) = 0;
   virtual int checkpoint_read(const char *path, int32_t *itime, int64_t *numpart_out, int32_t *numparticlecount) = 0;
 };
+EngineBase *make_engine_f32(const fpx_config *cfg, int *rc);   // defined by the unit that holds Engine<float>
+// The three kernels of the step are compiled in units of their own (fpx_tu.hpp: FPX_TU_PART 1 and 2) and reach the
+// engine as untyped host-stub addresses; the engine casts them to the kernel's signature (same headers, same layout).
+// real_bytes 8|4 picks the arithmetic type.
+const void *step_kernel_prep(int real_bytes, bool drydep, bool init, bool polar, bool nest);
+const void *step_kernel_loop(int real_bytes, bool lean, int turbswitch, int cblflag, int rng_mode);
+const void *step_kernel_finish(int real_bytes, bool drydep, bool polar, bool nest);
+FPX_TU_OPEN
 
 template <typename R>
 struct Engine : EngineBase {
@@ -1526,7 +1557,8 @@ struct Engine : EngineBase {
 
     const int nb = (int)((cap + kBlock - 1) / kBlock);
     k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, (long long)cap, nullptr);
-    k_fill<int><<<nb, kBlock, 0, stream>>>(P.itrasplit, 999999999, 0, (long long)cap, nullptr);
+    // "never split" carries the sign of the run's direction: the test is ldirect*itime >= ldirect*itrasplit (timemanager.f90:478)
+    k_fill<int><<<nb, kBlock, 0, stream>>>(P.itrasplit, (cfg.ldirect < 0 ? -1 : 1) * 999999999, 0, (long long)cap, nullptr);
     k_iota_pid<<<nb, kBlock, 0, stream>>>(P.pid, 0, (long long)cap);
     k_iota_pid<<<nb, kBlock, 0, stream>>>(d_iota, 0, (long long)cap);
     HIPCHK(hipGetLastError());
@@ -1864,7 +1896,8 @@ struct Engine : EngineBase {
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     vt_last_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (nest) nest_loaded[nest - 1][s] = true; else if (sfc) slot_loaded[s] = true;
+    // without sfc the slot's 2-D fields are still those of the previous wind field until fpx_calcpar has run: not loaded
+    if (nest) nest_loaded[nest - 1][s] = true; else slot_loaded[s] = sfc != nullptr;
     if (!nest) vt_slot_on_device = slot;      // whose model-level arrays the buffers hold (fpx_calcpar)
     return 0;
   }
@@ -2816,7 +2849,8 @@ struct Engine : EngineBase {
     if (p->idt) { if ((rc = put<int, int>(p->idt, P.idt, first, count))) return rc; } else if ((rc = fill<int>(P.idt, 0, first, count))) return rc;
     if (p->npoint) { if ((rc = put<int, int>(p->npoint, P.npoint, first, count))) return rc; } else if ((rc = fill<int>(P.npoint, 1, first, count))) return rc;
     if (p->nclass) { if ((rc = put<int, int>(p->nclass, P.nclass, first, count))) return rc; } else if ((rc = fill<int>(P.nclass, 1, first, count))) return rc;
-    if (p->itrasplit && (rc = put<int, int>(p->itrasplit, P.itrasplit, first, count))) return rc;
+    if (p->itrasplit) { if ((rc = put<int, int>(p->itrasplit, P.itrasplit, first, count))) return rc; }
+    else if ((rc = fill<int>(P.itrasplit, (cfg.ldirect < 0 ? -1 : 1) * 999999999, first, count))) return rc;   // "never", in the run's direction
     if (p->cbt) { if ((rc = put<short, short>(p->cbt, P.cbt, first, count))) return rc; } else if ((rc = fill<short>(P.cbt, (short)1, first, count))) return rc;
     for (int ks = 0; ks < cfg.nspec; ks++) {
       R *dst = P.xmass1 + (size_t)ks * P.cap;
@@ -3293,7 +3327,33 @@ struct Engine : EngineBase {
     uint64_t n_grid3, n_grid2, n_grid3n, n_grid2n, n_receptor, rng_bytes;
     uint64_t cbase_bytes;        // conv_mod cbaseflux (the convection scheme relaxes it from call to call)
     int64_t rel_global_count;    // particles released so far by all ranks
+    // version 2: what the arrays were sized with, and the length of the whole file (checked before anything is restored)
+    int32_t nx, ny, nz, maxspec, numbnests, nxn[kMaxNests], nyn[kMaxNests], pad;
+    uint64_t total_bytes;
   };
+  void ckpt_describe_grid(CkptHeader &h) const {
+    h.nx = cfg.nx; h.ny = cfg.ny; h.nz = cfg.nz; h.maxspec = cfg.maxspec; h.numbnests = V.numbnests;
+    for (int l = 0; l < kMaxNests; l++) { h.nxn[l] = l < V.numbnests ? h_nest[l].nx : 0; h.nyn[l] = l < V.numbnests ? h_nest[l].ny : 0; }
+    h.pad = 0;
+  }
+  // file length that goes with a header: header + RNG state + particle arrays + grids + receptors + cbaseflux
+  static uint64_t ckpt_total_bytes(const CkptHeader &h) {
+    const uint64_t per_particle = 2 * 8 + 7 * sizeof(R) + 6 * 4 + 2 + (uint64_t)h.nspec * sizeof(R);
+    return sizeof(CkptHeader) + h.rng_bytes + (uint64_t)h.numpart * per_particle + h.n_grid3 * sizeof(R) + 2 * h.n_grid2 * sizeof(float) +
+           h.n_grid3n * sizeof(R) + 2 * h.n_grid2n * sizeof(float) + h.n_receptor * sizeof(R) + h.cbase_bytes;
+  }
+  // a restore that failed half-way leaves no usable state behind: no particles, no valid reductions
+  int ckpt_invalidate(int rc) {
+    numpart = 0;
+    maybe_new = true;
+    for (bool &v : red_valid) v = false;
+    (void)hipStreamSynchronize(stream);
+    const int nb = (int)((P.cap + kBlock - 1) / kBlock);
+    k_fill<int><<<nb, kBlock, 0, stream>>>(P.itra1, kDead, 0, P.cap, nullptr);
+    (void)hipStreamSynchronize(stream);
+    g_err += " -- the engine holds no particles now (numpart = 0); restore from a complete checkpoint or release again";
+    return rc;
+  }
   static constexpr long long kCkptChunk = 1ll << 22;
   template <typename T>
   int ckpt_put_array(FILE *fh, const T *dev, long long n, std::vector<unsigned char> &buf) {
@@ -3352,7 +3412,7 @@ struct Engine : EngineBase {
     CkptHeader h;
     memset(&h, 0, sizeof(h));
     memcpy(h.magic, "FPXCKPT1", 8);
-    h.version = 1; h.real_bytes = (int)sizeof(R); h.nspec = cfg.nspec; h.rng_mode = cfg.rng_mode;
+    h.version = 2; h.real_bytes = (int)sizeof(R); h.nspec = cfg.nspec; h.rng_mode = cfg.rng_mode;
     h.numpart = numpart; h.particle_base = cfg.particle_base; h.seed = V.seed; h.step_counter = step_counter;
     h.itime = itime; h.numparticlecount = numparticlecount;
     h.n_grid3 = Gp.on ? n_grid3 : 0; h.n_grid2 = Gp.on ? n_grid2 : 0;
@@ -3361,6 +3421,8 @@ struct Engine : EngineBase {
     h.rng_bytes = sizeof(CkptRng);
     h.cbase_bytes = conv_cbase_bytes();
     h.rel_global_count = rel_global_count;
+    ckpt_describe_grid(h);
+    h.total_bytes = ckpt_total_bytes(h);
     if (fwrite(&h, sizeof(h), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
     CkptRng rs{rng4, rng8, rel_ran1};
     if (fwrite(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_write: write error");
@@ -3393,8 +3455,8 @@ struct Engine : EngineBase {
     if (!fh) return fail(FPX_ERR_ARG, std::string("checkpoint_read: cannot open ") + path);
     struct Closer { FILE *f; ~Closer() { if (f) fclose(f); } } closer{fh};
     CkptHeader h;
-    if (fread(&h, sizeof(h), 1, fh) != 1 || memcmp(h.magic, "FPXCKPT1", 8) != 0 || h.version != 1)
-      return fail(FPX_ERR_ARG, "checkpoint_read: not a checkpoint of this engine");
+    if (fread(&h, sizeof(h), 1, fh) != 1 || memcmp(h.magic, "FPXCKPT1", 8) != 0 || h.version != 2)
+      return fail(FPX_ERR_ARG, "checkpoint_read: not a checkpoint of this engine (version 2)");
     if (h.real_bytes != (int)sizeof(R) || h.nspec != cfg.nspec || h.rng_mode != cfg.rng_mode || h.rng_bytes != sizeof(CkptRng))
       return fail(FPX_ERR_ARG, "checkpoint_read: written with another precision, species count or random-number mode");
     if (h.numpart < 0 || h.numpart > P.cap) return fail(FPX_ERR_ARG, "checkpoint_read: more particles than storage spaces");
@@ -3405,6 +3467,19 @@ struct Engine : EngineBase {
       return fail(FPX_ERR_STATE, "checkpoint_read: the output grids of the checkpoint are not the ones configured (call fpx_outgrid_init ... first)");
     if (h.cbase_bytes != conv_cbase_bytes())
       return fail(FPX_ERR_STATE, "checkpoint_read: the checkpoint was written with (without) convection; call fpx_conv_init first (or not at all)");
+    {
+      CkptHeader mine = h;
+      ckpt_describe_grid(mine);
+      if (memcmp(&mine.nx, &h.nx, (const char *)&h.pad - (const char *)&h.nx) != 0)
+        return fail(FPX_ERR_ARG, "checkpoint_read: written on another grid (nx, ny, nz, maxspec or the nest extents differ)");
+      // the whole file must be there before a single array is touched
+      if (h.total_bytes != ckpt_total_bytes(h)) return fail(FPX_ERR_ARG, "checkpoint_read: inconsistent header");
+      if (fseek(fh, 0, SEEK_END) != 0) return fail(FPX_ERR_ARG, "checkpoint_read: cannot seek");
+      const long long len = (long long)ftell(fh);
+      if (len < 0 || (uint64_t)len != h.total_bytes)
+        return fail(FPX_ERR_ARG, "checkpoint_read: the file is truncated or has trailing bytes (" + std::to_string(len) + " bytes, header says " + std::to_string(h.total_bytes) + "); nothing was restored");
+      if (fseek(fh, (long)sizeof(h), SEEK_SET) != 0) return fail(FPX_ERR_ARG, "checkpoint_read: cannot seek");
+    }
     CkptRng rs;
     if (fread(&rs, sizeof(rs), 1, fh) != 1) return fail(FPX_ERR_ARG, "checkpoint_read: file too short");
     // storage spaces in particle-number order again
@@ -3420,20 +3495,20 @@ struct Engine : EngineBase {
     std::vector<unsigned char> buf((size_t)kCkptChunk * 8);
     const long long n = h.numpart;
     int rc;
-    if ((rc = ckpt_get_array(fh, P.xt, n, buf)) || (rc = ckpt_get_array(fh, P.yt, n, buf))) return rc;
-    for (R *a : {P.zt, P.up, P.vp, P.wp, P.us, P.vs, P.ws}) if ((rc = ckpt_get_array(fh, a, n, buf))) return rc;
-    for (int *a : {P.idt, P.itra1, P.itramem, P.npoint, P.nclass, P.itrasplit}) if ((rc = ckpt_get_array(fh, a, n, buf))) return rc;
-    if ((rc = ckpt_get_array(fh, P.cbt, n, buf))) return rc;
-    for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_get_array(fh, P.xmass1 + (size_t)ks * P.cap, n, buf))) return rc;
+    if ((rc = ckpt_get_array(fh, P.xt, n, buf)) || (rc = ckpt_get_array(fh, P.yt, n, buf))) return ckpt_invalidate(rc);
+    for (R *a : {P.zt, P.up, P.vp, P.wp, P.us, P.vs, P.ws}) if ((rc = ckpt_get_array(fh, a, n, buf))) return ckpt_invalidate(rc);
+    for (int *a : {P.idt, P.itra1, P.itramem, P.npoint, P.nclass, P.itrasplit}) if ((rc = ckpt_get_array(fh, a, n, buf))) return ckpt_invalidate(rc);
+    if ((rc = ckpt_get_array(fh, P.cbt, n, buf))) return ckpt_invalidate(rc);
+    for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_get_array(fh, P.xmass1 + (size_t)ks * P.cap, n, buf))) return ckpt_invalidate(rc);
     if (g3 && ((rc = ckpt_get_plain(fh, Gp.gridunc, n_grid3, buf)) || (rc = ckpt_get_plain(fh, Gp.drygridunc, n_grid2, buf)) ||
-               (rc = ckpt_get_plain(fh, Gp.wetgridunc, n_grid2, buf)))) return rc;
+               (rc = ckpt_get_plain(fh, Gp.wetgridunc, n_grid2, buf)))) return ckpt_invalidate(rc);
     if (g3n && ((rc = ckpt_get_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_get_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
-                (rc = ckpt_get_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return rc;
-    if (nr && (rc = ckpt_get_plain(fh, Gp.creceptor, (size_t)nr, buf))) return rc;
+                (rc = ckpt_get_plain(fh, Gp.wetgriduncn, n_grid2n, buf)))) return ckpt_invalidate(rc);
+    if (nr && (rc = ckpt_get_plain(fh, Gp.creceptor, (size_t)nr, buf))) return ckpt_invalidate(rc);
     if (h.cbase_bytes) {
-      if ((rc = ckpt_get_plain(fh, (unsigned char *)conv_cb, (size_t)cfg.nx * cfg.ny * cfg.host_real_bytes, buf))) return rc;
+      if ((rc = ckpt_get_plain(fh, (unsigned char *)conv_cb, (size_t)cfg.nx * cfg.ny * cfg.host_real_bytes, buf))) return ckpt_invalidate(rc);
       for (int l = 0; l < V.numbnests; l++)
-        if (conv_cb_n[l] && (rc = ckpt_get_plain(fh, (unsigned char *)conv_cb_n[l], (size_t)h_nest[l].nx * h_nest[l].ny * cfg.host_real_bytes, buf))) return rc;
+        if (conv_cb_n[l] && (rc = ckpt_get_plain(fh, (unsigned char *)conv_cb_n[l], (size_t)h_nest[l].nx * h_nest[l].ny * cfg.host_real_bytes, buf))) return ckpt_invalidate(rc);
     }
     for (bool &v : red_valid) v = false;
     rng4 = rs.r4; rng8 = rs.r8; rel_ran1 = rs.rel;
@@ -3610,12 +3685,7 @@ struct Engine : EngineBase {
       const bool polar = cfg.nglobal || cfg.sglobal;
       typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *, unsigned int *);
       const bool nest = V.numbnests > 0;
-      prep_fn f;
-#define FPX_PREP(DD, II) (polar ? (nest ? k_prep<R, DD, II, true, true> : k_prep<R, DD, II, true, false>) \
-                                : (nest ? k_prep<R, DD, II, false, true> : k_prep<R, DD, II, false, false>))
-      if (cfg.drydep) f = init ? FPX_PREP(true, true) : FPX_PREP(true, false);
-      else f = init ? FPX_PREP(false, true) : FPX_PREP(false, false);
-#undef FPX_PREP
+      const prep_fn f = (prep_fn)step_kernel_prep((int)sizeof(R), cfg.drydep != 0, init, polar, nest);
       f<<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag, d_pbl_ctr);
       maybe_new = false;
     }
@@ -3634,11 +3704,7 @@ struct Engine : EngineBase {
     {
       const bool polar = cfg.nglobal || cfg.sglobal, nest = V.numbnests > 0;
       typedef void (*fin_fn)(View<R>, GridP<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *);
-      fin_fn f;
-      if (cfg.drydep) f = polar ? (nest ? k_pbl_finish<R, true, true, true> : k_pbl_finish<R, true, true, false>)
-                                : (nest ? k_pbl_finish<R, true, false, true> : k_pbl_finish<R, true, false, false>);
-      else f = polar ? (nest ? k_pbl_finish<R, false, true, true> : k_pbl_finish<R, false, true, false>)
-                     : (nest ? k_pbl_finish<R, false, false, true> : k_pbl_finish<R, false, false, false>);
+      const fin_fn f = (fin_fn)step_kernel_finish((int)sizeof(R), cfg.drydep != 0, polar, nest);
       f<<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
     }
     HIPCHK(hipEventRecord(ev.e[3], stream));
@@ -3680,17 +3746,7 @@ struct Engine : EngineBase {
   typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *, unsigned int *);
   size_t loop_smem_bytes() const { return sizeof(R) * ((size_t)S_COUNT * kStashStride + (size_t)cfg.nz); }
   loop_fn loop_kernel() const {
-    const bool lean = !cfg.drydep && !cfg.lsettling;
-    const bool philox = cfg.rng_mode == FPX_RNG_PHILOX;
-    if (lean) {
-      if (cfg.turbswitch && cfg.cblflag == 1) return philox ? k_pbl_loop<R, true, 1, 1, 2> : k_pbl_loop<R, true, 1, 1, 0>;
-      if (cfg.turbswitch && cfg.cblflag != 1) return philox ? k_pbl_loop<R, true, 1, 0, 2> : k_pbl_loop<R, true, 1, 0, 0>;
-      if (!cfg.turbswitch && cfg.cblflag != 1) return philox ? k_pbl_loop<R, true, 0, 0, 2> : k_pbl_loop<R, true, 0, 0, 0>;
-    } else if (philox) {   // aerosols (settling / dry deposition) with the counter RNG: same switch specialisation
-      if (cfg.turbswitch && cfg.cblflag == 1) return k_pbl_loop<R, false, 1, 1, 2>;
-      if (cfg.turbswitch && cfg.cblflag != 1) return k_pbl_loop<R, false, 1, 0, 2>;
-    }
-    return k_pbl_loop<R, false, -1, -1, -1>;
+    return (loop_fn)step_kernel_loop((int)sizeof(R), !cfg.drydep && !cfg.lsettling, cfg.turbswitch, cfg.cblflag, cfg.rng_mode);
   }
 
   int sync() override {
@@ -4013,6 +4069,42 @@ struct Engine : EngineBase {
     HIPCHK(hipStreamSynchronize(stream));    // the bounce buffer is reused by the next grid
     return 0;
   }
+  // [live particles, numpart] of this rank and summed over the ranks: the reduction of numpart the reference's root does at
+  // every output time (timemanager_mpi.f90:552-562) -- here with the count of the particles that are still alive next to it
+  long long *d_count = nullptr;          // [0..1] local, [2..3] sums
+  int count_particles(int64_t *local, int64_t *total, int allreduce) override {
+    int rc;
+    if (!d_count && (rc = dalloc(&d_count, 4))) return rc;
+    HIPCHK(hipMemsetAsync(d_count, 0, 4 * sizeof(long long), stream));
+    if (numpart > 0) {
+      const int nb = (int)std::min<long long>((numpart + 255) / 256, 256 * 16);
+      k_count_live<<<nb, 256, 0, stream>>>(P.itra1, numpart, (unsigned long long *)d_count);
+      HIPCHK(hipGetLastError());
+    }
+    long long h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, d_count, sizeof(long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    h[1] = numpart;
+    h[2] = h[0]; h[3] = h[1];
+    if (allreduce && comm_ranks > 1) {
+      if (comm) {
+        HIPCHK(hipMemcpyAsync(d_count, h, 2 * sizeof(long long), hipMemcpyHostToDevice, stream));
+        ncclResult_t r = ncclAllReduce(d_count, d_count + 2, 2, ncclInt64, ncclSum, comm, stream);
+        if (r != ncclSuccess) return fail(FPX_ERR_DEVICE, std::string("ncclAllReduce: ") + ncclGetErrorString(r));
+        HIPCHK(hipMemcpyAsync(h + 2, d_count + 2, 2 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+      } else if (host_allreduce) {
+        double snd[2] = {(double)h[0], (double)h[1]}, rcv[2] = {0, 0};   // exact below 2^53
+        if (host_allreduce(host_allreduce_user, snd, rcv, 2, 1) != 0) return fail(FPX_ERR_DEVICE, "count_particles: the host's all-reduce callback failed");
+        h[2] = (long long)rcv[0]; h[3] = (long long)rcv[1];
+      } else {
+        return fail(FPX_ERR_STATE, "count_particles: allreduce requested without fpx_comm_init / fpx_comm_init_host");
+      }
+    }
+    if (local) { local[0] = h[0]; local[1] = h[1]; }
+    if (total) { total[0] = h[2]; total[1] = h[3]; }
+    return 0;
+  }
   int comm_init_host(int nranks, int rank, fpx_allreduce_fn fn, void *user) override {
     if (nranks < 1 || rank < 0 || rank >= nranks || !fn) return fail(FPX_ERR_ARG, "comm_init_host: bad argument");
     if (comm || host_allreduce) return fail(FPX_ERR_STATE, "comm_init_host: communicator exists");
@@ -4250,8 +4342,84 @@ struct Engine : EngineBase {
   void *stream_ptr() override { return (void *)stream; }
 };
 
+FPX_TU_CLOSE
+#if FPX_TU_PART == 1 || FPX_TU_PART < 0
+template <typename R>
+static const void *prep_table(bool drydep, bool init, bool polar, bool nest) {
+#define FPX_PREP(DD, II) (polar ? (nest ? (const void *)k_prep<R, DD, II, true, true> : (const void *)k_prep<R, DD, II, true, false>) \
+                                : (nest ? (const void *)k_prep<R, DD, II, false, true> : (const void *)k_prep<R, DD, II, false, false>))
+  if (drydep) return init ? FPX_PREP(true, true) : FPX_PREP(true, false);
+  return init ? FPX_PREP(false, true) : FPX_PREP(false, false);
+#undef FPX_PREP
+}
+#if FPX_TU_REAL != 4
+const void *step_kernel_prep_f64(bool drydep, bool init, bool polar, bool nest) { return prep_table<double>(drydep, init, polar, nest); }
+#endif
+#if FPX_TU_REAL != 8
+const void *step_kernel_prep_f32(bool drydep, bool init, bool polar, bool nest) { return prep_table<float>(drydep, init, polar, nest); }
+#endif
+#endif
+#if FPX_TU_PART == 2 || FPX_TU_PART < 0
+// the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
+template <typename R>
+static const void *loop_table(bool lean, int turbswitch, int cblflag, int rng_mode) {
+  const bool philox = rng_mode == FPX_RNG_PHILOX;
+  if (lean) {
+    if (turbswitch && cblflag == 1) return philox ? (const void *)k_pbl_loop<R, true, 1, 1, 2> : (const void *)k_pbl_loop<R, true, 1, 1, 0>;
+    if (turbswitch && cblflag != 1) return philox ? (const void *)k_pbl_loop<R, true, 1, 0, 2> : (const void *)k_pbl_loop<R, true, 1, 0, 0>;
+    if (!turbswitch && cblflag != 1) return philox ? (const void *)k_pbl_loop<R, true, 0, 0, 2> : (const void *)k_pbl_loop<R, true, 0, 0, 0>;
+  } else if (philox) {   // aerosols (settling / dry deposition) with the counter RNG: same switch specialisation
+    if (turbswitch && cblflag == 1) return (const void *)k_pbl_loop<R, false, 1, 1, 2>;
+    if (turbswitch && cblflag != 1) return (const void *)k_pbl_loop<R, false, 1, 0, 2>;
+  }
+  return (const void *)k_pbl_loop<R, false, -1, -1, -1>;
+}
+template <typename R>
+static const void *finish_table(bool drydep, bool polar, bool nest) {
+  if (drydep) return polar ? (nest ? (const void *)k_pbl_finish<R, true, true, true> : (const void *)k_pbl_finish<R, true, true, false>)
+                           : (nest ? (const void *)k_pbl_finish<R, true, false, true> : (const void *)k_pbl_finish<R, true, false, false>);
+  return polar ? (nest ? (const void *)k_pbl_finish<R, false, true, true> : (const void *)k_pbl_finish<R, false, true, false>)
+               : (nest ? (const void *)k_pbl_finish<R, false, false, true> : (const void *)k_pbl_finish<R, false, false, false>);
+}
+#if FPX_TU_REAL != 4
+const void *step_kernel_loop_f64(bool lean, int turbswitch, int cblflag, int rng_mode) { return loop_table<double>(lean, turbswitch, cblflag, rng_mode); }
+const void *step_kernel_finish_f64(bool drydep, bool polar, bool nest) { return finish_table<double>(drydep, polar, nest); }
+#endif
+#if FPX_TU_REAL != 8
+const void *step_kernel_loop_f32(bool lean, int turbswitch, int cblflag, int rng_mode) { return loop_table<float>(lean, turbswitch, cblflag, rng_mode); }
+const void *step_kernel_finish_f32(bool drydep, bool polar, bool nest) { return finish_table<float>(drydep, polar, nest); }
+#endif
+#endif
+#if FPX_TU_PART <= 0
+#if FPX_TU_REAL != 8
+EngineBase *make_engine_f32(const fpx_config *cfg, int *rc) {
+  auto *p = new (std::nothrow) Engine<float>();
+  if (!p) { *rc = fail(FPX_ERR_NOMEM, "fpx_create: out of host memory"); return nullptr; }
+  *rc = p->init(cfg);
+  return p;
+}
+#endif
+#if FPX_TU_REAL != 4
+const void *step_kernel_prep_f64(bool, bool, bool, bool);
+const void *step_kernel_prep_f32(bool, bool, bool, bool);
+const void *step_kernel_loop_f64(bool, int, int, int);
+const void *step_kernel_loop_f32(bool, int, int, int);
+const void *step_kernel_finish_f64(bool, bool, bool);
+const void *step_kernel_finish_f32(bool, bool, bool);
+const void *step_kernel_prep(int rb, bool drydep, bool init, bool polar, bool nest) {
+  return rb == 8 ? step_kernel_prep_f64(drydep, init, polar, nest) : step_kernel_prep_f32(drydep, init, polar, nest);
+}
+const void *step_kernel_loop(int rb, bool lean, int turbswitch, int cblflag, int rng_mode) {
+  return rb == 8 ? step_kernel_loop_f64(lean, turbswitch, cblflag, rng_mode) : step_kernel_loop_f32(lean, turbswitch, cblflag, rng_mode);
+}
+const void *step_kernel_finish(int rb, bool drydep, bool polar, bool nest) {
+  return rb == 8 ? step_kernel_finish_f64(drydep, polar, nest) : step_kernel_finish_f32(drydep, polar, nest);
+}
+#endif
+#endif   // FPX_TU_PART <= 0
 }  // namespace fpx
 
+#if FPX_TU_REAL != 4 && FPX_TU_PART <= 0
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
@@ -4298,10 +4466,8 @@ int fpx_create(fpx_handle *out, const fpx_config *cfg) {
     rc = p->init(cfg);
     e = p;
   } else if (cfg->compute_real_bytes == 4) {
-    auto *p = new (std::nothrow) fpx::Engine<float>();
-    if (!p) return fpx::fail(FPX_ERR_NOMEM, "fpx_create: out of host memory");
-    rc = p->init(cfg);
-    e = p;
+    e = fpx::make_engine_f32(cfg, &rc);
+    if (!e) return rc;
   } else {
     return fpx::fail(FPX_ERR_ARG, "fpx_create: compute_real_bytes must be 4 or 8");
   }
@@ -4402,6 +4568,7 @@ int fpx_comm_unique_id(void *id, int32_t nbytes) {
   memcpy(id, &uid, sizeof(uid));
   return FPX_OK;
 }
+int fpx_count_particles(fpx_handle h, int64_t local[2], int64_t total[2], int32_t allreduce) { FPX_GUARD(h); return h->impl->count_particles(local, total, allreduce); }
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
 int fpx_comm_init_host(fpx_handle h, int32_t nranks, int32_t rank, fpx_allreduce_fn fn, void *user) { FPX_GUARD(h); return h->impl->comm_init_host(nranks, rank, fn, user); }
 int fpx_nests_init(fpx_handle h, const fpx_nests *n) { FPX_GUARD(h); return h->impl->nests_init(n); }
@@ -4434,3 +4601,4 @@ int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n) {
 }
 
 }  // extern "C"
+#endif   // FPX_TU_REAL != 4 && FPX_TU_PART <= 0

@@ -4,11 +4,13 @@
 // Integer-exact restatement of random_mod.f90:93-139 (ran3), :70-90 (gasdev1),
 // :45-67 (gasdev); table fill as FLEXPART.f90:47,56-59.
 #pragma once
+#include "fpx_tu.hpp"
 #include <cmath>
 #include <cstdlib>
 #include <vector>
 
 namespace fpx {
+FPX_TU_OPEN
 
 template <typename R>
 struct HostRng {
@@ -100,4 +102,5 @@ struct HostRng {
   int start_index(int &idum, int maxrand) { return (int)(ran3(idum) * (R)(maxrand - 1)) + 1; }
 };
 
+FPX_TU_CLOSE
 }  // namespace fpx

@@ -12,9 +12,11 @@
 // with FMA contraction off, so only the libm calls (log, 10**x, cos, sin, atan) can differ
 // from the CPU result.
 #pragma once
+#include "fpx_tu.hpp"
 #include <hip/hip_runtime.h>
 
 namespace fpx {
+FPX_TU_OPEN
 namespace vt {
 
 template <typename H> struct M;
@@ -654,4 +656,5 @@ __global__ void __launch_bounds__(64) k_vt_polerow(Geo<H> G, Out<H> O, int south
 #undef VK
 
 }  // namespace vt
+FPX_TU_CLOSE
 }  // namespace fpx

@@ -749,6 +749,14 @@ class Engine:
         self._allreduce_cb = _lib.ALLREDUCE_FN(_allreduce)      # keep the thunk alive as long as the engine
         check(self.lib.fpx_comm_init_host(self.h, int(nranks), int(rank), self._allreduce_cb, None), "fpx_comm_init_host")
 
+    def count_particles(self, allreduce=False):
+        """(live, numpart) of this rank and summed over the ranks: the particle count the reference's root reduces at
+        every output time (timemanager_mpi.f90:552-562)."""
+        loc = (C.c_int64 * 2)()
+        tot = (C.c_int64 * 2)()
+        check(self.lib.fpx_count_particles(self.h, loc, tot, int(allreduce)), "fpx_count_particles")
+        return (int(loc[0]), int(loc[1])), (int(tot[0]), int(tot[1]))
+
     def comm_init(self, uid, nranks, rank):
         buf = (C.c_char * 128).from_buffer_copy(uid)
         check(self.lib.fpx_comm_init(self.h, buf, 128, int(nranks), int(rank)), "fpx_comm_init")

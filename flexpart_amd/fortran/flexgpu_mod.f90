@@ -32,7 +32,7 @@ module flexgpu_mod
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
-            flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, &
+            flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, flexgpu_count_particles, &
             flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar, &
             flexgpu_checkpoint_write, flexgpu_checkpoint_read, &
             flexgpu_conv_init, flexgpu_upload_conv_fields, flexgpu_convmix, flexgpu_cbaseflux
@@ -428,6 +428,12 @@ module flexgpu_mod
       type(c_funptr), value :: fn
       integer(c_int32_t), value :: nranks, rank
     end function
+    integer(c_int) function fpx_count_particles(h, local, total, allreduce) bind(C, name='fpx_count_particles')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), intent(out) :: local(2), total(2)
+      integer(c_int32_t), value :: allreduce
+    end function
     integer(c_int) function fpx_get_wetgrid(h, w, allreduce) bind(C, name='fpx_get_wetgrid')
       import :: c_ptr, c_int, c_int32_t
       type(c_ptr), value :: h, w
@@ -539,6 +545,11 @@ contains
     integer(c_int64_t), intent(in), optional :: seed, particle_base
     type(fpx_config) :: cfg
     integer :: ks
+    if (DRYBKDEP .or. WETBKDEP) then
+      ! backward runs with receptor scavenging (timemanager.f90:571-598, xscav_frac1) are not on the device path
+      ierr = -1
+      return
+    end if
     cfg%struct_bytes = int(c_sizeof(cfg), c_int32_t)
     cfg%device = 0; if (present(device)) cfg%device = device
     cfg%host_real_bytes = storage_size(1.0) / 8          ! 4 as shipped, 8 with -fdefault-real-8
@@ -1166,6 +1177,17 @@ contains
     integer, intent(out) :: ierr
     ierr = fpx_comm_init_host(flexgpu_handle, int(nranks, c_int32_t), int(rank, c_int32_t), fn, c_null_ptr)
   end subroutine flexgpu_comm_init_host
+
+  ! numpart_tot_mpi of timemanager_mpi.f90:552-562: numpart summed over the ranks (and, next to it, the particles that
+  ! are still alive); allreduce = .false. returns this rank's own counts
+  subroutine flexgpu_count_particles(allreduce, nlive, numpart_tot, ierr)
+    logical, intent(in) :: allreduce
+    integer(c_int64_t), intent(out) :: nlive, numpart_tot
+    integer, intent(out) :: ierr
+    integer(c_int64_t) :: loc(2), tot(2)
+    ierr = fpx_count_particles(flexgpu_handle, loc, tot, merge(1_c_int32_t, 0_c_int32_t, allreduce))
+    nlive = tot(1); numpart_tot = tot(2)
+  end subroutine flexgpu_count_particles
 
   ! ---- wet deposition: species parameters of readspecies.f90, fields of readwind/verttransform ----
   subroutine flexgpu_wet_init(ierr)

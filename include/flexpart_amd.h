@@ -123,7 +123,7 @@ typedef struct {
   int16_t *cbt;
   void *xmass1;            /* (count or ld, nspec) species-major, leading dim xmass1_ld */
   int64_t xmass1_ld;
-  int32_t *itrasplit;      /* com_mod.f90:683: next time the particle is split (NULL: left alone; 999999999 on a fresh engine) */
+  int32_t *itrasplit;      /* com_mod.f90:683: next time the particle is split (NULL: never, i.e. ldirect*999999999, the value of a fresh engine) */
 } fpx_particles;
 
 typedef struct {
@@ -512,6 +512,12 @@ int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, 
  *     fpx_get_grids_nest / fpx_get_receptors, in the same order on every rank. */
 typedef int (*fpx_allreduce_fn)(void *user, const void *send, void *recv, int64_t count, int32_t dtype);
 int fpx_comm_init_host(fpx_handle h, int32_t nranks, int32_t rank, fpx_allreduce_fn fn, void *user);
+/* The particle count the reference's root process reduces at every output time (MPI_Reduce of numpart,
+ * timemanager_mpi.f90:552-562): local[0] = live particles of this rank (itra1 /= -999999999), local[1] = its numpart;
+ * total[] = the same summed over the ranks of the communicator when allreduce != 0 (RCCL: one ncclAllReduce of two
+ * 64-bit integers on the handle's stream; host transport: the callback with two 8-byte reals), else a copy of local[].
+ * Collective when allreduce != 0: every rank calls it, in the same order relative to the grid reductions. */
+int fpx_count_particles(fpx_handle h, int64_t local[2], int64_t total[2], int32_t allreduce);
 
 /* ---- wet deposition ------------------------------------------------- */
 typedef struct {

@@ -138,3 +138,32 @@ def test_particles_advance_on_device_computed_boundary_layer(built):
         for k in ("xtra1", "ytra1", "ztra1"):
             bad |= np.abs(g[k] - w[k]) > 1e-7 * np.abs(w[k]).max()
     assert bad.sum() <= 0.01 * n, bad.sum()
+
+
+@pytest.mark.gpu
+def test_step_refuses_a_slot_whose_boundary_layer_fields_are_stale(built):
+    """fpx_verttransform_ecmwf(sfc = NULL) promises that fpx_calcpar follows.  From the second wind field on the slot
+    still holds the previous field's hmix / ustar / wstar / oli / tropopause: a step before calcpar must fail, not run
+    on new winds with old boundary-layer fields."""
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
+    from flexpart_amd._lib import FpxError
+    nx, ny, nz = 48, 32, 40
+    sc = syn.small(n=200, nx=nx, ny=ny, nz=nz, nsteps=1, ctl=5.0, ifine=4)
+    ms = [syn.model_levels(nx=nx, ny=ny, nz=nz, phase=p) for p in (0, 4, 8)]
+    cins = [syn.calcpar_inputs(m) for m in ms]
+    sce = {k: v for k, v in sc.items() if k not in ("uu", "vv", "ww", "rho", "drhodz", "tt", "hmix", "ustar", "wstar", "oli", "tropopause", "height", "nmixz")}
+    eng = Engine(sce, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ)
+    for s in range(2):
+        eng.verttransform(s + 1, ms[s], None, init=(s == 0), want=())
+        eng.calcpar(s + 1, cins[s])
+    eng.set_windtime(sc["memtime"], sc["memind"])
+    z = np.minimum(np.asarray(sc["ztra1"]), 5000.0)
+    eng.upload_particles_from_scenario(dict(sce, ztra1=z))
+    eng.step(0)
+    eng.verttransform(1, ms[2], None, want=())            # next wind field into slot 1, calcpar forgotten
+    with pytest.raises(FpxError) as e:
+        eng.step(900)
+    assert "field slots" in str(e.value)
+    eng.calcpar(1, cins[2])
+    eng.step(900)
+    eng.close()

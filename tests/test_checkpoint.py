@@ -118,3 +118,39 @@ def test_checkpoint_of_another_configuration_is_refused(built, tmp_path):
     with pytest.raises(FpxError):
         b.checkpoint_read(tmp_path / "junk")
     b.close()
+
+
+def test_truncated_checkpoint_and_checkpoint_of_another_grid_leave_the_engine_untouched(built, tmp_path):
+    """The header carries the grid the arrays were sized with and the length of the whole file; both are checked before a
+    single array is restored: a truncated file, a file with trailing bytes and a file of a run on another grid are refused
+    with every particle where it was."""
+    from flexpart_amd._lib import FpxError
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    sc = syn.small(n=700, nx=40, ny=24, nz=30, nsteps=1, ctl=5.0, ifine=4)
+    a = Engine(sc, rng_mode=RNG_PHILOX, seed=5)
+    a.step()
+    a.checkpoint_write(tmp_path / "ck")
+    want = a.download()
+    a.close()
+    raw = (tmp_path / "ck").read_bytes()
+    (tmp_path / "short").write_bytes(raw[:len(raw) - 1000])
+    (tmp_path / "long").write_bytes(raw + b"\0" * 8)
+    b = Engine(sc, rng_mode=RNG_PHILOX, seed=5)
+    before = b.download()
+    for name, word in (("short", "truncated"), ("long", "truncated")):
+        with pytest.raises(FpxError) as e:
+            b.checkpoint_read(tmp_path / name)
+        assert word in str(e.value) and "nothing was restored" in str(e.value)
+        after = b.download()
+        assert b.n == 700 and all(np.array_equal(before[k], after[k]) for k in KEYS)
+    b.checkpoint_read(tmp_path / "ck")                       # the complete file still restores
+    got = b.download()
+    assert all(np.array_equal(want[k], got[k]) for k in KEYS)
+    b.close()
+    # same particle count, same byte count, another grid
+    sc2 = syn.small(n=700, nx=24, ny=40, nz=30, nsteps=1, ctl=5.0, ifine=4)
+    c = Engine(sc2, rng_mode=RNG_PHILOX, seed=5)
+    with pytest.raises(FpxError) as e:
+        c.checkpoint_read(tmp_path / "ck")
+    assert "another grid" in str(e.value)
+    c.close()

@@ -57,12 +57,12 @@ def test_oracle_matches_live_release_reference(kind):
             assert np.array_equal(np.asarray(c[k]), np.asarray(o[k])), (kind, c["state"], k)
 
 
-def _engine(rs, kind, rng_mode):
+def _engine(rs, kind, rng_mode, ldirect=1):
     from flexpart_amd.engine import Engine
     rb = 8 if kind == "r8" else 4
     nx, ny, nz = (int(v) for v in rs["grid"])
     f = syn.make_fields(nx, ny, nz, rs["height"], nspec=int(rs["nspec"]))
-    sc = syn.base_scenario(nx, ny, nz, global_grid=bool(rs["xglobal"]), nspec=int(rs["nspec"]))
+    sc = syn.base_scenario(nx, ny, nz, global_grid=bool(rs["xglobal"]), nspec=int(rs["nspec"]), ldirect=ldirect)
     sc.update(f)
     sc["height"] = rs["height"]
     sc["nmixz"] = syn.nmixz_from_height(rs["height"])
@@ -78,7 +78,8 @@ def _engine(rs, kind, rng_mode):
     n0 = int(rs.get("npart", 0))
     if n0:
         for k in ("npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "itrasplit", "npoint", "nclass", "idt", "uap", "xmass1"):
-            sc[k] = rs[k]
+            if k in rs:
+                sc[k] = rs[k]
     sw = [int(v) for v in rs["switches"]]
     sc["mquasilag"] = sw[5]
     eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=rng_mode, max_particles=sw[6])
@@ -226,3 +227,43 @@ def test_release_split_over_ranks_gives_the_single_rank_particles(built):
         a = a[np.lexsort(a.T[::-1])]
         b = b[np.lexsort(b.T[::-1])]
         assert np.array_equal(a, b), ic
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ldirect", [1, -1])
+def test_particles_without_a_split_time_are_never_split(built, ldirect):
+    """Particles that arrive without itrasplit (seeded, or uploaded with itrasplit = NULL) carry "never" in the run's
+    direction -- ldirect*999999999, the sign releaseparticles.f90:181 / readpartpositions.f90:117 give it -- so the
+    test of timemanager.f90:478, ldirect*itime >= ldirect*itrasplit, stays false in forward AND backward runs (in a
+    backward run the outer guard ldirect*itime >= ldirect*itsplit is true at every step); a particle whose doubled
+    interval passes the 32-bit range saturates at "never" instead of overflowing."""
+    from flexpart_amd.engine import RNG_PHILOX
+    rs = syn.release_case(existing=400, itsplit=1800, maxpart=2000)
+    rs.pop("itrasplit")
+    rs["itra1"] = np.where(rs["itra1"] == 0, 0, rs["itra1"]).astype(np.int32)
+    eng = _engine(rs, "r8", RNG_PHILOX, ldirect=ldirect)
+    for itime in (0, 1800 * ldirect, 86400 * ldirect):
+        eng.split_particles(itime)
+        assert eng.n == 400
+    assert np.all(eng.download()["itrasplit"] == ldirect * 999999999)
+    eng.seed_particles(300)
+    eng.split_particles(3600 * ldirect)
+    assert eng.n == 300 and np.all(eng.download()["itrasplit"] == ldirect * 999999999)
+    eng.close()
+    # one particle released long ago whose split time is due: split once, the doubled interval saturates
+    rs1 = dict(rs, npart=1, itsplit=1800)
+    for k in ("xtra1", "ytra1", "ztra1", "npoint", "nclass", "idt", "uap"):
+        rs1[k] = np.asarray(rs[k])[:1]
+    rs1["xmass1"] = np.asarray(rs["xmass1"])[:, :1]
+    rs1["itramem"] = np.array([-ldirect * 900000000], np.int32)
+    rs1["itrasplit"] = np.array([ldirect * 800000000], np.int32)
+    rs1["itra1"] = np.array([ldirect * 800000000], np.int32)
+    sw = np.array(rs["switches"]); sw[6] = 8
+    rs1["switches"] = sw
+    eng = _engine(rs1, "r8", RNG_PHILOX, ldirect=ldirect)
+    eng.split_particles(ldirect * 800000000)
+    got = eng.download()
+    assert eng.n == 2 and np.all(got["itrasplit"] == ldirect * 999999999) and np.allclose(got["xmass1"], 0.005)
+    eng.split_particles(ldirect * 800000900)
+    assert eng.n == 2
+    eng.close()

@@ -144,3 +144,52 @@ def test_two_rank_two_output_times_keep_partial_sums(tmp_path):
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fpx_bench", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_bench_relaunches_itself_with_one_rank_per_gpu(monkeypatch):
+    """`python bench.py --gpus N` without a launcher starts N ranks through torch.distributed.run -- as a child
+    process, before torch is imported -- and hands its own arguments on."""
+    bench = _load_bench()
+    argv = bench.relaunch_argv(4, ["--gpus", "4", "--steps", "3", "--config", "4"], 29517)
+    assert argv[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=4" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29517"
+    assert argv[-7] == os.path.join(ROOT, "bench.py") and argv[-6:] == ["--gpus", "4", "--steps", "3", "--config", "4"]
+
+    calls = []
+
+    class Done:
+        returncode = 0
+
+    def fake_run(cmd, **kw):
+        calls.append(cmd)
+        return Done()
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--particles", "2e7"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0 and len(calls) == 1
+    assert "--nproc-per-node=2" in calls[0] and calls[0][-4:] == ["--gpus", "2", "--particles", "2e7"]
+    assert "torch" not in bench.__dict__        # nothing touched the GPU runtime in the launcher process
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus(monkeypatch):
+    bench = _load_bench()
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "--gpus 4" in str(e.value.code) and "2 rank" in str(e.value.code)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])             # torchrun with two ranks but the default --gpus 1
+    with pytest.raises(SystemExit):
+        bench.main()

@@ -11,6 +11,7 @@ import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
@@ -42,9 +43,9 @@ def main():
     fe = per_kernel(newest(os.path.join(src, "fetch", "*", "*counter_collection.csv")))
     wr = per_kernel(newest(os.path.join(src, "write", "*", "*counter_collection.csv")))
     for k in sq:
-        if "fpx::k_" not in k:
+        if "fpx::" not in k or "::k_" not in k:
             continue
-        short = k.split("(")[0].replace("void ", "")
+        short = re.sub(r"tu_r\d+_p\w+::", "", k.split("(")[0].replace("void ", ""))   # drop the translation unit's inline namespace
         d = {c: v[-1] for c, v in sq[k].items()}             # last launch = a timed step
         e = {"launches_profiled": len(next(iter(sq[k].values()))), "sq_last_launch": d}
         if d.get("SQ_ACTIVE_INST_VALU"):
