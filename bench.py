@@ -392,6 +392,9 @@ def main():
                      "limiter": ("memory latency of dependent gathers at 3 waves/SIMD (165 VGPRs), not HBM bandwidth" if args.config == 2
                                  else f"{'fp64' if rb == 8 else 'fp32'} VALU issue")},
     }
+    ls = eng.lane_stats()
+    if any(v[0] for v in ls.values()):        # only a library built with -DFPX_LANE_STATS counts
+        out["roofline"]["lane_stats"] = ls
     if args.pmc_child:
         eng.close()
         return

@@ -173,7 +173,7 @@ SYMBOLS = [
     "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points", "fpx_release_init", "fpx_releaseparticles", "fpx_split_particles",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
-    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_count_particles", "fpx_wet_init", "fpx_upload_wet_fields",
+    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_count_particles", "fpx_lane_stats", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
     "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_calcpar", "fpx_calcpar_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
@@ -267,6 +267,7 @@ def load():
     lib.fpx_get_wetgrid.argtypes = [vp, vp, C.c_int32]
     lib.fpx_comm_init_host.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, vp]
     lib.fpx_count_particles.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
+    lib.fpx_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32, C.c_int32]
     _lib = lib
     return lib
 

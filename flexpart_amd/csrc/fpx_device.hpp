@@ -129,6 +129,104 @@ FPX_DEV double m_logp(double x) {
   const double dk = (double)e;
   return dk * 6.93147180369123816490e-01 - ((hfsq - (s * (hfsq + Rr) + dk * 1.90821492927058770002e-10)) - f);
 }
+// ln(x) to an ABSOLUTE error of 1e-13 (not a relative one) for positive normal x, at a third of m_logp's instructions: the mantissa
+// m in [0.5, 1) is divided by the centre c of its 1/64-wide interval (32-entry table of 1/c and ln c, 512 B; the Langevin kernel
+// reads a copy in LDS), which leaves log1p(f) with |f| <= 2^-6 for a degree-6 series (truncation f^7/7 < 4e-14).  Used where a
+// logarithm only feeds a factor x**delta with |delta| ~ 1e-5 (hanna_short's exponents .33333 and .66666 against 1/3 and 2/3):
+// the result's relative error is delta times this absolute one.
+static __device__ const double kLogTab[32][2] = {
+  {1.9692307692307693, -0.6776429940239801},
+  {1.9104477611940298, -0.6473376445286511},
+  {1.855072463768116, -0.6179237593223578},
+  {1.8028169014084507, -0.5893503868783018},
+  {1.7534246575342465, -0.561570822771226},
+  {1.7066666666666668, -0.5345421503833068},
+  {1.6623376623376624, -0.5082248420659333},
+  {1.620253164556962, -0.48258241145259567},
+  {1.5802469135802468, -0.4575811092471784},
+  {1.5421686746987953, -0.43318965612301924},
+  {1.5058823529411764, -0.4093790074293007},
+  {1.471264367816092, -0.38612214526503347},
+  {1.4382022471910112, -0.3633938941874773},
+  {1.4065934065934067, -0.34117075740276714},
+  {1.3763440860215055, -0.3194307707663612},
+  {1.3473684210526315, -0.29815337231907635},
+  {1.3195876288659794, -0.27731928541623435},
+  {1.292929292929293, -0.2569104137850272},
+  {1.2673267326732673, -0.2369097470783577},
+  {1.2427184466019416, -0.2173012756899814},
+  {1.2190476190476192, -0.1980699137620938},
+  {1.1962616822429906, -0.179201429457711},
+  {1.1743119266055047, -0.16068238169047347},
+  {1.1531531531531531, -0.14250006260728304},
+  {1.1327433628318584, -0.1246424452072766},
+  {1.1130434782608696, -0.1070981355563671},
+  {1.0940170940170941, -0.08985632912186105},
+  {1.0756302521008403, -0.07290677080808779},
+  {1.0578512396694215, -0.05623971832287608},
+  {1.0406504065040652, -0.039845908547199674},
+  {1.024, -0.023716526617316044},
+  {1.0078740157480315, -0.007843177461025893}
+};
+// 2**(j/32), j = 0 .. 31 (m_exp_tab)
+static __device__ const double kExpTab[32] = {
+  1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
+  1.0905077326652577, 1.1143867425958924, 1.1387886347566916, 1.1637248587775775,
+  1.189207115002721, 1.215247359980469, 1.241857812073484, 1.2690509571917332,
+  1.2968395546510096, 1.3252366431597413, 1.3542555469368927, 1.383909881963832,
+  1.4142135623730951, 1.4451808069770467, 1.4768261459394993, 1.5091644275934228,
+  1.5422108254079407, 1.5759808451078865, 1.6104903319492543, 1.645755478153965,
+  1.681792830507429, 1.718619298122478, 1.7562521603732995, 1.7947090750031072,
+  1.8340080864093424, 1.8741676341103, 1.9152065613971474, 1.9571441241754002
+};
+// The two tables as the Langevin kernel reads them: a copy per block in LDS, [0..63] = kLogTab, [64..95] = kExpTab.  768 bytes:
+// the kernel's 25-slot stash + height column + these must stay under 53248 B per block for three blocks per CU (the hardware
+// allocates LDS in coarser units than hipOccupancyMaxActiveBlocksPerMultiprocessor assumes: 54352 B was measured to hold two).
+constexpr int kLdsTabDoubles = 96, kLdsExpTabAt = 64;
+typedef __attribute__((address_space(3))) const double *lds_tab_ptr;
+template <typename TP>
+FPX_DEV double m_log_abs(double x, TP tab /* kLogTab layout: [32][2] */) {
+  const double m = __builtin_amdgcn_frexp_mant(x);                  // [0.5, 1)
+  const int e = __builtin_amdgcn_frexp_exp(x);
+  const unsigned int j = (__double2hiint(m) >> 15) & 31u;           // top five bits of the fraction
+  const double ic = tab[2 * j], lc = tab[2 * j + 1];
+  const double f = fma(m, ic, -1.0);
+  double p = fma(f, -1.0 / 6.0, 0.2);
+  p = fma(f, p, -0.25);
+  p = fma(f, p, 1.0 / 3.0);
+  p = fma(f, p, -0.5);
+  p = fma(f, p, 1.0);
+  return fma((double)e, 6.93147180559945309417e-01, lc) + f * p;
+}
+FPX_DEV double m_log_abs(double x) { return m_log_abs(x, &kLogTab[0][0]); }
+// exp(x) with a 32-entry table of 2**(j/32) (Tang's scheme): k = rint(x*32/ln2), r = x - k*ln2/32 (two-part constant, |r| <= 0.011),
+// exp(x) = 2**(k>>5) * T[k&31] * (1 + r + r^2/2 + .. + r^6/720) (truncation r^7/5040 < 4e-18).  16 instructions against the 21 of
+// m_expp; about 1 ulp.  Saturates like m_expp (v_ldexp_f64), NaN propagates.
+template <typename TP>
+FPX_DEV double m_exp_tab(double x, TP tab /* kExpTab layout */) {
+  const double k = rint(x * 46.16624130844683);
+  double r = fma(k, -0.02166084938653512, x);
+  r = fma(k, -5.9631716539705866e-12, r);
+  const int ki = (int)k;
+  const double t = tab[ki & 31];
+  double p = fma(r, 1.3888888888888888889e-03, 8.3333333333333333333e-03);
+  p = fma(r, p, 4.1666666666666666667e-02);
+  p = fma(r, p, 1.6666666666666666667e-01);
+  p = fma(r, p, 0.5);
+  p = fma(r, p, 1.0);
+  return ldexp(fma(t, r * p, t), ki >> 5);
+}
+// x**(-1/3) for x in the f32 exponent range: f32 seed, two Newton steps r <- r + r*(1 - x*r^3)/3
+FPX_DEV double m_rcbrt(double x) {
+  double r = (double)__builtin_amdgcn_exp2f(__log2f((float)x) * (-1.0f / 3.0f));
+  const double third = 1.0 / 3.0;
+#pragma unroll
+  for (int it = 0; it < 2; it++) {
+    const double e = fma(-(x * (r * r)), r, 1.0);
+    r = fma(r * third, e, r);
+  }
+  return r;
+}
 // exp(x): k = rint(x/ln2), r = x - k*ln2 (two-part ln2), exp(r) by the degree-13 Taylor polynomial
 // split into even and odd halves (|r| <= 0.347: truncation 4e-18), scaled by ldexp.  Leaves out the
 // library's range screening: v_ldexp_f64 saturates to 0 / inf by itself, NaN propagates.
@@ -356,16 +454,36 @@ struct SeqRng {
 
 struct Stats {
   unsigned long long n_due, n_init, n_left, n_minmass, n_maxage, nan_count, nan_count2, n_badpos;
+  // diagnostics of an instrumented build (-DFPX_LANE_STATS): per code region of the Langevin kernel, how often a wave ran it
+  // and with how many lanes (fpx_lane_stats)
+  unsigned long long lanes[16][2];
 };
+// regions: 0 a pass, 1 a fine sub-step, 2 its CBL branch, 3 the Gaussian branch under cblflag, 4 the exponential-form branch,
+// 5/6/7 hanna_short neutral / unstable / stable, 8 lane refill, 9 hand-over of a finished particle, 10 the kernel's loop iterations
+#ifdef FPX_LANE_STATS
+#define FPX_LANES(st, region)                                                                     \
+  do {                                                                                            \
+    const unsigned long long m_ = __ballot(1);                                                    \
+    if ((int)(threadIdx.x & 63) == __ffsll((long long)m_) - 1) {                                  \
+      atomicAdd(&(st)->lanes[region][0], 1ull);                                                   \
+      atomicAdd(&(st)->lanes[region][1], (unsigned long long)__popcll(m_));                       \
+    }                                                                                             \
+  } while (0)
+#else
+#define FPX_LANES(st, region) do {} while (0)
+#endif
 
 // ---------------------------------------------------------------------------
-// counter-based generator: Philox4x32-10 (Salmon et al. 2011), keyed by seed,
-// counter = (particle id, step, draw index)
+// counter-based generator: Philox4x32 (Salmon et al. 2011), keyed by seed,
+// counter = (particle id, step, draw index).  Seven rounds: the fewest for which the authors report that the
+// generator passes BigCrush ("Crush-resistant", their Table 2; ten is their default with a safety margin) -- the
+// rounds are 32-bit multiplies at a quarter of the VALU rate, and the Langevin kernel is VALU-bound.
 // ---------------------------------------------------------------------------
+constexpr int kPhiloxRounds = 7;
 FPX_DEV void philox4x32(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
                         unsigned int k0, unsigned int k1, unsigned int out[4]) {
 #pragma unroll
-  for (int r = 0; r < 10; r++) {
+  for (int r = 0; r < kPhiloxRounds; r++) {
     unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
     unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
     unsigned int n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
@@ -394,19 +512,19 @@ struct Rng {
     if (blk != cblk) {
       unsigned int o[4];
       philox4x32(pid, step, blk, 0x47415553u, k0, k1, o);
-      // clipped Box-Muller pairs (the distribution of gasdev1, random_mod.f90:70-90)
+      // clipped Box-Muller pairs (the distribution of gasdev1, random_mod.f90:70-90), on the hardware's f32 transcendentals:
+      // v_log_f32 is a base-2 logarithm, v_sin_f32 / v_cos_f32 take their argument in revolutions -- sin(2*pi*u) is one
+      // instruction, no range reduction (30 instructions for four normals where the library forms took 74)
       const float u1 = ((float)(o[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);
       const float u2 = ((float)(o[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
       const float u3 = ((float)(o[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
       const float u4 = ((float)(o[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-      const float ra = sqrtf(-2.0f * __logf(u1)), rb = sqrtf(-2.0f * __logf(u3));
-      float sa, ca, sb, cb;
-      __sincosf(6.2831853071795865f * u2, &sa, &ca);
-      __sincosf(6.2831853071795865f * u4, &sb, &cb);
-      c0 = fminf(3.0f, fmaxf(-3.0f, ra * ca));
-      c1 = fminf(3.0f, fmaxf(-3.0f, ra * sa));
-      c2 = fminf(3.0f, fmaxf(-3.0f, rb * cb));
-      c3 = fminf(3.0f, fmaxf(-3.0f, rb * sb));
+      const float ra = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u) = sqrt(-2 ln2 log2 u)
+      const float rb = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u3));
+      c0 = __builtin_amdgcn_fmed3f(ra * __builtin_amdgcn_cosf(u2), -3.0f, 3.0f);
+      c1 = __builtin_amdgcn_fmed3f(ra * __builtin_amdgcn_sinf(u2), -3.0f, 3.0f);
+      c2 = __builtin_amdgcn_fmed3f(rb * __builtin_amdgcn_cosf(u4), -3.0f, 3.0f);
+      c3 = __builtin_amdgcn_fmed3f(rb * __builtin_amdgcn_sinf(u4), -3.0f, 3.0f);
       cblk = blk;
     }
     const int ph = idx & 3;
@@ -715,7 +833,7 @@ enum StashSlot {
   S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
   S_ZT0, S_W,                                                                   // height at the start of the pass (u, v follow from it and the cached levels); interpol_mod w
   S_UP, S_VP,                                                                   // turbulent velocities along/across wind
-  S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; cbl.f90:79-81 transition
+  S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; wst^3 * the transition of cbl.f90:79-81
   S_RHOAUX,                                                                     // per-pass invariant of the fine loop: rhograd/rhoa
   S_COUNT
 };
@@ -725,6 +843,11 @@ struct Stash {
   // an LDS (address space 3) pointer, so that the accesses are ds_read/ds_write and not flat memory operations
   typedef __attribute__((address_space(3))) volatile R *lds_ptr;
   lds_ptr p;       // &lds[0][threadIdx.x]
+  lds_tab_ptr tab; // the block's copy of kLogTab | kExpTab (fp64 build only)
+  FPX_DEV double logabs(double x) const { return m_log_abs(x, tab); }
+  FPX_DEV double expt(double x) const { return m_exp_tab(x, tab + kLdsExpTabAt); }
+  FPX_DEV float logabs(float x) const { return m_logp(x); }
+  FPX_DEV float expt(float x) const { return m_expp(x); }
   FPX_DEV R get(int k) const { return p[k * kStashStride]; }
   FPX_DEV void put(int k, R v) const { p[k * kStashStride] = v; }
   FPX_DEV void add(int k, R v) const { p[k * kStashStride] = p[k * kStashStride] + v; }
@@ -760,7 +883,7 @@ template <typename R, typename ST>
 FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   // hanna_short.f90:41-92
   if (I.regime == 0) {
     const R corr = z * I.iaux;
-    T.sigw = K(1.3) * m_expp(K(-2.e-4) * corr);
+    T.sigw = K(1.3) * S.expt(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
     T.sigw = T.sigw * S.get(S_UST) + K(1.e-2);
     const R qn = K(1.) + K(1.5e-3) * corr;
@@ -773,11 +896,20 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     // the last factor by its cubic Taylor polynomial (|1.e-5*log zeta| < 1e-3: remainder < 1e-17)
     R z23, zm13;
     if (sizeof(R) == 8) {
-      const R lz = m_logp(T.zeta);
-      const R e13 = m_expp(K(-.33333) * lz);
+      // zeta**(-.33333) = zeta**(-1/3) * exp(+(1/3 - .33333)*log zeta) and zeta**0.66666 = zeta * zeta**(-.33333) * exp(-1.e-5*log zeta)
+      // (0.66666 = 1 - 0.33333 - 1.e-5): the cube root by Newton steps from an f32 seed, the two tiny exponents through
+      // their cubic Taylor polynomials (|d| < 3e-4: remainder < 1e-15) with a logarithm that is only good to 1e-13 ABSOLUTE
+      // (m_log_abs) -- a relative 1e-18 in the factors.  39 instructions where one m_logp and one m_expp took 68.
+      const bool tiny = !(T.zeta > K(1.e-37));                 // 0 and what the f32 seed cannot hold: handled below
+      const R zc = tiny ? K(1.) : T.zeta;
+      const R lz = S.logabs(zc);
+      const R r13 = m_rcbrt(zc);
+      const R d1 = ((K(1.) / K(3.)) - K(.33333)) * lz;
+      const R e13 = r13 * (K(1.) + d1 * (K(1.) + d1 * (K(0.5) + d1 * K(0.16666666666666666))));
       const R d = ((K(1.) - K(.33333)) - K(0.66666)) * lz;       // 1.e-5 * log(zeta)
       const R corr = K(1.) - d * (K(1.) - d * (K(0.5) - d * K(0.16666666666666666)));
-      z23 = T.zeta > K(0.) ? T.zeta * e13 * corr : K(0.);   // 0**0.66666 = 0 (log(0) = -inf would give 0*inf)
+      // zeta < 1e-37: zeta**0.66666 < 3e-25 is below the rounding of the ust**2 term (ust >= 1e-4) of sigw
+      z23 = tiny ? K(0.) : T.zeta * e13 * corr;
       zm13 = T.zeta > K(1.e-3) ? e13 : K(9.9997697441416293);   // (1.e-3)**(-.33333)
     } else {   // reference typing: x**y as exp(y*log x) in f32 (a few ulp from powf, at a third of its cost)
       const R lz = m_logp(T.zeta);
@@ -796,7 +928,7 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     T.dsigwdz = K(0.5) * isig * I.ih * (K(-1.4) * ust2 + wst2 * (K(0.8) * zm13 - K(1.8) * z23));
     if (low) T.tlw = K(0.1) * z * i2;
     else if (T.zeta < K(0.1)) T.tlw = K(0.59) * z * isig;
-    else T.tlw = K(0.15) * T.h * isig * (K(1.) - m_expp(K(-5) * T.zeta));
+    else T.tlw = K(0.15) * T.h * isig * (K(1.) - S.expt(K(-5) * T.zeta));
   } else {
     const R ust = S.get(S_UST);
     T.sigw = K(1.e-2) + K(1.3) * ust * (K(1.) - T.zeta);
@@ -826,36 +958,43 @@ FPX_DEV R cbl_transition(R h, R ol) {   // cbl.f90:79-81
 }
 
 // cbl.f90:70-210 -> drift ath, diffusion bth, blow-up flag.
-// Same algebra as the reference, arranged for a VALU-bound fp64 kernel: every quotient that
-// shares a divisor shares one reciprocal, and the square roots come with their reciprocals:
-//   w2**0.5 = sigmaw (sigmaw > 0), so skew = w3/sigmaw^3, dskew = (..)/sigmaw^6, dradw2 = dsigmawdz;
-//   den_r = ((3+f^2)^2 f^2) = den_x^2 with den_x = (3+f^2) f:  one reciprocal for rluarw, xluarw
-//   and their derivatives ((N*den - num*D)/den^2 = (N - (num/den)*D)/den);
-//   with x = aluarw*bluarw*(1+f^2) and rs = x**-0.5:  (b/(a(1+f^2)))**0.5 = b*rs, its inverse = a(1+f^2)*rs,
-//   1/(a(1+f^2)) = b*rs^2 (and the same with a and b exchanged), 1/sigmawa = (1/sigmaw)*a(1+f^2)*rs;
+// Same mathematics as the reference, re-derived for a VALU-bound fp64 kernel (results differ by rounding only).
+// With f = fluarw, s = skew, a1 = 1+f^2, a3 = 3+f^2, x = xluarw, r = rluarw, al = aluarw, bl = bluarw, sw = sigmaw:
+//   w2**0.5 = sw (sw > 0), so s = w3/sw^3, ds = dw3/sw^3 - 3 s dsw/sw, dradw2 = dsigmawdz;
+//   r = x^2 identically (cbl.f90:122-123: (1+f^2)^3 s^2/((3+f^2)^2 f^2) against (1+f^2)^1.5 s/((3+f^2) f)), hence
+//     dr = 2 x dx, and with 4 + r - x^2 = 4 the derivative :144-146 collapses to dal = -2 dx (4+r)^-1.5;
+//   al*bl = (1 - x^2/(4+r))/4 = 1/(4+r), so (bl/(al a1))**0.5 = bl*rs with rs = (4+r)^0.5 * a1^-0.5:
+//     sigmawa = sw*rs*bl, sigmawb = sw*rs*al, 1/sigmawa = (a1^0.5 (4+r)^0.5 / sw) * al, 1/sigmawb = (..) * bl
+//     -- two coupled sqrt/rsqrt pairs (a1 and 4+r) give every root and reciprocal root of :148-167;
+//   the derivative of the first quotient, dbl*t1 - bl*(dal*a1 + al*ffd) over t1^2 with dbl = -dal and al+bl = 1,
+//     is -(dal*a1 + al*bl*ffd)*bl^2*rs^4, so 0.5/qa05 times it = -0.5*bl*rs^3*(dal*a1 + al*bl*ffd);
+//     for the second quotient +0.5*al*rs^3*(dal*a1 - al*bl*ffd);
+//   sigmawa*dwa - wa*dsigmawa = dfluarw*sigmawa^2 (dwa = df*sigmawa + f*dsigmawa, wa = f*sigmawa), so the last bracket
+//     of :193-194 is wold*dfluarw (and -wold*dfluarw in :198-199);
+//   alfa = 2 w2/(C0 tlw) and bth = sqrt(C0 alfa) = sw*sqrt(2/tlw) from one rsqrt(tlw);
 //   the two cube roots of cbl.f90:115-121 from one x**(-1/3) (m_cuberoot_parts).
-// What is left is 3 reciprocals, 2 sqrt, 1 sqrt+rsqrt, 1 rsqrt, 2 exp and 2 erf per call
+// What is left is 2 reciprocals, 1 sqrt, 2 coupled sqrt+rsqrt, 1 rsqrt, 2 exp and 2 erf per call
 // (the straightforward form has 20 divisions, 7 square roots, 1 log and 4 exp).
-// `transition` (cbl.f90:79-81) depends on h/ol only and is passed in.
-template <typename R>
-FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rhograd/rhoa */, R sigmaw, R irw /* 1/sigmaw */, R dsigmawdz, R tlw, R transition,
+// `wt` = wst^3 * transition (cbl.f90:79-81,103-104): depends on h, ol, wst only and is passed in.
+// ST: the source of the lookup tables of exp (the loop kernel's stash)
+template <typename R, typename ST>
+FPX_DEV void cbl(const ST &S, int ldirect, R wp, R zp, R wt /* wst^3 * transition */, R ih /* 1/h */, R rhoaux /* rhograd/rhoa */, R sigmaw, R irw /* 1/sigmaw */, R dsigmawdz, R tlw,
                  R &ath, R &bth, int &flagrein) {
   const R usurad2 = K(0.7071067812), usurad2p = K(0.3989422804), C0 = K(3), costluar4 = K(0.66667), eps = K(0.000001);
   const R timedir = (R)ldirect;
   const R z = zp * ih;
   const R w2 = sigmaw * sigmaw;
-  const R alfa = K(2.) * w2 * m_rcp(C0 * tlw);
+  const R rtl = m_rsqrt(tlw);                        // tlw >= 30 (hanna_short.f90:91)
+  const R alfa = (K(2.) / C0) * w2 * (rtl * rtl);
   const R wold = timedir * wp;
   const R omz = K(1.) - z;
   const R omz05 = m_sqrtp(omz), omz15 = omz * omz05;
-  const R wst3 = wst * wst * wst;
-  const R w3 = (K(1.2) * z * omz15 + eps) * wst3 * transition;
-  const R dw3 = (K(1.2) * (omz15 + z * K(1.5) * omz05 * K(-1.))) * wst3 * ih * transition;
+  const R w3 = (K(1.2) * z * omz15 + eps) * wt;
+  const R dw3 = (K(1.2) * (omz15 - z * K(1.5) * omz05)) * (wt * ih);
   const R irw2 = irw * irw, irw3 = irw2 * irw;
   const R skew = w3 * irw3;
-  const R skew2 = skew * skew;
   const R dskew = irw3 * dw3 - K(3.) * skew * dsigmawdz * irw;   // (dw3*w2**1.5 - w3*1.5*w2**0.5*dw2)/w2**3 with w2 = sigmaw^2
-  R fluarw = K(0.), dfluarw = K(0.), rluarw = K(0.), drluarw = K(0.), xluarw = K(0.), dxluarw = K(0.);
+  R fluarw = K(0.), dfluarw = K(0.), xluarw = K(0.), dxluarw = K(0.);
   if (skew != K(0)) {
     R croot, icroot2;
     m_cuberoot_parts(m_abs(skew), croot, icroot2);
@@ -865,33 +1004,28 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rho
   const R fluarw2 = fluarw * fluarw;
   const R a1 = K(1.) + fluarw2, a3 = K(3.) + fluarw2;
   const R ffd = K(2.) * fluarw * dfluarw;
+  R a105, ia105;
+  m_sqrt_rsqrt(a1, a105, ia105);
   if (skew != K(0)) {
-    const R a105 = m_sqrtp(a1);
-    const R a1c = a1 * a1 * a1, a115 = a1 * a105;
-    const R ix = m_rcp(a3 * fluarw), ix2 = ix * ix;
-    rluarw = a1c * skew2 * ix2;
+    const R a115 = a1 * a105;
+    const R ix = m_rcp(a3 * fluarw);
     xluarw = a115 * skew * ix;
-    drluarw = ((K(3.) * (a1 * a1) * ffd * skew2 + a1c * K(2.) * skew * dskew) - rluarw * (K(2.) * a3 * ffd * fluarw2 + a3 * a3 * ffd)) * ix2;
     dxluarw = ((K(1.5) * a105 * ffd * skew + a115 * dskew) - xluarw * (K(3.) * dfluarw * a1)) * ix;
   }
-  const R r4 = K(4.) + rluarw;
+  const R r4 = m_fma(xluarw, xluarw, K(4.));         // 4 + rluarw
   R r405, ir405;
   m_sqrt_rsqrt(r4, r405, ir405);
   const R aluarw = K(0.5) * (K(1.) - xluarw * ir405);
   const R bluarw = K(1.) - aluarw;
-  const R daluarw = K(-0.5) * ((dxluarw * r405) - (K(0.5) * xluarw * ir405 * drluarw)) * (ir405 * ir405);
+  const R ir4 = ir405 * ir405;                       // = aluarw*bluarw
+  const R daluarw = K(-2.) * dxluarw * (ir405 * ir4);
   const R dbluarw = -daluarw;
-  // With x = aluarw*bluarw*a1 and rs = x**-0.5 (a1 = 1+fluarw^2):
-  //   (bluarw/(aluarw*a1))**0.5 = bluarw*rs, its inverse = aluarw*a1*rs (and the same with a and b exchanged);
-  //   the derivative of the first quotient, dbl*t1 - bl*(dal*a1 + al*ffd) over t1^2 with dbl = -dal and al+bl = 1,
-  //   is -(dal*a1 + al*bl*ffd)*bl^2*rs^4, so 0.5/qa05 times it = -0.5*bl*rs^3*(dal*a1 + al*bl*ffd);
-  //   for the second quotient +0.5*al*rs^3*(dal*a1 - al*bl*ffd).
-  const R ab = aluarw * bluarw;
-  const R rs = m_rsqrt(ab * a1), rs3 = rs * (rs * rs);
-  const R qa05 = bluarw * rs, iqa05 = aluarw * a1 * rs;
-  const R qb05 = aluarw * rs, iqb05 = bluarw * a1 * rs;
+  const R rs = r405 * ia105, rs3 = rs * (rs * rs);
+  const R qa05 = bluarw * rs, qb05 = aluarw * rs;
   const R sigmawa = sigmaw * qa05, sigmawb = sigmaw * qb05;
-  const R da1 = daluarw * a1, abf = ab * ffd, hs3 = K(0.5) * sigmaw * rs3;
+  const R iv = irw * (a105 * r405);                  // 1/sigmawa = 1/(sigmaw*rs*bl) = (a1^0.5 (4+r)^-0.5/sigmaw) * al*(4+r) = iv*al
+  const R isa = iv * aluarw, isb = iv * bluarw;
+  const R da1 = daluarw * a1, abf = ir4 * ffd, hs3 = K(0.5) * sigmaw * rs3;
   const R dsigmawa = dsigmawdz * qa05 - hs3 * bluarw * (da1 + abf);
   const R dsigmawb = dsigmawdz * qb05 + hs3 * aluarw * (da1 - abf);
   const R wa = fluarw * sigmawa, wb = fluarw * sigmawb;
@@ -899,31 +1033,32 @@ FPX_DEV void cbl(int ldirect, R wp, R zp, R wst, R ih /* 1/h */, R rhoaux /* rho
   const R dwb = dfluarw * sigmawb + fluarw * dsigmawb;
   const R deltawa = wold - wa, deltawb = wold + wb;
   const R wold2 = wold * wold;
-  const R isa = irw * iqa05, isb = irw * iqb05;
   const R isa2 = isa * isa, isb2 = isb * isb;
-  if (m_abs(deltawa) > K(6.) * sigmawa && m_abs(deltawb) > K(6.) * sigmawb) flagrein = 1;
   const R da = deltawa * isa, db = deltawb * isb;
+  if (m_abs(da) > K(6.) && m_abs(db) > K(6.)) flagrein = 1;   // abs(deltawa) > 6*sigmawa .and. abs(deltawb) > 6*sigmawb
   const R da2 = da * da, db2 = db * db;
-  const R ea = m_expp(-(K(0.5) * da2)), eb = m_expp(-(K(0.5) * db2));
+  const R ea = S.expt(-(K(0.5) * da2)), eb = S.expt(-(K(0.5) * db2));
   const R pa = (usurad2p * isa) * ea;
   const R pb = (usurad2p * isb) * eb;
-  const R aperfa = deltawa * usurad2 * isa;
-  const R aperfb = deltawb * usurad2 * isb;
+  const R aperfa = da * usurad2;
+  const R aperfb = db * usurad2;
   // The air density multiplies every term of ptot, Q and Phi (cbl.f90:175-205) and cancels in
   // ath = (-(C0/2)*alfa*Q + Phi)/ptot; what is left of it is rx = rhograd/rhoa.
   const R rx = rhoaux;
-  const R ptot = aluarw * pa + bluarw * pb;
+  const R apa = aluarw * pa, bpb = bluarw * pb;
+  const R ptot = apa + bpb;
   const R Ta = aluarw * (dwa + wa * rx) + wa * daluarw;
   const R Tb = bluarw * (dwb + wb * rx) + wb * dbluarw;
-  const R Ua = sigmawa * (aluarw * (dsigmawa * (wold2 * isa2 + K(1.)) + wold * isa2 * (sigmawa * dwa - wa * dsigmawa)) + sigmawa * (daluarw + rx * aluarw));
-  const R Ub = sigmawb * (bluarw * (dsigmawb * (wold2 * isb2 + K(1.)) + wold * isb2 * (wb * dsigmawb - sigmawb * dwb)) + sigmawb * (dbluarw + rx * bluarw));
+  const R wdf = wold * dfluarw;
+  const R Ua = sigmawa * (aluarw * (dsigmawa * (wold2 * isa2 + K(1.)) + wdf) + sigmawa * (daluarw + rx * aluarw));
+  const R Ub = sigmawb * (bluarw * (dsigmawb * (wold2 * isb2 + K(1.)) - wdf) + sigmawb * (dbluarw + rx * bluarw));
   // exp(-aperf^2) from exp(-d^2/2): aperf = d*usurad2 and usurad2^2 - 0.5 = 5.9e-12 (the reference's 10-digit 1/sqrt(2))
   const R cu = usurad2 * usurad2 - K(0.5);
   const R erfa = m_erf_e(aperfa, ea - ea * (da2 * cu)), erfb = m_erf_e(aperfb, eb - eb * (db2 * cu));
   const R Phi = K(0.5) * (Tb * erfb - Ta * erfa) + Ua * pa + Ub * pb;
-  const R Q = timedir * ((aluarw * deltawa * isa2) * pa + (bluarw * deltawb * isb2) * pb);
+  const R Q = timedir * ((da * isa) * apa + (db * isb) * bpb);
   ath = m_rcp(ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
-  bth = m_sqrtp(C0 * alfa);
+  bth = (sigmaw * K(1.4142135623730951)) * rtl;     // sqrt(C0*alfa) = sigmaw*sqrt(2/tlw)
 }
 
 // bi-Gaussian pdf parameters shared by re_initialize_particle.f90:47-70 and initialize_cbl_vel.f90:46-73
@@ -1724,16 +1859,19 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const HsInv<R> HI = hanna_short_prepare(T);
 
   // vertical Langevin, ifine sub-steps, advance.f90:396-498
+  FPX_LANES(st, 0);
   for (int i = 1; i <= V.ifine; i++) {
     R delz;
+    FPX_LANES(st, 1);
     if (turbswitch) {
       if (dtftlw < K(.5)) {
         if (cblflag) {
           if (cbl_on) {
+            FPX_LANES(st, 2);
             int flagrein = 0;
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
-            cbl(V.ldirect, wp, zt, S.get(S_WST), HI.ih, S.get(S_RHOAUX), T.sigw, T.isigw, T.dsigwdz, T.tlw, S.get(S_TRANS), ath, bth, flagrein);
+            cbl(S, V.ldirect, wp, zt, S.get(S_TRANS), HI.ih, S.get(S_RHOAUX), T.sigw, T.isigw, T.dsigwdz, T.tlw, ath, bth, flagrein);
             wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
             delz = wp * dtf;
             if (__builtin_expect(flagrein == 1, 0)) {
@@ -1743,6 +1881,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
               atomicAdd(&st->nan_count, 1ull);
             }
           } else {
+            FPX_LANES(st, 3);
             nrand = nrand + 1;
             R ath = -wp * m_rcp(T.tlw) + T.sigw * T.dsigwdz + wp * wp * T.isigw * T.dsigwdz + T.sigw * T.sigw * S.get(S_RHOAUX);
             R bth = T.sigw * G.at(nrand) * m_sqrtp(K(2.) * dtftlw);
@@ -1761,6 +1900,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
           delz = wp * T.sigw * dtf;
         }
       } else {
+        FPX_LANES(st, 4);
         R rw = m_expp(-dtftlw);
         wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw)) * (R)icbt;
         delz = wp * T.sigw * dtf;
@@ -1785,6 +1925,9 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     }
     if (i != V.ifine) {
       T.zeta = zt * HI.ih;
+#ifdef FPX_LANE_STATS
+      if (HI.regime == 0) FPX_LANES(st, 5); else if (HI.regime == 1) FPX_LANES(st, 6); else FPX_LANES(st, 7);
+#endif
       hanna_short(T, zt, HI, S);
     }
   }

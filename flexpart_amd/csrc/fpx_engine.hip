@@ -4,6 +4,7 @@
 // met fields stay resident in HBM between calls; a step is a single launch of
 // k_advance (one thread per particle slot) on the handle's stream.
 #include <hip/hip_runtime.h>
+#include <cstddef>
 #include <cstring>
 #include <rccl/rccl.h>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -1033,8 +1034,12 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
   R *stash_mem = reinterpret_cast<R *>(fpx_loop_smem);
   R *hgt = stash_mem + S_COUNT * kStashStride;
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  // the block's copy of the lookup tables of the fp64 logarithm and exponential (m_log_abs, m_exp_tab): 768 B
+  __shared__ double lds_tab[sizeof(R) == 8 ? kLdsTabDoubles : 1];
+  if (sizeof(R) == 8)
+    for (int k = threadIdx.x; k < kLdsTabDoubles; k += blockDim.x) lds_tab[k] = k < kLdsExpTabAt ? kLogTab[k >> 1][k & 1] : kExpTab[k - kLdsExpTabAt];
   __syncthreads();
-  const Stash<R> S{(typename Stash<R>::lds_ptr)(stash_mem + threadIdx.x)};
+  const Stash<R> S{(typename Stash<R>::lds_ptr)(stash_mem + threadIdx.x), (lds_tab_ptr)lds_tab};
   const unsigned int nlist = *pbl_count;
   const int lane = threadIdx.x & 63;
   const TimeW<R> W = time_weights(V, itime);   // wave-uniform
@@ -1060,6 +1065,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
   R prob[kMaxSpec];
 
   for (;;) {
+    FPX_LANES(st, 10);
     const unsigned long long need = __ballot(!have);
     if (need != 0ull && !out_of_chunks) {
       if (cur >= end) {   // wave-uniform: take the next chunk
@@ -1078,6 +1084,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
         const unsigned int rank = __popcll(need & ((1ull << lane) - 1ull));
         const unsigned int my = cur + rank;
         if (my < end) {
+          FPX_LANES(st, 8);
           s = pbl_list[my];
           xt = P.xt[s]; yt = P.yt[s]; zt = P.zt[s];
           wp = P.wp[s];
@@ -1096,7 +1103,8 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
           S.put(S_UP, P.up[s]); S.put(S_VP, P.vp[s]);
           {
             const PblRecord<R> &r = Q.rec[s];
-            S.put(S_UST, r.v[0]); S.put(S_WST, r.v[1]); S.put(S_OL, r.v[2]); S.put(S_TRANS, r.v[3]);
+            S.put(S_UST, r.v[0]); S.put(S_WST, r.v[1]); S.put(S_OL, r.v[2]);
+            S.put(S_TRANS, (r.v[1] * r.v[1] * r.v[1]) * r.v[3]);   // (wst**3)*transition, cbl.f90:103-104
           }
           A.ilo = -1;
           if (!LEAN && V.drydep) {
@@ -1118,6 +1126,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
       int indz = 1;
       const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, icbt, A, S, indz, prob, st);
       if (rc != PBL_CONTINUE) {
+        FPX_LANES(st, 9);
         {
           // the particle's state at the end of its last pass goes into its hand-over record: one contiguous line;
           // k_pbl_finish writes the particle arrays from it
@@ -1156,6 +1165,9 @@ __global__ void k_math_probe(int fn, const double *__restrict__ x, double *__res
     case 5: m_cuberoot_parts(v, c, ic2); r = c; break;
     case 7: r = m_erf_e(v, m_expp(-(v * v))); break;
     case 8: r = m_pow08(v); break;
+    case 9: r = m_exp_tab(v, &kExpTab[0]); break;
+    case 10: r = m_log_abs(v); break;
+    case 11: r = m_rcbrt(v); break;
     default: m_cuberoot_parts(v, c, ic2); r = ic2; break;
   }
   y[i] = r;
@@ -1317,6 +1329,7 @@ struct EngineBase {
   virtual int conccalc(int itime, double weight) = 0;
   virtual int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) = 0;
   virtual int count_particles(int64_t *local, int64_t *total, int allreduce) = 0;
+  virtual int lane_stats(uint64_t *out, int n, int reset) = 0;
   virtual int comm_init(const void *id, int nbytes, int nranks, int rank) = 0;
   virtual int comm_init_host(int nranks, int rank, fpx_allreduce_fn fn, void *user) = 0;
   virtual int nests_init(const fpx_nests *n) = 0;
@@ -3666,6 +3679,7 @@ struct Engine : EngineBase {
       HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, loop_smem_bytes()));
       if (const char *env = getenv("FPX_PBL_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, atoi(env)));   // experiments: fewer resident waves
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
+      if (getenv("FPX_VERBOSE")) fprintf(stderr, "[fpx] Langevin kernel: %d blocks per CU by the occupancy query, %zu B of dynamic LDS, grid %d\n", per_cu, loop_smem_bytes(), pbl_grid);
     }
     {
       size_t need = 0;
@@ -3731,6 +3745,14 @@ struct Engine : EngineBase {
     out->n_left_domain = (int64_t)(a.n_left - b.n_left); out->n_min_mass = (int64_t)(a.n_minmass - b.n_minmass);
     out->n_max_age = (int64_t)(a.n_maxage - b.n_maxage); out->nan_count = (int64_t)(a.nan_count - b.nan_count);
     out->nan_count2 = (int64_t)(a.nan_count2 - b.nan_count2); out->n_bad_position = (int64_t)(a.n_badpos - b.n_badpos);
+  }
+  int lane_stats(uint64_t *out, int n, int reset) override {
+    Stats hs;
+    HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(Stats), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    for (int i = 0; i < n && i < 32; i++) out[i] = hs.lanes[i / 2][i % 2];
+    if (reset) HIPCHK(hipMemsetAsync((char *)d_stats + offsetof(Stats, lanes), 0, sizeof(hs.lanes), stream));
+    return 0;
   }
   int counters(fpx_step_stats *out, int reset) override {
     Stats hs;
@@ -4569,6 +4591,7 @@ int fpx_comm_unique_id(void *id, int32_t nbytes) {
   return FPX_OK;
 }
 int fpx_count_particles(fpx_handle h, int64_t local[2], int64_t total[2], int32_t allreduce) { FPX_GUARD(h); return h->impl->count_particles(local, total, allreduce); }
+int fpx_lane_stats(fpx_handle h, uint64_t *out, int32_t n, int32_t reset) { FPX_GUARD(h); if (!out || n < 0) return fpx::fail(FPX_ERR_ARG, "fpx_lane_stats: bad argument"); return h->impl->lane_stats(out, n, reset); }
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
 int fpx_comm_init_host(fpx_handle h, int32_t nranks, int32_t rank, fpx_allreduce_fn fn, void *user) { FPX_GUARD(h); return h->impl->comm_init_host(nranks, rank, fn, user); }
 int fpx_nests_init(fpx_handle h, const fpx_nests *n) { FPX_GUARD(h); return h->impl->nests_init(n); }
@@ -4585,7 +4608,7 @@ int fpx_receptors_init(fpx_handle h, int32_t numreceptor, const void *xreceptor,
 int fpx_get_receptors(fpx_handle h, void *creceptor, int32_t ld, int32_t allreduce, int32_t clear) { FPX_GUARD(h); return h->impl->get_receptors(creceptor, ld, allreduce, clear); }
 
 int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n) {
-  if (fn < 0 || fn > 8 || !x || !y || n < 0) return FPX_ERR_ARG;
+  if (fn < 0 || fn > 11 || !x || !y || n < 0) return FPX_ERR_ARG;
   if (n == 0) return FPX_OK;
   double *dx = nullptr, *dy = nullptr;
   if (hipMalloc(&dx, n * sizeof(double)) != hipSuccess) return FPX_ERR_NOMEM;

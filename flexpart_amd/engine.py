@@ -757,6 +757,14 @@ class Engine:
         check(self.lib.fpx_count_particles(self.h, loc, tot, int(allreduce)), "fpx_count_particles")
         return (int(loc[0]), int(loc[1])), (int(tot[0]), int(tot[1]))
 
+    def lane_stats(self, reset=False):
+        """Per code region of the Langevin kernel: (executions by a wave, mean active lanes); zeros unless the library was
+        built with -DFPX_LANE_STATS."""
+        out = (C.c_uint64 * 32)()
+        check(self.lib.fpx_lane_stats(self.h, out, 32, int(reset)), "fpx_lane_stats")
+        names = ("pass", "substep", "cbl", "gauss_cblflag", "exp_form", "hs_neutral", "hs_unstable", "hs_stable", "refill", "handover", "outer_loop")
+        return {nm: (int(out[2 * i]), (out[2 * i + 1] / out[2 * i]) if out[2 * i] else 0.0) for i, nm in enumerate(names)}
+
     def comm_init(self, uid, nranks, rank):
         buf = (C.c_char * 128).from_buffer_copy(uid)
         check(self.lib.fpx_comm_init(self.h, buf, 128, int(nranks), int(rank)), "fpx_comm_init")

@@ -58,7 +58,7 @@ typedef enum {
  * in particle order (advance.f90:153, initialize.f90:68).  TABLE_COUNTER keeps
  * the table but draws the start index from a counter-based generator keyed on
  * (seed, particle id, step) -- order-independent, hence shardable.  PHILOX
- * replaces the table by Philox4x32-10 keyed on (seed, particle id, step, draw index / 4):
+ * replaces the table by Philox4x32-7 keyed on (seed, particle id, step, draw index / 4):
  * one call gives four clipped Box-Muller normals. */
 typedef enum { FPX_RNG_TABLE_SEQ = 0, FPX_RNG_TABLE_COUNTER = 1, FPX_RNG_PHILOX = 2 } fpx_rng_mode;
 
@@ -586,9 +586,16 @@ void *fpx_stream(fpx_handle h);
 /* Diagnostics: evaluates one of the engine's fp64 device math helpers (fpx_device.hpp: the 1-2 ulp
  * replacements of exp/log/sqrt/division used inside the Langevin loop) on n host values, on the
  * current device.  fn: 0 m_expp, 1 m_logp, 2 m_sqrtp, 3 m_rcp, 4 m_rsqrt, 5 x**0.333333333 and
- * 6 x**(-2*0.333333333) (m_cuberoot_parts), 7 m_erf_e(x, m_expp(-x*x)), 8 m_pow08.  No reference counterpart; used by the parity tests to bound
+ * 6 x**(-2*0.333333333) (m_cuberoot_parts), 7 m_erf_e(x, m_expp(-x*x)), 8 m_pow08,
+ * 9 m_exp_tab, 10 m_log_abs, 11 m_rcbrt (the table-based helpers of the fine sub-step).  No reference counterpart; used by the parity tests to bound
  * the helpers against libm.  Returns 0 or a negative fpx_status. */
 int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n);
+/* Diagnostics of a library built with -DFPX_LANE_STATS (all zeros otherwise): for code region r of the Langevin kernel
+ * out[2r] = how many times a wave executed it, out[2r+1] = the lanes that were active, summed.  Regions: 0 a pass,
+ * 1 a fine sub-step, 2 its CBL branch, 3 the Gaussian branch under cblflag, 4 the exponential-form branch, 5/6/7 hanna_short
+ * neutral / unstable / stable, 8 lane refill, 9 hand-over of a finished particle, 10 iterations of the kernel's outer loop.
+ * n <= 32 values are written; reset != 0 zeroes the counters. */
+int fpx_lane_stats(fpx_handle h, uint64_t *out, int32_t n, int32_t reset);
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@
 ! synchronisation step.  This file is our own code: it contains no reference
 ! source, only calls into it and assignments to its module variables.
 !
-! Usage:  flexref_rK scenario.bin out.bin [timing|gpu]
+! Usage:  flexref_rK scenario.bin out.bin [timing|gpu|gpu32]
 !   gpu: the same host arrays (com_mod) are advanced by the MI355X engine through the
 !        ISO_C_BINDING shim flexpart_amd/fortran/flexgpu_mod.f90 instead of the Fortran loop --
 !        the drop-in integration test (needs a GPU; run on the GPU box).
@@ -81,6 +81,7 @@ program flexref
     call get_command_argument(3, arg3)
     if (trim(arg3) .eq. 'timing') timing = 1
     if (trim(arg3) .eq. 'gpu') use_gpu = 1
+    if (trim(arg3) .eq. 'gpu32') use_gpu = 2      ! the reference-typed f32 engine (compute_real_bytes = 4)
   end if
 
   ! Random number table exactly as the reference main program fills it
@@ -398,9 +399,13 @@ program flexref
     call put_d('derived', tmp, 4)
   end if
 
-  if (use_gpu .eq. 1) then
+  if (use_gpu .ge. 1) then
     ! ---- drop-in: the engine replaces the particle loop -------------------------------
-    call flexgpu_init(gerr, nmaxpart=numpart)
+    if (use_gpu .eq. 2) then
+      call flexgpu_init(gerr, nmaxpart=numpart, compute_real_bytes=4)
+    else
+      call flexgpu_init(gerr, nmaxpart=numpart)
+    end if
     if (gerr .ne. 0) call gpu_fail('flexgpu_init')
     call flexgpu_use_table_rng(gerr)
     if (gerr .ne. 0) call gpu_fail('flexgpu_use_table_rng')

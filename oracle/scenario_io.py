@@ -85,7 +85,8 @@ def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=F
     fs = os.path.join(workdir, f"{tag}_{os.getpid()}.scen")
     fo = os.path.join(workdir, f"{tag}_{os.getpid()}.out")
     write_scenario(fs, sc)
-    cmd = f"ulimit -s unlimited; exec {ref_binary(kind)} {fs} {fo}" + (" timing" if timing else "") + (" gpu" if gpu else "")
+    # gpu = True: the Fortran host drives the engine (fp64 arithmetic); gpu = 32: the reference-typed f32 engine
+    cmd = f"ulimit -s unlimited; exec {ref_binary(kind)} {fs} {fo}" + (" timing" if timing else "") + (" gpu32" if gpu == 32 else (" gpu" if gpu else ""))
     res = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"reference driver failed: {res.stdout}\n{res.stderr}")

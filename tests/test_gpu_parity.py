@@ -210,13 +210,40 @@ def test_reference_typed_f32_on_nests(built, name):
 @pytest.mark.parametrize("name,kw", [
     ("hanna", dict(ctl=5.0, ifine=4)),
     ("hanna1_method0", dict(ctl=-5.0)),
+    ("cbl", dict(ctl=5.0, ifine=4, cblflag=1)),
 ])
 def test_reference_typed_f32_matches_oracle(built, name, kw):
     """Reference typing (f32 state, f64 xy): rounding differs at 1e-7 per operation, so a few
-    particles flip an int() truncation; they are counted, not hidden."""
+    particles flip an int() truncation; they are counted, not hidden.  `cbl` runs the f32 instance of the Langevin
+    kernel with the skewed CBL scheme (cbl.f90:70-210 with hardware rcp / sqrt / exp / log): the kernel instance of
+    BASELINE config 5."""
     sc = syn.small(n=4000, nx=60, ny=40, nz=40, nsteps=3, **kw)
     got, want = run_pair(sc, "r4")
     assert_close(got[-1], want[-1], 2e-6, 5e-3, max_diverged=80)   # <= 2 % of 4000
+
+
+@pytest.mark.parametrize("name", ["cbl", "backward_cbl"])
+def test_reference_typed_f32_cbl_against_reference_fixtures(built, name):
+    """The f32 CBL kernel instance on the golden scenarios `cbl` and `backward_cbl` (ldirect = -1): against the r4 oracle
+    (same divergence accounting as the other f32 tests: <= 2 % of the particles may flip an int() truncation) and
+    directly against the outputs of the r4 flang build of the unmodified reference (tests/golden/*_r4.npz)."""
+    import os
+    from test_oracle_cpu import GOLD, golden_scenario
+    sc = golden_scenario(name)
+    n = int(sc["npart"])
+    got, want = run_pair(sc, "r4")
+    div = 0
+    for g, w in zip(got, want):
+        div = assert_close(g, w, 2e-6, 5e-3, max_diverged=int(0.02 * n))
+    gold = np.load(os.path.join(GOLD, f"{name}_r4.npz"))
+    bad = np.zeros(n, bool)
+    for i, g in enumerate(got):
+        for k in ("xtra1", "ytra1", "ztra1"):
+            ref = gold[f"s{i}_{k}"].astype(np.float64)
+            bad |= np.abs(g[k] - ref) > 2e-6 * np.abs(ref).max()
+    assert bad.sum() <= 0.03 * n, f"{bad.sum()} of {n} particles differ from the r4 reference ({div} from the oracle)"
+    # the scheme was exercised: a good part of the cloud sits in columns with -h/L > 5 (cbl.f90 branch of advance.f90:405)
+    assert np.abs(got[-1]["uzp"]).max() > 0
 
 
 def test_padded_host_arrays(built):
@@ -394,6 +421,27 @@ def test_fortran_host_drop_in(built, kind):
     limit = 0.01 * n if kind == "r8" else 0.05 * n
     assert bad.sum() <= limit, f"{bad.sum()} of {n} particles differ"
     assert np.array_equal(gpu["steps"][-1]["itra1"], ref["steps"][-1]["itra1"])
+
+
+@pytest.mark.parametrize("cbl", [0, 1])
+def test_fortran_host_drives_the_f32_engine(built, cbl):
+    """The reference as shipped (default real = 4 bytes) handing its com_mod arrays to the reference-typed f32 engine
+    through flexgpu_mod (flexgpu_init(compute_real_bytes = 4)): the same arithmetic types on both sides, so the
+    comparison is the f32 parity test (<= 2 % of the particles may flip an int() truncation), with and without the
+    CBL scheme (cblflag = 1: the kernel instance of BASELINE config 5)."""
+    from oracle import scenario_io as sio
+    if not sio.have_ref("r4"):
+        pytest.skip("oracle/_ref binaries not present in this snapshot")
+    sc = syn.small(n=2000, nx=60, ny=40, nz=40, nsteps=3, ctl=5.0, ifine=4, seed=4242, cblflag=cbl)
+    ref = sio.run_reference(sc, "r4")
+    gpu = sio.run_reference(sc, "r4", gpu=32, tag="gpu32")
+    n = int(sc["npart"])
+    bad = np.zeros(n, bool)
+    for a, b in zip(gpu["steps"], ref["steps"]):
+        for k in ("xtra1", "ytra1", "ztra1"):
+            bad |= np.abs(a[k] - b[k]) > 2e-6 * np.abs(b[k]).max()
+    assert bad.sum() <= 0.03 * n, f"{bad.sum()} of {n} particles differ"     # 2 % truncation flips + the D1/D2 leaks of the serial host
+    assert (gpu["steps"][-1]["itra1"] != ref["steps"][-1]["itra1"]).sum() <= 0.01 * n
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
@@ -771,3 +819,14 @@ def test_device_math_helpers_against_libm(built):
     tol = ulp4 * (1.0 + np.abs(lg))       # exp(y*log x) amplifies the rounding of log x by |y log x|
     assert np.max(np.abs(probe(5, sk) / np.exp(0.333333333 * lg) - 1.0) / tol) < 1.0
     assert np.max(np.abs(probe(6, sk) / np.exp(-2.0 * 0.333333333 * lg) - 1.0) / tol) < 1.0
+    # the table-based helpers of the fine sub-step: exp with a 64-entry table of 2**(j/64) (4 ulp); the logarithm that is
+    # only asked for an ABSOLUTE accuracy (1e-13: it feeds factors zeta**delta with |delta| ~ 1e-5); zeta**(-1/3) by Newton steps
+    xt = np.concatenate([rng.uniform(-745.0, 700.0, n), rng.uniform(-40.0, 2.0, n), rng.uniform(-1e-3, 1e-3, 1000), [0.0, -0.0, 1e-300, -800.0]])
+    got, want = probe(9, xt), np.exp(xt)
+    norm = want > 1e-300
+    assert np.max(np.abs(got[norm] - want[norm]) / want[norm]) < ulp4
+    assert np.all(np.abs(got[~norm] - want[~norm]) <= 1e-300)
+    pl = np.concatenate([10.0 ** rng.uniform(-37, 3, n), rng.uniform(0.0, 1.0, n)[1:], 1.0 + rng.uniform(-1e-8, 1e-8, 1000), [1.0, 0.5, 1e-37, 1e-3]])
+    assert np.max(np.abs(probe(10, pl) - np.log(pl))) < 1e-13
+    zc = np.concatenate([10.0 ** rng.uniform(-37, 2, n), rng.uniform(0.0, 1.0, n)[1:], [1.0, 1e-3]])
+    assert np.max(np.abs(probe(11, zc) * np.cbrt(zc) - 1.0)) < ulp4
