@@ -168,6 +168,15 @@ static __device__ const double kLogTab[32][2] = {
   {1.024, -0.023716526617316044},
   {1.0078740157480315, -0.007843177461025893}
 };
+// a*b + c with the literal c held in a scalar register pair.  Left to itself the compiler picks the two-address v_fmac_f64,
+// whose addend must sit in vector registers: two v_mov_b32 per Horner step (4.8 issue cycles next to the fma's 4.4), since
+// the literals are re-materialised inside the loop (MachineLICM is off, see __graft_entry__.py).  The three-address v_fma_f64
+// reads the constant from SGPRs, which the otherwise idle scalar unit loads.
+FPX_DEV double m_fma_k(double a, double b, double c /* compile-time constant */) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
 // 2**(j/32), j = 0 .. 31 (m_exp_tab)
 static __device__ const double kExpTab[32] = {
   1.0, 1.0218971486541166, 1.0442737824274138, 1.0671404006768237,
@@ -191,9 +200,9 @@ FPX_DEV double m_log_abs(double x, TP tab /* kLogTab layout: [32][2] */) {
   const unsigned int j = (__double2hiint(m) >> 15) & 31u;           // top five bits of the fraction
   const double ic = tab[2 * j], lc = tab[2 * j + 1];
   const double f = fma(m, ic, -1.0);
-  double p = fma(f, -1.0 / 6.0, 0.2);
-  p = fma(f, p, -0.25);
-  p = fma(f, p, 1.0 / 3.0);
+  double p = m_fma_k(f, -1.0 / 6.0, 0.2);
+  p = m_fma_k(f, p, -0.25);
+  p = m_fma_k(f, p, 1.0 / 3.0);
   p = fma(f, p, -0.5);
   p = fma(f, p, 1.0);
   return fma((double)e, 6.93147180559945309417e-01, lc) + f * p;
@@ -209,9 +218,9 @@ FPX_DEV double m_exp_tab(double x, TP tab /* kExpTab layout */) {
   r = fma(k, -5.9631716539705866e-12, r);
   const int ki = (int)k;
   const double t = tab[ki & 31];
-  double p = fma(r, 1.3888888888888888889e-03, 8.3333333333333333333e-03);
-  p = fma(r, p, 4.1666666666666666667e-02);
-  p = fma(r, p, 1.6666666666666666667e-01);
+  double p = m_fma_k(r, 1.3888888888888888889e-03, 8.3333333333333333333e-03);
+  p = m_fma_k(r, p, 4.1666666666666666667e-02);
+  p = m_fma_k(r, p, 1.6666666666666666667e-01);
   p = fma(r, p, 0.5);
   p = fma(r, p, 1.0);
   return ldexp(fma(t, r * p, t), ki >> 5);
@@ -627,7 +636,12 @@ FPX_DEV void ld3(const R *base, long long col, int nz, int n, int slot, R &a, R 
 template <typename R, bool WITH_WIND, bool WITH_RHO, bool WITH_SIG>
 FPX_DEV void level_profile(const View<R> &V, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, int n, Level<R> &L) {
   const R eps = K(1.0e-30);
+#ifdef FPX_EXP_FAKE_GATHER   // timing experiment only: every lane reads the same column (no memory latency), results are wrong
+  Cols<R> Q = cols_of(F.nx, C);
+  Q.c00 = 0; Q.c10 = 1; Q.c01 = 2; Q.c11 = 3; n = 1 + (n & 1);
+#else
   const Cols<R> Q = cols_of(F.nx, C);
+#endif
   const R *w3 = F.w3;
   R y1[2], y2[2], y3[2], rho1[2], rhograd1[2];
   R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
@@ -706,30 +720,73 @@ struct Turb {
   R isigw;   // 1/sigw, kept by hanna_short for the Langevin step that follows (PBL loop only)
 };
 
-template <typename R>
-FPX_DEV R tlw_unstable(const Turb<R> &T, R z) {   // hanna.f90:78-84
+// Where exp and the absolute-accuracy logarithm come from: the polynomial / global-table forms (k_prep, k_pbl_finish: not
+// VALU-bound), or the Langevin kernel's stash with its LDS copies of the tables (Stash::expt, Stash::logabs).
+struct PlainMath {
+  FPX_DEV double expt(double x) const { return m_expp(x); }
+  FPX_DEV double logabs(double x) const { return m_log_abs(x); }
+  FPX_DEV float expt(float x) const { return m_expp(x); }
+  FPX_DEV float logabs(float x) const { return m_logp(x); }
+};
+
+// zeta**0.66666 and max(zeta,1.e-3)**(-.33333) of hanna.f90:67-70 / hanna_short.f90:60-63.
+// fp64: zeta**(-.33333) = zeta**(-1/3) * exp(+(1/3 - .33333)*log zeta) and zeta**0.66666 = zeta * zeta**(-.33333) * exp(-1.e-5*log zeta)
+// (0.66666 = 1 - 0.33333 - 1.e-5): the cube root by Newton steps from an f32 seed, the two tiny exponents through
+// their cubic Taylor polynomials (|d| < 3e-4: remainder < 1e-15) with a logarithm that is only good to 1e-13 ABSOLUTE
+// (m_log_abs) -- a relative 1e-18 in the factors.  39 instructions where one m_logp and one m_expp took 68.
+template <typename R, typename MS>
+FPX_DEV void zeta_powers(R zeta, const MS &M, R &z23, R &zm13) {
+  if (sizeof(R) == 8) {
+    const bool tiny = !(zeta > K(1.e-37));                   // 0 and what the f32 seed cannot hold: handled below
+    const R zc = tiny ? K(1.) : zeta;
+    const R lz = M.logabs(zc);
+    const R r13 = m_rcbrt(zc);
+    const R d1 = ((K(1.) / K(3.)) - K(.33333)) * lz;
+    const R e13 = r13 * (K(1.) + d1 * (K(1.) + d1 * (K(0.5) + d1 * K(0.16666666666666666))));
+    const R d = ((K(1.) - K(.33333)) - K(0.66666)) * lz;       // 1.e-5 * log(zeta)
+    const R corr = K(1.) - d * (K(1.) - d * (K(0.5) - d * K(0.16666666666666666)));
+    // zeta < 1e-37: zeta**0.66666 < 3e-25 is below the rounding of the ust**2 term (ust >= 1e-4) of sigw
+    z23 = tiny ? K(0.) : zeta * e13 * corr;
+    zm13 = zeta > K(1.e-3) ? e13 : K(9.9997697441416293);   // (1.e-3)**(-.33333)
+  } else {   // reference typing: x**y as exp(y*log x) in f32 (a few ulp from powf, at a third of its cost)
+    const R lz = m_logp(zeta);
+    z23 = zeta > K(0.) ? m_expp(K(0.66666) * lz) : K(0.);
+    zm13 = m_expp(K(-.33333) * (zeta > K(1.e-3) ? lz : m_logp(K(1.e-3))));
+  }
+}
+// x**0.33333 for x >= 12 (hanna.f90:60: sigu = ust*(12 - 0.5*h/ol)**0.33333): x * (x**(-1/3))**2 * exp(-(1/3 - .33333)*log x)
+template <typename MS>
+FPX_DEV double m_pow13(double x, const MS &M) {
+  if (__builtin_expect(!(x < 1.0e37), 0)) return m_powr(x, 0.33333);
+  const double r = m_rcbrt(x);
+  const double d = ((1.0 / 3.0) - .33333) * M.logabs(x);
+  return (x * (r * r)) * (1.0 - d * (1.0 - d * (0.5 - d * 0.16666666666666666)));
+}
+template <typename MS>
+FPX_DEV float m_pow13(float x, const MS &) { return m_powr(x, 0.33333f); }
+
+template <typename R, typename MS>
+FPX_DEV R tlw_unstable(const Turb<R> &T, R z, const MS &M) {   // hanna.f90:78-84
   if (z < m_abs(T.ol)) return K(0.1) * z * m_rcp(T.sigw * (K(0.55) - K(0.38) * m_abs(z * m_rcp(T.ol))));
   if (T.zeta < K(0.1)) return K(0.59) * z * m_rcp(T.sigw);
-  return K(0.15) * T.h * m_rcp(T.sigw) * (K(1.) - m_expp(K(-5) * T.zeta));
+  return K(0.15) * T.h * m_rcp(T.sigw) * (K(1.) - M.expt(K(-5) * T.zeta));
 }
 
-template <typename R>
-FPX_DEV void sigw_unstable(Turb<R> &T) {   // hanna.f90:67-70 == hanna_short.f90:60-63
-  // zeta**0.66666 and max(zeta,1.e-3)**(-.33333) from one logarithm
-  const R lz = m_logp(T.zeta);
-  const R z23 = T.zeta > K(0.) ? m_expp(K(0.66666) * lz) : K(0.);
-  const R zm13 = m_expp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : m_logp(K(1.e-3))));
+template <typename R, typename MS>
+FPX_DEV void sigw_unstable(Turb<R> &T, const MS &M) {   // hanna.f90:67-70 == hanna_short.f90:60-63
+  R z23, zm13;
+  zeta_powers(T.zeta, M, z23, zm13);
   T.sigw = m_sqrtp(K(1.2) * (T.wst * T.wst) * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * (T.ust * T.ust)) + K(1.e-2);
   T.dsigwdz = K(0.5) * m_rcp(T.sigw * T.h) * (K(-1.4) * (T.ust * T.ust) + (T.wst * T.wst) * (K(0.8) * zm13 - K(1.8) * z23));
 }
 
-template <typename R>
-FPX_DEV void hanna(Turb<R> &T, R z) {   // hanna.f90:41-106
+template <typename R, typename MS = PlainMath>
+FPX_DEV void hanna(Turb<R> &T, R z, const MS &M = MS()) {   // hanna.f90:41-106
   if (T.h / m_abs(T.ol) < K(1.)) {
     T.ust = m_max(K(1.e-4), T.ust);
     R corr = z * m_rcp(T.ust);
-    T.sigu = K(1.e-2) + K(2.0) * T.ust * m_expp(K(-3.e-4) * corr);
-    T.sigw = K(1.3) * T.ust * m_expp(K(-2.e-4) * corr);
+    T.sigu = K(1.e-2) + K(2.0) * T.ust * M.expt(K(-3.e-4) * corr);
+    T.sigw = K(1.3) * T.ust * M.expt(K(-2.e-4) * corr);
     T.dsigwdz = K(-2.e-4) * T.sigw;
     T.sigw = T.sigw + K(1.e-2);
     T.sigv = T.sigw;
@@ -737,12 +794,12 @@ FPX_DEV void hanna(Turb<R> &T, R z) {   // hanna.f90:41-106
     T.tlv = T.tlu;
     T.tlw = T.tlu;
   } else if (T.ol < K(0.)) {
-    T.sigu = K(1.e-2) + T.ust * m_powr(K(12) - K(0.5) * T.h * m_rcp(T.ol), K(0.33333));
+    T.sigu = K(1.e-2) + T.ust * m_pow13(K(12) - K(0.5) * T.h * m_rcp(T.ol), M);
     T.sigv = T.sigu;
-    sigw_unstable(T);
+    sigw_unstable(T, M);
     T.tlu = K(0.15) * T.h * m_rcp(T.sigu);
     T.tlv = T.tlu;
-    T.tlw = tlw_unstable(T, z);
+    T.tlw = tlw_unstable(T, z, M);
   } else {
     T.sigu = K(1.e-2) + K(2.) * T.ust * (K(1.) - T.zeta);
     T.sigv = K(1.e-2) + K(1.3) * T.ust * (K(1.) - T.zeta);
@@ -798,7 +855,7 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
     T.sigw = m_max(T.sigw, K(1.e-6));
     T.tlu = K(0.15) * T.h / T.sigu;
     T.tlv = T.tlu;
-    T.tlw = tlw_unstable(T, z);
+    T.tlw = tlw_unstable(T, z, PlainMath());
   } else {
     T.sigu = K(2.) * T.ust * (K(1.) - T.zeta);
     T.sigv = K(1.3) * T.ust * (K(1.) - T.zeta);
@@ -828,10 +885,9 @@ FPX_DEV void hanna1(Turb<R> &T, R z) {   // hanna1.f90:41-129
 // the compiler does not forward the values through registers across the loop.
 // ---------------------------------------------------------------------------
 enum StashSlot {
-  S_ULO, S_VLO, S_WLO, S_RHOLO, S_RGLO, S_UHI, S_VHI, S_WHI, S_RHOHI, S_RGHI,   // the two profile levels of the current pass
+  S_U, S_V, S_W,                                                                // interpol_mod u, v, w of the current pass (advance.f90:342-346)
   S_DDX, S_DDY,                                                                 // position inside the cell (interpol_all.f90:57-58); p1..p4 follow from it
   S_DX, S_DY, S_DAW, S_DCW,                                                     // dxsave, dysave, dawsave, dcwsave
-  S_ZT0, S_W,                                                                   // height at the start of the pass (u, v follow from it and the cached levels); interpol_mod w
   S_UP, S_VP,                                                                   // turbulent velocities along/across wind
   S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; wst^3 * the transition of cbl.f90:79-81
   S_RHOAUX,                                                                     // per-pass invariant of the fine loop: rhograd/rhoa
@@ -891,31 +947,8 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     T.isigw = in2 * qn;
     T.tlw = K(0.5) * z * in2;
   } else if (I.regime == 1) {
-    // zeta**0.66666 and max(zeta,1.e-3)**(-.33333) from one logarithm and one exponential:
-    // 0.66666 = 1 - 0.33333 - 1.e-5, so zeta**0.66666 = zeta * zeta**(-.33333) * exp(-1.e-5*log(zeta)),
-    // the last factor by its cubic Taylor polynomial (|1.e-5*log zeta| < 1e-3: remainder < 1e-17)
     R z23, zm13;
-    if (sizeof(R) == 8) {
-      // zeta**(-.33333) = zeta**(-1/3) * exp(+(1/3 - .33333)*log zeta) and zeta**0.66666 = zeta * zeta**(-.33333) * exp(-1.e-5*log zeta)
-      // (0.66666 = 1 - 0.33333 - 1.e-5): the cube root by Newton steps from an f32 seed, the two tiny exponents through
-      // their cubic Taylor polynomials (|d| < 3e-4: remainder < 1e-15) with a logarithm that is only good to 1e-13 ABSOLUTE
-      // (m_log_abs) -- a relative 1e-18 in the factors.  39 instructions where one m_logp and one m_expp took 68.
-      const bool tiny = !(T.zeta > K(1.e-37));                 // 0 and what the f32 seed cannot hold: handled below
-      const R zc = tiny ? K(1.) : T.zeta;
-      const R lz = S.logabs(zc);
-      const R r13 = m_rcbrt(zc);
-      const R d1 = ((K(1.) / K(3.)) - K(.33333)) * lz;
-      const R e13 = r13 * (K(1.) + d1 * (K(1.) + d1 * (K(0.5) + d1 * K(0.16666666666666666))));
-      const R d = ((K(1.) - K(.33333)) - K(0.66666)) * lz;       // 1.e-5 * log(zeta)
-      const R corr = K(1.) - d * (K(1.) - d * (K(0.5) - d * K(0.16666666666666666)));
-      // zeta < 1e-37: zeta**0.66666 < 3e-25 is below the rounding of the ust**2 term (ust >= 1e-4) of sigw
-      z23 = tiny ? K(0.) : T.zeta * e13 * corr;
-      zm13 = T.zeta > K(1.e-3) ? e13 : K(9.9997697441416293);   // (1.e-3)**(-.33333)
-    } else {   // reference typing: x**y as exp(y*log x) in f32 (a few ulp from powf, at a third of its cost)
-      const R lz = m_logp(T.zeta);
-      z23 = T.zeta > K(0.) ? m_expp(K(0.66666) * lz) : K(0.);
-      zm13 = m_expp(K(-.33333) * (T.zeta > K(1.e-3) ? lz : m_logp(K(1.e-3))));
-    }
+    zeta_powers(T.zeta, S, z23, zm13);
     const R ust = S.get(S_UST), wst = S.get(S_WST);
     const R ust2 = ust * ust, wst2 = wst * wst;
     T.sigw = m_sqrtp(K(1.2) * wst2 * (K(1.) - K(.9) * T.zeta) * z23 + (K(1.8) - K(1.4) * T.zeta) * ust2) + K(1.e-2);
@@ -1723,7 +1756,6 @@ struct LoopCtx {                // register-resident state of a lane across pass
   int ngrid, ix, jy, ixp, jyp;  // interpol_mod ix..jyp, ngrid
   R h;
   int itimec, nrand;
-  int ilo;                      // level index of the *lo profile level in the stash (the last pass's pair)
   int nsp;                      // species of the settling pick (aerosol kernels only)
 };
 
@@ -1743,27 +1775,51 @@ FPX_DEV Cell<R> stash_cell(const LoopCtx<R> &L, const Stash<R> &S) {
 // neighbouring pair) was built first and measured slower than recomputing: a lane crosses a level in ~20 % of
 // its passes, so nearly every pass of a wave ran the miss path anyway, with a fifth of its lanes active.
 template <typename R>
-FPX_DEV void fetch_levels_stash(const View<R> &V, const Fld<R> &F, const TimeW<R> &W, LoopCtx<R> &L, const Stash<R> &S, int indz) {
-  const Cell<R> C = stash_cell(L, S);
-  Level<R> Lv;
-  level_profile<R, true, true, false>(V, F, C, W, indz, Lv);
-  S.put(S_ULO, Lv.u); S.put(S_VLO, Lv.v); S.put(S_WLO, Lv.w); S.put(S_RHOLO, Lv.rho); S.put(S_RGLO, Lv.rhograd);
-  level_profile<R, true, true, false>(V, F, C, W, indz + 1, Lv);
-  S.put(S_UHI, Lv.u); S.put(S_VHI, Lv.v); S.put(S_WHI, Lv.w); S.put(S_RHOHI, Lv.rho); S.put(S_RGHI, Lv.rhograd);
-  L.ilo = indz;   // pass_wind() needs the level pair of the last pass
-}
-
-// interpol_mod u, v of the pass that just ended (advance.f90:342-346), from the pass's start height
-// and the two cached levels -- the same expressions pbl_pass evaluates, so the same bits
-template <typename R>
-FPX_DEV void pass_wind(const R *hgt, const LoopCtx<R> &L, const Stash<R> &S, R &u, R &v) {
-  const int indz = L.ilo, indzp = indz + 1;
-  const R zt0 = S.get(S_ZT0);
-  const R dz = m_rcp(hgt[indzp - 1] - hgt[indz - 1]);
-  const R dz1 = (zt0 - hgt[indz - 1]) * dz;
-  const R dz2 = (hgt[indzp - 1] - zt0) * dz;
-  u = dz1 * S.get(S_UHI) + dz2 * S.get(S_ULO);
-  v = dz1 * S.get(S_VHI) + dz2 * S.get(S_VLO);
+FPX_DEV void fetch_level_pair(const View<R> &V, const Fld<R> &F, const TimeW<R> &W, const LoopCtx<R> &L, const Stash<R> &S, int indz, R (&lv)[2][5] /* [lo|hi][u v w rho rhograd] */) {
+  // Both levels of the pair at once: with z fastest in the packs the 2 levels x 2 slots of a corner column are ONE run of
+  // 12 (u, v, w) and one of 8 (rho, drhodz) values, so a corner costs one address (32-bit cell index, one 64-bit scale per
+  // pack) instead of eight; the horizontal sums p1*y(ix,jy) + p2*y(ixp,jy) + p3*y(ix,jyp) + p4*y(ixp,jyp) are taken corner
+  // by corner in the reference's left-to-right order (interpol_all.f90:147-187), 20 running sums live.
+  const R ddx = S.get(S_DDX), ddy = S.get(S_DDY);          // as cell_setup, interpol_all.f90:59-64
+  const R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
+  R a3[2][2][3], a2[2][2][2];                               // [level][physical slot][variable]
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const int jyc = (c & 2) ? L.jyp : L.jy, ixc = (c & 1) ? L.ixp : L.ix;
+    const R pw = c == 0 ? rddx * rddy : c == 1 ? ddx * rddy : c == 2 ? rddx * ddy : ddx * ddy;
+    const unsigned int cell = (unsigned int)(jyc * F.nx + ixc) * (unsigned int)V.nz + (unsigned int)(indz - 1);   // < nx*ny*nz
+    const R *p = F.w3 + (size_t)cell * 6;
+    const R *q = F.r2 + (size_t)cell * 4;
+#pragma unroll
+    for (int lev = 0; lev < 2; lev++) {
+#pragma unroll
+      for (int sl = 0; sl < 2; sl++) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const R x = p[(lev * 2 + sl) * 3 + k];
+          a3[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a3[lev][sl][k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+          const R x = q[(lev * 2 + sl) * 2 + k];
+          a2[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a2[lev][sl][k]);
+        }
+      }
+    }
+  }
+  const bool h1 = V.m1 != 0, h2 = V.m2 != 0;               // wave-uniform: physical slot of memind(1) / memind(2)
+#pragma unroll
+  for (int lev = 0; lev < 2; lev++) {
+    R y[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+      const R y1 = k < 3 ? (h1 ? a3[lev][1][k] : a3[lev][0][k]) : (h1 ? a2[lev][1][k - 3] : a2[lev][0][k - 3]);
+      const R y2 = k < 3 ? (h2 ? a3[lev][1][k] : a3[lev][0][k]) : (h2 ? a2[lev][1][k - 3] : a2[lev][0][k - 3]);
+      y[k] = (y1 * W.dt2 + y2 * W.dt1) * W.dtt;           // interpol_all.f90:189-198
+    }
+#pragma unroll
+    for (int k = 0; k < 5; k++) lv[lev][k] = y[k];
+  }
 }
 
 template <int T>
@@ -1798,7 +1854,8 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   const int indz = find_level(hgt, V.nz, zt);
   const int indzp = indz + 1;
   indz_last = indz;
-  fetch_levels_stash(V, F, W, A, S, indz);
+  R lv[2][5];
+  fetch_level_pair(V, F, W, A, S, indz, lv);
 
   // advance.f90:342-350
   const R dz = m_rcp(hgt[indzp - 1] - hgt[indz - 1]);
@@ -1807,20 +1864,20 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   {
     // grid-scale wind of this pass and its contribution to the displacement sums (advance.f90:539-540;
     // the sums do not depend on the fine loop, so they are taken here and stay out of registers)
-    const R u = dz1 * S.get(S_UHI) + dz2 * S.get(S_ULO);
-    const R v = dz1 * S.get(S_VHI) + dz2 * S.get(S_VLO);
-    S.put(S_ZT0, zt);          // pass_wind() recomputes u, v from it when the particle leaves the loop
-    S.put(S_W, dz1 * S.get(S_WHI) + dz2 * S.get(S_WLO));
+    const R u = dz1 * lv[1][0] + dz2 * lv[0][0];
+    const R v = dz1 * lv[1][1] + dz2 * lv[0][1];
+    S.put(S_U, u); S.put(S_V, v);      // handed over with the particle when it leaves the loop
+    S.put(S_W, dz1 * lv[1][2] + dz2 * lv[0][2]);
     S.add(S_DX, u * dt);
     S.add(S_DY, v * dt);
   }
   {
-    const R rhoa = dz1 * S.get(S_RHOHI) + dz2 * S.get(S_RHOLO);
-    const R rhograd = dz1 * S.get(S_RGHI) + dz2 * S.get(S_RGLO);
+    const R rhoa = dz1 * lv[1][3] + dz2 * lv[0][3];
+    const R rhograd = dz1 * lv[1][4] + dz2 * lv[0][4];
     S.put(S_RHOAUX, rhograd * m_rcp(rhoa));
   }
 
-  if (turbswitch) hanna(T, zt); else hanna1(T, zt);
+  if (turbswitch) hanna(T, zt, S); else hanna1(T, zt);
   S.put(S_UST, T.ust);   // hanna may floor ust at 1.e-4 (hanna.f90:43) and the module variable keeps it
   T.isigw = m_rcp(T.sigw);
 
@@ -1836,13 +1893,13 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     if (dttlu < K(.5)) {
       up = (K(1.) - dttlu) * up + g1 * T.sigu * m_sqrtp(K(2.) * dttlu);
     } else {
-      R ru = m_expp(-dttlu);
+      R ru = S.expt(-dttlu);
       up = ru * up + g1 * T.sigu * m_sqrtp(K(1.) - ru * ru);
     }
     if (dttlv < K(.5)) {
       vp = (K(1.) - dttlv) * vp + g2 * T.sigv * m_sqrtp(K(2.) * dttlv);
     } else {
-      R rv = m_expp(-dttlv);
+      R rv = S.expt(-dttlv);
       vp = rv * vp + g2 * T.sigv * m_sqrtp(K(1.) - rv * rv);
     }
     S.put(S_UP, up); S.put(S_VP, vp);
@@ -1901,7 +1958,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
         }
       } else {
         FPX_LANES(st, 4);
-        R rw = m_expp(-dtftlw);
+        R rw = S.expt(-dtftlw);
         wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw)) * (R)icbt;
         delz = wp * T.sigw * dtf;
       }

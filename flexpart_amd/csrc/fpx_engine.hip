@@ -1106,7 +1106,6 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
             S.put(S_UST, r.v[0]); S.put(S_WST, r.v[1]); S.put(S_OL, r.v[2]);
             S.put(S_TRANS, (r.v[1] * r.v[1] * r.v[1]) * r.v[3]);   // (wst**3)*transition, cbl.f90:103-104
           }
-          A.ilo = -1;
           if (!LEAN && V.drydep) {
 #pragma unroll
             for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
@@ -1132,9 +1131,7 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
           // k_pbl_finish writes the particle arrays from it
           PblRecord<R> r;
           r.v[0] = S.get(S_DX); r.v[1] = S.get(S_DY); r.v[2] = S.get(S_DAW); r.v[3] = S.get(S_DCW);
-          R u, v;
-          pass_wind(hgt, A, S, u, v);
-          r.v[4] = u; r.v[5] = v; r.v[6] = S.get(S_W);
+          r.v[4] = S.get(S_U); r.v[5] = S.get(S_V); r.v[6] = S.get(S_W);
           r.v[7] = zt; r.v[8] = S.get(S_UP); r.v[9] = S.get(S_VP); r.v[10] = wp;
           r.i[0] = A.nrand; r.i[1] = A.itimec; r.i[2] = rc | (indz << 2); r.i[3] = ldt; r.i[4] = icbt;
           Q.rec[s] = r;
@@ -1471,6 +1468,7 @@ struct Engine : EngineBase {
     cfg = *c;
     if (cfg.nz > kMaxNz) return fail(FPX_ERR_ARG, "nz exceeds the engine's level limit (512)");
     if (cfg.nx < 2 || cfg.ny < 2 || cfg.nz < 2) return fail(FPX_ERR_ARG, "grid too small");
+    if ((long long)cfg.nx * cfg.ny * cfg.nz > 0xFFFFFFF0ll) return fail(FPX_ERR_ARG, "grid too large: nx*ny*nz must fit 32 bits (the kernels index grid cells with 32-bit integers)");
     if (cfg.nxmax < cfg.nx || cfg.nymax < cfg.ny || cfg.nzmax < cfg.nz) return fail(FPX_ERR_ARG, "allocated extents smaller than used extents");
     if (cfg.nspec < 1 || cfg.nspec > FPX_MAXSPEC || cfg.maxspec < cfg.nspec) return fail(FPX_ERR_ARG, "bad nspec/maxspec");
     if (cfg.max_particles < 1 || cfg.max_particles > 0xFFFFFFF0ll) return fail(FPX_ERR_ARG, "bad max_particles");
@@ -4178,6 +4176,7 @@ struct Engine : EngineBase {
     int rc;
     for (int l = 0; l < n->numbnests; l++) {
       if (n->nxn[l] < 2 || n->nyn[l] < 2 || n->nxn[l] > n->nxmaxn || n->nyn[l] > n->nymaxn) return fail(FPX_ERR_ARG, "nests_init: bad nest extents");
+      if ((long long)n->nxn[l] * n->nyn[l] * cfg.nz > 0xFFFFFFF0ll) return fail(FPX_ERR_ARG, "nests_init: nest too large: nxn*nyn*nz must fit 32 bits");
       if (!(n->xln[l] >= 0 && n->yln[l] >= 0 && n->xrn[l] <= cfg.nx - 1 && n->yrn[l] <= cfg.ny - 1)) return fail(FPX_ERR_ARG, "nests_init: nest outside the mother grid (gridcheck_nests.f90:381)");
       NestDesc<R> &N = h_nest[l];
       N.nx = n->nxn[l]; N.ny = n->nyn[l];
