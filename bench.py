@@ -209,7 +209,7 @@ def cpu_baseline(args, sc, frac_pbl):
     is serial: no OpenMP, no MPI here).  Falls back to the C oracle when _ref is absent."""
     from flexpart_amd import synthetic as syn
     from oracle import scenario_io as sio
-    n = args.cpu_sample or (200_000 if args.config == 3 else 2_000_000)
+    n = args.cpu_sample or (2_000_000 if args.config == 2 else 200_000)     # about 10-30 s of CPU work either way
     s2 = dict(sc)
     s2["nsteps"] = 2
     nx, ny, nz = (int(v) for v in sc["grid"])

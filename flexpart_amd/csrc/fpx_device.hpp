@@ -2243,22 +2243,35 @@ FPX_DEV float wave_sum(float v) {
   return v;
 }
 
-// Add val to base[idx] for the lanes with valid set.  Must be called by the whole wave.
-// After a locality sort the lanes of a wave mostly target the same cell (a point release puts
-// *all* particles into a handful of cells): then the wave is reduced in registers and issues
-// one atomic instead of 64 colliding ones.
+// Add val to base[idx] for the lanes with valid set -- one atomic per RUN of neighbouring lanes that target the same
+// element.  After a locality sort the slots of a wave are ordered by met-grid cell, so lanes that hit the same output cell
+// sit next to each other (a 2-D deposition cell collects a whole column of particles, a point release puts everything
+// into a handful of cells): their contributions are summed in registers with a segmented reduction over the wave
+// (six shuffle steps) and the first lane of every run issues the atomic -- instead of up to 64 atomics colliding on one
+// address in L2.  May be called from divergent code: lanes that are not executing split the runs.
 template <typename T>
-FPX_DEV void wave_scatter_add(T *base, long long idx, T val, bool valid) {
-  const unsigned long long m = __ballot(valid);
-  if (m == 0ull) return;
-  const int first = __ffsll((long long)m) - 1;
-  const long long idx0 = __shfl(idx, first);
-  if (__all(!valid || idx == idx0)) {
-    T v = wave_sum(valid ? val : (T)0);
-    if ((int)(threadIdx.x & 63) == first) atomicAdd(base + idx0, v);
-  } else if (valid) {
-    atomicAdd(base + idx, val);
+FPX_DEV void wave_run_add(T *base, long long idx, T val, bool valid) {
+  const unsigned long long vm = __ballot(valid);
+  if (vm == 0ull) return;                                   // nothing to add in this wave
+  const int lane = (int)(threadIdx.x & 63);
+  if (__popcll(vm) <= 2) {                                  // not worth the shuffles
+    if (valid) atomicAdd(base + idx, val);
+    return;
   }
+  const unsigned long long act = __ballot(1);               // the lanes that execute this call
+  const long long key = valid ? idx : (long long)(-1 - lane);   // a lane without a contribution is a run of its own
+  const long long pkey = __shfl_up(key, 1);
+  const bool head = lane == 0 || !((act >> (lane - 1)) & 1ull) || pkey != key;
+  const unsigned long long hm = __ballot(head);
+  const int rid = __popcll(hm & (~0ull >> (63 - lane)));    // number of the run this lane belongs to
+  T v = valid ? val : (T)0;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const T v2 = __shfl_down(v, o);
+    const int r2 = __shfl_down(rid, o);
+    if (lane + o < 64 && ((act >> ((lane + o) & 63)) & 1ull) && r2 == rid) v += v2;
+  }
+  if (head && valid) atomicAdd(base + idx, v);
 }
 
 // Guard without a counterpart in the reference: a particle older than lage(nageclass) (nage = nageclass+1 after the
@@ -2327,10 +2340,10 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
       // the base is wave-uniform, the whole (cell, level, species, point, class, age) offset is the per-lane index:
       // lanes are merged into one atomic only when all of it agrees
       const long long o = off + sstride * ks;
-      wave_scatter_add<R>(G.grid, o + (long long)jy * G.numx + ix, direct ? m : m * (wx * wy), inside && okx && oky);
-      wave_scatter_add<R>(G.grid, o + (long long)jyp * G.numx + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
-      wave_scatter_add<R>(G.grid, o + (long long)jyp * G.numx + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
-      wave_scatter_add<R>(G.grid, o + (long long)jy * G.numx + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
+      wave_run_add<R>(G.grid, o + (long long)jy * G.numx + ix, direct ? m : m * (wx * wy), inside && okx && oky);
+      wave_run_add<R>(G.grid, o + (long long)jyp * G.numx + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
+      wave_run_add<R>(G.grid, o + (long long)jyp * G.numx + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
+      wave_run_add<R>(G.grid, o + (long long)jy * G.numx + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
     }
   }
   // concentrations at receptor points, parabolic kernel: conccalc.f90:451-498.  The reference sums the
@@ -2351,15 +2364,15 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
     const R xkern = factor * (K(1.) - r2);
     const R area = Gp.receptor[2 * Gp.numreceptor + n];
     for (int ks = 0; ks < V.nspec; ks++)
-      wave_scatter_add<R>(Gp.creceptor, (long long)ks * Gp.numreceptor + n, hit ? K(2.) * weight * (xmass[ks] * xkern / h) / area : K(0.), hit);
+      wave_run_add<R>(Gp.creceptor, (long long)ks * Gp.numreceptor + n, hit ? K(2.) * weight * (xmass[ks] * xkern / h) / area : K(0.), hit);
   }
 }
 
 // drydepokernel.f90:41-116 for one species (deposit already in dep_prec = float)
 template <typename R>
 FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp0, int nunc, float deposit, int ks, R x, R y, int nage, int kp, bool nest = false) {
-  if (!(fabsf(deposit) > 0.f)) return;
-  if (!grid_planes_ok(Gp0, nage, nunc, kp)) return;
+  // every lane that reaches the call takes part in the run-merged adds (wave_run_add); `on` says whether it contributes
+  const bool on = fabsf(deposit) > 0.f && grid_planes_ok(Gp0, nage, nunc, kp);
   // the nested variant (drydepokernel_nest.f90:38-100) always uses the kernel
   struct { int numxgrid, numygrid, maxspec, maxpointspec_act, nclassunc, lusekerneloutput; R dxout, dyout, xoutshift, youtshift; float *drygridunc; } Gp;
   {
@@ -2377,17 +2390,17 @@ FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp0, int nunc, f
   if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
   if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
   const long long plane = (long long)Gp.numxgrid * Gp.numygrid;
-  float *g = Gp.drygridunc + plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1))));
+  const long long g = on ? plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1)))) : 0;
   const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
   const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
-  if (!Gp.lusekerneloutput) {
-    if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, deposit);
+  if (!Gp.lusekerneloutput) {   // wave-uniform
+    wave_run_add<float>(Gp.drygridunc, g + (long long)jy * Gp.numxgrid + ix, deposit, on && okx && oky);
     return;
   }
-  if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, (float)((R)deposit * (wx * wy)));
-  if (okxp && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * (K(1.) - wy))));
-  if (okxp && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * wy)));
-  if (okx && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ix, (float)((R)deposit * (wx * (K(1.) - wy))));
+  wave_run_add<float>(Gp.drygridunc, g + (long long)jy * Gp.numxgrid + ix, (float)((R)deposit * (wx * wy)), on && okx && oky);
+  wave_run_add<float>(Gp.drygridunc, g + (long long)jyp * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * (K(1.) - wy))), on && okxp && okyp);
+  wave_run_add<float>(Gp.drygridunc, g + (long long)jy * Gp.numxgrid + ixp, (float)((R)deposit * ((K(1.) - wx) * wy)), on && okxp && oky);
+  wave_run_add<float>(Gp.drygridunc, g + (long long)jyp * Gp.numxgrid + ix, (float)((R)deposit * (wx * (K(1.) - wy))), on && okx && okyp);
 }
 
 // ---------------------------------------------------------------------------
@@ -2519,7 +2532,8 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
 // wetdepokernel.f90:38-108 for one species (deposit is a default real, the grid is dep_prec)
 template <typename R>
 FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp0, int nunc, R deposit, int ks, R x, R y, int nage, int kp, bool nest = false) {
-  if (!grid_planes_ok(Gp0, nage, nunc, kp)) return;
+  // every lane that reaches the call takes part in the run-merged adds (wave_run_add); adding zero changes nothing
+  const bool on = grid_planes_ok(Gp0, nage, nunc, kp) && deposit != K(0.);
   // the nested variant (wetdepokernel_nest.f90:38-107) always uses the kernel and truncates with floor()
   struct { int numxgrid, numygrid, maxspec, maxpointspec_act, nclassunc, lusekerneloutput; R dxout, dyout, xoutshift, youtshift; float *wetgridunc; } Gp;
   {
@@ -2537,18 +2551,17 @@ FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp0, int nunc, R 
   if (ddx > K(0.5)) { ixp = ix + 1; wx = K(1.5) - ddx; } else { ixp = ix - 1; wx = K(0.5) + ddx; }
   if (ddy > K(0.5)) { jyp = jy + 1; wy = K(1.5) - ddy; } else { jyp = jy - 1; wy = K(0.5) + ddy; }
   const long long plane = (long long)Gp.numxgrid * Gp.numygrid;
-  float *g = Gp.wetgridunc + plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1))));
+  const long long g = on ? plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1)))) : 0;
   const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
   const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
-  if (deposit == K(0.)) return;   // adding zero changes nothing
-  if (!Gp.lusekerneloutput) {
-    if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, (float)deposit);
+  if (!Gp.lusekerneloutput) {   // wave-uniform
+    wave_run_add<float>(Gp.wetgridunc, g + (long long)jy * Gp.numxgrid + ix, (float)deposit, on && okx && oky);
     return;
   }
-  if (okx && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ix, (float)(deposit * (wx * wy)));
-  if (okxp && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * (K(1.) - wy))));
-  if (okxp && oky) atomicAdd(g + (long long)jy * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * wy)));
-  if (okx && okyp) atomicAdd(g + (long long)jyp * Gp.numxgrid + ix, (float)(deposit * (wx * (K(1.) - wy))));
+  wave_run_add<float>(Gp.wetgridunc, g + (long long)jy * Gp.numxgrid + ix, (float)(deposit * (wx * wy)), on && okx && oky);
+  wave_run_add<float>(Gp.wetgridunc, g + (long long)jyp * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * (K(1.) - wy))), on && okxp && okyp);
+  wave_run_add<float>(Gp.wetgridunc, g + (long long)jy * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * wy)), on && okxp && oky);
+  wave_run_add<float>(Gp.wetgridunc, g + (long long)jyp * Gp.numxgrid + ix, (float)(deposit * (wx * (K(1.) - wy))), on && okx && okyp);
 }
 
 #undef K
