@@ -41,7 +41,8 @@ class FpxConfig(C.Structure):
         ("decay", C.c_double * FPX_MAXSPEC),
         ("mquasilag", C.c_int32), ("lage_last", C.c_int32),
         ("rng_mode", C.c_int32), ("seed", C.c_uint64),
-        ("sort_interval", C.c_int32), ("par_nxmax", C.c_int32), ("particle_base", C.c_int64), ("reserved", C.c_int32 * 4),
+        ("sort_interval", C.c_int32), ("par_nxmax", C.c_int32), ("particle_base", C.c_int64),
+        ("drybkdep", C.c_int32), ("wetbkdep", C.c_int32), ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -111,7 +112,7 @@ class FpxParticles(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws",
                  "itra1", "itramem", "idt", "npoint", "nclass", "cbt", "xmass1")] + \
-               [("xmass1_ld", C.c_int64), ("itrasplit", C.c_void_p)]
+               [("xmass1_ld", C.c_int64), ("itrasplit", C.c_void_p), ("xscav_frac1", C.c_void_p)]
 
 
 class FpxRelease(C.Structure):
@@ -170,7 +171,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 SYMBOLS = [
     "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_polar_maps", "fpx_set_height",
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
-    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points", "fpx_release_init", "fpx_releaseparticles", "fpx_split_particles",
+    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points", "fpx_set_release_heights", "fpx_release_init", "fpx_releaseparticles", "fpx_split_particles",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_count_particles", "fpx_lane_stats", "fpx_wet_init", "fpx_upload_wet_fields",
@@ -266,6 +267,7 @@ def load():
     lib.fpx_wetdepo.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32]
     lib.fpx_get_wetgrid.argtypes = [vp, vp, C.c_int32]
     lib.fpx_comm_init_host.argtypes = [vp, C.c_int32, C.c_int32, ALLREDUCE_FN, vp]
+    lib.fpx_set_release_heights.argtypes = [vp, C.c_int32, vp, vp]
     lib.fpx_count_particles.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
     lib.fpx_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32, C.c_int32]
     _lib = lib

@@ -448,6 +448,7 @@ struct Parts {
   int *itrasplit;        // com_mod.f90:683 (release + splitting on the device)
   short *cbt;
   R *xmass1;             // [nspec][cap]
+  R *xscav;              // [nspec][cap] xscav_frac1 (com_mod.f90:683,712), only in backward runs with DRYBKDEP / WETBKDEP; else null
   unsigned int *pid;     // reference particle number - 1 (stable across locality sorts)
   long long cap;
 };
@@ -2285,7 +2286,7 @@ FPX_DEV bool grid_planes_ok(const GridP<R> &Gp, int nage, int nclass, int kp) {
 // conccalc.f90:50-295 for one particle (active == this lane holds a particle that is due)
 template <typename R>
 FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hgt, bool active, double xt, double yt, R zt,
-                               int itage, int npoint, int nclass, const R *xmass, R weight) {
+                               int itage, int npoint, int nclass, const R *xmass, R weight, const R *scav = nullptr /* max(xscav_frac1, 0) per species, or null */) {
   const int nage = ageclass(Gp, itage);
   const bool planes_ok = grid_planes_ok(Gp, nage, nclass, (Gp.ioutputforeachrelease == 0 || V.mdomainfill == 1) ? 1 : npoint);
   R rhoi = K(1.);
@@ -2336,7 +2337,8 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
     // offset of (.., kz, ks=1, nrelpointer, nclass, nage)
     const long long off = plane * (kz - 1) + sstride * ((long long)Gp.maxspec * ((nrelpointer - 1) + (long long)Gp.maxpointspec_act * ((nclass - 1) + (long long)Gp.nclassunc * (nage - 1))));
     for (int ks = 0; ks < V.nspec; ks++) {
-      const R m = active ? xmass[ks] / rhoi * weight : K(0.);
+      R m = active ? xmass[ks] / rhoi * weight : K(0.);
+      if (scav) m = m * scav[ks];      // DRYBKDEP / WETBKDEP: conccalc.f90:177-181,226-230, ...
       // the base is wave-uniform, the whole (cell, level, species, point, class, age) offset is the per-lane index:
       // lanes are merged into one atomic only when all of it agrees
       const long long o = off + sstride * ks;

@@ -184,6 +184,7 @@ __global__ void k_permute(Parts<R> A, Parts<R> B, const unsigned int *__restrict
     B.npoint[i] = A.npoint[j]; B.nclass[i] = A.nclass[j]; B.cbt[i] = A.cbt[j]; B.itrasplit[i] = A.itrasplit[j];
     B.pid[i] = A.pid[j];
     for (int ks = 0; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
+    if (A.xscav) for (int ks = 0; ks < nspec; ks++) B.xscav[(size_t)ks * B.cap + i] = A.xscav[(size_t)ks * A.cap + j];
   }
 }
 
@@ -247,6 +248,7 @@ __global__ void k_permute_unpack(const SortRecord<R> *__restrict__ rec, Parts<R>
   B.idt[i] = r.i[0]; B.itra1[i] = r.i[1]; B.itramem[i] = r.i[2]; B.npoint[i] = r.i[3]; B.nclass[i] = r.i[4]; B.itrasplit[i] = r.i[5];
   B.pid[i] = r.pid; B.cbt[i] = (short)r.cbt;
   for (int ks = 1; ks < nspec; ks++) B.xmass1[(size_t)ks * B.cap + i] = A.xmass1[(size_t)ks * A.cap + j];
+  if (A.xscav) for (int ks = 0; ks < nspec; ks++) B.xscav[(size_t)ks * B.cap + i] = A.xscav[(size_t)ks * A.cap + j];
 }
 // number of neighbours in the new order whose sources lie more than `window` storage spaces apart
 __global__ void k_perm_disorder(const unsigned int *__restrict__ perm, long long n, unsigned int window, unsigned long long *__restrict__ count) {
@@ -308,6 +310,7 @@ __global__ void k_seed(View<R> V, Parts<R> P, long long n, unsigned long long se
   P.idt[i] = 0; P.itra1[i] = itime0; P.itramem[i] = itime0; P.npoint[i] = 1; P.nclass[i] = 1; P.itrasplit[i] = V.ldirect * 999999999;   // "never", signed like itra1 + ldirect*itsplit (releaseparticles.f90:181)
   P.cbt[i] = 1; P.pid[i] = (unsigned int)i;
   for (int ks = 0; ks < V.nspec; ks++) P.xmass1[(size_t)ks * P.cap + i] = (R)1;
+  if (P.xscav) for (int ks = 0; ks < V.nspec; ks++) P.xscav[(size_t)ks * P.cap + i] = (R)-1;
   }
 }
 
@@ -823,6 +826,7 @@ __global__ void __launch_bounds__(kBlock) k_release(View<R> V, Parts<R> P, DiagP
     H m = RP.mass[(size_t)ks * RP.numpoint + i];
     if (dens) m = m * rhoout;
     P.xmass1[(size_t)ks * P.cap + s] = (R)m;
+    if (P.xscav) P.xscav[(size_t)ks * P.cap + s] = (R)-1;      // releaseparticles.f90:167-171: not yet scavenged
   }
   P.xt[s] = xt; P.yt[s] = yt; P.zt[s] = (R)zt;
   P.nclass[s] = nc;
@@ -867,6 +871,7 @@ __global__ void k_split(Parts<R> P, const unsigned int *__restrict__ slot_of_pid
     const R m = P.xmass1[(size_t)ks * P.cap + j] / (R)2;
     P.xmass1[(size_t)ks * P.cap + j] = m;
     P.xmass1[(size_t)ks * P.cap + n] = m;
+    if (P.xscav) P.xscav[(size_t)ks * P.cap + n] = P.xscav[(size_t)ks * P.cap + j];   // the copy inherits the receptor's scavenged fraction
   }
 }
 
@@ -906,6 +911,7 @@ __global__ void __launch_bounds__(kBlock) k_readpart(Parts<R> P, const unsigned 
   P.cbt[i] = 1; P.pid[i] = (unsigned int)i;
   const unsigned int *x = w + 3 + 3 * hw + 7 * hw;
   for (int ks = 0; ks < nspec; ks++) P.xmass1[(size_t)ks * P.cap + i] = (R)get(x + ks * hw);
+  if (P.xscav) for (int ks = 0; ks < nspec; ks++) P.xscav[(size_t)ks * P.cap + i] = (R)-1;   // as after a release; the dump does not carry it
 }
 
 // ---------------------------------------------------------------------------
@@ -1244,7 +1250,83 @@ __global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V, GridP<R> Gp, Par
       if (ks < V.nspec) xm[ks] = P.xmass1[(size_t)ks * P.cap + s];
     if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) active = false;
   }
-  conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight);
+  if (P.xscav) {   // wave-uniform: DRYBKDEP / WETBKDEP
+    R sc[kMaxSpec];
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++) sc[ks] = (active && ks < V.nspec) ? m_max(P.xscav[(size_t)ks * P.cap + s], (R)0) : (R)0;
+    conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight, sc);
+  } else {
+    conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight);
+  }
+}
+
+// The receptor block of timemanager.f90:564-598 (backward runs with DRYBKDEP / WETBKDEP): once per particle, before it is
+// moved for the first time -- xscav_frac1 < 0 marks a particle that has not been through it (releaseparticles.f90:167-171).
+// get_vdep_prob.f90 sets the cell (the nest's inside a nest) but not the weights p1..p4, dt1, dt2, dtt that
+// interpol_vdep[_nests] reads: those are the ones initialize() of the same particle left in interpol_mod, i.e. the
+// mother grid's weights at the particle's position and the step's time weights -- computed here from the position.
+template <typename R>
+__global__ void __launch_bounds__(kBlock) k_bkdep(View<R> V, WetP<R> Wp, Parts<R> P, long long numpart, int itime, int drybkdep, int wetbkdep,
+                                                  const R *__restrict__ zspan /* [numpoint] zpoint2 - zpoint1 */) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= numpart) return;
+  if (P.itra1[s] != itime) return;
+  bool todo = false;
+  for (int ks = 0; ks < V.nspec; ks++) todo = todo || P.xscav[(size_t)ks * P.cap + s] < (R)0;
+  if (!todo) return;
+  const double xt = P.xt[s], yt = P.yt[s];
+  const R zt = P.zt[s];
+  if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) return;   // k_prep terminates it
+  if (drybkdep) {
+    const R href = (R)15.;
+    // get_vdep_prob.f90:52-99
+    const int ngrid = pick_grid<R, false>(V, xt, yt);
+    int ix, jy;
+    if (ngrid > 0) {
+      const NestDesc<R> &N = V.nest[ngrid - 1];
+      ix = (int)(R)((xt - (double)N.xl) * (double)N.xres);
+      jy = (int)(R)((yt - (double)N.yl) * (double)N.yres);
+    } else {
+      ix = (int)xt; jy = (int)yt;
+    }
+    Cell<R> C;
+    cell_setup(C, ix, jy, ix + 1, jy + 1, (R)xt, (R)yt);
+    {   // the weights of initialize(): ddx = real(xt) - real(int(xt)) on the mother grid
+      const int ixm = (int)xt, jym = (int)yt;
+      const R ddx = (R)xt - (R)ixm, ddy = (R)yt - (R)jym, rddx = (R)1 - ddx, rddy = (R)1 - ddy;
+      C.p1 = rddx * rddy; C.p2 = ddx * rddy; C.p3 = rddx * ddy; C.p4 = ddx * ddy;
+    }
+    const Fld<R> F = fld_of(V, ngrid);
+    const TimeW<R> W = time_weights(V, itime);
+    for (int ks = 0; ks < V.nspec; ks++) {
+      if (!(P.xscav[(size_t)ks * P.cap + s] < (R)0)) continue;
+      if (V.drydepspec[ks]) {
+        R prob = (R)0;
+        if (V.drydep && zt < (R)2. * href) prob = interp_vdep(V, F, C, W, ks);   // :105-127: the deposition velocity itself
+        P.xscav[(size_t)ks * P.cap + s] = prob;
+      } else {
+        P.xmass1[(size_t)ks * P.cap + s] = (R)0;
+        P.xscav[(size_t)ks * P.cap + s] = (R)0;
+      }
+    }
+  }
+  if (wetbkdep) {
+    const int np = release_index(V, P.npoint[s]);
+    for (int ks = 0; ks < V.nspec; ks++) {
+      if (!(P.xscav[(size_t)ks * P.cap + s] < (R)0)) continue;
+      R grfr = (R)0;
+      const R wetscav = get_wetscav(V, Wp, hgt, itime, V.lsynctime, xt, yt, zt, ks, grfr);
+      if (wetscav > (R)0) {
+        P.xscav[(size_t)ks * P.cap + s] = wetscav * zspan[np] * grfr;
+      } else {
+        P.xmass1[(size_t)ks * P.cap + s] = (R)0;
+        P.xscav[(size_t)ks * P.cap + s] = (R)0;
+      }
+    }
+  }
 }
 
 // wetdepo.f90:58-151: every live particle that is due or overdue
@@ -1311,6 +1393,7 @@ struct EngineBase {
   virtual int download_particles(long long first, long long count, const fpx_particles *p) = 0;
   virtual int set_numpart(long long n) = 0;
   virtual int set_release_points(int numpoint, const void *xmass, const int32_t *npart) = 0;
+  virtual int set_release_heights(int numpoint, const void *zpoint1, const void *zpoint2) = 0;
   virtual int release_init(const fpx_release *r) = 0;
   virtual int releaseparticles(int itime, int64_t *numpart, int32_t *numparticlecount, void *xmasssave, void *rho_rel, int64_t *nreleased) = 0;
   virtual int split_particles(int itime, int64_t *numpart) = 0;
@@ -1542,6 +1625,13 @@ struct Engine : EngineBase {
     for (auto q : is) if ((rc = dalloc(q, cap))) return rc;
     if ((rc = dalloc(&P.cbt, cap))) return rc;
     if ((rc = dalloc(&P.xmass1, cap * cfg.nspec))) return rc;
+    if (cfg.drybkdep || cfg.wetbkdep) {
+      // backward runs with receptor scavenging (readcommand.f90:320-340): xscav_frac1(maxpart,maxspec), -1 = not yet scavenged
+      if (cfg.ldirect != -1) return fail(FPX_ERR_ARG, "drybkdep / wetbkdep are options of backward runs (ldirect = -1)");
+      if (cfg.drybkdep && cfg.wetbkdep) return fail(FPX_ERR_ARG, "drybkdep and wetbkdep exclude each other (COMMAND ind_receptor 3 or 4)");
+      if ((rc = dalloc(&P.xscav, cap * cfg.nspec))) return rc;
+      k_fill<R><<<(int)((cap * cfg.nspec + kBlock - 1) / kBlock), kBlock, 0, stream>>>(P.xscav, (R)-1, 0, (long long)(cap * cfg.nspec), nullptr);
+    }
     if ((rc = dalloc(&P.pid, cap))) return rc;
     if ((rc = dalloc(&d_pbl_list, cap))) return rc;
     if ((rc = dalloc(&d_pbl_ctr, 2))) return rc;
@@ -2383,6 +2473,10 @@ struct Engine : EngineBase {
     table(r->point_hour, 24, rel.point_hour); table(r->area_hour, 24, rel.area_hour);
     table(r->point_dow, 7, rel.point_dow); table(r->area_dow, 7, rel.area_dow);
     rel.set = true;
+    if (cfg.wetbkdep) {   // the height range of every point, which WETBKDEP needs in the particle loop (timemanager.f90:590-591)
+      int rc = set_release_heights(np, r->zpoint1, r->zpoint2);
+      if (rc) return rc;
+    }
     return 0;
   }
 
@@ -2870,6 +2964,14 @@ struct Engine : EngineBase {
         if ((rc = put_real(src, dst, first, count))) return rc;
       } else if ((rc = fill<R>(dst, (R)1, first, count))) return rc;
     }
+    if (P.xscav)
+      for (int ks = 0; ks < cfg.nspec; ks++) {
+        R *dst = P.xscav + (size_t)ks * P.cap;
+        if (p->xscav_frac1) {
+          const char *src = (const char *)p->xscav_frac1 + (size_t)ks * p->xmass1_ld * cfg.host_real_bytes;
+          if ((rc = put_real(src, dst, first, count))) return rc;
+        } else if ((rc = fill<R>(dst, (R)-1, first, count))) return rc;     // as releaseparticles.f90:167-171 leaves a new particle
+      }
     HIPCHK(hipStreamSynchronize(stream));
     numpart = std::max(numpart, first + count);
     maybe_new = true;
@@ -2900,6 +3002,11 @@ struct Engine : EngineBase {
       for (int ks = 0; ks < cfg.nspec; ks++) {
         char *dst = (char *)p->xmass1 + (size_t)ks * p->xmass1_ld * cfg.host_real_bytes;
         if ((rc = get_real(dst, P.xmass1 + (size_t)ks * P.cap, first, count))) return rc;
+      }
+    if (p->xscav_frac1 && P.xscav)
+      for (int ks = 0; ks < cfg.nspec; ks++) {
+        char *dst = (char *)p->xscav_frac1 + (size_t)ks * p->xmass1_ld * cfg.host_real_bytes;
+        if ((rc = get_real(dst, P.xscav + (size_t)ks * P.cap, first, count))) return rc;
       }
     return 0;
   }
@@ -3345,11 +3452,11 @@ struct Engine : EngineBase {
   void ckpt_describe_grid(CkptHeader &h) const {
     h.nx = cfg.nx; h.ny = cfg.ny; h.nz = cfg.nz; h.maxspec = cfg.maxspec; h.numbnests = V.numbnests;
     for (int l = 0; l < kMaxNests; l++) { h.nxn[l] = l < V.numbnests ? h_nest[l].nx : 0; h.nyn[l] = l < V.numbnests ? h_nest[l].ny : 0; }
-    h.pad = 0;
+    h.pad = P.xscav ? 1 : 0;      // the file carries xscav_frac1 (backward runs with DRYBKDEP / WETBKDEP)
   }
   // file length that goes with a header: header + RNG state + particle arrays + grids + receptors + cbaseflux
   static uint64_t ckpt_total_bytes(const CkptHeader &h) {
-    const uint64_t per_particle = 2 * 8 + 7 * sizeof(R) + 6 * 4 + 2 + (uint64_t)h.nspec * sizeof(R);
+    const uint64_t per_particle = 2 * 8 + 7 * sizeof(R) + 6 * 4 + 2 + (uint64_t)h.nspec * sizeof(R) * (h.pad ? 2 : 1);   // pad = 1: xscav_frac1 follows xmass1
     return sizeof(CkptHeader) + h.rng_bytes + (uint64_t)h.numpart * per_particle + h.n_grid3 * sizeof(R) + 2 * h.n_grid2 * sizeof(float) +
            h.n_grid3n * sizeof(R) + 2 * h.n_grid2n * sizeof(float) + h.n_receptor * sizeof(R) + h.cbase_bytes;
   }
@@ -3445,6 +3552,7 @@ struct Engine : EngineBase {
     for (int *a : {P.idt, P.itra1, P.itramem, P.npoint, P.nclass, P.itrasplit}) if ((rc = ckpt_put_array(fh, a, n, buf))) return rc;
     if ((rc = ckpt_put_array(fh, P.cbt, n, buf))) return rc;
     for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_put_array(fh, P.xmass1 + (size_t)ks * P.cap, n, buf))) return rc;
+    if (P.xscav) for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_put_array(fh, P.xscav + (size_t)ks * P.cap, n, buf))) return rc;
     if (h.n_grid3 && ((rc = ckpt_put_plain(fh, Gp.gridunc, n_grid3, buf)) || (rc = ckpt_put_plain(fh, Gp.drygridunc, n_grid2, buf)) ||
                       (rc = ckpt_put_plain(fh, Gp.wetgridunc, n_grid2, buf)))) return rc;
     if (h.n_grid3n && ((rc = ckpt_put_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_put_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
@@ -3483,6 +3591,7 @@ struct Engine : EngineBase {
       ckpt_describe_grid(mine);
       if (memcmp(&mine.nx, &h.nx, (const char *)&h.pad - (const char *)&h.nx) != 0)
         return fail(FPX_ERR_ARG, "checkpoint_read: written on another grid (nx, ny, nz, maxspec or the nest extents differ)");
+      if (mine.pad != h.pad) return fail(FPX_ERR_ARG, "checkpoint_read: written with (without) DRYBKDEP / WETBKDEP");
       // the whole file must be there before a single array is touched
       if (h.total_bytes != ckpt_total_bytes(h)) return fail(FPX_ERR_ARG, "checkpoint_read: inconsistent header");
       if (fseek(fh, 0, SEEK_END) != 0) return fail(FPX_ERR_ARG, "checkpoint_read: cannot seek");
@@ -3511,6 +3620,7 @@ struct Engine : EngineBase {
     for (int *a : {P.idt, P.itra1, P.itramem, P.npoint, P.nclass, P.itrasplit}) if ((rc = ckpt_get_array(fh, a, n, buf))) return ckpt_invalidate(rc);
     if ((rc = ckpt_get_array(fh, P.cbt, n, buf))) return ckpt_invalidate(rc);
     for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_get_array(fh, P.xmass1 + (size_t)ks * P.cap, n, buf))) return ckpt_invalidate(rc);
+    if (P.xscav) for (int ks = 0; ks < cfg.nspec; ks++) if ((rc = ckpt_get_array(fh, P.xscav + (size_t)ks * P.cap, n, buf))) return ckpt_invalidate(rc);
     if (g3 && ((rc = ckpt_get_plain(fh, Gp.gridunc, n_grid3, buf)) || (rc = ckpt_get_plain(fh, Gp.drygridunc, n_grid2, buf)) ||
                (rc = ckpt_get_plain(fh, Gp.wetgridunc, n_grid2, buf)))) return ckpt_invalidate(rc);
     if (g3n && ((rc = ckpt_get_plain(fh, Gp.griduncn, n_grid3n, buf)) || (rc = ckpt_get_plain(fh, Gp.drygriduncn, n_grid2n, buf)) ||
@@ -3533,6 +3643,21 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // point_mod zpoint1, zpoint2(numpoint): the height range of a release, which WETBKDEP multiplies the scavenging
+  // coefficient with (timemanager.f90:590-591)
+  R *d_zspan = nullptr;
+  int zspan_n = 0;
+  int set_release_heights(int numpoint, const void *zpoint1, const void *zpoint2) override {
+    if (numpoint < 1 || !zpoint1 || !zpoint2) return fail(FPX_ERR_ARG, "set_release_heights: numpoint >= 1, zpoint1 and zpoint2 are required");
+    std::vector<R> z((size_t)numpoint);
+    for (int i = 0; i < numpoint; i++)
+      z[i] = cfg.host_real_bytes == 4 ? (R)(((const float *)zpoint2)[i] - ((const float *)zpoint1)[i]) : (R)(((const double *)zpoint2)[i] - ((const double *)zpoint1)[i]);
+    int rc;
+    if (numpoint > zspan_n) { if ((rc = dalloc(&d_zspan, (size_t)numpoint))) return rc; zspan_n = numpoint; }
+    HIPCHK(hipMemcpyAsync(d_zspan, z.data(), (size_t)numpoint * sizeof(R), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
   // point_mod xmass(numpoint,maxspec), npart(numpoint): device tables indexed by npoint(j)
   int set_release_points(int numpoint, const void *xmass, const int32_t *npart) override {
     if (numpoint < 1 || !xmass || !npart) return fail(FPX_ERR_ARG, "set_release_points: numpoint >= 1, xmass and npart are required");
@@ -3638,6 +3763,9 @@ struct Engine : EngineBase {
     if (!height_set || !window_set || !slot_loaded[0] || !slot_loaded[1]) return fail(FPX_ERR_STATE, "step: height, both field slots and the wind-time window must be set first");
     if (cfg.rng_mode != FPX_RNG_PHILOX && !table_set) return fail(FPX_ERR_STATE, "step: the table RNG modes need fpx_rng_fill_table/fpx_rng_set_table");
     if (V.memtime0 == V.memtime1) return fail(FPX_ERR_STATE, "step: empty wind-time window");
+    if (cfg.wetbkdep && (!wet_on || !wet_slot[0] || !wet_slot[1])) return fail(FPX_ERR_STATE, "step: WETBKDEP needs the wet-deposition set-up (fpx_wet_init, fpx_upload_wet_fields for both slots)");
+    if (cfg.wetbkdep && (!d_zspan || V.numpoint > zspan_n)) return fail(FPX_ERR_STATE, "step: WETBKDEP needs the release heights zpoint1, zpoint2 (fpx_set_release_heights)");
+    if (cfg.drybkdep && !cfg.drydep) return fail(FPX_ERR_STATE, "step: DRYBKDEP without DRYDEP: there is no deposition velocity to take");
     if (V.numpoint == 0 && cfg.mdomainfill == 0 && cfg.mquasilag == 0)
       return fail(FPX_ERR_STATE, "step: the release-point tables xmass, npart are needed for the mass-fraction test (fpx_set_release_points)");
     for (int l = 0; l < V.numbnests; l++)
@@ -3690,6 +3818,10 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
     HIPCHK(hipEventRecord(ev.e[0], stream));
+    if (P.xscav) {   // timemanager.f90:564-598, before the particle is moved
+      k_bkdep<R><<<nb, kBlock, 0, stream>>>(V, Wp, P, numpart, itime, cfg.drybkdep, cfg.wetbkdep, d_zspan);
+      HIPCHK(hipGetLastError());
+    }
     {
       // specialised variants: dry deposition (aerosols), initialize() only when new particles can
       // exist (after an upload/seed or at itime 0), polar maps only on grids with poles
@@ -3818,6 +3950,10 @@ struct Engine : EngineBase {
     for (auto q : is) if ((rc = dalloc(q, cap))) return rc;
     if ((rc = dalloc(&Q.cbt, cap))) return rc;
     if ((rc = dalloc(&Q.xmass1, cap * cfg.nspec))) return rc;
+    if (P.xscav) {
+      if ((rc = dalloc(&Q.xscav, cap * cfg.nspec))) return rc;
+      k_fill<R><<<(int)((cap * cfg.nspec + kBlock - 1) / kBlock), kBlock, 0, stream>>>(Q.xscav, (R)-1, 0, (long long)(cap * cfg.nspec), nullptr);
+    }
     if ((rc = dalloc(&Q.pid, cap))) return rc;
     {   // zeroed like the first set (storage spaces behind numpart keep their contents across the ping-pong)
       R *rz[] = {Q.zt, Q.up, Q.vp, Q.wp, Q.us, Q.vs, Q.ws};
@@ -4453,7 +4589,7 @@ struct fpx_engine {
 
 extern "C" {
 
-int fpx_abi_version(void) { return 2; }
+int fpx_abi_version(void) { return 3; }
 
 int fpx_polar_maps(int32_t host_real_bytes, double dy, double north[9], double south[9]) {
   if (!north || !south || !(dy > 0)) return fpx::fail(FPX_ERR_ARG, "fpx_polar_maps: bad argument");
@@ -4590,6 +4726,7 @@ int fpx_comm_unique_id(void *id, int32_t nbytes) {
   return FPX_OK;
 }
 int fpx_count_particles(fpx_handle h, int64_t local[2], int64_t total[2], int32_t allreduce) { FPX_GUARD(h); return h->impl->count_particles(local, total, allreduce); }
+int fpx_set_release_heights(fpx_handle h, int32_t numpoint, const void *zpoint1, const void *zpoint2) { FPX_GUARD(h); return h->impl->set_release_heights(numpoint, zpoint1, zpoint2); }
 int fpx_lane_stats(fpx_handle h, uint64_t *out, int32_t n, int32_t reset) { FPX_GUARD(h); if (!out || n < 0) return fpx::fail(FPX_ERR_ARG, "fpx_lane_stats: bad argument"); return h->impl->lane_stats(out, n, reset); }
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
 int fpx_comm_init_host(fpx_handle h, int32_t nranks, int32_t rank, fpx_allreduce_fn fn, void *user) { FPX_GUARD(h); return h->impl->comm_init_host(nranks, rank, fn, user); }

@@ -98,6 +98,8 @@ class Engine:
         # it so that runs compare with the reference binary they were pinned against (361 or 721)
         cfg.par_nxmax = int(sc.get("par_nxmax", 361))
         cfg.particle_base = int(particle_base or sc.get("particle_base", 0))
+        cfg.drybkdep, cfg.wetbkdep = int(sc.get("drybkdep", 0)), int(sc.get("wetbkdep", 0))   # backward runs with receptor scavenging
+        self.bkdep = bool(cfg.drybkdep or cfg.wetbkdep)
         self.cfg = cfg
         self.h = C.c_void_p()
         check(self.lib.fpx_create(C.byref(self.h), C.byref(cfg)), "fpx_create")
@@ -108,6 +110,10 @@ class Engine:
         self.lsynctime = int(sc["lsynctime"])
         self.n = 0
         self.set_release_points(*release_tables(sc))
+        if "zpoint1" in sc and "zpoint2" in sc:      # point_mod zpoint1/zpoint2: WETBKDEP multiplies with the release's height range
+            z1 = np.ascontiguousarray(np.asarray(sc["zpoint1"]).astype(rt))
+            z2 = np.ascontiguousarray(np.asarray(sc["zpoint2"]).astype(rt))
+            check(self.lib.fpx_set_release_heights(self.h, z1.size, _vp(z1), _vp(z2)), "fpx_set_release_heights")
         if rng_mode != RNG_PHILOX:
             check(self.lib.fpx_rng_fill_table(self.h), "fpx_rng_fill_table")
         if "uu" in sc:
@@ -565,6 +571,10 @@ class Engine:
             keep["xmass1"] = np.ascontiguousarray(np.asarray(sc["xmass1"]).astype(rt).reshape(self.nspec, n))
             p.xmass1 = keep["xmass1"].ctypes.data
             p.xmass1_ld = n
+        if "xscav_frac1" in sc:
+            keep["xscav_frac1"] = np.ascontiguousarray(np.asarray(sc["xscav_frac1"]).astype(rt).reshape(self.nspec, n))
+            p.xscav_frac1 = keep["xscav_frac1"].ctypes.data
+            p.xmass1_ld = n
         check(self.lib.fpx_upload_particles(self.h, first, n, C.byref(p)), "fpx_upload_particles")
         self.n = max(self.n, first + n)
 
@@ -584,6 +594,8 @@ class Engine:
                    itramem=np.empty(n, np.int32), idt=np.empty(n, np.int32), npoint=np.empty(n, np.int32),
                    nclass=np.empty(n, np.int32), itrasplit=np.empty(n, np.int32), cbt=np.empty(n, np.int16),
                    xmass1=np.empty((self.nspec, n), rt))
+        if self.bkdep:
+            out["xscav_frac1"] = np.empty((self.nspec, n), rt)
         p = FpxParticles()
         for k, a in out.items():
             setattr(p, k, a.ctypes.data)

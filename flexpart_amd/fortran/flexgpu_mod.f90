@@ -66,7 +66,8 @@ module flexgpu_mod
     integer(c_int32_t) :: sort_interval
     integer(c_int32_t) :: par_nxmax
     integer(c_int64_t) :: particle_base
-    integer(c_int32_t) :: reserved(4)
+    integer(c_int32_t) :: drybkdep, wetbkdep
+    integer(c_int32_t) :: reserved(2)
   end type fpx_config
 
   type, bind(C) :: fpx_fields
@@ -122,6 +123,7 @@ module flexgpu_mod
     type(c_ptr) :: xmass1
     integer(c_int64_t) :: xmass1_ld
     type(c_ptr) :: itrasplit
+    type(c_ptr) :: xscav_frac1
   end type fpx_particles
 
   type, bind(C) :: fpx_calcpar_in
@@ -191,6 +193,11 @@ module flexgpu_mod
       type(c_ptr), value :: h
       integer(c_int32_t), value :: itime
       integer(c_int64_t), intent(inout) :: numpart
+    end function
+    integer(c_int) function fpx_set_release_heights(h, numpoint, z1, z2) bind(C, name='fpx_set_release_heights')
+      import :: c_ptr, c_int, c_int32_t
+      type(c_ptr), value :: h, z1, z2
+      integer(c_int32_t), value :: numpoint
     end function
     integer(c_int) function fpx_set_release_points(h, numpoint, xmass, npart) bind(C, name='fpx_set_release_points')
       import :: c_ptr, c_int, c_int32_t
@@ -545,11 +552,6 @@ contains
     integer(c_int64_t), intent(in), optional :: seed, particle_base
     type(fpx_config) :: cfg
     integer :: ks
-    if (DRYBKDEP .or. WETBKDEP) then
-      ! backward runs with receptor scavenging (timemanager.f90:571-598, xscav_frac1) are not on the device path
-      ierr = -1
-      return
-    end if
     cfg%struct_bytes = int(c_sizeof(cfg), c_int32_t)
     cfg%device = 0; if (present(device)) cfg%device = device
     cfg%host_real_bytes = storage_size(1.0) / 8          ! 4 as shipped, 8 with -fdefault-real-8
@@ -582,6 +584,7 @@ contains
     cfg%sort_interval = 8
     cfg%par_nxmax = nxmax          ! eps = nxmax/3.e5, advance.f90:107
     cfg%particle_base = 0; if (present(particle_base)) cfg%particle_base = particle_base
+    cfg%drybkdep = merge(1, 0, DRYBKDEP); cfg%wetbkdep = merge(1, 0, WETBKDEP)   ! timemanager.f90:564-598 runs in flexgpu_step
     cfg%reserved = 0
     ierr = fpx_create(flexgpu_handle, cfg)
     if (ierr /= 0) return
@@ -589,6 +592,10 @@ contains
     ! (timemanager.f90:663-666, advance.f90:518-531)
     if (allocated(xmass) .and. allocated(npart)) then
       ierr = fpx_set_release_points(flexgpu_handle, int(size(npart), c_int32_t), loc_r(xmass), loc_i(npart))
+      if (ierr /= 0) return
+    end if
+    if (WETBKDEP .and. allocated(zpoint1) .and. allocated(zpoint2)) then      ! timemanager.f90:590-591
+      ierr = fpx_set_release_heights(flexgpu_handle, int(size(zpoint1), c_int32_t), loc_r(zpoint1), loc_r(zpoint2))
       if (ierr /= 0) return
     end if
     if (present(defer_height)) then
@@ -987,6 +994,8 @@ contains
     p%xmass1 = loc_r(xmass1(j1:,1))
     p%xmass1_ld = size(xmass1, 1)
     p%itrasplit = loc_i(itrasplit(j1:))
+    p%xscav_frac1 = c_null_ptr       ! com_mod.f90:683: allocated by readcommand.f90:329,338 for DRYBKDEP / WETBKDEP only
+    if (allocated(xscav_frac1)) p%xscav_frac1 = loc_r(xscav_frac1(j1:,1))
   end subroutine particle_ptrs
 
   ! particles j1..j2 (Fortran numbering) host -> device / device -> host

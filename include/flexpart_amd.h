@@ -99,7 +99,11 @@ typedef struct {
    * key on the global number, and fpx_seed_particles generates that slice of the global synthetic cloud, so results
    * do not depend on how many ranks share the particles.  Particle indices at the boundary (first, count) stay local. */
   int64_t particle_base;
-  int32_t reserved[4];
+  /* Backward runs with receptor scavenging (COMMAND ind_receptor = 4 / 3; com_mod.f90:591 DRYBKDEP, WETBKDEP;
+   * readcommand.f90:320-340): the particle array xscav_frac1 exists, the first step of a particle fills it
+   * (timemanager.f90:564-598) and fpx_conccalc weights every contribution with max(xscav_frac1, 0).  ldirect must be -1. */
+  int32_t drybkdep, wetbkdep;
+  int32_t reserved[2];
 } fpx_config;
 
 /* One time slot of the met fields the path gathers from (com_mod.f90:355-371,
@@ -124,6 +128,8 @@ typedef struct {
   void *xmass1;            /* (count or ld, nspec) species-major, leading dim xmass1_ld */
   int64_t xmass1_ld;
   int32_t *itrasplit;      /* com_mod.f90:683: next time the particle is split (NULL: never, i.e. ldirect*999999999, the value of a fresh engine) */
+  void *xscav_frac1;       /* com_mod.f90:683 xscav_frac1(maxpart,maxspec), laid out like xmass1 (leading dim xmass1_ld); only with
+                              drybkdep / wetbkdep.  NULL on upload: -1 (not yet scavenged, releaseparticles.f90:167-171) */
 } fpx_particles;
 
 typedef struct {
@@ -396,6 +402,10 @@ int fpx_set_numpart(fpx_handle h, int64_t numpart);   /* com_mod numpart */
  * the tables every particle takes species 1).  A particle whose npoint lies outside 1..numpoint
  * (the reference would read outside the arrays) is treated as a particle of the nearest point. */
 int fpx_set_release_points(fpx_handle h, int32_t numpoint, const void *xmass, const int32_t *npart);
+/* point_mod zpoint1(numpoint), zpoint2(numpoint) in the host's real kind: the height range of every release point.  Needed by
+ * WETBKDEP only (xscav_frac1 = wetscav * (zpoint2 - zpoint1) * grfraction(1), timemanager.f90:590-591); fpx_release_init
+ * sets it from its own tables. */
+int fpx_set_release_heights(fpx_handle h, int32_t numpoint, const void *zpoint1, const void *zpoint2);
 
 /* ---- releaseparticles and particle splitting on the device (SURVEY section 8 f, item 2) --------------------
  * fpx_releaseparticles replaces `call releaseparticles(itime)` (timemanager.f90:246; the routine:

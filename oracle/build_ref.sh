@@ -22,7 +22,7 @@ MODS="par_mod com_mod interpol_mod hanna_mod cmapf_mod point_mod xmass_mod rando
 SUBS="advance initialize interpol_all interpol_wind interpol_wind_short interpol_misslev interpol_vdep \
 interpol_all_nests interpol_wind_nests interpol_wind_short_nests interpol_misslev_nests interpol_vdep_nests \
 hanna hanna1 hanna_short cbl re_initialize_particle initialize_cbl_vel windalign get_settling dynamic_viscosity \
-conccalc drydepokernel drydepokernel_nest wetdepo get_wetscav interpol_rain interpol_rain_nests wetdepokernel wetdepokernel_nest"
+conccalc drydepokernel drydepokernel_nest wetdepo get_wetscav get_vdep_prob interpol_rain interpol_rain_nests wetdepokernel wetdepokernel_nest"
 
 # The class counts maxageclass and nclassunc are compile-time sizes of par_mod ("maximum number of age classes used
 # for output", "number of classes used to calculate the uncertainty", par_mod.f90:187-192), both 1 as shipped -- a

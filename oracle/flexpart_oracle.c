@@ -145,6 +145,9 @@ typedef struct {
   const signed char *clouds;                    /* [slot][level][jy][ix] */
   const int *cloudsh;                           /* [slot][jy][ix] */
   long blc_count[ORC_MAXSPEC], inc_count[ORC_MAXSPEC];
+  /* ---- backward runs with receptor scavenging (com_mod.f90:591,611: DRYBKDEP, WETBKDEP; readcommand.f90:320-340) */
+  int drybkdep, wetbkdep;
+  real *zpoint1, *zpoint2;                      /* point_mod zpoint1/zpoint2(numpoint): release height range */
 } orc_ctx;
 
 #define F3(f, i, j, k, m) ((f)[(((size_t)((m) - 1) * c->nz + (size_t)((k) - 1)) * c->ny + (size_t)(j)) * c->nx + (size_t)(i)])
@@ -1514,8 +1517,11 @@ static int orc_ageclass(orc_ctx *c, int itage) {   /* conccalc.f90:54-58, timema
 /* conccalc.f90:50-295 */
 void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const double *xtra1, const double *ytra1,
                   const real *ztra1, const int *itra1, const int *itramem, const int *npoint, const int *nclass,
-                  const real *xmass1) {
+                  const real *xmass1, const real *xscav_frac1) {
   const real weight = (real)weight_d;
+  /* DRYBKDEP / WETBKDEP: every contribution carries the factor max(xscav_frac1(i,ks), 0.), conccalc.f90:177-181,226-230 ... */
+  const int bk = (c->drybkdep || c->wetbkdep) && xscav_frac1;
+#define SCAV(ks_) (bk ? r_max(xscav_frac1[(size_t)((ks_) - 1) * npart + i], K(0.)) : K(1.))
   int i, ks;
   for (i = 0; i < npart; i++) {
     int itage, nage, ix, jy, ixp, jyp, kz, nrelpointer, il, ind, indz = 1, indzp = 2;
@@ -1555,7 +1561,7 @@ void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const doubl
         xl > (real)(c->numxgrid - 1) - K(0.5) || yl > (real)(c->numygrid - 1) - K(0.5)) {
       if (ix >= 0 && jy >= 0 && ix <= c->numxgrid - 1 && jy <= c->numygrid - 1)
         for (ks = 1; ks <= c->nspec; ks++)
-          c->gridunc[GIDX(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight;
+          c->gridunc[GIDX(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * SCAV(ks);
     } else {
       ddx = xl - (real)ix;
       ddy = yl - (real)jy;
@@ -1564,21 +1570,21 @@ void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const doubl
       if (ix >= 0 && ix <= c->numxgrid - 1) {
         if (jy >= 0 && jy <= c->numygrid - 1) {
           w = wx * wy;
-          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += (bk ? xmass1[(size_t)(ks - 1) * npart + i] / rhoi * w * weight * SCAV(ks) : xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w);
         }
         if (jyp >= 0 && jyp <= c->numygrid - 1) {
           w = wx * (K(1.) - wy);
-          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ix, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ix, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w * SCAV(ks);
         }
       }
       if (ixp >= 0 && ixp <= c->numxgrid - 1) {
         if (jyp >= 0 && jyp <= c->numygrid - 1) {
           w = (K(1.) - wx) * (K(1.) - wy);
-          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ixp, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ixp, jyp, kz, ks, nrelpointer, nclass[i], nage)] += (bk ? xmass1[(size_t)(ks - 1) * npart + i] / rhoi * w * weight * SCAV(ks) : xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w);
         }
         if (jy >= 0 && jy <= c->numygrid - 1) {
           w = (K(1.) - wx) * wy;
-          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ixp, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+          for (ks = 1; ks <= c->nspec; ks++) c->gridunc[GIDX(ixp, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w * SCAV(ks);
         }
       }
     }
@@ -1591,7 +1597,7 @@ void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const doubl
           yl > (real)(c->numygridn - 1) - K(0.5) || !c->lusekerneloutput) {
         if (ix >= 0 && jy >= 0 && ix <= c->numxgridn - 1 && jy <= c->numygridn - 1)
           for (ks = 1; ks <= c->nspec; ks++)
-            c->griduncn[ORC_GIDXN(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight;
+            c->griduncn[ORC_GIDXN(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * SCAV(ks);
       } else {
         ddx = xl - (real)ix;
         ddy = yl - (real)jy;
@@ -1600,21 +1606,21 @@ void orc_conccalc(orc_ctx *c, int itime, double weight_d, int npart, const doubl
         if (ix >= 0 && ix <= c->numxgridn - 1) {
           if (jy >= 0 && jy <= c->numygridn - 1) {
             w = wx * wy;
-            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ix, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w * SCAV(ks);
           }
           if (jyp >= 0 && jyp <= c->numygridn - 1) {
             w = wx * (K(1.) - wy);
-            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ix, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ix, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w * SCAV(ks);
           }
         }
         if (ixp >= 0 && ixp <= c->numxgridn - 1) {
           if (jyp >= 0 && jyp <= c->numygridn - 1) {
             w = (K(1.) - wx) * (K(1.) - wy);
-            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ixp, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ixp, jyp, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w * SCAV(ks);
           }
           if (jy >= 0 && jy <= c->numygridn - 1) {
             w = (K(1.) - wx) * wy;
-            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ixp, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w;
+            for (ks = 1; ks <= c->nspec; ks++) c->griduncn[ORC_GIDXN(ixp, jy, kz, ks, nrelpointer, nclass[i], nage)] += xmass1[(size_t)(ks - 1) * npart + i] / rhoi * weight * w * SCAV(ks);
           }
         }
       }
@@ -2000,7 +2006,7 @@ orc_ctx *orc_create(void) {
   orc_fill_rannumb(c);
   return c;
 }
-void orc_destroy(orc_ctx *c) { free(c->xmass_pt); free(c->npart_pt); free(c); }
+void orc_destroy(orc_ctx *c) { free(c->xmass_pt); free(c->npart_pt); free(c->zpoint1); free(c->zpoint2); free(c); }
 int orc_real_size(void) { return (int)sizeof(real); }
 const real *orc_rannumb(orc_ctx *c) { return &c->rannumb[1]; }
 
@@ -2112,10 +2118,82 @@ void orc_set_fields(orc_ctx *c, const real *uu, const real *vv, const real *ww, 
    loop of timemanager.f90:531-712 (initialize if new :553-555, advance :609-611,
    epilogue :630-708 without the deposition-grid kernels).  prob_out (npart*nspec,
    species-major) receives advance's dry-deposition probabilities or may be NULL. */
+/* get_vdep_prob.f90:4-145 -- "probability" (in fact the deposition velocity, :136-139) of dry deposition at the
+   receptor, used by backward runs with DRYBKDEP.  The routine sets ngrid, ix, jy, ixp, jyp but NOT the horizontal
+   weights p1..p4 and the time weights dt1, dt2, dtt that interpol_vdep[_nests] reads: those are whatever interpol_mod
+   holds -- left by initialize() of the same particle (timemanager.f90:553-556 runs just before; mother-grid weights
+   also for a particle inside a nest, as initialize() knows no nests). */
+static void orc_get_vdep_prob(orc_ctx *c, int itime, double xt, double yt, real zt, real *prob) {
+  const real eps = c->eps_nxmax / K(3.e5);
+  const real href = K(15.);
+  int ks;
+  real xtn, ytn, vdepo[ORC_MAXSPEC];
+  (void)itime;
+  if (c->drydep)
+    for (ks = 0; ks < c->nspec; ks++) { c->depoindicator[ks] = 1; prob[ks] = K(0.); }
+  c->ngrid = orc_pick_grid(c, xt, yt, eps);   /* :52-69 */
+  if (c->ngrid > 0) {                          /* :84-99 */
+    xtn = (real)((xt - (double)c->xln[c->ngrid - 1]) * (double)c->xresoln[c->ngrid - 1]);
+    ytn = (real)((yt - (double)c->yln[c->ngrid - 1]) * (double)c->yresoln[c->ngrid - 1]);
+    c->ix = (int)xtn; c->jy = (int)ytn;
+  } else {
+    c->ix = (int)xt; c->jy = (int)yt;
+  }
+  c->ixp = c->ix + 1;
+  c->jyp = c->jy + 1;
+  if (c->drydep && zt < K(2.) * href) {        /* :105-127 */
+    for (ks = 0; ks < c->nspec; ks++) {
+      if (c->drydepspec[ks]) {
+        if (c->depoindicator[ks]) {
+          if (c->ngrid <= 0) orc_interpol_vdep(c, ks + 1, &vdepo[ks]);
+          else orc_interpol_vdep_nests(c, ks + 1, &vdepo[ks]);
+        }
+        prob[ks] = vdepo[ks];
+      }
+    }
+  }
+}
+
+void orc_set_bkdep(orc_ctx *c, int drybkdep, int wetbkdep, int numpoint, const double *zpoint1, const double *zpoint2) {
+  int i;
+  c->drybkdep = drybkdep; c->wetbkdep = wetbkdep;
+  free(c->zpoint1); free(c->zpoint2);
+  c->zpoint1 = (real *)calloc((size_t)(numpoint > 0 ? numpoint : 1), sizeof(real));
+  c->zpoint2 = (real *)calloc((size_t)(numpoint > 0 ? numpoint : 1), sizeof(real));
+  for (i = 0; i < numpoint; i++) { c->zpoint1[i] = (real)zpoint1[i]; c->zpoint2[i] = (real)zpoint2[i]; }
+}
+
+/* the receptor block of timemanager.f90:564-598: once per particle, before it is moved for the first time */
+static void orc_receptor_scavenging(orc_ctx *c, int itime, int j, int npart, double xt, double yt, real zt, int npoint,
+                                    real *xmass1, real *xscav_frac1) {
+  int ks;
+  if (c->drybkdep) {
+    for (ks = 0; ks < c->nspec; ks++) {
+      if (xscav_frac1[(size_t)ks * npart + j] < K(0.)) {
+        real prob_rec[ORC_MAXSPEC];
+        orc_get_vdep_prob(c, itime, xt, yt, zt, prob_rec);
+        if (c->drydepspec[ks]) xscav_frac1[(size_t)ks * npart + j] = prob_rec[ks];
+        else { xmass1[(size_t)ks * npart + j] = K(0.); xscav_frac1[(size_t)ks * npart + j] = K(0.); }
+      }
+    }
+  }
+  if (c->wetbkdep) {
+    for (ks = 0; ks < c->nspec; ks++) {
+      if (xscav_frac1[(size_t)ks * npart + j] < K(0.)) {
+        real grfraction[3] = {K(0.), K(0.), K(0.)};
+        const real wetscav = orc_get_wetscav(c, itime, c->lsynctime, xt, yt, zt, ks, grfraction);
+        if (wetscav > K(0.))
+          xscav_frac1[(size_t)ks * npart + j] = wetscav * (c->zpoint2[npoint - 1] - c->zpoint1[npoint - 1]) * grfraction[0];
+        else { xmass1[(size_t)ks * npart + j] = K(0.); xscav_frac1[(size_t)ks * npart + j] = K(0.); }
+      }
+    }
+  }
+}
+
 long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, real *ztra1,
               real *uap, real *ucp, real *uzp, real *us, real *vs, real *ws,
               int *idt, int *itra1, const int *itramem, const int *npoint, int16_t *cbt,
-              real *xmass1, real *prob_out, const int *nclass_arr) {
+              real *xmass1, real *prob_out, const int *nclass_arr, real *xscav_frac1) {
   const real minmass = K(0.0001);
   long nadv = 0;
   int j, ks, nstop;
@@ -2125,6 +2203,8 @@ long orc_step(orc_ctx *c, int itime, int npart, double *xtra1, double *ytra1, re
     c->cur_particle = j;
     if (itramem[j] == itime || itime == 0)
       orc_initialize(c, itime, &idt[j], &uap[j], &ucp[j], &uzp[j], &us[j], &vs[j], &ws[j], xtra1[j], ytra1[j], ztra1[j], &cbt[j]);
+    if ((c->drybkdep || c->wetbkdep) && xscav_frac1 && xmass1)   /* timemanager.f90:564-598 */
+      orc_receptor_scavenging(c, itime, j, npart, xtra1[j], ytra1[j], ztra1[j], npoint ? npoint[j] : 1, xmass1, xscav_frac1);
     for (ks = 0; ks < ORC_MAXSPEC; ks++) prob[ks] = K(0.);
     nstop = orc_advance(c, itime, npoint ? npoint[j] : 1, &idt[j], &uap[j], &ucp[j], &uzp[j], &us[j], &vs[j], &ws[j],
                         &xtra1[j], &ytra1[j], &ztra1[j], prob, &cbt[j]);

@@ -161,6 +161,18 @@ class Oracle:
         self.has_wet = bool(sc.get("wetdep", 0))
         if self.has_wet:
             self._init_wet(sc)
+        # backward runs with receptor scavenging (DRYBKDEP / WETBKDEP, timemanager.f90:564-598): xscav_frac1 starts at -1
+        # (releaseparticles.f90:167-171) unless the scenario carries the array
+        self.bkdep = (int(sc.get("drybkdep", 0)), int(sc.get("wetbkdep", 0)))
+        self.xscav = None
+        if any(self.bkdep):
+            z1 = _f64(sc.get("zpoint1", np.zeros(self.numpoint)))
+            z2 = _f64(sc.get("zpoint2", np.zeros(self.numpoint)))
+            lib.orc_set_bkdep(self.h, self.bkdep[0], self.bkdep[1], self.numpoint, z1.ctypes.data_as(dp), z2.ctypes.data_as(dp))
+            if "xscav_frac1" in sc:
+                self.xscav = np.ascontiguousarray(np.asarray(sc["xscav_frac1"]).astype(self.rt).reshape(nspec, n))
+            else:
+                self.xscav = np.full((nspec, n), -1.0, self.rt)
 
     def _init_wet(self, sc):
         lib = self.lib
@@ -258,18 +270,21 @@ class Oracle:
         nadv = self.lib.orc_step(self.h, self.itime, self.n, vp(self.x), vp(self.y), vp(self.z),
                                  vp(self.uap), vp(self.ucp), vp(self.uzp), vp(self.us), vp(self.vs),
                                  vp(self.ws), vp(self.idt), vp(self.itra1), vp(self.itramem),
-                                 vp(self.npoint), vp(self.cbt), vp(self.xmass1), vp(self.prob), vp(self.nclass))
+                                 vp(self.npoint), vp(self.cbt), vp(self.xmass1), vp(self.prob), vp(self.nclass), self._xscav_ptr())
         self.itime += int(self.sc["lsynctime"])
         if self.has_grid:   # sample at the new positions (conccalc.f90), weight 1
             self.lib.orc_conccalc(self.h, self.itime, C.c_double(1.0), self.n, vp(self.x), vp(self.y), vp(self.z),
-                                  vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1))
+                                  vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1), self._xscav_ptr())
         return nadv
+
+    def _xscav_ptr(self):
+        return self.xscav.ctypes.data_as(C.c_void_p) if self.xscav is not None else C.c_void_p(0)
 
     def sample(self, weight=1.0):
         """conccalc at the current time and positions."""
         vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
         self.lib.orc_conccalc(self.h, self.itime, C.c_double(weight), self.n, vp(self.x), vp(self.y), vp(self.z),
-                              vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1))
+                              vp(self.itra1), vp(self.itramem), vp(self.npoint), vp(self.nclass), vp(self.xmass1), self._xscav_ptr())
 
     def state(self):
         return dict(xtra1=self.x.copy(), ytra1=self.y.copy(), ztra1=self.z.astype(np.float64),
@@ -277,7 +292,8 @@ class Oracle:
                     uzp=self.uzp.astype(np.float64), us=self.us.astype(np.float64),
                     vs=self.vs.astype(np.float64), ws=self.ws.astype(np.float64),
                     idt=self.idt.copy(), itra1=self.itra1.copy(), cbt=self.cbt.astype(np.int32),
-                    xmass1=self.xmass1.astype(np.float64), prob=self.prob.astype(np.float64))
+                    xmass1=self.xmass1.astype(np.float64), prob=self.prob.astype(np.float64),
+                    **({"xscav_frac1": self.xscav.astype(np.float64)} if self.xscav is not None else {}))
 
     def run(self, nsteps=None):
         out = []

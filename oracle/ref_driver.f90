@@ -67,6 +67,8 @@ program flexref
   integer :: ldeltat, loutnext_d, itage
   integer(kind=8) :: c0, c1, crate, nadv
   real :: prob(maxspec), decfact, xmassfract, weight
+  real :: prob_rec(maxspec), grfraction(3), wetscav                    ! as timemanager.f90:105,109
+  integer(selected_int_kind(16)), dimension(maxspec) :: idummy1, idummy2
   real(dep_prec) :: drydeposit(maxspec)      ! as timemanager.f90:104
   real :: sizenorth, sizesouth
   real(kind=8), allocatable :: tmp(:)
@@ -97,6 +99,7 @@ program flexref
   fine=0.25; turbswitch=.true.; cblflag=0; mdomainfill=0; mquasilag=0
   lsettling=.false.; nspec=1; maxpointspec_act=1
   DRYDEP=.false.; WETDEP=.false.; DRYBKDEP=.false.; WETBKDEP=.false.
+  idummy1(:)=0; idummy2(:)=0
   DRYDEPSPEC(:)=.false.; WETDEPSPEC(:)=.false.
   density(:)=0.; decay(:)=0.; dquer(:)=0.; vsetaver(:)=0.; cunningham(:)=1.
   numbnests=0; nageclass=1; lage(1)=999999999
@@ -318,6 +321,19 @@ program flexref
       itra1(:)=-999999999; npoint(:)=1; nclass(:)=1; idt(:)=0; itramem(:)=0
       itrasplit(:)=999999999; xmass1(:,:)=0.
       uap(:)=0.; ucp(:)=0.; uzp(:)=0.; us(:)=0.; vs(:)=0.; ws(:)=0.; cbt(:)=1
+    ! --- backward runs with receptor scavenging (readcommand.f90:320-340, readreleases.f90:508-517) ------
+    case ('drybkdep')
+      DRYBKDEP=(ibuf(1).ne.0)
+      if (DRYBKDEP .and. .not. allocated(xscav_frac1)) then
+        allocate(xscav_frac1(npart_in,maxspec)); xscav_frac1(:,:)=-1.      ! releaseparticles.f90:167-171
+      end if
+    case ('wetbkdep')
+      WETBKDEP=(ibuf(1).ne.0)
+      if (WETBKDEP .and. .not. allocated(xscav_frac1)) then
+        allocate(xscav_frac1(npart_in,maxspec)); xscav_frac1(:,:)=-1.
+      end if
+    case ('zpoint1');  if (.not. allocated(zpoint1)) allocate(zpoint1(numpoint)); zpoint1(1:n)=dbuf(1:n)
+    case ('zpoint2');  if (.not. allocated(zpoint2)) allocate(zpoint2(numpoint)); zpoint2(1:n)=dbuf(1:n)
     case ('xtra1');   xtra1(1:n)=dbuf(1:n)
     case ('ytra1');   ytra1(1:n)=dbuf(1:n)
     case ('ztra1');   ztra1(1:n)=dbuf(1:n)
@@ -498,6 +514,35 @@ program flexref
         if ((itramem(j).eq.itime).or.(itime.eq.0)) &
              call initialize(itime,idt(j),uap(j),ucp(j),uzp(j), &
              us(j),vs(j),ws(j),xtra1(j),ytra1(j),ztra1(j),cbt(j))
+        ! RECEPTOR: dry/wet depovel -- the statements of timemanager.f90:571-598, calling the reference's own
+        ! get_vdep_prob and get_wetscav
+        if  (DRYBKDEP) then
+          do ks=1,nspec
+            if  ((xscav_frac1(j,ks).lt.0)) then
+              call get_vdep_prob(itime,xtra1(j),ytra1(j),ztra1(j),prob_rec)
+              if (DRYDEPSPEC(ks)) then
+                xscav_frac1(j,ks)=prob_rec(ks)
+              else
+                xmass1(j,ks)=0.
+                xscav_frac1(j,ks)=0.
+              endif
+            endif
+          enddo
+        endif
+        if (WETBKDEP) then
+          do ks=1,nspec
+            if  ((xscav_frac1(j,ks).lt.0)) then
+              call get_wetscav(itime,lsynctime,loutnext_d,j,ks,grfraction,idummy1,idummy2,wetscav)
+              if (wetscav.gt.0) then
+                xscav_frac1(j,ks)=wetscav* &
+                     (zpoint2(npoint(j))-zpoint1(npoint(j)))*grfraction(1)
+              else
+                xmass1(j,ks)=0.
+                xscav_frac1(j,ks)=0.
+              endif
+            endif
+          enddo
+        endif
         call advance(itime,npoint(j),idt(j),uap(j),ucp(j),uzp(j), &
              us(j),vs(j),ws(j),nstop,xtra1(j),ytra1(j),ztra1(j),prob, &
              cbt(j))
@@ -689,6 +734,11 @@ contains
     do kk=1,nspec
       tmp(1:np)=xmass1(1:np,kk); call put_d('xmass1', tmp, np)
     end do
+    if (DRYBKDEP .or. WETBKDEP) then
+      do kk=1,nspec
+        tmp(1:np)=xscav_frac1(1:np,kk); call put_d('xscav_frac1', tmp, np)
+      end do
+    end if
     deallocate(it)
   end subroutine dump_state
 

@@ -26,11 +26,13 @@ _ORDER = ["grid", "geom", "globalflags", "height", "nmixz", "memtime", "memind",
           "nest", "nestgeom", "uun", "vvn", "wwn", "rhon", "drhodzn", "hmixn", "ustarn", "wstarn", "olin",
           "tropopausen", "vdepn", "lsprecn", "convprecn", "tccn", "ttn", "cloudsn", "cloudshn", "lsprec", "convprec", "tcc", "clouds", "cloudsh",
           "numpoint", "npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt",
-          "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass", "npart_rel"]
+          "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1", "xmass", "npart_rel",
+          "drybkdep", "wetbkdep", "zpoint1", "zpoint2"]      # backward runs with receptor scavenging: after 'numpoint' and 'npart' 
 _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsynctime", "method",
         "mintime", "ifine", "turbswitch", "cblflag", "mdomainfill", "lsettling", "nspec",
         "drydep", "drydepspec", "lage", "nclassunc", "mquasilag", "numpoint", "npart_rel", "nsteps", "itime0", "npart", "itra1", "itramem",
-        "npoint", "nclass", "idt", "cbt", "outgrid", "outgridn", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "cloudsn", "cloudshn", "nest"}
+        "npoint", "nclass", "idt", "cbt", "outgrid", "outgridn", "concflags", "outtimes", "wetdep", "wetdepspec", "clouds", "cloudsh", "cloudsn", "cloudshn", "nest",
+        "drybkdep", "wetbkdep"}
 
 
 def write_scenario(path, sc):
@@ -103,10 +105,10 @@ def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=F
         if name == "xtra1":
             cur = {}
             out["steps"].append(cur)
-        if name == "xmass1":
-            cur.setdefault("xmass1", []).append(a)
-            if len(cur["xmass1"]) == nspec:
-                cur["xmass1"] = np.stack(cur["xmass1"])
+        if name in ("xmass1", "xscav_frac1"):
+            cur.setdefault(name, []).append(a)
+            if len(cur[name]) == nspec:
+                cur[name] = np.stack(cur[name])
         else:
             cur[name] = a
     return out

@@ -33,7 +33,7 @@ def main():
             ref = sio.run_reference(sc, kind + REF_VARIANT.get(name, ""))
             out = {}
             for i, s in enumerate(ref["steps"]):
-                for k in KEYS:
+                for k in KEYS + (("xscav_frac1",) if "xscav_frac1" in s else ()):
                     a = s[k]
                     if kind == "r4" and a.dtype == np.float64 and k not in ("xtra1", "ytra1"):
                         a = a.astype(np.float32)      # exact: the values are f32 in the r4 build

@@ -64,7 +64,8 @@ def test_fp64_matches_oracle(built, name, kw):
 
 
 @pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "nest_wet", "sampling", "sampling_nest", "backward", "backward_cbl",
-                                  "limited_area", "three_species", "multi_release", "age_classes"])
+                                  "limited_area", "three_species", "multi_release", "age_classes",
+                                  "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep"])
 def test_fp64_matches_oracle_golden_scenarios(built, name):
     """The scenarios the golden fixtures were made on: polar caps through the stereographic maps
     (cmapf subset), an aerosol species with settling + dry deposition + decay, CBL, Hanna."""
@@ -78,7 +79,8 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
 
 
 @pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "nest_wet", "sampling",
-                                  "sampling_nest", "backward", "backward_cbl", "limited_area", "three_species", "multi_release", "age_classes"])
+                                  "sampling_nest", "backward", "backward_cbl", "limited_area", "three_species", "multi_release", "age_classes",
+                                  "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep"])
 def test_fp64_against_reference_fixtures(built, name):
     """HIP path directly against the outputs of the unmodified reference (tests/golden, flang r8 builds).  Only
     particles touched by the two order-dependent leaks of the serial code may differ, and WHICH
@@ -110,6 +112,53 @@ def test_fp64_against_reference_fixtures(built, name):
         assert affected.sum() > 100 and bad.sum() > 0      # the fixture does exercise D2
     else:
         assert affected.sum() <= 0.01 * n
+
+
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+@pytest.mark.parametrize("name", ["backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep"])
+def test_backward_receptor_scavenging(built, name, kind):
+    """Row a24: backward runs with DRYBKDEP / WETBKDEP (COMMAND ind_receptor 4 / 3).  The receptor block of
+    timemanager.f90:564-598 runs once per particle before it is moved (get_vdep_prob.f90 -> interpol_vdep[_nests];
+    get_wetscav.f90), sets xscav_frac1 and zeroes the mass of what is not scavenged; conccalc weights every contribution
+    with max(xscav_frac1, 0) (conccalc.f90:177-181 ...).  Against the oracle (which reproduces the flang build of the
+    unmodified routines, tests/golden/backward_*bkdep_*.npz) and against those fixtures directly: xscav_frac1 after the
+    first step is a pure function of the release position, so it is compared for EVERY particle."""
+    import os
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
+    from oracle.oracle import Oracle
+    from test_oracle_cpu import GOLD, golden_scenario
+    sc = golden_scenario(name)
+    rb = 8 if kind == "r8" else 4
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_TABLE_SEQ)
+    got = eng.run()          # wetdepo (mass loss only in a backward run) -> step -> conccalc, as the time manager orders them
+    g, _ = eng.grids()
+    eng.close()
+    orc = Oracle(sc, kind)
+    orc.lib.orc_set_parallel_semantics(orc.h, 1)
+    want = orc.run()
+    og, _ = orc.grids()
+    n = int(sc["npart"])
+    gold = np.load(os.path.join(GOLD, f"{name}_{kind}.npz"))
+    # f32: the Laakso / Kyro polynomials of get_wetscav.f90:230-240 sum terms of 1e5 to an exponent of order 1, so one ulp of
+    # log10f moves the scavenging coefficient by 1e-3 (the f32 wet-deposition grids are compared at 5e-3 for the same reason)
+    tol = 1e-12 if kind == "r8" else (2e-3 if "wet" in name else 2e-6)
+    for i, (gs, ws) in enumerate(zip(got, want)):
+        for ref in (ws["xscav_frac1"], gold[f"s{i}_xscav_frac1"].astype(np.float64)):
+            assert np.abs(gs["xscav_frac1"] - ref).max() <= tol * np.abs(ref).max(), (name, kind, i)
+        assert not (gs["xscav_frac1"] < 0).any()
+        # what is not scavenged at the receptor carries no mass from the first step on
+        dead_mass = (ws["xscav_frac1"] == 0) & (ws["xmass1"] == 0)
+        assert np.array_equal((gs["xmass1"] == 0) & (gs["xscav_frac1"] == 0), dead_mass)
+        if kind == "r8":
+            assert_close(gs, ws, 1e-9, 1e-7)
+            assert np.abs(gs["xmass1"] - ws["xmass1"]).max() <= 1e-12 * np.abs(ws["xmass1"]).max()
+        else:
+            assert_close(gs, ws, 2e-6, 5e-3, max_diverged=int(0.02 * n))
+    assert (got[0]["xscav_frac1"] > 0).sum() > 50 and (got[0]["xscav_frac1"] == 0).sum() > 50
+    assert og.sum() > 0 and g.size == og.size
+    g = g.reshape(og.shape)
+    assert np.abs(g - og).max() <= (1e-12 if kind == "r8" else 5e-3) * og.max()
+    assert abs(g.sum() - og.sum()) <= (1e-10 if kind == "r8" else 2e-3) * og.sum()
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
@@ -396,6 +445,32 @@ def test_fortran_host_drop_in_sampling(built, case, kind):
         assert a.shape == b.shape and b.sum() > 0, k
         assert np.abs(a - b).max() <= 0.02 * b.max(), (k, np.abs(a - b).max() / b.max())
         assert abs(a.sum() - b.sum()) <= 2e-3 * b.sum(), (k, a.sum(), b.sum())
+
+
+@pytest.mark.parametrize("case", ["backward_drybkdep", "backward_wetbkdep"])
+def test_fortran_host_backward_receptor_scavenging(built, case):
+    """Row a24 through the Fortran shim: the host's DRYBKDEP / WETBKDEP switches, its xscav_frac1(maxpart,maxspec) and
+    point_mod zpoint1/zpoint2 reach the engine through flexgpu_init / flexgpu_upload_particles; after every step the
+    host's own xscav_frac1, xmass1 and -- at the end -- gridunc equal those of the reference's loop (timemanager.f90:564-598,
+    conccalc.f90:177-181) in the same binary."""
+    from oracle import scenario_io as sio
+    if not sio.have_ref("r8"):
+        pytest.skip("oracle/_ref binaries not present in this snapshot")
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario(case)
+    ref = sio.run_reference(sc, "r8")
+    gpu = sio.run_reference(sc, "r8", gpu=True, tag="gpubk")
+    n = int(sc["npart"])
+    for i, (a, b) in enumerate(zip(gpu["steps"], ref["steps"])):
+        assert np.abs(a["xscav_frac1"] - b["xscav_frac1"]).max() <= 1e-12 * np.abs(b["xscav_frac1"]).max(), (case, i)
+        assert np.array_equal(a["xmass1"] == 0, b["xmass1"] == 0)
+        bad = np.zeros(n, bool)
+        for k in ("xtra1", "ytra1", "ztra1"):
+            bad |= np.abs(a[k] - b[k]) > 1e-9 * np.abs(b[k]).max()
+        assert bad.sum() <= 0.01 * n, f"{bad.sum()} of {n} particles differ"      # D1/D2 order effects of the serial host loop
+    a, b = gpu["gridunc"], ref["gridunc"]
+    assert a.shape == b.shape and b.sum() > 0
+    assert np.abs(a - b).max() <= 0.02 * b.max() and abs(a.sum() - b.sum()) <= 2e-3 * b.sum()
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
