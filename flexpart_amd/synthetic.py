@@ -585,9 +585,19 @@ def nest_model_levels(m, ix0=10, jy0=6, ix1=25, jy1=16, factor=2, phase=3):
 # --------------------------------------------------------------------------
 # concoutput: output grids with the run structure the sparse writer compresses
 # --------------------------------------------------------------------------
-def concoutput_case(nxg=24, nyg=16, nzg=4, nspec=2, wet=True, dry=True, itime=3600, seed=5):
+def concoutput_case(nxg=24, nyg=16, nzg=4, nspec=2, wet=True, dry=True, itime=3600, seed=5, classes=1):
     """gridunc / wetgridunc / drygridunc with empty stretches, single cells and long runs (float32 values, as the
-    sampling kernels leave them), plus area/volume as outgrid_init.f90:59-95 computes them."""
+    sampling kernels leave them), plus area/volume as outgrid_init.f90:59-95 computes them.  classes > 1: the grids carry
+    a leading uncertainty-class dimension [classes][nspec]... (nclassunc of par_mod; concoutput writes the class mean times
+    nclassunc, concoutput.f90:296-345 with mean_mod)."""
+    if classes > 1:
+        parts = [concoutput_case(nxg, nyg, nzg, nspec, wet, dry, itime, seed + 17 * c) for c in range(classes)]
+        co = dict(parts[0])
+        co["classes"] = np.array([classes], np.int32)
+        for k in ("gridunc", "wetgridunc", "drygridunc"):
+            if k in co:
+                co[k] = np.stack([p[k] for p in parts])
+        return co
     u = _uniform01(nspec * nzg * nyg * nxg, seed).reshape(nspec, nzg, nyg, nxg)
     blob = _wave(np.arange(nxg)[None, None, None, :] * 3 + np.arange(nyg)[None, None, :, None] * 5, 4 * nxg)
     g = np.where((u > 0.55) & (blob > -0.2), (u * 1.0e-3).astype(np.float32), np.float32(0.0)).astype(np.float64)

@@ -228,3 +228,8 @@ build_rel r4n -DFLEXREF_NESTS -DFLEXGPU_NESTS
 # several age classes / uncertainty classes (see build_one)
 FLEXREF_CLASSES="4 3" build_one r4c par_mod.f90
 FLEXREF_CLASSES="4 3" build_one r8c par_mod.f90 -fdefault-real-8
+# ... the same compile-time sizes for the class mean of concoutput (mean_mod over nclassunc = 3) and for the uncertainty
+# class readpartpositions draws for every particle of a warm start (ran1, readpartpositions.f90:142-143)
+build_co r4c
+build_rp r4c
+build_rp r8c -fdefault-real-8

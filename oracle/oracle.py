@@ -537,7 +537,7 @@ def co_oracle(co):
     lib.coo_concoutput.restype = C.c_long
     nxg, nyg, nzg, nspec, wet, dry, itime = (int(v) for v in co["outgrid"])
     a = _CooArgs()
-    a.nxg, a.nyg, a.nzg, a.nspec, a.nclassunc, a.wetdep, a.drydep, a.itime = nxg, nyg, nzg, nspec, 1, wet, dry, itime
+    a.nxg, a.nyg, a.nzg, a.nspec, a.nclassunc, a.wetdep, a.drydep, a.itime = nxg, nyg, nzg, nspec, int(np.asarray(co.get("classes", 1)).ravel()[0]), wet, dry, itime
     a.outnum = float(co["outgeom"][4])
     keep = {}
     fp = C.POINTER(C.c_float)

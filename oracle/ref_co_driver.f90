@@ -26,7 +26,7 @@ program coref
   integer(kind=8) :: cnt
   integer, allocatable :: ibuf(:)
   real(kind=8), allocatable :: dbuf(:)
-  integer :: ios, n, itime_out, nxg, nyg, nzg, i, ix, jy, kz, ks, use_nest
+  integer :: ios, n, itime_out, nxg, nyg, nzg, i, ix, jy, kz, ks, use_nest, kc, ncls = 1
   character(len=16) :: arg3
   real :: outnum, gtu
   real(dep_prec) :: wtu, dtu
@@ -118,31 +118,42 @@ program coref
           end do
         end do
       end do
-    case ('gridunc')   ! [nspec][nzg][nyg][nxg]
+    case ('classes')   ! uncertainty classes the grids below carry: must be the nclassunc this binary was built with (par_mod)
+      ncls=ibuf(1)
+      if (ncls .ne. nclassunc) then
+        write(*,*) 'ref_co_driver: the scenario has ', ncls, ' classes, this build nclassunc = ', nclassunc; stop 1
+      end if
+    case ('gridunc')   ! [classes][nspec][nzg][nyg][nxg]
+      do kc=1,ncls
       do ks=1,nspec
         do kz=1,nzg
           do jy=0,nyg-1
             do ix=0,nxg-1
-              gridunc(ix,jy,kz,ks,1,1,1)=dbuf(1+ix+nxg*(jy+nyg*((kz-1)+nzg*(ks-1))))
+              gridunc(ix,jy,kz,ks,1,kc,1)=dbuf(1+ix+nxg*(jy+nyg*((kz-1)+nzg*((ks-1)+nspec*(kc-1)))))
             end do
           end do
         end do
       end do
+      end do
     case ('wetgridunc')
+      do kc=1,ncls
       do ks=1,nspec
         do jy=0,nyg-1
           do ix=0,nxg-1
-            wetgridunc(ix,jy,ks,1,1,1)=dbuf(1+ix+nxg*(jy+nyg*(ks-1)))
+            wetgridunc(ix,jy,ks,1,kc,1)=dbuf(1+ix+nxg*(jy+nyg*((ks-1)+nspec*(kc-1))))
           end do
         end do
       end do
+      end do
     case ('drygridunc')
+      do kc=1,ncls
       do ks=1,nspec
         do jy=0,nyg-1
           do ix=0,nxg-1
-            drygridunc(ix,jy,ks,1,1,1)=dbuf(1+ix+nxg*(jy+nyg*(ks-1)))
+            drygridunc(ix,jy,ks,1,kc,1)=dbuf(1+ix+nxg*(jy+nyg*((ks-1)+nspec*(kc-1))))
           end do
         end do
+      end do
       end do
     case default
       write(*,*) 'ref_co_driver: unknown record ', trim(name); stop 1

@@ -265,10 +265,10 @@ def run_co_reference(co, kind="r4", workdir="/tmp", nest=False):
         fs = os.path.join(d, "co.scen")
         with open(fs, "wb") as fh:
             for name in ("outgrid", "outgeom", "outheight", "iout", "met", "metgeom", "height", "weightmolar", "rho2",
-                         "area", "volume", "gridunc", "wetgridunc", "drygridunc"):
+                         "area", "volume", "classes", "gridunc", "wetgridunc", "drygridunc"):
                 if name not in co:
                     continue
-                code = 1 if name in ("outgrid", "iout", "met") else 2
+                code = 1 if name in ("outgrid", "iout", "met", "classes") else 2
                 a = np.ascontiguousarray(np.asarray(co[name], dtype=np.int32 if code == 1 else np.float64).ravel())
                 fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
                 fh.write(a.tobytes())

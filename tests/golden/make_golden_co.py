@@ -14,7 +14,7 @@ from oracle import scenario_io as sio  # noqa: E402
 from test_concoutput import CASES  # noqa: E402
 
 for case, kw in CASES.items():
-    for name, b in sio.run_co_reference(syn.concoutput_case(**kw)).items():
+    for name, b in sio.run_co_reference(syn.concoutput_case(**kw), kind="r4c" if kw.get("classes", 1) > 1 else "r4").items():
         open(os.path.join(HERE, f"co_{case}_{name[-3:]}.bin"), "wb").write(b)
         print(case, name, len(b))
 

@@ -27,3 +27,14 @@ for kind in ("r4", "r8"):
     ref = sio.run_rp_reference(dump, restart_setup(sc, 2), kind)
     np.savez_compressed(os.path.join(HERE, f"rp_s2_{kind}.npz"), **{k: np.asarray(v) for k, v in ref.items()})
     print("rp", kind, ref["numpart"])
+
+# ... and with three uncertainty classes (the reference built with nclassunc = 3: rpref_r4c / rpref_r8c, oracle/build_ref.sh):
+# the class every particle draws from ran1 (readpartpositions.f90:142-143)
+for kind in ("r4", "r8"):
+    sc = scenario(2)
+    dump = open(os.path.join(HERE, f"po_s2_{kind}.bin"), "rb").read()
+    rs = restart_setup(sc, 2)
+    rs["restart"][7] = 3
+    ref = sio.run_rp_reference(dump, rs, kind + "c")
+    np.savez_compressed(os.path.join(HERE, f"rp_s2_classes_{kind}.npz"), **{k: np.asarray(v) for k, v in ref.items()})
+    print("rp classes", kind, ref["numpart"], np.bincount(ref["nclass"]))

@@ -15,7 +15,10 @@ import pytest
 from flexpart_amd import synthetic as syn
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-CASES = {"two_species": dict(), "no_deposition": dict(wet=False, dry=False, nspec=1), "odd_sizes": dict(nxg=37, nyg=19, nzg=3, nspec=3, seed=11)}
+CASES = {"two_species": dict(), "no_deposition": dict(wet=False, dry=False, nspec=1), "odd_sizes": dict(nxg=37, nyg=19, nzg=3, nspec=3, seed=11),
+         # three uncertainty classes: the files hold the class mean times nclassunc (concoutput.f90:296-345, mean_mod.f90); the
+         # fixture comes from the reference built with nclassunc = 3 (coref_r4c, oracle/build_ref.sh)
+         "classes": dict(nxg=30, nyg=20, nzg=3, nspec=2, seed=31, classes=3)}
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -56,6 +59,48 @@ def test_runs_and_signs():
     vals = np.frombuffer(b[q + 16:q + 16 + 4 * cr], np.float32)
     assert (ci, cr) == (3, 4) and idx == (32 + 1, 32 + 5, 32 + 7)      # + numxgrid*numygrid: kz is 1-based in the index
     assert list(np.sign(vals)) == [1, 1, -1, 1]
+
+
+@pytest.mark.ref
+def test_oracle_class_mean_equals_live_reference():
+    from oracle import oracle as orc, scenario_io as sio
+    if not os.access(os.path.join(os.path.dirname(sio.__file__), "_ref", "coref_r4c"), os.X_OK):
+        pytest.skip("flang-built reference (nclassunc = 3) not present (GPU box)")
+    co = syn.concoutput_case(nxg=41, nyg=23, nzg=4, nspec=3, seed=77, classes=3)
+    ref = sio.run_co_reference(co, kind="r4c")
+    got = orc.co_oracle(co)
+    assert len(ref) == 3
+    for name, b in ref.items():
+        assert got["_" + name[-3:]] == b, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("compute", [8, 4])
+def test_hip_concoutput_class_mean(built, tmp_path, compute):
+    """nclassunc = 3: the device sums the three class planes of gridunc / wetgridunc / drygridunc as mean_mod does
+    (mean times nclassunc, concoutput.f90:323-345) before the run-length compression; the files equal the oracle's, which
+    is pinned byte for byte to the reference built with nclassunc = 3 (tests/golden/co_classes_*.bin)."""
+    from flexpart_amd.engine import Engine
+    from oracle import oracle as orc
+    from test_oracle_cpu import golden_scenario
+    sc = syn.add_wet(syn.add_outgrid(golden_scenario("aerosol")))
+    syn.add_release_points(sc, xmass=[[1.0]], npart_rel=[int(sc["npart"])], ioutputforeachrelease=0, nclassunc=3)
+    eng = Engine(sc, compute_real_bytes=compute, host_real_bytes=4)
+    eng.run()
+    g, d = eng.grids()
+    w = eng.wetgrid()
+    na, nc, mp, nsp, nzg, nyg, nxg = eng.gshape
+    assert (na, nc, mp) == (1, 3, 1) and all((g[0, c] > 0).sum() > 100 for c in range(3))
+    case = syn.concoutput_case(nxg=nxg, nyg=nyg, nzg=nzg, nspec=nsp)
+    prefix = str(tmp_path / "grid_conc_20200101010000_")
+    eng.concoutput(3600, prefix, case["area"], case["volume"], outnum=4.0, wetdep=True, drydep=True, clear=True)
+    eng.close()
+    co = dict(outgrid=np.array([nxg, nyg, nzg, nsp, 1, 1, 3600], np.int32), outgeom=case["outgeom"], outheight=case["outheight"],
+              area=case["area"], volume=case["volume"], classes=np.array([3], np.int32),
+              gridunc=g[0, :, 0], wetgridunc=w[0, :, 0], drygridunc=d[0, :, 0])
+    want = orc.co_oracle(co)
+    for suffix, b in want.items():
+        assert open(prefix + suffix[1:], "rb").read() == b, suffix
 
 
 @pytest.mark.gpu

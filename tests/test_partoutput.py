@@ -143,6 +143,44 @@ def test_readpart_oracle_equals_reference_fixture(kind):
         assert np.array_equal(got[k], gold[k]), k
 
 
+@pytest.mark.parametrize("kind", ["r4", "r8"])
+def test_readpart_class_draw_equals_reference_fixture(kind):
+    """nclassunc = 3: every particle of a warm start draws its uncertainty class from ran1 (seed -8), in the order of the
+    records (readpartpositions.f90:142-143).  Fixture from the reference built with nclassunc = 3 (rpref_r4c / rpref_r8c)."""
+    from oracle import oracle as orc
+    sc = scenario(2)
+    dump = open(os.path.join(HERE, "golden", f"po_s2_{kind}.bin"), "rb").read()
+    gold = np.load(os.path.join(HERE, "golden", f"rp_s2_classes_{kind}.npz"))
+    rs = restart_setup(sc, 2)
+    rs["restart"][7] = 3
+    got = orc.rp_oracle(dump, rs, kind)
+    assert np.array_equal(got["nclass"], gold["nclass"]) and set(np.unique(gold["nclass"])) == {1, 2, 3}
+    for k in RP_KEYS + ("itrasplit",):
+        assert np.array_equal(got[k], gold[k]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_hip_readpartpositions_class_draw(built, tmp_path, kind):
+    """The same draw on the device path: fpx_readpartpositions(nclassunc = 3) replays the serial ran1 stream on the host and
+    hands every record its class; equal to the fixture of the reference built with nclassunc = 3."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    from oracle import oracle as orc
+    sc = scenario(2)
+    rb = 8 if kind == "r8" else 4
+    path = tmp_path / "partposit_end"
+    path.write_bytes(open(os.path.join(HERE, "golden", f"po_s2_{kind}.bin"), "rb").read())
+    gold = np.load(os.path.join(HERE, "golden", f"rp_s2_classes_{kind}.npz"))
+    sc2 = {k: v for k, v in sc.items() if k not in ("npart", "xtra1", "ytra1", "ztra1", "itra1", "itramem", "npoint", "nclass", "idt", "uap", "ucp", "uzp", "us", "vs", "ws", "cbt", "xmass1")}
+    b = Engine(sc2, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_PHILOX, max_particles=4000)
+    n, npc, itimein = b.readpartpositions(path, orc.juldate(20200101, 0, kind), orc.juldate(20200101, 10000, kind), mintime=5, nclassunc=3)
+    got = b.download()
+    b.close()
+    assert n == int(gold["numpart"])
+    for k in RP_KEYS:
+        assert np.array_equal(got[k], gold[k]), k
+
+
 @pytest.mark.ref
 @pytest.mark.parametrize("kind", ["r4", "r8"])
 def test_readpart_oracle_equals_live_reference(kind):
