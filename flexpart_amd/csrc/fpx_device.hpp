@@ -266,31 +266,43 @@ FPX_DEV double m_expp(double x) {
 // Branch-free: 40 instructions where the library's two-range erf costs 110 per wave as soon as the lanes
 // straddle |x| = 1.  Absolute error <= 5e-16 (the relative accuracy of erf near 0 is given up: the value is
 // only used as a term of O(1) sums).
+// The coefficients sit in constant memory: the wave fetches them with three scalar loads (s_load_dwordx16/x4) instead of
+// materialising 18 fp64 literals with 36 s_mov_b32 per call -- a wave issues one instruction per turn of its SIMD, so every
+// scalar instruction it spends is a turn in which it cannot feed the VALU (three waves per SIMD do not hide that).
+__constant__ double kErfC[18] = {      // not static, not const: a constant the compiler could fold back into literals
+  -4.6179706490756721764e-8, -2.4893389607188758124e-7, -2.1766619811183263845e-7, 1.3314749826389837962e-6,
+  2.1314123772486134504e-6, -8.0027446235445720124e-6, -1.2872811953274865798e-5, 6.4058505135542794022e-5,
+  4.52577749220917884e-5, -5.970618059279705004e-4, 7.0774621626041840357e-4, 4.2691363041920969877e-3,
+  -2.439249930876277646e-2, 7.1665837199359721633e-2, -1.5011593650098095142e-1, 2.4560380171230996017e-1,
+  -3.2623356004303588051e-1, 1.7900115118138999674e-1};
 template <typename T>
 FPX_DEV T m_erf_e(T x, T E) {
   const T ax = x < (T)0 ? -x : x;
   const T xc = ax < (T)6.5 ? ax : (T)6.5;
   const T t = (xc - (T)3.0) * m_rcp(xc + (T)3.0);
-  T p = (T)-4.6179706490756721764e-8;
-  p = p * t + (T)-2.4893389607188758124e-7;
-  p = p * t + (T)-2.1766619811183263845e-7;
-  p = p * t + (T)1.3314749826389837962e-6;
-  p = p * t + (T)2.1314123772486134504e-6;
-  p = p * t + (T)-8.0027446235445720124e-6;
-  p = p * t + (T)-1.2872811953274865798e-5;
-  p = p * t + (T)6.4058505135542794022e-5;
-  p = p * t + (T)4.52577749220917884e-5;
-  p = p * t + (T)-5.970618059279705004e-4;
-  p = p * t + (T)7.0774621626041840357e-4;
-  p = p * t + (T)4.2691363041920969877e-3;
-  p = p * t + (T)-2.439249930876277646e-2;
-  p = p * t + (T)7.1665837199359721633e-2;
-  p = p * t + (T)-1.5011593650098095142e-1;
-  p = p * t + (T)2.4560380171230996017e-1;
-  p = p * t + (T)-3.2623356004303588051e-1;
-  p = p * t + (T)1.7900115118138999674e-1;
+  T p = (T)kErfC[0];
+#pragma unroll
+  for (int i = 1; i < 18; i++) p = p * t + (T)kErfC[i];
   const T r = (T)1.0 - E * p;
   return x < (T)0 ? -r : r;
+}
+// Two error functions at once (cbl.f90:195-204 needs erf(aperfa) and erf(aperfb)): one fetch of the coefficients serves both
+// Horner chains.  The pointer passes through an empty asm so that the scalar loads stay where they are used -- hoisted to
+// the kernel's prologue (the table is loop-invariant) the 36 SGPRs would be spilled to vector lanes for the whole kernel.
+template <typename T>
+FPX_DEV void m_erf_e2(T xa, T Ea, T xb, T Eb, T &ra, T &rb) {
+  typedef const double __attribute__((address_space(4))) *const_ptr;      // constant address space: uniform loads are scalar loads
+  const_ptr c = (const_ptr)kErfC;
+  asm volatile("" : "+s"(c));
+  const T aa = xa < (T)0 ? -xa : xa, ab = xb < (T)0 ? -xb : xb;
+  const T ca = aa < (T)6.5 ? aa : (T)6.5, cb = ab < (T)6.5 ? ab : (T)6.5;
+  const T ta = (ca - (T)3.0) * m_rcp(ca + (T)3.0), tb = (cb - (T)3.0) * m_rcp(cb + (T)3.0);
+  T pa = (T)c[0], pb = (T)c[0];
+#pragma unroll
+  for (int i = 1; i < 18; i++) { const T k = (T)c[i]; pa = pa * ta + k; pb = pb * tb + k; }
+  const T qa = (T)1.0 - Ea * pa, qb = (T)1.0 - Eb * pb;
+  ra = xa < (T)0 ? -qa : qa;
+  rb = xb < (T)0 ? -qb : qb;
 }
 // x**y for the reference's non-integer exponents (0.33333, 0.66666, 0.8 ...).  fp64: exp(y*log(x)),
 // relative error <= ~|y ln x| ulp (a few 1e-16 here) at a fraction of the cost of the
@@ -1088,7 +1100,8 @@ FPX_DEV void cbl(const ST &S, int ldirect, R wp, R zp, R wt /* wst^3 * transitio
   const R Ub = sigmawb * (bluarw * (dsigmawb * (wold2 * isb2 + K(1.)) - wdf) + sigmawb * (dbluarw + rx * bluarw));
   // exp(-aperf^2) from exp(-d^2/2): aperf = d*usurad2 and usurad2^2 - 0.5 = 5.9e-12 (the reference's 10-digit 1/sqrt(2))
   const R cu = usurad2 * usurad2 - K(0.5);
-  const R erfa = m_erf_e(aperfa, ea - ea * (da2 * cu)), erfb = m_erf_e(aperfb, eb - eb * (db2 * cu));
+  R erfa, erfb;
+  m_erf_e2(aperfa, ea - ea * (da2 * cu), aperfb, eb - eb * (db2 * cu), erfa, erfb);
   const R Phi = K(0.5) * (Tb * erfb - Ta * erfa) + Ua * pa + Ub * pb;
   const R Q = timedir * ((da * isa) * apa + (db * isb) * bpb);
   ath = m_rcp(ptot) * (-(C0 / K(2.)) * alfa * Q + Phi);
