@@ -1678,6 +1678,9 @@ struct Engine : EngineBase {
     if (conv_scr) (void)hipFree(conv_scr);
     if (conv_scan_tmp) (void)hipFree(conv_scan_tmp);
     if (conv_alive) (void)hipFree(conv_alive);
+    if (rel_flags_buf) (void)hipFree(rel_flags_buf);
+    if (rel_rank_buf) (void)hipFree(rel_rank_buf);
+    if (rel_tmp_buf) (void)hipFree(rel_tmp_buf);
     if (d_sort_rec) (void)hipFree(d_sort_rec);
     if (red_pin) (void)hipHostFree(red_pin);
     if (comm) (void)ncclCommDestroy(comm);
@@ -2524,6 +2527,10 @@ struct Engine : EngineBase {
     std::vector<long long> first(np + 1, 0), gfirst(np, 0);
     long long gcount = rel_global_count;
     std::vector<H> mass((size_t)ns * np, (H)0), xp1(np), xaux(np), yp1(np), yaux(np), zp1(np), zaux(np);
+    // the fractional carry of every release point advances in a copy: the host's xmasssave is written only when the call
+    // succeeds ("nothing is released" on error -- a corrected retry must release what the reference would)
+    std::vector<H> xsave(xmasssave, xmasssave + np);
+    auto commit_carry = [&]() { for (int i = 0; i < np; i++) xmasssave[i] = xsave[i]; };
     bool any_p3 = false;
     for (int i = 0; i < np; i++) {
       long long numrel = 0;
@@ -2553,9 +2560,9 @@ struct Engine : EngineBase {
           H rfraction = (H)std::fabs((double)((H)rel_npart_h[i] * (H)cfg.lsynctime / (H)(rel.end[i] - rel.start[i])));
           if (itime == rel.start[i] || itime == rel.end[i]) rfraction = rfraction / (H)2.;
           rfraction = rfraction * avg;
-          rfraction = rfraction + xmasssave[i];
+          rfraction = rfraction + xsave[i];
           numrel = (long long)(int)rfraction;
-          xmasssave[i] = rfraction - (H)(int)numrel;
+          xsave[i] = rfraction - (H)(int)numrel;
         } else numrel = rel_npart_h[i];
         for (int k = 0; k < ns; k++) mass[(size_t)k * np + i] = (H)rel_xmass_h[(size_t)k * np + i] / (H)rel_npart_h[i] * tc[k] / avg;
         if (numrel > 0 && rel.kindz[i] == 3) any_p3 = true;
@@ -2576,7 +2583,7 @@ struct Engine : EngineBase {
     }
     const long long ntotal = first[np];
     if (nreleased) *nreleased = ntotal;
-    if (ntotal == 0) { rel_global_count = gcount; return 0; }
+    if (ntotal == 0) { rel_global_count = gcount; commit_carry(); return 0; }
     const bool dens = rel.ind_rel == 1 || rel.ind_rel == 3 || rel.ind_rel == 4;
     for (int l = 0; l < V.numbnests; l++) {
       if (!rel_nest_oro[l]) return fail(FPX_ERR_STATE, "releaseparticles: oron of every nest is needed (fpx_upload_diag_nest_fields slot 0)");
@@ -2597,8 +2604,9 @@ struct Engine : EngineBase {
     H *d_pts = nullptr, *d_mass = nullptr, *d_uni = nullptr, *d_rho = nullptr;
     short *d_kindz = nullptr;
     void *tmp = nullptr;
-    hipError_t e = mal(&flags, (size_t)cap);
-    if (e == hipSuccess) e = mal(&rank, (size_t)cap);
+    // the capacity-sized work arrays are kept between calls (grow-only): hipFree is a device-wide synchronisation, and at
+    // the bench size they are 0.8 GB per call
+    hipError_t e = rel_scratch((size_t)cap, &flags, &rank) ? hipErrorOutOfMemory : hipSuccess;
     if (e == hipSuccess) e = mal(&target, (size_t)ntotal);
     if (e == hipSuccess) e = mal(&d_max, 1);
     if (e == hipSuccess) e = mal(&d_first, (size_t)np + 1);
@@ -2610,8 +2618,7 @@ struct Engine : EngineBase {
     size_t tb = 0;
     if (e == hipSuccess) {
       (void)rocprim::exclusive_scan(nullptr, tb, flags, rank, 0u, (size_t)cap, rocprim::plus<unsigned int>(), stream);
-      e = hipMalloc(&tmp, std::max<size_t>(tb, 16));
-      if (e == hipSuccess) mine.push_back(tmp);
+      e = rel_scan_tmp(tb, &tmp) ? hipErrorOutOfMemory : hipSuccess;
     }
     if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("releaseparticles: ") + hipGetErrorString(e)); }
     const int nbc = (int)((cap + kBlock - 1) / kBlock);
@@ -2676,7 +2683,38 @@ struct Engine : EngineBase {
     *numpart_io = numpart;
     *npc_io = (int32_t)(*npc_io + ntotal);
     rel_global_count = gcount;
+    commit_carry();
     maybe_new = true;
+    return 0;
+  }
+  // grow-only scratch of fpx_releaseparticles / fpx_split_particles: two unsigned arrays of n elements and the scan's temporary
+  unsigned int *rel_flags_buf = nullptr, *rel_rank_buf = nullptr;
+  size_t rel_buf_n = 0;
+  void *rel_tmp_buf = nullptr;
+  size_t rel_tmp_bytes = 0;
+  int rel_scratch(size_t n, unsigned int **flags, unsigned int **rank) {
+    if (n > rel_buf_n) {
+      (void)hipStreamSynchronize(stream);
+      if (rel_flags_buf) (void)hipFree(rel_flags_buf);
+      if (rel_rank_buf) (void)hipFree(rel_rank_buf);
+      rel_flags_buf = rel_rank_buf = nullptr; rel_buf_n = 0;
+      if (hipMalloc(&rel_flags_buf, n * 4) != hipSuccess) return 1;
+      if (hipMalloc(&rel_rank_buf, n * 4) != hipSuccess) { (void)hipFree(rel_flags_buf); rel_flags_buf = nullptr; return 1; }
+      rel_buf_n = n;
+    }
+    *flags = rel_flags_buf; *rank = rel_rank_buf;
+    return 0;
+  }
+  int rel_scan_tmp(size_t bytes, void **tmp) {
+    bytes = std::max<size_t>(bytes, 16);
+    if (bytes > rel_tmp_bytes) {
+      (void)hipStreamSynchronize(stream);
+      if (rel_tmp_buf) (void)hipFree(rel_tmp_buf);
+      rel_tmp_buf = nullptr; rel_tmp_bytes = 0;
+      if (hipMalloc(&rel_tmp_buf, bytes) != hipSuccess) return 1;
+      rel_tmp_bytes = bytes;
+    }
+    *tmp = rel_tmp_buf;
     return 0;
   }
   int releaseparticles(int itime, int64_t *numpart_io, int32_t *npc_io, void *xmasssave, void *rho_rel, int64_t *nreleased) override {
@@ -2694,13 +2732,12 @@ struct Engine : EngineBase {
     const long long n = numpart, room = P.cap - n;
     unsigned int *flags = nullptr, *rank = nullptr;
     void *tmp = nullptr;
-    auto cleanup = [&]() { if (flags) (void)hipFree(flags); if (rank) (void)hipFree(rank); if (tmp) (void)hipFree(tmp); };
-    hipError_t e = hipMalloc(&flags, (size_t)n * 4);
-    if (e == hipSuccess) e = hipMalloc(&rank, (size_t)n * 4);
+    auto cleanup = [&]() {};      // the work arrays are the engine's grow-only scratch (rel_scratch)
+    hipError_t e = rel_scratch((size_t)n, &flags, &rank) ? hipErrorOutOfMemory : hipSuccess;
     size_t tb = 0;
     if (e == hipSuccess) {
       (void)rocprim::exclusive_scan(nullptr, tb, flags, rank, 0u, (size_t)n, rocprim::plus<unsigned int>(), stream);
-      e = hipMalloc(&tmp, std::max<size_t>(tb, 16));
+      e = rel_scan_tmp(tb, &tmp) ? hipErrorOutOfMemory : hipSuccess;
     }
     if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("split_particles: ") + hipGetErrorString(e)); }
     const int nb = (int)((n + kBlock - 1) / kBlock);

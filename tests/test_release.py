@@ -161,6 +161,7 @@ def test_release_refuses_more_particles_than_storage_spaces(built):
     rs = syn.release_case(maxpart=450)        # 474 particles at itime 0 against 80 vacant + 50 unused spaces
     eng = _engine(rs, "r8", RNG_TABLE_SEQ)
     before = eng.download()
+    carry = eng.xmasssave.copy()
     with pytest.raises(FpxError):
         eng.releaseparticles(0)
     after = eng.download()
@@ -168,6 +169,9 @@ def test_release_refuses_more_particles_than_storage_spaces(built):
     assert eng.n == 400 and eng.numparticlecount == 0
     for k in ("xtra1", "itra1", "npoint", "xmass1"):
         assert np.array_equal(before[k], after[k]), k
+    # the fractional carry of the release points (xmasssave) has not moved either: a retry with enough storage spaces
+    # releases exactly what the reference would
+    assert np.array_equal(eng.xmasssave, carry)
 
 
 @pytest.mark.gpu
