@@ -3867,7 +3867,9 @@ struct Engine : EngineBase {
       typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *, unsigned int *);
       const bool nest = V.numbnests > 0;
       const prep_fn f = (prep_fn)step_kernel_prep((int)sizeof(R), cfg.drydep != 0, init, polar, nest);
-      f<<<nb, kBlock, 0, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag, d_pbl_ctr);
+      static const int prep_pad = getenv("FPX_PREP_LDS_PAD") ? atoi(getenv("FPX_PREP_LDS_PAD")) : 0;   // experiments: unused dynamic LDS lowers the occupancy
+      if (prep_pad > 0) HIPCHK(hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, prep_pad));
+      f<<<nb, kBlock, (size_t)prep_pad, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag, d_pbl_ctr);
       maybe_new = false;
     }
     HIPCHK(hipEventRecord(ev.e[4], stream));
