@@ -1773,6 +1773,30 @@ struct LoopCtx {                // register-resident state of a lane across pass
   int nsp;                      // species of the settling pick (aerosol kernels only)
 };
 
+// adv_begin for a particle whose grid and mixing height k_prep has already determined and handed over in its record (the
+// refill of the Langevin kernel): no dependent memory access on the mother grid, one (the nest's descriptor) inside a nest.
+template <typename R>
+FPX_DEV void adv_begin_known(const View<R> &V, double xt, double yt, int ngrid, R h, LoopCtx<R> &L, R &ddx, R &ddy) {
+  int nyrows = V.ny, nxcols = V.nx;
+  R xr, yr;
+  L.ngrid = ngrid;
+  if (ngrid > 0) {   // advance.f90:191-197 nested grid coordinates
+    const NestDesc<R> &N = V.nest[ngrid - 1];
+    xr = (R)((xt - (double)N.xl) * (double)N.xres);
+    yr = (R)((yt - (double)N.yl) * (double)N.yres);
+    L.ix = (int)xr; L.jy = (int)yr;
+    nyrows = N.ny; nxcols = N.nx;
+  } else {
+    xr = (R)xt; yr = (R)yt;
+    L.ix = (int)xt; L.jy = (int)yt;
+  }
+  L.ixp = L.ix + 1; L.jyp = L.jy + 1;
+  if (L.jyp >= nyrows) L.jyp = L.jyp - 1;   // advance.f90:228-231
+  if (L.ixp >= nxcols) L.ixp = nxcols - 1;
+  L.h = h;
+  ddx = xr - (R)L.ix; ddy = yr - (R)L.jy;   // interpol_all.f90:57-58
+}
+
 template <typename R>
 FPX_DEV Cell<R> stash_cell(const LoopCtx<R> &L, const Stash<R> &S) {
   Cell<R> C;
@@ -1797,29 +1821,39 @@ FPX_DEV void fetch_level_pair(const View<R> &V, const Fld<R> &F, const TimeW<R> 
   const R ddx = S.get(S_DDX), ddy = S.get(S_DDY);          // as cell_setup, interpol_all.f90:59-64
   const R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
   R a3[2][2][3], a2[2][2][2];                               // [level][physical slot][variable]
+  typedef const R __attribute__((address_space(1))) *gptr;  // the packs live in device memory: global, not flat, loads
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const int jyc = (c & 2) ? L.jyp : L.jy, ixc = (c & 1) ? L.ixp : L.ix;
     const R pw = c == 0 ? rddx * rddy : c == 1 ? ddx * rddy : c == 2 ? rddx * ddy : ddx * ddy;
     const unsigned int cell = (unsigned int)(jyc * F.nx + ixc) * (unsigned int)V.nz + (unsigned int)(indz - 1);   // < nx*ny*nz
-    const R *p = F.w3 + (size_t)cell * 6;
-    const R *q = F.r2 + (size_t)cell * 4;
+    const gptr p = (gptr)(F.w3 + (size_t)cell * 6);
+    const gptr q = (gptr)(F.r2 + (size_t)cell * 4);
+    // the 20 values of a corner are requested together and used after ONE wait (left to itself the compiler, short of
+    // registers, waited after every second load: 17 dependent memory round trips per pass instead of 4)
+    R x3[12], x2[8];
+#pragma unroll
+    for (int k = 0; k < 12; k++) x3[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) x2[k] = q[k];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int lev = 0; lev < 2; lev++) {
 #pragma unroll
       for (int sl = 0; sl < 2; sl++) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-          const R x = p[(lev * 2 + sl) * 3 + k];
+          const R x = x3[(lev * 2 + sl) * 3 + k];
           a3[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a3[lev][sl][k]);
         }
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-          const R x = q[(lev * 2 + sl) * 2 + k];
+          const R x = x2[(lev * 2 + sl) * 2 + k];
           a2[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a2[lev][sl][k]);
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
   const bool h1 = V.m1 != 0, h2 = V.m2 != 0;               // wave-uniform: physical slot of memind(1) / memind(2)
 #pragma unroll

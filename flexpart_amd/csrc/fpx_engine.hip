@@ -432,7 +432,8 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
 // end of its last pass (out), k_pbl_finish reads it and writes the particle arrays, coalesced.
 template <typename R>
 struct alignas(16 * sizeof(R)) PblRecord {
-  // in : v[0..3] = ust, wst, ol, CBL transition (interpol_all.f90:80-107, cbl.f90:79-81); i[0] = nrand at entry
+  // in : v[0..3] = ust, wst, ol, CBL transition (interpol_all.f90:80-107, cbl.f90:79-81); v[4] = mixing height of the cell
+  //      (advance.f90:236-262); i[0] = nrand at entry, i[1] = ngrid
   // out: v[0..3] = dxsave, dysave, dawsave, dcwsave; v[4..6] = interpol_mod u, v, w of the last pass;
   //      v[7..10] = zt, up, vp, wp; i[0] = nrand, i[1] = itimec, i[2] = rc | indz << 2, i[3] = ldt, i[4] = icbt
   R v[11];
@@ -518,7 +519,8 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     {
       PblRecord<R> &r = Q.rec[s];
       r.v[0] = B.ust; r.v[1] = B.wst; r.v[2] = B.ol; r.v[3] = B.transition;
-      r.i[0] = A.nrand;
+      r.v[4] = A.h;
+      r.i[0] = A.nrand; r.i[1] = A.ngrid;
     }
     // Regime class of the particle's PBL passes (hanna.f90:42,59,91 and advance.f90:405-406).  The
     // work list is the slots stably sorted by this 3-bit key: class by class, each class in slot
@@ -1059,7 +1061,13 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
   // measured 429 -> 395 ms.  One atomic per 64 refills is still negligible.
   const unsigned int chunk = 64u;
   unsigned int cur = 0, end = 0;     // wave-uniform: the unread part of the wave's chunk
+  unsigned int cbase = 0;            // wave-uniform: first entry of the chunk
+  unsigned int ahead = 0;            // lane l: entry cbase + l of the list (the whole chunk, read with the claim)
   bool out_of_chunks = false;        // wave-uniform
+#ifdef FPX_LANE_STATS
+  const unsigned long long t_s = wall_clock64();   // 100 MHz; timeline of the wave: start, list exhausted, end
+  unsigned long long t_x = 0;
+#endif
 
   bool have = false;
   unsigned int s = 0, pid = 0;
@@ -1081,45 +1089,58 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
         const unsigned long long c0 = (unsigned long long)c * chunk;
         if (c0 >= nlist) {
           out_of_chunks = true;
+#ifdef FPX_LANE_STATS
+          t_x = wall_clock64();
+#endif
         } else {
-          cur = (unsigned int)c0;
+          cur = cbase = (unsigned int)c0;
           end = min(cur + chunk, nlist);
+          ahead = pbl_list[min(cbase + (unsigned int)lane, nlist - 1u)];
         }
       }
-      if (!out_of_chunks && !have) {
+      if (!out_of_chunks) {
+        // A refill is ONE memory round trip: the list entry comes from the chunk read above (cross-lane), everything else
+        // depends on the slot only and is requested together -- grid and mixing height travel in the record k_prep wrote.
+        // (Before: list entry -> state -> mixing height -> six stash values one after the other = nine dependent round
+        // trips, with two of the wave's lanes active, in 60 % of the passes.)
         const unsigned int rank = __popcll(need & ((1ull << lane) - 1ull));
         const unsigned int my = cur + rank;
-        if (my < end) {
+        const unsigned int s_new = (unsigned int)__builtin_amdgcn_ds_bpermute((int)(min(my - cbase, 63u) << 2), (int)ahead);   // all lanes
+        if (!have && my < end) {
           FPX_LANES(st, 8);
-          s = pbl_list[my];
-          xt = P.xt[s]; yt = P.yt[s]; zt = P.zt[s];
-          wp = P.wp[s];
-          ldt = P.idt[s]; icbt = P.cbt[s];
-          pid = P.pid[s];
+          s = s_new;
+          const PblRecord<R> *rp = Q.rec + s;
+          const double l_xt = P.xt[s], l_yt = P.yt[s];
+          const R l_zt = P.zt[s], l_wp = P.wp[s], l_up = P.up[s], l_vp = P.vp[s];
+          const int l_idt = P.idt[s];
+          const short l_cbt = P.cbt[s];
+          const unsigned int l_pid = P.pid[s];
+          const R r_ust = rp->v[0], r_wst = rp->v[1], r_ol = rp->v[2], r_trans = rp->v[3], r_h = rp->v[4];
+          const int r_nrand = rp->i[0], r_ngrid = rp->i[1];
+          int l_npoint = 0;
+          if (!LEAN && V.lsettling) l_npoint = P.npoint[s];
+          __builtin_amdgcn_sched_barrier(0);   // every load above is issued before the first value is used
+          xt = l_xt; yt = l_yt; zt = l_zt; wp = l_wp; ldt = l_idt; icbt = l_cbt; pid = l_pid;
           {
-            AdvCtx<R> A0;
-            adv_begin(V, xt, yt, zt, itime, Q.rec[s].i[0], A0);
-            A.ngrid = A0.ngrid; A.ix = A0.ix; A.jy = A0.jy; A.ixp = A0.ixp; A.jyp = A0.jyp;
-            A.h = A0.h; A.itimec = A0.itimec; A.nrand = A0.nrand;
-            A.nsp = (!LEAN && V.lsettling) ? settling_species(V, P.npoint[s]) : 0;
-            S.put(S_DDX, A0.xr - (R)A0.ix); S.put(S_DDY, A0.yr - (R)A0.jy);   // interpol_all.f90:57-58
+            R ddx, ddy;
+            adv_begin_known(V, xt, yt, r_ngrid, r_h, A, ddx, ddy);
+            A.itimec = itime; A.nrand = r_nrand;
+            A.nsp = (!LEAN && V.lsettling) ? settling_species(V, l_npoint) : 0;
+            S.put(S_DDX, ddx); S.put(S_DDY, ddy);
           }
           S.put(S_DX, (R)0); S.put(S_DY, (R)0); S.put(S_DAW, (R)0); S.put(S_DCW, (R)0);
           S.put(S_W, (R)0);
-          S.put(S_UP, P.up[s]); S.put(S_VP, P.vp[s]);
-          {
-            const PblRecord<R> &r = Q.rec[s];
-            S.put(S_UST, r.v[0]); S.put(S_WST, r.v[1]); S.put(S_OL, r.v[2]);
-            S.put(S_TRANS, (r.v[1] * r.v[1] * r.v[1]) * r.v[3]);   // (wst**3)*transition, cbl.f90:103-104
-          }
+          S.put(S_UP, l_up); S.put(S_VP, l_vp);
+          S.put(S_UST, r_ust); S.put(S_WST, r_wst); S.put(S_OL, r_ol);
+          S.put(S_TRANS, (r_wst * r_wst * r_wst) * r_trans);   // (wst**3)*transition, cbl.f90:103-104
           if (!LEAN && V.drydep) {
 #pragma unroll
             for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
           }
           have = true;
         }
+        cur = min(cur + (unsigned int)__popcll(need), end);
       }
-      if (!out_of_chunks) cur = min(cur + (unsigned int)__popcll(need), end);
     }
     if (!__any(have)) {
       if (out_of_chunks) break;   // no lane has work and the list is used up: the grid drains
@@ -1151,6 +1172,17 @@ __global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, 
       }
     }
   }
+#ifdef FPX_LANE_STATS
+  if (lane == 0) {
+    const unsigned long long t_e = wall_clock64();
+    atomicAdd(&st->lanes[11][0], 1ull);
+    atomicAdd(&st->lanes[11][1], t_x - t_s);            // sum over waves: start -> list exhausted
+    atomicAdd(&st->lanes[12][0], t_e - t_s);            // sum over waves: start -> end
+    atomicMax(&st->lanes[12][1], t_e - t_s);            // longest wave
+    atomicMax(&st->lanes[13][0], ~(t_x - t_s));         // ~(first wave to see the list exhausted)
+    atomicMax(&st->lanes[13][1], t_e - t_x);            // longest drain of one wave
+  }
+#endif
 }
 
 // diagnostics: the fp64 math helpers of fpx_device.hpp on plain arrays (fpx_math_probe)

@@ -775,7 +775,14 @@ class Engine:
         out = (C.c_uint64 * 32)()
         check(self.lib.fpx_lane_stats(self.h, out, 32, int(reset)), "fpx_lane_stats")
         names = ("pass", "substep", "cbl", "gauss_cblflag", "exp_form", "hs_neutral", "hs_unstable", "hs_stable", "refill", "handover", "outer_loop")
-        return {nm: (int(out[2 * i]), (out[2 * i + 1] / out[2 * i]) if out[2 * i] else 0.0) for i, nm in enumerate(names)}
+        d = {nm: (int(out[2 * i]), (out[2 * i + 1] / out[2 * i]) if out[2 * i] else 0.0) for i, nm in enumerate(names)}
+        nw = int(out[22])
+        if nw:   # timeline of the persistent waves, all launches together (100 MHz ticks -> ms)
+            ms = 1e-5
+            d["timeline_ms"] = (nw, {"mean_start_to_list_exhausted": out[23] / nw * ms, "mean_start_to_end": out[24] / nw * ms,
+                                     "longest_wave": out[25] * ms, "first_exhaustion": ((~out[26]) & (2**64 - 1)) * ms,
+                                     "longest_drain": out[27] * ms})
+        return d
 
     def comm_init(self, uid, nranks, rank):
         buf = (C.c_char * 128).from_buffer_copy(uid)
