@@ -1498,6 +1498,7 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const 
   };
 #pragma unroll
   for (int c = 0; c < FPX_GATHER_DEPTH && c < 4; c++) issue(c);
+  if (FPX_GATHER_DEPTH >= 4) late();
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from issuing all 24 loads first
@@ -2153,9 +2154,10 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
 
 // label 99 to the end: advance.f90:728-985.  Returns nstop (0 or 3).
 // POLAR = false compiles the stereographic-map branch out (grids without poles)
-template <typename R, typename RNG, bool POLAR = true, bool MOTHER = false>
+// LATE: a callable that issues the caller's loads with the last column of the Petterssen gather (see interp_wind)
+template <typename R, typename RNG, bool POLAR = true, bool MOTHER = false, typename LATE = NoLate>
 FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, PState<R> &P, AdvCtx<R> &A,
-                       R usig, R vsig, R wsig) {
+                       R usig, R vsig, R wsig, const LATE &late = LATE()) {
   const R eps = V.eps;
   const R eps2 = K(1.e-9);
   int nrand = A.nrand;
@@ -2183,12 +2185,13 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
     A.dysave = A.dysave + vy;
     move_xy<R, POLAR>(V, A.ngrid, P.xt, P.yt, A.dxsave, A.dysave, (R)V.ldirect);
   }
-  if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) return 3;   // advance.f90:784-813
+  // (every way out of this function runs the caller's late loads exactly once)
+  if (boundary(V, hgt, P.xt, P.yt, P.zt, eps)) { late(); return 3; }   // advance.f90:784-813
 
   // Petterssen correction, advance.f90:829-985
-  if (P.ldt != abs(V.lsynctime)) return 0;
-  if (abs(itime + P.ldt * V.ldirect) > abs(V.memtime1)) return 0;
-  if (pick_grid<R, MOTHER>(V, P.xt, P.yt) != A.ngrid) return 0;
+  if (P.ldt != abs(V.lsynctime)) { late(); return 0; }
+  if (abs(itime + P.ldt * V.ldirect) > abs(V.memtime1)) { late(); return 0; }
+  if (pick_grid<R, MOTHER>(V, P.xt, P.yt) != A.ngrid) { late(); return 0; }
   R xr, yr;
   int nyrows = V.ny, nxcols = V.nx;
   if (A.ngrid > 0) {   // advance.f90:862-866
@@ -2209,7 +2212,7 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
     R d0, d1, d2;
     Cell<R> C;
     cell_setup(C, ix, jy, ixp, jyp, xr, yr);
-    interp_wind<R, false>(V, hgt, fld_of(V, A.ngrid), C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2);
+    interp_wind<R, false>(V, hgt, fld_of(V, A.ngrid), C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2, late);
   }
   if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt, A.nsp);   // advance.f90:893-906
   u = (u - A.u) / K(2.);

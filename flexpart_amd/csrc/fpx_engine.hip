@@ -366,9 +366,25 @@ __device__ __forceinline__ int advance_start_index(const View<R> &V, const SeqRn
 // epilogue timemanager.f90:630-708 + write-back of the particle
 // TURB: also write up, vp, cbt -- changed only by initialize() and by the Langevin loop; a particle that
 // was above the mixing layer for the whole step keeps them (advance.f90:629-708 does not touch them)
+// What the epilogue reads of the particle itself (release point, masses): fetched by the caller together with its last
+// gather (EpiPre::load inside a `late` hook), so that the epilogue starts with them instead of with two more dependent
+// memory round trips at the tail of a latency-bound kernel.
+// (the release point and the first species' mass: three registers; the kernels have none to spare for more)
+template <typename R>
+struct EpiPre {
+  int npoint;
+  R xm0;
+  template <bool DRYDEP>
+  __device__ __forceinline__ void load(const View<R> &V, const GridP<R> &Gp, const Parts<R> &P, long long s) {
+    const bool massfract = V.mdomainfill == 0 && V.mquasilag == 0;
+    npoint = ((massfract && V.numpoint > 1) || (DRYDEP && Gp.on)) ? P.npoint[s] : 1;
+    xm0 = P.xmass1[s];
+  }
+};
+
 template <typename R, bool DRYDEP, bool TURB = true>
 __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> &Gp, Parts<R> &P, long long s, int itime, int itramem,
-                                               int nstop, const PState<R> &ps, const R *prob, Stats *st) {
+                                               int nstop, const PState<R> &ps, const R *prob, Stats *st, const EpiPre<R> *pre = nullptr) {
   int itra1;
   if (nstop > 1) {
     itra1 = kDead;
@@ -378,14 +394,19 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
     R xmassfract = (R)0;
     // release point of the particle: xmass(npoint(j),ks), npart(npoint(j)), timemanager.f90:663-666
     const bool massfract = V.mdomainfill == 0 && V.mquasilag == 0;
-    const int npoint = (massfract || (DRYDEP && Gp.on)) ? P.npoint[s] : 1;
+    // (with one release point every index into the point tables is clamped to it: npoint(j) is not needed, and the
+    // table loads below do not wait for it)
+    const int npoint = pre ? pre->npoint : ((massfract && V.numpoint > 1) || (DRYDEP && Gp.on)) ? P.npoint[s] : 1;
     const int kr = release_index(V, npoint);
     const R npart_r = massfract ? (R)V.rel_npart[kr] : (R)0;
+    R xmr_all[kMaxSpec];   // the release point's table entries in one round trip, not one per species
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++) xmr_all[ks] = (massfract && ks < V.nspec) ? V.rel_xmass[(size_t)ks * V.numpoint + kr] : (R)0;
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) {
       if (ks < V.nspec) {
         R decfact = V.decay[ks] > (R)0 ? m_exp(-(R)abs(V.lsynctime) * V.decay[ks]) : (R)1;
-        R xm = P.xmass1[(size_t)ks * P.cap + s];
+        R xm = (pre && ks == 0) ? pre->xm0 : P.xmass1[(size_t)ks * P.cap + s];
         if (DRYDEP && V.drydepspec[ks]) {
           // timemanager.f90:650-656; drydeposit is real(dep_prec): 4 bytes in every build
           float drydeposit = (float)(xm * prob[ks] * decfact);
@@ -403,7 +424,7 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
         } else xm = xm * decfact;
         if (DRYDEP || V.decay[ks] > (R)0) P.xmass1[(size_t)ks * P.cap + s] = xm;
         if (massfract) {   // timemanager.f90:663-666
-          const R xmr = V.rel_xmass[(size_t)ks * V.numpoint + kr];
+          const R xmr = xmr_all[ks];
           if (xmr > (R)0) xmassfract = m_max(xmassfract, npart_r * xm / xmr);
         } else {
           xmassfract = (R)1;
@@ -463,12 +484,18 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
   PState<R> ps;
   const int itra1_in = P.itra1[s];
   ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
-  const int itramem = P.itramem[s];
-  const unsigned int pid = P.pid[s];
+  int itramem = P.itramem[s];
+  unsigned int pid = P.pid[s];
+  // ONE round trip: without this the compiler sinks each load into the branch that first needs it (itra1 -> wait -> xt ->
+  // wait -> yt -> wait -> zt ...: five dependent round trips at the head of a latency-bound kernel)
+  {
+    int due_key = itra1_in;
+    asm volatile("" : "+v"(due_key), "+v"(ps.xt), "+v"(ps.yt), "+v"(ps.zt), "+v"(itramem), "+v"(pid));
+    if (due_key != itime) { pbl_flag[s] = 7; return; }    // timemanager.f90:537
+  }
   // key 7 = not due; 6 = due, finished in this kernel (above the PBL); 1..4 = PBL particle of that regime class.
   // The counts (particles due, length of the PBL work list) are read off the sorted keys by
   // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
-  if (itra1_in != itime) { pbl_flag[s] = 7; return; }    // timemanager.f90:537
 
   // a non-finite or out-of-grid position would index outside the fields (the reference
   // would read arbitrary memory): terminate the particle instead
@@ -545,6 +572,8 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     }
   };
   above_step<R, Rng<R>, true>(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig, late);
+  // (fetching the epilogue's npoint / xmass1 with the Petterssen gather was tried here: the three registers spill at the
+  // three-wave budget of this kernel; k_pbl_finish has them)
   const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
   R prob[kMaxSpec];
 #pragma unroll
@@ -1251,11 +1280,20 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
       cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
       level_pair_sigma(V, fld_of(V, A.ngrid), C, W, indz, usig, vsig, wsig);   // advance.f90:604-606
     }
-    const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+    // what the epilogue reads of the particle travels with the last gather
+    EpiPre<R> pre;
     R prob[kMaxSpec];
+    int itramem = 0;
+    unsigned int sl = s;
+    auto late_epi = [&]() {
+      asm volatile("" : "+v"(sl));
+      pre.template load<DRYDEP>(V, Gp, P, sl);
+      itramem = P.itramem[sl];
 #pragma unroll
-    for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (DRYDEP && ks < V.nspec) ? Q.prob[(size_t)ks * P.cap + s] : (R)0;
-    epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, P.itramem[s], nstop, ps, prob, st);
+      for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (DRYDEP && ks < V.nspec) ? Q.prob[(size_t)ks * P.cap + sl] : (R)0;
+    };
+    const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig, late_epi);
+    epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st, &pre);
   }
 }
 
