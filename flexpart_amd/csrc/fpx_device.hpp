@@ -1476,7 +1476,10 @@ struct NoLate { FPX_DEV void operator()() const {} };
 // instead of 48 (k_prep's register budget).  The horizontal sums p1*y(ix,jy) + p2*y(ixp,jy) + p3*y(ix,jyp) + p4*y(ixp,jyp)
 // keep the reference's left-to-right order; the 16-point sums of the standard deviation (:194-214) are taken in
 // corner order instead of (slot, level) order: the same 16 terms, a different rounding.
-template <typename R, bool SIG, typename LATE = NoLate>
+#ifndef FPX_GATHER_DEPTH
+#define FPX_GATHER_DEPTH 2
+#endif
+template <typename R, bool SIG, typename LATE = NoLate, int DEPTH = FPX_GATHER_DEPTH>
 FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, R zt,
                          R &u, R &v, R &w, R &usig, R &vsig, R &wsig, const LATE &late = LATE()) {
   const R eps = K(1.0e-30);
@@ -1484,11 +1487,8 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const 
   const int indz = find_level(hgt, V.nz, zt);
   R au[2][2], av[2][2], aw[2][2];   // [physical slot][level]
   R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
-  // software pipeline over the four columns, FPX_GATHER_DEPTH of them in flight (1: one dependent memory round trip
+  // software pipeline over the four columns, DEPTH of them in flight (1: one dependent memory round trip
   // per column, 12 loaded values live; 2: two round trips, 24 live; 4: one round trip, 48 live)
-#ifndef FPX_GATHER_DEPTH
-#define FPX_GATHER_DEPTH 2
-#endif
   R x[4][12];
   auto issue = [&](int c) {
     const long long col = (long long)((c & 2) ? C.jyp : C.jy) * F.nx + ((c & 1) ? C.ixp : C.ix);
@@ -1497,8 +1497,8 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const 
     for (int i = 0; i < 12; i++) x[c][i] = p[i];
   };
 #pragma unroll
-  for (int c = 0; c < FPX_GATHER_DEPTH && c < 4; c++) issue(c);
-  if (FPX_GATHER_DEPTH >= 4) late();
+  for (int c = 0; c < DEPTH && c < 4; c++) issue(c);
+  if (DEPTH >= 4) late();
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     __builtin_amdgcn_sched_barrier(0);   // keeps the scheduler from issuing all 24 loads first
@@ -1516,8 +1516,8 @@ FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const 
         }
       }
     }
-    if (c + FPX_GATHER_DEPTH < 4) issue(c + FPX_GATHER_DEPTH);
-    if (c + FPX_GATHER_DEPTH == 3) late();   // with the last column's loads: the caller's late loads share their round trip
+    if (c + DEPTH < 4) issue(c + DEPTH);
+    if (c + DEPTH == 3) late();   // with the last column's loads: the caller's late loads share their round trip
   }
   const R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
   const R dz1 = (zt - hgt[indz - 1]) * dz;
@@ -2105,7 +2105,10 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
   cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
   if (V.turbmesoscale == K(0.)) {   // the standard deviations only feed the mesoscale term (advance.f90:728-739)
     usig = K(0.); vsig = K(0.); wsig = K(0.);
-    interp_wind<R, false>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late);
+#ifndef FPX_ABOVE_DEPTH
+#define FPX_ABOVE_DEPTH 4
+#endif
+    interp_wind<R, false, LATE, FPX_ABOVE_DEPTH>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late);
   } else {
     interp_wind<R, true>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late);
   }
@@ -2212,7 +2215,10 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
     R d0, d1, d2;
     Cell<R> C;
     cell_setup(C, ix, jy, ixp, jyp, xr, yr);
-    interp_wind<R, false>(V, hgt, fld_of(V, A.ngrid), C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2, late);
+#ifndef FPX_PETTERSSEN_DEPTH
+#define FPX_PETTERSSEN_DEPTH 4
+#endif
+    interp_wind<R, false, LATE, FPX_PETTERSSEN_DEPTH>(V, hgt, fld_of(V, A.ngrid), C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2, late);
   }
   if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt, A.nsp);   // advance.f90:893-906
   u = (u - A.u) / K(2.);

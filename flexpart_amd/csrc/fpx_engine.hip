@@ -398,15 +398,24 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
     // table loads below do not wait for it)
     const int npoint = pre ? pre->npoint : ((massfract && V.numpoint > 1) || (DRYDEP && Gp.on)) ? P.npoint[s] : 1;
     const int kr = release_index(V, npoint);
-    const R npart_r = massfract ? (R)V.rel_npart[kr] : (R)0;
-    R xmr_all[kMaxSpec];   // the release point's table entries in one round trip, not one per species
+    // everything the species loop reads -- the release point's table entries and the particle's masses -- in ONE round
+    // trip (the asm ties the loads together; otherwise each is issued where it is first needed: three dependent trips)
+    int npart_i = massfract ? V.rel_npart[kr] : 0;
+    R xmr_all[kMaxSpec], xm_all[kMaxSpec];
 #pragma unroll
-    for (int ks = 0; ks < kMaxSpec; ks++) xmr_all[ks] = (massfract && ks < V.nspec) ? V.rel_xmass[(size_t)ks * V.numpoint + kr] : (R)0;
+    for (int ks = 0; ks < kMaxSpec; ks++) {
+      xmr_all[ks] = (massfract && ks < V.nspec) ? V.rel_xmass[(size_t)ks * V.numpoint + kr] : (R)0;
+      xm_all[ks] = ks < V.nspec ? ((pre && ks == 0) ? pre->xm0 : P.xmass1[(size_t)ks * P.cap + s]) : (R)0;
+    }
+    static_assert(kMaxSpec == 5, "the tie below names five species");
+    asm volatile("" : "+v"(npart_i), "+v"(xmr_all[0]), "+v"(xmr_all[1]), "+v"(xmr_all[2]), "+v"(xmr_all[3]), "+v"(xmr_all[4]),
+                      "+v"(xm_all[0]), "+v"(xm_all[1]), "+v"(xm_all[2]), "+v"(xm_all[3]), "+v"(xm_all[4]));
+    const R npart_r = (R)npart_i;
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) {
       if (ks < V.nspec) {
         R decfact = V.decay[ks] > (R)0 ? m_exp(-(R)abs(V.lsynctime) * V.decay[ks]) : (R)1;
-        R xm = (pre && ks == 0) ? pre->xm0 : P.xmass1[(size_t)ks * P.cap + s];
+        R xm = xm_all[ks];
         if (DRYDEP && V.drydepspec[ks]) {
           // timemanager.f90:650-656; drydeposit is real(dep_prec): 4 bytes in every build
           float drydeposit = (float)(xm * prob[ks] * decfact);
