@@ -1855,6 +1855,7 @@ FPX_DEV void fetch_level_pair(const View<R> &V, const Fld<R> &F, const TimeW<R> 
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    asm volatile("" ::: "memory");   // the next corner's loads stay behind this corner's sums (f32: 80 registers in flight otherwise)
   }
   const bool h1 = V.m1 != 0, h2 = V.m2 != 0;               // wave-uniform: physical slot of memind(1) / memind(2)
 #pragma unroll
@@ -2342,7 +2343,8 @@ FPX_DEV bool grid_planes_ok(const GridP<R> &Gp, int nage, int nclass, int kp) {
 // conccalc.f90:50-295 for one particle (active == this lane holds a particle that is due)
 template <typename R>
 FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hgt, bool active, double xt, double yt, R zt,
-                               int itage, int npoint, int nclass, const R *xmass, R weight, const R *scav = nullptr /* max(xscav_frac1, 0) per species, or null */) {
+                               int itage, int npoint, int nclass, const R *xmass, R weight, const R *scav = nullptr /* max(xscav_frac1, 0) per species, or null */,
+                               const R *outh = nullptr /* the block's copy of outheight in LDS, or null */) {
   const int nage = ageclass(Gp, itage);
   const bool planes_ok = grid_planes_ok(Gp, nage, nclass, (Gp.ioutputforeachrelease == 0 || V.mdomainfill == 1) ? 1 : npoint);
   R rhoi = K(1.);
@@ -2370,8 +2372,13 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
   }
   const int nrelpointer = (Gp.ioutputforeachrelease == 0 || V.mdomainfill == 1) ? 1 : npoint;
   int kz = 1;
-  for (; kz <= Gp.numzgrid; kz++)
-    if (Gp.outheight[kz - 1] > zt) break;
+  if (outh) {   // (from device memory this search is one dependent round trip per output level)
+    for (; kz <= Gp.numzgrid; kz++)
+      if (outh[kz - 1] > zt) break;
+  } else {
+    for (; kz <= Gp.numzgrid; kz++)
+      if (Gp.outheight[kz - 1] > zt) break;
+  }
   const bool inside = active && planes_ok && kz <= Gp.numzgrid;
   for (int ig = 0; ig < (Gp.nested ? 2 : 1); ig++) {   // mother grid :145-295, nested grid :301-441
     const OutGeom<R> G = out_geom(Gp, ig == 1);
@@ -2521,6 +2528,12 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
   int slot = V.m2;   // n = memind(2) unless memtime(1) is nearer (get_wetscav.f90:114-116)
   if (abs(V.memtime0 - interp_time) < abs(V.memtime1 - interp_time)) slot = V.m1;
   // interpol_rain.f90:68-130 / interpol_rain_nests.f90:68-142 (no time interpolation: the nearer slot only)
+  // cloud flag and temperature at the particle's level are requested WITH the precipitation gather (they depend on the
+  // position only): one memory round trip instead of three for a particle under a raining cloud
+  const int hz = find_level(hgt, V.nz, ztra1);
+  const long long cidx = (((long long)jy * gnx + ix) * V.nz + (hz - 1)) * 2 + slot;
+  int clouds_v = (int)clouds[cidx];
+  R act_temp = ttw[cidx];
   R lsp, convp, cc;
   {
     R xt = xtn, yt = ytn;
@@ -2535,10 +2548,8 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
     convp = p1 * a[1] + p2 * b[1] + p3 * c[1] + p4 * d[1];
     cc = p1 * a[2] + p2 * b[2] + p3 * c[2] + p4 * d[2];
   }
+  asm volatile("" : "+v"(lsp), "+v"(convp), "+v"(cc), "+v"(clouds_v), "+v"(act_temp));
   if (lsp < K(0.01) && convp < K(0.01)) return wetscav;
-  const int hz = find_level(hgt, V.nz, ztra1);
-  const long long cidx = (((long long)jy * gnx + ix) * V.nz + (hz - 1)) * 2 + slot;
-  const int clouds_v = (int)clouds[cidx];
   if (clouds_v <= 1) return wetscav;
   int i, j;
   if (lsp > K(20.)) i = 4; else if (lsp > K(8.)) i = 3; else if (lsp > K(3.)) i = 2; else if (lsp > K(1.)) i = 1; else i = 0;
@@ -2547,7 +2558,6 @@ FPX_DEV R get_wetscav(const View<R> &V, const WetP<R> &Wp, const R *hgt, int iti
   const R cf = j == 4 ? cfr[4] : j == 3 ? cfr[3] : j == 2 ? cfr[2] : j == 1 ? cfr[1] : cfr[0];
   grfr = m_max(K(0.05), cc * (lsp * lf + convp * cf) / (lsp + convp));
   const R prec1 = (lsp + convp) / grfr;
-  const R act_temp = ttw[cidx];
   if (clouds_v >= 4) {   // below cloud, get_wetscav.f90:206-246
     if (V.dquer[ks] <= K(0.) && (Wp.weta_gas[ks] > K(0.) || Wp.wetb_gas[ks] > K(0.))) {
       wetscav = Wp.weta_gas[ks] * m_pow(prec1, Wp.wetb_gas[ks]);

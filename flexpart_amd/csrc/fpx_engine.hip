@@ -51,6 +51,9 @@ constexpr int kBlock = 256;
 #ifndef FPX_FINISH_WAVES
 #define FPX_FINISH_WAVES 2 // register budget of k_pbl_finish
 #endif
+#ifndef FPX_LOOP_WAVES_F32
+#define FPX_LOOP_WAVES_F32 4   // the f32 instances fit 128 VGPRs: four waves per SIMD (measured: 168 -> 184 ms at 1e8 when they slipped to three)
+#endif
 #ifndef FPX_LOOP_WAVES
 #define FPX_LOOP_WAVES 3   // waves per SIMD the Langevin kernel is register-budgeted for (<= 168 VGPRs)
 #endif
@@ -563,8 +566,9 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     // (= cell) order, so the lanes of a wave run the same branch of the turbulence scheme.
     unsigned char cls;
     if (V.cblflag == 1 && V.turbswitch && (-A.h / B.ol > (R)5)) cls = 1;      // skewed CBL scheme
-    else if (A.h / m_abs(B.ol) < (R)1) cls = 2;                               // neutral
-    else if (B.ol < (R)0) cls = 3;                                            // unstable, Gaussian
+    else if (A.h / m_abs(B.ol) < (R)1) cls = 3;                               // neutral
+    else if (B.ol < (R)0) cls = 2;                                            // unstable, Gaussian: next to the CBL class, whose
+                                                                              // hanna_short branch it shares (waves at a class boundary run both classes)
     else cls = 4;                                                             // stable
     pbl_flag[s] = cls;
     return;
@@ -1069,7 +1073,7 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
 // where all lanes are active.
 // LEAN: no dry deposition, no settling (gases).  TSW / CBLF / RNGM: see pbl_pass.
 template <typename R, bool LEAN, int TSW, int CBLF, int RNGM>
-__global__ void __launch_bounds__(kBlock, FPX_LOOP_WAVES) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+__global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                      const unsigned int *__restrict__ pbl_list,
                                                      const unsigned int *__restrict__ pbl_count,
                                                      unsigned int *__restrict__ cursor) {
@@ -1310,7 +1314,9 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
 template <typename R>
 __global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V, GridP<R> Gp, Parts<R> P, long long numpart, int itime, R weight) {
   __shared__ R hgt[kMaxNz];
+  __shared__ R outh[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  for (int k = threadIdx.x; k < Gp.numzgrid; k += blockDim.x) outh[k] = Gp.outheight[k];
   __syncthreads();
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   bool active = s < numpart;
@@ -1319,23 +1325,29 @@ __global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V, GridP<R> Gp, Par
   int itage = 0, npoint = 1, nclass = 1;
 #pragma unroll
   for (int ks = 0; ks < kMaxSpec; ks++) xm[ks] = (R)0;
-  if (active) active = P.itra1[s] == itime;
   if (active) {
+    // the particle's state in ONE memory round trip (nearly every particle is due; the asm keeps the compiler from sinking
+    // each load behind the branch that first needs it)
+    int itra1 = P.itra1[s], itramem = P.itramem[s];
     xt = P.xt[s]; yt = P.yt[s]; zt = P.zt[s];
-    itage = abs(itime - P.itramem[s]);
     npoint = P.npoint[s]; nclass = P.nclass[s];
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++)
       if (ks < V.nspec) xm[ks] = P.xmass1[(size_t)ks * P.cap + s];
+    static_assert(kMaxSpec == 5, "the tie below names five species");
+    asm volatile("" : "+v"(itra1), "+v"(itramem), "+v"(xt), "+v"(yt), "+v"(zt), "+v"(npoint), "+v"(nclass),
+                      "+v"(xm[0]), "+v"(xm[1]), "+v"(xm[2]), "+v"(xm[3]), "+v"(xm[4]));
+    itage = abs(itime - itramem);
+    active = itra1 == itime;
     if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) active = false;
   }
   if (P.xscav) {   // wave-uniform: DRYBKDEP / WETBKDEP
     R sc[kMaxSpec];
 #pragma unroll
     for (int ks = 0; ks < kMaxSpec; ks++) sc[ks] = (active && ks < V.nspec) ? m_max(P.xscav[(size_t)ks * P.cap + s], (R)0) : (R)0;
-    conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight, sc);
+    conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight, sc, outh);
   } else {
-    conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight);
+    conccalc_particle(V, Gp, hgt, active, xt, yt, zt, itage, npoint, nclass, xm, weight, (const R *)nullptr, outh);
   }
 }
 
@@ -1417,22 +1429,28 @@ __global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V, GridP<R> Gp, WetP
   __syncthreads();
   const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= numpart) return;
-  const int itra1 = P.itra1[s];
+  // the particle's state in ONE memory round trip (as in k_conccalc)
+  int itra1 = P.itra1[s], itramem = P.itramem[s], nunc = P.nclass[s];
+  int kp = Gp.ioutputforeachrelease == 1 ? P.npoint[s] : 1;
+  double xt = P.xt[s], yt = P.yt[s];
+  R zt = P.zt[s];
+  R xm_all[kMaxSpec];
+#pragma unroll
+  for (int ks = 0; ks < kMaxSpec; ks++) xm_all[ks] = (ks < V.nspec && Wp.wetdepspec[ks]) ? P.xmass1[(size_t)ks * P.cap + s] : (R)0;
+  static_assert(kMaxSpec == 5, "the tie below names five species");
+  asm volatile("" : "+v"(itra1), "+v"(itramem), "+v"(nunc), "+v"(kp), "+v"(xt), "+v"(yt), "+v"(zt),
+                    "+v"(xm_all[0]), "+v"(xm_all[1]), "+v"(xm_all[2]), "+v"(xm_all[3]), "+v"(xm_all[4]));
   if (itra1 == kDead) return;
   if (V.ldirect == 1) { if (itra1 > itime) return; } else { if (itra1 < itime) return; }
-  const double xt = P.xt[s], yt = P.yt[s];
-  const R zt = P.zt[s];
   if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) return;
   const int ldeltat = itime <= loutnext ? itime - (loutnext - Gp.loutstep) : itime - loutnext;   // wetdepo.f90:58-62
-  const int nage = ageclass(Gp, abs(itra1 - P.itramem[s]));
-  const int kp = Gp.ioutputforeachrelease == 1 ? P.npoint[s] : 1;
-  const int nunc = P.nclass[s];
+  const int nage = ageclass(Gp, abs(itra1 - itramem));
   const R smallnum = sizeof(R) == 4 ? (R)1.17549435e-38f : (R)2.2250738585072014e-308;
   for (int ks = 0; ks < V.nspec; ks++) {
     if (!Wp.wetdepspec[ks]) continue;
     R grfr = (R)0;
     const R wetscav = get_wetscav(V, Wp, hgt, itime, ltsample, xt, yt, zt, ks, grfr);
-    const R xm = P.xmass1[(size_t)ks * P.cap + s];
+    const R xm = pick(xm_all, ks);
     R wetdeposit = (R)0;
     if (wetscav > (R)0) wetdeposit = xm * ((R)1 - m_exp(-wetscav * (R)abs(ltsample))) * grfr;
     const R restmass = xm - wetdeposit;
