@@ -190,11 +190,16 @@ def live_valu(args, kernel, avg_ms, launch_work):
         clk_ghz = e["GRBM_GUI_ACTIVE"] / 8.0 / e["ns"] if e.get("GRBM_GUI_ACTIVE") else None
         busy_cycles = 4.0 * e["SQ_ACTIVE_INST_VALU"]              # the SQ counters tick in quad-cycles
         issue_ms = busy_cycles / N_SIMD / ((clk_ghz or 2.4) * 1e9) * 1e3
+        # SQ_ACTIVE_INST_VALU charges every VALU instruction at least one quad-cycle; a 32-bit instruction issues in less
+        # (2.4 cycles measured, tools/valu_rates.hip), so for the f32 engine the "busy" time exceeds the launch and is no
+        # utilisation: reported as None there (the fp64 mix is 4.3 cycles per instruction, at the counter's granularity)
+        frac = issue_ms / avg_ms
         return {"insts_valu_per_launch": e["SQ_INSTS_VALU"], "valu_busy_cycles_per_launch": busy_cycles,
                 "cycles_per_valu_inst": busy_cycles / e["SQ_INSTS_VALU"],
                 "lane_utilisation": e["SQ_THREAD_CYCLES_VALU"] / (64.0 * e["SQ_ACTIVE_INST_VALU"]) if e.get("SQ_THREAD_CYCLES_VALU") else None,
                 "clock_ghz_under_pmc": clk_ghz, "kernel_ms_under_pmc": e["ns"] * 1e-6,
-                "issue_ms": issue_ms, "frac_of_launch": issue_ms / avg_ms,
+                "issue_ms": issue_ms, "frac_of_launch": frac if frac <= 1.0 else None,
+                "quad_cycle_time_over_launch": frac,
                 "insts_valu_per_particle_step": e["SQ_INSTS_VALU"] / max(launch_work, 1.0),   # wave-instructions per particle-step of the launch
                 "source": "rocprofv3 --pmc pass of this run (child process, same workload)"}
     except Exception as ex:          # the counter pass must not sink the GPU number

@@ -1823,39 +1823,51 @@ FPX_DEV void fetch_level_pair(const View<R> &V, const Fld<R> &F, const TimeW<R> 
   const R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
   R a3[2][2][3], a2[2][2][2];                               // [level][physical slot][variable]
   typedef const R __attribute__((address_space(1))) *gptr;  // the packs live in device memory: global, not flat, loads
+#ifndef FPX_FETCH_CORNERS
+#define FPX_FETCH_CORNERS 1
+#endif
+  // NC corners per batch: the 20 values of each are requested together and used after ONE wait (left to itself the
+  // compiler, short of registers, waited after every second load: 17 dependent memory round trips per pass)
+  constexpr int NC = FPX_FETCH_CORNERS;
 #pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const int jyc = (c & 2) ? L.jyp : L.jy, ixc = (c & 1) ? L.ixp : L.ix;
-    const R pw = c == 0 ? rddx * rddy : c == 1 ? ddx * rddy : c == 2 ? rddx * ddy : ddx * ddy;
-    const unsigned int cell = (unsigned int)(jyc * F.nx + ixc) * (unsigned int)V.nz + (unsigned int)(indz - 1);   // < nx*ny*nz
-    const gptr p = (gptr)(F.w3 + (size_t)cell * 6);
-    const gptr q = (gptr)(F.r2 + (size_t)cell * 4);
-    // the 20 values of a corner are requested together and used after ONE wait (left to itself the compiler, short of
-    // registers, waited after every second load: 17 dependent memory round trips per pass instead of 4)
-    R x3[12], x2[8];
+  for (int cb = 0; cb < 4; cb += NC) {
+    R x3[NC][12], x2[NC][8];
 #pragma unroll
-    for (int k = 0; k < 12; k++) x3[k] = p[k];
+    for (int j = 0; j < NC; j++) {
+      const int c = cb + j;
+      const int jyc = (c & 2) ? L.jyp : L.jy, ixc = (c & 1) ? L.ixp : L.ix;
+      const unsigned int cell = (unsigned int)(jyc * F.nx + ixc) * (unsigned int)V.nz + (unsigned int)(indz - 1);   // < nx*ny*nz
+      const gptr p = (gptr)(F.w3 + (size_t)cell * 6);
+      const gptr q = (gptr)(F.r2 + (size_t)cell * 4);
 #pragma unroll
-    for (int k = 0; k < 8; k++) x2[k] = q[k];
+      for (int k = 0; k < 12; k++) x3[j][k] = p[k];
+#pragma unroll
+      for (int k = 0; k < 8; k++) x2[j][k] = q[k];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int lev = 0; lev < 2; lev++) {
+    for (int j = 0; j < NC; j++) {
+      const int c = cb + j;
+      const R pw = c == 0 ? rddx * rddy : c == 1 ? ddx * rddy : c == 2 ? rddx * ddy : ddx * ddy;
 #pragma unroll
-      for (int sl = 0; sl < 2; sl++) {
+      for (int lev = 0; lev < 2; lev++) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-          const R x = x3[(lev * 2 + sl) * 3 + k];
-          a3[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a3[lev][sl][k]);
-        }
+        for (int sl = 0; sl < 2; sl++) {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-          const R x = x2[(lev * 2 + sl) * 2 + k];
-          a2[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a2[lev][sl][k]);
+          for (int k = 0; k < 3; k++) {
+            const R x = x3[j][(lev * 2 + sl) * 3 + k];
+            a3[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a3[lev][sl][k]);
+          }
+#pragma unroll
+          for (int k = 0; k < 2; k++) {
+            const R x = x2[j][(lev * 2 + sl) * 2 + k];
+            a2[lev][sl][k] = c == 0 ? pw * x : m_fma(pw, x, a2[lev][sl][k]);
+          }
         }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    asm volatile("" ::: "memory");   // the next corner's loads stay behind this corner's sums (f32: 80 registers in flight otherwise)
+    asm volatile("" ::: "memory");   // the next batch's loads stay behind this batch's sums (f32: 80 registers in flight otherwise)
   }
   const bool h1 = V.m1 != 0, h2 = V.m2 != 0;               // wave-uniform: physical slot of memind(1) / memind(2)
 #pragma unroll

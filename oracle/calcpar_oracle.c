@@ -26,6 +26,16 @@ typedef ORC_REAL real;
 static const real r_air = K(287.05), ga = K(9.81), cpa = K(1004.6), karman = K(0.40), convke = K(2.0);
 static const real hmixmin = K(100.), hmixmax = K(4500.);
 
+/* Test support: the smallest relative distance of any DISCRETE decision of a column (a level search that compares a
+ * computed number with a threshold) from its threshold.  A column whose margin is large must come out identical on any
+ * correct implementation; one whose margin is at rounding level may legitimately land on the neighbouring level. */
+static double g_margin;
+static void margin_rel(real v, real thr) {
+  double d = fabs((double)v - (double)thr), sc = fabs((double)thr) > fabs((double)v) ? fabs((double)thr) : fabs((double)v);
+  if (sc > 0.) d = d / sc;
+  if (d < g_margin) g_margin = d;
+}
+
 /* ew.f90:4-29 */
 real cpo_ew(real x) {
   real y, a, c, d;
@@ -88,6 +98,7 @@ static void cpo_richardson(real psurf, real ust, const real *ttlev, const real *
     for (k = 2; k <= nuvz; k++) {
       pint = akz[k - 1] + bkz[k - 1] * psurf;
       tv = ttlev[k - 1] * (K(1.) + K(0.608) * qvlev[k - 1]);
+      margin_rel(R_ABS(tv - tvold), K(0.2));
       if (R_ABS(tv - tvold) > K(0.2)) z = zold + konst * R_LOG(pold / pint) * (tv - tvold) / R_LOG(tv / tvold);
       else z = zold + konst * R_LOG(pold / pint) * tv;
       theta = tv * R_POW(K(100000.) / pint, r_air / cpa);
@@ -97,6 +108,7 @@ static void cpo_richardson(real psurf, real ust, const real *ttlev, const real *
         if (den < K(0.1)) den = K(0.1);
         ri = ga / thetaref * (theta - thetaref) * (z - zref) / den;
       }
+      margin_rel(ri, ric); margin_rel(theta, thetaold);
       if (ri > ric && thetaold < theta) break;
       tvold = tv; pold = pint; rhold = rh; thetaold = theta; zold = z;
     }
@@ -114,6 +126,7 @@ static void cpo_richardson(real psurf, real ust, const real *ttlev, const real *
       if (den < K(0.1)) den = K(0.1);
       ril = ga / thetaref * (thetal - thetaref) * (zl - zref) / den;
       zl2 = zl; theta2 = thetal;
+      margin_rel(ril, ric);
       if (ril > ric) break;
       zl1 = zl; theta1 = thetal;
     }
@@ -139,6 +152,7 @@ typedef struct {
   const double *tth, *qvh, *uuh, *vvh;                          /* [nuvz][ny][nx] */
   const double *akz, *bkz, *akm, *bkm;                          /* [nuvz] */
   double *ustar, *wstar, *oli, *hmix, *tropopause;              /* out [ny][nx]; tropopause keeps its input where no level qualifies */
+  double *margin;                                               /* out [ny][nx] or NULL: see margin_rel() */
 } cpo_args;
 
 /* calcpar.f90:76-265 without getvdep and calcpv */
@@ -161,6 +175,7 @@ void cpo_calcpar(const cpo_args *A) {
       const real ps = (real)A->ps[c], tt2 = (real)A->tt2[c], td2 = (real)A->td2[c];
       real ust, ol, hm, wst, hmixplus, subsceff, tvold, pold, zold;
       int kzmin = 1, found = 0;
+      g_margin = 1.;
       ust = cpo_scalev(ps, tt2, td2, (real)A->surfstr[c]);
       if (ust <= K(1.e-8)) ust = K(1.e-8);
       ol = cpo_obukhov(ps, tt2, td2, (real)A->tth[n2 * 1 + c], &ust, (real)A->sshf[c], akm, bkm);
@@ -183,18 +198,25 @@ void cpo_calcpar(const cpo_args *A) {
       zlev[0] = K(0.);                       /* zlev(1) is never assigned in the ECMWF branch; the search below starts at 1 */
       for (kz = 2; kz <= nuvz; kz++) {
         const real pint = akz[kz - 1] + bkz[kz - 1] * ps, tv = ttlev[kz - 1] * (K(1.) + K(0.608) * qvlev[kz - 1]);
+        margin_rel(R_ABS(tv - tvold), K(0.2));
         if (R_ABS(tv - tvold) > K(0.2)) zlev[kz - 1] = zold + konst * R_LOG(pold / pint) * (tv - tvold) / R_LOG(tv / tvold);
         else zlev[kz - 1] = zold + konst * R_LOG(pold / pint) * tv;
         tvold = tv; pold = pint; zold = zlev[kz - 1];
       }
-      for (kz = 1; kz <= nuvz; kz++)
+      for (kz = 1; kz <= nuvz; kz++) {
+        margin_rel(zlev[kz - 1], altmin);
         if (zlev[kz - 1] >= altmin) { kzmin = kz; break; }
+      }
       for (kz = kzmin; kz <= nuvz && !found; kz++)
-        for (lz = kz + 1; lz <= nuvz; lz++)
+        for (lz = kz + 1; lz <= nuvz; lz++) {
+          margin_rel(zlev[lz - 1] - zlev[kz - 1], K(2000.));
           if (zlev[lz - 1] - zlev[kz - 1] > K(2000.)) {
+            margin_rel((ttlev[kz - 1] - ttlev[lz - 1]) / (zlev[lz - 1] - zlev[kz - 1]), K(0.002));
             if ((ttlev[kz - 1] - ttlev[lz - 1]) / (zlev[lz - 1] - zlev[kz - 1]) < K(0.002)) { A->tropopause[c] = (double)zlev[kz - 1]; found = 1; }
             break;
           }
+        }
+      if (A->margin) A->margin[c] = g_margin;
     }
   }
   free(ulev); free(bkz);

@@ -669,12 +669,13 @@ def rl_oracle(rs, kind="r8"):
 class _CpoArgs(C.Structure):
     _fields_ = ([(k, C.c_int) for k in ("nx", "ny", "nuvz", "lsubgrid")] + [("dy", C.c_double), ("ylat0", C.c_double)]
                 + [(k, C.POINTER(C.c_double)) for k in ("ps", "tt2", "td2", "surfstr", "sshf", "excessoro", "tth", "qvh", "uuh", "vvh",
-                                                         "akz", "bkz", "akm", "bkm", "ustar", "wstar", "oli", "hmix", "tropopause")])
+                                                         "akz", "bkz", "akm", "bkm", "ustar", "wstar", "oli", "hmix", "tropopause", "margin")])
 
 
 def cp_oracle(m, cin, kind="r8"):
     """The C restatement of calcpar (ECMWF branch, without getvdep / calcpv) on a synthetic.model_levels() dict and
-    synthetic.calcpar_inputs(): -> dict of ustar, wstar, oli, hmix, tropopause [ny][nx]."""
+    synthetic.calcpar_inputs(): -> dict of ustar, wstar, oli, hmix, tropopause [ny][nx], and `margin`: the smallest relative
+    distance of any of the column's level-search decisions from its threshold (test support)."""
     build()
     lib = C.CDLL(os.path.join(HERE, f"libcporacle_{kind}.so"))
     nx, ny, nz = (int(v) for v in m["grid"])
@@ -687,7 +688,7 @@ def cp_oracle(m, cin, kind="r8"):
     for k, src in (("ps", m), ("tt2", m), ("td2", m), ("tth", m), ("qvh", m), ("uuh", m), ("vvh", m), ("akz", m), ("bkz", m),
                    ("surfstr", cin), ("sshf", cin), ("excessoro", cin), ("akm", cin), ("bkm", cin)):
         keep[k] = _f64(np.asarray(src[k]).astype(rt)); setattr(a, k, keep[k].ctypes.data_as(dp))
-    out = {k: np.zeros((ny, nx)) for k in ("ustar", "wstar", "oli", "hmix", "tropopause")}
+    out = {k: np.zeros((ny, nx)) for k in ("ustar", "wstar", "oli", "hmix", "tropopause", "margin")}
     for k, v in out.items():
         setattr(a, k, v.ctypes.data_as(dp))
     lib.cpo_calcpar(C.byref(a))

@@ -74,8 +74,8 @@ def test_calcpar_restatement_invariants(kind):
 def test_device_calcpar_matches_the_restatement(built, kind):
     """fpx_verttransform_ecmwf(sfc = NULL) + fpx_calcpar through the C ABI against oracle/calcpar_oracle.c.  The level
     searches (first level with Ri > 0.25, first layer meeting the lapse-rate criterion) are discrete: a column where
-    device and host libm round a Richardson number to different sides of the threshold lands on another level, so a
-    small share of columns may differ; everywhere else the fields agree to rounding."""
+    device and host libm round a Richardson number to different sides of the threshold lands on another level.  Which
+    columns those can be is known exactly (the oracle's decision margins): all others must agree to rounding."""
     from flexpart_amd.engine import Engine
     m = syn.model_levels(nx=72, ny=46, nz=60, polar=False)
     cin = syn.calcpar_inputs(m)
@@ -89,9 +89,17 @@ def test_device_calcpar_matches_the_restatement(built, kind):
     eng.close()
     tol = 1e-10 if kind == "r8" else 2e-4
     ncol = want["hmix"].size
+    # The oracle reports, per column, how close its closest level-search decision came to its threshold (relative).  A
+    # column that is not within rounding reach of a threshold must agree -- no exceptions; only the others may land on a
+    # neighbouring level.  fp64: rounding reach 1e-9 (no column of this case is that close: every column is checked);
+    # f32: the Richardson number carries theta - thetaref, a difference of numbers near 300 K: 1e-4.
+    reach = 1e-9 if kind == "r8" else 1e-4
+    fragile = want["margin"] < reach
+    assert fragile.mean() <= (0.0 if kind == "r8" else 0.25), float(fragile.mean())
     for k in ("ustar", "wstar", "oli", "hmix", "tropopause"):
         scale = np.abs(want[k]).max()
         bad = np.abs(got[k] - want[k]) > tol * scale
+        assert not (bad & ~fragile).any(), (k, int((bad & ~fragile).sum()), float(np.abs(got[k] - want[k])[~fragile].max() / scale))
         limit = 0 if k == "ustar" else 0.01 * ncol
         assert bad.sum() <= limit, (k, int(bad.sum()), float(np.abs(got[k] - want[k]).max() / scale))
     assert got["device_ms"] > 0
