@@ -171,7 +171,7 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int6
 SYMBOLS = [
     "fpx_create", "fpx_destroy", "fpx_last_error", "fpx_abi_version", "fpx_polar_maps", "fpx_set_height",
     "fpx_upload_fields", "fpx_set_windtime", "fpx_rng_fill_table", "fpx_rng_set_table",
-    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points", "fpx_set_release_heights", "fpx_release_init", "fpx_releaseparticles", "fpx_split_particles",
+    "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points", "fpx_set_release_heights", "fpx_release_init", "fpx_releaseparticles", "fpx_split_particles", "fpx_redist_plan", "fpx_redist_bytes", "fpx_redist_pack", "fpx_redist_unpack",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
     "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_count_particles", "fpx_lane_stats", "fpx_wet_init", "fpx_upload_wet_fields",
@@ -245,6 +245,11 @@ def load():
     lib.fpx_release_init.argtypes = [vp, C.POINTER(FpxRelease)]
     lib.fpx_releaseparticles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int32), vp, vp, C.POINTER(C.c_int64)]
     lib.fpx_split_particles.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
+    lib.fpx_redist_plan.argtypes = [C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.fpx_redist_bytes.argtypes = [vp, C.c_int64]
+    lib.fpx_redist_bytes.restype = C.c_uint64
+    lib.fpx_redist_pack.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_uint64, C.POINTER(C.c_int64)]
+    lib.fpx_redist_unpack.argtypes = [vp, C.c_int32, C.c_int64, vp, C.c_uint64, C.POINTER(C.c_int64)]
     lib.fpx_step.argtypes = [vp, C.c_int32, C.POINTER(FpxStepStats)]
     lib.fpx_step_async.argtypes = [vp, C.c_int32]
     lib.fpx_sync.argtypes = [vp]

@@ -166,6 +166,15 @@ __global__ void k_sort_keys(View<R> V, Parts<R> P, long long n, unsigned int *__
   vals[i] = (unsigned int)i;
 }
 
+// keys of the inverse operation: the particle number, so that the sort puts every particle back into the storage space
+// of its number (slot = pid)
+__global__ void k_sort_keys_pid(const unsigned int *__restrict__ pid, long long n, unsigned int *__restrict__ keys, unsigned int *__restrict__ vals) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = pid[i];
+  vals[i] = (unsigned int)i;
+}
+
 // out[i] = in[perm[i]] for every particle array at once.  Between two re-sorts a particle stays in or next to its grid
 // column, so the sources of neighbouring destination blocks share cache lines: workgroups are dealt to the eight XCDs
 // round-robin, therefore block b takes tile (b % 8) * tiles_per_xcd + b / 8 -- each XCD's L2 then sees one contiguous
@@ -919,6 +928,67 @@ __global__ void k_split(Parts<R> P, const unsigned int *__restrict__ slot_of_pid
   }
 }
 
+// Particle redistribution between ranks, mpi_mod.f90:661-856 (mpif_redist_part).  The message is what the reference sends,
+// in its order, as ONE buffer: nclass, npoint, itra1, idt, itramem, itrasplit (int32[n] each), xtra1, ytra1 (f64[n]), ztra1
+// (R[n]), xmass1 (R[nspec][n]).  As in the reference the turbulent velocities, cbt and xscav_frac1 do NOT travel.
+template <typename R>
+struct RedistBuf {
+  int *nclass, *npoint, *itra1, *idt, *itramem, *itrasplit;
+  double *xt, *yt;
+  R *zt, *xmass;   // xmass: [nspec][n]
+  long long n;
+  __host__ __device__ static size_t bytes(long long n, int nspec) { return (size_t)n * (6 * 4 + 2 * 8 + (size_t)(1 + nspec) * sizeof(R)); }
+  __host__ __device__ static RedistBuf at(void *base, long long n, int nspec) {
+    RedistBuf b;
+    unsigned char *q = (unsigned char *)base;
+    b.xt = (double *)q; q += (size_t)n * 8;            // the 8-byte arrays first: every array stays aligned for any n
+    b.yt = (double *)q; q += (size_t)n * 8;
+    b.zt = (R *)q; q += (size_t)n * sizeof(R);
+    b.xmass = (R *)q; q += (size_t)n * nspec * sizeof(R);
+    b.nclass = (int *)q; q += (size_t)n * 4;
+    b.npoint = (int *)q; q += (size_t)n * 4;
+    b.itra1 = (int *)q; q += (size_t)n * 4;
+    b.idt = (int *)q; q += (size_t)n * 4;
+    b.itramem = (int *)q; q += (size_t)n * 4;
+    b.itrasplit = (int *)q;
+    b.n = n;
+    return b;
+  }
+};
+// sender, :700-745: the storage spaces ll..ul = numpart-num_trans+1 .. numpart go into the message and are terminated
+template <typename R>
+__global__ void k_redist_pack(Parts<R> P, const unsigned int *__restrict__ slot_of_pid, long long first_pid, RedistBuf<R> B, int nspec) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B.n) return;
+  const long long pid = first_pid + i;
+  const long long s = slot_of_pid ? (long long)slot_of_pid[pid] : pid;
+  B.nclass[i] = P.nclass[s]; B.npoint[i] = P.npoint[s]; B.itra1[i] = P.itra1[s]; B.idt[i] = P.idt[s];
+  B.itramem[i] = P.itramem[s]; B.itrasplit[i] = P.itrasplit[s];
+  B.xt[i] = P.xt[s]; B.yt[i] = P.yt[s]; B.zt[i] = P.zt[s];
+  for (int ks = 0; ks < nspec; ks++) B.xmass[(size_t)ks * B.n + i] = P.xmass1[(size_t)ks * P.cap + s];
+  P.itra1[s] = kDead;                                  // :744
+}
+// receiver, :808-835: valid[i] = the i-th received particle is alive at itime ("we may have transferred invalid particles")
+__global__ void k_redist_valid(const int *__restrict__ itra1_tmp, long long n, int itime, unsigned int *__restrict__ valid) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) valid[i] = itra1_tmp[i] == itime ? 1u : 0u;
+}
+// the k-th valid received particle goes into the k-th storage space of 1..maxnumpart with itra1 /= itime (target[k], as
+// k_rel_targets builds it); everything else of that space stays what its last owner left
+template <typename R>
+__global__ void k_redist_unpack(Parts<R> P, const unsigned int *__restrict__ slot_of_pid, RedistBuf<R> B, int nspec, const unsigned int *__restrict__ valid,
+                                const unsigned int *__restrict__ vrank, const unsigned int *__restrict__ target, unsigned int *__restrict__ maxpid) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B.n || !valid[i]) return;
+  const unsigned int pid = target[vrank[i]];
+  const long long s = slot_of_pid ? (long long)slot_of_pid[pid] : (long long)pid;
+  P.itra1[s] = B.itra1[i]; P.npoint[s] = B.npoint[i]; P.nclass[s] = B.nclass[i]; P.idt[s] = B.idt[i];
+  P.itramem[s] = B.itramem[i]; P.itrasplit[s] = B.itrasplit[i];
+  P.xt[s] = B.xt[i]; P.yt[s] = B.yt[i]; P.zt[s] = B.zt[i];
+  for (int ks = 0; ks < nspec; ks++) P.xmass1[(size_t)ks * P.cap + s] = B.xmass[(size_t)ks * B.n + i];
+  atomicMax(maxpid, pid);
+}
+
 // readpartpositions.f90:115-148 -- warm start: the records of a dump (as partoutput writes them) -> particle SoA.
 // One lane per record; arithmetic of the coordinate conversion in the host's real kind H.
 template <typename R, typename H>
@@ -1494,6 +1564,9 @@ struct EngineBase {
   virtual int release_init(const fpx_release *r) = 0;
   virtual int releaseparticles(int itime, int64_t *numpart, int32_t *numparticlecount, void *xmasssave, void *rho_rel, int64_t *nreleased) = 0;
   virtual int split_particles(int itime, int64_t *numpart) = 0;
+  virtual size_t redist_bytes(int64_t num_trans) = 0;
+  virtual int redist_pack(int itime, int64_t num_trans, void *buf, size_t buf_bytes, int64_t *numpart) = 0;
+  virtual int redist_unpack(int itime, int64_t num_trans, const void *buf, size_t buf_bytes, int64_t *numpart) = 0;
   virtual int step(int itime, fpx_step_stats *st, bool async) = 0;
   virtual int sync() = 0;
   virtual int counters(fpx_step_stats *out, int reset) = 0;
@@ -1778,6 +1851,7 @@ struct Engine : EngineBase {
     if (rel_flags_buf) (void)hipFree(rel_flags_buf);
     if (rel_rank_buf) (void)hipFree(rel_rank_buf);
     if (rel_tmp_buf) (void)hipFree(rel_tmp_buf);
+    if (redist_dev) (void)hipFree(redist_dev);
     if (d_sort_rec) (void)hipFree(d_sort_rec);
     if (red_pin) (void)hipHostFree(red_pin);
     if (comm) (void)ncclCommDestroy(comm);
@@ -2856,6 +2930,88 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // ---- particle redistribution between ranks, mpi_mod.f90:661-856 ------------------------------
+  // The host keeps the transport (its MPI_Send / MPI_Recv, one message instead of the reference's 9 + nspec); the engine
+  // packs and places.  buf may be host or device memory (hipMemcpyDefault).
+  void *redist_dev = nullptr;
+  size_t redist_dev_bytes = 0;
+  int redist_stage(size_t bytes) {
+    if (bytes <= redist_dev_bytes) return 0;
+    if (redist_dev) { (void)hipStreamSynchronize(stream); (void)hipFree(redist_dev); redist_dev = nullptr; redist_dev_bytes = 0; }
+    if (hipMalloc(&redist_dev, bytes) != hipSuccess) return -1;
+    redist_dev_bytes = bytes;
+    return 0;
+  }
+  size_t redist_bytes(int64_t num_trans) override { return num_trans > 0 ? RedistBuf<R>::bytes(num_trans, cfg.nspec) : 0; }
+  int redist_pack(int itime, int64_t num_trans, void *buf, size_t buf_bytes, int64_t *numpart_io) override {
+    (void)itime;
+    if (!numpart_io || *numpart_io < 0 || *numpart_io > P.cap) return fail(FPX_ERR_ARG, "redist_pack: numpart outside capacity");
+    if (num_trans < 0 || num_trans > *numpart_io) return fail(FPX_ERR_ARG, "redist_pack: num_trans must be between 0 and numpart");
+    if (num_trans == 0) return 0;
+    const size_t need = redist_bytes(num_trans);
+    if (!buf || buf_bytes < need) return fail(FPX_ERR_ARG, "redist_pack: buffer smaller than fpx_redist_bytes(num_trans)");
+    if (redist_stage(need)) return fail(FPX_ERR_NOMEM, "redist_pack: staging buffer");
+    numpart = *numpart_io;
+    { const int rc = restore_particle_order(); if (rc) return rc; }   // numpart shrinks below
+    const RedistBuf<R> B = RedistBuf<R>::at(redist_dev, num_trans, cfg.nspec);
+    k_redist_pack<R><<<(int)((num_trans + kBlock - 1) / kBlock), kBlock, 0, stream>>>(P, slot_map(), numpart - num_trans, B, cfg.nspec);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(buf, redist_dev, need, hipMemcpyDefault, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); else (void)hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(FPX_ERR_DEVICE, std::string("redist_pack: ") + hipGetErrorString(e));
+    numpart -= num_trans;                                 // :746
+    *numpart_io = numpart;
+    return 0;
+  }
+  int redist_unpack(int itime, int64_t num_trans, const void *buf, size_t buf_bytes, int64_t *numpart_io) override {
+    if (!numpart_io || *numpart_io < 0 || *numpart_io > P.cap) return fail(FPX_ERR_ARG, "redist_unpack: numpart outside capacity");
+    if (num_trans < 0) return fail(FPX_ERR_ARG, "redist_unpack: num_trans < 0");
+    if (num_trans == 0) return 0;
+    const long long maxnumpart = *numpart_io + num_trans;   // :811
+    if (maxnumpart > P.cap) return fail(FPX_ERR_NOMEM, "redist_unpack: numpart + num_trans exceeds the particle capacity (the reference would write past maxpart)");
+    const size_t need = redist_bytes(num_trans);
+    if (!buf || buf_bytes < need) return fail(FPX_ERR_ARG, "redist_unpack: buffer smaller than fpx_redist_bytes(num_trans)");
+    // work arrays: vacancy flags + ranks over 1..maxnumpart, validity flags + ranks and the targets over the message
+    unsigned int *flags = nullptr, *rank = nullptr;
+    void *tmp = nullptr;
+    const size_t nwork = (size_t)maxnumpart + 3 * (size_t)num_trans + 1;
+    if (redist_stage(need)) return fail(FPX_ERR_NOMEM, "redist_unpack: staging buffer");
+    if (rel_scratch(nwork, &flags, &rank)) return fail(FPX_ERR_NOMEM, "redist_unpack: work arrays");
+    unsigned int *valid = flags + maxnumpart, *vrank = rank + maxnumpart;
+    unsigned int *target = flags + maxnumpart + num_trans, *d_max = rank + maxnumpart + num_trans;
+    size_t tb1 = 0, tb2 = 0;
+    (void)rocprim::exclusive_scan(nullptr, tb1, flags, rank, 0u, (size_t)maxnumpart, rocprim::plus<unsigned int>(), stream);
+    (void)rocprim::exclusive_scan(nullptr, tb2, valid, vrank, 0u, (size_t)num_trans, rocprim::plus<unsigned int>(), stream);
+    if (rel_scan_tmp(std::max(tb1, tb2), &tmp)) return fail(FPX_ERR_NOMEM, "redist_unpack: scan storage");
+    numpart = *numpart_io;
+    hipError_t e = hipMemcpyAsync(redist_dev, buf, need, hipMemcpyDefault, stream);
+    const RedistBuf<R> B = RedistBuf<R>::at(redist_dev, num_trans, cfg.nspec);
+    const int nbm = (int)((maxnumpart + kBlock - 1) / kBlock), nbt = (int)((num_trans + kBlock - 1) / kBlock);
+    if (e == hipSuccess) {
+      k_rel_flags<R><<<nbm, kBlock, 0, stream>>>(P, slot_map(), maxnumpart, itime, flags);          // vacant: itra1 /= itime (:818)
+      k_redist_valid<<<nbt, kBlock, 0, stream>>>(B.itra1, num_trans, itime, valid);                  // :816
+      e = rocprim::exclusive_scan(tmp, tb1, flags, rank, 0u, (size_t)maxnumpart, rocprim::plus<unsigned int>(), stream);
+    }
+    if (e == hipSuccess) e = rocprim::exclusive_scan(tmp, tb2, valid, vrank, 0u, (size_t)num_trans, rocprim::plus<unsigned int>(), stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_max, 0, 4, stream);
+    if (e == hipSuccess) {
+      // the spaces numpart+1 .. maxnumpart are vacant, so there are at least num_trans targets
+      k_rel_targets<<<nbm, kBlock, 0, stream>>>(flags, rank, maxnumpart, num_trans, target);
+      k_redist_unpack<R><<<nbt, kBlock, 0, stream>>>(P, slot_map(), B, cfg.nspec, valid, vrank, target, d_max);
+      e = hipGetLastError();
+    }
+    unsigned int maxpid = 0, nvalid[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(&maxpid, d_max, 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nvalid[0], vrank + (num_trans - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&nvalid[1], valid + (num_trans - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); else (void)hipStreamSynchronize(stream);
+    if (e != hipSuccess) return fail(FPX_ERR_DEVICE, std::string("redist_unpack: ") + hipGetErrorString(e));
+    if (nvalid[0] + nvalid[1] > 0) numpart = std::max<long long>(numpart, (long long)maxpid + 1);   // numpart=max(numpart,ipart), :836
+    *numpart_io = numpart;
+    maybe_new = true;
+    return 0;
+  }
+
   // ---- concoutput: the grid_conc files ------------------------------------
   int concoutput(int itime, const fpx_concout *c, const char *prefix, int clear) override {
     if (!Gp.on) return fail(FPX_ERR_STATE, "concoutput: fpx_outgrid_init first");
@@ -3827,6 +3983,7 @@ struct Engine : EngineBase {
 
   int set_numpart(long long n) override {
     if (n < 0 || n > P.cap) return fail(FPX_ERR_ARG, "set_numpart: outside capacity");
+    if (n < numpart) { const int rc = restore_particle_order(); if (rc) return rc; }
     numpart = n;
     return 0;
   }
@@ -4104,10 +4261,20 @@ struct Engine : EngineBase {
     return 0;
   }
 
+  // The locality sort permutes the storage spaces 1..numpart among themselves; an operation that SHRINKS numpart (the
+  // sender of a redistribution, fpx_set_numpart) must first put every particle back into the space of its number, or the
+  // spaces beyond the new numpart would still hold live particles.
+  int restore_particle_order() {
+    if (!slot_of_pid) return 0;
+    return sort_impl(true);
+  }
   int sort_particles() override {
     if (!height_set) return fail(FPX_ERR_STATE, "sort_particles: set_height first");
+    return sort_impl(false);
+  }
+  int sort_impl(bool by_pid) {
     const long long n = numpart;
-    if (n < 2) return 0;
+    if (n < 2) { if (by_pid) slot_of_pid = nullptr; return 0; }
     int rc;
     if (!have_p2) {
       if ((rc = alloc_parts(P2))) return rc;
@@ -4123,9 +4290,10 @@ struct Engine : EngineBase {
     const unsigned long long nkeys = (unsigned long long)cfg.nx * cfg.ny * cfg.nz + 1ull;
     if (nkeys > 0xFFFFFFFFull) return fail(FPX_ERR_UNSUPPORTED, "sort_particles: grid too large for 32-bit keys");
     unsigned int bits = 1;
-    while ((1ull << bits) < nkeys + 1ull) bits++;
+    while ((1ull << bits) < (by_pid ? (unsigned long long)n : nkeys) + 1ull) bits++;
     const int nb = (int)((n + kBlock - 1) / kBlock);
-    k_sort_keys<R><<<nb, kBlock, 0, stream>>>(V, P, n, d_keys, d_vals, (unsigned int)(nkeys - 1ull));
+    if (by_pid) k_sort_keys_pid<<<nb, kBlock, 0, stream>>>(P.pid, n, d_keys, d_vals);
+    else k_sort_keys<R><<<nb, kBlock, 0, stream>>>(V, P, n, d_keys, d_vals, (unsigned int)(nkeys - 1ull));
     HIPCHK(hipGetLastError());
     size_t need = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, need, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0u, bits, stream));
@@ -4179,8 +4347,8 @@ struct Engine : EngineBase {
       k_iota_pid<<<nbr, kBlock, 0, stream>>>(P.pid, n, rest);
       HIPCHK(hipGetLastError());
     }
-    slot_of_pid = d_slot_of_pid;
-    slot_map_dirty = true;
+    slot_of_pid = by_pid ? nullptr : d_slot_of_pid;      // back in particle-number order: the identity again
+    slot_map_dirty = !by_pid;
     return 0;
   }
 
@@ -4807,6 +4975,42 @@ int fpx_releaseparticles(fpx_handle h, int32_t itime, int64_t *numpart, int32_t 
   return h->impl->releaseparticles(itime, numpart, numparticlecount, xmasssave, rho_rel, nreleased);
 }
 int fpx_split_particles(fpx_handle h, int32_t itime, int64_t *numpart) { FPX_GUARD(h); return h->impl->split_particles(itime, numpart); }
+// mpi_mod.f90:566-658 (mpif_calculate_part_redist): which pairs of ranks exchange how many particles.  Pure host logic.
+int fpx_redist_plan(const int64_t *npart_per_process, int32_t nranks, int32_t rank, int32_t ipout, int32_t *role, int32_t *peer, int64_t *num_trans) {
+  if (!role || !peer || !num_trans) return FPX_ERR_ARG;
+  *role = 0; *peer = -1; *num_trans = 0;
+  if (!npart_per_process || nranks < 1 || rank < 0 || rank >= nranks) return FPX_ERR_ARG;
+  if (nranks == 1 || ipout == 3) return 0;                           // :597, :613
+  const double mp_redist_fract = 0.2;                                // mpi_mod.f90:156-157
+  const int64_t mp_min_redist = 100000;
+  std::vector<float> sorted((size_t)nranks);                         // the reference sorts the counts as default reals
+  std::vector<int> idx((size_t)nranks);
+  for (int i = 0; i < nranks; i++) { sorted[i] = (float)npart_per_process[i]; idx[i] = i; }
+  for (int i = 0; i <= nranks - 2; i++) {                            // :616-631, the reference's selection sort, ties included
+    float pmin = sorted[i];
+    int imin = idx[i];
+    for (int jj = i + 1; jj <= nranks - 1; jj++) {
+      if (pmin <= sorted[jj]) continue;
+      const float z = pmin; pmin = sorted[jj]; sorted[jj] = z;
+      const int nn = imin; imin = idx[jj]; idx[jj] = nn;
+    }
+    sorted[i] = pmin; idx[i] = imin;
+  }
+  int m = nranks - 1;
+  for (int i = 0; i <= nranks / 2 - 1; i++, m--) {                   // :639-655
+    const int64_t hi = npart_per_process[idx[m]], lo = npart_per_process[idx[i]], nt = hi - lo;
+    if (rank != idx[m] && rank != idx[i]) continue;
+    if (hi > mp_min_redist && (float)nt / (float)hi > (float)mp_redist_fract) {
+      *role = rank == idx[m] ? 1 : 2;
+      *peer = rank == idx[m] ? idx[i] : idx[m];
+      *num_trans = nt / 2;
+    }
+  }
+  return 0;
+}
+uint64_t fpx_redist_bytes(fpx_handle h, int64_t num_trans) { if (!h || !h->impl) return 0; return (uint64_t)h->impl->redist_bytes(num_trans); }
+int fpx_redist_pack(fpx_handle h, int32_t itime, int64_t num_trans, void *buf, uint64_t buf_bytes, int64_t *numpart) { FPX_GUARD(h); return h->impl->redist_pack(itime, num_trans, buf, (size_t)buf_bytes, numpart); }
+int fpx_redist_unpack(fpx_handle h, int32_t itime, int64_t num_trans, const void *buf, uint64_t buf_bytes, int64_t *numpart) { FPX_GUARD(h); return h->impl->redist_unpack(itime, num_trans, buf, (size_t)buf_bytes, numpart); }
 int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *st) { FPX_GUARD(h); return h->impl->step(itime, st, false); }
 int fpx_step_async(fpx_handle h, int32_t itime) { FPX_GUARD(h); return h->impl->step(itime, nullptr, true); }
 int fpx_sync(fpx_handle h) { FPX_GUARD(h); return h->impl->sync(); }

@@ -545,6 +545,23 @@ class Engine:
         check(self.lib.fpx_split_particles(self.h, int(itime), C.byref(n)), "fpx_split_particles")
         self.n = int(n.value)
 
+    # ---- mpi_mod.f90:566-856: levelling the ranks' particle counts (the host keeps the transport) ----
+    def redist_pack(self, itime, num_trans):
+        """Sender: the last num_trans storage spaces -> one message (numpy uint8 array); they are terminated, self.n shrinks."""
+        nb = int(self.lib.fpx_redist_bytes(self.h, int(num_trans)))
+        buf = np.zeros(max(nb, 1), np.uint8)
+        n = C.c_int64(self.n)
+        check(self.lib.fpx_redist_pack(self.h, int(itime), int(num_trans), _vp(buf), nb, C.byref(n)), "fpx_redist_pack")
+        self.n = int(n.value)
+        return buf[:nb]
+
+    def redist_unpack(self, itime, num_trans, buf):
+        """Receiver: places the message's particles that are alive at itime into vacant storage spaces; self.n follows."""
+        buf = np.ascontiguousarray(buf, np.uint8)
+        n = C.c_int64(self.n)
+        check(self.lib.fpx_redist_unpack(self.h, int(itime), int(num_trans), _vp(buf), buf.size, C.byref(n)), "fpx_redist_unpack")
+        self.n = int(n.value)
+
     def set_windtime(self, memtime, memind):
         mt = (C.c_int32 * 2)(int(memtime[0]), int(memtime[1]))
         mi = (C.c_int32 * 2)(int(memind[0]), int(memind[1]))

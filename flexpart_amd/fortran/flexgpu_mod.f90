@@ -34,6 +34,7 @@ module flexgpu_mod
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
             flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, flexgpu_count_particles, &
             flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar, &
+            flexgpu_redist_plan, flexgpu_redist_bytes, flexgpu_redist_pack, flexgpu_redist_unpack, &
             flexgpu_checkpoint_write, flexgpu_checkpoint_read, &
             flexgpu_conv_init, flexgpu_upload_conv_fields, flexgpu_convmix, flexgpu_cbaseflux
 #ifdef FLEXGPU_NESTS
@@ -192,6 +193,32 @@ module flexgpu_mod
       import :: c_ptr, c_int, c_int32_t, c_int64_t
       type(c_ptr), value :: h
       integer(c_int32_t), value :: itime
+      integer(c_int64_t), intent(inout) :: numpart
+    end function
+    integer(c_int) function fpx_redist_plan(npart, nranks, rank, ipout, role, peer, num_trans) bind(C, name='fpx_redist_plan')
+      import :: c_int, c_int32_t, c_int64_t
+      integer(c_int64_t), intent(in) :: npart(*)
+      integer(c_int32_t), value :: nranks, rank, ipout
+      integer(c_int32_t), intent(out) :: role, peer
+      integer(c_int64_t), intent(out) :: num_trans
+    end function
+    integer(c_int64_t) function fpx_redist_bytes(h, num_trans) bind(C, name='fpx_redist_bytes')
+      import :: c_ptr, c_int64_t
+      type(c_ptr), value :: h
+      integer(c_int64_t), value :: num_trans
+    end function
+    integer(c_int) function fpx_redist_pack(h, itime, num_trans, buf, buf_bytes, numpart) bind(C, name='fpx_redist_pack')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t
+      type(c_ptr), value :: h, buf
+      integer(c_int32_t), value :: itime
+      integer(c_int64_t), value :: num_trans, buf_bytes
+      integer(c_int64_t), intent(inout) :: numpart
+    end function
+    integer(c_int) function fpx_redist_unpack(h, itime, num_trans, buf, buf_bytes, numpart) bind(C, name='fpx_redist_unpack')
+      import :: c_ptr, c_int, c_int32_t, c_int64_t
+      type(c_ptr), value :: h, buf
+      integer(c_int32_t), value :: itime
+      integer(c_int64_t), value :: num_trans, buf_bytes
       integer(c_int64_t), intent(inout) :: numpart
     end function
     integer(c_int) function fpx_set_release_heights(h, numpoint, z1, z2) bind(C, name='fpx_set_release_heights')
@@ -1066,6 +1093,46 @@ contains
     if (ierr /= 0) return
     numpart = int(np)
   end subroutine flexgpu_split_particles
+
+  ! ---- mpi_mod.f90:566-856: levelling the processes' particle counts; the host keeps its MPI calls ----
+  ! mpif_calculate_part_redist without the MPI_Allgather: npart_per_process(0:np-1) -> what THIS process does
+  ! (role 0 nothing, 1 send, 2 receive num_trans particles to / from process peer)
+  subroutine flexgpu_redist_plan(npart_per_process, mp_np, mp_partid, role, peer, num_trans, ierr)
+    integer, intent(in) :: npart_per_process(0:), mp_np, mp_partid
+    integer, intent(out) :: role, peer, num_trans, ierr
+    integer(c_int64_t) :: cnt(0:mp_np-1), nt
+    integer(c_int32_t) :: r, p
+    cnt = int(npart_per_process(0:mp_np-1), c_int64_t)
+    ierr = fpx_redist_plan(cnt, int(mp_np, c_int32_t), int(mp_partid, c_int32_t), int(ipout, c_int32_t), r, p, nt)
+    role = int(r); peer = int(p); num_trans = int(nt)
+  end subroutine flexgpu_redist_plan
+
+  integer function flexgpu_redist_bytes(num_trans)
+    integer, intent(in) :: num_trans
+    flexgpu_redist_bytes = int(fpx_redist_bytes(flexgpu_handle, int(num_trans, c_int64_t)))
+  end function flexgpu_redist_bytes
+
+  ! the sending half of mpif_redist_part (:700-746): buf(1:flexgpu_redist_bytes(num_trans)) is the ONE message
+  subroutine flexgpu_redist_pack(itime, num_trans, buf, ierr)
+    integer, intent(in) :: itime, num_trans
+    integer(c_int8_t), intent(inout), target :: buf(:)
+    integer, intent(out) :: ierr
+    integer(c_int64_t) :: np
+    np = numpart
+    ierr = fpx_redist_pack(flexgpu_handle, int(itime, c_int32_t), int(num_trans, c_int64_t), c_loc(buf), int(size(buf), c_int64_t), np)
+    if (ierr == 0) numpart = int(np)
+  end subroutine flexgpu_redist_pack
+
+  ! the receiving half (:749-841)
+  subroutine flexgpu_redist_unpack(itime, num_trans, buf, ierr)
+    integer, intent(in) :: itime, num_trans
+    integer(c_int8_t), intent(in), target :: buf(:)
+    integer, intent(out) :: ierr
+    integer(c_int64_t) :: np
+    np = numpart
+    ierr = fpx_redist_unpack(flexgpu_handle, int(itime, c_int32_t), int(num_trans, c_int64_t), c_loc(buf), int(size(buf), c_int64_t), np)
+    if (ierr == 0) numpart = int(np)
+  end subroutine flexgpu_redist_unpack
 
   subroutine flexgpu_upload_particles(j1, j2, ierr)
     integer, intent(in) :: j1, j2

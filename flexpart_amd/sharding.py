@@ -59,3 +59,42 @@ def allreduce_sum_numpy(dist, a: np.ndarray) -> np.ndarray:
     t = torch.from_numpy(np.ascontiguousarray(a).copy())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.numpy()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Levelling the ranks' particle counts (mpi_mod.f90:566-856).  The plan is the library's (fpx_redist_plan, pure host
+# arithmetic); the transport is the host's -- here torch.distributed send/recv of the ONE message the engine packs.
+# ---------------------------------------------------------------------------------------------------------
+def redist_plan(counts, rank: int, ipout: int = 1, lib=None):
+    """(role, peer, num_trans) of `rank` for the particle counts of all ranks: role 0 = nothing, 1 = send, 2 = receive."""
+    import ctypes as C
+    if lib is None:
+        from . import _lib
+        lib = _lib.load()
+    counts = [int(c) for c in counts]
+    arr = (C.c_int64 * len(counts))(*counts)
+    role, peer, nt = C.c_int32(0), C.c_int32(-1), C.c_int64(0)
+    rc = lib.fpx_redist_plan(arr, len(counts), int(rank), int(ipout), C.byref(role), C.byref(peer), C.byref(nt))
+    if rc != 0:
+        raise ValueError(f"fpx_redist_plan: status {rc}")
+    return int(role.value), int(peer.value), int(nt.value)
+
+
+def redistribute_particles(dist, eng, itime: int, ipout: int = 1):
+    """mpif_calculate_part_redist + mpif_redist_part for one engine per rank: all-gather of numpart, the plan, and one
+    send / recv of the packed particles between the two ranks of a pair.  Returns (role, peer, num_trans)."""
+    import torch
+    world, rank = dist.get_world_size(), dist.get_rank()
+    mine = torch.tensor([int(eng.n)], dtype=torch.int64)
+    allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, mine)                                   # MPI_Allgather(numpart ...), mpi_mod.f90:603
+    role, peer, nt = redist_plan([int(t.item()) for t in allc], rank, ipout, eng.lib)
+    if role == 1:
+        buf = eng.redist_pack(itime, nt)
+        dist.send(torch.from_numpy(np.ascontiguousarray(buf)), dst=peer)
+    elif role == 2:
+        nb = int(eng.lib.fpx_redist_bytes(eng.h, nt))
+        t = torch.zeros(nb, dtype=torch.uint8)
+        dist.recv(t, src=peer)
+        eng.redist_unpack(itime, nt, t.numpy())
+    return role, peer, nt

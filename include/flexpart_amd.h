@@ -450,6 +450,27 @@ int fpx_releaseparticles(fpx_handle h, int32_t itime, int64_t *numpart, int32_t 
  * there is room), both halves carry half the mass and the doubled splitting interval.  numpart in/out. */
 int fpx_split_particles(fpx_handle h, int32_t itime, int64_t *numpart);
 
+/* ---- keeping the ranks' particle counts level (mpi_mod.f90:566-856) ---------------------------------------
+ * mpif_calculate_part_redist (:566-658): every rank knows all counts (the host's MPI_Allgather of numpart, :603); the
+ * counts are sorted, the rank with the most particles is paired with the one with the fewest, the second with the
+ * second-fewest ...; a pair exchanges (difference)/2 particles when the larger count exceeds mp_min_redist = 100000 and
+ * the difference more than mp_redist_fract = 0.2 of it; never with ipout = 3.  role: 0 nothing to do, 1 this rank sends,
+ * 2 it receives num_trans particles from / to peer.  Pure host arithmetic: no handle, no device. */
+int fpx_redist_plan(const int64_t *npart_per_process, int32_t nranks, int32_t rank, int32_t ipout, int32_t *role, int32_t *peer,
+                    int64_t *num_trans);
+/* mpif_redist_part (:661-856).  The host keeps the transport: ONE message of fpx_redist_bytes(h, num_trans) bytes instead
+ * of the reference's 9 + nspec.  Sender (:700-746): the storage spaces numpart-num_trans+1 .. numpart are copied into buf
+ * and terminated (itra1 = -999999999), numpart -= num_trans.  Receiver (:749-841): the received particles that are alive
+ * at itime go, in order, into the storage spaces 1 .. numpart+num_trans whose itra1 /= itime; numpart = max(numpart, last
+ * space used).  As in the reference only nclass, npoint, itra1, idt, itramem, itrasplit, xtra1, ytra1, ztra1 and xmass1
+ * travel: the turbulent velocities, cbt (and xscav_frac1) of a storage space stay what its last owner left.
+ * buf: host or device memory; layout (n = num_trans, R = the engine's compute real): xtra1 f64[n], ytra1 f64[n], ztra1 R[n],
+ * xmass1 R[nspec][n], then int32[n] each: nclass, npoint, itra1, idt, itramem, itrasplit.  Both ranks must run the same
+ * configuration.  numpart + num_trans beyond the capacity: FPX_ERR_NOMEM, nothing changed. */
+uint64_t fpx_redist_bytes(fpx_handle h, int64_t num_trans);
+int fpx_redist_pack(fpx_handle h, int32_t itime, int64_t num_trans, void *buf, uint64_t buf_bytes, int64_t *numpart);
+int fpx_redist_unpack(fpx_handle h, int32_t itime, int64_t num_trans, const void *buf, uint64_t buf_bytes, int64_t *numpart);
+
 /* ---- the hot path --------------------------------------------------------- */
 /* One pass of the particle loop timemanager.f90:531-712 at time itime. */
 int fpx_step(fpx_handle h, int32_t itime, fpx_step_stats *stats);

@@ -115,3 +115,67 @@ def test_two_ranks_one_gpu_two_output_times(built, tmp_path):
     for k in ("drygridunc", "wetgridunc", "drygriduncn", "wetgriduncn"):
         assert s[f"o1_{k}"].sum() > 1.2 * s[f"o0_{k}"].sum(), k        # the deposition grids did accumulate over the run
     assert s["o1_gridunc"].sum() < 1.5 * s["o0_gridunc"].sum()          # gridunc was zeroed after the first output
+
+
+REDIST_WORKER = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %(root)r)
+    import numpy as np
+    import torch.distributed as dist
+    from flexpart_amd import sharding, synthetic as syn
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    rank = int(sys.argv[1])
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
+    n = (260000, 120000)[rank]
+    sc = syn.small(n=n, nx=48, ny=32, nz=36, nsteps=2, ctl=5.0, ifine=4, cblflag=1, seed=100 + rank)
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, seed=4711, max_particles=300000,
+                 particle_base=rank * 300000)
+    eng.upload_particles_from_scenario(sc)
+    eng.step()                                   # a step first: some particles leave, the slots get sorted on rank 0
+    if rank == 0:
+        eng.sort()
+    before = eng.download()
+    itime = eng.itime
+    role, peer, nt = sharding.redistribute_particles(dist, eng, itime)
+    after = eng.download(0, 300000)
+    stats = eng.step()                           # the received particles advance with everything else
+    np.savez(%(out)r + f"_rank{rank}.npz", role=role, peer=peer, nt=nt, n_after=eng.n, itime=itime, due=stats["n_due"],
+             bx=before["xtra1"], by=before["ytra1"], bz=before["ztra1"], bi=before["itra1"], bm=before["xmass1"],
+             ax=after["xtra1"], ay=after["ytra1"], az=after["ztra1"], ai=after["itra1"], am=after["xmass1"])
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_two_ranks_level_their_particle_counts(built, tmp_path):
+    """mpif_calculate_part_redist + mpif_redist_part (mpi_mod.f90:566-856) between two processes on one GPU, the transport
+    being the host's (gloo send / recv of the one packed message): 260000 and 120000 particles -> the plan moves 70000; the
+    particles alive at itime are the same set before and after (position, height and mass of each), the counts are levelled,
+    and the next step advances every one of them."""
+    out = str(tmp_path / "rd")
+    port = 35500 + (os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ws = tmp_path / "redist_worker.py"
+    ws.write_text(REDIST_WORKER % dict(root=ROOT, port=port, out=out))
+    procs = [subprocess.Popen([sys.executable, str(ws), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    a, b = (np.load(out + f"_rank{r}.npz") for r in (0, 1))
+    assert (int(a["role"]), int(a["peer"]), int(a["nt"])) == (1, 1, 70000)
+    assert (int(b["role"]), int(b["peer"]), int(b["nt"])) == (2, 0, 70000)
+    itime = int(a["itime"])
+
+    def alive(d, p):
+        m = d[p + "i"] == itime
+        rows = np.stack([d[p + "x"][m], d[p + "y"][m], d[p + "z"][m], d[p + "m"].reshape(-1, d[p + "i"].size)[0][m]], axis=1)
+        return rows[np.lexsort(rows.T[::-1])]
+    before = np.concatenate([alive(a, "b"), alive(b, "b")])
+    after = np.concatenate([alive(a, "a"), alive(b, "a")])
+    before, after = (v[np.lexsort(v.T[::-1])] for v in (before, after))
+    assert before.shape == after.shape and np.array_equal(before, after)
+    na, nb = int((a["ai"] == itime).sum()), int((b["ai"] == itime).sum())
+    nb0 = int((b["bi"] == itime).sum())
+    assert nb > nb0 and nb - nb0 <= 70000 and int(a["n_after"]) == 260000 - 70000
+    assert int(a["due"]) == na and int(b["due"]) == nb                         # every particle, received ones included, advanced

@@ -1,0 +1,183 @@
+"""Levelling the ranks' particle counts (mpi_mod.f90:566-856): fpx_redist_plan, fpx_redist_pack,
+fpx_redist_unpack against the restatement in oracle/redist_oracle.py (parity unpinned: mpi_mod needs MPI to compile)."""
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import redist_oracle as ro        # noqa: E402  (the checker)
+
+
+@pytest.fixture(scope="module")
+def built_lib(built):
+    from flexpart_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture()
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _cases():
+    rng = np.random.default_rng(11)
+    cases = [[50], [200000, 100000], [100000, 200000], [120000, 100001], [99999, 10], [100001, 10], [300000, 300000, 300000],
+             [5, 400000, 250000], [400000, 5, 250000, 260000, 1000000], [100001, 80001], [100001, 80000], [150000] * 4]
+    for n in range(2, 10):
+        for _ in range(6):
+            cases.append([int(v) for v in rng.integers(0, 600000, n)])
+        cases.append([int(v) for v in rng.choice([90000, 130000, 500000], n)])     # ties
+    return cases
+
+
+def test_plan_matches_the_restatement_and_is_mutual(built_lib):
+    from flexpart_amd import sharding
+    for counts in _cases():
+        want = ro.plan(counts)
+        got = [sharding.redist_plan(counts, r, 1, built_lib) for r in range(len(counts))]
+        pairs = sorted((r, peer, nt) for r, (role, peer, nt) in enumerate(got) if role == 1)
+        assert pairs == sorted(want), (counts, pairs, want)
+        for r, (role, peer, nt) in enumerate(got):
+            if role == 1:
+                assert got[peer] == (2, r, nt), (counts, r, got)
+            elif role == 2:
+                assert got[peer] == (1, r, nt), (counts, r, got)
+            else:
+                assert (peer, nt) == (-1, 0)
+        # ipout = 3: never (mpi_mod.f90:613)
+        assert all(sharding.redist_plan(counts, r, 3, built_lib)[0] == 0 for r in range(len(counts)))
+        # after the exchange no pair that exchanged is further apart than one particle
+        after = list(counts)
+        for s, d, nt in want:
+            after[s] -= nt; after[d] += nt
+            assert abs(after[s] - after[d]) <= 1
+
+
+def test_plan_rejects_bad_arguments(built_lib):
+    import ctypes as C
+    role, peer, nt = C.c_int32(), C.c_int32(), C.c_int64()
+    arr = (C.c_int64 * 2)(1, 2)
+    assert built_lib.fpx_redist_plan(arr, 2, 2, 1, C.byref(role), C.byref(peer), C.byref(nt)) != 0
+    assert built_lib.fpx_redist_plan(None, 2, 0, 1, C.byref(role), C.byref(peer), C.byref(nt)) != 0
+    assert built_lib.fpx_redist_plan(arr, 0, 0, 1, C.byref(role), C.byref(peer), C.byref(nt)) != 0
+
+
+PLAN_WORKER = textwrap.dedent("""
+    import sys
+    sys.path.insert(0, %(root)r)
+    import torch, torch.distributed as dist
+    from flexpart_amd import sharding
+    rank, world = int(sys.argv[1]), %(world)d
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+    counts = %(counts)r
+    mine = torch.tensor([counts[rank]], dtype=torch.int64)
+    allc = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allc, mine)
+    role, peer, nt = sharding.redist_plan([int(t.item()) for t in allc], rank)
+    # the two ranks of a pair agree: exchange the plan with the peer
+    if role:
+        other = torch.zeros(3, dtype=torch.int64)
+        me = torch.tensor([role, rank, nt], dtype=torch.int64)
+        if role == 1:
+            dist.send(me, dst=peer); dist.recv(other, src=peer)
+        else:
+            dist.recv(other, src=peer); dist.send(me, dst=peer)
+        assert [int(v) for v in other] == [3 - role, peer, nt], (rank, role, peer, nt, other)
+    print("PLAN", rank, role, peer, nt, flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_plan_over_gloo_three_ranks(built_lib, free_port):
+    counts = [400000, 120000, 260000]
+    src = PLAN_WORKER % dict(root=ROOT, world=3, port=free_port, counts=counts)
+    procs = [subprocess.Popen([sys.executable, "-c", src, str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    got = {}
+    for o in outs:
+        for line in o.splitlines():
+            if line.startswith("PLAN"):
+                _, r, role, peer, nt = line.split()
+                got[int(r)] = (int(role), int(peer), int(nt))
+    assert got == {0: (1, 1, 140000), 1: (2, 0, 140000), 2: (0, -1, 0)}, got
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _ref_arrays(st, nspec):
+    d = {k: np.array(st[k]) for k in ("xtra1", "ytra1", "ztra1", "itra1", "idt", "itramem", "itrasplit", "npoint", "nclass")}
+    d["xmass1"] = np.array(st["xmass1"]).reshape(nspec, -1)
+    return d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["r8", "r4"])
+def test_pack_and_unpack_move_particles_like_the_reference(built, kind):
+    """Two engines (= two ranks' particle sets) on one device: the message of the sender, placed by the receiver, equals the
+    restatement of mpif_redist_part array by array, bit for bit -- with dead particles inside the transferred range, vacant
+    spaces in the receiver, and after a locality sort on both sides; what does not travel (turbulent velocities, cbt) stays."""
+    from flexpart_amd import synthetic as syn
+    from flexpart_amd.engine import Engine
+    rb = 8 if kind == "r8" else 4
+    itime, nspec, cap = 0, 2, 1500
+    engs = []
+    for seed, n in ((3, 900), (5, 500)):
+        sc = syn.small(n=n, nx=24, ny=16, nz=20, nsteps=1, seed=seed)
+        rng = np.random.default_rng(seed)
+        sc["nspec"] = nspec
+        sc["xmass1"] = rng.random((nspec, n))
+        for k in ("decay", "density", "dquer", "vsetaver", "cunningham", "xmass"):
+            if k in sc:
+                sc[k] = np.resize(np.asarray(sc[k], float), nspec)
+        if "drydepspec" in sc:
+            sc["drydepspec"] = np.resize(np.asarray(sc["drydepspec"], np.int32), nspec)
+        it = np.array(sc["itra1"]); it[rng.random(n) < 0.2] = -999999999        # vacancies / dead particles in the message
+        sc["itra1"] = it
+        sc["itrasplit"] = rng.integers(1000, 900000, n).astype(np.int32)
+        sc["nclass"] = rng.integers(1, 4, n).astype(np.int32)
+        eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, max_particles=cap)
+        eng.upload_particles_from_scenario(sc)
+        engs.append(eng)
+    a, b = engs
+    for sorted_first in (False, True):
+        if sorted_first:
+            a.sort(); b.sort()
+        na0, nb0 = a.n, b.n
+        nt = 300
+        sa, sb = a.download(0, cap), b.download(0, cap)
+        ra, rb_ = _ref_arrays(sa, nspec), _ref_arrays(sb, nspec)
+        na, nb = ro.redist_part(ra, rb_, na0, nb0, nt, itime)
+        buf = a.redist_pack(itime, nt)
+        assert buf.size == int(a.lib.fpx_redist_bytes(a.h, nt))
+        b.redist_unpack(itime, nt, buf)
+        assert (a.n, b.n) == (na, nb), ((a.n, b.n), (na, nb))
+        ga, gb = a.download(0, cap), b.download(0, cap)
+        # storage spaces that either side has ever used (beyond them: never-used storage, only required to be vacant)
+        for k in ro.ARRAYS:
+            for got, want, used, who in ((ga, ra, na0, "sender"), (gb, rb_, nb0 + nt, "receiver")):
+                g = np.asarray(got[k]).reshape(nspec, -1) if k == "xmass1" else np.asarray(got[k])
+                assert np.array_equal(g[..., :used], want[k][..., :used]), (k, who, sorted_first)
+                if k == "itra1":
+                    assert np.all(g[used:] != itime), (who, sorted_first)
+        for k in ("uap", "ucp", "uzp", "us", "vs", "ws", "cbt"):
+            assert np.array_equal(np.asarray(gb[k])[:nb0 + nt], np.asarray(sb[k])[:nb0 + nt]), (k, "stays what the space's last owner left")
+    # nothing to do / refusals
+    n0 = (a.n, b.n)
+    assert a.redist_pack(itime, 0).size == 0 and (a.n, b.n) == n0
+    with pytest.raises(RuntimeError):
+        b.redist_unpack(itime, cap, np.zeros(int(b.lib.fpx_redist_bytes(b.h, cap)), np.uint8))      # beyond the capacity
+    with pytest.raises(RuntimeError):
+        a.redist_pack(itime, a.n + 1)
+    assert (a.n, b.n) == n0
+    for e in engs:
+        e.close()

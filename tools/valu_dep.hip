@@ -4,7 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 
-#define ITER 4096
+#define ITER 65536
 template <int NCHAIN>
 __global__ void __launch_bounds__(256) k_dep(double *out, double a, double b) {
   double r0 = a + threadIdx.x, r1 = a * 2 + threadIdx.x, r2 = a * 3, r3 = a * 5;
@@ -57,7 +57,7 @@ int main() {
   hipMalloc(&out, sizeof(double) * 256 * cus * 8);
   const double ghz = p.clockRate * 1e-6;
   printf("device %s, %d CUs, %.2f GHz nominal\n", p.name, cus, ghz);
-  for (int wps = 1; wps <= 4; wps++) {   // waves per SIMD = blocks of 256 threads per CU
+  for (int wps : {1, 2, 3, 4, 6, 8}) {   // waves per SIMD = blocks of 256 threads per CU
     const int grid = cus * wps;
     const double n = 8.0 * ITER * wps;   // FMAs per SIMD
     double t1 = time_ms([&] { hipLaunchKernelGGL(k_dep<1>, dim3(grid), dim3(256), 0, 0, out, 1.0, 1.0000001); });
