@@ -579,6 +579,10 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     else if (B.ol < (R)0) cls = 2;                                            // unstable, Gaussian: next to the CBL class, whose
                                                                               // hanna_short branch it shares (waves at a class boundary run both classes)
     else cls = 4;                                                             // stable
+    // (measured and not kept: the reverse order -- 297.3 instead of 293.7 ms at 1e8, 47.9 instead of 42.2 ms at an eighth
+    // of the cloud: the launch must not END on the CBL class, whose particles make the most passes; a cursor per class
+    // with the waves dealt to the classes by their work -- 46.7 ms at an eighth: every class then ends at the end of the
+    // launch; a cost bucket (octaves of (ustar+wstar)/h) below the class in the key: no measurable change)
     pbl_flag[s] = cls;
     return;
   }
