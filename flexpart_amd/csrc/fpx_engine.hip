@@ -2790,25 +2790,28 @@ struct Engine : EngineBase {
     if (e == hipSuccess) e = mal(&d_mass, (size_t)ns * np);
     if (e == hipSuccess) e = mal(&d_kindz, (size_t)np);
     if (e == hipSuccess) e = mal(&d_rho, (size_t)np);
+    // the vacancies are looked for in the storage spaces 1 .. numpart + ntotal only: the spaces behind numpart are vacant, so
+    // the first ntotal vacancies lie in there (or, past the capacity, do not exist) -- not a scan of the whole capacity per call
+    const long long scan_n = std::min<long long>(cap, numpart + ntotal);
     size_t tb = 0;
     if (e == hipSuccess) {
-      (void)rocprim::exclusive_scan(nullptr, tb, flags, rank, 0u, (size_t)cap, rocprim::plus<unsigned int>(), stream);
+      (void)rocprim::exclusive_scan(nullptr, tb, flags, rank, 0u, (size_t)scan_n, rocprim::plus<unsigned int>(), stream);
       e = rel_scan_tmp(tb, &tmp) ? hipErrorOutOfMemory : hipSuccess;
     }
     if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_NOMEM, std::string("releaseparticles: ") + hipGetErrorString(e)); }
-    const int nbc = (int)((cap + kBlock - 1) / kBlock);
-    k_rel_flags<R><<<nbc, kBlock, 0, stream>>>(P, slot_map(), cap, itime, flags);
-    e = rocprim::exclusive_scan(tmp, tb, flags, rank, 0u, (size_t)cap, rocprim::plus<unsigned int>(), stream);
+    const int nbc = (int)((scan_n + kBlock - 1) / kBlock);
+    k_rel_flags<R><<<nbc, kBlock, 0, stream>>>(P, slot_map(), scan_n, itime, flags);
+    e = rocprim::exclusive_scan(tmp, tb, flags, rank, 0u, (size_t)scan_n, rocprim::plus<unsigned int>(), stream);
     unsigned int last[2] = {0, 0};
-    if (e == hipSuccess) e = hipMemcpyAsync(&last[0], rank + (cap - 1), 4, hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], flags + (cap - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[0], rank + (scan_n - 1), 4, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&last[1], flags + (scan_n - 1), 4, hipMemcpyDeviceToHost, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) { cleanup(); return fail(FPX_ERR_DEVICE, std::string("releaseparticles: ") + hipGetErrorString(e)); }
     if ((long long)last[0] + last[1] < ntotal) {
       cleanup();
       return fail(FPX_ERR_NOMEM, "releaseparticles: total number of particles required exceeds the maximum allowed number (releaseparticles.f90:369-378)");
     }
-    k_rel_targets<<<nbc, kBlock, 0, stream>>>(flags, rank, cap, ntotal, target);
+    k_rel_targets<<<nbc, kBlock, 0, stream>>>(flags, rank, scan_n, ntotal, target);
     // ---- the four uniforms of every particle: serial ran1 stream (x, y, class, z per particle) or counter RNG ----
     std::vector<H> uni;
     if (cfg.rng_mode == FPX_RNG_TABLE_SEQ) {
