@@ -421,6 +421,10 @@ struct View {
   const R *height;   // [nz]
   const R *w3;       // [ny][nx][nz][2 slots][3]  (uu, vv, ww)
   const R *w3pol;    // same with (uupol, vvpol, ww); only when a pole is in the grid
+  // Time-blended copies of w3 for the step in flight, [jy][ix][iz][3], or NULL (see Engine::blend_winds): the wind at itime
+  // (w3t0) and at itime + lsynctime*ldirect (w3t1, the Petterssen re-interpolation).  The time weights are the same for every
+  // particle of a step, so a gather that needs no standard deviations reads half the bytes from these.
+  const R *w3t0, *w3t1;
   const R *r2;       // [ny][nx][nz][2 slots][2]  (rho, drhodz)
   const R *sfc;      // [ny][nx][2 slots][4]      (ustar, wstar, oli, hmix)
   const R *hcell;    // [ny][nx]  max of hmix over the cell's 4 corners x 2 slots
@@ -610,6 +614,7 @@ template <typename R>
 struct Fld {
   int nx;
   const R *w3, *r2, *sfc, *hcell, *tropo, *vdep;
+  const R *w3t0, *w3t1;   // time-blended wind packs of the mother grid (View), NULL elsewhere
 };
 template <typename R>
 FPX_DEV Fld<R> fld_of(const View<R> &V, int ngrid) {
@@ -618,8 +623,10 @@ FPX_DEV Fld<R> fld_of(const View<R> &V, int ngrid) {
     const int l = ngrid - 1;
     const NestDesc<R> &N = V.nest[l];
     F.nx = N.nx; F.w3 = N.w3; F.r2 = N.r2; F.sfc = N.sfc; F.hcell = N.hcell; F.tropo = N.tropo; F.vdep = N.vdep;
+    F.w3t0 = nullptr; F.w3t1 = nullptr;
   } else {
     F.nx = V.nx; F.w3 = ngrid < 0 ? V.w3pol : V.w3; F.r2 = V.r2; F.sfc = V.sfc; F.hcell = V.hcell; F.tropo = V.tropo; F.vdep = V.vdep;
+    F.w3t0 = ngrid < 0 ? nullptr : V.w3t0; F.w3t1 = ngrid < 0 ? nullptr : V.w3t1;
   }
   return F;
 }
@@ -1481,10 +1488,38 @@ struct NoLate { FPX_DEV void operator()() const {} };
 #endif
 template <typename R, bool SIG, typename LATE = NoLate, int DEPTH = FPX_GATHER_DEPTH>
 FPX_DEV void interp_wind(const View<R> &V, const R *hgt, const Fld<R> &F, const Cell<R> &C, const TimeW<R> &W, R zt,
-                         R &u, R &v, R &w, R &usig, R &vsig, R &wsig, const LATE &late = LATE()) {
+                         R &u, R &v, R &w, R &usig, R &vsig, R &wsig, const LATE &late = LATE(), const R *blended = nullptr) {
   const R eps = K(1.0e-30);
   const R *w3 = F.w3;
   const int indz = find_level(hgt, V.nz, zt);
+  if (!SIG && blended) {
+    // wave-uniform: the pack already carries (y(m1)*dt2 + y(m2)*dt1)*dtt of this call's time (interpol_wind.f90:189-191 taken
+    // before the horizontal and vertical sums instead of after: the same numbers up to rounding).  6 values per column
+    // instead of 12; all four columns in one round trip.
+    R x[4][6];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const long long col = (long long)((c & 2) ? C.jyp : C.jy) * F.nx + ((c & 1) ? C.ixp : C.ix);
+      const R *p = blended + (col * V.nz + (indz - 1)) * 3;
+#pragma unroll
+      for (int i = 0; i < 6; i++) x[c][i] = p[i];
+    }
+    late();
+    __builtin_amdgcn_sched_barrier(0);
+    R a[2][3];
+#pragma unroll
+    for (int n = 0; n < 2; n++)
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+        a[n][k] = ((C.p1 * x[0][n * 3 + k] + C.p2 * x[1][n * 3 + k]) + C.p3 * x[2][n * 3 + k]) + C.p4 * x[3][n * 3 + k];
+    const R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
+    const R dz1 = (zt - hgt[indz - 1]) * dz;
+    const R dz2 = (hgt[indz] - zt) * dz;
+    u = dz2 * a[0][0] + dz1 * a[1][0];
+    v = dz2 * a[0][1] + dz1 * a[1][1];
+    w = dz2 * a[0][2] + dz1 * a[1][2];
+    return;
+  }
   R au[2][2], av[2][2], aw[2][2];   // [physical slot][level]
   R usl = 0, vsl = 0, wsl = 0, usq = 0, vsq = 0, wsq = 0;
   // software pipeline over the four columns, DEPTH of them in flight (1: one dependent memory round trip
@@ -2121,7 +2156,7 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
 #ifndef FPX_ABOVE_DEPTH
 #define FPX_ABOVE_DEPTH 4
 #endif
-    interp_wind<R, false, LATE, FPX_ABOVE_DEPTH>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late);
+    interp_wind<R, false, LATE, FPX_ABOVE_DEPTH>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late, F.w3t0);
   } else {
     interp_wind<R, true>(V, hgt, F, C, W, zt, A.u, A.v, A.w, usig, vsig, wsig, late);
   }
@@ -2231,7 +2266,9 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
 #ifndef FPX_PETTERSSEN_DEPTH
 #define FPX_PETTERSSEN_DEPTH 4
 #endif
-    interp_wind<R, false, LATE, FPX_PETTERSSEN_DEPTH>(V, hgt, fld_of(V, A.ngrid), C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2, late);
+    // (P.ldt = |lsynctime| here, :829: the blended pack of itime + lsynctime*ldirect is this call's)
+    const Fld<R> FP = fld_of(V, A.ngrid);
+    interp_wind<R, false, LATE, FPX_PETTERSSEN_DEPTH>(V, hgt, FP, C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2, late, FP.w3t1);
   }
   if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt, A.nsp);   // advance.f90:893-906
   u = (u - A.u) / K(2.);

@@ -1104,6 +1104,22 @@ __global__ void __launch_bounds__(kBlock) k_co_density(View<R> V, int nxg, int n
   dens[i] = (r1 * dz1 + r0 * dz2) / dz;
 }
 
+// The wind pack blended in time for the step in flight: out0 at itime, out1 (may be NULL) at itime + lsynctime*ldirect.
+// (y(memind(1))*dt2 + y(memind(2))*dt1)*dtt, interpol_wind.f90:189-191, per grid point instead of per particle.
+template <typename R>
+__global__ void __launch_bounds__(256) k_blend_w3(const R *__restrict__ w3, long long npoint, int m1, int m2, R dt1a, R dt2a, R dtta,
+                                                  R dt1b, R dt2b, R dttb, R *__restrict__ out0, R *__restrict__ out1) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npoint) return;
+  const R *p = w3 + i * 6;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const R y1 = p[m1 * 3 + k], y2 = p[m2 * 3 + k];
+    out0[i * 3 + k] = (y1 * dt2a + y2 * dt1a) * dtta;
+    if (out1) out1[i * 3 + k] = (y1 * dt2b + y2 * dt1b) * dttb;
+  }
+}
+
 // After the stable sort of the slots by their 3-bit key: list length = number of keys <= 4 (PBL
 // classes), particles due = number of keys <= 6.  One wave, two 64-ary searches (5 dependent
 // loads each at 1e8 keys).
@@ -1639,6 +1655,29 @@ struct Engine : EngineBase {
   size_t staging_bytes = 0;
   unsigned int *slot_of_pid = nullptr;   // only after a locality sort; read it through slot_map()
   bool slot_map_dirty = false;
+  // Time-blended wind packs of the step in flight (View::w3t0 / w3t1).  Worth their 0.65 GB of extra traffic per step only
+  // for a large cloud: from FPX_BLEND_MIN particles on (default 3e7; 0 = never, 1 = always -- the parity tests).
+  R *d_w3t[2] = {nullptr, nullptr};
+  int blend_winds(int itime) {
+    const char *env = getenv("FPX_BLEND_MIN");      // read per step: the tests switch it inside one process
+    const long long blend_min = env ? atoll(env) : 30000000ll;
+    V.w3t0 = nullptr; V.w3t1 = nullptr;
+    if (blend_min <= 0 || numpart < blend_min) return 0;
+    const long long npoint = (long long)cfg.nx * cfg.ny * cfg.nz;
+    int rc;
+    for (int k = 0; k < 2; k++)
+      if (!d_w3t[k]) { if ((rc = dalloc(&d_w3t[k], (size_t)npoint * 3))) return rc; }
+    const int t1 = itime + cfg.lsynctime * cfg.ldirect;
+    const bool have1 = std::abs((long long)t1) <= std::abs((long long)V.memtime1);      // advance.f90:836: no Petterssen step beyond the window
+    const R dt1a = (R)(itime - V.memtime0), dt2a = (R)(V.memtime1 - itime), dtta = (R)1 / (dt1a + dt2a);
+    const R dt1b = (R)(t1 - V.memtime0), dt2b = (R)(V.memtime1 - t1), dttb = have1 ? (R)1 / (dt1b + dt2b) : (R)0;
+    k_blend_w3<R><<<(int)((npoint + 255) / 256), 256, 0, stream>>>(V.w3, npoint, V.m1, V.m2, dt1a, dt2a, dtta, dt1b, dt2b, dttb,
+                                                                     d_w3t[0], have1 ? d_w3t[1] : (R *)nullptr);
+    HIPCHK(hipGetLastError());
+    V.w3t0 = d_w3t[0];
+    V.w3t1 = have1 ? d_w3t[1] : nullptr;
+    return 0;
+  }
   const unsigned int *slot_map() {
     if (slot_of_pid && slot_map_dirty) {
       k_slot_map<<<(int)((P.cap + kBlock - 1) / kBlock), kBlock, 0, stream>>>(P.pid, P.cap, d_slot_of_pid);
@@ -1855,7 +1894,7 @@ struct Engine : EngineBase {
     if (rel_flags_buf) (void)hipFree(rel_flags_buf);
     if (rel_rank_buf) (void)hipFree(rel_rank_buf);
     if (rel_tmp_buf) (void)hipFree(rel_tmp_buf);
-    if (redist_dev) (void)hipFree(redist_dev);
+    if (redist_dev) (void)hipFree(redist_dev);      // (d_w3t: dalloc'ed, freed with the engine's other owned buffers)
     if (d_sort_rec) (void)hipFree(d_sort_rec);
     if (red_pin) (void)hipHostFree(red_pin);
     if (comm) (void)ncclCommDestroy(comm);
@@ -4115,6 +4154,7 @@ struct Engine : EngineBase {
       }
     }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
+    { const int rc = blend_winds(itime); if (rc) return rc; }      // its own kernel (k_blend_w3), ahead of the per-kernel events
     HIPCHK(hipEventRecord(ev.e[0], stream));
     if (P.xscav) {   // timemanager.f90:564-598, before the particle is moved
       k_bkdep<R><<<nb, kBlock, 0, stream>>>(V, Wp, P, numpart, itime, cfg.drybkdep, cfg.wetbkdep, d_zspan);
@@ -4153,6 +4193,7 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
+    V.w3t0 = nullptr; V.w3t1 = nullptr;      // the blended packs belong to this step's itime only
     step_counter++;
     if (async) return 0;
     Stats hs;

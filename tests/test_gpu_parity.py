@@ -63,6 +63,36 @@ def test_fp64_matches_oracle(built, name, kw):
         assert_close(g, w, 1e-9, 1e-7)
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("above_pbl_only", dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True)),
+    ("hanna_no_mesoscale", dict(ctl=5.0, ifine=4, turb_off=True)),
+    ("cbl", dict(ctl=5.0, ifine=4, cblflag=1)),
+])
+def test_time_blended_wind_packs_change_rounding_only(built, monkeypatch, name, kw):
+    """From FPX_BLEND_MIN particles on (3e7 by default) the step first blends the wind pack in time -- the weights are the same
+    for every particle -- and the gathers that need no standard deviations (interpol_wind_short, and interpol_wind when the
+    mesoscale term is off) read half the bytes: (y1*dt2 + y2*dt1)*dtt is then taken before the horizontal and vertical sums
+    instead of after.  Forced on here: the results stay within the parity tolerance of the oracle and within rounding of the
+    unblended engine."""
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
+    sc = syn.small(n=4000, nx=60, ny=40, nz=40, nsteps=4, **kw)
+    monkeypatch.setenv("FPX_BLEND_MIN", "1")
+    got, want = run_pair(sc, "r8")
+    for g, w in zip(got, want):
+        assert_close(g, w, 1e-9, 1e-7)
+    monkeypatch.setenv("FPX_BLEND_MIN", "0")
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ)
+    plain = eng.run(4)
+    eng.close()
+    changed = 0.0
+    for g, p in zip(got, plain):
+        for k in POS:
+            changed = max(changed, float(np.abs(g[k] - p[k]).max() / max(np.abs(p[k]).max(), 1e-30)))
+            assert np.abs(g[k] - p[k]).max() <= 1e-11 * max(np.abs(p[k]).max(), 1e-30), k
+    if name == "above_pbl_only":
+        assert changed > 0.0          # the blended path did run (it rounds differently)
+
+
 @pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "nest_wet", "sampling", "sampling_nest", "backward", "backward_cbl",
                                   "limited_area", "three_species", "multi_release", "age_classes",
                                   "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep"])
