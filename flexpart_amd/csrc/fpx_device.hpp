@@ -425,6 +425,7 @@ struct View {
   // (w3t0) and at itime + lsynctime*ldirect (w3t1, the Petterssen re-interpolation).  The time weights are the same for every
   // particle of a step, so a gather that needs no standard deviations reads half the bytes from these.
   const R *w3t0, *w3t1;
+  const R *r2t0;     // the same for (rho, drhodz) at itime, [jy][ix][iz][2]: the Langevin kernel's profile fetch
   const R *r2;       // [ny][nx][nz][2 slots][2]  (rho, drhodz)
   const R *sfc;      // [ny][nx][2 slots][4]      (ustar, wstar, oli, hmix)
   const R *hcell;    // [ny][nx]  max of hmix over the cell's 4 corners x 2 slots
@@ -614,7 +615,7 @@ template <typename R>
 struct Fld {
   int nx;
   const R *w3, *r2, *sfc, *hcell, *tropo, *vdep;
-  const R *w3t0, *w3t1;   // time-blended wind packs of the mother grid (View), NULL elsewhere
+  const R *w3t0, *w3t1, *r2t0;   // time-blended packs of the mother grid (View), NULL elsewhere
 };
 template <typename R>
 FPX_DEV Fld<R> fld_of(const View<R> &V, int ngrid) {
@@ -623,10 +624,10 @@ FPX_DEV Fld<R> fld_of(const View<R> &V, int ngrid) {
     const int l = ngrid - 1;
     const NestDesc<R> &N = V.nest[l];
     F.nx = N.nx; F.w3 = N.w3; F.r2 = N.r2; F.sfc = N.sfc; F.hcell = N.hcell; F.tropo = N.tropo; F.vdep = N.vdep;
-    F.w3t0 = nullptr; F.w3t1 = nullptr;
+    F.w3t0 = nullptr; F.w3t1 = nullptr; F.r2t0 = nullptr;
   } else {
     F.nx = V.nx; F.w3 = ngrid < 0 ? V.w3pol : V.w3; F.r2 = V.r2; F.sfc = V.sfc; F.hcell = V.hcell; F.tropo = V.tropo; F.vdep = V.vdep;
-    F.w3t0 = ngrid < 0 ? nullptr : V.w3t0; F.w3t1 = ngrid < 0 ? nullptr : V.w3t1;
+    F.w3t0 = ngrid < 0 ? nullptr : V.w3t0; F.w3t1 = ngrid < 0 ? nullptr : V.w3t1; F.r2t0 = ngrid < 0 ? nullptr : V.r2t0;
   }
   return F;
 }
@@ -1856,8 +1857,54 @@ FPX_DEV void fetch_level_pair(const View<R> &V, const Fld<R> &F, const TimeW<R> 
   // by corner in the reference's left-to-right order (interpol_all.f90:147-187), 20 running sums live.
   const R ddx = S.get(S_DDX), ddy = S.get(S_DDY);          // as cell_setup, interpol_all.f90:59-64
   const R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
-  R a3[2][2][3], a2[2][2][2];                               // [level][physical slot][variable]
   typedef const R __attribute__((address_space(1))) *gptr;  // the packs live in device memory: global, not flat, loads
+  if (F.w3t0 && F.r2t0) {
+    // wave-uniform (large clouds on the mother grid): the packs blended in time once per step (View::w3t0, r2t0) -- 10 values
+    // per corner instead of 20, no time interpolation per particle; the blend is taken before the horizontal sums instead of
+    // after (interpol_all.f90:189-198): the same numbers up to rounding
+#ifndef FPX_BLEND_CORNERS
+#define FPX_BLEND_CORNERS 4   // all four corners in one round trip: 80 values in flight fit (161 VGPRs, no spill); 2: +0.8 % time
+#endif
+    constexpr int NB = FPX_BLEND_CORNERS;     // corners per memory round trip
+    R acc[2][5];
+#pragma unroll
+    for (int cb = 0; cb < 4; cb += NB) {
+      R y3[NB][6], y2[NB][4];
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const int c = cb + j;
+        const int jyc = (c & 2) ? L.jyp : L.jy, ixc = (c & 1) ? L.ixp : L.ix;
+        const unsigned int cell = (unsigned int)(jyc * F.nx + ixc) * (unsigned int)V.nz + (unsigned int)(indz - 1);
+        const gptr p = (gptr)(F.w3t0 + (size_t)cell * 3);
+        const gptr q = (gptr)(F.r2t0 + (size_t)cell * 2);
+#pragma unroll
+        for (int k = 0; k < 6; k++) y3[j][k] = p[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) y2[j][k] = q[k];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const int c = cb + j;
+        const R pw = c == 0 ? rddx * rddy : c == 1 ? ddx * rddy : c == 2 ? rddx * ddy : ddx * ddy;
+#pragma unroll
+        for (int lev = 0; lev < 2; lev++) {
+#pragma unroll
+          for (int k = 0; k < 3; k++) acc[lev][k] = c == 0 ? pw * y3[j][lev * 3 + k] : m_fma(pw, y3[j][lev * 3 + k], acc[lev][k]);
+#pragma unroll
+          for (int k = 0; k < 2; k++) acc[lev][3 + k] = c == 0 ? pw * y2[j][lev * 2 + k] : m_fma(pw, y2[j][lev * 2 + k], acc[lev][3 + k]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("" ::: "memory");
+    }
+#pragma unroll
+    for (int lev = 0; lev < 2; lev++)
+#pragma unroll
+      for (int k = 0; k < 5; k++) lv[lev][k] = acc[lev][k];
+    return;
+  }
+  R a3[2][2][3], a2[2][2][2];                               // [level][physical slot][variable]
 #ifndef FPX_FETCH_CORNERS
 #define FPX_FETCH_CORNERS 1
 #endif

@@ -1107,8 +1107,8 @@ __global__ void __launch_bounds__(kBlock) k_co_density(View<R> V, int nxg, int n
 // The wind pack blended in time for the step in flight: out0 at itime, out1 (may be NULL) at itime + lsynctime*ldirect.
 // (y(memind(1))*dt2 + y(memind(2))*dt1)*dtt, interpol_wind.f90:189-191, per grid point instead of per particle.
 template <typename R>
-__global__ void __launch_bounds__(256) k_blend_w3(const R *__restrict__ w3, long long npoint, int m1, int m2, R dt1a, R dt2a, R dtta,
-                                                  R dt1b, R dt2b, R dttb, R *__restrict__ out0, R *__restrict__ out1) {
+__global__ void __launch_bounds__(256) k_blend_w3(const R *__restrict__ w3, const R *__restrict__ r2, long long npoint, int m1, int m2, R dt1a, R dt2a, R dtta,
+                                                  R dt1b, R dt2b, R dttb, R *__restrict__ out0, R *__restrict__ out1, R *__restrict__ rout0) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= npoint) return;
   const R *p = w3 + i * 6;
@@ -1118,6 +1118,9 @@ __global__ void __launch_bounds__(256) k_blend_w3(const R *__restrict__ w3, long
     out0[i * 3 + k] = (y1 * dt2a + y2 * dt1a) * dtta;
     if (out1) out1[i * 3 + k] = (y1 * dt2b + y2 * dt1b) * dttb;
   }
+  const R *q = r2 + i * 4;                     // (rho, drhodz) of the two slots, interpol_all.f90:189-198
+#pragma unroll
+  for (int k = 0; k < 2; k++) rout0[i * 2 + k] = (q[m1 * 2 + k] * dt2a + q[m2 * 2 + k] * dt1a) * dtta;
 }
 
 // After the stable sort of the slots by their 3-bit key: list length = number of keys <= 4 (PBL
@@ -1657,24 +1660,30 @@ struct Engine : EngineBase {
   bool slot_map_dirty = false;
   // Time-blended wind packs of the step in flight (View::w3t0 / w3t1).  Worth their 0.65 GB of extra traffic per step only
   // for a large cloud: from FPX_BLEND_MIN particles on (default 3e7; 0 = never, 1 = always -- the parity tests).
-  R *d_w3t[2] = {nullptr, nullptr};
+  R *d_w3t[2] = {nullptr, nullptr}, *d_r2t = nullptr;
+  unsigned int *h_nlist = nullptr;   // pinned: length of the PBL work list of a recent step (copied asynchronously at its end)
   int blend_winds(int itime) {
     const char *env = getenv("FPX_BLEND_MIN");      // read per step: the tests switch it inside one process
     const long long blend_min = env ? atoll(env) : 30000000ll;
-    V.w3t0 = nullptr; V.w3t1 = nullptr;
-    if (blend_min <= 0 || numpart < blend_min) return 0;
+    V.w3t0 = nullptr; V.w3t1 = nullptr; V.r2t0 = nullptr;
+    // ... or from 1e6 particles in the boundary layer on (the work list of the previous step): the Langevin kernel fetches a
+    // level pair per pass and gains 5 % from the blended packs, which pays for the 0.23 ms long before 3e7 particles
+    const unsigned int last_nlist = h_nlist ? *(volatile unsigned int *)h_nlist : 0u;
+    if (blend_min <= 0 || (numpart < blend_min && last_nlist < 1000000u)) return 0;
     const long long npoint = (long long)cfg.nx * cfg.ny * cfg.nz;
     int rc;
     for (int k = 0; k < 2; k++)
       if (!d_w3t[k]) { if ((rc = dalloc(&d_w3t[k], (size_t)npoint * 3))) return rc; }
+    if (!d_r2t) { if ((rc = dalloc(&d_r2t, (size_t)npoint * 2))) return rc; }
     const int t1 = itime + cfg.lsynctime * cfg.ldirect;
     const bool have1 = std::abs((long long)t1) <= std::abs((long long)V.memtime1);      // advance.f90:836: no Petterssen step beyond the window
     const R dt1a = (R)(itime - V.memtime0), dt2a = (R)(V.memtime1 - itime), dtta = (R)1 / (dt1a + dt2a);
     const R dt1b = (R)(t1 - V.memtime0), dt2b = (R)(V.memtime1 - t1), dttb = have1 ? (R)1 / (dt1b + dt2b) : (R)0;
-    k_blend_w3<R><<<(int)((npoint + 255) / 256), 256, 0, stream>>>(V.w3, npoint, V.m1, V.m2, dt1a, dt2a, dtta, dt1b, dt2b, dttb,
-                                                                     d_w3t[0], have1 ? d_w3t[1] : (R *)nullptr);
+    k_blend_w3<R><<<(int)((npoint + 255) / 256), 256, 0, stream>>>(V.w3, V.r2, npoint, V.m1, V.m2, dt1a, dt2a, dtta, dt1b, dt2b, dttb,
+                                                                     d_w3t[0], have1 ? d_w3t[1] : (R *)nullptr, d_r2t);
     HIPCHK(hipGetLastError());
     V.w3t0 = d_w3t[0];
+    V.r2t0 = d_r2t;
     V.w3t1 = have1 ? d_w3t[1] : nullptr;
     return 0;
   }
@@ -1895,6 +1904,7 @@ struct Engine : EngineBase {
     if (rel_rank_buf) (void)hipFree(rel_rank_buf);
     if (rel_tmp_buf) (void)hipFree(rel_tmp_buf);
     if (redist_dev) (void)hipFree(redist_dev);      // (d_w3t: dalloc'ed, freed with the engine's other owned buffers)
+    if (h_nlist) (void)hipHostFree(h_nlist);
     if (d_sort_rec) (void)hipFree(d_sort_rec);
     if (red_pin) (void)hipHostFree(red_pin);
     if (comm) (void)ncclCommDestroy(comm);
@@ -4193,7 +4203,14 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
-    V.w3t0 = nullptr; V.w3t1 = nullptr;      // the blended packs belong to this step's itime only
+    V.w3t0 = nullptr; V.w3t1 = nullptr; V.r2t0 = nullptr;      // the blended packs belong to this step's itime only
+    // the length of this step's work list for the next step's decision (blend_winds): an asynchronous copy into pinned
+    // memory, read without waiting -- a host that runs ahead sees the value of an earlier step, which is as good
+    if (!h_nlist) {
+      HIPCHK(hipHostMalloc((void **)&h_nlist, sizeof(unsigned int), hipHostMallocDefault));
+      *h_nlist = 0u;
+    }
+    HIPCHK(hipMemcpyAsync(h_nlist, d_pbl_ctr, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     step_counter++;
     if (async) return 0;
     Stats hs;
