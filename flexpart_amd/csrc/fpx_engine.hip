@@ -1675,7 +1675,7 @@ struct Engine : EngineBase {
     for (int k = 0; k < 2; k++)
       if (!d_w3t[k]) { if ((rc = dalloc(&d_w3t[k], (size_t)npoint * 3))) return rc; }
     if (!d_r2t) { if ((rc = dalloc(&d_r2t, (size_t)npoint * 2))) return rc; }
-    const int t1 = itime + cfg.lsynctime * cfg.ldirect;
+    const int t1 = itime + std::abs(cfg.lsynctime) * cfg.ldirect;   // the time of advance.f90:836-841 (ldt = |lsynctime| there)
     const bool have1 = std::abs((long long)t1) <= std::abs((long long)V.memtime1);      // advance.f90:836: no Petterssen step beyond the window
     const R dt1a = (R)(itime - V.memtime0), dt2a = (R)(V.memtime1 - itime), dtta = (R)1 / (dt1a + dt2a);
     const R dt1b = (R)(t1 - V.memtime0), dt2b = (R)(V.memtime1 - t1), dttb = have1 ? (R)1 / (dt1b + dt2b) : (R)0;

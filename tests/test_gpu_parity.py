@@ -67,6 +67,8 @@ def test_fp64_matches_oracle(built, name, kw):
     ("above_pbl_only", dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True)),
     ("hanna_no_mesoscale", dict(ctl=5.0, ifine=4, turb_off=True)),
     ("cbl", dict(ctl=5.0, ifine=4, cblflag=1)),
+    ("backward_above_pbl", dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True, ldirect=-1)),
+    ("backward_cbl", dict(ctl=5.0, ifine=4, cblflag=1, ldirect=-1)),
 ])
 def test_time_blended_wind_packs_change_rounding_only(built, monkeypatch, name, kw):
     """From FPX_BLEND_MIN particles on (3e7 by default) the step first blends the wind pack in time -- the weights are the same
@@ -89,7 +91,7 @@ def test_time_blended_wind_packs_change_rounding_only(built, monkeypatch, name, 
         for k in POS:
             changed = max(changed, float(np.abs(g[k] - p[k]).max() / max(np.abs(p[k]).max(), 1e-30)))
             assert np.abs(g[k] - p[k]).max() <= 1e-11 * max(np.abs(p[k]).max(), 1e-30), k
-    if name == "above_pbl_only":
+    if "above_pbl" in name:
         assert changed > 0.0          # the blended path did run (it rounds differently)
 
 
