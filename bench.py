@@ -381,6 +381,9 @@ def main():
                                 + f", rng={args.rng}, lsynctime=900"),
                    "particles_total": ntot, "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
                    "sort_interval": args.sort_interval, "live_particles_all_ranks": nlive_total, "numpart_all_ranks": numpart_total,
+                   # the engine's own rule (Engine::blend_winds): met-field packs blended in time once per step for large clouds
+                   "time_blended_packs": (os.environ.get("FPX_BLEND_MIN", "30000000") != "0"
+                                          and (nper >= int(os.environ.get("FPX_BLEND_MIN", "30000000")) or frac_pbl * nper >= 1e6)),
                    "rccl_nranks": world if transport == "rccl" else 0, "reduction_transport": transport},
         # achieved / peak / frac: the HBM roofline on ALGORITHMIC bytes, as the bench contract defines it.  `bound` names what
         # actually limits the dominant kernel: config 2's k_prep is memory-latency bound at three waves per SIMD (gathers
