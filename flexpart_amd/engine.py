@@ -545,6 +545,12 @@ class Engine:
         check(self.lib.fpx_split_particles(self.h, int(itime), C.byref(n)), "fpx_split_particles")
         self.n = int(n.value)
 
+    def set_numpart(self, n):
+        """numpart (com_mod.f90:676) as the host sees it; a smaller value than the engine's puts a locality-sorted cloud back
+        into particle-number order first (the spaces beyond numpart must be vacant)."""
+        check(self.lib.fpx_set_numpart(self.h, int(n)), "fpx_set_numpart")
+        self.n = int(n)
+
     # ---- mpi_mod.f90:566-856: levelling the ranks' particle counts (the host keeps the transport) ----
     def redist_pack(self, itime, num_trans):
         """Sender: the last num_trans storage spaces -> one message (numpy uint8 array); they are terminated, self.n shrinks."""

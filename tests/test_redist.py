@@ -181,3 +181,25 @@ def test_pack_and_unpack_move_particles_like_the_reference(built, kind):
     assert (a.n, b.n) == n0
     for e in engs:
         e.close()
+
+
+@pytest.mark.gpu
+def test_shrinking_numpart_after_a_locality_sort_keeps_the_particles_of_the_low_numbers(built):
+    """The locality sort permutes the storage spaces 1..numpart among themselves; fpx_set_numpart(n) with a smaller n (and the
+    sender of a redistribution) must first put every particle back into the space of its number, or live particles of low numbers
+    would sit in spaces beyond the new numpart and never be advanced again."""
+    from flexpart_amd import synthetic as syn
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    n, keep = 3000, 1800
+    sc = syn.small(n=n, nx=24, ny=16, nz=20, nsteps=2, seed=9)
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX)
+    eng.upload_particles_from_scenario(sc)
+    before = eng.download()
+    eng.sort()
+    eng.set_numpart(keep)
+    after = eng.download()
+    for k in ("xtra1", "ytra1", "ztra1", "itra1", "idt", "uap", "us", "xmass1"):
+        assert np.array_equal(np.asarray(after[k])[..., :keep], np.asarray(before[k])[..., :keep]), k
+    stats = eng.step()
+    assert stats["n_due"] == int((np.asarray(before["itra1"])[:keep] == 0).sum())      # exactly the kept particles advance
+    eng.close()
