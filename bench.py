@@ -47,6 +47,11 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter pass that measures the dominant kernel's VALU issue time")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the short run the counter pass profiles
     ap.add_argument("--cpu-sample", type=int, default=None, help="particles in the CPU baseline sample")
+    ap.add_argument("--blend", default="auto", choices=("auto", "on", "off"), help="time-blended wind packs (fpx_config.blend_mode); auto: from the run's particle count over all ranks")
+    ap.add_argument("--global-particles", type=float, default=None, help="particle count of the run this job is a shard of (default: --particles); "
+                    "e.g. --particles 12500000 --global-particles 1e8 = the shard one of eight GPUs runs, with that run's decisions")
+    ap.add_argument("--slice-passes", type=int, default=0, help="fpx_config.pbl_slice_passes: 0 the engine's schedule, -1 one launch, k passes per launch")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="fpx_set_option knob (repeatable), e.g. --opt pbl_slices=48,96,0")
     return ap.parse_args()
 
 
@@ -124,12 +129,26 @@ def free_port():
 
 
 def child_bench_cmd(args):
-    return [sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(args.config), "--real", str(args.real),
+    return ([sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(args.config), "--real", str(args.real),
             "--rng", args.rng, "--sort-interval", str(args.sort_interval), "--steps", "3", "--warmup", "1",
-            "--no-cpu-baseline", "--no-pmc"] + (["--particles", repr(args.particles)] if args.particles else [])
+            "--no-cpu-baseline", "--no-pmc", "--blend", args.blend, "--slice-passes", str(args.slice_passes)]
+            + (["--particles", repr(args.particles)] if args.particles else [])
+            + (["--global-particles", repr(args.global_particles)] if args.global_particles else [])
+            + [a for o in args.opt for a in ("--opt", o)])
 
 
-def live_traffic(args, kernel):
+def step_groups(rows, group):
+    """The dispatches of one kernel in dispatch order, `group` consecutive ones (the launches of one step: the Langevin
+    kernel runs in time slices) summed into one entry."""
+    rows = sorted(rows, key=lambda e: e["id"])
+    out = []
+    for i in range(0, len(rows) - group + 1, group):
+        g = rows[i:i + group]
+        out.append({k: sum(e.get(k, 0.0) for e in g) for k in g[0] if k != "id"})
+    return out
+
+
+def live_traffic(args, kernel, group=1):
     """HBM bytes per launch of the dominant kernel, measured in THIS run: two child `rocprofv3 --pmc` passes over the same
     command, FETCH_SIZE and WRITE_SIZE in a pass each (MI355X_MICROARCH.md, HBM section: both count KiB, separate passes;
     on gfx950 FETCH_SIZE reports half the bytes of wide reads, so it is doubled; the raw counters are kept next to it)."""
@@ -145,8 +164,9 @@ def live_traffic(args, kernel):
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, {"error": f"{ctr} pass failed (rc {r.returncode}): {r.stderr[-300:]}"}
-            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+            rows = [{"id": int(row["Dispatch_Id"]), "v": float(row["Counter_Value"])} for row in csv.DictReader(open(files[0]))
                     if kernel + "<" in row["Kernel_Name"] and row["Counter_Name"] == ctr]
+            vals = [g["v"] for g in step_groups(rows, group)]
             if not vals:
                 return None, {"error": f"no dispatch of {kernel} in the {ctr} pass"}
             vals.sort()
@@ -158,7 +178,7 @@ def live_traffic(args, kernel):
     return (2.0 * raw["FETCH_SIZE_KiB"] + raw["WRITE_SIZE_KiB"]) * 1024.0, raw
 
 
-def live_valu(args, kernel, avg_ms, launch_work):
+def live_valu(args, kernel, avg_ms, launch_work, group=1):
     """VALU issue time of the dominant kernel, measured in THIS run: a child `rocprofv3 --pmc` pass over the same
     command (same workload, seeds and sizes; one warm-up and two timed steps) counts the wave-instructions the kernel
     executes (SQ_INSTS_VALU), the quad-cycles its VALUs are busy issuing them (SQ_ACTIVE_INST_VALU) and the shader clock
@@ -180,9 +200,9 @@ def live_valu(args, kernel, avg_ms, launch_work):
         for row in csv.DictReader(open(files[0])):
             if kernel + "<" not in row["Kernel_Name"]:
                 continue
-            e = per.setdefault(row["Dispatch_Id"], {"ns": float(row["End_Timestamp"]) - float(row["Start_Timestamp"])})
+            e = per.setdefault(row["Dispatch_Id"], {"id": int(row["Dispatch_Id"]), "ns": float(row["End_Timestamp"]) - float(row["Start_Timestamp"])})
             e[row["Counter_Name"]] = float(row["Counter_Value"])
-        disp = [e for e in per.values() if "SQ_INSTS_VALU" in e]
+        disp = step_groups([e for e in per.values() if "SQ_INSTS_VALU" in e], group)   # per step: all time slices of the kernel together
         if not disp:
             return {"error": f"no dispatch of {kernel} in the counter pass"}
         disp.sort(key=lambda e: e["SQ_INSTS_VALU"])
@@ -282,7 +302,9 @@ def main():
     sc["npart_rel"] = np.array([ntot], np.int32)           # npart(1): particles of the release on ALL ranks
     rng = RNG_PHILOX if args.rng == "philox" else RNG_TABLE_COUNTER
     eng = Engine(sc, compute_real_bytes=args.real, host_real_bytes=args.real, rng_mode=rng,
-                 seed=0x5EED, max_particles=nper, device=local, sort_interval=args.sort_interval, particle_base=lo)
+                 seed=0x5EED, max_particles=nper, device=local, sort_interval=args.sort_interval, particle_base=lo,
+                 blend_mode={"auto": 0, "on": 1, "off": 2}[args.blend], global_particles=int(args.global_particles or ntot),
+                 pbl_slice_passes=args.slice_passes, options=dict(o.split("=", 1) for o in args.opt))
     eng.seed_particles(nper, seed=0x5EED, frac_pbl=frac_pbl)   # slice [lo, hi) of the one global synthetic cloud
     if args.sort_interval > 0:
         eng.sort()          # a release normally arrives ordered; the synthetic cloud is random
@@ -334,6 +356,7 @@ def main():
     dt = time.perf_counter() - t0
     parts, launches = eng.kernel_times(reset=True)
     kms = sum(parts[:3])
+    n_slices = eng.info("pbl_launches_per_step")   # the Langevin kernel runs in time slices: launches per step
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -381,9 +404,11 @@ def main():
                                 + f", rng={args.rng}, lsynctime=900"),
                    "particles_total": ntot, "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
                    "sort_interval": args.sort_interval, "live_particles_all_ranks": nlive_total, "numpart_all_ranks": numpart_total,
-                   # the engine's own rule (Engine::blend_winds): met-field packs blended in time once per step for large clouds
-                   "time_blended_packs": (os.environ.get("FPX_BLEND_MIN", "30000000") != "0"
-                                          and (nper >= int(os.environ.get("FPX_BLEND_MIN", "30000000")) or frac_pbl * nper >= 1e6)),
+                   # asked of the engine (fpx_get_info): met-field packs blended in time once per step -- decided from the
+                   # configuration alone (blend_mode / the run's particle count over all ranks), identically on every rank
+                   "time_blended_packs": bool(eng.info("time_blended_packs")), "blended_steps": eng.info("blended_steps"),
+                   "global_particles": int(args.global_particles or ntot),
+                   "pbl_launches_per_step": n_slices, "options": args.opt,
                    "rccl_nranks": world if transport == "rccl" else 0, "reduction_transport": transport},
         # achieved / peak / frac: the HBM roofline on ALGORITHMIC bytes, as the bench contract defines it.  `bound` names what
         # actually limits the dominant kernel: config 2's k_prep is memory-latency bound at three waves per SIMD (gathers
@@ -394,6 +419,9 @@ def main():
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "traffic_source": traffic_src if traffic else None,
                      "kernel": dom_name, "avg_launch_ms": avg_ms, "launches": launches,
+                     "launch_note": (None if dom != 1 else f"k_pbl_loop runs as {n_slices} launches per step (time slices; the later ones work through the particles the "
+                                     "earlier ones suspended): avg_launch_ms, traffic and the VALU counters are per STEP, i.e. summed over a step's launches; a rocprofv3 "
+                                     f"kernel trace lists {n_slices} calls per step, whose durations add up to this figure"),
                      "step_kernels_ms": {"k_prep": parts[3] / max(launches, 1), "worklist_sort": (parts[0] - parts[3]) / max(launches, 1),
                                          "k_pbl_loop": parts[1] / max(launches, 1), "k_pbl_finish": parts[2] / max(launches, 1)},
                      "alg_bytes_per_particle_step": b_alg,
@@ -415,8 +443,9 @@ def main():
     eng.close()
     if rank == 0 and world == 1 and not args.no_pmc:
         # after the engine has released the GPU: the counter pass runs the same workload in a child process
-        out["roofline"]["valu"] = live_valu(args, dom_name, avg_ms, nsteps_local / max(launches, 1))
-        t_live, raw = live_traffic(args, dom_name)
+        grp = n_slices if dom == 1 else 1
+        out["roofline"]["valu"] = live_valu(args, dom_name, avg_ms, nsteps_local / max(launches, 1), grp)
+        t_live, raw = live_traffic(args, dom_name, grp)
         if t_live is not None:
             out["roofline"]["traffic"] = t_live
             out["roofline"]["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (child processes, same workload); 2*FETCH + WRITE"

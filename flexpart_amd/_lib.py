@@ -42,7 +42,10 @@ class FpxConfig(C.Structure):
         ("mquasilag", C.c_int32), ("lage_last", C.c_int32),
         ("rng_mode", C.c_int32), ("seed", C.c_uint64),
         ("sort_interval", C.c_int32), ("par_nxmax", C.c_int32), ("particle_base", C.c_int64),
-        ("drybkdep", C.c_int32), ("wetbkdep", C.c_int32), ("reserved", C.c_int32 * 2),
+        ("drybkdep", C.c_int32), ("wetbkdep", C.c_int32),
+        ("turboff", C.c_int32), ("interpolhmix", C.c_int32), ("blend_mode", C.c_int32), ("pbl_slice_passes", C.c_int32),
+        ("global_particles", C.c_int64), ("ipout", C.c_int32), ("iflux", C.c_int32), ("linit_cond", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 
@@ -174,7 +177,7 @@ SYMBOLS = [
     "fpx_rng_get_table", "fpx_upload_particles", "fpx_download_particles", "fpx_set_numpart", "fpx_set_release_points", "fpx_set_release_heights", "fpx_release_init", "fpx_releaseparticles", "fpx_split_particles", "fpx_redist_plan", "fpx_redist_bytes", "fpx_redist_pack", "fpx_redist_unpack",
     "fpx_step", "fpx_step_async", "fpx_sync", "fpx_counters", "fpx_kernel_time", "fpx_kernel_times", "fpx_sort_particles",
     "fpx_seed_particles", "fpx_stream", "fpx_outgrid_init", "fpx_set_output_times", "fpx_conccalc",
-    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_count_particles", "fpx_lane_stats", "fpx_wet_init", "fpx_upload_wet_fields",
+    "fpx_get_grids", "fpx_comm_unique_id", "fpx_comm_init", "fpx_comm_init_host", "fpx_count_particles", "fpx_lane_stats", "fpx_set_option", "fpx_get_info", "fpx_wet_init", "fpx_upload_wet_fields",
     "fpx_wetdepo", "fpx_get_wetgrid", "fpx_nests_init", "fpx_upload_nest_fields", "fpx_math_probe",
     "fpx_outgrid_nest_init", "fpx_get_grids_nest", "fpx_receptors_init", "fpx_get_receptors", "fpx_upload_wet_nest_fields",
     "fpx_verttransform_ecmwf", "fpx_verttransform_nest", "fpx_verttransform_time", "fpx_calcpar", "fpx_calcpar_time", "fpx_upload_diag_fields", "fpx_partoutput", "fpx_partoutput_time", "fpx_readpartpositions", "fpx_concoutput",
@@ -275,6 +278,8 @@ def load():
     lib.fpx_set_release_heights.argtypes = [vp, C.c_int32, vp, vp]
     lib.fpx_count_particles.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_int32]
     lib.fpx_lane_stats.argtypes = [vp, C.POINTER(C.c_uint64), C.c_int32, C.c_int32]
+    lib.fpx_set_option.argtypes = [vp, C.c_char_p, C.c_char_p]
+    lib.fpx_get_info.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 

@@ -408,6 +408,7 @@ struct View {
   R meso_r, meso_rs;   // r = exp(-2*|lsynctime|/lwindinterv), sqrt(1-r*r): advance.f90:728-729, set with the wind window
   // switches
   int ldirect, lsynctime, method, mintime, ifine, turbswitch, cblflag, mdomainfill, lsettling;
+  int turboff, interpolhmix;     // com_mod.f90:777-778 as run-time switches (fpx_config)
   int nspec, drydep, drydepspec[kMaxSpec];
   R ctl, fine, d_trop, d_strat, turbmesoscale;
   R density[kMaxSpec], dquer[kMaxSpec], vsetaver[kMaxSpec], cunningham[kMaxSpec], decay[kMaxSpec];
@@ -912,6 +913,8 @@ enum StashSlot {
   S_UP, S_VP,                                                                   // turbulent velocities along/across wind
   S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; wst^3 * the transition of cbl.f90:79-81
   S_RHOAUX,                                                                     // per-pass invariant of the fine loop: rhograd/rhoa
+  S_NPASS,                                                                      // passes the lane has run for its particle in this launch (time slices, k_pbl_loop)
+  S_TDEP,                                                                       // aerosol kernels: sum of |dt| over the passes that ended below 2*href (advance.f90:582-599)
   S_COUNT
 };
 constexpr int kStashStride = 256;   // threads per block of the loop kernel
@@ -1769,7 +1772,24 @@ FPX_DEV bool adv_begin(const View<R> &V, double xt, double yt, R zt, int itime, 
   if (A.ixp >= nxcols) A.ixp = nxcols - 1;  // guard for a non-cyclic domain edge
   {
     const Fld<R> F = fld_of(V, A.ngrid);
-    A.h = F.hcell[(long long)A.jy * F.nx + A.ix];        // advance.f90:236-262 (interpolhmix=.false.)
+    A.h = F.hcell[(long long)A.jy * F.nx + A.ix];        // advance.f90:236-262, interpolhmix = .false.: the maximum over the cell's corners and both times
+    if (__builtin_expect(V.interpolhmix != 0 && A.ngrid <= 0, 0)) {
+      // interpolhmix = .true. (advance.f90:240-244,266): bilinear in the cell, linear in time; p1..p4 of advance.f90:209-216
+      // (xt, yt are double precision there); the reference sets h1 on the mother grid only (nests: refused at fpx_nests_init)
+      const R ddx = (R)(xt - (double)(R)A.ix), ddy = (R)(yt - (double)(R)A.jy);
+      const R rddx = K(1.) - ddx, rddy = K(1.) - ddy;
+      const R p1 = rddx * rddy, p2 = ddx * rddy, p3 = rddx * ddy, p4 = ddx * ddy;
+      const TimeW<R> W = time_weights(V, itime);
+      R h1[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        const int m = k == 0 ? V.m1 : V.m2;
+        const long long c00 = (long long)A.jy * F.nx + A.ix, c10 = (long long)A.jy * F.nx + A.ixp;
+        const long long c01 = (long long)A.jyp * F.nx + A.ix, c11 = (long long)A.jyp * F.nx + A.ixp;
+        h1[k] = p1 * F.sfc[(c00 * 2 + m) * 4 + 3] + p2 * F.sfc[(c10 * 2 + m) * 4 + 3] + p3 * F.sfc[(c01 * 2 + m) * 4 + 3] + p4 * F.sfc[(c11 * 2 + m) * 4 + 3];
+      }
+      A.h = (h1[0] * W.dt2 + h1[1] * W.dt1) * W.dtt;
+    }
     if (TROPO) {
       // tropopause(nix,njy,1,1) / tropopausen(nix,njy,1,1,ngrid), advance.f90:253,263 (literal slot 1)
       const int nix = A.ngrid > 0 ? (int)lround((double)A.xr) : (int)lround(xt);
@@ -1796,7 +1816,7 @@ FPX_DEV void pbl_begin(const View<R> &V, double xt, double yt, const TimeW<R> &W
   B.transition = V.cblflag == 1 ? cbl_transition(A.h, T.ol) : K(1.);
 }
 
-// One pass of the loop advance.f90:282-609.  prob: dry-deposition probabilities (DRYDEP only).
+// One pass of the loop advance.f90:282-609.  DRYDEP: the time below 2*href is summed in the stash (S_TDEP).
 // indz_last receives the level pair of this pass: when the pass ends the interval (PBL_DONE)
 // the caller evaluates usig/vsig/wsig for it (advance.f90:604-606, level_pair_sigma).
 // TSW / CBLF: -1 = read turbswitch / cblflag at run time, 0/1 = fixed at compile time
@@ -1972,7 +1992,7 @@ FPX_DEV bool sw(int runtime) { return T < 0 ? runtime != 0 : T != 0; }
 template <typename R, bool DRYDEP, bool SETTLE, int TSW, int CBLF, typename RNG>
 FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R> &W, int itime, double xt, double yt,
                      R &zt, R &wp, int &ldt, short &icbt, LoopCtx<R> &A, const Stash<R> &S,
-                     int &indz_last, R *prob, Stats *st) {
+                     int &indz_last, Stats *st) {
   const R eps = V.eps;
   const R eps2 = K(1.e-9);
   const R href = K(15.);            // par_mod.f90:76
@@ -2046,6 +2066,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
       R rv = S.expt(-dttlv);
       vp = rv * vp + g2 * T.sigv * m_sqrtp(K(1.) - rv * rv);
     }
+    if (__builtin_expect(V.turboff != 0, 0)) { up = K(0.); vp = K(0.); }   // advance.f90:464-467: zeroed in the fine loop, before :541-542 read them
     S.put(S_UP, up); S.put(S_VP, vp);
     S.add(S_DAW, up * dt);   // advance.f90:541-542
     S.add(S_DCW, vp * dt);
@@ -2112,6 +2133,8 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
       delz = wp * dtf;
     }
 
+    if (__builtin_expect(V.turboff != 0, 0)) { wp = K(0.); delz = K(0.); }   // advance.f90:464-470 (turboff; the random numbers stay drawn)
+
     // reflection at the ground / mixing height, advance.f90:476-491
     if (__builtin_expect(m_abs(delz) > h, 0)) delz = m_fmod(delz, h);
     if (delz < -zt) {
@@ -2163,16 +2186,12 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     return PBL_ESCAPED;   // -> 700
   }
 
-  // dry-deposition probability, advance.f90:582-599
-  if (DRYDEP && zt < K(2.) * href) {
-#pragma unroll
-    for (int ks = 0; ks < kMaxSpec; ks++) {
-      if (ks < V.nspec && V.drydepspec[ks]) {
-        R vdepo = interp_vdep(V, F, stash_cell(A, S), W, ks);   // same value every pass (depoindicator cache in the reference)
-        prob[ks] = K(1.) + (prob[ks] - K(1.)) * m_expp(-vdepo * m_abs(dt) / (K(2.) * href));
-      }
-    }
-  }
+  // dry-deposition probability, advance.f90:582-599: prob(ks) = 1 + (prob(ks) - 1)*exp(-vdepo(ks)*|dt|/(2*href)) in every pass
+  // that ends below 2*href, from prob = 0.  vdepo is the same in every pass of the step (the cell and the time weights do not
+  // change: the reference's depoindicator cache), so 1 - prob is the product of the exponentials = exp(-vdepo*T/(2*href)) with
+  // T the sum of |dt| over those passes: the loop keeps T (integer seconds, exact) and k_pbl_finish takes one exponential per
+  // species -- the same number up to the rounding of the product.
+  if (DRYDEP && zt < K(2.) * href) S.add(S_TDEP, m_abs(dt));
 
   if (zt < K(0.)) zt = m_min(h - eps2, K(-1.) * zt);   // advance.f90:601
 
@@ -2211,9 +2230,9 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
   const R dt = (R)ldt;
   int nrand = A.nrand;
   R ux, vy;
-  if (V.d_trop == K(0.) && V.d_strat == K(0.)) {
-    // diffusivities switched off (wave-uniform): every random term below is multiplied by zero, so no random numbers
-    // are generated; nrand advances as in the three branches
+  if ((V.d_trop == K(0.) && V.d_strat == K(0.)) || V.turboff != 0) {
+    // diffusivities switched off (wave-uniform): every random term below is multiplied by zero -- or turboff zeroes ux, vy, wp
+    // after the draws (advance.f90:675-679) -- so no random numbers are generated; nrand advances as in the three branches
     ux = K(0.); vy = K(0.); wp = K(0.);
     if (zt < tropop) { if (nrand + 1 > V.maxrand) nrand = 1; nrand = nrand + 2; }
     else if (zt < tropop + K(1000.)) { if (nrand + 2 > V.maxrand) nrand = 1; nrand = nrand + 3; }

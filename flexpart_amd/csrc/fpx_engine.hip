@@ -57,6 +57,9 @@ constexpr int kBlock = 256;
 #ifndef FPX_LOOP_WAVES
 #define FPX_LOOP_WAVES 3   // waves per SIMD the Langevin kernel is register-budgeted for (<= 168 VGPRs)
 #endif
+#ifndef FPX_SLICE_SCHEDULE
+#define FPX_SLICE_SCHEDULE 64, 64, 64, 0   // pass budgets of the successive launches of the Langevin kernel (time slices), 0 = none
+#endif
 constexpr int kMaxNz = 512;
 
 // ---------------------------------------------------------------------------
@@ -470,22 +473,36 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
 // Per-slot hand-over record between the three PBL kernels: ONE contiguous, aligned record per particle (128 bytes in the
 // fp64 build = one cache line, 64 bytes in f32), so that a lane that retires its particle in the Langevin kernel -- about
 // two lanes of a wave per pass -- writes one line instead of a sector in each of sixteen arrays, and a refilling lane
-// reads one.  k_prep fills the surface-layer part (in), k_pbl_loop overwrites the record with the particle's state at the
-// end of its last pass (out), k_pbl_finish reads it and writes the particle arrays, coalesced.
+// reads one.  k_prep fills the surface-layer part (FRESH), k_pbl_loop writes the particle's state at the end of its last
+// pass (DONE / ESCAPED) -- or, when the launch's pass budget is used up (time slices, see k_pbl_loop), the state a later
+// launch continues from (CONTINUE); k_pbl_finish reads it and writes the particle arrays, coalesced.
+enum { PBL_FRESH = 3 };   // fourth value of the record's state next to PBL_CONTINUE / PBL_DONE / PBL_ESCAPED
 template <typename R>
 struct alignas(16 * sizeof(R)) PblRecord {
-  // in : v[0..3] = ust, wst, ol, CBL transition (interpol_all.f90:80-107, cbl.f90:79-81); v[4] = mixing height of the cell
-  //      (advance.f90:236-262); i[0] = nrand at entry, i[1] = ngrid
-  // out: v[0..3] = dxsave, dysave, dawsave, dcwsave; v[4..6] = interpol_mod u, v, w of the last pass;
-  //      v[7..10] = zt, up, vp, wp; i[0] = nrand, i[1] = itimec, i[2] = rc | indz << 2, i[3] = ldt, i[4] = icbt
-  R v[11];
-  int i[5];
+  // v[0..3]  = dxsave, dysave, dawsave, dcwsave                                  (CONTINUE, DONE, ESCAPED)
+  // v[4..7]  = zt, up, vp, wp                                                    (CONTINUE, DONE, ESCAPED)
+  // v[8..10] = ust, wst, ol (interpol_all.f90:80-107; ust as hanna.f90:43 floored it)  (FRESH, CONTINUE)
+  //          | interpol_mod u, v, w of the last pass                             (DONE, ESCAPED)
+  // v[11]    = CBL transition (cbl.f90:79-81), v[12] = mixing height of the cell (advance.f90:236-262): written by k_prep only
+  // i[0] = nrand, i[1] = ldt, i[2] = state | icbt < 0 | indz | ngrid | |itimec - itime|  (pbl_pack)
+  R v[13];
+  int i[3];
 };
 static_assert(sizeof(PblRecord<double>) == 128 && sizeof(PblRecord<float>) == 64, "one cache line / half a line per record");
+// state: bits 0-1, icbt = -1: bit 2, indz (<= 511): bits 3-11, ngrid + 2 (-2 .. kMaxNests): bits 12-14, |itimec - itime| (<= |lsynctime| <= 65535): bits 15-30
+__device__ __forceinline__ int pbl_pack(int state, int icbt, int indz, int ngrid, int elapsed) {
+  return state | (icbt < 0 ? 4 : 0) | (indz << 3) | ((ngrid + 2) << 12) | (elapsed << 15);
+}
+__device__ __forceinline__ int pbl_state(int pk) { return pk & 3; }
+__device__ __forceinline__ int pbl_icbt(int pk) { return (pk & 4) ? -1 : 1; }
+__device__ __forceinline__ int pbl_indz(int pk) { return (pk >> 3) & 511; }
+__device__ __forceinline__ int pbl_ngrid(int pk) { return ((pk >> 12) & 7) - 2; }
+__device__ __forceinline__ int pbl_elapsed(int pk) { return (pk >> 15) & 65535; }
+static_assert(kMaxNz <= 512 && kMaxNests + 2 <= 7, "pbl_pack field widths");
 template <typename R>
 struct PblRec {
   PblRecord<R> *rec;       // [cap]
-  R *prob;                 // [nspec][cap], DRYDEP only: dry-deposition probabilities of the step (advance.f90:582-599)
+  R *tdep;                 // [cap], DRYDEP only: seconds of the step the particle spent below 2*href (advance.f90:582-599, see pbl_pass)
 };
 
 // Register budget: the steady-state kernel of a run on the mother lat-lon grid is built for FPX_PREP_WAVES waves per SIMD
@@ -566,9 +583,9 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     pbl_begin(V, ps.xt, ps.yt, W, A, B);
     {
       PblRecord<R> &r = Q.rec[s];
-      r.v[0] = B.ust; r.v[1] = B.wst; r.v[2] = B.ol; r.v[3] = B.transition;
-      r.v[4] = A.h;
-      r.i[0] = A.nrand; r.i[1] = A.ngrid;
+      r.v[8] = B.ust; r.v[9] = B.wst; r.v[10] = B.ol; r.v[11] = B.transition;
+      r.v[12] = A.h;
+      r.i[0] = A.nrand; r.i[2] = pbl_pack(PBL_FRESH, 1, 0, A.ngrid, 0);
     }
     // Regime class of the particle's PBL passes (hanna.f90:42,59,91 and advance.f90:405-406).  The
     // work list is the slots stably sorted by this 3-bit key: class by class, each class in slot
@@ -1165,11 +1182,28 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
 // Only the pass loop lives here; set-up and completion run in k_prep / k_pbl_finish
 // where all lanes are active.
 // LEAN: no dry deposition, no settling (gases).  TSW / CBLF / RNGM: see pbl_pass.
+//
+// Time slices (cap_passes > 0): a lane gives its particle at most cap_passes passes in this launch.  A particle that needs
+// more is SUSPENDED: its state goes into its hand-over record (state PBL_CONTINUE) and its slot is appended to next_list
+// (one atomic per wave and pass in which lanes suspend); the host launches the kernel again on that list.  The particles
+// with hundreds of passes (a 2 s time step for the whole 900 s; the median is about 30 passes) are then shared by all waves
+// of the next launch instead of keeping the last waves of this one alive with a lane or two each; and the particles a wave
+// holds at any moment come from a narrower window of the class- and cell-sorted list.  A particle's random numbers are
+// keyed on (particle number, step, draw index) and the draw index travels in the record: the slicing does not change a bit
+// of the result (tests/test_gpu_parity.py::test_time_slices_do_not_change_a_bit).
 template <typename R, bool LEAN, int TSW, int CBLF, int RNGM>
 __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                      const unsigned int *__restrict__ pbl_list,
                                                      const unsigned int *__restrict__ pbl_count,
-                                                     unsigned int *__restrict__ cursor) {
+                                                     unsigned int *__restrict__ cursor,
+                                                     int cap_passes,
+                                                     unsigned int *__restrict__ next_list,
+                                                     unsigned int *__restrict__ next_count) {
+  const unsigned int nlist = *pbl_count;
+  // A short list (the later time slices): only as many blocks as it fills take part, so that its waves are spread over the
+  // CUs one block each instead of three to a SIMD on some and none on others (a pass of a wave alone on its SIMD takes a
+  // third of the time).
+  if ((unsigned long long)blockIdx.x * kBlock >= nlist) return;
   // dynamic LDS: [S_COUNT][kBlock] stash (per-lane pass-level state, see Stash) + the height column,
   // sized by the host (loop_smem_bytes) so that three blocks fit one CU for the usual nz
   extern __shared__ __align__(16) unsigned char fpx_loop_smem[];
@@ -1183,9 +1217,9 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
     for (int k = threadIdx.x; k < kLdsTabDoubles; k += blockDim.x) lds_tab[k] = k < kLdsExpTabAt ? kLogTab[k >> 1][k & 1] : kExpTab[k - kLdsExpTabAt];
   __syncthreads();
   const Stash<R> S{(typename Stash<R>::lds_ptr)(stash_mem + threadIdx.x), (lds_tab_ptr)lds_tab};
-  const unsigned int nlist = *pbl_count;
   const int lane = threadIdx.x & 63;
   const TimeW<R> W = time_weights(V, itime);   // wave-uniform
+  const R cap_r = cap_passes > 0 ? (R)cap_passes : (R)1e30;
 
   // The list is in slot order, i.e. sorted by grid cell after a locality sort.  A wave takes
   // CHUNKS of consecutive entries (one atomic per chunk) and refills its lanes from its own
@@ -1211,7 +1245,6 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   int ldt = 0;
   short icbt = 1;
   LoopCtx<R> A;
-  R prob[kMaxSpec];
 
   for (;;) {
     FPX_LANES(st, 10);
@@ -1246,32 +1279,42 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
           s = s_new;
           const PblRecord<R> *rp = Q.rec + s;
           const double l_xt = P.xt[s], l_yt = P.yt[s];
-          const R l_zt = P.zt[s], l_wp = P.wp[s], l_up = P.up[s], l_vp = P.vp[s];
-          const int l_idt = P.idt[s];
-          const short l_cbt = P.cbt[s];
           const unsigned int l_pid = P.pid[s];
-          const R r_ust = rp->v[0], r_wst = rp->v[1], r_ol = rp->v[2], r_trans = rp->v[3], r_h = rp->v[4];
-          const int r_nrand = rp->i[0], r_ngrid = rp->i[1];
+          const int r_nrand = rp->i[0], r_ldt = rp->i[1], r_pk = rp->i[2];
+          const R r_ust = rp->v[8], r_wst = rp->v[9], r_ol = rp->v[10], r_trans = rp->v[11], r_h = rp->v[12];
+          // a fresh particle's state is in the particle arrays, a suspended one's in its record: both are requested
+          // (one round trip either way; suspended particles are the few)
+          R l_zt = P.zt[s], l_wp = P.wp[s], l_up = P.up[s], l_vp = P.vp[s];
+          int l_idt = P.idt[s];
+          short l_cbt = P.cbt[s];
+          const R c_dx = rp->v[0], c_dy = rp->v[1], c_daw = rp->v[2], c_dcw = rp->v[3];
+          const R c_zt = rp->v[4], c_up = rp->v[5], c_vp = rp->v[6], c_wp = rp->v[7];
           int l_npoint = 0;
           if (!LEAN && V.lsettling) l_npoint = P.npoint[s];
+          R c_tdep = (R)0;
+          if (!LEAN && V.drydep) c_tdep = Q.tdep[s];
           __builtin_amdgcn_sched_barrier(0);   // every load above is issued before the first value is used
-          xt = l_xt; yt = l_yt; zt = l_zt; wp = l_wp; ldt = l_idt; icbt = l_cbt; pid = l_pid;
+          const bool resumed = pbl_state(r_pk) == PBL_CONTINUE;
+          xt = l_xt; yt = l_yt; pid = l_pid;
+          zt = resumed ? c_zt : l_zt; wp = resumed ? c_wp : l_wp;
+          ldt = resumed ? r_ldt : l_idt;
+          icbt = resumed ? (short)pbl_icbt(r_pk) : l_cbt;
           {
             R ddx, ddy;
-            adv_begin_known(V, xt, yt, r_ngrid, r_h, A, ddx, ddy);
-            A.itimec = itime; A.nrand = r_nrand;
+            adv_begin_known(V, xt, yt, pbl_ngrid(r_pk), r_h, A, ddx, ddy);
+            A.itimec = itime + pbl_elapsed(r_pk) * V.ldirect;   // FRESH: elapsed = 0
+            A.nrand = r_nrand;
             A.nsp = (!LEAN && V.lsettling) ? settling_species(V, l_npoint) : 0;
             S.put(S_DDX, ddx); S.put(S_DDY, ddy);
           }
-          S.put(S_DX, (R)0); S.put(S_DY, (R)0); S.put(S_DAW, (R)0); S.put(S_DCW, (R)0);
+          S.put(S_DX, resumed ? c_dx : (R)0); S.put(S_DY, resumed ? c_dy : (R)0);
+          S.put(S_DAW, resumed ? c_daw : (R)0); S.put(S_DCW, resumed ? c_dcw : (R)0);
           S.put(S_W, (R)0);
-          S.put(S_UP, l_up); S.put(S_VP, l_vp);
+          S.put(S_UP, resumed ? c_up : l_up); S.put(S_VP, resumed ? c_vp : l_vp);
           S.put(S_UST, r_ust); S.put(S_WST, r_wst); S.put(S_OL, r_ol);
           S.put(S_TRANS, (r_wst * r_wst * r_wst) * r_trans);   // (wst**3)*transition, cbl.f90:103-104
-          if (!LEAN && V.drydep) {
-#pragma unroll
-            for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
-          }
+          S.put(S_NPASS, (R)0);
+          if (!LEAN && V.drydep) S.put(S_TDEP, resumed ? c_tdep : (R)0);
           have = true;
         }
         cur = min(cur + (unsigned int)__popcll(need), end);
@@ -1281,29 +1324,43 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
       if (out_of_chunks) break;   // no lane has work and the list is used up: the grid drains
       continue;                   // chunk ran dry mid-refill: take the next one
     }
+    bool suspend = false;
     if (have) {
       Rng<R, RNGM> G;
       make_rng(V, pid, step, G);
       int indz = 1;
-      const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, icbt, A, S, indz, prob, st);
-      if (rc != PBL_CONTINUE) {
+      const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, icbt, A, S, indz, st);
+      const R npass = S.get(S_NPASS) + (R)1;
+      S.put(S_NPASS, npass);
+      suspend = rc == PBL_CONTINUE && npass >= cap_r;
+      if (rc != PBL_CONTINUE || suspend) {
         FPX_LANES(st, 9);
         {
-          // the particle's state at the end of its last pass goes into its hand-over record: one contiguous line;
-          // k_pbl_finish writes the particle arrays from it
-          PblRecord<R> r;
-          r.v[0] = S.get(S_DX); r.v[1] = S.get(S_DY); r.v[2] = S.get(S_DAW); r.v[3] = S.get(S_DCW);
-          r.v[4] = S.get(S_U); r.v[5] = S.get(S_V); r.v[6] = S.get(S_W);
-          r.v[7] = zt; r.v[8] = S.get(S_UP); r.v[9] = S.get(S_VP); r.v[10] = wp;
-          r.i[0] = A.nrand; r.i[1] = A.itimec; r.i[2] = rc | (indz << 2); r.i[3] = ldt; r.i[4] = icbt;
-          Q.rec[s] = r;
+          // the particle's state at the end of this pass goes into its hand-over record: one contiguous line;
+          // k_pbl_finish writes the particle arrays from it -- or a later launch continues from it
+          PblRecord<R> *rp = Q.rec + s;
+          rp->v[0] = S.get(S_DX); rp->v[1] = S.get(S_DY); rp->v[2] = S.get(S_DAW); rp->v[3] = S.get(S_DCW);
+          rp->v[4] = zt; rp->v[5] = S.get(S_UP); rp->v[6] = S.get(S_VP); rp->v[7] = wp;
+          if (suspend) {
+            rp->v[8] = S.get(S_UST);      // hanna.f90:43 may have floored it; v[9..12] stay as k_prep wrote them
+          } else {
+            rp->v[8] = S.get(S_U); rp->v[9] = S.get(S_V); rp->v[10] = S.get(S_W);
+          }
+          rp->i[0] = A.nrand; rp->i[1] = ldt;
+          rp->i[2] = pbl_pack(rc, icbt, indz, A.ngrid, abs(A.itimec - itime));
         }
-        if (!LEAN && V.drydep) {
-#pragma unroll
-          for (int ks = 0; ks < kMaxSpec; ks++)
-            if (ks < V.nspec) Q.prob[(size_t)ks * P.cap + s] = prob[ks];
-        }
+        if (!LEAN && V.drydep) Q.tdep[s] = S.get(S_TDEP);
         have = false;
+      }
+    }
+    if (cap_passes > 0) {
+      // the suspended particles of this pass, appended to the next launch's list: one atomic per wave
+      const unsigned long long sm = __ballot(suspend);
+      if (sm != 0ull) {
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(next_count, (unsigned int)__popcll(sm));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (suspend) next_list[base + (unsigned int)__popcll(sm & ((1ull << lane) - 1ull))] = s;
       }
     }
   }
@@ -1357,11 +1414,13 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
   for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < nlist; i += gridDim.x * blockDim.x) {
     const unsigned int s = pbl_list[i];
     const PblRecord<R> rec = Q.rec[s];
+    const R tdep = DRYDEP ? Q.tdep[s] : (R)0;
+    const int pk = rec.i[2];
     PState<R> ps;
-    ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = rec.v[7];
-    ps.up = rec.v[8]; ps.vp = rec.v[9]; ps.wp = rec.v[10];
+    ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = rec.v[4];
+    ps.up = rec.v[5]; ps.vp = rec.v[6]; ps.wp = rec.v[7];
     ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
-    ps.ldt = rec.i[3]; ps.icbt = (short)rec.i[4];
+    ps.ldt = rec.i[1]; ps.icbt = (short)pbl_icbt(pk);
     Rng<R> G;
     make_rng(V, P.pid[s], step, G);
     const TimeW<R> W = time_weights(V, itime);
@@ -1374,29 +1433,38 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
     }
     if (V.lsettling) A.nsp = settling_species(V, P.npoint[s]);
     A.dxsave = rec.v[0]; A.dysave = rec.v[1]; A.dawsave = rec.v[2]; A.dcwsave = rec.v[3];
-    A.u = rec.v[4]; A.v = rec.v[5]; A.w = rec.v[6];
-    A.nrand = rec.i[0]; A.itimec = rec.i[1];
-    const int status = rec.i[2];
-    const int rc = status & 3, indz = status >> 2;
+    A.u = rec.v[8]; A.v = rec.v[9]; A.w = rec.v[10];
+    A.nrand = rec.i[0]; A.itimec = itime + pbl_elapsed(pk) * V.ldirect;
+    const int rc = pbl_state(pk), indz = pbl_indz(pk);   // (every particle of the list is DONE or ESCAPED when the last time slice has run)
     R usig = (R)0, vsig = (R)0, wsig = (R)0;
-    if (rc == PBL_ESCAPED) {
-      above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
-    } else {
+    R prob[kMaxSpec];
+    {
       Cell<R> C;
       cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
-      level_pair_sigma(V, fld_of(V, A.ngrid), C, W, indz, usig, vsig, wsig);   // advance.f90:604-606
+      if (rc == PBL_ESCAPED) {
+        above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
+      } else {
+        level_pair_sigma(V, fld_of(V, A.ngrid), C, W, indz, usig, vsig, wsig);   // advance.f90:604-606
+      }
+      // advance.f90:582-599 in closed form: prob(ks) = 1 - exp(-vdepo(ks) * T / (2*href)), T = the loop's sum of |dt| over the
+      // passes that ended below 2*href (pbl_pass); the deposition velocity of the particle's cell, as every pass saw it
+#pragma unroll
+      for (int ks = 0; ks < kMaxSpec; ks++) {
+        prob[ks] = (R)0;
+        if (DRYDEP && ks < V.nspec && V.drydepspec[ks]) {
+          const R vdepo = interp_vdep(V, fld_of(V, A.ngrid), C, W, ks);
+          prob[ks] = (R)1 - m_expp(-vdepo * tdep / ((R)2. * (R)15.));   // href = 15, par_mod.f90:76
+        }
+      }
     }
     // what the epilogue reads of the particle travels with the last gather
     EpiPre<R> pre;
-    R prob[kMaxSpec];
     int itramem = 0;
     unsigned int sl = s;
     auto late_epi = [&]() {
       asm volatile("" : "+v"(sl));
       pre.template load<DRYDEP>(V, Gp, P, sl);
       itramem = P.itramem[sl];
-#pragma unroll
-      for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (DRYDEP && ks < V.nspec) ? Q.prob[(size_t)ks * P.cap + sl] : (R)0;
     };
     const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig, late_epi);
     epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st, &pre);
@@ -1603,6 +1671,8 @@ struct EngineBase {
   virtual int get_grids(void *gridunc, void *drygridunc, int allreduce, int clear) = 0;
   virtual int count_particles(int64_t *local, int64_t *total, int allreduce) = 0;
   virtual int lane_stats(uint64_t *out, int n, int reset) = 0;
+  virtual int set_option(const char *name, const char *value) = 0;
+  virtual int get_info(const char *name, int64_t *value) = 0;
   virtual int comm_init(const void *id, int nbytes, int nranks, int rank) = 0;
   virtual int comm_init_host(int nranks, int rank, fpx_allreduce_fn fn, void *user) = 0;
   virtual int nests_init(const fpx_nests *n) = 0;
@@ -1659,17 +1729,22 @@ struct Engine : EngineBase {
   unsigned int *slot_of_pid = nullptr;   // only after a locality sort; read it through slot_map()
   bool slot_map_dirty = false;
   // Time-blended wind packs of the step in flight (View::w3t0 / w3t1).  Worth their 0.65 GB of extra traffic per step only
-  // for a large cloud: from FPX_BLEND_MIN particles on (default 3e7; 0 = never, 1 = always -- the parity tests).
+  // for a large cloud.  Blended and unblended gathers round differently, so the switch is a function of the configuration
+  // alone -- fpx_config.blend_mode, or in its automatic mode the run's particle count over ALL ranks (global_particles) --
+  // never of what this rank or this step happens to hold: runs with different rank counts, restarted runs and runs under
+  // fpx_step_async stay bitwise equal (README_PARALLEL.md:189-192).
   R *d_w3t[2] = {nullptr, nullptr}, *d_r2t = nullptr;
-  unsigned int *h_nlist = nullptr;   // pinned: length of the PBL work list of a recent step (copied asynchronously at its end)
+  static constexpr long long kBlendMinGlobal = 30000000ll;
+  bool blend_on() const {
+    if (cfg.blend_mode == 1) return true;
+    if (cfg.blend_mode == 2) return false;
+    return (cfg.global_particles > 0 ? cfg.global_particles : cfg.max_particles) >= kBlendMinGlobal;
+  }
+  unsigned long long blended_steps = 0;
   int blend_winds(int itime) {
-    const char *env = getenv("FPX_BLEND_MIN");      // read per step: the tests switch it inside one process
-    const long long blend_min = env ? atoll(env) : 30000000ll;
     V.w3t0 = nullptr; V.w3t1 = nullptr; V.r2t0 = nullptr;
-    // ... or from 1e6 particles in the boundary layer on (the work list of the previous step): the Langevin kernel fetches a
-    // level pair per pass and gains 5 % from the blended packs, which pays for the 0.23 ms long before 3e7 particles
-    const unsigned int last_nlist = h_nlist ? *(volatile unsigned int *)h_nlist : 0u;
-    if (blend_min <= 0 || (numpart < blend_min && last_nlist < 1000000u)) return 0;
+    if (!blend_on()) return 0;
+    blended_steps++;
     const long long npoint = (long long)cfg.nx * cfg.ny * cfg.nz;
     int rc;
     for (int k = 0; k < 2; k++)
@@ -1701,7 +1776,16 @@ struct Engine : EngineBase {
   void *d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   Stats *d_stats = nullptr;
-  unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[0] = list length, ctr[1] = chunk cursor
+  unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[2j] = length of the list of time slice j, ctr[2j+1] = its chunk cursor
+  static constexpr int kMaxSlices = 16;
+  unsigned int *d_surv[2] = {nullptr, nullptr};               // lists of the suspended particles (ping-pong between launches), allocated with the first sliced step
+  std::vector<int> slice_caps;                                // pass budget of each launch of the Langevin kernel, the last one 0 (none)
+  struct Options {                                            // fpx_set_option
+    int verbose = 0, pbl_blocks_per_cu = 0, prep_lds_pad = 0, permute = 0 /* 0 auto, 1 direct, 2 staged */, vt_unfused = 0;
+    long conv_scratch_mb = 0;
+    int conv_one_lane = 0, conv_no_walk = 0, conv_rows_plain = 0;
+    std::vector<int> pbl_slices;
+  } opt;
   unsigned char *d_pbl_flag = nullptr, *d_pbl_flag2 = nullptr;
   unsigned int *d_iota = nullptr;
   PblRec<R> Q;
@@ -1778,6 +1862,13 @@ struct Engine : EngineBase {
     if (cfg.nspec < 1 || cfg.nspec > FPX_MAXSPEC || cfg.maxspec < cfg.nspec) return fail(FPX_ERR_ARG, "bad nspec/maxspec");
     if (cfg.max_particles < 1 || cfg.max_particles > 0xFFFFFFF0ll) return fail(FPX_ERR_ARG, "bad max_particles");
     if (cfg.ifine < 1) return fail(FPX_ERR_ARG, "ifine must be >= 1");
+    if (cfg.lsynctime == 0 || std::abs((long long)cfg.lsynctime) > 65535) return fail(FPX_ERR_ARG, "lsynctime must be non-zero and at most 65535 s in magnitude (the hand-over record of the Langevin kernel keeps |itimec - itime| in 16 bits)");
+    if (cfg.ipout == 3) return fail(FPX_ERR_UNSUPPORTED, "ipout = 3: the particle loop's partpos_average (timemanager.f90:617) is not computed by this engine");
+    if (cfg.iflux == 1) return fail(FPX_ERR_UNSUPPORTED, "iflux = 1: the particle loop's calcfluxes (timemanager.f90:623) is not computed by this engine");
+    if (cfg.linit_cond >= 1) return fail(FPX_ERR_UNSUPPORTED, "linit_cond >= 1: the particle loop's initial_cond_calc (timemanager.f90:631,702) is not computed by this engine");
+    if (cfg.blend_mode < 0 || cfg.blend_mode > 2) return fail(FPX_ERR_ARG, "blend_mode must be 0 (automatic), 1 (on) or 2 (off)");
+    if (cfg.global_particles < 0) return fail(FPX_ERR_ARG, "global_particles must not be negative");
+    if (cfg.pbl_slice_passes < -1) return fail(FPX_ERR_ARG, "pbl_slice_passes must be -1 (one launch), 0 (the engine's schedule) or a pass budget");
     HIPCHK(hipSetDevice(cfg.device));
     HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     memset(&V, 0, sizeof(V));
@@ -1797,6 +1888,7 @@ struct Engine : EngineBase {
     V.ldirect = cfg.ldirect; V.lsynctime = cfg.lsynctime; V.method = cfg.method; V.mintime = cfg.mintime;
     V.ifine = cfg.ifine; V.turbswitch = cfg.turbswitch; V.cblflag = cfg.cblflag; V.mdomainfill = cfg.mdomainfill;
     V.lsettling = cfg.lsettling; V.nspec = cfg.nspec; V.drydep = cfg.drydep;
+    V.turboff = cfg.turboff != 0; V.interpolhmix = cfg.interpolhmix != 0;
     V.ctl = (R)cfg.ctl; V.fine = (R)1. / (R)cfg.ifine;   // readcommand.f90:271
     V.d_trop = (R)cfg.d_trop; V.d_strat = (R)cfg.d_strat; V.turbmesoscale = (R)cfg.turbmesoscale;
     for (int i = 0; i < FPX_MAXSPEC; i++) {
@@ -1856,14 +1948,14 @@ struct Engine : EngineBase {
     }
     if ((rc = dalloc(&P.pid, cap))) return rc;
     if ((rc = dalloc(&d_pbl_list, cap))) return rc;
-    if ((rc = dalloc(&d_pbl_ctr, 2))) return rc;
+    if ((rc = dalloc(&d_pbl_ctr, 2 * kMaxSlices))) return rc;
     if ((rc = dalloc(&d_pbl_flag, cap))) return rc;
     if ((rc = dalloc(&d_pbl_flag2, cap))) return rc;
     if ((rc = dalloc(&d_iota, cap))) return rc;
     memset(&Q, 0, sizeof(Q));
     {
       if ((rc = dalloc(&Q.rec, cap))) return rc;
-      if (cfg.drydep && (rc = dalloc(&Q.prob, cap * cfg.nspec))) return rc;
+      if (cfg.drydep && (rc = dalloc(&Q.tdep, cap))) return rc;
     }
     // every storage space starts zeroed (releaseparticles leaves the turbulent state of a space it takes as it finds it;
     // the host's arrays start from zero too), dead (FLEXPART.f90:315-317) and identity-numbered
@@ -1904,7 +1996,6 @@ struct Engine : EngineBase {
     if (rel_rank_buf) (void)hipFree(rel_rank_buf);
     if (rel_tmp_buf) (void)hipFree(rel_tmp_buf);
     if (redist_dev) (void)hipFree(redist_dev);      // (d_w3t: dalloc'ed, freed with the engine's other owned buffers)
-    if (h_nlist) (void)hipHostFree(h_nlist);
     if (d_sort_rec) (void)hipFree(d_sort_rec);
     if (red_pin) (void)hipHostFree(red_pin);
     if (comm) (void)ncclCommDestroy(comm);
@@ -2137,8 +2228,7 @@ struct Engine : EngineBase {
     // fused path: the ECMWF level structure (nuvz = nwz = nz) and a tile's uvzlev fits the LDS of a CU twice
     constexpr int kVtWaves = FPX_VT_WAVES;
     const size_t sm_lev = (size_t)nz * vt::kVtCols * sizeof(H), sm_fused = sm_lev + (size_t)5 * nz * sizeof(H);
-    const char *vt_force = getenv("FPX_VT_UNFUSED");
-    const bool fused = m->nuvz == nz && m->nwz == nz && nz >= 3 && sm_fused <= (size_t)80 * 1024 && n3 < ((size_t)1 << 31) && !(vt_force && vt_force[0] == '1');
+    const bool fused = m->nuvz == nz && m->nwz == nz && nz >= 3 && sm_fused <= (size_t)80 * 1024 && n3 < ((size_t)1 << 31) && !opt.vt_unfused;
     if (fused) {
       vt::Tiles T;
       T.tiles_y = (gny + vt::kVtTy - 1) / vt::kVtTy;
@@ -3665,7 +3755,7 @@ struct Engine : EngineBase {
       size_t free_b = 0, total_b = 0;
       HIPCHK(hipMemGetInfo(&free_b, &total_b));
       budget = (free_b + conv_scr_bytes) / 4;
-      if (const char *env = getenv("FPX_CONV_SCRATCH_MB")) budget = (size_t)std::max(1l, atol(env)) << 20;
+      if (opt.conv_scratch_mb > 0) budget = (size_t)opt.conv_scratch_mb << 20;
     }
     if ((size_t)nact > conv_alive_cap) {
       if (conv_alive) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(conv_alive)); conv_alive = nullptr; }
@@ -3689,11 +3779,11 @@ struct Engine : EngineBase {
     H *vbuf = (H *)conv_scr, *cst = vbuf + vec_elems, *mbuf = cst + cst_elems;
     const H height_nz = (H)height_host[cfg.nz - 1];
     const bool seq = cfg.rng_mode == FPX_RNG_TABLE_SEQ;
-    const bool conv_one_lane = getenv("FPX_CONV_ONE_LANE") != nullptr;     // the one-lane-per-column kernel (kept as the check of the level-parallel ones)
+    const bool conv_one_lane = opt.conv_one_lane != 0;     // the one-lane-per-column kernel (kept as the check of the level-parallel ones)
     // fmassfrac stored along the rows (forward runs) / columns (backward) the particles walk (k_conv_matrix_walk, _walk_t);
     // FPX_CONV_NO_WALK=1: the interleaved form
-    const bool conv_walk = !conv_one_lane && getenv("FPX_CONV_NO_WALK") == nullptr;
-    const bool conv_rows_plain = getenv("FPX_CONV_ROWS_PLAIN") != nullptr;  // k_conv_rows without the LDS staging of its operands
+    const bool conv_walk = !conv_one_lane && !opt.conv_no_walk;
+    const bool conv_rows_plain = opt.conv_rows_plain != 0;  // k_conv_rows without the LDS staging of its operands
     conv::k_conv_column_a<H><<<conv::serial_grid(nact), 64, 0, stream>>>(F, vbuf, cst, nv, conv_act, nact, alive);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemsetAsync(conv_lconv, 0, (size_t)nact * sizeof(int), stream));
@@ -4150,9 +4240,22 @@ struct Engine : EngineBase {
       int per_cu = 0;
       HIPCHK(hipFuncSetAttribute((const void *)loop_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_smem_bytes()));
       HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, loop_smem_bytes()));
-      if (const char *env = getenv("FPX_PBL_BLOCKS_PER_CU")) per_cu = std::min(per_cu, std::max(1, atoi(env)));   // experiments: fewer resident waves
+      if (opt.pbl_blocks_per_cu > 0) per_cu = std::min(per_cu, opt.pbl_blocks_per_cu);   // experiments: fewer resident waves
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
-      if (getenv("FPX_VERBOSE")) fprintf(stderr, "[fpx] Langevin kernel: %d blocks per CU by the occupancy query, %zu B of dynamic LDS, grid %d\n", per_cu, loop_smem_bytes(), pbl_grid);
+      if (opt.verbose) fprintf(stderr, "[fpx] Langevin kernel: %d blocks per CU by the occupancy query, %zu B of dynamic LDS, grid %d\n", per_cu, loop_smem_bytes(), pbl_grid);
+    }
+    // the pass budgets of the Langevin kernel's launches (time slices, k_pbl_loop); the last launch has none
+    if (slice_caps.empty()) {
+      if (!opt.pbl_slices.empty()) slice_caps = opt.pbl_slices;
+      else if (cfg.pbl_slice_passes < 0) slice_caps = {0};
+      else if (cfg.pbl_slice_passes > 0) slice_caps = std::vector<int>(kMaxSlices - 1, cfg.pbl_slice_passes);
+      else slice_caps = {FPX_SLICE_SCHEDULE};
+      if ((int)slice_caps.size() > kMaxSlices - 1) slice_caps.resize(kMaxSlices - 1);
+      if (slice_caps.empty() || slice_caps.back() != 0) slice_caps.push_back(0);
+      if (slice_caps.size() > 1 && !d_surv[0]) {
+        int rc;
+        for (int k = 0; k < 2; k++) if ((rc = dalloc(&d_surv[k], (size_t)P.cap))) return rc;
+      }
     }
     {
       size_t need = 0;
@@ -4163,7 +4266,7 @@ struct Engine : EngineBase {
         sel_tmp_bytes = need;
       }
     }
-    HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * sizeof(unsigned int), stream));
+    HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * kMaxSlices * sizeof(unsigned int), stream));
     { const int rc = blend_winds(itime); if (rc) return rc; }      // its own kernel (k_blend_w3), ahead of the per-kernel events
     HIPCHK(hipEventRecord(ev.e[0], stream));
     if (P.xscav) {   // timemanager.f90:564-598, before the particle is moved
@@ -4178,7 +4281,7 @@ struct Engine : EngineBase {
       typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *, unsigned int *);
       const bool nest = V.numbnests > 0;
       const prep_fn f = (prep_fn)step_kernel_prep((int)sizeof(R), cfg.drydep != 0, init, polar, nest);
-      static const int prep_pad = getenv("FPX_PREP_LDS_PAD") ? atoi(getenv("FPX_PREP_LDS_PAD")) : 0;   // experiments: unused dynamic LDS lowers the occupancy
+      const int prep_pad = opt.prep_lds_pad;   // experiments: unused dynamic LDS lowers the occupancy
       if (prep_pad > 0) HIPCHK(hipFuncSetAttribute((const void *)f, hipFuncAttributeMaxDynamicSharedMemorySize, prep_pad));
       f<<<nb, kBlock, (size_t)prep_pad, stream>>>(V, Gp, P, S, Q, numpart, itime, step_counter, d_stats, d_pbl_flag, d_pbl_ctr);
       maybe_new = false;
@@ -4193,7 +4296,13 @@ struct Engine : EngineBase {
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
     HIPCHK(hipEventRecord(ev.e[1], stream));
-    loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr, d_pbl_ctr + 1);
+    for (size_t j = 0; j < slice_caps.size(); j++) {
+      // launch j works through the particles launch j-1 suspended (ctr[2j] = list length, written by that launch's appends;
+      // ctr[2j+1] = chunk cursor); a launch whose list is empty ends at once
+      const unsigned int *list = j == 0 ? d_pbl_list : d_surv[(j - 1) & 1];
+      loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, list, d_pbl_ctr + 2 * j, d_pbl_ctr + 2 * j + 1,
+                                                                     slice_caps[j], d_surv[j & 1], d_pbl_ctr + 2 * (j + 1));
+    }
     HIPCHK(hipEventRecord(ev.e[2], stream));
     {
       const bool polar = cfg.nglobal || cfg.sglobal, nest = V.numbnests > 0;
@@ -4204,13 +4313,14 @@ struct Engine : EngineBase {
     HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
     V.w3t0 = nullptr; V.w3t1 = nullptr; V.r2t0 = nullptr;      // the blended packs belong to this step's itime only
-    // the length of this step's work list for the next step's decision (blend_winds): an asynchronous copy into pinned
-    // memory, read without waiting -- a host that runs ahead sees the value of an earlier step, which is as good
-    if (!h_nlist) {
-      HIPCHK(hipHostMalloc((void **)&h_nlist, sizeof(unsigned int), hipHostMallocDefault));
-      *h_nlist = 0u;
+    if (opt.verbose > 1) {   // the lists of the time slices (a synchronisation per step: diagnostics only)
+      unsigned int hc[2 * kMaxSlices];
+      HIPCHK(hipMemcpyAsync(hc, d_pbl_ctr, sizeof(hc), hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+      fprintf(stderr, "[fpx] step %u: Langevin lists", step_counter);
+      for (size_t j = 0; j < slice_caps.size(); j++) fprintf(stderr, " %u(cap %d)", hc[2 * j], slice_caps[j]);
+      fprintf(stderr, "\n");
     }
-    HIPCHK(hipMemcpyAsync(h_nlist, d_pbl_ctr, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     step_counter++;
     if (async) return 0;
     Stats hs;
@@ -4242,6 +4352,57 @@ struct Engine : EngineBase {
     if (reset) HIPCHK(hipMemsetAsync((char *)d_stats + offsetof(Stats, lanes), 0, sizeof(hs.lanes), stream));
     return 0;
   }
+  int set_option(const char *name, const char *value) override {
+    const std::string n(name), v(value);
+    char *end = nullptr;
+    const long iv = strtol(value, &end, 10);
+    const bool is_int = end != value && *end == 0;
+    auto need_int = [&](long lo) -> bool { return is_int && iv >= lo; };
+    if (n == "verbose") { if (!need_int(0)) goto bad; opt.verbose = (int)iv; return 0; }
+    if (n == "pbl_blocks_per_cu") { if (!need_int(0)) goto bad; opt.pbl_blocks_per_cu = (int)iv; pbl_grid = 0; return 0; }
+    if (n == "prep_lds_pad") { if (!need_int(0) || iv > 160 * 1024) goto bad; opt.prep_lds_pad = (int)iv; return 0; }
+    if (n == "vt_unfused") { if (!need_int(0)) goto bad; opt.vt_unfused = iv != 0; return 0; }
+    if (n == "conv_scratch_mb") { if (!need_int(0)) goto bad; opt.conv_scratch_mb = iv; return 0; }
+    if (n == "conv_one_lane") { if (!need_int(0)) goto bad; opt.conv_one_lane = iv != 0; return 0; }
+    if (n == "conv_no_walk") { if (!need_int(0)) goto bad; opt.conv_no_walk = iv != 0; return 0; }
+    if (n == "conv_rows_plain") { if (!need_int(0)) goto bad; opt.conv_rows_plain = iv != 0; return 0; }
+    if (n == "permute") {
+      if (v == "auto") opt.permute = 0; else if (v == "direct") opt.permute = 1; else if (v == "staged") opt.permute = 2; else goto bad;
+      return 0;
+    }
+    if (n == "pbl_slices") {   // "48,96,0": pass budgets of the successive launches; "" = back to the configuration's
+      std::vector<int> caps;
+      const char *q = value;
+      while (*q) {
+        char *e2 = nullptr;
+        const long c = strtol(q, &e2, 10);
+        if (e2 == q || c < 0 || c > 1000000) goto bad;
+        caps.push_back((int)c);
+        q = e2;
+        if (*q == ',') q++; else if (*q) goto bad;
+      }
+      if ((int)caps.size() > kMaxSlices - 1) goto bad;
+      opt.pbl_slices = caps;
+      slice_caps.clear();
+      return 0;
+    }
+  bad:
+    return fail(FPX_ERR_ARG, "fpx_set_option: unknown option or malformed value: " + n + " = " + v);
+  }
+  int get_info(const char *name, int64_t *value) override {
+    const std::string n(name);
+    if (n == "time_blended_packs") *value = blend_on() ? 1 : 0;
+    else if (n == "blended_steps") *value = (int64_t)blended_steps;
+    else if (n == "pbl_launches_per_step") {
+      if (!slice_caps.empty()) *value = (int64_t)slice_caps.size();
+      else if (!opt.pbl_slices.empty()) *value = (int64_t)opt.pbl_slices.size() + (opt.pbl_slices.back() != 0 ? 1 : 0);
+      else if (cfg.pbl_slice_passes < 0) *value = 1;
+      else if (cfg.pbl_slice_passes > 0) *value = kMaxSlices;
+      else { const int d[] = {FPX_SLICE_SCHEDULE}; *value = (int64_t)(sizeof(d) / sizeof(d[0])); }
+    } else if (n == "pbl_grid") *value = pbl_grid;
+    else return fail(FPX_ERR_ARG, "fpx_get_info: unknown name: " + n);
+    return 0;
+  }
   int counters(fpx_step_stats *out, int reset) override {
     Stats hs;
     HIPCHK(hipMemcpyAsync(&hs, d_stats, sizeof(Stats), hipMemcpyDeviceToHost, stream));
@@ -4253,7 +4414,7 @@ struct Engine : EngineBase {
   }
 
   // the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
-  typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *, unsigned int *);
+  typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *, unsigned int *, int, unsigned int *, unsigned int *);
   size_t loop_smem_bytes() const { return sizeof(R) * ((size_t)S_COUNT * kStashStride + (size_t)cfg.nz); }
   loop_fn loop_kernel() const {
     return (loop_fn)step_kernel_loop((int)sizeof(R), !cfg.drydep && !cfg.lsettling, cfg.turbswitch, cfg.cblflag, cfg.rng_mode);
@@ -4368,12 +4529,11 @@ struct Engine : EngineBase {
       sort_tmp_bytes = need;
     }
     HIPCHK(rocprim::radix_sort_pairs(d_sort_tmp, need, d_keys, d_keys2, d_vals, d_vals2, (size_t)n, 0u, bits, stream));
-    // which gather: by the locality of the permutation (FPX_PERMUTE=direct|staged overrides, for tests)
+    // which gather: by the locality of the permutation (fpx_set_option "permute" = direct|staged overrides, for tests)
     bool staged = false;
     {
-      const char *force = getenv("FPX_PERMUTE");
-      if (force && !strcmp(force, "staged")) staged = true;
-      else if (!(force && !strcmp(force, "direct")) && n >= (1 << 16)) {
+      if (opt.permute == 2) staged = true;
+      else if (opt.permute != 1 && n >= (1 << 16)) {
         HIPCHK(hipMemsetAsync(d_disorder, 0, sizeof(unsigned long long), stream));
         k_perm_disorder<<<std::min(nb, 4096), kBlock, 0, stream>>>(d_vals2, n, 1u << 14, d_disorder);
         unsigned long long far = 0;
@@ -4678,6 +4838,7 @@ struct Engine : EngineBase {
     if (!n || n->struct_bytes != (int32_t)sizeof(fpx_nests)) return fail(FPX_ERR_ARG, "nests_init: null or fpx_nests size mismatch (ABI)");
     if (n->numbnests < 1 || n->numbnests > kMaxNests) return fail(FPX_ERR_ARG, "nests_init: numbnests out of range");
     if (V.numbnests) return fail(FPX_ERR_STATE, "nests_init: already initialised");
+    if (cfg.interpolhmix) return fail(FPX_ERR_UNSUPPORTED, "nests_init: interpolhmix with nested wind fields -- the reference reads the unset h1 for a particle inside a nest (advance.f90:254-266)");
     int rc;
     for (int l = 0; l < n->numbnests; l++) {
       if (n->nxn[l] < 2 || n->nyn[l] < 2 || n->nxn[l] > n->nxmaxn || n->nyn[l] > n->nymaxn) return fail(FPX_ERR_ARG, "nests_init: bad nest extents");
@@ -4958,7 +5119,7 @@ struct fpx_engine {
 
 extern "C" {
 
-int fpx_abi_version(void) { return 3; }
+int fpx_abi_version(void) { return 4; }
 
 int fpx_polar_maps(int32_t host_real_bytes, double dy, double north[9], double south[9]) {
   if (!north || !south || !(dy > 0)) return fpx::fail(FPX_ERR_ARG, "fpx_polar_maps: bad argument");
@@ -5132,6 +5293,8 @@ int fpx_comm_unique_id(void *id, int32_t nbytes) {
 }
 int fpx_count_particles(fpx_handle h, int64_t local[2], int64_t total[2], int32_t allreduce) { FPX_GUARD(h); return h->impl->count_particles(local, total, allreduce); }
 int fpx_set_release_heights(fpx_handle h, int32_t numpoint, const void *zpoint1, const void *zpoint2) { FPX_GUARD(h); return h->impl->set_release_heights(numpoint, zpoint1, zpoint2); }
+int fpx_set_option(fpx_handle h, const char *name, const char *value) { FPX_GUARD(h); if (!name || !value) return fpx::fail(FPX_ERR_ARG, "fpx_set_option: null argument"); return h->impl->set_option(name, value); }
+int fpx_get_info(fpx_handle h, const char *name, int64_t *value) { FPX_GUARD(h); if (!name || !value) return fpx::fail(FPX_ERR_ARG, "fpx_get_info: null argument"); return h->impl->get_info(name, value); }
 int fpx_lane_stats(fpx_handle h, uint64_t *out, int32_t n, int32_t reset) { FPX_GUARD(h); if (!out || n < 0) return fpx::fail(FPX_ERR_ARG, "fpx_lane_stats: bad argument"); return h->impl->lane_stats(out, n, reset); }
 int fpx_comm_init(fpx_handle h, const void *id, int32_t nbytes, int32_t nranks, int32_t rank) { FPX_GUARD(h); return h->impl->comm_init(id, nbytes, nranks, rank); }
 int fpx_comm_init_host(fpx_handle h, int32_t nranks, int32_t rank, fpx_allreduce_fn fn, void *user) { FPX_GUARD(h); return h->impl->comm_init_host(nranks, rank, fn, user); }

@@ -39,7 +39,7 @@ def release_tables(sc):
 class Engine:
     def __init__(self, sc, *, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ,
                  seed=0x5EED, max_particles=None, device=0, pad=(0, 0, 0), sort_interval=0,
-                 polemaps=None, particle_base=0):
+                 polemaps=None, particle_base=0, blend_mode=0, global_particles=0, pbl_slice_passes=0, options=None):
         """sc: scenario dict (flexpart_amd.synthetic).  pad: extra allocated (nxmax-nx,
         nymax-ny, nzmax-nz) to exercise the reference's padded-array convention."""
         self.lib = _lib.load()
@@ -100,9 +100,16 @@ class Engine:
         cfg.particle_base = int(particle_base or sc.get("particle_base", 0))
         cfg.drybkdep, cfg.wetbkdep = int(sc.get("drybkdep", 0)), int(sc.get("wetbkdep", 0))   # backward runs with receptor scavenging
         self.bkdep = bool(cfg.drybkdep or cfg.wetbkdep)
+        cfg.turboff, cfg.interpolhmix = int(sc.get("turboff", 0)), int(sc.get("interpolhmix", 0))   # com_mod.f90:777-778
+        cfg.ipout, cfg.iflux, cfg.linit_cond = int(sc.get("ipout", 0)), int(sc.get("iflux", 0)), int(sc.get("linit_cond", 0))   # refused when set
+        cfg.blend_mode = int(blend_mode)                # 0: from global_particles, 1 on, 2 off
+        cfg.global_particles = int(global_particles)    # the run's particle count over all ranks
+        cfg.pbl_slice_passes = int(pbl_slice_passes)    # 0: the engine's schedule, -1: one launch, k: k passes per launch
         self.cfg = cfg
         self.h = C.c_void_p()
         check(self.lib.fpx_create(C.byref(self.h), C.byref(cfg)), "fpx_create")
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
         if "height" in sc:
             hgt = np.ascontiguousarray(np.asarray(sc["height"]).astype(rt))
             check(self.lib.fpx_set_height(self.h, _vp(hgt), nz), "fpx_set_height")
@@ -791,6 +798,16 @@ class Engine:
         tot = (C.c_int64 * 2)()
         check(self.lib.fpx_count_particles(self.h, loc, tot, int(allreduce)), "fpx_count_particles")
         return (int(loc[0]), int(loc[1])), (int(tot[0]), int(tot[1]))
+
+    def set_option(self, name, value):
+        """fpx_set_option: a tuning / diagnostic knob of this handle (include/flexpart_amd.h lists the names)."""
+        check(self.lib.fpx_set_option(self.h, str(name).encode(), str(value).encode()), f"fpx_set_option({name})")
+
+    def info(self, name):
+        """fpx_get_info: what the engine decided or did ("time_blended_packs", "blended_steps", "pbl_launches_per_step", ...)."""
+        v = C.c_int64(0)
+        check(self.lib.fpx_get_info(self.h, str(name).encode(), C.byref(v)), f"fpx_get_info({name})")
+        return int(v.value)
 
     def lane_stats(self, reset=False):
         """Per code region of the Langevin kernel: (executions by a wave, mean active lanes); zeros unless the library was

@@ -68,7 +68,12 @@ module flexgpu_mod
     integer(c_int32_t) :: par_nxmax
     integer(c_int64_t) :: particle_base
     integer(c_int32_t) :: drybkdep, wetbkdep
-    integer(c_int32_t) :: reserved(2)
+    integer(c_int32_t) :: turboff, interpolhmix
+    integer(c_int32_t) :: blend_mode
+    integer(c_int32_t) :: pbl_slice_passes
+    integer(c_int64_t) :: global_particles
+    integer(c_int32_t) :: ipout, iflux, linit_cond
+    integer(c_int32_t) :: reserved(3)
   end type fpx_config
 
   type, bind(C) :: fpx_fields
@@ -571,12 +576,18 @@ contains
   ! com_mod/par_mod -> fpx_config; creates the engine on `device` for `nmaxpart` particles.
   ! defer_height: the z levels do not exist yet -- the first flexgpu_verttransform derives them
   ! particle_base (MPI host): global number of this rank's first particle, so that the counter RNG does not depend on the
-  ! number of ranks
-  subroutine flexgpu_init(ierr, device, nmaxpart, compute_real_bytes, rng_mode, seed, defer_height, particle_base)
+  ! number of ranks; global_particles (MPI host): maxpart of the whole run = the sum over the ranks -- decisions every rank
+  ! must take alike (the time-blended wind packs) are taken from it, never from what one rank holds; blend_mode: 0 from
+  ! global_particles, 1 on, 2 off.
+  ! The run's ipout / iflux / linit_cond travel along: the engine refuses (ierr = -5) a run whose particle loop would also
+  ! call partpos_average, calcfluxes or initial_cond_calc (timemanager.f90:617,623,631,702), which it does not compute.
+  ! turboff / interpolhmix: the host's compile-time parameters (com_mod.f90:777-778) become the engine's run-time switches.
+  subroutine flexgpu_init(ierr, device, nmaxpart, compute_real_bytes, rng_mode, seed, defer_height, particle_base, &
+                          global_particles, blend_mode)
     integer, intent(out) :: ierr
-    integer, intent(in), optional :: device, nmaxpart, compute_real_bytes, rng_mode
+    integer, intent(in), optional :: device, nmaxpart, compute_real_bytes, rng_mode, blend_mode
     logical, intent(in), optional :: defer_height
-    integer(c_int64_t), intent(in), optional :: seed, particle_base
+    integer(c_int64_t), intent(in), optional :: seed, particle_base, global_particles
     type(fpx_config) :: cfg
     integer :: ks
     cfg%struct_bytes = int(c_sizeof(cfg), c_int32_t)
@@ -612,6 +623,11 @@ contains
     cfg%par_nxmax = nxmax          ! eps = nxmax/3.e5, advance.f90:107
     cfg%particle_base = 0; if (present(particle_base)) cfg%particle_base = particle_base
     cfg%drybkdep = merge(1, 0, DRYBKDEP); cfg%wetbkdep = merge(1, 0, WETBKDEP)   ! timemanager.f90:564-598 runs in flexgpu_step
+    cfg%turboff = merge(1, 0, turboff); cfg%interpolhmix = merge(1, 0, interpolhmix)   ! com_mod.f90:777-778
+    cfg%blend_mode = 0; if (present(blend_mode)) cfg%blend_mode = blend_mode
+    cfg%pbl_slice_passes = 0
+    cfg%global_particles = cfg%max_particles; if (present(global_particles)) cfg%global_particles = global_particles
+    cfg%ipout = ipout; cfg%iflux = iflux; cfg%linit_cond = linit_cond
     cfg%reserved = 0
     ierr = fpx_create(flexgpu_handle, cfg)
     if (ierr /= 0) return

@@ -103,7 +103,30 @@ typedef struct {
    * readcommand.f90:320-340): the particle array xscav_frac1 exists, the first step of a particle fills it
    * (timemanager.f90:564-598) and fpx_conccalc weights every contribution with max(xscav_frac1, 0).  ldirect must be -1. */
   int32_t drybkdep, wetbkdep;
-  int32_t reserved[2];
+  /* The two compile-time logicals of com_mod.f90:777-778 as run-time switches (a host passes its own parameters):
+   * turboff /= 0: no turbulence (advance.f90:464-470: wp = 0, delz = 0 in the vertical Langevin loop; :675-679: no
+   * random displacement above the boundary layer; the shipped value is .false.);
+   * interpolhmix /= 0: the mixing height of the cell is interpolated in time (advance.f90:240-249 / :254-262 for a
+   * nest) instead of taken as the maximum over both times (shipped: .false.). */
+  int32_t turboff, interpolhmix;
+  /* Time-blended wind packs (u, v, w, rho, drhodz blended in time once per step, because the time
+   * weights are the same for every particle).  The blended and the unblended gather round differently (1e-11), so the
+   * choice must not depend on anything a rank sees alone: 0 = decide from global_particles (on from 3e7), 1 = on,
+   * 2 = off.  Every rank of a run must pass the same values. */
+  int32_t blend_mode;
+  /* Time slices of the Langevin kernel (k_pbl_loop): a launch gives a particle at most this many passes of the loop
+   * advance.f90:282-609, the particles that need more continue in the next launch, shared by all waves.
+   * 0 = the engine's schedule, -1 = one launch without a budget, k > 0 = k passes per launch.  Results do not depend on it. */
+  int32_t pbl_slice_passes;
+  /* The run's particle count over ALL ranks (what maxpart / the planned releases amount to), 0 = max_particles of this
+   * rank: the basis of decisions that every rank must take alike (blend_mode = 0). */
+  int64_t global_particles;
+  /* Diagnostics inside the particle loop that the engine does NOT compute (out of scope): the host passes
+   * its COMMAND switches and fpx_create refuses (FPX_ERR_UNSUPPORTED) a run that would need them, instead of dropping their
+   * output silently: ipout = 3 (partpos_average, timemanager.f90:617), iflux = 1 (calcfluxes, :623), linit_cond >= 1
+   * (initial_cond_calc, :631,702).  Zero-initialised fields mean "not requested". */
+  int32_t ipout, iflux, linit_cond;
+  int32_t reserved[3];
 } fpx_config;
 
 /* One time slot of the met fields the path gathers from (com_mod.f90:355-371,
@@ -627,6 +650,21 @@ int fpx_math_probe(int32_t fn, const double *x, double *y, int64_t n);
  * neutral / unstable / stable, 8 lane refill, 9 hand-over of a finished particle, 10 iterations of the kernel's outer loop.
  * n <= 32 values are written; reset != 0 zeroes the counters. */
 int fpx_lane_stats(fpx_handle h, uint64_t *out, int32_t n, int32_t reset);
+
+/* Tuning and diagnostic knobs of one handle (none of them changes a result; measurements and A/B runs only -- the library
+ * reads no environment variable).  Names: "verbose" (0|1: the engine reports its launch geometry on stderr),
+ * "pbl_blocks_per_cu" (1..: fewer resident blocks of the Langevin kernel), "pbl_slices" (comma-separated pass budgets of the
+ * successive launches of the Langevin kernel, 0 = no budget, e.g. "48,96,0"; overrides fpx_config.pbl_slice_passes),
+ * "prep_lds_pad" (bytes of unused dynamic LDS of k_prep: lowers its occupancy), "permute" ("soa"|"record"|"auto": the
+ * permutation kernel of the locality sort), "vt_unfused" (0|1: the level-parallel chain of fpx_verttransform_ecmwf instead
+ * of the fused tile kernels), "conv_scratch_mb", "conv_one_lane", "conv_no_walk", "conv_rows_plain" (fpx_convmix variants).
+ * Unknown names and malformed values return FPX_ERR_ARG. */
+int fpx_set_option(fpx_handle h, const char *name, const char *value);
+/* What the engine decided or did, by name: "time_blended_packs" (1 when the steps of this handle blend the wind packs in
+ * time: fpx_config.blend_mode / global_particles), "blended_steps" (steps that did so far), "pbl_launches_per_step"
+ * (launches of the Langevin kernel per step = time slices + 1), "pbl_grid" (its persistent grid, blocks; 0 before the
+ * first step).  Unknown names return FPX_ERR_ARG. */
+int fpx_get_info(fpx_handle h, const char *name, int64_t *value);
 
 #ifdef __cplusplus
 }

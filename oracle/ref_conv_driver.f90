@@ -97,6 +97,7 @@ program convref
     nx = nxl; ny = nyl; nxmin1 = nx - 1; nymin1 = ny - 1
     dx = 1.; dy = 1.; xlon0 = -20.; ylat0 = 20.; xglobal = .false.; nglobal = .false.; sglobal = .false.
     switchnorthg = 999999.; switchsouthg = 999999.
+    ipout = 0; iflux = 0; linit_cond = 0
     do k = 1, nz
       height(k) = real(hnz) * real(k - 1) / real(nz - 1)
     end do

@@ -95,7 +95,7 @@ program flexref
   call gasdev1(idummy,rannumb(maxrand),rannumb(maxrand-1))
 
   ! ---- defaults ----------------------------------------------------------
-  ipout=0; ldirect=1; lsynctime=900; method=1; mintime=1; ctl=0.2; ifine=4
+  ipout=0; iflux=0; ldirect=1; lsynctime=900; method=1; mintime=1; ctl=0.2; ifine=4
   fine=0.25; turbswitch=.true.; cblflag=0; mdomainfill=0; mquasilag=0
   lsettling=.false.; nspec=1; maxpointspec_act=1
   DRYDEP=.false.; WETDEP=.false.; DRYBKDEP=.false.; WETBKDEP=.false.

@@ -103,6 +103,7 @@ program poref
   if (use_gpu .eq. 1) then
     ! run switches flexgpu_init reads (no particle step is taken here)
     ldirect=1; lsynctime=900; method=1; mintime=1; ctl=0.2; ifine=4; turbswitch=.true.; cblflag=0
+    iflux=0; linit_cond=0          ! (ipout = 2 above: the dump at the end of the run, partoutput.f90:84-86)
     mdomainfill=0; lsettling=.false.; DRYDEP=.false.; nageclass=1; lage(1)=999999999
     xglobal=.false.; nglobal=.false.; sglobal=.false.; switchnorthg=999999.; switchsouthg=999999.
     dxconst=180./(dx*r_earth*pi); dyconst=180./(dy*r_earth*pi)

@@ -169,6 +169,7 @@ program relref
   if (use_gpu .eq. 1) then
     ! run switches flexgpu_init reads (no trajectory step is taken here)
     method=1; ctl=0.2; ifine=4; turbswitch=.true.; cblflag=0
+    ipout=0; iflux=0; linit_cond=0
     mdomainfill=0; lsettling=.false.; DRYDEP=.false.; nageclass=1; lage(1)=999999999
     nglobal=.false.; sglobal=.false.; switchnorthg=999999.; switchsouthg=999999.
     dxconst=180./(dx*r_earth*pi); dyconst=180./(dy*r_earth*pi)

@@ -72,7 +72,7 @@ program rpref
   do i=1,nspec
     species(i) = 'SPEC001'
   end do
-  ipout=0
+  ipout=0; iflux=0; linit_cond=0
   call com_mod_allocate_part(maxp)
 
   ! the header file: only the records readpartpositions reads or skips (readpartpositions.f90:59-113)

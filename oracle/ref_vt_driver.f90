@@ -179,7 +179,7 @@ program vtref
     ldirect=1; lsynctime=900; method=1; mintime=1; ctl=0.2; ifine=4; turbswitch=.true.; cblflag=0
     mdomainfill=0; lsettling=.false.; nspec=1; DRYDEP=.false.; nageclass=1; lage(1)=999999999
     numpoint=1; allocate(xmass(1,maxspec), npart(1)); xmass=1.; npart(1)=1
-    ipout=0; call com_mod_allocate_part(1)
+    ipout=0; iflux=0; linit_cond=0; call com_mod_allocate_part(1)
     hmix(:,:,1,1)=500.; ustar(:,:,1,1)=0.3; wstar(:,:,1,1)=1.; oli(:,:,1,1)=0.01; tropopause(:,:,1,1)=10000.
     call flexgpu_init(gerr, nmaxpart=1, defer_height=.true.)
     if (gerr .ne. 0) then

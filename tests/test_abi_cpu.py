@@ -38,7 +38,7 @@ def test_struct_sizes_match_header(built):
     cfg.host_real_bytes = 3
     rc = lib.fpx_create(C.byref(h), C.byref(cfg))
     assert rc == -1 and b"host_real_bytes" in lib.fpx_last_error()
-    assert lib.fpx_abi_version() == 3
+    assert lib.fpx_abi_version() == 4
 
 
 def test_no_device_is_an_error_not_a_fallback(built):

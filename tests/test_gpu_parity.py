@@ -70,21 +70,20 @@ def test_fp64_matches_oracle(built, name, kw):
     ("backward_above_pbl", dict(ctl=-5.0, hmix_const=100.0, frac_pbl=0.0, turb_off=True, ldirect=-1)),
     ("backward_cbl", dict(ctl=5.0, ifine=4, cblflag=1, ldirect=-1)),
 ])
-def test_time_blended_wind_packs_change_rounding_only(built, monkeypatch, name, kw):
-    """From FPX_BLEND_MIN particles on (3e7 by default) the step first blends the wind pack in time -- the weights are the same
+def test_time_blended_wind_packs_change_rounding_only(built, name, kw):
+    """With fpx_config.blend_mode = 1 (automatic: from 3e7 particles of the whole run on) the step first blends the wind pack in time -- the weights are the same
     for every particle -- and the gathers that need no standard deviations (interpol_wind_short, and interpol_wind when the
     mesoscale term is off) read half the bytes: (y1*dt2 + y2*dt1)*dtt is then taken before the horizontal and vertical sums
     instead of after.  Forced on here: the results stay within the parity tolerance of the oracle and within rounding of the
     unblended engine."""
     from flexpart_amd.engine import Engine, RNG_TABLE_SEQ
     sc = syn.small(n=4000, nx=60, ny=40, nz=40, nsteps=4, **kw)
-    monkeypatch.setenv("FPX_BLEND_MIN", "1")
-    got, want = run_pair(sc, "r8")
+    got, want = run_pair(sc, "r8", blend_mode=1)
     for g, w in zip(got, want):
         assert_close(g, w, 1e-9, 1e-7)
-    monkeypatch.setenv("FPX_BLEND_MIN", "0")
-    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ)
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_TABLE_SEQ, blend_mode=2)
     plain = eng.run(4)
+    assert eng.info("blended_steps") == 0 and eng.info("time_blended_packs") == 0
     eng.close()
     changed = 0.0
     for g, p in zip(got, plain):
@@ -93,6 +92,40 @@ def test_time_blended_wind_packs_change_rounding_only(built, monkeypatch, name, 
             assert np.abs(g[k] - p[k]).max() <= 1e-11 * max(np.abs(p[k]).max(), 1e-30), k
     if "above_pbl" in name:
         assert changed > 0.0          # the blended path did run (it rounds differently)
+
+
+@pytest.mark.parametrize("rb", [8, 4])
+@pytest.mark.parametrize("name,kw", [
+    ("cbl", dict(ctl=5.0, ifine=4, cblflag=1)),
+    ("hanna_backward", dict(ctl=5.0, ifine=4, ldirect=-1)),
+    ("aerosol", None),
+    ("nest", None),
+])
+def test_time_slices_do_not_change_a_bit(built, name, kw, rb):
+    """The Langevin kernel runs in time slices: a launch gives a particle a budget of passes, a particle that needs more is
+    suspended into its hand-over record and continues in the next launch (k_pbl_loop).  Budgets of 1, 2 and 5 passes -- so
+    that nearly every particle is suspended several times, on every path (CBL, Gaussian, settling + dry deposition, inside a
+    nest) -- give every array of the single-launch run bit for bit, in both counter-RNG modes and with the serial stream."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX, RNG_TABLE_SEQ
+    if kw is None:
+        from test_oracle_cpu import golden_scenario
+        sc = golden_scenario(name)
+    else:
+        sc = syn.small(n=3000, nx=40, ny=24, nz=30, nsteps=3, **kw)
+    keys = ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt", "xmass1")
+    for mode in (RNG_PHILOX, RNG_TABLE_SEQ):
+        ref = None
+        for slices in ("0", "1,2,5,0", "3,3,3,3,3,3,3,3,3,3,3,3,3,3,0"):
+            eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=mode, seed=77, options={"pbl_slices": slices})
+            out = eng.run(3)
+            assert eng.info("pbl_launches_per_step") == len(slices.split(","))
+            eng.close()
+            if ref is None:
+                ref = out
+                continue
+            for a, b in zip(ref, out):
+                for k in keys:
+                    assert np.array_equal(a[k], b[k]), (mode, slices, k)
 
 
 @pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "nest_wet", "sampling", "sampling_nest", "backward", "backward_cbl",
@@ -364,19 +397,18 @@ def test_config1_closed_form(built):
 
 @pytest.mark.parametrize("gather", ["direct", "staged"])
 @pytest.mark.parametrize("rb", [8, 4])
-def test_locality_sort_does_not_change_results(built, monkeypatch, gather, rb):
+def test_locality_sort_does_not_change_results(built, gather, rb):
     """Sorting permutes device slots only: particle numbering at the boundary and every
     result (table RNG is indexed by particle number) must be unchanged -- bitwise.  Both gathers of the re-sort
     (direct per array; through one 128-byte record per particle, chosen for permutations without locality), two
     species with different masses, and particles uploaded by number after a sort."""
     from flexpart_amd.engine import Engine
-    monkeypatch.setenv("FPX_PERMUTE", gather)
     sc = syn.small(n=3000, nx=40, ny=24, nz=30, nsteps=3, ctl=5.0, ifine=4, nspec=2)
     sc["xmass1"] = np.stack([np.linspace(1.0, 2.0, 3000), np.linspace(5.0, 3.0, 3000)])
     a = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb)
     ra = a.run()
     a.close()
-    b = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb)
+    b = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, options={"permute": gather})
     b.sort()
     b.step()
     b.sort()

@@ -231,10 +231,10 @@ def test_hip_verttransform_at_the_baseline_grid(built):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["r8", "r4"])
 @pytest.mark.parametrize("grid", ["global_polar", "limited_area", "baseline"])
-def test_fused_transform_keeps_every_bit_of_the_unfused_chain(built, monkeypatch, grid, kind):
+def test_fused_transform_keeps_every_bit_of_the_unfused_chain(built, grid, kind):
     """The fused kernels (k_vt_levels + k_vt_fused: one scratch array instead of six, rhoh / wzlev / pinmconv and the
     level indices recomputed in registers, the running indices of a wave's level range initialised by bisection)
-    against the five-kernel chain they replace (FPX_VT_UNFUSED=1): every output array identical bit for bit, on the
+    against the five-kernel chain they replace (fpx_set_option "vt_unfused"): every output array identical bit for bit, on the
     small grids (tiles cut by the grid edge, columns above their own top, polar caps) and on 361x181x138."""
     from flexpart_amd.engine import Engine, RNG_PHILOX
     kw = dict(nx=361, ny=181, nz=138, global_grid=True, polar=True) if grid == "baseline" else CASES[grid]
@@ -245,12 +245,12 @@ def test_fused_transform_keeps_every_bit_of_the_unfused_chain(built, monkeypatch
     rb = 8 if kind == "r8" else 4
     outs = []
     for unfused in ("1", "0"):
-        monkeypatch.setenv("FPX_VT_UNFUSED", unfused)
         sc = dict(syn.small(n=0, nx=nx, ny=ny, nz=nz, nsteps=1), grid=m["grid"], geom=m["geom"], globalflags=m["globalflags"])
         sfc = {k: sc[k][0] for k in ("hmix", "ustar", "wstar", "oli", "tropopause")}
         for k in ("height", "nmixz", "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol", "hmix", "ustar", "wstar", "oli", "tropopause", "vdep"):
             sc.pop(k, None)
-        eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_PHILOX, pad=(0, 0, 0) if grid == "baseline" else (3, 2, 1))
+        eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_PHILOX, pad=(0, 0, 0) if grid == "baseline" else (3, 2, 1),
+                     options={"vt_unfused": unfused})
         outs.append(eng.verttransform(1, m, sfc, init=True))
         eng.close()
     for k in FIELDS:

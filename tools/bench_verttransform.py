@@ -47,7 +47,7 @@ def main():
     sfc = {k: sc[k][0] for k in ("hmix", "ustar", "wstar", "oli", "tropopause")}
     for k in ("height", "nmixz", "uu", "vv", "ww", "rho", "drhodz", "tt", "uupol", "vvpol", "hmix", "ustar", "wstar", "oli", "tropopause", "vdep"):
         sc.pop(k, None)
-    eng = Engine(sc, compute_real_bytes=a.real, host_real_bytes=a.real, rng_mode=RNG_PHILOX)
+    eng = Engine(sc, compute_real_bytes=a.real, host_real_bytes=a.real, rng_mode=RNG_PHILOX, options={"vt_unfused": os.environ.get("FPX_VT_UNFUSED", "0")})   # the tool reads the variable, the library reads none
     eng.verttransform(1, m, sfc, init=True, want=())          # warm-up, allocations, z levels
     dev, wall, wall_pinned = [], [], []
     for _ in range(a.reps):
