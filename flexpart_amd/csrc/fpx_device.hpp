@@ -409,6 +409,7 @@ struct View {
   // switches
   int ldirect, lsynctime, method, mintime, ifine, turbswitch, cblflag, mdomainfill, lsettling;
   int turboff, interpolhmix;     // com_mod.f90:777-778 as run-time switches (fpx_config)
+  int pbl_cost_buckets;          // work-list order: cost buckets below the stability class (k_prep; scheduling only)
   int nspec, drydep, drydepspec[kMaxSpec];
   R ctl, fine, d_trop, d_strat, turbmesoscale;
   R density[kMaxSpec], dquer[kMaxSpec], vsetaver[kMaxSpec], cunningham[kMaxSpec], decay[kMaxSpec];

@@ -57,10 +57,17 @@ constexpr int kBlock = 256;
 #ifndef FPX_LOOP_WAVES
 #define FPX_LOOP_WAVES 3   // waves per SIMD the Langevin kernel is register-budgeted for (<= 168 VGPRs)
 #endif
+#ifndef FPX_COST_BUCKETS
+#define FPX_COST_BUCKETS 1   // the work list orders each class by the expected number of passes, longest first (k_prep)
+#endif
 #ifndef FPX_SLICE_SCHEDULE
-#define FPX_SLICE_SCHEDULE 64, 64, 64, 0   // pass budgets of the successive launches of the Langevin kernel (time slices), 0 = none
+#define FPX_SLICE_SCHEDULE 0   // pass budgets of the successive launches of the Langevin kernel, 0 = none; one entry = ONE launch (measured best)
+#endif
+#ifndef FPX_DRAIN_LANES
+#define FPX_DRAIN_LANES 32   // a wave of a non-final launch whose list is used up hands its particles on when fewer lanes than this hold one
 #endif
 constexpr int kMaxNz = 512;
+constexpr unsigned char kKeyDone = 16, kKeyNotDue = 17;   // keys of the work-list sort (5 bits); 0..15: PBL particles, class-major (k_prep)
 
 // ---------------------------------------------------------------------------
 // field repacking kernels
@@ -529,9 +536,10 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
   {
     int due_key = itra1_in;
     asm volatile("" : "+v"(due_key), "+v"(ps.xt), "+v"(ps.yt), "+v"(ps.zt), "+v"(itramem), "+v"(pid));
-    if (due_key != itime) { pbl_flag[s] = 7; return; }    // timemanager.f90:537
+    if (due_key != itime) { pbl_flag[s] = kKeyNotDue; return; }    // timemanager.f90:537
   }
-  // key 7 = not due; 6 = due, finished in this kernel (above the PBL); 1..4 = PBL particle of that regime class.
+  // key kKeyNotDue = not due; kKeyDone = due, finished in this kernel (above the PBL); 4 (c - 1) + 0..3 = PBL particle of regime
+  // class c = 1..4, cost bucket 3..0 (see below).
   // The counts (particles due, length of the PBL work list) are read off the sorted keys by
   // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
 
@@ -539,7 +547,7 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
   // would read arbitrary memory): terminate the particle instead
   if (!(ps.xt >= 0. && ps.xt <= (double)V.nxmin1 && ps.yt >= 0. && ps.yt <= (double)V.nymin1) || !(ps.zt == ps.zt)) {
     P.itra1[s] = kDead;
-    pbl_flag[s] = 6;
+    pbl_flag[s] = kKeyDone;
     atomicAdd(&st->n_badpos, 1ull);
     return;
   }
@@ -600,14 +608,25 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     // of the cloud: the launch must not END on the CBL class, whose particles make the most passes; a cursor per class
     // with the waves dealt to the classes by their work -- 46.7 ms at an eighth: every class then ends at the end of the
     // launch; a cost bucket (octaves of (ustar+wstar)/h) below the class in the key: no measurable change)
-    pbl_flag[s] = cls;
+    // Below the class: a cost bucket, the most expensive first.  The number of passes a particle makes is about |lsynctime| /
+    // (its time step); its last time step of the previous step (idt) predicts that well where the time step is set by the
+    // cell (ust, ol, h: the stable class keeps one value for the whole step).  With the long particles of a class at the head
+    // of its segment, what the waves still hold when the cursor leaves the class -- and at the end of the launch -- are short
+    // particles: less of the launch runs with half-empty or two-class waves.  Each bucket stays in slot (= cell) order.
+    unsigned char bucket = 0;
+    if (V.pbl_cost_buckets) {
+      const int idt = is_new ? ps.ldt : P.idt[s];
+      const int est = abs(V.lsynctime) / max(idt, 1);          // passes, if the time step stayed
+      bucket = est >= 128 ? 3 : est >= 64 ? 2 : est >= 32 ? 1 : 0;
+    }
+    pbl_flag[s] = (unsigned char)((cls - 1) * 4 + (3 - bucket));
     return;
   }
   // Above the mixing layer for the whole step (advance.f90:629-708 -> 99): wp and ldt are set, not read; up, vp and cbt
   // are not touched; the mesoscale velocities are fetched with the last column of the 48-value gather (same round
   // trip, not live across the gather: the asm ties the loads to that point of the program).
   R usig, vsig, wsig;
-  pbl_flag[s] = 6;
+  pbl_flag[s] = kKeyDone;
   auto late = [&]() {
     if (!is_new) {
       asm volatile("" : "+v"(s));
@@ -1168,12 +1187,25 @@ __global__ void __launch_bounds__(256) k_count_live(const int *__restrict__ itra
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
 }
-__global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, long long n, unsigned int *__restrict__ pbl_count, Stats *st) {
+// Counters of the step's work list (unsigned ints, zeroed at the start of every step):
+//   [0]     length of the whole list (all PBL particles; k_pbl_finish)
+//   [1..4]  first entry of the segment of stability class 1..4 (the list is sorted by class)
+//   [kCtrBase + 8 j + c], c = 0..3: launch j of the Langevin kernel: particles of class c + 1 in its list (they sit at the
+//           head of the class's segment); [kCtrBase + 8 j + 4 + c]: the chunk cursor of that class
+constexpr int kMaxSlices = 16, kCtrBase = 8, kCtrWords = kCtrBase + (kMaxSlices + 1) * 8;
+__global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, long long n, unsigned int *__restrict__ ctr, Stats *st) {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
-  const long long npbl = count_le_sorted(sorted_keys, 0, n, 4);
-  const long long ndue = count_le_sorted(sorted_keys, npbl, n, 6);
+  long long upto[5];
+  upto[0] = 0;
+  for (int c = 1; c <= 4; c++) upto[c] = count_le_sorted(sorted_keys, upto[c - 1], n, (unsigned char)(4 * c - 1));
+  const long long npbl = upto[4];
+  const long long ndue = count_le_sorted(sorted_keys, npbl, n, kKeyDone);
   if (threadIdx.x == 0) {
-    *pbl_count = (unsigned int)npbl;
+    ctr[0] = (unsigned int)npbl;
+    for (int c = 1; c <= 4; c++) {
+      ctr[c] = (unsigned int)upto[c - 1];
+      ctr[kCtrBase + c - 1] = (unsigned int)(upto[c] - upto[c - 1]);
+    }
     st->n_due += (unsigned long long)ndue;
   }
 }
@@ -1183,27 +1215,40 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
 // where all lanes are active.
 // LEAN: no dry deposition, no settling (gases).  TSW / CBLF / RNGM: see pbl_pass.
 //
-// Time slices (cap_passes > 0): a lane gives its particle at most cap_passes passes in this launch.  A particle that needs
-// more is SUSPENDED: its state goes into its hand-over record (state PBL_CONTINUE) and its slot is appended to next_list
-// (one atomic per wave and pass in which lanes suspend); the host launches the kernel again on that list.  The particles
-// with hundreds of passes (a 2 s time step for the whole 900 s; the median is about 30 passes) are then shared by all waves
-// of the next launch instead of keeping the last waves of this one alive with a lane or two each; and the particles a wave
-// holds at any moment come from a narrower window of the class- and cell-sorted list.  A particle's random numbers are
-// keyed on (particle number, step, draw index) and the draw index travels in the record: the slicing does not change a bit
-// of the result (tests/test_gpu_parity.py::test_time_slices_do_not_change_a_bit).
+// The kernel runs as a short sequence of launches per step (Engine::step).  A lane can SUSPEND its particle between two
+// passes: the state goes into the particle's hand-over record (state PBL_CONTINUE) and the slot is appended to the next
+// launch's list, class by class (one atomic per wave and event); the next launch continues it.  Three rules, all decided
+// per wave:
+//  * class purity: the list is sorted by stability class, every class has a chunk cursor of its own and a wave draws from
+//    ONE class at a time.  When that class has no chunk left the wave runs on with what it holds, without refilling,
+//    until fewer than drain_lanes lanes are busy, suspends those particles and moves to the next class with all lanes
+//    free -- so the lanes of a wave always run ONE branch of hanna_short / cbl (before: for up to 300 passes after the
+//    cursor had crossed a class boundary the waves ran both classes' code for the sake of a few long-lived particles:
+//    12 % of the hanna_short and 7 % of the CBL sub-steps at 1.25e7 particles);
+//  * drain: the same rule after the last class -- the wave hands its last particles on and ends; the next launch packs
+//    the leftovers of all waves densely (before: the last tenth of a launch ran with waves of a lane or two);
+//  * pass budget (cap_passes > 0, optional): at most cap_passes passes per particle and launch.
+// The last launch of the sequence has no next list (drain_lanes = 0, cap_passes = 0): it runs everything to the end.
+// A particle's random numbers are keyed on (particle number, step, draw index) and the draw index travels in the record:
+// suspending does not change a bit of the result (tests/test_gpu_parity.py::test_time_slices_do_not_change_a_bit).
 template <typename R, bool LEAN, int TSW, int CBLF, int RNGM>
 __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                      const unsigned int *__restrict__ pbl_list,
-                                                     const unsigned int *__restrict__ pbl_count,
-                                                     unsigned int *__restrict__ cursor,
-                                                     int cap_passes,
-                                                     unsigned int *__restrict__ next_list,
-                                                     unsigned int *__restrict__ next_count) {
-  const unsigned int nlist = *pbl_count;
-  // A short list (the later time slices): only as many blocks as it fills take part, so that its waves are spread over the
+                                                     unsigned int *__restrict__ ctr,
+                                                     int launch,
+                                                     int cap_passes, int drain_lanes,
+                                                     unsigned int *__restrict__ next_list) {
+  // this launch's list: per class c the first ncls[c] entries of the class's segment [coff[c], ...) of pbl_list
+  const unsigned int *mine = ctr + kCtrBase + 8 * launch;
+  unsigned int *cursor = ctr + kCtrBase + 8 * launch + 4;   // one per class
+  unsigned int *next_cnt = ctr + kCtrBase + 8 * (launch + 1);
+  const unsigned int n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
+  const unsigned int o0 = ctr[1], o1 = ctr[2], o2 = ctr[3], o3 = ctr[4];
+  // A short list (the later launches): only as many blocks as it fills take part, so that its waves are spread over the
   // CUs one block each instead of three to a SIMD on some and none on others (a pass of a wave alone on its SIMD takes a
   // third of the time).
-  if ((unsigned long long)blockIdx.x * kBlock >= nlist) return;
+  if ((unsigned long long)blockIdx.x * kBlock >= (unsigned long long)n0 + n1 + n2 + n3) return;
+  const bool can_suspend = drain_lanes > 0 || cap_passes > 0;
   // dynamic LDS: [S_COUNT][kBlock] stash (per-lane pass-level state, see Stash) + the height column,
   // sized by the host (loop_smem_bytes) so that three blocks fit one CU for the usual nz
   extern __shared__ __align__(16) unsigned char fpx_loop_smem[];
@@ -1228,11 +1273,13 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   // 64 entries per claim: with larger chunks (nlist/(8*nwaves) = 2000 entries at 1e8 was tried first) the kernel
   // ended half a chunk's worth of work -- tens of milliseconds -- after the list ran out, most waves idle;
   // measured 429 -> 395 ms.  One atomic per 64 refills is still negligible.
-  const unsigned int chunk = 64u;
+  const unsigned int k0 = (n0 + 63u) >> 6, k1 = (n1 + 63u) >> 6, k2 = (n2 + 63u) >> 6, k3 = (n3 + 63u) >> 6;   // chunks per class
   unsigned int cur = 0, end = 0;     // wave-uniform: the unread part of the wave's chunk
   unsigned int cbase = 0;            // wave-uniform: first entry of the chunk
   unsigned int ahead = 0;            // lane l: entry cbase + l of the list (the whole chunk, read with the claim)
   bool out_of_chunks = false;        // wave-uniform
+  int wcls = 0;                      // wave-uniform: class (0..3) the wave draws its particles from
+  bool cls_out = false;              // wave-uniform: that class has no chunk left
 #ifdef FPX_LANE_STATS
   const unsigned long long t_s = wall_clock64();   // 100 MHz; timeline of the wave: start, list exhausted, end
   unsigned long long t_x = 0;
@@ -1246,27 +1293,71 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   short icbt = 1;
   LoopCtx<R> A;
 
+  // the lanes of `who` (all of them hold a particle) hand their particles on: record written, slot appended to the next
+  // launch's list in the segment of the wave's class
+  auto write_record = [&](int state, int indz) {
+    PblRecord<R> *rp = Q.rec + s;
+    rp->v[0] = S.get(S_DX); rp->v[1] = S.get(S_DY); rp->v[2] = S.get(S_DAW); rp->v[3] = S.get(S_DCW);
+    rp->v[4] = zt; rp->v[5] = S.get(S_UP); rp->v[6] = S.get(S_VP); rp->v[7] = wp;
+    if (state == PBL_CONTINUE) {
+      rp->v[8] = S.get(S_UST);      // hanna.f90:43 may have floored it; v[9..12] stay as k_prep wrote them
+    } else {
+      rp->v[8] = S.get(S_U); rp->v[9] = S.get(S_V); rp->v[10] = S.get(S_W);
+    }
+    rp->i[0] = A.nrand; rp->i[1] = ldt;
+    rp->i[2] = pbl_pack(state, icbt, indz, A.ngrid, abs(A.itimec - itime));
+    if (!LEAN && V.drydep) Q.tdep[s] = S.get(S_TDEP);
+  };
+  auto suspend = [&](bool mine_goes) {   // convergent: every lane of the wave calls it
+    const unsigned long long sm = __ballot(mine_goes);
+    if (sm == 0ull) return;
+    if (mine_goes) { write_record(PBL_CONTINUE, 1); have = false; }
+    unsigned int base = 0;
+    if (lane == 0) base = atomicAdd(next_cnt + wcls, (unsigned int)__popcll(sm));
+    base = __builtin_amdgcn_readfirstlane(base);
+    const unsigned int seg = wcls == 0 ? o0 : wcls == 1 ? o1 : wcls == 2 ? o2 : o3;
+    if (mine_goes) next_list[seg + base + (unsigned int)__popcll(sm & ((1ull << lane) - 1ull))] = s;
+  };
+
   for (;;) {
     FPX_LANES(st, 10);
-    const unsigned long long need = __ballot(!have);
+    unsigned long long need = __ballot(!have);
     if (need != 0ull && !out_of_chunks) {
-      if (cur >= end) {   // wave-uniform: take the next chunk
-        unsigned int c = 0;
-        if (lane == 0) c = atomicAdd(cursor, 1u);
-        c = __builtin_amdgcn_readfirstlane(c);
-        const unsigned long long c0 = (unsigned long long)c * chunk;
-        if (c0 >= nlist) {
+      while (cur >= end && !out_of_chunks) {   // wave-uniform: take the next chunk of the wave's class
+        const unsigned int kk = wcls == 0 ? k0 : wcls == 1 ? k1 : wcls == 2 ? k2 : k3;
+        if (!cls_out) {
+          unsigned int c = 0;
+          if (lane == 0) c = atomicAdd(cursor + wcls, 1u);
+          c = __builtin_amdgcn_readfirstlane(c);
+          if (c < kk) {
+            const unsigned int seg = wcls == 0 ? o0 : wcls == 1 ? o1 : wcls == 2 ? o2 : o3;
+            const unsigned int nseg = wcls == 0 ? n0 : wcls == 1 ? n1 : wcls == 2 ? n2 : n3;
+            cur = cbase = seg + c * 64u;
+            end = min(cur + 64u, seg + nseg);
+            ahead = pbl_list[min(cbase + (unsigned int)lane, end - 1u)];
+            break;
+          }
+          cls_out = true;
+        }
+        // The wave's class has no chunk left.  A launch that can hand particles on keeps the wave on what it holds -- no
+        // refill, so no second class in the wave -- until fewer than drain_lanes lanes are busy, then suspends those and
+        // moves on to the next class with all lanes free; the last launch moves on at once (and mixes).
+        if (can_suspend) {
+          const int live = __popcll(__ballot(have));
+          if (live > 0 && live >= drain_lanes) break;
+          suspend(have);
+          need = ~0ull;
+        }
+        wcls++;
+        cls_out = false;
+        if (wcls == 4) {
           out_of_chunks = true;
 #ifdef FPX_LANE_STATS
           t_x = wall_clock64();
 #endif
-        } else {
-          cur = cbase = (unsigned int)c0;
-          end = min(cur + chunk, nlist);
-          ahead = pbl_list[min(cbase + (unsigned int)lane, nlist - 1u)];
         }
       }
-      if (!out_of_chunks) {
+      if (cur < end) {
         // A refill is ONE memory round trip: the list entry comes from the chunk read above (cross-lane), everything else
         // depends on the slot only and is requested together -- grid and mixing height travel in the record k_prep wrote.
         // (Before: list entry -> state -> mixing height -> six stash values one after the other = nine dependent round
@@ -1324,7 +1415,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
       if (out_of_chunks) break;   // no lane has work and the list is used up: the grid drains
       continue;                   // chunk ran dry mid-refill: take the next one
     }
-    bool suspend = false;
+    bool over_budget = false;
     if (have) {
       Rng<R, RNGM> G;
       make_rng(V, pid, step, G);
@@ -1332,37 +1423,15 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
       const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, icbt, A, S, indz, st);
       const R npass = S.get(S_NPASS) + (R)1;
       S.put(S_NPASS, npass);
-      suspend = rc == PBL_CONTINUE && npass >= cap_r;
-      if (rc != PBL_CONTINUE || suspend) {
+      if (rc != PBL_CONTINUE) {
         FPX_LANES(st, 9);
-        {
-          // the particle's state at the end of this pass goes into its hand-over record: one contiguous line;
-          // k_pbl_finish writes the particle arrays from it -- or a later launch continues from it
-          PblRecord<R> *rp = Q.rec + s;
-          rp->v[0] = S.get(S_DX); rp->v[1] = S.get(S_DY); rp->v[2] = S.get(S_DAW); rp->v[3] = S.get(S_DCW);
-          rp->v[4] = zt; rp->v[5] = S.get(S_UP); rp->v[6] = S.get(S_VP); rp->v[7] = wp;
-          if (suspend) {
-            rp->v[8] = S.get(S_UST);      // hanna.f90:43 may have floored it; v[9..12] stay as k_prep wrote them
-          } else {
-            rp->v[8] = S.get(S_U); rp->v[9] = S.get(S_V); rp->v[10] = S.get(S_W);
-          }
-          rp->i[0] = A.nrand; rp->i[1] = ldt;
-          rp->i[2] = pbl_pack(rc, icbt, indz, A.ngrid, abs(A.itimec - itime));
-        }
-        if (!LEAN && V.drydep) Q.tdep[s] = S.get(S_TDEP);
+        // the particle's state at the end of its last pass goes into its hand-over record: one contiguous line;
+        // k_pbl_finish writes the particle arrays from it
+        write_record(rc, indz);
         have = false;
-      }
+      } else over_budget = npass >= cap_r;
     }
-    if (cap_passes > 0) {
-      // the suspended particles of this pass, appended to the next launch's list: one atomic per wave
-      const unsigned long long sm = __ballot(suspend);
-      if (sm != 0ull) {
-        unsigned int base = 0;
-        if (lane == 0) base = atomicAdd(next_count, (unsigned int)__popcll(sm));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (suspend) next_list[base + (unsigned int)__popcll(sm & ((1ull << lane) - 1ull))] = s;
-      }
-    }
+    if (cap_passes > 0) suspend(over_budget);
   }
 #ifdef FPX_LANE_STATS
   if (lane == 0) {
@@ -1404,15 +1473,18 @@ __global__ void k_math_probe(int fn, const double *__restrict__ x, double *__res
 // mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
 template <typename R, bool DRYDEP, bool POLAR, bool NEST>
 __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
-                                                       const unsigned int *__restrict__ pbl_list,
-                                                       const unsigned int *__restrict__ pbl_count) {
+                                                       const unsigned char *__restrict__ pbl_key, long long numpart) {
+  // In SLOT order (every slot whose key of this step says "boundary layer"), not in the order of the work list: the list is
+  // grouped by class and cost bucket -- sixteen interleaved sub-sequences of the cell-sorted slots -- and following it cost
+  // this kernel half of its time again in scattered record and state accesses (0.58 -> 0.87 ms at 1.25e7 particles).  After
+  // a locality sort the boundary-layer particles of a column are consecutive slots, so the waves stay nearly full.
   constexpr bool MOTHER = !POLAR && !NEST;
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
-  const unsigned int nlist = *pbl_count;
-  for (unsigned int i = blockIdx.x * blockDim.x + threadIdx.x; i < nlist; i += gridDim.x * blockDim.x) {
-    const unsigned int s = pbl_list[i];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numpart; i += (long long)gridDim.x * blockDim.x) {
+    if (pbl_key[i] >= kKeyDone) continue;
+    const unsigned int s = (unsigned int)i;
     const PblRecord<R> rec = Q.rec[s];
     const R tdep = DRYDEP ? Q.tdep[s] : (R)0;
     const int pk = rec.i[2];
@@ -1777,15 +1849,16 @@ struct Engine : EngineBase {
   size_t sort_tmp_bytes = 0;
   Stats *d_stats = nullptr;
   unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[2j] = length of the list of time slice j, ctr[2j+1] = its chunk cursor
-  static constexpr int kMaxSlices = 16;
   unsigned int *d_surv[2] = {nullptr, nullptr};               // lists of the suspended particles (ping-pong between launches), allocated with the first sliced step
   std::vector<int> slice_caps;                                // pass budget of each launch of the Langevin kernel, the last one 0 (none)
   struct Options {                                            // fpx_set_option
     int verbose = 0, pbl_blocks_per_cu = 0, prep_lds_pad = 0, permute = 0 /* 0 auto, 1 direct, 2 staged */, vt_unfused = 0;
     long conv_scratch_mb = 0;
     int conv_one_lane = 0, conv_no_walk = 0, conv_rows_plain = 0;
+    int pbl_drain_lanes = -1;                     // -1: the engine's default (FPX_DRAIN_LANES)
     std::vector<int> pbl_slices;
   } opt;
+  int drain_lanes() const { return opt.pbl_drain_lanes >= 0 ? opt.pbl_drain_lanes : FPX_DRAIN_LANES; }
   unsigned char *d_pbl_flag = nullptr, *d_pbl_flag2 = nullptr;
   unsigned int *d_iota = nullptr;
   PblRec<R> Q;
@@ -1889,6 +1962,7 @@ struct Engine : EngineBase {
     V.ifine = cfg.ifine; V.turbswitch = cfg.turbswitch; V.cblflag = cfg.cblflag; V.mdomainfill = cfg.mdomainfill;
     V.lsettling = cfg.lsettling; V.nspec = cfg.nspec; V.drydep = cfg.drydep;
     V.turboff = cfg.turboff != 0; V.interpolhmix = cfg.interpolhmix != 0;
+    V.pbl_cost_buckets = FPX_COST_BUCKETS;
     V.ctl = (R)cfg.ctl; V.fine = (R)1. / (R)cfg.ifine;   // readcommand.f90:271
     V.d_trop = (R)cfg.d_trop; V.d_strat = (R)cfg.d_strat; V.turbmesoscale = (R)cfg.turbmesoscale;
     for (int i = 0; i < FPX_MAXSPEC; i++) {
@@ -1948,7 +2022,7 @@ struct Engine : EngineBase {
     }
     if ((rc = dalloc(&P.pid, cap))) return rc;
     if ((rc = dalloc(&d_pbl_list, cap))) return rc;
-    if ((rc = dalloc(&d_pbl_ctr, 2 * kMaxSlices))) return rc;
+    if ((rc = dalloc(&d_pbl_ctr, kCtrWords))) return rc;
     if ((rc = dalloc(&d_pbl_flag, cap))) return rc;
     if ((rc = dalloc(&d_pbl_flag2, cap))) return rc;
     if ((rc = dalloc(&d_iota, cap))) return rc;
@@ -4259,14 +4333,14 @@ struct Engine : EngineBase {
     }
     {
       size_t need = 0;
-      HIPCHK(rocprim::radix_sort_pairs(nullptr, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 3u, stream));
+      HIPCHK(rocprim::radix_sort_pairs(nullptr, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 5u, stream));
       if (need > sel_tmp_bytes) {
         if (d_sel_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_sel_tmp)); d_sel_tmp = nullptr; }
         HIPCHK(hipMalloc(&d_sel_tmp, need));
         sel_tmp_bytes = need;
       }
     }
-    HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, 2 * kMaxSlices * sizeof(unsigned int), stream));
+    HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, kCtrWords * sizeof(unsigned int), stream));
     { const int rc = blend_winds(itime); if (rc) return rc; }      // its own kernel (k_blend_w3), ahead of the per-kernel events
     HIPCHK(hipEventRecord(ev.e[0], stream));
     if (P.xscav) {   // timemanager.f90:564-598, before the particle is moved
@@ -4288,37 +4362,41 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipEventRecord(ev.e[4], stream));
     {
-      // work list = slots stably sorted by the 3-bit regime key (non-PBL slots, key 7, end up behind
-      // the d_pbl_ctr[0] entries that are used)
+      // work list = slots stably sorted by the 5-bit key of k_prep: class, cost bucket (non-PBL slots, keys 16 and 17, end
+      // up behind the d_pbl_ctr[0] entries that are used)
       size_t need = sel_tmp_bytes;
-      HIPCHK(rocprim::radix_sort_pairs(d_sel_tmp, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 3u, stream));
+      HIPCHK(rocprim::radix_sort_pairs(d_sel_tmp, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 5u, stream));
       k_list_counts<<<1, 64, 0, stream>>>(d_pbl_flag2, numpart, d_pbl_ctr, d_stats);
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
     HIPCHK(hipEventRecord(ev.e[1], stream));
     for (size_t j = 0; j < slice_caps.size(); j++) {
-      // launch j works through the particles launch j-1 suspended (ctr[2j] = list length, written by that launch's appends;
-      // ctr[2j+1] = chunk cursor); a launch whose list is empty ends at once
+      // launch j works through the particles launch j-1 suspended (k_pbl_loop); a launch whose list is empty ends at once;
+      // the last launch suspends nothing
+      const bool last = j + 1 == slice_caps.size();
       const unsigned int *list = j == 0 ? d_pbl_list : d_surv[(j - 1) & 1];
-      loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, list, d_pbl_ctr + 2 * j, d_pbl_ctr + 2 * j + 1,
-                                                                     slice_caps[j], d_surv[j & 1], d_pbl_ctr + 2 * (j + 1));
+      loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, list, d_pbl_ctr, (int)j, last ? 0 : slice_caps[j],
+                                                                     last ? 0 : drain_lanes(), d_surv[j & 1]);
     }
     HIPCHK(hipEventRecord(ev.e[2], stream));
     {
       const bool polar = cfg.nglobal || cfg.sglobal, nest = V.numbnests > 0;
-      typedef void (*fin_fn)(View<R>, GridP<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *);
+      typedef void (*fin_fn)(View<R>, GridP<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned char *, long long);
       const fin_fn f = (fin_fn)step_kernel_finish((int)sizeof(R), cfg.drydep != 0, polar, nest);
-      f<<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_list, d_pbl_ctr);
+      f<<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_flag, numpart);
     }
     HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
     V.w3t0 = nullptr; V.w3t1 = nullptr; V.r2t0 = nullptr;      // the blended packs belong to this step's itime only
-    if (opt.verbose > 1) {   // the lists of the time slices (a synchronisation per step: diagnostics only)
-      unsigned int hc[2 * kMaxSlices];
+    if (opt.verbose > 1) {   // the lists of the launches (a synchronisation per step: diagnostics only)
+      unsigned int hc[kCtrWords];
       HIPCHK(hipMemcpyAsync(hc, d_pbl_ctr, sizeof(hc), hipMemcpyDeviceToHost, stream));
       HIPCHK(hipStreamSynchronize(stream));
-      fprintf(stderr, "[fpx] step %u: Langevin lists", step_counter);
-      for (size_t j = 0; j < slice_caps.size(); j++) fprintf(stderr, " %u(cap %d)", hc[2 * j], slice_caps[j]);
+      fprintf(stderr, "[fpx] step %u: Langevin lists (per class)", step_counter);
+      for (size_t j = 0; j < slice_caps.size(); j++) {
+        const unsigned int *m = hc + kCtrBase + 8 * j;
+        fprintf(stderr, " | %u %u %u %u", m[0], m[1], m[2], m[3]);
+      }
       fprintf(stderr, "\n");
     }
     step_counter++;
@@ -4366,6 +4444,8 @@ struct Engine : EngineBase {
     if (n == "conv_one_lane") { if (!need_int(0)) goto bad; opt.conv_one_lane = iv != 0; return 0; }
     if (n == "conv_no_walk") { if (!need_int(0)) goto bad; opt.conv_no_walk = iv != 0; return 0; }
     if (n == "conv_rows_plain") { if (!need_int(0)) goto bad; opt.conv_rows_plain = iv != 0; return 0; }
+    if (n == "pbl_cost_buckets") { if (!need_int(0)) goto bad; V.pbl_cost_buckets = iv != 0; return 0; }
+    if (n == "pbl_drain_lanes") { if (!is_int || iv < -1 || iv > 64) goto bad; opt.pbl_drain_lanes = (int)iv; return 0; }
     if (n == "permute") {
       if (v == "auto") opt.permute = 0; else if (v == "direct") opt.permute = 1; else if (v == "staged") opt.permute = 2; else goto bad;
       return 0;
@@ -4414,7 +4494,7 @@ struct Engine : EngineBase {
   }
 
   // the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
-  typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, const unsigned int *, unsigned int *, int, unsigned int *, unsigned int *);
+  typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, unsigned int *, int, int, int, unsigned int *);
   size_t loop_smem_bytes() const { return sizeof(R) * ((size_t)S_COUNT * kStashStride + (size_t)cfg.nz); }
   loop_fn loop_kernel() const {
     return (loop_fn)step_kernel_loop((int)sizeof(R), !cfg.drydep && !cfg.lsettling, cfg.turbswitch, cfg.cblflag, cfg.rng_mode);

@@ -105,7 +105,9 @@ def test_time_slices_do_not_change_a_bit(built, name, kw, rb):
     """The Langevin kernel runs in time slices: a launch gives a particle a budget of passes, a particle that needs more is
     suspended into its hand-over record and continues in the next launch (k_pbl_loop).  Budgets of 1, 2 and 5 passes -- so
     that nearly every particle is suspended several times, on every path (CBL, Gaussian, settling + dry deposition, inside a
-    nest) -- give every array of the single-launch run bit for bit, in both counter-RNG modes and with the serial stream."""
+    nest) -- give every array of the single-launch run bit for bit, in the counter-RNG mode and with the serial stream; so do the
+    two other reasons to suspend: a wave that moves on to another stability class, and a wave that is down to fewer than
+    "pbl_drain_lanes" particles when the list is used up (64: every wave hands everything on as soon as the list is empty)."""
     from flexpart_amd.engine import Engine, RNG_PHILOX, RNG_TABLE_SEQ
     if kw is None:
         from test_oracle_cpu import golden_scenario
@@ -115,8 +117,9 @@ def test_time_slices_do_not_change_a_bit(built, name, kw, rb):
     keys = ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt", "xmass1")
     for mode in (RNG_PHILOX, RNG_TABLE_SEQ):
         ref = None
-        for slices in ("0", "1,2,5,0", "3,3,3,3,3,3,3,3,3,3,3,3,3,3,0"):
-            eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=mode, seed=77, options={"pbl_slices": slices})
+        for slices, drain in (("0", 0), ("0,0,0", 32), ("0,0,0,0,0", 64), ("1,2,5,0", 0), ("3,3,3,3,3,3,3,3,3,3,3,3,3,3,0", 48), ("2,7,0", 16)):
+            eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=mode, seed=77,
+                         options={"pbl_slices": slices, "pbl_drain_lanes": drain})
             out = eng.run(3)
             assert eng.info("pbl_launches_per_step") == len(slices.split(","))
             eng.close()
