@@ -3171,8 +3171,11 @@ struct Engine : EngineBase {
     const size_t need = redist_bytes(num_trans);
     if (!buf || buf_bytes < need) return fail(FPX_ERR_ARG, "redist_pack: buffer smaller than fpx_redist_bytes(num_trans)");
     if (redist_stage(need)) return fail(FPX_ERR_NOMEM, "redist_pack: staging buffer");
-    numpart = *numpart_io;
+    // first back into particle-number order over the extent the engine itself holds (the extent of the last locality sort:
+    // its slots are a permutation of exactly those numbers), then the host's count -- as set_numpart does; the other order
+    // would sort a range whose numbers are not a permutation and lose live particles
     { const int rc = restore_particle_order(); if (rc) return rc; }   // numpart shrinks below
+    numpart = *numpart_io;
     const RedistBuf<R> B = RedistBuf<R>::at(redist_dev, num_trans, cfg.nspec);
     k_redist_pack<R><<<(int)((num_trans + kBlock - 1) / kBlock), kBlock, 0, stream>>>(P, slot_map(), numpart - num_trans, B, cfg.nspec);
     hipError_t e = hipGetLastError();

@@ -656,7 +656,7 @@ class Engine:
         for i, v in enumerate(lage):
             g.lage[i] = int(v)
         g.ind_samp, g.ioutputforeachrelease = (int(v) for v in sc["concflags"])
-        g.lusekerneloutput = 1
+        g.lusekerneloutput = int(sc.get("lusekerneloutput", 1))   # par_mod.f90:39 (a compile-time switch of the host)
         oh = np.ascontiguousarray(np.asarray(sc["outheight"]).astype(rt))
         check(self.lib.fpx_outgrid_init(self.h, C.byref(g), _vp(oh)), "fpx_outgrid_init")
         if "outtimes" in sc:

@@ -1123,9 +1123,11 @@ contains
     role = int(r); peer = int(p); num_trans = int(nt)
   end subroutine flexgpu_redist_plan
 
-  integer function flexgpu_redist_bytes(num_trans)
+  ! bytes of the one message of num_trans particles: 64-bit (56 B per particle and more: a default integer overflows from
+  ! about 3.8e7 particles on)
+  integer(c_int64_t) function flexgpu_redist_bytes(num_trans)
     integer, intent(in) :: num_trans
-    flexgpu_redist_bytes = int(fpx_redist_bytes(flexgpu_handle, int(num_trans, c_int64_t)))
+    flexgpu_redist_bytes = fpx_redist_bytes(flexgpu_handle, int(num_trans, c_int64_t))
   end function flexgpu_redist_bytes
 
   ! the sending half of mpif_redist_part (:700-746): buf(1:flexgpu_redist_bytes(num_trans)) is the ONE message

@@ -40,10 +40,23 @@ build_one() {
       src="$REF/$m.f90"
       [ "$m" = "par_mod" ] && src="$REF/$parmod"
       [ "$obj/$m.o" -nt "$src" ] && continue
+      # compile-time parameters of the reference that a user changes by editing one line (class counts: FLEXREF_CLASSES;
+      # any other: FLEXREF_EDIT="module|text as shipped|replacement", e.g. "com_mod|turboff=.false.|turboff=.true."): the
+      # one assignment is rewritten in a pipe into the compiler's stdin -- no edited source is ever written anywhere
+      local edit=""
       if [ "$m" = "par_mod" ] && [ -n "${FLEXREF_CLASSES:-}" ]; then
         set -- $FLEXREF_CLASSES
         grep -q 'maxageclass=1,nclassunc=1$' "$src" || { echo "build_ref: par_mod has no 'maxageclass=1,nclassunc=1' line"; exit 1; }
-        sed "s/maxageclass=1,nclassunc=1\$/maxageclass=$1,nclassunc=$2/" "$src" | "$FC" -c -cpp -O2 -mcmodel=medium $flags -x f95-cpp-input - -o "$m.o"
+        edit="s/maxageclass=1,nclassunc=1\$/maxageclass=$1,nclassunc=$2/"
+      fi
+      if [ -n "${FLEXREF_EDIT:-}" ] && [ "${FLEXREF_EDIT%%|*}" = "$m" ]; then
+        local rest="${FLEXREF_EDIT#*|}"
+        local from="${rest%%|*}" to="${rest#*|}"
+        [ "$(grep -cF "$from" "$src")" = "1" ] || { echo "build_ref: $m has not exactly one '$from'"; exit 1; }
+        edit="s/$from/$to/"
+      fi
+      if [ -n "$edit" ]; then
+        sed "$edit" "$src" | "$FC" -c -cpp -O2 -mcmodel=medium $flags -x f95-cpp-input - -o "$m.o"
       else
         "$FC" -c -cpp -O2 -mcmodel=medium $flags "$src" -o "$m.o"
       fi
@@ -228,6 +241,14 @@ build_rel r4n -DFLEXREF_NESTS -DFLEXGPU_NESTS
 # several age classes / uncertainty classes (see build_one)
 FLEXREF_CLASSES="4 3" build_one r4c par_mod.f90
 FLEXREF_CLASSES="4 3" build_one r8c par_mod.f90 -fdefault-real-8
+# the reference's other compile-time switches of the path, one at a time (see build_one): turbulence off and the
+# time-interpolated mixing height (com_mod.f90:777-778), the output grid without the kernel (par_mod.f90:39)
+FLEXREF_EDIT="com_mod|turboff=.false.|turboff=.true." build_one r8t par_mod.f90 -fdefault-real-8
+FLEXREF_EDIT="com_mod|turboff=.false.|turboff=.true." build_one r4t par_mod.f90
+FLEXREF_EDIT="com_mod|interpolhmix=.false.|interpolhmix=.true." build_one r8h par_mod.f90 -fdefault-real-8
+FLEXREF_EDIT="com_mod|interpolhmix=.false.|interpolhmix=.true." build_one r4h par_mod.f90
+FLEXREF_EDIT="par_mod|lusekerneloutput=.true.|lusekerneloutput=.false." build_one r8k par_mod.f90 -fdefault-real-8
+FLEXREF_EDIT="par_mod|lusekerneloutput=.true.|lusekerneloutput=.false." build_one r4k par_mod.f90
 # ... the same compile-time sizes for the class mean of concoutput (mean_mod over nclassunc = 3) and for the uncertainty
 # class readpartpositions draws for every particle of a warm start (ran1, readpartpositions.f90:142-143)
 build_co r4c

@@ -112,6 +112,7 @@ typedef struct {
      are replaced by the particle's own values -- what an order-independent (parallel)
      engine computes; see DESIGN.md "deviations" D1/D2. */
   int parallel_semantics;
+  int turboff, interpolhmix;   /* com_mod.f90:777-778: compile-time logicals of the reference (both .false. as shipped) */
   /* optional bookkeeping for the tests (orc_set_leak_flags): which particles the two leaks touch.  flags[j] |= 1 when
      particle j takes advance.f90:550 (D1), |= 2 when initialize() runs for it with an ngrid left by its predecessor
      that selects the other wind arrays (polar vs. lat-lon) than the particle's own position would (D2). */
@@ -1174,16 +1175,23 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
   c->dtt = K(1.) / (c->dt1 + c->dt2);
   if (c->jyp >= (c->ngrid > 0 ? c->nyn[c->ngrid - 1] : c->ny)) c->jyp = c->jyp - 1;   /* :228-231 (compact layouts: the row count of the grid in use) */
 
-  /* :236-267, interpolhmix = .false. */
+  /* :236-267 */
   c->h = K(0.);
   if (c->ngrid <= 0) {
+    real h1[2] = {K(0.), K(0.)};
     for (k = 0; k < 2; k++) {
       int jj, ii;
       mind = c->memind[k];
-      for (jj = c->jy; jj <= c->jyp; jj++)
-        for (ii = c->ix; ii <= c->ixp; ii++)
-          if (F2(c->hmix, ii, jj, mind) > c->h) c->h = F2(c->hmix, ii, jj, mind);
+      if (c->interpolhmix) {   /* :240-244 */
+        h1[k] = c->p1 * F2(c->hmix, c->ix, c->jy, mind) + c->p2 * F2(c->hmix, c->ixp, c->jy, mind)
+              + c->p3 * F2(c->hmix, c->ix, c->jyp, mind) + c->p4 * F2(c->hmix, c->ixp, c->jyp, mind);
+      } else {
+        for (jj = c->jy; jj <= c->jyp; jj++)
+          for (ii = c->ix; ii <= c->ixp; ii++)
+            if (F2(c->hmix, ii, jj, mind) > c->h) c->h = F2(c->hmix, ii, jj, mind);
+      }
     }
+    if (c->interpolhmix) c->h = (h1[0] * c->dt2 + h1[1] * c->dt1) * c->dtt;   /* :266 (on the mother grid; h1 is unset inside a nest) */
     tropop = F2(c->tropopause, nix, njy, 1);
   } else {   /* :255-263 */
     const int l = c->ngrid;
@@ -1311,7 +1319,12 @@ static int orc_advance(orc_ctx *c, int itime, int nrelpoint, int *ldt, real *up,
         *wp = (rw * *wp + c->rannumb[nrand + i] * r_sqrt(K(1.) - rw * rw) * c->sigw + c->tlw * (K(1.) - rw) * (c->dsigw2dz + rhoaux * (c->sigw * c->sigw))) * (real)*icbt;
         delz = *wp * dtf;
       }
-      /* turboff = .false. (com_mod.f90:778) */
+      if (c->turboff) {   /* :464-470 */
+        *up = K(0.);
+        *vp = K(0.);
+        *wp = K(0.);
+        delz = K(0.);
+      }
 
       /* :476-491 */
       if (r_abs(delz) > c->h) delz = r_mod(delz, c->h);
@@ -1423,6 +1436,12 @@ L700:
     wpscale = r_sqrt(K(2.) * c->d_strat / dt);
     *wp = c->rannumb[nrand] * wpscale;
     nrand = nrand + 1;
+  }
+
+  if (c->turboff) {   /* :675-679 */
+    ux = K(0.);
+    vy = K(0.);
+    *wp = K(0.);
   }
 
   /* :686-699 */
@@ -2272,6 +2291,7 @@ void orc_set_nest(orc_ctx *c, int nxn, int nyn, double dxn, double dyn, double x
   c->vdepn[0] = vdepn;
 }
 void orc_set_parallel_semantics(orc_ctx *c, int on) { c->parallel_semantics = on; }
+void orc_set_com_parameters(orc_ctx *c, int turboff, int interpolhmix) { c->turboff = turboff; c->interpolhmix = interpolhmix; }
 void orc_set_leak_flags(orc_ctx *c, unsigned char *flags) { c->leak_flags = flags; }
 
 long orc_nan_count(orc_ctx *c, int which) { return which == 2 ? c->nan_count2 : c->nan_count; }

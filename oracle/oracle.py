@@ -80,6 +80,7 @@ class Oracle:
                              int(sc["lsettling"]), nspec, int(sc["drydep"]),
                              dds.ctypes.data_as(C.POINTER(C.c_int)), C.c_double(float(tp[0])),
                              C.c_double(float(tp[1])), C.c_double(float(tp[2])))
+        lib.orc_set_com_parameters(self.h, int(sc.get("turboff", 0)), int(sc.get("interpolhmix", 0)))   # com_mod.f90:777-778
         arrs = [_f64(sc[k]) for k in ("density", "dquer", "vsetaver", "cunningham", "decay")]
         lib.orc_set_species(self.h, *[a.ctypes.data_as(dp) for a in arrs],
                             int(np.asarray(sc["lage"]).ravel()[-1]), int(sc.get("mquasilag", 0)))
@@ -143,7 +144,7 @@ class Oracle:
             self.gshape = (len(lage), ncu, mps, nspec, nzg, nyg, nxg)   # (nage, nclassunc, maxpointspec, spec, z, y, x)
             lib.orc_set_outgrid(self.h, nxg, nyg, nzg, C.c_double(dxo), C.c_double(dyo), C.c_double(lon0),
                                 C.c_double(lat0), oh.ctypes.data_as(dp), mps, ncu, len(lage),
-                                lage.ctypes.data_as(C.POINTER(C.c_int)), ind_samp, iofr, 1, nspec)
+                                lage.ctypes.data_as(C.POINTER(C.c_int)), ind_samp, iofr, int(sc.get("lusekerneloutput", 1)), nspec)
             if "outtimes" in sc:
                 lib.orc_set_output_times(self.h, int(sc["outtimes"][0]), int(sc["outtimes"][1]))
             self.has_grid_nest = "outgridn" in sc

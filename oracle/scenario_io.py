@@ -35,6 +35,10 @@ _INT = {"grid", "globalflags", "nmixz", "memtime", "memind", "ldirect", "lsyncti
         "drybkdep", "wetbkdep"}
 
 
+# scenario key -> (value as shipped, suffix of the flang build with the other value: oracle/build_ref.sh)
+_COMPILED = {"turboff": (0, "t"), "interpolhmix": (0, "h"), "lusekerneloutput": (1, "k")}
+
+
 def write_scenario(path, sc):
     with open(path, "wb") as fh:
         for name in _ORDER:
@@ -50,7 +54,9 @@ def write_scenario(path, sc):
             fh.write(struct.pack("<16siq", name.encode().ljust(16), code, a.size))
             fh.write(a.tobytes())
         fh.write(struct.pack("<16siq", b"END".ljust(16), 1, 0))
-    unknown = set(sc) - set(_ORDER) - {"par_nxmax", "particle_base"}
+    # (turboff, interpolhmix, lusekerneloutput are compile-time parameters of the reference: not in the file, but the
+    # binary must be the variant built with them -- run_reference checks)
+    unknown = set(sc) - set(_ORDER) - {"par_nxmax", "particle_base"} - set(_COMPILED)
     if unknown:
         raise KeyError(f"scenario keys not understood by the reference driver: {sorted(unknown)}")
 
@@ -84,6 +90,10 @@ def have_ref(kind="r8"):
 def run_reference(sc, kind="r8", workdir="/tmp", timing=False, tag="scen", gpu=False):
     """Run the compiled reference on a scenario -> dict(steps=[{...}], rannumb=..., ...)."""
     os.makedirs(workdir, exist_ok=True)
+    for key, (shipped, suffix) in _COMPILED.items():
+        if (int(sc.get(key, shipped)) != shipped) != kind.endswith(suffix):
+            raise ValueError(f"scenario {key} = {sc.get(key, shipped)} needs the reference build "
+                             f"{'with' if int(sc.get(key, shipped)) != shipped else 'without'} suffix '{suffix}', not {kind}")
     fs = os.path.join(workdir, f"{tag}_{os.getpid()}.scen")
     fo = os.path.join(workdir, f"{tag}_{os.getpid()}.out")
     write_scenario(fs, sc)

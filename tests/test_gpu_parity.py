@@ -94,6 +94,43 @@ def test_time_blended_wind_packs_change_rounding_only(built, name, kw):
         assert changed > 0.0          # the blended path did run (it rounds differently)
 
 
+def test_blend_switch_does_not_depend_on_timing_or_restarts(built, tmp_path):
+    """The decision to blend the wind packs in time is a function of the configuration alone (round 3 read the length of an
+    earlier step's work list from pinned memory without synchronisation): two runs under fpx_step_async are bitwise equal,
+    every step of them blends from the first on, and a run continued from a checkpoint equals the uninterrupted one."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    sc = syn.small(n=20000, nx=60, ny=40, nz=40, nsteps=5, ctl=5.0, ifine=4, cblflag=1)
+    kw = dict(rng_mode=RNG_PHILOX, seed=31, global_particles=50_000_000)
+    keys = ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt")
+    runs = []
+    for _ in range(2):
+        eng = Engine(sc, **kw)
+        for _ in range(5):
+            eng.step_async()
+        eng.sync()
+        assert eng.info("time_blended_packs") == 1 and eng.info("blended_steps") == 5
+        runs.append(eng.download())
+        eng.close()
+    for k in keys:
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+    eng = Engine(sc, **kw)
+    for _ in range(2):
+        eng.step()
+    eng.checkpoint_write(tmp_path / "ck")
+    eng.close()
+    eng = Engine(sc, **kw)
+    eng.checkpoint_read(tmp_path / "ck")
+    for _ in range(3):
+        eng.step()
+    cont = eng.download()
+    eng.close()
+    for k in keys:
+        assert np.array_equal(cont[k], runs[0][k]), k
+    plain = Engine(sc, rng_mode=RNG_PHILOX, seed=31)          # 20000 particles in all: below the threshold, no blend
+    assert plain.info("time_blended_packs") == 0
+    plain.close()
+
+
 @pytest.mark.parametrize("rb", [8, 4])
 @pytest.mark.parametrize("name,kw", [
     ("cbl", dict(ctl=5.0, ifine=4, cblflag=1)),
@@ -133,7 +170,8 @@ def test_time_slices_do_not_change_a_bit(built, name, kw, rb):
 
 @pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "nest", "nest_wet", "sampling", "sampling_nest", "backward", "backward_cbl",
                                   "limited_area", "three_species", "multi_release", "age_classes",
-                                  "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep"])
+                                  "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep",
+                                  "turboff", "interpolhmix", "domainfill", "quasilag_step", "nokernel"])
 def test_fp64_matches_oracle_golden_scenarios(built, name):
     """The scenarios the golden fixtures were made on: polar caps through the stereographic maps
     (cmapf subset), an aerosol species with settling + dry deposition + decay, CBL, Hanna."""
@@ -148,7 +186,8 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
 
 @pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "nest_wet", "sampling",
                                   "sampling_nest", "backward", "backward_cbl", "limited_area", "three_species", "multi_release", "age_classes",
-                                  "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep"])
+                                  "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep",
+                                  "turboff", "interpolhmix", "domainfill", "quasilag_step", "nokernel"])
 def test_fp64_against_reference_fixtures(built, name):
     """HIP path directly against the outputs of the unmodified reference (tests/golden, flang r8 builds).  Only
     particles touched by the two order-dependent leaks of the serial code may differ, and WHICH
@@ -230,9 +269,12 @@ def test_backward_receptor_scavenging(built, name, kind):
 
 
 @pytest.mark.parametrize("kind", ["r8", "r4"])
-@pytest.mark.parametrize("name", ["multi_release", "age_classes"])
+@pytest.mark.parametrize("name", ["multi_release", "age_classes", "domainfill", "quasilag_step", "nokernel"])
 def test_release_points_age_classes_and_terminations(built, name, kind):
-    """Per-release-point xmass / npart in the mass-fraction termination (timemanager.f90:663-666,681-686) and in the
+    """domainfill / quasilag_step: the same cloud with mdomainfill = 1 (no settling, no mass-fraction test, nrelpointer = 1 in the
+    grids although ioutputforeachrelease = 1) and with mquasilag = 1 (no mass-fraction test); nokernel: the host built with
+    lusekerneloutput = .false. (par_mod.f90:39) -- every contribution into the particle's own cell, mother and nested grid.
+    Per-release-point xmass / npart in the mass-fraction termination (timemanager.f90:663-666,681-686) and in the
     settling species pick (advance.f90:518-531), the maximum-age termination (:701-707), and the trailing indices
     (species, release point, uncertainty class, age class) of gridunc / drygridunc / wetgridunc and their nested twins
     (conccalc.f90:54-58,140-143; drydepokernel, wetdepokernel) -- against the oracle, which reproduces the flang
@@ -252,7 +294,7 @@ def test_release_points_age_classes_and_terminations(built, name, kind):
         got.append(eng.download())
     g, d = eng.grids()
     w = eng.wetgrid()
-    gn = eng.grids_nest() if name == "age_classes" else None
+    gn = eng.grids_nest() if name in ("age_classes", "nokernel") else None
     eng.close()
     orc = Oracle(sc, kind)
     orc.lib.orc_set_parallel_semantics(orc.h, 1)
@@ -269,10 +311,13 @@ def test_release_points_age_classes_and_terminations(built, name, kind):
             assert_close(gs, ws, 2e-6, 5e-3, max_diverged=int(0.02 * n))
             assert (gs["itra1"] != ws["itra1"]).sum() <= 0.02 * n
     dead = [int((ws["itra1"] == -999999999).sum()) for ws in want]
-    assert dead[0] > 0 and dead[-1] > dead[0]
     kills = sum(s["n_min_mass"] + s["n_max_age"] + s["n_left_domain"] for s in stats)
     assert kills == int((got[-1]["itra1"] == -999999999).sum())
-    assert sum(s["n_max_age"] for s in stats) > 0
+    if name != "nokernel":
+        assert dead[0] > 0 and dead[-1] > dead[0]
+        assert sum(s["n_max_age"] for s in stats) > 0
+    if name in ("domainfill", "quasilag_step"):      # timemanager.f90:662-666: xmassfract = 1, nothing ends for want of mass
+        assert sum(s["n_min_mass"] for s in stats) == 0
     if name == "multi_release":
         assert sum(s["n_min_mass"] for s in stats) > 0
         # release point 4 carries no mass at all: xmassfract stays 0, every one of its particles ends in the first epilogue
@@ -280,16 +325,20 @@ def test_release_points_age_classes_and_terminations(built, name, kind):
         assert p4.sum() > 0 and np.all(got[0]["itra1"][p4] == -999999999)
     tol_g = 1e-12 if kind == "r8" else 5e-3
     tol_d = 2e-5 if kind == "r8" else 5e-3
-    assert g.shape == og.shape and d.shape == od.shape and w.shape == ow.shape and g.ndim == 7
+    if name == "nokernel":      # one age class, one uncertainty class, one release-point plane: the oracle drops those axes
+        g, d, w = g.reshape(og.shape), d.reshape(od.shape), w.reshape(ow.shape)
+        assert og.sum() > 0 and od.sum() > 0 and ow.sum() > 0
+    assert g.shape == og.shape and d.shape == od.shape and w.shape == ow.shape and (g.ndim == 7 or name == "nokernel")
     assert np.abs(g - og).max() <= tol_g * og.max(), np.abs(g - og).max() / og.max()
     assert np.abs(d - od).max() <= tol_d * od.max(), np.abs(d - od).max() / od.max()
     assert np.abs(w - ow).max() <= tol_d * ow.max(), np.abs(w - ow).max() / ow.max()
     # plane by plane: mass that lands in the wrong (age, class, point) plane would leave the per-plane sums unequal
-    for a, b, t8 in ((g, og, 1e-9), (d, od, 1e-5), (w, ow, 1e-5)):      # the deposition grids are f32 sums in every build
+    for a, b, t8 in ((g, og, 1e-9), (d, od, 1e-5), (w, ow, 1e-5)) if g.ndim == 7 else ():      # the deposition grids are f32 sums in every build
         tail = tuple(range(3, a.ndim))
         assert np.abs(a.sum(axis=tail) - b.sum(axis=tail)).max() <= (t8 if kind == "r8" else 2e-2) * b.sum(axis=tail).max()
     if gn is not None:
         for a, b in zip(gn, orc.grids_nest()):
+            a = a.reshape(b.shape) if name == "nokernel" else a
             assert a.shape == b.shape and b.sum() > 0
             assert np.abs(a - b).max() <= tol_d * b.max()
 
@@ -563,6 +612,47 @@ def test_fortran_host_drop_in(built, kind):
     limit = 0.01 * n if kind == "r8" else 0.05 * n
     assert bad.sum() <= limit, f"{bad.sum()} of {n} particles differ"
     assert np.array_equal(gpu["steps"][-1]["itra1"], ref["steps"][-1]["itra1"])
+
+
+@pytest.mark.parametrize("variant,case", [("r8t", "turboff"), ("r4t", "turboff"), ("r8h", "interpolhmix")])
+def test_fortran_host_passes_its_compile_time_switches(built, variant, case):
+    """A host built with turboff = .true. or interpolhmix = .true. (com_mod.f90:777-778: compile-time parameters of the
+    reference) hands them to the engine as run-time switches (flexgpu_init): the engine driven by that host reproduces that
+    host's own loop -- which differs from the shipped behaviour (checked: the two fixtures are not the same trajectories)."""
+    import os
+    from oracle import scenario_io as sio
+    from test_oracle_cpu import GOLD, golden_scenario
+    if not sio.have_ref(variant):
+        pytest.skip("oracle/_ref binaries not present in this snapshot")
+    sc = golden_scenario(case)
+    ref = sio.run_reference(sc, variant)
+    gpu = sio.run_reference(sc, variant, gpu=True, tag="gpu")
+    n = int(sc["npart"])
+    bad = np.zeros(n, bool)
+    tol = 1e-9 if variant.startswith("r8") else 2e-5
+    for a, b in zip(gpu["steps"], ref["steps"]):
+        for k in ("xtra1", "ytra1", "ztra1"):
+            bad |= np.abs(a[k] - b[k]) > tol * np.abs(b[k]).max()
+    assert bad.sum() <= (0.01 if variant.startswith("r8") else 0.05) * n, f"{bad.sum()} of {n} particles differ"
+    stock = dict(sc)
+    stock.pop(case)
+    plain = sio.run_reference(stock, variant[:2])          # the shipped parameters on the same cloud
+    moved = np.abs(plain["steps"][-1]["ztra1"] - ref["steps"][-1]["ztra1"]) > 1e-6 * np.abs(ref["steps"][-1]["ztra1"]).max()
+    assert moved.sum() > 0.2 * n
+
+
+@pytest.mark.parametrize("key,value", [("ipout", 3), ("iflux", 1), ("linit_cond", 1), ("linit_cond", 2)])
+def test_in_loop_diagnostics_are_refused_not_dropped(built, key, value):
+    """The block timemanager.f90:531-712 also calls partpos_average (ipout = 3, :617), calcfluxes (iflux = 1, :623) and
+    initial_cond_calc (linit_cond >= 1, :631,702).  The engine does not compute them (out of scope); a host
+    that asks for them gets FPX_ERR_UNSUPPORTED at fpx_create instead of a run that silently lacks their output."""
+    from flexpart_amd.engine import Engine
+    sc = syn.small(n=10, nx=20, ny=12, nz=10, nsteps=1)
+    sc[key] = value
+    with pytest.raises(Exception, match="not computed by this engine"):
+        Engine(sc)
+    sc[key] = 0 if key != "ipout" else 2
+    Engine(sc).close()
 
 
 @pytest.mark.parametrize("cbl", [0, 1])

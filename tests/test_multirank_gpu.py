@@ -58,12 +58,12 @@ WORKER = COMMON + textwrap.dedent("""
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=2)
     sc = scenario()
     mine = sharding.shard_scenario(sc, 2, rank)
-    eng = Engine(mine, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, seed=4711)   # particle_base from the shard
+    eng = Engine(mine, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, seed=4711, **%(ekw)r)   # particle_base from the shard
     eng.comm_init_host(dist, 2, rank)
     outs = run(eng, True, sort_at=0 if rank == 1 else None)
     state = eng.download()
     np.savez(%(out)r + f"_rank{rank}.npz", x=state["xtra1"], z=state["ztra1"], itra1=state["itra1"], m=state["xmass1"],
-             **{f"o{i}_{k}": v for i, o in enumerate(outs) for k, v in o.items()})
+             blended=eng.info("blended_steps"), **{f"o{i}_{k}": v for i, o in enumerate(outs) for k, v in o.items()})
     eng.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -71,17 +71,22 @@ WORKER = COMMON + textwrap.dedent("""
 
 SERIAL = COMMON + textwrap.dedent("""
     sc = scenario()
-    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, seed=4711)
+    eng = Engine(sc, compute_real_bytes=8, host_real_bytes=8, rng_mode=RNG_PHILOX, seed=4711, **%(ekw)r)
     outs = run(eng, False)
     state = eng.download()
     np.savez(%(out)r + "_serial.npz", x=state["xtra1"], z=state["ztra1"], itra1=state["itra1"], m=state["xmass1"],
-             **{f"o{i}_{k}": v for i, o in enumerate(outs) for k, v in o.items()})
+             blended=eng.info("blended_steps"), **{f"o{i}_{k}": v for i, o in enumerate(outs) for k, v in o.items()})
     eng.close()
 """)
 
 
-def test_two_ranks_one_gpu_two_output_times(built, tmp_path):
-    """mpi_mod.f90:2451-2492 through the engine: two ranks share one cloud (contiguous ranges of particle numbers,
+@pytest.mark.parametrize("blend", ["off", "forced_on", "auto_from_the_global_count"])
+def test_two_ranks_one_gpu_two_output_times(built, tmp_path, blend):
+    """blend: the time-blended wind packs round differently from the plain gather, so whether a step uses them must not
+    depend on the rank count: fpx_config.blend_mode (1 = on) or, in the automatic mode, the run's particle count over ALL
+    ranks (global_particles: 4e7 here, above the threshold on every rank although each holds 3000 particles) -- the sharded
+    and the single-rank run stay bitwise equal with the blend ON (README_PARALLEL.md:189-192), and it did run (blended_steps).
+    mpi_mod.f90:2451-2492 through the engine: two ranks share one cloud (contiguous ranges of particle numbers,
     README_PARALLEL.md:60-67), reduce gridunc / drygridunc / wetgridunc (+ nested grids, creceptor) at two output
     times into receive buffers and keep accumulating their partial sums in between.  (i) With the counter RNG keyed on
     the global particle number every particle ends exactly where the single-rank run puts it.  (ii) The sums at BOTH
@@ -89,10 +94,11 @@ def test_two_ranks_one_gpu_two_output_times(built, tmp_path):
     out = str(tmp_path / "mr")
     port = 33500 + (os.getpid() % 2000)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ekw = {"off": {}, "forced_on": {"blend_mode": 1}, "auto_from_the_global_count": {"global_particles": 40000000}}[blend]
     ws = tmp_path / "worker.py"
-    ws.write_text(WORKER % dict(root=ROOT, port=port, out=out))
+    ws.write_text(WORKER % dict(root=ROOT, port=port, out=out, ekw=ekw))
     ss = tmp_path / "serial.py"
-    ss.write_text(SERIAL % dict(root=ROOT, out=out))
+    ss.write_text(SERIAL % dict(root=ROOT, out=out, ekw=ekw))
     procs = [subprocess.Popen([sys.executable, str(ws), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
              for r in range(2)]
     outs = [p.communicate(timeout=600)[0] for p in procs]
@@ -100,6 +106,8 @@ def test_two_ranks_one_gpu_two_output_times(built, tmp_path):
     r = subprocess.run([sys.executable, str(ss)], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     a, b, s = (np.load(out + f"_{t}.npz") for t in ("rank0", "rank1", "serial"))
+    for d in (a, b, s):
+        assert (int(d["blended"]) > 0) == (blend != "off"), blend
     # (i) sharding does not change any particle (counter RNG keyed on the global number; rank 1 even re-sorted its slots)
     for k in ("x", "z", "itra1"):
         assert np.array_equal(np.concatenate([a[k], b[k]]), s[k]), k
