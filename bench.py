@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 counter pass that measures the dominant kernel's VALU issue time")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)   # the short run the counter pass profiles
     ap.add_argument("--cpu-sample", type=int, default=None, help="particles in the CPU baseline sample")
+    ap.add_argument("--poles", action="store_true", help="the full-globe variant (SURVEY 8d): nglobal = sglobal = 1 (gridcheck_ecmwf.f90:341-366), particles up to "
+                    "|lat| < 89 deg; beyond +-75 deg they move on the polar stereographic maps (advance.f90:161-164,754-778)")
+    ap.add_argument("--without", default="", help="config 5 only, for attributing its kernel time: comma-separated parts to leave out (nest, aerosol, settling, drydep, wet)")
     ap.add_argument("--blend", default="auto", choices=("auto", "on", "off"), help="time-blended wind packs (fpx_config.blend_mode); auto: from the run's particle count over all ranks")
     ap.add_argument("--global-particles", type=float, default=None, help="particle count of the run this job is a shard of (default: --particles); "
                     "e.g. --particles 12500000 --global-particles 1e8 = the shard one of eight GPUs runs, with that run's decisions")
@@ -55,13 +58,13 @@ def parse():
     return ap.parse_args()
 
 
-def build_scenario(cfg, nsteps):
+def build_scenario(cfg, nsteps, poles=False, without=()):
     from flexpart_amd import synthetic as syn
     if cfg == 2:
-        sc = syn.base_scenario(ctl=-5.0, ifine=4, turb_off=True, hmix_const=syn.HMIXMIN, nsteps=nsteps)
+        sc = syn.base_scenario(ctl=-5.0, ifine=4, turb_off=True, hmix_const=syn.HMIXMIN, nsteps=nsteps, polar=poles)
         frac_pbl = 0.0
     else:
-        sc = syn.base_scenario(ctl=5.0, ifine=4, cblflag=1, nsteps=nsteps)
+        sc = syn.base_scenario(ctl=5.0, ifine=4, cblflag=1, nsteps=nsteps, polar=poles)
         frac_pbl = 0.5
         if cfg == 4:
             # config 4: + conccalc into a global 360x180x10 output grid every step, grids summed
@@ -76,18 +79,26 @@ def build_scenario(cfg, nsteps):
             # config 5: one aerosol species (settling, dry deposition, decay), a 2x nest over the middle of
             # the domain (interpol_*_nests), wet deposition (mother + nest precipitation/cloud fields) and
             # the output grid every step; meant for --real 4 (fp32 mixed: positions stay fp64)
-            sc.update(lsettling=1, drydep=1, drydepspec=np.array([1], np.int32), density=np.array([2000.0]),
-                      dquer=np.array([8.0]), vsetaver=np.array([-0.004]), cunningham=np.array([1.02]),
-                      decay=np.array([1.0e-6]), xmass=np.array([1.0]))
+            if "aerosol" not in without:
+                sc.update(lsettling=1, drydep=1, drydepspec=np.array([1], np.int32), density=np.array([2000.0]),
+                          dquer=np.array([8.0]), vsetaver=np.array([-0.004]), cunningham=np.array([1.02]),
+                          decay=np.array([1.0e-6]), xmass=np.array([1.0]))
+                if "settling" in without:
+                    sc.update(lsettling=0)
+                if "drydep" in without:
+                    sc.update(drydep=0, drydepspec=np.array([0], np.int32))
             sc["npart"] = 1
             sc["itramem"] = np.zeros(1, np.int32)
             sc["itime0"] = 0
             syn.add_outgrid(sc, nxg=360, nyg=180, nzg=10, outlon0=-180.0, outlat0=-90.0, dxout=1.0, dyout=1.0,
                             ind_samp=-1, old_fraction=0.0)
             del sc["npart"], sc["itramem"]
-            syn.add_nest(sc, ix0=120, jy0=60, ix1=240, jy1=120, factor=2)
-            syn.add_wet(sc, gas=False)
-            syn.add_wet_nest(sc)
+            if "nest" not in without:
+                syn.add_nest(sc, ix0=120, jy0=60, ix1=240, jy1=120, factor=2)
+            if "wet" not in without:
+                syn.add_wet(sc, gas="aerosol" in without)
+                if "nest" not in without:
+                    syn.add_wet_nest(sc)
     return sc, frac_pbl
 
 
@@ -131,9 +142,10 @@ def free_port():
 def child_bench_cmd(args):
     return ([sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--config", str(args.config), "--real", str(args.real),
             "--rng", args.rng, "--sort-interval", str(args.sort_interval), "--steps", "3", "--warmup", "1",
-            "--no-cpu-baseline", "--no-pmc", "--blend", args.blend, "--slice-passes", str(args.slice_passes)]
+            "--no-cpu-baseline", "--no-pmc", "--blend", args.blend, "--slice-passes", str(args.slice_passes)] + (["--poles"] if args.poles else [])
             + (["--particles", repr(args.particles)] if args.particles else [])
             + (["--global-particles", repr(args.global_particles)] if args.global_particles else [])
+            + (["--without", args.without] if args.without else [])
             + [a for o in args.opt for a in ("--opt", o)])
 
 
@@ -298,14 +310,14 @@ def main():
     lo, hi = sharding.shard_bounds(ntot, world, rank)      # this rank's range of the global particle numbers
     nper = hi - lo
     total_steps = args.warmup + args.steps
-    sc, frac_pbl = build_scenario(args.config, total_steps)
+    sc, frac_pbl = build_scenario(args.config, total_steps, args.poles, tuple(w for w in args.without.split(",") if w))
     sc["npart_rel"] = np.array([ntot], np.int32)           # npart(1): particles of the release on ALL ranks
     rng = RNG_PHILOX if args.rng == "philox" else RNG_TABLE_COUNTER
     eng = Engine(sc, compute_real_bytes=args.real, host_real_bytes=args.real, rng_mode=rng,
                  seed=0x5EED, max_particles=nper, device=local, sort_interval=args.sort_interval, particle_base=lo,
                  blend_mode={"auto": 0, "on": 1, "off": 2}[args.blend], global_particles=int(args.global_particles or ntot),
                  pbl_slice_passes=args.slice_passes, options=dict(o.split("=", 1) for o in args.opt))
-    eng.seed_particles(nper, seed=0x5EED, frac_pbl=frac_pbl)   # slice [lo, hi) of the one global synthetic cloud
+    eng.seed_particles(nper, seed=0x5EED, frac_pbl=frac_pbl, lat_margin_cells=1.0 if args.poles else None)   # slice [lo, hi) of the one global synthetic cloud
     if args.sort_interval > 0:
         eng.sort()          # a release normally arrives ordered; the synthetic cloud is random
     transport = None
@@ -328,7 +340,7 @@ def main():
         itime = i * lsync
         w0 = (itime // window) * window
         eng.set_windtime((w0, w0 + window), (1, 2))
-        if args.config == 5 and itime != 0:
+        if args.config == 5 and itime != 0 and eng.has_wet:
             eng.wetdepo(itime, lsync, 3600)            # timemanager.f90:164-169: before the particle loop
         eng.step_async(itime)
         if args.config in (4, 5):
@@ -345,10 +357,16 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, total_steps):
         do_step(i)
+    grid_sum = None
     if args.config in (4, 5):
         grid, _ = eng.grids(allreduce=world > 1)     # the grid reduction over the ranks + D2H of the sums: part of the job
+        grid_sum = float(np.asarray(grid, dtype=np.float64).sum())
     # the end of the timed region is an output time: the particle count over the ranks, as the reference's root reduces it
+    t_cnt = time.perf_counter()
+    eng.sync()
+    t_cnt0 = time.perf_counter()
     (nlive_local, _), (nlive_total, numpart_total) = eng.count_particles(allreduce=world > 1)
+    t_cnt = time.perf_counter() - t_cnt0             # the count + its reduction alone (the stream was drained just before): a fixed cost per output time
     eng.sync()
     torch.cuda.synchronize()
     if dist:
@@ -395,12 +413,13 @@ def main():
         "data": "synthetic",
         "config": {"workload": (f"BASELINE config {args.config}: {ntot:.0e} particles"
                                 + (f" sharded over {world} GPUs ({nper} on rank 0)" if world > 1 else "") + ", synthetic "
-                                f"{nx}x{ny}x{nz} ECMWF-shaped fields, "
+                                f"{nx}x{ny}x{nz} ECMWF-shaped fields" + (" with both polar caps (nglobal = sglobal = 1, particles to |lat| < 89)" if args.poles else "") + ", "
                                 + ("advance+interpol_wind only (all above PBL, turbulence off)" if args.config == 2
                                    else "Hanna turbulence + CBL (ctl=1/5, ifine=11), PBL sub-stepping")
                                 + (" + conccalc 360x180x10 every step + RCCL grid all-reduce" if args.config == 4 else "")
                                 + (" + aerosol (settling, dry deposition), 241x121 nest, wet deposition, conccalc 360x180x10 every step"
                                    if args.config == 5 else "")
+                                + (f" WITHOUT {args.without} (attribution run, not the config)" if args.without else "")
                                 + f", rng={args.rng}, lsynctime=900"),
                    "particles_total": ntot, "particles_per_gpu": nper, "particle_steps_timed": psteps, "counters": cnt, "parallelism": f"particle-shard x{world}",
                    "sort_interval": args.sort_interval, "live_particles_all_ranks": nlive_total, "numpart_all_ranks": numpart_total,
@@ -409,7 +428,9 @@ def main():
                    "time_blended_packs": bool(eng.info("time_blended_packs")), "blended_steps": eng.info("blended_steps"),
                    "global_particles": int(args.global_particles or ntot),
                    "pbl_launches_per_step": n_slices, "options": args.opt,
-                   "rccl_nranks": world if transport == "rccl" else 0, "reduction_transport": transport},
+                   "rccl_nranks": world if transport == "rccl" else 0, "reduction_transport": transport,
+                   "count_reduction_ms": t_cnt * 1e3,      # inside the timed region (an output time of the reference: timemanager_mpi.f90:552-562)
+                   "gridunc_sum_all_ranks": grid_sum},
         # achieved / peak / frac: the HBM roofline on ALGORITHMIC bytes, as the bench contract defines it.  `bound` names what
         # actually limits the dominant kernel: config 2's k_prep is memory-latency bound at three waves per SIMD (gathers
         # and state streaming); the Langevin kernel of configs 3-5 is VALU-issue bound -- its HBM fraction is small by

@@ -915,7 +915,11 @@ enum StashSlot {
   S_UST, S_WST, S_OL, S_TRANS,                                                  // hanna_mod ust, wst, ol; wst^3 * the transition of cbl.f90:79-81
   S_RHOAUX,                                                                     // per-pass invariant of the fine loop: rhograd/rhoa
   S_NPASS,                                                                      // passes the lane has run for its particle in this launch (time slices, k_pbl_loop)
-  S_TDEP,                                                                       // aerosol kernels: sum of |dt| over the passes that ended below 2*href (advance.f90:582-599)
+  S_COUNT_LEAN,                                                                 // the gas kernels (LEAN) stop here
+  S_TDEP = S_COUNT_LEAN,                                                        // aerosol kernels: sum of |dt| over the passes that ended below 2*href (advance.f90:582-599)
+  S_SETCELL,                                                                    // aerosol kernels: column (njy*nx + nix) of get_settling -- so that xt, yt need not stay in registers
+  S_SET_NUM, S_SET_DQ6, S_SET_V0,                                               // ... and its species constants 4*ga*dquer/1.e6*density*cunningham (0: no settling), dquer/1.e6, vsetaver
+  S_RT_TAG, S_RT_RHO1, S_RT_TT1, S_RT_RHO2, S_RT_TT2,                           // aerosol kernels: rho, tt of get_settling.f90:83-84 for the level pair S_RT_TAG (0: none) of the lane's column
   S_COUNT
 };
 constexpr int kStashStride = 256;   // threads per block of the loop kernel
@@ -1347,32 +1351,96 @@ inline void polar_maps(R dy, R *north, R *south) {
 // ---------------------------------------------------------------------------
 // gravitational settling: get_settling.f90:52-127, dynamic_viscosity.f90:7-17
 // ---------------------------------------------------------------------------
+// FAST (the Langevin kernel, once per pass): the level search starts from the pass's level (the particle rarely leaves it),
+// the divisions and the root are the 1-2 ulp helpers of the fine loop, t**1.5 is t*sqrt(t), and everything that does not
+// change inside the iteration is taken out of it (the same expressions in the same order: 4*ga*dquer/1.e6*density*cunningham
+// and dquer/1.e6 are evaluated once instead of up to twenty times).
 template <typename R>
-FPX_DEV R get_settling(const View<R> &V, const R *hgt, R xt, R yt, R zt, int nsp) {
-  const R ga = K(9.81);
+FPX_DEV int settling_column(const View<R> &V, R xt, R yt) {   // nix = int(xt), njy = int(yt) of get_settling.f90:52-53 as one column index
   int nix = (int)xt, njy = (int)yt;
   nix = min(max(nix, 0), V.nx - 1);
   njy = min(max(njy, 0), V.ny - 1);
-  int indz = find_level(hgt, V.nz, zt);
-  R dz = K(1.) / (hgt[indz] - hgt[indz - 1]);
+  return njy * V.nx + nix;
+}
+template <typename R> struct Stash;
+template <typename R>
+struct SettleSpec { R num, dq6, vset; };   // the species constants of get_settling.f90:96-117 as the routine evaluates them
+template <typename R>
+FPX_DEV SettleSpec<R> settle_spec(const View<R> &V, int nsp) {
+  const R ga = K(9.81);
+  SettleSpec<R> c;
+  c.dq6 = pick(V.dquer, nsp) / K(1.e6);
+  c.vset = pick(V.vsetaver, nsp);
+  c.num = K(4) * ga * pick(V.dquer, nsp) / K(1.e6) * pick(V.density, nsp) * pick(V.cunningham, nsp);
+  return c;
+}
+template <typename R, bool FAST = false>
+FPX_DEV R get_settling(const View<R> &V, const R *hgt, int column, R zt, int nsp, int level_hint = 0, const Stash<R> *ST = nullptr) {
+#if defined(FPX_EXP_SETTLE) && FPX_EXP_SETTLE == 1   // timing experiment only (wrong results): no settling computation at all
+  if (FAST) return pick(V.vsetaver, nsp);
+#endif
+  int indz = level_hint;
+  // the level with height(indz) <= zt < height(indz+1), as the search of get_settling.f90:58-64 finds it
+  if (!(FAST && indz >= 1 && indz <= V.nz - 1 && hgt[indz] > zt && (indz == 1 || !(hgt[indz - 1] > zt)))) indz = find_level(hgt, V.nz, zt);
+  R rho1, tt1, rho2, tt2;
+  if (ST != nullptr && (int)ST->get(S_RT_TAG) == indz) {
+    // the lane's column does not change inside the step and the particle leaves its level pair in a fifth of its passes:
+    // the four values stay in the stash from pass to pass (before: one dependent 16-byte gather -- a cache line of its own
+    // -- at the end of every pass: 56 GB of fetches per launch at 1e8 particles, 5 times the rest of the kernel's)
+    rho1 = ST->get(S_RT_RHO1); tt1 = ST->get(S_RT_TT1); rho2 = ST->get(S_RT_RHO2); tt2 = ST->get(S_RT_TT2);
+  } else {
+    const R *q = V.rhott + ((long long)column * V.nz + (indz - 1)) * 2;
+    rho1 = q[0]; tt1 = q[1]; rho2 = q[2]; tt2 = q[3];
+    if (ST != nullptr) {
+      ST->put(S_RT_TAG, (R)indz); ST->put(S_RT_RHO1, rho1); ST->put(S_RT_TT1, tt1); ST->put(S_RT_RHO2, rho2); ST->put(S_RT_TT2, tt2);
+    }
+  }
+  R dz = FAST ? m_rcp(hgt[indz] - hgt[indz - 1]) : K(1.) / (hgt[indz] - hgt[indz - 1]);
   R dz1 = (zt - hgt[indz - 1]) * dz;
   R dz2 = (hgt[indz] - zt) * dz;
-  const R *q = V.rhott + (((long long)njy * V.nx + nix) * V.nz + (indz - 1)) * 2;
-  R rho1 = q[0], tt1 = q[1], rho2 = q[2], tt2 = q[3];
   R temperature = dz2 * tt1 + dz1 * tt2;
   R airdens = dz2 * rho1 + dz1 * rho2;
   const R cc = K(120.), t_0 = K(291.15), eta_0 = K(1.827e-5);
+  R dq6, vset, num;
+  if (FAST && ST != nullptr) {   // taken once per particle at the lane's refill (a per-lane subscript into the species tables is a memory round trip)
+    dq6 = ST->get(S_SET_DQ6); vset = ST->get(S_SET_V0); num = ST->get(S_SET_NUM);
+  } else {
+    const SettleSpec<R> c = settle_spec(V, nsp);
+    dq6 = c.dq6; vset = c.vset; num = c.num;
+  }
+  if (FAST) {
+    const R tr = temperature * m_rcp(t_0);
+    const R vis_dyn = eta_0 * (t_0 + cc) * m_rcp(temperature + cc) * (tr * m_sqrtp(tr));   // dynamic_viscosity.f90:14
+    const R ivis_kin = airdens * m_rcp(vis_dyn);
+    R reynolds = dq6 * m_abs(vset) * ivis_kin;
+    R settling_old = vset, settling = K(0.);
+#if defined(FPX_EXP_SETTLE) && FPX_EXP_SETTLE == 2   // timing experiment only (wrong results): one iteration
+    for (int i = 1; i <= 1; i++) {
+#else
+    for (int i = 1; i <= 20; i++) {
+#endif
+      R icd;      // 1 / c_d
+      if (__builtin_expect(reynolds < K(1.917), 1)) icd = reynolds * (K(1.) / K(24.));
+      else if (reynolds < K(500.)) icd = m_pow(reynolds, K(0.6)) * (K(1.) / K(18.5));
+      else icd = K(1.) / K(0.44);
+      settling = K(-1.) * m_sqrtp(num * icd * m_rcp(K(3.) * airdens));
+      if (m_abs((settling - settling_old) * m_rcp(settling)) < K(0.01)) break;
+      reynolds = dq6 * m_abs(settling) * ivis_kin;
+      settling_old = settling;
+    }
+    return settling;
+  }
   R vis_dyn = eta_0 * (t_0 + cc) / (temperature + cc) * m_pow(temperature / t_0, K(1.5));
   R vis_kin = vis_dyn / airdens;
-  R reynolds = pick(V.dquer, nsp) / K(1.e6) * m_abs(pick(V.vsetaver, nsp)) / vis_kin;
-  R settling_old = pick(V.vsetaver, nsp), settling = K(0.), c_d;
+  R reynolds = dq6 * m_abs(vset) / vis_kin;
+  R settling_old = vset, settling = K(0.), c_d;
   for (int i = 1; i <= 20; i++) {
     if (reynolds < K(1.917)) c_d = K(24.) / reynolds;
     else if (reynolds < K(500.)) c_d = K(18.5) / m_pow(reynolds, K(0.6));
     else c_d = K(0.44);
-    settling = K(-1.) * m_sqrt(K(4) * ga * pick(V.dquer, nsp) / K(1.e6) * pick(V.density, nsp) * pick(V.cunningham, nsp) / (K(3.) * c_d * airdens));
+    settling = K(-1.) * m_sqrt(num / (K(3.) * c_d * airdens));
     if (m_abs((settling - settling_old) / settling) < K(0.01)) break;
-    reynolds = pick(V.dquer, nsp) / K(1.e6) * m_abs(settling) / vis_kin;
+    reynolds = dq6 * m_abs(settling) / vis_kin;
     settling_old = settling;
   }
   return settling;
@@ -1391,11 +1459,11 @@ FPX_DEV int settling_species(const View<R> &V, int npoint) {
 }
 
 // settling velocity of species nsp, the block repeated at advance.f90:518-531,686-699,893-906
-template <typename R>
-FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt, R zt, int nsp) {
+template <typename R, bool FAST = false>
+FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt, R zt, int nsp, int level_hint = 0) {
   if (V.mdomainfill != 0 || !V.lsettling) return K(0.);
   if (!(pick(V.density, nsp) > K(0.))) return K(0.);
-  return get_settling(V, hgt, (R)xt, (R)yt, zt, nsp);
+  return get_settling<R, FAST>(V, hgt, settling_column(V, (R)xt, (R)yt), zt, nsp, level_hint);
 }
 
 // ---------------------------------------------------------------------------
@@ -2168,7 +2236,8 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 
   R w = S.get(S_W);
   if (SETTLE && V.lsettling) {   // advance.f90:518-531
-    w = w + settling_velocity(V, hgt, xt, yt, zt, A.nsp);
+    // (column and species of get_settling come from the stash: the position itself need not stay in registers for this)
+    if (V.mdomainfill == 0 && S.get(S_SET_NUM) > K(0.)) w = w + get_settling<R, true>(V, hgt, (int)S.get(S_SETCELL), zt, 0, indz, &S);
     S.put(S_W, w);
   }
 

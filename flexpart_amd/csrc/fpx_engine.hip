@@ -67,7 +67,7 @@ constexpr int kBlock = 256;
 #define FPX_DRAIN_LANES 32   // a wave of a non-final launch whose list is used up hands its particles on when fewer lanes than this hold one
 #endif
 constexpr int kMaxNz = 512;
-constexpr unsigned char kKeyDone = 16, kKeyNotDue = 17;   // keys of the work-list sort (5 bits); 0..15: PBL particles, class-major (k_prep)
+constexpr unsigned char kKeyDone = 32, kKeyNotDue = 33;   // keys of the work-list sort (6 bits); 0..31: PBL particles, class-major (k_prep)
 
 // ---------------------------------------------------------------------------
 // field repacking kernels
@@ -538,8 +538,8 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     asm volatile("" : "+v"(due_key), "+v"(ps.xt), "+v"(ps.yt), "+v"(ps.zt), "+v"(itramem), "+v"(pid));
     if (due_key != itime) { pbl_flag[s] = kKeyNotDue; return; }    // timemanager.f90:537
   }
-  // key kKeyNotDue = not due; kKeyDone = due, finished in this kernel (above the PBL); 4 (c - 1) + 0..3 = PBL particle of regime
-  // class c = 1..4, cost bucket 3..0 (see below).
+  // key kKeyNotDue = not due; kKeyDone = due, finished in this kernel (above the PBL); 8 (c - 1) + 0..7 = PBL particle of regime
+  // class c = 1..4, cost bucket 7..0 (see below).
   // The counts (particles due, length of the PBL work list) are read off the sorted keys by
   // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
 
@@ -617,9 +617,11 @@ __global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 
     if (V.pbl_cost_buckets) {
       const int idt = is_new ? ps.ldt : P.idt[s];
       const int est = abs(V.lsynctime) / max(idt, 1);          // passes, if the time step stayed
-      bucket = est >= 128 ? 3 : est >= 64 ? 2 : est >= 32 ? 1 : 0;
+      if (V.pbl_cost_buckets == 1) bucket = est >= 128 ? 3 : est >= 64 ? 2 : est >= 32 ? 1 : 0;
+      else if (V.pbl_cost_buckets == 2) bucket = est >= 64 ? 1 : 0;
+      else bucket = est >= 256 ? 7 : est >= 128 ? 6 : est >= 96 ? 5 : est >= 64 ? 4 : est >= 48 ? 3 : est >= 32 ? 2 : est >= 16 ? 1 : 0;
     }
-    pbl_flag[s] = (unsigned char)((cls - 1) * 4 + (3 - bucket));
+    pbl_flag[s] = (unsigned char)((cls - 1) * 8 + (7 - bucket));
     return;
   }
   // Above the mixing layer for the whole step (advance.f90:629-708 -> 99): wp and ldt are set, not read; up, vp and cbt
@@ -1197,7 +1199,7 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   long long upto[5];
   upto[0] = 0;
-  for (int c = 1; c <= 4; c++) upto[c] = count_le_sorted(sorted_keys, upto[c - 1], n, (unsigned char)(4 * c - 1));
+  for (int c = 1; c <= 4; c++) upto[c] = count_le_sorted(sorted_keys, upto[c - 1], n, (unsigned char)(8 * c - 1));
   const long long npbl = upto[4];
   const long long ndue = count_le_sorted(sorted_keys, npbl, n, kKeyDone);
   if (threadIdx.x == 0) {
@@ -1254,7 +1256,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   extern __shared__ __align__(16) unsigned char fpx_loop_smem[];
   static_assert(kStashStride == kBlock, "stash layout is one column per thread of the block");
   R *stash_mem = reinterpret_cast<R *>(fpx_loop_smem);
-  R *hgt = stash_mem + S_COUNT * kStashStride;
+  R *hgt = stash_mem + (LEAN ? S_COUNT_LEAN : S_COUNT) * kStashStride;   // (the host sizes the block's LDS alike: loop_smem_bytes)
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   // the block's copy of the lookup tables of the fp64 logarithm and exponential (m_log_abs, m_exp_tab): 768 B
   __shared__ double lds_tab[sizeof(R) == 8 ? kLdsTabDoubles : 1];
@@ -1395,7 +1397,15 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
             adv_begin_known(V, xt, yt, pbl_ngrid(r_pk), r_h, A, ddx, ddy);
             A.itimec = itime + pbl_elapsed(r_pk) * V.ldirect;   // FRESH: elapsed = 0
             A.nrand = r_nrand;
-            A.nsp = (!LEAN && V.lsettling) ? settling_species(V, l_npoint) : 0;
+            A.nsp = 0;
+            if (!LEAN && V.lsettling) {
+              const int nsp = settling_species(V, l_npoint);
+              const SettleSpec<R> sp = settle_spec(V, nsp);
+              S.put(S_SET_NUM, pick(V.density, nsp) > (R)0 ? sp.num : (R)0);   // density(nsp) <= 0: no settling (advance.f90:525)
+              S.put(S_SET_DQ6, sp.dq6); S.put(S_SET_V0, sp.vset);
+              S.put(S_SETCELL, (R)settling_column(V, (R)xt, (R)yt));   // < nx*ny: exact in R (f32: grids up to 2^24 columns, checked at fpx_create)
+              S.put(S_RT_TAG, (R)0);
+            }
             S.put(S_DDX, ddx); S.put(S_DDY, ddy);
           }
           S.put(S_DX, resumed ? c_dx : (R)0); S.put(S_DY, resumed ? c_dy : (R)0);
@@ -1939,6 +1949,7 @@ struct Engine : EngineBase {
     if (cfg.ipout == 3) return fail(FPX_ERR_UNSUPPORTED, "ipout = 3: the particle loop's partpos_average (timemanager.f90:617) is not computed by this engine");
     if (cfg.iflux == 1) return fail(FPX_ERR_UNSUPPORTED, "iflux = 1: the particle loop's calcfluxes (timemanager.f90:623) is not computed by this engine");
     if (cfg.linit_cond >= 1) return fail(FPX_ERR_UNSUPPORTED, "linit_cond >= 1: the particle loop's initial_cond_calc (timemanager.f90:631,702) is not computed by this engine");
+    if (cfg.lsettling && cfg.compute_real_bytes == 4 && (long long)cfg.nx * cfg.ny > (1ll << 24)) return fail(FPX_ERR_ARG, "lsettling with the f32 engine: nx*ny must not exceed 2^24 (the Langevin kernel keeps the column index of get_settling in an f32 stash slot)");
     if (cfg.blend_mode < 0 || cfg.blend_mode > 2) return fail(FPX_ERR_ARG, "blend_mode must be 0 (automatic), 1 (on) or 2 (off)");
     if (cfg.global_particles < 0) return fail(FPX_ERR_ARG, "global_particles must not be negative");
     if (cfg.pbl_slice_passes < -1) return fail(FPX_ERR_ARG, "pbl_slice_passes must be -1 (one launch), 0 (the engine's schedule) or a pass budget");
@@ -4336,7 +4347,7 @@ struct Engine : EngineBase {
     }
     {
       size_t need = 0;
-      HIPCHK(rocprim::radix_sort_pairs(nullptr, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 5u, stream));
+      HIPCHK(rocprim::radix_sort_pairs(nullptr, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 6u, stream));
       if (need > sel_tmp_bytes) {
         if (d_sel_tmp) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d_sel_tmp)); d_sel_tmp = nullptr; }
         HIPCHK(hipMalloc(&d_sel_tmp, need));
@@ -4365,10 +4376,10 @@ struct Engine : EngineBase {
     }
     HIPCHK(hipEventRecord(ev.e[4], stream));
     {
-      // work list = slots stably sorted by the 5-bit key of k_prep: class, cost bucket (non-PBL slots, keys 16 and 17, end
+      // work list = slots stably sorted by the 6-bit key of k_prep: class, cost bucket (non-PBL slots, keys 32 and 33, end
       // up behind the d_pbl_ctr[0] entries that are used)
       size_t need = sel_tmp_bytes;
-      HIPCHK(rocprim::radix_sort_pairs(d_sel_tmp, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 5u, stream));
+      HIPCHK(rocprim::radix_sort_pairs(d_sel_tmp, need, d_pbl_flag, d_pbl_flag2, d_iota, d_pbl_list, (size_t)numpart, 0u, 6u, stream));
       k_list_counts<<<1, 64, 0, stream>>>(d_pbl_flag2, numpart, d_pbl_ctr, d_stats);
     }
     const int fin_grid = std::min(nb, 8 * 256 * 4);
@@ -4447,7 +4458,7 @@ struct Engine : EngineBase {
     if (n == "conv_one_lane") { if (!need_int(0)) goto bad; opt.conv_one_lane = iv != 0; return 0; }
     if (n == "conv_no_walk") { if (!need_int(0)) goto bad; opt.conv_no_walk = iv != 0; return 0; }
     if (n == "conv_rows_plain") { if (!need_int(0)) goto bad; opt.conv_rows_plain = iv != 0; return 0; }
-    if (n == "pbl_cost_buckets") { if (!need_int(0)) goto bad; V.pbl_cost_buckets = iv != 0; return 0; }
+    if (n == "pbl_cost_buckets") { if (!need_int(0) || iv > 3) goto bad; V.pbl_cost_buckets = (int)iv; return 0; }   // 0 none, 1: four buckets, 2: two, 3: eight
     if (n == "pbl_drain_lanes") { if (!is_int || iv < -1 || iv > 64) goto bad; opt.pbl_drain_lanes = (int)iv; return 0; }
     if (n == "permute") {
       if (v == "auto") opt.permute = 0; else if (v == "direct") opt.permute = 1; else if (v == "staged") opt.permute = 2; else goto bad;
@@ -4498,7 +4509,9 @@ struct Engine : EngineBase {
 
   // the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
   typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, unsigned int *, int, int, int, unsigned int *);
-  size_t loop_smem_bytes() const { return sizeof(R) * ((size_t)S_COUNT * kStashStride + (size_t)cfg.nz); }
+  // (the gas kernels -- LEAN instances of k_pbl_loop, see loop_table -- leave the aerosol slots of the stash out)
+  bool loop_is_lean() const { return !cfg.drydep && !cfg.lsettling && (cfg.turbswitch || cfg.cblflag != 1); }
+  size_t loop_smem_bytes() const { return sizeof(R) * ((size_t)(loop_is_lean() ? S_COUNT_LEAN : S_COUNT) * kStashStride + (size_t)cfg.nz); }
   loop_fn loop_kernel() const {
     return (loop_fn)step_kernel_loop((int)sizeof(R), !cfg.drydep && !cfg.lsettling, cfg.turbswitch, cfg.cblflag, cfg.rng_mode);
   }
@@ -5142,7 +5155,7 @@ static const void *loop_table(bool lean, int turbswitch, int cblflag, int rng_mo
     if (turbswitch && cblflag == 1) return (const void *)k_pbl_loop<R, false, 1, 1, 2>;
     if (turbswitch && cblflag != 1) return (const void *)k_pbl_loop<R, false, 1, 0, 2>;
   }
-  return (const void *)k_pbl_loop<R, false, -1, -1, -1>;
+  return (const void *)k_pbl_loop<R, false, -1, -1, -1>;   // (Engine::loop_is_lean mirrors which configurations get a LEAN instance)
 }
 template <typename R>
 static const void *finish_table(bool drydep, bool polar, bool nest) {

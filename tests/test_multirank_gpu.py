@@ -187,3 +187,28 @@ def test_two_ranks_level_their_particle_counts(built, tmp_path):
     nb0 = int((b["bi"] == itime).sum())
     assert nb > nb0 and nb - nb0 <= 70000 and int(a["n_after"]) == 260000 - 70000
     assert int(a["due"]) == na and int(b["due"]) == nb                         # every particle, received ones included, advanced
+
+
+def test_bench_two_ranks_is_the_single_rank_job(built, tmp_path):
+    """bench.py --gpus 2 as the driver will start it (here: bench.py launches its two ranks itself, as fresh child processes;
+    on this one-GPU box they share the device and reduce over the host transport -- on a node each has its own GPU and RCCL):
+    the line reports two ranks, every particle of the one cloud is alive on some rank, and the all-reduced concentration
+    grid is the single-rank run's (mpi_mod.f90:2451-2492, timemanager_mpi.f90:552-562)."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    lines = {}
+    for n in (1, 2):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--config", "4", "--particles", "2e6", "--steps", "2", "--warmup", "1",
+               "--no-cpu-baseline", "--no-pmc"]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=str(tmp_path))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        lines[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    one, two = lines[1], lines[2]
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["live_particles_all_ranks"] == one["config"]["live_particles_all_ranks"] == 2000000
+    assert two["config"]["particles_per_gpu"] == 1000000 and two["config"]["reduction_transport"] is not None
+    assert two["config"]["time_blended_packs"] == one["config"]["time_blended_packs"]
+    a, b = one["config"]["gridunc_sum_all_ranks"], two["config"]["gridunc_sum_all_ranks"]
+    assert a > 0 and abs(a - b) <= 1e-6 * a, (a, b)
+    assert abs(two["config"]["particle_steps_timed"] - one["config"]["particle_steps_timed"]) <= 2
