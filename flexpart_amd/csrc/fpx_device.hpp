@@ -403,6 +403,7 @@ struct View {
   int xglobal, nglobal, sglobal;
   R switchnorthg, switchsouthg;
   R northpolemap[9], southpolemap[9];
+  const R *polemaps;   // the same 18 values in device memory (the out-of-line polar move reads them there)
   // wind-field window, com_mod.f90:276,286
   int memtime0, memtime1, m1, m2, lwindinterv;   // m1/m2: physical slot (0|1) of memind(1)/(2)
   R meso_r, meso_rs;   // r = exp(-2*|lsynctime|/lwindinterv), sqrt(1-r*r): advance.f90:728-729, set with the wind window
@@ -1524,6 +1525,31 @@ FPX_DEV int boundary(const View<R> &V, const R *hgt, double &xt, double &yt, R &
 }
 
 // horizontal move by (du,dv) metres on grid `ngrid`: advance.f90:750-778 == :923-951
+// The move on a polar stereographic map (advance.f90:754-775), OUT OF LINE: a sixth of the particles of a global run take it,
+// but inlined its trigonometry (cll2xy, cgszll, cxy2ll) set the register budget of every kernel that moves particles -- the
+// polar instances of k_prep / k_pbl_finish ran at two waves per SIMD instead of three.  The map records come from device
+// memory (View::polemaps: north | south, 9 values each); the function call keeps its registers to itself.
+struct XY { double x, y; };
+template <typename R>
+__device__ __attribute__((noinline)) XY polar_move(const R *__restrict__ map, R xlon0, R ylat0, R dx, R dy, double xt, double yt, R du, R dv, R fac) {
+  R m[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) m[i] = map[i];
+  R xlon = (R)((double)xlon0 + xt * (double)dx);
+  R ylat = (R)((double)ylat0 + yt * (double)dy);
+  R xpol, ypol;
+  cll2xy(m, ylat, xlon, xpol, ypol);
+  R gridsize = K(1000.) * cgszll(m, ylat);
+  du = du / gridsize;
+  dv = dv / gridsize;
+  xpol = xpol + du * fac;
+  ypol = ypol + dv * fac;
+  cxy2ll(m, xpol, ypol, ylat, xlon);
+  XY r;
+  r.x = (double)((xlon - xlon0) / dx);
+  r.y = (double)((ylat - ylat0) / dy);
+  return r;
+}
 template <typename R, bool POLAR = true>
 FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, R dv, R fac) {
   const R pi180 = FPX_PI_PAR / K(180.);
@@ -1532,6 +1558,7 @@ FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, 
     xt = xt + (double)(du * cosfact * fac);
     yt = yt + (double)(dv * V.dyconst * fac);
   } else {
+#ifdef FPX_POLAR_INLINE
     const R *map = ngrid == -1 ? V.northpolemap : V.southpolemap;
     R xlon = (R)((double)V.xlon0 + xt * (double)V.dx);
     R ylat = (R)((double)V.ylat0 + yt * (double)V.dy);
@@ -1545,6 +1572,10 @@ FPX_DEV void move_xy(const View<R> &V, int ngrid, double &xt, double &yt, R du, 
     cxy2ll(map, xpol, ypol, ylat, xlon);
     xt = (double)((xlon - V.xlon0) / V.dx);
     yt = (double)((ylat - V.ylat0) / V.dy);
+#else
+    const XY r = polar_move<R>(V.polemaps + (ngrid == -1 ? 0 : 9), V.xlon0, V.ylat0, V.dx, V.dy, xt, yt, du, dv, fac);
+    xt = r.x; yt = r.y;
+#endif
   }
 }
 
@@ -2517,6 +2548,59 @@ FPX_DEV void wave_run_add(T *base, long long idx, T val, bool valid) {
   if (head && valid) atomicAdd(base + idx, v);
 }
 
+// The uniform kernel of conccalc / wetdepokernel / drydepokernel spreads a particle over its own output cell c0 = (ix, jy)
+// and three neighbours (ix +- 1, jy +- 1: which side depends on where in the cell it sits).  Every lane of the wave calls this
+// (convergent code): c0 = kNoCell = nothing to add; dix, djy = +-1; w00 -> c0, w10 -> c0 + dix, w01 -> c0 + djy*numx,
+// w11 -> c0 + djy*numx + dix (a weight is zero where the target lies outside the grid).
+// The lanes that share c0 (same cell, level, species, point, class, age) -- after a locality sort that is most of a wave,
+// since the output grids are no finer than the met grid and a deposition grid collects whole columns -- are summed into the
+// 3 x 3 neighbourhood of c0 with nine wave reductions, and nine lanes issue ONE atomic wave instruction.
+// Why: float atomics run at the memory side (rocprofv3: TCC_EA0_ATOMIC = TCC_ATOMIC for these kernels, 1800 cycles in flight
+// each), scattered dwords at about 2e10 per second for the whole chip; the run-merging of wave_run_add only catches
+// NEIGHBOURING lanes with the same target, and the three neighbour cells alternate from lane to lane with the particle's
+// quadrant: 0.86 atomics per particle in k_wetdepo, 0.43 in k_conccalc before this.
+constexpr long long kNoCell = (long long)0x8000000000000000ull;   // "this lane adds nothing" (a cell index may be negative: the own cell can lie outside the grid)
+template <typename T>
+FPX_DEV void wave_kernel_add(T *base, long long c0, int numx, int dix, int djy, T w00, T w10, T w01, T w11) {
+  const bool valid = c0 != kNoCell;
+  unsigned long long rem = __ballot(valid);
+  if (rem == 0ull) return;
+  const int lane = (int)(threadIdx.x & 63);
+  for (int round = 0; rem != 0ull; round++) {      // wave-uniform
+    const int lead = __ffsll((unsigned long long)rem) - 1;
+    const long long ref = __shfl(c0, lead);
+    // (a cloud that is not cell-sorted has a wave's lanes in as many cells: after a few groups the rest goes one by one)
+    const bool in = valid && ((rem >> lane) & 1ull) && (c0 == ref || round >= 6);
+    const unsigned long long gm = __ballot(in);
+    rem &= ~gm;
+    if (__popcll(gm) <= 2 || round >= 6) {   // not worth the reductions
+      if (in) {
+        if (w00 != (T)0) atomicAdd(base + c0, w00);
+        if (w10 != (T)0) atomicAdd(base + c0 + dix, w10);
+        if (w01 != (T)0) atomicAdd(base + c0 + (long long)djy * numx, w01);
+        if (w11 != (T)0) atomicAdd(base + c0 + (long long)djy * numx + dix, w11);
+      }
+      continue;
+    }
+    T mine = (T)0;             // lane b < 9: the sum of bin b = (bx + 1) + 3 (by + 1)
+#pragma unroll
+    for (int b = 0; b < 9; b++) {
+      const int bx = b % 3 - 1, by = b / 3 - 1;
+      T v = (T)0;
+      if (in) {
+        if (bx == 0 && by == 0) v = w00;
+        else if (by == 0) v = bx == dix ? w10 : (T)0;
+        else if (bx == 0) v = by == djy ? w01 : (T)0;
+        else v = (bx == dix && by == djy) ? w11 : (T)0;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == b) mine = v;
+    }
+    if (lane < 9 && mine != (T)0) atomicAdd(base + ref + (lane % 3 - 1) + (long long)(lane / 3 - 1) * numx, mine);
+  }
+}
+
 // Guard without a counterpart in the reference: a particle older than lage(nageclass) (nage = nageclass+1 after the
 // loop; possible only before its first epilogue, e.g. after a warm start), an uncertainty class outside 1..nclassunc
 // or a release point outside 1..maxpointspec_act would address planes outside the grids; such a particle is not sampled.
@@ -2590,10 +2674,14 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
       // the base is wave-uniform, the whole (cell, level, species, point, class, age) offset is the per-lane index:
       // lanes are merged into one atomic only when all of it agrees
       const long long o = off + sstride * ks;
-      wave_run_add<R>(G.grid, o + (long long)jy * G.numx + ix, direct ? m : m * (wx * wy), inside && okx && oky);
-      wave_run_add<R>(G.grid, o + (long long)jyp * G.numx + ix, m * (wx * (K(1.) - wy)), inside && !direct && okx && okyp);
-      wave_run_add<R>(G.grid, o + (long long)jyp * G.numx + ixp, m * ((K(1.) - wx) * (K(1.) - wy)), inside && !direct && okxp && okyp);
-      wave_run_add<R>(G.grid, o + (long long)jy * G.numx + ixp, m * ((K(1.) - wx) * wy), inside && !direct && okxp && oky);
+      // (the weights of targets outside the grid are zero; a particle whose own cell lies outside still feeds the
+      // neighbours that lie inside, as in the reference: c0 may then address a cell that is never written)
+      const bool any = inside && ((okx && oky) || (!direct && (okxp || okyp)));
+      wave_kernel_add<R>(G.grid, any ? o + (long long)jy * G.numx + ix : kNoCell, G.numx, ixp - ix, jyp - jy,
+                         (okx && oky) ? (direct ? m : m * (wx * wy)) : K(0.),
+                         (!direct && okxp && oky) ? m * ((K(1.) - wx) * wy) : K(0.),
+                         (!direct && okx && okyp) ? m * (wx * (K(1.) - wy)) : K(0.),
+                         (!direct && okxp && okyp) ? m * ((K(1.) - wx) * (K(1.) - wy)) : K(0.));
     }
   }
   // concentrations at receptor points, parabolic kernel: conccalc.f90:451-498.  The reference sums the
@@ -2807,14 +2895,14 @@ FPX_DEV void wetdepo_scatter(const View<R> &V, const GridP<R> &Gp0, int nunc, R 
   const long long g = on ? plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1)))) : 0;
   const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
   const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
-  if (!Gp.lusekerneloutput) {   // wave-uniform
-    wave_run_add<float>(Gp.wetgridunc, g + (long long)jy * Gp.numxgrid + ix, (float)deposit, on && okx && oky);
-    return;
-  }
-  wave_run_add<float>(Gp.wetgridunc, g + (long long)jy * Gp.numxgrid + ix, (float)(deposit * (wx * wy)), on && okx && oky);
-  wave_run_add<float>(Gp.wetgridunc, g + (long long)jyp * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * (K(1.) - wy))), on && okxp && okyp);
-  wave_run_add<float>(Gp.wetgridunc, g + (long long)jy * Gp.numxgrid + ixp, (float)(deposit * ((K(1.) - wx) * wy)), on && okxp && oky);
-  wave_run_add<float>(Gp.wetgridunc, g + (long long)jyp * Gp.numxgrid + ix, (float)(deposit * (wx * (K(1.) - wy))), on && okx && okyp);
+  // (every lane of the wave is here: k_wetdepo keeps its waves convergent for the neighbourhood sums of wave_kernel_add)
+  const bool kern = Gp.lusekerneloutput != 0;   // wave-uniform
+  const bool any = on && ((okx && oky) || (kern && (okxp || okyp)));
+  wave_kernel_add<float>(Gp.wetgridunc, any ? g + (long long)jy * Gp.numxgrid + ix : kNoCell, Gp.numxgrid, ixp - ix, jyp - jy,
+                         (okx && oky) ? (kern ? (float)(deposit * (wx * wy)) : (float)deposit) : 0.f,
+                         (kern && okxp && oky) ? (float)(deposit * ((K(1.) - wx) * wy)) : 0.f,
+                         (kern && okx && okyp) ? (float)(deposit * (wx * (K(1.) - wy))) : 0.f,
+                         (kern && okxp && okyp) ? (float)(deposit * ((K(1.) - wx) * (K(1.) - wy))) : 0.f);
 }
 
 #undef K

@@ -48,6 +48,9 @@ constexpr int kBlock = 256;
 #ifndef FPX_PREP_WAVES
 #define FPX_PREP_WAVES 3   // register budget (waves per SIMD) of k_prep (<= 168 VGPRs)
 #endif
+#ifndef FPX_POLAR_PREP_3WAVES
+#define FPX_POLAR_PREP_3WAVES 1   // the polar instance of k_prep at the three-wave register budget (the polar move is out of line: polar_move)
+#endif
 #ifndef FPX_FINISH_WAVES
 #define FPX_FINISH_WAVES 2 // register budget of k_pbl_finish
 #endif
@@ -516,7 +519,7 @@ struct PblRec {
 // (<= 168 VGPRs, no scratch); the variants that also carry initialize(), the polar maps or the nest table would spill at
 // that budget and keep two waves.
 template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, (INIT || POLAR || NEST || DRYDEP) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock, (INIT || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
                                                  unsigned int *__restrict__ pbl_count) {
   constexpr bool MOTHER = !POLAR && !NEST;
@@ -1670,8 +1673,11 @@ __global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V, GridP<R> Gp, WetP
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
-  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= numpart) return;
+  // every lane stays to the end (the wave-level sums of wetdepo_scatter need convergent waves): `live` says whether the lane
+  // holds a particle that is scavenged at all
+  const long long s0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  bool live = s0 < numpart;
+  const long long s = live ? s0 : 0;
   // the particle's state in ONE memory round trip (as in k_conccalc)
   int itra1 = P.itra1[s], itramem = P.itramem[s], nunc = P.nclass[s];
   int kp = Gp.ioutputforeachrelease == 1 ? P.npoint[s] : 1;
@@ -1683,22 +1689,25 @@ __global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V, GridP<R> Gp, WetP
   static_assert(kMaxSpec == 5, "the tie below names five species");
   asm volatile("" : "+v"(itra1), "+v"(itramem), "+v"(nunc), "+v"(kp), "+v"(xt), "+v"(yt), "+v"(zt),
                     "+v"(xm_all[0]), "+v"(xm_all[1]), "+v"(xm_all[2]), "+v"(xm_all[3]), "+v"(xm_all[4]));
-  if (itra1 == kDead) return;
-  if (V.ldirect == 1) { if (itra1 > itime) return; } else { if (itra1 < itime) return; }
-  if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) return;
+  if (itra1 == kDead) live = false;
+  if (V.ldirect == 1) { if (itra1 > itime) live = false; } else { if (itra1 < itime) live = false; }
+  if (!(xt >= 0. && xt <= (double)V.nxmin1 && yt >= 0. && yt <= (double)V.nymin1) || !(zt == zt)) live = false;
+  if (!live) { xt = 0.; yt = 0.; zt = (R)0; }      // a harmless position for the lanes that only take part in the sums
   const int ldeltat = itime <= loutnext ? itime - (loutnext - Gp.loutstep) : itime - loutnext;   // wetdepo.f90:58-62
   const int nage = ageclass(Gp, abs(itra1 - itramem));
   const R smallnum = sizeof(R) == 4 ? (R)1.17549435e-38f : (R)2.2250738585072014e-308;
   for (int ks = 0; ks < V.nspec; ks++) {
     if (!Wp.wetdepspec[ks]) continue;
     R grfr = (R)0;
-    const R wetscav = get_wetscav(V, Wp, hgt, itime, ltsample, xt, yt, zt, ks, grfr);
-    const R xm = pick(xm_all, ks);
     R wetdeposit = (R)0;
-    if (wetscav > (R)0) wetdeposit = xm * ((R)1 - m_exp(-wetscav * (R)abs(ltsample))) * grfr;
-    const R restmass = xm - wetdeposit;
-    P.xmass1[(size_t)ks * P.cap + s] = restmass > smallnum ? restmass : (R)0;
-    if (V.decay[ks] > (R)0) wetdeposit = wetdeposit * m_exp((R)abs(ldeltat) * V.decay[ks]);
+    if (live) {
+      const R wetscav = get_wetscav(V, Wp, hgt, itime, ltsample, xt, yt, zt, ks, grfr);
+      const R xm = pick(xm_all, ks);
+      if (wetscav > (R)0) wetdeposit = xm * ((R)1 - m_exp(-wetscav * (R)abs(ltsample))) * grfr;
+      const R restmass = xm - wetdeposit;
+      P.xmass1[(size_t)ks * P.cap + s] = restmass > smallnum ? restmass : (R)0;
+      if (V.decay[ks] > (R)0) wetdeposit = wetdeposit * m_exp((R)abs(ldeltat) * V.decay[ks]);
+    }
     if (V.ldirect == 1 && Gp.on) wetdepo_scatter(V, Gp, nunc, wetdeposit, ks, (R)xt, (R)yt, nage, kp);
     if (V.ldirect == 1 && Gp.on && Gp.nested) wetdepo_scatter(V, Gp, nunc, wetdeposit, ks, (R)xt, (R)yt, nage, kp, true);   // wetdepo.f90:142
   }
@@ -1969,6 +1978,7 @@ struct Engine : EngineBase {
     V.xglobal = cfg.xglobal; V.nglobal = cfg.nglobal; V.sglobal = cfg.sglobal;
     V.switchnorthg = (R)cfg.switchnorthg; V.switchsouthg = (R)cfg.switchsouthg;
     for (int i = 0; i < 9; i++) { V.northpolemap[i] = (R)cfg.northpolemap[i]; V.southpolemap[i] = (R)cfg.southpolemap[i]; }
+    V.polemaps = nullptr;   // allocated below, with the other device arrays
     V.ldirect = cfg.ldirect; V.lsynctime = cfg.lsynctime; V.method = cfg.method; V.mintime = cfg.mintime;
     V.ifine = cfg.ifine; V.turbswitch = cfg.turbswitch; V.cblflag = cfg.cblflag; V.mdomainfill = cfg.mdomainfill;
     V.lsettling = cfg.lsettling; V.nspec = cfg.nspec; V.drydep = cfg.drydep;
@@ -1996,6 +2006,13 @@ struct Engine : EngineBase {
     R *p;
     int rc;
     if ((rc = dalloc(&p, cfg.nz))) return rc; V.height = p;
+    {
+      R maps[18];
+      for (int i = 0; i < 9; i++) { maps[i] = V.northpolemap[i]; maps[9 + i] = V.southpolemap[i]; }
+      if ((rc = dalloc(&p, 18))) return rc;
+      HIPCHK(hipMemcpy(p, maps, sizeof(maps), hipMemcpyHostToDevice));
+      V.polemaps = p;
+    }
     if ((rc = dalloc(&p, nlev * 6))) return rc; V.w3 = p;
     HIPCHK(hipMemsetAsync(p, 0, nlev * 6 * sizeof(R), stream));
     if (cfg.nglobal || cfg.sglobal) {
