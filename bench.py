@@ -240,6 +240,57 @@ def live_valu(args, kernel, avg_ms, launch_work, group=1):
         shutil.rmtree(d, ignore_errors=True)
 
 
+# cycles per wave64 instruction per SIMD, measured on this part with tools/valu_rates.hip (profiles/r4/valu_rates.txt)
+VALU_CLASS_CYCLES = {"ADD_F32": 2.4, "MUL_F32": 2.4, "FMA_F32": 3.6, "TRANS_F32": 8.2, "INT32": 2.4, "INT64": 4.3, "CVT": 4.2,
+                     "ADD_F64": 4.5, "MUL_F64": 4.5, "FMA_F64": 4.5, "TRANS_F64": 16.2}
+VALU_OTHER_CYCLES = 2.4     # moves, compares, selects, cross-lane: the cheapest class (an underestimate for 64-bit moves and VOP3 forms)
+
+
+def live_valu_classes(args, kernel, avg_ms, valu, group=1):
+    """VALU issue time of the dominant kernel from the per-class instruction counters (SQ_INSTS_VALU_ADD_F32 ... TRANS_F64) of
+    two more counter passes over the same command, each class priced at its measured issue cost.  Unlike the quad-cycle
+    counter SQ_ACTIVE_INST_VALU -- which charges every instruction at least four cycles and so exceeds the launch for a
+    kernel of 2.4-cycle f32 instructions -- this gives a distance-to-limit figure for the f32 engine too."""
+    import csv, glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None or "error" in valu:
+        return {"error": "no counter pass"}
+    sets = [["SQ_INSTS_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_INT32"],
+            ["SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"]]
+    counts = {}
+    for ctrs in sets:
+        d = tempfile.mkdtemp(prefix="fpx_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+        try:
+            cmd = ["rocprofv3", "--pmc"] + ctrs + ["--output-format", "csv", "-d", d, "--"] + child_bench_cmd(args)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=600)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return {"error": f"class counter pass failed (rc {r.returncode}): {r.stderr[-300:]}"}
+            per = {}
+            for row in csv.DictReader(open(files[0])):
+                if kernel + "<" in row["Kernel_Name"]:
+                    e = per.setdefault(row["Dispatch_Id"], {"id": int(row["Dispatch_Id"])})
+                    e[row["Counter_Name"]] = float(row["Counter_Value"])
+            disp = step_groups(list(per.values()), group)
+            if not disp:
+                return {"error": f"no dispatch of {kernel} in the class counter pass"}
+            key = ctrs[0]
+            disp.sort(key=lambda e: e.get(key, 0.0))
+            counts.update({k: v for k, v in disp[len(disp) // 2 if len(disp) > 2 else 0].items()})
+        except Exception as ex:
+            return {"error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    total = counts.get("SQ_INSTS_VALU", 0.0)
+    by_class = {k: counts.get("SQ_INSTS_VALU_" + k, 0.0) for k in VALU_CLASS_CYCLES}
+    other = max(total - sum(by_class.values()), 0.0)
+    cycles = sum(by_class[k] * c for k, c in VALU_CLASS_CYCLES.items()) + other * VALU_OTHER_CYCLES
+    clk = (valu.get("clock_ghz_under_pmc") or 2.4) * 1e9
+    issue_ms = cycles / N_SIMD / clk * 1e3
+    return {"insts_by_class_per_launch": dict(by_class, OTHER=other), "cycles_per_class": dict(VALU_CLASS_CYCLES, OTHER=VALU_OTHER_CYCLES),
+            "issue_ms": issue_ms, "frac_of_launch": issue_ms / avg_ms,
+            "note": "wave-instructions of each class x its measured issue cost (tools/valu_rates.hip), summed over the SIMDs; unclassified instructions at the cheapest rate"}
+
+
 def cpu_baseline(args, sc, frac_pbl):
     """The reference itself (oracle/_ref, flang build of the unmodified Fortran) timed on this
     box's host cores on a bounded sample of the same workload; 1 core (the reference hot path
@@ -466,6 +517,8 @@ def main():
         # after the engine has released the GPU: the counter pass runs the same workload in a child process
         grp = n_slices if dom == 1 else 1
         out["roofline"]["valu"] = live_valu(args, dom_name, avg_ms, nsteps_local / max(launches, 1), grp)
+        if dom == 1:
+            out["roofline"]["valu"]["by_class"] = live_valu_classes(args, dom_name, avg_ms, out["roofline"]["valu"], grp)
         t_live, raw = live_traffic(args, dom_name, grp)
         if t_live is not None:
             out["roofline"]["traffic"] = t_live

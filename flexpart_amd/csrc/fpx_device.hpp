@@ -2373,7 +2373,9 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
 // label 99 to the end: advance.f90:728-985.  Returns nstop (0 or 3).
 // POLAR = false compiles the stereographic-map branch out (grids without poles)
 // LATE: a callable that issues the caller's loads with the last column of the Petterssen gather (see interp_wind)
-template <typename R, typename RNG, bool POLAR = true, bool MOTHER = false, typename LATE = NoLate>
+// CAPCHECK (with MOTHER): the grid has polar caps, this particle started outside them -- the grid test after the move
+// still has to see a particle that has entered one
+template <typename R, typename RNG, bool POLAR = true, bool MOTHER = false, typename LATE = NoLate, bool CAPCHECK = false>
 FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, PState<R> &P, AdvCtx<R> &A,
                        R usig, R vsig, R wsig, const LATE &late = LATE()) {
   const R eps = V.eps;
@@ -2409,7 +2411,7 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
   // Petterssen correction, advance.f90:829-985
   if (P.ldt != abs(V.lsynctime)) { late(); return 0; }
   if (abs(itime + P.ldt * V.ldirect) > abs(V.memtime1)) { late(); return 0; }
-  if (pick_grid<R, MOTHER>(V, P.xt, P.yt) != A.ngrid) { late(); return 0; }
+  if ((MOTHER && CAPCHECK ? pick_polar(V, P.yt) : pick_grid<R, MOTHER>(V, P.xt, P.yt)) != A.ngrid) { late(); return 0; }
   R xr, yr;
   int nyrows = V.ny, nxcols = V.nx;
   if (A.ngrid > 0) {   // advance.f90:862-866

@@ -61,7 +61,7 @@ constexpr int kBlock = 256;
 #define FPX_LOOP_WAVES 3   // waves per SIMD the Langevin kernel is register-budgeted for (<= 168 VGPRs)
 #endif
 #ifndef FPX_COST_BUCKETS
-#define FPX_COST_BUCKETS 1   // the work list orders each class by the expected number of passes, longest first (k_prep)
+#define FPX_COST_BUCKETS -1  // the work list orders each class by the expected number of passes, longest first (k_prep): -1 = for clouds below 5e7 particles
 #endif
 #ifndef FPX_SLICE_SCHEDULE
 #define FPX_SLICE_SCHEDULE 0   // pass budgets of the successive launches of the Langevin kernel, 0 = none; one entry = ONE launch (measured best)
@@ -518,43 +518,16 @@ struct PblRec {
 // Register budget: the steady-state kernel of a run on the mother lat-lon grid is built for FPX_PREP_WAVES waves per SIMD
 // (<= 168 VGPRs, no scratch); the variants that also carry initialize(), the polar maps or the nest table would spill at
 // that budget and keep two waves.
-template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, (INIT || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
-                                                 unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
-                                                 unsigned int *__restrict__ pbl_count) {
+// The particle's step from the point where it is known to be due and inside the grid: initialize() if new, the boundary-layer
+// test, the set-up of a boundary-layer particle or the whole step of one above it.  A function of its own so that k_prep can
+// hold two instances: on a grid with polar caps (POLAR) the waves none of whose particles sits in a cap run the mother-grid
+// instance (POLAR = false: compile-time ngrid = 0, field pointers in scalar registers, no stereographic code) with CAPCHECK
+// (the test of advance.f90:843 still sees a particle that has moved INTO a cap); only the waves of the caps run the polar one.
+template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST, bool CAPCHECK>
+__device__ __forceinline__ void prep_body(const View<R> &V, const GridP<R> &Gp, Parts<R> &P, const SeqRng &S, const PblRec<R> &Q, long long s, int itime,
+                                          unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag, const R *hgt,
+                                          PState<R> &ps, int itramem, unsigned int pid) {
   constexpr bool MOTHER = !POLAR && !NEST;
-  __shared__ R hgt[kMaxNz];
-  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
-  __syncthreads();
-  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= numpart) return;
-  // the position travels in the same memory round trip as the due test (nearly every particle is due)
-  PState<R> ps;
-  const int itra1_in = P.itra1[s];
-  ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
-  int itramem = P.itramem[s];
-  unsigned int pid = P.pid[s];
-  // ONE round trip: without this the compiler sinks each load into the branch that first needs it (itra1 -> wait -> xt ->
-  // wait -> yt -> wait -> zt ...: five dependent round trips at the head of a latency-bound kernel)
-  {
-    int due_key = itra1_in;
-    asm volatile("" : "+v"(due_key), "+v"(ps.xt), "+v"(ps.yt), "+v"(ps.zt), "+v"(itramem), "+v"(pid));
-    if (due_key != itime) { pbl_flag[s] = kKeyNotDue; return; }    // timemanager.f90:537
-  }
-  // key kKeyNotDue = not due; kKeyDone = due, finished in this kernel (above the PBL); 8 (c - 1) + 0..7 = PBL particle of regime
-  // class c = 1..4, cost bucket 7..0 (see below).
-  // The counts (particles due, length of the PBL work list) are read off the sorted keys by
-  // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
-
-  // a non-finite or out-of-grid position would index outside the fields (the reference
-  // would read arbitrary memory): terminate the particle instead
-  if (!(ps.xt >= 0. && ps.xt <= (double)V.nxmin1 && ps.yt >= 0. && ps.yt <= (double)V.nymin1) || !(ps.zt == ps.zt)) {
-    P.itra1[s] = kDead;
-    pbl_flag[s] = kKeyDone;
-    atomicAdd(&st->n_badpos, 1ull);
-    return;
-  }
-
   Rng<R> G;
   make_rng(V, pid, step, G);
   const bool is_new = INIT && ((itramem == itime) || (itime == 0));   // timemanager.f90:553
@@ -641,12 +614,59 @@ __global__ void __launch_bounds__(kBlock, (INIT || NEST || DRYDEP || (POLAR && !
   above_step<R, Rng<R>, true>(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig, late);
   // (fetching the epilogue's npoint / xmass1 with the Petterssen gather was tried here: the three registers spill at the
   // three-wave budget of this kernel; k_pbl_finish has them)
-  const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
+  const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER, NoLate, CAPCHECK>(V, hgt, G, itime, ps, A, usig, vsig, wsig);
   R prob[kMaxSpec];
 #pragma unroll
   for (int ks = 0; ks < kMaxSpec; ks++) prob[ks] = (R)0;
   if (is_new) epilogue_store<R, DRYDEP, true>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
   else epilogue_store<R, DRYDEP, false>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st);
+}
+
+template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
+__global__ void __launch_bounds__(kBlock, (INIT || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+                                                 unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
+                                                 unsigned int *__restrict__ pbl_count) {
+  __shared__ R hgt[kMaxNz];
+  for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
+  __syncthreads();
+  long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= numpart) return;
+  // the position travels in the same memory round trip as the due test (nearly every particle is due)
+  PState<R> ps;
+  const int itra1_in = P.itra1[s];
+  ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = P.zt[s];
+  int itramem = P.itramem[s];
+  unsigned int pid = P.pid[s];
+  // ONE round trip: without this the compiler sinks each load into the branch that first needs it (itra1 -> wait -> xt ->
+  // wait -> yt -> wait -> zt ...: five dependent round trips at the head of a latency-bound kernel)
+  {
+    int due_key = itra1_in;
+    asm volatile("" : "+v"(due_key), "+v"(ps.xt), "+v"(ps.yt), "+v"(ps.zt), "+v"(itramem), "+v"(pid));
+    if (due_key != itime) { pbl_flag[s] = kKeyNotDue; return; }    // timemanager.f90:537
+  }
+  // key kKeyNotDue = not due; kKeyDone = due, finished in this kernel (above the PBL); 8 (c - 1) + 0..7 = PBL particle of regime
+  // class c = 1..4, cost bucket 7..0 (see below).
+  // The counts (particles due, length of the PBL work list) are read off the sorted keys by
+  // k_list_counts: one atomic per wave on a single address costs more than the whole kernel.
+
+  // a non-finite or out-of-grid position would index outside the fields (the reference
+  // would read arbitrary memory): terminate the particle instead
+  if (!(ps.xt >= 0. && ps.xt <= (double)V.nxmin1 && ps.yt >= 0. && ps.yt <= (double)V.nymin1) || !(ps.zt == ps.zt)) {
+    P.itra1[s] = kDead;
+    pbl_flag[s] = kKeyDone;
+    atomicAdd(&st->n_badpos, 1ull);
+    return;
+  }
+
+  if (POLAR && !NEST) {
+    // wave-uniform: does any particle of this wave start in a polar cap (advance.f90:161-164)?  The slots are cell-sorted, so
+    // five waves in six of a global run do not
+    if (!__any(pick_polar(V, ps.yt) != 0)) {
+      prep_body<R, DRYDEP, INIT, false, false, true>(V, Gp, P, S, Q, s, itime, step, st, pbl_flag, hgt, ps, itramem, pid);
+      return;
+    }
+  }
+  prep_body<R, DRYDEP, INIT, POLAR, NEST, false>(V, Gp, P, S, Q, s, itime, step, st, pbl_flag, hgt, ps, itramem, pid);
 }
 
 // ---------------------------------------------------------------------------
@@ -1482,77 +1502,96 @@ __global__ void k_math_probe(int fn, const double *__restrict__ x, double *__res
   y[i] = r;
 }
 
-// completion of the PBL particles: label 700 if the particle left the PBL, sigmas for the
-// mesoscale term, label 99 to the end of advance(), epilogue.  One thread per list entry.
+// completion of ONE boundary-layer particle: label 700 if it left the PBL, sigmas for the mesoscale term, label 99 to the end
+// of advance(), epilogue.  A function of its own for the same reason as prep_body: on a grid with polar caps the waves without
+// a particle in a cap run the mother-grid instance (POLAR = false, CAPCHECK), the others the polar one.
+template <typename R, bool DRYDEP, bool POLAR, bool NEST, bool CAPCHECK>
+__device__ __forceinline__ void finish_body(const View<R> &V, const GridP<R> &Gp, Parts<R> &P, unsigned int s, const PblRecord<R> &rec, R tdep,
+                                            int itime, unsigned int step, Stats *st, const R *hgt) {
+  constexpr bool MOTHER = !POLAR && !NEST;
+  const int pk = rec.i[2];
+  PState<R> ps;
+  ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = rec.v[4];
+  ps.up = rec.v[5]; ps.vp = rec.v[6]; ps.wp = rec.v[7];
+  ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
+  ps.ldt = rec.i[1]; ps.icbt = (short)pbl_icbt(pk);
+  Rng<R> G;
+  make_rng(V, P.pid[s], step, G);
+  const TimeW<R> W = time_weights(V, itime);
+  AdvCtx<R> A;
+  {
+    // same cell as at entry: the horizontal position does not change inside the loop
+    AdvCtx<R> A0;
+    adv_begin<R, MOTHER>(V, ps.xt, ps.yt, ps.zt, itime, 0, A0);
+    A = A0;
+  }
+  if (V.lsettling) A.nsp = settling_species(V, P.npoint[s]);
+  A.dxsave = rec.v[0]; A.dysave = rec.v[1]; A.dawsave = rec.v[2]; A.dcwsave = rec.v[3];
+  A.u = rec.v[8]; A.v = rec.v[9]; A.w = rec.v[10];
+  A.nrand = rec.i[0]; A.itimec = itime + pbl_elapsed(pk) * V.ldirect;
+  const int rc = pbl_state(pk), indz = pbl_indz(pk);   // (every particle of the list is DONE or ESCAPED when the last time slice has run)
+  R usig = (R)0, vsig = (R)0, wsig = (R)0;
+  R prob[kMaxSpec];
+  {
+    Cell<R> C;
+    cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
+    if (rc == PBL_ESCAPED) {
+      above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
+    } else {
+      level_pair_sigma(V, fld_of(V, A.ngrid), C, W, indz, usig, vsig, wsig);   // advance.f90:604-606
+    }
+    // advance.f90:582-599 in closed form: prob(ks) = 1 - exp(-vdepo(ks) * T / (2*href)), T = the loop's sum of |dt| over the
+    // passes that ended below 2*href (pbl_pass); the deposition velocity of the particle's cell, as every pass saw it
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++) {
+      prob[ks] = (R)0;
+      if (DRYDEP && ks < V.nspec && V.drydepspec[ks]) {
+        const R vdepo = interp_vdep(V, fld_of(V, A.ngrid), C, W, ks);
+        prob[ks] = (R)1 - m_expp(-vdepo * tdep / ((R)2. * (R)15.));   // href = 15, par_mod.f90:76
+      }
+    }
+  }
+  // what the epilogue reads of the particle travels with the last gather
+  EpiPre<R> pre;
+  int itramem = 0;
+  unsigned int sl = s;
+  auto late_epi = [&]() {
+    asm volatile("" : "+v"(sl));
+    pre.template load<DRYDEP>(V, Gp, P, sl);
+    itramem = P.itramem[sl];
+  };
+  const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER, decltype(late_epi), CAPCHECK>(V, hgt, G, itime, ps, A, usig, vsig, wsig, late_epi);
+  epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st, &pre);
+}
+
+// completion of the PBL particles (finish_body).  One thread per list entry or slot.
 template <typename R, bool DRYDEP, bool POLAR, bool NEST>
 __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
-                                                       const unsigned char *__restrict__ pbl_key, long long numpart) {
-  // In SLOT order (every slot whose key of this step says "boundary layer"), not in the order of the work list: the list is
-  // grouped by class and cost bucket -- sixteen interleaved sub-sequences of the cell-sorted slots -- and following it cost
-  // this kernel half of its time again in scattered record and state accesses (0.58 -> 0.87 ms at 1.25e7 particles).  After
-  // a locality sort the boundary-layer particles of a column are consecutive slots, so the waves stay nearly full.
-  constexpr bool MOTHER = !POLAR && !NEST;
+                                                       const unsigned char *__restrict__ pbl_key, long long numpart,
+                                                       const unsigned int *__restrict__ pbl_list, const unsigned int *__restrict__ pbl_count) {
+  // Two orders.  pbl_list given: the work list (class by class, each class in slot = cell order): every lane busy.  With cost
+  // buckets in the list (32 interleaved sub-sequences of the cell-sorted slots) following it costs this kernel half of its
+  // time again in scattered record and state accesses (0.58 -> 0.87 ms at 1.25e7 particles); then pbl_list is null and the
+  // kernel goes through the SLOTS, taking those whose key of this step says "boundary layer": after a locality sort the
+  // boundary-layer particles of a column are consecutive slots, so the waves stay nearly full (0.77 ms).
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < numpart; i += (long long)gridDim.x * blockDim.x) {
-    if (pbl_key[i] >= kKeyDone) continue;
-    const unsigned int s = (unsigned int)i;
+  const long long nwork = pbl_list ? (long long)*pbl_count : numpart;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += (long long)gridDim.x * blockDim.x) {
+    unsigned int s;
+    if (pbl_list) s = pbl_list[i];
+    else {
+      if (pbl_key[i] >= kKeyDone) continue;
+      s = (unsigned int)i;
+    }
     const PblRecord<R> rec = Q.rec[s];
     const R tdep = DRYDEP ? Q.tdep[s] : (R)0;
-    const int pk = rec.i[2];
-    PState<R> ps;
-    ps.xt = P.xt[s]; ps.yt = P.yt[s]; ps.zt = rec.v[4];
-    ps.up = rec.v[5]; ps.vp = rec.v[6]; ps.wp = rec.v[7];
-    ps.usigold = P.us[s]; ps.vsigold = P.vs[s]; ps.wsigold = P.ws[s];
-    ps.ldt = rec.i[1]; ps.icbt = (short)pbl_icbt(pk);
-    Rng<R> G;
-    make_rng(V, P.pid[s], step, G);
-    const TimeW<R> W = time_weights(V, itime);
-    AdvCtx<R> A;
-    {
-      // same cell as at entry: the horizontal position does not change inside the loop
-      AdvCtx<R> A0;
-      adv_begin<R, MOTHER>(V, ps.xt, ps.yt, ps.zt, itime, 0, A0);
-      A = A0;
+    if (POLAR && !NEST && !__any(pbl_ngrid(rec.i[2]) < 0)) {   // wave-uniform: no particle of this wave sits in a polar cap
+      finish_body<R, DRYDEP, false, false, true>(V, Gp, P, s, rec, tdep, itime, step, st, hgt);
+      continue;
     }
-    if (V.lsettling) A.nsp = settling_species(V, P.npoint[s]);
-    A.dxsave = rec.v[0]; A.dysave = rec.v[1]; A.dawsave = rec.v[2]; A.dcwsave = rec.v[3];
-    A.u = rec.v[8]; A.v = rec.v[9]; A.w = rec.v[10];
-    A.nrand = rec.i[0]; A.itimec = itime + pbl_elapsed(pk) * V.ldirect;
-    const int rc = pbl_state(pk), indz = pbl_indz(pk);   // (every particle of the list is DONE or ESCAPED when the last time slice has run)
-    R usig = (R)0, vsig = (R)0, wsig = (R)0;
-    R prob[kMaxSpec];
-    {
-      Cell<R> C;
-      cell_setup(C, A.ix, A.jy, A.ixp, A.jyp, A.xr, A.yr);
-      if (rc == PBL_ESCAPED) {
-        above_step(V, hgt, G, W, itime, ps.xt, ps.yt, ps.zt, ps.wp, ps.ldt, A, usig, vsig, wsig);
-      } else {
-        level_pair_sigma(V, fld_of(V, A.ngrid), C, W, indz, usig, vsig, wsig);   // advance.f90:604-606
-      }
-      // advance.f90:582-599 in closed form: prob(ks) = 1 - exp(-vdepo(ks) * T / (2*href)), T = the loop's sum of |dt| over the
-      // passes that ended below 2*href (pbl_pass); the deposition velocity of the particle's cell, as every pass saw it
-#pragma unroll
-      for (int ks = 0; ks < kMaxSpec; ks++) {
-        prob[ks] = (R)0;
-        if (DRYDEP && ks < V.nspec && V.drydepspec[ks]) {
-          const R vdepo = interp_vdep(V, fld_of(V, A.ngrid), C, W, ks);
-          prob[ks] = (R)1 - m_expp(-vdepo * tdep / ((R)2. * (R)15.));   // href = 15, par_mod.f90:76
-        }
-      }
-    }
-    // what the epilogue reads of the particle travels with the last gather
-    EpiPre<R> pre;
-    int itramem = 0;
-    unsigned int sl = s;
-    auto late_epi = [&]() {
-      asm volatile("" : "+v"(sl));
-      pre.template load<DRYDEP>(V, Gp, P, sl);
-      itramem = P.itramem[sl];
-    };
-    const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER>(V, hgt, G, itime, ps, A, usig, vsig, wsig, late_epi);
-    epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st, &pre);
+    finish_body<R, DRYDEP, POLAR, NEST, false>(V, Gp, P, s, rec, tdep, itime, step, st, hgt);
   }
 }
 
@@ -1875,6 +1914,7 @@ struct Engine : EngineBase {
     long conv_scratch_mb = 0;
     int conv_one_lane = 0, conv_no_walk = 0, conv_rows_plain = 0;
     int pbl_drain_lanes = -1;                     // -1: the engine's default (FPX_DRAIN_LANES)
+    int pbl_cost_buckets = FPX_COST_BUCKETS;      // -1: by the size of this rank's cloud
     std::vector<int> pbl_slices;
   } opt;
   int drain_lanes() const { return opt.pbl_drain_lanes >= 0 ? opt.pbl_drain_lanes : FPX_DRAIN_LANES; }
@@ -1983,7 +2023,7 @@ struct Engine : EngineBase {
     V.ifine = cfg.ifine; V.turbswitch = cfg.turbswitch; V.cblflag = cfg.cblflag; V.mdomainfill = cfg.mdomainfill;
     V.lsettling = cfg.lsettling; V.nspec = cfg.nspec; V.drydep = cfg.drydep;
     V.turboff = cfg.turboff != 0; V.interpolhmix = cfg.interpolhmix != 0;
-    V.pbl_cost_buckets = FPX_COST_BUCKETS;
+    V.pbl_cost_buckets = 0;   // set per step (Engine::step)
     V.ctl = (R)cfg.ctl; V.fine = (R)1. / (R)cfg.ifine;   // readcommand.f90:271
     V.d_trop = (R)cfg.d_trop; V.d_strat = (R)cfg.d_strat; V.turbmesoscale = (R)cfg.turbmesoscale;
     for (int i = 0; i < FPX_MAXSPEC; i++) {
@@ -4372,6 +4412,12 @@ struct Engine : EngineBase {
       }
     }
     HIPCHK(hipMemsetAsync(d_pbl_ctr, 0, kCtrWords * sizeof(unsigned int), stream));
+    // Cost buckets in the work list (k_prep): pure scheduling, no effect on any result, so the rank's own particle count
+    // may decide.  They pay where particles per grid cell are few -- the shard one of eight GPUs runs: -4.5 % of the
+    // Langevin kernel at 1.25e7 particles -- and cost locality: at 1e8 on one GPU they gain under 1 % and take the kernel's
+    // HBM traffic from 1.04 to 2.4 times the algorithmic bytes (the level-pair fetches of neighbouring list entries no
+    // longer share cache lines).
+    V.pbl_cost_buckets = opt.pbl_cost_buckets >= 0 ? opt.pbl_cost_buckets : (numpart < 50000000ll ? 3 : 0);
     { const int rc = blend_winds(itime); if (rc) return rc; }      // its own kernel (k_blend_w3), ahead of the per-kernel events
     HIPCHK(hipEventRecord(ev.e[0], stream));
     if (P.xscav) {   // timemanager.f90:564-598, before the particle is moved
@@ -4412,9 +4458,10 @@ struct Engine : EngineBase {
     HIPCHK(hipEventRecord(ev.e[2], stream));
     {
       const bool polar = cfg.nglobal || cfg.sglobal, nest = V.numbnests > 0;
-      typedef void (*fin_fn)(View<R>, GridP<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned char *, long long);
+      typedef void (*fin_fn)(View<R>, GridP<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned char *, long long, const unsigned int *, const unsigned int *);
       const fin_fn f = (fin_fn)step_kernel_finish((int)sizeof(R), cfg.drydep != 0, polar, nest);
-      f<<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_flag, numpart);
+      f<<<fin_grid, kBlock, 0, stream>>>(V, Gp, P, Q, itime, step_counter, d_stats, d_pbl_flag, numpart,
+                                         V.pbl_cost_buckets ? (const unsigned int *)nullptr : d_pbl_list, d_pbl_ctr);
     }
     HIPCHK(hipEventRecord(ev.e[3], stream));
     HIPCHK(hipGetLastError());
@@ -4475,7 +4522,7 @@ struct Engine : EngineBase {
     if (n == "conv_one_lane") { if (!need_int(0)) goto bad; opt.conv_one_lane = iv != 0; return 0; }
     if (n == "conv_no_walk") { if (!need_int(0)) goto bad; opt.conv_no_walk = iv != 0; return 0; }
     if (n == "conv_rows_plain") { if (!need_int(0)) goto bad; opt.conv_rows_plain = iv != 0; return 0; }
-    if (n == "pbl_cost_buckets") { if (!need_int(0) || iv > 3) goto bad; V.pbl_cost_buckets = (int)iv; return 0; }   // 0 none, 1: four buckets, 2: two, 3: eight
+    if (n == "pbl_cost_buckets") { if (!is_int || iv < -1 || iv > 3) goto bad; opt.pbl_cost_buckets = (int)iv; return 0; }   // -1 automatic, 0 none, 1: four buckets, 2: two, 3: eight
     if (n == "pbl_drain_lanes") { if (!is_int || iv < -1 || iv > 64) goto bad; opt.pbl_drain_lanes = (int)iv; return 0; }
     if (n == "permute") {
       if (v == "auto") opt.permute = 0; else if (v == "direct") opt.permute = 1; else if (v == "staged") opt.permute = 2; else goto bad;

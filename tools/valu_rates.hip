@@ -93,6 +93,24 @@ KERNEL32_1(rcp_f32, "v_rcp_f32")
 KERNEL32_1(sqrt_f32, "v_sqrt_f32")
 KERNEL32_1(sin_f32, "v_sin_f32")
 
+// packed f32: two lanes' worth of f32 per 64-bit register pair and instruction (v_pk_fma_f32, v_pk_mul_f32, v_pk_add_f32):
+// does a two-particles-per-lane f32 fine loop issue at twice the scalar-f32 flop rate?
+#define KERNELPK(name, insn, nops)                                                  \
+  __global__ void k_##name(double *out, double a, double b) {                      \
+    double r0 = a + threadIdx.x, r1 = a * 2 + threadIdx.x, r2 = a * 3, r3 = a * 5; \
+    double c = b;                                                                   \
+    for (int i = 0; i < ITER; i++) {                                                \
+      REP8(asm volatile(insn " %0, %0, " nops "\n" insn " %1, %1, " nops "\n" insn " %2, %2, " nops "\n" insn " %3, %3, " nops \
+                        : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3) : "v"(c));)        \
+    }                                                                               \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r0 + r1 + r2 + r3;                \
+  }
+KERNELPK(pk_fma_f32, "v_pk_fma_f32", "%4, %4")
+KERNELPK(pk_mul_f32, "v_pk_mul_f32", "%4")
+KERNELPK(pk_add_f32, "v_pk_add_f32", "%4")
+KERNEL32(mul_f32, "v_mul_f32")
+KERNEL32(max_f32, "v_max_f32")
+
 // 64-bit results from 32-bit operands
 __global__ void k_mad_u64_u32(double *out, double a, double b) {
   unsigned long long r0 = (unsigned long long)a + threadIdx.x, r1 = r0 * 3u, r2 = r0 * 5u, r3 = r0 * 7u;
@@ -154,7 +172,7 @@ int main() {
 #define EC(n) {#n, k_##n, 4.0 * ITER}
     E(add_f64), E(mul_f64), E(fma_f64), E(min_f64), E(rcp_f64), E(rsq_f64), E(sqrt_f64), E(fract_f64), E(floor_f64), E(mov_b64),
     E(xor_b32), E(add_u32), E(mul_lo_u32), E(mul_hi_u32), E(mul_u32_u24), E(mad_u32_u24), E(mad_u64_u32), E(alignbit),
-    E(add_f32), E(fma_f32), E(exp_f32), E(log_f32), E(rcp_f32), E(sqrt_f32), E(sin_f32), E(cvt_f64_f32), E(cvt_f32_f64),
+    E(add_f32), E(mul_f32), E(max_f32), E(fma_f32), E(pk_fma_f32), E(pk_mul_f32), E(pk_add_f32), E(exp_f32), E(log_f32), E(rcp_f32), E(sqrt_f32), E(sin_f32), E(cvt_f64_f32), E(cvt_f32_f64),
     EC(c_div), EC(c_sqrt), EC(c_exp), EC(c_log), EC(c_erf), EC(c_pow), EC(c_expf)};
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (auto &t : ts) {
