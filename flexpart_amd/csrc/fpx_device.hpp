@@ -2101,6 +2101,9 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
   int nrand = A.nrand;
   const bool turbswitch = sw<TSW>(V.turbswitch);
   const bool cblflag = sw<CBLF>(V.cblflag == 1);
+  // turboff (com_mod.f90:778, .false. as shipped) exists in the general instance only: in the specialised kernels the two
+  // selects per fine sub-step it compiles to cost 1 % of the kernel; a run with turboff takes the general instance (loop_table)
+  const bool turboff = TSW < 0 && V.turboff != 0;
   Turb<R> T;
   T.ust = S.get(S_UST); T.wst = S.get(S_WST); T.ol = S.get(S_OL); T.h = h;
   T.sigw = K(0.); T.dsigw2dz = K(0.); T.dsigwdz = K(0.);   // only read if hanna1 meets zeta >= 1 (see hanna1)
@@ -2166,7 +2169,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
       R rv = S.expt(-dttlv);
       vp = rv * vp + g2 * T.sigv * m_sqrtp(K(1.) - rv * rv);
     }
-    if (__builtin_expect(V.turboff != 0, 0)) { up = K(0.); vp = K(0.); }   // advance.f90:464-467: zeroed in the fine loop, before :541-542 read them
+    if (turboff) { up = K(0.); vp = K(0.); }   // advance.f90:464-467: zeroed in the fine loop, before :541-542 read them
     S.put(S_UP, up); S.put(S_VP, vp);
     S.add(S_DAW, up * dt);   // advance.f90:541-542
     S.add(S_DCW, vp * dt);
@@ -2233,7 +2236,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
       delz = wp * dtf;
     }
 
-    if (__builtin_expect(V.turboff != 0, 0)) { wp = K(0.); delz = K(0.); }   // advance.f90:464-470 (turboff; the random numbers stay drawn)
+    if (turboff) { wp = K(0.); delz = K(0.); }   // advance.f90:464-470 (turboff; the random numbers stay drawn)
 
     // reflection at the ground / mixing height, advance.f90:476-491
     if (__builtin_expect(m_abs(delz) > h, 0)) delz = m_fmod(delz, h);

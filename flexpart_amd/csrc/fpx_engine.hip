@@ -1214,10 +1214,11 @@ __global__ void __launch_bounds__(256) k_count_live(const int *__restrict__ itra
 }
 // Counters of the step's work list (unsigned ints, zeroed at the start of every step):
 //   [0]     length of the whole list (all PBL particles; k_pbl_finish)
-//   [1..4]  first entry of the segment of stability class 1..4 (the list is sorted by class)
-//   [kCtrBase + 8 j + c], c = 0..3: launch j of the Langevin kernel: particles of class c + 1 in its list (they sit at the
-//           head of the class's segment); [kCtrBase + 8 j + 4 + c]: the chunk cursor of that class
-constexpr int kMaxSlices = 16, kCtrBase = 8, kCtrWords = kCtrBase + (kMaxSlices + 1) * 8;
+//   [kCtrBase + 12 j + ...]: launch j of the Langevin kernel (ONE pointer gives a launch everything it needs):
+//     + c,     c = 0..3: particles of stability class c + 1 in its list (they sit at the head of the class's segment)
+//     + 4 + c: the chunk cursor of that class
+//     + 8 + c: first entry of the class's segment in the list (the list is sorted by class; the same in every launch)
+constexpr int kMaxSlices = 16, kCtrBase = 8, kCtrStride = 12, kCtrWords = kCtrBase + (kMaxSlices + 1) * kCtrStride;
 __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, long long n, unsigned int *__restrict__ ctr, Stats *st) {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   long long upto[5];
@@ -1228,8 +1229,8 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
   if (threadIdx.x == 0) {
     ctr[0] = (unsigned int)npbl;
     for (int c = 1; c <= 4; c++) {
-      ctr[c] = (unsigned int)upto[c - 1];
       ctr[kCtrBase + c - 1] = (unsigned int)(upto[c] - upto[c - 1]);
+      for (int j = 0; j <= kMaxSlices; j++) ctr[kCtrBase + kCtrStride * j + 8 + c - 1] = (unsigned int)upto[c - 1];
     }
     st->n_due += (unsigned long long)ndue;
   }
@@ -1256,24 +1257,26 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
 // The last launch of the sequence has no next list (drain_lanes = 0, cap_passes = 0): it runs everything to the end.
 // A particle's random numbers are keyed on (particle number, step, draw index) and the draw index travels in the record:
 // suspending does not change a bit of the result (tests/test_gpu_parity.py::test_time_slices_do_not_change_a_bit).
-template <typename R, bool LEAN, int TSW, int CBLF, int RNGM>
+// SUSP = false: the instance of a step with ONE launch -- nothing can be suspended or resumed, and the refill, which runs with two
+// lanes of the wave, carries none of that (the hand-over of suspended particles cost 2 % of the kernel's instructions at 1e8).
+template <typename R, bool LEAN, int TSW, int CBLF, int RNGM, bool SUSP = false>
 __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                      const unsigned int *__restrict__ pbl_list,
-                                                     unsigned int *__restrict__ ctr,
-                                                     int launch,
+                                                     unsigned int *__restrict__ blk,
                                                      int cap_passes, int drain_lanes,
                                                      unsigned int *__restrict__ next_list) {
-  // this launch's list: per class c the first ncls[c] entries of the class's segment [coff[c], ...) of pbl_list
-  const unsigned int *mine = ctr + kCtrBase + 8 * launch;
-  unsigned int *cursor = ctr + kCtrBase + 8 * launch + 4;   // one per class
-  unsigned int *next_cnt = ctr + kCtrBase + 8 * (launch + 1);
-  const unsigned int n0 = mine[0], n1 = mine[1], n2 = mine[2], n3 = mine[3];
-  const unsigned int o0 = ctr[1], o1 = ctr[2], o2 = ctr[3], o3 = ctr[4];
+  // blk: this launch's block of the counters (see k_list_counts): per class c the first blk[c] entries of the class's segment
+  // [blk[8 + c], ...) of pbl_list, the class's chunk cursor blk[4 + c]; the next launch's block follows
+  const unsigned int *mine = blk;
+  unsigned int *next_cnt = blk + kCtrStride;
+  // (only the current class's length and segment start live in scalar registers, not all four: twelve registers through the
+  // whole kernel were taken from the polynomial constants of the fine loop, which then came back through v_readlane in
+  // every sub-step)
   // A short list (the later launches): only as many blocks as it fills take part, so that its waves are spread over the
   // CUs one block each instead of three to a SIMD on some and none on others (a pass of a wave alone on its SIMD takes a
   // third of the time).
-  if ((unsigned long long)blockIdx.x * kBlock >= (unsigned long long)n0 + n1 + n2 + n3) return;
-  const bool can_suspend = drain_lanes > 0 || cap_passes > 0;
+  if ((unsigned long long)blockIdx.x * kBlock >= (unsigned long long)mine[0] + mine[1] + mine[2] + mine[3]) return;
+  const bool can_suspend = SUSP && (drain_lanes > 0 || cap_passes > 0);
   // dynamic LDS: [S_COUNT][kBlock] stash (per-lane pass-level state, see Stash) + the height column,
   // sized by the host (loop_smem_bytes) so that three blocks fit one CU for the usual nz
   extern __shared__ __align__(16) unsigned char fpx_loop_smem[];
@@ -1298,13 +1301,19 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   // 64 entries per claim: with larger chunks (nlist/(8*nwaves) = 2000 entries at 1e8 was tried first) the kernel
   // ended half a chunk's worth of work -- tens of milliseconds -- after the list ran out, most waves idle;
   // measured 429 -> 395 ms.  One atomic per 64 refills is still negligible.
-  const unsigned int k0 = (n0 + 63u) >> 6, k1 = (n1 + 63u) >> 6, k2 = (n2 + 63u) >> 6, k3 = (n3 + 63u) >> 6;   // chunks per class
   unsigned int cur = 0, end = 0;     // wave-uniform: the unread part of the wave's chunk
   unsigned int cbase = 0;            // wave-uniform: first entry of the chunk
   unsigned int ahead = 0;            // lane l: entry cbase + l of the list (the whole chunk, read with the claim)
   bool out_of_chunks = false;        // wave-uniform
   int wcls = 0;                      // wave-uniform: class (0..3) the wave draws its particles from
-  bool cls_out = false;              // wave-uniform: that class has no chunk left
+  unsigned int cls_out = 0u;         // wave-uniform: that class has no chunk left
+  unsigned int cls_n = mine[0], cls_seg = mine[8];   // wave-uniform: length and first entry of that class's segment (read again when the wave moves on)
+  // The wave-uniform values that are only read where a chunk is claimed -- once per 64 particles -- are kept in VECTOR
+  // registers (the kernel has nine to spare; the empty asm makes them lane values for the compiler), not in scalar ones: the
+  // scalar file is what the fine loop's polynomial constants live in, and every scalar held across the loop came back as a
+  // v_readlane in each sub-step (+0.8 % VALU instructions at 1e8 with all of these in scalar registers).
+#define FPX_IN_VGPR(x) asm volatile("" : "+v"(x))
+  FPX_IN_VGPR(cbase); FPX_IN_VGPR(cls_out); FPX_IN_VGPR(cls_n); FPX_IN_VGPR(cls_seg);
 #ifdef FPX_LANE_STATS
   const unsigned long long t_s = wall_clock64();   // 100 MHz; timeline of the wave: start, list exhausted, end
   unsigned long long t_x = 0;
@@ -1340,7 +1349,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
     unsigned int base = 0;
     if (lane == 0) base = atomicAdd(next_cnt + wcls, (unsigned int)__popcll(sm));
     base = __builtin_amdgcn_readfirstlane(base);
-    const unsigned int seg = wcls == 0 ? o0 : wcls == 1 ? o1 : wcls == 2 ? o2 : o3;
+    const unsigned int seg = mine[8 + wcls];
     if (mine_goes) next_list[seg + base + (unsigned int)__popcll(sm & ((1ull << lane) - 1ull))] = s;
   };
 
@@ -1349,20 +1358,20 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
     unsigned long long need = __ballot(!have);
     if (need != 0ull && !out_of_chunks) {
       while (cur >= end && !out_of_chunks) {   // wave-uniform: take the next chunk of the wave's class
-        const unsigned int kk = wcls == 0 ? k0 : wcls == 1 ? k1 : wcls == 2 ? k2 : k3;
-        if (!cls_out) {
+        if (__builtin_amdgcn_readfirstlane(cls_out) == 0u) {
+          const unsigned int nseg = __builtin_amdgcn_readfirstlane(cls_n), seg = __builtin_amdgcn_readfirstlane(cls_seg);
+          const unsigned int kk = (nseg + 63u) >> 6;       // this class's length in chunks
           unsigned int c = 0;
-          if (lane == 0) c = atomicAdd(cursor + wcls, 1u);
+          if (lane == 0) c = atomicAdd(blk + 4 + wcls, 1u);
           c = __builtin_amdgcn_readfirstlane(c);
           if (c < kk) {
-            const unsigned int seg = wcls == 0 ? o0 : wcls == 1 ? o1 : wcls == 2 ? o2 : o3;
-            const unsigned int nseg = wcls == 0 ? n0 : wcls == 1 ? n1 : wcls == 2 ? n2 : n3;
-            cur = cbase = seg + c * 64u;
+            cur = seg + c * 64u;
+            cbase = cur; FPX_IN_VGPR(cbase);
             end = min(cur + 64u, seg + nseg);
-            ahead = pbl_list[min(cbase + (unsigned int)lane, end - 1u)];
+            ahead = pbl_list[min(cur + (unsigned int)lane, end - 1u)];
             break;
           }
-          cls_out = true;
+          cls_out = 1u; FPX_IN_VGPR(cls_out);
         }
         // The wave's class has no chunk left.  A launch that can hand particles on keeps the wave on what it holds -- no
         // refill, so no second class in the wave -- until fewer than drain_lanes lanes are busy, then suspends those and
@@ -1374,7 +1383,8 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
           need = ~0ull;
         }
         wcls++;
-        cls_out = false;
+        cls_out = 0u; FPX_IN_VGPR(cls_out);
+        if (wcls < 4) { cls_n = mine[wcls]; cls_seg = mine[8 + wcls]; FPX_IN_VGPR(cls_n); FPX_IN_VGPR(cls_seg); }
         if (wcls == 4) {
           out_of_chunks = true;
 #ifdef FPX_LANE_STATS
@@ -1396,21 +1406,21 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
           const PblRecord<R> *rp = Q.rec + s;
           const double l_xt = P.xt[s], l_yt = P.yt[s];
           const unsigned int l_pid = P.pid[s];
-          const int r_nrand = rp->i[0], r_ldt = rp->i[1], r_pk = rp->i[2];
+          const int r_nrand = rp->i[0], r_ldt = SUSP ? rp->i[1] : 0, r_pk = rp->i[2];
           const R r_ust = rp->v[8], r_wst = rp->v[9], r_ol = rp->v[10], r_trans = rp->v[11], r_h = rp->v[12];
           // a fresh particle's state is in the particle arrays, a suspended one's in its record: both are requested
           // (one round trip either way; suspended particles are the few)
           R l_zt = P.zt[s], l_wp = P.wp[s], l_up = P.up[s], l_vp = P.vp[s];
           int l_idt = P.idt[s];
           short l_cbt = P.cbt[s];
-          const R c_dx = rp->v[0], c_dy = rp->v[1], c_daw = rp->v[2], c_dcw = rp->v[3];
-          const R c_zt = rp->v[4], c_up = rp->v[5], c_vp = rp->v[6], c_wp = rp->v[7];
+          const R c_dx = SUSP ? rp->v[0] : (R)0, c_dy = SUSP ? rp->v[1] : (R)0, c_daw = SUSP ? rp->v[2] : (R)0, c_dcw = SUSP ? rp->v[3] : (R)0;
+          const R c_zt = SUSP ? rp->v[4] : (R)0, c_up = SUSP ? rp->v[5] : (R)0, c_vp = SUSP ? rp->v[6] : (R)0, c_wp = SUSP ? rp->v[7] : (R)0;
           int l_npoint = 0;
           if (!LEAN && V.lsettling) l_npoint = P.npoint[s];
           R c_tdep = (R)0;
-          if (!LEAN && V.drydep) c_tdep = Q.tdep[s];
+          if (SUSP && !LEAN && V.drydep) c_tdep = Q.tdep[s];
           __builtin_amdgcn_sched_barrier(0);   // every load above is issued before the first value is used
-          const bool resumed = pbl_state(r_pk) == PBL_CONTINUE;
+          const bool resumed = SUSP && pbl_state(r_pk) == PBL_CONTINUE;
           xt = l_xt; yt = l_yt; pid = l_pid;
           zt = resumed ? c_zt : l_zt; wp = resumed ? c_wp : l_wp;
           ldt = resumed ? r_ldt : l_idt;
@@ -1418,7 +1428,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
           {
             R ddx, ddy;
             adv_begin_known(V, xt, yt, pbl_ngrid(r_pk), r_h, A, ddx, ddy);
-            A.itimec = itime + pbl_elapsed(r_pk) * V.ldirect;   // FRESH: elapsed = 0
+            A.itimec = SUSP ? itime + pbl_elapsed(r_pk) * V.ldirect : itime;   // FRESH: elapsed = 0
             A.nrand = r_nrand;
             A.nsp = 0;
             if (!LEAN && V.lsettling) {
@@ -1437,7 +1447,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
           S.put(S_UP, resumed ? c_up : l_up); S.put(S_VP, resumed ? c_vp : l_vp);
           S.put(S_UST, r_ust); S.put(S_WST, r_wst); S.put(S_OL, r_ol);
           S.put(S_TRANS, (r_wst * r_wst * r_wst) * r_trans);   // (wst**3)*transition, cbl.f90:103-104
-          S.put(S_NPASS, (R)0);
+          if (SUSP) S.put(S_NPASS, (R)0);
           if (!LEAN && V.drydep) S.put(S_TDEP, resumed ? c_tdep : (R)0);
           have = true;
         }
@@ -1454,17 +1464,17 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
       make_rng(V, pid, step, G);
       int indz = 1;
       const int rc = pbl_pass<R, !LEAN, !LEAN, TSW, CBLF>(V, hgt, G, W, itime, xt, yt, zt, wp, ldt, icbt, A, S, indz, st);
-      const R npass = S.get(S_NPASS) + (R)1;
-      S.put(S_NPASS, npass);
+      R npass = (R)0;
+      if (SUSP) { npass = S.get(S_NPASS) + (R)1; S.put(S_NPASS, npass); }
       if (rc != PBL_CONTINUE) {
         FPX_LANES(st, 9);
         // the particle's state at the end of its last pass goes into its hand-over record: one contiguous line;
         // k_pbl_finish writes the particle arrays from it
         write_record(rc, indz);
         have = false;
-      } else over_budget = npass >= cap_r;
+      } else over_budget = SUSP && npass >= cap_r;
     }
-    if (cap_passes > 0) suspend(over_budget);
+    if (SUSP && cap_passes > 0) suspend(over_budget);
   }
 #ifdef FPX_LANE_STATS
   if (lane == 0) {
@@ -1839,7 +1849,7 @@ EngineBase *make_engine_f32(const fpx_config *cfg, int *rc);   // defined by the
 // engine as untyped host-stub addresses; the engine casts them to the kernel's signature (same headers, same layout).
 // real_bytes 8|4 picks the arithmetic type.
 const void *step_kernel_prep(int real_bytes, bool drydep, bool init, bool polar, bool nest);
-const void *step_kernel_loop(int real_bytes, bool lean, int turbswitch, int cblflag, int rng_mode);
+const void *step_kernel_loop(int real_bytes, bool lean, int turbswitch, int cblflag, int rng_mode, bool susp, bool *is_lean);
 const void *step_kernel_finish(int real_bytes, bool drydep, bool polar, bool nest);
 FPX_TU_OPEN
 
@@ -1906,7 +1916,7 @@ struct Engine : EngineBase {
   void *d_sort_tmp = nullptr;
   size_t sort_tmp_bytes = 0;
   Stats *d_stats = nullptr;
-  unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // ctr[2j] = length of the list of time slice j, ctr[2j+1] = its chunk cursor
+  unsigned int *d_pbl_list = nullptr, *d_pbl_ctr = nullptr;   // the counters of the work list and of the launches that go through it (layout: k_list_counts)
   unsigned int *d_surv[2] = {nullptr, nullptr};               // lists of the suspended particles (ping-pong between launches), allocated with the first sliced step
   std::vector<int> slice_caps;                                // pass budget of each launch of the Langevin kernel, the last one 0 (none)
   struct Options {                                            // fpx_set_option
@@ -4378,17 +4388,6 @@ struct Engine : EngineBase {
     }
     auto &ev = ev_pool[ev_used++];
     const int nb = (int)((numpart + kBlock - 1) / kBlock);
-    if (pbl_grid == 0) {
-      // persistent grid: as many blocks as the chip holds at this kernel's register budget
-      hipDeviceProp_t prop;
-      HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
-      int per_cu = 0;
-      HIPCHK(hipFuncSetAttribute((const void *)loop_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_smem_bytes()));
-      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, loop_smem_bytes()));
-      if (opt.pbl_blocks_per_cu > 0) per_cu = std::min(per_cu, opt.pbl_blocks_per_cu);   // experiments: fewer resident waves
-      pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
-      if (opt.verbose) fprintf(stderr, "[fpx] Langevin kernel: %d blocks per CU by the occupancy query, %zu B of dynamic LDS, grid %d\n", per_cu, loop_smem_bytes(), pbl_grid);
-    }
     // the pass budgets of the Langevin kernel's launches (time slices, k_pbl_loop); the last launch has none
     if (slice_caps.empty()) {
       if (!opt.pbl_slices.empty()) slice_caps = opt.pbl_slices;
@@ -4401,6 +4400,17 @@ struct Engine : EngineBase {
         int rc;
         for (int k = 0; k < 2; k++) if ((rc = dalloc(&d_surv[k], (size_t)P.cap))) return rc;
       }
+    }
+    if (pbl_grid == 0) {
+      // persistent grid: as many blocks as the chip holds at this kernel's register budget
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
+      int per_cu = 0;
+      HIPCHK(hipFuncSetAttribute((const void *)loop_kernel(), hipFuncAttributeMaxDynamicSharedMemorySize, (int)loop_smem_bytes()));
+      HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, loop_smem_bytes()));
+      if (opt.pbl_blocks_per_cu > 0) per_cu = std::min(per_cu, opt.pbl_blocks_per_cu);   // experiments: fewer resident waves
+      pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
+      if (opt.verbose) fprintf(stderr, "[fpx] Langevin kernel: %d blocks per CU by the occupancy query, %zu B of dynamic LDS, grid %d\n", per_cu, loop_smem_bytes(), pbl_grid);
     }
     {
       size_t need = 0;
@@ -4452,7 +4462,7 @@ struct Engine : EngineBase {
       // the last launch suspends nothing
       const bool last = j + 1 == slice_caps.size();
       const unsigned int *list = j == 0 ? d_pbl_list : d_surv[(j - 1) & 1];
-      loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, list, d_pbl_ctr, (int)j, last ? 0 : slice_caps[j],
+      loop_kernel()<<<pbl_grid, kBlock, loop_smem_bytes(), stream>>>(V, P, Q, itime, step_counter, d_stats, list, d_pbl_ctr + kCtrBase + kCtrStride * j, last ? 0 : slice_caps[j],
                                                                      last ? 0 : drain_lanes(), d_surv[j & 1]);
     }
     HIPCHK(hipEventRecord(ev.e[2], stream));
@@ -4472,7 +4482,7 @@ struct Engine : EngineBase {
       HIPCHK(hipStreamSynchronize(stream));
       fprintf(stderr, "[fpx] step %u: Langevin lists (per class)", step_counter);
       for (size_t j = 0; j < slice_caps.size(); j++) {
-        const unsigned int *m = hc + kCtrBase + 8 * j;
+        const unsigned int *m = hc + kCtrBase + kCtrStride * j;
         fprintf(stderr, " | %u %u %u %u", m[0], m[1], m[2], m[3]);
       }
       fprintf(stderr, "\n");
@@ -4542,6 +4552,7 @@ struct Engine : EngineBase {
       if ((int)caps.size() > kMaxSlices - 1) goto bad;
       opt.pbl_slices = caps;
       slice_caps.clear();
+      pbl_grid = 0;      // another instance of the kernel may run the next step
       return 0;
     }
   bad:
@@ -4572,12 +4583,26 @@ struct Engine : EngineBase {
   }
 
   // the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
-  typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, unsigned int *, int, int, int, unsigned int *);
-  // (the gas kernels -- LEAN instances of k_pbl_loop, see loop_table -- leave the aerosol slots of the stash out)
-  bool loop_is_lean() const { return !cfg.drydep && !cfg.lsettling && (cfg.turbswitch || cfg.cblflag != 1); }
-  size_t loop_smem_bytes() const { return sizeof(R) * ((size_t)(loop_is_lean() ? S_COUNT_LEAN : S_COUNT) * kStashStride + (size_t)cfg.nz); }
-  loop_fn loop_kernel() const {
-    return (loop_fn)step_kernel_loop((int)sizeof(R), !cfg.drydep && !cfg.lsettling, cfg.turbswitch, cfg.cblflag, cfg.rng_mode);
+  typedef void (*loop_fn)(View<R>, Parts<R>, PblRec<R>, int, unsigned int, Stats *, const unsigned int *, unsigned int *, int, int, unsigned int *);
+  // The kernel instance of this engine: by the run's switches, and by whether a step is one launch or several (time slices);
+  // the gas kernels -- LEAN instances, see loop_table -- leave the aerosol slots of the stash out of the block's LDS.
+  bool loop_sliced() const {
+    if (!slice_caps.empty()) return slice_caps.size() > 1;
+    if (!opt.pbl_slices.empty()) return opt.pbl_slices.size() > 1 || opt.pbl_slices.back() != 0;
+    if (cfg.pbl_slice_passes != 0) return cfg.pbl_slice_passes > 0;
+    const int d[] = {FPX_SLICE_SCHEDULE};
+    return sizeof(d) / sizeof(d[0]) > 1 || d[0] != 0;
+  }
+  loop_fn loop_kernel(bool *is_lean = nullptr) const {
+    bool lean = false;
+    const loop_fn f = (loop_fn)step_kernel_loop((int)sizeof(R), !cfg.drydep && !cfg.lsettling, cfg.turboff ? -1 : cfg.turbswitch, cfg.cblflag, cfg.rng_mode, loop_sliced(), &lean);
+    if (is_lean) *is_lean = lean;
+    return f;
+  }
+  size_t loop_smem_bytes() const {
+    bool lean = false;
+    (void)loop_kernel(&lean);
+    return sizeof(R) * ((size_t)(lean ? S_COUNT_LEAN : S_COUNT) * kStashStride + (size_t)cfg.nz);
   }
 
   int sync() override {
@@ -5208,18 +5233,28 @@ const void *step_kernel_prep_f32(bool drydep, bool init, bool polar, bool nest) 
 #endif
 #if FPX_TU_PART == 2 || FPX_TU_PART < 0
 // the Langevin kernel specialised for the run's switches (gases: LEAN) or the general one
-template <typename R>
-static const void *loop_table(bool lean, int turbswitch, int cblflag, int rng_mode) {
+template <typename R, bool SUSP>
+static const void *loop_table_s(bool lean, int turbswitch, int cblflag, int rng_mode, bool *is_lean) {
   const bool philox = rng_mode == FPX_RNG_PHILOX;
+  *is_lean = false;
+  if (turbswitch < 0) return (const void *)k_pbl_loop<R, false, -1, -1, -1, SUSP>;   // turboff: the general instance (it alone has the switch)
   if (lean) {
-    if (turbswitch && cblflag == 1) return philox ? (const void *)k_pbl_loop<R, true, 1, 1, 2> : (const void *)k_pbl_loop<R, true, 1, 1, 0>;
-    if (turbswitch && cblflag != 1) return philox ? (const void *)k_pbl_loop<R, true, 1, 0, 2> : (const void *)k_pbl_loop<R, true, 1, 0, 0>;
-    if (!turbswitch && cblflag != 1) return philox ? (const void *)k_pbl_loop<R, true, 0, 0, 2> : (const void *)k_pbl_loop<R, true, 0, 0, 0>;
+    *is_lean = true;
+    if (turbswitch && cblflag == 1) return philox ? (const void *)k_pbl_loop<R, true, 1, 1, 2, SUSP> : (const void *)k_pbl_loop<R, true, 1, 1, 0, SUSP>;
+    if (turbswitch && cblflag != 1) return philox ? (const void *)k_pbl_loop<R, true, 1, 0, 2, SUSP> : (const void *)k_pbl_loop<R, true, 1, 0, 0, SUSP>;
+    if (!turbswitch && cblflag != 1) return philox ? (const void *)k_pbl_loop<R, true, 0, 0, 2, SUSP> : (const void *)k_pbl_loop<R, true, 0, 0, 0, SUSP>;
+    *is_lean = false;
   } else if (philox) {   // aerosols (settling / dry deposition) with the counter RNG: same switch specialisation
-    if (turbswitch && cblflag == 1) return (const void *)k_pbl_loop<R, false, 1, 1, 2>;
-    if (turbswitch && cblflag != 1) return (const void *)k_pbl_loop<R, false, 1, 0, 2>;
+    if (turbswitch && cblflag == 1) return (const void *)k_pbl_loop<R, false, 1, 1, 2, SUSP>;
+    if (turbswitch && cblflag != 1) return (const void *)k_pbl_loop<R, false, 1, 0, 2, SUSP>;
   }
-  return (const void *)k_pbl_loop<R, false, -1, -1, -1>;   // (Engine::loop_is_lean mirrors which configurations get a LEAN instance)
+  return (const void *)k_pbl_loop<R, false, -1, -1, -1, SUSP>;
+}
+// (a step of several launches runs the SUSP twin of the SAME specialisation: the arithmetic of a particle must not depend on
+// how its step is scheduled -- two instances with different compile-time switches round differently)
+template <typename R>
+static const void *loop_table(bool lean, int turbswitch, int cblflag, int rng_mode, bool susp, bool *is_lean) {
+  return susp ? loop_table_s<R, true>(lean, turbswitch, cblflag, rng_mode, is_lean) : loop_table_s<R, false>(lean, turbswitch, cblflag, rng_mode, is_lean);
 }
 template <typename R>
 static const void *finish_table(bool drydep, bool polar, bool nest) {
@@ -5229,11 +5264,11 @@ static const void *finish_table(bool drydep, bool polar, bool nest) {
                : (nest ? (const void *)k_pbl_finish<R, false, false, true> : (const void *)k_pbl_finish<R, false, false, false>);
 }
 #if FPX_TU_REAL != 4
-const void *step_kernel_loop_f64(bool lean, int turbswitch, int cblflag, int rng_mode) { return loop_table<double>(lean, turbswitch, cblflag, rng_mode); }
+const void *step_kernel_loop_f64(bool lean, int turbswitch, int cblflag, int rng_mode, bool susp, bool *is_lean) { return loop_table<double>(lean, turbswitch, cblflag, rng_mode, susp, is_lean); }
 const void *step_kernel_finish_f64(bool drydep, bool polar, bool nest) { return finish_table<double>(drydep, polar, nest); }
 #endif
 #if FPX_TU_REAL != 8
-const void *step_kernel_loop_f32(bool lean, int turbswitch, int cblflag, int rng_mode) { return loop_table<float>(lean, turbswitch, cblflag, rng_mode); }
+const void *step_kernel_loop_f32(bool lean, int turbswitch, int cblflag, int rng_mode, bool susp, bool *is_lean) { return loop_table<float>(lean, turbswitch, cblflag, rng_mode, susp, is_lean); }
 const void *step_kernel_finish_f32(bool drydep, bool polar, bool nest) { return finish_table<float>(drydep, polar, nest); }
 #endif
 #endif
@@ -5249,15 +5284,15 @@ EngineBase *make_engine_f32(const fpx_config *cfg, int *rc) {
 #if FPX_TU_REAL != 4
 const void *step_kernel_prep_f64(bool, bool, bool, bool);
 const void *step_kernel_prep_f32(bool, bool, bool, bool);
-const void *step_kernel_loop_f64(bool, int, int, int);
-const void *step_kernel_loop_f32(bool, int, int, int);
+const void *step_kernel_loop_f64(bool, int, int, int, bool, bool *);
+const void *step_kernel_loop_f32(bool, int, int, int, bool, bool *);
 const void *step_kernel_finish_f64(bool, bool, bool);
 const void *step_kernel_finish_f32(bool, bool, bool);
 const void *step_kernel_prep(int rb, bool drydep, bool init, bool polar, bool nest) {
   return rb == 8 ? step_kernel_prep_f64(drydep, init, polar, nest) : step_kernel_prep_f32(drydep, init, polar, nest);
 }
-const void *step_kernel_loop(int rb, bool lean, int turbswitch, int cblflag, int rng_mode) {
-  return rb == 8 ? step_kernel_loop_f64(lean, turbswitch, cblflag, rng_mode) : step_kernel_loop_f32(lean, turbswitch, cblflag, rng_mode);
+const void *step_kernel_loop(int rb, bool lean, int turbswitch, int cblflag, int rng_mode, bool susp, bool *is_lean) {
+  return rb == 8 ? step_kernel_loop_f64(lean, turbswitch, cblflag, rng_mode, susp, is_lean) : step_kernel_loop_f32(lean, turbswitch, cblflag, rng_mode, susp, is_lean);
 }
 const void *step_kernel_finish(int rb, bool drydep, bool polar, bool nest) {
   return rb == 8 ? step_kernel_finish_f64(drydep, polar, nest) : step_kernel_finish_f32(drydep, polar, nest);
