@@ -2564,6 +2564,38 @@ FPX_DEV void wave_run_add(T *base, long long idx, T val, bool valid) {
 // each), scattered dwords at about 2e10 per second for the whole chip; the run-merging of wave_run_add only catches
 // NEIGHBOURING lanes with the same target, and the three neighbour cells alternate from lane to lane with the particle's
 // quadrant: 0.86 atomics per particle in k_wetdepo, 0.43 in k_conccalc before this.
+// Sum over the 64 lanes of a wave through DPP (data-parallel primitives: the adds read their second operand from another lane
+// of the row / the previous rows directly, no LDS crossbar as with ds_bpermute): two quad permutes and two mirrors leave every
+// lane of a 16-lane row with its row's sum, row_bcast15 / row_bcast31 carry the sums on to the rows behind; lane 63 holds the
+// total.  Every lane of the wave must be active.  (The neighbourhood sums of wave_kernel_add are nine of these per group of
+// lanes: with __shfl_xor they were 54 cross-lane moves through LDS for f32 and 108 for fp64, and k_conccalc<double> took 6.8
+// instead of 4.5 ms.)
+template <int CTRL, int ROW_MASK = 0xf>
+FPX_DEV int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, true); }
+template <int CTRL, int ROW_MASK = 0xf>
+FPX_DEV float dpp_get(float v) { return __int_as_float(dpp_mov<CTRL, ROW_MASK>(__float_as_int(v))); }
+template <int CTRL, int ROW_MASK = 0xf>
+FPX_DEV double dpp_get(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = dpp_mov<CTRL, ROW_MASK>((int)(b & 0xffffffffll)), hi = dpp_mov<CTRL, ROW_MASK>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+template <typename T>
+FPX_DEV T wave_total(T v) {
+  v += dpp_get<0xB1>(v);          // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E>(v);          // quad_perm [2,3,0,1]
+  v += dpp_get<0x141>(v);         // row_half_mirror
+  v += dpp_get<0x140>(v);         // row_mirror: every lane holds the sum of its row of 16
+  v += dpp_get<0x142, 0xa>(v);    // row_bcast15 into rows 1 and 3: + the row before
+  v += dpp_get<0x143, 0xc>(v);    // row_bcast31 into rows 2 and 3: + rows 0 and 1
+  if (sizeof(T) == 8) {
+    const long long b = __double_as_longlong((double)v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), 63), hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return (T)__longlong_as_double(((long long)hi << 32) | (long long)(unsigned int)lo);
+  }
+  return (T)__int_as_float(__builtin_amdgcn_readlane(__float_as_int((float)v), 63));
+}
+
 constexpr long long kNoCell = (long long)0x8000000000000000ull;   // "this lane adds nothing" (a cell index may be negative: the own cell can lie outside the grid)
 template <typename T>
 FPX_DEV void wave_kernel_add(T *base, long long c0, int numx, int dix, int djy, T w00, T w10, T w01, T w11) {
@@ -2598,8 +2630,7 @@ FPX_DEV void wave_kernel_add(T *base, long long c0, int numx, int dix, int djy, 
         else if (bx == 0) v = by == djy ? w01 : (T)0;
         else v = (bx == dix && by == djy) ? w11 : (T)0;
       }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      v = wave_total(v);
       if (lane == b) mine = v;
     }
     if (lane < 9 && mine != (T)0) atomicAdd(base + ref + (lane % 3 - 1) + (long long)(lane / 3 - 1) * numx, mine);
