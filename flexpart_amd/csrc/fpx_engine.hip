@@ -1275,7 +1275,8 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   // A short list (the later launches): only as many blocks as it fills take part, so that its waves are spread over the
   // CUs one block each instead of three to a SIMD on some and none on others (a pass of a wave alone on its SIMD takes a
   // third of the time).
-  if ((unsigned long long)blockIdx.x * kBlock >= (unsigned long long)mine[0] + mine[1] + mine[2] + mine[3]) return;
+  const unsigned int nlist_all = mine[0] + mine[1] + mine[2] + mine[3];
+  if ((unsigned long long)blockIdx.x * kBlock >= (unsigned long long)nlist_all) return;
   const bool can_suspend = SUSP && (drain_lanes > 0 || cap_passes > 0);
   // dynamic LDS: [S_COUNT][kBlock] stash (per-lane pass-level state, see Stash) + the height column,
   // sized by the host (loop_smem_bytes) so that three blocks fit one CU for the usual nz
@@ -1313,7 +1314,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   // scalar file is what the fine loop's polynomial constants live in, and every scalar held across the loop came back as a
   // v_readlane in each sub-step (+0.8 % VALU instructions at 1e8 with all of these in scalar registers).
 #define FPX_IN_VGPR(x) asm volatile("" : "+v"(x))
-  FPX_IN_VGPR(cbase); FPX_IN_VGPR(cls_out); FPX_IN_VGPR(cls_n); FPX_IN_VGPR(cls_seg);
+  if (SUSP) { FPX_IN_VGPR(cbase); FPX_IN_VGPR(cls_out); FPX_IN_VGPR(cls_n); FPX_IN_VGPR(cls_seg); }
 #ifdef FPX_LANE_STATS
   const unsigned long long t_s = wall_clock64();   // 100 MHz; timeline of the wave: start, list exhausted, end
   unsigned long long t_x = 0;
@@ -1357,6 +1358,27 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
     FPX_LANES(st, 10);
     unsigned long long need = __ballot(!have);
     if (need != 0ull && !out_of_chunks) {
+      if (!SUSP) {
+        // One launch, nothing to suspend: the class segments of the list are adjacent, so the wave walks the list as ONE
+        // sequence with ONE cursor (chunks may straddle a class boundary, as in round 3)
+        if (cur >= end) {
+          unsigned int c = 0;
+          if (lane == 0) c = atomicAdd(blk + 4, 1u);
+          c = __builtin_amdgcn_readfirstlane(c);
+          const unsigned long long c0 = (unsigned long long)c * 64u;
+          if (c0 >= nlist_all) {
+            out_of_chunks = true;
+#ifdef FPX_LANE_STATS
+            t_x = wall_clock64();
+#endif
+          } else {
+            cur = (unsigned int)c0;
+            cbase = cur;
+            end = min(cur + 64u, nlist_all);
+            ahead = pbl_list[min(cur + (unsigned int)lane, nlist_all - 1u)];
+          }
+        }
+      } else
       while (cur >= end && !out_of_chunks) {   // wave-uniform: take the next chunk of the wave's class
         if (__builtin_amdgcn_readfirstlane(cls_out) == 0u) {
           const unsigned int nseg = __builtin_amdgcn_readfirstlane(cls_n), seg = __builtin_amdgcn_readfirstlane(cls_seg);

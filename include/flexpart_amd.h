@@ -446,7 +446,7 @@ int fpx_set_release_heights(fpx_handle h, int32_t numpoint, const void *zpoint1,
  * slot 2 (fpx_upload_diag_fields slot 2 or fpx_verttransform_ecmwf); rho comes from the met fields of slot 2.
  * Nested met grids (releaseparticles.f90:196-226): a particle released inside a nest takes the nest's orography, density and
  * temperature (fpx_upload_diag_nest_fields + the nest's field pack).
- * xscav_frac1 (backward deposition runs, :161-166) is not a particle array of the engine. */
+ * With fpx_config.drybkdep / wetbkdep a new particle gets xscav_frac1 = -1 ("not yet through the receptor block", :167-171). */
 typedef struct {
   int32_t struct_bytes;
   int32_t numpoint;
