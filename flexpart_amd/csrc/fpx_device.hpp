@@ -2366,7 +2366,7 @@ FPX_DEV void above_step(const View<R> &V, const R *hgt, const RNG &G, const Time
     nrand = nrand + 1;
   }
   A.nrand = nrand;
-  if (V.lsettling) A.w = A.w + settling_velocity(V, hgt, xt, yt, zt, A.nsp);   // advance.f90:686-699
+  if (V.lsettling) A.w = A.w + settling_velocity<R, true>(V, hgt, xt, yt, zt, A.nsp);   // advance.f90:686-699
   A.dxsave = A.dxsave + (A.u + ux) * dt;
   A.dysave = A.dysave + (A.v + vy) * dt;
   zt = zt + (A.w + wp) * dt * (R)V.ldirect;
@@ -2442,7 +2442,7 @@ FPX_DEV int adv_finish(const View<R> &V, const R *hgt, const RNG &G, int itime, 
     const Fld<R> FP = fld_of(V, A.ngrid);
     interp_wind<R, false, LATE, FPX_PETTERSSEN_DEPTH>(V, hgt, FP, C, time_weights(V, itime + P.ldt * V.ldirect), P.zt, u, v, w, d0, d1, d2, late, FP.w3t1);
   }
-  if (V.lsettling) w = w + settling_velocity(V, hgt, P.xt, P.yt, P.zt, A.nsp);   // advance.f90:893-906
+  if (V.lsettling) w = w + settling_velocity<R, true>(V, hgt, P.xt, P.yt, P.zt, A.nsp);   // advance.f90:893-906
   u = (u - A.u) / K(2.);
   v = (v - A.v) / K(2.);
   w = (w - A.w) / K(2.);
@@ -2743,7 +2743,8 @@ FPX_DEV void conccalc_particle(const View<R> &V, const GridP<R> &Gp, const R *hg
 }
 
 // drydepokernel.f90:41-116 for one species (deposit already in dep_prec = float)
-template <typename R>
+// CONV: every lane of the wave is here (k_pbl_finish): the neighbourhood sums of wave_kernel_add instead of the run merging
+template <typename R, bool CONV = false>
 FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp0, int nunc, float deposit, int ks, R x, R y, int nage, int kp, bool nest = false) {
   // every lane that reaches the call takes part in the run-merged adds (wave_run_add); `on` says whether it contributes
   const bool on = fabsf(deposit) > 0.f && grid_planes_ok(Gp0, nage, nunc, kp);
@@ -2767,6 +2768,16 @@ FPX_DEV void drydepo_particle(const View<R> &V, const GridP<R> &Gp0, int nunc, f
   const long long g = on ? plane * (ks + (long long)Gp.maxspec * ((kp - 1) + (long long)Gp.maxpointspec_act * ((nunc - 1) + (long long)Gp.nclassunc * (nage - 1)))) : 0;
   const bool okx = ix >= 0 && ix <= Gp.numxgrid - 1, oky = jy >= 0 && jy <= Gp.numygrid - 1;
   const bool okxp = ixp >= 0 && ixp <= Gp.numxgrid - 1, okyp = jyp >= 0 && jyp <= Gp.numygrid - 1;
+  if (CONV) {
+    const bool kern = Gp.lusekerneloutput != 0;   // wave-uniform
+    const bool any = on && ((okx && oky) || (kern && (okxp || okyp)));
+    wave_kernel_add<float>(Gp.drygridunc, any ? g + (long long)jy * Gp.numxgrid + ix : kNoCell, Gp.numxgrid, ixp - ix, jyp - jy,
+                           (okx && oky) ? (kern ? (float)((R)deposit * (wx * wy)) : deposit) : 0.f,
+                           (kern && okxp && oky) ? (float)((R)deposit * ((K(1.) - wx) * wy)) : 0.f,
+                           (kern && okx && okyp) ? (float)((R)deposit * (wx * (K(1.) - wy))) : 0.f,
+                           (kern && okxp && okyp) ? (float)((R)deposit * ((K(1.) - wx) * (K(1.) - wy))) : 0.f);
+    return;
+  }
   if (!Gp.lusekerneloutput) {   // wave-uniform
     wave_run_add<float>(Gp.drygridunc, g + (long long)jy * Gp.numxgrid + ix, deposit, on && okx && oky);
     return;

@@ -407,9 +407,19 @@ struct EpiPre {
   }
 };
 
+// the dry deposition of one particle's step, handed back to a caller that scatters it where its wave is convergent again
+// (k_pbl_finish: the neighbourhood sums of wave_kernel_add need every lane of the wave)
+template <typename R>
+struct DryDep {
+  float dep[kMaxSpec];   // drydeposit(ks), timemanager.f90:650-656,690-693 (0: nothing)
+  R x, y;                // the particle's position the kernel is centred on (xtra1, ytra1 after the step)
+  int nage, kp, nclass;
+};
+
 template <typename R, bool DRYDEP, bool TURB = true>
 __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> &Gp, Parts<R> &P, long long s, int itime, int itramem,
-                                               int nstop, const PState<R> &ps, const R *prob, Stats *st, const EpiPre<R> *pre = nullptr) {
+                                               int nstop, const PState<R> &ps, const R *prob, Stats *st, const EpiPre<R> *pre = nullptr,
+                                               DryDep<R> *defer = nullptr) {
   int itra1;
   if (nstop > 1) {
     itra1 = kDead;
@@ -452,8 +462,12 @@ __device__ __forceinline__ void epilogue_store(const View<R> &V, const GridP<R> 
             }
             const int nage = ageclass(Gp, abs(itime - itramem));
             const int kp = Gp.ioutputforeachrelease == 1 ? npoint : 1;
-            drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp);
-            if (Gp.nested) drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp, true);   // timemanager.f90:694-696
+            if (defer) {
+              defer->dep[ks] = drydeposit; defer->x = (R)ps.xt; defer->y = (R)ps.yt; defer->nage = nage; defer->kp = kp; defer->nclass = P.nclass[s];
+            } else {
+              drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp);
+              if (Gp.nested) drydepo_particle(V, Gp, P.nclass[s], drydeposit, ks, (R)ps.xt, (R)ps.yt, nage, kp, true);   // timemanager.f90:694-696
+            }
           }
         } else xm = xm * decfact;
         if (DRYDEP || V.decay[ks] > (R)0) P.xmass1[(size_t)ks * P.cap + s] = xm;
@@ -1539,7 +1553,7 @@ __global__ void k_math_probe(int fn, const double *__restrict__ x, double *__res
 // a particle in a cap run the mother-grid instance (POLAR = false, CAPCHECK), the others the polar one.
 template <typename R, bool DRYDEP, bool POLAR, bool NEST, bool CAPCHECK>
 __device__ __forceinline__ void finish_body(const View<R> &V, const GridP<R> &Gp, Parts<R> &P, unsigned int s, const PblRecord<R> &rec, R tdep,
-                                            int itime, unsigned int step, Stats *st, const R *hgt) {
+                                            int itime, unsigned int step, Stats *st, const R *hgt, DryDep<R> *dry) {
   constexpr bool MOTHER = !POLAR && !NEST;
   const int pk = rec.i[2];
   PState<R> ps;
@@ -1593,7 +1607,7 @@ __device__ __forceinline__ void finish_body(const View<R> &V, const GridP<R> &Gp
     itramem = P.itramem[sl];
   };
   const int nstop = adv_finish<R, Rng<R>, POLAR, MOTHER, decltype(late_epi), CAPCHECK>(V, hgt, G, itime, ps, A, usig, vsig, wsig, late_epi);
-  epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st, &pre);
+  epilogue_store<R, DRYDEP>(V, Gp, P, s, itime, itramem, nstop, ps, prob, st, &pre, dry);
 }
 
 // completion of the PBL particles (finish_body).  One thread per list entry or slot.
@@ -1610,20 +1624,39 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
   const long long nwork = pbl_list ? (long long)*pbl_count : numpart;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nwork; i += (long long)gridDim.x * blockDim.x) {
-    unsigned int s;
-    if (pbl_list) s = pbl_list[i];
-    else {
-      if (pbl_key[i] >= kKeyDone) continue;
-      s = (unsigned int)i;
+  // (the loop bound is the same for every lane of a wave: the dry-deposition scatter at the end of the body needs them all)
+  for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < nwork; i0 += (long long)gridDim.x * blockDim.x) {
+    const long long i = i0 + threadIdx.x;
+    bool mine = i < nwork;
+    unsigned int s = 0;
+    if (mine) {
+      if (pbl_list) s = pbl_list[i];
+      else { mine = pbl_key[i] < kKeyDone; s = (unsigned int)i; }
     }
-    const PblRecord<R> rec = Q.rec[s];
-    const R tdep = DRYDEP ? Q.tdep[s] : (R)0;
-    if (POLAR && !NEST && !__any(pbl_ngrid(rec.i[2]) < 0)) {   // wave-uniform: no particle of this wave sits in a polar cap
-      finish_body<R, DRYDEP, false, false, true>(V, Gp, P, s, rec, tdep, itime, step, st, hgt);
-      continue;
+    DryDep<R> dry;
+#pragma unroll
+    for (int ks = 0; ks < kMaxSpec; ks++) dry.dep[ks] = 0.f;
+    dry.x = (R)0; dry.y = (R)0; dry.nage = 1; dry.kp = 1; dry.nclass = 1;
+    if (mine) {
+      const PblRecord<R> rec = Q.rec[s];
+      const R tdep = DRYDEP ? Q.tdep[s] : (R)0;
+      if (POLAR && !NEST && !__any(pbl_ngrid(rec.i[2]) < 0)) {   // wave-uniform: no particle of this wave sits in a polar cap
+        finish_body<R, DRYDEP, false, false, true>(V, Gp, P, s, rec, tdep, itime, step, st, hgt, DRYDEP ? &dry : nullptr);
+      } else {
+        finish_body<R, DRYDEP, POLAR, NEST, false>(V, Gp, P, s, rec, tdep, itime, step, st, hgt, DRYDEP ? &dry : nullptr);
+      }
     }
-    finish_body<R, DRYDEP, POLAR, NEST, false>(V, Gp, P, s, rec, tdep, itime, step, st, hgt);
+    if (DRYDEP && Gp.on && V.ldirect == 1) {
+      // drydepokernel / drydepokernel_nest (timemanager.f90:690-696), with every lane of the wave: lanes of the same output
+      // cell are summed into its neighbourhood before the atomics (wave_kernel_add); a lane without a deposit adds nothing
+#pragma unroll
+      for (int ks = 0; ks < kMaxSpec; ks++) {
+        if (ks < V.nspec && V.drydepspec[ks]) {
+          drydepo_particle<R, true>(V, Gp, dry.nclass, dry.dep[ks], ks, dry.x, dry.y, dry.nage, dry.kp);
+          if (Gp.nested) drydepo_particle<R, true>(V, Gp, dry.nclass, dry.dep[ks], ks, dry.x, dry.y, dry.nage, dry.kp, true);
+        }
+      }
+    }
   }
 }
 
