@@ -32,7 +32,7 @@ module flexgpu_mod
             flexgpu_outgrid_init, flexgpu_conccalc, flexgpu_get_grids, &
             flexgpu_wet_init, flexgpu_upload_wet_fields, flexgpu_wetdepo, flexgpu_verttransform, &
             flexgpu_upload_diag_fields, flexgpu_partoutput, flexgpu_readpartpositions, &
-            flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, flexgpu_count_particles, &
+            flexgpu_concoutput, flexgpu_abi_sizes, flexgpu_comm_init_host, flexgpu_count_particles, flexgpu_set_option, flexgpu_get_info, &
             flexgpu_release_init, flexgpu_releaseparticles, flexgpu_split_particles, flexgpu_calcpar, &
             flexgpu_redist_plan, flexgpu_redist_bytes, flexgpu_redist_pack, flexgpu_redist_unpack, &
             flexgpu_checkpoint_write, flexgpu_checkpoint_read, &
@@ -472,6 +472,17 @@ module flexgpu_mod
       type(c_ptr), value :: h
       integer(c_int64_t), intent(out) :: local(2), total(2)
       integer(c_int32_t), value :: allreduce
+    end function
+    integer(c_int) function fpx_set_option(h, name, value) bind(C, name='fpx_set_option')
+      import :: c_ptr, c_int, c_char
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: name(*), value(*)
+    end function
+    integer(c_int) function fpx_get_info(h, name, value) bind(C, name='fpx_get_info')
+      import :: c_ptr, c_int, c_char, c_int64_t
+      type(c_ptr), value :: h
+      character(kind=c_char), intent(in) :: name(*)
+      integer(c_int64_t), intent(out) :: value
     end function
     integer(c_int) function fpx_get_wetgrid(h, w, allreduce) bind(C, name='fpx_get_wetgrid')
       import :: c_ptr, c_int, c_int32_t
@@ -1282,6 +1293,21 @@ contains
     ierr = fpx_count_particles(flexgpu_handle, loc, tot, merge(1_c_int32_t, 0_c_int32_t, allreduce))
     nlive = tot(1); numpart_tot = tot(2)
   end subroutine flexgpu_count_particles
+
+  ! a tuning / diagnostic knob of the engine (include/flexpart_amd.h: fpx_set_option; none changes a result), and what the
+  ! engine decided ("time_blended_packs", "blended_steps", "pbl_launches_per_step")
+  subroutine flexgpu_set_option(name, value, ierr)
+    character(len=*), intent(in) :: name, value
+    integer, intent(out) :: ierr
+    ierr = fpx_set_option(flexgpu_handle, trim(name)//c_null_char, trim(value)//c_null_char)
+  end subroutine flexgpu_set_option
+
+  subroutine flexgpu_get_info(name, value, ierr)
+    character(len=*), intent(in) :: name
+    integer(c_int64_t), intent(out) :: value
+    integer, intent(out) :: ierr
+    ierr = fpx_get_info(flexgpu_handle, trim(name)//c_null_char, value)
+  end subroutine flexgpu_get_info
 
   ! ---- wet deposition: species parameters of readspecies.f90, fields of readwind/verttransform ----
   subroutine flexgpu_wet_init(ierr)
