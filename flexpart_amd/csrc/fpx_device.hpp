@@ -920,9 +920,12 @@ enum StashSlot {
   S_TDEP = S_COUNT_LEAN,                                                        // aerosol kernels: sum of |dt| over the passes that ended below 2*href (advance.f90:582-599)
   S_SETCELL,                                                                    // aerosol kernels: column (njy*nx + nix) of get_settling -- so that xt, yt need not stay in registers
   S_SET_NUM, S_SET_DQ6, S_SET_V0,                                               // ... and its species constants 4*ga*dquer/1.e6*density*cunningham (0: no settling), dquer/1.e6, vsetaver
-  S_RT_TAG, S_RT_RHO1, S_RT_TT1, S_RT_RHO2, S_RT_TT2,                           // aerosol kernels: rho, tt of get_settling.f90:83-84 for the level pair S_RT_TAG (0: none) of the lane's column
+  S_COUNT_AERO64,                                                               // the fp64 aerosol kernels stop here (22 slots = 45 KB per block: three blocks per CU; with the five below it would be two)
+  S_RT_TAG = S_COUNT_AERO64, S_RT_RHO1, S_RT_TT1, S_RT_RHO2, S_RT_TT2,          // f32 aerosol kernels: rho, tt of get_settling.f90:83-84 for the level pair S_RT_TAG (0: none) of the lane's column
   S_COUNT
 };
+// stash slots of a Langevin kernel instance (the host sizes the block's LDS with the same rule)
+template <typename R> constexpr int stash_slots(bool lean) { return lean ? S_COUNT_LEAN : (sizeof(R) == 8 ? S_COUNT_AERO64 : S_COUNT); }
 constexpr int kStashStride = 256;   // threads per block of the loop kernel
 template <typename R>
 struct Stash {
@@ -1384,7 +1387,8 @@ FPX_DEV R get_settling(const View<R> &V, const R *hgt, int column, R zt, int nsp
   // the level with height(indz) <= zt < height(indz+1), as the search of get_settling.f90:58-64 finds it
   if (!(FAST && indz >= 1 && indz <= V.nz - 1 && hgt[indz] > zt && (indz == 1 || !(hgt[indz - 1] > zt)))) indz = find_level(hgt, V.nz, zt);
   R rho1, tt1, rho2, tt2;
-  if (ST != nullptr && (int)ST->get(S_RT_TAG) == indz) {
+  const bool cached = sizeof(R) == 4 && ST != nullptr;      // (the fp64 kernels have no room for the five slots at three blocks per CU)
+  if (cached && (int)ST->get(S_RT_TAG) == indz) {
     // the lane's column does not change inside the step and the particle leaves its level pair in a fifth of its passes:
     // the four values stay in the stash from pass to pass (before: one dependent 16-byte gather -- a cache line of its own
     // -- at the end of every pass: 56 GB of fetches per launch at 1e8 particles, 5 times the rest of the kernel's)
@@ -1392,7 +1396,7 @@ FPX_DEV R get_settling(const View<R> &V, const R *hgt, int column, R zt, int nsp
   } else {
     const R *q = V.rhott + ((long long)column * V.nz + (indz - 1)) * 2;
     rho1 = q[0]; tt1 = q[1]; rho2 = q[2]; tt2 = q[3];
-    if (ST != nullptr) {
+    if (cached) {
       ST->put(S_RT_TAG, (R)indz); ST->put(S_RT_RHO1, rho1); ST->put(S_RT_TT1, tt1); ST->put(S_RT_RHO2, rho2); ST->put(S_RT_TT2, tt2);
     }
   }

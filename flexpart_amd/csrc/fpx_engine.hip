@@ -1297,7 +1297,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   extern __shared__ __align__(16) unsigned char fpx_loop_smem[];
   static_assert(kStashStride == kBlock, "stash layout is one column per thread of the block");
   R *stash_mem = reinterpret_cast<R *>(fpx_loop_smem);
-  R *hgt = stash_mem + (LEAN ? S_COUNT_LEAN : S_COUNT) * kStashStride;   // (the host sizes the block's LDS alike: loop_smem_bytes)
+  R *hgt = stash_mem + stash_slots<R>(LEAN) * kStashStride;   // (the host sizes the block's LDS alike: loop_smem_bytes)
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   // the block's copy of the lookup tables of the fp64 logarithm and exponential (m_log_abs, m_exp_tab): 768 B
   __shared__ double lds_tab[sizeof(R) == 8 ? kLdsTabDoubles : 1];
@@ -1473,7 +1473,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
               S.put(S_SET_NUM, pick(V.density, nsp) > (R)0 ? sp.num : (R)0);   // density(nsp) <= 0: no settling (advance.f90:525)
               S.put(S_SET_DQ6, sp.dq6); S.put(S_SET_V0, sp.vset);
               S.put(S_SETCELL, (R)settling_column(V, (R)xt, (R)yt));   // < nx*ny: exact in R (f32: grids up to 2^24 columns, checked at fpx_create)
-              S.put(S_RT_TAG, (R)0);
+              if (sizeof(R) == 4) S.put(S_RT_TAG, (R)0);
             }
             S.put(S_DDX, ddx); S.put(S_DDY, ddy);
           }
@@ -2011,7 +2011,7 @@ struct Engine : EngineBase {
   enum { RG_GRID = 0, RG_DRY, RG_WET, RG_GRIDN, RG_DRYN, RG_WETN, RG_REC };
   void *d_sel_tmp = nullptr;
   size_t sel_tmp_bytes = 0;
-  int pbl_grid = 0;
+  int pbl_grid = 0, pbl_per_cu = 0;
   // TABLE_SEQ state
   HostRng<float> rng4;
   HostRng<double> rng8;
@@ -4465,6 +4465,7 @@ struct Engine : EngineBase {
       HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, loop_kernel(), kBlock, loop_smem_bytes()));
       if (opt.pbl_blocks_per_cu > 0) per_cu = std::min(per_cu, opt.pbl_blocks_per_cu);   // experiments: fewer resident waves
       pbl_grid = prop.multiProcessorCount * std::max(per_cu, 1);
+      pbl_per_cu = std::max(per_cu, 1);
       if (opt.verbose) fprintf(stderr, "[fpx] Langevin kernel: %d blocks per CU by the occupancy query, %zu B of dynamic LDS, grid %d\n", per_cu, loop_smem_bytes(), pbl_grid);
     }
     {
@@ -4624,6 +4625,7 @@ struct Engine : EngineBase {
       else if (cfg.pbl_slice_passes > 0) *value = kMaxSlices;
       else { const int d[] = {FPX_SLICE_SCHEDULE}; *value = (int64_t)(sizeof(d) / sizeof(d[0])); }
     } else if (n == "pbl_grid") *value = pbl_grid;
+    else if (n == "pbl_blocks_per_cu") *value = pbl_per_cu;
     else return fail(FPX_ERR_ARG, "fpx_get_info: unknown name: " + n);
     return 0;
   }
@@ -4657,7 +4659,7 @@ struct Engine : EngineBase {
   size_t loop_smem_bytes() const {
     bool lean = false;
     (void)loop_kernel(&lean);
-    return sizeof(R) * ((size_t)(lean ? S_COUNT_LEAN : S_COUNT) * kStashStride + (size_t)cfg.nz);
+    return sizeof(R) * ((size_t)stash_slots<R>(lean) * kStashStride + (size_t)cfg.nz);
   }
 
   int sync() override {

@@ -663,7 +663,8 @@ int fpx_set_option(fpx_handle h, const char *name, const char *value);
 /* What the engine decided or did, by name: "time_blended_packs" (1 when the steps of this handle blend the wind packs in
  * time: fpx_config.blend_mode / global_particles), "blended_steps" (steps that did so far), "pbl_launches_per_step"
  * (launches of the Langevin kernel per step = time slices + 1), "pbl_grid" (its persistent grid, blocks; 0 before the
- * first step).  Unknown names return FPX_ERR_ARG. */
+ * first step), "pbl_blocks_per_cu" (resident blocks of four waves per CU the grid was sized for).  Unknown names return
+ * FPX_ERR_ARG. */
 int fpx_get_info(fpx_handle h, const char *name, int64_t *value);
 
 #ifdef __cplusplus

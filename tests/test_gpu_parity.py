@@ -1062,3 +1062,20 @@ def test_device_math_helpers_against_libm(built):
     assert np.max(np.abs(probe(10, pl) - np.log(pl))) < 1e-13
     zc = np.concatenate([10.0 ** rng.uniform(-37, 2, n), rng.uniform(0.0, 1.0, n)[1:], [1.0, 1e-3]])
     assert np.max(np.abs(probe(11, zc) * np.cbrt(zc) - 1.0)) < ulp4
+
+
+@pytest.mark.parametrize("rb,aerosol,waves", [(8, False, 3), (8, True, 3), (4, False, 4), (4, True, 4)])
+def test_langevin_kernel_keeps_its_occupancy(built, rb, aerosol, waves):
+    """The persistent grid of the Langevin kernel = resident blocks per CU x CUs: three blocks of four waves per CU in fp64, four in
+    f32 -- also for the aerosol instances, whose stash (LDS) is the larger one: an LDS or register budget that silently costs a
+    block per CU is a 15-30 % slower kernel ("LDS budget rule")."""
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    sc = syn.small(n=3000, nx=40, ny=24, nz=138, nsteps=1, ctl=5.0, ifine=4, cblflag=1)
+    if aerosol:
+        sc.update(lsettling=1, drydep=1, drydepspec=np.array([1], np.int32), density=np.array([2000.0]),
+                  dquer=np.array([8.0]), vsetaver=np.array([-0.004]), cunningham=np.array([1.02]), xmass=np.array([1.0]))
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_PHILOX)
+    eng.step()
+    per_cu, grid = eng.info("pbl_blocks_per_cu"), eng.info("pbl_grid")
+    eng.close()
+    assert per_cu == waves and grid % waves == 0 and grid >= waves * 64, (per_cu, grid)
