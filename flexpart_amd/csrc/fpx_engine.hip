@@ -1618,20 +1618,47 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
   // Two orders.  pbl_list given: the work list (class by class, each class in slot = cell order): every lane busy.  With cost
   // buckets in the list (32 interleaved sub-sequences of the cell-sorted slots) following it costs this kernel half of its
   // time again in scattered record and state accesses (0.58 -> 0.87 ms at 1.25e7 particles); then pbl_list is null and the
-  // kernel goes through the SLOTS, taking those whose key of this step says "boundary layer": after a locality sort the
-  // boundary-layer particles of a column are consecutive slots, so the waves stay nearly full (0.77 ms).
+  // kernel goes through the SLOTS, taking those whose key of this step says "boundary layer" (0.77 ms when every slot has a
+  // lane and the others idle; with the per-wave queue below the waves are full).
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
-  const long long nwork = pbl_list ? (long long)*pbl_count : numpart;
-  // (the loop bound is the same for every lane of a wave: the dry-deposition scatter at the end of the body needs them all)
-  for (long long i0 = (long long)blockIdx.x * blockDim.x; i0 < nwork; i0 += (long long)gridDim.x * blockDim.x) {
-    const long long i = i0 + threadIdx.x;
-    bool mine = i < nwork;
+  // Slot order: every wave walks tiles of 64 consecutive slots, collects the boundary-layer ones in a queue of its own in LDS
+  // and works them off 64 at a time -- full waves in (nearly) slot order, whatever share of a tile is boundary layer.
+  __shared__ unsigned int queue_mem[kBlock / 64][128];
+  volatile unsigned int *queue = queue_mem[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  unsigned int qlen = 0;   // wave-uniform
+  const long long nwork = pbl_list ? (long long)*pbl_count : (numpart + 63) >> 6;   // list entries | tiles of 64 slots
+  const long long stride = pbl_list ? (long long)gridDim.x * blockDim.x : (long long)gridDim.x * (kBlock / 64);
+  long long it = pbl_list ? (long long)blockIdx.x * blockDim.x : (long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+  for (;;) {   // ONE body for both orders (the body is large: a single call site keeps it inlined once)
+    // one wave's worth of particles: slot s for the lanes with `mine` (every lane of the wave goes through the body: the
+    // dry-deposition scatter at its end needs them all)
     unsigned int s = 0;
-    if (mine) {
-      if (pbl_list) s = pbl_list[i];
-      else { mine = pbl_key[i] < kKeyDone; s = (unsigned int)i; }
+    bool mine = false;
+    if (pbl_list) {
+      if (it >= nwork) break;          // the same for every lane of the block
+      const long long i = it + threadIdx.x;
+      mine = i < nwork;
+      if (mine) s = pbl_list[i];
+      it += stride;
+    } else {
+      while (qlen < 64u && it < nwork) {
+        const long long i = it * 64 + lane;
+        const bool pbl = i < numpart && pbl_key[i] < kKeyDone;
+        const unsigned long long m = __ballot(pbl);
+        if (pbl) queue[qlen + (unsigned int)__popcll(m & ((1ull << lane) - 1ull))] = (unsigned int)i;
+        qlen += (unsigned int)__popcll(m);
+        it += stride;
+      }
+      if (qlen == 0u) break;           // the same for every lane of the wave
+      const unsigned int take = min(qlen, 64u), rest = qlen - take;
+      mine = (unsigned int)lane < take;
+      if (mine) s = queue[lane];
+      const unsigned int carry = (unsigned int)lane < rest ? queue[64 + lane] : 0u;
+      if ((unsigned int)lane < rest) queue[lane] = carry;
+      qlen = rest;
     }
     DryDep<R> dry;
 #pragma unroll
