@@ -925,7 +925,8 @@ enum StashSlot {
   S_COUNT
 };
 // stash slots of a Langevin kernel instance (the host sizes the block's LDS with the same rule)
-template <typename R> constexpr int stash_slots(bool lean) { return lean ? S_COUNT_LEAN : (sizeof(R) == 8 ? S_COUNT_AERO64 : S_COUNT); }
+// (a one-launch gas kernel -- SUSP = false -- never touches S_NPASS, the last of its slots)
+template <typename R> constexpr int stash_slots(bool lean, bool susp = true) { return lean ? (susp ? (int)S_COUNT_LEAN : (int)S_NPASS) : (sizeof(R) == 8 ? (int)S_COUNT_AERO64 : (int)S_COUNT); }
 constexpr int kStashStride = 256;   // threads per block of the loop kernel
 template <typename R>
 struct Stash {

@@ -1297,7 +1297,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
   extern __shared__ __align__(16) unsigned char fpx_loop_smem[];
   static_assert(kStashStride == kBlock, "stash layout is one column per thread of the block");
   R *stash_mem = reinterpret_cast<R *>(fpx_loop_smem);
-  R *hgt = stash_mem + stash_slots<R>(LEAN) * kStashStride;   // (the host sizes the block's LDS alike: loop_smem_bytes)
+  R *hgt = stash_mem + stash_slots<R>(LEAN, SUSP) * kStashStride;   // (the host sizes the block's LDS alike: loop_smem_bytes)
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   // the block's copy of the lookup tables of the fp64 logarithm and exponential (m_log_abs, m_exp_tab): 768 B
   __shared__ double lds_tab[sizeof(R) == 8 ? kLdsTabDoubles : 1];
@@ -4686,7 +4686,7 @@ struct Engine : EngineBase {
   size_t loop_smem_bytes() const {
     bool lean = false;
     (void)loop_kernel(&lean);
-    return sizeof(R) * ((size_t)stash_slots<R>(lean) * kStashStride + (size_t)cfg.nz);
+    return sizeof(R) * ((size_t)stash_slots<R>(lean, loop_sliced()) * kStashStride + (size_t)cfg.nz);
   }
 
   int sync() override {
