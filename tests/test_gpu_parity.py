@@ -1079,3 +1079,33 @@ def test_langevin_kernel_keeps_its_occupancy(built, rb, aerosol, waves):
     per_cu, grid = eng.info("pbl_blocks_per_cu"), eng.info("pbl_grid")
     eng.close()
     assert per_cu == waves and grid % waves == 0 and grid >= waves * 64, (per_cu, grid)
+
+
+def test_options_and_info_are_checked(built):
+    """fpx_set_option / fpx_get_info: unknown names and malformed values are refused (FPX_ERR_ARG), nothing is read from the
+    environment, and a knob that is set is what the engine reports."""
+    import os
+    from flexpart_amd.engine import Engine, RNG_PHILOX
+    sc = syn.small(n=500, nx=20, ny=12, nz=10, nsteps=1, ctl=5.0, ifine=4)
+    os.environ["FPX_BLEND_MIN"] = "1"          # round 3's switch: must be ignored now
+    try:
+        eng = Engine(sc, rng_mode=RNG_PHILOX)
+        assert eng.info("time_blended_packs") == 0
+        for name, value in (("no_such_option", "1"), ("pbl_slices", "4,x"), ("pbl_slices", "-3"), ("permute", "sideways"), ("pbl_drain_lanes", "65"),
+                            ("pbl_cost_buckets", "9"), ("verbose", "yes")):
+            with pytest.raises(Exception, match="unknown option or malformed value"):
+                eng.set_option(name, value)
+        with pytest.raises(Exception, match="unknown name"):
+            eng.info("no_such_info")
+        eng.set_option("pbl_slices", "5,5,0")
+        assert eng.info("pbl_launches_per_step") == 3
+        eng.set_option("pbl_slices", "0")
+        assert eng.info("pbl_launches_per_step") == 1
+        eng.step()
+        assert eng.info("blended_steps") == 0 and eng.info("pbl_blocks_per_cu") == 3
+        eng.close()
+        for bad in (dict(blend_mode=3), dict(global_particles=-1), dict(pbl_slice_passes=-2)):
+            with pytest.raises(Exception):
+                Engine(sc, rng_mode=RNG_PHILOX, **bad)
+    finally:
+        del os.environ["FPX_BLEND_MIN"]
