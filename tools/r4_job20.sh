@@ -1,5 +1,6 @@
 #!/bin/bash
-# A/B on ONE box: round 3's tree (_r3tmp) against the current one, config 3 at 1e8 and at the shard of an eighth
+# A/B on ONE box: round 3's tree against the current one, config 3 at 1e8 and at the shard of an eighth.
+# Needs the round-3 tree next to this one first:  git worktree add -f _r3tmp 0e65107 && (cd _r3tmp && python -c "import __graft_entry__ as g; g.build_library()")
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 for i in 1 2; do
   (cd _r3tmp && FPX_BLEND_MIN=1 timeout -k 10 400 python bench.py --no-cpu-baseline --no-pmc --steps 6 --warmup 3 > ../gpurun_out/r4_j20_r3_1e8_$i.json 2> ../gpurun_out/r4_j20_r3_1e8_$i.err); echo "r3 1e8 rc=$?"

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the round-3 worktree of tools/r4_job20.sh)
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 C="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SMEM"
 rm -rf gpurun_out/r4_j21_r3 gpurun_out/r4_j21_r4
