@@ -451,11 +451,17 @@ struct View {
 // Per-lane (divergent) subscripts into the small by-value tables of View.  A dynamic subscript
 // would force the whole kernel argument into private (scratch) memory and with it every uniform
 // scalar into vector registers; a select chain over constant subscripts keeps View in SGPRs.
+// Every element is read BEFORE the selects: with the read inside the conditional, the optimiser (which sees this function
+// before it is inlined, View then being a plain pointer) merges the arms into one load at a selected address -- the
+// dynamic subscript after all.  (That cost the f32 k_prep instances with initialize() 576 B of scratch per lane and 13 ms.)
 template <typename T, int N>
 FPX_DEV T pick(const T (&a)[N], int l) {
-  T r = a[0];
+  T v[N];
 #pragma unroll
-  for (int k = 1; k < N; k++) r = (l == k) ? a[k] : r;
+  for (int k = 0; k < N; k++) v[k] = a[k];
+  T r = v[0];
+#pragma unroll
+  for (int k = 1; k < N; k++) r = (l == k) ? v[k] : r;
   return r;
 }
 

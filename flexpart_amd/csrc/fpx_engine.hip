@@ -48,6 +48,9 @@ constexpr int kBlock = 256;
 #ifndef FPX_PREP_WAVES
 #define FPX_PREP_WAVES 3   // register budget (waves per SIMD) of k_prep (<= 168 VGPRs)
 #endif
+#ifndef FPX_INIT_PREP_3WAVES
+#define FPX_INIT_PREP_3WAVES 1    // the INIT instance of k_prep at the three-wave budget too: its initialize() body runs only in waves that hold a new particle
+#endif
 #ifndef FPX_POLAR_PREP_3WAVES
 #define FPX_POLAR_PREP_3WAVES 1   // the polar instance of k_prep at the three-wave register budget (the polar move is out of line: polar_move)
 #endif
@@ -637,7 +640,7 @@ __device__ __forceinline__ void prep_body(const View<R> &V, const GridP<R> &Gp, 
 }
 
 template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, (INIT || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock, ((INIT && !FPX_INIT_PREP_3WAVES) || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
                                                  unsigned int *__restrict__ pbl_count) {
   __shared__ R hgt[kMaxNz];
@@ -672,15 +675,23 @@ __global__ void __launch_bounds__(kBlock, (INIT || NEST || DRYDEP || (POLAR && !
     return;
   }
 
+  // wave-uniform: is any particle of this wave new (timemanager.f90:553)?  The INIT instance runs whenever particles MAY have
+  // been released since the last step -- every step of a run with a continuous release -- but only the waves that do hold a
+  // new particle need the body with initialize() in it (a dynamically indexed array in scratch, more registers); the others
+  // run the steady-state body, so that the instance costs what the steady-state kernel costs.
+  if (INIT && __any((itramem == itime) || (itime == 0))) {
+    prep_body<R, DRYDEP, true, POLAR, NEST, false>(V, Gp, P, S, Q, s, itime, step, st, pbl_flag, hgt, ps, itramem, pid);
+    return;
+  }
   if (POLAR && !NEST) {
     // wave-uniform: does any particle of this wave start in a polar cap (advance.f90:161-164)?  The slots are cell-sorted, so
     // five waves in six of a global run do not
     if (!__any(pick_polar(V, ps.yt) != 0)) {
-      prep_body<R, DRYDEP, INIT, false, false, true>(V, Gp, P, S, Q, s, itime, step, st, pbl_flag, hgt, ps, itramem, pid);
+      prep_body<R, DRYDEP, false, false, false, true>(V, Gp, P, S, Q, s, itime, step, st, pbl_flag, hgt, ps, itramem, pid);
       return;
     }
   }
-  prep_body<R, DRYDEP, INIT, POLAR, NEST, false>(V, Gp, P, S, Q, s, itime, step, st, pbl_flag, hgt, ps, itramem, pid);
+  prep_body<R, DRYDEP, false, POLAR, NEST, false>(V, Gp, P, S, Q, s, itime, step, st, pbl_flag, hgt, ps, itramem, pid);
 }
 
 // ---------------------------------------------------------------------------
@@ -2006,6 +2017,7 @@ struct Engine : EngineBase {
     long conv_scratch_mb = 0;
     int conv_one_lane = 0, conv_no_walk = 0, conv_rows_plain = 0;
     int pbl_drain_lanes = -1;                     // -1: the engine's default (FPX_DRAIN_LANES)
+    int prep_init_always = 0;                     // measurements: every step runs the instance of k_prep that can initialize() new particles
     int pbl_cost_buckets = FPX_COST_BUCKETS;      // -1: by the size of this rank's cloud
     std::vector<int> pbl_slices;
   } opt;
@@ -4520,7 +4532,7 @@ struct Engine : EngineBase {
     {
       // specialised variants: dry deposition (aerosols), initialize() only when new particles can
       // exist (after an upload/seed or at itime 0), polar maps only on grids with poles
-      const bool init = maybe_new || itime == 0;
+      const bool init = maybe_new || itime == 0 || opt.prep_init_always;
       const bool polar = cfg.nglobal || cfg.sglobal;
       typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *, unsigned int *);
       const bool nest = V.numbnests > 0;
@@ -4616,6 +4628,7 @@ struct Engine : EngineBase {
     if (n == "conv_no_walk") { if (!need_int(0)) goto bad; opt.conv_no_walk = iv != 0; return 0; }
     if (n == "conv_rows_plain") { if (!need_int(0)) goto bad; opt.conv_rows_plain = iv != 0; return 0; }
     if (n == "pbl_cost_buckets") { if (!is_int || iv < -1 || iv > 3) goto bad; opt.pbl_cost_buckets = (int)iv; return 0; }   // -1 automatic, 0 none, 1: four buckets, 2: two, 3: eight
+    if (n == "prep_init_always") { if (!need_int(0)) goto bad; opt.prep_init_always = iv != 0; return 0; }
     if (n == "pbl_drain_lanes") { if (!is_int || iv < -1 || iv > 64) goto bad; opt.pbl_drain_lanes = (int)iv; return 0; }
     if (n == "permute") {
       if (v == "auto") opt.permute = 0; else if (v == "direct") opt.permute = 1; else if (v == "staged") opt.permute = 2; else goto bad;

@@ -655,7 +655,8 @@ int fpx_lane_stats(fpx_handle h, uint64_t *out, int32_t n, int32_t reset);
  * reads no environment variable).  Names: "verbose" (0|1: the engine reports its launch geometry on stderr),
  * "pbl_blocks_per_cu" (1..: fewer resident blocks of the Langevin kernel), "pbl_slices" (comma-separated pass budgets of the
  * successive launches of the Langevin kernel, 0 = no budget, e.g. "48,96,0"; overrides fpx_config.pbl_slice_passes),
- * "prep_lds_pad" (bytes of unused dynamic LDS of k_prep: lowers its occupancy), "permute" ("soa"|"record"|"auto": the
+ * "prep_lds_pad" (bytes of unused dynamic LDS of k_prep: lowers its occupancy), "prep_init_always" (0|1: every step runs the
+ * instance of k_prep that can initialize() new particles, as in a run with a continuous release), "pbl_drain_lanes", "pbl_cost_buckets", "permute" ("soa"|"record"|"auto": the
  * permutation kernel of the locality sort), "vt_unfused" (0|1: the level-parallel chain of fpx_verttransform_ecmwf instead
  * of the fused tile kernels), "conv_scratch_mb", "conv_one_lane", "conv_no_walk", "conv_rows_plain" (fpx_convmix variants).
  * Unknown names and malformed values return FPX_ERR_ARG. */
