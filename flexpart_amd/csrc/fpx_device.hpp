@@ -1763,7 +1763,15 @@ FPX_DEV void initialize_particle(const View<R> &V, const R *hgt, const RNG &G, i
   // The reference's initialize() reads the module variable ngrid left behind by the
   // previous particle's advance() (interpol_all.f90:144); a parallel engine has no
   // "previous particle", so the particle's own polar/lat-lon choice is used.
-  const Fld<R> F = fld_of(V, pick_polar(V, P.yt));
+  // (both wind packs read before the choice, for the reason given at pick(): `pole ? V.w3pol : V.w3` becomes one load at a
+  // selected address and the fp64 instances with a polar or nest table then kept the kernel argument in scratch, 816 B a lane)
+  Fld<R> F = fld_of(V, 0);
+  {
+    const R *w3pol = V.w3pol;
+    const bool pole = pick_polar(V, P.yt) != 0;
+    F.w3 = pole ? w3pol : F.w3;
+    F.w3t0 = pole ? nullptr : F.w3t0; F.w3t1 = pole ? nullptr : F.w3t1; F.r2t0 = pole ? nullptr : F.r2t0;
+  }
   R usig, vsig, wsig;
   if (T.zeta <= K(1.)) {
     interp_surface(V, F, C, W, T);
