@@ -413,7 +413,8 @@ struct View {
   int pbl_cost_buckets;          // work-list order: cost buckets below the stability class (k_prep; scheduling only)
   int nspec, drydep, drydepspec[kMaxSpec];
   R ctl, fine, d_trop, d_strat, turbmesoscale;
-  R density[kMaxSpec], dquer[kMaxSpec], vsetaver[kMaxSpec], cunningham[kMaxSpec], decay[kMaxSpec];
+  R density[kMaxSpec], dquer[kMaxSpec], vsetaver[kMaxSpec], cunningham[kMaxSpec], decay[kMaxSpec];   // for compile-time subscripts only
+  const R *spec;                 // [kMaxSpec][4] = (density, dquer, vsetaver, cunningham) of each species in device memory: what a per-lane subscript reads (spec_row)
   // release-point tables of point_mod (fpx_set_release_points), indexed per lane by npoint(j): device memory
   int numpoint, mquasilag;
   const R *rel_xmass;            // [maxspec][numpoint]: xmass(numpoint, maxspec), column-major like the host's
@@ -448,20 +449,18 @@ struct View {
   unsigned int pid_base;   // global number of this rank's particle 0 (fpx_config.particle_base): key of the counter RNG
 };
 
-// Per-lane (divergent) subscripts into the small by-value tables of View.  A dynamic subscript
-// would force the whole kernel argument into private (scratch) memory and with it every uniform
-// scalar into vector registers; a select chain over constant subscripts keeps View in SGPRs.
-// Every element is read BEFORE the selects: with the read inside the conditional, the optimiser (which sees this function
-// before it is inlined, View then being a plain pointer) merges the arms into one load at a selected address -- the
-// dynamic subscript after all.  (That cost the f32 k_prep instances with initialize() 576 B of scratch per lane and 13 ms.)
+// A per-lane (divergent) subscript into a small table held in REGISTERS: a select chain over constant subscripts.
+// Never use it on a table inside View: a dynamic subscript forces the whole kernel argument into private (scratch) memory and
+// with it every uniform scalar into vector registers -- and a select chain does not prevent that: the optimiser sees the
+// function before it is inlined, View then being a plain pointer, and merges the conditional loads into ONE load at a selected
+// address (measured: 576 B of scratch per lane and 13 ms in the f32 k_prep instances with initialize()); reading all elements
+// first avoids it but holds 40 scalar registers, which the polar k_prep instances paid with 22 spilled VGPRs (0.72 -> 0.85 ms).
+// Tables with a per-lane subscript live in device memory (View::nest, View::spec, View::polemaps).
 template <typename T, int N>
 FPX_DEV T pick(const T (&a)[N], int l) {
-  T v[N];
+  T r = a[0];
 #pragma unroll
-  for (int k = 0; k < N; k++) v[k] = a[k];
-  T r = v[0];
-#pragma unroll
-  for (int k = 1; k < N; k++) r = (l == k) ? v[k] : r;
+  for (int k = 1; k < N; k++) r = (l == k) ? a[k] : r;
   return r;
 }
 
@@ -1374,21 +1373,34 @@ FPX_DEV int settling_column(const View<R> &V, R xt, R yt) {   // nix = int(xt), 
   return njy * V.nx + nix;
 }
 template <typename R> struct Stash;
+// the per-species constants of the settling routine for a per-lane species index: one row of View::spec (device memory).
+// An index outside the table reads species 0, as the select chain this replaces did.
+template <typename R>
+struct alignas(4 * sizeof(R)) SpecRow { R density, dquer, vsetaver, cunningham; };
+template <typename R>
+FPX_DEV SpecRow<R> spec_row(const View<R> &V, int nsp) {
+  typedef const SpecRow<R> __attribute__((address_space(1))) *row_ptr;   // a global load, said so (as a flat one it tripped the compiler in the Langevin kernel, whose other tables are in LDS)
+  const SpecRow<R> __attribute__((address_space(1))) &g = ((row_ptr)V.spec)[(unsigned int)nsp < (unsigned int)kMaxSpec ? nsp : 0];
+  SpecRow<R> r;
+  r.density = g.density; r.dquer = g.dquer; r.vsetaver = g.vsetaver; r.cunningham = g.cunningham;
+  return r;
+}
 template <typename R>
 struct SettleSpec { R num, dq6, vset; };   // the species constants of get_settling.f90:96-117 as the routine evaluates them
 template <typename R>
 FPX_DEV SettleSpec<R> settle_spec(const View<R> &V, int nsp) {
   const R ga = K(9.81);
   SettleSpec<R> c;
-  c.dq6 = pick(V.dquer, nsp) / K(1.e6);
-  c.vset = pick(V.vsetaver, nsp);
-  c.num = K(4) * ga * pick(V.dquer, nsp) / K(1.e6) * pick(V.density, nsp) * pick(V.cunningham, nsp);
+  const SpecRow<R> sp = spec_row(V, nsp);
+  c.dq6 = sp.dquer / K(1.e6);
+  c.vset = sp.vsetaver;
+  c.num = K(4) * ga * sp.dquer / K(1.e6) * sp.density * sp.cunningham;
   return c;
 }
 template <typename R, bool FAST = false>
 FPX_DEV R get_settling(const View<R> &V, const R *hgt, int column, R zt, int nsp, int level_hint = 0, const Stash<R> *ST = nullptr) {
 #if defined(FPX_EXP_SETTLE) && FPX_EXP_SETTLE == 1   // timing experiment only (wrong results): no settling computation at all
-  if (FAST) return pick(V.vsetaver, nsp);
+  if (FAST) return spec_row(V, nsp).vsetaver;
 #endif
   int indz = level_hint;
   // the level with height(indz) <= zt < height(indz+1), as the search of get_settling.f90:58-64 finds it
@@ -1474,7 +1486,7 @@ FPX_DEV int settling_species(const View<R> &V, int npoint) {
 template <typename R, bool FAST = false>
 FPX_DEV R settling_velocity(const View<R> &V, const R *hgt, double xt, double yt, R zt, int nsp, int level_hint = 0) {
   if (V.mdomainfill != 0 || !V.lsettling) return K(0.);
-  if (!(pick(V.density, nsp) > K(0.))) return K(0.);
+  if (!(spec_row(V, nsp).density > K(0.))) return K(0.);
   return get_settling<R, FAST>(V, hgt, settling_column(V, (R)xt, (R)yt), zt, nsp, level_hint);
 }
 

@@ -45,6 +45,19 @@ FPX_TU_OPEN
   } while (0)
 
 constexpr int kBlock = 256;
+// The big kernels read the fields of their first argument, the View, THROUGH the kernel-argument segment instead of from the
+// by-value parameter.  A by-value aggregate is a private copy that the optimiser splits into one scalar per field, all loaded at the
+// kernel's entry: in k_prep that is 40 scalar loads whose results do not fit the scalar file and travel as lanes of a vector
+// register (800-1300 v_readlane per kernel; polar k_prep 0.78 instead of 0.71 ms) -- and as soon as ONE access has an address
+// the optimiser cannot resolve (a per-lane subscript, a select between two fields' addresses) the whole copy lives in scratch
+// (576-816 B per lane in three instance families before this).  Read in place, every field is a scalar load from constant memory
+// next to its use, re-loaded rather than spilled, and no copy exists that could end up in scratch.  The View must be the kernel's
+// FIRST parameter (offset 0 of the segment).
+#ifndef FPX_VIEW_BY_VALUE
+#define FPX_VIEW_FROM_KERNARG(V, V_arg) const View<R> &V = *(const View<R> *)(const void *)__builtin_amdgcn_kernarg_segment_ptr(); (void)V_arg
+#else
+#define FPX_VIEW_FROM_KERNARG(V, V_arg) const View<R> &V = V_arg
+#endif
 #ifndef FPX_PREP_WAVES
 #define FPX_PREP_WAVES 3   // register budget (waves per SIMD) of k_prep (<= 168 VGPRs)
 #endif
@@ -640,9 +653,10 @@ __device__ __forceinline__ void prep_body(const View<R> &V, const GridP<R> &Gp, 
 }
 
 template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, ((INIT && !FPX_INIT_PREP_3WAVES) || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock, ((INIT && !FPX_INIT_PREP_3WAVES) || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V_arg, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
                                                  unsigned int *__restrict__ pbl_count) {
+  FPX_VIEW_FROM_KERNARG(V, V_arg);
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
@@ -1285,11 +1299,12 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
 // SUSP = false: the instance of a step with ONE launch -- nothing can be suspended or resumed, and the refill, which runs with two
 // lanes of the wave, carries none of that (the hand-over of suspended particles cost 2 % of the kernel's instructions at 1e8).
 template <typename R, bool LEAN, int TSW, int CBLF, int RNGM, bool SUSP = false>
-__global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+__global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V_arg, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                      const unsigned int *__restrict__ pbl_list,
                                                      unsigned int *__restrict__ blk,
                                                      int cap_passes, int drain_lanes,
                                                      unsigned int *__restrict__ next_list) {
+  FPX_VIEW_FROM_KERNARG(V, V_arg);   // (k_pbl_loop<double, true, 1, 1, 2>: 157 -> 153 VGPRs, 49 -> 19 spilled SGPRs, 24 B -> no scratch; -0.5 to -1 % of the launch)
   // blk: this launch's block of the counters (see k_list_counts): per class c the first blk[c] entries of the class's segment
   // [blk[8 + c], ...) of pbl_list, the class's chunk cursor blk[4 + c]; the next launch's block follows
   const unsigned int *mine = blk;
@@ -1481,7 +1496,7 @@ __global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : 
             if (!LEAN && V.lsettling) {
               const int nsp = settling_species(V, l_npoint);
               const SettleSpec<R> sp = settle_spec(V, nsp);
-              S.put(S_SET_NUM, pick(V.density, nsp) > (R)0 ? sp.num : (R)0);   // density(nsp) <= 0: no settling (advance.f90:525)
+              S.put(S_SET_NUM, spec_row(V, nsp).density > (R)0 ? sp.num : (R)0);   // density(nsp) <= 0: no settling (advance.f90:525)
               S.put(S_SET_DQ6, sp.dq6); S.put(S_SET_V0, sp.vset);
               S.put(S_SETCELL, (R)settling_column(V, (R)xt, (R)yt));   // < nx*ny: exact in R (f32: grids up to 2^24 columns, checked at fpx_create)
               if (sizeof(R) == 4) S.put(S_RT_TAG, (R)0);
@@ -1623,7 +1638,7 @@ __device__ __forceinline__ void finish_body(const View<R> &V, const GridP<R> &Gp
 
 // completion of the PBL particles (finish_body).  One thread per list entry or slot.
 template <typename R, bool DRYDEP, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R> V, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+__global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R> V_arg, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
                                                        const unsigned char *__restrict__ pbl_key, long long numpart,
                                                        const unsigned int *__restrict__ pbl_list, const unsigned int *__restrict__ pbl_count) {
   // Two orders.  pbl_list given: the work list (class by class, each class in slot = cell order): every lane busy.  With cost
@@ -1631,13 +1646,16 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
   // time again in scattered record and state accesses (0.58 -> 0.87 ms at 1.25e7 particles); then pbl_list is null and the
   // kernel goes through the SLOTS, taking those whose key of this step says "boundary layer" (0.77 ms when every slot has a
   // lane and the others idle; with the per-wave queue below the waves are full).
+  FPX_VIEW_FROM_KERNARG(V, V_arg);
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
   // Slot order: every wave walks tiles of 64 consecutive slots, collects the boundary-layer ones in a queue of its own in LDS
   // and works them off 64 at a time -- full waves in (nearly) slot order, whatever share of a tile is boundary layer.
   __shared__ unsigned int queue_mem[kBlock / 64][128];
-  volatile unsigned int *queue = queue_mem[threadIdx.x >> 6];
+  // (an LDS pointer by type: as a generic one it made the compiler emit an instruction its own verifier rejects in the polar instance)
+  typedef volatile unsigned int __attribute__((address_space(3))) *lds_queue_ptr;
+  const lds_queue_ptr queue = (lds_queue_ptr)&queue_mem[threadIdx.x >> 6][0];
   const int lane = threadIdx.x & 63;
   unsigned int qlen = 0;   // wave-uniform
   const long long nwork = pbl_list ? (long long)*pbl_count : (numpart + 63) >> 6;   // list entries | tiles of 64 slots
@@ -1700,7 +1718,8 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
 
 // conccalc.f90:50-295: every slot, whole waves stay convergent for the wave-level pre-reduction
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V, GridP<R> Gp, Parts<R> P, long long numpart, int itime, R weight) {
+__global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V_arg, GridP<R> Gp, Parts<R> P, long long numpart, int itime, R weight) {
+  FPX_VIEW_FROM_KERNARG(V, V_arg);
   __shared__ R hgt[kMaxNz];
   __shared__ R outh[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
@@ -1745,8 +1764,9 @@ __global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V, GridP<R> Gp, Par
 // interpol_vdep[_nests] reads: those are the ones initialize() of the same particle left in interpol_mod, i.e. the
 // mother grid's weights at the particle's position and the step's time weights -- computed here from the position.
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_bkdep(View<R> V, WetP<R> Wp, Parts<R> P, long long numpart, int itime, int drybkdep, int wetbkdep,
+__global__ void __launch_bounds__(kBlock) k_bkdep(View<R> V_arg, WetP<R> Wp, Parts<R> P, long long numpart, int itime, int drybkdep, int wetbkdep,
                                                   const R *__restrict__ zspan /* [numpoint] zpoint2 - zpoint1 */) {
+  FPX_VIEW_FROM_KERNARG(V, V_arg);
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
@@ -1810,8 +1830,9 @@ __global__ void __launch_bounds__(kBlock) k_bkdep(View<R> V, WetP<R> Wp, Parts<R
 
 // wetdepo.f90:58-151: every live particle that is due or overdue
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V, GridP<R> Gp, WetP<R> Wp, Parts<R> P, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V_arg, GridP<R> Gp, WetP<R> Wp, Parts<R> P, long long numpart, int itime,
                                                     int ltsample, int loutnext) {
+  FPX_VIEW_FROM_KERNARG(V, V_arg);
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
@@ -2156,6 +2177,13 @@ struct Engine : EngineBase {
       if ((rc = dalloc(&p, 18))) return rc;
       HIPCHK(hipMemcpy(p, maps, sizeof(maps), hipMemcpyHostToDevice));
       V.polemaps = p;
+    }
+    {
+      R rows[kMaxSpec][4];
+      for (int i = 0; i < kMaxSpec; i++) { rows[i][0] = V.density[i]; rows[i][1] = V.dquer[i]; rows[i][2] = V.vsetaver[i]; rows[i][3] = V.cunningham[i]; }
+      if ((rc = dalloc(&p, kMaxSpec * 4))) return rc;
+      HIPCHK(hipMemcpy(p, rows, sizeof(rows), hipMemcpyHostToDevice));
+      V.spec = p;
     }
     if ((rc = dalloc(&p, nlev * 6))) return rc; V.w3 = p;
     HIPCHK(hipMemsetAsync(p, 0, nlev * 6 * sizeof(R), stream));

@@ -184,6 +184,37 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
         assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * scale
 
 
+@pytest.mark.parametrize("rb", [8, 4])
+@pytest.mark.parametrize("case", ["settling_only", "drydep_only", "settling_only_polar"])
+def test_settling_and_dry_deposition_are_switched_separately(built, case, rb):
+    """k_prep / k_pbl_finish have two families of instances: one for runs with neither dry deposition nor settling (the settling
+    routine is not compiled into it) and one with both compiled in, each still behind its run-time switch.  A run with only one
+    of the two features takes the second family: settling without deposition velocities, deposition of a species that does not
+    settle.  Both against the oracle; the polar variant runs the instance with the stereographic maps."""
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario("polar" if case.endswith("polar") else "aerosol")
+    if case.startswith("settling_only"):
+        sc.update(lsettling=1, drydep=0, drydepspec=np.array([0], np.int32), density=np.array([2000.0]), dquer=np.array([8.0]),
+                  vsetaver=np.array([-0.004]), cunningham=np.array([1.02]), decay=np.array([0.0]), xmass=np.array([1.0]))
+        sc.pop("vdep", None)
+    else:
+        sc.update(lsettling=0)
+    got, want = run_pair(sc, "r8" if rb == 8 else "r4")
+    for g, w in zip(got, want):
+        if rb == 8:
+            assert_close(g, w, 1e-9, 1e-7)
+            assert np.abs(g["xmass1"] - w["xmass1"]).max() <= 1e-12 * np.abs(w["xmass1"]).max()
+        else:
+            assert_close(g, w, 2e-6, 5e-3, max_diverged=int(0.02 * len(w["xtra1"])))
+    # the feature that is on did act: settling moves the particles down against the same run without it / deposition takes mass
+    if case.startswith("settling_only"):
+        sc0 = dict(sc); sc0.update(lsettling=0)
+        base, _ = run_pair(sc0, "r8" if rb == 8 else "r4")
+        assert np.mean(got[-1]["ztra1"]) < np.mean(base[-1]["ztra1"])
+    else:
+        assert got[-1]["xmass1"].sum() < got[0]["xmass1"].sum() or got[-1]["xmass1"].sum() < float(np.asarray(sc["xmass1"]).sum())
+
+
 @pytest.mark.parametrize("name", ["polar", "aerosol", "cbl", "hanna", "hanna1_method0", "above_pbl_only", "nest", "nest_wet", "sampling",
                                   "sampling_nest", "backward", "backward_cbl", "limited_area", "three_species", "multi_release", "age_classes",
                                   "backward_drybkdep", "backward_drybkdep_nest", "backward_wetbkdep",
