@@ -653,10 +653,17 @@ __device__ __forceinline__ void prep_body(const View<R> &V, const GridP<R> &Gp, 
 }
 
 template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, ((INIT && !FPX_INIT_PREP_3WAVES) || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V_arg, GridP<R> Gp, Parts<R> P, SeqRng S, PblRec<R> Q, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock, ((INIT && !FPX_INIT_PREP_3WAVES) || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V_arg, GridP<R> Gp_arg, Parts<R> P_arg, SeqRng S_arg, PblRec<R> Q_arg, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
                                                  unsigned int *__restrict__ pbl_count) {
-  FPX_VIEW_FROM_KERNARG(V, V_arg);
+#ifndef FPX_VIEW_BY_VALUE
+  struct KArgs { View<R> V; GridP<R> Gp; Parts<R> P; SeqRng S; PblRec<R> Q; };   // the leading parameters as the segment holds them
+  const KArgs &ka = *(const KArgs *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  const View<R> &V = ka.V; const GridP<R> &Gp = ka.Gp; Parts<R> &P = const_cast<Parts<R> &>(ka.P); const SeqRng &S = ka.S; const PblRec<R> &Q = ka.Q;
+  (void)V_arg; (void)Gp_arg; (void)P_arg; (void)S_arg; (void)Q_arg;
+#else
+  const View<R> &V = V_arg; const GridP<R> &Gp = Gp_arg; Parts<R> &P = P_arg; const SeqRng &S = S_arg; const PblRec<R> &Q = Q_arg;
+#endif
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
@@ -1299,12 +1306,21 @@ __global__ void k_list_counts(const unsigned char *__restrict__ sorted_keys, lon
 // SUSP = false: the instance of a step with ONE launch -- nothing can be suspended or resumed, and the refill, which runs with two
 // lanes of the wave, carries none of that (the hand-over of suspended particles cost 2 % of the kernel's instructions at 1e8).
 template <typename R, bool LEAN, int TSW, int CBLF, int RNGM, bool SUSP = false>
-__global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V_arg, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+__global__ void __launch_bounds__(kBlock, sizeof(R) == 4 ? FPX_LOOP_WAVES_F32 : FPX_LOOP_WAVES) k_pbl_loop(View<R> V_arg, Parts<R> P_arg, PblRec<R> Q_arg, int itime, unsigned int step, Stats *st,
                                                      const unsigned int *__restrict__ pbl_list,
                                                      unsigned int *__restrict__ blk,
                                                      int cap_passes, int drain_lanes,
                                                      unsigned int *__restrict__ next_list) {
-  FPX_VIEW_FROM_KERNARG(V, V_arg);   // (k_pbl_loop<double, true, 1, 1, 2>: 157 -> 153 VGPRs, 49 -> 19 spilled SGPRs, 24 B -> no scratch; -0.5 to -1 % of the launch)
+  // (the View alone: k_pbl_loop<double, true, 1, 1, 2> 157 -> 153 VGPRs, 49 -> 19 spilled SGPRs, 24 B -> no scratch; -0.5 to -1 % of the launch)
+#if !defined(FPX_VIEW_BY_VALUE) && !defined(FPX_LOOP_ONLY_VIEW)
+  struct KArgs { View<R> V; Parts<R> P; PblRec<R> Q; };
+  const KArgs &ka = *(const KArgs *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  const View<R> &V = ka.V; const Parts<R> &P = ka.P; const PblRec<R> &Q = ka.Q;
+  (void)V_arg; (void)P_arg; (void)Q_arg;
+#else
+  FPX_VIEW_FROM_KERNARG(V, V_arg);
+  const Parts<R> &P = P_arg; const PblRec<R> &Q = Q_arg;
+#endif
   // blk: this launch's block of the counters (see k_list_counts): per class c the first blk[c] entries of the class's segment
   // [blk[8 + c], ...) of pbl_list, the class's chunk cursor blk[4 + c]; the next launch's block follows
   const unsigned int *mine = blk;
@@ -1638,15 +1654,22 @@ __device__ __forceinline__ void finish_body(const View<R> &V, const GridP<R> &Gp
 
 // completion of the PBL particles (finish_body).  One thread per list entry or slot.
 template <typename R, bool DRYDEP, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R> V_arg, GridP<R> Gp, Parts<R> P, PblRec<R> Q, int itime, unsigned int step, Stats *st,
+__global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R> V_arg, GridP<R> Gp_arg, Parts<R> P_arg, PblRec<R> Q_arg, int itime, unsigned int step, Stats *st,
                                                        const unsigned char *__restrict__ pbl_key, long long numpart,
                                                        const unsigned int *__restrict__ pbl_list, const unsigned int *__restrict__ pbl_count) {
+#ifndef FPX_VIEW_BY_VALUE
+  struct KArgs { View<R> V; GridP<R> Gp; Parts<R> P; PblRec<R> Q; };
+  const KArgs &ka = *(const KArgs *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  const View<R> &V = ka.V; const GridP<R> &Gp = ka.Gp; Parts<R> &P = const_cast<Parts<R> &>(ka.P); const PblRec<R> &Q = ka.Q;
+  (void)V_arg; (void)Gp_arg; (void)P_arg; (void)Q_arg;
+#else
+  const View<R> &V = V_arg; const GridP<R> &Gp = Gp_arg; Parts<R> &P = P_arg; const PblRec<R> &Q = Q_arg;
+#endif
   // Two orders.  pbl_list given: the work list (class by class, each class in slot = cell order): every lane busy.  With cost
   // buckets in the list (32 interleaved sub-sequences of the cell-sorted slots) following it costs this kernel half of its
   // time again in scattered record and state accesses (0.58 -> 0.87 ms at 1.25e7 particles); then pbl_list is null and the
   // kernel goes through the SLOTS, taking those whose key of this step says "boundary layer" (0.77 ms when every slot has a
   // lane and the others idle; with the per-wave queue below the waves are full).
-  FPX_VIEW_FROM_KERNARG(V, V_arg);
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4 job 39: the View through the kernel-argument segment in all big kernels (k_prep, k_pbl_loop, k_pbl_finish, k_conccalc, k_wetdepo, k_bkdep): full GPU suite + bench lines
+# round 4 job 39: the leading aggregate parameters (View, GridP, Parts, PblRec, SeqRng) read through the kernel-argument segment in k_prep, k_pbl_loop, k_pbl_finish (the View alone in k_conccalc, k_wetdepo, k_bkdep): full GPU suite + bench lines
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r4_gputest39.log 2>&1; echo "pytest rc=$?"; tail -5 gpurun_out/r4_gputest39.log
 rm -f gpurun_out/r4_j39_*.json
