@@ -64,6 +64,10 @@ constexpr int kBlock = 256;
 #ifndef FPX_INIT_PREP_3WAVES
 #define FPX_INIT_PREP_3WAVES 1    // the INIT instance of k_prep at the three-wave budget too: its initialize() body runs only in waves that hold a new particle
 #endif
+#ifndef FPX_PREP_TWO_WAVES   // which instances of k_prep keep the two-wave register budget: none since the arguments are read in place (the nest
+// instances fit 168 VGPRs without a spill, the ones with dry deposition spill 6-12 registers; round 3: every INIT / POLAR / NEST / DRYDEP instance at two waves)
+#define FPX_PREP_TWO_WAVES(INIT, POLAR, NEST, DRYDEP) ((INIT && !FPX_INIT_PREP_3WAVES) || (POLAR && !FPX_POLAR_PREP_3WAVES))
+#endif
 #ifndef FPX_POLAR_PREP_3WAVES
 #define FPX_POLAR_PREP_3WAVES 1   // the polar instance of k_prep at the three-wave register budget (the polar move is out of line: polar_move)
 #endif
@@ -653,7 +657,7 @@ __device__ __forceinline__ void prep_body(const View<R> &V, const GridP<R> &Gp, 
 }
 
 template <typename R, bool DRYDEP, bool INIT, bool POLAR, bool NEST>
-__global__ void __launch_bounds__(kBlock, ((INIT && !FPX_INIT_PREP_3WAVES) || NEST || DRYDEP || (POLAR && !FPX_POLAR_PREP_3WAVES)) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V_arg, GridP<R> Gp_arg, Parts<R> P_arg, SeqRng S_arg, PblRec<R> Q_arg, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock, FPX_PREP_TWO_WAVES(INIT, POLAR, NEST, DRYDEP) ? 2 : FPX_PREP_WAVES) k_prep(View<R> V_arg, GridP<R> Gp_arg, Parts<R> P_arg, SeqRng S_arg, PblRec<R> Q_arg, long long numpart, int itime,
                                                  unsigned int step, Stats *st, unsigned char *__restrict__ pbl_flag,
                                                  unsigned int *__restrict__ pbl_count) {
 #ifndef FPX_VIEW_BY_VALUE
