@@ -97,3 +97,31 @@ def test_fortran_bind_c_types_match_the_c_header(kind):
     want = [C.sizeof(t) for t in (_lib.FpxConfig, _lib.FpxFields, _lib.FpxParticles, _lib.FpxStepStats, _lib.FpxModelLevels,
                                   _lib.FpxFieldsOut, _lib.FpxDiagFields, _lib.FpxRestart, _lib.FpxConcout, _lib.FpxNests)]
     assert got == want
+
+
+def test_kernels_that_read_their_arguments_in_place_have_them_first():
+    """k_prep, k_pbl_loop, k_pbl_finish and the scatter kernels read the View (and the aggregates behind it) through the
+    kernel-argument segment at offset 0 (FPX_VIEW_FROM_KERNARG / the KArgs mirror structs).  That is only right while the
+    parameter list starts with exactly the members of the mirror, in the same order."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flexpart_amd", "csrc", "fpx_engine.hip")).read()
+    kernels = list(re.finditer(r"__global__\s+void\s+(?:__launch_bounds__\([^;{]*?\)\s*)?(k_\w+)\(([^{;]*?)\)\s*\{", src, re.S))
+    assert len(kernels) > 30
+    seen = 0
+    for i, m in enumerate(kernels):
+        end = kernels[i + 1].start() if i + 1 < len(kernels) else len(src)
+        body = src[m.end():end]
+        head = body[:1500]
+        if "FPX_VIEW_FROM_KERNARG(V, V_arg)" not in head and "__builtin_amdgcn_kernarg_segment_ptr()" not in head:
+            continue
+        seen += 1
+        params = [p.strip() for p in re.sub(r"\s+", " ", m.group(2)).split(",")]
+        assert params[0] == "View<R> V_arg", (m.group(1), params[0])
+        mirror = re.search(r"struct KArgs \{([^}]*)\}", head)
+        if mirror:
+            members = [re.sub(r"\s+", " ", x.strip()) for x in mirror.group(1).split(";") if x.strip()]
+            types = [x.rsplit(" ", 1)[0] for x in members]
+            got = [p.rsplit(" ", 1)[0] for p in params[:len(types)]]
+            assert got == types, (m.group(1), got, types)
+    assert seen >= 6
