@@ -1745,8 +1745,15 @@ __global__ void __launch_bounds__(kBlock, FPX_FINISH_WAVES) k_pbl_finish(View<R>
 
 // conccalc.f90:50-295: every slot, whole waves stay convergent for the wave-level pre-reduction
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V_arg, GridP<R> Gp, Parts<R> P, long long numpart, int itime, R weight) {
-  FPX_VIEW_FROM_KERNARG(V, V_arg);
+__global__ void __launch_bounds__(kBlock) k_conccalc(View<R> V_arg, GridP<R> Gp_arg, Parts<R> P_arg, long long numpart, int itime, R weight) {
+#ifndef FPX_VIEW_BY_VALUE
+  struct KArgs { View<R> V; GridP<R> Gp; Parts<R> P; };
+  const KArgs &ka = *(const KArgs *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  const View<R> &V = ka.V; const GridP<R> &Gp = ka.Gp; const Parts<R> &P = ka.P;
+  (void)V_arg; (void)Gp_arg; (void)P_arg;
+#else
+  const View<R> &V = V_arg; const GridP<R> &Gp = Gp_arg; const Parts<R> &P = P_arg;
+#endif
   __shared__ R hgt[kMaxNz];
   __shared__ R outh[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
@@ -1857,9 +1864,16 @@ __global__ void __launch_bounds__(kBlock) k_bkdep(View<R> V_arg, WetP<R> Wp, Par
 
 // wetdepo.f90:58-151: every live particle that is due or overdue
 template <typename R>
-__global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V_arg, GridP<R> Gp, WetP<R> Wp, Parts<R> P, long long numpart, int itime,
+__global__ void __launch_bounds__(kBlock) k_wetdepo(View<R> V_arg, GridP<R> Gp_arg, WetP<R> Wp_arg, Parts<R> P_arg, long long numpart, int itime,
                                                     int ltsample, int loutnext) {
-  FPX_VIEW_FROM_KERNARG(V, V_arg);
+#ifndef FPX_VIEW_BY_VALUE
+  struct KArgs { View<R> V; GridP<R> Gp; WetP<R> Wp; Parts<R> P; };
+  const KArgs &ka = *(const KArgs *)(const void *)__builtin_amdgcn_kernarg_segment_ptr();
+  const View<R> &V = ka.V; const GridP<R> &Gp = ka.Gp; const WetP<R> &Wp = ka.Wp; const Parts<R> &P = ka.P;
+  (void)V_arg; (void)Gp_arg; (void)Wp_arg; (void)P_arg;
+#else
+  const View<R> &V = V_arg; const GridP<R> &Gp = Gp_arg; const WetP<R> &Wp = Wp_arg; const Parts<R> &P = P_arg;
+#endif
   __shared__ R hgt[kMaxNz];
   for (int k = threadIdx.x; k < V.nz; k += blockDim.x) hgt[k] = V.height[k];
   __syncthreads();
