@@ -1262,6 +1262,14 @@ __global__ void __launch_bounds__(256) k_count_live(const int *__restrict__ itra
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(out, (unsigned long long)(part[0] + part[1] + part[2] + part[3]));
 }
+// the latest time of birth (itramem, in the run's time direction) among the live particles of the first n storage spaces
+__global__ void __launch_bounds__(256) k_birth_max(const int *__restrict__ itra1, const int *__restrict__ itramem, long long n, int ldirect, long long *__restrict__ out) {
+  long long m = LLONG_MIN;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    if (itra1[i] != kDead) m = max(m, (long long)ldirect * itramem[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_down(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m != LLONG_MIN) atomicMax(out, m);
+}
 // Counters of the step's work list (unsigned ints, zeroed at the start of every step):
 //   [0]     length of the whole list (all PBL particles; k_pbl_finish)
 //   [kCtrBase + 12 j + ...]: launch j of the Langevin kernel (ONE pointer gives a launch everything it needs):
@@ -2015,6 +2023,27 @@ struct Engine : EngineBase {
   View<R> V;
   Parts<R> P;
   bool maybe_new = true;   // particles may have been released since the last step
+  // A particle is initialised in the step whose time equals its itramem (timemanager.f90:553) -- normally the step after it was
+  // released or uploaded (maybe_new).  A host may also hand over particles that are born LATER (itra1 = itramem in the future):
+  // the instance of k_prep that can initialize() runs at every step up to the latest birth among the particles the host placed
+  // (found by one reduction over the particle arrays at the first step after an upload, a warm start, a restore or a receive).
+  bool births_unknown = true;
+  long long birth_horizon = LLONG_MIN;   // ldirect * itramem, the latest among the live particles at the last such event
+  int find_birth_horizon() {
+    births_unknown = false;
+    birth_horizon = LLONG_MIN;
+    if (numpart == 0) return 0;
+    int rc;
+    if (!d_count && (rc = dalloc(&d_count, 4))) return rc;
+    const long long init = LLONG_MIN;
+    HIPCHK(hipMemcpyAsync(d_count, &init, sizeof(long long), hipMemcpyHostToDevice, stream));
+    const int nb = (int)std::min<long long>((numpart + 255) / 256, 256 * 16);
+    k_birth_max<<<nb, 256, 0, stream>>>(P.itra1, P.itramem, numpart, cfg.ldirect, d_count);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&birth_horizon, d_count, sizeof(long long), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+  }
   bool height_set = false, window_set = false, table_set = false, slot_loaded[2] = {false, false};
   long long numpart = 0;
   // owned device memory
@@ -3055,7 +3084,7 @@ struct Engine : EngineBase {
                                                   : "readpartpositions: the file does not hold exactly one dump (header, records, closing record)");
     numpart = n;
     slot_of_pid = nullptr;
-    maybe_new = true;
+    maybe_new = true; births_unknown = true;
     if (numpart_out) *numpart_out = n;
     if (numparticlecount) *numparticlecount = status[1];
     if (itimein_out) *itimein_out = itimein;
@@ -3472,7 +3501,7 @@ struct Engine : EngineBase {
     if (e != hipSuccess) return fail(FPX_ERR_DEVICE, std::string("redist_unpack: ") + hipGetErrorString(e));
     if (nvalid[0] + nvalid[1] > 0) numpart = std::max<long long>(numpart, (long long)maxpid + 1);   // numpart=max(numpart,ipart), :836
     *numpart_io = numpart;
-    maybe_new = true;
+    maybe_new = true; births_unknown = true;
     return 0;
   }
 
@@ -3728,7 +3757,7 @@ struct Engine : EngineBase {
       }
     HIPCHK(hipStreamSynchronize(stream));
     numpart = std::max(numpart, first + count);
-    maybe_new = true;
+    maybe_new = true; births_unknown = true;
     return 0;
   }
 
@@ -4217,7 +4246,7 @@ struct Engine : EngineBase {
   // a restore that failed half-way leaves no usable state behind: no particles, no valid reductions
   int ckpt_invalidate(int rc) {
     numpart = 0;
-    maybe_new = true;
+    maybe_new = true; births_unknown = true;
     for (bool &v : red_valid) v = false;
     (void)hipStreamSynchronize(stream);
     const int nb = (int)((P.cap + kBlock - 1) / kBlock);
@@ -4390,7 +4419,7 @@ struct Engine : EngineBase {
     step_counter = h.step_counter;
     rel_global_count = h.rel_global_count;
     numpart = n;
-    maybe_new = true;
+    maybe_new = true; births_unknown = true;
     if (itime) *itime = h.itime;
     if (numpart_out) *numpart_out = n;
     if (numparticlecount) *numparticlecount = h.numparticlecount;
@@ -4460,7 +4489,7 @@ struct Engine : EngineBase {
     HIPCHK(hipStreamSynchronize(stream));
     slot_of_pid = nullptr;
     numpart = n;
-    maybe_new = true;
+    maybe_new = true; births_unknown = true;
     return 0;
   }
 
@@ -4601,7 +4630,8 @@ struct Engine : EngineBase {
     {
       // specialised variants: dry deposition (aerosols), initialize() only when new particles can
       // exist (after an upload/seed or at itime 0), polar maps only on grids with poles
-      const bool init = maybe_new || itime == 0 || opt.prep_init_always;
+      if (births_unknown) { const int rc = find_birth_horizon(); if (rc) return rc; }
+      const bool init = maybe_new || itime == 0 || (long long)cfg.ldirect * itime <= birth_horizon || opt.prep_init_always;
       const bool polar = cfg.nglobal || cfg.sglobal;
       typedef void (*prep_fn)(View<R>, GridP<R>, Parts<R>, SeqRng, PblRec<R>, long long, int, unsigned int, Stats *, unsigned char *, unsigned int *);
       const bool nest = V.numbnests > 0;

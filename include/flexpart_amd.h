@@ -411,7 +411,10 @@ int fpx_rng_get_table(fpx_handle h, void *rannumb, int32_t maxrand);
 /* ---- particles ------------------------------------------------------------ */
 /* Copy particles [first, first+count) from the host SoA (after releaseparticles,
  * particle splitting or a warm start) / back to it. Indices are the reference's
- * particle numbers j-1; an internal locality sort never changes them. */
+ * particle numbers j-1; an internal locality sort never changes them.
+ * A particle is initialised (initialize.f90) in the step whose time equals its itramem
+ * (timemanager.f90:553) -- also one that the host uploads ahead of its birth (itra1 =
+ * itramem = a later time): it is not due before, and the step at that time initialises it. */
 int fpx_upload_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p);
 int fpx_download_particles(fpx_handle h, int64_t first, int64_t count, const fpx_particles *p);
 int fpx_set_numpart(fpx_handle h, int64_t numpart);   /* com_mod numpart */

@@ -185,6 +185,51 @@ def test_fp64_matches_oracle_golden_scenarios(built, name):
 
 
 @pytest.mark.parametrize("rb", [8, 4])
+@pytest.mark.parametrize("name", ["cbl", "polar", "nest", "aerosol"])
+def test_particles_born_after_the_upload_are_initialised_at_their_time(built, name, rb):
+    """timemanager.f90:553 initialises a particle in the step whose time equals its itramem.  A host may upload particles that are
+    born later (itra1 = itramem = a future step): they are not due before, and the step at their time must run initialize() for
+    them although nothing was uploaded or released since -- the engine finds the latest birth among the uploaded particles and
+    keeps the k_prep instance with initialize() until then.  Against the oracle, and bit for bit against the same run with that
+    instance at every step ("prep_init_always")."""
+    from flexpart_amd.engine import Engine, RNG_TABLE_SEQ, RNG_PHILOX
+    from oracle.oracle import Oracle
+    from test_oracle_cpu import golden_scenario
+    sc = golden_scenario(name)
+    n = len(sc["xtra1"])
+    dt = int(sc["lsynctime"]) * int(sc["ldirect"])
+    born = int(sc["itime0"]) + dt * (np.arange(n) % 3)          # a third each at the first, second and third step
+    sc["itra1"] = born.astype(np.int32)
+    sc["itramem"] = born.astype(np.int32)
+    kind = "r8" if rb == 8 else "r4"
+    eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=RNG_TABLE_SEQ)
+    got = eng.run(3)
+    assert eng.counters()["n_initialized"] == n, "every particle is initialised exactly once, in its own step"
+    eng.close()
+    orc = Oracle(sc, kind)
+    orc.lib.orc_set_parallel_semantics(orc.h, 1)
+    want = orc.run(3)
+    for g, w in zip(got, want):
+        if rb == 8:
+            assert_close(g, w, 1e-9, 1e-7)
+        else:
+            assert_close(g, w, 2e-6, 5e-3, max_diverged=int(0.02 * n))
+    keys = ("xtra1", "ytra1", "ztra1", "uap", "ucp", "uzp", "us", "vs", "ws", "idt", "itra1", "cbt", "xmass1")
+    for mode in (RNG_PHILOX, RNG_TABLE_SEQ):
+        ref = None
+        for always in (0, 1):
+            eng = Engine(sc, compute_real_bytes=rb, host_real_bytes=rb, rng_mode=mode, seed=5, options={"prep_init_always": always})
+            out = eng.run(3)
+            eng.close()
+            if ref is None:
+                ref = out
+                continue
+            for a, b in zip(ref, out):
+                for k in keys:
+                    assert np.array_equal(a[k], b[k]), (mode, k)
+
+
+@pytest.mark.parametrize("rb", [8, 4])
 @pytest.mark.parametrize("case", ["settling_only", "drydep_only", "settling_only_polar"])
 def test_settling_and_dry_deposition_are_switched_separately(built, case, rb):
     """k_prep / k_pbl_finish have two families of instances: one for runs with neither dry deposition nor settling (the settling
