@@ -46,13 +46,18 @@ def main():
         if "fpx::" not in k or "::k_" not in k:
             continue
         short = re.sub(r"tu_r\d+_p\w+::", "", k.split("(")[0].replace("void ", ""))   # drop the translation unit's inline namespace
-        d = {c: v[-1] for c, v in sq[k].items()}             # last launch = a timed step
-        e = {"launches_profiled": len(next(iter(sq[k].values()))), "sq_last_launch": d}
+        # a timed step: the launch before the last (the last dispatch of a kernel in a counter pass can report SQ_WAVES
+        # of two dispatches -- seen for k_pbl_loop: 6144 instead of 3072 with every other counter in line)
+        n_l = len(next(iter(sq[k].values())))
+        pick = -2 if n_l >= 2 else -1
+        d = {c: v[pick] for c, v in sq[k].items()}
+        e = {"launches_profiled": n_l, "sq_last_launch": d}
         if d.get("SQ_ACTIVE_INST_VALU"):
             e["valu_lane_utilisation"] = d["SQ_THREAD_CYCLES_VALU"] / (d["SQ_ACTIVE_INST_VALU"] * 64)
             e["valu_active_per_wave_cycle"] = d["SQ_ACTIVE_INST_VALU"] / d["SQ_WAVE_CYCLES"]
-        f = fe.get(k, {}).get("FETCH_SIZE", [0])[-1]
-        w = wr.get(k, {}).get("WRITE_SIZE", [0])[-1]
+        fl, wl = fe.get(k, {}).get("FETCH_SIZE", [0]), wr.get(k, {}).get("WRITE_SIZE", [0])
+        f = fl[-2] if len(fl) >= 2 else fl[-1]
+        w = wl[-2] if len(wl) >= 2 else wl[-1]
         e["FETCH_SIZE_KiB"] = f
         e["WRITE_SIZE_KiB"] = w
         e["hbm_bytes_per_launch"] = (2.0 * f + w) * 1024.0
