@@ -519,8 +519,10 @@ FPX_DEV void philox4x32(unsigned int c0, unsigned int c1, unsigned int c2, unsig
                         unsigned int k0, unsigned int k1, unsigned int out[4]) {
 #pragma unroll
   for (int r = 0; r < kPhiloxRounds; r++) {
-    unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    // the 64-bit product in ONE instruction (v_mad_u64_u32, 4.3 issue cycles) instead of v_mul_hi_u32 + v_mul_lo_u32 (8.3)
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned int hi0 = (unsigned int)(p0 >> 32), lo0 = (unsigned int)p0;
+    const unsigned int hi1 = (unsigned int)(p1 >> 32), lo1 = (unsigned int)p1;
     unsigned int n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
     c0 = n0; c1 = n1; c2 = n2; c3 = n3;
     k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
