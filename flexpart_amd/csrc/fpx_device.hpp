@@ -98,14 +98,16 @@ FPX_DEV double m_rsqrt(double x) {   // x > 0
 // sqrt(x) for x >= 0 (0 allowed), 47 cycles
 FPX_DEV float m_sqrtp(float x) { return __builtin_amdgcn_sqrtf(x); }
 FPX_DEV double m_sqrtp(double x) {
-  double y = __builtin_amdgcn_rsq(x);
+  // rsq(0) = inf would make 0 * inf = NaN: bounded by 1e300 (1/sqrt of the smallest subnormal is 4.5e161) every step below
+  // gives exactly 0 for x = 0 -- one v_min_f64 instead of a compare and two conditional moves on the result
+  double y = __builtin_fmin(__builtin_amdgcn_rsq(x), 1.0e300);
   double g = x * y, h = 0.5 * y;
   double r = fma(-h, g, 0.5);
   g = fma(g, r, g);
   h = fma(h, r, h);
   double d = fma(-g, g, x);
   g = fma(d, h, g);
-  return x == 0.0 ? 0.0 : g;
+  return g;
 }
 // log(x) for the x**y = exp(y*log x) of the turbulence profiles: argument reduction to
 // [sqrt(1/2), sqrt(2)) and the degree-7 series in s = f/(2+f) (the classical fdlibm scheme);
@@ -383,6 +385,18 @@ template <typename R> FPX_HD R m_abs(R x) { return x < 0 ? -x : x; }
 template <typename R> FPX_HD R m_max(R a, R b) { return a > b ? a : b; }
 template <typename R> FPX_HD R m_min(R a, R b) { return a < b ? a : b; }
 template <typename R> FPX_HD R m_sign(R a, R b) { R m = m_abs(a); return (b < 0 || (b == 0 && signbit(b))) ? -m : m; }
+// The floating-point forms as the hardware has them: |x| is a source modifier (free), max / min one instruction, sign() one bit-field
+// insert -- written as comparisons and selects each costs a compare and two conditional moves per fp64 value (9.5 issue cycles
+// where the instruction takes 4.4 or nothing), and the fine loop of the Langevin kernel has ten of them per sub-step.  They differ
+// from the select forms only for NaN operands (max / min return the other operand) and for -0.0 (abs(-0.0) = +0.0, as in Fortran).
+FPX_HD float m_abs(float x) { return __builtin_fabsf(x); }
+FPX_HD double m_abs(double x) { return __builtin_fabs(x); }
+FPX_HD float m_max(float a, float b) { return __builtin_fmaxf(a, b); }
+FPX_HD double m_max(double a, double b) { return __builtin_fmax(a, b); }
+FPX_HD float m_min(float a, float b) { return __builtin_fminf(a, b); }
+FPX_HD double m_min(double a, double b) { return __builtin_fmin(a, b); }
+FPX_HD float m_sign(float a, float b) { return __builtin_copysignf(a, b); }     // sign(a,b) of Fortran: |a| with the sign bit of b
+FPX_HD double m_sign(double a, double b) { return __builtin_copysign(a, b); }
 FPX_HD double d_modulo(double a, double p) { double r = fmod(a, p); if (r != 0.0 && ((r < 0) != (p < 0))) r += p; return r; }
 
 // ---------------------------------------------------------------------------

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 4 job 47: Philox rounds with one v_mad_u64_u32 per product: parity tests + bench lines
+# round 4 job 47: instruction-level work on the fine loop (Philox products, native abs / max / min / sign, sqrt without selects): parity tests + bench lines
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/r4_gputest47.log 2>&1; echo "pytest rc=$?"; tail -4 gpurun_out/r4_gputest47.log
 rm -f gpurun_out/r4_j47_*.json
