@@ -45,6 +45,22 @@ FPX_HD float m_erf(float x) { return erff(x); }
 FPX_HD double m_erf(double x) { return erf(x); }
 FPX_HD float m_pow(float x, float y) { return powf(x, y); }
 FPX_HD double m_pow(double x, double y) { return pow(x, y); }
+template <typename R> FPX_HD R m_abs(R x) { return x < 0 ? -x : x; }
+template <typename R> FPX_HD R m_max(R a, R b) { return a > b ? a : b; }
+template <typename R> FPX_HD R m_min(R a, R b) { return a < b ? a : b; }
+template <typename R> FPX_HD R m_sign(R a, R b) { R m = m_abs(a); return (b < 0 || (b == 0 && signbit(b))) ? -m : m; }
+// The floating-point forms as the hardware has them: |x| is a source modifier (free), max / min one instruction, sign() one bit-field
+// insert -- written as comparisons and selects each costs a compare and two conditional moves per fp64 value (9.5 issue cycles
+// where the instruction takes 4.4 or nothing), and the fine loop of the Langevin kernel has ten of them per sub-step.  They differ
+// from the select forms only for NaN operands (max / min return the other operand) and for -0.0 (abs(-0.0) = +0.0, as in Fortran).
+FPX_HD float m_abs(float x) { return __builtin_fabsf(x); }
+FPX_HD double m_abs(double x) { return __builtin_fabs(x); }
+FPX_HD float m_max(float a, float b) { return __builtin_fmaxf(a, b); }
+FPX_HD double m_max(double a, double b) { return __builtin_fmax(a, b); }
+FPX_HD float m_min(float a, float b) { return __builtin_fminf(a, b); }
+FPX_HD double m_min(double a, double b) { return __builtin_fmin(a, b); }
+FPX_HD float m_sign(float a, float b) { return __builtin_copysignf(a, b); }     // sign(a,b) of Fortran: |a| with the sign bit of b
+FPX_HD double m_sign(double a, double b) { return __builtin_copysign(a, b); }
 // ---------------------------------------------------------------------------
 // Cheap fp64 building blocks for the Langevin inner loop.  Issue costs measured on MI355X
 // with tools/valu_rates.hip (cycles per wave64 instruction): add/mul/fma f64 4.4, v_rcp/v_rsq_f64 16,
@@ -279,14 +295,14 @@ __constant__ double kErfC[18] = {      // not static, not const: a constant the 
   -3.2623356004303588051e-1, 1.7900115118138999674e-1};
 template <typename T>
 FPX_DEV T m_erf_e(T x, T E) {
-  const T ax = x < (T)0 ? -x : x;
-  const T xc = ax < (T)6.5 ? ax : (T)6.5;
+  const T ax = m_abs(x);
+  const T xc = m_min(ax, (T)6.5);
   const T t = (xc - (T)3.0) * m_rcp(xc + (T)3.0);
   T p = (T)kErfC[0];
 #pragma unroll
   for (int i = 1; i < 18; i++) p = p * t + (T)kErfC[i];
   const T r = (T)1.0 - E * p;
-  return x < (T)0 ? -r : r;
+  return m_sign(r, x);
 }
 // Two error functions at once (cbl.f90:195-204 needs erf(aperfa) and erf(aperfb)): one fetch of the coefficients serves both
 // Horner chains.  The pointer passes through an empty asm so that the scalar loads stay where they are used -- hoisted to
@@ -296,15 +312,17 @@ FPX_DEV void m_erf_e2(T xa, T Ea, T xb, T Eb, T &ra, T &rb) {
   typedef const double __attribute__((address_space(4))) *const_ptr;      // constant address space: uniform loads are scalar loads
   const_ptr c = (const_ptr)kErfC;
   asm volatile("" : "+s"(c));
-  const T aa = xa < (T)0 ? -xa : xa, ab = xb < (T)0 ? -xb : xb;
-  const T ca = aa < (T)6.5 ? aa : (T)6.5, cb = ab < (T)6.5 ? ab : (T)6.5;
+  const T aa = m_abs(xa), ab = m_abs(xb);
+  const T ca = m_min(aa, (T)6.5), cb = m_min(ab, (T)6.5);
   const T ta = (ca - (T)3.0) * m_rcp(ca + (T)3.0), tb = (cb - (T)3.0) * m_rcp(cb + (T)3.0);
   T pa = (T)c[0], pb = (T)c[0];
 #pragma unroll
   for (int i = 1; i < 18; i++) { const T k = (T)c[i]; pa = pa * ta + k; pb = pb * tb + k; }
   const T qa = (T)1.0 - Ea * pa, qb = (T)1.0 - Eb * pb;
-  ra = xa < (T)0 ? -qa : qa;
-  rb = xb < (T)0 ? -qb : qb;
+  // the sign of x by a bit-field insert instead of a compare and two selects; qa, qb >= 0 up to the rounding of 1 - E*p at x = 0,
+  // where the two forms can differ by an ulp of 1 in the sign of a value of that size
+  ra = m_sign(qa, xa);
+  rb = m_sign(qb, xb);
 }
 // x**y for the reference's non-integer exponents (0.33333, 0.66666, 0.8 ...).  fp64: exp(y*log(x)),
 // relative error <= ~|y ln x| ulp (a few 1e-16 here) at a fraction of the cost of the
@@ -381,22 +399,6 @@ FPX_DEV void m_cuberoot_parts(double x, double &c, double &ic2) {
 }
 FPX_HD float m_fmod(float x, float y) { return fmodf(x, y); }
 FPX_HD double m_fmod(double x, double y) { return fmod(x, y); }
-template <typename R> FPX_HD R m_abs(R x) { return x < 0 ? -x : x; }
-template <typename R> FPX_HD R m_max(R a, R b) { return a > b ? a : b; }
-template <typename R> FPX_HD R m_min(R a, R b) { return a < b ? a : b; }
-template <typename R> FPX_HD R m_sign(R a, R b) { R m = m_abs(a); return (b < 0 || (b == 0 && signbit(b))) ? -m : m; }
-// The floating-point forms as the hardware has them: |x| is a source modifier (free), max / min one instruction, sign() one bit-field
-// insert -- written as comparisons and selects each costs a compare and two conditional moves per fp64 value (9.5 issue cycles
-// where the instruction takes 4.4 or nothing), and the fine loop of the Langevin kernel has ten of them per sub-step.  They differ
-// from the select forms only for NaN operands (max / min return the other operand) and for -0.0 (abs(-0.0) = +0.0, as in Fortran).
-FPX_HD float m_abs(float x) { return __builtin_fabsf(x); }
-FPX_HD double m_abs(double x) { return __builtin_fabs(x); }
-FPX_HD float m_max(float a, float b) { return __builtin_fmaxf(a, b); }
-FPX_HD double m_max(double a, double b) { return __builtin_fmax(a, b); }
-FPX_HD float m_min(float a, float b) { return __builtin_fminf(a, b); }
-FPX_HD double m_min(double a, double b) { return __builtin_fmin(a, b); }
-FPX_HD float m_sign(float a, float b) { return __builtin_copysignf(a, b); }     // sign(a,b) of Fortran: |a| with the sign bit of b
-FPX_HD double m_sign(double a, double b) { return __builtin_copysign(a, b); }
 FPX_HD double d_modulo(double a, double p) { double r = fmod(a, p); if (r != 0.0 && ((r < 0) != (p < 0))) r += p; return r; }
 
 // ---------------------------------------------------------------------------
