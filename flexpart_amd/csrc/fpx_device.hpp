@@ -351,12 +351,19 @@ FPX_DEV double m_coslat(double x) {
   p = fma(p, z, -0.5);
   return fma(p, z, 1.0);
 }
+// x * icbt for icbt = +-1 kept as a sign mask (0 | 0x80000000): one v_xor_b32 on the word with the sign bit instead of an
+// int -> fp64 conversion and a multiplication (8.7 issue cycles) in every fine sub-step; the same bits
+FPX_DEV double m_flip(double x, unsigned int flip) { return __hiloint2double(__double2hiint(x) ^ (int)flip, __double2loint(x)); }
+FPX_DEV float m_flip(float x, unsigned int flip) { return __uint_as_float(__float_as_uint(x) ^ flip); }
+// is x a positive number the f32 seeds below can hold (2^-122 <= x < 2^122)?  One integer subtraction and one unsigned compare on
+// the high word instead of two fp64 compares: zero, negative numbers, subnormals, infinities and NaN all fall outside.
+FPX_DEV bool m_in_seed_range(double x) { return (unsigned int)(__double2hiint(x) - 0x38500000) < (unsigned int)(0x47900000 - 0x38500000); }
 // x**0.8 for 0 <= x (hanna.f90:97, hanna_short.f90:80: tlw = 0.1*h/sigw*zeta**0.8): 0.8 = 4/5, so x**0.8 = x*r with
 // r = x**(-1/5) from an f32 seed and two Newton steps r <- r + r*(1 - x*r^5)/5 (the literal 0.8 differs from 4/5
 // by 4e-17: invisible).  19 instructions instead of log + exp (58).
 FPX_DEV float m_pow08(float x) { return x > 0.0f ? __expf(0.8f * __logf(x)) : 0.0f; }
 FPX_DEV double m_pow08(double x) {
-  if (__builtin_expect(!(x > 1.0e-37 && x < 1.0e37), 0)) return x > 0.0 ? m_expp(0.8 * m_logp(x)) : (x == 0.0 ? 0.0 : x * __builtin_nan(""));   // x < 0: NaN like pow
+  if (__builtin_expect(!m_in_seed_range(x), 0)) return x > 0.0 ? m_expp(0.8 * m_logp(x)) : (x == 0.0 ? 0.0 : x * __builtin_nan(""));   // x < 0: NaN like pow
   double r = (double)__builtin_amdgcn_exp2f(__log2f((float)x) * -0.2f);
 #pragma unroll
   for (int it = 0; it < 2; it++) {
@@ -377,7 +384,7 @@ FPX_DEV void m_cuberoot_parts(float x, float &c, float &ic2) {
   ic2 = __expf(-2.0f * 0.333333333f * l);
 }
 FPX_DEV void m_cuberoot_parts(double x, double &c, double &ic2) {
-  if (__builtin_expect(!(x > 1.0e-37 && x < 1.0e37), 0)) {
+  if (__builtin_expect(!m_in_seed_range(x), 0)) {
     const double l = log(x);
     c = exp(0.333333333 * l);
     ic2 = exp(-2.0 * 0.333333333 * l);
@@ -784,16 +791,17 @@ struct PlainMath {
 template <typename R, typename MS>
 FPX_DEV void zeta_powers(R zeta, const MS &M, R &z23, R &zm13) {
   if (sizeof(R) == 8) {
-    const bool tiny = !(zeta > K(1.e-37));                   // 0 and what the f32 seed cannot hold: handled below
-    const R zc = tiny ? K(1.) : zeta;
+    // 0 and what the f32 seed cannot hold: the seed and the logarithm see 1e-37 instead (one v_max_f64, no selects); z23 below
+    // is then zeta * 2e12 < 2e-25 for such a zeta (exactly 0 for zeta = 0) -- under the rounding of the ust**2 term (ust >= 1e-4)
+    // of sigw either way
+    const R zc = m_max(zeta, K(1.e-37));
     const R lz = M.logabs(zc);
     const R r13 = m_rcbrt(zc);
     const R d1 = ((K(1.) / K(3.)) - K(.33333)) * lz;
     const R e13 = r13 * (K(1.) + d1 * (K(1.) + d1 * (K(0.5) + d1 * K(0.16666666666666666))));
     const R d = ((K(1.) - K(.33333)) - K(0.66666)) * lz;       // 1.e-5 * log(zeta)
     const R corr = K(1.) - d * (K(1.) - d * (K(0.5) - d * K(0.16666666666666666)));
-    // zeta < 1e-37: zeta**0.66666 < 3e-25 is below the rounding of the ust**2 term (ust >= 1e-4) of sigw
-    z23 = tiny ? K(0.) : zeta * e13 * corr;
+    z23 = zeta * e13 * corr;
     zm13 = zeta > K(1.e-3) ? e13 : K(9.9997697441416293);   // (1.e-3)**(-.33333)
   } else {   // reference typing: x**y as exp(y*log x) in f32 (a few ulp from powf, at a third of its cost)
     const R lz = m_logp(zeta);
@@ -2234,6 +2242,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 
   // vertical Langevin, ifine sub-steps, advance.f90:396-498
   FPX_LANES(st, 0);
+  unsigned int flip = icbt < 0 ? 0x80000000u : 0u;   // icbt as a sign mask inside the loop (m_flip)
   for (int i = 1; i <= V.ifine; i++) {
     R delz;
     FPX_LANES(st, 1);
@@ -2246,7 +2255,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             nrand = nrand + 1;
             R old_wp_buf = wp, ath, bth;
             cbl(S, V.ldirect, wp, zt, S.get(S_TRANS), HI.ih, S.get(S_RHOAUX), T.sigw, T.isigw, T.dsigwdz, T.tlw, ath, bth, flagrein);
-            wp = (wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf) * (R)icbt;
+            wp = m_flip(wp + ath * dtf + bth * G.at(nrand) * sqrt_dtf, flip);
             delz = wp * dtf;
             if (__builtin_expect(flagrein == 1, 0)) {
               re_initialize_particle(V.ldirect, G, zt, S.get(S_WST), h, T.sigw, old_wp_buf, nrand, S.get(S_OL));
@@ -2259,7 +2268,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             nrand = nrand + 1;
             R ath = -wp * m_rcp(T.tlw) + T.sigw * T.dsigwdz + wp * wp * T.isigw * T.dsigwdz + T.sigw * T.sigw * S.get(S_RHOAUX);
             R bth = T.sigw * G.at(nrand) * m_sqrtp(K(2.) * dtftlw);
-            wp = (wp + ath * dtf + bth) * (R)icbt;
+            wp = m_flip(wp + ath * dtf + bth, flip);
             delz = wp * dtf;
             // del_test=(1.-wp)/wp is NaN exactly when wp is NaN or infinite (advance.f90:440-441)
             if (__builtin_expect(!isfinite(wp), 0)) {
@@ -2270,18 +2279,18 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
             }
           }
         } else {
-          wp = ((K(1.) - dtftlw) * wp + G.at(nrand + i) * m_sqrtp(K(2.) * dtftlw) + dtf * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw)) * (R)icbt;
+          wp = m_flip((K(1.) - dtftlw) * wp + G.at(nrand + i) * m_sqrtp(K(2.) * dtftlw) + dtf * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw), flip);
           delz = wp * T.sigw * dtf;
         }
       } else {
         FPX_LANES(st, 4);
         R rw = S.expt(-dtftlw);
-        wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw)) * (R)icbt;
+        wp = m_flip(rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) + T.tlw * (K(1.) - rw) * (T.dsigwdz + S.get(S_RHOAUX) * T.sigw), flip);
         delz = wp * T.sigw * dtf;
       }
     } else {
       R rw = m_expp(-dtftlw);
-      wp = (rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + S.get(S_RHOAUX) * (T.sigw * T.sigw))) * (R)icbt;
+      wp = m_flip(rw * wp + G.at(nrand + i) * m_sqrtp(K(1.) - rw * rw) * T.sigw + T.tlw * (K(1.) - rw) * (T.dsigw2dz + S.get(S_RHOAUX) * (T.sigw * T.sigw)), flip);
       delz = wp * dtf;
     }
 
@@ -2290,13 +2299,13 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
     // reflection at the ground / mixing height, advance.f90:476-491
     if (__builtin_expect(m_abs(delz) > h, 0)) delz = m_fmod(delz, h);
     if (delz < -zt) {
-      icbt = -1;
+      flip = 0x80000000u;
       zt = -zt - delz;
     } else if (delz > (h - zt)) {
-      icbt = -1;
+      flip = 0x80000000u;
       zt = -zt - delz + K(2.) * h;
     } else {
-      icbt = 1;
+      flip = 0u;
       zt = zt + delz;
     }
     if (i != V.ifine) {
@@ -2307,6 +2316,7 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
       hanna_short(T, zt, HI, S);
     }
   }
+  icbt = flip ? (short)-1 : (short)1;
   if (!cblflag) nrand = nrand + V.ifine + 1;   // "nrand=nrand+i", i = ifine+1 after the loop (advance.f90:499)
   A.nrand = nrand;
 
