@@ -587,8 +587,17 @@ struct Rng {
       c3 = __builtin_amdgcn_fmed3f(rb * __builtin_amdgcn_sinf(u4), -3.0f, 3.0f);
       cblk = blk;
     }
-    const int ph = idx & 3;
-    const float g = ph == 0 ? c0 : (ph == 1 ? c1 : (ph == 2 ? c2 : c3));
+    // the draw's normal out of the block's four, branch-free: two sign-extended bit fields of the index as masks and three
+    // bit-field inserts (left as a chain of ?: the compiler makes nested divergent branches of it: three compares, four
+    // conditional moves and a dozen exec-mask instructions per draw)
+    // (as inline assembly: from the C form the compiler builds ten and / or / sub instructions and a select)
+    int m0, m1;
+    float lo, hi, g;
+    asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(m0) : "v"(idx));                       // bit 0 of the index, sign-extended: 0 | ~0
+    asm("v_bfe_i32 %0, %1, 1, 1" : "=v"(m1) : "v"(idx));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(m0), "v"(c1), "v"(c0));     // (m0 & c1) | (~m0 & c0)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(m0), "v"(c3), "v"(c2));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(g) : "v"(m1), "v"(hi), "v"(lo));
     return (R)g;
   }
   // uniform [0,1) and start index for the counter modes
