@@ -2307,15 +2307,14 @@ FPX_DEV int pbl_pass(const View<R> &V, const R *hgt, const RNG &G, const TimeW<R
 
     // reflection at the ground / mixing height, advance.f90:476-491
     if (__builtin_expect(m_abs(delz) > h, 0)) delz = m_fmod(delz, h);
-    if (delz < -zt) {
-      flip = 0x80000000u;
-      zt = -zt - delz;
-    } else if (delz > (h - zt)) {
-      flip = 0x80000000u;
-      zt = -zt - delz + K(2.) * h;
-    } else {
-      flip = 0u;
-      zt = zt + delz;
+    {
+      // branch-free (three short arms as divergent branches cost more in exec-mask and branch instructions than in work):
+      // the same sums in the same order as the three arms of the reference
+      const bool below = delz < -zt, above = !below && delz > (h - zt);
+      const R refl = -zt - delz;
+      const R zn = below ? refl : (above ? refl + K(2.) * h : zt + delz);
+      flip = (below || above) ? 0x80000000u : 0u;
+      zt = zn;
     }
     if (i != V.ifine) {
       T.zeta = zt * HI.ih;
