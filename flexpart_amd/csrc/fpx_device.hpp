@@ -1033,6 +1033,7 @@ FPX_DEV void hanna_short(Turb<R> &T, R z, const HsInv<R> &I, const ST &S) {   //
     const R isig = i2 * q;
     T.isigw = isig;
     T.dsigwdz = K(0.5) * isig * I.ih * (K(-1.4) * ust2 + wst2 * (K(0.8) * zm13 - K(1.8) * z23));
+    // (kept as branches: computing the third arm's exponential for every lane and selecting measured 0.2 % slower)
     if (low) T.tlw = K(0.1) * z * i2;
     else if (T.zeta < K(0.1)) T.tlw = K(0.59) * z * isig;
     else T.tlw = K(0.15) * T.h * isig * (K(1.) - S.expt(K(-5) * T.zeta));
